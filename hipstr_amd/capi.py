@@ -1,0 +1,309 @@
+"""ctypes view of include/hipstr_hmm.h plus a small numpy batch builder.
+
+This module is plumbing for tests and bench.py: it mirrors the two C structs of
+the boundary (hipstr_batch_t, hipstr_post_batch_t), loads the product library
+(hipstr_amd/csrc/libhipstr_hmm.so — HIP, no CPU fallback) and the bench/test
+support libraries.  Loading anything under oracle/ is restricted to tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg (see load_oracle /
+load_ref docstrings).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HMM_LIB = os.path.join(ROOT, "hipstr_amd", "csrc", "libhipstr_hmm.so")
+SYNTH_LIB = os.path.join(ROOT, "hipstr_amd", "synth", "libhipstr_synth.so")
+ORACLE_LIB = os.path.join(ROOT, "oracle", "libhipstr_oracle.so")
+REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libhipstr_ref.so")
+
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+
+
+class HipstrBatch(C.Structure):
+    _fields_ = [
+        ("n_loci", C.c_int32),
+        ("blk_start", _i32p), ("blk_end", _i32p), ("blk_nopts", _i32p), ("period", _i32p),
+        ("stutter", _f64p), ("opt_off", _i32p), ("seq", C.c_char_p), ("hap_off", _i32p), ("realign_hap", _u8p),
+        ("read_off", _i32p), ("base_off", _i32p), ("bases", C.c_char_p), ("quals", C.c_char_p),
+        ("read_start", _i32p), ("cigar_off", _i32p), ("cigar_op", C.c_char_p), ("cigar_len", _i32p),
+        ("realign_read", _u8p),
+    ]
+
+
+class HipstrPostBatch(C.Structure):
+    _fields_ = [
+        ("n_loci", C.c_int32),
+        ("n_alleles", _i32p), ("n_samples", _i32p), ("read_off", _i32p), ("sample_label", _i32p),
+        ("log_p1", _f64p), ("log_p2", _f64p), ("read_weight", _i32p), ("log_aln_probs", _f64p), ("haploid", _u8p),
+    ]
+
+
+def _ptr(a, typ):
+    return None if a is None else a.ctypes.data_as(typ)
+
+
+def gray_num_combs(nopts):
+    return int(nopts[0]) * int(nopts[1]) * int(nopts[2])
+
+
+class Batch:
+    """Host-side flat batch: numpy arrays + the ctypes struct that points into them."""
+
+    def __init__(self):
+        self.blk_start, self.blk_end, self.blk_nopts, self.period, self.stutter = [], [], [], [], []
+        self.opt_off, self.seq = [0], bytearray()
+        self.hap_off, self.realign_hap = [0], []
+        self.read_off, self.base_off, self.bases, self.quals = [0], [0], bytearray(), bytearray()
+        self.read_start, self.cigar_off, self.cigar_op, self.cigar_len, self.realign_read = [], [0], bytearray(), [], []
+        self._use_hap_mask = False
+        self._use_read_mask = False
+        self.struct = None
+
+    def add_locus(self, blocks, period, stutter, reads, realign_hap=None):
+        """blocks: 3 tuples (start, end, [option sequences]); reads: list of dicts
+        {seq, qual, start, cigar:[(op,len)...], realign:bool}."""
+        assert len(blocks) == 3
+        nopts = []
+        for (start, end, opts) in blocks:
+            self.blk_start.append(start); self.blk_end.append(end); self.blk_nopts.append(len(opts))
+            nopts.append(len(opts))
+            for o in opts:
+                self.seq += o.encode()
+                self.opt_off.append(len(self.seq))
+        A = gray_num_combs(nopts)
+        self.period.append(period)
+        self.stutter += list(stutter)
+        self.hap_off.append(self.hap_off[-1] + A)
+        if realign_hap is None:
+            self.realign_hap += [1] * A
+        else:
+            assert len(realign_hap) == A
+            self._use_hap_mask = True
+            self.realign_hap += [1 if x else 0 for x in realign_hap]
+        for rd in reads:
+            assert len(rd["seq"]) == len(rd["qual"])
+            self.bases += rd["seq"].encode(); self.quals += rd["qual"].encode()
+            self.base_off.append(len(self.bases))
+            self.read_start.append(rd["start"])
+            for (op, n) in rd["cigar"]:
+                self.cigar_op += op.encode(); self.cigar_len.append(n)
+            self.cigar_off.append(len(self.cigar_op))
+            flag = rd.get("realign", True)
+            if not flag:
+                self._use_read_mask = True
+            self.realign_read.append(1 if flag else 0)
+        self.read_off.append(self.read_off[-1] + len(reads))
+        return A
+
+    def finalize(self):
+        i32 = lambda x: np.ascontiguousarray(np.array(x, dtype=np.int32))
+        a = self.arrays = dict(
+            blk_start=i32(self.blk_start), blk_end=i32(self.blk_end), blk_nopts=i32(self.blk_nopts), period=i32(self.period),
+            stutter=np.ascontiguousarray(np.array(self.stutter, dtype=np.float64)), opt_off=i32(self.opt_off),
+            seq=bytes(self.seq) + b"\0", hap_off=i32(self.hap_off),
+            realign_hap=np.array(self.realign_hap, dtype=np.uint8) if self._use_hap_mask else None,
+            read_off=i32(self.read_off), base_off=i32(self.base_off), bases=bytes(self.bases) + b"\0", quals=bytes(self.quals) + b"\0",
+            read_start=i32(self.read_start), cigar_off=i32(self.cigar_off), cigar_op=bytes(self.cigar_op) + b"\0",
+            cigar_len=i32(self.cigar_len if self.cigar_len else [0]),
+            realign_read=np.array(self.realign_read, dtype=np.uint8) if self._use_read_mask else None,
+        )
+        s = HipstrBatch()
+        s.n_loci = len(self.period)
+        for name in ("blk_start", "blk_end", "blk_nopts", "period", "opt_off", "hap_off", "read_off", "base_off", "read_start",
+                     "cigar_off", "cigar_len"):
+            setattr(s, name, _ptr(a[name], _i32p))
+        s.stutter = _ptr(a["stutter"], _f64p)
+        s.seq, s.bases, s.quals, s.cigar_op = a["seq"], a["bases"], a["quals"], a["cigar_op"]
+        s.realign_hap = _ptr(a["realign_hap"], _u8p)
+        s.realign_read = _ptr(a["realign_read"], _u8p)
+        self.struct = s
+        return self
+
+    @property
+    def ptr(self):
+        return C.byref(self.struct)
+
+
+def batch_dims(bptr):
+    """(n_reads, n_out, out_off[n_loci+1]) of a hipstr_batch_t given as ctypes pointer/byref/struct."""
+    b = bptr.contents if hasattr(bptr, "contents") else (bptr._obj if hasattr(bptr, "_obj") else bptr)
+    n = b.n_loci
+    read_off = np.ctypeslib.as_array(b.read_off, shape=(n + 1,))
+    hap_off = np.ctypeslib.as_array(b.hap_off, shape=(n + 1,))
+    P = np.diff(read_off).astype(np.int64)
+    A = np.diff(hap_off).astype(np.int64)
+    out_off = np.concatenate([[0], np.cumsum(P * A)])
+    return int(read_off[-1]), int(out_off[-1]), out_off
+
+
+class PostBatch:
+    def __init__(self, n_alleles, n_samples, read_off, sample_label, log_p1, log_p2, read_weight, log_aln_probs, haploid=None):
+        i32 = lambda x: np.ascontiguousarray(np.asarray(x, dtype=np.int32))
+        f64 = lambda x: np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+        self.a = dict(n_alleles=i32(n_alleles), n_samples=i32(n_samples), read_off=i32(read_off), sample_label=i32(sample_label),
+                      log_p1=f64(log_p1), log_p2=f64(log_p2), read_weight=i32(read_weight),
+                      log_aln_probs=None if log_aln_probs is None else f64(log_aln_probs),
+                      haploid=None if haploid is None else np.ascontiguousarray(np.asarray(haploid, dtype=np.uint8)))
+        s = HipstrPostBatch()
+        s.n_loci = len(self.a["n_alleles"])
+        for name in ("n_alleles", "n_samples", "read_off", "sample_label", "read_weight"):
+            setattr(s, name, _ptr(self.a[name], _i32p))
+        s.log_p1 = _ptr(self.a["log_p1"], _f64p); s.log_p2 = _ptr(self.a["log_p2"], _f64p)
+        s.log_aln_probs = _ptr(self.a["log_aln_probs"], _f64p)
+        s.haploid = _ptr(self.a["haploid"], _u8p)
+        self.struct = s
+        A = self.a["n_alleles"].astype(np.int64); S = self.a["n_samples"].astype(np.int64)
+        self.post_off = np.concatenate([[0], np.cumsum(S * A * A)])
+        self.samp_off = np.concatenate([[0], np.cumsum(S)])
+
+    @property
+    def ptr(self):
+        return C.byref(self.struct)
+
+
+# ----------------------------------------------------------------------------- loaders
+def _sig(fn, restype, argtypes):
+    fn.restype = restype
+    fn.argtypes = argtypes
+
+
+_BP = C.POINTER(HipstrBatch)
+_PBP = C.POINTER(HipstrPostBatch)
+
+
+def _common_align_sigs(lib, prefix):
+    _sig(getattr(lib, prefix + "process_reads"), C.c_int, [_BP, _f64p, _i32p])
+    _sig(getattr(lib, prefix + "posteriors"), C.c_int, [_PBP, _f64p, _f64p, _i32p, _f64p])
+
+
+_scalar_probes = {
+    "int_log": (C.c_double, [C.c_int]),
+    "transition": (C.c_double, [C.c_int, C.c_int]),
+    "base_quality": (C.c_double, [C.c_int, C.c_int]),
+    "stutter_pmf": (C.c_double, [_f64p, C.c_int, C.c_int, C.c_int]),
+    "fast_lse_vec": (C.c_double, [_f64p, C.c_int]),
+    "fast_lse2": (C.c_double, [C.c_double, C.c_double]),
+    "log_sum_exp": (C.c_double, [_f64p, C.c_int]),
+}
+
+
+def load_oracle():
+    """oracle/libhipstr_oracle.so — the C restatement.  TEST INFRASTRUCTURE: callers must be
+    tests/, __graft_entry__.smoke() or bench.py's cpu_baseline leg."""
+    lib = C.CDLL(ORACLE_LIB)
+    _common_align_sigs(lib, "oracle_")
+    _sig(lib.oracle_calc_seed_bases, C.c_int, [_BP, _i32p])
+    _sig(lib.oracle_allele_options, C.c_int, [_i32p, C.c_int, _i32p])
+    for name, (rt, at) in _scalar_probes.items():
+        _sig(getattr(lib, "oracle_" + name), rt, at)
+    return lib
+
+
+def load_ref():
+    """oracle/_ref/libhipstr_ref.so — the real reference sources compiled by oracle/Makefile.
+    genotyper.cpp leaves FastaReader/htslib symbols undefined (only get_vcf_header uses them), so
+    the library is opened with lazy binding.  TEST INFRASTRUCTURE, same rule as load_oracle."""
+    libc = C.CDLL(None)
+    libc.dlopen.restype = C.c_void_p
+    libc.dlopen.argtypes = [C.c_char_p, C.c_int]
+    handle = libc.dlopen(REF_LIB.encode(), os.RTLD_LAZY)
+    if not handle:
+        raise OSError("cannot dlopen " + REF_LIB)
+    lib = C.CDLL(REF_LIB, handle=handle)
+    _common_align_sigs(lib, "ref_")
+    _sig(lib.ref_hap_sequences, C.c_int, [_BP, C.c_int, C.c_char_p, C.c_int, _i32p])
+    _sig(lib.ref_log_thresh, C.c_double, [])
+    _sig(lib.ref_log_one_half, C.c_double, [])
+    for name, (rt, at) in _scalar_probes.items():
+        _sig(getattr(lib, "ref_" + name), rt, at)
+    return lib
+
+
+def have_ref():
+    return os.path.exists(REF_LIB)
+
+
+def load_synth():
+    lib = C.CDLL(SYNTH_LIB)
+    _sig(lib.synth_create, C.c_void_p, [C.c_int32] * 7 + [C.c_uint64, C.c_double])
+    _sig(lib.synth_batch, _BP, [C.c_void_p])
+    _sig(lib.synth_src_allele, _i32p, [C.c_void_p])
+    _sig(lib.synth_free, None, [C.c_void_p])
+    return lib
+
+
+class SynthBatch:
+    """Seeded synthetic loci (hipstr_amd/synth/synth.cpp).  .ptr is a hipstr_batch_t*."""
+
+    def __init__(self, n_loci, reads_per_locus, n_str_alleles, read_len=150, flank_len=60, str_bp=40, n_flank_opts=1,
+                 seed=20260928, mask_rate=0.0):
+        self.lib = load_synth()
+        self.h = self.lib.synth_create(n_loci, reads_per_locus, n_str_alleles, read_len, flank_len, str_bp, n_flank_opts, seed, mask_rate)
+        self.ptr = self.lib.synth_batch(self.h)
+        self.n_reads, self.n_out, self.out_off = batch_dims(self.ptr)
+        self.n_loci = n_loci
+
+    def src_allele(self):
+        return np.ctypeslib.as_array(self.lib.synth_src_allele(self.h), shape=(self.n_reads,)).copy()
+
+    def close(self):
+        if self.h:
+            self.lib.synth_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def load_hmm():
+    """The product: hipstr_amd/csrc/libhipstr_hmm.so (HIP/gfx950).  Raises if it is missing —
+    there is deliberately no CPU fallback."""
+    if not os.path.exists(HMM_LIB):
+        raise RuntimeError("libhipstr_hmm.so is not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(HMM_LIB)
+    _sig(lib.hipstr_batch_out_offsets, C.c_int, [_BP, C.POINTER(C.c_int64)])
+    _sig(lib.hipstr_hmm_init, C.c_int, [C.c_int])
+    _sig(lib.hipstr_hmm_shutdown, None, [])
+    _sig(lib.hipstr_hmm_upload, C.c_void_p, [_BP])
+    _sig(lib.hipstr_hmm_free, None, [C.c_void_p])
+    _sig(lib.hipstr_hmm_align, C.c_int, [C.c_void_p, C.c_void_p])
+    _sig(lib.hipstr_hmm_align_timed, C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)])
+    _sig(lib.hipstr_hmm_fetch, C.c_int, [C.c_void_p, _f64p, _i32p])
+    _sig(lib.hipstr_hmm_dev_aln_probs, C.c_void_p, [C.c_void_p])
+    _sig(lib.hipstr_hmm_process_reads, C.c_int, [_BP, _f64p, _i32p])
+    _sig(lib.hipstr_calc_seed_bases, C.c_int, [_BP, _i32p])
+    _sig(lib.hipstr_post_offsets, C.c_int, [_PBP, C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
+    _sig(lib.hipstr_post_run, C.c_int, [_PBP, C.c_void_p, _f64p, _f64p, _i32p, _f64p])
+    _sig(lib.hipstr_post_run_timed, C.c_int, [_PBP, C.c_int, C.POINTER(C.c_float)])
+    _sig(lib.hipstr_last_error, C.c_char_p, [])
+    return lib
+
+
+def run_align(lib, prefix, bptr, fill=np.nan):
+    """Call <prefix>process_reads on a batch; returns (aln_probs, seeds) numpy arrays.
+    Entries the callee leaves untouched keep `fill`."""
+    n_reads, n_out, _ = batch_dims(bptr)
+    probs = np.full(max(n_out, 1), fill, dtype=np.float64)
+    seeds = np.full(max(n_reads, 1), -7, dtype=np.int32)
+    rc = getattr(lib, prefix + "process_reads")(bptr, probs.ctypes.data_as(_f64p), seeds.ctypes.data_as(_i32p))
+    if rc != 0:
+        raise RuntimeError("%sprocess_reads failed rc=%d" % (prefix, rc))
+    return probs[:n_out], seeds[:n_reads]
+
+
+def run_posteriors(lib, prefix, pb):
+    S = int(pb.samp_off[-1])
+    post = np.zeros(max(int(pb.post_off[-1]), 1)); tot = np.zeros(max(S, 1)); gt = np.zeros(max(2 * S, 2), dtype=np.int32)
+    ltot = np.zeros(max(pb.struct.n_loci, 1))
+    fn = getattr(lib, prefix + "posteriors")
+    rc = fn(pb.ptr, post.ctypes.data_as(_f64p), tot.ctypes.data_as(_f64p), gt.ctypes.data_as(_i32p), ltot.ctypes.data_as(_f64p))
+    if rc != 0:
+        raise RuntimeError("%sposteriors failed rc=%d" % (prefix, rc))
+    return post[:int(pb.post_off[-1])], tot[:S], gt[:2 * S].reshape(-1, 2), ltot[:pb.struct.n_loci]

@@ -1,0 +1,174 @@
+/*
+ * hipstr_hmm.h — C-ABI of the MI355X-native read-to-haplotype HMM alignment and
+ * diplotype-posterior core (drop-in boundary for tfwillems/HipSTR's hot path).
+ *
+ * Every entry point below names the reference interface it replaces
+ * (paths relative to the HipSTR v0.7 tree).  Plain pointers and sizes only; no
+ * C++ or torch types cross this boundary.  The library never falls back to a
+ * CPU path: if no gfx950 device can be opened every call returns non-zero and
+ * hipstr_last_error() says why.
+ *
+ * Conventions
+ *   - all log-likelihoods are natural logs, IEEE double (the reference computes
+ *     in double; only its log-sum-exp approximations drop to float, and those
+ *     are bit-replicated on the device)
+ *   - a "locus" is one STR region = one Haplotype of exactly three HapBlocks
+ *     [left flank, STR block, right flank] (the reference asserts this shape,
+ *     src/SeqAlignment/Haplotype.cpp:12)
+ *   - a "read" on this boundary is a pooled read (ReadPooler pool,
+ *     src/read_pooler.h:13-53) — the unit HapAligner::process_reads sees
+ *   - candidate haplotypes ("alleles") of a locus are indexed in the visit
+ *     order of Haplotype::next() (reflected mixed-radix Gray code, block 0
+ *     fastest; src/SeqAlignment/Haplotype.cpp:157-196)
+ *   - return value 0 = ok; non-zero = error (the C++ adapter turns it into
+ *     printErrorAndDie, src/error.cpp:5-9, to keep the reference convention)
+ */
+#ifndef HIPSTR_HMM_H_
+#define HIPSTR_HMM_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPSTR_NUM_BLOCKS        3   /* Haplotype.cpp:12 */
+#define HIPSTR_MAX_STUTTER_REPS  6   /* RepeatStutterInfo.h:10-11 (MAX_STUTTER_REPEAT_INS / _DEL) */
+#define HIPSTR_NUM_ARTIFACTS     (2 * HIPSTR_MAX_STUTTER_REPS + 1)
+#define HIPSTR_MAX_HOMOP_LEN     15  /* AlignmentModel.h:6 */
+
+/*
+ * A batch of independent loci, flattened structure-of-arrays.  Host memory,
+ * read-only, owned by the caller; the library copies what it needs.
+ *
+ * It carries exactly what the reference hands to
+ *   HapAligner::HapAligner(Haplotype*, std::vector<bool>& realign_to_haplotype)   (HapAligner.h:56)
+ *   HapAligner::process_reads(alignments, init_read_index, base_quality,
+ *                             realign_read, aln_probs, seed_positions)           (HapAligner.h:86)
+ * i.e. the HapBlock/RepeatBlock contents of the Haplotype (HapBlock.h:18-148,
+ * RepeatBlock.h:26-43), the StutterModel parameters of the STR block
+ * (stutter_model.h:31-60) and, per pooled read, the fields of `Alignment` the
+ * path touches: sequence, base qualities, start and CIGAR (AlignmentData.h:28-137).
+ */
+typedef struct hipstr_batch {
+  int32_t        n_loci;
+
+  /* ---- haplotype structure ---- */
+  const int32_t* blk_start;    /* [3*n_loci] HapBlock::start(), inclusive reference coordinate        */
+  const int32_t* blk_end;      /* [3*n_loci] HapBlock::end(), exclusive                                */
+  const int32_t* blk_nopts;    /* [3*n_loci] HapBlock::num_options() (option 0 = reference sequence)   */
+  const int32_t* period;       /* [n_loci]   RepeatStutterInfo::get_period() of block 1                */
+  const double*  stutter;      /* [6*n_loci] StutterModel ctor order: inframe_geom, inframe_up,
+                                  inframe_down, outframe_geom, outframe_up, outframe_down
+                                  (stutter_model.h:31-32); motif_len = period                         */
+  const int32_t* opt_off;      /* [n_opts+1] byte offsets into seq; options are enumerated
+                                  locus-major, block-major, option-minor                               */
+  const char*    seq;          /* concatenated option sequences, ACGTN                                 */
+  const int32_t* hap_off;      /* [n_loci+1] prefix sums of Haplotype::num_combs()                     */
+  const uint8_t* realign_hap;  /* [hap_off[n_loci]] realign_to_haplotype flags, or NULL = all true     */
+
+  /* ---- pooled reads ---- */
+  const int32_t* read_off;     /* [n_loci+1] prefix sums of reads per locus                            */
+  const int32_t* base_off;     /* [n_reads+1] offsets into bases/quals                                 */
+  const char*    bases;        /* Alignment::get_sequence()                                            */
+  const char*    quals;        /* Alignment::get_base_qualities(), Phred+33                            */
+  const int32_t* read_start;   /* [n_reads] Alignment::get_start()                                     */
+  const int32_t* cigar_off;    /* [n_reads+1] offsets into cigar_op/cigar_len                          */
+  const char*    cigar_op;     /* CigarElement::get_type(): '=', 'X', 'I', 'D' only (HapAligner.cpp:309) */
+  const int32_t* cigar_len;    /* CigarElement::get_num()                                              */
+  const uint8_t* realign_read; /* [n_reads] realign_read flags, or NULL = all true                     */
+} hipstr_batch_t;
+
+/* Output layout shared by every align entry point:
+ *   aln_probs[out_off[l] + i*A_l + k], i = read within locus l, k = allele, A_l = num_combs,
+ *   out_off[l] = sum_{l'<l} P_l' * A_l'   — the row-major layout process_reads writes
+ *   (HapAligner.cpp:324); seeds[read] = HapAligner::calc_seed_base (HapAligner.cpp:270-318). */
+int hipstr_batch_out_offsets(const hipstr_batch_t* batch, int64_t* out_off /* [n_loci+1] */);
+
+/* Opaque device-resident batch (prepared tables + reads + output buffers in HBM). */
+typedef struct hipstr_dev_batch hipstr_dev_batch_t;
+
+/* Selects the device and builds the constant tables the reference keeps in
+ * globals: INT_LOGS (mathops.cpp:13-21, precompute_integer_logs), the
+ * LOG_MATCH_TO_* transition tables (AlignmentModel.cpp:20-32,
+ * init_alignment_model) and BaseQuality's log tables (base_quality.h:29-38). */
+int hipstr_hmm_init(int device_ordinal);
+void hipstr_hmm_shutdown(void);
+
+/* Flattens and uploads a batch.  Replaces HapAligner's constructor work
+ * (reversed haplotype, StutterAlignerClass tables; HapAligner.h:56-69,
+ * RepeatBlock.h:29-43) and calc_seed_base for every read. */
+hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch);
+void hipstr_hmm_free(hipstr_dev_batch_t* dev);
+
+/* Runs the forward HMM for every (realign_read, realign_hap) pair of the batch:
+ * HapAligner::process_reads → process_read → align_seq_to_hap +
+ * compute_aln_logprob (HapAligner.cpp:320-343, 573-709, 26-161, 163-231) with
+ * StutterAlignerClass (StutterAlignerClass.cpp:12-162).  Asynchronous on
+ * `hip_stream` (a hipStream_t, or NULL for the library's own stream). */
+int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream);
+
+/* Same, repeated `reps` times between two HIP events recorded on the stream the
+ * kernels are launched on; *ms_total = elapsed milliseconds for all reps.
+ * *ms_kernel (may be NULL) = time of the dominant DP kernel only. */
+int hipstr_hmm_align_timed(hipstr_dev_batch_t* dev, int reps, float* ms_total, float* ms_kernel);
+
+/* Copies results back.  Entries whose read or allele was not realigned are left
+ * untouched in the caller's buffers, as process_reads does (HapAligner.cpp:326-329,
+ * 615-619); reads with seed -1 get 0 for every realigned allele (HapAligner.cpp:333-337). */
+int hipstr_hmm_fetch(hipstr_dev_batch_t* dev, double* aln_probs, int32_t* seeds);
+
+/* Device pointer to the batch's aln_probs buffer (same layout), for chaining
+ * into hipstr_post_run without a host round trip. */
+double* hipstr_hmm_dev_aln_probs(hipstr_dev_batch_t* dev);
+
+/* One-shot convenience = upload + align + fetch + free: the drop-in for
+ * HapAligner::process_reads (HapAligner.h:86-87). */
+int hipstr_hmm_process_reads(const hipstr_batch_t* batch, double* aln_probs, int32_t* seeds);
+
+/* HapAligner::calc_seed_base (HapAligner.cpp:270-318) for every read of a batch,
+ * host only (no device needed): seeds[r] = read offset of the seed base or -1.
+ * Returns non-zero on the inputs the reference dies on ("Invalid alignment
+ * seed", "Unrecognized CIGAR char"). */
+int hipstr_calc_seed_bases(const hipstr_batch_t* batch, int32_t* seeds);
+
+/*
+ * Diplotype posteriors: Genotyper::calc_log_sample_posteriors (genotyper.cpp:44-80)
+ * with the default priors of Genotyper::init_log_sample_priors (genotyper.cpp:20-42)
+ * and the MAP scan of Genotyper::get_optimal_haplotypes (genotyper.cpp:82-97),
+ * batched over loci.  All arrays are host pointers unless stated.
+ */
+typedef struct hipstr_post_batch {
+  int32_t        n_loci;
+  const int32_t* n_alleles;     /* [n_loci] num_alleles_                                               */
+  const int32_t* n_samples;     /* [n_loci] num_samples_                                               */
+  const int32_t* read_off;      /* [n_loci+1] prefix sums of num_reads_ (un-pooled reads)              */
+  const int32_t* sample_label;  /* [n_reads] sample index within the locus (genotyper.h:26)            */
+  const double*  log_p1;        /* [n_reads] SNP phasing log-likelihoods (genotyper.h:25)              */
+  const double*  log_p2;        /* [n_reads]                                                           */
+  const int32_t* read_weight;   /* [n_reads] read_weights_ (0 for second mates; genotyper.h:44-46)     */
+  const double*  log_aln_probs; /* [sum R_l*A_l] log_aln_probs_, read-major (genotyper.h:33); may be
+                                   NULL when a device buffer is given to hipstr_post_run              */
+  const uint8_t* haploid;       /* [n_loci] haploid_ flag, or NULL = diploid                           */
+} hipstr_post_batch_t;
+
+/* log_post[post_off[l] + (s*A + a1)*A + a2]; post_off[l] = sum_{l'<l} S_l'*A_l'^2
+ * sample_total_ll[samp_off[l] + s];           samp_off[l] = sum_{l'<l} S_l'
+ * map_gt[2*(samp_off[l]+s) + {0,1}]                                                                     */
+int hipstr_post_offsets(const hipstr_post_batch_t* pb, int64_t* post_off, int64_t* samp_off);
+
+/* dev_log_aln_probs: optional device pointer overriding pb->log_aln_probs.
+ * locus_total_ll[l] = the return value of calc_log_sample_posteriors (sum of sample totals). */
+int hipstr_post_run(const hipstr_post_batch_t* pb, const double* dev_log_aln_probs,
+                    double* log_post, double* sample_total_ll, int32_t* map_gt, double* locus_total_ll);
+
+/* Timed variant for bench.py: inputs uploaded once, kernel repeated `reps` times
+ * between HIP events on the launch stream. */
+int hipstr_post_run_timed(const hipstr_post_batch_t* pb, int reps, float* ms_total);
+
+const char* hipstr_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPSTR_HMM_H_ */

@@ -1,0 +1,681 @@
+/*
+ * hipstr_oracle.c — TEST INFRASTRUCTURE ONLY.  CPU restatement (plain C11,
+ * double precision, single thread) of HipSTR v0.7's read-to-haplotype HMM
+ * forward score and diplotype posteriors.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this file's shared object; the
+ * product library never does.
+ *
+ * PARITY STATUS: pinned.  tests/test_oracle_vs_ref.py compares every entry point
+ * with the compiled reference (oracle/_ref/libhipstr_ref.so, built by
+ * oracle/Makefile from the sources under /root/reference) on seeded random loci
+ * and on the two known-answer vectors of SURVEY.md §8(c); the committed fixtures
+ * under tests/golden/ were produced by that reference build
+ * (tests/golden/make_golden.py).  Agreement is bit-exact (max |diff| == 0).
+ *
+ * Each function cites the reference code (HipSTR v0.7 paths) whose arithmetic,
+ * operation order and tie rules it restates.  The restatement works on the flat
+ * hipstr_batch_t, keeps the reference's evaluation order for every double
+ * operation (so results are bit-identical, which matters because the float
+ * log-sum-exp approximations are discontinuous in their inputs), and simulates
+ * the reference's allele loop literally — including its reuse of leading-flank
+ * rows computed under an earlier allele's homopolymer context
+ * (HapAligner.cpp:54-60, 612-634).
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/hipstr_hmm.h"
+
+#define IMPOSSIBLE     (-1000000000.0)   /* HapAligner.cpp:20 */
+#define LARGE_NEGATIVE (-10e6)           /* RepeatStutterInfo.h:12 */
+#define MIN_SEED_DIST  5                 /* HapAligner.cpp:17 */
+#define INT_LOG_N      10000             /* mathops.cpp:13 */
+
+/* ------------------------------------------------------------------ tables */
+static double g_int_log[INT_LOG_N];                 /* mathops.cpp:13-21 */
+static double g_m2m[16], g_m2i[16], g_m2d[16];      /* AlignmentModel.cpp:20-32 */
+static double g_q_correct[256], g_q_error[256];     /* base_quality.h:29-38 */
+static double g_log_thresh, g_log_half;             /* mathops.h:36, mathops.cpp:9 */
+static const double I2I = -1.0, I2M = -0.4586751453870818910216436;   /* AlignmentModel.h:7-10 */
+static const double D2D = -1.0, D2M = -0.4586751453870818910216436;
+static int g_ready = 0;
+
+static void oracle_init(void){
+  if (g_ready) return;
+  g_int_log[0] = -1000;
+  for (int i = 1; i < INT_LOG_N; i++) g_int_log[i] = log((double)i);
+  static const double dindel[10] = {2.9e-5, 2.9e-5, 2.9e-5, 2.9e-5, 4.3e-5, 1.1e-4, 2.4e-4, 5.7e-4, 1.0e-3, 1.4e-3};
+  g_m2m[0] = g_m2i[0] = g_m2d[0] = 0;
+  for (unsigned int i = 1; i <= 15; i++){
+    g_m2i[i] = (i <= 10 ? log(dindel[i-1]) : log(dindel[9]+(4.3e-4)*(i-10)));
+    g_m2d[i] = g_m2i[i];
+    g_m2m[i] = log(1.0 - exp(g_m2i[i]) - exp(g_m2d[i]));
+  }
+  g_q_correct[0] = -100000;
+  g_q_error[0]   = -log(3);
+  for (int i = 1; i <= 'J'-'!'; i++){
+    g_q_correct[i] = log(1.0 - pow(10.0, i/(-10.0)));
+    g_q_error[i]   = log(pow(10.0, i/(-10.0))/3.0);
+  }
+  g_log_thresh = log(0.001);
+  g_log_half   = log(0.5);
+  g_ready = 1;
+}
+
+static int qual_index(char q){            /* base_quality.h:44-75 clamps */
+  if (q < '!') return 0;
+  if (q > 'J') return 'J'-'!';
+  return q - '!';
+}
+
+/* ------------------------------------------- float approximations (A.5) */
+static float bits_to_float(uint32_t u){ float f; memcpy(&f, &u, 4); return f; }
+static uint32_t float_to_bits(float f){ uint32_t u; memcpy(&u, &f, 4); return u; }
+
+static float o_fasterexp(float p){                   /* fastonebigheader.h:206-218 */
+  float y = 1.442695040f * p;
+  float clipp = (y < -126) ? -126.0f : y;
+  return bits_to_float((uint32_t)((float)(1 << 23) * (clipp + 126.94269504f)));
+}
+static float o_fasterlog(float x){                   /* fastonebigheader.h:348-358 */
+  float y = (float)float_to_bits(x);
+  y *= 8.2629582881927490e-8f;
+  return y - 87.989971088f;
+}
+static float o_fastexp(float p){                     /* fastonebigheader.h:188-204 */
+  float q = 1.442695040f * p;
+  float offset = (q < 0) ? 1.0f : 0.0f;
+  float clipp = (q < -126) ? -126.0f : q;
+  int w = (int)clipp;
+  float z = clipp - w + offset;
+  return bits_to_float((uint32_t)((float)(1 << 23) * (clipp + 121.2740575f + 27.7280233f / (4.84252568f - z) - 1.49012907f * z)));
+}
+static float o_fastlog(float x){                     /* fastonebigheader.h:320-338 */
+  uint32_t vi = float_to_bits(x);
+  float mx = bits_to_float((vi & 0x007FFFFF) | 0x3f000000);
+  float y = (float)vi;
+  y *= 1.1920928955078125e-7f;
+  float l2 = y - 124.22551499f - 1.498030302f * mx - 1.72587999f / (0.3520887068f + mx);
+  return 0.69314718f * l2;
+}
+
+double oracle_fast_lse_vec(const double* v, int n){  /* mathops.cpp:97-106 */
+  oracle_init();
+  double m = v[0];
+  for (int i = 1; i < n; i++) if (v[i] > m) m = v[i];
+  double total = 0;
+  for (int i = 0; i < n; i++){
+    double diff = v[i] - m;
+    if (diff > g_log_thresh) total += o_fasterexp((float)diff);
+  }
+  return m + o_fasterlog((float)total);
+}
+
+double oracle_fast_lse2(double a, double b){         /* mathops.cpp:86-95 */
+  oracle_init();
+  if (a > b){
+    double diff = b - a;
+    return diff < g_log_thresh ? a : a + o_fastlog(1 + o_fastexp((float)diff));
+  } else {
+    double diff = a - b;
+    return diff < g_log_thresh ? b : b + o_fastlog(1 + o_fastexp((float)diff));
+  }
+}
+
+double oracle_log_sum_exp(const double* v, int n){   /* mathops.cpp:44-50 (exact) */
+  double m = v[0];
+  for (int i = 1; i < n; i++) if (v[i] > m) m = v[i];
+  double total = 0.0;
+  for (int i = 0; i < n; i++) total += exp(v[i] - m);
+  return m + log(total);
+}
+
+double oracle_int_log(int v){ oracle_init(); return g_int_log[v]; }
+double oracle_transition(int which, int h){
+  oracle_init();
+  switch (which){ case 0: return g_m2m[h]; case 1: return g_m2i[h]; case 2: return g_m2d[h];
+                  case 3: return I2I; case 4: return I2M; case 5: return D2D; default: return D2M; }
+}
+double oracle_base_quality(int q, int correct){ oracle_init(); return correct ? g_q_correct[qual_index((char)q)] : g_q_error[qual_index((char)q)]; }
+
+/* stutter_model.cpp:29-53 + ctor logs (stutter_model.h:31-60) */
+double oracle_stutter_pmf(const double* sp, int period, int sample_bps, int read_bps){
+  double in_step = log(1-sp[0]), in_nostep = log(sp[0]), in_up = log(sp[1]), in_down = log(sp[2]);
+  double out_step = log(1-sp[3]), out_nostep = log(sp[3]), out_up = log(sp[4]), out_down = log(sp[5]);
+  double log_equal = log(1-sp[1]-sp[2]-sp[4]-sp[5]);
+  int bp_diff = read_bps - sample_bps;
+  if (bp_diff % period != 0){
+    int eff = bp_diff - (bp_diff/period);
+    if (eff < 0) return out_down + out_nostep + out_step*(-eff-1);
+    return out_up + out_nostep + out_step*(eff-1);
+  }
+  int rep = bp_diff/period;
+  if (rep == 0) return log_equal;
+  if (rep < 0) return in_down + in_nostep + in_step*(-rep-1);
+  return in_up + in_nostep + in_step*(rep-1);
+}
+
+/* ------------------------------------------------- haplotype side model */
+typedef struct {
+  int nopts;
+  char** seq;     /* [nopts] in this side's orientation */
+  int*   len;
+  int**  llen;    /* HapBlock.cpp:7-30 homopolymer run tables */
+  int**  rlen;
+} OBlock;
+
+typedef struct {
+  OBlock blk[3];          /* in side order (rev: blocks reversed, sequences reversed) */
+  int    str_blk;         /* index of the STR block (always 1) */
+  int    counts[3];       /* current option per block */
+  int    max_size;
+  /* per STR option: upstream-match tables U[d-1][x] for shifts (d*period), StutterAlignerClass.h:35-42,70-74 */
+  int*** ups;             /* [nopts][ntab][len] */
+  int*   ntab;            /* tables per option */
+  int*   ndel;            /* num_deletions_ per option (StutterAlignerClass.h:64-69) */
+} OSide;
+
+static void run_tables(const char* s, int n, int** ll, int** rl){
+  if (n == 0){ *ll = NULL; *rl = NULL; return; }
+  int* l = malloc(sizeof(int)*n); int* r = malloc(sizeof(int)*n);
+  l[0] = 0; int count = 0;
+  for (int j = 1; j < n; j++){ count = (s[j-1] == s[j] ? count+1 : 0); l[j] = count; }
+  r[n-1] = 0;
+  for (int j = n-2; j >= 0; j--){ count = (s[j+1] == s[j] ? count+1 : 0); r[j] = count; }
+  *ll = l; *rl = r;
+}
+
+static int* upstream_matches(const char* s, int n, int shift){   /* StutterAlignerClass.h:35-42 */
+  int* m = malloc(sizeof(int)*(n > 0 ? n : 1));
+  for (int i = 0; i < (shift < n ? shift : n); i++) m[i] = 0;
+  for (int i = shift; i < n; i++) m[i] = (s[i-shift] != s[i] ? 0 : 1 + m[i-1]);
+  return m;
+}
+
+static void side_build(OSide* sd, const hipstr_batch_t* b, int l, int opt_base, int reversed){
+  int period = b->period[l];
+  int cursor = opt_base;
+  const char* src[3][1024]; int slen[3][1024]; int nopt[3];
+  for (int k = 0; k < 3; k++){
+    nopt[k] = b->blk_nopts[3*l+k];
+    for (int o = 0; o < nopt[k]; o++, cursor++){ src[k][o] = b->seq + b->opt_off[cursor]; slen[k][o] = b->opt_off[cursor+1]-b->opt_off[cursor]; }
+  }
+  sd->max_size = 0;
+  for (int k = 0; k < 3; k++){
+    int from = reversed ? 2-k : k;
+    OBlock* ob = &sd->blk[k];
+    ob->nopts = nopt[from];
+    ob->seq = malloc(sizeof(char*)*ob->nopts); ob->len = malloc(sizeof(int)*ob->nopts);
+    ob->llen = malloc(sizeof(int*)*ob->nopts); ob->rlen = malloc(sizeof(int*)*ob->nopts);
+    int mx = 0;
+    for (int o = 0; o < ob->nopts; o++){
+      int n = slen[from][o];
+      ob->len[o] = n; ob->seq[o] = malloc(n+1);
+      for (int i = 0; i < n; i++) ob->seq[o][i] = reversed ? src[from][o][n-1-i] : src[from][o][i];
+      ob->seq[o][n] = 0;
+      run_tables(ob->seq[o], n, &ob->llen[o], &ob->rlen[o]);
+      if (n > mx) mx = n;
+    }
+    sd->max_size += mx;
+  }
+  sd->str_blk = 1;
+  OBlock* sb = &sd->blk[1];
+  sd->ups = malloc(sizeof(int**)*sb->nopts); sd->ntab = malloc(sizeof(int)*sb->nopts); sd->ndel = malloc(sizeof(int)*sb->nopts);
+  for (int o = 0; o < sb->nopts; o++){
+    int B = sb->len[o];
+    int nd = HIPSTR_MAX_STUTTER_REPS;               /* -(max_deletion/period) */
+    while (nd*period > B) nd--;
+    sd->ndel[o] = nd;
+    int nt = nd > 0 ? nd : 1;                       /* "required for insertion calculations" */
+    sd->ntab[o] = nt;
+    sd->ups[o] = malloc(sizeof(int*)*nt);
+    for (int t = 0; t < nt; t++) sd->ups[o][t] = upstream_matches(sb->seq[o], B, (t+1)*period);
+  }
+}
+
+static void side_free(OSide* sd){
+  for (int k = 0; k < 3; k++){
+    OBlock* ob = &sd->blk[k];
+    for (int o = 0; o < ob->nopts; o++){ free(ob->seq[o]); free(ob->llen[o]); free(ob->rlen[o]); }
+    free(ob->seq); free(ob->len); free(ob->llen); free(ob->rlen);
+  }
+  OBlock* sb = &sd->blk[1];
+  for (int o = 0; o < sb->nopts; o++){ for (int t = 0; t < sd->ntab[o]; t++) free(sd->ups[o][t]); free(sd->ups[o]); }
+  free(sd->ups); free(sd->ntab); free(sd->ndel);
+}
+
+/* Haplotype.cpp:239-287, including the fact that the cross-block extension never looks past one neighbour */
+static int nb_left(const OSide* sd, char c, int bi){
+  int total = 0;
+  while (bi >= 0){
+    const OBlock* ob = &sd->blk[bi]; int o = sd->counts[bi]; int n = ob->len[o];
+    if (n > 0){
+      if (ob->seq[o][n-1] == c){
+        int ll = ob->llen[o][n-1];
+        total += 1 + ll;
+        if (ll != n) break;
+      } else break;
+    }
+    bi--;
+  }
+  return total;
+}
+static int nb_right(const OSide* sd, char c, int bi){
+  int total = 0;
+  while (bi < 3){
+    const OBlock* ob = &sd->blk[bi]; int o = sd->counts[bi]; int n = ob->len[o];
+    if (n > 0){
+      if (ob->seq[o][0] == c){
+        int rl = ob->rlen[o][0];
+        total += 1 + rl;
+        if (rl != n) break;
+      } else break;
+    }
+    bi++;
+  }
+  return total;
+}
+static int hom_len(const OSide* sd, int bi, int base){
+  const OBlock* ob = &sd->blk[bi]; int o = sd->counts[bi]; int n = ob->len[o];
+  int ll = ob->llen[o][base], rl = ob->rlen[o][base];
+  if (base - ll == 0)   ll += nb_left(sd, ob->seq[o][base], bi-1);
+  if (base + rl == n-1) rl += nb_right(sd, ob->seq[o][base], bi+1);
+  return ll + rl + 1;
+}
+
+/* ---------------------------------------------- stutter block (A.3) */
+typedef struct {
+  int n, B, p, nins, ndel;
+  const char* blk;          /* block sequence (side orientation), blk[B-1] = rightmost */
+  const char* rd; const double* blc; const double* blw;   /* read side arrays, index 0..n-1 */
+  double* Mt; double* Dl; double* In;   /* indexed by from-the-right offset */
+  int** ups;
+  double* scratch; int nscratch;
+} OStut;
+
+static double emit1(char r, char c, double lc, double lw){ return r == c ? lc : lw; }
+
+/* StutterAlignerClass.cpp:12-53 */
+static void stut_load(OStut* s){
+  int n = s->n, B = s->B, p = s->p, maxdel = s->ndel*p, maxins = s->nins*p;
+  int ins_i = 0, del_i = 0;
+  for (int i = 0; i < n; i++){
+    int e = n-1-i;          /* read index the sums end at */
+    int j; double lp = 0.0;
+    int lim = (n-i < maxdel ? n-i : maxdel);
+    for (j = 0; j < lim; j++){
+      lp += emit1(s->rd[e-j], s->blk[B-1-j], s->blc[e-j], s->blw[e-j]);
+      if ((j+1) % p == 0) s->Dl[del_i++] = lp;
+    }
+    for (; j < maxdel; j++) if ((j+1) % p == 0) del_i++;
+    int lim2 = (n-i < B ? n-i : B);
+    for (; j < lim2; j++) lp += emit1(s->rd[e-j], s->blk[B-1-j], s->blc[e-j], s->blw[e-j]);
+    s->Mt[i] = lp;
+    double li = 0.0;
+    int lim3 = (maxins < n-i ? maxins : n-i);
+    for (j = 0; j < lim3; j++){
+      if (j % p < B) li += emit1(s->rd[e-j], s->blk[B-1-(j%p)], s->blc[e-j], s->blw[e-j]);
+      else           li += s->blc[e-j];
+      if ((j+1) % p == 0) s->In[ins_i++] = li;
+    }
+    for (; j < maxins; j++) if ((j+1) % p == 0) s->In[ins_i++] = li;
+  }
+}
+
+/* StutterAlignerClass.cpp:59-104; j = read index of the segment's right end, len = base_seq_len, off = n-1-j */
+static double stut_ins(OStut* s, int len, int j, int D){
+  int B = s->B, p = s->p, off = s->n-1-j, cnt = 0;
+  double* v = s->scratch;
+  const int* up = s->ups[0];
+  double lp = -g_int_log[B+1] + s->In[s->nins*off + D/p - 1] + (len > D ? s->Mt[off+D] : 0);
+  v[cnt++] = lp;
+  int lim = len-D; if (lim < 0) lim = 0; if (lim > B) lim = B;
+  int i = 0;
+  for (; i > -lim; i--){
+    if (-i + p < B){
+      int U = up[B-1+i];
+      if (U == 0){
+        for (int idx = i-p; idx >= i-D; idx -= p){
+          lp -= emit1(s->rd[j+idx], s->blk[B-1+i],   s->blc[j+idx], s->blw[j+idx]);
+          lp += emit1(s->rd[j+idx], s->blk[B-1+i-p], s->blc[j+idx], s->blw[j+idx]);
+        }
+        v[cnt++] = lp;
+      } else {
+        v[cnt++] = g_int_log[U] + lp;
+        i -= (U-1);
+      }
+    } else v[cnt++] = lp;
+  }
+  if (i > -B) v[cnt++] = g_int_log[B+i] + lp;
+  return oracle_fast_lse_vec(v, cnt);
+}
+
+/* StutterAlignerClass.cpp:106-150 */
+static double stut_del(OStut* s, int len, int j, int D){
+  int B = s->B, p = s->p, off = s->n-1-j, cnt = 0;
+  double* v = s->scratch;
+  const int* up = s->ups[-D/p - 1];
+  double lp = -g_int_log[B+D+1];
+  if (off + D >= 0)
+    lp += s->Mt[off+D] - s->Dl[(off+D)*s->ndel - D/p - 1];
+  else
+    for (int k = 0; k > -len; k--) lp += emit1(s->rd[j+k], s->blk[B-1+k+D], s->blc[j+k], s->blw[j+k]);
+  v[cnt++] = lp;
+  int i;
+  for (i = 0; i > -len; i--){
+    int U = up[B-1+i];
+    if (U == 0){
+      lp -= emit1(s->rd[j+i], s->blk[B-1+i+D], s->blc[j+i], s->blw[j+i]);
+      lp += emit1(s->rd[j+i], s->blk[B-1+i],   s->blc[j+i], s->blw[j+i]);
+      v[cnt++] = lp;
+    } else {
+      v[cnt++] = g_int_log[U] + lp;
+      i -= (U-1);
+    }
+  }
+  if (-i < B+D) v[cnt++] = g_int_log[B+D+i] + lp;
+  return oracle_fast_lse_vec(v, cnt);
+}
+
+/* ---------------------------------------------- the DP (A.2) */
+typedef struct {
+  int n;
+  const char* rd; const double* blc; const double* blw;
+  double *M, *I, *D;        /* [max_size * n] row = haplotype position */
+  double side_prob;
+} OAln;
+
+/* HapAligner.cpp:26-161.  pmf = stutter pmf per STR option [nopts][13]. */
+static void align_side(OSide* sd, int reuse, int last_changed, OAln* a, const double* pmf, int period){
+  int n = a->n;
+  double* M = a->M; double* I = a->I; double* D = a->D;
+  double run = 0.0;
+  char first = sd->blk[0].seq[sd->counts[0]][0];
+  for (int j = 0; j < n; j++){
+    M[j] = emit1(a->rd[j], first, a->blc[j], a->blw[j]) + run;
+    I[j] = a->blc[j] + run;
+    D[j] = IMPOSSIBLE;
+    run += a->blc[j];
+  }
+  a->side_prob = run;
+  int hi = 1, stutR = -1;
+  for (int bi = 0; bi < 3; bi++){
+    const OBlock* ob = &sd->blk[bi]; int o = sd->counts[bi];
+    const char* bs = ob->seq[o]; int blen = ob->len[o];
+    if (reuse && bi < last_changed){
+      hi += blen + (bi == 0 ? -1 : 0);
+      if (bi == 1) stutR = hi-1;
+      continue;
+    }
+    if (bi == 1){
+      OStut st;
+      st.n = n; st.B = blen; st.p = period; st.nins = HIPSTR_MAX_STUTTER_REPS; st.ndel = sd->ndel[o];
+      st.blk = bs; st.rd = a->rd; st.blc = a->blc; st.blw = a->blw; st.ups = sd->ups[o];
+      st.Mt = malloc(sizeof(double)*n);
+      st.Dl = malloc(sizeof(double)*n*(st.ndel > 0 ? st.ndel : 1));
+      st.In = malloc(sizeof(double)*n*st.nins);
+      st.scratch = malloc(sizeof(double)*(blen+8));
+      stut_load(&st);
+      const double* prevM = M + (size_t)n*(hi-1);
+      double* rowM = M + (size_t)n*(hi+blen-1); double* rowI = I + (size_t)n*(hi+blen-1); double* rowD = D + (size_t)n*(hi+blen-1);
+      for (int j = 0; j < n; j++){
+        double terms[HIPSTR_NUM_ARTIFACTS]; int t = 0;
+        for (int art = -HIPSTR_MAX_STUTTER_REPS*period; art <= HIPSTR_MAX_STUTTER_REPS*period; art += period, t++){
+          int len = blen+art < j+1 ? blen+art : j+1;
+          if (len >= 0){
+            double pr = art == 0 ? st.Mt[n-1-j] : art > 0 ? stut_ins(&st, len, j, art) : stut_del(&st, len, j, art);
+            double pre = (j-len < 0 ? 0 : prevM[j-len]);
+            terms[t] = pmf[o*HIPSTR_NUM_ARTIFACTS + t] + pr + pre;
+          } else terms[t] = IMPOSSIBLE;
+        }
+        rowM[j] = oracle_fast_lse_vec(terms, HIPSTR_NUM_ARTIFACTS);
+        rowI[j] = IMPOSSIBLE; rowD[j] = IMPOSSIBLE;
+      }
+      free(st.Mt); free(st.Dl); free(st.In); free(st.scratch);
+      stutR = hi + blen - 1;
+      hi += blen;
+    } else {
+      for (int ci = (bi == 0 ? 1 : 0); ci < blen; ci++, hi++){
+        char hc = bs[ci];
+        int h1 = hom_len(sd, bi, ci), h2 = hom_len(sd, bi, ci-1 > 0 ? ci-1 : 0);
+        int h = h1 > h2 ? h1 : h2; if (h > HIPSTR_MAX_HOMOP_LEN) h = HIPSTR_MAX_HOMOP_LEN;
+        double* m = M + (size_t)n*hi; double* ins = I + (size_t)n*hi; double* del = D + (size_t)n*hi;
+        const double* pm = m - n; const double* pd = del - n;
+        int after_str = (hi == stutR+1);
+        m[0]   = emit1(a->rd[0], hc, a->blc[0], a->blw[0]);
+        ins[0] = after_str ? IMPOSSIBLE : a->blc[0];
+        del[0] = after_str ? IMPOSSIBLE : fmax(pd[0]+D2D, pm[0]+D2M);
+        if (after_str){
+          for (int j = 1; j < n; j++){
+            m[j] = emit1(a->rd[j], hc, a->blc[j], a->blw[j]) + pm[j-1];
+            ins[j] = IMPOSSIBLE; del[j] = IMPOSSIBLE;
+          }
+          continue;
+        }
+        for (int j = 1; j < n; j++){
+          double c0 = ins[j-1] + g_m2i[h], c1 = pm[j-1] + g_m2m[h], c2 = pd[j-1] + g_m2d[h];
+          m[j]   = emit1(a->rd[j], hc, a->blc[j], a->blw[j]) + fmax(c0, fmax(c1, c2));
+          ins[j] = a->blc[j] + fmax(pm[j-1] + I2M, ins[j-1] + I2I);
+          del[j] = fmax(pm[j] + D2M, pd[j] + D2D);
+        }
+      }
+    }
+  }
+}
+
+/* HapAligner.cpp:163-231 (forward haplotype = L side) */
+static double combine(const OSide* fw, const OAln* L, const OAln* R, char seed_c, double seed_lw, double seed_lc, double* scratch){
+  int nL = L->n, nR = R->n, H = 0, nseeds = 0, cnt = 0;
+  for (int bi = 0; bi < 3; bi++){ int len = fw->blk[bi].len[fw->counts[bi]]; H += len; if (bi != 1) nseeds += len; }
+  double prior = -g_int_log[nseeds];
+  const char* b0 = fw->blk[0].seq[fw->counts[0]];
+  const char* b2 = fw->blk[2].seq[fw->counts[2]]; int l2 = fw->blk[2].len[fw->counts[2]];
+  scratch[cnt++] = prior + (seed_c == b0[0] ? seed_lc : seed_lw) + L->side_prob + R->M[(size_t)nR*(H-1)-1];
+  scratch[cnt++] = prior + (seed_c == b2[l2-1] ? seed_lc : seed_lw) + R->side_prob + L->M[(size_t)nL*(H-1)-1];
+  const double* lp = L->M + (nL-1);
+  const double* rp = R->M + ((size_t)nR*(H-2) - 1);
+  for (int bi = 0; bi < 3; bi++){
+    const char* bs = fw->blk[bi].seq[fw->counts[bi]]; int blen = fw->blk[bi].len[fw->counts[bi]];
+    if (bi == 1){ lp += (size_t)nL*blen; rp -= (size_t)nR*blen; continue; }
+    int ci = (bi == 0 ? 1 : 0), ce = (bi == 2 ? blen-1 : blen);
+    for (; ci < ce; ci++){
+      scratch[cnt++] = prior + (seed_c == bs[ci] ? seed_lc : seed_lw) + *lp + *rp;
+      lp += nL; rp -= nR;
+    }
+  }
+  return oracle_fast_lse_vec(scratch, cnt);
+}
+
+/* ---------------------------------------------- seed (A.6) */
+static void best_seed_in(int32_t rs, int32_t re, int32_t rep_s, int32_t rep_e, int32_t* best_dist, int32_t* best_pos){
+  /* HapAligner.cpp:238-264 with a single repeat interval [rep_s, rep_e) */
+  *best_dist = *best_pos = -1;
+  int32_t pos = rs; int ri = 0;
+  while (ri < 1 && pos <= re){
+    if (pos < rep_s){
+      int32_t e = re < rep_s-1 ? re : rep_s-1;
+      int32_t dist = 1 + (e-pos)/2;
+      if (dist >= *best_dist){ *best_dist = dist; *best_pos = dist-1+pos; }
+      pos = rep_e; ri++;
+    } else if (pos < rep_e){ pos = rep_e; ri++; }
+    else ri++;
+  }
+  if (pos <= re){
+    int32_t dist = 1 + (re-pos)/2;
+    if (dist >= *best_dist){ *best_dist = dist; *best_pos = dist-1+pos; }
+  }
+}
+
+/* HapAligner.cpp:270-318; returns -2 on the inputs the reference dies on */
+static int seed_base(const hipstr_batch_t* b, int l, int r){
+  int32_t pos = b->read_start[r];
+  int best = -1, cur = 0, max_dist = MIN_SEED_DIST;
+  int32_t first_start = b->blk_start[3*l], last_end = b->blk_end[3*l+2];
+  int32_t rep_s = b->blk_start[3*l+1], rep_e = b->blk_end[3*l+1];
+  for (int c = b->cigar_off[r]; c < b->cigar_off[r+1]; c++){
+    int num = b->cigar_len[c];
+    switch (b->cigar_op[c]){
+      case '=': {
+        int32_t lo = pos, hi = pos+num-1;
+        if (lo < first_start) lo = first_start;
+        if (hi > last_end-1)  hi = last_end-1;
+        if (lo <= hi){
+          int32_t dist, dpos;
+          best_seed_in(lo, hi, rep_s, rep_e, &dist, &dpos);
+          if (dist >= max_dist){ max_dist = dist; best = cur + (dpos-pos); }
+        }
+        pos += num; cur += num; break;
+      }
+      case 'I': cur += num; break;
+      case 'X': pos += num; cur += num; break;
+      case 'D': pos += num; break;
+      default: return -2;
+    }
+  }
+  int len = b->base_off[r+1]-b->base_off[r];
+  if (best < -1 || best == 0 || best >= len-1) return -2;
+  return best;
+}
+
+int oracle_calc_seed_bases(const hipstr_batch_t* b, int32_t* seeds){
+  for (int l = 0; l < b->n_loci; l++)
+    for (int r = b->read_off[l]; r < b->read_off[l+1]; r++){
+      seeds[r] = seed_base(b, l, r);
+      if (seeds[r] == -2) return 1;
+    }
+  return 0;
+}
+
+/* ---------------------------------------------- allele iterator (A.7) */
+typedef struct { int n[3], f[3], dir[3], cnt[3], counter, ncombs, last_changed; } OIter;   /* Haplotype.cpp:123-196 */
+static void iter_reset(OIter* it){
+  it->ncombs = 1;
+  for (int i = 0; i < 3; i++){ it->f[i] = it->ncombs; it->ncombs *= it->n[i]; it->dir[i] = 1; it->cnt[i] = 0; }
+  it->counter = 0; it->last_changed = -1;
+}
+static int iter_next(OIter* it){
+  if (it->counter == it->ncombs-1) return 0;
+  int t = it->counter+1, idx = -1;
+  for (int j = 2; j >= 0; j--){ t %= it->f[j]; if (t == 0){ idx = j; break; } }
+  it->last_changed = idx;
+  it->cnt[idx] += it->dir[idx];
+  if (it->cnt[idx] == 0 || it->cnt[idx] == it->n[idx]-1) it->dir[idx] *= -1;
+  it->counter++;
+  return 1;
+}
+
+/* option index per block of allele k (fw block order), for tests of the Gray code */
+int oracle_allele_options(const int32_t* nopts, int k, int32_t* opts){
+  OIter it; for (int i = 0; i < 3; i++) it.n[i] = nopts[i];
+  iter_reset(&it);
+  if (k < 0 || k >= it.ncombs) return 1;
+  while (it.counter < k) iter_next(&it);
+  for (int i = 0; i < 3; i++) opts[i] = it.cnt[i];
+  return 0;
+}
+
+/* ---------------------------------------------- process_reads (A.1) */
+int oracle_process_reads(const hipstr_batch_t* b, double* aln_probs, int32_t* seeds){
+  oracle_init();
+  int opt_cursor = 0;
+  int64_t out_off = 0;
+  for (int l = 0; l < b->n_loci; l++){
+    int period = b->period[l];
+    OSide fw, rv;
+    side_build(&fw, b, l, opt_cursor, 0);
+    side_build(&rv, b, l, opt_cursor, 1);
+    OIter it;
+    for (int k = 0; k < 3; k++){ it.n[k] = b->blk_nopts[3*l+k]; opt_cursor += it.n[k]; }
+    iter_reset(&it);
+    int A = it.ncombs;
+    if (A != b->hap_off[l+1]-b->hap_off[l]){ side_free(&fw); side_free(&rv); return 2; }
+    /* stutter pmf per STR option (RepeatStutterInfo.h:53-61): identical for both orientations */
+    int nso = fw.blk[1].nopts;
+    double* pmf = malloc(sizeof(double)*nso*HIPSTR_NUM_ARTIFACTS);
+    for (int o = 0; o < nso; o++){
+      int size = fw.blk[1].len[o], t = 0;
+      for (int art = -HIPSTR_MAX_STUTTER_REPS*period; art <= HIPSTR_MAX_STUTTER_REPS*period; art += period, t++)
+        pmf[o*HIPSTR_NUM_ARTIFACTS+t] = (size+art < 0) ? LARGE_NEGATIVE : oracle_stutter_pmf(b->stutter+6*l, period, size, size+art);
+    }
+    int Hmax = fw.max_size;
+    for (int r = b->read_off[l]; r < b->read_off[l+1]; r++){
+      double* out = aln_probs + out_off + (int64_t)(r-b->read_off[l])*A;
+      if (b->realign_read && !b->realign_read[r]) continue;
+      int sb = seed_base(b, l, r);
+      if (sb == -2){ free(pmf); side_free(&fw); side_free(&rv); return 1; }
+      seeds[r] = sb;
+      if (sb == -1){ for (int k = 0; k < A; k++) out[k] = 0; continue; }     /* HapAligner.cpp:333-337 */
+      int len = b->base_off[r+1]-b->base_off[r];
+      const char* bases = b->bases + b->base_off[r]; const char* quals = b->quals + b->base_off[r];
+      double* lw = malloc(sizeof(double)*len); double* lc = malloc(sizeof(double)*len);
+      for (int j = 0; j < len; j++){ lw[j] = g_q_error[qual_index(quals[j])]; lc[j] = g_q_correct[qual_index(quals[j])]; }
+      int nL = sb, nR = len-sb-1;
+      char* rrd = malloc(nR+1); double* rlw = malloc(sizeof(double)*nR); double* rlc = malloc(sizeof(double)*nR);
+      for (int j = 0; j < nR; j++){ rrd[j] = bases[len-1-j]; rlw[j] = lw[len-1-j]; rlc[j] = lc[len-1-j]; }
+      OAln L, R;
+      L.n = nL; L.rd = bases; L.blc = lc; L.blw = lw;
+      R.n = nR; R.rd = rrd;  R.blc = rlc; R.blw = rlw;
+      L.M = malloc(sizeof(double)*(size_t)nL*Hmax); L.I = malloc(sizeof(double)*(size_t)nL*Hmax); L.D = malloc(sizeof(double)*(size_t)nL*Hmax);
+      R.M = malloc(sizeof(double)*(size_t)nR*Hmax); R.I = malloc(sizeof(double)*(size_t)nR*Hmax); R.D = malloc(sizeof(double)*(size_t)nR*Hmax);
+      double* scratch = malloc(sizeof(double)*(Hmax+4));
+      iter_reset(&it);
+      int reuse = 0;
+      do {
+        if (b->realign_hap && !b->realign_hap[b->hap_off[l]+it.counter]){ reuse = 0; continue; }
+        for (int k = 0; k < 3; k++){ fw.counts[k] = it.cnt[k]; rv.counts[k] = it.cnt[2-k]; }
+        int lc_fw = it.last_changed, lc_rv = it.last_changed < 0 ? -1 : 2-it.last_changed;
+        align_side(&fw, reuse, lc_fw, &L, pmf, period);
+        align_side(&rv, reuse, lc_rv, &R, pmf, period);
+        out[it.counter] = combine(&fw, &L, &R, bases[sb], lw[sb], lc[sb], scratch);
+        reuse = 1;
+      } while (iter_next(&it));
+      free(scratch);
+      free(L.M); free(L.I); free(L.D); free(R.M); free(R.I); free(R.D);
+      free(rrd); free(rlw); free(rlc); free(lw); free(lc);
+    }
+    out_off += (int64_t)(b->read_off[l+1]-b->read_off[l])*A;
+    free(pmf); side_free(&fw); side_free(&rv);
+  }
+  return 0;
+}
+
+/* ---------------------------------------------- posteriors (A.8, a15/a16) */
+int oracle_posteriors(const hipstr_post_batch_t* pb, double* log_post, double* sample_total_ll, int32_t* map_gt, double* locus_total_ll){
+  oracle_init();
+  int64_t post_off = 0, samp_off = 0, ll_off = 0;
+  for (int l = 0; l < pb->n_loci; l++){
+    int A = pb->n_alleles[l], S = pb->n_samples[l], nd = A*A;
+    int hap = pb->haploid ? pb->haploid[l] : 0;
+    /* genotyper.cpp:20-42 */
+    double hom = hap ? -g_int_log[A] : g_int_log[2] - g_int_log[A] - g_int_log[A+1];
+    double het = hap ? -DBL_MAX/2 : -g_int_log[A] - g_int_log[A+1];
+    double* post = log_post + post_off;
+    for (int s = 0; s < S; s++) for (int i = 0; i < A; i++) for (int j = 0; j < A; j++) post[(size_t)s*nd + i*A + j] = (i == j ? hom : het);
+    /* genotyper.cpp:49-61 */
+    for (int r = pb->read_off[l]; r < pb->read_off[l+1]; r++){
+      const double* LL = pb->log_aln_probs + ll_off + (int64_t)(r-pb->read_off[l])*A;
+      double* sp = post + (size_t)pb->sample_label[r]*nd;
+      for (int i = 0; i < A; i++) for (int j = 0; j < A; j++)
+        sp[i*A+j] += pb->read_weight[r]*oracle_fast_lse2(g_log_half + pb->log_p1[r] + LL[i], g_log_half + pb->log_p2[r] + LL[j]);
+    }
+    /* genotyper.cpp:63-72, 82-97 */
+    double total = 0.0;
+    for (int s = 0; s < S; s++){
+      double* sp = post + (size_t)s*nd;
+      double tot = oracle_log_sum_exp(sp, nd);
+      sample_total_ll[samp_off+s] = tot;
+      for (int i = 0; i < nd; i++) sp[i] -= tot;
+      total += tot;
+      double best = -DBL_MAX; int g1 = -1, g2 = -1;
+      for (int i = 0; i < A; i++) for (int j = 0; j < A; j++) if (sp[i*A+j] > best){ best = sp[i*A+j]; g1 = i; g2 = j; }
+      map_gt[2*(samp_off+s)] = g1; map_gt[2*(samp_off+s)+1] = g2;
+    }
+    locus_total_ll[l] = total;
+    post_off += (int64_t)S*nd; samp_off += S; ll_off += (int64_t)(pb->read_off[l+1]-pb->read_off[l])*A;
+  }
+  return 0;
+}

@@ -1,0 +1,227 @@
+/*
+ * ref_driver.cpp — TEST INFRASTRUCTURE ONLY.
+ *
+ * Thin C entry points around the *real* HipSTR v0.7 classes, compiled together
+ * with the reference's own translation units straight from /root/reference (see
+ * oracle/Makefile; nothing from the reference is copied into this repository).
+ * The resulting oracle/_ref/libhipstr_ref.so is used to
+ *   (1) pin the C restatement in oracle/hipstr_oracle.c,
+ *   (2) generate the golden fixtures under tests/golden/,
+ *   (3) serve as the "reference" CPU baseline in bench.py.
+ * It is never linked or loaded by the product library.
+ *
+ * The driver only rebuilds the reference's objects (HapBlock/RepeatBlock/
+ * Haplotype/Alignment/BaseQuality/StutterModel) from the flat hipstr_batch_t and
+ * calls the reference's public API.
+ */
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "SeqAlignment/AlignmentData.h"
+#include "SeqAlignment/AlignmentModel.h"
+#include "SeqAlignment/AlignmentTraceback.h"
+#include "SeqAlignment/HapAligner.h"
+#include "SeqAlignment/HapBlock.h"
+#include "SeqAlignment/Haplotype.h"
+#include "SeqAlignment/RepeatBlock.h"
+#include "base_quality.h"
+#include "genotyper.h"
+#include "mathops.h"
+#include "stutter_model.h"
+#include "fastonebigheader.h"
+
+#include "../include/hipstr_hmm.h"
+
+static bool g_ready = false;
+static void ensure_ready(){
+  if (!g_ready){
+    precompute_integer_logs();   // hipstr_main.cpp:352
+    init_alignment_model();      // seq_stutter_genotyper.cpp:631
+    g_ready = true;
+  }
+}
+
+namespace {
+struct RefLocus {
+  std::vector<HapBlock*> blocks;
+  Haplotype* hap;
+  StutterModel* model;
+  RefLocus() : hap(NULL), model(NULL) {}
+  ~RefLocus(){
+    delete hap;
+    for (size_t i = 0; i < blocks.size(); i++) delete blocks[i];
+    delete model;
+  }
+};
+
+// Rebuild the Haplotype of locus l; opt_cursor walks the flat option table.
+void build_locus(const hipstr_batch_t* b, int l, int& opt_cursor, RefLocus& out){
+  const double* sp = b->stutter + 6*l;
+  out.model = new StutterModel(sp[0], sp[1], sp[2], sp[3], sp[4], sp[5], b->period[l]);
+  for (int blk = 0; blk < 3; blk++){
+    int nopts = b->blk_nopts[3*l+blk];
+    std::vector<std::string> seqs;
+    for (int o = 0; o < nopts; o++, opt_cursor++)
+      seqs.push_back(std::string(b->seq + b->opt_off[opt_cursor], b->opt_off[opt_cursor+1]-b->opt_off[opt_cursor]));
+    HapBlock* hb;
+    if (blk == 1)
+      hb = new RepeatBlock(b->blk_start[3*l+blk], b->blk_end[3*l+blk], seqs[0], b->period[l], out.model);
+    else
+      hb = new HapBlock(b->blk_start[3*l+blk], b->blk_end[3*l+blk], seqs[0]);
+    for (int o = 1; o < nopts; o++)
+      hb->add_alternate(seqs[o]);
+    out.blocks.push_back(hb);
+  }
+  out.hap = new Haplotype(out.blocks);
+}
+
+Alignment make_alignment(const hipstr_batch_t* b, int r){
+  int len = b->base_off[r+1]-b->base_off[r];
+  std::string seq(b->bases + b->base_off[r], len), qual(b->quals + b->base_off[r], len);
+  int32_t stop = b->read_start[r];
+  Alignment aln(b->read_start[r], 0, false, "R", qual, seq, "");
+  for (int c = b->cigar_off[r]; c < b->cigar_off[r+1]; c++){
+    aln.add_cigar_element(CigarElement(b->cigar_op[c], b->cigar_len[c]));
+    if (b->cigar_op[c] != 'I') stop += b->cigar_len[c];
+  }
+  aln.set_stop(stop);
+  return aln;
+}
+} // namespace
+
+extern "C" {
+
+int ref_process_reads(const hipstr_batch_t* b, double* aln_probs, int32_t* seeds){
+  ensure_ready();
+  BaseQuality bq;
+  int opt_cursor = 0;
+  int64_t out_off = 0;
+  for (int l = 0; l < b->n_loci; l++){
+    RefLocus loc;
+    build_locus(b, l, opt_cursor, loc);
+    int A = loc.hap->num_combs();
+    if (A != b->hap_off[l+1]-b->hap_off[l]){ fprintf(stderr, "ref_driver: num_combs mismatch\n"); return 1; }
+    std::vector<bool> realign_hap(A, true);
+    if (b->realign_hap) for (int k = 0; k < A; k++) realign_hap[k] = b->realign_hap[b->hap_off[l]+k] != 0;
+    int r0 = b->read_off[l], r1 = b->read_off[l+1];
+    std::vector<Alignment> alns;
+    std::vector<bool> realign_read(r1-r0, true);
+    for (int r = r0; r < r1; r++){
+      alns.push_back(make_alignment(b, r));
+      if (b->realign_read) realign_read[r-r0] = b->realign_read[r] != 0;
+    }
+    HapAligner aligner(loc.hap, realign_hap);
+    aligner.process_reads(alns, 0, &bq, realign_read, aln_probs + out_off, seeds + r0);
+    out_off += (int64_t)(r1-r0)*A;
+  }
+  return 0;
+}
+
+/* Haplotype sequence of allele k of locus l in Haplotype::next() order, NUL terminated (for pinning the Gray code). */
+int ref_hap_sequences(const hipstr_batch_t* b, int l_want, char* out, int out_cap, int32_t* lens){
+  ensure_ready();
+  int opt_cursor = 0;
+  for (int l = 0; l < b->n_loci; l++){
+    RefLocus loc;
+    build_locus(b, l, opt_cursor, loc);
+    if (l != l_want) continue;
+    int pos = 0, k = 0;
+    do {
+      std::string s = loc.hap->get_seq();
+      if (pos + (int)s.size() > out_cap) return 1;
+      memcpy(out+pos, s.data(), s.size());
+      pos += s.size();
+      lens[k++] = s.size();
+    } while (loc.hap->next());
+    return 0;
+  }
+  return 1;
+}
+
+/* ---- scalar probes used to pin host tables and the float LSE approximations ---- */
+double ref_int_log(int v){ ensure_ready(); return int_log(v); }
+double ref_log_thresh(){ return LOG_THRESH; }
+double ref_log_one_half(){ return LOG_ONE_HALF; }
+double ref_transition(int which, int h){
+  ensure_ready();
+  switch (which){
+    case 0: return LOG_MATCH_TO_MATCH[h];
+    case 1: return LOG_MATCH_TO_INS[h];
+    case 2: return LOG_MATCH_TO_DEL[h];
+    case 3: return LOG_INS_TO_INS;
+    case 4: return LOG_INS_TO_MATCH;
+    case 5: return LOG_DEL_TO_DEL;
+    default: return LOG_DEL_TO_MATCH;
+  }
+}
+double ref_base_quality(int qual_char, int correct){
+  BaseQuality bq;
+  return correct ? bq.log_prob_correct((char)qual_char) : bq.log_prob_error((char)qual_char);
+}
+double ref_stutter_pmf(const double* sp, int period, int sample_bps, int read_bps){
+  StutterModel m(sp[0], sp[1], sp[2], sp[3], sp[4], sp[5], period);
+  return m.log_stutter_pmf(sample_bps, read_bps);
+}
+double ref_fast_lse_vec(const double* v, int n){
+  std::vector<double> vals(v, v+n);
+  return fast_log_sum_exp(vals);
+}
+double ref_fast_lse2(double a, double b){ return fast_log_sum_exp(a, b); }
+double ref_log_sum_exp(const double* v, int n){ return log_sum_exp(v, v+n); }
+
+} // extern "C"
+
+/* ---- posteriors: a subclass that exposes the protected members of Genotyper ---- */
+namespace {
+class ProbeGenotyper : public Genotyper {
+ public:
+  ProbeGenotyper(bool haploid, const std::vector<std::string>& names,
+                 const std::vector< std::vector<double> >& p1, const std::vector< std::vector<double> >& p2, int num_alleles)
+    : Genotyper(haploid, names, p1, p2){
+    num_alleles_           = num_alleles;
+    log_sample_posteriors_ = new double[(size_t)num_samples_*num_alleles_*num_alleles_];
+    log_aln_probs_         = new double[(size_t)num_reads_*num_alleles_];
+  }
+  double run(const double* LL, const int32_t* weights, double* post, double* totals, int32_t* map_gt){
+    memcpy(log_aln_probs_, LL, sizeof(double)*(size_t)num_reads_*num_alleles_);
+    std::vector<int> w(weights, weights+num_reads_);
+    double total = calc_log_sample_posteriors(w);
+    memcpy(post,   log_sample_posteriors_, sizeof(double)*(size_t)num_samples_*num_alleles_*num_alleles_);
+    memcpy(totals, sample_total_LLs_,      sizeof(double)*num_samples_);
+    std::vector< std::pair<int,int> > gts;
+    get_optimal_haplotypes(gts);
+    for (int s = 0; s < num_samples_; s++){ map_gt[2*s] = gts[s].first; map_gt[2*s+1] = gts[s].second; }
+    return total;
+  }
+};
+} // namespace
+
+extern "C" int ref_posteriors(const hipstr_post_batch_t* pb, double* log_post, double* sample_total_ll,
+                              int32_t* map_gt, double* locus_total_ll){
+  ensure_ready();
+  int64_t post_off = 0, samp_off = 0, ll_off = 0;
+  for (int l = 0; l < pb->n_loci; l++){
+    int A = pb->n_alleles[l], S = pb->n_samples[l];
+    int r0 = pb->read_off[l], r1 = pb->read_off[l+1];
+    std::vector<std::string> names;
+    std::vector< std::vector<double> > p1(S), p2(S);
+    for (int s = 0; s < S; s++){ char buf[32]; snprintf(buf, sizeof buf, "S%d", s); names.push_back(buf); }
+    int prev = 0;
+    for (int r = r0; r < r1; r++){
+      int s = pb->sample_label[r];
+      if (s < prev || s >= S){ fprintf(stderr, "ref_driver: reads must be grouped by ascending sample\n"); return 1; }
+      prev = s;
+      p1[s].push_back(pb->log_p1[r]);
+      p2[s].push_back(pb->log_p2[r]);
+    }
+    ProbeGenotyper g(pb->haploid ? pb->haploid[l] != 0 : false, names, p1, p2, A);
+    locus_total_ll[l] = g.run(pb->log_aln_probs + ll_off, pb->read_weight + r0, log_post + post_off,
+                              sample_total_ll + samp_off, map_gt + 2*samp_off);
+    post_off += (int64_t)S*A*A;
+    samp_off += S;
+    ll_off   += (int64_t)(r1-r0)*A;
+  }
+  return 0;
+}
