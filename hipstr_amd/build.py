@@ -1,0 +1,61 @@
+"""Builds every native artefact in-tree (so the .so files travel with the repo snapshot).
+
+  hipstr_amd/csrc/libhipstr_hmm.so    product: HIP kernels (gfx950) + C-ABI          [hipcc]
+  hipstr_amd/synth/libhipstr_synth.so bench/test input generator                     [g++]
+  oracle/libhipstr_oracle.so          TEST INFRASTRUCTURE: C restatement              [gcc, oracle/Makefile]
+  oracle/_ref/libhipstr_ref.so        TEST INFRASTRUCTURE: the compiled reference     [only where /root/reference exists]
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "hipstr_amd", "csrc")
+HIP_SOURCES = ["api.hip", "hmm_kernels.hip", "post_kernels.hip", "prep.cpp"]
+HIP_HEADERS = ["layout.h", "post_layout.h", "prep.h", os.path.join("..", "..", "include", "hipstr_hmm.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-result", "-Wno-unused-value"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _run(cmd, cwd=None):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=cwd)
+
+
+def build_hmm(force=False):
+    out = os.path.join(CSRC, "libhipstr_hmm.so")
+    deps = [os.path.join(CSRC, s) for s in HIP_SOURCES + HIP_HEADERS]
+    if force or _stale(out, deps):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        _run([hipcc] + HIPCC_FLAGS + ["-o", out] + [os.path.join(CSRC, s) for s in HIP_SOURCES])
+    return out
+
+
+def build_synth(force=False):
+    src = os.path.join(ROOT, "hipstr_amd", "synth", "synth.cpp")
+    out = os.path.join(ROOT, "hipstr_amd", "synth", "libhipstr_synth.so")
+    if force or _stale(out, [src, os.path.join(ROOT, "include", "hipstr_hmm.h")]):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out, src])
+    return out
+
+
+def build_oracle(force=False):
+    _run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"] + (["-B"] if force else []))
+    if os.path.isdir("/root/reference/src"):
+        _run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref", "-j8"])
+
+
+def build_all(force=False):
+    build_synth(force)
+    build_oracle(force)
+    build_hmm(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

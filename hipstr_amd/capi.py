@@ -198,6 +198,7 @@ def load_oracle():
     _common_align_sigs(lib, "oracle_")
     _sig(lib.oracle_calc_seed_bases, C.c_int, [_BP, _i32p])
     _sig(lib.oracle_allele_options, C.c_int, [_i32p, C.c_int, _i32p])
+    _sig(lib.oracle_debug_row_h, C.c_int, [_BP, C.c_int, _i32p, _i32p, C.c_int])
     for name, (rt, at) in _scalar_probes.items():
         _sig(getattr(lib, "oracle_" + name), rt, at)
     return lib
@@ -282,6 +283,7 @@ def load_hmm():
     _sig(lib.hipstr_post_offsets, C.c_int, [_PBP, C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
     _sig(lib.hipstr_post_run, C.c_int, [_PBP, C.c_void_p, _f64p, _f64p, _i32p, _f64p])
     _sig(lib.hipstr_post_run_timed, C.c_int, [_PBP, C.c_int, C.POINTER(C.c_float)])
+    _sig(lib.hipstr_debug_rows, C.c_int, [_BP, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_int])
     _sig(lib.hipstr_last_error, C.c_char_p, [])
     return lib
 

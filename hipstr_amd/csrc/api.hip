@@ -1,0 +1,362 @@
+// api.hip — the C-ABI of include/hipstr_hmm.h on top of the HIP kernels.
+//
+// Host responsibilities only: prepare (prep.cpp), move bytes, launch, time with HIP events on
+// the launch stream, and re-impose the reference's "leave untouched what was not realigned"
+// output contract.  There is no CPU compute path here: without a gfx950 device every entry
+// point fails and hipstr_last_error() says so.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hipstr_hmm.h"
+#include "layout.h"
+#include "post_layout.h"
+#include "prep.h"
+
+extern "C" __global__ void hs_forward_kernel(const hs_dev_t* dp);
+extern "C" __global__ void hs_posterior_kernel(const hs_post_dev_t* dp);
+extern "C" size_t hs_forward_lds_bytes(int lds_len, int lds_flank);
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const std::string& m){ g_err = m; return 1; }
+
+#define HS_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess){ \
+  g_err = std::string(#call) + ": " + hipGetErrorString(e_); return 1; } } while (0)
+#define HS_HIP_NULL(call) do { hipError_t e_ = (call); if (e_ != hipSuccess){ \
+  g_err = std::string(#call) + ": " + hipGetErrorString(e_); return NULL; } } while (0)
+
+struct DevTables {
+  bool ready = false;
+  int device = -1;
+  double *int_log = NULL, *qc = NULL, *qe = NULL, *m2m = NULL, *m2i = NULL;
+  hipStream_t stream = NULL;
+} g_tab;
+
+template <typename T> int to_device(const std::vector<T>& v, T** out){
+  *out = NULL;
+  const size_t bytes = (v.size() ? v.size() : 1) * sizeof(T);
+  HS_HIP(hipMalloc((void**)out, bytes));
+  if (!v.empty()) HS_HIP(hipMemcpy(*out, v.data(), v.size()*sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+int to_device_bytes(const void* p, size_t n, char** out){
+  *out = NULL;
+  HS_HIP(hipMalloc((void**)out, n ? n : 1));
+  if (n) HS_HIP(hipMemcpy(*out, p, n, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int ensure_init(){
+  if (g_tab.ready) return 0;
+  return hipstr_hmm_init(0);
+}
+
+}  // namespace
+
+struct hipstr_dev_batch {
+  hipstr::Prepared prep;
+  hs_dev_t h;             // host copy of the argument block (device pointers inside)
+  hs_dev_t* d_args = NULL;
+  std::vector<void*> allocs;
+  dim3 grid;
+  size_t lds_bytes = 0;
+  hipEvent_t ev0 = NULL, ev1 = NULL;
+};
+
+extern "C" {
+
+const char* hipstr_last_error(void){ return g_err.c_str(); }
+
+int hipstr_batch_out_offsets(const hipstr_batch_t* b, int64_t* out_off){
+  if (!b || !out_off) return fail("null argument");
+  int64_t acc = 0;
+  for (int l = 0; l < b->n_loci; l++){
+    out_off[l] = acc;
+    acc += (int64_t)(b->read_off[l+1]-b->read_off[l]) * (b->hap_off[l+1]-b->hap_off[l]);
+  }
+  out_off[b->n_loci] = acc;
+  return 0;
+}
+
+int hipstr_hmm_init(int device_ordinal){
+  if (g_tab.ready && g_tab.device == device_ordinal) return 0;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail("no HIP device available: this library has no CPU path (build/run on an MI355X)");
+  if (device_ordinal < 0 || device_ordinal >= ndev) return fail("device ordinal out of range");
+  HS_HIP(hipSetDevice(device_ordinal));
+  hipDeviceProp_t prop;
+  HS_HIP(hipGetDeviceProperties(&prop, device_ordinal));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(std::string("kernels are built for gfx950 only; device is ") + prop.gcnArchName);
+  const hipstr::HostTables& T = hipstr::host_tables();
+  std::vector<double> m2m(T.m2m, T.m2m+16), m2i(T.m2i, T.m2i+16);
+  if (to_device(T.int_log, &g_tab.int_log) || to_device(T.qual_correct, &g_tab.qc) || to_device(T.qual_error, &g_tab.qe) ||
+      to_device(m2m, &g_tab.m2m) || to_device(m2i, &g_tab.m2i)) return 1;
+  HS_HIP(hipStreamCreateWithFlags(&g_tab.stream, hipStreamNonBlocking));
+  g_tab.device = device_ordinal;
+  g_tab.ready = true;
+  return 0;
+}
+
+void hipstr_hmm_shutdown(void){
+  if (!g_tab.ready) return;
+  hipFree(g_tab.int_log); hipFree(g_tab.qc); hipFree(g_tab.qe); hipFree(g_tab.m2m); hipFree(g_tab.m2i);
+  hipStreamDestroy(g_tab.stream);
+  g_tab = DevTables();
+}
+
+int hipstr_calc_seed_bases(const hipstr_batch_t* b, int32_t* seeds){
+  if (!b || !seeds) return fail("null argument");
+  for (int l = 0; l < b->n_loci; l++)
+    for (int r = b->read_off[l]; r < b->read_off[l+1]; r++){
+      seeds[r] = hipstr::calc_seed_base(b, l, r);
+      if (seeds[r] == -2) return fail("Invalid alignment seed or unrecognized CIGAR char (HapAligner.cpp:309,316)");
+    }
+  return 0;
+}
+
+void hipstr_hmm_free(hipstr_dev_batch_t* dev){
+  if (!dev) return;
+  for (void* p : dev->allocs) hipFree(p);
+  if (dev->ev0) hipEventDestroy(dev->ev0);
+  if (dev->ev1) hipEventDestroy(dev->ev1);
+  delete dev;
+}
+
+hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){
+  if (ensure_init()) return NULL;
+  hipstr_dev_batch_t* dev = new hipstr_dev_batch_t();
+  std::string err;
+  if (hipstr::prepare_batch(batch, dev->prep, err)){ g_err = err; delete dev; return NULL; }
+  hipstr::Prepared& P = dev->prep;
+  hs_dev_t& h = dev->h;
+  memset(&h, 0, sizeof h);
+#define UP(field, vec, T) do { T* p_ = NULL; if (to_device(vec, &p_)){ hipstr_hmm_free(dev); return NULL; } dev->allocs.push_back(p_); h.field = p_; } while (0)
+  UP(loci, P.loci, hs_locus_t); UP(alleles, P.alleles, hs_allele_t); UP(stropts, P.stropts, hs_stropt_t);
+  UP(rowsets, P.rowsets, hs_rowset_t); UP(rows, P.rows, hs_row_t); UP(visits, P.visits, hs_visit_t);
+  UP(f64pool, P.f64pool, double); UP(chars, P.chars, char); UP(reads, P.reads, hs_read_t); UP(active, P.active, int32_t);
+#undef UP
+  char* p = NULL;
+  if (to_device_bytes(P.bases.data(), P.bases.size(), &p)){ hipstr_hmm_free(dev); return NULL; } dev->allocs.push_back(p); h.bases = p;
+  if (to_device_bytes(P.quals.data(), P.quals.size(), &p)){ hipstr_hmm_free(dev); return NULL; } dev->allocs.push_back(p); h.quals = p;
+  double* out = NULL;
+  const size_t out_bytes = (size_t)(P.n_out ? P.n_out : 1) * sizeof(double);
+  HS_HIP_NULL(hipMalloc((void**)&out, out_bytes)); dev->allocs.push_back(out);
+  HS_HIP_NULL(hipMemset(out, 0, out_bytes));
+  h.aln_probs = out;
+  const hipstr::HostTables& T = hipstr::host_tables();
+  h.int_log = g_tab.int_log; h.qual_correct = g_tab.qc; h.qual_error = g_tab.qe; h.m2m = g_tab.m2m; h.m2i = g_tab.m2i;
+  h.log_thresh = T.log_thresh; h.log_half = T.log_half;
+  h.n_active = (int32_t)P.active.size();
+  h.lds_len = P.max_read_len; h.lds_flank = P.max_flank;
+  // Workgroups: one per active read, times enough allele chunks to put >= ~4096 workgroups on the 256 CUs
+  int maxA = 1;
+  for (const hs_locus_t& l : P.loci) maxA = l.n_alleles > maxA ? l.n_alleles : maxA;
+  int gy = 1;
+  if (h.n_active > 0 && h.n_active < 4096){ gy = (4096 + h.n_active - 1) / h.n_active; if (gy > maxA) gy = maxA; }
+  h.allele_chunk = (maxA + gy - 1) / gy;
+  gy = (maxA + h.allele_chunk - 1) / h.allele_chunk;
+  dev->grid = dim3(h.n_active > 0 ? h.n_active : 1, gy, 1);
+  dev->lds_bytes = hs_forward_lds_bytes(h.lds_len, h.lds_flank);
+  if (dev->lds_bytes > 160*1024){ g_err = "batch needs more than 160 KiB of LDS per workgroup"; hipstr_hmm_free(dev); return NULL; }
+  if (dev->lds_bytes > 48*1024)
+    HS_HIP_NULL(hipFuncSetAttribute((const void*)hs_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->lds_bytes));
+  HS_HIP_NULL(hipMalloc((void**)&dev->d_args, sizeof(hs_dev_t))); dev->allocs.push_back(dev->d_args);
+  HS_HIP_NULL(hipMemcpy(dev->d_args, &h, sizeof h, hipMemcpyHostToDevice));
+  HS_HIP_NULL(hipEventCreate(&dev->ev0)); HS_HIP_NULL(hipEventCreate(&dev->ev1));
+  return dev;
+}
+
+int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
+  if (!dev) return fail("null device batch");
+  if (dev->h.n_active == 0) return 0;
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_tab.stream;
+  hipLaunchKernelGGL(hs_forward_kernel, dev->grid, dim3(128), dev->lds_bytes, st, (const hs_dev_t*)dev->d_args);
+  HS_HIP(hipGetLastError());
+  return 0;
+}
+
+int hipstr_hmm_align_timed(hipstr_dev_batch_t* dev, int reps, float* ms_total, float* ms_kernel){
+  if (!dev || reps < 1 || !ms_total) return fail("bad argument");
+  hipStream_t st = g_tab.stream;
+  HS_HIP(hipEventRecord(dev->ev0, st));
+  for (int i = 0; i < reps; i++) if (hipstr_hmm_align(dev, st)) return 1;
+  HS_HIP(hipEventRecord(dev->ev1, st));
+  HS_HIP(hipEventSynchronize(dev->ev1));
+  HS_HIP(hipEventElapsedTime(ms_total, dev->ev0, dev->ev1));
+  if (ms_kernel) *ms_kernel = *ms_total;     // the pass is a single kernel
+  return 0;
+}
+
+double* hipstr_hmm_dev_aln_probs(hipstr_dev_batch_t* dev){ return dev ? dev->h.aln_probs : NULL; }
+
+int hipstr_hmm_fetch(hipstr_dev_batch_t* dev, double* aln_probs, int32_t* seeds){
+  if (!dev || !aln_probs || !seeds) return fail("null argument");
+  HS_HIP(hipStreamSynchronize(g_tab.stream));
+  HS_HIP(hipDeviceSynchronize());
+  const hipstr::Prepared& P = dev->prep;
+  std::vector<double> tmp((size_t)P.n_out);
+  if (P.n_out) HS_HIP(hipMemcpy(tmp.data(), dev->h.aln_probs, (size_t)P.n_out*sizeof(double), hipMemcpyDeviceToHost));
+  for (const hs_locus_t& loc : P.loci){
+    const int A = loc.n_alleles;
+    for (int i = 0; i < loc.n_reads; i++){
+      const int r = loc.read_begin + i;
+      if (!P.realign_read[r]) continue;                       // HapAligner.cpp:326-329
+      seeds[r] = P.seeds[r];
+      double* dst = aln_probs + loc.out_off + (int64_t)i*A;
+      const double* src = tmp.data() + loc.out_off + (int64_t)i*A;
+      if (P.seeds[r] == -1){ for (int k = 0; k < A; k++) dst[k] = 0; continue; }   // HapAligner.cpp:333-337
+      for (int k = 0; k < A; k++) if (P.realign_hap[loc.hap_begin + k]) dst[k] = src[k];   // HapAligner.cpp:615-619
+    }
+  }
+  return 0;
+}
+
+int hipstr_hmm_process_reads(const hipstr_batch_t* batch, double* aln_probs, int32_t* seeds){
+  hipstr_dev_batch_t* dev = hipstr_hmm_upload(batch);
+  if (!dev) return 1;
+  int rc = hipstr_hmm_align(dev, NULL);
+  if (!rc) rc = hipstr_hmm_fetch(dev, aln_probs, seeds);
+  hipstr_hmm_free(dev);
+  return rc;
+}
+
+// Diagnostics for the host preparation (no device needed): the haplotype rows, as they enter the
+// systolic sweep, of allele k / side / block (0 = leading flank, 1 = trailing flank) of a ONE-locus batch.
+int hipstr_debug_rows(const hipstr_batch_t* batch, int k, int side, int which, uint32_t* rows, int cap){
+  hipstr::Prepared P; std::string err;
+  if (hipstr::prepare_batch(batch, P, err)){ g_err = err; return -1; }
+  if (k < 0 || k >= (int)P.alleles.size() || side < 0 || side > 1) return -1;
+  const hs_allele_t& al = P.alleles[k];
+  if (!al.realign) return 0;
+  const hs_rowset_t rs = P.rowsets[which ? al.trail_rows[side] : al.lead_rows[side]];
+  for (int i = 0; i < rs.len && i < cap; i++) rows[i] = P.rows[rs.off + i];
+  return rs.len;
+}
+
+// ----------------------------------------------------------------------------- posteriors
+int hipstr_post_offsets(const hipstr_post_batch_t* pb, int64_t* post_off, int64_t* samp_off){
+  if (!pb || !post_off || !samp_off) return fail("null argument");
+  int64_t po = 0, so = 0;
+  for (int l = 0; l < pb->n_loci; l++){
+    post_off[l] = po; samp_off[l] = so;
+    po += (int64_t)pb->n_samples[l]*pb->n_alleles[l]*pb->n_alleles[l];
+    so += pb->n_samples[l];
+  }
+  post_off[pb->n_loci] = po; samp_off[pb->n_loci] = so;
+  return 0;
+}
+
+namespace {
+struct PostRun {
+  std::vector<hs_post_unit_t> units;
+  std::vector<void*> allocs;
+  hs_post_dev_t h;
+  hs_post_dev_t* d_args = NULL;
+  int64_t n_post = 0, n_samp = 0, n_ll = 0;
+  int n_reads = 0;
+  ~PostRun(){ for (void* p : allocs) hipFree(p); }
+};
+
+int post_setup(const hipstr_post_batch_t* pb, const double* dev_ll, PostRun& R){
+  const hipstr::HostTables& T = hipstr::host_tables();
+  int64_t po = 0, so = 0, lo = 0;
+  for (int l = 0; l < pb->n_loci; l++){
+    const int A = pb->n_alleles[l], S = pb->n_samples[l];
+    const int r0 = pb->read_off[l], r1 = pb->read_off[l+1];
+    if (A < 1 || A+1 >= 10000) return fail("allele count out of range");
+    const bool hap = pb->haploid && pb->haploid[l];
+    const double hom = hap ? -T.int_log[A] : T.int_log[2] - T.int_log[A] - T.int_log[A+1];     // genotyper.cpp:20-25
+    const double het = hap ? -DBL_MAX/2 : -T.int_log[A] - T.int_log[A+1];                     // genotyper.cpp:27-32
+    int r = r0;
+    for (int s = 0; s < S; s++){
+      hs_post_unit_t u;
+      u.post_off = po + (int64_t)s*A*A; u.n_alleles = A; u.samp_index = (int32_t)(so + s);
+      u.log_hom_prior = hom; u.log_het_prior = het;
+      u.read_begin = r; u.ll_off = lo + (int64_t)(r-r0)*A;
+      while (r < r1 && pb->sample_label[r] == s) r++;
+      u.n_reads = r - u.read_begin;
+      R.units.push_back(u);
+    }
+    if (r != r1) return fail("reads of a locus must be grouped by ascending sample label (genotyper.h:112-119)");
+    po += (int64_t)S*A*A; so += S; lo += (int64_t)(r1-r0)*A;
+  }
+  R.n_post = po; R.n_samp = so; R.n_ll = lo; R.n_reads = pb->n_loci ? pb->read_off[pb->n_loci] : 0;
+  memset(&R.h, 0, sizeof R.h);
+  hs_post_unit_t* du = NULL;
+  if (to_device(R.units, &du)) return 1;
+  R.allocs.push_back(du); R.h.units = du;
+  auto up = [&](const void* src, size_t bytes, void** out){
+    *out = NULL;
+    if (hipMalloc(out, bytes ? bytes : 1) != hipSuccess) return fail("hipMalloc failed");
+    R.allocs.push_back(*out);
+    if (src && bytes && hipMemcpy(*out, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
+    return 0;
+  };
+  void* p;
+  if (up(pb->log_p1, sizeof(double)*R.n_reads, &p)) return 1; R.h.log_p1 = (const double*)p;
+  if (up(pb->log_p2, sizeof(double)*R.n_reads, &p)) return 1; R.h.log_p2 = (const double*)p;
+  if (up(pb->read_weight, sizeof(int32_t)*R.n_reads, &p)) return 1; R.h.read_weight = (const int32_t*)p;
+  if (dev_ll) R.h.log_aln_probs = dev_ll;
+  else {
+    if (!pb->log_aln_probs) return fail("no log_aln_probs given");
+    if (up(pb->log_aln_probs, sizeof(double)*R.n_ll, &p)) return 1; R.h.log_aln_probs = (const double*)p;
+  }
+  if (up(NULL, sizeof(double)*R.n_post, &p)) return 1; R.h.log_post = (double*)p;
+  if (up(NULL, sizeof(double)*R.n_samp, &p)) return 1; R.h.sample_total = (double*)p;
+  if (up(NULL, sizeof(int32_t)*2*R.n_samp, &p)) return 1; R.h.map_gt = (int32_t*)p;
+  R.h.log_thresh = T.log_thresh; R.h.log_half = T.log_half;
+  if (up(&R.h, sizeof R.h, &p)) return 1; R.d_args = (hs_post_dev_t*)p;
+  return 0;
+}
+}  // namespace
+
+int hipstr_post_run(const hipstr_post_batch_t* pb, const double* dev_log_aln_probs,
+                    double* log_post, double* sample_total_ll, int32_t* map_gt, double* locus_total_ll){
+  if (!pb || !log_post || !sample_total_ll || !map_gt || !locus_total_ll) return fail("null argument");
+  if (ensure_init()) return 1;
+  PostRun R;
+  if (post_setup(pb, dev_log_aln_probs, R)) return 1;
+  if (!R.units.empty()){
+    hipLaunchKernelGGL(hs_posterior_kernel, dim3((unsigned)R.units.size()), dim3(256), 0, g_tab.stream, (const hs_post_dev_t*)R.d_args);
+    HS_HIP(hipGetLastError());
+    HS_HIP(hipStreamSynchronize(g_tab.stream));
+    HS_HIP(hipMemcpy(log_post, R.h.log_post, sizeof(double)*R.n_post, hipMemcpyDeviceToHost));
+    HS_HIP(hipMemcpy(sample_total_ll, R.h.sample_total, sizeof(double)*R.n_samp, hipMemcpyDeviceToHost));
+    HS_HIP(hipMemcpy(map_gt, R.h.map_gt, sizeof(int32_t)*2*R.n_samp, hipMemcpyDeviceToHost));
+  }
+  int64_t so = 0;
+  for (int l = 0; l < pb->n_loci; l++){           // sum(sample_total_LLs_) (genotyper.cpp:75)
+    double tot = 0.0;
+    for (int s = 0; s < pb->n_samples[l]; s++) tot += sample_total_ll[so+s];
+    locus_total_ll[l] = tot;
+    so += pb->n_samples[l];
+  }
+  return 0;
+}
+
+int hipstr_post_run_timed(const hipstr_post_batch_t* pb, int reps, float* ms_total){
+  if (!pb || reps < 1 || !ms_total) return fail("bad argument");
+  if (ensure_init()) return 1;
+  PostRun R;
+  if (post_setup(pb, NULL, R)) return 1;
+  hipEvent_t e0, e1;
+  HS_HIP(hipEventCreate(&e0)); HS_HIP(hipEventCreate(&e1));
+  HS_HIP(hipEventRecord(e0, g_tab.stream));
+  for (int i = 0; i < reps; i++)
+    hipLaunchKernelGGL(hs_posterior_kernel, dim3((unsigned)R.units.size()), dim3(256), 0, g_tab.stream, (const hs_post_dev_t*)R.d_args);
+  HS_HIP(hipEventRecord(e1, g_tab.stream));
+  HS_HIP(hipEventSynchronize(e1));
+  HS_HIP(hipEventElapsedTime(ms_total, e0, e1));
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+// layout.h — HBM layout of a prepared (device-resident) batch, shared by the host
+// preparation code (prep.cpp) and the HIP kernels (hmm_kernels.hip).
+//
+// Everything the kernels touch is a flat pool + small POD tables of offsets; nothing
+// is pointer-chased.  Terminology follows the reference: a locus has candidate
+// haplotypes ("alleles") built from [left flank | STR block | right flank]; each
+// pooled read is split at its seed base into a LEFT problem (read prefix vs the
+// forward haplotype) and a RIGHT problem (reversed read suffix vs the reversed
+// haplotype) — HapAligner.cpp:606-628.  "side" 0 = left/forward, 1 = right/reversed.
+#pragma once
+#include <stdint.h>
+
+#define HS_NART          13        // artifact sizes -6p..+6p (RepeatStutterInfo.h:10-11)
+#define HS_MAXREP        6
+#define HS_MAX_COLS      4         // max read columns per lane in the systolic sweep
+#define HS_MAX_SIDE_LEN  (64 * HS_MAX_COLS)
+#define HS_IMPOSSIBLE    (-1000000000.0)   // HapAligner.cpp:20
+
+// One haplotype row of a flank block, as it enters the systolic sweep.
+//   bits  0..7   haplotype base (raw char, compared with read chars for equality)
+//   bits  8..11  min(15, homopolymer length) -> index into LOG_MATCH_TO_* (HapAligner.cpp:119-120)
+//   bits 12..23  compact row index u (see lastcol layout below)
+//   bit  31      valid
+typedef uint32_t hs_row_t;
+#define HS_ROW_VALID 0x80000000u
+
+// A contiguous run of rows in the row pool: the rows of one flank block option under
+// one homopolymer context.  Row 0 of a lead rowset is matrix row 0 (HapAligner.cpp:36-42);
+// row 0 of a trail rowset is the "stutter block must be followed by a match" row
+// (HapAligner.cpp:130-139).
+struct hs_rowset_t { int32_t off, len; };
+
+// Visiting list entry for StutterAlignerClass's artifact-position loops
+// (StutterAlignerClass.cpp:74-96 and :123-142): which block offsets the loop visits is
+// a function of the block sequence only, so the host enumerates them once per STR
+// option and the device replays the list uniformly across lanes.
+//   meta bits  0..15  ni = -i, the (non-positive) loop variable negated
+//        bits 16..31  U  = upstream match run length at this position (0 = none)
+//        bits 32..39  ca = block char whose emission is SUBTRACTED when U == 0
+//        bits 40..47  cb = block char whose emission is ADDED when U == 0
+//        bit  48      plain: push the running value unchanged (insertion branch `-i+p >= B`)
+//   logU = int_log(U) (mathops.cpp:13-21), valid when U > 0
+struct hs_visit_t { uint64_t meta; double logU; };
+
+// Per (STR option, side): block sequence in side orientation + everything derived from it.
+struct hs_stropt_t {
+  int32_t seq_off;           // into char pool
+  int32_t B;                 // block length
+  int32_t nd;                // num_deletions_ (StutterAlignerClass.h:64-69)
+  int32_t period;
+  int32_t f64_off;           // into f64 pool: pmf[13] | -int_log(B+1) | -int_log(B+D+1) for D=-p..-6p
+  int32_t ins_off, ins_len;  // visiting list shared by all insertion sizes
+  int32_t del_off[HS_MAXREP], del_len[HS_MAXREP];
+  int32_t pad;
+};
+
+struct hs_allele_t {
+  int32_t lead_rows[2];      // rowset id per side
+  int32_t trail_rows[2];
+  int32_t str_opt[2];        // hs_stropt_t index per side
+  int32_t n_flank;           // F0 + F2: number of non-STR haplotype bases (compute_aln_logprob's num_seeds)
+  int32_t realign;           // realign_to_haplotype flag
+};
+
+struct hs_locus_t {
+  int64_t out_off;           // offset of this locus' [P x A] block in aln_probs
+  int32_t hap_begin, n_alleles;
+  int32_t read_begin, n_reads;
+};
+
+struct hs_read_t {
+  int32_t base_off;          // into bases/quals pools
+  int32_t len;
+  int32_t seed;              // calc_seed_base result (-1 = none)
+  int32_t locus;
+};
+
+// Kernel argument block (all device pointers).
+struct hs_dev_t {
+  const hs_locus_t*  loci;
+  const hs_allele_t* alleles;
+  const hs_stropt_t* stropts;
+  const hs_rowset_t* rowsets;
+  const hs_row_t*    rows;
+  const hs_visit_t*  visits;
+  const double*      f64pool;
+  const char*        chars;      // STR block sequences
+  const hs_read_t*   reads;
+  const char*        bases;
+  const char*        quals;
+  const int32_t*     active;     // read indices that need alignment (realign && seed >= 0)
+  double*            aln_probs;
+  // constant tables
+  const double*      int_log;    // [10000]
+  const double*      qual_correct; // [256] indexed by raw quality char (clamps applied)
+  const double*      qual_error;   // [256]
+  const double*      m2m;        // [16] LOG_MATCH_TO_MATCH
+  const double*      m2i;        // [16] LOG_MATCH_TO_INS (== LOG_MATCH_TO_DEL, AlignmentModel.cpp:27-28)
+  double             log_thresh;   // LOG_THRESH = log(0.001), mathops.h:36 (host libm bits)
+  double             log_half;     // LOG_ONE_HALF, mathops.cpp:9
+  int32_t            n_active;
+  int32_t            allele_chunk;   // alleles per workgroup
+  int32_t            lds_len;        // max read length in the batch (LDS carve)
+  int32_t            lds_flank;      // max n_flank + 1
+};

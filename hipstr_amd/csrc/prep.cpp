@@ -1,0 +1,377 @@
+// prep.cpp — flatten a batch of loci into the device layout (layout.h).
+//
+// This is the host half of what HapAligner's constructor and the RepeatBlock /
+// StutterAlignerClass constructors do in the reference (HapAligner.h:56-69,
+// RepeatBlock.h:29-43, StutterAlignerClass.h:52-82): build the reversed haplotype,
+// the homopolymer-indexed rows of every flank block, the stutter pmf and the
+// periodicity structure of every STR allele — but emitted as flat pools the kernels
+// stream, instead of objects the CPU loop walks.  O(A·H) work per locus; the
+// O(P·A·H·L) dynamic programme runs on the device.
+#include "prep.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+
+namespace hipstr {
+
+static const int MIN_SEED_DIST = 5;          // HapAligner.cpp:17
+static const double LARGE_NEGATIVE = -10e6;  // RepeatStutterInfo.h:12
+
+const HostTables& host_tables(){
+  static HostTables t;
+  static bool ready = false;
+  if (!ready){
+    t.int_log.resize(10000);
+    t.int_log[0] = -1000;
+    for (int i = 1; i < 10000; i++) t.int_log[i] = log((double)i);
+    static const double dindel[10] = {2.9e-5, 2.9e-5, 2.9e-5, 2.9e-5, 4.3e-5, 1.1e-4, 2.4e-4, 5.7e-4, 1.0e-3, 1.4e-3};
+    t.m2m[0] = t.m2i[0] = 0;
+    for (unsigned int i = 1; i <= 15; i++){
+      t.m2i[i] = (i <= 10 ? log(dindel[i-1]) : log(dindel[9]+(4.3e-4)*(i-10)));
+      t.m2m[i] = log(1.0 - exp(t.m2i[i]) - exp(t.m2i[i]));
+    }
+    const int maxq = 'J'-'!';
+    std::vector<double> lc(maxq+1), le(maxq+1);
+    lc[0] = -100000; le[0] = -log(3);
+    for (int i = 1; i <= maxq; i++){
+      lc[i] = log(1.0 - pow(10.0, i/(-10.0)));
+      le[i] = log(pow(10.0, i/(-10.0))/3.0);
+    }
+    t.qual_correct.resize(256); t.qual_error.resize(256);
+    for (int c = 0; c < 256; c++){
+      char q = (char)c;                       // `char` is signed in the reference build as well
+      int idx = q < '!' ? 0 : (q > 'J' ? maxq : q-'!');
+      t.qual_correct[c] = lc[idx]; t.qual_error[c] = le[idx];
+    }
+    t.log_thresh = log(0.001);
+    t.log_half   = log(0.5);
+    ready = true;
+  }
+  return t;
+}
+
+double log_stutter_pmf(const double* sp, int period, int sample_bps, int read_bps){
+  const double in_step = log(1-sp[0]), in_nostep = log(sp[0]), in_up = log(sp[1]), in_down = log(sp[2]);
+  const double out_step = log(1-sp[3]), out_nostep = log(sp[3]), out_up = log(sp[4]), out_down = log(sp[5]);
+  const int diff = read_bps - sample_bps;
+  if (diff % period != 0){
+    const int eff = diff - diff/period;
+    return eff < 0 ? out_down + out_nostep + out_step*(-eff-1) : out_up + out_nostep + out_step*(eff-1);
+  }
+  const int rep = diff/period;
+  if (rep == 0) return log(1-sp[1]-sp[2]-sp[4]-sp[5]);
+  return rep < 0 ? in_down + in_nostep + in_step*(-rep-1) : in_up + in_nostep + in_step*(rep-1);
+}
+
+void allele_options(const int32_t nopts[3], int k, int32_t opts[3]){
+  // reflected mixed-radix Gray code, block 0 the fastest digit
+  int f = 1;
+  for (int i = 0; i < 3; i++){
+    const int n = nopts[i];
+    const int digit = (k / f) % n;
+    const bool reflected = ((k / (f*n)) & 1) != 0;
+    opts[i] = reflected ? n-1-digit : digit;
+    f *= n;
+  }
+}
+
+// block whose option changes when stepping from allele k-1 to k (k >= 1)
+static int changed_block(const int32_t nopts[3], int k){
+  const int f1 = nopts[0], f2 = nopts[0]*nopts[1];
+  if (k % f2 == 0) return 2;
+  if (k % f1 == 0) return 1;
+  return 0;
+}
+
+int calc_seed_base(const hipstr_batch_t* b, int l, int r){
+  const int32_t win_lo = b->blk_start[3*l], win_hi = b->blk_end[3*l+2]-1;
+  const int32_t rep_lo = b->blk_start[3*l+1], rep_hi = b->blk_end[3*l+1];   // [rep_lo, rep_hi)
+  int32_t pos = b->read_start[r];
+  int best = -1, consumed = 0, best_dist = MIN_SEED_DIST;
+  for (int c = b->cigar_off[r]; c < b->cigar_off[r+1]; c++){
+    const int num = b->cigar_len[c];
+    const char op = b->cigar_op[c];
+    if (op == '='){
+      const int32_t lo = std::max(pos, win_lo), hi = std::min(pos+num-1, win_hi);
+      if (lo <= hi){
+        // candidate sub-intervals of [lo,hi] free of the repeat: the part left of it, then the part right of it;
+        // ties go to the later one (the reference uses >= throughout)
+        int32_t d = -1, p = -1;
+        int32_t cur = lo;
+        if (cur < rep_lo){
+          const int32_t e = std::min(hi, rep_lo-1);
+          d = 1 + (e-cur)/2; p = cur + d - 1;
+          cur = rep_hi;
+        } else if (cur < rep_hi) cur = rep_hi;
+        if (cur <= hi){
+          const int32_t d2 = 1 + (hi-cur)/2;
+          if (d2 >= d){ d = d2; p = cur + d2 - 1; }
+        }
+        if (d >= best_dist){ best_dist = d; best = consumed + (p - pos); }
+      }
+      pos += num; consumed += num;
+    }
+    else if (op == 'X'){ pos += num; consumed += num; }
+    else if (op == 'I') consumed += num;
+    else if (op == 'D') pos += num;
+    else return -2;    // "Unrecognized CIGAR char in calc_seed_base()"
+  }
+  const int len = b->base_off[r+1]-b->base_off[r];
+  if (best < -1 || best == 0 || best >= len-1) return -2;   // "Invalid alignment seed"
+  return best;
+}
+
+namespace {
+
+struct SideSeqs {                 // the three block sequences of one allele in one orientation
+  std::string s[3];
+  std::vector<int> lrun[3], rrun[3];
+  // Run-length tables of HapBlock::calc_homopolymer_lengths (HapBlock.cpp:7-30).  The reference
+  // does not reset its counter between the forward and the backward pass, so the backward
+  // ("right") lengths near the end of a block are inflated by the block's trailing run; the
+  // transition tables are indexed with those values, so the quirk is reproduced on purpose.
+  void index(){
+    for (int b = 0; b < 3; b++){
+      const std::string& q = s[b];
+      const int n = q.size();
+      lrun[b].assign(n, 0); rrun[b].assign(n, 0);
+      if (n == 0) continue;
+      int count = 0;
+      for (int j = 1; j < n; j++){ count = (q[j-1] == q[j]) ? count+1 : 0; lrun[b][j] = count; }
+      for (int j = n-2; j >= 0; j--){ count = (q[j+1] == q[j]) ? count+1 : 0; rrun[b][j] = count; }
+    }
+  }
+};
+
+// Haplotype::homopolymer_length with its neighbour-block extensions (Haplotype.cpp:239-287).
+int homopolymer_len(const SideSeqs& h, int bi, int pos){
+  const std::string& q = h.s[bi];
+  const char c = q[pos];
+  int l = h.lrun[bi][pos], r = h.rrun[bi][pos];
+  if (pos - l == 0){
+    for (int nb = bi-1; nb >= 0; nb--){
+      const int n = h.s[nb].size();
+      if (n == 0) continue;
+      if (h.s[nb][n-1] != c) break;
+      const int ll = h.lrun[nb][n-1];
+      l += 1 + ll;
+      if (ll != n) break;
+    }
+  }
+  if (pos + r == (int)q.size()-1){
+    for (int nb = bi+1; nb < 3; nb++){
+      const int n = h.s[nb].size();
+      if (n == 0) continue;
+      if (h.s[nb][0] != c) break;
+      const int rl = h.rrun[nb][0];
+      r += 1 + rl;
+      if (rl != n) break;
+    }
+  }
+  return l + r + 1;
+}
+
+// rows of flank block `bi` (0 = lead, 2 = trail) under context h; u0 = compact index of its first row
+std::vector<hs_row_t> flank_rows(const SideSeqs& h, int bi, int u0){
+  const std::string& q = h.s[bi];
+  std::vector<hs_row_t> rows(q.size());
+  for (int i = 0; i < (int)q.size(); i++){
+    const int hl = std::min(HIPSTR_MAX_HOMOP_LEN, std::max(homopolymer_len(h, bi, i), homopolymer_len(h, bi, std::max(0, i-1))));
+    rows[i] = HS_ROW_VALID | ((uint32_t)(u0+i) << 12) | ((uint32_t)hl << 8) | (uint8_t)q[i];
+  }
+  return rows;
+}
+
+std::vector<int> upstream_runs(const std::string& s, int shift){   // StutterAlignerClass.h:35-42
+  std::vector<int> m(s.size(), 0);
+  for (int i = shift; i < (int)s.size(); i++) m[i] = (s[i-shift] != s[i]) ? 0 : 1 + m[i-1];
+  return m;
+}
+
+inline hs_visit_t visit(int ni, int U, char ca, char cb, bool plain, double logU){
+  hs_visit_t v;
+  v.meta = (uint64_t)(uint16_t)ni | ((uint64_t)(uint16_t)U << 16) | ((uint64_t)(uint8_t)ca << 32) | ((uint64_t)(uint8_t)cb << 40) | ((uint64_t)(plain ? 1 : 0) << 48);
+  v.logU = logU;
+  return v;
+}
+
+// One STR option in one orientation -> hs_stropt_t (+ its pools)
+void emit_stropt(const std::string& blk, int period, const double* stutter, Prepared& out){
+  const HostTables& T = host_tables();
+  const int B = blk.size();
+  hs_stropt_t so; memset(&so, 0, sizeof so);
+  so.seq_off = out.chars.size();
+  out.chars.insert(out.chars.end(), blk.begin(), blk.end());
+  while (out.chars.size() % 4) out.chars.push_back(0);
+  so.B = B; so.period = period;
+  int nd = HIPSTR_MAX_STUTTER_REPS;
+  while (nd*period > B) nd--;
+  so.nd = nd;
+  so.f64_off = out.f64pool.size();
+  for (int t = 0; t < HS_NART; t++){
+    const int art = (t - HS_MAXREP)*period;
+    out.f64pool.push_back(B+art < 0 ? LARGE_NEGATIVE : log_stutter_pmf(stutter, period, B, B+art));
+  }
+  out.f64pool.push_back(-T.int_log[B+1]);                                   // StutterAlignerClass.cpp:64
+  for (int q = 0; q < HS_MAXREP; q++){
+    const int D = -(q+1)*period;
+    out.f64pool.push_back(B+D >= 0 ? -T.int_log[B+D+1] : 0.0);              // StutterAlignerClass.cpp:112
+  }
+  // insertion visiting list (StutterAlignerClass.cpp:74-96); uses the shift-`period` run table
+  {
+    const std::vector<int> up = upstream_runs(blk, period);
+    so.ins_off = out.visits.size();
+    int i = 0;
+    for (;;){
+      const int ni = -i;
+      if (ni >= B){ out.visits.push_back(visit(ni, 0, 0, 0, true, 0)); break; }
+      if (-i + period < B){
+        const int U = up[B-1+i];
+        if (U == 0){ out.visits.push_back(visit(ni, 0, blk[B-1+i], blk[B-1+i-period], false, 0)); i -= 1; }
+        else       { out.visits.push_back(visit(ni, U, 0, 0, false, T.int_log[U])); i -= U; }
+      } else { out.visits.push_back(visit(ni, 0, 0, 0, true, 0)); i -= 1; }
+    }
+    so.ins_len = out.visits.size() - so.ins_off;
+  }
+  // deletion visiting lists (StutterAlignerClass.cpp:123-142); one per deletion size, shift = |D|
+  for (int q = 0; q < HS_MAXREP; q++){
+    const int D = -(q+1)*period;
+    so.del_off[q] = out.visits.size();
+    if (B+D < 0){ so.del_len[q] = 0; continue; }
+    const std::vector<int> up = upstream_runs(blk, -D);
+    int i = 0;
+    for (;;){
+      const int ni = -i;
+      if (ni >= B+D){ out.visits.push_back(visit(ni, 0, 0, 0, true, 0)); break; }
+      const int U = up[B-1+i];
+      if (U == 0){ out.visits.push_back(visit(ni, 0, blk[B-1+i+D], blk[B-1+i], false, 0)); i -= 1; }
+      else       { out.visits.push_back(visit(ni, U, 0, 0, false, T.int_log[U])); i -= U; }
+    }
+    so.del_len[q] = out.visits.size() - so.del_off[q];
+  }
+  out.stropts.push_back(so);
+}
+
+}  // namespace
+
+int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err){
+  host_tables();
+  if (b == NULL || b->n_loci < 0){ err = "null or negative-size batch"; return 1; }
+  const int n_reads_total = b->n_loci > 0 ? b->read_off[b->n_loci] : 0;
+  out.seeds.assign(n_reads_total, -1);
+  out.realign_read.assign(n_reads_total, 1);
+  out.reads.resize(n_reads_total);
+  const int total_bases = n_reads_total > 0 ? b->base_off[n_reads_total] : 0;
+  out.bases.assign(b->bases ? b->bases : "", total_bases);
+  out.quals.assign(b->quals ? b->quals : "", total_bases);
+  int opt_cursor = 0;
+  int64_t out_off = 0;
+  for (int l = 0; l < b->n_loci; l++){
+    const int period = b->period[l];
+    if (period < 1 || period > 9){ err = "STR period must be in [1,9] (stutter_model.h:38)"; return 1; }
+    int32_t nopts[3];
+    std::vector<std::string> opt[3];
+    for (int k = 0; k < 3; k++){
+      nopts[k] = b->blk_nopts[3*l+k];
+      if (nopts[k] < 1){ err = "haplotype block without options"; return 1; }
+      for (int o = 0; o < nopts[k]; o++, opt_cursor++)
+        opt[k].push_back(std::string(b->seq + b->opt_off[opt_cursor], b->opt_off[opt_cursor+1]-b->opt_off[opt_cursor]));
+    }
+    for (int k = 0; k < 3; k += 2)
+      for (size_t o = 0; o < opt[k].size(); o++)
+        if (opt[k][o].empty()){ err = "empty flank sequence"; return 1; }
+    for (size_t o = 0; o < opt[1].size(); o++){
+      if (opt[1][o].empty()){ err = "empty STR allele is not supported"; return 1; }
+      if (opt[1][o].size() > 256){ err = "STR allele longer than 256 bp is not supported"; return 1; }
+    }
+    const int A = nopts[0]*nopts[1]*nopts[2];
+    if (A != b->hap_off[l+1]-b->hap_off[l]){ err = "hap_off does not match the product of block options"; return 1; }
+
+    hs_locus_t loc;
+    loc.out_off = out_off; loc.hap_begin = out.alleles.size(); loc.n_alleles = A;
+    loc.read_begin = b->read_off[l]; loc.n_reads = b->read_off[l+1]-b->read_off[l];
+
+    // STR options: forward then reversed orientation
+    const int so_base = out.stropts.size();
+    for (int side = 0; side < 2; side++)
+      for (int o = 0; o < nopts[1]; o++){
+        std::string s = opt[1][o];
+        if (side) std::reverse(s.begin(), s.end());
+        emit_stropt(s, period, b->stutter + 6*l, out);
+      }
+
+    // alleles in visit order, replaying the reference's row reuse (HapAligner.cpp:54-60, 612-634):
+    // the lead block of a side is (re)computed only when reuse is off or it is the block that changed;
+    // otherwise its rows — and the homopolymer context they were computed under — are inherited.
+    std::map<std::vector<hs_row_t>, int> rowset_ids;
+    auto intern = [&](const std::vector<hs_row_t>& rows){
+      auto it = rowset_ids.find(rows);
+      if (it != rowset_ids.end()) return it->second;
+      hs_rowset_t rs; rs.off = out.rows.size(); rs.len = rows.size();
+      out.rows.insert(out.rows.end(), rows.begin(), rows.end());
+      const int id = out.rowsets.size();
+      out.rowsets.push_back(rs);
+      rowset_ids[rows] = id;
+      return id;
+    };
+    bool reuse = false;
+    int lead_id[2] = {-1, -1};
+    int n_realigned = 0;
+    for (int k = 0; k < A; k++){
+      const bool realign = b->realign_hap ? b->realign_hap[b->hap_off[l]+k] != 0 : true;
+      out.realign_hap.push_back(realign ? 1 : 0);
+      hs_allele_t al; memset(&al, 0, sizeof al);
+      al.realign = realign ? 1 : 0;
+      int32_t o3[3];
+      allele_options(nopts, k, o3);
+      al.n_flank = opt[0][o3[0]].size() + opt[2][o3[2]].size();
+      out.max_flank = std::max(out.max_flank, al.n_flank);
+      if (!realign){ reuse = false; out.alleles.push_back(al); continue; }
+      n_realigned++;
+      const int cb = k == 0 ? -1 : changed_block(nopts, k);
+      for (int side = 0; side < 2; side++){
+        SideSeqs h;
+        for (int j = 0; j < 3; j++){
+          h.s[j] = opt[side ? 2-j : j][o3[side ? 2-j : j]];
+          if (side) std::reverse(h.s[j].begin(), h.s[j].end());
+        }
+        h.index();
+        const int side_changed = cb < 0 ? -1 : (side ? 2-cb : cb);
+        if (!reuse || side_changed <= 0) lead_id[side] = intern(flank_rows(h, 0, 0));
+        al.lead_rows[side]  = lead_id[side];
+        al.trail_rows[side] = intern(flank_rows(h, 2, (int)h.s[0].size() + 1));
+        al.str_opt[side]    = so_base + side*nopts[1] + o3[1];
+      }
+      reuse = true;
+      out.alleles.push_back(al);
+    }
+
+    for (int r = loc.read_begin; r < loc.read_begin + loc.n_reads; r++){
+      hs_read_t rd;
+      rd.base_off = b->base_off[r]; rd.len = b->base_off[r+1]-b->base_off[r]; rd.locus = l; rd.seed = -1;
+      const bool realign = b->realign_read ? b->realign_read[r] != 0 : true;
+      out.realign_read[r] = realign ? 1 : 0;
+      if (realign){
+        const int s = calc_seed_base(b, l, r);
+        if (s == -2){ err = "Invalid alignment seed or unrecognized CIGAR char (HapAligner.cpp:309,316)"; return 1; }
+        rd.seed = s;
+        out.seeds[r] = s;
+        if (s >= 0){
+          if (s > HS_MAX_SIDE_LEN || rd.len-s-1 > HS_MAX_SIDE_LEN){ err = "read side longer than 256 bases is not supported"; return 1; }
+          out.active.push_back(r);
+          out.n_alignments += n_realigned;
+          out.max_read_len = std::max(out.max_read_len, rd.len);
+        }
+      }
+      out.reads[r] = rd;
+    }
+    out.loci.push_back(loc);
+    out_off += (int64_t)loc.n_reads * A;
+  }
+  out.n_out = out_off;
+  return 0;
+}
+
+}  // namespace hipstr

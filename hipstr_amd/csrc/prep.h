@@ -1,0 +1,57 @@
+// prep.h — host-side preparation of a hipstr_batch_t into the flat HBM layout of layout.h.
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/hipstr_hmm.h"
+#include "layout.h"
+
+namespace hipstr {
+
+// Constant tables the reference keeps in globals; computed once with the host libm so they
+// carry exactly the bits the reference computes (mathops.cpp:13-21, AlignmentModel.cpp:20-32,
+// base_quality.h:29-38 and its clamps :44-75, mathops.h:36, mathops.cpp:9).
+struct HostTables {
+  std::vector<double> int_log;        // [10000]
+  std::vector<double> qual_correct;   // [256] by raw quality char
+  std::vector<double> qual_error;     // [256]
+  double m2m[16], m2i[16];
+  double log_thresh, log_half;
+};
+const HostTables& host_tables();
+
+struct Prepared {
+  std::vector<hs_locus_t>  loci;
+  std::vector<hs_allele_t> alleles;
+  std::vector<hs_stropt_t> stropts;
+  std::vector<hs_rowset_t> rowsets;
+  std::vector<hs_row_t>    rows;
+  std::vector<hs_visit_t>  visits;
+  std::vector<double>      f64pool;
+  std::vector<char>        chars;
+  std::vector<hs_read_t>   reads;
+  std::vector<int32_t>     active;
+  std::vector<int32_t>     seeds;          // per read (valid only where realign_read)
+  std::vector<uint8_t>     realign_read;   // per read
+  std::vector<uint8_t>     realign_hap;    // per global allele
+  std::string              bases, quals;
+  int64_t n_out        = 0;
+  int64_t n_alignments = 0;   // (active read) x (realigned allele) pairs = HMM alignments per pass
+  int32_t max_read_len = 0;
+  int32_t max_flank    = 0;   // max n_flank over alleles
+};
+
+// Returns 0 on success; otherwise fills err.
+int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err);
+
+// HapAligner::calc_seed_base (HapAligner.cpp:238-318).  Returns -2 on the inputs the reference dies on.
+int calc_seed_base(const hipstr_batch_t* b, int locus, int read);
+
+// Option index per block of allele k in Haplotype::next() order (Haplotype.cpp:123-196).
+void allele_options(const int32_t nopts[3], int k, int32_t opts[3]);
+
+// StutterModel::log_stutter_pmf (stutter_model.cpp:29-53) from the six constructor parameters.
+double log_stutter_pmf(const double* sp, int period, int sample_bps, int read_bps);
+
+}  // namespace hipstr

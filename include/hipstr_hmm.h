@@ -166,6 +166,13 @@ int hipstr_post_run(const hipstr_post_batch_t* pb, const double* dev_log_aln_pro
  * between HIP events on the launch stream. */
 int hipstr_post_run_timed(const hipstr_post_batch_t* pb, int reps, float* ms_total);
 
+/* Diagnostics (host only, no device): the haplotype rows of allele k of a ONE-locus batch as the
+ * device sweep consumes them — side 0 = forward/left problem, 1 = reversed/right problem; which 0 =
+ * leading flank block, 1 = trailing flank block.  Row encoding: bits 0-7 base, 8-11 homopolymer index
+ * min(15, ..) of HapAligner.cpp:119-120, 12-23 compact row index, bit 31 valid.  Returns the row
+ * count (0 if the allele is not realigned, -1 on error).  Used by tests/test_prep.py. */
+int hipstr_debug_rows(const hipstr_batch_t* batch, int k, int side, int which, uint32_t* rows, int cap);
+
 const char* hipstr_last_error(void);
 
 #ifdef __cplusplus

@@ -389,6 +389,11 @@ typedef struct {
   double side_prob;
 } OAln;
 
+/* test hook: when set, align_side records the homopolymer index used for every flank row */
+static int* g_dbg_h[2] = {NULL, NULL};
+static int g_dbg_stop = -1;
+static int g_dbg_side = 0;
+
 /* HapAligner.cpp:26-161.  pmf = stutter pmf per STR option [nopts][13]. */
 static void align_side(OSide* sd, int reuse, int last_changed, OAln* a, const double* pmf, int period){
   int n = a->n;
@@ -443,6 +448,7 @@ static void align_side(OSide* sd, int reuse, int last_changed, OAln* a, const do
         char hc = bs[ci];
         int h1 = hom_len(sd, bi, ci), h2 = hom_len(sd, bi, ci-1 > 0 ? ci-1 : 0);
         int h = h1 > h2 ? h1 : h2; if (h > HIPSTR_MAX_HOMOP_LEN) h = HIPSTR_MAX_HOMOP_LEN;
+        if (g_dbg_h[g_dbg_side]) g_dbg_h[g_dbg_side][hi] = h;
         double* m = M + (size_t)n*hi; double* ins = I + (size_t)n*hi; double* del = D + (size_t)n*hi;
         const double* pm = m - n; const double* pd = del - n;
         int after_str = (hi == stutR+1);
@@ -628,8 +634,9 @@ int oracle_process_reads(const hipstr_batch_t* b, double* aln_probs, int32_t* se
         if (b->realign_hap && !b->realign_hap[b->hap_off[l]+it.counter]){ reuse = 0; continue; }
         for (int k = 0; k < 3; k++){ fw.counts[k] = it.cnt[k]; rv.counts[k] = it.cnt[2-k]; }
         int lc_fw = it.last_changed, lc_rv = it.last_changed < 0 ? -1 : 2-it.last_changed;
-        align_side(&fw, reuse, lc_fw, &L, pmf, period);
-        align_side(&rv, reuse, lc_rv, &R, pmf, period);
+        g_dbg_side = 0; align_side(&fw, reuse, lc_fw, &L, pmf, period);
+        g_dbg_side = 1; align_side(&rv, reuse, lc_rv, &R, pmf, period);
+        if (g_dbg_h[0] && it.counter == g_dbg_stop){ g_dbg_h[0] = g_dbg_h[1] = NULL; }
         out[it.counter] = combine(&fw, &L, &R, bases[sb], lw[sb], lc[sb], scratch);
         reuse = 1;
       } while (iter_next(&it));
@@ -678,4 +685,17 @@ int oracle_posteriors(const hipstr_post_batch_t* pb, double* log_post, double* s
     post_off += (int64_t)S*nd; samp_off += S; ll_off += (int64_t)(pb->read_off[l+1]-pb->read_off[l])*A;
   }
   return 0;
+}
+
+/* test hook: homopolymer index per matrix row (both sides) as in effect when allele k of a one-locus,
+ * one-read batch is scored (rows of blocks that were reused keep the values of the allele they were computed under) */
+int oracle_debug_row_h(const hipstr_batch_t* b, int k, int32_t* h_fw, int32_t* h_rv, int cap){
+  for (int i = 0; i < cap; i++){ h_fw[i] = 0; h_rv[i] = 0; }
+  g_dbg_h[0] = h_fw; g_dbg_h[1] = h_rv; g_dbg_stop = k;
+  int64_t n = (int64_t)b->read_off[b->n_loci] * 4096;
+  double* probs = malloc(sizeof(double)*(n > 0 ? n : 1)); int32_t* seeds = malloc(sizeof(int32_t)*(b->read_off[b->n_loci]+1));
+  int rc = oracle_process_reads(b, probs, seeds);
+  g_dbg_h[0] = g_dbg_h[1] = NULL;
+  free(probs); free(seeds);
+  return rc;
 }
