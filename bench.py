@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""bench.py — read x allele HMM alignments/sec (and STR loci/sec) on 1..8 MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over one resident batch of synthetic loci: the forward-HMM kernel
+(every pooled read x every candidate allele) followed by the diplotype-posterior kernel.  STR loci are
+independent, so ranks hold disjoint loci (different seeds), no collective touches the data path, and the
+run is weak-scaling: per-GPU work is fixed.  `value` = alignments of all ranks x K / max-over-ranks wall
+time of the K timed steps, with inputs already resident in HBM (host preparation + PCIe are reported
+separately under "host").
+
+Also printed in the same JSON line:
+  roofline      forward kernel: ALGORITHMIC bytes per launch (SURVEY.md §8d formula, computed from the batch)
+                / average launch duration measured with HIP events on the launch stream, vs the 8 TB/s HBM peak.
+                The kernel is a latency/issue-bound FP64 max-plus recurrence, so the fraction is ~1e-5 by
+                construction; "valu" reports the limiter that actually binds (DP cell updates vs FP64 VALU issue).
+  cpu_baseline  the compiled reference (oracle/_ref, kind "reference") or, if absent, the C oracle (kind
+                "port") timed single-threaded on this host on a bounded sample of the same workload; rank 0, N=1.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (loci, reads/locus, STR alleles, read length, flank length, STR bp, description)
+    "ns": (1000, 500, 32, 150, 60, 40, "north-star shape of BASELINE configs[1] (SURVEY §8d NS): 1000 STR loci x 500 pooled 150bp reads x 32 candidate alleles"),
+    "c1": (1, 50, 4, 150, 60, 40, "BASELINE configs[0]: 1 locus x 50 reads x 4 alleles"),
+    "c2": (1000, 40, 32, 150, 60, 40, "BASELINE configs[1] at literal 30x depth: 1000 loci x 40 reads x 32 alleles"),
+    "c5": (256, 200, 128, 250, 110, 100, "BASELINE configs[4] stress: 256 loci x 200 250bp reads x 128 alleles, ~100bp STR blocks"),
+}
+
+
+def cpu_baseline(capi, wl, budget_s=20.0):
+    """Single-thread CPU time of the same hot path on a bounded sample (a few loci of the same generator)."""
+    loci, P, A, L, F, sbp, _ = wl
+    if capi.have_ref():
+        lib, pfx, kind = capi.load_ref(), "ref_", "reference"
+    else:
+        lib, pfx, kind = capi.load_oracle(), "oracle_", "port"
+    n_loci = 1
+    total_aln, total_t = 0, 0.0
+    seed = 977
+    while total_t < budget_s * 0.5 and n_loci <= 64:
+        sb = capi.SynthBatch(n_loci=min(n_loci, loci), reads_per_locus=P, n_str_alleles=A, read_len=L, flank_len=F, str_bp=sbp, seed=seed)
+        probs = np.zeros(sb.n_out); seeds = np.zeros(sb.n_reads, np.int32)
+        t0 = time.perf_counter()
+        rc = getattr(lib, pfx + "process_reads")(sb.ptr, probs.ctypes.data_as(capi._f64p), seeds.ctypes.data_as(capi._i32p))
+        dt = time.perf_counter() - t0
+        assert rc == 0
+        total_aln += int((seeds >= 0).sum()) * (sb.n_out // sb.n_reads)
+        total_t += dt
+        if dt * 2 > budget_s:
+            break
+        n_loci *= 2; seed += 1
+    return {"value": total_aln / total_t, "unit": "alignments/s", "cores": 1, "kind": kind,
+            "sample": "%d alignments of the same generator/shape (%d reads x %d alleles x %dbp per locus), %.1f s, HapAligner::process_reads only"
+                      % (total_aln, P, A, L, total_t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
+    ap.add_argument("--loci", type=int, default=0, help="override the number of loci per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from hipstr_amd import capi
+    hmm = capi.load_hmm()
+    if hmm.hipstr_hmm_init(local) != 0:
+        raise SystemExit("hipstr_hmm_init: " + hmm.hipstr_last_error().decode())
+
+    wl = WORKLOADS[args.workload]
+    loci, P, A, L, F, sbp, desc = wl
+    if args.loci:
+        loci = args.loci
+    # --- synthetic batch of this rank (disjoint loci per rank: rank-specific seed), prepared and made resident
+    t0 = time.perf_counter()
+    sb = capi.SynthBatch(n_loci=loci, reads_per_locus=P, n_str_alleles=A, read_len=L, flank_len=F, str_bp=sbp, seed=20260928 + 1000 * rank)
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    dev = hmm.hipstr_hmm_upload(sb.ptr)
+    if not dev:
+        raise SystemExit("upload failed: " + hmm.hipstr_last_error().decode())
+    torch.cuda.synchronize()
+    t_upload = time.perf_counter() - t0
+    n_aln = C.c_int64(0); algo = C.c_int64(0); cells = C.c_int64(0)
+    hmm.hipstr_hmm_workload(dev, C.byref(n_aln), C.byref(algo), C.byref(cells))
+    # posteriors: one sample per locus (configs[1]: "1 sample"), every pooled read its own read, no SNP phasing information
+    hap_off = np.ctypeslib.as_array(sb.ptr.contents.hap_off, shape=(loci + 1,))
+    pb = capi.PostBatch(np.diff(hap_off), np.ones(loci, np.int32), np.arange(loci + 1, dtype=np.int32) * P, np.zeros(loci * P, np.int32),
+                        np.zeros(loci * P), np.zeros(loci * P), np.ones(loci * P, np.int32), None)
+    pd = hmm.hipstr_post_upload(pb.ptr, hmm.hipstr_hmm_dev_aln_probs(dev))
+    if not pd:
+        raise SystemExit("posterior upload failed: " + hmm.hipstr_last_error().decode())
+
+    def step():
+        if hmm.hipstr_hmm_align(dev, None) != 0 or hmm.hipstr_post_launch(pd, None) != 0:
+            raise SystemExit("launch failed: " + hmm.hipstr_last_error().decode())
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    hmm.hipstr_hmm_profile(dev, 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    hmm.hipstr_hmm_profile(dev, 0)
+    ms = (C.c_float * args.steps)()
+    n_ms = hmm.hipstr_hmm_profile_read(dev, ms, args.steps)
+    kernel_ms = float(np.mean(ms[:n_ms])) if n_ms > 0 else float("nan")
+
+    # --- a D2H of the results after the timed region (sanity + the PCIe-inclusive figure for DESIGN.md)
+    t0 = time.perf_counter()
+    probs = np.zeros(sb.n_out); seeds = np.zeros(sb.n_reads, np.int32)
+    assert hmm.hipstr_hmm_fetch(dev, probs.ctypes.data_as(capi._f64p), seeds.ctypes.data_as(capi._i32p)) == 0
+    t_fetch = time.perf_counter() - t0
+    assert np.all(np.isfinite(probs)) and np.all(probs <= 1e-10), "forward scores must be finite log-likelihoods <= 0"
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([float(n_aln.value), float(loci)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        total_aln, total_loci = float(cnt[0].item()), float(cnt[1].item())
+    else:
+        total_aln, total_loci = float(n_aln.value), float(loci)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_aln * args.steps / elapsed
+        achieved = algo.value / (kernel_ms * 1e-3) / 1e9 if kernel_ms == kernel_ms else None
+        fp64_ops_per_cell = 13.0           # 13 FP64 add/max per M/I/D cell triple (hmm_kernels.hip sweep)
+        valu_peak = 256 * 4 * 16 * 2.4e9   # FP64 VALU lanes/clk on 256 CUs x 4 SIMD x 16 lanes at 2.4 GHz (ops/s, add or max)
+        out = {
+            "metric": "read x allele HMM alignments/sec", "value": value, "unit": "alignments/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %s" % (args.workload, desc) if not args.loci else "%s with %d loci/GPU: %s" % (args.workload, loci, desc),
+                       "loci_per_gpu": loci, "reads_per_locus": P, "alleles_per_locus": A, "read_len": L,
+                       "alignments_per_step_per_gpu": n_aln.value, "sharding": "loci across ranks, no collective on the data path"},
+            "loci_per_sec": total_loci * args.steps / elapsed,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": (achieved / 8000.0) if achieved else None, "traffic": None,
+                         "kernel": "hs_forward_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo.value,
+                         "bytes_per_alignment": algo.value / max(1, n_aln.value)},
+            "valu": {"dp_cells_per_launch": cells.value, "cells_per_s": cells.value / (kernel_ms * 1e-3) if kernel_ms == kernel_ms else None,
+                     "fp64_ops_per_cell": fp64_ops_per_cell, "fp64_valu_peak_ops_per_s": valu_peak,
+                     "frac": (cells.value * fp64_ops_per_cell / (kernel_ms * 1e-3) / valu_peak) if kernel_ms == kernel_ms else None},
+            "host": {"synth_s": t_gen, "prepare_upload_s": t_upload, "fetch_s": t_fetch,
+                     "value_incl_prepare_pcie": total_aln / world / (t_upload + elapsed / args.steps + t_fetch) * world},
+        }
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(capi, wl)
+            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        print(json.dumps(out), flush=True)
+    hmm.hipstr_post_free(pd)
+    hmm.hipstr_hmm_free(dev)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

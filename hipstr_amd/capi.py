@@ -284,7 +284,13 @@ def load_hmm():
     _sig(lib.hipstr_calc_seed_bases, C.c_int, [_BP, _i32p])
     _sig(lib.hipstr_post_offsets, C.c_int, [_PBP, C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
     _sig(lib.hipstr_post_run, C.c_int, [_PBP, C.c_void_p, _f64p, _f64p, _i32p, _f64p])
-    _sig(lib.hipstr_post_run_timed, C.c_int, [_PBP, C.c_int, C.POINTER(C.c_float)])
+    _sig(lib.hipstr_post_upload, C.c_void_p, [_PBP, C.c_void_p])
+    _sig(lib.hipstr_post_launch, C.c_int, [C.c_void_p, C.c_void_p])
+    _sig(lib.hipstr_post_fetch, C.c_int, [C.c_void_p, _f64p, _f64p, _i32p, _f64p])
+    _sig(lib.hipstr_post_free, None, [C.c_void_p])
+    _sig(lib.hipstr_hmm_profile, C.c_int, [C.c_void_p, C.c_int])
+    _sig(lib.hipstr_hmm_profile_read, C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int])
+    _sig(lib.hipstr_hmm_workload, C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
     _sig(lib.hipstr_debug_rows, C.c_int, [_BP, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_int])
     _sig(lib.hipstr_last_error, C.c_char_p, [])
     return lib

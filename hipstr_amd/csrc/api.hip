@@ -67,6 +67,10 @@ struct hipstr_dev_batch {
   dim3 grid;
   size_t lds_bytes = 0;
   hipEvent_t ev0 = NULL, ev1 = NULL;
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t> > prof_pool;   // reusable event pairs
+  size_t prof_used = 0;
+  int64_t algo_bytes = 0, dp_cells = 0;
 };
 
 extern "C" {
@@ -127,6 +131,7 @@ void hipstr_hmm_free(hipstr_dev_batch_t* dev){
   for (void* p : dev->allocs) hipFree(p);
   if (dev->ev0) hipEventDestroy(dev->ev0);
   if (dev->ev1) hipEventDestroy(dev->ev1);
+  for (auto& pr : dev->prof_pool){ hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   delete dev;
 }
 
@@ -136,6 +141,27 @@ hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){
   std::string err;
   if (hipstr::prepare_batch(batch, dev->prep, err)){ g_err = err; delete dev; return NULL; }
   hipstr::Prepared& P = dev->prep;
+  {  // SURVEY.md §8(d) algorithmic traffic and flank-cell work of one pass
+    int64_t bytes = 0, cells = 0;
+    for (const hs_locus_t& loc : P.loci){
+      int64_t hap_bytes = 0, flank_rows = 0; int n_re = 0;
+      for (int k = 0; k < loc.n_alleles; k++){
+        const hs_allele_t& al = P.alleles[loc.hap_begin + k];
+        if (!al.realign) continue;
+        const int B = P.stropts[al.str_opt[0]].B;
+        hap_bytes += 2*(int64_t)(al.n_flank + B) + 8*13 + 2*6*(int64_t)B + 16;
+        flank_rows += al.n_flank; n_re++;
+      }
+      bytes += hap_bytes;
+      for (int i = 0; i < loc.n_reads; i++){
+        const hs_read_t& rd = P.reads[loc.read_begin + i];
+        if (!P.realign_read[loc.read_begin + i] || rd.seed < 0) continue;
+        bytes += 2*(int64_t)rd.len + 8 + 4 + 8*(int64_t)n_re;
+        cells += (int64_t)(rd.len - 1) * flank_rows;      // (n_L + n_R) x flank rows, leading flank counted per allele as the reference recomputes it without reuse
+      }
+    }
+    dev->algo_bytes = bytes; dev->dp_cells = cells;
+  }
   hs_dev_t& h = dev->h;
   memset(&h, 0, sizeof h);
 #define UP(field, vec, T) do { T* p_ = NULL; if (to_device(vec, &p_)){ hipstr_hmm_free(dev); return NULL; } dev->allocs.push_back(p_); h.field = p_; } while (0)
@@ -178,8 +204,44 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
   if (!dev) return fail("null device batch");
   if (dev->h.n_active == 0) return 0;
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_tab.stream;
+  std::pair<hipEvent_t, hipEvent_t>* pr = NULL;
+  if (dev->profiling){
+    if (dev->prof_used == dev->prof_pool.size()){
+      hipEvent_t a, b;
+      HS_HIP(hipEventCreate(&a)); HS_HIP(hipEventCreate(&b));
+      dev->prof_pool.push_back(std::make_pair(a, b));
+    }
+    pr = &dev->prof_pool[dev->prof_used++];
+    HS_HIP(hipEventRecord(pr->first, st));
+  }
   hipLaunchKernelGGL(hs_forward_kernel, dev->grid, dim3(128), dev->lds_bytes, st, (const hs_dev_t*)dev->d_args);
   HS_HIP(hipGetLastError());
+  if (pr) HS_HIP(hipEventRecord(pr->second, st));
+  return 0;
+}
+
+int hipstr_hmm_profile(hipstr_dev_batch_t* dev, int enable){
+  if (!dev) return fail("null device batch");
+  dev->profiling = enable != 0;
+  return 0;
+}
+
+int hipstr_hmm_profile_read(hipstr_dev_batch_t* dev, float* ms, int cap){
+  if (!dev || !ms) return -1;
+  int n = 0;
+  for (size_t i = 0; i < dev->prof_used && n < cap; i++, n++){
+    if (hipEventSynchronize(dev->prof_pool[i].second) != hipSuccess) return -1;
+    if (hipEventElapsedTime(&ms[n], dev->prof_pool[i].first, dev->prof_pool[i].second) != hipSuccess) return -1;
+  }
+  dev->prof_used = 0;
+  return n;
+}
+
+int hipstr_hmm_workload(hipstr_dev_batch_t* dev, int64_t* n_alignments, int64_t* algorithmic_bytes, int64_t* dp_cells){
+  if (!dev) return fail("null device batch");
+  if (n_alignments) *n_alignments = dev->prep.n_alignments;
+  if (algorithmic_bytes) *algorithmic_bytes = dev->algo_bytes;
+  if (dp_cells) *dp_cells = dev->dp_cells;
   return 0;
 }
 
@@ -318,45 +380,56 @@ int post_setup(const hipstr_post_batch_t* pb, const double* dev_ll, PostRun& R){
 }
 }  // namespace
 
-int hipstr_post_run(const hipstr_post_batch_t* pb, const double* dev_log_aln_probs,
-                    double* log_post, double* sample_total_ll, int32_t* map_gt, double* locus_total_ll){
-  if (!pb || !log_post || !sample_total_ll || !map_gt || !locus_total_ll) return fail("null argument");
-  if (ensure_init()) return 1;
-  PostRun R;
-  if (post_setup(pb, dev_log_aln_probs, R)) return 1;
+struct hipstr_post_dev { PostRun R; std::vector<int32_t> n_samples; };
+
+hipstr_post_dev_t* hipstr_post_upload(const hipstr_post_batch_t* pb, const double* dev_log_aln_probs){
+  if (!pb){ g_err = "null argument"; return NULL; }
+  if (ensure_init()) return NULL;
+  hipstr_post_dev_t* pd = new hipstr_post_dev_t();
+  if (post_setup(pb, dev_log_aln_probs, pd->R)){ delete pd; return NULL; }
+  pd->n_samples.assign(pb->n_samples, pb->n_samples + pb->n_loci);
+  return pd;
+}
+
+int hipstr_post_launch(hipstr_post_dev_t* pd, void* hip_stream){
+  if (!pd) return fail("null argument");
+  if (pd->R.units.empty()) return 0;
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_tab.stream;
+  hipLaunchKernelGGL(hs_posterior_kernel, dim3((unsigned)pd->R.units.size()), dim3(256), 0, st, (const hs_post_dev_t*)pd->R.d_args);
+  HS_HIP(hipGetLastError());
+  return 0;
+}
+
+int hipstr_post_fetch(hipstr_post_dev_t* pd, double* log_post, double* sample_total_ll, int32_t* map_gt, double* locus_total_ll){
+  if (!pd || !log_post || !sample_total_ll || !map_gt || !locus_total_ll) return fail("null argument");
+  PostRun& R = pd->R;
+  HS_HIP(hipDeviceSynchronize());
   if (!R.units.empty()){
-    hipLaunchKernelGGL(hs_posterior_kernel, dim3((unsigned)R.units.size()), dim3(256), 0, g_tab.stream, (const hs_post_dev_t*)R.d_args);
-    HS_HIP(hipGetLastError());
-    HS_HIP(hipStreamSynchronize(g_tab.stream));
     HS_HIP(hipMemcpy(log_post, R.h.log_post, sizeof(double)*R.n_post, hipMemcpyDeviceToHost));
     HS_HIP(hipMemcpy(sample_total_ll, R.h.sample_total, sizeof(double)*R.n_samp, hipMemcpyDeviceToHost));
     HS_HIP(hipMemcpy(map_gt, R.h.map_gt, sizeof(int32_t)*2*R.n_samp, hipMemcpyDeviceToHost));
   }
   int64_t so = 0;
-  for (int l = 0; l < pb->n_loci; l++){           // sum(sample_total_LLs_) (genotyper.cpp:75)
+  for (size_t l = 0; l < pd->n_samples.size(); l++){     // sum(sample_total_LLs_) in sample order (genotyper.cpp:75)
     double tot = 0.0;
-    for (int s = 0; s < pb->n_samples[l]; s++) tot += sample_total_ll[so+s];
+    for (int s = 0; s < pd->n_samples[l]; s++) tot += sample_total_ll[so+s];
     locus_total_ll[l] = tot;
-    so += pb->n_samples[l];
+    so += pd->n_samples[l];
   }
   return 0;
 }
 
-int hipstr_post_run_timed(const hipstr_post_batch_t* pb, int reps, float* ms_total){
-  if (!pb || reps < 1 || !ms_total) return fail("bad argument");
-  if (ensure_init()) return 1;
-  PostRun R;
-  if (post_setup(pb, NULL, R)) return 1;
-  hipEvent_t e0, e1;
-  HS_HIP(hipEventCreate(&e0)); HS_HIP(hipEventCreate(&e1));
-  HS_HIP(hipEventRecord(e0, g_tab.stream));
-  for (int i = 0; i < reps; i++)
-    hipLaunchKernelGGL(hs_posterior_kernel, dim3((unsigned)R.units.size()), dim3(256), 0, g_tab.stream, (const hs_post_dev_t*)R.d_args);
-  HS_HIP(hipEventRecord(e1, g_tab.stream));
-  HS_HIP(hipEventSynchronize(e1));
-  HS_HIP(hipEventElapsedTime(ms_total, e0, e1));
-  hipEventDestroy(e0); hipEventDestroy(e1);
-  return 0;
+void hipstr_post_free(hipstr_post_dev_t* pd){ delete pd; }
+
+int hipstr_post_run(const hipstr_post_batch_t* pb, const double* dev_log_aln_probs,
+                    double* log_post, double* sample_total_ll, int32_t* map_gt, double* locus_total_ll){
+  if (!pb || !log_post || !sample_total_ll || !map_gt || !locus_total_ll) return fail("null argument");
+  hipstr_post_dev_t* pd = hipstr_post_upload(pb, dev_log_aln_probs);
+  if (!pd) return 1;
+  int rc = hipstr_post_launch(pd, NULL);
+  if (!rc) rc = hipstr_post_fetch(pd, log_post, sample_total_ll, map_gt, locus_total_ll);
+  hipstr_post_free(pd);
+  return rc;
 }
 
 }  // extern "C"

@@ -113,6 +113,19 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream);
  * *ms_kernel (may be NULL) = time of the dominant DP kernel only. */
 int hipstr_hmm_align_timed(hipstr_dev_batch_t* dev, int reps, float* ms_total, float* ms_kernel);
 
+/* Per-launch timing of the forward kernel with HIP events recorded on the launch stream: after
+ * hipstr_hmm_profile(dev, 1) every hipstr_hmm_align call brackets its kernel with an event pair;
+ * hipstr_hmm_profile_read synchronises and returns up to `cap` launch durations (ms), oldest first,
+ * and clears the log.  Returns the number of durations written, or -1. */
+int hipstr_hmm_profile(hipstr_dev_batch_t* dev, int enable);
+int hipstr_hmm_profile_read(hipstr_dev_batch_t* dev, float* ms, int cap);
+
+/* Number of (read x allele) HMM alignments one hipstr_hmm_align pass computes (realigned reads with a
+ * seed x realigned alleles) and the ALGORITHMIC bytes of that pass (read bases+quals+len+seed,
+ * per-allele haplotype bytes + homopolymer bytes + stutter pmf + run tables + block table, 8 B per output
+ * log-likelihood, 4 B per seed). */
+int hipstr_hmm_workload(hipstr_dev_batch_t* dev, int64_t* n_alignments, int64_t* algorithmic_bytes, int64_t* dp_cells);
+
 /* Copies results back.  Entries whose read or allele was not realigned are left
  * untouched in the caller's buffers, as process_reads does (HapAligner.cpp:326-329,
  * 615-619); reads with seed -1 get 0 for every realigned allele (HapAligner.cpp:333-337). */
@@ -162,9 +175,13 @@ int hipstr_post_offsets(const hipstr_post_batch_t* pb, int64_t* post_off, int64_
 int hipstr_post_run(const hipstr_post_batch_t* pb, const double* dev_log_aln_probs,
                     double* log_post, double* sample_total_ll, int32_t* map_gt, double* locus_total_ll);
 
-/* Timed variant for bench.py: inputs uploaded once, kernel repeated `reps` times
- * between HIP events on the launch stream. */
-int hipstr_post_run_timed(const hipstr_post_batch_t* pb, int reps, float* ms_total);
+/* Resident form of the same computation (inputs uploaded once, kernel launched asynchronously on the
+ * library stream or `hip_stream`, results fetched on demand) — what bench.py times. */
+typedef struct hipstr_post_dev hipstr_post_dev_t;
+hipstr_post_dev_t* hipstr_post_upload(const hipstr_post_batch_t* pb, const double* dev_log_aln_probs);
+int  hipstr_post_launch(hipstr_post_dev_t* pd, void* hip_stream);
+int  hipstr_post_fetch(hipstr_post_dev_t* pd, double* log_post, double* sample_total_ll, int32_t* map_gt, double* locus_total_ll);
+void hipstr_post_free(hipstr_post_dev_t* pd);
 
 /* Diagnostics (host only, no device): the haplotype rows of allele k of a ONE-locus batch as the
  * device sweep consumes them — side 0 = forward/left problem, 1 = reversed/right problem; which 0 =
