@@ -9,6 +9,7 @@
 #include <cfloat>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -182,6 +183,7 @@ hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){
   h.log_thresh = T.log_thresh; h.log_half = T.log_half;
   h.n_active = (int32_t)P.active.size();
   h.lds_len = P.max_read_len; h.lds_flank = P.max_flank;
+  h.debug_skip = getenv("HIPSTR_DEBUG_SKIP") ? atoi(getenv("HIPSTR_DEBUG_SKIP")) : 0;
   // Workgroups: one per active read, times enough allele chunks to put >= ~4096 workgroups on the 256 CUs
   int maxA = 1;
   for (const hs_locus_t& l : P.loci) maxA = l.n_alleles > maxA ? l.n_alleles : maxA;

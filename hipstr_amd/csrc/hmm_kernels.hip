@@ -119,7 +119,7 @@ template <int C>
 __device__ __forceinline__ void sweep(const hs_dev_t& d, const hs_row_t* __restrict__ rows, int nrows, const Side& s,
                                       const uint8_t (&rd)[C], const double (&blc)[C], const double (&blw)[C],
                                       double (&Mrow)[C], double (&Drow)[C], double* lastcol, double tab_m2m, double tab_m2i){
-  if (nrows <= 0) return;
+  if (nrows <= 0 || (d.debug_skip & 2)) return;
   const int lane = threadIdx.x & 63;
   const int nl = (s.n + C - 1) / C, lastlane = (s.n - 1) / C, klast = (s.n - 1) % C;
   const int steps = nrows + nl - 1;
@@ -167,20 +167,22 @@ struct StrCtx {
   int blkv;          // lane x holds block chars 4x..4x+3
   double cst;        // lane t<20 holds f64pool[f64_off+t]: pmf[13] | prior_ins | prior_del[6]
   const hs_visit_t* visits;
-  hs_stropt_t so;
+  const hs_stropt_t* so;
 };
 __device__ __forceinline__ uint8_t blk_at(const StrCtx& c, int x){    // x wave-uniform
   return (uint8_t)(((uint32_t)rdlane(c.blkv, x >> 2) >> ((x & 3)*8)) & 0xff);
 }
 
-// artifact-position marginalisation for an insertion of D=(q+1)*p bases (StutterAlignerClass.cpp:59-104)
-__device__ __forceinline__ double stutter_ins(const hs_dev_t& d, const Lds& L, const Side& s, const StrCtx& c, int q, int j, bool actj, double in_q){
+// Marginalisation over the artifact position (StutterAlignerClass.cpp:59-104 insertion, :106-150 deletion).
+// The loop over block offsets is the same for every read column, so the host enumerated it (hs_visit_t) and
+// the wave replays it in lock step; a lane drops out once the offset reaches its own bound `lim`.
+//   lp0     value for the artifact at the block's right end (position 0)
+//   nsub    read bases whose emission changes when the artifact moves one base left: D/p for an insertion, 1 for a deletion
+//   stride  distance between those bases: p for an insertion, 0 for a deletion
+//   tail    number of remaining equal-likelihood configurations is (tail - offset): B (insertion) or B+D (deletion)
+__device__ __forceinline__ double visit_eval(const hs_dev_t& d, const Lds& L, int o, int j, double lp0, int lim, int limmax,
+                                             const hs_visit_t* __restrict__ list, int llen, int nsub, int stride, int tail){
   const int lane = threadIdx.x & 63;
-  const int B = c.B, p = c.p, D = (q+1)*p, o = s.o;
-  const int len = min(B + D, j + 1);
-  const double lp0 = (rdlane(c.cst, 13) + in_q) + ((len > D) ? L.Mt[o + j - D] : 0.0);
-  const int lim = actj ? min(max(0, len - D), B) : 0;
-  const int limmax = uni(wave_max_i(lim));
   Lse acc;
   for (int pass = 0; pass < 2; pass++){
     double lp = lp0;
@@ -188,9 +190,9 @@ __device__ __forceinline__ double stutter_ins(const hs_dev_t& d, const Lds& L, c
     acc.push(pass, lp0, d.log_thresh);
     int nistop = 0; bool stopped = false;
     int vbase = 0;
-    hs_visit_t vv = c.visits[c.so.ins_off + min(lane, c.so.ins_len-1)];
-    for (int v = 0; v < c.so.ins_len; v++){
-      if (v - vbase == 64){ vbase += 64; vv = c.visits[c.so.ins_off + min(vbase + lane, c.so.ins_len-1)]; }
+    hs_visit_t vv = list[min(lane, llen-1)];
+    for (int v = 0; v < llen; v++){
+      if (v - vbase == 64){ vbase += 64; vv = list[min(vbase + lane, llen-1)]; }
       const uint64_t meta = rdlane(vv.meta, v - vbase);
       const int ni = (int)(meta & 0xffff);
       if (ni >= limmax){ if (!stopped) nistop = ni; break; }
@@ -200,8 +202,8 @@ __device__ __forceinline__ double stutter_ins(const hs_dev_t& d, const Lds& L, c
       if ((meta >> 48) & 1){ if (act) acc.push(pass, lp, d.log_thresh); }
       else if (U == 0){
         const uint8_t ca = (uint8_t)(meta >> 32), cb = (uint8_t)(meta >> 40);
-        for (int m = 1; m <= q+1; m++){
-          const int pos = o + max(j - ni - m*p, 0);
+        for (int m = 1; m <= nsub; m++){
+          const int pos = o + max(j - ni - m*stride, 0);
           const uint8_t r = L.rd[pos]; const double2 bq = L.bq[pos];
           if (act){ lp -= emit(r, ca, bq); lp += emit(r, cb, bq); }
         }
@@ -211,58 +213,7 @@ __device__ __forceinline__ double stutter_ins(const hs_dev_t& d, const Lds& L, c
         if (act) acc.push(pass, logU + lp, d.log_thresh);
       }
     }
-    if (nistop < B) acc.push(pass, d.int_log[B - nistop] + lp, d.log_thresh);
-  }
-  return acc.finish();
-}
-
-// deletion of |D|=(q+1)*p bases (StutterAlignerClass.cpp:106-150); caller guarantees B+D >= 0
-__device__ __forceinline__ double stutter_del(const hs_dev_t& d, const Lds& L, const Side& s, const StrCtx& c, int q, int j, bool actj){
-  const int lane = threadIdx.x & 63;
-  const int B = c.B, p = c.p, aD = (q+1)*p, o = s.o;
-  const int len = min(B - aD, j + 1);
-  double lp0 = rdlane(c.cst, 14 + q);
-  const bool direct = (j + aD <= s.n - 1);
-  if (direct) lp0 += L.Mt[o + j + aD] - L.Dl[q*L.Lc + o + j + aD];
-  if (__any(!direct)){
-    const int tmax = min(B - aD, s.n);
-    for (int t = 0; t < tmax; t++){
-      const uint8_t bc = blk_at(c, B-1-t-aD);
-      const int pos = o + max(j - t, 0);
-      const double e = emit(L.rd[pos], bc, L.bq[pos]);
-      if (!direct && t < len) lp0 += e;
-    }
-  }
-  const int lim = actj ? len : 0;
-  const int limmax = uni(wave_max_i(lim));
-  const int loff = c.so.del_off[q], llen = c.so.del_len[q];
-  Lse acc;
-  for (int pass = 0; pass < 2; pass++){
-    double lp = lp0;
-    acc.start(pass, lp0);
-    acc.push(pass, lp0, d.log_thresh);
-    int nistop = 0; bool stopped = false;
-    int vbase = 0;
-    hs_visit_t vv = c.visits[loff + min(lane, llen-1)];
-    for (int v = 0; v < llen; v++){
-      if (v - vbase == 64){ vbase += 64; vv = c.visits[loff + min(vbase + lane, llen-1)]; }
-      const uint64_t meta = rdlane(vv.meta, v - vbase);
-      const int ni = (int)(meta & 0xffff);
-      if (ni >= limmax){ if (!stopped) nistop = ni; break; }
-      const bool act = ni < lim;
-      if (!act && !stopped){ nistop = ni; stopped = true; }
-      const int U = (int)((meta >> 16) & 0xffff);
-      if (U == 0){
-        const uint8_t ca = (uint8_t)(meta >> 32), cb = (uint8_t)(meta >> 40);
-        const int pos = o + max(j - ni, 0);
-        const uint8_t r = L.rd[pos]; const double2 bq = L.bq[pos];
-        if (act){ lp -= emit(r, ca, bq); lp += emit(r, cb, bq); acc.push(pass, lp, d.log_thresh); }
-      } else {
-        const double logU = rdlane(vv.logU, v - vbase);
-        if (act) acc.push(pass, logU + lp, d.log_thresh);
-      }
-    }
-    if (nistop < B - aD) acc.push(pass, d.int_log[B - aD - nistop] + lp, d.log_thresh);
+    if (nistop < tail) acc.push(pass, d.int_log[tail - nistop] + lp, d.log_thresh);
   }
   return acc.finish();
 }
@@ -271,13 +222,15 @@ __device__ __forceinline__ double stutter_del(const hs_dev_t& d, const Lds& L, c
 __device__ __forceinline__ void phase_str(const hs_dev_t& d, const Lds& L, const Side& s, int str_opt, int flead){
   const int lane = threadIdx.x & 63;
   StrCtx c;
-  c.so = d.stropts[str_opt];
-  c.B = c.so.B; c.p = c.so.period; c.nd = c.so.nd;
+  c.so = d.stropts + str_opt;
+  c.B = uni(c.so->B); c.p = uni(c.so->period); c.nd = uni(c.so->nd);
   c.visits = d.visits;
-  c.blkv = ((const int*)(d.chars + c.so.seq_off))[min(lane, (c.B + 3)/4 - 1)];
-  c.cst = d.f64pool[c.so.f64_off + min(lane, 19)];
+  c.blkv = ((const int*)(d.chars + uni(c.so->seq_off)))[min(lane, (c.B + 3)/4 - 1)];
+  c.cst = d.f64pool[uni(c.so->f64_off) + min(lane, 19)];
   const int B = c.B, p = c.p, n = s.n, o = s.o;
   const int ncyc = (n + 63) / 64;
+  const hs_visit_t* ins_list = d.visits + uni(c.so->ins_off);
+  const int ins_len = uni(c.so->ins_len);
 
   // --- StutterAlignerClass::load_read (StutterAlignerClass.cpp:12-53): match_probs_ and del_probs_
   for (int kk = 0; kk < ncyc; kk++){
@@ -302,45 +255,61 @@ __device__ __forceinline__ void phase_str(const hs_dev_t& d, const Lds& L, const
     const int jraw = lane + 64*kk;
     const bool actj = jraw < n;
     const int j = min(jraw, n-1);
-    // ins_probs_ of this column (StutterAlignerClass.cpp:40-51)
-    double in_q[HS_MAXREP];
-    {
-      double li = 0.0;
+    const int jmax = min(n-1, 64*kk + 63);        // largest column of this chunk: bounds are monotone in j
+    // The 13 artifact terms are produced by ONE runtime loop (no artifact, insertions +p..+6p, deletions -p..-6p) and kept
+    // in a rotating register window; fast_log_sum_exp (mathops.cpp:97-106) does not depend on their order.
+    double terms[HS_NART];
 #pragma unroll
-      for (int q = 0; q < HS_MAXREP; q++){
-        for (int m = 0; m < p; m++){
+    for (int t = 0; t < HS_NART; t++) terms[t] = IMP;
+    double li = 0.0;                               // running ins_probs_ sum (StutterAlignerClass.cpp:40-51)
+    for (int it = 0; it < HS_NART; it++){
+      double term = IMP;
+      if (it == 0){                                // no artifact (StutterAlignerClass.cpp:55-57)
+        const int len = min(B, j + 1);
+        const double pre = (j - len < 0) ? 0.0 : L.rowP[o + j - len];
+        term = (rdlane(c.cst, HS_MAXREP) + L.Mt[o + j]) + pre;
+      } else if (it <= HS_MAXREP){                 // insertion of D = (q+1) p
+        const int q = it - 1, D = (q+1)*p;
+        for (int m = 0; m < p; m++){               // extend the insertion table by one repeat unit
           const int t = q*p + m;
           const int pos = o + max(j - t, 0);
           const double2 bq = L.bq[pos];
           const double e = (m < B) ? emit(L.rd[pos], blk_at(c, B-1-m), bq) : bq.x;
           if (t <= j) li += e;
         }
-        in_q[q] = li;
-      }
-    }
-    double terms[HS_NART];
-    {   // no artifact (StutterAlignerClass.cpp:55-57)
-      const int len = min(B, j + 1);
-      const double pre = (j - len < 0) ? 0.0 : L.rowP[o + j - len];
-      terms[HS_MAXREP] = (rdlane(c.cst, HS_MAXREP) + L.Mt[o + j]) + pre;
-    }
-#pragma unroll
-    for (int q = 0; q < HS_MAXREP; q++){
-      const int D = (q+1)*p;
-      const int len = min(B + D, j + 1);
-      const double S = stutter_ins(d, L, s, c, q, j, actj, in_q[q]);
-      const double pre = (j - len < 0) ? 0.0 : L.rowP[o + j - len];
-      terms[HS_MAXREP + 1 + q] = (rdlane(c.cst, HS_MAXREP + 1 + q) + S) + pre;
-    }
-#pragma unroll
-    for (int q = 0; q < HS_MAXREP; q++){
-      const int aD = (q+1)*p;
-      if (B - aD >= 0){
-        const int len = min(B - aD, j + 1);
-        const double S = stutter_del(d, L, s, c, q, j, actj);
+        const int len = min(B + D, j + 1);
+        const double lp0 = (rdlane(c.cst, 13) + li) + ((len > D) ? L.Mt[o + max(j - D, 0)] : 0.0);
+        const int lim = actj ? min(max(0, len - D), B) : 0;
+        const int limmax = min(max(0, min(B + D, jmax + 1) - D), B);
+        const double S = visit_eval(d, L, o, j, lp0, lim, limmax, ins_list, ins_len, q+1, p, B);
         const double pre = (j - len < 0) ? 0.0 : L.rowP[o + j - len];
-        terms[HS_MAXREP - 1 - q] = (rdlane(c.cst, HS_MAXREP - 1 - q) + S) + pre;
-      } else terms[HS_MAXREP - 1 - q] = IMP;
+        term = (rdlane(c.cst, HS_MAXREP + 1 + q) + S) + pre;
+      } else {                                     // deletion of aD = (q+1) p bases
+        const int q = it - 1 - HS_MAXREP, aD = (q+1)*p;
+        if (B - aD >= 0){
+          const int len = min(B - aD, j + 1);
+          double lp0 = rdlane(c.cst, 14 + q);
+          const bool direct = (j + aD <= n - 1);
+          if (direct) lp0 += L.Mt[o + j + aD] - L.Dl[q*L.Lc + o + j + aD];
+          if (jmax + aD > n - 1){                  // some column of the chunk ends within aD of the read end
+            const int tmax = min(B - aD, n);
+            for (int t = 0; t < tmax; t++){
+              const uint8_t bc = blk_at(c, B-1-t-aD);
+              const int pos = o + max(j - t, 0);
+              const double e = emit(L.rd[pos], bc, L.bq[pos]);
+              if (!direct && t < len) lp0 += e;
+            }
+          }
+          const int lim = actj ? len : 0;
+          const int limmax = min(B - aD, jmax + 1);
+          const double S = visit_eval(d, L, o, j, lp0, lim, limmax, d.visits + uni(c.so->del_off[q]), uni(c.so->del_len[q]), 1, 0, B - aD);
+          const double pre = (j - len < 0) ? 0.0 : L.rowP[o + j - len];
+          term = (rdlane(c.cst, HS_MAXREP - 1 - q) + S) + pre;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t + 1 < HS_NART; t++) terms[t] = terms[t+1];
+      terms[HS_NART-1] = term;
     }
     Lse acc;
     for (int pass = 0; pass < 2; pass++){
@@ -360,7 +329,7 @@ __device__ __forceinline__ void phase_str(const hs_dev_t& d, const Lds& L, const
 // One flank block of one side: is_lead selects phase A (row 0 + leading flank, result cached in
 // LDS across alleles) or phase C (trailing flank of the current allele).
 template <int C>
-__device__ __forceinline__ void run_flank(const hs_dev_t& d, const Lds& L, const Side& s, const hs_allele_t& al, bool is_lead,
+__device__ __forceinline__ void run_flank(const hs_dev_t& d, const Lds& L, const Side& s, int rowset_id, bool is_lead,
                                           double tab_m2m, double tab_m2i){
   const int lane = threadIdx.x & 63;
   uint8_t rd[C]; double blc[C], blw[C];
@@ -371,7 +340,8 @@ __device__ __forceinline__ void run_flank(const hs_dev_t& d, const Lds& L, const
     const double2 q = L.bq[s.o + j];
     blc[k] = q.x; blw[k] = q.y;
   }
-  const hs_rowset_t rs = d.rowsets[is_lead ? al.lead_rows[s.side] : al.trail_rows[s.side]];
+  hs_rowset_t rs;
+  rs.off = uni(d.rowsets[rowset_id].off); rs.len = uni(d.rowsets[rowset_id].len);
   const hs_row_t* rows = d.rows + rs.off;
   const uint32_t r0 = rows[0];
   const uint8_t c0 = (uint8_t)(r0 & 0xff);
@@ -472,25 +442,27 @@ hs_forward_kernel(const hs_dev_t* __restrict__ dp){
   double* out = d.aln_probs + loc.out_off + (int64_t)(r - loc.read_begin)*loc.n_alleles;
   int cur_lead = -1;
   for (int k = k0; k < k1; k++){
-    const hs_allele_t al = d.alleles[loc.hap_begin + k];
-    if (!al.realign) continue;
-    const bool run_lead = al.lead_rows[w] != cur_lead;
-    cur_lead = al.lead_rows[w];
+    const hs_allele_t* alp = d.alleles + loc.hap_begin + k;
+    if (!uni(alp->realign)) continue;
+    const int lead_id = uni(alp->lead_rows[w]), trail_id = uni(alp->trail_rows[w]), str_id = uni(alp->str_opt[w]);
+    const bool run_lead = lead_id != cur_lead;
+    cur_lead = lead_id;
     for (int ph = run_lead ? 0 : 1; ph < 2; ph++){
-      if (ph == 1) phase_str(d, L, s, al.str_opt[w], d.rowsets[al.lead_rows[w]].len);
+      if (ph == 1 && !(d.debug_skip & 1)) phase_str(d, L, s, str_id, uni(d.rowsets[lead_id].len));
+      const int rsid = ph == 0 ? lead_id : trail_id;
       switch (C){
-        case 1:  run_flank<1>(d, L, s, al, ph == 0, tab_m2m, tab_m2i); break;
-        case 2:  run_flank<2>(d, L, s, al, ph == 0, tab_m2m, tab_m2i); break;
-        case 3:  run_flank<3>(d, L, s, al, ph == 0, tab_m2m, tab_m2i); break;
-        default: run_flank<4>(d, L, s, al, ph == 0, tab_m2m, tab_m2i); break;
+        case 1:  run_flank<1>(d, L, s, rsid, ph == 0, tab_m2m, tab_m2i); break;
+        case 2:  run_flank<2>(d, L, s, rsid, ph == 0, tab_m2m, tab_m2i); break;
+        case 3:  run_flank<3>(d, L, s, rsid, ph == 0, tab_m2m, tab_m2i); break;
+        default: run_flank<4>(d, L, s, rsid, ph == 0, tab_m2m, tab_m2i); break;
       }
     }
     __syncthreads();
-    if (w == 0){
+    if (w == 0 && !(d.debug_skip & 4)){
       // compute_aln_logprob (HapAligner.cpp:163-231): log-sum-exp over the haplotype positions the seed base can sit on
-      const int N = al.n_flank;
-      const hs_rowset_t lead = d.rowsets[al.lead_rows[0]], trail = d.rowsets[al.trail_rows[0]];
-      const int F0 = lead.len;
+      const int N = uni(alp->n_flank);
+      const hs_rowset_t lead = d.rowsets[alp->lead_rows[0]], trail = d.rowsets[alp->trail_rows[0]];
+      const int F0 = uni(lead.len);
       const double prior = -d.int_log[N];
       const double* lcL = L.lastcol; const double* lcR = L.lastcol + (L.nflank+1);
       Lse acc;

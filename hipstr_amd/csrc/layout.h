@@ -102,4 +102,5 @@ struct hs_dev_t {
   int32_t            allele_chunk;   // alleles per workgroup
   int32_t            lds_len;        // max read length in the batch (LDS carve)
   int32_t            lds_flank;      // max n_flank + 1
+  int32_t            debug_skip;     // timing experiments only (HIPSTR_DEBUG_SKIP): 1 = skip STR phase, 2 = skip flank sweeps, 4 = skip combine
 };
