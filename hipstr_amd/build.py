@@ -33,7 +33,8 @@ def build_hmm(force=False):
     deps = [os.path.join(CSRC, s) for s in HIP_SOURCES + HIP_HEADERS]
     if force or _stale(out, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        _run([hipcc] + HIPCC_FLAGS + ["-o", out] + [os.path.join(CSRC, s) for s in HIP_SOURCES])
+        extra = ["-DHS_MIN_WAVES=" + os.environ["HIPSTR_MIN_WAVES"]] if os.environ.get("HIPSTR_MIN_WAVES") else []
+        _run([hipcc] + HIPCC_FLAGS + extra + ["-o", out] + [os.path.join(CSRC, s) for s in HIP_SOURCES])
     return out
 
 

@@ -405,7 +405,10 @@ extern "C" size_t hs_forward_lds_bytes(int lds_len, int lds_flank){
   return Lc*16 + Lc*8*3 + Lc*8*HS_MAXREP + 2*((size_t)lds_flank+1)*8 + 4*8 + ((Lc + 15) & ~(size_t)15);
 }
 
-extern "C" __global__ void __launch_bounds__(128)
+#ifndef HS_MIN_WAVES
+#define HS_MIN_WAVES 5   // waves per SIMD the register allocator must leave room for (measured best: profiles/r01_notes.md)
+#endif
+extern "C" __global__ void __launch_bounds__(128, HS_MIN_WAVES)
 hs_forward_kernel(const hs_dev_t* __restrict__ dp){
   const hs_dev_t& d = *dp;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -1,0 +1,353 @@
+// hipstr_hmm.hpp — C++ host API above the C-ABI (include/hipstr_hmm.h), header-only.
+//
+// Mirrors, for the hot path only, the classes a HipSTR caller touches — same names, same
+// constructor/argument meaning, same ownership and error behaviour — so code written against
+// the reference's SeqAlignment/HapAligner + Genotyper interfaces reads the same here:
+//
+//   reference (HipSTR v0.7)                               here (namespace hipstr_amd)
+//   ----------------------------------------------------- -----------------------------------------
+//   StutterModel(ig, iu, id, og, ou, od, motif)           StutterModel                (stutter_model.h:31)
+//   BaseQuality::median_base_qualities                    BaseQuality                 (base_quality.cpp:11-28)
+//   CigarElement / Alignment                              CigarElement / Alignment    (AlignmentData.h:12-137)
+//   HapBlock(start,end,ref) / add_alternate               HapBlock                    (HapBlock.h:43-70)
+//   RepeatBlock(start,end,ref,period,stutter_model)       RepeatBlock                 (RepeatBlock.h:28-43)
+//   Haplotype(std::vector<HapBlock*>&) / num_combs        Haplotype                   (Haplotype.h:33-52)
+//   ReadPooler::add_alignment / pool / get_alignments     ReadPooler                  (read_pooler.h:13-53)
+//   HapAligner(Haplotype*, std::vector<bool>&)            HapAligner                  (HapAligner.h:56)
+//     ::calc_seed_base / ::process_reads                                              (HapAligner.h:81-87)
+//   Genotyper::calc_log_sample_posteriors /               Genotyper                   (genotyper.h:72-79)
+//     ::get_optimal_haplotypes
+//   SeqStutterGenotyper::calc_hap_aln_probs               calc_hap_aln_probs()        (seq_stutter_genotyper.cpp:519-568)
+//
+// All arithmetic of the path happens on the MI355X behind hipstr_hmm_process_reads /
+// hipstr_post_run; these classes only hold and flatten data.  Fatal conditions follow the
+// reference's convention: message on stderr, exit(1) (error.cpp:5-9).
+#ifndef HIPSTR_HMM_HPP_
+#define HIPSTR_HMM_HPP_
+
+#include <algorithm>
+#include <cassert>
+#include <cstdint>
+#include <cstdlib>
+#include <iostream>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "hipstr_hmm.h"
+
+namespace hipstr_amd {
+
+inline void printErrorAndDie(const std::string& message){
+  std::cerr << "ERROR: " << message << "\n" << "Exiting..." << std::endl;
+  exit(1);
+}
+
+class StutterModel {
+  double p_[6]; int motif_len_;
+ public:
+  StutterModel(double inframe_geom, double inframe_up, double inframe_down,
+               double outframe_geom, double outframe_up, double outframe_down, int motif_len){
+    assert(inframe_geom > 0.0 && inframe_geom < 1.0 && outframe_geom > 0.0 && outframe_geom < 1.0);
+    assert(inframe_up + inframe_down + outframe_up + outframe_down < 1.0 && motif_len > 0 && motif_len < 10);
+    p_[0] = inframe_geom; p_[1] = inframe_up; p_[2] = inframe_down; p_[3] = outframe_geom; p_[4] = outframe_up; p_[5] = outframe_down;
+    motif_len_ = motif_len;
+  }
+  StutterModel* copy() const { return new StutterModel(*this); }
+  int period() const { return motif_len_; }
+  const double* parameters() const { return p_; }
+};
+
+class BaseQuality {
+ public:
+  static const char MIN_BASE_QUALITY = '!';
+  static const char MAX_BASE_QUALITY = 'J';
+  // upper median per position over the reads of a pool (base_quality.cpp:11-28)
+  std::string median_base_qualities(const std::vector<const std::string*>& qualities) const {
+    assert(!qualities.empty());
+    for (size_t i = 0; i < qualities.size(); i++)
+      if (qualities[i]->size() != qualities[0]->size())
+        printErrorAndDie("All base quality strings must be of the same length when averaging probabilities");
+    std::string med(qualities[0]->size(), 'N');
+    std::vector<char> col(qualities.size());
+    for (size_t i = 0; i < med.size(); i++){
+      for (size_t j = 0; j < qualities.size(); j++) col[j] = (*qualities[j])[i];
+      std::sort(col.begin(), col.end());
+      med[i] = col[col.size()/2];
+    }
+    return med;
+  }
+};
+
+class CigarElement {
+  char type_; int num_;
+ public:
+  CigarElement(char type, int num) : type_(type), num_(num) {}
+  char get_type() const { return type_; }
+  int  get_num()  const { return num_;  }
+};
+
+class Alignment {
+  int32_t start_, stop_;
+  std::vector<CigarElement> cigar_list_;
+  std::string name_, base_qualities_, sequence_, alignment_;
+  bool rev_strand_;
+ public:
+  Alignment(int32_t start, int32_t stop, bool rev_strand, const std::string& name, const std::string& base_qualities,
+            const std::string& sequence, const std::string& alignment)
+    : start_(start), stop_(stop), name_(name), base_qualities_(base_qualities), sequence_(sequence), alignment_(alignment), rev_strand_(rev_strand) {}
+  const std::string& get_name() const { return name_; }
+  int32_t get_start() const { return start_; }
+  int32_t get_stop()  const { return stop_;  }
+  bool is_from_reverse_strand() const { return rev_strand_; }
+  void add_cigar_element(CigarElement e){ cigar_list_.push_back(e); }
+  void set_cigar_list(const std::vector<CigarElement>& l){ cigar_list_ = l; }
+  void set_base_qualities(const std::string& q){ base_qualities_ = q; }
+  const std::string& get_base_qualities() const { return base_qualities_; }
+  const std::string& get_sequence()       const { return sequence_; }
+  const std::string& get_alignment()      const { return alignment_; }
+  const std::vector<CigarElement>& get_cigar_list() const { return cigar_list_; }
+};
+
+class HapBlock {
+ protected:
+  std::string ref_seq_;
+  std::vector<std::string> alt_seqs_;
+  int32_t start_, end_;
+ public:
+  HapBlock(int32_t start, int32_t end, const std::string& ref_seq) : ref_seq_(ref_seq), start_(start), end_(end) {}
+  virtual ~HapBlock() {}
+  virtual const StutterModel* get_stutter_model() const { return NULL; }   // non-NULL <=> the reference's get_repeat_info() != NULL
+  virtual int get_period() const { return 0; }
+  int32_t start() const { return start_; }
+  int32_t end()   const { return end_;   }
+  int num_options() const { return 1 + (int)alt_seqs_.size(); }
+  virtual void add_alternate(const std::string& alt){ alt_seqs_.push_back(alt); }
+  const std::string& get_seq(unsigned int index) const { return index == 0 ? ref_seq_ : alt_seqs_.at(index-1); }
+};
+
+class RepeatBlock : public HapBlock {
+  int period_; StutterModel* model_;
+ public:
+  RepeatBlock(int32_t start, int32_t end, const std::string& ref_seq, int period, const StutterModel* stutter_model)
+    : HapBlock(start, end, ref_seq), period_(period), model_(stutter_model->copy()) { assert(period > 0); }
+  ~RepeatBlock(){ delete model_; }
+  const StutterModel* get_stutter_model() const { return model_; }
+  int get_period() const { return period_; }
+};
+
+// Candidate-haplotype container.  Borrowed blocks, as in the reference (Haplotype.h:33-40); allele k means the k-th
+// haplotype in the visit order of the reference's Haplotype::next() (the device uses the same order).
+class Haplotype {
+  std::vector<HapBlock*> blocks_;
+  int ncombs_;
+ public:
+  explicit Haplotype(std::vector<HapBlock*>& blocks) : blocks_(blocks), ncombs_(1) {
+    if (blocks_.size() != HIPSTR_NUM_BLOCKS) printErrorAndDie("Haplotype must consist of [flank, repeat, flank] blocks");   // Haplotype.cpp:12
+    if (blocks_[0]->get_stutter_model() != NULL || blocks_[1]->get_stutter_model() == NULL || blocks_[2]->get_stutter_model() != NULL)
+      printErrorAndDie("Haplotype must consist of [flank, repeat, flank] blocks");
+    for (size_t i = 0; i < blocks_.size(); i++) ncombs_ *= blocks_[i]->num_options();
+  }
+  int num_blocks() const { return (int)blocks_.size(); }
+  int num_combs()  const { return ncombs_; }
+  HapBlock* get_block(int i)   const { return blocks_[i]; }
+  HapBlock* get_first_block()  const { return blocks_.front(); }
+  HapBlock* get_last_block()   const { return blocks_.back();  }
+};
+
+class ReadPooler {
+  std::vector<Alignment> pooled_alns_;
+  std::vector< std::vector<std::string> > qualities_by_pool_;
+  std::map<std::string, int32_t> seq_to_pool_;
+  bool pooled_; int32_t pool_index_;
+ public:
+  ReadPooler() : pooled_(false), pool_index_(0) {}
+  int32_t num_pools() const { return pool_index_; }
+  int32_t add_alignment(Alignment& aln){                         // read_pooler.cpp:3-20
+    if (pooled_) printErrorAndDie("Cannot call add_alignment function once pool() function has been invoked");
+    std::map<std::string, int32_t>::iterator it = seq_to_pool_.find(aln.get_sequence());
+    if (it == seq_to_pool_.end()){
+      seq_to_pool_[aln.get_sequence()] = pool_index_;
+      pooled_alns_.push_back(Alignment(aln.get_start(), aln.get_stop(), false, "READPOOL", "", aln.get_sequence(), aln.get_alignment()));
+      pooled_alns_.back().set_cigar_list(aln.get_cigar_list());
+      qualities_by_pool_.push_back(std::vector<std::string>(1, aln.get_base_qualities()));
+      return pool_index_++;
+    }
+    qualities_by_pool_[it->second].push_back(aln.get_base_qualities());
+    return it->second;
+  }
+  void pool(const BaseQuality& base_quality){                    // read_pooler.h:42-48
+    for (size_t i = 0; i < pooled_alns_.size(); i++){
+      std::vector<const std::string*> ptrs;
+      for (size_t j = 0; j < qualities_by_pool_[i].size(); j++) ptrs.push_back(&qualities_by_pool_[i][j]);
+      pooled_alns_[i].set_base_qualities(base_quality.median_base_qualities(ptrs));
+    }
+    pooled_ = true;
+  }
+  std::vector<Alignment>& get_alignments(){ return pooled_alns_; }
+};
+
+// Flat one-locus batch built from the classes above (what the C-ABI consumes).
+struct FlatLocus {
+  std::vector<int32_t> blk_start, blk_end, blk_nopts, opt_off, hap_off, read_off, base_off, read_start, cigar_off, cigar_len;
+  std::vector<double> stutter;
+  std::vector<uint8_t> realign_hap, realign_read;
+  std::string seq, bases, quals, cigar_op;
+  int32_t period;
+  hipstr_batch_t batch;
+  void set_haplotype(const Haplotype* h, const std::vector<bool>& realign_to_hap){
+    opt_off.assign(1, 0); hap_off.assign(1, 0);
+    for (int i = 0; i < h->num_blocks(); i++){
+      const HapBlock* b = h->get_block(i);
+      blk_start.push_back(b->start()); blk_end.push_back(b->end()); blk_nopts.push_back(b->num_options());
+      for (int o = 0; o < b->num_options(); o++){ seq += b->get_seq(o); opt_off.push_back((int32_t)seq.size()); }
+    }
+    const HapBlock* rb = h->get_block(1);
+    period = rb->get_period();
+    stutter.assign(rb->get_stutter_model()->parameters(), rb->get_stutter_model()->parameters() + 6);
+    hap_off.push_back(h->num_combs());
+    realign_hap.resize(realign_to_hap.size());
+    for (size_t k = 0; k < realign_to_hap.size(); k++) realign_hap[k] = realign_to_hap[k] ? 1 : 0;
+  }
+  void set_reads(const std::vector<Alignment>& alns, const std::vector<bool>& realign){
+    read_off.assign(1, 0); base_off.assign(1, 0); cigar_off.assign(1, 0);
+    for (size_t i = 0; i < alns.size(); i++){
+      const Alignment& a = alns[i];
+      if (a.get_sequence().size() != a.get_base_qualities().size()) printErrorAndDie("Read sequence and base qualities differ in length");
+      bases += a.get_sequence(); quals += a.get_base_qualities();
+      base_off.push_back((int32_t)bases.size());
+      read_start.push_back(a.get_start());
+      for (size_t c = 0; c < a.get_cigar_list().size(); c++){ cigar_op += a.get_cigar_list()[c].get_type(); cigar_len.push_back(a.get_cigar_list()[c].get_num()); }
+      cigar_off.push_back((int32_t)cigar_op.size());
+      realign_read.push_back(realign[i] ? 1 : 0);
+    }
+    read_off.push_back((int32_t)alns.size());
+  }
+  const hipstr_batch_t* finish(){
+    if (cigar_len.empty()) cigar_len.push_back(0);
+    batch.n_loci = 1;
+    batch.blk_start = blk_start.data(); batch.blk_end = blk_end.data(); batch.blk_nopts = blk_nopts.data(); batch.period = &period;
+    batch.stutter = stutter.data(); batch.opt_off = opt_off.data(); batch.seq = seq.data(); batch.hap_off = hap_off.data();
+    batch.realign_hap = realign_hap.data(); batch.read_off = read_off.data(); batch.base_off = base_off.data();
+    batch.bases = bases.data(); batch.quals = quals.data(); batch.read_start = read_start.data(); batch.cigar_off = cigar_off.data();
+    batch.cigar_op = cigar_op.data(); batch.cigar_len = cigar_len.data(); batch.realign_read = realign_read.data();
+    return &batch;
+  }
+};
+
+class HapAligner {
+  Haplotype* fw_haplotype_;                // borrowed (HapAligner.h:58)
+  std::vector<bool> realign_to_hap_;
+ public:
+  HapAligner(Haplotype* haplotype, std::vector<bool>& realign_to_haplotype) : fw_haplotype_(haplotype), realign_to_hap_(realign_to_haplotype) {
+    assert((int)realign_to_haplotype.size() == haplotype->num_combs());
+  }
+  // 0-based index of the seed base, or -1 if none (HapAligner.h:78-81)
+  int calc_seed_base(const Alignment& alignment){
+    FlatLocus f; f.set_haplotype(fw_haplotype_, realign_to_hap_);
+    f.set_reads(std::vector<Alignment>(1, alignment), std::vector<bool>(1, true));
+    int32_t seed = -1;
+    if (hipstr_calc_seed_bases(f.finish(), &seed) != 0) printErrorAndDie(hipstr_last_error());
+    return seed;
+  }
+  // Same contract as HapAligner::process_reads (HapAligner.cpp:320-343): row init_read_index+i of aln_probs / entry
+  // init_read_index+i of seed_positions is written for every realign_read[i]; other entries are left untouched.
+  // The BaseQuality argument is kept for signature compatibility: its tables are constants of the model.
+  void process_reads(const std::vector<Alignment>& alignments, int init_read_index, const BaseQuality* /*base_quality*/,
+                     const std::vector<bool>& realign_read, double* aln_probs, int* seed_positions){
+    assert(alignments.size() == realign_read.size());
+    FlatLocus f; f.set_haplotype(fw_haplotype_, realign_to_hap_); f.set_reads(alignments, realign_read);
+    if (hipstr_hmm_process_reads(f.finish(), aln_probs + (size_t)init_read_index*fw_haplotype_->num_combs(), seed_positions + init_read_index) != 0)
+      printErrorAndDie(hipstr_last_error());
+  }
+};
+
+// SeqStutterGenotyper::calc_hap_aln_probs (seq_stutter_genotyper.cpp:519-568): align the pooled reads, copy each pool's row
+// to its reads for the realigned haplotypes, and give both mates of a pair the sum of their rows (only for newly aligned
+// haplotypes, "or we'll effectively keep doubling those values with each iteration").
+inline void calc_hap_aln_probs(Haplotype* haplotype, ReadPooler& pooler, const BaseQuality& base_quality,
+                               const int* pool_index, const bool* second_mate, unsigned int num_reads,
+                               std::vector<bool>& realign_to_haplotype, std::vector<bool>& realign_pool, std::vector<bool>& copy_read,
+                               double* log_aln_probs, int* seed_positions){
+  const int num_alleles = haplotype->num_combs();
+  assert((int)realign_to_haplotype.size() == num_alleles);
+  HapAligner hap_aligner(haplotype, realign_to_haplotype);
+  std::vector<Alignment>& pooled_alns = pooler.get_alignments();
+  std::vector<double> pool_probs(pooled_alns.size()*(size_t)num_alleles);
+  std::vector<int> pool_seeds(pooled_alns.size());
+  hap_aligner.process_reads(pooled_alns, 0, &base_quality, realign_pool, pool_probs.data(), pool_seeds.data());
+  for (unsigned int i = 0; i < num_reads; i++){
+    if (!copy_read[i]) continue;
+    seed_positions[i] = pool_seeds[pool_index[i]];
+    for (int j = 0; j < num_alleles; j++)
+      if (realign_to_haplotype[j]) log_aln_probs[(size_t)i*num_alleles + j] = pool_probs[(size_t)pool_index[i]*num_alleles + j];
+  }
+  for (unsigned int i = 0; i < num_reads; i++){
+    if (!second_mate[i] || !copy_read[i]) continue;
+    for (int j = 0; j < num_alleles; j++)
+      if (realign_to_haplotype[j]){
+        const double total = log_aln_probs[(size_t)(i-1)*num_alleles + j] + log_aln_probs[(size_t)i*num_alleles + j];
+        log_aln_probs[(size_t)(i-1)*num_alleles + j] = total;
+        log_aln_probs[(size_t)i*num_alleles + j]     = total;
+      }
+  }
+}
+
+// Posterior half of the reference's Genotyper base class (genotyper.h:14-130): flat per-read arrays owned by the object,
+// calc_log_sample_posteriors() fills log_sample_posteriors_ / sample_total_LLs_ and returns the total log-likelihood.
+class Genotyper {
+ protected:
+  unsigned int num_reads_; int num_samples_, num_alleles_;
+  double *log_p1_, *log_p2_; int* sample_label_; bool haploid_;
+  double* log_sample_posteriors_;   // samples, then allele_1, then allele_2
+  double* log_aln_probs_;           // reads, then alleles
+  double* sample_total_LLs_;
+  std::vector<int> read_weights_;
+  std::vector< std::pair<int,int> > map_gts_;
+
+  double calc_log_sample_posteriors(std::vector<int>& read_weights){
+    assert(read_weights.size() == num_reads_ && log_sample_posteriors_ != NULL && log_aln_probs_ != NULL);
+    int32_t A = num_alleles_, S = num_samples_, read_off[2] = {0, (int32_t)num_reads_};
+    uint8_t hap = haploid_ ? 1 : 0;
+    std::vector<int32_t> w(read_weights.begin(), read_weights.end()), gt(2*(size_t)S);
+    hipstr_post_batch_t pb;
+    pb.n_loci = 1; pb.n_alleles = &A; pb.n_samples = &S; pb.read_off = read_off; pb.sample_label = sample_label_;
+    pb.log_p1 = log_p1_; pb.log_p2 = log_p2_; pb.read_weight = w.data(); pb.log_aln_probs = log_aln_probs_; pb.haploid = &hap;
+    double total = 0;
+    if (hipstr_post_run(&pb, NULL, log_sample_posteriors_, sample_total_LLs_, gt.data(), &total) != 0) printErrorAndDie(hipstr_last_error());
+    map_gts_.resize(S);
+    for (int s = 0; s < S; s++) map_gts_[s] = std::pair<int,int>(gt[2*s], gt[2*s+1]);
+    return total;
+  }
+  double calc_log_sample_posteriors(){ return calc_log_sample_posteriors(read_weights_); }
+
+  // MAP phased diplotype per sample: first maximum in allele_1-major order (genotyper.cpp:82-97); computed by the same kernel
+  void get_optimal_haplotypes(std::vector< std::pair<int,int> >& gts) const { assert(gts.empty()); gts = map_gts_; }
+
+ public:
+  Genotyper(bool haploid, const std::vector<std::string>& sample_names,
+            const std::vector< std::vector<double> >& log_p1, const std::vector< std::vector<double> >& log_p2){
+    assert(log_p1.size() == log_p2.size() && log_p1.size() == sample_names.size());
+    num_reads_ = 0;
+    for (size_t i = 0; i < log_p1.size(); i++) num_reads_ += log_p1[i].size();
+    num_alleles_ = -1; haploid_ = haploid; num_samples_ = (int)log_p1.size();
+    log_p1_ = new double[num_reads_]; log_p2_ = new double[num_reads_]; sample_label_ = new int[num_reads_];
+    sample_total_LLs_ = new double[num_samples_];
+    read_weights_ = std::vector<int>(num_reads_, 1);
+    unsigned int r = 0;
+    for (size_t i = 0; i < log_p1.size(); i++)
+      for (size_t j = 0; j < log_p1[i].size(); j++, r++){
+        assert(log_p1[i][j] <= 0.0 && log_p2[i][j] <= 0.0);
+        log_p1_[r] = log_p1[i][j]; log_p2_[r] = log_p2[i][j]; sample_label_[r] = (int)i;
+      }
+    log_sample_posteriors_ = NULL; log_aln_probs_ = NULL;
+  }
+  virtual ~Genotyper(){
+    delete [] log_p1_; delete [] log_p2_; delete [] sample_label_; delete [] sample_total_LLs_;
+    delete [] log_sample_posteriors_; delete [] log_aln_probs_;
+  }
+};
+
+}  // namespace hipstr_amd
+#endif  // HIPSTR_HMM_HPP_

@@ -1,0 +1,91 @@
+// Exercises include/hipstr_hmm.hpp the way seq_stutter_genotyper.cpp uses the reference classes.
+//   host_api_test            host-only parts (read pooling, median qualities, seed bases)
+//   host_api_test --gpu      + HapAligner::process_reads, calc_hap_aln_probs, Genotyper posteriors on the device
+// Prints "key value..." lines that tests/test_host_api.py compares with the golden vectors of SURVEY.md §8(c).
+#include <cstdio>
+#include <cstring>
+#include "hipstr_hmm.hpp"
+using namespace hipstr_amd;
+
+class ProbeGenotyper : public Genotyper {   // the reference's derived genotypers allocate these once the allele count is known
+ public:
+  ProbeGenotyper(bool haploid, const std::vector<std::string>& names, const std::vector< std::vector<double> >& p1,
+                 const std::vector< std::vector<double> >& p2, int num_alleles, const double* LL) : Genotyper(haploid, names, p1, p2){
+    num_alleles_ = num_alleles;
+    log_sample_posteriors_ = new double[(size_t)num_samples_*num_alleles_*num_alleles_];
+    log_aln_probs_ = new double[(size_t)num_reads_*num_alleles_];
+    memcpy(log_aln_probs_, LL, sizeof(double)*(size_t)num_reads_*num_alleles_);
+  }
+  void run(){
+    double total = calc_log_sample_posteriors();
+    std::vector< std::pair<int,int> > gts; get_optimal_haplotypes(gts);
+    printf("post_total %.12f\n", total);
+    for (size_t s = 0; s < gts.size(); s++) printf("post_gt %d %d\n", gts[s].first, gts[s].second);
+    printf("post_first %.12f %.12f %.12f\n", log_sample_posteriors_[0], log_sample_posteriors_[1], log_sample_posteriors_[2]);
+  }
+};
+
+int main(int argc, char** argv){
+  const bool gpu = argc > 1 && strcmp(argv[1], "--gpu") == 0;
+  const std::string lf = "ACGTTGCATGCATGACCTGAGTCCATGACTTGACA", rf = "TTGACCGTAGGCTAGGCTTAACGGATCCGATTAGC";
+  std::string gata10, gata11, gata12, gata9;
+  for (int i = 0; i < 12; i++){ if (i < 9) gata9 += "GATA"; if (i < 10) gata10 += "GATA"; if (i < 11) gata11 += "GATA"; gata12 += "GATA"; }
+  StutterModel model(0.9, 0.05, 0.05, 0.7, 0.005, 0.005, 4);
+  HapBlock left(100, 135, lf), right(175, 210, rf);
+  RepeatBlock str(135, 175, gata10, 4, &model);
+  str.add_alternate(gata11); str.add_alternate(gata12); str.add_alternate(gata9);
+  std::vector<HapBlock*> blocks; blocks.push_back(&left); blocks.push_back(&str); blocks.push_back(&right);
+  Haplotype hap(blocks);
+  printf("num_combs %d\n", hap.num_combs());
+
+  // three reads: two identical sequences with different qualities (one pool), their mate, plus an unrelated read
+  const std::string seq = lf.substr(10) + gata11 + rf.substr(0, 25);
+  std::vector<Alignment> alns;
+  const char* quals[3] = {"I", "5", "F"};
+  for (int i = 0; i < 3; i++){
+    alns.push_back(Alignment(110, 200, false, i < 2 ? "pairA" : "readB", std::string(seq.size(), quals[i][0]), seq, ""));
+    alns.back().add_cigar_element(CigarElement('=', 65)); alns.back().add_cigar_element(CigarElement('I', 4)); alns.back().add_cigar_element(CigarElement('=', 25));
+  }
+  const std::string seq2 = lf.substr(5) + gata10 + rf.substr(0, 30);
+  alns.push_back(Alignment(105, 205, false, "readC", std::string(seq2.size(), 'I'), seq2, ""));
+  alns.back().add_cigar_element(CigarElement('=', (int)seq2.size()));
+
+  BaseQuality bq;
+  ReadPooler pooler;
+  std::vector<int> pool_index(alns.size()); std::vector<char> second(alns.size(), 0);
+  std::string prev = "";
+  for (size_t i = 0; i < alns.size(); i++){
+    pool_index[i] = pooler.add_alignment(alns[i]);
+    second[i] = alns[i].get_name() == prev; prev = alns[i].get_name();     // seq_stutter_genotyper.cpp:497-503
+  }
+  pooler.pool(bq);
+  printf("num_pools %d\n", pooler.num_pools());
+  printf("pool0_qual %c\n", pooler.get_alignments()[0].get_base_qualities()[0]);   // upper median of {I,5,F} = F
+
+  std::vector<bool> all_haps(hap.num_combs(), true);
+  HapAligner aligner(&hap, all_haps);
+  printf("seed %d %d\n", aligner.calc_seed_base(pooler.get_alignments()[0]), aligner.calc_seed_base(pooler.get_alignments()[1]));
+  if (!gpu) return 0;
+
+  // single pooled read with quality 'I' == the known-answer vector
+  std::vector<Alignment> kat(1, alns[0]);
+  double probs[4]; int seeds[1];
+  aligner.process_reads(kat, 0, &bq, std::vector<bool>(1, true), probs, seeds);
+  printf("kat_seed %d\nkat_ll %.11f %.11f %.11f %.11f\n", seeds[0], probs[0], probs[1], probs[2], probs[3]);
+
+  // pool -> read scatter + mate-pair summation
+  std::vector<bool> realign_pool(pooler.num_pools(), true), copy_read(alns.size(), true);
+  std::vector<double> ll(alns.size()*4, -777.0); std::vector<int> sd(alns.size(), -5);
+  bool sm[4]; for (int i = 0; i < 4; i++) sm[i] = second[i] != 0;
+  calc_hap_aln_probs(&hap, pooler, bq, pool_index.data(), sm, (unsigned)alns.size(), all_haps, realign_pool, copy_read, ll.data(), sd.data());
+  for (size_t i = 0; i < alns.size(); i++) printf("read_ll %zu %d %.11f %.11f %.11f %.11f\n", i, sd[i], ll[4*i], ll[4*i+1], ll[4*i+2], ll[4*i+3]);
+
+  // posteriors: SURVEY §8(c) second known-answer vector
+  const double LL[15] = {-4.4,-7.3,-9.6, -7.1,-4.2,-7.5, -4.5,-7.0,-9.9, -9.0,-6.0,-4.1, -9.2,-6.3,-4.0};
+  std::vector<std::string> names; names.push_back("s1"); names.push_back("s2");
+  std::vector< std::vector<double> > p1(2), p2(2);
+  p1[0] = std::vector<double>{0, -0.01, 0}; p2[0] = std::vector<double>{0, -5, 0}; p1[1] = std::vector<double>{0, 0}; p2[1] = std::vector<double>{0, 0};
+  ProbeGenotyper g(false, names, p1, p2, 3, LL);
+  g.run();
+  return 0;
+}

@@ -1,0 +1,52 @@
+"""The C++ host API (include/hipstr_hmm.hpp): compiled here with g++, host-only parts on CPU, device parts on the GPU."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "host_api_test")
+
+
+def _build():
+    src = os.path.join(ROOT, "tests", "cpp", "host_api_test.cpp")
+    deps = [src, os.path.join(ROOT, "include", "hipstr_hmm.hpp"), os.path.join(ROOT, "include", "hipstr_hmm.h"),
+            os.path.join(ROOT, "hipstr_amd", "csrc", "libhipstr_hmm.so")]
+    if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
+        libdir = os.path.join(ROOT, "hipstr_amd", "csrc")
+        subprocess.check_call(["g++", "-std=c++11", "-O1", "-I", os.path.join(ROOT, "include"), src, "-o", EXE,
+                               "-L", libdir, "-lhipstr_hmm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+
+
+def _run(*args):
+    _build()
+    out = subprocess.run([EXE] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    kv = {}
+    for line in out.stdout.splitlines():
+        k, _, v = line.partition(" ")
+        kv.setdefault(k, []).append(v.split())
+    return kv
+
+
+def test_host_only_parts(_native_built):
+    kv = _run()
+    assert kv["num_combs"] == [["4"]]
+    assert kv["num_pools"] == [["2"]]            # identical sequences pool together (read_pooler.cpp:3-20)
+    assert kv["pool0_qual"] == [["F"]]           # upper median of {I,5,F} (base_quality.cpp:25)
+    assert kv["seed"] == [["81", "84"]]          # seed 81 for the 65=4I25= read; 100= read: ties go right (HapAligner.cpp:246,259)
+
+
+@pytest.mark.gpu
+def test_device_parts(_native_built):
+    kv = _run("--gpu")
+    assert kv["kat_seed"] == [["81"]]
+    want = [-7.37582683338, -4.37708234692, -7.35198679536, -9.68433975817]
+    assert all(abs(float(a) - b) < 5e-11 for a, b in zip(kv["kat_ll"][0], want))
+    rows = {int(r[0]): (int(r[1]), [float(x) for x in r[2:]]) for r in kv["read_ll"]}
+    # reads 0 and 1 are mates from the same pool: both rows = 2 x pool row; read 2 = pool row; all share the pool seed
+    assert rows[0][1] == rows[1][1] and all(abs(a - 2 * b) < 1e-9 for a, b in zip(rows[0][1], rows[2][1]))
+    assert rows[0][0] == rows[2][0] == 81 and rows[3][0] == 84
+    assert abs(float(kv["post_total"][0][0]) - (-26.5207888808)) < 1e-9
+    assert kv["post_gt"] == [["1", "0"], ["2", "2"]]
+    assert all(abs(float(a) - b) < 1e-9 for a, b in zip(kv["post_first"][0], [-1.39627803547, -3.2336875797, -3.4679593086]))
