@@ -52,10 +52,17 @@ def build_oracle(force=False):
         _run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref", "-j8"])
 
 
+def build_dropin():
+    """integration/HapAlignerMI355X (the reference-side binding) + its equivalence check, only where the HipSTR tree exists."""
+    if os.path.isdir("/root/reference/src"):
+        _run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "dropin"])
+
+
 def build_all(force=False):
     build_synth(force)
     build_oracle(force)
     build_hmm(force)
+    build_dropin()
 
 
 if __name__ == "__main__":

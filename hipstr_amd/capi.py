@@ -38,7 +38,7 @@ class HipstrPostBatch(C.Structure):
     _fields_ = [
         ("n_loci", C.c_int32),
         ("n_alleles", _i32p), ("n_samples", _i32p), ("read_off", _i32p), ("sample_label", _i32p),
-        ("log_p1", _f64p), ("log_p2", _f64p), ("read_weight", _i32p), ("log_aln_probs", _f64p), ("haploid", _u8p),
+        ("log_p1", _f64p), ("log_p2", _f64p), ("read_weight", _i32p), ("log_aln_probs", _f64p), ("haploid", _u8p), ("log_prior", _f64p),
     ]
 
 
@@ -142,13 +142,14 @@ def batch_dims(bptr):
 
 
 class PostBatch:
-    def __init__(self, n_alleles, n_samples, read_off, sample_label, log_p1, log_p2, read_weight, log_aln_probs, haploid=None):
+    def __init__(self, n_alleles, n_samples, read_off, sample_label, log_p1, log_p2, read_weight, log_aln_probs, haploid=None, log_prior=None):
         i32 = lambda x: np.ascontiguousarray(np.asarray(x, dtype=np.int32))
         f64 = lambda x: np.ascontiguousarray(np.asarray(x, dtype=np.float64))
         self.a = dict(n_alleles=i32(n_alleles), n_samples=i32(n_samples), read_off=i32(read_off), sample_label=i32(sample_label),
                       log_p1=f64(log_p1), log_p2=f64(log_p2), read_weight=i32(read_weight),
                       log_aln_probs=None if log_aln_probs is None else f64(log_aln_probs),
-                      haploid=None if haploid is None else np.ascontiguousarray(np.asarray(haploid, dtype=np.uint8)))
+                      haploid=None if haploid is None else np.ascontiguousarray(np.asarray(haploid, dtype=np.uint8)),
+                      log_prior=None if log_prior is None else f64(log_prior))
         s = HipstrPostBatch()
         s.n_loci = len(self.a["n_alleles"])
         for name in ("n_alleles", "n_samples", "read_off", "sample_label", "read_weight"):
@@ -156,6 +157,7 @@ class PostBatch:
         s.log_p1 = _ptr(self.a["log_p1"], _f64p); s.log_p2 = _ptr(self.a["log_p2"], _f64p)
         s.log_aln_probs = _ptr(self.a["log_aln_probs"], _f64p)
         s.haploid = _ptr(self.a["haploid"], _u8p)
+        s.log_prior = _ptr(self.a["log_prior"], _f64p)
         s._keepalive = self.a
         self.struct = s
         A = self.a["n_alleles"].astype(np.int64); S = self.a["n_samples"].astype(np.int64)

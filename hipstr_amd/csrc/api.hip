@@ -368,6 +368,7 @@ int post_setup(const hipstr_post_batch_t* pb, const double* dev_ll, PostRun& R){
   if (up(pb->log_p1, sizeof(double)*R.n_reads, &p)) return 1; R.h.log_p1 = (const double*)p;
   if (up(pb->log_p2, sizeof(double)*R.n_reads, &p)) return 1; R.h.log_p2 = (const double*)p;
   if (up(pb->read_weight, sizeof(int32_t)*R.n_reads, &p)) return 1; R.h.read_weight = (const int32_t*)p;
+  if (pb->log_prior){ if (up(pb->log_prior, sizeof(double)*R.n_post, &p)) return 1; R.h.log_prior = (const double*)p; }
   if (dev_ll) R.h.log_aln_probs = dev_ll;
   else {
     if (!pb->log_aln_probs) return fail("no log_aln_probs given");

@@ -20,6 +20,7 @@ struct hs_post_dev_t {
   const double*  log_p1;
   const double*  log_p2;
   const int32_t* read_weight;
+  const double*  log_prior;      // optional [n_post] prior array (NULL = hom/het defaults of the unit)
   double*        log_post;
   double*        sample_total;
   int32_t*       map_gt;

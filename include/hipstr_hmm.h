@@ -163,6 +163,10 @@ typedef struct hipstr_post_batch {
   const double*  log_aln_probs; /* [sum R_l*A_l] log_aln_probs_, read-major (genotyper.h:33); may be
                                    NULL when a device buffer is given to hipstr_post_run              */
   const uint8_t* haploid;       /* [n_loci] haploid_ flag, or NULL = diploid                           */
+  const double*  log_prior;     /* [sum S_l*A_l^2] optional: the array a derived class's virtual
+                                   init_log_sample_priors fills (genotyper.h:69; EMStutterGenotyper
+                                   overrides it, em_stutter_genotyper.cpp:129-144); NULL = the default
+                                   hom/het priors of genotyper.cpp:20-42                               */
 } hipstr_post_batch_t;
 
 /* log_post[post_off[l] + (s*A + a1)*A + a2]; post_off[l] = sum_{l'<l} S_l'*A_l'^2

@@ -305,6 +305,12 @@ class Genotyper {
   double* sample_total_LLs_;
   std::vector<int> read_weights_;
   std::vector< std::pair<int,int> > map_gts_;
+  bool custom_priors_;              // set by a derived class that overrides init_log_sample_priors
+
+  // Default: leave the array untouched and let the device apply the hom/het priors of genotyper.cpp:20-42.
+  // A derived class (the reference's EMStutterGenotyper does, em_stutter_genotyper.cpp:129-144) overrides this,
+  // fills log_sample_ptr[samples][allele_1][allele_2] and sets custom_priors_ = true.
+  virtual void init_log_sample_priors(double* /*log_sample_ptr*/){}
 
   double calc_log_sample_posteriors(std::vector<int>& read_weights){
     assert(read_weights.size() == num_reads_ && log_sample_posteriors_ != NULL && log_aln_probs_ != NULL);
@@ -314,6 +320,9 @@ class Genotyper {
     hipstr_post_batch_t pb;
     pb.n_loci = 1; pb.n_alleles = &A; pb.n_samples = &S; pb.read_off = read_off; pb.sample_label = sample_label_;
     pb.log_p1 = log_p1_; pb.log_p2 = log_p2_; pb.read_weight = w.data(); pb.log_aln_probs = log_aln_probs_; pb.haploid = &hap;
+    std::vector<double> prior((size_t)S*A*A);
+    init_log_sample_priors(prior.data());        // virtual, as in the reference (genotyper.h:69)
+    pb.log_prior = custom_priors_ ? prior.data() : NULL;
     double total = 0;
     if (hipstr_post_run(&pb, NULL, log_sample_posteriors_, sample_total_LLs_, gt.data(), &total) != 0) printErrorAndDie(hipstr_last_error());
     map_gts_.resize(S);
@@ -341,7 +350,7 @@ class Genotyper {
         assert(log_p1[i][j] <= 0.0 && log_p2[i][j] <= 0.0);
         log_p1_[r] = log_p1[i][j]; log_p2_[r] = log_p2[i][j]; sample_label_[r] = (int)i;
       }
-    log_sample_posteriors_ = NULL; log_aln_probs_ = NULL;
+    log_sample_posteriors_ = NULL; log_aln_probs_ = NULL; custom_priors_ = false;
   }
   virtual ~Genotyper(){
     delete [] log_p1_; delete [] log_p2_; delete [] sample_label_; delete [] sample_total_LLs_;

@@ -1,0 +1,54 @@
+// HapAlignerMI355X.h — the reference-side binding a HipSTR maintainer adds to src/SeqAlignment/.
+//
+// A class with HapAligner's public interface (HapAligner.h:56-93) written against the REFERENCE's
+// own types (Haplotype, HapBlock, RepeatBlock, Alignment, BaseQuality, AlignmentTrace), so that
+// seq_stutter_genotyper.cpp keeps compiling unchanged apart from the type name at its three
+// construction sites (seq_stutter_genotyper.cpp:522, :814, :1076) — see INTEGRATION.md.
+//
+//   process_reads / calc_seed_base  ->  libhipstr_hmm.so  (include/hipstr_hmm.h, MI355X kernels)
+//   trace_optimal_aln               ->  the reference's CPU HapAligner (Viterbi traceback is the next tier)
+//
+// This file is NOT part of the product library and is only compiled where the HipSTR tree is
+// available (oracle/Makefile target `dropin`, which also builds the drop-in equivalence check).
+#ifndef HAP_ALIGNER_MI355X_H_
+#define HAP_ALIGNER_MI355X_H_
+
+#include <string>
+#include <vector>
+
+#include "AlignmentData.h"
+#include "AlignmentTraceback.h"
+#include "HapAligner.h"
+#include "Haplotype.h"
+#include "../base_quality.h"
+
+class HapAlignerMI355X {
+ private:
+  Haplotype* fw_haplotype_;                 // borrowed, as in HapAligner (HapAligner.h:58)
+  std::vector<bool> realign_to_hap_;
+  HapAligner cpu_aligner_;                  // traceback only
+
+  // flattened haplotype (built once per aligner, like the reference builds its reversed haplotype once)
+  std::vector<int32_t> blk_start_, blk_end_, blk_nopts_, opt_off_, hap_off_;
+  std::vector<double> stutter_;
+  std::vector<uint8_t> realign_hap_;
+  std::string seq_;
+  int32_t period_;
+
+  HapAlignerMI355X(const HapAlignerMI355X& other);
+  HapAlignerMI355X& operator=(const HapAlignerMI355X& other);
+
+ public:
+  HapAlignerMI355X(Haplotype* haplotype, std::vector<bool>& realign_to_haplotype);
+
+  int calc_seed_base(const Alignment& alignment);
+
+  void process_reads(const std::vector<Alignment>& alignments, int init_read_index, const BaseQuality* base_quality,
+		     const std::vector<bool>& realign_read, double* aln_probs, int* seed_positions);
+
+  AlignmentTrace* trace_optimal_aln(const Alignment& orig_aln, int seed_base, int best_haplotype, const BaseQuality* base_quality){
+    return cpu_aligner_.trace_optimal_aln(orig_aln, seed_base, best_haplotype, base_quality);
+  }
+};
+
+#endif

@@ -661,7 +661,8 @@ int oracle_posteriors(const hipstr_post_batch_t* pb, double* log_post, double* s
     double hom = hap ? -g_int_log[A] : g_int_log[2] - g_int_log[A] - g_int_log[A+1];
     double het = hap ? -DBL_MAX/2 : -g_int_log[A] - g_int_log[A+1];
     double* post = log_post + post_off;
-    for (int s = 0; s < S; s++) for (int i = 0; i < A; i++) for (int j = 0; j < A; j++) post[(size_t)s*nd + i*A + j] = (i == j ? hom : het);
+    for (int s = 0; s < S; s++) for (int i = 0; i < A; i++) for (int j = 0; j < A; j++)
+      post[(size_t)s*nd + i*A + j] = pb->log_prior ? pb->log_prior[post_off + (size_t)s*nd + i*A + j] : (i == j ? hom : het);   /* virtual init_log_sample_priors, genotyper.h:69 */
     /* genotyper.cpp:49-61 */
     for (int r = pb->read_off[l]; r < pb->read_off[l+1]; r++){
       const double* LL = pb->log_aln_probs + ll_off + (int64_t)(r-pb->read_off[l])*A;

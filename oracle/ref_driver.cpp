@@ -176,10 +176,18 @@ double ref_log_sum_exp(const double* v, int n){ return log_sum_exp(v, v+n); }
 /* ---- posteriors: a subclass that exposes the protected members of Genotyper ---- */
 namespace {
 class ProbeGenotyper : public Genotyper {
+  const double* custom_prior_;
  public:
+  void set_prior(const double* p){ custom_prior_ = p; }
+  // the virtual hook EMStutterGenotyper overrides (genotyper.h:69)
+  void init_log_sample_priors(double* log_sample_ptr){
+    if (custom_prior_ == NULL){ Genotyper::init_log_sample_priors(log_sample_ptr); return; }
+    memcpy(log_sample_ptr, custom_prior_, sizeof(double)*(size_t)num_samples_*num_alleles_*num_alleles_);
+  }
   ProbeGenotyper(bool haploid, const std::vector<std::string>& names,
                  const std::vector< std::vector<double> >& p1, const std::vector< std::vector<double> >& p2, int num_alleles)
     : Genotyper(haploid, names, p1, p2){
+    custom_prior_          = NULL;
     num_alleles_           = num_alleles;
     log_sample_posteriors_ = new double[(size_t)num_samples_*num_alleles_*num_alleles_];
     log_aln_probs_         = new double[(size_t)num_reads_*num_alleles_];
@@ -217,6 +225,7 @@ extern "C" int ref_posteriors(const hipstr_post_batch_t* pb, double* log_post, d
       p2[s].push_back(pb->log_p2[r]);
     }
     ProbeGenotyper g(pb->haploid ? pb->haploid[l] != 0 : false, names, p1, p2, A);
+    if (pb->log_prior) g.set_prior(pb->log_prior + post_off);
     locus_total_ll[l] = g.run(pb->log_aln_probs + ll_off, pb->read_weight + r0, log_post + post_off,
                               sample_total_ll + samp_off, map_gt + 2*samp_off);
     post_off += (int64_t)S*A*A;

@@ -112,3 +112,15 @@ def test_full_size_properties(hmm, oracle):
         if key in seen:
             assert np.array_equal(rows[r], rows[seen[key]])
         seen[key] = r
+
+
+def test_dropin_adapter_against_reference_objects(hmm):
+    """integration/HapAlignerMI355X — HapAligner's interface on the reference's own Haplotype/Alignment objects — next to
+    the reference's CPU HapAligner in one process (oracle/_ref/dropin_check, prebuilt where the HipSTR tree is mounted)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "dropin_check")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/dropin_check not built (needs the reference tree at build time)")
+    for args in (["6", "24", "8", "2"], ["3", "40", "32", "1"]):
+        out = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+        assert out.returncode == 0 and " 0 mismatches" in out.stdout, out.stdout

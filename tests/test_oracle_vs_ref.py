@@ -58,3 +58,15 @@ def test_posteriors_match_reference(oracle, ref):
                             np.concatenate([-rng.random(r * a) * 30 for r, a in zip(R, A)]), haploid=(rng.random(nl) < 0.3))
         a = capi.run_posteriors(ref, "ref_", pb); b = capi.run_posteriors(oracle, "oracle_", pb)
         assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_custom_priors_match_reference(oracle, ref):
+    """The virtual init_log_sample_priors hook (genotyper.h:69; EMStutterGenotyper overrides it): arbitrary prior arrays."""
+    rng = np.random.default_rng(8)
+    A = np.array([3, 5]); S = np.array([2, 3]); R = [7, 9]
+    ro = np.concatenate([[0], np.cumsum(R)]); lab = np.concatenate([np.sort(rng.integers(0, s, r)) for s, r in zip(S, R)])
+    n = int(ro[-1]); prior = -rng.random(int((S * A * A).sum())) * 5
+    pb = capi.PostBatch(A, S, ro, lab, -rng.random(n), -rng.random(n), np.ones(n, int), np.concatenate([-rng.random(r * a) * 20 for r, a in zip(R, A)]),
+                        log_prior=prior)
+    a = capi.run_posteriors(ref, "ref_", pb); b = capi.run_posteriors(oracle, "oracle_", pb)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))

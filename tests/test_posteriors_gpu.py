@@ -84,3 +84,15 @@ def test_ungrouped_samples_rejected(hmm):
     post = np.zeros(8); tot = np.zeros(2); gt = np.zeros(4, np.int32); lt = np.zeros(1)
     assert hmm.hipstr_post_run(pb.ptr, None, post.ctypes.data_as(capi._f64p), tot.ctypes.data_as(capi._f64p),
                                gt.ctypes.data_as(capi._i32p), lt.ctypes.data_as(capi._f64p)) != 0
+
+
+def test_custom_prior_array(hmm, oracle):
+    """Population priors supplied by the caller (what EMStutterGenotyper's init_log_sample_priors override produces)."""
+    rng = np.random.default_rng(21)
+    A = np.array([4, 9]); S = np.array([3, 2]); R = [12, 10]
+    ro = np.concatenate([[0], np.cumsum(R)]); lab = np.concatenate([np.sort(rng.integers(0, s, r)) for s, r in zip(S, R)])
+    n = int(ro[-1]); prior = -rng.random(int((S * A * A).sum())) * 6
+    pb = capi.PostBatch(A, S, ro, lab, -rng.random(n), -rng.random(n), np.ones(n, int), np.concatenate([-rng.random(r * a) * 25 for r, a in zip(R, A)]),
+                        log_prior=prior)
+    got = _run(hmm, pb); want = capi.run_posteriors(oracle, "oracle_", pb)
+    assert _finite_close(got[0], want[0]) and _finite_close(got[1], want[1]) and np.array_equal(got[2], want[2])
