@@ -1,0 +1,99 @@
+"""Sharding of a locus batch across GPUs (one process per GPU) and the host-side ordered gather.
+
+STR loci are independent (the reference's own scale-out is "N processes on N BED shards", README.md:167-171), so
+the region list is cut into `world` contiguous, cost-balanced chunks; no collective touches the data path.  The
+only communication is the gather of per-rank results on rank 0 in rank order, which — the chunks being
+contiguous — is locus order, the order the reference's VCF writer needs (vcf_writer.cpp:7-36)."""
+import numpy as np
+
+from . import capi
+from .capi import HipstrBatch, _i32p, _f64p, _u8p
+
+
+def locus_costs(a):
+    """DP work estimate per locus: reads x alleles x read length x haplotype length."""
+    n = len(a["period"])
+    P = np.diff(a["read_off"]).astype(np.float64); A = np.diff(a["hap_off"]).astype(np.float64)
+    nb = np.diff(a["base_off"]).astype(np.float64)
+    bases_per_locus = np.array([nb[a["read_off"][l]:a["read_off"][l + 1]].sum() for l in range(n)])
+    opt_len = np.diff(a["opt_off"]).astype(np.float64)
+    nopt = a["blk_nopts"].reshape(n, 3)
+    H = np.zeros(n); c = 0
+    for l in range(n):
+        for k in range(3):
+            H[l] += opt_len[c:c + nopt[l, k]].mean(); c += nopt[l, k]
+    return np.maximum(1.0, bases_per_locus * A * H) + 0 * P
+
+
+def split_loci(costs, world):
+    """Boundaries [b_0=0, ..., b_world=n] of contiguous chunks with near-equal total cost."""
+    costs = np.asarray(costs, dtype=np.float64)
+    cum = np.concatenate([[0.0], np.cumsum(costs)])
+    bounds = [0]
+    for r in range(1, world):
+        bounds.append(int(np.searchsorted(cum, cum[-1] * r / world, side="left")))
+    bounds.append(len(costs))
+    for i in range(1, len(bounds)):
+        bounds[i] = max(bounds[i], bounds[i - 1])
+    return bounds
+
+
+def subset_arrays(a, lo, hi):
+    """Arrays (as in capi.Batch.arrays) of loci [lo, hi) of a batch, re-based to start at zero."""
+    out = {}
+    out["blk_start"] = a["blk_start"][3 * lo:3 * hi].copy(); out["blk_end"] = a["blk_end"][3 * lo:3 * hi].copy()
+    out["blk_nopts"] = a["blk_nopts"][3 * lo:3 * hi].copy(); out["period"] = a["period"][lo:hi].copy()
+    out["stutter"] = a["stutter"][6 * lo:6 * hi].copy()
+    o0 = int(a["blk_nopts"][:3 * lo].sum()); o1 = o0 + int(out["blk_nopts"].sum())
+    s0, s1 = int(a["opt_off"][o0]), int(a["opt_off"][o1])
+    out["opt_off"] = (a["opt_off"][o0:o1 + 1] - s0).astype(np.int32)
+    out["seq"] = bytes(a["seq"][s0:s1]) + b"\0"
+    h0, h1 = int(a["hap_off"][lo]), int(a["hap_off"][hi])
+    out["hap_off"] = (a["hap_off"][lo:hi + 1] - h0).astype(np.int32)
+    out["realign_hap"] = None if a["realign_hap"] is None else a["realign_hap"][h0:h1].copy()
+    r0, r1 = int(a["read_off"][lo]), int(a["read_off"][hi])
+    out["read_off"] = (a["read_off"][lo:hi + 1] - r0).astype(np.int32)
+    b0, b1 = int(a["base_off"][r0]), int(a["base_off"][r1])
+    out["base_off"] = (a["base_off"][r0:r1 + 1] - b0).astype(np.int32)
+    out["bases"] = bytes(a["bases"][b0:b1]) + b"\0"; out["quals"] = bytes(a["quals"][b0:b1]) + b"\0"
+    out["read_start"] = a["read_start"][r0:r1].copy()
+    c0, c1 = int(a["cigar_off"][r0]), int(a["cigar_off"][r1])
+    out["cigar_off"] = (a["cigar_off"][r0:r1 + 1] - c0).astype(np.int32)
+    out["cigar_op"] = bytes(a["cigar_op"][c0:c1]) + b"\0"
+    out["cigar_len"] = a["cigar_len"][c0:c1].copy() if c1 > c0 else np.zeros(1, np.int32)
+    out["realign_read"] = None if a["realign_read"] is None else a["realign_read"][r0:r1].copy()
+    return out
+
+
+def batch_from_arrays(a):
+    b = capi.Batch()
+    b.arrays = {k: (np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v) for k, v in a.items()}
+    a = b.arrays
+    s = HipstrBatch()
+    s.n_loci = len(a["period"])
+    for k in ("blk_start", "blk_end", "blk_nopts", "period", "opt_off", "hap_off", "read_off", "base_off", "read_start", "cigar_off", "cigar_len"):
+        setattr(s, k, a[k].ctypes.data_as(_i32p))
+    s.stutter = a["stutter"].ctypes.data_as(_f64p)
+    s.seq, s.bases, s.quals, s.cigar_op = a["seq"], a["bases"], a["quals"], a["cigar_op"]
+    s.realign_hap = None if a["realign_hap"] is None else a["realign_hap"].ctypes.data_as(_u8p)
+    s.realign_read = None if a["realign_read"] is None else a["realign_read"].ctypes.data_as(_u8p)
+    s._keepalive = a
+    b.struct = s
+    return b
+
+
+def run_sharded(arrays, align_fn, rank, world, group=None):
+    """Every rank aligns its contiguous chunk of loci with align_fn(batch_ptr) -> (aln_probs, seeds); rank 0 returns the
+    results of the whole batch in locus order (other ranks return None).  No collective on the data path: one gather."""
+    bounds = split_loci(locus_costs(arrays), world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    local = batch_from_arrays(subset_arrays(arrays, lo, hi))
+    probs, seeds = align_fn(local.ptr) if hi > lo else (np.zeros(0), np.zeros(0, np.int32))
+    if world == 1:
+        return probs, seeds
+    import torch.distributed as dist
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object((probs, seeds), gathered, dst=0, group=group)
+    if rank != 0:
+        return None
+    return np.concatenate([g[0] for g in gathered]), np.concatenate([g[1] for g in gathered])
