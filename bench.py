@@ -137,9 +137,12 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     hmm.hipstr_hmm_profile(dev, 0)
-    ms = (C.c_float * args.steps)()
+    ms = (C.c_float * (4 * args.steps))()
     n_ms = hmm.hipstr_hmm_profile_read(dev, ms, args.steps)
-    kernel_ms = float(np.mean(ms[:n_ms])) if n_ms > 0 else float("nan")
+    phase_ms = np.array(ms[:4 * n_ms], dtype=np.float64).reshape(-1, 4).mean(axis=0) if n_ms > 0 else np.full(4, np.nan)
+    phase_names = ["hs_flank_kernel<C,lead>", "hs_str_kernel", "hs_flank_kernel<C,trail>", "hs_combine_kernel"]
+    dom = int(np.nanargmax(phase_ms)) if n_ms > 0 else 1
+    kernel_ms = float(phase_ms[dom])          # average duration of the dominant kernel (group) per pass
 
     # --- a D2H of the results after the timed region (sanity + the PCIe-inclusive figure for DESIGN.md)
     t0 = time.perf_counter()
@@ -174,11 +177,12 @@ def main():
             "loci_per_sec": total_loci * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": (achieved / 8000.0) if achieved else None, "traffic": None,
-                         "kernel": "hs_forward_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo.value,
+                         "kernel": phase_names[dom], "kernel_ms": kernel_ms,
+                         "phase_ms": dict(zip(phase_names, [float(x) for x in phase_ms])), "algorithmic_bytes_per_launch": algo.value,
                          "bytes_per_alignment": algo.value / max(1, n_aln.value)},
-            "valu": {"dp_cells_per_launch": cells.value, "cells_per_s": cells.value / (kernel_ms * 1e-3) if kernel_ms == kernel_ms else None,
+            "valu": {"dp_cells_per_launch": cells.value, "cells_per_s": cells.value / (float(phase_ms.sum()) * 1e-3) if n_ms > 0 else None,
                      "fp64_ops_per_cell": fp64_ops_per_cell, "fp64_valu_peak_ops_per_s": valu_peak,
-                     "frac": (cells.value * fp64_ops_per_cell / (kernel_ms * 1e-3) / valu_peak) if kernel_ms == kernel_ms else None},
+                     "frac": (cells.value * fp64_ops_per_cell / (float(phase_ms.sum()) * 1e-3) / valu_peak) if n_ms > 0 else None},
             "host": {"synth_s": t_gen, "prepare_upload_s": t_upload, "fetch_s": t_fetch,
                      "value_incl_prepare_pcie": total_aln / world / (t_upload + elapsed / args.steps + t_fetch) * world},
         }

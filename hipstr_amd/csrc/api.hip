@@ -18,9 +18,11 @@
 #include "post_layout.h"
 #include "prep.h"
 
-extern "C" __global__ void hs_forward_kernel(const hs_dev_t* dp);
+extern "C" __global__ void hs_str_kernel(const hs_dev_t* dp, int active_begin);
+extern "C" __global__ void hs_combine_kernel(const hs_dev_t* dp, int active_begin);
 extern "C" __global__ void hs_posterior_kernel(const hs_post_dev_t* dp);
-extern "C" size_t hs_forward_lds_bytes(int lds_len, int lds_flank);
+extern "C" size_t hs_str_lds_bytes(int lds_len);
+extern "C" void hs_launch_flank(int cls, int is_lead, unsigned gx, unsigned gy, hipStream_t st, const hs_dev_t* dp, int item_begin);
 
 namespace {
 
@@ -65,11 +67,11 @@ struct hipstr_dev_batch {
   hs_dev_t h;             // host copy of the argument block (device pointers inside)
   hs_dev_t* d_args = NULL;
   std::vector<void*> allocs;
-  dim3 grid;
+  int grid_y = 1, max_alleles = 1, n_lead_items = 0;
   size_t lds_bytes = 0;
   hipEvent_t ev0 = NULL, ev1 = NULL;
   bool profiling = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t> > prof_pool;   // reusable event pairs
+  std::vector<hipEvent_t> prof_pool;        // reusable events; every pass records 5 per chunk (phase boundaries)
   size_t prof_used = 0;
   int64_t algo_bytes = 0, dp_cells = 0;
 };
@@ -132,7 +134,7 @@ void hipstr_hmm_free(hipstr_dev_batch_t* dev){
   for (void* p : dev->allocs) hipFree(p);
   if (dev->ev0) hipEventDestroy(dev->ev0);
   if (dev->ev1) hipEventDestroy(dev->ev1);
-  for (auto& pr : dev->prof_pool){ hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  for (hipEvent_t e : dev->prof_pool) hipEventDestroy(e);
   delete dev;
 }
 
@@ -140,7 +142,8 @@ hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){
   if (ensure_init()) return NULL;
   hipstr_dev_batch_t* dev = new hipstr_dev_batch_t();
   std::string err;
-  if (hipstr::prepare_batch(batch, dev->prep, err)){ g_err = err; delete dev; return NULL; }
+  const int64_t budget = getenv("HIPSTR_WS_GIB") ? (int64_t)(atof(getenv("HIPSTR_WS_GIB"))*134217728.0) : ((int64_t)3 << 30);   // doubles per workspace
+  if (hipstr::prepare_batch(batch, dev->prep, err, budget)){ g_err = err; delete dev; return NULL; }
   hipstr::Prepared& P = dev->prep;
   {  // SURVEY.md §8(d) algorithmic traffic and flank-cell work of one pass
     int64_t bytes = 0, cells = 0;
@@ -182,20 +185,32 @@ hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){
   h.int_log = g_tab.int_log; h.qual_correct = g_tab.qc; h.qual_error = g_tab.qe; h.m2m = g_tab.m2m; h.m2i = g_tab.m2i;
   h.log_thresh = T.log_thresh; h.log_half = T.log_half;
   h.n_active = (int32_t)P.active.size();
-  h.lds_len = P.max_read_len; h.lds_flank = P.max_flank;
-  h.debug_skip = getenv("HIPSTR_DEBUG_SKIP") ? atoi(getenv("HIPSTR_DEBUG_SKIP")) : 0;
-  // Workgroups: one per active read, times enough allele chunks to put >= ~4096 workgroups on the 256 CUs
+  h.lds_len = P.max_read_len;
+  {  // work items (leading-flank items first, then side items), workspace offsets and the workspaces themselves
+    std::vector<hs_item_t> items(P.lead_items);
+    items.insert(items.end(), P.side_items.begin(), P.side_items.end());
+    dev->n_lead_items = (int)P.lead_items.size();
+    hs_item_t* di = NULL; hs_ws_t* dw = NULL;
+    if (to_device(items, &di) || to_device(P.ws, &dw)){ hipstr_hmm_free(dev); return NULL; }
+    dev->allocs.push_back(di); dev->allocs.push_back(dw);
+    h.items = di; h.ws = dw;
+    double* w = NULL;
+    HS_HIP_NULL(hipMalloc((void**)&w, sizeof(double)*(size_t)(P.ws_mr_size ? P.ws_mr_size : 1))); dev->allocs.push_back(w); h.ws_mr = w;
+    HS_HIP_NULL(hipMalloc((void**)&w, sizeof(double)*(size_t)(P.ws_lt_size ? P.ws_lt_size : 1))); dev->allocs.push_back(w); h.ws_lt = w;
+    HS_HIP_NULL(hipMalloc((void**)&w, sizeof(double)*(size_t)(P.ws_lead_size ? P.ws_lead_size : 1))); dev->allocs.push_back(w); h.ws_lead = w;
+  }
+  // Workgroups: one per (active read[, side]), times enough allele chunks to put >= ~8192 wavefronts on the 256 CUs
   int maxA = 1;
   for (const hs_locus_t& l : P.loci) maxA = l.n_alleles > maxA ? l.n_alleles : maxA;
   int gy = 1;
   if (h.n_active > 0 && h.n_active < 4096){ gy = (4096 + h.n_active - 1) / h.n_active; if (gy > maxA) gy = maxA; }
   h.allele_chunk = (maxA + gy - 1) / gy;
-  gy = (maxA + h.allele_chunk - 1) / h.allele_chunk;
-  dev->grid = dim3(h.n_active > 0 ? h.n_active : 1, gy, 1);
-  dev->lds_bytes = hs_forward_lds_bytes(h.lds_len, h.lds_flank);
+  dev->grid_y = (maxA + h.allele_chunk - 1) / h.allele_chunk;
+  dev->max_alleles = maxA;
+  dev->lds_bytes = hs_str_lds_bytes(h.lds_len);
   if (dev->lds_bytes > 160*1024){ g_err = "batch needs more than 160 KiB of LDS per workgroup"; hipstr_hmm_free(dev); return NULL; }
   if (dev->lds_bytes > 48*1024)
-    HS_HIP_NULL(hipFuncSetAttribute((const void*)hs_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->lds_bytes));
+    HS_HIP_NULL(hipFuncSetAttribute((const void*)hs_str_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->lds_bytes));
   HS_HIP_NULL(hipMalloc((void**)&dev->d_args, sizeof(hs_dev_t))); dev->allocs.push_back(dev->d_args);
   HS_HIP_NULL(hipMemcpy(dev->d_args, &h, sizeof h, hipMemcpyHostToDevice));
   HS_HIP_NULL(hipEventCreate(&dev->ev0)); HS_HIP_NULL(hipEventCreate(&dev->ev1));
@@ -206,19 +221,32 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
   if (!dev) return fail("null device batch");
   if (dev->h.n_active == 0) return 0;
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_tab.stream;
-  std::pair<hipEvent_t, hipEvent_t>* pr = NULL;
-  if (dev->profiling){
-    if (dev->prof_used == dev->prof_pool.size()){
-      hipEvent_t a, b;
-      HS_HIP(hipEventCreate(&a)); HS_HIP(hipEventCreate(&b));
-      dev->prof_pool.push_back(std::make_pair(a, b));
+  const hs_dev_t* dp = dev->d_args;
+  auto mark = [&]() -> int {
+    if (!dev->profiling) return 0;
+    if (dev->prof_used == dev->prof_pool.size()){ hipEvent_t e; HS_HIP(hipEventCreate(&e)); dev->prof_pool.push_back(e); }
+    HS_HIP(hipEventRecord(dev->prof_pool[dev->prof_used++], st));
+    return 0;
+  };
+  for (const hipstr::Prepared::Chunk& ch : dev->prep.chunks){
+    const unsigned nact = ch.active_end - ch.active_begin;
+    if (mark()) return 1;
+    for (int c = 0; c < 4; c++){       // leading flanks, by columns-per-lane class
+      const int cnt = ch.lead_begin[c+1] - ch.lead_begin[c];
+      if (cnt > 0) hs_launch_flank(c+1, 1, cnt, 1, st, dp, ch.lead_begin[c]);
     }
-    pr = &dev->prof_pool[dev->prof_used++];
-    HS_HIP(hipEventRecord(pr->first, st));
+    if (mark()) return 1;
+    hipLaunchKernelGGL(hs_str_kernel, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin);
+    if (mark()) return 1;
+    for (int c = 0; c < 4; c++){       // trailing flanks
+      const int cnt = ch.side_begin[c+1] - ch.side_begin[c];
+      if (cnt > 0) hs_launch_flank(c+1, 0, cnt, dev->grid_y, st, dp, dev->n_lead_items + ch.side_begin[c]);
+    }
+    if (mark()) return 1;
+    hipLaunchKernelGGL(hs_combine_kernel, dim3(nact, (dev->max_alleles + 3)/4), dim3(256), 0, st, dp, ch.active_begin);
+    if (mark()) return 1;
+    HS_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(hs_forward_kernel, dev->grid, dim3(128), dev->lds_bytes, st, (const hs_dev_t*)dev->d_args);
-  HS_HIP(hipGetLastError());
-  if (pr) HS_HIP(hipEventRecord(pr->second, st));
   return 0;
 }
 
@@ -228,12 +256,22 @@ int hipstr_hmm_profile(hipstr_dev_batch_t* dev, int enable){
   return 0;
 }
 
+// ms[4*i + {0,1,2,3}] = {leading flanks, STR block, trailing flanks, combine} of pass i (summed over chunks)
 int hipstr_hmm_profile_read(hipstr_dev_batch_t* dev, float* ms, int cap){
   if (!dev || !ms) return -1;
+  const size_t per_pass = 5 * dev->prep.chunks.size();
+  if (per_pass == 0) return 0;
   int n = 0;
-  for (size_t i = 0; i < dev->prof_used && n < cap; i++, n++){
-    if (hipEventSynchronize(dev->prof_pool[i].second) != hipSuccess) return -1;
-    if (hipEventElapsedTime(&ms[n], dev->prof_pool[i].first, dev->prof_pool[i].second) != hipSuccess) return -1;
+  for (size_t base = 0; base + per_pass <= dev->prof_used && n < cap; base += per_pass, n++){
+    float acc[4] = {0, 0, 0, 0};
+    for (size_t c = 0; c < dev->prep.chunks.size(); c++)
+      for (int ph = 0; ph < 4; ph++){
+        hipEvent_t a = dev->prof_pool[base + 5*c + ph], b = dev->prof_pool[base + 5*c + ph + 1];
+        float t = 0;
+        if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&t, a, b) != hipSuccess) return -1;
+        acc[ph] += t;
+      }
+    for (int ph = 0; ph < 4; ph++) ms[4*n + ph] = acc[ph];
   }
   dev->prof_used = 0;
   return n;
@@ -255,7 +293,7 @@ int hipstr_hmm_align_timed(hipstr_dev_batch_t* dev, int reps, float* ms_total, f
   HS_HIP(hipEventRecord(dev->ev1, st));
   HS_HIP(hipEventSynchronize(dev->ev1));
   HS_HIP(hipEventElapsedTime(ms_total, dev->ev0, dev->ev1));
-  if (ms_kernel) *ms_kernel = *ms_total;     // the pass is a single kernel
+  if (ms_kernel) *ms_kernel = *ms_total;
   return 0;
 }
 

@@ -60,12 +60,19 @@ struct hs_allele_t {
   int32_t str_opt[2];        // hs_stropt_t index per side
   int32_t n_flank;           // F0 + F2: number of non-STR haplotype bases (compute_aln_logprob's num_seeds)
   int32_t realign;           // realign_to_haplotype flag
+  int32_t lead_slot[2];      // which of the locus' distinct leading-flank rowsets (per side) this allele uses
+  int32_t re_ord;            // ordinal among the realigned alleles of the locus (workspace row)
+  int32_t pad;
 };
 
 struct hs_locus_t {
   int64_t out_off;           // offset of this locus' [P x A] block in aln_probs
   int32_t hap_begin, n_alleles;
   int32_t read_begin, n_reads;
+  int32_t n_re;              // realigned alleles
+  int32_t lt_stride;         // max n_flank over realigned alleles: stride of the trailing last-column workspace
+  int32_t lead_flank[2];     // max leading-flank length per side (lead workspace record = n_side + lead_flank + 1 doubles)
+  int32_t n_lead[2];         // distinct leading-flank rowsets per side
 };
 
 struct hs_read_t {
@@ -74,6 +81,16 @@ struct hs_read_t {
   int32_t seed;              // calc_seed_base result (-1 = none)
   int32_t locus;
 };
+
+// Workspace offsets (in doubles) of one active read inside the current chunk's workspaces.
+//   mr   : [n_re][len-1]   M of the STR block's last row, left side columns then right side columns
+//   lt   : [n_re][lt_stride] last read column of the trailing-flank rows: left side (F2 rows) then right side (F0 rows)
+//   lead : per side [n_lead][n_side + lead_flank + 1]: rowP (M of the row before the STR block) | last column of the
+//          leading-flank rows | side_prob
+struct hs_ws_t { int64_t mr, lt, lead[2]; };
+
+// Work items of the phase kernels (sorted by columns-per-lane class where the kernel is templated on it).
+struct hs_item_t { int32_t active; int32_t side; int32_t rowset; int32_t slot; };
 
 // Kernel argument block (all device pointers).
 struct hs_dev_t {
@@ -89,6 +106,11 @@ struct hs_dev_t {
   const char*        bases;
   const char*        quals;
   const int32_t*     active;     // read indices that need alignment (realign && seed >= 0)
+  const hs_ws_t*     ws;         // [n_active] workspace offsets
+  const hs_item_t*   items;      // lead items and side items, grouped (see api.hip)
+  double*            ws_mr;
+  double*            ws_lt;
+  double*            ws_lead;
   double*            aln_probs;
   // constant tables
   const double*      int_log;    // [10000]
@@ -100,7 +122,6 @@ struct hs_dev_t {
   double             log_half;     // LOG_ONE_HALF, mathops.cpp:9
   int32_t            n_active;
   int32_t            allele_chunk;   // alleles per workgroup
-  int32_t            lds_len;        // max read length in the batch (LDS carve)
-  int32_t            lds_flank;      // max n_flank + 1
-  int32_t            debug_skip;     // timing experiments only (HIPSTR_DEBUG_SKIP): 1 = skip STR phase, 2 = skip flank sweeps, 4 = skip combine
+  int32_t            lds_len;        // max read length in the batch (LDS carve of the STR kernel)
+  int32_t            pad;
 };

@@ -256,7 +256,7 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
 
 }  // namespace
 
-int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err){
+int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int64_t ws_budget){
   host_tables();
   if (b == NULL || b->n_loci < 0){ err = "null or negative-size batch"; return 1; }
   const int n_reads_total = b->n_loci > 0 ? b->read_off[b->n_loci] : 0;
@@ -268,6 +268,7 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err){
   out.quals.assign(b->quals ? b->quals : "", total_bases);
   int opt_cursor = 0;
   int64_t out_off = 0;
+  std::vector< std::vector<int> > locus_leads;      // [2*locus + side] -> rowset ids by slot
   for (int l = 0; l < b->n_loci; l++){
     const int period = b->period[l];
     if (period < 1 || period > 9){ err = "STR period must be in [1,9] (stutter_model.h:38)"; return 1; }
@@ -319,6 +320,8 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err){
     bool reuse = false;
     int lead_id[2] = {-1, -1};
     int n_realigned = 0;
+    std::vector<int> lead_sets[2];          // distinct leading-flank rowsets per side, in order of first use
+    loc.lt_stride = 0; loc.lead_flank[0] = loc.lead_flank[1] = 0;
     for (int k = 0; k < A; k++){
       const bool realign = b->realign_hap ? b->realign_hap[b->hap_off[l]+k] != 0 : true;
       out.realign_hap.push_back(realign ? 1 : 0);
@@ -329,7 +332,8 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err){
       al.n_flank = opt[0][o3[0]].size() + opt[2][o3[2]].size();
       out.max_flank = std::max(out.max_flank, al.n_flank);
       if (!realign){ reuse = false; out.alleles.push_back(al); continue; }
-      n_realigned++;
+      al.re_ord = n_realigned++;
+      loc.lt_stride = std::max(loc.lt_stride, al.n_flank);
       const int cb = k == 0 ? -1 : changed_block(nopts, k);
       for (int side = 0; side < 2; side++){
         SideSeqs h;
@@ -341,6 +345,13 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err){
         const int side_changed = cb < 0 ? -1 : (side ? 2-cb : cb);
         if (!reuse || side_changed <= 0) lead_id[side] = intern(flank_rows(h, 0, 0));
         al.lead_rows[side]  = lead_id[side];
+        {
+          std::vector<int>& ls = lead_sets[side];
+          size_t slot = std::find(ls.begin(), ls.end(), lead_id[side]) - ls.begin();
+          if (slot == ls.size()) ls.push_back(lead_id[side]);
+          al.lead_slot[side] = (int32_t)slot;
+          loc.lead_flank[side] = std::max(loc.lead_flank[side], (int32_t)h.s[0].size());
+        }
         al.trail_rows[side] = intern(flank_rows(h, 2, (int)h.s[0].size() + 1));
         al.str_opt[side]    = so_base + side*nopts[1] + o3[1];
       }
@@ -348,6 +359,9 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err){
       out.alleles.push_back(al);
     }
 
+    loc.n_re = n_realigned;
+    loc.n_lead[0] = lead_sets[0].size(); loc.n_lead[1] = lead_sets[1].size();
+    locus_leads.push_back(lead_sets[0]); locus_leads.push_back(lead_sets[1]);
     for (int r = loc.read_begin; r < loc.read_begin + loc.n_reads; r++){
       hs_read_t rd;
       rd.base_off = b->base_off[r]; rd.len = b->base_off[r+1]-b->base_off[r]; rd.locus = l; rd.seed = -1;
@@ -371,6 +385,53 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err){
     out_off += (int64_t)loc.n_reads * A;
   }
   out.n_out = out_off;
+
+  // ---- launch plan: workspaces + work items, chunked so that the workspaces stay within the budget
+  out.ws.resize(out.active.size());
+  Prepared::Chunk ch; memset(&ch, 0, sizeof ch);
+  int64_t mr = 0, lt = 0, lead = 0;
+  std::vector<hs_item_t> lead_tmp[4], side_tmp[4];
+  auto flush = [&](int active_end){
+    ch.active_end = active_end;
+    for (int c = 0; c < 4; c++){
+      ch.lead_begin[c] = out.lead_items.size(); out.lead_items.insert(out.lead_items.end(), lead_tmp[c].begin(), lead_tmp[c].end()); lead_tmp[c].clear();
+    }
+    ch.lead_begin[4] = out.lead_items.size();
+    for (int c = 0; c < 4; c++){
+      ch.side_begin[c] = out.side_items.size(); out.side_items.insert(out.side_items.end(), side_tmp[c].begin(), side_tmp[c].end()); side_tmp[c].clear();
+    }
+    ch.side_begin[4] = out.side_items.size();
+    out.ws_mr_size = std::max(out.ws_mr_size, mr); out.ws_lt_size = std::max(out.ws_lt_size, lt); out.ws_lead_size = std::max(out.ws_lead_size, lead);
+    if (ch.active_end > ch.active_begin) out.chunks.push_back(ch);
+    memset(&ch, 0, sizeof ch); ch.active_begin = active_end;
+    mr = lt = lead = 0;
+  };
+  for (size_t ai = 0; ai < out.active.size(); ai++){
+    const hs_read_t& rd = out.reads[out.active[ai]];
+    const hs_locus_t& loc = out.loci[rd.locus];
+    const int n_side[2] = { rd.seed, rd.len - rd.seed - 1 };
+    const int64_t need_mr = (int64_t)loc.n_re*(rd.len-1), need_lt = (int64_t)loc.n_re*loc.lt_stride;
+    int64_t need_lead = 0;
+    for (int s = 0; s < 2; s++) need_lead += (int64_t)loc.n_lead[s]*(n_side[s] + loc.lead_flank[s] + 1);
+    if (ch.active_begin < (int)ai && (mr + need_mr > ws_budget || lt + need_lt > ws_budget || lead + need_lead > ws_budget)) flush((int)ai);
+    hs_ws_t w; w.mr = mr; w.lt = lt;
+    for (int s = 0; s < 2; s++){
+      w.lead[s] = lead;
+      const std::vector<int>& ls = locus_leads[2*rd.locus + s];
+      const int cls = (n_side[s] + 63)/64 - 1;
+      for (size_t slot = 0; slot < ls.size(); slot++){
+        hs_item_t it; it.active = (int32_t)ai; it.side = s; it.rowset = ls[slot]; it.slot = (int32_t)slot;
+        lead_tmp[cls].push_back(it);
+      }
+      hs_item_t it; it.active = (int32_t)ai; it.side = s; it.rowset = -1; it.slot = 0;
+      side_tmp[cls].push_back(it);
+      lead += (int64_t)loc.n_lead[s]*(n_side[s] + loc.lead_flank[s] + 1);
+    }
+    out.ws[ai] = w;
+    mr += need_mr; lt += need_lt;
+    ch.n_alignments += loc.n_re;
+  }
+  flush((int)out.active.size());
   return 0;
 }
 

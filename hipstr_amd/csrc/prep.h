@@ -36,6 +36,18 @@ struct Prepared {
   std::vector<uint8_t>     realign_read;   // per read
   std::vector<uint8_t>     realign_hap;    // per global allele
   std::string              bases, quals;
+  // ---- launch plan: the batch is cut into chunks of consecutive active reads whose workspaces fit the budget
+  struct Chunk {
+    int32_t active_begin, active_end;      // range in `active`
+    int32_t lead_begin[5];                 // lead_items range per columns-per-lane class 1..4 (begin[c-1] .. begin[c])
+    int32_t side_begin[5];                 // side_items range per class
+    int64_t n_alignments;
+  };
+  std::vector<Chunk>      chunks;
+  std::vector<hs_ws_t>    ws;              // per active read, offsets inside its chunk's workspaces
+  std::vector<hs_item_t>  lead_items;      // (active, side, rowset, slot): leading flank to compute once per read
+  std::vector<hs_item_t>  side_items;      // (active, side): trailing-flank sweeps
+  int64_t ws_mr_size = 0, ws_lt_size = 0, ws_lead_size = 0;   // doubles, max over chunks
   int64_t n_out        = 0;
   int64_t n_alignments = 0;   // (active read) x (realigned allele) pairs = HMM alignments per pass
   int32_t max_read_len = 0;
@@ -43,7 +55,7 @@ struct Prepared {
 };
 
 // Returns 0 on success; otherwise fills err.
-int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err);
+int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int64_t ws_budget_doubles = (int64_t)3 << 30);
 
 // HapAligner::calc_seed_base (HapAligner.cpp:238-318).  Returns -2 on the inputs the reference dies on.
 int calc_seed_base(const hipstr_batch_t* b, int locus, int read);

@@ -113,10 +113,11 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream);
  * *ms_kernel (may be NULL) = time of the dominant DP kernel only. */
 int hipstr_hmm_align_timed(hipstr_dev_batch_t* dev, int reps, float* ms_total, float* ms_kernel);
 
-/* Per-launch timing of the forward kernel with HIP events recorded on the launch stream: after
- * hipstr_hmm_profile(dev, 1) every hipstr_hmm_align call brackets its kernel with an event pair;
- * hipstr_hmm_profile_read synchronises and returns up to `cap` launch durations (ms), oldest first,
- * and clears the log.  Returns the number of durations written, or -1. */
+/* Per-pass, per-phase timing with HIP events recorded on the launch stream: after hipstr_hmm_profile(dev, 1)
+ * every hipstr_hmm_align call records events at its phase boundaries; hipstr_hmm_profile_read synchronises and
+ * writes, for up to `cap` passes (oldest first), four durations in ms: ms[4*i+0] leading-flank kernels,
+ * [4*i+1] STR-block kernel, [4*i+2] trailing-flank kernels, [4*i+3] combine kernel; then clears the log.
+ * Returns the number of passes written, or -1. */
 int hipstr_hmm_profile(hipstr_dev_batch_t* dev, int enable);
 int hipstr_hmm_profile_read(hipstr_dev_batch_t* dev, float* ms, int cap);
 
