@@ -270,8 +270,10 @@ struct StrLds {     // one side of one read
   double*  Mt;      // [n] StutterAligner match_probs_
   double*  Dl;      // [6][ld] StutterAligner del_probs_
   uint8_t* rd;      // [n] read bases
+  const double* ilog;   // [HS_ILOG_LDS] LDS copy of int_log(0..): ln of block-length-sized integers
   int ld;
 };
+#define HS_ILOG_LDS 264
 
 // Marginalisation over the artifact position (StutterAlignerClass.cpp:59-104 insertion, :106-150 deletion).
 // The loop over block offsets is the same for every read column, so the host enumerated it (hs_visit_t) and
@@ -281,19 +283,20 @@ struct StrLds {     // one side of one read
 //   stride  distance between those bases: p for an insertion, 0 for a deletion
 //   tail    number of remaining equal-likelihood configurations is (tail - offset): B (insertion) or B+D (deletion)
 __device__ __forceinline__ double visit_eval(const hs_dev_t& d, const StrLds& L, int j, double lp0, int lim, int limmax,
-                                             const hs_visit_t* __restrict__ list, int llen, int nsub, int stride, int tail){
-  const int lane = threadIdx.x & 63;
+                                             const hs_visit_t& bundle, int rel, const hs_visit_t* __restrict__ list, int llen,
+                                             int nsub, int stride, int tail){
+  // `bundle` holds the first 64 visiting-list entries of this STR option, one per lane (all seven lists back to back);
+  // the list evaluated here starts at bundle entry `rel` and at `list` in memory (used only beyond the bundle).
   Lse acc;
   for (int pass = 0; pass < 2; pass++){
     double lp = lp0;
     acc.start(pass, lp0);
     acc.push(pass, lp0, d.log_thresh);
     int nistop = 0; bool stopped = false;
-    int vbase = 0;
-    hs_visit_t vv = list[min(lane, llen-1)];
     for (int v = 0; v < llen; v++){
-      if (v - vbase == 64){ vbase += 64; vv = list[min(vbase + lane, llen-1)]; }
-      const uint64_t meta = rdlane(vv.meta, v - vbase);
+      uint64_t meta; double logU;
+      if (rel + v < 64){ meta = rdlane(bundle.meta, rel + v); logU = rdlane(bundle.logU, rel + v); }
+      else { const hs_visit_t e = list[v]; meta = rdlane(e.meta, 0); logU = rdlane(e.logU, 0); }
       const int ni = (int)(meta & 0xffff);
       if (ni >= limmax){ if (!stopped) nistop = ni; break; }
       const bool act = ni < lim;
@@ -309,11 +312,10 @@ __device__ __forceinline__ double visit_eval(const hs_dev_t& d, const StrLds& L,
         }
         if (act) acc.push(pass, lp, d.log_thresh);
       } else {
-        const double logU = rdlane(vv.logU, v - vbase);
         if (act) acc.push(pass, logU + lp, d.log_thresh);
       }
     }
-    if (nistop < tail) acc.push(pass, d.int_log[tail - nistop] + lp, d.log_thresh);
+    if (nistop < tail) acc.push(pass, L.ilog[tail - nistop] + lp, d.log_thresh);
   }
   return acc.finish();
 }
@@ -325,7 +327,7 @@ extern __shared__ double hs_lds_raw[];
 // LDS bytes of one hs_str_kernel workgroup (both sides of a read) for a batch whose longest read has lds_len bases.
 extern "C" size_t hs_str_lds_bytes(int lds_len){
   const size_t Lc = ((size_t)lds_len + 3) & ~(size_t)1;
-  return Lc*16 + Lc*8*2 + Lc*8*HS_MAXREP + ((Lc + 15) & ~(size_t)15);
+  return Lc*16 + Lc*8*2 + Lc*8*HS_MAXREP + HS_ILOG_LDS*8 + ((Lc + 15) & ~(size_t)15);
 }
 
 // Workgroup = one active read: wave 0 the left side, wave 1 the right side (independent; they share only the LDS
@@ -345,9 +347,12 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
     double* rowP = (double*)(bq + Lc);
     double* Mt = rowP + Lc;
     double* Dl = Mt + Lc;
-    uint8_t* rdb = (uint8_t*)(Dl + HS_MAXREP*Lc);
-    L.bq = bq + o; L.rowP = rowP + o; L.Mt = Mt + o; L.Dl = Dl + o; L.rd = rdb + o; L.ld = Lc;
+    double* ilog = Dl + HS_MAXREP*Lc;
+    uint8_t* rdb = (uint8_t*)(ilog + HS_ILOG_LDS);
+    L.bq = bq + o; L.rowP = rowP + o; L.Mt = Mt + o; L.Dl = Dl + o; L.rd = rdb + o; L.ilog = ilog; L.ld = Lc;
+    for (int i = threadIdx.x; i < HS_ILOG_LDS; i += 128) ilog[i] = d.int_log[i];
   }
+  __syncthreads();
   for (int j = lane; j < n; j += 64){
     const int src = v.base_off + (w ? v.len - 1 - j : j);
     const uint8_t q = (uint8_t)d.quals[src];
@@ -375,8 +380,14 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
     c.blkv = ((const int*)(d.chars + uni(c.so->seq_off)))[min(lane, (c.B + 3)/4 - 1)];
     c.cst = d.f64pool[uni(c.so->f64_off) + min(lane, 19)];
     const int B = c.B, p = c.p;
-    const hs_visit_t* ins_list = d.visits + uni(c.so->ins_off);
-    const int ins_len = uni(c.so->ins_len);
+    // all seven visiting lists of the option sit back to back in memory: one coalesced 16 B/lane load brings the first
+    // 64 entries; list offsets/lengths ride in one lane-indexed register (lane q: deletion list q, lane 6: insertion list)
+    const int ins_off = uni(c.so->ins_off), ins_len = uni(c.so->ins_len);
+    const hs_visit_t* ins_list = d.visits + ins_off;
+    const int lofs = (lane < HS_MAXREP) ? c.so->del_off[lane] - ins_off : 0;
+    const int llen = (lane < HS_MAXREP) ? c.so->del_len[lane] : 0;
+    const int total = uni(c.so->del_off[HS_MAXREP-1]) + uni(c.so->del_len[HS_MAXREP-1]) - ins_off;
+    const hs_visit_t bundle = ins_list[min(lane, max(total, ins_len) - 1)];
 
     // --- StutterAlignerClass::load_read (StutterAlignerClass.cpp:12-53): match_probs_ and del_probs_
     for (int kk = 0; kk < ncyc; kk++){
@@ -427,7 +438,7 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
           const double lp0 = (rdlane(c.cst, 13) + li) + ((len > D) ? L.Mt[max(j - D, 0)] : 0.0);
           const int lim = actj ? min(max(0, len - D), B) : 0;
           const int limmax = min(max(0, min(B + D, jmax + 1) - D), B);
-          const double S = visit_eval(d, L, j, lp0, lim, limmax, ins_list, ins_len, q+1, p, B);
+          const double S = visit_eval(d, L, j, lp0, lim, limmax, bundle, 0, ins_list, ins_len, q+1, p, B);
           const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
           term = (rdlane(c.cst, HS_MAXREP + 1 + q) + S) + pre;
         } else {                                     // deletion of aD = (q+1) p bases
@@ -448,7 +459,8 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
             }
             const int lim = actj ? len : 0;
             const int limmax = min(B - aD, jmax + 1);
-            const double S = visit_eval(d, L, j, lp0, lim, limmax, d.visits + uni(c.so->del_off[q]), uni(c.so->del_len[q]), 1, 0, B - aD);
+            const int rel = rdlane(lofs, q);
+            const double S = visit_eval(d, L, j, lp0, lim, limmax, bundle, rel, ins_list + rel, rdlane(llen, q), 1, 0, B - aD);
             const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
             term = (rdlane(c.cst, HS_MAXREP - 1 - q) + S) + pre;
           }
