@@ -8,6 +8,7 @@
 
 #include <cfloat>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <cstdlib>
 #include <string>
@@ -22,7 +23,8 @@ extern "C" __global__ void hs_str_kernel(const hs_dev_t* dp, int active_begin);
 extern "C" __global__ void hs_combine_kernel(const hs_dev_t* dp, int active_begin);
 extern "C" __global__ void hs_posterior_kernel(const hs_post_dev_t* dp);
 extern "C" size_t hs_str_lds_bytes(int lds_len);
-extern "C" void hs_launch_flank(int cls, int is_lead, unsigned gx, unsigned gy, hipStream_t st, const hs_dev_t* dp, int item_begin);
+extern "C" void hs_launch_lead(int cls, unsigned gx, hipStream_t st, const hs_dev_t* dp, int item_begin);
+extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end);
 
 namespace {
 
@@ -67,7 +69,7 @@ struct hipstr_dev_batch {
   hs_dev_t h;             // host copy of the argument block (device pointers inside)
   hs_dev_t* d_args = NULL;
   std::vector<void*> allocs;
-  int grid_y = 1, max_alleles = 1, n_lead_items = 0;
+  int grid_y = 1, max_alleles = 1, n_lead_items = 0, trail_waves = 1;
   size_t lds_bytes = 0;
   hipEvent_t ev0 = NULL, ev1 = NULL;
   bool profiling = false;
@@ -188,7 +190,7 @@ hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){
   h.lds_len = P.max_read_len;
   {  // work items (leading-flank items first, then side items), workspace offsets and the workspaces themselves
     std::vector<hs_item_t> items(P.lead_items);
-    items.insert(items.end(), P.side_items.begin(), P.side_items.end());
+    items.insert(items.end(), P.trail_items.begin(), P.trail_items.end());
     dev->n_lead_items = (int)P.lead_items.size();
     hs_item_t* di = NULL; hs_ws_t* dw = NULL;
     if (to_device(items, &di) || to_device(P.ws, &dw)){ hipstr_hmm_free(dev); return NULL; }
@@ -198,6 +200,14 @@ hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){
     HS_HIP_NULL(hipMalloc((void**)&w, sizeof(double)*(size_t)(P.ws_mr_size ? P.ws_mr_size : 1))); dev->allocs.push_back(w); h.ws_mr = w;
     HS_HIP_NULL(hipMalloc((void**)&w, sizeof(double)*(size_t)(P.ws_lt_size ? P.ws_lt_size : 1))); dev->allocs.push_back(w); h.ws_lt = w;
     HS_HIP_NULL(hipMalloc((void**)&w, sizeof(double)*(size_t)(P.ws_lead_size ? P.ws_lead_size : 1))); dev->allocs.push_back(w); h.ws_lead = w;
+    HS_HIP_NULL(hipMalloc((void**)&w, sizeof(double)*(size_t)(P.ws_col_size ? P.ws_col_size : 1))); dev->allocs.push_back(w); h.ws_col = w;
+    // trailing-flank kernel: persistent wavefronts, each with two band-boundary rows of [max side columns][64 lanes][M,D]
+    h.band_cols = P.max_side_len > 0 ? P.max_side_len : 1;
+    dev->trail_waves = (int)std::min<size_t>(P.trail_items.size() ? P.trail_items.size() : 1, 256 * 24);
+    HS_HIP_NULL(hipMalloc((void**)&w, sizeof(double)*(size_t)dev->trail_waves*2*h.band_cols*64*2)); dev->allocs.push_back(w); h.ws_band = w;
+    hs_tgroup_t* dg = NULL; int32_t* dm = NULL;
+    if (to_device(P.tgroups, &dg) || to_device(P.tmembers, &dm)){ hipstr_hmm_free(dev); return NULL; }
+    dev->allocs.push_back(dg); dev->allocs.push_back(dm); h.tgroups = dg; h.tmembers = dm;
   }
   // Workgroups: one per (active read[, side]), times enough allele chunks to put >= ~8192 wavefronts on the 256 CUs
   int maxA = 1;
@@ -233,15 +243,14 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
     if (mark()) return 1;
     for (int c = 0; c < 4; c++){       // leading flanks, by columns-per-lane class
       const int cnt = ch.lead_begin[c+1] - ch.lead_begin[c];
-      if (cnt > 0) hs_launch_flank(c+1, 1, cnt, 1, st, dp, ch.lead_begin[c]);
+      if (cnt > 0) hs_launch_lead(c+1, cnt, st, dp, ch.lead_begin[c]);
     }
     if (mark()) return 1;
     hipLaunchKernelGGL(hs_str_kernel, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin);
     if (mark()) return 1;
-    for (int c = 0; c < 4; c++){       // trailing flanks
-      const int cnt = ch.side_begin[c+1] - ch.side_begin[c];
-      if (cnt > 0) hs_launch_flank(c+1, 0, cnt, dev->grid_y, st, dp, dev->n_lead_items + ch.side_begin[c]);
-    }
+    if (ch.trail_end > ch.trail_begin)     // trailing flanks: persistent wavefronts striding over (read side, allele group) items
+      hs_launch_trail((unsigned)std::min(dev->trail_waves, ch.trail_end - ch.trail_begin), st, dp,
+                      dev->n_lead_items + ch.trail_begin, dev->n_lead_items + ch.trail_end);
     if (mark()) return 1;
     hipLaunchKernelGGL(hs_combine_kernel, dim3(nact, (dev->max_alleles + 3)/4), dim3(256), 0, st, dp, ch.active_begin);
     if (mark()) return 1;

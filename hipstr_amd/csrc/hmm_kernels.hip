@@ -12,7 +12,10 @@
 //   hs_str_kernel             STR block (HapAligner.cpp:62-109 + StutterAlignerClass.cpp): one lane per read
 //                             column, 13 artifact sizes, artifact position marginalised by replaying a
 //                             host-enumerated visiting list broadcast with v_readlane.    -> MR
-//   hs_flank_kernel<C,false>  trailing flank per allele.                                  -> last column
+//   hs_trail_kernel<R>        trailing flank: the same recurrence, but with ALLELES as lanes: all alleles of a locus
+//                             share the read and (per group) the flank rows, so emissions and transitions are
+//                             wave-uniform scalars and a lane needs no neighbour at all; the matrix is swept in
+//                             bands of R haplotype rows held in registers.                 -> last column
 //   hs_combine_kernel         compute_aln_logprob (HapAligner.cpp:163-231): log-sum-exp over seed positions.
 //
 // The flank recurrence is swept along anti-diagonals as a systolic array: lane t owns C consecutive read
@@ -52,6 +55,9 @@ __device__ __forceinline__ uint64_t rdlane(uint64_t v, int l){
 __device__ __forceinline__ int uni(int v){ return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int64_t uni(int64_t v){
   return ((int64_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+__device__ __forceinline__ double uni(double v){
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 __device__ __forceinline__ void wave_lds_sync(){
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -97,7 +103,7 @@ __device__ __forceinline__ double emit(uint8_t r, uint8_t c, double2 q){ return 
 struct SideView {
   int ai, r, side, n, nL, len, base_off;
   const hs_locus_t* loc;
-  int64_t ws_mr, ws_lt, ws_lead;
+  int64_t ws_mr, ws_lt, ws_lead, ws_col;
 };
 __device__ __forceinline__ SideView side_view(const hs_dev_t& d, int ai, int side){
   SideView v;
@@ -107,7 +113,7 @@ __device__ __forceinline__ SideView side_view(const hs_dev_t& d, int ai, int sid
   v.len = uni(rd->len); v.nL = uni(rd->seed); v.base_off = uni(rd->base_off);
   v.n = side ? v.len - v.nL - 1 : v.nL;
   v.loc = d.loci + uni(rd->locus);
-  v.ws_mr = uni(d.ws[ai].mr); v.ws_lt = uni(d.ws[ai].lt); v.ws_lead = uni(d.ws[ai].lead[side]);
+  v.ws_mr = uni(d.ws[ai].mr); v.ws_lt = uni(d.ws[ai].lt); v.ws_lead = uni(d.ws[ai].lead[side]); v.ws_col = uni(d.ws[ai].col);
   return v;
 }
 // lead workspace record of (side, slot): rowP[n] | last column of the leading-flank rows [lead_flank] | side_prob
@@ -139,6 +145,14 @@ __global__ void __launch_bounds__(64) hs_flank_kernel(const hs_dev_t* __restrict
     blc[k] = d.qual_correct[q]; blw[k] = d.qual_error[q];
   }
   const double tab_m2m = d.m2m[lane & 15], tab_m2i = d.m2i[lane & 15];
+  if (IS_LEAD){   // per-column emission logs in side orientation, for the scalar loads of hs_trail_kernel
+    double* col = d.ws_col + v.ws_col + 3*(int64_t)(v.side ? v.nL : 0);
+#pragma unroll
+    for (int k = 0; k < C; k++){
+      const int j = lane*C + k;
+      if (j < n){ col[3*j] = blc[k]; col[3*j+1] = blw[k]; col[3*j+2] = (double)rd[k]; }
+    }
+  }
 
   const int k0 = IS_LEAD ? 0 : blockIdx.y * d.allele_chunk;
   const int k1 = IS_LEAD ? 1 : min(uni(v.loc->n_alleles), k0 + d.allele_chunk);
@@ -249,6 +263,146 @@ __global__ void __launch_bounds__(64) hs_flank_kernel(const hs_dev_t* __restrict
     if (IS_LEAD){
 #pragma unroll
       for (int kk = 0; kk < C; kk++){ const int j = lane*C + kk; if (j < n) lead_rec[j] = Mrow[kk]; }     // rowP
+    }
+  }
+}
+
+// ------------------------------------------------------------------ trailing flank: alleles as lanes, banded sweep
+// Work item = (read side, group of <= 64 alleles sharing the trailing-flank rowset).  Lane = allele.  Every quantity
+// that depends on the read column or on the haplotype row — base, log P(correct/error), flank base, transition
+// logs, hence the emission — is wave-uniform and lives in SGPRs; a lane only carries its own M/I/D values, so the
+// recurrence (HapAligner.cpp:144-153) needs no cross-lane traffic, no emission select and no pipeline fill.
+// The matrix is swept column by column in bands of R rows whose previous-column M/I/D sit in registers; the last
+// row of a band goes to a per-wavefront scratch row (L2-resident) and comes back as the next band's top boundary.
+// Persistent wavefronts: blockIdx.x strides over the items so that the scratch is per wavefront, not per item.
+// One band of NR haplotype rows (fully unrolled, branch-free per row) swept over all n read columns.
+//   FIRST: the band's top boundary is the "must be followed by a match" row, built from MR (HapAligner.cpp:130-139);
+//          otherwise it is read from `bin`, written by the previous band.   LAST: no bottom boundary is written.
+template <int NR, bool FIRST, bool LAST>
+__device__ __forceinline__ void band_sweep(const hs_dev_t& d, int lane, bool live, int n, const double* __restrict__ col,
+                                           const hs_row_t* __restrict__ rows, int row0, int c0,
+                                           const double* __restrict__ mr, const double* __restrict__ bin, double* __restrict__ bout,
+                                           double* __restrict__ lt){
+  int hc[NR]; double m2m[NR], m2i[NR];
+#pragma unroll
+  for (int r = 0; r < NR; r++){
+    const int meta = uni((int)rows[row0 + r]);
+    hc[r] = meta & 0xff;
+    m2m[r] = uni(d.m2m[(meta >> 8) & 15]); m2i[r] = uni(d.m2i[(meta >> 8) & 15]);
+  }
+  double Mp[NR], Dp[NR], Ip[NR];
+  // software pipeline: the loads of column j+1 are issued before column j is computed
+  double nx_blc = col[0], nx_blw = col[1], nx_rd = col[2];
+  double nx_mr = 0.0; double2 nx_b = make_double2(0.0, 0.0);
+  if (!FIRST) nx_b = *(const double2*)(bin + (size_t)lane*2);
+  double diagM = 0, diagD = 0;
+  for (int j = 0; j < n; j++){
+    const double blcj = uni(nx_blc), blwj = uni(nx_blw); const int rdj = (int)uni(nx_rd);
+    const double cur_mr = nx_mr; const double2 cur_b = nx_b;
+    {
+      const int jn = min(j + 1, n - 1);
+      nx_blc = col[3*jn]; nx_blw = col[3*jn+1]; nx_rd = col[3*jn+2];
+      if (FIRST) nx_mr = mr[jn - 1 >= 0 ? jn - 1 : 0];
+      else       nx_b = *(const double2*)(bin + ((size_t)jn*64 + lane)*2);
+    }
+    double upM, upD;
+    if (FIRST){
+      const double e0 = (rdj == c0) ? blcj : blwj;
+      upM = (j == 0) ? e0 : e0 + cur_mr;
+      upD = IMP;
+      if (j == n-1 && live) lt[0] = upM;
+    } else { upM = cur_b.x; upD = cur_b.y; }
+    const double topM = upM, topD = upD;
+    if (j == 0){
+#pragma unroll
+      for (int r = 0; r < NR; r++){           // first read column (HapAligner.cpp:123-126)
+        const double e = (rdj == hc[r]) ? blcj : blwj;
+        const double nD = fmax(upM + T_D2M, upD + T_D2D);
+        Mp[r] = e; Ip[r] = blcj; Dp[r] = nD;
+        upM = e; upD = nD;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < NR; r++){
+        const double e = (rdj == hc[r]) ? blcj : blwj;
+        // max(I+m2i, M+m2m, D+m2d) with m2d == m2i: adding the same value is monotone, so max(a+x, b+x) == max(a,b)+x exactly
+        const double nM = e + fmax(diagM + m2m[r], fmax(Ip[r], diagD) + m2i[r]);
+        const double nI = blcj + fmax(diagM + T_I2M, Ip[r] + T_I2I);
+        const double nD = fmax(upM + T_D2M, upD + T_D2D);
+        diagM = Mp[r]; diagD = Dp[r];          // (row r, column j-1): the diagonal of row r+1
+        Mp[r] = nM; Dp[r] = nD; Ip[r] = nI;
+        upM = nM; upD = nD;
+      }
+    }
+    if (!LAST) *(double2*)(bout + ((size_t)j*64 + lane)*2) = make_double2(upM, upD);
+    diagM = topM; diagD = topD;                // top boundary of this column = diagonal of the band's first row next column
+  }
+  if (live){
+#pragma unroll
+    for (int r = 0; r < NR; r++) lt[row0 + r] = Mp[r];           // column n-1
+  }
+}
+
+template <int NR>
+__device__ __forceinline__ void band_dispatch(bool first, bool last, const hs_dev_t& d, int lane, bool live, int n, const double* col,
+                                              const hs_row_t* rows, int row0, int c0, const double* mr, const double* bin, double* bout, double* lt){
+  if (first){ if (last) band_sweep<NR, true, true>(d, lane, live, n, col, rows, row0, c0, mr, bin, bout, lt);
+              else      band_sweep<NR, true, false>(d, lane, live, n, col, rows, row0, c0, mr, bin, bout, lt); }
+  else      { if (last) band_sweep<NR, false, true>(d, lane, live, n, col, rows, row0, c0, mr, bin, bout, lt);
+              else      band_sweep<NR, false, false>(d, lane, live, n, col, rows, row0, c0, mr, bin, bout, lt); }
+}
+
+template <int R>
+__global__ void __launch_bounds__(64) hs_trail_kernel(const hs_dev_t* __restrict__ dp, int item_begin, int item_end){
+  const hs_dev_t& d = *dp;
+  const int lane = threadIdx.x;
+  const size_t band_stride = (size_t)d.band_cols * 64 * 2;
+  double* const band_a = d.ws_band + (size_t)blockIdx.x * 2 * band_stride;
+  double* const band_b = band_a + band_stride;
+  for (int item = item_begin + blockIdx.x; item < item_end; item += gridDim.x){
+    const hs_item_t* it = d.items + item;
+    const SideView v = side_view(d, uni(it->active), uni(it->side));
+    const int n = v.n;
+    const hs_tgroup_t* g = d.tgroups + uni(it->slot);
+    const int nm = uni(g->n_members);
+    const bool live = lane < nm;
+    const int k = d.tmembers[uni(g->member_off) + min(lane, nm-1)];
+    const hs_allele_t* al = d.alleles + uni(v.loc->hap_begin) + k;
+    const int ord = al->re_ord;
+    const double* mr = d.ws_mr + v.ws_mr + (int64_t)ord*(v.len-1) + (v.side ? v.nL : 0);
+    // trailing last columns of an alignment: left side first (F2 rows), then right side (F0 rows)
+    double* lt = d.ws_lt + v.ws_lt + (int64_t)ord*uni(v.loc->lt_stride) + (v.side ? d.rowsets[al->trail_rows[0]].len : 0);
+    const double* col = d.ws_col + v.ws_col + 3*(int64_t)(v.side ? v.nL : 0);
+    const int rowset = uni(g->rowset);
+    const int rs_off = uni(d.rowsets[rowset].off), rs_len = uni(d.rowsets[rowset].len);
+    const hs_row_t* rows = d.rows + rs_off;
+    const int c0 = uni((int)rows[0]) & 0xff;
+    const int nbands = (rs_len - 1 + R - 1) / R;
+
+    if (nbands == 0){     // the block is the single "must be followed by a match" row (HapAligner.cpp:130-139)
+      const int j = n - 1;
+      const double blcj = uni(col[3*j]), blwj = uni(col[3*j+1]); const int rdj = (int)uni(col[3*j+2]);
+      const double e0 = (rdj == c0) ? blcj : blwj;
+      if (live) lt[0] = (j == 0) ? e0 : e0 + mr[max(j-1, 0)];
+      continue;
+    }
+    // a short band first (if the row count is not a multiple of R), then full bands
+    const int nr_first = (rs_len - 1) - (nbands - 1)*R;
+    int row0 = 1;
+    for (int b = 0; b < nbands; b++){
+      const int nr = (b == 0) ? nr_first : R;
+      const double* bin = (b & 1) ? band_a : band_b;      // written by band b-1
+      double* bout = (b & 1) ? band_b : band_a;
+      const bool first = (b == 0), last = (b + 1 == nbands);
+      if (nr == R) band_dispatch<R>(first, last, d, lane, live, n, col, rows, row0, c0, mr, bin, bout, lt);
+      else switch (nr){
+#define HS_BAND_CASE(N_) case N_: if (N_ < R) band_dispatch<(N_ < R ? N_ : 1)>(first, last, d, lane, live, n, col, rows, row0, c0, mr, bin, bout, lt); break;
+        HS_BAND_CASE(1) HS_BAND_CASE(2) HS_BAND_CASE(3) HS_BAND_CASE(4) HS_BAND_CASE(5) HS_BAND_CASE(6) HS_BAND_CASE(7) HS_BAND_CASE(8)
+        HS_BAND_CASE(9) HS_BAND_CASE(10) HS_BAND_CASE(11) HS_BAND_CASE(12) HS_BAND_CASE(13) HS_BAND_CASE(14) HS_BAND_CASE(15)
+#undef HS_BAND_CASE
+        default: break;
+      }
+      row0 += nr;
     }
   }
 }
@@ -527,10 +681,18 @@ hs_combine_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
 }
 
 // ------------------------------------------------------------------ host-side launch helper (called from api.hip)
-extern "C" void hs_launch_flank(int cls, int is_lead, unsigned gx, unsigned gy, hipStream_t st, const hs_dev_t* dp, int item_begin){
-  const dim3 grid(gx, gy, 1);
-#define HS_FL(C_) do { if (is_lead) hipLaunchKernelGGL((hs_flank_kernel<C_, true>),  grid, dim3(64), 0, st, dp, item_begin); \
-                       else         hipLaunchKernelGGL((hs_flank_kernel<C_, false>), grid, dim3(64), 0, st, dp, item_begin); } while (0)
-  switch (cls){ case 1: HS_FL(1); break; case 2: HS_FL(2); break; case 3: HS_FL(3); break; default: HS_FL(4); break; }
-#undef HS_FL
+extern "C" void hs_launch_lead(int cls, unsigned gx, hipStream_t st, const hs_dev_t* dp, int item_begin){
+  const dim3 grid(gx, 1, 1);
+  switch (cls){
+    case 1:  hipLaunchKernelGGL((hs_flank_kernel<1, true>), grid, dim3(64), 0, st, dp, item_begin); break;
+    case 2:  hipLaunchKernelGGL((hs_flank_kernel<2, true>), grid, dim3(64), 0, st, dp, item_begin); break;
+    case 3:  hipLaunchKernelGGL((hs_flank_kernel<3, true>), grid, dim3(64), 0, st, dp, item_begin); break;
+    default: hipLaunchKernelGGL((hs_flank_kernel<4, true>), grid, dim3(64), 0, st, dp, item_begin); break;
+  }
+}
+#ifndef HS_TRAIL_ROWS
+#define HS_TRAIL_ROWS 12
+#endif
+extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end){
+  hipLaunchKernelGGL((hs_trail_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end);
 }

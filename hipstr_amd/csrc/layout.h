@@ -73,6 +73,8 @@ struct hs_locus_t {
   int32_t lt_stride;         // max n_flank over realigned alleles: stride of the trailing last-column workspace
   int32_t lead_flank[2];     // max leading-flank length per side (lead workspace record = n_side + lead_flank + 1 doubles)
   int32_t n_lead[2];         // distinct leading-flank rowsets per side
+  int32_t tg_begin[2];       // trailing-flank allele groups of this locus per side: range in tgroups[]
+  int32_t tg_count[2];
 };
 
 struct hs_read_t {
@@ -87,7 +89,12 @@ struct hs_read_t {
 //   lt   : [n_re][lt_stride] last read column of the trailing-flank rows: left side (F2 rows) then right side (F0 rows)
 //   lead : per side [n_lead][n_side + lead_flank + 1]: rowP (M of the row before the STR block) | last column of the
 //          leading-flank rows | side_prob
-struct hs_ws_t { int64_t mr, lt, lead[2]; };
+//   col  : [len-1][3] per read column, left side then right side: log P(correct), log P(error), base (as a double)
+struct hs_ws_t { int64_t mr, lt, lead[2], col; };
+
+// Alleles of one locus and side that share a trailing-flank rowset (identical rows incl. homopolymer context):
+// the trailing-flank kernel runs them as the 64 lanes of one wavefront.
+struct hs_tgroup_t { int32_t rowset; int32_t member_off; int32_t n_members; int32_t pad; };
 
 // Work items of the phase kernels (sorted by columns-per-lane class where the kernel is templated on it).
 struct hs_item_t { int32_t active; int32_t side; int32_t rowset; int32_t slot; };
@@ -107,7 +114,11 @@ struct hs_dev_t {
   const char*        quals;
   const int32_t*     active;     // read indices that need alignment (realign && seed >= 0)
   const hs_ws_t*     ws;         // [n_active] workspace offsets
-  const hs_item_t*   items;      // lead items and side items, grouped (see api.hip)
+  const hs_item_t*   items;      // lead items and trail items, grouped (see api.hip)
+  const hs_tgroup_t* tgroups;
+  const int32_t*     tmembers;   // allele indices (within the locus) of the trail groups
+  double*            ws_col;
+  double*            ws_band;    // per persistent wavefront: 2 x [band_cols][64 lanes][2] band-boundary rows (M, D)
   double*            ws_mr;
   double*            ws_lt;
   double*            ws_lead;
@@ -123,5 +134,5 @@ struct hs_dev_t {
   int32_t            n_active;
   int32_t            allele_chunk;   // alleles per workgroup
   int32_t            lds_len;        // max read length in the batch (LDS carve of the STR kernel)
-  int32_t            pad;
+  int32_t            band_cols;      // max columns of one read side (rows of a band-boundary buffer)
 };

@@ -361,6 +361,22 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
 
     loc.n_re = n_realigned;
     loc.n_lead[0] = lead_sets[0].size(); loc.n_lead[1] = lead_sets[1].size();
+    for (int side = 0; side < 2; side++){      // alleles sharing a trailing-flank rowset run as lanes of one wavefront (<= 64 each)
+      std::map<int, std::vector<int> > by_rowset;
+      for (int k = 0; k < A; k++){
+        const hs_allele_t& al = out.alleles[loc.hap_begin + k];
+        if (al.realign) by_rowset[al.trail_rows[side]].push_back(k);
+      }
+      loc.tg_begin[side] = out.tgroups.size();
+      for (std::map<int, std::vector<int> >::iterator it = by_rowset.begin(); it != by_rowset.end(); ++it)
+        for (size_t m0 = 0; m0 < it->second.size(); m0 += 64){
+          hs_tgroup_t g; g.rowset = it->first; g.member_off = out.tmembers.size(); g.pad = 0;
+          g.n_members = (int32_t)std::min<size_t>(64, it->second.size() - m0);
+          out.tmembers.insert(out.tmembers.end(), it->second.begin() + m0, it->second.begin() + m0 + g.n_members);
+          out.tgroups.push_back(g);
+        }
+      loc.tg_count[side] = out.tgroups.size() - loc.tg_begin[side];
+    }
     locus_leads.push_back(lead_sets[0]); locus_leads.push_back(lead_sets[1]);
     for (int r = loc.read_begin; r < loc.read_begin + loc.n_reads; r++){
       hs_read_t rd;
@@ -389,22 +405,22 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
   // ---- launch plan: workspaces + work items, chunked so that the workspaces stay within the budget
   out.ws.resize(out.active.size());
   Prepared::Chunk ch; memset(&ch, 0, sizeof ch);
-  int64_t mr = 0, lt = 0, lead = 0;
-  std::vector<hs_item_t> lead_tmp[4], side_tmp[4];
+  int64_t mr = 0, lt = 0, lead = 0, col = 0;
+  std::vector<hs_item_t> lead_tmp[4], trail_tmp;
   auto flush = [&](int active_end){
     ch.active_end = active_end;
     for (int c = 0; c < 4; c++){
       ch.lead_begin[c] = out.lead_items.size(); out.lead_items.insert(out.lead_items.end(), lead_tmp[c].begin(), lead_tmp[c].end()); lead_tmp[c].clear();
     }
     ch.lead_begin[4] = out.lead_items.size();
-    for (int c = 0; c < 4; c++){
-      ch.side_begin[c] = out.side_items.size(); out.side_items.insert(out.side_items.end(), side_tmp[c].begin(), side_tmp[c].end()); side_tmp[c].clear();
-    }
-    ch.side_begin[4] = out.side_items.size();
+    ch.trail_begin = out.trail_items.size();
+    out.trail_items.insert(out.trail_items.end(), trail_tmp.begin(), trail_tmp.end()); trail_tmp.clear();
+    ch.trail_end = out.trail_items.size();
     out.ws_mr_size = std::max(out.ws_mr_size, mr); out.ws_lt_size = std::max(out.ws_lt_size, lt); out.ws_lead_size = std::max(out.ws_lead_size, lead);
+    out.ws_col_size = std::max(out.ws_col_size, col);
     if (ch.active_end > ch.active_begin) out.chunks.push_back(ch);
     memset(&ch, 0, sizeof ch); ch.active_begin = active_end;
-    mr = lt = lead = 0;
+    mr = lt = lead = col = 0;
   };
   for (size_t ai = 0; ai < out.active.size(); ai++){
     const hs_read_t& rd = out.reads[out.active[ai]];
@@ -414,7 +430,7 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
     int64_t need_lead = 0;
     for (int s = 0; s < 2; s++) need_lead += (int64_t)loc.n_lead[s]*(n_side[s] + loc.lead_flank[s] + 1);
     if (ch.active_begin < (int)ai && (mr + need_mr > ws_budget || lt + need_lt > ws_budget || lead + need_lead > ws_budget)) flush((int)ai);
-    hs_ws_t w; w.mr = mr; w.lt = lt;
+    hs_ws_t w; w.mr = mr; w.lt = lt; w.col = col;
     for (int s = 0; s < 2; s++){
       w.lead[s] = lead;
       const std::vector<int>& ls = locus_leads[2*rd.locus + s];
@@ -423,12 +439,15 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
         hs_item_t it; it.active = (int32_t)ai; it.side = s; it.rowset = ls[slot]; it.slot = (int32_t)slot;
         lead_tmp[cls].push_back(it);
       }
-      hs_item_t it; it.active = (int32_t)ai; it.side = s; it.rowset = -1; it.slot = 0;
-      side_tmp[cls].push_back(it);
+      for (int g = 0; g < loc.tg_count[s]; g++){
+        hs_item_t it; it.active = (int32_t)ai; it.side = s; it.rowset = -1; it.slot = loc.tg_begin[s] + g;
+        trail_tmp.push_back(it);
+      }
+      out.max_side_len = std::max(out.max_side_len, n_side[s]);
       lead += (int64_t)loc.n_lead[s]*(n_side[s] + loc.lead_flank[s] + 1);
     }
     out.ws[ai] = w;
-    mr += need_mr; lt += need_lt;
+    mr += need_mr; lt += need_lt; col += 3*(int64_t)(rd.len-1);
     ch.n_alignments += loc.n_re;
   }
   flush((int)out.active.size());

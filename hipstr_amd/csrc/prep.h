@@ -40,14 +40,17 @@ struct Prepared {
   struct Chunk {
     int32_t active_begin, active_end;      // range in `active`
     int32_t lead_begin[5];                 // lead_items range per columns-per-lane class 1..4 (begin[c-1] .. begin[c])
-    int32_t side_begin[5];                 // side_items range per class
+    int32_t trail_begin, trail_end;        // trail_items range
     int64_t n_alignments;
   };
   std::vector<Chunk>      chunks;
   std::vector<hs_ws_t>    ws;              // per active read, offsets inside its chunk's workspaces
   std::vector<hs_item_t>  lead_items;      // (active, side, rowset, slot): leading flank to compute once per read
-  std::vector<hs_item_t>  side_items;      // (active, side): trailing-flank sweeps
-  int64_t ws_mr_size = 0, ws_lt_size = 0, ws_lead_size = 0;   // doubles, max over chunks
+  std::vector<hs_item_t>  trail_items;     // (active, side, -, group): trailing flank of one allele group of one read side
+  std::vector<hs_tgroup_t> tgroups;
+  std::vector<int32_t>    tmembers;
+  int64_t ws_mr_size = 0, ws_lt_size = 0, ws_lead_size = 0, ws_col_size = 0;   // doubles, max over chunks
+  int32_t max_side_len = 0;
   int64_t n_out        = 0;
   int64_t n_alignments = 0;   // (active read) x (realigned allele) pairs = HMM alignments per pass
   int32_t max_read_len = 0;
