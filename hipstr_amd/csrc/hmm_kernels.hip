@@ -474,6 +474,31 @@ __device__ __forceinline__ double visit_eval(const hs_dev_t& d, const StrLds& L,
   return acc.finish();
 }
 
+// Closed form of visit_eval for a "simple" visiting list (hs_stropt_t::shape = U0 >= 0): every pushed value is
+// lp0 plus a constant, so the log-sum-exp needs no list traversal.  Pushes, in the reference's order:
+//   lp0 | [0 < lim] ln(U0) + lp0 (run of U0 equal configurations, only if U0 > 0) | lp0 once per plain offset in
+//   [U0, lim) | [stop < tail] ln(tail - stop) + lp0, stop = first visited offset >= lim.
+__device__ __forceinline__ double simple_eval(const hs_dev_t& d, const StrLds& L, double lp0, int lim, int U0, int tail){
+  const bool skip = (U0 > 0) && (lim > 0);
+  const int start = U0;                                         // first plain offset
+  const int nplain = max(0, lim - start);
+  const int stop = (lim <= 0) ? 0 : ((U0 > 0 && lim <= U0) ? U0 : lim);
+  const bool has_tail = stop < tail;
+  const double v_skip = L.ilog[U0] + lp0;
+  const double v_tail = L.ilog[max(tail - stop, 0)] + lp0;
+  double mx = lp0;
+  if (skip) mx = fmax(mx, v_skip);
+  if (has_tail) mx = fmax(mx, v_tail);
+  double tot = 0.0;
+  {
+    const double dd = lp0 - mx;
+    if (dd > d.log_thresh) tot += (double)(1 + nplain) * (double)f_fasterexp((float)dd);   // equal float terms: the sum is exact
+  }
+  if (skip){ const double dd = v_skip - mx; if (dd > d.log_thresh) tot += (double)f_fasterexp((float)dd); }
+  if (has_tail){ const double dd = v_tail - mx; if (dd > d.log_thresh) tot += (double)f_fasterexp((float)dd); }
+  return mx + (double)f_fasterlog((float)tot);
+}
+
 }  // namespace
 
 extern __shared__ double hs_lds_raw[];
@@ -541,6 +566,7 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
     const int lofs = (lane < HS_MAXREP) ? c.so->del_off[lane] - ins_off : 0;
     const int llen = (lane < HS_MAXREP) ? c.so->del_len[lane] : 0;
     const int total = uni(c.so->del_off[HS_MAXREP-1]) + uni(c.so->del_len[HS_MAXREP-1]) - ins_off;
+    const int shapes = (lane <= HS_MAXREP) ? c.so->shape[lane] : -1;
     const hs_visit_t bundle = ins_list[min(lane, max(total, ins_len) - 1)];
 
     // --- StutterAlignerClass::load_read (StutterAlignerClass.cpp:12-53): match_probs_ and del_probs_
@@ -592,7 +618,9 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
           const double lp0 = (rdlane(c.cst, 13) + li) + ((len > D) ? L.Mt[max(j - D, 0)] : 0.0);
           const int lim = actj ? min(max(0, len - D), B) : 0;
           const int limmax = min(max(0, min(B + D, jmax + 1) - D), B);
-          const double S = visit_eval(d, L, j, lp0, lim, limmax, bundle, 0, ins_list, ins_len, q+1, p, B);
+          const int shape = rdlane(shapes, HS_MAXREP);
+          const double S = (shape >= 0) ? simple_eval(d, L, lp0, lim, shape, B)
+                                        : visit_eval(d, L, j, lp0, lim, limmax, bundle, 0, ins_list, ins_len, q+1, p, B);
           const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
           term = (rdlane(c.cst, HS_MAXREP + 1 + q) + S) + pre;
         } else {                                     // deletion of aD = (q+1) p bases
@@ -614,7 +642,9 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
             const int lim = actj ? len : 0;
             const int limmax = min(B - aD, jmax + 1);
             const int rel = rdlane(lofs, q);
-            const double S = visit_eval(d, L, j, lp0, lim, limmax, bundle, rel, ins_list + rel, rdlane(llen, q), 1, 0, B - aD);
+            const int shape = rdlane(shapes, q);
+            const double S = (shape >= 0) ? simple_eval(d, L, lp0, lim, shape, B - aD)
+                                          : visit_eval(d, L, j, lp0, lim, limmax, bundle, rel, ins_list + rel, rdlane(llen, q), 1, 0, B - aD);
             const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
             term = (rdlane(c.cst, HS_MAXREP - 1 - q) + S) + pre;
           }

@@ -51,7 +51,11 @@ struct hs_stropt_t {
   int32_t f64_off;           // into f64 pool: pmf[13] | -int_log(B+1) | -int_log(B+D+1) for D=-p..-6p
   int32_t ins_off, ins_len;  // visiting list shared by all insertion sizes
   int32_t del_off[HS_MAXREP], del_len[HS_MAXREP];
-  int32_t pad;
+  // Shape of each visiting list (index 0..5: deletion lists, 6: insertion list).  Periodic blocks give "simple" lists —
+  // at most one run-skip entry at offset 0 (covering offsets 0..U0-1) followed only by plain entries at consecutive
+  // offsets — whose log-sum-exp has a closed form in (lp0, bound); everything else replays the list.
+  //   shape = -1: generic list;  shape = U0 >= 0: simple list, U0 = 0 means "no skip entry, plain entries from offset 0"
+  int32_t shape[HS_MAXREP + 1];
 };
 
 struct hs_allele_t {

@@ -235,11 +235,28 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
     }
     so.ins_len = out.visits.size() - so.ins_off;
   }
+  auto classify = [&](int off, int len, int limmax) -> int {
+    // simple: [optional entry (ni=0, U>0)] then plain entries at consecutive offsets up to the terminal at limmax
+    int v = 0, next = 0, U0 = 0;
+    const hs_visit_t* L = out.visits.data() + off;
+    auto ni_of = [](const hs_visit_t& e){ return (int)(e.meta & 0xffff); };
+    auto U_of  = [](const hs_visit_t& e){ return (int)((e.meta >> 16) & 0xffff); };
+    auto plain = [](const hs_visit_t& e){ return ((e.meta >> 48) & 1) != 0; };
+    if (len >= 1 && ni_of(L[0]) == 0 && !plain(L[0]) && U_of(L[0]) > 0 && limmax > 0){ U0 = U_of(L[0]); next = U0; v = 1; }
+    for (; v < len; v++){
+      if (ni_of(L[v]) != next) return -1;
+      if (next >= limmax) return (v == len-1) ? U0 : -1;      // terminal entry
+      if (!plain(L[v])) return -1;
+      next++;
+    }
+    return -1;
+  };
+  so.shape[HS_MAXREP] = classify(so.ins_off, so.ins_len, B);
   // deletion visiting lists (StutterAlignerClass.cpp:123-142); one per deletion size, shift = |D|
   for (int q = 0; q < HS_MAXREP; q++){
     const int D = -(q+1)*period;
     so.del_off[q] = out.visits.size();
-    if (B+D < 0){ so.del_len[q] = 0; continue; }
+    if (B+D < 0){ so.del_len[q] = 0; so.shape[q] = -1; continue; }
     const std::vector<int> up = upstream_runs(blk, -D);
     int i = 0;
     for (;;){
@@ -250,6 +267,7 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
       else       { out.visits.push_back(visit(ni, U, 0, 0, false, T.int_log[U])); i -= U; }
     }
     so.del_len[q] = out.visits.size() - so.del_off[q];
+    so.shape[q] = classify(so.del_off[q], so.del_len[q], B+D);
   }
   out.stropts.push_back(so);
 }
