@@ -425,9 +425,14 @@ struct StrLds {     // one side of one read
   double*  Dl;      // [6][ld] StutterAligner del_probs_
   uint8_t* rd;      // [n] read bases
   const double* ilog;   // [HS_ILOG_LDS] LDS copy of int_log(0..): ln of block-length-sized integers
+  double*  nd;      // [6][HS_ND_STRIDE] deletion start values of the columns within |D| of the read end
+  double*  cstl;    // [20] pmf[13] | prior_ins | prior_del[6] of the current allele
+  uint8_t* blk;     // [HS_BLK_LDS] block bases of the current allele
   int ld;
 };
 #define HS_ILOG_LDS 264
+#define HS_ND_STRIDE 56
+#define HS_BLK_LDS 272
 
 // Marginalisation over the artifact position (StutterAlignerClass.cpp:59-104 insertion, :106-150 deletion).
 // The loop over block offsets is the same for every read column, so the host enumerated it (hs_visit_t) and
@@ -506,7 +511,7 @@ extern __shared__ double hs_lds_raw[];
 // LDS bytes of one hs_str_kernel workgroup (both sides of a read) for a batch whose longest read has lds_len bases.
 extern "C" size_t hs_str_lds_bytes(int lds_len){
   const size_t Lc = ((size_t)lds_len + 3) & ~(size_t)1;
-  return Lc*16 + Lc*8*2 + Lc*8*HS_MAXREP + HS_ILOG_LDS*8 + ((Lc + 15) & ~(size_t)15);
+  return Lc*16 + Lc*8*2 + Lc*8*HS_MAXREP + HS_ILOG_LDS*8 + 2*(HS_MAXREP*HS_ND_STRIDE + 24)*8 + 2*HS_BLK_LDS + ((Lc + 15) & ~(size_t)15);
 }
 
 // Workgroup = one active read: wave 0 the left side, wave 1 the right side (independent; they share only the LDS
@@ -527,8 +532,11 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
     double* Mt = rowP + Lc;
     double* Dl = Mt + Lc;
     double* ilog = Dl + HS_MAXREP*Lc;
-    uint8_t* rdb = (uint8_t*)(ilog + HS_ILOG_LDS);
+    double* ndb = ilog + HS_ILOG_LDS;                       // per wave: nd[6][HS_ND_STRIDE] | cstl[24]
+    uint8_t* blkb = (uint8_t*)(ndb + 2*(HS_MAXREP*HS_ND_STRIDE + 24));
+    uint8_t* rdb = blkb + 2*HS_BLK_LDS;
     L.bq = bq + o; L.rowP = rowP + o; L.Mt = Mt + o; L.Dl = Dl + o; L.rd = rdb + o; L.ilog = ilog; L.ld = Lc;
+    L.nd = ndb + w*(HS_MAXREP*HS_ND_STRIDE + 24); L.cstl = L.nd + HS_MAXREP*HS_ND_STRIDE; L.blk = blkb + w*HS_BLK_LDS;
     for (int i = threadIdx.x; i < HS_ILOG_LDS; i += 128) ilog[i] = d.int_log[i];
   }
   __syncthreads();
@@ -569,6 +577,9 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
     const int shapes = (lane <= HS_MAXREP) ? c.so->shape[lane] : -1;
     const hs_visit_t bundle = ins_list[min(lane, max(total, ins_len) - 1)];
 
+    if (lane < (B + 3)/4) ((int*)L.blk)[lane] = c.blkv;
+    if (lane < 20) L.cstl[lane] = c.cst;
+
     // --- StutterAlignerClass::load_read (StutterAlignerClass.cpp:12-53): match_probs_ and del_probs_
     for (int kk = 0; kk < ncyc; kk++){
       const int j = min(lane + 64*kk, n-1);
@@ -585,6 +596,35 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
         }
       }
       L.Mt[j] = lp;
+    }
+    wave_lds_sync();
+
+    // --- deletion start values of the columns whose segment reaches the read end (the `else` branch of
+    // StutterAlignerClass.cpp:117-120: a sequential sum starting from the position prior).  There are only
+    // min(|D|, n) such columns per deletion size, so (size, column) pairs are spread over the lanes instead of
+    // looping over the block once per deletion size.
+    {
+      int cnt[HS_MAXREP], npairs = 0;
+#pragma unroll
+      for (int q = 0; q < HS_MAXREP; q++){ cnt[q] = (B - (q+1)*p >= 0) ? min((q+1)*p, n) : 0; npairs += cnt[q]; }
+      const int tmax = min(B - p, n);
+      for (int base = 0; base < npairs; base += 64){
+        int off = base + lane; const bool valid = off < npairs;
+        int q = 0;
+#pragma unroll
+        for (int qq = 0; qq < HS_MAXREP - 1; qq++) if (q == qq && off >= cnt[qq]){ off -= cnt[qq]; q = qq + 1; }
+        if (!valid){ q = 0; off = 0; }
+        const int aD = (q+1)*p;
+        const int j = max(0, n - aD) + off;
+        const int len = valid ? min(B - aD, j + 1) : 0;
+        double lp = L.cstl[14 + q];
+        for (int t = 0; t < tmax; t++){
+          const int pos = max(j - t, 0);
+          const double e = emit(L.rd[pos], L.blk[max(B-1-aD-t, 0)], L.bq[pos]);
+          if (t < len) lp += e;
+        }
+        if (valid) L.nd[q*HS_ND_STRIDE + off] = lp;
+      }
     }
     wave_lds_sync();
 
@@ -627,18 +667,10 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
           const int q = itn - 1 - HS_MAXREP, aD = (q+1)*p;
           if (B - aD >= 0){
             const int len = min(B - aD, j + 1);
-            double lp0 = rdlane(c.cst, 14 + q);
             const bool direct = (j + aD <= n - 1);
+            double lp0 = rdlane(c.cst, 14 + q);
             if (direct) lp0 += L.Mt[min(j + aD, n-1)] - L.Dl[q*L.ld + min(j + aD, n-1)];
-            if (jmax + aD > n - 1){                  // some column of the chunk ends within aD of the read end
-              const int tmax = min(B - aD, n);
-              for (int t = 0; t < tmax; t++){
-                const uint8_t bc = blk_at(c, B-1-t-aD);
-                const int pos = max(j - t, 0);
-                const double e = emit(L.rd[pos], bc, L.bq[pos]);
-                if (!direct && t < len) lp0 += e;
-              }
-            }
+            else        lp0 = L.nd[q*HS_ND_STRIDE + min(max(j - max(0, n - aD), 0), HS_ND_STRIDE-1)];
             const int lim = actj ? len : 0;
             const int limmax = min(B - aD, jmax + 1);
             const int rel = rdlane(lofs, q);

@@ -124,3 +124,34 @@ def test_dropin_adapter_against_reference_objects(hmm):
     for args in (["6", "24", "8", "2"], ["3", "40", "32", "1"]):
         out = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
         assert out.returncode == 0 and " 0 mismatches" in out.stdout, out.stdout
+
+
+def test_workspace_chunking(hmm, oracle, monkeypatch):
+    """The phase kernels hand results over through HBM workspaces; a batch larger than the workspace budget is cut into
+    chunks of reads.  Force many tiny chunks and check the result is unchanged."""
+    sb = capi.SynthBatch(n_loci=6, reads_per_locus=40, n_str_alleles=12, n_flank_opts=2, seed=44, mask_rate=0.15)
+    want, ws = capi.run_align(oracle, "oracle_", sb.ptr, fill=-9.5)
+    monkeypatch.setenv("HIPSTR_WS_GIB", "0.0005")        # ~0.5 MiB per workspace -> a few reads per chunk
+    got, gs = capi.run_align(hmm, "hipstr_hmm_", sb.ptr, fill=-9.5)
+    monkeypatch.delenv("HIPSTR_WS_GIB")
+    assert np.array_equal(gs, ws) and np.array_equal(got, want)
+
+
+def test_imperfect_repeats_and_long_periods(hmm, oracle):
+    """Interrupted repeats (generic visiting lists incl. lists longer than one 64-entry bundle), period 9, alleles near the
+    256 bp limit: the slow paths of the STR kernel."""
+    import random
+    rnd = random.Random(5)
+    lf = "".join(rnd.choice("ACGT") for _ in range(48)); rf = "".join(rnd.choice("ACGT") for _ in range(48))
+    motif = "ACGGTTCAG"
+    strs = [motif * 8, motif * 9, motif * 7 + "ACGGTTCAT", "ACGATTCAG" + motif * 7, motif * 3 + "T" + motif * 4]
+    long_imp = "".join(rnd.choice("ACGT") for _ in range(230))                  # aperiodic 230 bp block: lists of ~230 entries
+    strs.append(long_imp)
+    hap = lf + strs[0] + rf
+    reads = [(hap[s:s + 150], None, s, True) for s in (0, 3, 9, 14, 18)]
+    reads.append((lf[10:] + long_imp[:120], None, 10, True, [("=", 38), ("X", 120)]))
+    b, A = simple_locus(lf, strs, rf, 9, reads)
+    b.finalize()
+    got, gs = capi.run_align(hmm, "hipstr_hmm_", b.ptr)
+    want, ws = capi.run_align(oracle, "oracle_", b.ptr)
+    assert np.array_equal(gs, ws) and np.array_equal(got, want), np.max(np.abs(got - want))
