@@ -275,14 +275,17 @@ __global__ void __launch_bounds__(64) hs_flank_kernel(const hs_dev_t* __restrict
 // The matrix is swept column by column in bands of R rows whose previous-column M/I/D sit in registers; the last
 // row of a band goes to a per-wavefront scratch row (L2-resident) and comes back as the next band's top boundary.
 // Persistent wavefronts: blockIdx.x strides over the items so that the scratch is per wavefront, not per item.
-// One band of NR haplotype rows (fully unrolled, branch-free per row) swept over all n read columns.
+// When a group has <= 32 alleles, 64/npad reads of the same locus and side are packed into one wavefront.
+// One band of NR haplotype rows (fully unrolled, branch-free per row) swept over the read columns.
 //   FIRST: the band's top boundary is the "must be followed by a match" row, built from MR (HapAligner.cpp:130-139);
-//          otherwise it is read from `bin`, written by the previous band.   LAST: no bottom boundary is written.
+//          otherwise it is read from `bnd`, written by the previous band (in place: column j is read before it is rewritten).
+//   LAST:  no bottom boundary is written.
+// Lanes may belong to different reads (packing): n, the column table and the workspaces are per lane; the flank rows
+// (hence bases and transition logs) are wave-uniform.
 template <int NR, bool FIRST, bool LAST>
-__device__ __forceinline__ void band_sweep(const hs_dev_t& d, int lane, bool live, int n, const double* __restrict__ col,
+__device__ __forceinline__ void band_sweep(const hs_dev_t& d, int lane, bool live, int n, int nmax, const double* __restrict__ col,
                                            const hs_row_t* __restrict__ rows, int row0, int c0,
-                                           const double* __restrict__ mr, const double* __restrict__ bin, double* __restrict__ bout,
-                                           double* __restrict__ lt){
+                                           const double* __restrict__ mr, double* __restrict__ bnd, double* __restrict__ lt){
   int hc[NR]; double m2m[NR], m2i[NR];
 #pragma unroll
   for (int r = 0; r < NR; r++){
@@ -294,16 +297,16 @@ __device__ __forceinline__ void band_sweep(const hs_dev_t& d, int lane, bool liv
   // software pipeline: the loads of column j+1 are issued before column j is computed
   double nx_blc = col[0], nx_blw = col[1], nx_rd = col[2];
   double nx_mr = 0.0; double2 nx_b = make_double2(0.0, 0.0);
-  if (!FIRST) nx_b = *(const double2*)(bin + (size_t)lane*2);
+  if (!FIRST) nx_b = *(const double2*)(bnd + (size_t)lane*2);
   double diagM = 0, diagD = 0;
-  for (int j = 0; j < n; j++){
-    const double blcj = uni(nx_blc), blwj = uni(nx_blw); const int rdj = (int)uni(nx_rd);
+  for (int j = 0; j < nmax; j++){
+    const double blcj = nx_blc, blwj = nx_blw; const int rdj = (int)nx_rd;
     const double cur_mr = nx_mr; const double2 cur_b = nx_b;
     {
-      const int jn = min(j + 1, n - 1);
+      const int jn = min(j + 1, n - 1);           // a lane past its own read end keeps re-reading its last column
       nx_blc = col[3*jn]; nx_blw = col[3*jn+1]; nx_rd = col[3*jn+2];
       if (FIRST) nx_mr = mr[jn - 1 >= 0 ? jn - 1 : 0];
-      else       nx_b = *(const double2*)(bin + ((size_t)jn*64 + lane)*2);
+      else       nx_b = *(const double2*)(bnd + ((size_t)min(j + 1, nmax - 1)*64 + lane)*2);
     }
     double upM, upD;
     if (FIRST){
@@ -334,45 +337,54 @@ __device__ __forceinline__ void band_sweep(const hs_dev_t& d, int lane, bool liv
         upM = nM; upD = nD;
       }
     }
-    if (!LAST) *(double2*)(bout + ((size_t)j*64 + lane)*2) = make_double2(upM, upD);
+    if (!LAST) *(double2*)(bnd + ((size_t)j*64 + lane)*2) = make_double2(upM, upD);
     diagM = topM; diagD = topD;                // top boundary of this column = diagonal of the band's first row next column
-  }
-  if (live){
+    if (j == n-1 && live){
 #pragma unroll
-    for (int r = 0; r < NR; r++) lt[row0 + r] = Mp[r];           // column n-1
+      for (int r = 0; r < NR; r++) lt[row0 + r] = Mp[r];           // last read column of this lane's read
+    }
   }
 }
 
 template <int NR>
-__device__ __forceinline__ void band_dispatch(bool first, bool last, const hs_dev_t& d, int lane, bool live, int n, const double* col,
-                                              const hs_row_t* rows, int row0, int c0, const double* mr, const double* bin, double* bout, double* lt){
-  if (first){ if (last) band_sweep<NR, true, true>(d, lane, live, n, col, rows, row0, c0, mr, bin, bout, lt);
-              else      band_sweep<NR, true, false>(d, lane, live, n, col, rows, row0, c0, mr, bin, bout, lt); }
-  else      { if (last) band_sweep<NR, false, true>(d, lane, live, n, col, rows, row0, c0, mr, bin, bout, lt);
-              else      band_sweep<NR, false, false>(d, lane, live, n, col, rows, row0, c0, mr, bin, bout, lt); }
+__device__ __forceinline__ void band_dispatch(bool first, bool last, const hs_dev_t& d, int lane, bool live, int n, int nmax, const double* col,
+                                              const hs_row_t* rows, int row0, int c0, const double* mr, double* bnd, double* lt){
+  if (first){ if (last) band_sweep<NR, true, true>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt);
+              else      band_sweep<NR, true, false>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt); }
+  else      { if (last) band_sweep<NR, false, true>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt);
+              else      band_sweep<NR, false, false>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt); }
 }
 
 template <int R>
 __global__ void __launch_bounds__(64) hs_trail_kernel(const hs_dev_t* __restrict__ dp, int item_begin, int item_end){
   const hs_dev_t& d = *dp;
   const int lane = threadIdx.x;
-  const size_t band_stride = (size_t)d.band_cols * 64 * 2;
-  double* const band_a = d.ws_band + (size_t)blockIdx.x * 2 * band_stride;
-  double* const band_b = band_a + band_stride;
+  double* const bnd = d.ws_band + (size_t)blockIdx.x * d.band_cols * 64 * 2;
   for (int item = item_begin + blockIdx.x; item < item_end; item += gridDim.x){
     const hs_item_t* it = d.items + item;
-    const SideView v = side_view(d, uni(it->active), uni(it->side));
-    const int n = v.n;
+    const int side = uni(it->side), nreads = uni(it->rowset);
     const hs_tgroup_t* g = d.tgroups + uni(it->slot);
     const int nm = uni(g->n_members);
-    const bool live = lane < nm;
-    const int k = d.tmembers[uni(g->member_off) + min(lane, nm-1)];
-    const hs_allele_t* al = d.alleles + uni(v.loc->hap_begin) + k;
+    int npad = 1; while (npad < nm) npad <<= 1;
+    // lane -> (packed read, allele of the group)
+    const int sub = lane / npad, slot = lane - sub*npad;
+    const bool live = (sub < nreads) && (slot < nm);
+    const int ai = d.tpack[uni(it->active) + min(sub, nreads-1)];
+    const int r = d.active[ai];
+    const hs_read_t rdv = d.reads[r];
+    const hs_locus_t* loc = d.loci + uni(rdv.locus);
+    const int nL = rdv.seed, n = side ? rdv.len - rdv.seed - 1 : rdv.seed;
+    int nmax = n;
+    for (int m = 32; m >= 1; m >>= 1) nmax = max(nmax, __shfl_xor(nmax, m));
+    nmax = uni(nmax);
+    const hs_ws_t wsr = d.ws[ai];
+    const int k = d.tmembers[uni(g->member_off) + min(slot, nm-1)];
+    const hs_allele_t* al = d.alleles + uni(loc->hap_begin) + k;
     const int ord = al->re_ord;
-    const double* mr = d.ws_mr + v.ws_mr + (int64_t)ord*(v.len-1) + (v.side ? v.nL : 0);
+    const double* mr = d.ws_mr + wsr.mr + (int64_t)ord*(rdv.len-1) + (side ? nL : 0);
     // trailing last columns of an alignment: left side first (F2 rows), then right side (F0 rows)
-    double* lt = d.ws_lt + v.ws_lt + (int64_t)ord*uni(v.loc->lt_stride) + (v.side ? d.rowsets[al->trail_rows[0]].len : 0);
-    const double* col = d.ws_col + v.ws_col + 3*(int64_t)(v.side ? v.nL : 0);
+    double* lt = d.ws_lt + wsr.lt + (int64_t)ord*uni(loc->lt_stride) + (side ? d.rowsets[al->trail_rows[0]].len : 0);
+    const double* col = d.ws_col + wsr.col + 3*(int64_t)(side ? nL : 0);
     const int rowset = uni(g->rowset);
     const int rs_off = uni(d.rowsets[rowset].off), rs_len = uni(d.rowsets[rowset].len);
     const hs_row_t* rows = d.rows + rs_off;
@@ -381,7 +393,7 @@ __global__ void __launch_bounds__(64) hs_trail_kernel(const hs_dev_t* __restrict
 
     if (nbands == 0){     // the block is the single "must be followed by a match" row (HapAligner.cpp:130-139)
       const int j = n - 1;
-      const double blcj = uni(col[3*j]), blwj = uni(col[3*j+1]); const int rdj = (int)uni(col[3*j+2]);
+      const double blcj = col[3*j], blwj = col[3*j+1]; const int rdj = (int)col[3*j+2];
       const double e0 = (rdj == c0) ? blcj : blwj;
       if (live) lt[0] = (j == 0) ? e0 : e0 + mr[max(j-1, 0)];
       continue;
@@ -391,14 +403,13 @@ __global__ void __launch_bounds__(64) hs_trail_kernel(const hs_dev_t* __restrict
     int row0 = 1;
     for (int b = 0; b < nbands; b++){
       const int nr = (b == 0) ? nr_first : R;
-      const double* bin = (b & 1) ? band_a : band_b;      // written by band b-1
-      double* bout = (b & 1) ? band_b : band_a;
       const bool first = (b == 0), last = (b + 1 == nbands);
-      if (nr == R) band_dispatch<R>(first, last, d, lane, live, n, col, rows, row0, c0, mr, bin, bout, lt);
+      if (nr == R) band_dispatch<R>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt);
       else switch (nr){
-#define HS_BAND_CASE(N_) case N_: if (N_ < R) band_dispatch<(N_ < R ? N_ : 1)>(first, last, d, lane, live, n, col, rows, row0, c0, mr, bin, bout, lt); break;
+#define HS_BAND_CASE(N_) case N_: if (N_ < R) band_dispatch<(N_ < R ? N_ : 1)>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt); break;
         HS_BAND_CASE(1) HS_BAND_CASE(2) HS_BAND_CASE(3) HS_BAND_CASE(4) HS_BAND_CASE(5) HS_BAND_CASE(6) HS_BAND_CASE(7) HS_BAND_CASE(8)
         HS_BAND_CASE(9) HS_BAND_CASE(10) HS_BAND_CASE(11) HS_BAND_CASE(12) HS_BAND_CASE(13) HS_BAND_CASE(14) HS_BAND_CASE(15)
+        HS_BAND_CASE(16) HS_BAND_CASE(17) HS_BAND_CASE(18) HS_BAND_CASE(19) HS_BAND_CASE(20) HS_BAND_CASE(21) HS_BAND_CASE(22) HS_BAND_CASE(23)
 #undef HS_BAND_CASE
         default: break;
       }

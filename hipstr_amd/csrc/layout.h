@@ -121,6 +121,7 @@ struct hs_dev_t {
   const hs_item_t*   items;      // lead items and trail items, grouped (see api.hip)
   const hs_tgroup_t* tgroups;
   const int32_t*     tmembers;   // allele indices (within the locus) of the trail groups
+  const int32_t*     tpack;      // active-read indices of the reads packed into one trail item
   double*            ws_col;
   double*            ws_band;    // per persistent wavefront: 2 x [band_cols][64 lanes][2] band-boundary rows (M, D)
   double*            ws_mr;

@@ -424,15 +424,41 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
   out.ws.resize(out.active.size());
   Prepared::Chunk ch; memset(&ch, 0, sizeof ch);
   int64_t mr = 0, lt = 0, lead = 0, col = 0;
-  std::vector<hs_item_t> lead_tmp[4], trail_tmp;
+  std::vector<hs_item_t> lead_tmp[4];
   auto flush = [&](int active_end){
     ch.active_end = active_end;
     for (int c = 0; c < 4; c++){
       ch.lead_begin[c] = out.lead_items.size(); out.lead_items.insert(out.lead_items.end(), lead_tmp[c].begin(), lead_tmp[c].end()); lead_tmp[c].clear();
     }
     ch.lead_begin[4] = out.lead_items.size();
+    // trailing-flank items: lanes = alleles of a group; when a group has <= 32 alleles, 64/npad reads of the same locus and
+    // side (sorted by side length, so that packed reads finish together) share one wavefront
     ch.trail_begin = out.trail_items.size();
-    out.trail_items.insert(out.trail_items.end(), trail_tmp.begin(), trail_tmp.end()); trail_tmp.clear();
+    for (int a0 = ch.active_begin; a0 < active_end; ){
+      const int locus = out.reads[out.active[a0]].locus;
+      int a1 = a0;
+      while (a1 < active_end && out.reads[out.active[a1]].locus == locus) a1++;
+      const hs_locus_t& loc = out.loci[locus];
+      for (int s = 0; s < 2; s++){
+        std::vector<int> order;
+        for (int a = a0; a < a1; a++) order.push_back(a);
+        auto side_len = [&](int a){ const hs_read_t& r = out.reads[out.active[a]]; return s ? r.len - r.seed - 1 : r.seed; };
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y){ return side_len(x) < side_len(y); });
+        for (int g = 0; g < loc.tg_count[s]; g++){
+          const int nm = out.tgroups[loc.tg_begin[s] + g].n_members;
+          int npad = 1; while (npad < nm) npad <<= 1;
+          const int per_wave = 64 / npad;
+          for (size_t i = 0; i < order.size(); i += per_wave){
+            hs_item_t it; it.side = s; it.slot = loc.tg_begin[s] + g;
+            it.active = (int32_t)out.tpack.size();
+            it.rowset = (int32_t)std::min<size_t>(per_wave, order.size() - i);
+            out.tpack.insert(out.tpack.end(), order.begin() + i, order.begin() + i + it.rowset);
+            out.trail_items.push_back(it);
+          }
+        }
+      }
+      a0 = a1;
+    }
     ch.trail_end = out.trail_items.size();
     out.ws_mr_size = std::max(out.ws_mr_size, mr); out.ws_lt_size = std::max(out.ws_lt_size, lt); out.ws_lead_size = std::max(out.ws_lead_size, lead);
     out.ws_col_size = std::max(out.ws_col_size, col);
@@ -456,10 +482,6 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
       for (size_t slot = 0; slot < ls.size(); slot++){
         hs_item_t it; it.active = (int32_t)ai; it.side = s; it.rowset = ls[slot]; it.slot = (int32_t)slot;
         lead_tmp[cls].push_back(it);
-      }
-      for (int g = 0; g < loc.tg_count[s]; g++){
-        hs_item_t it; it.active = (int32_t)ai; it.side = s; it.rowset = -1; it.slot = loc.tg_begin[s] + g;
-        trail_tmp.push_back(it);
       }
       out.max_side_len = std::max(out.max_side_len, n_side[s]);
       lead += (int64_t)loc.n_lead[s]*(n_side[s] + loc.lead_flank[s] + 1);

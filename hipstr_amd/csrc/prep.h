@@ -46,7 +46,9 @@ struct Prepared {
   std::vector<Chunk>      chunks;
   std::vector<hs_ws_t>    ws;              // per active read, offsets inside its chunk's workspaces
   std::vector<hs_item_t>  lead_items;      // (active, side, rowset, slot): leading flank to compute once per read
-  std::vector<hs_item_t>  trail_items;     // (active, side, -, group): trailing flank of one allele group of one read side
+  std::vector<hs_item_t>  trail_items;     // (first entry in tpack, side, number of packed reads, group): trailing flank of one
+                                           // allele group for up to 64/npad reads of one locus and side
+  std::vector<int32_t>    tpack;           // active-read indices of the packed reads
   std::vector<hs_tgroup_t> tgroups;
   std::vector<int32_t>    tmembers;
   int64_t ws_mr_size = 0, ws_lt_size = 0, ws_lead_size = 0, ws_col_size = 0;   // doubles, max over chunks

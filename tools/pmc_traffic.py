@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""HBM traffic per kernel from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), as MI355X_MICROARCH.md §HBM
+prescribes: FETCH_SIZE/WRITE_SIZE are KB per dispatch derived from TCC_EA0_RDREQ/WRREQ; on gfx950 FETCH_SIZE counts a
+128-B read request of a wide coalesced stream as 64 B, so the read side is reported raw and x2 (upper bound); WRITE_SIZE is
+uncalibrated and reported raw.
+usage: python tools/pmc_traffic.py <fetch.db> <write.db> <alignments_per_launch> > profiles/<name>.json"""
+import json
+import sqlite3
+import sys
+
+
+def per_kernel(db, counter):
+    out = {}
+    for name, n, avg in sqlite3.connect(db).execute(
+            "select kernel_name,count(*),avg(value) from counters_collection where counter_name=? group by kernel_name", (counter,)):
+        if "hs_" in name:
+            key = name.split("::")[-1].split("(")[0]
+            out[key] = out.get(key, 0.0) + avg * 1024.0
+    return out
+
+
+fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+n_aln = float(sys.argv[3])
+res = {"alignments_per_launch": n_aln, "kernels": {}}
+tot_f = tot_w = 0.0
+for k in sorted(set(fetch) | set(write)):
+    f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+    tot_f += f; tot_w += w
+    res["kernels"][k] = {"fetch_bytes_per_launch_raw": f, "write_bytes_per_launch_raw": w}
+res["pass"] = {"fetch_bytes_raw": tot_f, "fetch_bytes_x2": 2 * tot_f, "write_bytes_raw": tot_w,
+               "bytes_per_alignment_raw": (tot_f + tot_w) / n_aln, "bytes_per_alignment_fetch_x2": (2 * tot_f + tot_w) / n_aln}
+print(json.dumps(res, indent=1))
