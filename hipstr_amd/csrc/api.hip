@@ -22,7 +22,7 @@
 extern "C" __global__ void hs_str_kernel(const hs_dev_t* dp, int active_begin);
 extern "C" __global__ void hs_combine_kernel(const hs_dev_t* dp, int active_begin);
 extern "C" __global__ void hs_posterior_kernel(const hs_post_dev_t* dp);
-extern "C" size_t hs_str_lds_bytes(int lds_len);
+extern "C" size_t hs_str_lds_bytes(int lds_len, int max_B);
 extern "C" void hs_launch_lead(int cls, unsigned gx, hipStream_t st, const hs_dev_t* dp, int item_begin);
 extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end);
 
@@ -217,7 +217,8 @@ hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){
   h.allele_chunk = (maxA + gy - 1) / gy;
   dev->grid_y = (maxA + h.allele_chunk - 1) / h.allele_chunk;
   dev->max_alleles = maxA;
-  dev->lds_bytes = hs_str_lds_bytes(h.lds_len);
+  h.max_B = P.max_B;
+  dev->lds_bytes = hs_str_lds_bytes(h.lds_len, h.max_B);
   if (dev->lds_bytes > 160*1024){ g_err = "batch needs more than 160 KiB of LDS per workgroup"; hipstr_hmm_free(dev); return NULL; }
   if (dev->lds_bytes > 48*1024)
     HS_HIP_NULL(hipFuncSetAttribute((const void*)hs_str_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->lds_bytes));

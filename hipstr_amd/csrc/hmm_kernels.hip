@@ -398,11 +398,11 @@ __global__ void __launch_bounds__(64) hs_trail_kernel(const hs_dev_t* __restrict
       if (live) lt[0] = (j == 0) ? e0 : e0 + mr[max(j-1, 0)];
       continue;
     }
-    // a short band first (if the row count is not a multiple of R), then full bands
-    const int nr_first = (rs_len - 1) - (nbands - 1)*R;
+    // bands of (almost) equal height <= R
+    const int nr_base = (rs_len - 1) / nbands, nr_rem = (rs_len - 1) - nr_base*nbands;
     int row0 = 1;
     for (int b = 0; b < nbands; b++){
-      const int nr = (b == 0) ? nr_first : R;
+      const int nr = nr_base + (b < nr_rem ? 1 : 0);
       const bool first = (b == 0), last = (b + 1 == nbands);
       if (nr == R) band_dispatch<R>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt);
       else switch (nr){
@@ -421,13 +421,11 @@ __global__ void __launch_bounds__(64) hs_trail_kernel(const hs_dev_t* __restrict
 // ------------------------------------------------------------------ the STR block
 struct StrCtx {
   int B, p, nd;
-  int blkv;          // lane x holds block chars 4x..4x+3
   double cst;        // lane t<20 holds f64pool[f64_off+t]: pmf[13] | prior_ins | prior_del[6]
   const hs_stropt_t* so;
+  const uint8_t* blk;   // block bases of the current allele, in LDS
 };
-__device__ __forceinline__ uint8_t blk_at(const StrCtx& c, int x){    // x wave-uniform
-  return (uint8_t)(((uint32_t)rdlane(c.blkv, x >> 2) >> ((x & 3)*8)) & 0xff);
-}
+__device__ __forceinline__ uint8_t blk_at(const StrCtx& c, int x){ return c.blk[x]; }   // x wave-uniform: LDS broadcast
 
 struct StrLds {     // one side of one read
   double2* bq;      // [n] (log P(correct), log P(error)) per read column
@@ -438,12 +436,10 @@ struct StrLds {     // one side of one read
   const double* ilog;   // [HS_ILOG_LDS] LDS copy of int_log(0..): ln of block-length-sized integers
   double*  nd;      // [6][HS_ND_STRIDE] deletion start values of the columns within |D| of the read end
   double*  cstl;    // [20] pmf[13] | prior_ins | prior_del[6] of the current allele
-  uint8_t* blk;     // [HS_BLK_LDS] block bases of the current allele
+  uint8_t* blk;     // [blk_len] block bases of the current allele
   int ld;
 };
-#define HS_ILOG_LDS 264
 #define HS_ND_STRIDE 56
-#define HS_BLK_LDS 272
 
 // Marginalisation over the artifact position (StutterAlignerClass.cpp:59-104 insertion, :106-150 deletion).
 // The loop over block offsets is the same for every read column, so the host enumerated it (hs_visit_t) and
@@ -520,9 +516,10 @@ __device__ __forceinline__ double simple_eval(const hs_dev_t& d, const StrLds& L
 extern __shared__ double hs_lds_raw[];
 
 // LDS bytes of one hs_str_kernel workgroup (both sides of a read) for a batch whose longest read has lds_len bases.
-extern "C" size_t hs_str_lds_bytes(int lds_len){
+extern "C" size_t hs_str_lds_bytes(int lds_len, int max_B){
   const size_t Lc = ((size_t)lds_len + 3) & ~(size_t)1;
-  return Lc*16 + Lc*8*2 + Lc*8*HS_MAXREP + HS_ILOG_LDS*8 + 2*(HS_MAXREP*HS_ND_STRIDE + 24)*8 + 2*HS_BLK_LDS + ((Lc + 15) & ~(size_t)15);
+  const size_t ilog_len = ((size_t)max_B + 9) & ~(size_t)1, blk_len = ((size_t)max_B + 19) & ~(size_t)15;
+  return Lc*16 + Lc*8*2 + Lc*8*HS_MAXREP + ilog_len*8 + 2*(HS_MAXREP*HS_ND_STRIDE + 24)*8 + 2*blk_len + ((Lc + 15) & ~(size_t)15);
 }
 
 // Workgroup = one active read: wave 0 the left side, wave 1 the right side (independent; they share only the LDS
@@ -542,13 +539,14 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
     double* rowP = (double*)(bq + Lc);
     double* Mt = rowP + Lc;
     double* Dl = Mt + Lc;
+    const int ilog_len = (d.max_B + 9) & ~1, blk_len = (d.max_B + 19) & ~15;
     double* ilog = Dl + HS_MAXREP*Lc;
-    double* ndb = ilog + HS_ILOG_LDS;                       // per wave: nd[6][HS_ND_STRIDE] | cstl[24]
+    double* ndb = ilog + ilog_len;                          // per wave: nd[6][HS_ND_STRIDE] | cstl[24]
     uint8_t* blkb = (uint8_t*)(ndb + 2*(HS_MAXREP*HS_ND_STRIDE + 24));
-    uint8_t* rdb = blkb + 2*HS_BLK_LDS;
+    uint8_t* rdb = blkb + 2*blk_len;
     L.bq = bq + o; L.rowP = rowP + o; L.Mt = Mt + o; L.Dl = Dl + o; L.rd = rdb + o; L.ilog = ilog; L.ld = Lc;
-    L.nd = ndb + w*(HS_MAXREP*HS_ND_STRIDE + 24); L.cstl = L.nd + HS_MAXREP*HS_ND_STRIDE; L.blk = blkb + w*HS_BLK_LDS;
-    for (int i = threadIdx.x; i < HS_ILOG_LDS; i += 128) ilog[i] = d.int_log[i];
+    L.nd = ndb + w*(HS_MAXREP*HS_ND_STRIDE + 24); L.cstl = L.nd + HS_MAXREP*HS_ND_STRIDE; L.blk = blkb + w*blk_len;
+    for (int i = threadIdx.x; i < ilog_len; i += 128) ilog[i] = d.int_log[i];
   }
   __syncthreads();
   for (int j = lane; j < n; j += 64){
@@ -575,8 +573,8 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
     StrCtx c;
     c.so = d.stropts + str_opt;
     c.B = uni(c.so->B); c.p = uni(c.so->period); c.nd = uni(c.so->nd);
-    c.blkv = ((const int*)(d.chars + uni(c.so->seq_off)))[min(lane, (c.B + 3)/4 - 1)];
     c.cst = d.f64pool[uni(c.so->f64_off) + min(lane, 19)];
+    c.blk = L.blk;
     const int B = c.B, p = c.p;
     // all seven visiting lists of the option sit back to back in memory: one coalesced 16 B/lane load brings the first
     // 64 entries; list offsets/lengths ride in one lane-indexed register (lane q: deletion list q, lane 6: insertion list)
@@ -588,8 +586,12 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
     const int shapes = (lane <= HS_MAXREP) ? c.so->shape[lane] : -1;
     const hs_visit_t bundle = ins_list[min(lane, max(total, ins_len) - 1)];
 
-    if (lane < (B + 3)/4) ((int*)L.blk)[lane] = c.blkv;
+    {
+      const int* src = (const int*)(d.chars + uni(c.so->seq_off));
+      for (int i = lane; i < (B + 3)/4; i += 64) ((int*)L.blk)[i] = src[i];
+    }
     if (lane < 20) L.cstl[lane] = c.cst;
+    wave_lds_sync();
 
     // --- StutterAlignerClass::load_read (StutterAlignerClass.cpp:12-53): match_probs_ and del_probs_
     for (int kk = 0; kk < ncyc; kk++){
@@ -764,7 +766,7 @@ extern "C" void hs_launch_lead(int cls, unsigned gx, hipStream_t st, const hs_de
   }
 }
 #ifndef HS_TRAIL_ROWS
-#define HS_TRAIL_ROWS 12
+#define HS_TRAIL_ROWS 16
 #endif
 extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end){
   hipLaunchKernelGGL((hs_trail_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end);

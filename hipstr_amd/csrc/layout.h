@@ -140,4 +140,5 @@ struct hs_dev_t {
   int32_t            allele_chunk;   // alleles per workgroup
   int32_t            lds_len;        // max read length in the batch (LDS carve of the STR kernel)
   int32_t            band_cols;      // max columns of one read side (rows of a band-boundary buffer)
+  int32_t            max_B;          // longest STR allele of the batch (LDS carve of the STR kernel)
 };

@@ -303,7 +303,8 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
         if (opt[k][o].empty()){ err = "empty flank sequence"; return 1; }
     for (size_t o = 0; o < opt[1].size(); o++){
       if (opt[1][o].empty()){ err = "empty STR allele is not supported"; return 1; }
-      if (opt[1][o].size() > 256){ err = "STR allele longer than 256 bp is not supported"; return 1; }
+      if (opt[1][o].size() > 1024){ err = "STR allele longer than 1024 bp is not supported"; return 1; }
+      out.max_B = std::max(out.max_B, (int32_t)opt[1][o].size());
     }
     const int A = nopts[0]*nopts[1]*nopts[2];
     if (A != b->hap_off[l+1]-b->hap_off[l]){ err = "hap_off does not match the product of block options"; return 1; }

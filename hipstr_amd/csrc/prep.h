@@ -53,6 +53,7 @@ struct Prepared {
   std::vector<int32_t>    tmembers;
   int64_t ws_mr_size = 0, ws_lt_size = 0, ws_lead_size = 0, ws_col_size = 0;   // doubles, max over chunks
   int32_t max_side_len = 0;
+  int32_t max_B = 1;          // longest STR allele
   int64_t n_out        = 0;
   int64_t n_alignments = 0;   // (active read) x (realigned allele) pairs = HMM alignments per pass
   int32_t max_read_len = 0;
