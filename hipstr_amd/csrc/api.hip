@@ -205,9 +205,10 @@ hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){
     h.band_cols = P.max_side_len > 0 ? P.max_side_len : 1;
     dev->trail_waves = (int)std::min<size_t>(P.trail_items.size() ? P.trail_items.size() : 1, 256 * 16);
     HS_HIP_NULL(hipMalloc((void**)&w, sizeof(double)*(size_t)dev->trail_waves*h.band_cols*64*2)); dev->allocs.push_back(w); h.ws_band = w;
-    hs_tgroup_t* dg = NULL; int32_t* dm = NULL; int32_t* dk = NULL;
-    if (to_device(P.tgroups, &dg) || to_device(P.tmembers, &dm) || to_device(P.tpack, &dk)){ hipstr_hmm_free(dev); return NULL; }
-    dev->allocs.push_back(dg); dev->allocs.push_back(dm); dev->allocs.push_back(dk); h.tgroups = dg; h.tmembers = dm; h.tpack = dk;
+    hs_tgroup_t* dg = NULL; int32_t* dm = NULL; int32_t* dk = NULL; int32_t* dor = NULL;
+    if (to_device(P.tgroups, &dg) || to_device(P.tmembers, &dm) || to_device(P.tpack, &dk) || to_device(P.str_order, &dor)){ hipstr_hmm_free(dev); return NULL; }
+    dev->allocs.push_back(dg); dev->allocs.push_back(dm); dev->allocs.push_back(dk); dev->allocs.push_back(dor);
+    h.tgroups = dg; h.tmembers = dm; h.tpack = dk; h.str_order = dor;
   }
   // Workgroups: one per (active read[, side]), times enough allele chunks to put >= ~8192 wavefronts on the 256 CUs
   int maxA = 1;

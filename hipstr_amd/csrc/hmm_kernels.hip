@@ -556,11 +556,14 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
     L.bq[j] = make_double2(d.qual_correct[q], d.qual_error[q]);
   }
   const int ncyc = (n + 63) / 64;
-  const int k0 = blockIdx.y * d.allele_chunk, k1 = min(uni(v.loc->n_alleles), k0 + d.allele_chunk);
-  int cur_slot = -1;
-  for (int k = k0; k < k1; k++){
-    const hs_allele_t* al = d.alleles + uni(v.loc->hap_begin) + k;
-    if (!uni(al->realign)) continue;
+  // alleles in the side's processing order (nested STR blocks follow each other); a chunk of positions per workgroup
+  const int i0 = blockIdx.y * d.allele_chunk, i1 = min(uni(v.loc->n_re), i0 + d.allele_chunk);
+  const int32_t* order = d.str_order + uni(v.loc->order_off[w]);
+  int cur_slot = -1, prev_B = 0;
+  for (int i = i0; i < i1; i++){
+    const int oe = uni(order[i]);
+    const bool chained = (i > i0) && ((oe >> 30) & 1);
+    const hs_allele_t* al = d.alleles + uni(v.loc->hap_begin) + (oe & 0x3fffffff);
     const int slot = uni(al->lead_slot[w]), str_opt = uni(al->str_opt[w]);
     double* mr_out = d.ws_mr + v.ws_mr + (int64_t)uni(al->re_ord)*(v.len-1) + (w ? v.nL : 0);
     wave_lds_sync();                // the previous allele's readers of rowP/Mt/Dl are done
@@ -594,12 +597,15 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
     wave_lds_sync();
 
     // --- StutterAlignerClass::load_read (StutterAlignerClass.cpp:12-53): match_probs_ and del_probs_
+    // (a block that ends with the previous allele's block only appends terms to that allele's sums)
+    const int t0 = chained ? min(prev_B, n) : 0;
+    prev_B = B;
     for (int kk = 0; kk < ncyc; kk++){
       const int j = min(lane + 64*kk, n-1);
-      double lp = 0.0;
+      double lp = (t0 > 0) ? L.Mt[j] : 0.0;
       const int tmax = min(B, n);
       const int ndp = c.nd * p;
-      for (int t = 0; t < tmax; t++){
+      for (int t = t0; t < tmax; t++){
         const uint8_t bc = blk_at(c, B-1-t);
         const int pos = max(j - t, 0);
         const double e = emit(L.rd[pos], bc, L.bq[pos]);

@@ -79,6 +79,7 @@ struct hs_locus_t {
   int32_t n_lead[2];         // distinct leading-flank rowsets per side
   int32_t tg_begin[2];       // trailing-flank allele groups of this locus per side: range in tgroups[]
   int32_t tg_count[2];
+  int32_t order_off[2];      // STR-kernel processing order of the realigned alleles per side: range [order_off, +n_re) in str_order[]
 };
 
 struct hs_read_t {
@@ -122,6 +123,8 @@ struct hs_dev_t {
   const hs_tgroup_t* tgroups;
   const int32_t*     tmembers;   // allele indices (within the locus) of the trail groups
   const int32_t*     tpack;      // active-read indices of the reads packed into one trail item
+  const int32_t*     str_order;  // allele index (within the locus) per processing position; bit 30 set = this allele's STR block,
+                                 // in side orientation, ends with the previous position's block (its tables are continued)
   double*            ws_col;
   double*            ws_band;    // per persistent wavefront: 2 x [band_cols][64 lanes][2] band-boundary rows (M, D)
   double*            ws_mr;

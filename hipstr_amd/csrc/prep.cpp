@@ -380,6 +380,32 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
 
     loc.n_re = n_realigned;
     loc.n_lead[0] = lead_sets[0].size(); loc.n_lead[1] = lead_sets[1].size();
+    for (int side = 0; side < 2; side++){
+      // STR-kernel order: by STR option, options sorted by length; an option whose block (in side orientation) ends with the
+      // previous option's block continues that option's match/deletion tables (StutterAlignerClass::load_read sums run
+      // from the block's right end, so a longer block with the same tail only appends terms)
+      std::vector<int> ks;
+      for (int k = 0; k < A; k++) if (out.alleles[loc.hap_begin + k].realign) ks.push_back(k);
+      auto block_of = [&](int k){
+        int32_t o3[3]; allele_options(nopts, k, o3);
+        std::string q = opt[1][o3[1]];
+        if (side) std::reverse(q.begin(), q.end());
+        return q;
+      };
+      std::stable_sort(ks.begin(), ks.end(), [&](int x, int y){
+        const std::string a = block_of(x), b2 = block_of(y);
+        if (a.size() != b2.size()) return a.size() < b2.size();
+        return a < b2;
+      });
+      loc.order_off[side] = out.str_order.size();
+      std::string prev;
+      for (size_t i = 0; i < ks.size(); i++){
+        const std::string cur = block_of(ks[i]);
+        const bool chained = i > 0 && cur.size() >= prev.size() && cur.compare(cur.size() - prev.size(), prev.size(), prev) == 0;
+        out.str_order.push_back(ks[i] | (chained ? (1 << 30) : 0));
+        prev = cur;
+      }
+    }
     for (int side = 0; side < 2; side++){      // alleles sharing a trailing-flank rowset run as lanes of one wavefront (<= 64 each)
       std::map<int, std::vector<int> > by_rowset;
       for (int k = 0; k < A; k++){

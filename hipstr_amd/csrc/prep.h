@@ -49,6 +49,7 @@ struct Prepared {
   std::vector<hs_item_t>  trail_items;     // (first entry in tpack, side, number of packed reads, group): trailing flank of one
                                            // allele group for up to 64/npad reads of one locus and side
   std::vector<int32_t>    tpack;           // active-read indices of the packed reads
+  std::vector<int32_t>    str_order;       // per locus and side: realigned alleles sorted so that nested STR blocks follow each other
   std::vector<hs_tgroup_t> tgroups;
   std::vector<int32_t>    tmembers;
   int64_t ws_mr_size = 0, ws_lt_size = 0, ws_lead_size = 0, ws_col_size = 0;   // doubles, max over chunks
