@@ -587,6 +587,8 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
     const int llen = (lane < HS_MAXREP) ? c.so->del_len[lane] : 0;
     const int total = uni(c.so->del_off[HS_MAXREP-1]) + uni(c.so->del_len[HS_MAXREP-1]) - ins_off;
     const int shapes = (lane <= HS_MAXREP) ? c.so->shape[lane] : -1;
+    // deletion sizes larger than the block have no list (shape -1) but are never evaluated
+    const bool all_simple = __all((lane > HS_MAXREP) || (shapes >= 0) || (lane < HS_MAXREP && B - (lane+1)*p < 0));
     const hs_visit_t bundle = ins_list[min(lane, max(total, ins_len) - 1)];
 
     {
@@ -655,6 +657,47 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
       // The 13 artifact terms are produced by ONE runtime loop (no artifact, insertions +p..+6p, deletions -p..-6p) and
       // kept in a rotating register window; fast_log_sum_exp (mathops.cpp:97-106) does not depend on their order.
       double terms[HS_NART];
+      if (all_simple){
+        // every visiting list of this STR option is "simple" (periodic block): closed-form evaluators, statically indexed terms
+        {
+          const int len = min(B, j + 1);
+          const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
+          terms[HS_MAXREP] = (rdlane(c.cst, HS_MAXREP) + L.Mt[j]) + pre;
+        }
+        double li = 0.0;
+#pragma unroll
+        for (int q = 0; q < HS_MAXREP; q++){
+          const int D = (q+1)*p;
+          for (int m = 0; m < p; m++){
+            const int t = q*p + m;
+            const int pos = max(j - t, 0);
+            const double2 bq = L.bq[pos];
+            const double e = (m < B) ? emit(L.rd[pos], blk_at(c, B-1-min(m, B-1)), bq) : bq.x;
+            if (t <= j) li += e;
+          }
+          const int len = min(B + D, j + 1);
+          const double lp0 = (rdlane(c.cst, 13) + li) + ((len > D) ? L.Mt[max(j - D, 0)] : 0.0);
+          const int lim = actj ? min(max(0, len - D), B) : 0;
+          const double S = simple_eval(d, L, lp0, lim, rdlane(shapes, HS_MAXREP), B);
+          const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
+          terms[HS_MAXREP + 1 + q] = (rdlane(c.cst, HS_MAXREP + 1 + q) + S) + pre;
+        }
+#pragma unroll
+        for (int q = 0; q < HS_MAXREP; q++){
+          const int aD = (q+1)*p;
+          terms[HS_MAXREP - 1 - q] = IMP;
+          if (B - aD >= 0){
+            const int len = min(B - aD, j + 1);
+            const bool direct = (j + aD <= n - 1);
+            double lp0 = rdlane(c.cst, 14 + q);
+            if (direct) lp0 += L.Mt[min(j + aD, n-1)] - L.Dl[q*L.ld + min(j + aD, n-1)];
+            else        lp0 = L.nd[q*HS_ND_STRIDE + min(max(j - max(0, n - aD), 0), HS_ND_STRIDE-1)];
+            const double S = simple_eval(d, L, lp0, actj ? len : 0, rdlane(shapes, q), B - aD);
+            const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
+            terms[HS_MAXREP - 1 - q] = (rdlane(c.cst, HS_MAXREP - 1 - q) + S) + pre;
+          }
+        }
+      } else {
 #pragma unroll
       for (int t = 0; t < HS_NART; t++) terms[t] = IMP;
       double li = 0.0;                               // running ins_probs_ sum (StutterAlignerClass.cpp:40-51)
@@ -703,6 +746,7 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
 #pragma unroll
         for (int t = 0; t + 1 < HS_NART; t++) terms[t] = terms[t+1];
         terms[HS_NART-1] = term;
+      }
       }
       Lse acc;
       for (int pass = 0; pass < 2; pass++){
