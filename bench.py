@@ -83,10 +83,17 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # HIPSTR_BENCH_SHARE_GPU=1 (testing only): all ranks use GPU 0 and rendezvous over gloo, to exercise the N>1 code path on a 1-GPU box
+    share = os.environ.get("HIPSTR_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from hipstr_amd import capi
     hmm = capi.load_hmm()
@@ -152,10 +159,11 @@ def main():
     assert np.all(np.isfinite(probs)) and np.all(probs <= 1e-10), "forward scores must be finite log-likelihoods <= 0"
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dev_t = "cpu" if share else "cuda"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        cnt = torch.tensor([float(n_aln.value), float(loci)], dtype=torch.float64, device="cuda")
+        cnt = torch.tensor([float(n_aln.value), float(loci)], dtype=torch.float64, device=dev_t)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         total_aln, total_loci = float(cnt[0].item()), float(cnt[1].item())
     else:

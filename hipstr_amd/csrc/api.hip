@@ -144,7 +144,14 @@ hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){
   if (ensure_init()) return NULL;
   hipstr_dev_batch_t* dev = new hipstr_dev_batch_t();
   std::string err;
-  const int64_t budget = getenv("HIPSTR_WS_GIB") ? (int64_t)(atof(getenv("HIPSTR_WS_GIB"))*134217728.0) : ((int64_t)3 << 30);   // doubles per workspace
+  // workspace budget (doubles per workspace; there are two large ones): HIPSTR_WS_GIB, else a fifth of the free HBM, at most 24 GiB
+  int64_t budget = (int64_t)3 << 30;
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) budget = std::min<int64_t>(budget, (int64_t)(free_b / 5 / sizeof(double)));
+    if (getenv("HIPSTR_WS_GIB")) budget = (int64_t)(atof(getenv("HIPSTR_WS_GIB"))*134217728.0);
+    if (budget < 1024) budget = 1024;
+  }
   if (hipstr::prepare_batch(batch, dev->prep, err, budget)){ g_err = err; delete dev; return NULL; }
   hipstr::Prepared& P = dev->prep;
   {  // SURVEY.md §8(d) algorithmic traffic and flank-cell work of one pass
