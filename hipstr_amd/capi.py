@@ -42,6 +42,73 @@ class HipstrPostBatch(C.Structure):
     ]
 
 
+class HipstrTraceOut(C.Structure):
+    _fields_ = [("ll", _f64p), ("max_index", _i32p), ("hap_aln_off", _i32p), ("hap_aln", C.c_char_p), ("stutter_size", _i32p),
+                ("str_seq_off", _i32p), ("str_seq", C.c_char_p), ("flank_seq_off", _i32p), ("flank_seq", C.c_char_p),
+                ("flank_ins", _i32p), ("flank_del", _i32p), ("indel_off", _i32p), ("indel_pos", _i32p), ("indel_size", _i32p),
+                ("snp_off", _i32p), ("snp_pos", _i32p), ("snp_base", C.c_char_p), ("aln_start", _i32p), ("aln_stop", _i32p),
+                ("cigar_off", _i32p), ("cigar_op", C.c_char_p), ("cigar_len", _i32p), ("aln_str_off", _i32p), ("aln_str", C.c_char_p),
+                ("cap_chars", C.c_int32)]
+
+
+def run_trace(lib, prefix, bptr, req_read, req_allele, hap_to_ref=None, cap=1 << 16):
+    """Call <prefix>trace on a one-locus batch; returns a list of dicts (one per request) with python-typed fields.
+    hap_to_ref: list of bytes (one per allele) or None.  The reference probe (prefix 'ref_') always stitches."""
+    n = len(req_read)
+    o = HipstrTraceOut(); keep = {}
+    def i32(name, m):
+        a = np.zeros(m, np.int32); keep[name] = a; setattr(o, name, a.ctypes.data_as(_i32p))
+    def chars(name):
+        a = C.create_string_buffer(cap); keep[name] = a; setattr(o, name, C.cast(a, C.c_char_p))
+    keep["ll"] = np.zeros(max(n, 1)); o.ll = keep["ll"].ctypes.data_as(_f64p)
+    for nm, m in (("max_index", n), ("hap_aln_off", n + 1), ("stutter_size", n), ("str_seq_off", n + 1), ("flank_seq_off", 2 * n + 1),
+                  ("flank_ins", n), ("flank_del", n), ("indel_off", n + 1), ("indel_pos", cap), ("indel_size", cap), ("snp_off", n + 1),
+                  ("snp_pos", cap), ("aln_start", n), ("aln_stop", n), ("cigar_off", n + 1), ("cigar_len", cap), ("aln_str_off", n + 1)):
+        i32(nm, max(m, 1))
+    for nm in ("hap_aln", "str_seq", "flank_seq", "snp_base", "cigar_op", "aln_str"):
+        chars(nm)
+    o.cap_chars = cap
+    rr = np.ascontiguousarray(np.asarray(req_read, np.int32)); aa = np.ascontiguousarray(np.asarray(req_allele, np.int32))
+    fn = getattr(lib, prefix + "trace")
+    if prefix == "ref_":
+        fn.restype = C.c_int; fn.argtypes = [_BP, C.c_int32, _i32p, _i32p, C.POINTER(HipstrTraceOut)]
+        rc = fn(bptr, n, rr.ctypes.data_as(_i32p), aa.ctypes.data_as(_i32p), C.byref(o))
+    else:
+        fn.restype = C.c_int; fn.argtypes = [_BP, C.c_int32, _i32p, _i32p, C.POINTER(C.c_char_p), C.POINTER(HipstrTraceOut)]
+        h2r = None
+        if hap_to_ref is not None:
+            h2r = (C.c_char_p * len(hap_to_ref))(*hap_to_ref)
+        rc = fn(bptr, n, rr.ctypes.data_as(_i32p), aa.ctypes.data_as(_i32p), h2r, C.byref(o))
+    if rc != 0:
+        raise RuntimeError("%strace failed rc=%d" % (prefix, rc))
+    def piece(pool, off, i):
+        return keep[pool].raw[keep[off][i]:keep[off][i + 1]].decode()
+    out = []
+    for q in range(n):
+        out.append(dict(
+            ll=float(keep["ll"][q]), max_index=int(keep["max_index"][q]), hap_aln=piece("hap_aln", "hap_aln_off", q),
+            stutter_size=int(keep["stutter_size"][q]), str_seq=piece("str_seq", "str_seq_off", q),
+            flank_left=piece("flank_seq", "flank_seq_off", 2 * q), flank_right=piece("flank_seq", "flank_seq_off", 2 * q + 1),
+            flank_ins=int(keep["flank_ins"][q]), flank_del=int(keep["flank_del"][q]),
+            indels=[(int(keep["indel_pos"][i]), int(keep["indel_size"][i])) for i in range(keep["indel_off"][q], keep["indel_off"][q + 1])],
+            snps=[(int(keep["snp_pos"][i]), keep["snp_base"].raw[i:i + 1].decode()) for i in range(keep["snp_off"][q], keep["snp_off"][q + 1])],
+            aln_start=int(keep["aln_start"][q]), aln_stop=int(keep["aln_stop"][q]),
+            cigar="".join("%d%s" % (keep["cigar_len"][i], keep["cigar_op"].raw[i:i + 1].decode()) for i in range(keep["cigar_off"][q], keep["cigar_off"][q + 1])),
+            aln_str=piece("aln_str", "aln_str_off", q)))
+    return out
+
+
+def ref_hap_aln_info(ref, bptr, n_alleles, cap=1 << 20):
+    """Haplotype::get_aln_info() of every allele (list of bytes) from the compiled reference."""
+    ref.ref_hap_aln_info.restype = C.c_int
+    ref.ref_hap_aln_info.argtypes = [_BP, C.c_char_p, C.c_int, _i32p]
+    buf = C.create_string_buffer(cap); offs = np.zeros(n_alleles + 1, np.int32)
+    rc = ref.ref_hap_aln_info(bptr, buf, cap, offs.ctypes.data_as(_i32p))
+    if rc != 0:
+        raise RuntimeError("ref_hap_aln_info rc=%d" % rc)
+    return [buf.raw[offs[k]:offs[k + 1] - 1] for k in range(n_alleles)]
+
+
 def _ptr(a, typ):
     return None if a is None else a.ctypes.data_as(typ)
 

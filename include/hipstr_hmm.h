@@ -188,6 +188,50 @@ int  hipstr_post_launch(hipstr_post_dev_t* pd, void* hip_stream);
 int  hipstr_post_fetch(hipstr_post_dev_t* pd, double* log_post, double* sample_total_ll, int32_t* map_gt, double* locus_total_ll);
 void hipstr_post_free(hipstr_post_dev_t* pd);
 
+/*
+ * Viterbi traceback: HapAligner::trace_optimal_aln (HapAligner.cpp:711-722) = process_read(..., retrace_aln=true) on one
+ * fixed haplotype: full M/I/D matrices of both sides, arg-max seed position (compute_aln_logprob's max_index,
+ * HapAligner.cpp:184-222), HapAligner::retrace (HapAligner.cpp:363-571) with its 0.001-nat tie tolerances, and — when the
+ * caller supplies the haplotype-to-reference alignment strings (Haplotype::get_aln_info) — stitch_alignment_trace
+ * (AlignmentTraceback.cpp:55-144).  One request = (read, allele) of a ONE-locus batch; the read must have a seed.
+ * Everything an AlignmentTrace holds (AlignmentTraceback.h:10-108) comes back flattened; all arrays are caller-allocated,
+ * string pools are filled back to back with *_off[] giving the start of each request's piece ([n_req+1] entries).
+ */
+#define HIPSTR_NO_STR_DATA (-100000)     /* str_data_[block] == NULL: the alignment never entered the STR block */
+typedef struct hipstr_trace_out {
+  double*  ll;             /* [n_req] log-likelihood of the traced alignment (== the forward score)                  */
+  int32_t* max_index;      /* [n_req] haplotype position aligned with the seed base                                   */
+  int32_t* hap_aln_off;    /* [n_req+1] */
+  char*    hap_aln;        /* AlignmentTrace::hap_aln(): read-vs-haplotype operations 'M','I','D','S'                 */
+  int32_t* stutter_size;   /* [n_req] AlignmentTrace::stutter_size(1) or HIPSTR_NO_STR_DATA                            */
+  int32_t* str_seq_off;    /* [n_req+1] */
+  char*    str_seq;        /* AlignmentTrace::str_seq(1)                                                              */
+  int32_t* flank_seq_off;  /* [2*n_req+1]: left flank (block 0) then right flank (block 2) of each request            */
+  char*    flank_seq;      /* AlignmentTrace::flank_seq(block)                                                        */
+  int32_t* flank_ins;      /* [n_req] flank_ins_size()                                                                */
+  int32_t* flank_del;      /* [n_req] flank_del_size()                                                                */
+  int32_t* indel_off;      /* [n_req+1] */
+  int32_t* indel_pos;      /* flank_indel_data(): (position, size) pairs in the order retrace records them             */
+  int32_t* indel_size;
+  int32_t* snp_off;        /* [n_req+1] */
+  int32_t* snp_pos;        /* flank_snp_data(): (position, base)                                                       */
+  char*    snp_base;
+  /* stitched alignment against the reference (only when hap_to_ref is given) */
+  int32_t* aln_start;      /* [n_req] traced_aln().get_start()                                                        */
+  int32_t* aln_stop;       /* [n_req] traced_aln().get_stop()                                                         */
+  int32_t* cigar_off;      /* [n_req+1] */
+  char*    cigar_op;       /* traced_aln().get_cigar_list()                                                           */
+  int32_t* cigar_len;
+  int32_t* aln_str_off;    /* [n_req+1] */
+  char*    aln_str;        /* traced_aln().get_alignment()                                                            */
+  int32_t  cap_chars;      /* capacity of every char pool / pair pool above (per pool)                                */
+} hipstr_trace_out_t;
+
+/* hap_to_ref: NULL, or for every allele k of the locus the NUL-terminated Haplotype::get_aln_info() string
+ * ('M','I','D' of the haplotype against the reference haplotype), [num_combs] pointers. */
+int hipstr_hmm_trace(const hipstr_batch_t* one_locus, int32_t n_req, const int32_t* req_read, const int32_t* req_allele,
+                     const char* const* hap_to_ref, hipstr_trace_out_t* out);
+
 /* Diagnostics (host only, no device): the haplotype rows of allele k of a ONE-locus batch as the
  * device sweep consumes them — side 0 = forward/left problem, 1 = reversed/right problem; which 0 =
  * leading flank block, 1 = trailing flank block.  Row encoding: bits 0-7 base, 8-11 homopolymer index

@@ -295,6 +295,8 @@ typedef struct {
   double* Mt; double* Dl; double* In;   /* indexed by from-the-right offset */
   int** ups;
   double* scratch; int nscratch;
+  int left_align;           /* RepeatBlock.h:29,42,51: true for the forward haplotype, false for the reversed one */
+  int best_pos;             /* arg-max artifact position of the last stut_ins/stut_del call (traceback only) */
 } OStut;
 
 static double emit1(char r, char c, double lc, double lw){ return r == c ? lc : lw; }
@@ -333,6 +335,7 @@ static double stut_ins(OStut* s, int len, int j, int D){
   const int* up = s->ups[0];
   double lp = -g_int_log[B+1] + s->In[s->nins*off + D/p - 1] + (len > D ? s->Mt[off+D] : 0);
   v[cnt++] = lp;
+  double best = lp; s->best_pos = 0;
   int lim = len-D; if (lim < 0) lim = 0; if (lim > B) lim = B;
   int i = 0;
   for (; i > -lim; i--){
@@ -349,6 +352,7 @@ static double stut_ins(OStut* s, int len, int j, int D){
         i -= (U-1);
       }
     } else v[cnt++] = lp;
+    if (lp > best || (s->left_align && lp == best)){ s->best_pos = 1-i; best = lp; }   /* StutterAlignerClass.cpp:92-95 */
   }
   if (i > -B) v[cnt++] = g_int_log[B+i] + lp;
   return oracle_fast_lse_vec(v, cnt);
@@ -365,6 +369,7 @@ static double stut_del(OStut* s, int len, int j, int D){
   else
     for (int k = 0; k > -len; k--) lp += emit1(s->rd[j+k], s->blk[B-1+k+D], s->blc[j+k], s->blw[j+k]);
   v[cnt++] = lp;
+  double best = lp; s->best_pos = 0;
   int i;
   for (i = 0; i > -len; i--){
     int U = up[B-1+i];
@@ -376,6 +381,7 @@ static double stut_del(OStut* s, int len, int j, int D){
       v[cnt++] = g_int_log[U] + lp;
       i -= (U-1);
     }
+    if (lp > best || (s->left_align && lp == best)){ s->best_pos = 1-i; best = lp; }   /* StutterAlignerClass.cpp:138-141 */
   }
   if (-i < B+D) v[cnt++] = g_int_log[B+D+i] + lp;
   return oracle_fast_lse_vec(v, cnt);
@@ -387,6 +393,8 @@ typedef struct {
   const char* rd; const double* blc; const double* blw;
   double *M, *I, *D;        /* [max_size * n] row = haplotype position */
   double side_prob;
+  int *art_size, *art_pos;  /* [n] best artifact size / position per read column of the STR block (traceback), or NULL */
+  int left_align;
 } OAln;
 
 /* test hook: when set, align_side records the homopolymer index used for every flank row */
@@ -420,6 +428,7 @@ static void align_side(OSide* sd, int reuse, int last_changed, OAln* a, const do
       OStut st;
       st.n = n; st.B = blen; st.p = period; st.nins = HIPSTR_MAX_STUTTER_REPS; st.ndel = sd->ndel[o];
       st.blk = bs; st.rd = a->rd; st.blc = a->blc; st.blw = a->blw; st.ups = sd->ups[o];
+      st.left_align = a->left_align; st.best_pos = -1;
       st.Mt = malloc(sizeof(double)*n);
       st.Dl = malloc(sizeof(double)*n*(st.ndel > 0 ? st.ndel : 1));
       st.In = malloc(sizeof(double)*n*st.nins);
@@ -429,13 +438,19 @@ static void align_side(OSide* sd, int reuse, int last_changed, OAln* a, const do
       double* rowM = M + (size_t)n*(hi+blen-1); double* rowI = I + (size_t)n*(hi+blen-1); double* rowD = D + (size_t)n*(hi+blen-1);
       for (int j = 0; j < n; j++){
         double terms[HIPSTR_NUM_ARTIFACTS]; int t = 0;
+        double best_ll = IMPOSSIBLE;                      /* HapAligner.cpp:81-97 */
+        if (a->art_size) a->art_size[j] = -10000;
         for (int art = -HIPSTR_MAX_STUTTER_REPS*period; art <= HIPSTR_MAX_STUTTER_REPS*period; art += period, t++){
           int len = blen+art < j+1 ? blen+art : j+1;
+          int apos = -1;
           if (len >= 0){
-            double pr = art == 0 ? st.Mt[n-1-j] : art > 0 ? stut_ins(&st, len, j, art) : stut_del(&st, len, j, art);
+            double pr;
+            if (art == 0) pr = st.Mt[n-1-j];
+            else { pr = art > 0 ? stut_ins(&st, len, j, art) : stut_del(&st, len, j, art); apos = st.best_pos; }
             double pre = (j-len < 0 ? 0 : prevM[j-len]);
             terms[t] = pmf[o*HIPSTR_NUM_ARTIFACTS + t] + pr + pre;
           } else terms[t] = IMPOSSIBLE;
+          if (a->art_size && terms[t] > best_ll){ a->art_size[j] = art; a->art_pos[j] = apos; best_ll = terms[t]; }
         }
         rowM[j] = oracle_fast_lse_vec(terms, HIPSTR_NUM_ARTIFACTS);
         rowI[j] = IMPOSSIBLE; rowD[j] = IMPOSSIBLE;
@@ -474,7 +489,7 @@ static void align_side(OSide* sd, int reuse, int last_changed, OAln* a, const do
 }
 
 /* HapAligner.cpp:163-231 (forward haplotype = L side) */
-static double combine(const OSide* fw, const OAln* L, const OAln* R, char seed_c, double seed_lw, double seed_lc, double* scratch){
+static double combine(const OSide* fw, const OAln* L, const OAln* R, char seed_c, double seed_lw, double seed_lc, double* scratch, int* max_index){
   int nL = L->n, nR = R->n, H = 0, nseeds = 0, cnt = 0;
   for (int bi = 0; bi < 3; bi++){ int len = fw->blk[bi].len[fw->counts[bi]]; H += len; if (bi != 1) nseeds += len; }
   double prior = -g_int_log[nseeds];
@@ -482,17 +497,22 @@ static double combine(const OSide* fw, const OAln* L, const OAln* R, char seed_c
   const char* b2 = fw->blk[2].seq[fw->counts[2]]; int l2 = fw->blk[2].len[fw->counts[2]];
   scratch[cnt++] = prior + (seed_c == b0[0] ? seed_lc : seed_lw) + L->side_prob + R->M[(size_t)nR*(H-1)-1];
   scratch[cnt++] = prior + (seed_c == b2[l2-1] ? seed_lc : seed_lw) + R->side_prob + L->M[(size_t)nL*(H-1)-1];
+  int mi = 0; double mll = scratch[0];                    /* HapAligner.cpp:184-193 */
+  if (scratch[1] > mll){ mi = H-1; mll = scratch[1]; }
+  int hap_index = 1;
   const double* lp = L->M + (nL-1);
   const double* rp = R->M + ((size_t)nR*(H-2) - 1);
   for (int bi = 0; bi < 3; bi++){
     const char* bs = fw->blk[bi].seq[fw->counts[bi]]; int blen = fw->blk[bi].len[fw->counts[bi]];
-    if (bi == 1){ lp += (size_t)nL*blen; rp -= (size_t)nR*blen; continue; }
+    if (bi == 1){ lp += (size_t)nL*blen; rp -= (size_t)nR*blen; hap_index += blen; continue; }
     int ci = (bi == 0 ? 1 : 0), ce = (bi == 2 ? blen-1 : blen);
-    for (; ci < ce; ci++){
+    for (; ci < ce; ci++, hap_index++){
       scratch[cnt++] = prior + (seed_c == bs[ci] ? seed_lc : seed_lw) + *lp + *rp;
+      if (scratch[cnt-1] > mll){ mi = hap_index; mll = scratch[cnt-1]; }   /* HapAligner.cpp:219-222 */
       lp += nL; rp -= nR;
     }
   }
+  if (max_index) *max_index = mi;
   return oracle_fast_lse_vec(scratch, cnt);
 }
 
@@ -623,8 +643,8 @@ int oracle_process_reads(const hipstr_batch_t* b, double* aln_probs, int32_t* se
       char* rrd = malloc(nR+1); double* rlw = malloc(sizeof(double)*nR); double* rlc = malloc(sizeof(double)*nR);
       for (int j = 0; j < nR; j++){ rrd[j] = bases[len-1-j]; rlw[j] = lw[len-1-j]; rlc[j] = lc[len-1-j]; }
       OAln L, R;
-      L.n = nL; L.rd = bases; L.blc = lc; L.blw = lw;
-      R.n = nR; R.rd = rrd;  R.blc = rlc; R.blw = rlw;
+      L.n = nL; L.rd = bases; L.blc = lc; L.blw = lw; L.art_size = L.art_pos = NULL; L.left_align = 1;
+      R.n = nR; R.rd = rrd;  R.blc = rlc; R.blw = rlw; R.art_size = R.art_pos = NULL; R.left_align = 0;
       L.M = malloc(sizeof(double)*(size_t)nL*Hmax); L.I = malloc(sizeof(double)*(size_t)nL*Hmax); L.D = malloc(sizeof(double)*(size_t)nL*Hmax);
       R.M = malloc(sizeof(double)*(size_t)nR*Hmax); R.I = malloc(sizeof(double)*(size_t)nR*Hmax); R.D = malloc(sizeof(double)*(size_t)nR*Hmax);
       double* scratch = malloc(sizeof(double)*(Hmax+4));
@@ -637,7 +657,7 @@ int oracle_process_reads(const hipstr_batch_t* b, double* aln_probs, int32_t* se
         g_dbg_side = 0; align_side(&fw, reuse, lc_fw, &L, pmf, period);
         g_dbg_side = 1; align_side(&rv, reuse, lc_rv, &R, pmf, period);
         if (g_dbg_h[0] && it.counter == g_dbg_stop){ g_dbg_h[0] = g_dbg_h[1] = NULL; }
-        out[it.counter] = combine(&fw, &L, &R, bases[sb], lw[sb], lc[sb], scratch);
+        out[it.counter] = combine(&fw, &L, &R, bases[sb], lw[sb], lc[sb], scratch, NULL);
         reuse = 1;
       } while (iter_next(&it));
       free(scratch);
@@ -698,5 +718,297 @@ int oracle_debug_row_h(const hipstr_batch_t* b, int k, int32_t* h_fw, int32_t* h
   int rc = oracle_process_reads(b, probs, seeds);
   g_dbg_h[0] = g_dbg_h[1] = NULL;
   free(probs); free(seeds);
+  return rc;
+}
+
+/* ====================================================================== traceback (A.12)
+ * HapAligner::trace_optimal_aln (HapAligner.cpp:711-722) -> process_read(retrace_aln = true) on ONE fixed haplotype
+ * (HapAligner.cpp:573-709), HapAligner::retrace (363-571) and stitch_alignment_trace (AlignmentTraceback.cpp:55-144).
+ * Restated on the flat batch; output flattened into hipstr_trace_out_t.                                            */
+#define TRACE_LL_TOL 0.001                                   /* HapAligner.cpp:345 */
+#define MIN_SNP_LOG_PROB_CORRECT (-0.0043648054)             /* HapAligner.cpp:24 */
+
+typedef struct { char* s; int n, cap; } OStr;
+static void ostr_init(OStr* o, int cap){ o->s = malloc(cap+1); o->n = 0; o->cap = cap; o->s[0] = 0; }
+static void ostr_push(OStr* o, char c){ if (o->n + 1 >= o->cap){ o->cap *= 2; o->s = realloc(o->s, o->cap+1); } o->s[o->n++] = c; o->s[o->n] = 0; }
+static void ostr_rev(OStr* o){ for (int i = 0, j = o->n-1; i < j; i++, j--){ char t = o->s[i]; o->s[i] = o->s[j]; o->s[j] = t; } }
+static void ostr_cat(OStr* d, const OStr* a){ for (int i = 0; i < a->n; i++) ostr_push(d, a->s[i]); }
+
+typedef struct {                                /* what AlignmentTrace accumulates (AlignmentTraceback.h:27-34) */
+  int str_set, stutter_size; OStr str_seq;
+  OStr flank[3];
+  int flank_ins, flank_del;
+  int n_indel, indel_pos[512], indel_size[512];
+  int n_snp, snp_pos[512]; char snp_base[512];
+} OTrace;
+
+static int tri_idx(int rev, double v1, double v2, double v3){       /* HapAligner.cpp:346-358 */
+  if (!rev){ if (v1 > v2+TRACE_LL_TOL) return (v1 > v3+TRACE_LL_TOL ? 0 : 2); return (v2 > v3+TRACE_LL_TOL ? 1 : 2); }
+  if (v3 > v2+TRACE_LL_TOL) return (v3 > v1+TRACE_LL_TOL ? 2 : 0);
+  return (v2 > v1+TRACE_LL_TOL ? 1 : 0);
+}
+static int pair_idx(int rev, double v1, double v2){                 /* HapAligner.cpp:360-361 */
+  if (!rev) return (v1 > v2+TRACE_LL_TOL ? 0 : 1);
+  return (v2 > v1+TRACE_LL_TOL ? 1 : 0);
+}
+
+/* block start coordinate as the (possibly reversed) haplotype reports it: HapBlock::reverse() builds HapBlock(end_-1, start_-1, ..),
+ * RepeatBlock::reverse() keeps (start_, end_) (HapBlock.h:123-133, RepeatBlock.h:48-58) */
+static int32_t side_block_start(const hipstr_batch_t* b, int rev, int bi){
+  int fb = rev ? 2-bi : bi;
+  if (!rev || fb == 1) return b->blk_start[fb];
+  return b->blk_end[fb]-1;
+}
+
+/* HapAligner::retrace (HapAligner.cpp:363-571) */
+static void retrace_side(const hipstr_batch_t* b, const OSide* sd, int rev, const OAln* a, int block_index, int base_index, long matrix_index,
+                         OTrace* tr, OStr* aln){
+  const int MATCH = 0, DEL = 1, INS = 2, NONE = -1;
+  int n = a->n, seq_index = n-1, matrix_type = MATCH;
+  const double* M = a->M; const double* I = a->I; const double* D = a->D;
+  while (block_index >= 0){
+    const OBlock* ob = &sd->blk[block_index]; int o = sd->counts[block_index];
+    const char* bs = ob->seq[o]; int blen = ob->len[o];
+    if (block_index == 1){
+      int size = a->art_size[seq_index], apos = a->art_pos[seq_index];
+      OStr ss; ostr_init(&ss, blen + 64);
+      int i = 0;
+      for (; i < (seq_index+1 < apos ? seq_index+1 : apos); i++){ ostr_push(aln, 'M'); ostr_push(&ss, a->rd[seq_index-i]); }
+      if (size < 0) for (int k = 0; k < -size; k++) ostr_push(aln, 'D');
+      else for (; i < (seq_index+1 < apos+size ? seq_index+1 : apos+size); i++){ ostr_push(aln, 'I'); ostr_push(&ss, a->rd[seq_index-i]); }
+      for (; i < (blen+size < seq_index+1 ? blen+size : seq_index+1); i++){ ostr_push(aln, 'M'); ostr_push(&ss, a->rd[seq_index-i]); }
+      if (!rev) ostr_rev(&ss);
+      tr->str_set = 1; tr->stutter_size = size; tr->str_seq.n = 0; ostr_cat(&tr->str_seq, &ss);
+      free(ss.s);
+      if (blen + size >= seq_index+1) return;          /* sequence doesn't span the stutter block */
+      matrix_index -= (blen + size + (long)n*blen);
+      matrix_type = MATCH;
+      seq_index -= (blen + size);
+    } else {
+      int prev_type = NONE;
+      int32_t pos = side_block_start(b, rev, block_index) + (rev ? -base_index : base_index);
+      const int32_t inc = rev ? 1 : -1;
+      int indel_seq_index = -1; int32_t indel_position = -1;
+      OStr fs; ostr_init(&fs, blen + 64);
+      int out_block = rev ? 2-block_index : block_index;
+      while (base_index >= 0 && seq_index >= 0){
+        int h1 = hom_len(sd, block_index, base_index), h2 = hom_len(sd, block_index, base_index-1 > 0 ? base_index-1 : 0);
+        int h = h1 > h2 ? h1 : h2; if (h > HIPSTR_MAX_HOMOP_LEN) h = HIPSTR_MAX_HOMOP_LEN;
+        if (matrix_type != prev_type){
+          if (prev_type == DEL){
+            if (rev){ tr->indel_pos[tr->n_indel] = indel_position; tr->indel_size[tr->n_indel++] = indel_position - pos; }
+            else    { tr->indel_pos[tr->n_indel] = pos+1;          tr->indel_size[tr->n_indel++] = pos - indel_position; }
+          } else if (prev_type == INS){
+            tr->indel_pos[tr->n_indel] = indel_position + (rev ? 0 : 1); tr->indel_size[tr->n_indel++] = indel_seq_index - seq_index;
+          }
+          if (matrix_type == DEL || matrix_type == INS){ indel_seq_index = seq_index; indel_position = pos; }
+          prev_type = matrix_type;
+        }
+        if (matrix_type == MATCH){
+          if (bs[base_index] != a->rd[seq_index] && a->blc[seq_index] > MIN_SNP_LOG_PROB_CORRECT){
+            tr->snp_pos[tr->n_snp] = pos; tr->snp_base[tr->n_snp++] = a->rd[seq_index];
+          }
+          ostr_push(&fs, a->rd[seq_index]); ostr_push(aln, 'M'); seq_index--; base_index--; pos += inc;
+        } else if (matrix_type == DEL){
+          tr->flank_del++; ostr_push(aln, 'D'); base_index--; pos += inc;
+        } else {
+          tr->flank_ins++; ostr_push(&fs, a->rd[seq_index]); ostr_push(aln, 'I'); seq_index--;
+        }
+        if (seq_index == -1 || (base_index == -1 && block_index == 0)){
+          while (seq_index != -1){ ostr_push(aln, 'S'); seq_index--; }
+          if (!rev) ostr_rev(&fs);
+          ostr_cat(&tr->flank[out_block], &fs);
+          free(fs.s);
+          return;
+        }
+        int best;
+        if (matrix_type == MATCH){
+          best = tri_idx(rev, I[matrix_index-1] + g_m2i[h], D[matrix_index-n-1] + g_m2d[h], M[matrix_index-n-1] + g_m2m[h]);
+          if (best == 0){ matrix_type = INS; matrix_index -= 1; }
+          else if (best == 1){ matrix_type = DEL; matrix_index -= (n+1); }
+          else { matrix_type = MATCH; matrix_index -= (n+1); }
+        } else if (matrix_type == DEL){
+          best = pair_idx(rev, D[matrix_index-n] + D2D, M[matrix_index-n] + D2M);
+          matrix_type = (best == 0) ? DEL : MATCH; matrix_index -= n;
+        } else {
+          best = pair_idx(rev, I[matrix_index-1] + I2I, M[matrix_index-n-1] + I2M);
+          if (best == 0){ matrix_type = INS; matrix_index -= 1; }
+          else { matrix_type = MATCH; matrix_index -= (n+1); }
+        }
+      }
+      if (!rev) ostr_rev(&fs);
+      ostr_cat(&tr->flank[out_block], &fs);
+      free(fs.s);
+    }
+    block_index--;
+    if (block_index >= 0) base_index = sd->blk[block_index].len[sd->counts[block_index]] - 1;
+  }
+}
+
+/* AlignmentTraceback.cpp:7-52 */
+static void stitch_dir(const char* hap_aln, int hlen, const char* read_aln, int rlen, int h_index, int r_index, int inc, OStr* out){
+  while (r_index >= 0 && r_index < rlen){
+    if (read_aln[r_index] == 'S'){ ostr_push(out, 'S'); r_index += inc; continue; }
+    if (h_index < 0 || h_index >= hlen) return;
+    if (hap_aln[h_index] == 'D'){
+      if (read_aln[r_index] == 'I'){ ostr_push(out, 'M'); r_index += inc; h_index += inc; }
+      else { ostr_push(out, 'D'); h_index += inc; }
+    }
+    else if (read_aln[r_index] == 'I'){ ostr_push(out, 'I'); r_index += inc; }
+    else if (read_aln[r_index] == 'D'){
+      if (hap_aln[h_index] == 'M') ostr_push(out, 'D');
+      r_index += inc; h_index += inc;
+    }
+    else { ostr_push(out, hap_aln[h_index]); r_index += inc; h_index += inc; }
+  }
+}
+
+static int put_pool(char* pool, int32_t* off, int idx, const char* s, int n, int cap){
+  if (off[idx] + n > cap) return 1;
+  memcpy(pool + off[idx], s, n); off[idx+1] = off[idx] + n; return 0;
+}
+
+int oracle_trace(const hipstr_batch_t* b, int32_t n_req, const int32_t* req_read, const int32_t* req_allele,
+                 const char* const* hap_to_ref, hipstr_trace_out_t* o){
+  oracle_init();
+  if (b->n_loci != 1) return 1;
+  int period = b->period[0];
+  OSide fw, rv;
+  side_build(&fw, b, 0, 0, 0);
+  side_build(&rv, b, 0, 0, 1);
+  OIter it;
+  for (int k = 0; k < 3; k++) it.n[k] = b->blk_nopts[k];
+  int nso = fw.blk[1].nopts;
+  double* pmf = malloc(sizeof(double)*nso*HIPSTR_NUM_ARTIFACTS);
+  for (int oo = 0; oo < nso; oo++){
+    int size = fw.blk[1].len[oo], t = 0;
+    for (int art = -HIPSTR_MAX_STUTTER_REPS*period; art <= HIPSTR_MAX_STUTTER_REPS*period; art += period, t++)
+      pmf[oo*HIPSTR_NUM_ARTIFACTS+t] = (size+art < 0) ? LARGE_NEGATIVE : oracle_stutter_pmf(b->stutter, period, size, size+art);
+  }
+  int Hmax = fw.max_size, rc = 0;
+  o->hap_aln_off[0] = o->str_seq_off[0] = o->flank_seq_off[0] = o->indel_off[0] = o->snp_off[0] = 0;
+  o->cigar_off[0] = o->aln_str_off[0] = 0;
+  for (int q = 0; q < n_req && rc == 0; q++){
+    int r = req_read[q];
+    int sb = seed_base(b, 0, r);
+    if (sb < 0){ rc = 2; break; }
+    iter_reset(&it);
+    while (it.counter < req_allele[q]) if (!iter_next(&it)){ rc = 4; break; }
+    if (rc) break;
+    for (int k = 0; k < 3; k++){ fw.counts[k] = it.cnt[k]; rv.counts[k] = it.cnt[2-k]; }
+    int len = b->base_off[r+1]-b->base_off[r];
+    const char* bases = b->bases + b->base_off[r]; const char* quals = b->quals + b->base_off[r];
+    double* lw = malloc(sizeof(double)*len); double* lc = malloc(sizeof(double)*len);
+    for (int j = 0; j < len; j++){ lw[j] = g_q_error[qual_index(quals[j])]; lc[j] = g_q_correct[qual_index(quals[j])]; }
+    int nL = sb, nR = len-sb-1;
+    char* rrd = malloc(nR+1); double* rlw = malloc(sizeof(double)*nR); double* rlc = malloc(sizeof(double)*nR);
+    for (int j = 0; j < nR; j++){ rrd[j] = bases[len-1-j]; rlw[j] = lw[len-1-j]; rlc[j] = lc[len-1-j]; }
+    OAln L, R;
+    L.n = nL; L.rd = bases; L.blc = lc; L.blw = lw; L.left_align = 1;
+    R.n = nR; R.rd = rrd;  R.blc = rlc; R.blw = rlw; R.left_align = 0;
+    OAln* sides[2] = { &L, &R };
+    for (int s2 = 0; s2 < 2; s2++){
+      OAln* a = sides[s2];
+      a->M = malloc(sizeof(double)*(size_t)a->n*Hmax); a->I = malloc(sizeof(double)*(size_t)a->n*Hmax); a->D = malloc(sizeof(double)*(size_t)a->n*Hmax);
+      a->art_size = malloc(sizeof(int)*a->n); a->art_pos = malloc(sizeof(int)*a->n);
+    }
+    double* scratch = malloc(sizeof(double)*(Hmax+4));
+    align_side(&fw, 0, -1, &L, pmf, period);                 /* go_to() clears last_changed: nothing is reused (Haplotype.cpp:206) */
+    align_side(&rv, 0, -1, &R, pmf, period);
+    int max_index = 0;
+    double LL = combine(&fw, &L, &R, bases[sb], lw[sb], lc[sb], scratch, &max_index);
+    int H = 0, blen3[3];
+    for (int k = 0; k < 3; k++){ blen3[k] = fw.blk[k].len[fw.counts[k]]; H += blen3[k]; }
+
+    OTrace tr; memset(&tr, 0, sizeof tr);
+    ostr_init(&tr.str_seq, 64); for (int k = 0; k < 3; k++) ostr_init(&tr.flank[k], 64);
+    OStr left, right, full; ostr_init(&left, len + H + 8); ostr_init(&right, len + H + 8); ostr_init(&full, 2*(len + H) + 8);
+    /* left of the seed (HapAligner.cpp:642-659) */
+    int sblock = 0, scoord = max_index;
+    for (int k = 0; k < 3; k++){ if (scoord < blen3[k]){ sblock = k; break; } scoord -= blen3[k]; }
+    if (max_index == 0) for (int i = 0; i < nL; i++) ostr_push(&left, 'S');
+    else {
+      long mi = (long)nL*max_index - 1;
+      if (scoord == 0) retrace_side(b, &fw, 0, &L, sblock-1, blen3[sblock-1]-1, mi, &tr, &left);
+      else             retrace_side(b, &fw, 0, &L, sblock, scoord-1, mi, &tr, &left);
+    }
+    ostr_rev(&left);
+    if (sblock != 1) ostr_push(&tr.flank[sblock], bases[sb]);       /* HapAligner.cpp:661-665 */
+    /* right of the seed (HapAligner.cpp:667-684) */
+    int rmax = H-1-max_index, rblock = 0, rcoord = rmax, rlen3[3] = { blen3[2], blen3[1], blen3[0] };
+    for (int k = 0; k < 3; k++){ if (rcoord < rlen3[k]){ rblock = k; break; } rcoord -= rlen3[k]; }
+    if (rmax == 0) for (int i = 0; i < nR; i++) ostr_push(&right, 'S');
+    else {
+      long mi = (long)nR*rmax - 1;
+      if (rcoord == 0) retrace_side(b, &rv, 1, &R, rblock-1, rlen3[rblock-1]-1, mi, &tr, &right);
+      else             retrace_side(b, &rv, 1, &R, rblock, rcoord-1, mi, &tr, &right);
+    }
+    ostr_cat(&full, &left); ostr_push(&full, 'M'); ostr_cat(&full, &right);
+
+    o->ll[q] = LL; o->max_index[q] = max_index;
+    rc |= put_pool(o->hap_aln, o->hap_aln_off, q, full.s, full.n, o->cap_chars);
+    o->stutter_size[q] = tr.str_set ? tr.stutter_size : HIPSTR_NO_STR_DATA;
+    rc |= put_pool(o->str_seq, o->str_seq_off, q, tr.str_seq.s, tr.str_set ? tr.str_seq.n : 0, o->cap_chars);
+    rc |= put_pool(o->flank_seq, o->flank_seq_off, 2*q, tr.flank[0].s, tr.flank[0].n, o->cap_chars);
+    rc |= put_pool(o->flank_seq, o->flank_seq_off, 2*q+1, tr.flank[2].s, tr.flank[2].n, o->cap_chars);
+    o->flank_ins[q] = tr.flank_ins; o->flank_del[q] = tr.flank_del;
+    int io = o->indel_off[q];
+    for (int i = 0; i < tr.n_indel && io < o->cap_chars; i++, io++){ o->indel_pos[io] = tr.indel_pos[i]; o->indel_size[io] = tr.indel_size[i]; }
+    o->indel_off[q+1] = io;
+    int so = o->snp_off[q];
+    for (int i = 0; i < tr.n_snp && so < o->cap_chars; i++, so++){ o->snp_pos[so] = tr.snp_pos[i]; o->snp_base[so] = tr.snp_base[i]; }
+    o->snp_off[q+1] = so;
+
+    /* stitch_alignment_trace (AlignmentTraceback.cpp:55-144) */
+    o->cigar_off[q+1] = o->cigar_off[q]; o->aln_str_off[q+1] = o->aln_str_off[q]; o->aln_start[q] = o->aln_stop[q] = 0;
+    if (hap_to_ref != NULL && rc == 0){
+      const char* h2r = hap_to_ref[req_allele[q]]; int hlen = (int)strlen(h2r);
+      int hap_index = max_index, hai = 0; int32_t seed_pos = b->blk_start[0];
+      while (hap_index > 0 && hai < hlen){
+        if (h2r[hai] == 'M' || h2r[hai] == 'I') hap_index--;
+        if (h2r[hai] == 'M' || h2r[hai] == 'D') seed_pos++;
+        hai++;
+      }
+      while (hai < hlen && h2r[hai] == 'D') hai++;
+      int sbase = sb, rai = 0;
+      while (sbase > 0 && rai < full.n){
+        if (full.s[rai] == 'M' || full.s[rai] == 'I' || full.s[rai] == 'S') sbase--;
+        rai++;
+      }
+      while (rai < full.n && full.s[rai] == 'D') rai++;
+      OStr la, ra, fa; ostr_init(&la, full.n + hlen + 8); ostr_init(&ra, full.n + hlen + 8); ostr_init(&fa, 2*(full.n + hlen) + 8);
+      stitch_dir(h2r, hlen, full.s, full.n, hai-1, rai-1, -1, &la);
+      ostr_rev(&la);
+      stitch_dir(h2r, hlen, full.s, full.n, hai+1, rai+1, 1, &ra);
+      ostr_cat(&fa, &la); ostr_push(&fa, 'M'); ostr_cat(&fa, &ra);
+      for (int i = 0; i < fa.n; i++){ if (fa.s[i] == 'I') fa.s[i] = 'S'; else break; }
+      int32_t start = seed_pos, stop = seed_pos;
+      for (int i = 0; i < la.n; i++) if (la.s[i] == 'D' || la.s[i] == 'M') start--;
+      for (int i = 0; i < ra.n; i++) if (ra.s[i] == 'D' || ra.s[i] == 'M') stop++;
+      o->aln_start[q] = start; o->aln_stop[q] = stop;
+      int co = o->cigar_off[q]; char cc = fa.s[0]; int num = 1;
+      for (int i = 1; i <= fa.n; i++){
+        if (i == fa.n || fa.s[i] != cc){
+          if (co < o->cap_chars){ o->cigar_op[co] = cc; o->cigar_len[co] = num; co++; }
+          if (i < fa.n){ cc = fa.s[i]; num = 1; }
+        } else num++;
+      }
+      o->cigar_off[q+1] = co;
+      OStr as; ostr_init(&as, fa.n + 8);
+      int ri = 0;
+      for (int i = 0; i < fa.n; i++){
+        if (fa.s[i] == 'S') ri++;
+        else if (fa.s[i] == 'M' || fa.s[i] == 'I') ostr_push(&as, bases[ri++]);
+        else ostr_push(&as, '-');
+      }
+      rc |= put_pool(o->aln_str, o->aln_str_off, q, as.s, as.n, o->cap_chars);
+      free(la.s); free(ra.s); free(fa.s); free(as.s);
+    }
+    free(left.s); free(right.s); free(full.s); free(tr.str_seq.s); for (int k = 0; k < 3; k++) free(tr.flank[k].s);
+    free(scratch);
+    for (int s2 = 0; s2 < 2; s2++){ OAln* a = sides[s2]; free(a->M); free(a->I); free(a->D); free(a->art_size); free(a->art_pos); }
+    free(rrd); free(rlw); free(rlc); free(lw); free(lc);
+  }
+  free(pmf); side_free(&fw); side_free(&rv);
   return rc;
 }

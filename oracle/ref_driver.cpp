@@ -21,7 +21,11 @@
 
 #include "SeqAlignment/AlignmentData.h"
 #include "SeqAlignment/AlignmentModel.h"
+// AlignmentTrace offers no "is the STR block set?" accessor (stutter_size()/str_seq() assert instead), so the test driver
+// reads str_data_ directly.  Access specifiers do not change the class layout, and only this TU is compiled this way.
+#define private public
 #include "SeqAlignment/AlignmentTraceback.h"
+#undef private
 #include "SeqAlignment/HapAligner.h"
 #include "SeqAlignment/HapBlock.h"
 #include "SeqAlignment/Haplotype.h"
@@ -232,5 +236,90 @@ extern "C" int ref_posteriors(const hipstr_post_batch_t* pb, double* log_post, d
     samp_off += S;
     ll_off   += (int64_t)(r1-r0)*A;
   }
+  return 0;
+}
+
+/* ---- traceback: HapAligner::trace_optimal_aln on the reference's own objects, flattened into hipstr_trace_out_t ---- */
+namespace {
+bool put_str(char* pool, int32_t* off, int idx, const std::string& s, int cap){
+  if (off[idx] + (int)s.size() > cap) return false;
+  memcpy(pool + off[idx], s.data(), s.size());
+  off[idx+1] = off[idx] + (int)s.size();
+  return true;
+}
+}
+
+extern "C" int ref_trace(const hipstr_batch_t* b, int32_t n_req, const int32_t* req_read, const int32_t* req_allele,
+                         hipstr_trace_out_t* o){
+  ensure_ready();
+  if (b->n_loci != 1) return 1;
+  BaseQuality bq;
+  int opt_cursor = 0;
+  RefLocus loc;
+  build_locus(b, 0, opt_cursor, loc);
+  const int A = loc.hap->num_combs();
+  std::vector<bool> realign_hap(A, true);
+  HapAligner aligner(loc.hap, realign_hap);
+  o->hap_aln_off[0] = o->str_seq_off[0] = o->flank_seq_off[0] = o->indel_off[0] = o->snp_off[0] = 0;
+  o->cigar_off[0] = o->aln_str_off[0] = 0;
+  for (int q = 0; q < n_req; q++){
+    Alignment aln = make_alignment(b, req_read[q]);
+    int seed = aligner.calc_seed_base(aln);
+    if (seed < 0) return 2;
+    AlignmentTrace* tr = aligner.trace_optimal_aln(aln, seed, req_allele[q], &bq);
+    o->ll[q] = 0; o->max_index[q] = -1;      /* not exposed by the reference's API; checked through hap_aln instead */
+    if (!put_str(o->hap_aln, o->hap_aln_off, q, tr->hap_aln(), o->cap_chars)) return 3;
+    if (tr->str_data_[1] != NULL){
+      o->stutter_size[q] = tr->stutter_size(1);
+      if (!put_str(o->str_seq, o->str_seq_off, q, tr->str_seq(1), o->cap_chars)) return 3;
+    } else {
+      o->stutter_size[q] = HIPSTR_NO_STR_DATA;
+      o->str_seq_off[q+1] = o->str_seq_off[q];
+    }
+    if (!put_str(o->flank_seq, o->flank_seq_off, 2*q,   tr->flank_seq(0), o->cap_chars)) return 3;
+    if (!put_str(o->flank_seq, o->flank_seq_off, 2*q+1, tr->flank_seq(2), o->cap_chars)) return 3;
+    o->flank_ins[q] = tr->flank_ins_size(); o->flank_del[q] = tr->flank_del_size();
+    int io = o->indel_off[q];
+    for (size_t i = 0; i < tr->flank_indel_data().size(); i++, io++){
+      if (io >= o->cap_chars) return 3;
+      o->indel_pos[io] = tr->flank_indel_data()[i].first; o->indel_size[io] = tr->flank_indel_data()[i].second;
+    }
+    o->indel_off[q+1] = io;
+    int so = o->snp_off[q];
+    for (size_t i = 0; i < tr->flank_snp_data().size(); i++, so++){
+      if (so >= o->cap_chars) return 3;
+      o->snp_pos[so] = tr->flank_snp_data()[i].first; o->snp_base[so] = tr->flank_snp_data()[i].second;
+    }
+    o->snp_off[q+1] = so;
+    Alignment& ta = tr->traced_aln();
+    o->aln_start[q] = ta.get_start(); o->aln_stop[q] = ta.get_stop();
+    int co = o->cigar_off[q];
+    for (size_t i = 0; i < ta.get_cigar_list().size(); i++, co++){
+      if (co >= o->cap_chars) return 3;
+      o->cigar_op[co] = ta.get_cigar_list()[i].get_type(); o->cigar_len[co] = ta.get_cigar_list()[i].get_num();
+    }
+    o->cigar_off[q+1] = co;
+    if (!put_str(o->aln_str, o->aln_str_off, q, ta.get_alignment(), o->cap_chars)) return 3;
+    delete tr;
+  }
+  return 0;
+}
+
+/* Haplotype::get_aln_info() of every allele in visit order (NUL-separated), the input stitch_alignment_trace needs */
+extern "C" int ref_hap_aln_info(const hipstr_batch_t* b, char* out, int out_cap, int32_t* offs){
+  ensure_ready();
+  if (b->n_loci != 1) return 1;
+  int opt_cursor = 0;
+  RefLocus loc;
+  build_locus(b, 0, opt_cursor, loc);
+  int pos = 0, k = 0;
+  do {
+    const std::string& s = loc.hap->get_aln_info();
+    if (pos + (int)s.size() + 1 > out_cap) return 2;
+    offs[k++] = pos;
+    memcpy(out + pos, s.c_str(), s.size() + 1);
+    pos += s.size() + 1;
+  } while (loc.hap->next());
+  offs[k] = pos;
   return 0;
 }
