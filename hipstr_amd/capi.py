@@ -80,7 +80,11 @@ def run_trace(lib, prefix, bptr, req_read, req_allele, hap_to_ref=None, cap=1 <<
             h2r = (C.c_char_p * len(hap_to_ref))(*hap_to_ref)
         rc = fn(bptr, n, rr.ctypes.data_as(_i32p), aa.ctypes.data_as(_i32p), h2r, C.byref(o))
     if rc != 0:
-        raise RuntimeError("%strace failed rc=%d" % (prefix, rc))
+        why = ""
+        if prefix == "hipstr_hmm_":
+            lib.hipstr_last_error.restype = C.c_char_p
+            why = ": " + lib.hipstr_last_error().decode()
+        raise RuntimeError("%strace failed rc=%d%s" % (prefix, rc, why))
     def piece(pool, off, i):
         return keep[pool].raw[keep[off][i]:keep[off][i + 1]].decode()
     out = []

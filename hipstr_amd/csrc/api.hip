@@ -18,6 +18,7 @@
 #include "layout.h"
 #include "post_layout.h"
 #include "prep.h"
+#include "api_internal.h"
 
 extern "C" __global__ void hs_str_kernel(const hs_dev_t* dp, int active_begin);
 extern "C" __global__ void hs_combine_kernel(const hs_dev_t* dp, int active_begin);
@@ -63,6 +64,17 @@ int ensure_init(){
 }
 
 }  // namespace
+
+// what the other translation units of the library (trace.hip) need from this one: api_internal.h
+namespace hipstr {
+int api_fail(const std::string& m){ return fail(m); }
+int api_device_tables(ApiTables* t){
+  if (ensure_init()) return 1;
+  t->int_log = g_tab.int_log; t->qual_correct = g_tab.qc; t->qual_error = g_tab.qe; t->m2m = g_tab.m2m; t->m2i = g_tab.m2i;
+  t->stream = g_tab.stream;
+  return 0;
+}
+}  // namespace hipstr
 
 struct hipstr_dev_batch {
   hipstr::Prepared prep;

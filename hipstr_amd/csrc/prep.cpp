@@ -274,6 +274,16 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
 
 }  // namespace
 
+// ---- helpers shared with the traceback path (trace.hip)
+void fresh_flank_rows(const std::string side_seqs[3], std::vector<hs_row_t>& lead, std::vector<hs_row_t>& trail){
+  SideSeqs h;
+  for (int j = 0; j < 3; j++) h.s[j] = side_seqs[j];
+  h.index();
+  lead = flank_rows(h, 0, 0);
+  trail = flank_rows(h, 2, (int)h.s[0].size() + 1);
+}
+void append_stropt(const std::string& blk, int period, const double* stutter, Prepared& out){ emit_stropt(blk, period, stutter, out); }
+
 int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int64_t ws_budget){
   host_tables();
   if (b == NULL || b->n_loci < 0){ err = "null or negative-size batch"; return 1; }

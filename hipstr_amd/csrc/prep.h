@@ -70,6 +70,12 @@ int calc_seed_base(const hipstr_batch_t* b, int locus, int read);
 // Option index per block of allele k in Haplotype::next() order (Haplotype.cpp:123-196).
 void allele_options(const int32_t nopts[3], int k, int32_t opts[3]);
 
+// Rows of the leading and trailing flank of one allele in one orientation under the allele's OWN homopolymer context
+// (what a non-reusing alignment such as trace_optimal_aln computes); side_seqs = the three block sequences in side order.
+void fresh_flank_rows(const std::string side_seqs[3], std::vector<hs_row_t>& lead, std::vector<hs_row_t>& trail);
+// Appends one hs_stropt_t (+ visiting lists, f64 constants, block bytes) for a block sequence given in side orientation.
+void append_stropt(const std::string& blk, int period, const double* stutter, Prepared& out);
+
 // StutterModel::log_stutter_pmf (stutter_model.cpp:29-53) from the six constructor parameters.
 double log_stutter_pmf(const double* sp, int period, int sample_bps, int read_bps);
 

@@ -1,0 +1,877 @@
+// trace.hip — Viterbi traceback of one read against one fixed haplotype on gfx950.
+//
+// Replaces HapAligner::trace_optimal_aln (HapAligner.cpp:711-722): process_read(retrace_aln = true) on ONE haplotype
+// (HapAligner.cpp:573-709) = full M/I/D matrices of the left and the right problem, compute_aln_logprob with its
+// arg-max seed position (HapAligner.cpp:163-231), HapAligner::retrace (HapAligner.cpp:363-571) from that position, and
+// stitch_alignment_trace (AlignmentTraceback.cpp:55-144).
+//
+//   hs_trace_fill<C>   one wavefront per (request, side): the same systolic anti-diagonal flank sweep as the forward
+//                      path, but every cell of M/I/D goes to HBM (compact rows: the interior rows of the STR block,
+//                      which nothing ever reads, are not stored); the STR row is evaluated one read column per lane by
+//                      replaying the host-enumerated visiting lists, remembering the best artifact size and position
+//                      (HapAligner.cpp:81-97, StutterAlignerClass.cpp:92-95,138-141).
+//   hs_trace_walk      one wavefront per request: seed arg-max + log-sum-exp over the lanes, then lane 0 walks the
+//                      left matrices and lane 1 the right ones, emitting the operation strings.
+//
+// trace_optimal_aln positions the haplotype with go_to(), which clears last_changed_, so NOTHING is reused: rows are built
+// under the allele's own homopolymer context (prep.h fresh_flank_rows), unlike the forward pass.
+// The host then replays the operation strings into the flat hipstr_trace_out_t (the bookkeeping of retrace that touches
+// no matrix: flank sequences, SNPs, indels, STR sequence) and stitches them with the haplotype-to-reference strings.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/hipstr_hmm.h"
+#include "layout.h"
+#include "device_common.h"
+#include "prep.h"
+#include "api_internal.h"
+
+struct hs_tside_t {               // one side of one request
+  int32_t base_off, len, seed;    // the read in the base/quality pools
+  int32_t side;                   // 0 = left problem (forward haplotype), 1 = right problem (reversed read and haplotype)
+  int32_t n;                      // read columns on this side
+  int32_t lead_off, F0;           // rows of the leading flank in this orientation
+  int32_t trail_off, F2;
+  int32_t stropt;
+  int32_t art_off;                // ints: art_size[n] | art_pos[n]
+  int32_t ops_off, ops_cap;
+  int32_t pad_;
+  int64_t mat_off;                // doubles: M | I | D planes, each (F0 + 1 + F2) x n; row F0 is the STR block's last row
+};
+
+struct hs_tdev_t {
+  const hs_tside_t*  sides;       // [2*n_req]: left, right of each request
+  const int32_t*     items;       // side indices grouped by columns-per-lane class
+  const hs_row_t*    rows;
+  const hs_stropt_t* stropts;
+  const hs_visit_t*  visits;
+  const double*      f64pool;
+  const char*        chars;
+  const char*        bases;
+  const char*        quals;
+  const double *int_log, *qual_correct, *qual_error, *m2m, *m2i;
+  double             log_thresh;
+  double*            mats;
+  int32_t*           arts;
+  char*              ops;
+  double*            side_prob;   // [2*n_req]
+  double*            ll;          // [n_req]
+  int32_t*           max_index;   // [n_req]
+  int32_t*           n_ops;       // [2*n_req]
+  int32_t*           str_size;    // [2*n_req] artifact size taken in the STR block, or HIPSTR_NO_STR_DATA
+  int32_t*           str_pos;     // [2*n_req]
+};
+
+namespace {
+
+constexpr double TRACE_LL_TOL = 0.001;     // HapAligner.cpp:345
+
+struct TraceLds {
+  double blc[HS_MAX_SIDE_LEN], blw[HS_MAX_SIDE_LEN];
+  double prev[HS_MAX_SIDE_LEN];            // M of the row before the STR block
+  double mr[HS_MAX_SIDE_LEN];              // M of the STR block's last row
+  double Mt[HS_MAX_SIDE_LEN];              // StutterAlignerClass match table
+  double Dl[HS_MAX_SIDE_LEN*HS_MAXREP];
+  double In[HS_MAX_SIDE_LEN*HS_MAXREP];
+  double terms[HS_NART*64];
+  uint8_t rd[HS_MAX_SIDE_LEN];
+  uint8_t blk[1024];
+};
+
+__device__ __forceinline__ double emit_l(const TraceLds& L, int x, uint8_t c){ return L.rd[x] == c ? L.blc[x] : L.blw[x]; }
+
+// StutterAlignerClass::align_pcr_insertion_reverse (StutterAlignerClass.cpp:59-104) for one read column.
+__device__ double trace_ins(const hs_tdev_t& d, const TraceLds& L, const hs_stropt_t& so, const double* f64, int n, int len, int j, int D,
+                            bool left_align, int& best_pos){
+  const int B = so.B, p = so.period, off = n-1-j;
+  const double lp0 = f64[HS_NART] + L.In[HS_MAXREP*off + D/p - 1] + (len > D ? L.Mt[off+D] : 0.0);
+  const int lim = min(max(len-D, 0), B);
+  Lse lse;
+  double best = lp0; best_pos = 0;
+  for (int pass = 0; pass < 2; pass++){
+    double lp = lp0;
+    lse.start(pass, lp);
+    lse.push(pass, lp, d.log_thresh);
+    const hs_visit_t* e = d.visits + so.ins_off;
+    int ni;
+    for (;; e++){
+      const uint64_t meta = e->meta;
+      ni = (int)(meta & 0xffff);
+      if (ni >= lim) break;
+      const int U = (int)((meta >> 16) & 0xffff);
+      int pos = 1 + ni;
+      double v;
+      if ((meta >> 48) & 1) v = lp;
+      else if (U == 0){
+        const uint8_t ca = (uint8_t)(meta >> 32), cb = (uint8_t)(meta >> 40);
+        for (int idx = -ni-p; idx >= -ni-D; idx -= p){
+          lp -= emit_l(L, j+idx, ca);
+          lp += emit_l(L, j+idx, cb);
+        }
+        v = lp;
+      } else { v = e->logU + lp; pos = ni + U; }
+      lse.push(pass, v, d.log_thresh);
+      if (pass == 0 && (lp > best || (left_align && lp == best))){ best_pos = pos; best = lp; }
+    }
+    if (ni < B) lse.push(pass, d.int_log[B-ni] + lp, d.log_thresh);
+  }
+  return lse.finish();
+}
+
+// StutterAlignerClass::align_pcr_deletion_reverse (StutterAlignerClass.cpp:106-150) for one read column.
+__device__ double trace_del(const hs_tdev_t& d, const TraceLds& L, const hs_stropt_t& so, const double* f64, int n, int len, int j, int D,
+                            bool left_align, int& best_pos){
+  const int B = so.B, p = so.period, off = n-1-j, q = -D/p - 1;
+  double lp0 = f64[HS_NART+1+q];
+  if (off + D >= 0) lp0 += L.Mt[off+D] - L.Dl[(off+D)*HS_MAXREP + q];
+  else for (int k = 0; k > -len; k--) lp0 += emit_l(L, j+k, L.blk[B-1+k+D]);
+  Lse lse;
+  double best = lp0; best_pos = 0;
+  for (int pass = 0; pass < 2; pass++){
+    double lp = lp0;
+    lse.start(pass, lp);
+    lse.push(pass, lp, d.log_thresh);
+    const hs_visit_t* e = d.visits + so.del_off[q];
+    int ni;
+    for (;; e++){
+      const uint64_t meta = e->meta;
+      ni = (int)(meta & 0xffff);
+      if (ni >= len) break;
+      const int U = (int)((meta >> 16) & 0xffff);
+      int pos = 1 + ni;
+      double v;
+      if (U == 0){
+        const uint8_t ca = (uint8_t)(meta >> 32), cb = (uint8_t)(meta >> 40);
+        lp -= emit_l(L, j-ni, ca);
+        lp += emit_l(L, j-ni, cb);
+        v = lp;
+      } else { v = e->logU + lp; pos = ni + U; }
+      lse.push(pass, v, d.log_thresh);
+      if (pass == 0 && (lp > best || (left_align && lp == best))){ best_pos = pos; best = lp; }
+    }
+    if (ni < B+D) lse.push(pass, d.int_log[B+D-ni] + lp, d.log_thresh);
+  }
+  return lse.finish();
+}
+
+// ------------------------------------------------------------------ matrices of one (request, side)
+template <int C>
+__global__ void __launch_bounds__(64) hs_trace_fill(const hs_tdev_t* __restrict__ dp, int item_begin){
+  __shared__ TraceLds L;
+  const hs_tdev_t& d = *dp;
+  const int lane = threadIdx.x;
+  const int si = uni(d.items[item_begin + blockIdx.x]);
+  const hs_tside_t* S = d.sides + si;
+  const int n = uni(S->n), len = uni(S->len), base_off = uni(S->base_off), side = uni(S->side);
+  const int F0 = uni(S->F0), F2 = uni(S->F2);
+  const int64_t plane = (int64_t)(F0 + 1 + F2) * n;
+  double* M = d.mats + uni(S->mat_off);
+  double* I = M + plane;
+  double* Dm = I + plane;
+  const int nl = (n + C - 1) / C, lastlane = (n - 1) / C;
+
+  uint8_t rd[C]; double blc[C], blw[C];
+#pragma unroll
+  for (int k = 0; k < C; k++){
+    const int j = min(lane*C + k, n-1);
+    const int src = base_off + (side ? len - 1 - j : j);
+    const uint8_t q = (uint8_t)d.quals[src];
+    rd[k] = (uint8_t)d.bases[src];
+    blc[k] = d.qual_correct[q]; blw[k] = d.qual_error[q];
+    if (lane*C + k < n){ L.rd[j] = rd[k]; L.blc[j] = blc[k]; L.blw[j] = blw[k]; }
+  }
+  const double tab_m2m = d.m2m[lane & 15], tab_m2i = d.m2i[lane & 15];
+
+  double Mrow[C], Drow[C];
+  // rows 1.. of a flank block enter at lane 0, one per step; lane t works on row (step - t); every cell is stored
+  auto sweep = [&](const hs_row_t* nr, int nrows){
+    const int steps = nrows + nl - 1;
+    int chunk = 0;
+    uint32_t rowv = (lane < nrows) ? nr[lane] : 0u;
+    double oM = 0, oD = 0, oI = 0, om2m = 0, om2i = 0;
+    int oMeta = 0;
+    for (int st = 0; st < steps; st++){
+      int meta0 = 0; double f_m2m = 0, f_m2i = 0;
+      if (st < nrows){
+        if (st - chunk == 64){ chunk += 64; rowv = (chunk + lane < nrows) ? nr[chunk + lane] : 0u; }
+        meta0 = rdlane((int)rowv, st - chunk);
+        const int h = (meta0 >> 8) & 15;
+        f_m2m = rdlane(tab_m2m, h); f_m2i = rdlane(tab_m2i, h);
+      }
+      const int meta = shr1(meta0, oMeta);
+      const double m2m = shr1(f_m2m, om2m), m2i = shr1(f_m2i, om2i);
+      double mdiag = shr1(0.0, oM), ddiag = shr1(0.0, oD), ileft = shr1(0.0, oI);
+      if (meta < 0){
+        const uint8_t hc = (uint8_t)(meta & 0xff);
+        const int64_t ro = (int64_t)((meta >> 12) & 0xfff) * n;
+        oM = Mrow[C-1]; oD = Drow[C-1];
+#pragma unroll
+        for (int kk = 0; kk < C; kk++){
+          const double e = (rd[kk] == hc) ? blc[kk] : blw[kk];
+          const double c0v = ileft + m2i, c1v = mdiag + m2m, c2v = ddiag + m2i;
+          double nM = e + fmax(c0v, fmax(c1v, c2v));
+          double nI = blc[kk] + fmax(mdiag + T_I2M, ileft + T_I2I);
+          const double nD = fmax(Mrow[kk] + T_D2M, Drow[kk] + T_D2D);
+          if (kk == 0 && lane == 0){ nM = e; nI = blc[kk]; }     // HapAligner.cpp:123-126
+          mdiag = Mrow[kk]; ddiag = Drow[kk]; ileft = nI;
+          Mrow[kk] = nM; Drow[kk] = nD;
+          const int j = lane*C + kk;
+          if (j < n){ M[ro + j] = nM; I[ro + j] = nI; Dm[ro + j] = nD; }
+        }
+        oI = ileft;
+      }
+      oMeta = meta; om2m = m2m; om2i = m2i;
+    }
+  };
+
+  // ---- matrix row 0 (HapAligner.cpp:33-42) and the leading flank
+  const hs_row_t* lead = d.rows + uni(S->lead_off);
+  {
+    const uint8_t c0 = (uint8_t)(uni((int)lead[0]) & 0xff);
+    double pre[C];
+#pragma unroll
+    for (int kk = 0; kk < C; kk++) pre[kk] = 0.0;
+    double carry = 0.0;
+    for (int t = 0; t < nl; t++){
+      const double cin = shr1(0.0, carry);
+      if (lane == t){
+        double run = (t == 0) ? 0.0 : cin;
+#pragma unroll
+        for (int kk = 0; kk < C; kk++){ pre[kk] = run; if (lane*C + kk < n) run += blc[kk]; }
+        carry = run;
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < C; kk++){
+      Mrow[kk] = ((rd[kk] == c0) ? blc[kk] : blw[kk]) + pre[kk];
+      Drow[kk] = IMP;
+      const int j = lane*C + kk;
+      if (j < n){ M[j] = Mrow[kk]; I[j] = blc[kk] + pre[kk]; Dm[j] = IMP; }
+    }
+    if (lane == lastlane) d.side_prob[si] = carry;
+  }
+  if (F0 > 1) sweep(lead + 1, F0 - 1);
+#pragma unroll
+  for (int kk = 0; kk < C; kk++){ const int j = lane*C + kk; if (j < n) L.prev[j] = Mrow[kk]; }
+
+  // ---- STR block (HapAligner.cpp:62-109)
+  const hs_stropt_t so = d.stropts[uni(S->stropt)];
+  const int B = so.B, p = so.period, nd = so.nd;
+  const double* f64 = d.f64pool + so.f64_off;
+  for (int x = lane; x < B; x += 64) L.blk[x] = (uint8_t)d.chars[so.seq_off + x];
+  __syncthreads();
+  // StutterAlignerClass::load_read (StutterAlignerClass.cpp:12-53), one table position per lane
+  {
+    const int maxdel = nd*p, maxins = HS_MAXREP*p;
+    for (int i = lane; i < n; i += 64){
+      const int e = n-1-i;
+      double lp = 0.0;
+      int j;
+      const int lim = min(n-i, maxdel);
+      for (j = 0; j < lim; j++){
+        lp += emit_l(L, e-j, L.blk[B-1-j]);
+        if ((j+1) % p == 0) L.Dl[i*HS_MAXREP + (j+1)/p - 1] = lp;
+      }
+      const int lim2 = min(n-i, B);
+      for (j = maxdel; j < lim2; j++) lp += emit_l(L, e-j, L.blk[B-1-j]);
+      L.Mt[i] = lp;
+      double li = 0.0;
+      const int lim3 = min(maxins, n-i);
+      for (j = 0; j < lim3; j++){
+        if (j % p < B) li += emit_l(L, e-j, L.blk[B-1-(j%p)]);
+        else           li += L.blc[e-j];
+        if ((j+1) % p == 0) L.In[i*HS_MAXREP + (j+1)/p - 1] = li;
+      }
+      for (; j < maxins; j++) if ((j+1) % p == 0) L.In[i*HS_MAXREP + (j+1)/p - 1] = li;
+    }
+  }
+  __syncthreads();
+  {
+    const bool left_align = (side == 0);        // forward: left-align the artifact, reverse: right-align (HapAligner.cpp:69-71)
+    int32_t* art_size = d.arts + uni(S->art_off);
+    int32_t* art_pos = art_size + n;
+    const int64_t ro = (int64_t)F0 * n;
+    for (int j = lane; j < n; j += 64){
+      int bsize = -10000, bpos = -1;
+      double best_ll = IMP;
+      for (int t = 0; t < HS_NART; t++){
+        const int art = (t - HS_MAXREP)*p;
+        const int alen = min(B+art, j+1);
+        double term = IMP;
+        int apos = -1;
+        if (alen >= 0){
+          double pr;
+          if (art == 0) pr = L.Mt[n-1-j];
+          else if (art > 0) pr = trace_ins(d, L, so, f64, n, alen, j, art, left_align, apos);
+          else pr = trace_del(d, L, so, f64, n, alen, j, art, left_align, apos);
+          const double pre = (j-alen < 0) ? 0.0 : L.prev[j-alen];
+          term = f64[t] + pr + pre;
+        }
+        L.terms[t*64 + lane] = term;
+        if (term > best_ll){ bsize = art; bpos = apos; best_ll = term; }
+      }
+      Lse lse;
+      for (int pass = 0; pass < 2; pass++){
+        lse.start(pass, L.terms[lane]);
+        for (int t = 0; t < HS_NART; t++) lse.push(pass, L.terms[t*64 + lane], d.log_thresh);
+      }
+      const double v = lse.finish();
+      L.mr[j] = v;
+      M[ro + j] = v; I[ro + j] = IMP; Dm[ro + j] = IMP;
+      art_size[j] = bsize; art_pos[j] = bpos;
+    }
+  }
+  __syncthreads();
+
+  // ---- trailing flank: "stutter block must be followed by a match" (HapAligner.cpp:122-139), then the plain recurrence
+  const hs_row_t* trail = d.rows + uni(S->trail_off);
+  {
+    const uint8_t c0 = (uint8_t)(uni((int)trail[0]) & 0xff);
+    const int64_t ro = (int64_t)(F0 + 1) * n;
+#pragma unroll
+    for (int kk = 0; kk < C; kk++){
+      const int j = min(lane*C + kk, n-1);
+      const double e = (rd[kk] == c0) ? blc[kk] : blw[kk];
+      Mrow[kk] = (j == 0) ? e : e + L.mr[max(j - 1, 0)];
+      Drow[kk] = IMP;
+      if (lane*C + kk < n){ M[ro + j] = Mrow[kk]; I[ro + j] = IMP; Dm[ro + j] = IMP; }
+    }
+  }
+  if (F2 > 1) sweep(trail + 1, F2 - 1);
+}
+
+// ------------------------------------------------------------------ seed arg-max, total likelihood and the walk
+__device__ __forceinline__ int tri_idx(bool rev, double v1, double v2, double v3){       // HapAligner.cpp:346-358
+  if (!rev){ if (v1 > v2+TRACE_LL_TOL) return (v1 > v3+TRACE_LL_TOL ? 0 : 2); return (v2 > v3+TRACE_LL_TOL ? 1 : 2); }
+  if (v3 > v2+TRACE_LL_TOL) return (v3 > v1+TRACE_LL_TOL ? 2 : 0);
+  return (v2 > v1+TRACE_LL_TOL ? 1 : 0);
+}
+__device__ __forceinline__ int pair_idx(bool rev, double v1, double v2){                 // HapAligner.cpp:360-361
+  if (!rev) return (v1 > v2+TRACE_LL_TOL ? 0 : 1);
+  return (v2 > v1+TRACE_LL_TOL ? 1 : 0);
+}
+
+// HapAligner::retrace (HapAligner.cpp:363-571): only the decisions; the bookkeeping is replayed on the host from `ops`.
+__device__ void trace_walk(const hs_tdev_t& d, int si, int B, int max_index){
+  const hs_tside_t* S = d.sides + si;
+  const bool rev = S->side != 0;
+  const int n = S->n, F0 = S->F0, F2 = S->F2;
+  const int64_t plane = (int64_t)(F0 + 1 + F2) * n;
+  const double* M = d.mats + S->mat_off;
+  const double* I = M + plane;
+  const double* Dm = I + plane;
+  const int32_t* art_size = d.arts + S->art_off;
+  const int32_t* art_pos = art_size + n;
+  char* ops = d.ops + S->ops_off;
+  const int cap = S->ops_cap;
+  int k = 0;
+  auto push = [&](char c){ if (k < cap) ops[k] = c; k++; };
+  d.str_size[si] = HIPSTR_NO_STR_DATA; d.str_pos[si] = -1;
+  if (max_index == 0){            // HapAligner.cpp:646-648
+    for (int i = 0; i < n; i++) push('S');
+    d.n_ops[si] = k;
+    return;
+  }
+  const int blen[3] = { F0, B, F2 };
+  int sblock = 0, scoord = max_index;
+  for (int b = 0; b < 3; b++){ if (scoord < blen[b]){ sblock = b; break; } scoord -= blen[b]; }
+  int block, base;
+  if (scoord == 0){ block = sblock-1; base = blen[block]-1; } else { block = sblock; base = scoord-1; }
+  const int row = max_index - 1;
+  int u = row < F0 ? row : (row < F0+B ? F0 : row - B + 1);
+  int seq = n-1, c = n-1, type = 0;           // 0 match, 1 deletion, 2 insertion
+  while (block >= 0){
+    if (block == 1){
+      const int size = art_size[seq], apos = art_pos[seq];
+      d.str_size[si] = size; d.str_pos[si] = apos;
+      int i = 0;
+      for (; i < min(seq+1, apos); i++) push('M');
+      if (size < 0) for (int x = 0; x < -size; x++) push('D');
+      else for (; i < min(seq+1, apos+size); i++) push('I');
+      for (; i < min(B+size, seq+1); i++) push('M');
+      if (B + size >= seq+1) break;            // the read does not span the STR block
+      u = F0 - 1; c -= B + size; seq -= B + size; type = 0;
+    } else {
+      const hs_row_t* rows = d.rows + (block == 0 ? S->lead_off : S->trail_off);
+      bool done = false;
+      while (base >= 0 && seq >= 0){
+        const int h = (rows[base] >> 8) & 15;
+        push(type == 0 ? 'M' : (type == 1 ? 'D' : 'I'));
+        if (type == 0){ seq--; base--; } else if (type == 1) base--; else seq--;
+        if (seq == -1 || (base == -1 && block == 0)){
+          while (seq != -1){ push('S'); seq--; }
+          done = true;
+          break;
+        }
+        if (type == 0){
+          const int best = tri_idx(rev, I[(int64_t)u*n + c-1] + d.m2i[h], Dm[(int64_t)(u-1)*n + c-1] + d.m2i[h], M[(int64_t)(u-1)*n + c-1] + d.m2m[h]);
+          if (best == 0){ type = 2; c -= 1; }
+          else { type = (best == 1) ? 1 : 0; u--; c--; }
+        } else if (type == 1){
+          const int best = pair_idx(rev, Dm[(int64_t)(u-1)*n + c] + T_D2D, M[(int64_t)(u-1)*n + c] + T_D2M);
+          type = (best == 0) ? 1 : 0; u--;
+        } else {
+          const int best = pair_idx(rev, I[(int64_t)u*n + c-1] + T_I2I, M[(int64_t)(u-1)*n + c-1] + T_I2M);
+          if (best == 0) c--;
+          else { type = 0; u--; c--; }
+        }
+      }
+      if (done) break;
+    }
+    block--;
+    if (block >= 0) base = blen[block] - 1;
+  }
+  d.n_ops[si] = k;
+}
+
+__global__ void __launch_bounds__(64) hs_trace_walk(const hs_tdev_t* __restrict__ dp, int req_begin){
+  const hs_tdev_t& d = *dp;
+  const int lane = threadIdx.x;
+  const int q = req_begin + blockIdx.x;
+  const hs_tside_t* SL = d.sides + 2*q;
+  const hs_tside_t* SR = SL + 1;
+  const int nL = uni(SL->n), nR = uni(SR->n), F0 = uni(SL->F0), F2 = uni(SL->F2);
+  const int B = uni(d.stropts[uni(SL->stropt)].B);
+  const int H = F0 + B + F2;
+  const double* LM = d.mats + uni(SL->mat_off);
+  const double* RM = d.mats + uni(SR->mat_off);
+  const int sp = uni(SL->base_off) + uni(SL->seed);
+  const uint8_t sc = (uint8_t)d.bases[sp];
+  const uint8_t sq = (uint8_t)d.quals[sp];
+  const double lc = d.qual_correct[sq], lw = d.qual_error[sq];
+  const double prior = -d.int_log[F0 + F2];
+  const double spL = d.side_prob[2*q], spR = d.side_prob[2*q+1];
+  auto cL = [&](int r){ return r < F0 ? r : (r < F0+B ? F0 : r - B + 1); };
+  auto cR = [&](int r){ return r < F2 ? r : (r < F2+B ? F2 : r - B + 1); };
+  auto term = [&](int x){       // compute_aln_logprob (HapAligner.cpp:163-231), one seed position
+    const uint32_t rw = x < F0 ? d.rows[SL->lead_off + x] : d.rows[SL->trail_off + x - F0 - B];
+    const double pe = prior + (sc == (uint8_t)(rw & 0xff) ? lc : lw);
+    if (x == 0)   return (pe + spL) + RM[(int64_t)cR(H-2)*nR + nR-1];
+    if (x == H-1) return (pe + spR) + LM[(int64_t)cL(H-2)*nL + nL-1];
+    return (pe + LM[(int64_t)cL(x-1)*nL + nL-1]) + RM[(int64_t)cR(H-2-x)*nR + nR-1];
+  };
+  // the reference pushes x = 0, x = H-1, then the interior positions in order, keeping the FIRST maximum (HapAligner.cpp:184-222)
+  double bv = -__builtin_huge_val(); int brank = 0x7fffffff;
+  for (int kk = lane; kk < F0 + F2; kk += 64){
+    const int x = kk < F0 ? kk : kk + B;
+    const double v = term(x);
+    const int rank = x == 0 ? 0 : (x == H-1 ? 1 : x + 1);
+    if (v > bv || (v == bv && rank < brank)){ bv = v; brank = rank; }
+  }
+  const double mx = wave_max_d(bv);
+  const int rank = (int)-wave_max_d(-(double)(bv == mx ? brank : 0x7fffffff));
+  const int max_index = rank == 0 ? 0 : (rank == 1 ? H-1 : rank - 1);
+  double tot = 0.0;
+  for (int kk = lane; kk < F0 + F2; kk += 64){
+    const int x = kk < F0 ? kk : kk + B;
+    const double df = term(x) - mx;
+    if (df > d.log_thresh) tot += (double)f_fasterexp((float)df);
+  }
+  tot = wave_sum_d(tot);
+  if (lane == 0){ d.ll[q] = mx + (double)f_fasterlog((float)tot); d.max_index[q] = max_index; }
+  if (lane == 0) trace_walk(d, 2*q, B, max_index);
+  else if (lane == 1) trace_walk(d, 2*q+1, B, H-1-max_index);
+}
+
+// ------------------------------------------------------------------ host side
+#define TR_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess){ \
+  hipstr::api_fail(std::string(#call) + ": " + hipGetErrorString(e_)); return 1; } } while (0)
+
+struct DevBufs {
+  std::vector<void*> p;
+  ~DevBufs(){ for (void* x : p) hipFree(x); }
+  template <typename T> int alloc(T** out, size_t count){
+    *out = NULL;
+    TR_HIP(hipMalloc((void**)out, (count ? count : 1)*sizeof(T)));
+    p.push_back(*out);
+    return 0;
+  }
+  template <typename T> int put(T** out, const T* src, size_t count){
+    if (alloc(out, count)) return 1;
+    if (count) TR_HIP(hipMemcpy(*out, src, count*sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+  }
+};
+
+struct AllelePrep {
+  std::string seq[2][3];          // block sequences per orientation, in side order
+  int lead_off[2], trail_off[2], stropt[2];
+};
+
+struct TraceAcc {                 // what AlignmentTrace accumulates (AlignmentTraceback.h:27-34)
+  bool str_set = false; int stutter_size = 0; std::string str_seq;
+  std::string flank[3];
+  int flank_ins = 0, flank_del = 0;
+  std::vector<std::pair<int32_t,int32_t>> indels;
+  std::vector<std::pair<int32_t,char>> snps;
+};
+
+// start coordinate a (possibly reversed) haplotype block reports: HapBlock::reverse() builds HapBlock(end_-1, start_-1, ..),
+// RepeatBlock::reverse() keeps (start_, end_) (HapBlock.h:123-133, RepeatBlock.h:48-58)
+int32_t side_block_start(const hipstr_batch_t* b, bool rev, int bi){
+  const int fb = rev ? 2-bi : bi;
+  if (!rev || fb == 1) return b->blk_start[fb];
+  return b->blk_end[fb]-1;
+}
+
+const double MIN_SNP_LOG_PROB_CORRECT = -0.0043648054;     // HapAligner.cpp:24
+
+// The matrix-free half of HapAligner::retrace (HapAligner.cpp:363-571): the device decided the move at every step
+// (`ops`); this replays them to collect flank sequences, SNPs, indels and the STR sequence.  rd/lc: the side's read
+// (reversed for the right problem).  Returns false if the operation string is inconsistent.
+bool replay_side(const hipstr_batch_t* b, const std::string sseq[3], bool rev, const std::string& rd, const std::vector<double>& lc,
+                 const std::string& ops, int size, int apos, int block, int base, TraceAcc& tr){
+  const int MATCH = 0, DEL = 1, INS = 2, NONE = -1;
+  const int n = rd.size();
+  int seq = n-1;
+  size_t k = 0;
+  while (block >= 0){
+    const std::string& bs = sseq[block];
+    const int blen = bs.size();
+    if (block == 1){
+      std::string ss;
+      int i = 0;
+      for (; i < std::min(seq+1, apos); i++){ ss.push_back(rd[seq-i]); k++; }
+      if (size < 0) k += -size;
+      else for (; i < std::min(seq+1, apos+size); i++){ ss.push_back(rd[seq-i]); k++; }
+      for (; i < std::min(blen+size, seq+1); i++){ ss.push_back(rd[seq-i]); k++; }
+      if (!rev) std::reverse(ss.begin(), ss.end());
+      tr.str_set = true; tr.stutter_size = size; tr.str_seq = ss;
+      if (blen + size >= seq+1) return k == ops.size();
+      seq -= blen + size;
+    } else {
+      int prev = NONE;
+      int32_t pos = side_block_start(b, rev, block) + (rev ? -base : base);
+      const int32_t inc = rev ? 1 : -1;
+      int indel_seq = -1; int32_t indel_position = -1;
+      std::string fs;
+      const int out_block = rev ? 2-block : block;
+      auto flush = [&](){ if (!rev) std::reverse(fs.begin(), fs.end()); tr.flank[out_block] += fs; };
+      while (base >= 0 && seq >= 0){
+        if (k >= ops.size()) return false;
+        const char oc = ops[k++];
+        const int type = oc == 'M' ? MATCH : (oc == 'D' ? DEL : (oc == 'I' ? INS : NONE));
+        if (type == NONE) return false;
+        if (type != prev){
+          if (prev == DEL){
+            if (rev) tr.indels.push_back(std::make_pair(indel_position, indel_position - pos));
+            else     tr.indels.push_back(std::make_pair(pos+1, pos - indel_position));
+          } else if (prev == INS)
+            tr.indels.push_back(std::make_pair(indel_position + (rev ? 0 : 1), (int32_t)(indel_seq - seq)));
+          if (type == DEL || type == INS){ indel_seq = seq; indel_position = pos; }
+          prev = type;
+        }
+        if (type == MATCH){
+          if (bs[base] != rd[seq] && lc[seq] > MIN_SNP_LOG_PROB_CORRECT) tr.snps.push_back(std::make_pair(pos, rd[seq]));
+          fs.push_back(rd[seq]); seq--; base--; pos += inc;
+        } else if (type == DEL){ tr.flank_del++; base--; pos += inc; }
+        else { tr.flank_ins++; fs.push_back(rd[seq]); seq--; }
+        if (seq == -1 || (base == -1 && block == 0)){
+          k += seq + 1;                        // soft clips
+          flush();
+          return k == ops.size();
+        }
+      }
+      flush();
+    }
+    block--;
+    if (block >= 0) base = (int)sseq[block].size() - 1;
+  }
+  return k == ops.size();
+}
+
+// AlignmentTraceback.cpp:7-52
+void stitch_dir(const char* hap_aln, int hlen, const std::string& read_aln, int h_index, int r_index, int inc, std::string& out){
+  const int rlen = read_aln.size();
+  while (r_index >= 0 && r_index < rlen){
+    if (read_aln[r_index] == 'S'){ out.push_back('S'); r_index += inc; continue; }
+    if (h_index < 0 || h_index >= hlen) return;
+    if (hap_aln[h_index] == 'D'){
+      if (read_aln[r_index] == 'I'){ out.push_back('M'); r_index += inc; h_index += inc; }
+      else { out.push_back('D'); h_index += inc; }
+    }
+    else if (read_aln[r_index] == 'I'){ out.push_back('I'); r_index += inc; }
+    else if (read_aln[r_index] == 'D'){
+      if (hap_aln[h_index] == 'M') out.push_back('D');
+      r_index += inc; h_index += inc;
+    }
+    else { out.push_back(hap_aln[h_index]); r_index += inc; h_index += inc; }
+  }
+}
+
+bool put_pool(char* pool, int32_t* off, int idx, const std::string& s, int cap){
+  if ((int64_t)off[idx] + (int64_t)s.size() > cap) return false;
+  memcpy(pool + off[idx], s.data(), s.size());
+  off[idx+1] = off[idx] + (int32_t)s.size();
+  return true;
+}
+
+}  // namespace
+
+extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const int32_t* req_read, const int32_t* req_allele,
+                                const char* const* hap_to_ref, hipstr_trace_out_t* o){
+  using hipstr::api_fail;
+  if (!b || !o || n_req < 0 || (n_req > 0 && (!req_read || !req_allele))) return api_fail("null argument");
+  if (b->n_loci != 1) return api_fail("hipstr_hmm_trace takes a one-locus batch");
+  hipstr::ApiTables T;
+  if (hipstr::api_device_tables(&T)) return 1;
+  const hipstr::HostTables& HT = hipstr::host_tables();
+  const int period = b->period[0];
+  if (period < 1 || period > 9) return api_fail("STR period must be in [1,9] (stutter_model.h:38)");
+  std::vector<std::string> opt[3];
+  int32_t nopts[3];
+  int A = 1;
+  for (int k = 0, cur = 0; k < 3; k++){
+    nopts[k] = b->blk_nopts[k];
+    if (nopts[k] < 1) return api_fail("haplotype block without options");
+    for (int x = 0; x < nopts[k]; x++, cur++){
+      opt[k].push_back(std::string(b->seq + b->opt_off[cur], b->opt_off[cur+1]-b->opt_off[cur]));
+      if (opt[k].back().empty()) return api_fail(k == 1 ? "empty STR allele is not supported" : "empty flank sequence");
+      if (k == 1 && opt[k].back().size() > 1024) return api_fail("STR allele longer than 1024 bp is not supported");
+    }
+    A *= nopts[k];
+  }
+  const int n_reads = b->read_off[1] - b->read_off[0];
+  o->hap_aln_off[0] = o->str_seq_off[0] = o->flank_seq_off[0] = o->indel_off[0] = o->snp_off[0] = 0;
+  o->cigar_off[0] = o->aln_str_off[0] = 0;
+  if (n_req == 0) return 0;
+
+  // ---- per request: seed, allele rows (own homopolymer context), sizes
+  hipstr::Prepared P;              // only its row / STR-option pools are used
+  std::vector<hs_row_t> rows;
+  std::map<int, AllelePrep> alleles;
+  std::vector<int32_t> seeds(n_req);
+  for (int q = 0; q < n_req; q++){
+    const int r = req_read[q], k = req_allele[q];
+    if (r < 0 || r >= n_reads) return api_fail("request names a read outside the locus");
+    if (k < 0 || k >= A) return api_fail("request names an allele outside the locus");
+    const int s = hipstr::calc_seed_base(b, 0, r);
+    if (s == -2) return api_fail("Invalid alignment seed or unrecognized CIGAR char (HapAligner.cpp:309,316)");
+    if (s < 0) return api_fail("read without a seed base cannot be traced (HapAligner.cpp:586-594)");
+    const int len = b->base_off[r+1] - b->base_off[r];
+    if (s > HS_MAX_SIDE_LEN || len-s-1 > HS_MAX_SIDE_LEN) return api_fail("read side longer than 256 bases is not supported");
+    seeds[q] = s;
+    if (alleles.count(k)) continue;
+    AllelePrep ap;
+    int32_t oi[3];
+    hipstr::allele_options(nopts, k, oi);
+    for (int x = 0; x < 3; x++){
+      ap.seq[0][x] = opt[x][oi[x]];
+      ap.seq[1][2-x] = std::string(opt[x][oi[x]].rbegin(), opt[x][oi[x]].rend());
+    }
+    if (ap.seq[0][0].size() + 1 + ap.seq[0][2].size() > 4095) return api_fail("flanks longer than 4094 bases in total are not supported");
+    for (int sd = 0; sd < 2; sd++){
+      std::vector<hs_row_t> lead, trail;
+      hipstr::fresh_flank_rows(ap.seq[sd], lead, trail);
+      ap.lead_off[sd] = rows.size();  rows.insert(rows.end(), lead.begin(), lead.end());
+      ap.trail_off[sd] = rows.size(); rows.insert(rows.end(), trail.begin(), trail.end());
+      ap.stropt[sd] = P.stropts.size();
+      hipstr::append_stropt(ap.seq[sd][1], period, b->stutter, P);
+    }
+    alleles[k] = ap;
+  }
+
+  // ---- static device data
+  DevBufs dev;
+  hs_tdev_t h; memset(&h, 0, sizeof h);
+  const int total_bases = b->base_off[n_reads];
+  {
+    hs_row_t* d_rows; hs_stropt_t* d_so; hs_visit_t* d_vis; double* d_f64; char *d_chars, *d_bases, *d_quals;
+    if (dev.put(&d_rows, rows.data(), rows.size()) || dev.put(&d_so, P.stropts.data(), P.stropts.size()) ||
+        dev.put(&d_vis, P.visits.data(), P.visits.size()) || dev.put(&d_f64, P.f64pool.data(), P.f64pool.size()) ||
+        dev.put(&d_chars, P.chars.data(), P.chars.size()) || dev.put(&d_bases, b->bases, total_bases) ||
+        dev.put(&d_quals, b->quals, total_bases)) return 1;
+    h.rows = d_rows; h.stropts = d_so; h.visits = d_vis; h.f64pool = d_f64; h.chars = d_chars; h.bases = d_bases; h.quals = d_quals;
+  }
+  h.int_log = T.int_log; h.qual_correct = T.qual_correct; h.qual_error = T.qual_error; h.m2m = T.m2m; h.m2i = T.m2i;
+  h.log_thresh = HT.log_thresh;
+
+  // ---- chunks of requests whose matrices fit the workspace budget
+  size_t free_b = 0, total_b = 0;
+  TR_HIP(hipMemGetInfo(&free_b, &total_b));
+  int64_t budget = std::min<int64_t>((int64_t)8 << 30, (int64_t)(free_b / 4)) / 8;      // doubles
+  if (const char* e = getenv("HIPSTR_TRACE_WS_MIB")) budget = std::max<int64_t>(1, atoll(e)) * ((1 << 20) / 8);
+  std::vector<hs_tside_t> sides(2*(size_t)n_req);
+  std::vector<int64_t> need(n_req);
+  for (int q = 0; q < n_req; q++){
+    const int r = req_read[q];
+    const AllelePrep& ap = alleles[req_allele[q]];
+    const int len = b->base_off[r+1] - b->base_off[r];
+    need[q] = 0;
+    for (int sd = 0; sd < 2; sd++){
+      hs_tside_t& S = sides[2*q+sd];
+      memset(&S, 0, sizeof S);
+      S.base_off = b->base_off[r]; S.len = len; S.seed = seeds[q]; S.side = sd;
+      S.n = sd ? len - seeds[q] - 1 : seeds[q];
+      S.lead_off = ap.lead_off[sd]; S.F0 = ap.seq[sd][0].size();
+      S.trail_off = ap.trail_off[sd]; S.F2 = ap.seq[sd][2].size();
+      S.stropt = ap.stropt[sd];
+      S.ops_cap = S.n + S.F0 + S.F2 + (int)ap.seq[sd][1].size() + 2*HS_MAXREP*period + 16;
+      need[q] += 3*(int64_t)(S.F0 + 1 + S.F2)*S.n;
+    }
+    if (need[q] > budget) return api_fail("one traceback needs more workspace than the device offers");
+  }
+
+  int rc = 0;
+  for (int q0 = 0; q0 < n_req && rc == 0; ){
+    int q1 = q0; int64_t mat = 0; int64_t n_art = 0, n_ops = 0;
+    while (q1 < n_req && mat + need[q1] <= budget){
+      for (int sd = 0; sd < 2; sd++){
+        hs_tside_t& S = sides[2*q1+sd];
+        S.mat_off = mat; mat += 3*(int64_t)(S.F0 + 1 + S.F2)*S.n;
+        S.art_off = n_art; n_art += 2*S.n;
+        S.ops_off = n_ops; n_ops += S.ops_cap;
+      }
+      q1++;
+    }
+    const int nq = q1 - q0;
+    // launch order: sides grouped by columns-per-lane class
+    std::vector<int32_t> items; int cls_begin[HS_MAX_COLS+1];
+    for (int cl = 1; cl <= HS_MAX_COLS; cl++){
+      cls_begin[cl-1] = items.size();
+      for (int si = 2*q0; si < 2*q1; si++) if ((sides[si].n + 63)/64 == cl) items.push_back(si - 2*q0);
+    }
+    cls_begin[HS_MAX_COLS] = items.size();
+
+    DevBufs ws;
+    hs_tdev_t hc = h;
+    hs_tside_t* d_sides; int32_t* d_items; hs_tdev_t* d_args;
+    if (ws.put(&d_sides, sides.data() + 2*q0, 2*(size_t)nq) || ws.put(&d_items, items.data(), items.size())) return 1;
+    hc.sides = d_sides; hc.items = d_items;
+    if (ws.alloc(&hc.mats, mat) || ws.alloc(&hc.arts, n_art) || ws.alloc(&hc.ops, n_ops) || ws.alloc(&hc.side_prob, 2*(size_t)nq) ||
+        ws.alloc(&hc.ll, nq) || ws.alloc(&hc.max_index, nq) || ws.alloc(&hc.n_ops, 2*(size_t)nq) ||
+        ws.alloc(&hc.str_size, 2*(size_t)nq) || ws.alloc(&hc.str_pos, 2*(size_t)nq)) return 1;
+    if (ws.put(&d_args, &hc, 1)) return 1;
+    for (int cl = 1; cl <= HS_MAX_COLS; cl++){
+      const int cnt = cls_begin[cl] - cls_begin[cl-1];
+      if (cnt == 0) continue;
+      switch (cl){
+        case 1: hipLaunchKernelGGL(hs_trace_fill<1>, dim3(cnt), dim3(64), 0, T.stream, d_args, cls_begin[cl-1]); break;
+        case 2: hipLaunchKernelGGL(hs_trace_fill<2>, dim3(cnt), dim3(64), 0, T.stream, d_args, cls_begin[cl-1]); break;
+        case 3: hipLaunchKernelGGL(hs_trace_fill<3>, dim3(cnt), dim3(64), 0, T.stream, d_args, cls_begin[cl-1]); break;
+        default: hipLaunchKernelGGL(hs_trace_fill<4>, dim3(cnt), dim3(64), 0, T.stream, d_args, cls_begin[cl-1]); break;
+      }
+    }
+    hipLaunchKernelGGL(hs_trace_walk, dim3(nq), dim3(64), 0, T.stream, d_args, 0);
+    TR_HIP(hipGetLastError());
+    TR_HIP(hipStreamSynchronize(T.stream));
+    std::vector<double> ll(nq); std::vector<int32_t> mxi(nq), nops(2*(size_t)nq), ssz(2*(size_t)nq), spos(2*(size_t)nq);
+    std::vector<char> opsbuf(n_ops ? n_ops : 1);
+    TR_HIP(hipMemcpy(ll.data(), hc.ll, nq*sizeof(double), hipMemcpyDeviceToHost));
+    TR_HIP(hipMemcpy(mxi.data(), hc.max_index, nq*sizeof(int32_t), hipMemcpyDeviceToHost));
+    TR_HIP(hipMemcpy(nops.data(), hc.n_ops, 2*(size_t)nq*sizeof(int32_t), hipMemcpyDeviceToHost));
+    TR_HIP(hipMemcpy(ssz.data(), hc.str_size, 2*(size_t)nq*sizeof(int32_t), hipMemcpyDeviceToHost));
+    TR_HIP(hipMemcpy(spos.data(), hc.str_pos, 2*(size_t)nq*sizeof(int32_t), hipMemcpyDeviceToHost));
+    TR_HIP(hipMemcpy(opsbuf.data(), hc.ops, n_ops, hipMemcpyDeviceToHost));
+
+    // ---- replay + outputs (HapAligner.cpp:642-707)
+    for (int q = q0; q < q1; q++){
+      const int r = req_read[q], sb = seeds[q];
+      const AllelePrep& ap = alleles[req_allele[q]];
+      const int len = b->base_off[r+1] - b->base_off[r];
+      const char* bases = b->bases + b->base_off[r];
+      const char* quals = b->quals + b->base_off[r];
+      const int max_index = mxi[q-q0];
+      const int blen3[3] = { (int)ap.seq[0][0].size(), (int)ap.seq[0][1].size(), (int)ap.seq[0][2].size() };
+      const int H = blen3[0] + blen3[1] + blen3[2];
+      // left retrace, then the seed base joins the flank it sits in, then the right retrace (HapAligner.cpp:642-684)
+      TraceAcc acc;
+      std::string side_ops[2];
+      int seed_block = 0;
+      for (int x = 0, crd = max_index; x < 3; x++){ if (crd < blen3[x]){ seed_block = x; break; } crd -= blen3[x]; }
+      for (int sd = 0; sd < 2; sd++){
+        const hs_tside_t& S = sides[2*q+sd];
+        const int cnt = nops[2*(q-q0)+sd];
+        if (cnt > S.ops_cap) return api_fail("internal error: traceback operation buffer overflow");
+        side_ops[sd].assign(opsbuf.data() + S.ops_off, cnt);
+        if (sd == 1 && seed_block != 1) acc.flank[seed_block].push_back(bases[sb]);
+        const int mx = sd ? H-1-max_index : max_index;
+        if (mx == 0) continue;                         // this side is all soft clips
+        std::string rd(S.n, ' '); std::vector<double> lc(S.n);
+        for (int j = 0; j < S.n; j++){
+          const int src = sd ? len-1-j : j;
+          rd[j] = bases[src]; lc[j] = HT.qual_correct[(uint8_t)quals[src]];
+        }
+        int blk = 0, crd = mx;
+        for (int x = 0; x < 3; x++){ const int bl = ap.seq[sd][x].size(); if (crd < bl){ blk = x; break; } crd -= bl; }
+        int block, base;
+        if (crd == 0){ block = blk-1; base = (int)ap.seq[sd][block].size()-1; } else { block = blk; base = crd-1; }
+        if (!replay_side(b, ap.seq[sd], sd != 0, rd, lc, side_ops[sd], ssz[2*(q-q0)+sd], spos[2*(q-q0)+sd], block, base, acc))
+          return api_fail("internal error: inconsistent traceback operation string");
+      }
+      o->ll[q] = ll[q-q0]; o->max_index[q] = max_index;
+      std::string full(side_ops[0].rbegin(), side_ops[0].rend());
+      full.push_back('M');
+      full += side_ops[1];
+      bool ok = put_pool(o->hap_aln, o->hap_aln_off, q, full, o->cap_chars);
+      o->stutter_size[q] = acc.str_set ? acc.stutter_size : HIPSTR_NO_STR_DATA;
+      ok = put_pool(o->str_seq, o->str_seq_off, q, acc.str_set ? acc.str_seq : std::string(), o->cap_chars) && ok;
+      ok = put_pool(o->flank_seq, o->flank_seq_off, 2*q, acc.flank[0], o->cap_chars) && ok;
+      ok = put_pool(o->flank_seq, o->flank_seq_off, 2*q+1, acc.flank[2], o->cap_chars) && ok;
+      o->flank_ins[q] = acc.flank_ins; o->flank_del[q] = acc.flank_del;
+      int io = o->indel_off[q];
+      if ((int64_t)io + (int64_t)acc.indels.size() > o->cap_chars) ok = false;
+      else for (size_t i = 0; i < acc.indels.size(); i++, io++){ o->indel_pos[io] = acc.indels[i].first; o->indel_size[io] = acc.indels[i].second; }
+      o->indel_off[q+1] = io;
+      int so = o->snp_off[q];
+      if ((int64_t)so + (int64_t)acc.snps.size() > o->cap_chars) ok = false;
+      else for (size_t i = 0; i < acc.snps.size(); i++, so++){ o->snp_pos[so] = acc.snps[i].first; o->snp_base[so] = acc.snps[i].second; }
+      o->snp_off[q+1] = so;
+
+      // ---- stitch_alignment_trace (AlignmentTraceback.cpp:55-144)
+      o->cigar_off[q+1] = o->cigar_off[q]; o->aln_str_off[q+1] = o->aln_str_off[q]; o->aln_start[q] = o->aln_stop[q] = 0;
+      if (hap_to_ref != NULL && ok){
+        const char* h2r = hap_to_ref[req_allele[q]];
+        const int hlen = (int)strlen(h2r);
+        int hap_index = max_index, hai = 0; int32_t seed_pos = b->blk_start[0];
+        while (hap_index > 0 && hai < hlen){
+          if (h2r[hai] == 'M' || h2r[hai] == 'I') hap_index--;
+          if (h2r[hai] == 'M' || h2r[hai] == 'D') seed_pos++;
+          hai++;
+        }
+        while (hai < hlen && h2r[hai] == 'D') hai++;
+        int sbase = sb, rai = 0;
+        while (sbase > 0 && rai < (int)full.size()){
+          if (full[rai] == 'M' || full[rai] == 'I' || full[rai] == 'S') sbase--;
+          rai++;
+        }
+        while (rai < (int)full.size() && full[rai] == 'D') rai++;
+        std::string la, ra;
+        stitch_dir(h2r, hlen, full, hai-1, rai-1, -1, la);
+        std::reverse(la.begin(), la.end());
+        stitch_dir(h2r, hlen, full, hai+1, rai+1, 1, ra);
+        std::string fa = la + "M" + ra;
+        for (size_t i = 0; i < fa.size(); i++){ if (fa[i] == 'I') fa[i] = 'S'; else break; }
+        int32_t start = seed_pos, stop = seed_pos;
+        for (char ch : la) if (ch == 'D' || ch == 'M') start--;
+        for (char ch : ra) if (ch == 'D' || ch == 'M') stop++;
+        o->aln_start[q] = start; o->aln_stop[q] = stop;
+        int co = o->cigar_off[q]; char cc = fa[0]; int num = 1;
+        for (size_t i = 1; i <= fa.size(); i++){
+          if (i == fa.size() || fa[i] != cc){
+            if (co < o->cap_chars){ o->cigar_op[co] = cc; o->cigar_len[co] = num; co++; } else ok = false;
+            if (i < fa.size()){ cc = fa[i]; num = 1; }
+          } else num++;
+        }
+        o->cigar_off[q+1] = co;
+        std::string as;
+        int ri = 0;
+        for (char ch : fa){
+          if (ch == 'S') ri++;
+          else if (ch == 'M' || ch == 'I') as.push_back(bases[ri++]);
+          else as.push_back('-');
+        }
+        ok = put_pool(o->aln_str, o->aln_str_off, q, as, o->cap_chars) && ok;
+      }
+      if (!ok) return api_fail("hipstr_trace_out_t pools are too small (cap_chars)");
+    }
+    q0 = q1;
+  }
+  return rc;
+}

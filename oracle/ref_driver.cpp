@@ -23,10 +23,12 @@
 #include "SeqAlignment/AlignmentModel.h"
 // AlignmentTrace offers no "is the STR block set?" accessor (stutter_size()/str_seq() assert instead), so the test driver
 // reads str_data_ directly.  Access specifiers do not change the class layout, and only this TU is compiled this way.
+// HapAligner::trace_optimal_aln drops the likelihood process_read hands it; to pin the traced alignment's score the driver
+// positions the aligner's two haplotypes the same way and calls the (public) process_read itself.
 #define private public
 #include "SeqAlignment/AlignmentTraceback.h"
-#undef private
 #include "SeqAlignment/HapAligner.h"
+#undef private
 #include "SeqAlignment/HapBlock.h"
 #include "SeqAlignment/Haplotype.h"
 #include "SeqAlignment/RepeatBlock.h"
@@ -267,7 +269,16 @@ extern "C" int ref_trace(const hipstr_batch_t* b, int32_t n_req, const int32_t* 
     int seed = aligner.calc_seed_base(aln);
     if (seed < 0) return 2;
     AlignmentTrace* tr = aligner.trace_optimal_aln(aln, seed, req_allele[q], &bq);
-    o->ll[q] = 0; o->max_index[q] = -1;      /* not exposed by the reference's API; checked through hap_aln instead */
+    {   /* the score of the same alignment: haplotypes positioned as trace_optimal_aln does (HapAligner.cpp:711-722) */
+      double prob = 0;
+      AlignmentTrace scratch(loc.hap->num_blocks());
+      aligner.fw_haplotype_->go_to(req_allele[q]);  aligner.fw_haplotype_->fix();
+      aligner.rev_haplotype_->go_to(req_allele[q]); aligner.rev_haplotype_->fix();
+      aligner.process_read(aln, seed, &bq, false, &prob, scratch);
+      aligner.fw_haplotype_->unfix(); aligner.rev_haplotype_->unfix();
+      o->ll[q] = prob;
+    }
+    o->max_index[q] = -1;      /* a local of process_read; checked through hap_aln (the seed's 'M' splits the two sides) */
     if (!put_str(o->hap_aln, o->hap_aln_off, q, tr->hap_aln(), o->cap_chars)) return 3;
     if (tr->str_data_[1] != NULL){
       o->stutter_size[q] = tr->stutter_size(1);

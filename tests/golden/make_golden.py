@@ -27,6 +27,39 @@ def main():
         np.savez_compressed(os.path.join(HERE, "align_%s.npz" % name), **d)
         print(name, "alignments", probs.size, "seed -1:", int((seeds == -1).sum()), "untouched:", int((probs == SENTINEL).sum()))
 
+    # Viterbi traceback (HapAligner::trace_optimal_aln + stitch_alignment_trace) on one-locus cuts of the same cases
+    import json
+    from hipstr_amd import shard
+    rng_t = np.random.default_rng(20260929)
+    for name, make in CASES.items():
+        b = make()
+        _, seeds = capi.run_align(ref, "ref_", b.ptr, fill=SENTINEL)
+        a = b.arrays
+        out = {}; traced = 0; n_req = 0
+        for l in range(len(a["period"])):
+            r0, r1 = int(a["read_off"][l]), int(a["read_off"][l + 1])
+            A = int(a["hap_off"][l + 1] - a["hap_off"][l])
+            ok = [r - r0 for r in range(r0, r1) if seeds[r] >= 0]
+            if not ok or traced >= 6:
+                continue
+            one = shard.batch_from_arrays(shard.subset_arrays(a, l, l + 1))
+            rr, aa = [], []
+            for r in ok[:12]:
+                for k in rng_t.choice(A, size=min(A, 3), replace=False):
+                    rr.append(r); aa.append(int(k))
+            exp = capi.run_trace(ref, "ref_", one.ptr, rr, aa, cap=1 << 20)
+            h2r = capi.ref_hap_aln_info(ref, one.ptr, A)
+            pre = "L%d_" % traced
+            out.update(batch_to_dict(one, pre))
+            out[pre + "req_read"] = np.array(rr, np.int32); out[pre + "req_allele"] = np.array(aa, np.int32)
+            out[pre + "h2r"] = np.frombuffer(b"\n".join(h2r), dtype=np.uint8).copy()
+            out[pre + "expect"] = np.frombuffer(json.dumps(exp).encode(), dtype=np.uint8).copy()
+            traced += 1; n_req += len(rr)
+        if traced:
+            out["n_traced"] = np.array([traced])
+            np.savez_compressed(os.path.join(HERE, "trace_%s.npz" % name), **out)
+        print("trace", name, "loci", traced, "requests", n_req)
+
     # posteriors: SURVEY §8(c) second KAT + seeded random cases
     rng = np.random.default_rng(20260928)
     posts = {}

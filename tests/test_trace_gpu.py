@@ -1,0 +1,105 @@
+"""GPU: hipstr_hmm_trace (Viterbi traceback of one read against one fixed haplotype, HapAligner.cpp:711-722) through the
+C-ABI, against the golden vectors of the compiled reference and against the oracle on seeded loci.  Every output is an
+integer, a string or the bit-replicated log-likelihood, so the bar is exact equality."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from hipstr_amd import capi
+import util
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURES = sorted(glob.glob(os.path.join(HERE, "golden", "trace_*.npz")))
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[6:-4] for p in FIXTURES])
+def test_trace_matches_golden(hmm, path):
+    for b, rr, aa, h2r, exp in util.load_trace_fixture(path):
+        got = capi.run_trace(hmm, "hipstr_hmm_", b.ptr, rr, aa, h2r, cap=1 << 20)
+        util.assert_traces_equal(got, exp, os.path.basename(path))
+
+
+def _requests(oracle, sb, per_read, seed):
+    _, seeds = capi.run_align(oracle, "oracle_", sb.ptr)
+    A = sb.n_out // sb.n_reads
+    rng = np.random.default_rng(seed)
+    rr, aa = [], []
+    for r in range(sb.n_reads):
+        if seeds[r] >= 0:
+            for k in rng.choice(A, size=min(A, per_read), replace=False):
+                rr.append(r); aa.append(int(k))
+    return rr, aa
+
+
+@pytest.mark.parametrize("kw", [
+    dict(reads_per_locus=50, n_str_alleles=4, seed=1),
+    dict(reads_per_locus=40, n_str_alleles=8, n_flank_opts=2, seed=7),
+    dict(reads_per_locus=20, n_str_alleles=16, read_len=250, flank_len=110, str_bp=100, seed=5),       # 2-4 columns per lane
+    dict(reads_per_locus=60, n_str_alleles=12, read_len=100, flank_len=35, str_bp=30, seed=3),         # reads overhang the flanks
+    dict(reads_per_locus=24, n_str_alleles=6, read_len=250, flank_len=160, str_bp=60, seed=9),
+])
+def test_trace_matches_oracle_on_seeded_loci(hmm, oracle, kw):
+    sb = capi.SynthBatch(n_loci=1, **kw)
+    rr, aa = _requests(oracle, sb, 3, kw["seed"])
+    h2r = util.synthetic_hap_to_ref(oracle, sb.ptr)
+    want = capi.run_trace(oracle, "oracle_", sb.ptr, rr, aa, h2r, cap=1 << 21)
+    got = capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, rr, aa, h2r, cap=1 << 21)
+    util.assert_traces_equal(got, want, str(kw))
+
+
+def test_trace_without_reference_strings_skips_the_stitch(hmm, oracle):
+    sb = capi.SynthBatch(n_loci=1, reads_per_locus=12, n_str_alleles=4, seed=12)
+    rr, aa = _requests(oracle, sb, 2, 12)
+    got = capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, rr, aa, None)
+    want = capi.run_trace(oracle, "oracle_", sb.ptr, rr, aa, None)
+    util.assert_traces_equal(got, want)
+    assert all(g["cigar"] == "" and g["aln_str"] == "" for g in got)
+
+
+def test_trace_is_independent_of_the_workspace_chunking(hmm, oracle, monkeypatch):
+    """A small HIPSTR_TRACE_WS_MIB forces several launches; the results must not change."""
+    sb = capi.SynthBatch(n_loci=1, reads_per_locus=40, n_str_alleles=6, seed=21)
+    rr, aa = _requests(oracle, sb, 2, 21)
+    h2r = util.synthetic_hap_to_ref(oracle, sb.ptr)
+    whole = capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, rr, aa, h2r)
+    monkeypatch.setenv("HIPSTR_TRACE_WS_MIB", "2")
+    pieces = capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, rr, aa, h2r)
+    util.assert_traces_equal(pieces, whole)
+
+
+def test_traced_score_equals_forward_score_of_a_single_allele_locus(hmm):
+    """With one allele nothing can be reused, so the forward pass and the traceback score the same alignment."""
+    sb = capi.SynthBatch(n_loci=1, reads_per_locus=30, n_str_alleles=1, seed=41)
+    probs, seeds = capi.run_align(hmm, "hipstr_hmm_", sb.ptr)
+    rr = [r for r in range(sb.n_reads) if seeds[r] >= 0]
+    got = capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, rr, [0] * len(rr), None)
+    assert [g["ll"] for g in got] == [float(probs[r]) for r in rr]
+
+
+def test_hap_aln_consumes_exactly_the_read(hmm, oracle):
+    """Size-independent property: the operation string spends every read base once ('M', 'I', 'S')."""
+    sb = capi.SynthBatch(n_loci=1, reads_per_locus=200, n_str_alleles=8, seed=51)
+    rr, aa = _requests(oracle, sb, 1, 51)
+    got = capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, rr, aa, None, cap=1 << 21)
+    b = sb.ptr.contents
+    base_off = np.ctypeslib.as_array(b.base_off, shape=(sb.n_reads + 1,))
+    for g, r in zip(got, rr):
+        assert sum(g["hap_aln"].count(c) for c in "MIS") == base_off[r + 1] - base_off[r]
+        assert len(g["flank_left"]) + len(g["flank_right"]) + len(g["str_seq"]) + g["hap_aln"].count("S") == base_off[r + 1] - base_off[r]
+
+
+def test_trace_errors(hmm, oracle):
+    sb2 = capi.SynthBatch(n_loci=2, reads_per_locus=4, n_str_alleles=2, seed=61)
+    with pytest.raises(RuntimeError, match="one-locus"):
+        capi.run_trace(hmm, "hipstr_hmm_", sb2.ptr, [0], [0], None)
+    sb = capi.SynthBatch(n_loci=1, reads_per_locus=4, n_str_alleles=2, seed=62)
+    with pytest.raises(RuntimeError, match="allele outside"):
+        capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, [0], [99], None)
+    with pytest.raises(RuntimeError, match="read outside"):
+        capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, [99], [0], None)
+    with pytest.raises(RuntimeError, match="too small"):
+        capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, [0, 1, 2, 3], [0, 0, 0, 0], None, cap=64)
+    assert capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, [], [], None) == []

@@ -106,3 +106,58 @@ def simple_locus(lf, str_opts, rf, period, reads, start=500, lf_opts=None, rf_op
               (start + len(lf) + len(str_opts[0]), start + len(ref_hap), [rf] + (rf_opts or []))]
     A = b.add_locus(blocks, period, STUTTER, rds, realign_hap=realign_hap)
     return b, A
+
+
+def synthetic_hap_to_ref(ora, bptr):
+    """A syntactically valid Haplotype::get_aln_info()-style string per allele of a ONE-locus batch: every block is
+    aligned to option 0 of the same block end to end (common prefix 'M', then 'I' or 'D' for the length difference).
+    stitch_alignment_trace only needs #M + #I == haplotype length; real strings come with the golden fixtures."""
+    import ctypes as C
+    b = bptr.contents if hasattr(bptr, "contents") else (bptr._obj if hasattr(bptr, "_obj") else bptr)
+    nopts = np.ctypeslib.as_array(b.blk_nopts, shape=(3,)).astype(np.int32)
+    opt_off = np.ctypeslib.as_array(b.opt_off, shape=(int(nopts.sum()) + 1,))
+    lens, cur = [], 0
+    for k in range(3):
+        lens.append([int(opt_off[cur + o + 1] - opt_off[cur + o]) for o in range(nopts[k])])
+        cur += int(nopts[k])
+    out = []
+    opts = np.zeros(3, np.int32)
+    i32p = C.POINTER(C.c_int32)
+    for k in range(int(np.prod(nopts))):
+        ora.oracle_allele_options(nopts.ctypes.data_as(i32p), k, opts.ctypes.data_as(i32p))
+        s = ""
+        for blk in range(3):
+            n, n0 = lens[blk][opts[blk]], lens[blk][0]
+            s += "M" * min(n, n0) + ("I" * (n - n0) if n > n0 else "D" * (n0 - n))
+        out.append(s.encode())
+    return out
+
+
+TRACE_FIELDS = ("max_index", "hap_aln", "stutter_size", "str_seq", "flank_left", "flank_right", "flank_ins", "flank_del", "indels", "snps",
+                "aln_start", "aln_stop", "cigar", "aln_str")
+
+
+def load_trace_fixture(path):
+    """tests/golden/trace_*.npz -> list of (one-locus capi.Batch, req_read, req_allele, hap_to_ref, expected dicts)."""
+    import json
+    d = np.load(path)
+    out = []
+    for i in range(int(d["n_traced"][0])):
+        pre = "L%d_" % i
+        b = batch_from_dict(d, pre)
+        h2r = bytes(d[pre + "h2r"].tobytes()).split(b"\n")
+        exp = json.loads(bytes(d[pre + "expect"].tobytes()).decode())
+        for e in exp:     # json turned the tuples into lists
+            e["indels"] = [tuple(x) for x in e["indels"]]; e["snps"] = [tuple(x) for x in e["snps"]]
+        out.append((b, d[pre + "req_read"], d[pre + "req_allele"], h2r, exp))
+    return out
+
+
+def assert_traces_equal(got, want, what=""):
+    assert len(got) == len(want)
+    for q, (g, w) in enumerate(zip(got, want)):
+        assert g["ll"] == w["ll"], "%s request %d: ll %r != %r" % (what, q, g["ll"], w["ll"])
+        for f in TRACE_FIELDS:
+            if f == "max_index" and w[f] == -1:       # the reference keeps it in a local; the seed's 'M' in hap_aln pins it
+                continue
+            assert g[f] == w[f], "%s request %d: %s %r != %r" % (what, q, f, g[f], w[f])
