@@ -97,7 +97,13 @@ class Alignment {
   Alignment(int32_t start, int32_t stop, bool rev_strand, const std::string& name, const std::string& base_qualities,
             const std::string& sequence, const std::string& alignment)
     : start_(start), stop_(stop), name_(name), base_qualities_(base_qualities), sequence_(sequence), alignment_(alignment), rev_strand_(rev_strand) {}
+  explicit Alignment(const std::string& name) : start_(0), stop_(-1), name_(name), rev_strand_(false) {}    // AlignmentData.h:53-59
   const std::string& get_name() const { return name_; }
+  std::string getCigarString() const {                           // AlignmentData.h:131-137
+    std::string s;
+    for (size_t i = 0; i < cigar_list_.size(); i++){ s += std::to_string(cigar_list_[i].get_num()); s += cigar_list_[i].get_type(); }
+    return s;
+  }
   int32_t get_start() const { return start_; }
   int32_t get_stop()  const { return stop_;  }
   bool is_from_reverse_strand() const { return rev_strand_; }
@@ -154,6 +160,17 @@ class Haplotype {
   HapBlock* get_block(int i)   const { return blocks_[i]; }
   HapBlock* get_first_block()  const { return blocks_.front(); }
   HapBlock* get_last_block()   const { return blocks_.back();  }
+  // Haplotype::get_aln_info() (Haplotype.h:65) per haplotype index.  The reference derives these strings while it BUILDS the
+  // haplotype (Needleman-Wunsch of every allele against the reference allele, Haplotype.cpp:58-86) — candidate-allele
+  // generation, outside the alignment hot path — so here they are an input: hand over what that step produced.
+  void set_aln_info(const std::vector<std::string>& hap_aln_info){
+    if ((int)hap_aln_info.size() != ncombs_) printErrorAndDie("set_aln_info needs one string per haplotype");
+    hap_aln_info_ = hap_aln_info;
+  }
+  bool has_aln_info() const { return !hap_aln_info_.empty(); }
+  const std::string& get_aln_info(int hap_index) const { return hap_aln_info_[hap_index]; }
+ private:
+  std::vector<std::string> hap_aln_info_;
 };
 
 class ReadPooler {
@@ -186,6 +203,36 @@ class ReadPooler {
     pooled_ = true;
   }
   std::vector<Alignment>& get_alignments(){ return pooled_alns_; }
+};
+
+// AlignmentTrace (AlignmentTraceback.h:10-108): what a traceback reports about one read.
+class AlignmentTrace {
+  std::string hap_aln_;
+  Alignment trace_vs_ref_;
+  int flank_ins_size_, flank_del_size_;
+  std::vector<int> stutter_size_; std::vector<std::string> str_seq_; std::vector<bool> str_set_;
+  std::vector<std::string> flank_seqs_;
+  std::vector< std::pair<int32_t,int32_t> > flank_indel_data_;
+  std::vector< std::pair<int32_t,char> > flank_snp_data_;
+  friend class HapAligner;
+ public:
+  explicit AlignmentTrace(int num_haplotype_blocks)
+    : trace_vs_ref_("TRACE"), flank_ins_size_(0), flank_del_size_(0), stutter_size_(num_haplotype_blocks, 0), str_seq_(num_haplotype_blocks),
+      str_set_(num_haplotype_blocks, false), flank_seqs_(num_haplotype_blocks) {}
+  int flank_ins_size()         const { return flank_ins_size_; }
+  int flank_del_size()         const { return flank_del_size_; }
+  const std::string& hap_aln() const { return hap_aln_; }
+  Alignment& traced_aln()            { return trace_vs_ref_; }
+  const std::vector< std::pair<int32_t,int32_t> >& flank_indel_data() const { return flank_indel_data_; }
+  const std::vector< std::pair<int32_t,char> >& flank_snp_data()      const { return flank_snp_data_; }
+  bool has_stutter() const {                                    // AlignmentTraceback.h:79-85
+    for (size_t i = 0; i < str_set_.size(); i++) if (str_set_[i] && stutter_size_[i] != 0) return true;
+    return false;
+  }
+  bool has_str_data(int block_index) const { return str_set_[block_index]; }     // str_data_[block_index] != NULL
+  int stutter_size(int block_index)  const { assert(str_set_[block_index]); return stutter_size_[block_index]; }
+  const std::string& str_seq(int block_index)   const { assert(str_set_[block_index]); return str_seq_[block_index]; }
+  const std::string& flank_seq(int block_index) const { return flank_seqs_[block_index]; }
 };
 
 // Flat one-locus batch built from the classes above (what the C-ABI consumes).
@@ -260,6 +307,69 @@ class HapAligner {
     FlatLocus f; f.set_haplotype(fw_haplotype_, realign_to_hap_); f.set_reads(alignments, realign_read);
     if (hipstr_hmm_process_reads(f.finish(), aln_probs + (size_t)init_read_index*fw_haplotype_->num_combs(), seed_positions + init_read_index) != 0)
       printErrorAndDie(hipstr_last_error());
+  }
+  // HapAligner::trace_optimal_aln (HapAligner.h:88-92, HapAligner.cpp:711-722); the caller owns the result.
+  AlignmentTrace* trace_optimal_aln(const Alignment& orig_aln, int /*seed_base*/, int best_haplotype, const BaseQuality* base_quality){
+    std::vector<AlignmentTrace*> traces;
+    trace_optimal_alns(std::vector<Alignment>(1, orig_aln), std::vector<int>(1, best_haplotype), base_quality, traces);
+    return traces[0];
+  }
+  // All tracebacks of a locus in one launch: request i = alignments[i] against haplotype best_haplotypes[i] (what
+  // SeqStutterGenotyper::retrace_alignments, seq_stutter_genotyper.cpp:805-841, asks for one read at a time).  The stitched
+  // alignment against the reference (traced_aln()) is produced when the haplotype carries its get_aln_info() strings.
+  void trace_optimal_alns(const std::vector<Alignment>& alignments, const std::vector<int>& best_haplotypes, const BaseQuality* /*base_quality*/,
+                          std::vector<AlignmentTrace*>& traces){
+    assert(alignments.size() == best_haplotypes.size());
+    traces.clear();
+    std::vector<Alignment> alns; std::vector<int32_t> req_read, req_allele;
+    for (size_t i = 0; i < alignments.size(); i++)          // a masked haplotype is skipped by process_read: empty trace (HapAligner.cpp:614-618)
+      if (realign_to_hap_[best_haplotypes[i]]){ req_read.push_back((int32_t)alns.size()); req_allele.push_back(best_haplotypes[i]); alns.push_back(alignments[i]); }
+    const int n = (int)alns.size();
+    FlatLocus f; f.set_haplotype(fw_haplotype_, realign_to_hap_); f.set_reads(alns, std::vector<bool>(alns.size(), true));
+    std::vector<const char*> hap_to_ref;
+    size_t chars = 64;
+    if (fw_haplotype_->has_aln_info())
+      for (int k = 0; k < fw_haplotype_->num_combs(); k++) hap_to_ref.push_back(fw_haplotype_->get_aln_info(k).c_str());
+    for (int i = 0; i < n; i++)
+      chars += 2*alns[i].get_sequence().size() + 64 + (hap_to_ref.empty() ? 0 : 2*fw_haplotype_->get_aln_info(req_allele[i]).size());
+    const int32_t cap = (int32_t)chars;
+    std::vector<double> ll(n + 1);
+    std::vector<int32_t> max_index(n + 1), hap_aln_off(n + 1), stutter_size(n + 1), str_seq_off(n + 1), flank_seq_off(2*n + 1), flank_ins(n + 1), flank_del(n + 1),
+      indel_off(n + 1), indel_pos(cap), indel_size(cap), snp_off(n + 1), snp_pos(cap), aln_start(n + 1), aln_stop(n + 1), cigar_off(n + 1), cigar_len(cap), aln_str_off(n + 1);
+    std::vector<char> hap_aln(cap), str_seq(cap), flank_seq(cap), snp_base(cap), cigar_op(cap), aln_str(cap);
+    hipstr_trace_out_t o;
+    o.ll = ll.data(); o.max_index = max_index.data(); o.hap_aln_off = hap_aln_off.data(); o.hap_aln = hap_aln.data();
+    o.stutter_size = stutter_size.data(); o.str_seq_off = str_seq_off.data(); o.str_seq = str_seq.data();
+    o.flank_seq_off = flank_seq_off.data(); o.flank_seq = flank_seq.data(); o.flank_ins = flank_ins.data(); o.flank_del = flank_del.data();
+    o.indel_off = indel_off.data(); o.indel_pos = indel_pos.data(); o.indel_size = indel_size.data();
+    o.snp_off = snp_off.data(); o.snp_pos = snp_pos.data(); o.snp_base = snp_base.data();
+    o.aln_start = aln_start.data(); o.aln_stop = aln_stop.data(); o.cigar_off = cigar_off.data(); o.cigar_op = cigar_op.data(); o.cigar_len = cigar_len.data();
+    o.aln_str_off = aln_str_off.data(); o.aln_str = aln_str.data(); o.cap_chars = cap;
+    if (n > 0 && hipstr_hmm_trace(f.finish(), n, req_read.data(), req_allele.data(), hap_to_ref.empty() ? NULL : hap_to_ref.data(), &o) != 0)
+      printErrorAndDie(hipstr_last_error());
+    for (size_t i = 0, q = 0; i < alignments.size(); i++){
+      AlignmentTrace* t = new AlignmentTrace(fw_haplotype_->num_blocks());
+      traces.push_back(t);
+      if (!realign_to_hap_[best_haplotypes[i]]) continue;
+      t->hap_aln_.assign(hap_aln.data() + hap_aln_off[q], hap_aln_off[q+1] - hap_aln_off[q]);
+      if (stutter_size[q] != HIPSTR_NO_STR_DATA){
+        t->str_set_[1] = true; t->stutter_size_[1] = stutter_size[q];
+        t->str_seq_[1].assign(str_seq.data() + str_seq_off[q], str_seq_off[q+1] - str_seq_off[q]);
+      }
+      t->flank_seqs_[0].assign(flank_seq.data() + flank_seq_off[2*q], flank_seq_off[2*q+1] - flank_seq_off[2*q]);
+      t->flank_seqs_[2].assign(flank_seq.data() + flank_seq_off[2*q+1], flank_seq_off[2*q+2] - flank_seq_off[2*q+1]);
+      t->flank_ins_size_ = flank_ins[q]; t->flank_del_size_ = flank_del[q];
+      for (int k = indel_off[q]; k < indel_off[q+1]; k++) t->flank_indel_data_.push_back(std::pair<int32_t,int32_t>(indel_pos[k], indel_size[k]));
+      for (int k = snp_off[q]; k < snp_off[q+1]; k++) t->flank_snp_data_.push_back(std::pair<int32_t,char>(snp_pos[k], snp_base[k]));
+      if (!hap_to_ref.empty()){
+        t->trace_vs_ref_ = Alignment(aln_start[q], aln_stop[q], false, "TRACE", alignments[i].get_base_qualities(), alignments[i].get_sequence(),
+                                     std::string(aln_str.data() + aln_str_off[q], aln_str_off[q+1] - aln_str_off[q]));
+        std::vector<CigarElement> cigar_list;
+        for (int k = cigar_off[q]; k < cigar_off[q+1]; k++) cigar_list.push_back(CigarElement(cigar_op[k], cigar_len[k]));
+        t->trace_vs_ref_.set_cigar_list(cigar_list);
+      }
+      q++;
+    }
   }
 };
 

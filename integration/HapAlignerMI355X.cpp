@@ -9,7 +9,7 @@
 #include "hipstr_hmm.h"
 
 HapAlignerMI355X::HapAlignerMI355X(Haplotype* haplotype, std::vector<bool>& realign_to_haplotype)
-  : fw_haplotype_(haplotype), realign_to_hap_(realign_to_haplotype), cpu_aligner_(haplotype, realign_to_haplotype){
+  : fw_haplotype_(haplotype), realign_to_hap_(realign_to_haplotype){
   assert(realign_to_haplotype.size() == (size_t)haplotype->num_combs());
   if (haplotype->num_blocks() != HIPSTR_NUM_BLOCKS)
     printErrorAndDie("HapAlignerMI355X requires a [flank, repeat, flank] haplotype");
@@ -89,4 +89,91 @@ void HapAlignerMI355X::process_reads(const std::vector<Alignment>& alignments, i
   FILL_BATCH(b, r)
   if (hipstr_hmm_process_reads(&b, aln_probs + (size_t)init_read_index*fw_haplotype_->num_combs(), seed_positions + init_read_index) != 0)
     printErrorAndDie(hipstr_last_error());
+}
+
+AlignmentTrace* HapAlignerMI355X::trace_optimal_aln(const Alignment& orig_aln, int seed_base, int best_haplotype, const BaseQuality* base_quality){
+  (void)seed_base;        // recomputed by the library; the reference passes calc_seed_base's value back in (seq_stutter_genotyper.cpp:831)
+  std::vector<AlignmentTrace*> traces;
+  trace_optimal_alns(std::vector<Alignment>(1, orig_aln), std::vector<int>(1, best_haplotype), base_quality, traces);
+  return traces[0];
+}
+
+void HapAlignerMI355X::trace_optimal_alns(const std::vector<Alignment>& alignments, const std::vector<int>& best_haplotypes,
+					  const BaseQuality* base_quality, std::vector<AlignmentTrace*>& traces){
+  assert(alignments.size() == best_haplotypes.size());
+  (void)base_quality;
+  traces.clear();
+  // A haplotype the aligner was told not to realign to is skipped by process_read (HapAligner.cpp:614-618), which leaves the
+  // AlignmentTrace empty; the reference's own callers always trace with an all-true mask (seq_stutter_genotyper.cpp:813).
+  {
+    bool any_masked = false;
+    for (size_t i = 0; i < best_haplotypes.size(); i++) any_masked |= !realign_to_hap_[best_haplotypes[i]];
+    if (any_masked){
+      std::vector<Alignment> sub_alns; std::vector<int> sub_haps;
+      for (size_t i = 0; i < alignments.size(); i++)
+        if (realign_to_hap_[best_haplotypes[i]]){ sub_alns.push_back(alignments[i]); sub_haps.push_back(best_haplotypes[i]); }
+      std::vector<AlignmentTrace*> sub;
+      trace_optimal_alns(sub_alns, sub_haps, base_quality, sub);
+      for (size_t i = 0, k = 0; i < alignments.size(); i++)
+        traces.push_back(realign_to_hap_[best_haplotypes[i]] ? sub[k++] : new AlignmentTrace(fw_haplotype_->num_blocks()));
+      return;
+    }
+  }
+  const int n = (int)alignments.size();
+  if (n == 0) return;
+  FlatReads r(alignments, std::vector<bool>(alignments.size(), true));
+  FILL_BATCH(b, r)
+
+  // Haplotype::get_aln_info() of every haplotype, in the order the reference visits them (Haplotype::next)
+  std::vector<std::string> aln_info;
+  fw_haplotype_->reset();
+  do { aln_info.push_back(fw_haplotype_->get_aln_info()); } while (fw_haplotype_->next());
+  fw_haplotype_->reset();
+  std::vector<const char*> hap_to_ref;
+  for (size_t k = 0; k < aln_info.size(); k++) hap_to_ref.push_back(aln_info[k].c_str());
+
+  std::vector<int32_t> req_read(n), req_allele(best_haplotypes.begin(), best_haplotypes.end());
+  size_t chars = 64;
+  for (int i = 0; i < n; i++){ req_read[i] = i; chars += 2*alignments[i].get_sequence().size() + 2*aln_info[best_haplotypes[i]].size() + 64; }
+  const int32_t cap = (int32_t)chars;
+  std::vector<double> ll(n);
+  std::vector<int32_t> max_index(n), hap_aln_off(n+1), stutter_size(n), str_seq_off(n+1), flank_seq_off(2*n+1), flank_ins(n), flank_del(n),
+    indel_off(n+1), indel_pos(cap), indel_size(cap), snp_off(n+1), snp_pos(cap), aln_start(n), aln_stop(n), cigar_off(n+1), cigar_len(cap), aln_str_off(n+1);
+  std::vector<char> hap_aln(cap), str_seq(cap), flank_seq(cap), snp_base(cap), cigar_op(cap), aln_str(cap);
+  hipstr_trace_out_t o;
+  o.ll = ll.data(); o.max_index = max_index.data(); o.hap_aln_off = hap_aln_off.data(); o.hap_aln = hap_aln.data();
+  o.stutter_size = stutter_size.data(); o.str_seq_off = str_seq_off.data(); o.str_seq = str_seq.data();
+  o.flank_seq_off = flank_seq_off.data(); o.flank_seq = flank_seq.data(); o.flank_ins = flank_ins.data(); o.flank_del = flank_del.data();
+  o.indel_off = indel_off.data(); o.indel_pos = indel_pos.data(); o.indel_size = indel_size.data();
+  o.snp_off = snp_off.data(); o.snp_pos = snp_pos.data(); o.snp_base = snp_base.data();
+  o.aln_start = aln_start.data(); o.aln_stop = aln_stop.data(); o.cigar_off = cigar_off.data(); o.cigar_op = cigar_op.data(); o.cigar_len = cigar_len.data();
+  o.aln_str_off = aln_str_off.data(); o.aln_str = aln_str.data(); o.cap_chars = cap;
+  if (hipstr_hmm_trace(&b, n, req_read.data(), req_allele.data(), hap_to_ref.data(), &o) != 0)
+    printErrorAndDie(hipstr_last_error());
+
+  // the same AlignmentTrace the reference's process_read fills (HapAligner.cpp:642-707), through its public mutators
+  for (int i = 0; i < n; i++){
+    AlignmentTrace* t = new AlignmentTrace(fw_haplotype_->num_blocks());
+    std::string s(hap_aln.data() + hap_aln_off[i], hap_aln_off[i+1] - hap_aln_off[i]);
+    t->set_hap_aln(s);
+    if (stutter_size[i] != HIPSTR_NO_STR_DATA){
+      std::string ss(str_seq.data() + str_seq_off[i], str_seq_off[i+1] - str_seq_off[i]);
+      t->add_str_data(1, stutter_size[i], ss);
+    }
+    for (int side = 0; side < 2; side++){
+      std::string fs(flank_seq.data() + flank_seq_off[2*i+side], flank_seq_off[2*i+side+1] - flank_seq_off[2*i+side]);
+      t->add_flank_data(side == 0 ? 0 : 2, fs);
+    }
+    for (int k = 0; k < flank_ins[i]; k++) t->inc_flank_ins();
+    for (int k = 0; k < flank_del[i]; k++) t->inc_flank_del();
+    for (int k = indel_off[i]; k < indel_off[i+1]; k++) t->add_flank_indel(std::pair<int32_t,int32_t>(indel_pos[k], indel_size[k]));
+    for (int k = snp_off[i]; k < snp_off[i+1]; k++) t->add_flank_snp(snp_pos[k], snp_base[k]);
+    const Alignment& orig = alignments[i];
+    t->traced_aln() = Alignment(aln_start[i], aln_stop[i], false, "TRACE", orig.get_base_qualities(), orig.get_sequence(),
+				std::string(aln_str.data() + aln_str_off[i], aln_str_off[i+1] - aln_str_off[i]));
+    std::vector<CigarElement> cigar_list;
+    for (int k = cigar_off[i]; k < cigar_off[i+1]; k++) cigar_list.push_back(CigarElement(cigar_op[k], cigar_len[k]));
+    t->traced_aln().set_cigar_list(cigar_list);
+    traces.push_back(t);
+  }
 }

@@ -6,7 +6,10 @@
 // construction sites (seq_stutter_genotyper.cpp:522, :814, :1076) — see INTEGRATION.md.
 //
 //   process_reads / calc_seed_base  ->  libhipstr_hmm.so  (include/hipstr_hmm.h, MI355X kernels)
-//   trace_optimal_aln               ->  the reference's CPU HapAligner (Viterbi traceback is the next tier)
+//   trace_optimal_aln               ->  hipstr_hmm_trace (one request), same AlignmentTrace the reference builds
+//   trace_optimal_alns              ->  hipstr_hmm_trace (all requests of a locus in one launch): what
+//                                       SeqStutterGenotyper::retrace_alignments (seq_stutter_genotyper.cpp:805-841) and
+//                                       the loop at :1111-1122 should call once instead of trace_optimal_aln per read
 //
 // This file is NOT part of the product library and is only compiled where the HipSTR tree is
 // available (oracle/Makefile target `dropin`, which also builds the drop-in equivalence check).
@@ -26,7 +29,6 @@ class HapAlignerMI355X {
  private:
   Haplotype* fw_haplotype_;                 // borrowed, as in HapAligner (HapAligner.h:58)
   std::vector<bool> realign_to_hap_;
-  HapAligner cpu_aligner_;                  // traceback only
 
   // flattened haplotype (built once per aligner, like the reference builds its reversed haplotype once)
   std::vector<int32_t> blk_start_, blk_end_, blk_nopts_, opt_off_, hap_off_;
@@ -46,9 +48,13 @@ class HapAlignerMI355X {
   void process_reads(const std::vector<Alignment>& alignments, int init_read_index, const BaseQuality* base_quality,
 		     const std::vector<bool>& realign_read, double* aln_probs, int* seed_positions);
 
-  AlignmentTrace* trace_optimal_aln(const Alignment& orig_aln, int seed_base, int best_haplotype, const BaseQuality* base_quality){
-    return cpu_aligner_.trace_optimal_aln(orig_aln, seed_base, best_haplotype, base_quality);
-  }
+  // HapAligner::trace_optimal_aln (HapAligner.h:88-92).  The caller owns the returned object, as with the reference.
+  AlignmentTrace* trace_optimal_aln(const Alignment& orig_aln, int seed_base, int best_haplotype, const BaseQuality* base_quality);
+
+  // Batched form: request i traces alignments[i] against haplotype best_haplotypes[i]; traces[i] is a new AlignmentTrace.
+  // The seed of every read is recomputed on the way (calc_seed_base is a pure function of the read and the haplotype).
+  void trace_optimal_alns(const std::vector<Alignment>& alignments, const std::vector<int>& best_haplotypes,
+			  const BaseQuality* base_quality, std::vector<AlignmentTrace*>& traces);
 };
 
 #endif

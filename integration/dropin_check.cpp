@@ -32,7 +32,7 @@ int main(int argc, char** argv){
   void* h = synth_create(n_loci, reads, alleles, 150, 60, 40, flank_opts, 4242, 0.2);
   const hipstr_batch_t* b = synth_batch(h);
   BaseQuality bq;
-  int opt = 0; long n_cmp = 0, n_bad = 0; double max_diff = 0;
+  int opt = 0; long n_cmp = 0, n_bad = 0, n_trace = 0; double max_diff = 0;
   for (int l = 0; l < b->n_loci; l++){
     const double* sp = b->stutter + 6*l;
     StutterModel model(sp[0], sp[1], sp[2], sp[3], sp[4], sp[5], b->period[l]);
@@ -70,9 +70,39 @@ int main(int argc, char** argv){
       if (memcmp(&want[i], &got[i], 8) != 0){ n_bad++; if (fabs(want[i]-got[i]) > max_diff) max_diff = fabs(want[i]-got[i]); }
     }
     if (!alns.empty() && wseed[0] >= 0 && gpu.calc_seed_base(alns[0]) != cpu.calc_seed_base(alns[0])) n_bad++;
+    // Viterbi traceback: the reference's trace_optimal_aln per read vs one batched call on the MI355X
+    {
+      std::vector<Alignment> t_alns; std::vector<int> t_haps;
+      for (size_t i = 0; i < alns.size(); i++)
+        if (wseed[i] >= 0){ t_alns.push_back(alns[i]); t_haps.push_back((int)((i*7 + l) % A)); }
+      std::vector<AlignmentTrace*> got_tr;
+      gpu.trace_optimal_alns(t_alns, t_haps, &bq, got_tr);
+      for (size_t i = 0; i < t_alns.size(); i++){
+        AlignmentTrace* w = cpu.trace_optimal_aln(t_alns[i], cpu.calc_seed_base(t_alns[i]), t_haps[i], &bq);
+        AlignmentTrace* g = got_tr[i];
+        bool same = w->hap_aln() == g->hap_aln() && w->flank_ins_size() == g->flank_ins_size() && w->flank_del_size() == g->flank_del_size()
+          && w->flank_seq(0) == g->flank_seq(0) && w->flank_seq(2) == g->flank_seq(2)
+          && w->flank_indel_data() == g->flank_indel_data() && w->flank_snp_data() == g->flank_snp_data()
+          && w->has_stutter() == g->has_stutter()
+          && w->traced_aln().get_start() == g->traced_aln().get_start() && w->traced_aln().get_stop() == g->traced_aln().get_stop()
+          && w->traced_aln().getCigarString() == g->traced_aln().getCigarString()
+          && w->traced_aln().get_alignment() == g->traced_aln().get_alignment()
+          && w->traced_aln().get_sequence() == g->traced_aln().get_sequence();
+        if (same && w->has_stutter()) same = w->stutter_size(1) == g->stutter_size(1) && w->str_seq(1) == g->str_seq(1);
+        n_trace++;
+        if (!same){
+          n_bad++;
+          if (n_bad <= 3)
+            fprintf(stderr, "trace mismatch locus %d read %zu hap %d\n  hap_aln want %s\n          got  %s\n  cigar want %s got %s start %d/%d stop %d/%d\n", l, i, t_haps[i],
+                    w->hap_aln().c_str(), g->hap_aln().c_str(), w->traced_aln().getCigarString().c_str(), g->traced_aln().getCigarString().c_str(),
+                    w->traced_aln().get_start(), g->traced_aln().get_start(), w->traced_aln().get_stop(), g->traced_aln().get_stop());
+        }
+        delete w; delete g;
+      }
+    }
     for (size_t k = 0; k < blocks.size(); k++) delete blocks[k];
   }
   synth_free(h);
-  printf("dropin_check: %ld log-likelihoods compared, %ld mismatches, max|diff| %g\n", n_cmp, n_bad, max_diff);
+  printf("dropin_check: %ld log-likelihoods and %ld tracebacks compared, %ld mismatches, max|diff| %g\n", n_cmp, n_trace, n_bad, max_diff);
   return n_bad == 0 ? 0 : 1;
 }

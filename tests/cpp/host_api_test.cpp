@@ -80,6 +80,25 @@ int main(int argc, char** argv){
   calc_hap_aln_probs(&hap, pooler, bq, pool_index.data(), sm, (unsigned)alns.size(), all_haps, realign_pool, copy_read, ll.data(), sd.data());
   for (size_t i = 0; i < alns.size(); i++) printf("read_ll %zu %d %.11f %.11f %.11f %.11f\n", i, sd[i], ll[4*i], ll[4*i+1], ll[4*i+2], ll[4*i+3]);
 
+  // Viterbi traceback of the known-answer read against every haplotype; argv[2..5] = Haplotype::get_aln_info() strings
+  if (argc >= 6){
+    hap.set_aln_info(std::vector<std::string>(argv + 2, argv + 6));
+    std::vector<Alignment> t_alns(4, alns[0]); std::vector<int> t_haps;
+    for (int k = 0; k < 4; k++) t_haps.push_back(k);
+    std::vector<AlignmentTrace*> tr;
+    aligner.trace_optimal_alns(t_alns, t_haps, &bq, tr);
+    for (int k = 0; k < 4; k++){
+      printf("trace %d %s %d %s %s %s %d %d %d %d %s %s\n", k, tr[k]->hap_aln().c_str(), tr[k]->has_str_data(1) ? tr[k]->stutter_size(1) : -100000,
+             tr[k]->has_str_data(1) ? tr[k]->str_seq(1).c_str() : "-", tr[k]->flank_seq(0).c_str(), tr[k]->flank_seq(2).c_str(),
+             tr[k]->flank_ins_size(), tr[k]->flank_del_size(), tr[k]->traced_aln().get_start(), tr[k]->traced_aln().get_stop(),
+             tr[k]->traced_aln().getCigarString().c_str(), tr[k]->traced_aln().get_alignment().c_str());
+      delete tr[k];
+    }
+    AlignmentTrace* one = aligner.trace_optimal_aln(alns[0], seeds[0], 1, &bq);
+    printf("trace_one %s\n", one->hap_aln().c_str());
+    delete one;
+  }
+
   // posteriors: SURVEY §8(c) second known-answer vector
   const double LL[15] = {-4.4,-7.3,-9.6, -7.1,-4.2,-7.5, -4.5,-7.0,-9.9, -9.0,-6.0,-4.1, -9.2,-6.3,-4.0};
   std::vector<std::string> names; names.push_back("s1"); names.push_back("s2");

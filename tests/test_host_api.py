@@ -39,7 +39,17 @@ def test_host_only_parts(_native_built):
 
 @pytest.mark.gpu
 def test_device_parts(_native_built):
-    kv = _run("--gpu")
+    import util
+    (b, rr, aa, h2r, exp), = util.load_trace_fixture(os.path.join(ROOT, "tests", "golden", "trace_kat_survey.npz"))
+    kv = _run("--gpu", *[s.decode() for s in h2r])
+    # the C++ classes' traceback of the known-answer read against the golden vectors of the compiled reference
+    rows = {int(r[0]): r[1:] for r in kv["trace"]}
+    assert len(rows) == 4 and len(exp) >= 3
+    for k, e in zip(aa, exp):
+        got = rows[int(k)]
+        assert got == [e["hap_aln"], str(e["stutter_size"]), e["str_seq"], e["flank_left"], e["flank_right"], str(e["flank_ins"]), str(e["flank_del"]),
+                       str(e["aln_start"]), str(e["aln_stop"]), e["cigar"], e["aln_str"]]
+    assert kv["trace_one"] == [[rows[1][0]]]
     assert kv["kat_seed"] == [["81"]]
     want = [-7.37582683338, -4.37708234692, -7.35198679536, -9.68433975817]
     assert all(abs(float(a) - b) < 5e-11 for a, b in zip(kv["kat_ll"][0], want))
