@@ -51,7 +51,7 @@ class HipstrTraceOut(C.Structure):
                 ("cap_chars", C.c_int32)]
 
 
-def run_trace(lib, prefix, bptr, req_read, req_allele, hap_to_ref=None, cap=1 << 16):
+def run_trace(lib, prefix, bptr, req_read, req_allele, hap_to_ref=None, cap=1 << 16, timing=None):
     """Call <prefix>trace on a one-locus batch; returns a list of dicts (one per request) with python-typed fields.
     hap_to_ref: list of bytes (one per allele) or None.  The reference probe (prefix 'ref_') always stitches."""
     n = len(req_read)
@@ -70,6 +70,8 @@ def run_trace(lib, prefix, bptr, req_read, req_allele, hap_to_ref=None, cap=1 <<
     o.cap_chars = cap
     rr = np.ascontiguousarray(np.asarray(req_read, np.int32)); aa = np.ascontiguousarray(np.asarray(req_allele, np.int32))
     fn = getattr(lib, prefix + "trace")
+    import time
+    t_call = time.perf_counter()
     if prefix == "ref_":
         fn.restype = C.c_int; fn.argtypes = [_BP, C.c_int32, _i32p, _i32p, C.POINTER(HipstrTraceOut)]
         rc = fn(bptr, n, rr.ctypes.data_as(_i32p), aa.ctypes.data_as(_i32p), C.byref(o))
@@ -79,6 +81,8 @@ def run_trace(lib, prefix, bptr, req_read, req_allele, hap_to_ref=None, cap=1 <<
         if hap_to_ref is not None:
             h2r = (C.c_char_p * len(hap_to_ref))(*hap_to_ref)
         rc = fn(bptr, n, rr.ctypes.data_as(_i32p), aa.ctypes.data_as(_i32p), h2r, C.byref(o))
+    if timing is not None:
+        timing["call_s"] = timing.get("call_s", 0.0) + time.perf_counter() - t_call
     if rc != 0:
         why = ""
         if prefix == "hipstr_hmm_":

@@ -21,6 +21,8 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <string>
@@ -619,6 +621,10 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
   using hipstr::api_fail;
   if (!b || !o || n_req < 0 || (n_req > 0 && (!req_read || !req_allele))) return api_fail("null argument");
   if (b->n_loci != 1) return api_fail("hipstr_hmm_trace takes a one-locus batch");
+  const bool timing = getenv("HIPSTR_TRACE_TIMING") != NULL;
+  auto now = [](){ return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b){ return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto t_begin = now();
   hipstr::ApiTables T;
   if (hipstr::api_device_tables(&T)) return 1;
   const hipstr::HostTables& HT = hipstr::host_tables();
@@ -677,6 +683,7 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
     alleles[k] = ap;
   }
 
+  const auto t_prep = now();
   // ---- static device data
   DevBufs dev;
   hs_tdev_t h; memset(&h, 0, sizeof h);
@@ -719,7 +726,10 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
   }
 
   int rc = 0;
+  const auto t_static = now();
+  double ms_alloc = 0, ms_kernel = 0, ms_d2h = 0, ms_replay = 0;
   for (int q0 = 0; q0 < n_req && rc == 0; ){
+    const auto c0 = now();
     int q1 = q0; int64_t mat = 0; int64_t n_art = 0, n_ops = 0;
     while (q1 < n_req && mat + need[q1] <= budget){
       for (int sd = 0; sd < 2; sd++){
@@ -748,6 +758,7 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
         ws.alloc(&hc.ll, nq) || ws.alloc(&hc.max_index, nq) || ws.alloc(&hc.n_ops, 2*(size_t)nq) ||
         ws.alloc(&hc.str_size, 2*(size_t)nq) || ws.alloc(&hc.str_pos, 2*(size_t)nq)) return 1;
     if (ws.put(&d_args, &hc, 1)) return 1;
+    const auto c1 = now();
     for (int cl = 1; cl <= HS_MAX_COLS; cl++){
       const int cnt = cls_begin[cl] - cls_begin[cl-1];
       if (cnt == 0) continue;
@@ -761,6 +772,7 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
     hipLaunchKernelGGL(hs_trace_walk, dim3(nq), dim3(64), 0, T.stream, d_args, 0);
     TR_HIP(hipGetLastError());
     TR_HIP(hipStreamSynchronize(T.stream));
+    const auto c2 = now();
     std::vector<double> ll(nq); std::vector<int32_t> mxi(nq), nops(2*(size_t)nq), ssz(2*(size_t)nq), spos(2*(size_t)nq);
     std::vector<char> opsbuf(n_ops ? n_ops : 1);
     TR_HIP(hipMemcpy(ll.data(), hc.ll, nq*sizeof(double), hipMemcpyDeviceToHost));
@@ -770,6 +782,7 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
     TR_HIP(hipMemcpy(spos.data(), hc.str_pos, 2*(size_t)nq*sizeof(int32_t), hipMemcpyDeviceToHost));
     TR_HIP(hipMemcpy(opsbuf.data(), hc.ops, n_ops, hipMemcpyDeviceToHost));
 
+    const auto c3 = now();
     // ---- replay + outputs (HapAligner.cpp:642-707)
     for (int q = q0; q < q1; q++){
       const int r = req_read[q], sb = seeds[q];
@@ -872,6 +885,11 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
       if (!ok) return api_fail("hipstr_trace_out_t pools are too small (cap_chars)");
     }
     q0 = q1;
+    const auto c4 = now();
+    ms_alloc += ms(c0, c1); ms_kernel += ms(c1, c2); ms_d2h += ms(c2, c3); ms_replay += ms(c3, c4);
   }
+  if (timing)
+    fprintf(stderr, "hipstr_hmm_trace: %d requests; prep %.3f ms, static upload %.3f, chunk alloc+upload %.3f, kernels %.3f, d2h %.3f, replay %.3f, total %.3f\n",
+            n_req, ms(t_begin, t_prep), ms(t_prep, t_static), ms_alloc, ms_kernel, ms_d2h, ms_replay, ms(t_begin, now()));
   return rc;
 }
