@@ -51,7 +51,7 @@ class HipstrTraceOut(C.Structure):
                 ("cap_chars", C.c_int32)]
 
 
-def run_trace(lib, prefix, bptr, req_read, req_allele, hap_to_ref=None, cap=1 << 16, timing=None):
+def run_trace(lib, prefix, bptr, req_read, req_allele, hap_to_ref=None, cap=1 << 16, timing=None, unpack=True):
     """Call <prefix>trace on a one-locus batch; returns a list of dicts (one per request) with python-typed fields.
     hap_to_ref: list of bytes (one per allele) or None.  The reference probe (prefix 'ref_') always stitches."""
     n = len(req_read)
@@ -89,6 +89,8 @@ def run_trace(lib, prefix, bptr, req_read, req_allele, hap_to_ref=None, cap=1 <<
             lib.hipstr_last_error.restype = C.c_char_p
             why = ": " + lib.hipstr_last_error().decode()
         raise RuntimeError("%strace failed rc=%d%s" % (prefix, rc, why))
+    if not unpack:
+        return keep
     def piece(pool, off, i):
         return keep[pool].raw[keep[off][i]:keep[off][i + 1]].decode()
     out = []

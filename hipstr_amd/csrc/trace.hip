@@ -26,6 +26,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hipstr_hmm.h"
@@ -516,10 +517,10 @@ struct TraceAcc {                 // what AlignmentTrace accumulates (AlignmentT
 
 // start coordinate a (possibly reversed) haplotype block reports: HapBlock::reverse() builds HapBlock(end_-1, start_-1, ..),
 // RepeatBlock::reverse() keeps (start_, end_) (HapBlock.h:123-133, RepeatBlock.h:48-58)
-int32_t side_block_start(const hipstr_batch_t* b, bool rev, int bi){
+int32_t side_block_start(const hipstr_batch_t* b, int locus, bool rev, int bi){
   const int fb = rev ? 2-bi : bi;
-  if (!rev || fb == 1) return b->blk_start[fb];
-  return b->blk_end[fb]-1;
+  if (!rev || fb == 1) return b->blk_start[3*locus + fb];
+  return b->blk_end[3*locus + fb]-1;
 }
 
 const double MIN_SNP_LOG_PROB_CORRECT = -0.0043648054;     // HapAligner.cpp:24
@@ -527,7 +528,7 @@ const double MIN_SNP_LOG_PROB_CORRECT = -0.0043648054;     // HapAligner.cpp:24
 // The matrix-free half of HapAligner::retrace (HapAligner.cpp:363-571): the device decided the move at every step
 // (`ops`); this replays them to collect flank sequences, SNPs, indels and the STR sequence.  rd/lc: the side's read
 // (reversed for the right problem).  Returns false if the operation string is inconsistent.
-bool replay_side(const hipstr_batch_t* b, const std::string sseq[3], bool rev, const std::string& rd, const std::vector<double>& lc,
+bool replay_side(const hipstr_batch_t* b, int locus, const std::string sseq[3], bool rev, const std::string& rd, const std::vector<double>& lc,
                  const std::string& ops, int size, int apos, int block, int base, TraceAcc& tr){
   const int MATCH = 0, DEL = 1, INS = 2, NONE = -1;
   const int n = rd.size();
@@ -549,7 +550,7 @@ bool replay_side(const hipstr_batch_t* b, const std::string sseq[3], bool rev, c
       seq -= blen + size;
     } else {
       int prev = NONE;
-      int32_t pos = side_block_start(b, rev, block) + (rev ? -base : base);
+      int32_t pos = side_block_start(b, locus, rev, block) + (rev ? -base : base);
       const int32_t inc = rev ? 1 : -1;
       int indel_seq = -1; int32_t indel_position = -1;
       std::string fs;
@@ -608,11 +609,20 @@ void stitch_dir(const char* hap_aln, int hlen, const std::string& read_aln, int 
 }
 
 bool put_pool(char* pool, int32_t* off, int idx, const std::string& s, int cap){
+  off[idx+1] = off[idx];
   if ((int64_t)off[idx] + (int64_t)s.size() > cap) return false;
   memcpy(pool + off[idx], s.data(), s.size());
   off[idx+1] = off[idx] + (int32_t)s.size();
   return true;
 }
+
+struct ReqOut {                    // one request's results, built by a worker thread, copied into the flat pools in order
+  bool ok = true;
+  std::string hap_aln, aln_str;
+  TraceAcc acc;
+  int32_t aln_start = 0, aln_stop = 0;
+  std::vector<std::pair<char,int32_t>> cigar;
+};
 
 }  // namespace
 
@@ -620,7 +630,7 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
                                 const char* const* hap_to_ref, hipstr_trace_out_t* o){
   using hipstr::api_fail;
   if (!b || !o || n_req < 0 || (n_req > 0 && (!req_read || !req_allele))) return api_fail("null argument");
-  if (b->n_loci != 1) return api_fail("hipstr_hmm_trace takes a one-locus batch");
+  if (b->n_loci < 1) return api_fail("hipstr_hmm_trace needs at least one locus");
   const bool timing = getenv("HIPSTR_TRACE_TIMING") != NULL;
   auto now = [](){ return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b){ return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -628,48 +638,54 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
   hipstr::ApiTables T;
   if (hipstr::api_device_tables(&T)) return 1;
   const hipstr::HostTables& HT = hipstr::host_tables();
-  const int period = b->period[0];
-  if (period < 1 || period > 9) return api_fail("STR period must be in [1,9] (stutter_model.h:38)");
-  std::vector<std::string> opt[3];
-  int32_t nopts[3];
-  int A = 1;
-  for (int k = 0, cur = 0; k < 3; k++){
-    nopts[k] = b->blk_nopts[k];
-    if (nopts[k] < 1) return api_fail("haplotype block without options");
-    for (int x = 0; x < nopts[k]; x++, cur++){
-      opt[k].push_back(std::string(b->seq + b->opt_off[cur], b->opt_off[cur+1]-b->opt_off[cur]));
-      if (opt[k].back().empty()) return api_fail(k == 1 ? "empty STR allele is not supported" : "empty flank sequence");
-      if (k == 1 && opt[k].back().size() > 1024) return api_fail("STR allele longer than 1024 bp is not supported");
+  const int n_loci = b->n_loci;
+  const int n_reads = b->read_off[n_loci];
+  std::vector<int32_t> opt_base(n_loci + 1, 0);           // first option (over all blocks) of every locus
+  for (int l = 0; l < n_loci; l++){
+    if (b->period[l] < 1 || b->period[l] > 9) return api_fail("STR period must be in [1,9] (stutter_model.h:38)");
+    int cnt = 0;
+    for (int k = 0; k < 3; k++){
+      if (b->blk_nopts[3*l+k] < 1) return api_fail("haplotype block without options");
+      cnt += b->blk_nopts[3*l+k];
     }
-    A *= nopts[k];
+    opt_base[l+1] = opt_base[l] + cnt;
   }
-  const int n_reads = b->read_off[1] - b->read_off[0];
   o->hap_aln_off[0] = o->str_seq_off[0] = o->flank_seq_off[0] = o->indel_off[0] = o->snp_off[0] = 0;
   o->cigar_off[0] = o->aln_str_off[0] = 0;
   if (n_req == 0) return 0;
 
-  // ---- per request: seed, allele rows (own homopolymer context), sizes
+  // ---- per request: locus, seed, allele rows (own homopolymer context), sizes
   hipstr::Prepared P;              // only its row / STR-option pools are used
   std::vector<hs_row_t> rows;
-  std::map<int, AllelePrep> alleles;
-  std::vector<int32_t> seeds(n_req);
+  std::map<int64_t, int> allele_slot;                    // (locus, allele) -> entry of `alleles`
+  std::vector<AllelePrep> alleles;
+  std::vector<int32_t> seeds(n_req), req_locus(n_req), req_ap(n_req);
   for (int q = 0; q < n_req; q++){
     const int r = req_read[q], k = req_allele[q];
-    if (r < 0 || r >= n_reads) return api_fail("request names a read outside the locus");
-    if (k < 0 || k >= A) return api_fail("request names an allele outside the locus");
-    const int s = hipstr::calc_seed_base(b, 0, r);
+    if (r < 0 || r >= n_reads) return api_fail("request names a read outside the batch");
+    const int l = (int)(std::upper_bound(b->read_off, b->read_off + n_loci + 1, r) - b->read_off) - 1;
+    const int32_t* nopts = b->blk_nopts + 3*l;
+    const int A = nopts[0]*nopts[1]*nopts[2];
+    if (k < 0 || k >= A) return api_fail("request names an allele outside its locus");
+    const int s = hipstr::calc_seed_base(b, l, r);
     if (s == -2) return api_fail("Invalid alignment seed or unrecognized CIGAR char (HapAligner.cpp:309,316)");
     if (s < 0) return api_fail("read without a seed base cannot be traced (HapAligner.cpp:586-594)");
     const int len = b->base_off[r+1] - b->base_off[r];
     if (s > HS_MAX_SIDE_LEN || len-s-1 > HS_MAX_SIDE_LEN) return api_fail("read side longer than 256 bases is not supported");
-    seeds[q] = s;
-    if (alleles.count(k)) continue;
+    seeds[q] = s; req_locus[q] = l;
+    const int64_t key = ((int64_t)l << 32) | (uint32_t)k;
+    std::map<int64_t, int>::iterator hit = allele_slot.find(key);
+    if (hit != allele_slot.end()){ req_ap[q] = hit->second; continue; }
     AllelePrep ap;
     int32_t oi[3];
     hipstr::allele_options(nopts, k, oi);
-    for (int x = 0; x < 3; x++){
-      ap.seq[0][x] = opt[x][oi[x]];
-      ap.seq[1][2-x] = std::string(opt[x][oi[x]].rbegin(), opt[x][oi[x]].rend());
+    for (int x = 0, cur = opt_base[l]; x < 3; cur += nopts[x], x++){
+      const int oidx = cur + oi[x];
+      const std::string sq(b->seq + b->opt_off[oidx], b->opt_off[oidx+1] - b->opt_off[oidx]);
+      if (sq.empty()) return api_fail(x == 1 ? "empty STR allele is not supported" : "empty flank sequence");
+      if (x == 1 && sq.size() > 1024) return api_fail("STR allele longer than 1024 bp is not supported");
+      ap.seq[0][x] = sq;
+      ap.seq[1][2-x] = std::string(sq.rbegin(), sq.rend());
     }
     if (ap.seq[0][0].size() + 1 + ap.seq[0][2].size() > 4095) return api_fail("flanks longer than 4094 bases in total are not supported");
     for (int sd = 0; sd < 2; sd++){
@@ -678,9 +694,10 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
       ap.lead_off[sd] = rows.size();  rows.insert(rows.end(), lead.begin(), lead.end());
       ap.trail_off[sd] = rows.size(); rows.insert(rows.end(), trail.begin(), trail.end());
       ap.stropt[sd] = P.stropts.size();
-      hipstr::append_stropt(ap.seq[sd][1], period, b->stutter, P);
+      hipstr::append_stropt(ap.seq[sd][1], b->period[l], b->stutter + 6*l, P);
     }
-    alleles[k] = ap;
+    req_ap[q] = allele_slot[key] = (int)alleles.size();
+    alleles.push_back(ap);
   }
 
   const auto t_prep = now();
@@ -708,7 +725,7 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
   std::vector<int64_t> need(n_req);
   for (int q = 0; q < n_req; q++){
     const int r = req_read[q];
-    const AllelePrep& ap = alleles[req_allele[q]];
+    const AllelePrep& ap = alleles[req_ap[q]];
     const int len = b->base_off[r+1] - b->base_off[r];
     need[q] = 0;
     for (int sd = 0; sd < 2; sd++){
@@ -719,24 +736,43 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
       S.lead_off = ap.lead_off[sd]; S.F0 = ap.seq[sd][0].size();
       S.trail_off = ap.trail_off[sd]; S.F2 = ap.seq[sd][2].size();
       S.stropt = ap.stropt[sd];
-      S.ops_cap = S.n + S.F0 + S.F2 + (int)ap.seq[sd][1].size() + 2*HS_MAXREP*period + 16;
+      S.ops_cap = S.n + S.F0 + S.F2 + (int)ap.seq[sd][1].size() + 2*HS_MAXREP*b->period[req_locus[q]] + 16;
       need[q] += 3*(int64_t)(S.F0 + 1 + S.F2)*S.n;
     }
     if (need[q] > budget) return api_fail("one traceback needs more workspace than the device offers");
   }
 
-  int rc = 0;
+  // workspaces are sized for the largest chunk once and reused
+  int64_t max_mat = 0, max_art = 0, max_ops = 0; int max_nq = 0;
+  {
+    int64_t mat = 0, art = 0, ops = 0; int nq = 0;
+    for (int q = 0; q < n_req; q++){
+      if (mat + need[q] > budget){ mat = art = ops = 0; nq = 0; }
+      mat += need[q]; art += 2*(int64_t)(sides[2*q].n + sides[2*q+1].n); ops += sides[2*q].ops_cap + sides[2*q+1].ops_cap; nq++;
+      max_mat = std::max(max_mat, mat); max_art = std::max(max_art, art); max_ops = std::max(max_ops, ops); max_nq = std::max(max_nq, nq);
+    }
+  }
+  if (max_art > 0x7fffffff || max_ops > 0x7fffffff) return api_fail("too many requests for one call; split the request list");
+  hs_tdev_t hc = h;
+  hs_tside_t* d_sides; int32_t* d_items; hs_tdev_t* d_args;
+  if (dev.alloc(&d_sides, 2*(size_t)max_nq) || dev.alloc(&d_items, 2*(size_t)max_nq) || dev.alloc(&d_args, 1)) return 1;
+  hc.sides = d_sides; hc.items = d_items;
+  if (dev.alloc(&hc.mats, max_mat) || dev.alloc(&hc.arts, max_art) || dev.alloc(&hc.ops, max_ops) || dev.alloc(&hc.side_prob, 2*(size_t)max_nq) ||
+      dev.alloc(&hc.ll, max_nq) || dev.alloc(&hc.max_index, max_nq) || dev.alloc(&hc.n_ops, 2*(size_t)max_nq) ||
+      dev.alloc(&hc.str_size, 2*(size_t)max_nq) || dev.alloc(&hc.str_pos, 2*(size_t)max_nq)) return 1;
+  TR_HIP(hipMemcpy(d_args, &hc, sizeof hc, hipMemcpyHostToDevice));
+
   const auto t_static = now();
   double ms_alloc = 0, ms_kernel = 0, ms_d2h = 0, ms_replay = 0;
-  for (int q0 = 0; q0 < n_req && rc == 0; ){
+  for (int q0 = 0; q0 < n_req; ){
     const auto c0 = now();
     int q1 = q0; int64_t mat = 0; int64_t n_art = 0, n_ops = 0;
     while (q1 < n_req && mat + need[q1] <= budget){
       for (int sd = 0; sd < 2; sd++){
         hs_tside_t& S = sides[2*q1+sd];
         S.mat_off = mat; mat += 3*(int64_t)(S.F0 + 1 + S.F2)*S.n;
-        S.art_off = n_art; n_art += 2*S.n;
-        S.ops_off = n_ops; n_ops += S.ops_cap;
+        S.art_off = (int32_t)n_art; n_art += 2*S.n;
+        S.ops_off = (int32_t)n_ops; n_ops += S.ops_cap;
       }
       q1++;
     }
@@ -748,16 +784,8 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
       for (int si = 2*q0; si < 2*q1; si++) if ((sides[si].n + 63)/64 == cl) items.push_back(si - 2*q0);
     }
     cls_begin[HS_MAX_COLS] = items.size();
-
-    DevBufs ws;
-    hs_tdev_t hc = h;
-    hs_tside_t* d_sides; int32_t* d_items; hs_tdev_t* d_args;
-    if (ws.put(&d_sides, sides.data() + 2*q0, 2*(size_t)nq) || ws.put(&d_items, items.data(), items.size())) return 1;
-    hc.sides = d_sides; hc.items = d_items;
-    if (ws.alloc(&hc.mats, mat) || ws.alloc(&hc.arts, n_art) || ws.alloc(&hc.ops, n_ops) || ws.alloc(&hc.side_prob, 2*(size_t)nq) ||
-        ws.alloc(&hc.ll, nq) || ws.alloc(&hc.max_index, nq) || ws.alloc(&hc.n_ops, 2*(size_t)nq) ||
-        ws.alloc(&hc.str_size, 2*(size_t)nq) || ws.alloc(&hc.str_pos, 2*(size_t)nq)) return 1;
-    if (ws.put(&d_args, &hc, 1)) return 1;
+    TR_HIP(hipMemcpy(d_sides, sides.data() + 2*q0, 2*(size_t)nq*sizeof(hs_tside_t), hipMemcpyHostToDevice));
+    TR_HIP(hipMemcpy(d_items, items.data(), items.size()*sizeof(int32_t), hipMemcpyHostToDevice));
     const auto c1 = now();
     for (int cl = 1; cl <= HS_MAX_COLS; cl++){
       const int cnt = cls_begin[cl] - cls_begin[cl-1];
@@ -781,68 +809,54 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
     TR_HIP(hipMemcpy(ssz.data(), hc.str_size, 2*(size_t)nq*sizeof(int32_t), hipMemcpyDeviceToHost));
     TR_HIP(hipMemcpy(spos.data(), hc.str_pos, 2*(size_t)nq*sizeof(int32_t), hipMemcpyDeviceToHost));
     TR_HIP(hipMemcpy(opsbuf.data(), hc.ops, n_ops, hipMemcpyDeviceToHost));
-
     const auto c3 = now();
-    // ---- replay + outputs (HapAligner.cpp:642-707)
-    for (int q = q0; q < q1; q++){
-      const int r = req_read[q], sb = seeds[q];
-      const AllelePrep& ap = alleles[req_allele[q]];
-      const int len = b->base_off[r+1] - b->base_off[r];
-      const char* bases = b->bases + b->base_off[r];
-      const char* quals = b->quals + b->base_off[r];
-      const int max_index = mxi[q-q0];
-      const int blen3[3] = { (int)ap.seq[0][0].size(), (int)ap.seq[0][1].size(), (int)ap.seq[0][2].size() };
-      const int H = blen3[0] + blen3[1] + blen3[2];
-      // left retrace, then the seed base joins the flank it sits in, then the right retrace (HapAligner.cpp:642-684)
-      TraceAcc acc;
-      std::string side_ops[2];
-      int seed_block = 0;
-      for (int x = 0, crd = max_index; x < 3; x++){ if (crd < blen3[x]){ seed_block = x; break; } crd -= blen3[x]; }
-      for (int sd = 0; sd < 2; sd++){
-        const hs_tside_t& S = sides[2*q+sd];
-        const int cnt = nops[2*(q-q0)+sd];
-        if (cnt > S.ops_cap) return api_fail("internal error: traceback operation buffer overflow");
-        side_ops[sd].assign(opsbuf.data() + S.ops_off, cnt);
-        if (sd == 1 && seed_block != 1) acc.flank[seed_block].push_back(bases[sb]);
-        const int mx = sd ? H-1-max_index : max_index;
-        if (mx == 0) continue;                         // this side is all soft clips
-        std::string rd(S.n, ' '); std::vector<double> lc(S.n);
-        for (int j = 0; j < S.n; j++){
-          const int src = sd ? len-1-j : j;
-          rd[j] = bases[src]; lc[j] = HT.qual_correct[(uint8_t)quals[src]];
-        }
-        int blk = 0, crd = mx;
-        for (int x = 0; x < 3; x++){ const int bl = ap.seq[sd][x].size(); if (crd < bl){ blk = x; break; } crd -= bl; }
-        int block, base;
-        if (crd == 0){ block = blk-1; base = (int)ap.seq[sd][block].size()-1; } else { block = blk; base = crd-1; }
-        if (!replay_side(b, ap.seq[sd], sd != 0, rd, lc, side_ops[sd], ssz[2*(q-q0)+sd], spos[2*(q-q0)+sd], block, base, acc))
-          return api_fail("internal error: inconsistent traceback operation string");
-      }
-      o->ll[q] = ll[q-q0]; o->max_index[q] = max_index;
-      std::string full(side_ops[0].rbegin(), side_ops[0].rend());
-      full.push_back('M');
-      full += side_ops[1];
-      bool ok = put_pool(o->hap_aln, o->hap_aln_off, q, full, o->cap_chars);
-      o->stutter_size[q] = acc.str_set ? acc.stutter_size : HIPSTR_NO_STR_DATA;
-      ok = put_pool(o->str_seq, o->str_seq_off, q, acc.str_set ? acc.str_seq : std::string(), o->cap_chars) && ok;
-      ok = put_pool(o->flank_seq, o->flank_seq_off, 2*q, acc.flank[0], o->cap_chars) && ok;
-      ok = put_pool(o->flank_seq, o->flank_seq_off, 2*q+1, acc.flank[2], o->cap_chars) && ok;
-      o->flank_ins[q] = acc.flank_ins; o->flank_del[q] = acc.flank_del;
-      int io = o->indel_off[q];
-      if ((int64_t)io + (int64_t)acc.indels.size() > o->cap_chars) ok = false;
-      else for (size_t i = 0; i < acc.indels.size(); i++, io++){ o->indel_pos[io] = acc.indels[i].first; o->indel_size[io] = acc.indels[i].second; }
-      o->indel_off[q+1] = io;
-      int so = o->snp_off[q];
-      if ((int64_t)so + (int64_t)acc.snps.size() > o->cap_chars) ok = false;
-      else for (size_t i = 0; i < acc.snps.size(); i++, so++){ o->snp_pos[so] = acc.snps[i].first; o->snp_base[so] = acc.snps[i].second; }
-      o->snp_off[q+1] = so;
 
-      // ---- stitch_alignment_trace (AlignmentTraceback.cpp:55-144)
-      o->cigar_off[q+1] = o->cigar_off[q]; o->aln_str_off[q+1] = o->aln_str_off[q]; o->aln_start[q] = o->aln_stop[q] = 0;
-      if (hap_to_ref != NULL && ok){
-        const char* h2r = hap_to_ref[req_allele[q]];
+    // ---- replay (HapAligner.cpp:642-707) + stitch, request by request; independent, so spread over host threads
+    std::vector<ReqOut> res(nq);
+    auto work = [&](int qa, int qb){
+      for (int q = qa; q < qb; q++){
+        ReqOut& R = res[q-q0];
+        const int r = req_read[q], sb = seeds[q], l = req_locus[q];
+        const AllelePrep& ap = alleles[req_ap[q]];
+        const int len = b->base_off[r+1] - b->base_off[r];
+        const char* bases = b->bases + b->base_off[r];
+        const char* quals = b->quals + b->base_off[r];
+        const int max_index = mxi[q-q0];
+        const int blen3[3] = { (int)ap.seq[0][0].size(), (int)ap.seq[0][1].size(), (int)ap.seq[0][2].size() };
+        const int H = blen3[0] + blen3[1] + blen3[2];
+        // left retrace, then the seed base joins the flank it sits in, then the right retrace (HapAligner.cpp:642-684)
+        std::string side_ops[2];
+        int seed_block = 0;
+        for (int x = 0, crd = max_index; x < 3; x++){ if (crd < blen3[x]){ seed_block = x; break; } crd -= blen3[x]; }
+        for (int sd = 0; sd < 2 && R.ok; sd++){
+          const hs_tside_t& S = sides[2*q+sd];
+          const int cnt = nops[2*(q-q0)+sd];
+          if (cnt > S.ops_cap){ R.ok = false; break; }
+          side_ops[sd].assign(opsbuf.data() + S.ops_off, cnt);
+          if (sd == 1 && seed_block != 1) R.acc.flank[seed_block].push_back(bases[sb]);
+          const int mx = sd ? H-1-max_index : max_index;
+          if (mx == 0) continue;                         // this side is all soft clips
+          std::string rd(S.n, ' '); std::vector<double> lc(S.n);
+          for (int j = 0; j < S.n; j++){
+            const int src = sd ? len-1-j : j;
+            rd[j] = bases[src]; lc[j] = HT.qual_correct[(uint8_t)quals[src]];
+          }
+          int blk = 0, crd = mx;
+          for (int x = 0; x < 3; x++){ const int bl = ap.seq[sd][x].size(); if (crd < bl){ blk = x; break; } crd -= bl; }
+          int block, base;
+          if (crd == 0){ block = blk-1; base = (int)ap.seq[sd][block].size()-1; } else { block = blk; base = crd-1; }
+          if (!replay_side(b, l, ap.seq[sd], sd != 0, rd, lc, side_ops[sd], ssz[2*(q-q0)+sd], spos[2*(q-q0)+sd], block, base, R.acc)) R.ok = false;
+        }
+        if (!R.ok) continue;
+        R.hap_aln.assign(side_ops[0].rbegin(), side_ops[0].rend());
+        R.hap_aln.push_back('M');
+        R.hap_aln += side_ops[1];
+        if (hap_to_ref == NULL) continue;
+        // ---- stitch_alignment_trace (AlignmentTraceback.cpp:55-144)
+        const std::string& full = R.hap_aln;
+        const char* h2r = hap_to_ref[b->hap_off[l] + req_allele[q]];
         const int hlen = (int)strlen(h2r);
-        int hap_index = max_index, hai = 0; int32_t seed_pos = b->blk_start[0];
+        int hap_index = max_index, hai = 0; int32_t seed_pos = b->blk_start[3*l];
         while (hap_index > 0 && hai < hlen){
           if (h2r[hai] == 'M' || h2r[hai] == 'I') hap_index--;
           if (h2r[hai] == 'M' || h2r[hai] == 'D') seed_pos++;
@@ -864,24 +878,62 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
         int32_t start = seed_pos, stop = seed_pos;
         for (char ch : la) if (ch == 'D' || ch == 'M') start--;
         for (char ch : ra) if (ch == 'D' || ch == 'M') stop++;
-        o->aln_start[q] = start; o->aln_stop[q] = stop;
-        int co = o->cigar_off[q]; char cc = fa[0]; int num = 1;
+        R.aln_start = start; R.aln_stop = stop;
+        char cc = fa[0]; int num = 1;
         for (size_t i = 1; i <= fa.size(); i++){
           if (i == fa.size() || fa[i] != cc){
-            if (co < o->cap_chars){ o->cigar_op[co] = cc; o->cigar_len[co] = num; co++; } else ok = false;
+            R.cigar.push_back(std::make_pair(cc, (int32_t)num));
             if (i < fa.size()){ cc = fa[i]; num = 1; }
           } else num++;
         }
-        o->cigar_off[q+1] = co;
-        std::string as;
         int ri = 0;
         for (char ch : fa){
           if (ch == 'S') ri++;
-          else if (ch == 'M' || ch == 'I') as.push_back(bases[ri++]);
-          else as.push_back('-');
+          else if (ch == 'M' || ch == 'I') R.aln_str.push_back(bases[ri++]);
+          else R.aln_str.push_back('-');
         }
-        ok = put_pool(o->aln_str, o->aln_str_off, q, as, o->cap_chars) && ok;
       }
+    };
+    {
+      int nthreads = 1;
+      if (nq >= 512){
+        nthreads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+        if (const char* e = getenv("HIPSTR_TRACE_THREADS")) nthreads = std::max(1, atoi(e));
+        nthreads = std::min(nthreads, nq / 128);
+      }
+      if (nthreads <= 1) work(q0, q1);
+      else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; t++)
+          pool.push_back(std::thread(work, q0 + (int)((int64_t)nq*t/nthreads), q0 + (int)((int64_t)nq*(t+1)/nthreads)));
+        for (std::thread& th : pool) th.join();
+      }
+    }
+    // ---- copy into the caller's flat pools, in request order
+    for (int q = q0; q < q1; q++){
+      const ReqOut& R = res[q-q0];
+      if (!R.ok) return api_fail("internal error: inconsistent traceback operation string");
+      o->ll[q] = ll[q-q0]; o->max_index[q] = mxi[q-q0];
+      bool ok = put_pool(o->hap_aln, o->hap_aln_off, q, R.hap_aln, o->cap_chars);
+      o->stutter_size[q] = R.acc.str_set ? R.acc.stutter_size : HIPSTR_NO_STR_DATA;
+      ok = put_pool(o->str_seq, o->str_seq_off, q, R.acc.str_set ? R.acc.str_seq : std::string(), o->cap_chars) && ok;
+      ok = put_pool(o->flank_seq, o->flank_seq_off, 2*q, R.acc.flank[0], o->cap_chars) && ok;
+      ok = put_pool(o->flank_seq, o->flank_seq_off, 2*q+1, R.acc.flank[2], o->cap_chars) && ok;
+      o->flank_ins[q] = R.acc.flank_ins; o->flank_del[q] = R.acc.flank_del;
+      int io = o->indel_off[q];
+      if ((int64_t)io + (int64_t)R.acc.indels.size() > o->cap_chars) ok = false;
+      else for (size_t i = 0; i < R.acc.indels.size(); i++, io++){ o->indel_pos[io] = R.acc.indels[i].first; o->indel_size[io] = R.acc.indels[i].second; }
+      o->indel_off[q+1] = io;
+      int so = o->snp_off[q];
+      if ((int64_t)so + (int64_t)R.acc.snps.size() > o->cap_chars) ok = false;
+      else for (size_t i = 0; i < R.acc.snps.size(); i++, so++){ o->snp_pos[so] = R.acc.snps[i].first; o->snp_base[so] = R.acc.snps[i].second; }
+      o->snp_off[q+1] = so;
+      o->aln_start[q] = R.aln_start; o->aln_stop[q] = R.aln_stop;
+      int co = o->cigar_off[q];
+      if ((int64_t)co + (int64_t)R.cigar.size() > o->cap_chars) ok = false;
+      else for (size_t i = 0; i < R.cigar.size(); i++, co++){ o->cigar_op[co] = R.cigar[i].first; o->cigar_len[co] = R.cigar[i].second; }
+      o->cigar_off[q+1] = co;
+      ok = put_pool(o->aln_str, o->aln_str_off, q, R.aln_str, o->cap_chars) && ok;
       if (!ok) return api_fail("hipstr_trace_out_t pools are too small (cap_chars)");
     }
     q0 = q1;
@@ -889,7 +941,7 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
     ms_alloc += ms(c0, c1); ms_kernel += ms(c1, c2); ms_d2h += ms(c2, c3); ms_replay += ms(c3, c4);
   }
   if (timing)
-    fprintf(stderr, "hipstr_hmm_trace: %d requests; prep %.3f ms, static upload %.3f, chunk alloc+upload %.3f, kernels %.3f, d2h %.3f, replay %.3f, total %.3f\n",
+    fprintf(stderr, "hipstr_hmm_trace: %d requests; prep %.3f ms, static upload+alloc %.3f, chunk upload %.3f, kernels %.3f, d2h %.3f, replay %.3f, total %.3f\n",
             n_req, ms(t_begin, t_prep), ms(t_prep, t_static), ms_alloc, ms_kernel, ms_d2h, ms_replay, ms(t_begin, now()));
-  return rc;
+  return 0;
 }

@@ -193,7 +193,9 @@ void hipstr_post_free(hipstr_post_dev_t* pd);
  * fixed haplotype: full M/I/D matrices of both sides, arg-max seed position (compute_aln_logprob's max_index,
  * HapAligner.cpp:184-222), HapAligner::retrace (HapAligner.cpp:363-571) with its 0.001-nat tie tolerances, and — when the
  * caller supplies the haplotype-to-reference alignment strings (Haplotype::get_aln_info) — stitch_alignment_trace
- * (AlignmentTraceback.cpp:55-144).  One request = (read, allele) of a ONE-locus batch; the read must have a seed.
+ * (AlignmentTraceback.cpp:55-144).  One request = (read, allele): req_read indexes the reads of the whole batch (which fixes
+ * the locus), req_allele the haplotypes of that locus; the read must have a seed.  Requests of many loci go in one call —
+ * that is what fills the device (one locus alone offers only ~2 wavefronts per request).
  * Everything an AlignmentTrace holds (AlignmentTraceback.h:10-108) comes back flattened; all arrays are caller-allocated,
  * string pools are filled back to back with *_off[] giving the start of each request's piece ([n_req+1] entries).
  */
@@ -227,9 +229,9 @@ typedef struct hipstr_trace_out {
   int32_t  cap_chars;      /* capacity of every char pool / pair pool above (per pool)                                */
 } hipstr_trace_out_t;
 
-/* hap_to_ref: NULL, or for every allele k of the locus the NUL-terminated Haplotype::get_aln_info() string
- * ('M','I','D' of the haplotype against the reference haplotype), [num_combs] pointers. */
-int hipstr_hmm_trace(const hipstr_batch_t* one_locus, int32_t n_req, const int32_t* req_read, const int32_t* req_allele,
+/* hap_to_ref: NULL, or for every haplotype of every locus the NUL-terminated Haplotype::get_aln_info() string ('M','I','D' of
+ * the haplotype against the reference haplotype): hap_to_ref[hap_off[locus] + k], [hap_off[n_loci]] pointers. */
+int hipstr_hmm_trace(const hipstr_batch_t* batch, int32_t n_req, const int32_t* req_read, const int32_t* req_allele,
                      const char* const* hap_to_ref, hipstr_trace_out_t* out);
 
 /* Diagnostics (host only, no device): the haplotype rows of allele k of a ONE-locus batch as the

@@ -91,10 +91,31 @@ def test_hap_aln_consumes_exactly_the_read(hmm, oracle):
         assert len(g["flank_left"]) + len(g["flank_right"]) + len(g["str_seq"]) + g["hap_aln"].count("S") == base_off[r + 1] - base_off[r]
 
 
+def test_trace_requests_of_many_loci_in_one_call(hmm, oracle):
+    """req_read indexes the whole batch; every locus is checked against the (one-locus) oracle on its own cut."""
+    from hipstr_amd import shard
+    sb = capi.SynthBatch(n_loci=5, reads_per_locus=30, n_str_alleles=6, n_flank_opts=2, seed=71)
+    whole = util.synth_to_batch(sb)
+    a = whole.arrays
+    _, seeds = capi.run_align(oracle, "oracle_", sb.ptr)
+    rng = np.random.default_rng(71)
+    rr, aa, want, h2r_all = [], [], [], []
+    for l in range(5):
+        r0, r1 = int(a["read_off"][l]), int(a["read_off"][l + 1])
+        A = int(a["hap_off"][l + 1] - a["hap_off"][l])
+        one = shard.batch_from_arrays(shard.subset_arrays(a, l, l + 1))
+        h2r = util.synthetic_hap_to_ref(oracle, one.ptr)
+        h2r_all += h2r
+        lr = [r for r in range(r0, r1) if seeds[r] >= 0]
+        la = [int(rng.integers(A)) for _ in lr]
+        want += capi.run_trace(oracle, "oracle_", one.ptr, [r - r0 for r in lr], la, h2r, cap=1 << 20)
+        rr += lr; aa += la
+    order = rng.permutation(len(rr))                 # requests need not be grouped by locus
+    got = capi.run_trace(hmm, "hipstr_hmm_", whole.ptr, [rr[i] for i in order], [aa[i] for i in order], h2r_all, cap=1 << 21)
+    util.assert_traces_equal(got, [want[i] for i in order])
+
+
 def test_trace_errors(hmm, oracle):
-    sb2 = capi.SynthBatch(n_loci=2, reads_per_locus=4, n_str_alleles=2, seed=61)
-    with pytest.raises(RuntimeError, match="one-locus"):
-        capi.run_trace(hmm, "hipstr_hmm_", sb2.ptr, [0], [0], None)
     sb = capi.SynthBatch(n_loci=1, reads_per_locus=4, n_str_alleles=2, seed=62)
     with pytest.raises(RuntimeError, match="allele outside"):
         capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, [0], [99], None)
