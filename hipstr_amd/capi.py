@@ -42,6 +42,69 @@ class HipstrPostBatch(C.Structure):
     ]
 
 
+class HipstrGtRequest(C.Structure):
+    _fields_ = [("n_variants", _i32p), ("hap_to_allele", _i32p), ("calc_gls", C.c_int32), ("calc_pls", C.c_int32), ("calc_phased_gls", C.c_int32)]
+
+
+class HipstrGtOut(C.Structure):
+    _fields_ = [("best_hap", _i32p), ("best_gt", _i32p), ("log_phased_post", _f64p), ("log_unphased_post", _f64p),
+                ("hap_log_phased_post", _f64p), ("hap_log_unphased_post", _f64p), ("gl_diff", _f64p), ("gls", _f64p), ("pls", _i32p),
+                ("phased_gls", _f64p)]
+
+
+def run_gt_extract(lib, prefix, pb, n_variants, hap_to_allele, calc_gls=True, calc_pls=True, calc_phased_gls=True):
+    """Genotype calls of a PostBatch: <prefix>gt_extract(pb, request, out) for the oracle / reference probe (which compute
+    the posteriors themselves), hipstr_post_upload + launch + hipstr_post_extract for the product.  Returns a dict of arrays;
+    gls / pls / phased_gls are lists with one array per sample."""
+    nl = pb.struct.n_loci
+    S = int(pb.samp_off[-1])
+    nv = np.ascontiguousarray(np.asarray(n_variants, np.int32)); h2a = np.ascontiguousarray(np.asarray(hap_to_allele, np.int32))
+    rq = HipstrGtRequest(nv.ctypes.data_as(_i32p), h2a.ctypes.data_as(_i32p), int(calc_gls), int(calc_pls), int(calc_phased_gls))
+    hap = pb.a["haploid"] if pb.a["haploid"] is not None else np.zeros(nl, np.uint8)
+    gl_off = [0]; pgl_off = [0]
+    for l in range(nl):
+        V = int(nv[l])
+        for _ in range(int(pb.a["n_samples"][l])):
+            gl_off.append(gl_off[-1] + (V if hap[l] else V * (V + 1) // 2)); pgl_off.append(pgl_off[-1] + (V if hap[l] else V * V))
+    k = dict(best_hap=np.zeros(max(2 * S, 2), np.int32), best_gt=np.zeros(max(2 * S, 2), np.int32))
+    for nm in ("log_phased_post", "log_unphased_post", "hap_log_phased_post", "hap_log_unphased_post", "gl_diff"):
+        k[nm] = np.zeros(max(S, 1))
+    k["gls"] = np.zeros(max(gl_off[-1], 1)); k["pls"] = np.zeros(max(gl_off[-1], 1), np.int32); k["phased_gls"] = np.zeros(max(pgl_off[-1], 1))
+    o = HipstrGtOut(*[k[f].ctypes.data_as(t) for f, t in HipstrGtOut._fields_])
+    if prefix == "hipstr_":
+        lib.hipstr_post_extract.restype = C.c_int; lib.hipstr_post_extract.argtypes = [C.c_void_p, C.POINTER(HipstrGtRequest), C.POINTER(HipstrGtOut)]
+        lib.hipstr_gt_offsets.restype = C.c_int
+        lib.hipstr_gt_offsets.argtypes = [C.POINTER(HipstrPostBatch), C.POINTER(HipstrGtRequest), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        go = np.zeros(S + 1, np.int64); pgo = np.zeros(S + 1, np.int64)
+        i64p = C.POINTER(C.c_int64)
+        assert lib.hipstr_gt_offsets(pb.ptr, C.byref(rq), go.ctypes.data_as(i64p), pgo.ctypes.data_as(i64p)) == 0
+        assert list(go) == gl_off and list(pgo) == pgl_off
+        pd = lib.hipstr_post_upload(pb.ptr, None)
+        if not pd:
+            raise RuntimeError("hipstr_post_upload failed: " + lib.hipstr_last_error().decode())
+        try:
+            rc = lib.hipstr_post_launch(pd, None)
+            if rc == 0:
+                rc = lib.hipstr_post_extract(pd, C.byref(rq), C.byref(o))
+        finally:
+            lib.hipstr_post_free(pd)
+        if rc != 0:
+            raise RuntimeError("hipstr_post_extract failed: " + lib.hipstr_last_error().decode())
+    else:
+        fn = getattr(lib, prefix + "gt_extract")
+        fn.restype = C.c_int; fn.argtypes = [C.POINTER(HipstrPostBatch), C.POINTER(HipstrGtRequest), C.POINTER(HipstrGtOut)]
+        rc = fn(pb.ptr, C.byref(rq), C.byref(o))
+        if rc != 0:
+            raise RuntimeError("%sgt_extract failed rc=%d" % (prefix, rc))
+    out = dict(best_hap=k["best_hap"][:2 * S].reshape(-1, 2), best_gt=k["best_gt"][:2 * S].reshape(-1, 2))
+    for nm in ("log_phased_post", "log_unphased_post", "hap_log_phased_post", "hap_log_unphased_post", "gl_diff"):
+        out[nm] = k[nm][:S]
+    out["gls"] = [k["gls"][gl_off[s]:gl_off[s + 1]] for s in range(S)]
+    out["pls"] = [k["pls"][gl_off[s]:gl_off[s + 1]] for s in range(S)]
+    out["phased_gls"] = [k["phased_gls"][pgl_off[s]:pgl_off[s + 1]] for s in range(S)]
+    return out
+
+
 class HipstrTraceOut(C.Structure):
     _fields_ = [("ll", _f64p), ("max_index", _i32p), ("hap_aln_off", _i32p), ("hap_aln", C.c_char_p), ("stutter_size", _i32p),
                 ("str_seq_off", _i32p), ("str_seq", C.c_char_p), ("flank_seq_off", _i32p), ("flank_seq", C.c_char_p),

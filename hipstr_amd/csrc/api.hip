@@ -23,6 +23,7 @@
 extern "C" __global__ void hs_str_kernel(const hs_dev_t* dp, int active_begin);
 extern "C" __global__ void hs_combine_kernel(const hs_dev_t* dp, int active_begin);
 extern "C" __global__ void hs_posterior_kernel(const hs_post_dev_t* dp);
+extern "C" __global__ void hs_genotype_kernel(const hs_gt_dev_t* dp);
 extern "C" size_t hs_str_lds_bytes(int lds_len, int max_B);
 extern "C" void hs_launch_lead(int cls, unsigned gx, hipStream_t st, const hs_dev_t* dp, int item_begin);
 extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end);
@@ -451,7 +452,7 @@ int post_setup(const hipstr_post_batch_t* pb, const double* dev_ll, PostRun& R){
 }
 }  // namespace
 
-struct hipstr_post_dev { PostRun R; std::vector<int32_t> n_samples; };
+struct hipstr_post_dev { PostRun R; std::vector<int32_t> n_samples, n_alleles; std::vector<uint8_t> haploid; };
 
 hipstr_post_dev_t* hipstr_post_upload(const hipstr_post_batch_t* pb, const double* dev_log_aln_probs){
   if (!pb){ g_err = "null argument"; return NULL; }
@@ -459,6 +460,9 @@ hipstr_post_dev_t* hipstr_post_upload(const hipstr_post_batch_t* pb, const doubl
   hipstr_post_dev_t* pd = new hipstr_post_dev_t();
   if (post_setup(pb, dev_log_aln_probs, pd->R)){ delete pd; return NULL; }
   pd->n_samples.assign(pb->n_samples, pb->n_samples + pb->n_loci);
+  pd->n_alleles.assign(pb->n_alleles, pb->n_alleles + pb->n_loci);
+  pd->haploid.assign(pb->n_loci, 0);
+  if (pb->haploid) pd->haploid.assign(pb->haploid, pb->haploid + pb->n_loci);
   return pd;
 }
 
@@ -491,6 +495,100 @@ int hipstr_post_fetch(hipstr_post_dev_t* pd, double* log_post, double* sample_to
 }
 
 void hipstr_post_free(hipstr_post_dev_t* pd){ delete pd; }
+
+int hipstr_gt_offsets(const hipstr_post_batch_t* pb, const hipstr_gt_request_t* rq, int64_t* gl_off, int64_t* pgl_off){
+  if (!pb || !rq || !gl_off || !pgl_off) return fail("null argument");
+  int64_t g = 0, pg = 0, so = 0;
+  for (int l = 0; l < pb->n_loci; l++){
+    const int64_t V = rq->n_variants[l];
+    const bool hap = pb->haploid && pb->haploid[l];
+    for (int s = 0; s < pb->n_samples[l]; s++, so++){
+      gl_off[so] = g; pgl_off[so] = pg;
+      g += hap ? V : V*(V+1)/2; pg += hap ? V : V*V;
+    }
+  }
+  gl_off[so] = g; pgl_off[so] = pg;
+  return 0;
+}
+
+int hipstr_post_extract(hipstr_post_dev_t* pd, const hipstr_gt_request_t* rq, hipstr_gt_out_t* out){
+  if (!pd || !rq || !out || !rq->n_variants || !rq->hap_to_allele) return fail("null argument");
+  if (!out->best_hap || !out->best_gt || !out->log_phased_post || !out->log_unphased_post || !out->hap_log_phased_post || !out->hap_log_unphased_post)
+    return fail("null output array");
+  const bool any = rq->calc_gls || rq->calc_pls || rq->calc_phased_gls;
+  if (any && !out->gl_diff) return fail("gl_diff output missing");
+  if ((rq->calc_gls && !out->gls) || (rq->calc_pls && !out->pls) || (rq->calc_phased_gls && !out->phased_gls)) return fail("requested output array missing");
+  PostRun& R = pd->R;
+  const hipstr::HostTables& T = hipstr::host_tables();
+  const size_t n_loci = pd->n_samples.size();
+  std::vector<hs_gt_unit_t> units;
+  std::vector<int32_t> gmem, goff;
+  int64_t po = 0, tot = 0, g = 0, pg = 0; int so = 0, map_off = 0;
+  for (size_t l = 0; l < n_loci; l++){
+    const int A = pd->n_alleles[l], S = pd->n_samples[l], V = rq->n_variants[l];
+    const bool hap = pd->haploid[l] != 0;
+    if (V < 1 || V > A) return fail("n_variants must be in [1, n_alleles]");
+    const int32_t* h2a = rq->hap_to_allele + map_off;
+    std::vector<int> count(V, 0);
+    for (int a = 0; a < A; a++){ if (h2a[a] < 0 || h2a[a] >= V) return fail("hap_to_allele entry out of range"); count[h2a[a]]++; }
+    const int goff_off = (int)goff.size();
+    int run = 0;
+    for (int v = 0; v < V; v++){ if (count[v] == 0) return fail("every variant must be carried by a haplotype"); goff.push_back(run); run += count[v]; }
+    goff.push_back(run);
+    for (int v = 0; v < V; v++) for (int a = 0; a < A; a++) if (h2a[a] == v) gmem.push_back(a);
+    const double hom = hap ? -T.int_log[A] : T.int_log[2] - T.int_log[A] - T.int_log[A+1];
+    const double het = hap ? 0.0 : -T.int_log[A] - T.int_log[A+1];                           // genotyper.cpp:198
+    const double gl_ncfg  = hap ? T.int_log[2] + T.int_log[A] - T.int_log[V] : T.int_log[2] + 2*(T.int_log[A] - T.int_log[V]);
+    const double pgl_ncfg = hap ? T.int_log[A] - T.int_log[V] : 2*(T.int_log[A] - T.int_log[V]);
+    for (int s = 0; s < S; s++, so++){
+      hs_gt_unit_t u; memset(&u, 0, sizeof u);
+      u.post_off = po + (int64_t)s*A*A; u.tot_off = tot; tot += (int64_t)V*V;
+      u.gl_off = g; u.pgl_off = pg; g += hap ? V : (int64_t)V*(V+1)/2; pg += hap ? V : (int64_t)V*V;
+      u.n_alleles = A; u.n_variants = V; u.samp_index = so; u.haploid = hap ? 1 : 0;
+      u.map_off = map_off; u.goff_off = goff_off;
+      u.hom_corr = hom; u.het_corr = het; u.gl_ncfg = gl_ncfg; u.pgl_ncfg = pgl_ncfg;
+      units.push_back(u);
+    }
+    po += (int64_t)S*A*A; map_off += A;
+  }
+  if (units.empty()) return 0;
+  std::vector<void*> tmp;
+  struct Free { std::vector<void*>& v; ~Free(){ for (void* p : v) hipFree(p); } } guard{tmp};
+  auto dalloc = [&](size_t bytes, void** outp) -> int { *outp = NULL; HS_HIP(hipMalloc(outp, bytes ? bytes : 1)); tmp.push_back(*outp); return 0; };
+  hs_gt_dev_t h; memset(&h, 0, sizeof h);
+  void* p;
+  if (dalloc(units.size()*sizeof(hs_gt_unit_t), &p)) return 1; HS_HIP(hipMemcpy(p, units.data(), units.size()*sizeof(hs_gt_unit_t), hipMemcpyHostToDevice)); h.units = (const hs_gt_unit_t*)p;
+  if (dalloc((size_t)map_off*4, &p)) return 1; HS_HIP(hipMemcpy(p, rq->hap_to_allele, (size_t)map_off*4, hipMemcpyHostToDevice)); h.h2a = (const int32_t*)p;
+  if (dalloc(gmem.size()*4, &p)) return 1; HS_HIP(hipMemcpy(p, gmem.data(), gmem.size()*4, hipMemcpyHostToDevice)); h.gmem = (const int32_t*)p;
+  if (dalloc(goff.size()*4, &p)) return 1; HS_HIP(hipMemcpy(p, goff.data(), goff.size()*4, hipMemcpyHostToDevice)); h.goff = (const int32_t*)p;
+  h.log_post = R.h.log_post; h.sample_total = R.h.sample_total; h.map_gt = R.h.map_gt;
+  if (dalloc((size_t)tot*8, &p)) return 1; h.tot = (double*)p;
+  if (dalloc((size_t)so*2*4, &p)) return 1; h.best_gt = (int32_t*)p;
+  double* five = NULL;
+  if (dalloc((size_t)so*5*8, &p)) return 1; five = (double*)p;
+  h.log_phased = five; h.log_unphased = five + so; h.hap_log_phased = five + 2*(size_t)so; h.hap_log_unphased = five + 3*(size_t)so; h.gl_diff = five + 4*(size_t)so;
+  if (any){ if (dalloc((size_t)g*8, &p)) return 1; h.gls = (double*)p; }
+  if (rq->calc_pls){ if (dalloc((size_t)g*4, &p)) return 1; h.pls = (int32_t*)p; }
+  if (rq->calc_phased_gls){ if (dalloc((size_t)pg*8, &p)) return 1; h.pgls = (double*)p; }
+  h.calc_any = any; h.calc_gls = rq->calc_gls; h.calc_pls = rq->calc_pls; h.calc_pgls = rq->calc_phased_gls;
+  h.log_thresh = T.log_thresh;
+  if (dalloc(sizeof h, &p)) return 1; HS_HIP(hipMemcpy(p, &h, sizeof h, hipMemcpyHostToDevice));
+  HS_HIP(hipDeviceSynchronize());          // the posterior kernel may still be running on another stream
+  hipLaunchKernelGGL(hs_genotype_kernel, dim3((unsigned)units.size()), dim3(256), 0, g_tab.stream, (const hs_gt_dev_t*)p);
+  HS_HIP(hipGetLastError());
+  HS_HIP(hipStreamSynchronize(g_tab.stream));
+  HS_HIP(hipMemcpy(out->best_hap, R.h.map_gt, (size_t)so*2*4, hipMemcpyDeviceToHost));
+  HS_HIP(hipMemcpy(out->best_gt, h.best_gt, (size_t)so*2*4, hipMemcpyDeviceToHost));
+  HS_HIP(hipMemcpy(out->log_phased_post, h.log_phased, (size_t)so*8, hipMemcpyDeviceToHost));
+  HS_HIP(hipMemcpy(out->log_unphased_post, h.log_unphased, (size_t)so*8, hipMemcpyDeviceToHost));
+  HS_HIP(hipMemcpy(out->hap_log_phased_post, h.hap_log_phased, (size_t)so*8, hipMemcpyDeviceToHost));
+  HS_HIP(hipMemcpy(out->hap_log_unphased_post, h.hap_log_unphased, (size_t)so*8, hipMemcpyDeviceToHost));
+  if (any) HS_HIP(hipMemcpy(out->gl_diff, h.gl_diff, (size_t)so*8, hipMemcpyDeviceToHost));
+  if (rq->calc_gls) HS_HIP(hipMemcpy(out->gls, h.gls, (size_t)g*8, hipMemcpyDeviceToHost));
+  if (rq->calc_pls) HS_HIP(hipMemcpy(out->pls, h.pls, (size_t)g*4, hipMemcpyDeviceToHost));
+  if (rq->calc_phased_gls) HS_HIP(hipMemcpy(out->phased_gls, h.pgls, (size_t)pg*8, hipMemcpyDeviceToHost));
+  return 0;
+}
 
 int hipstr_post_run(const hipstr_post_batch_t* pb, const double* dev_log_aln_probs,
                     double* log_post, double* sample_total_ll, int32_t* map_gt, double* locus_total_ll){

@@ -96,3 +96,95 @@ hs_posterior_kernel(const hs_post_dev_t* __restrict__ dp){
     d.map_gt[2*u.samp_index+1] = red_i[0] % A;
   }
 }
+
+
+// Genotyper::extract_genotypes_and_likelihoods (genotyper.cpp:129-251), calc_PLs (99-104), calc_gl_diff (106-127).
+// One workgroup per (locus, sample).  A thread owns genotypes (v1, v2) and streams over the haplotype pairs that map to
+// them in the reference's scan order (index_1 ascending, then index_2), so update_streaming_log_sum_exp (mathops.cpp:72-80)
+// sees the same sequence; device exp/log differ from the host libm in the last bits (tolerance in tests/test_genotypes_gpu.py).
+extern "C" __global__ void __launch_bounds__(256)
+hs_genotype_kernel(const hs_gt_dev_t* __restrict__ dp){
+  const hs_gt_dev_t& d = *dp;
+  const hs_gt_unit_t u = d.units[blockIdx.x];
+  const int A = u.n_alleles, V = u.n_variants, tid = threadIdx.x;
+  const double* post = d.log_post + u.post_off;
+  double* T = d.tot + u.tot_off;
+  const int32_t* h2a = d.h2a + u.map_off;
+  const int32_t* gmem = d.gmem + u.map_off;
+  const int32_t* goff = d.goff + u.goff_off;
+  const double LOG_E_BASE_10 = 0.4342944819;           // mathops.cpp:11
+  const double TOLERANCE = 1e-10;                      // mathops.cpp:10
+  __shared__ double red_v[256];
+
+  for (int gt = tid; gt < V*V; gt += 256){
+    const int v1 = gt / V, v2 = gt - v1*V;
+    double mx = -1.7976931348623157e308/2, tot = 0.0;   // -DBL_MAX/2 (genotyper.cpp:152)
+    for (int x = goff[v1]; x < goff[v1+1]; x++){
+      const double* row = post + (int64_t)gmem[x]*A;
+      for (int y = goff[v2]; y < goff[v2+1]; y++){
+        const double lv = row[gmem[y]];
+        if (lv <= mx) tot += exp(lv - mx);
+        else { tot *= exp(mx - lv); tot += 1.0; mx = lv; }
+      }
+    }
+    T[gt] = mx + log(tot);
+  }
+  __syncthreads();
+
+  const int s = u.samp_index;
+  const int ha = d.map_gt[2*s], hb = d.map_gt[2*s+1];
+  const int ga = h2a[ha], gb = h2a[hb];
+  if (tid == 0){
+    d.best_gt[2*s] = ga; d.best_gt[2*s+1] = gb;
+    const double pab = post[(int64_t)ha*A + hb], pba = post[(int64_t)hb*A + ha];
+    d.hap_log_phased[s] = pab;
+    d.hap_log_unphased[s] = (ha != hb) ? fast_lse2(pab, pba, d.log_thresh) : pab;
+    const double lp = T[V*ga + gb];
+    d.log_phased[s] = lp;
+    if (ga == gb) d.log_unphased[s] = lp;
+    else {
+      const double alt = T[V*gb + ga];                 // exact pair log_sum_exp (mathops.cpp:52-57)
+      d.log_unphased[s] = (lp > alt) ? lp + log(1 + exp(alt - lp)) : alt + log(1 + exp(lp - alt));
+    }
+  }
+  if (!d.calc_any) return;
+
+  // GLs in VCF order, PHASEDGLs (genotyper.cpp:211-229); kept in the output (or scratch-free registers) for GLDIFF / PL
+  const double total_ll = d.sample_total[s];
+  const int ngl = u.haploid ? V : V*(V+1)/2;
+  double* gls = d.gls + u.gl_off;                     // always allocated when any flag is set (GLDIFF needs them)
+  for (int gt = tid; gt < V*V; gt += 256){
+    const int i1 = gt / V, i2 = gt - i1*V;
+    const double corr = (i1 == i2) ? u.hom_corr : u.het_corr;
+    if ((i2 <= i1) && (!u.haploid || i1 == i2)){
+      const double gl_e = (total_ll - (corr + u.gl_ncfg)) + fast_lse2(T[gt], T[i2*V + i1], d.log_thresh);
+      gls[u.haploid ? i1 : i1*(i1+1)/2 + i2] = gl_e*LOG_E_BASE_10;
+    }
+    if (d.calc_pgls && (!u.haploid || i1 == i2))
+      d.pgls[u.pgl_off + (u.haploid ? i1 : gt)] = ((total_ll - (corr + u.pgl_ncfg)) + T[gt])*LOG_E_BASE_10;
+  }
+  __syncthreads();
+  // max and runner-up GL (calc_gl_diff)
+  double m = -1.7976931348623157e308;
+  for (int g = tid; g < ngl; g += 256) m = fmax(m, gls[g]);
+  red_v[tid] = m; __syncthreads();
+  for (int st = 128; st > 0; st >>= 1){ if (tid < st) red_v[tid] = fmax(red_v[tid], red_v[tid+st]); __syncthreads(); }
+  const double max_gl = red_v[0]; __syncthreads();
+  double m2 = -1.7976931348623157e308;
+  for (int g = tid; g < ngl; g += 256) if (gls[g] < max_gl) m2 = fmax(m2, gls[g]);
+  red_v[tid] = m2; __syncthreads();
+  for (int st = 128; st > 0; st >>= 1){ if (tid < st) red_v[tid] = fmax(red_v[tid], red_v[tid+st]); __syncthreads(); }
+  double second_gl = red_v[0];
+  if (second_gl == -1.7976931348623157e308) second_gl = max_gl;
+  if (tid == 0){
+    double diff = -1000;
+    if (A != 1){
+      const int lo = min(ga, gb), hi = max(ga, gb);
+      const int gi = u.haploid ? ga : hi*(hi+1)/2 + lo;
+      diff = (fabs(max_gl - gls[gi]) < TOLERANCE) ? (max_gl - second_gl) : gls[gi] - max_gl;
+    }
+    d.gl_diff[s] = diff;
+  }
+  if (d.calc_pls)
+    for (int g = tid; g < ngl; g += 256) d.pls[u.gl_off + g] = min(999, (int)(-10*(gls[g] - max_gl)));
+}

@@ -26,3 +26,33 @@ struct hs_post_dev_t {
   int32_t*       map_gt;
   double         log_thresh, log_half;
 };
+
+// One (locus, sample) pair of the genotype extraction (Genotyper::extract_genotypes_and_likelihoods, genotyper.cpp:129-251).
+struct hs_gt_unit_t {
+  int64_t post_off;        // this sample's [A x A] posteriors
+  int64_t tot_off;         // scratch: this sample's [V x V] total_log_phased_posteriors
+  int64_t gl_off, pgl_off; // this sample's pieces of the GL/PL and PHASEDGL outputs
+  int32_t n_alleles, n_variants;
+  int32_t samp_index;
+  int32_t haploid;
+  int32_t map_off;         // into h2a / gmem (per locus: A entries)
+  int32_t goff_off;        // into goff (per locus: V+1 entries, relative to map_off)
+  double  hom_corr, het_corr;     // priors to take out again (genotyper.cpp:197-198)
+  double  gl_ncfg, pgl_ncfg;      // corrections for the number of averaged haplotype configurations (:201-209)
+};
+
+struct hs_gt_dev_t {
+  const hs_gt_unit_t* units;
+  const double*  log_post;
+  const double*  sample_total;
+  const int32_t* map_gt;          // MAP haplotype pair per sample (hs_posterior_kernel)
+  const int32_t* h2a;             // hap_to_allele
+  const int32_t* gmem;            // haplotypes of a locus sorted by (variant, haplotype index)
+  const int32_t* goff;            // start of every variant's haplotypes in gmem
+  double*  tot;                   // scratch
+  int32_t* best_gt;               // [2*n_samp]
+  double*  log_phased, *log_unphased, *hap_log_phased, *hap_log_unphased, *gl_diff;   // [n_samp]
+  double*  gls;  int32_t* pls;  double* pgls;
+  int32_t  calc_any, calc_gls, calc_pls, calc_pgls;
+  double   log_thresh;
+};

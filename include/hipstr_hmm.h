@@ -189,6 +189,35 @@ int  hipstr_post_fetch(hipstr_post_dev_t* pd, double* log_post, double* sample_t
 void hipstr_post_free(hipstr_post_dev_t* pd);
 
 /*
+ * Genotype calls: Genotyper::extract_genotypes_and_likelihoods (genotyper.cpp:129-251) with calc_PLs (99-104) and calc_gl_diff
+ * (106-127) on the resident posteriors of a hipstr_post_dev_t (after hipstr_post_launch): MAP haplotype pair -> genotype of
+ * the STR block, haplotype posteriors marginalised to genotype posteriors (streaming log-sum-exp in the reference's order),
+ * Q / PQ values, GL (log10, priors removed), GLDIFF, PL, PHASEDGL.  hap_to_allele maps every haplotype of a locus to its
+ * variant (option of the STR block, SeqStutterGenotyper::haps_to_alleles); every variant must be hit by a haplotype.
+ * Per sample the GL / PL arrays hold V(V+1)/2 values (diploid, VCF order) or V (haploid); PHASEDGL V*V or V.
+ */
+typedef struct hipstr_gt_request {
+  const int32_t* n_variants;      /* [n_loci] V                                                                      */
+  const int32_t* hap_to_allele;   /* [sum A_l]                                                                       */
+  int32_t calc_gls, calc_pls, calc_phased_gls;
+} hipstr_gt_request_t;
+typedef struct hipstr_gt_out {
+  int32_t* best_hap;              /* [2*n_samp] best_haplotypes                                                      */
+  int32_t* best_gt;               /* [2*n_samp] best_gts                                                             */
+  double*  log_phased_post;       /* [n_samp]                                                                        */
+  double*  log_unphased_post;     /* [n_samp]                                                                        */
+  double*  hap_log_phased_post;   /* [n_samp]                                                                        */
+  double*  hap_log_unphased_post; /* [n_samp]                                                                        */
+  double*  gl_diff;               /* [n_samp]; written when any calc_* flag is set                                    */
+  double*  gls;                   /* [gl_off[n_samp]]  when calc_gls                                                  */
+  int32_t* pls;                   /* [gl_off[n_samp]]  when calc_pls                                                  */
+  double*  phased_gls;            /* [pgl_off[n_samp]] when calc_phased_gls                                           */
+} hipstr_gt_out_t;
+/* gl_off / pgl_off: [n_samp+1] starts of every sample's piece (samples in locus order, as sample_total_ll). */
+int hipstr_gt_offsets(const hipstr_post_batch_t* pb, const hipstr_gt_request_t* rq, int64_t* gl_off, int64_t* pgl_off);
+int hipstr_post_extract(hipstr_post_dev_t* pd, const hipstr_gt_request_t* rq, hipstr_gt_out_t* out);
+
+/*
  * Viterbi traceback: HapAligner::trace_optimal_aln (HapAligner.cpp:711-722) = process_read(..., retrace_aln=true) on one
  * fixed haplotype: full M/I/D matrices of both sides, arg-max seed position (compute_aln_logprob's max_index,
  * HapAligner.cpp:184-222), HapAligner::retrace (HapAligner.cpp:363-571) with its 0.001-nat tie tolerances, and — when the

@@ -444,6 +444,54 @@ class Genotyper {
   // MAP phased diplotype per sample: first maximum in allele_1-major order (genotyper.cpp:82-97); computed by the same kernel
   void get_optimal_haplotypes(std::vector< std::pair<int,int> >& gts) const { assert(gts.empty()); gts = map_gts_; }
 
+  // Genotyper::extract_genotypes_and_likelihoods (genotyper.h:98-106, genotyper.cpp:129-251): same arguments, same outputs.
+  // The posteriors are those of the current log_aln_probs_ / read_weights_ (recomputed on the device, where they stay).
+  void extract_genotypes_and_likelihoods(int num_variants, std::vector<int>& hap_to_allele,
+                                         std::vector< std::pair<int,int> >& best_haplotypes, std::vector< std::pair<int,int> >& best_gts,
+                                         std::vector<double>& log_phased_posteriors, std::vector<double>& log_unphased_posteriors,
+                                         std::vector<double>& hap_log_phased_posteriors, std::vector<double>& hap_log_unphased_posteriors,
+                                         bool calc_gls, std::vector< std::vector<double> >& gls, std::vector<double>& gl_diffs,
+                                         bool calc_pls, std::vector< std::vector<int> >& pls,
+                                         bool calc_phased_gls, std::vector< std::vector<double> >& phased_gls){
+    assert(log_phased_posteriors.empty() && log_unphased_posteriors.empty() && gl_diffs.empty());
+    assert(best_haplotypes.empty() && best_gts.empty() && gls.empty() && pls.empty() && phased_gls.empty());
+    assert((int)hap_to_allele.size() == num_alleles_);
+    int32_t A = num_alleles_, S = num_samples_, V = num_variants, read_off[2] = {0, (int32_t)num_reads_};
+    uint8_t hap = haploid_ ? 1 : 0;
+    std::vector<int32_t> w(read_weights_.begin(), read_weights_.end()), h2a(hap_to_allele.begin(), hap_to_allele.end());
+    hipstr_post_batch_t pb;
+    pb.n_loci = 1; pb.n_alleles = &A; pb.n_samples = &S; pb.read_off = read_off; pb.sample_label = sample_label_;
+    pb.log_p1 = log_p1_; pb.log_p2 = log_p2_; pb.read_weight = w.data(); pb.log_aln_probs = log_aln_probs_; pb.haploid = &hap;
+    std::vector<double> prior((size_t)S*A*A);
+    init_log_sample_priors(prior.data());
+    pb.log_prior = custom_priors_ ? prior.data() : NULL;
+    hipstr_gt_request_t rq; rq.n_variants = &V; rq.hap_to_allele = h2a.data();
+    rq.calc_gls = calc_gls; rq.calc_pls = calc_pls; rq.calc_phased_gls = calc_phased_gls;
+    const bool any = calc_gls || calc_pls || calc_phased_gls;
+    const size_t ngl = haploid_ ? V : (size_t)V*(V+1)/2, npgl = haploid_ ? V : (size_t)V*V;
+    std::vector<int32_t> bh(2*(size_t)S), bg(2*(size_t)S), pl(any ? S*ngl : 1);
+    std::vector<double> lp(S), lu(S), hlp(S), hlu(S), gd(S), gl(any ? S*ngl : 1), pgl(calc_phased_gls ? S*npgl : 1);
+    hipstr_gt_out_t o;
+    o.best_hap = bh.data(); o.best_gt = bg.data(); o.log_phased_post = lp.data(); o.log_unphased_post = lu.data();
+    o.hap_log_phased_post = hlp.data(); o.hap_log_unphased_post = hlu.data(); o.gl_diff = gd.data();
+    o.gls = gl.data(); o.pls = pl.data(); o.phased_gls = pgl.data();
+    rq.calc_gls = any;                       // GLDIFF needs the GLs; they are dropped below when not asked for (genotyper.cpp:247-248)
+    hipstr_post_dev_t* pd = hipstr_post_upload(&pb, NULL);
+    if (pd == NULL || hipstr_post_launch(pd, NULL) != 0 || hipstr_post_extract(pd, &rq, &o) != 0) printErrorAndDie(hipstr_last_error());
+    hipstr_post_free(pd);
+    for (int s = 0; s < S; s++){
+      best_haplotypes.push_back(std::pair<int,int>(bh[2*s], bh[2*s+1]));
+      best_gts.push_back(std::pair<int,int>(bg[2*s], bg[2*s+1]));
+    }
+    log_phased_posteriors = lp; log_unphased_posteriors = lu; hap_log_phased_posteriors = hlp; hap_log_unphased_posteriors = hlu;
+    if (any){
+      gl_diffs = gd;
+      if (calc_gls) for (int s = 0; s < S; s++) gls.push_back(std::vector<double>(gl.begin() + s*ngl, gl.begin() + (s+1)*ngl));
+      if (calc_pls) for (int s = 0; s < S; s++) pls.push_back(std::vector<int>(pl.begin() + s*ngl, pl.begin() + (s+1)*ngl));
+      if (calc_phased_gls) for (int s = 0; s < S; s++) phased_gls.push_back(std::vector<double>(pgl.begin() + s*npgl, pgl.begin() + (s+1)*npgl));
+    }
+  }
+
  public:
   Genotyper(bool haploid, const std::vector<std::string>& sample_names,
             const std::vector< std::vector<double> >& log_p1, const std::vector< std::vector<double> >& log_p2){

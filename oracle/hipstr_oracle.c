@@ -710,6 +710,87 @@ int oracle_posteriors(const hipstr_post_batch_t* pb, double* log_post, double* s
 
 /* test hook: homopolymer index per matrix row (both sides) as in effect when allele k of a one-locus,
  * one-read batch is scored (rows of blocks that were reused keep the values of the allele they were computed under) */
+/* ---------------------------------------------- genotype calls (A.9)
+ * Genotyper::extract_genotypes_and_likelihoods (genotyper.cpp:129-251), calc_PLs (99-104), calc_gl_diff (106-127). */
+static void stream_update(double lv, double* mx, double* tot){          /* mathops.cpp:72-80 */
+  if (lv <= *mx) *tot += exp(lv - *mx);
+  else { *tot *= exp(*mx - lv); *tot += 1.0; *mx = lv; }
+}
+static double exact_lse2(double a, double b){                           /* mathops.cpp:52-57 */
+  return a > b ? a + log(1 + exp(b - a)) : b + log(1 + exp(a - b));
+}
+
+int oracle_gt_extract(const hipstr_post_batch_t* pb, const hipstr_gt_request_t* rq, hipstr_gt_out_t* o){
+  oracle_init();
+  const double LOG_E_BASE_10 = 0.4342944819, TOL = 1e-10;               /* mathops.cpp:10-11 */
+  int64_t n_post = 0; int n_samp = 0;
+  for (int l = 0; l < pb->n_loci; l++){ n_post += (int64_t)pb->n_samples[l]*pb->n_alleles[l]*pb->n_alleles[l]; n_samp += pb->n_samples[l]; }
+  double* post = malloc(sizeof(double)*(n_post ? n_post : 1));
+  double* totals = malloc(sizeof(double)*(n_samp ? n_samp : 1));
+  double* ltot = malloc(sizeof(double)*(pb->n_loci ? pb->n_loci : 1));
+  int rc = oracle_posteriors(pb, post, totals, o->best_hap, ltot);
+  int calc_any = rq->calc_gls || rq->calc_pls || rq->calc_phased_gls;
+  int64_t po = 0, g = 0, pg = 0; int so = 0, map_off = 0;
+  for (int l = 0; l < pb->n_loci && rc == 0; l++){
+    int A = pb->n_alleles[l], S = pb->n_samples[l], V = rq->n_variants[l];
+    int hap = pb->haploid && pb->haploid[l];
+    const int32_t* h2a = rq->hap_to_allele + map_off;
+    double hom = hap ? -g_int_log[A] : g_int_log[2] - g_int_log[A] - g_int_log[A+1];
+    double het = hap ? 0 : -g_int_log[A] - g_int_log[A+1];
+    double gl_ncfg  = hap ? g_int_log[2] + g_int_log[A] - g_int_log[V] : g_int_log[2] + 2*(g_int_log[A] - g_int_log[V]);
+    double pgl_ncfg = hap ? g_int_log[A] - g_int_log[V] : 2*(g_int_log[A] - g_int_log[V]);
+    double* mx = malloc(sizeof(double)*V*V); double* T = malloc(sizeof(double)*V*V);
+    int ngl = hap ? V : V*(V+1)/2, npgl = hap ? V : V*V;
+    double* gls = malloc(sizeof(double)*ngl);
+    for (int s = 0; s < S; s++, so++){
+      const double* P = post + po + (int64_t)s*A*A;
+      for (int i = 0; i < V*V; i++){ mx[i] = -DBL_MAX/2; T[i] = 0.0; }
+      for (int i1 = 0; i1 < A; i1++)
+        for (int i2 = 0; i2 < A; i2++){ int gi = V*h2a[i1] + h2a[i2]; stream_update(P[(int64_t)i1*A + i2], &mx[gi], &T[gi]); }
+      for (int i = 0; i < V*V; i++) T[i] = mx[i] + log(T[i]);
+      int ha = o->best_hap[2*so], hb = o->best_hap[2*so+1];
+      int ga = h2a[ha], gb = h2a[hb];
+      o->best_gt[2*so] = ga; o->best_gt[2*so+1] = gb;
+      double pab = P[(int64_t)ha*A + hb], pba = P[(int64_t)hb*A + ha];
+      o->hap_log_phased_post[so] = pab;
+      o->hap_log_unphased_post[so] = (ha != hb) ? oracle_fast_lse2(pab, pba) : pab;
+      double lp = T[V*ga + gb];
+      o->log_phased_post[so] = lp;
+      o->log_unphased_post[so] = (ga == gb) ? lp : exact_lse2(lp, T[V*gb + ga]);
+      if (!calc_any) continue;
+      int k = 0, pk = 0;
+      for (int i1 = 0; i1 < V; i1++)
+        for (int i2 = 0; i2 < V; i2++){
+          int gi = i1*V + i2, alt = i2*V + i1;
+          double corr = (i1 == i2) ? hom : het;
+          if (i2 <= i1 && (!hap || i1 == i2))
+            gls[k++] = (totals[so] - (corr + gl_ncfg) + oracle_fast_lse2(T[gi], T[alt]))*LOG_E_BASE_10;
+          if (rq->calc_phased_gls && (!hap || i1 == i2))
+            o->phased_gls[pg + pk++] = (totals[so] - (corr + pgl_ncfg) + T[gi])*LOG_E_BASE_10;
+        }
+      double max_gl = gls[0], second = -DBL_MAX;
+      for (int i = 1; i < ngl; i++) if (gls[i] > max_gl) max_gl = gls[i];
+      for (int i = 0; i < ngl; i++) if (gls[i] < max_gl && gls[i] > second) second = gls[i];
+      if (second == -DBL_MAX) second = max_gl;
+      if (A == 1) o->gl_diff[so] = -1000;
+      else {
+        int lo = ga < gb ? ga : gb, hi = ga < gb ? gb : ga;
+        int gi = hap ? ga : hi*(hi+1)/2 + lo;
+        o->gl_diff[so] = (fabs(max_gl - gls[gi]) < TOL) ? (max_gl - second) : gls[gi] - max_gl;
+      }
+      for (int i = 0; i < ngl; i++){
+        if (rq->calc_gls) o->gls[g + i] = gls[i];
+        if (rq->calc_pls){ int pl = (int)(-10*(gls[i] - max_gl)); o->pls[g + i] = pl < 999 ? pl : 999; }
+      }
+      g += ngl; pg += npgl;
+    }
+    free(mx); free(T); free(gls);
+    po += (int64_t)S*A*A; map_off += A;
+  }
+  free(post); free(totals); free(ltot);
+  return rc;
+}
+
 int oracle_debug_row_h(const hipstr_batch_t* b, int k, int32_t* h_fw, int32_t* h_rv, int cap){
   for (int i = 0; i < cap; i++){ h_fw[i] = 0; h_rv[i] = 0; }
   g_dbg_h[0] = h_fw; g_dbg_h[1] = h_rv; g_dbg_stop = k;

@@ -209,6 +209,29 @@ class ProbeGenotyper : public Genotyper {
     for (int s = 0; s < num_samples_; s++){ map_gt[2*s] = gts[s].first; map_gt[2*s+1] = gts[s].second; }
     return total;
   }
+  // Genotyper::extract_genotypes_and_likelihoods (protected, genotyper.h:98-106) on the posteriors of the last run()
+  void extract(int num_variants, const int32_t* h2a, const hipstr_gt_request_t* rq, hipstr_gt_out_t* o, int samp_off, int64_t& g, int64_t& pg){
+    std::vector<int> hap_to_allele(h2a, h2a + num_alleles_);
+    std::vector< std::pair<int,int> > haps, gts;
+    std::vector<double> lp, lu, hlp, hlu, gl_diffs;
+    std::vector< std::vector<double> > gls, pgls;
+    std::vector< std::vector<int> > pls;
+    extract_genotypes_and_likelihoods(num_variants, hap_to_allele, haps, gts, lp, lu, hlp, hlu, rq->calc_gls != 0, gls, gl_diffs,
+                                      rq->calc_pls != 0, pls, rq->calc_phased_gls != 0, pgls);
+    for (int s = 0; s < num_samples_; s++){
+      const int so = samp_off + s;
+      o->best_hap[2*so] = haps[s].first; o->best_hap[2*so+1] = haps[s].second;
+      o->best_gt[2*so] = gts[s].first; o->best_gt[2*so+1] = gts[s].second;
+      o->log_phased_post[so] = lp[s]; o->log_unphased_post[so] = lu[s];
+      o->hap_log_phased_post[so] = hlp[s]; o->hap_log_unphased_post[so] = hlu[s];
+      if (!gl_diffs.empty()) o->gl_diff[so] = gl_diffs[s];
+      const int ngl = haploid_ ? num_variants : num_variants*(num_variants+1)/2, npgl = haploid_ ? num_variants : num_variants*num_variants;
+      if (rq->calc_gls) for (int i = 0; i < ngl; i++) o->gls[g + i] = gls[s][i];
+      if (rq->calc_pls) for (int i = 0; i < ngl; i++) o->pls[g + i] = pls[s][i];
+      if (rq->calc_phased_gls) for (int i = 0; i < npgl; i++) o->phased_gls[pg + i] = pgls[s][i];
+      g += ngl; pg += npgl;
+    }
+  }
 };
 } // namespace
 
@@ -237,6 +260,25 @@ extern "C" int ref_posteriors(const hipstr_post_batch_t* pb, double* log_post, d
     post_off += (int64_t)S*A*A;
     samp_off += S;
     ll_off   += (int64_t)(r1-r0)*A;
+  }
+  return 0;
+}
+
+extern "C" int ref_gt_extract(const hipstr_post_batch_t* pb, const hipstr_gt_request_t* rq, hipstr_gt_out_t* o){
+  ensure_ready();
+  int64_t ll_off = 0, g = 0, pg = 0; int samp_off = 0, map_off = 0;
+  for (int l = 0; l < pb->n_loci; l++){
+    int A = pb->n_alleles[l], S = pb->n_samples[l];
+    int r0 = pb->read_off[l], r1 = pb->read_off[l+1];
+    std::vector<std::string> names;
+    std::vector< std::vector<double> > p1(S), p2(S);
+    for (int s = 0; s < S; s++){ char buf[32]; snprintf(buf, sizeof buf, "S%d", s); names.push_back(buf); }
+    for (int r = r0; r < r1; r++){ p1[pb->sample_label[r]].push_back(pb->log_p1[r]); p2[pb->sample_label[r]].push_back(pb->log_p2[r]); }
+    ProbeGenotyper gt(pb->haploid ? pb->haploid[l] != 0 : false, names, p1, p2, A);
+    std::vector<double> post((size_t)S*A*A), totals(S); std::vector<int32_t> map_gt(2*S);
+    gt.run(pb->log_aln_probs + ll_off, pb->read_weight + r0, post.data(), totals.data(), map_gt.data());
+    gt.extract(rq->n_variants[l], rq->hap_to_allele + map_off, rq, o, samp_off, g, pg);
+    samp_off += S; map_off += A; ll_off += (int64_t)(r1-r0)*A;
   }
   return 0;
 }

@@ -22,6 +22,18 @@ class ProbeGenotyper : public Genotyper {   // the reference's derived genotyper
     printf("post_total %.12f\n", total);
     for (size_t s = 0; s < gts.size(); s++) printf("post_gt %d %d\n", gts[s].first, gts[s].second);
     printf("post_first %.12f %.12f %.12f\n", log_sample_posteriors_[0], log_sample_posteriors_[1], log_sample_posteriors_[2]);
+    // genotype calls with haplotypes {0,1,2} carrying variants {0,1,1}
+    std::vector<int> h2a; h2a.push_back(0); h2a.push_back(1); h2a.push_back(1);
+    std::vector< std::pair<int,int> > haps, bgts;
+    std::vector<double> lp, lu, hlp, hlu, gld;
+    std::vector< std::vector<double> > gls, pgls; std::vector< std::vector<int> > pls;
+    extract_genotypes_and_likelihoods(2, h2a, haps, bgts, lp, lu, hlp, hlu, true, gls, gld, true, pls, true, pgls);
+    for (size_t s = 0; s < bgts.size(); s++){
+      printf("gt_call %zu %d %d %d %d %.12f %.12f %.12f %.12f %.12f", s, haps[s].first, haps[s].second, bgts[s].first, bgts[s].second, lp[s], lu[s], hlp[s], hlu[s], gld[s]);
+      for (size_t i = 0; i < gls[s].size(); i++) printf(" %.12f %d", gls[s][i], pls[s][i]);
+      for (size_t i = 0; i < pgls[s].size(); i++) printf(" %.12f", pgls[s][i]);
+      printf("\n");
+    }
   }
 };
 

@@ -86,6 +86,28 @@ def main():
         np.savez_compressed(os.path.join(HERE, "post_%s.npz" % name), **out)
         print("post", name, "samples", tot.size)
 
+    # genotype calls (Genotyper::extract_genotypes_and_likelihoods) on the same posterior cases + a random haplotype->variant map
+    rng_g = np.random.default_rng(20260930)
+    for name, kw in posts.items():
+        pb = capi.PostBatch(**kw)
+        A = np.asarray(kw["n_alleles"])
+        nv, h2a = [], []
+        for a in A:
+            v = int(rng_g.integers(1, a + 1))
+            m = np.concatenate([np.arange(v), rng_g.integers(0, v, a - v)]); rng_g.shuffle(m)     # every variant carried by a haplotype
+            nv.append(v); h2a.append(m)
+        h2a = np.concatenate(h2a).astype(np.int32)
+        e = capi.run_gt_extract(ref, "ref_", pb, nv, h2a)
+        out = {k: np.asarray(v) for k, v in kw.items()}
+        out.update(n_variants=np.array(nv, np.int32), hap_to_allele=h2a)
+        for k2 in ("best_hap", "best_gt", "log_phased_post", "log_unphased_post", "hap_log_phased_post", "hap_log_unphased_post", "gl_diff"):
+            out["expect_" + k2] = e[k2]
+        for k2 in ("gls", "pls", "phased_gls"):
+            out["expect_" + k2] = np.concatenate(e[k2]) if e[k2] else np.zeros(0)
+            out["expect_" + k2 + "_len"] = np.array([len(x) for x in e[k2]])
+        np.savez_compressed(os.path.join(HERE, "gt_%s.npz" % name), **out)
+        print("gt", name, "samples", len(e["gl_diff"]), "GLs", sum(len(x) for x in e["gls"]))
+
     # scalar probes: constant tables and the float log-sum-exp approximations
     f64p = capi._f64p
     vals = {}

@@ -60,3 +60,15 @@ def test_device_parts(_native_built):
     assert abs(float(kv["post_total"][0][0]) - (-26.5207888808)) < 1e-9
     assert kv["post_gt"] == [["1", "0"], ["2", "2"]]
     assert all(abs(float(a) - b) < 1e-9 for a, b in zip(kv["post_first"][0], [-1.39627803547, -3.2336875797, -3.4679593086]))
+    # Genotyper::extract_genotypes_and_likelihoods through the C++ class, checked against the oracle on the same posterior case
+    from hipstr_amd import capi
+    pb, _, _, _ = util.load_gt_fixture(os.path.join(ROOT, "tests", "golden", "gt_kat_survey.npz"))
+    want = capi.run_gt_extract(capi.load_oracle(), "oracle_", pb, [2], [0, 1, 1])
+    for row in kv["gt_call"]:
+        s = int(row[0]); vals = [float(x) for x in row[1:]]
+        exp = list(want["best_hap"][s]) + list(want["best_gt"][s]) + [want[k][s] for k in ("log_phased_post", "log_unphased_post", "hap_log_phased_post",
+                                                                                          "hap_log_unphased_post", "gl_diff")]
+        for g, p in zip(want["gls"][s], want["pls"][s]):
+            exp += [g, p]
+        exp += list(want["phased_gls"][s])
+        assert len(vals) == len(exp) and all(abs(a - b) < 1e-9 * max(1, abs(b)) for a, b in zip(vals, exp))

@@ -161,3 +161,41 @@ def assert_traces_equal(got, want, what=""):
             if f == "max_index" and w[f] == -1:       # the reference keeps it in a local; the seed's 'M' in hap_aln pins it
                 continue
             assert g[f] == w[f], "%s request %d: %s %r != %r" % (what, q, f, g[f], w[f])
+
+
+def load_gt_fixture(path):
+    """tests/golden/gt_*.npz -> (PostBatch, n_variants, hap_to_allele, expected dict in run_gt_extract's shape)."""
+    d = np.load(path)
+    pb = capi.PostBatch(d["n_alleles"], d["n_samples"], d["read_off"], d["sample_label"], d["log_p1"], d["log_p2"], d["read_weight"],
+                        d["log_aln_probs"], d["haploid"])
+    exp = {k: d["expect_" + k] for k in ("best_hap", "best_gt", "log_phased_post", "log_unphased_post", "hap_log_phased_post",
+                                         "hap_log_unphased_post", "gl_diff")}
+    for k in ("gls", "pls", "phased_gls"):
+        cuts = np.cumsum(d["expect_" + k + "_len"])[:-1]
+        exp[k] = np.split(d["expect_" + k], cuts)
+    return pb, d["n_variants"], d["hap_to_allele"], exp
+
+
+def assert_genotypes_close(got, want, tol, what=""):
+    """tol = 0 demands identical bits.  PLs are truncated integers of -10*(GL - maxGL): with tol > 0 a PL may differ by one
+    only where that product sits within 1e-6 of an integer."""
+    assert np.array_equal(got["best_hap"], want["best_hap"]), what
+    assert np.array_equal(got["best_gt"], want["best_gt"]), what
+    def close(a, b):
+        a = np.asarray(a, float); b = np.asarray(b, float)
+        if tol == 0:
+            return np.array_equal(a, b)
+        fin = np.isfinite(b)
+        return np.array_equal(np.isfinite(a), fin) and np.all(np.abs(a[fin] - b[fin]) <= tol * np.maximum(1, np.abs(b[fin])))
+    for k in ("log_phased_post", "log_unphased_post", "hap_log_phased_post", "hap_log_unphased_post", "gl_diff"):
+        assert close(got[k], want[k]), "%s %s" % (what, k)
+    for s in range(len(want["gls"])):
+        assert close(got["gls"][s], want["gls"][s]), "%s gls of sample %d" % (what, s)
+        assert close(got["phased_gls"][s], want["phased_gls"][s]), "%s phased gls of sample %d" % (what, s)
+        gp, wp = np.asarray(got["pls"][s]), np.asarray(want["pls"][s])
+        if tol == 0:
+            assert np.array_equal(gp, wp), "%s pls of sample %d" % (what, s)
+        else:
+            bad = np.nonzero(gp != wp)[0]
+            g = np.asarray(want["gls"][s]); x = -10 * (g - g.max())
+            assert np.all(np.abs(gp[bad] - wp[bad]) <= 1) and np.all(np.abs(x[bad] - np.round(x[bad])) < 1e-6), "%s pls of sample %d" % (what, s)
