@@ -42,6 +42,32 @@ class HipstrPostBatch(C.Structure):
     ]
 
 
+class HipstrEmBatch(C.Structure):
+    _fields_ = [("n_loci", C.c_int32), ("period", _i32p), ("haploid", _u8p), ("n_samples", _i32p), ("read_off", _i32p), ("sample_label", _i32p),
+                ("num_bps", _i32p), ("log_p1", _f64p), ("log_p2", _f64p), ("ref_allele", C.c_int32), ("max_iter", C.c_int32),
+                ("min_ll_abs_change", C.c_double), ("min_ll_frac_change", C.c_double)]
+
+
+def run_em(lib, prefix, period, n_samples, read_off, sample_label, num_bps, log_p1, log_p2, haploid=None, ref_allele=0, max_iter=100,
+           min_ll_abs_change=0.01, min_ll_frac_change=0.001):
+    """<prefix>em_train on a batch of loci -> (trained[n_loci] bool, stutter[n_loci, 6], n_iter[n_loci], final_ll[n_loci])."""
+    i32 = lambda x: np.ascontiguousarray(np.asarray(x, np.int32)); f64 = lambda x: np.ascontiguousarray(np.asarray(x, np.float64))
+    a = dict(period=i32(period), n_samples=i32(n_samples), read_off=i32(read_off), sample_label=i32(sample_label), num_bps=i32(num_bps),
+             log_p1=f64(log_p1), log_p2=f64(log_p2), haploid=None if haploid is None else np.ascontiguousarray(np.asarray(haploid, np.uint8)))
+    nl = len(a["period"])
+    eb = HipstrEmBatch(nl, a["period"].ctypes.data_as(_i32p), _ptr(a["haploid"], _u8p), a["n_samples"].ctypes.data_as(_i32p),
+                       a["read_off"].ctypes.data_as(_i32p), a["sample_label"].ctypes.data_as(_i32p), a["num_bps"].ctypes.data_as(_i32p),
+                       a["log_p1"].ctypes.data_as(_f64p), a["log_p2"].ctypes.data_as(_f64p), ref_allele, max_iter, min_ll_abs_change, min_ll_frac_change)
+    trained = np.zeros(max(nl, 1), np.uint8); st = np.zeros(max(6 * nl, 6)); it = np.zeros(max(nl, 1), np.int32); ll = np.zeros(max(nl, 1))
+    fn = getattr(lib, prefix + "em_train")
+    fn.restype = C.c_int; fn.argtypes = [C.POINTER(HipstrEmBatch), _u8p, _f64p, _i32p, _f64p]
+    rc = fn(C.byref(eb), trained.ctypes.data_as(_u8p), st.ctypes.data_as(_f64p), it.ctypes.data_as(_i32p), ll.ctypes.data_as(_f64p))
+    if rc != 0:
+        why = lib.hipstr_last_error().decode() if prefix == "hipstr_" else ""
+        raise RuntimeError("%sem_train failed rc=%d %s" % (prefix, rc, why))
+    return trained[:nl].astype(bool), st[:6 * nl].reshape(-1, 6), it[:nl], ll[:nl]
+
+
 class HipstrGtRequest(C.Structure):
     _fields_ = [("n_variants", _i32p), ("hap_to_allele", _i32p), ("calc_gls", C.c_int32), ("calc_pls", C.c_int32), ("calc_phased_gls", C.c_int32)]
 

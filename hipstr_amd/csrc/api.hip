@@ -411,7 +411,7 @@ int post_setup(const hipstr_post_batch_t* pb, const double* dev_ll, PostRun& R){
     int r = r0;
     for (int s = 0; s < S; s++){
       hs_post_unit_t u;
-      u.post_off = po + (int64_t)s*A*A; u.n_alleles = A; u.samp_index = (int32_t)(so + s);
+      u.post_off = u.prior_off = po + (int64_t)s*A*A; u.n_alleles = A; u.samp_index = (int32_t)(so + s);
       u.log_hom_prior = hom; u.log_het_prior = het;
       u.read_begin = r; u.ll_off = lo + (int64_t)(r-r0)*A;
       while (r < r1 && pb->sample_label[r] == s) r++;

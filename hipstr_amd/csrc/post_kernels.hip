@@ -44,6 +44,7 @@ __device__ __forceinline__ double fast_lse2(double a, double b, double thr){    
 extern "C" __global__ void __launch_bounds__(256)
 hs_posterior_kernel(const hs_post_dev_t* __restrict__ dp){
   const hs_post_dev_t& d = *dp;
+  if (d.unit_active && !d.unit_active[blockIdx.x]) return;
   const hs_post_unit_t u = d.units[blockIdx.x];
   const int A = u.n_alleles, nd = A*A, tid = threadIdx.x;
   double* post = d.log_post + u.post_off;
@@ -56,7 +57,7 @@ hs_posterior_kernel(const hs_post_dev_t* __restrict__ dp){
   double lmax = -1.0e300;
   for (int idx = tid; idx < nd; idx += 256){
     const int a1 = idx / A, a2 = idx - a1*A;
-    double v = d.log_prior ? d.log_prior[u.post_off + idx] : ((a1 == a2) ? u.log_hom_prior : u.log_het_prior);
+    double v = d.log_prior ? d.log_prior[u.prior_off + idx] : ((a1 == a2) ? u.log_hom_prior : u.log_het_prior);
     for (int r = 0; r < u.n_reads; r++){
       const int g = u.read_begin + r;
       const double* LL = LL0 + (int64_t)r*A;

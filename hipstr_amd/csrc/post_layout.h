@@ -5,6 +5,7 @@
 // One (locus, sample) pair: the unit a workgroup processes.
 struct hs_post_unit_t {
   int64_t post_off;        // offset of this sample's [A x A] block in log_post
+  int64_t prior_off;       // offset of this sample's [A x A] block in log_prior (the EM shares one block per locus)
   int64_t ll_off;          // offset in log_aln_probs of the row of this sample's FIRST read
   int32_t n_alleles;
   int32_t read_begin;      // global read index of the sample's first read (reads of a sample are contiguous)
@@ -20,7 +21,8 @@ struct hs_post_dev_t {
   const double*  log_p1;
   const double*  log_p2;
   const int32_t* read_weight;
-  const double*  log_prior;      // optional [n_post] prior array (NULL = hom/het defaults of the unit)
+  const double*  log_prior;      // optional prior array (NULL = hom/het defaults of the unit)
+  const int32_t* unit_active;    // optional per-unit flag: 0 = skip (loci whose EM has converged); NULL = all
   double*        log_post;
   double*        sample_total;
   int32_t*       map_gt;

@@ -218,6 +218,34 @@ int hipstr_gt_offsets(const hipstr_post_batch_t* pb, const hipstr_gt_request_t* 
 int hipstr_post_extract(hipstr_post_dev_t* pd, const hipstr_gt_request_t* rq, hipstr_gt_out_t* out);
 
 /*
+ * De novo stutter model: EMStutterGenotyper::train (em_stutter_genotyper.cpp:146-226) with its E-step
+ * (calc_hap_aln_probs :146-150, Genotyper::calc_log_sample_posteriors under the allele-frequency priors of :129-144,
+ * recalc_log_read_phase_posteriors :152-169) and M-step (recalc_log_gt_priors :22-57, recalc_stutter_model :64-127), batched
+ * over loci.  A read is its observed STR size (bp difference from the reference); the alleles of a locus are the distinct
+ * sizes, the reference size first and the rest ascending (em_stutter_genotyper.h:55-78).  Reads of a locus are grouped by
+ * ascending sample, as in hipstr_post_batch_t.
+ */
+typedef struct hipstr_em_batch {
+  int32_t        n_loci;
+  const int32_t* period;        /* [n_loci] motif length                                                          */
+  const uint8_t* haploid;       /* [n_loci] or NULL = diploid                                                     */
+  const int32_t* n_samples;     /* [n_loci]                                                                       */
+  const int32_t* read_off;      /* [n_loci+1]                                                                     */
+  const int32_t* sample_label;  /* [n_reads]                                                                      */
+  const int32_t* num_bps;       /* [n_reads] observed STR size of the read                                        */
+  const double*  log_p1;        /* [n_reads]                                                                      */
+  const double*  log_p2;        /* [n_reads]                                                                      */
+  int32_t        ref_allele;    /* size of the reference allele (0 at both call sites of the reference)           */
+  int32_t        max_iter;      /* MAX_EM_ITER = 100 (genotyper_bam_processor.h:106)                              */
+  double         min_ll_abs_change;   /* ABS_LL_CONVERGE = 0.01                                                   */
+  double         min_ll_frac_change;  /* FRAC_LL_CONVERGE = 0.001                                                 */
+} hipstr_em_batch_t;
+/* trained[l]   = the return value of train();
+ * stutter[6*l] = inframe geom, up, down, outframe geom, up, down of get_stutter_model() after train();
+ * n_iter[l]    = E-steps performed;  final_ll[l] = the last E-step's total log-likelihood. */
+int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, double* stutter, int32_t* n_iter, double* final_ll);
+
+/*
  * Viterbi traceback: HapAligner::trace_optimal_aln (HapAligner.cpp:711-722) = process_read(..., retrace_aln=true) on one
  * fixed haplotype: full M/I/D matrices of both sides, arg-max seed position (compute_aln_logprob's max_index,
  * HapAligner.cpp:184-222), HapAligner::retrace (HapAligner.cpp:363-571) with its 0.001-nat tie tolerances, and — when the

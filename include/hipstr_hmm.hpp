@@ -516,5 +516,49 @@ class Genotyper {
   }
 };
 
+// EMStutterGenotyper (em_stutter_genotyper.h:15-127): length-based EM that learns a locus' stutter model.  Same constructor and
+// train()/get_stutter_model() as the reference; the whole EM loop runs in the library (hipstr_em_train).
+class EMStutterGenotyper {
+  bool haploid_; int motif_len_, ref_allele_;
+  std::vector<int32_t> n_bps_, label_; std::vector<double> p1_, p2_; int32_t num_samples_;
+  StutterModel* stutter_model_;
+  int num_iter_; double final_LL_;
+  EMStutterGenotyper(const EMStutterGenotyper&); EMStutterGenotyper& operator=(const EMStutterGenotyper&);
+ public:
+  EMStutterGenotyper(bool haploid, int motif_length, const std::vector< std::vector<int> >& num_bps,
+                     const std::vector< std::vector<double> >& log_p1, const std::vector< std::vector<double> >& log_p2,
+                     const std::vector<std::string>& sample_names, int ref_allele)
+    : haploid_(haploid), motif_len_(motif_length), ref_allele_(ref_allele), num_samples_((int32_t)num_bps.size()), stutter_model_(NULL), num_iter_(0), final_LL_(0) {
+    assert(num_bps.size() == log_p1.size() && num_bps.size() == log_p2.size() && num_bps.size() == sample_names.size());
+    for (size_t i = 0; i < num_bps.size(); i++){
+      assert(num_bps[i].size() == log_p1[i].size() && num_bps[i].size() == log_p2[i].size());
+      for (size_t j = 0; j < num_bps[i].size(); j++){
+        assert(log_p1[i][j] <= 0.0 && log_p2[i][j] <= 0.0);
+        n_bps_.push_back(num_bps[i][j]); label_.push_back((int32_t)i); p1_.push_back(log_p1[i][j]); p2_.push_back(log_p2[i][j]);
+      }
+    }
+  }
+  ~EMStutterGenotyper(){ delete stutter_model_; }
+  // EMStutterGenotyper::train (em_stutter_genotyper.cpp:171-226); disp_stats/logger are accepted for signature compatibility
+  bool train(int max_iter, double min_LL_abs_change, double min_LL_frac_change, bool /*disp_stats*/, std::ostream& /*logger*/){
+    int32_t period = motif_len_, read_off[2] = {0, (int32_t)n_bps_.size()}; uint8_t hap = haploid_ ? 1 : 0, ok = 0;
+    hipstr_em_batch_t eb;
+    eb.n_loci = 1; eb.period = &period; eb.haploid = &hap; eb.n_samples = &num_samples_; eb.read_off = read_off;
+    eb.sample_label = label_.data(); eb.num_bps = n_bps_.data(); eb.log_p1 = p1_.data(); eb.log_p2 = p2_.data();
+    eb.ref_allele = ref_allele_; eb.max_iter = max_iter; eb.min_ll_abs_change = min_LL_abs_change; eb.min_ll_frac_change = min_LL_frac_change;
+    double sp[6];
+    if (hipstr_em_train(&eb, &ok, sp, &num_iter_, &final_LL_) != 0) printErrorAndDie(hipstr_last_error());
+    delete stutter_model_;
+    stutter_model_ = new StutterModel(sp[0], sp[1], sp[2], sp[3], sp[4], sp[5], motif_len_);
+    return ok != 0;
+  }
+  StutterModel* get_stutter_model() const {
+    if (stutter_model_ == NULL) printErrorAndDie("No stutter model has been specified or learned");
+    return stutter_model_;
+  }
+  int num_iterations() const { return num_iter_; }      // extras: E-steps performed and the last total log-likelihood
+  double final_LL()    const { return final_LL_; }
+};
+
 }  // namespace hipstr_amd
 #endif  // HIPSTR_HMM_HPP_

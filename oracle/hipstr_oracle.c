@@ -710,6 +710,130 @@ int oracle_posteriors(const hipstr_post_batch_t* pb, double* log_post, double* s
 
 /* test hook: homopolymer index per matrix row (both sides) as in effect when allele k of a one-locus,
  * one-read batch is scored (rows of blocks that were reused keep the values of the allele they were computed under) */
+/* ---------------------------------------------- de novo stutter EM (A.10)
+ * EMStutterGenotyper (em_stutter_genotyper.h:55-102, em_stutter_genotyper.cpp:10-226), one locus at a time. */
+static void stream_update(double lv, double* mx, double* tot);
+static double exact_lse2(double a, double b);
+typedef struct { double in_geom, in_up, in_down, out_geom, out_up, out_down; } OModel;
+static int cmp_int(const void* a, const void* b){ int x = *(const int*)a, y = *(const int*)b; return (x > y) - (x < y); }
+
+int oracle_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, double* stutter, int32_t* n_iter, double* final_ll){
+  oracle_init();
+  for (int l = 0; l < eb->n_loci; l++){
+    int S = eb->n_samples[l], r0 = eb->read_off[l], R = eb->read_off[l+1] - r0, p = eb->period[l];
+    int hap = eb->haploid && eb->haploid[l];
+    const int32_t* lab = eb->sample_label + r0; const int32_t* nb = eb->num_bps + r0;
+    const double* lp1 = eb->log_p1 + r0; const double* lp2 = eb->log_p2 + r0;
+    /* alleles: the reference size first, the other distinct sizes ascending (em_stutter_genotyper.h:59-78) */
+    int* sizes = malloc(sizeof(int)*(R+1)); int A = 0;
+    for (int r = 0; r < R; r++) if (nb[r] != eb->ref_allele) sizes[A++] = nb[r];
+    qsort(sizes, A, sizeof(int), cmp_int);
+    int u = 0; for (int i = 0; i < A; i++) if (i == 0 || sizes[i] != sizes[i-1]) sizes[u++] = sizes[i];
+    A = u + 1;
+    int* bps = malloc(sizeof(int)*A); bps[0] = eb->ref_allele; memcpy(bps+1, sizes, sizeof(int)*u);
+    const size_t Rn = (size_t)(R > 0 ? R : 1);
+    int* ai = malloc(sizeof(int)*Rn);
+    for (int r = 0; r < R; r++) for (int a = 0; a < A; a++) if (bps[a] == nb[r]){ ai[r] = a; break; }
+    int* per_sample = calloc(S, sizeof(int)); for (int r = 0; r < R; r++) per_sample[lab[r]]++;
+    double* gtp = malloc(sizeof(double)*A);
+    double* post = malloc(sizeof(double)*(size_t)S*A*A); double* prior = malloc(sizeof(double)*(size_t)S*A*A);
+    double* LLm = malloc(sizeof(double)*Rn*A); double* totals = malloc(sizeof(double)*S);
+    double* phase = malloc(sizeof(double)*Rn*A*A*2);
+    int32_t* mapgt = malloc(sizeof(int32_t)*2*S); int32_t* w = malloc(sizeof(int32_t)*Rn);
+    for (int r = 0; r < R; r++) w[r] = 1;
+    /* init_log_gt_priors (:10-20) */
+    for (int a = 0; a < A; a++) gtp[a] = 1;
+    for (int r = 0; r < R; r++) gtp[ai[r]] += 1.0/per_sample[lab[r]];
+    { double tot = 0; for (int a = 0; a < A; a++) tot += gtp[a]; double lt = log(tot); for (int a = 0; a < A; a++) gtp[a] = log(gtp[a]) - lt; }
+    OModel m = { 0.9, 0.1, 0.1, 0.8, 0.01, 0.01 };                       /* init_stutter_model (:59-62) */
+    int it = 1, ok = 0, done = 0; double LL = -DBL_MAX, new_LL = 0;
+    int32_t one_A = A, one_S = S, roff[2] = { 0, R }; uint8_t hp = (uint8_t)hap;
+    while (it <= eb->max_iter && !done){
+      double sp[6] = { m.in_geom, m.in_up, m.in_down, m.out_geom, m.out_up, m.out_down };
+      /* E-step: calc_hap_aln_probs (:146-150), priors (:129-144), posteriors, read phase posteriors (:152-169) */
+      for (int r = 0; r < R; r++) for (int a = 0; a < A; a++) LLm[(size_t)r*A + a] = oracle_stutter_pmf(sp, p, bps[a], bps[ai[r]]);
+      for (int s = 0; s < S; s++) for (int i1 = 0; i1 < A; i1++) for (int i2 = 0; i2 < A; i2++)
+        prior[((size_t)s*A + i1)*A + i2] = !hap ? gtp[i1] + gtp[i2] : (i1 == i2 ? gtp[i1] : -DBL_MAX/2);
+      hipstr_post_batch_t pb = { 1, &one_A, &one_S, roff, lab, lp1, lp2, w, LLm, &hp, prior };
+      double ltot;
+      oracle_posteriors(&pb, post, totals, mapgt, &ltot);
+      new_LL = ltot;
+      for (int r = 0; r < R; r++) for (int i1 = 0; i1 < A; i1++) for (int i2 = 0; i2 < A; i2++){
+        double one = g_log_half + lp1[r] + oracle_stutter_pmf(sp, p, bps[i1], bps[ai[r]]);
+        double two = g_log_half + lp2[r] + oracle_stutter_pmf(sp, p, bps[i2], bps[ai[r]]);
+        double tot = oracle_fast_lse2(one, two);
+        double* ph = phase + (((size_t)r*A + i1)*A + i2)*2;
+        ph[0] = one - tot; ph[1] = two - tot;
+      }
+      if (new_LL < LL + 1e-10){ ok = 1; break; }                          /* :190-194 */
+      /* M-step: recalc_log_gt_priors (:22-57) */
+      {
+        double* mx = malloc(sizeof(double)*A); double* tt = malloc(sizeof(double)*A);
+        for (int a = 0; a < A; a++){ mx[a] = -DBL_MAX/2; tt[a] = 0; }
+        for (int s = 0; s < S; s++) for (int i1 = 0; i1 < A; i1++)
+          stream_update(oracle_log_sum_exp(post + ((size_t)s*A + i1)*A, A), &mx[i1], &tt[i1]);
+        for (int s = 0; s < S; s++) for (int i1 = 0; i1 < A; i1++) for (int i2 = 0; i2 < A; i2++)
+          stream_update(post[((size_t)s*A + i1)*A + i2], &mx[i2], &tt[i2]);
+        for (int a = 0; a < A; a++) gtp[a] = mx[a] + log(tt[a]);
+        double lt = oracle_log_sum_exp(gtp, A);
+        for (int a = 0; a < A; a++) gtp[a] -= lt;
+        free(mx); free(tt);
+      }
+      /* recalc_stutter_model (:64-127) */
+      OModel prev = m;
+      {
+        size_t cap = (size_t)R*A*A*2 + 4;
+        double* v[7]; size_t n[7];                   /* in_up, in_down, in_eq, in_diffs, out_up, out_down, out_diffs */
+        for (int k = 0; k < 7; k++){ v[k] = malloc(sizeof(double)*cap); n[k] = 0; }
+        v[0][n[0]++] = 0.0; v[1][n[1]++] = 0.0; v[3][n[3]++] = 0.0; v[3][n[3]++] = log(1.1);
+        v[4][n[4]++] = 0.0; v[5][n[5]++] = 0.0; v[6][n[6]++] = 0.0; v[6][n[6]++] = log(1.1);
+        v[2][n[2]++] = 0.0;
+        for (int r = 0; r < R; r++){
+          const double* gp = post + (size_t)lab[r]*A*A;
+          for (int i1 = 0; i1 < A; i1++) for (int i2 = 0; i2 < A; i2++) for (int ph = 0; ph < 2; ph++){
+            int gi = ph == 0 ? i1 : i2;
+            int bd = bps[ai[r]] - bps[gi];
+            double f = gp[(size_t)i1*A + i2] + phase[(((size_t)r*A + i1)*A + i2)*2 + ph];
+            if (bd == 0) v[2][n[2]++] = f;
+            else if (bd % p != 0){
+              int eff = bd - bd/p;
+              v[6][n[6]++] = f + g_int_log[abs(eff)];
+              if (bd > 0) v[4][n[4]++] = f; else v[5][n[5]++] = f;
+            } else {
+              int eff = bd/p;
+              v[3][n[3]++] = f + g_int_log[abs(eff)];
+              if (bd > 0) v[0][n[0]++] = f; else v[1][n[1]++] = f;
+            }
+          }
+        }
+        double t[7];
+        for (int k = 0; k < 7; k++){ t[k] = oracle_fast_lse_vec(v[k], (int)n[k]); free(v[k]); }
+        double out_total = oracle_fast_lse2(t[4], t[5]);
+        double in_pgeom = fmin(0.999, exp(exact_lse2(t[0], t[1]) - t[3]));
+        double out_pgeom = fmin(0.999, exp(out_total - t[6]));
+        double mx3 = fmax(fmax(t[0], t[1]), t[2]);
+        double lse3 = mx3 + log(exp(t[0]-mx3) + exp(t[1]-mx3) + exp(t[2]-mx3));       /* mathops.cpp:59-62 */
+        double log_total = exact_lse2(lse3, out_total);
+        m.in_geom = in_pgeom; m.in_up = exp(t[0] - log_total); m.in_down = exp(t[1] - log_total);
+        m.out_geom = out_pgeom; m.out_up = exp(t[4] - log_total); m.out_down = exp(t[5] - log_total);
+      }
+      double abs_change = new_LL - LL, frac_change = -(new_LL - LL)/LL;
+      int conv = 0;
+      if (abs_change < eb->min_ll_abs_change && frac_change < eb->min_ll_frac_change) conv = 1;
+      else if (fabs(prev.in_geom - m.in_geom) < 0.0001 && fabs(prev.in_up - m.in_up) < 0.0001 && fabs(prev.in_down - m.in_down) < 0.0001 &&
+               fabs(prev.out_geom - m.out_geom) < 0.0001 && fabs(prev.out_up - m.out_up) < 0.0001 && fabs(prev.out_down - m.out_down) < 0.0001) conv = 1;
+      if (conv){ ok = 1; done = 1; break; }
+      LL = new_LL; it++;
+    }
+    trained[l] = (uint8_t)ok;
+    n_iter[l] = it <= eb->max_iter ? it : eb->max_iter;
+    final_ll[l] = new_LL;
+    stutter[6*l] = m.in_geom; stutter[6*l+1] = m.in_up; stutter[6*l+2] = m.in_down; stutter[6*l+3] = m.out_geom; stutter[6*l+4] = m.out_up; stutter[6*l+5] = m.out_down;
+    free(sizes); free(bps); free(ai); free(per_sample); free(gtp); free(post); free(prior); free(LLm); free(totals); free(phase); free(mapgt); free(w);
+  }
+  return 0;
+}
+
 /* ---------------------------------------------- genotype calls (A.9)
  * Genotyper::extract_genotypes_and_likelihoods (genotyper.cpp:129-251), calc_PLs (99-104), calc_gl_diff (106-127). */
 static void stream_update(double lv, double* mx, double* tot){          /* mathops.cpp:72-80 */

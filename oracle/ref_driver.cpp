@@ -16,6 +16,7 @@
  */
 #include <cstdio>
 #include <cstring>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -34,6 +35,7 @@
 #include "SeqAlignment/RepeatBlock.h"
 #include "base_quality.h"
 #include "genotyper.h"
+#include "em_stutter_genotyper.h"
 #include "mathops.h"
 #include "stutter_model.h"
 #include "fastonebigheader.h"
@@ -279,6 +281,49 @@ extern "C" int ref_gt_extract(const hipstr_post_batch_t* pb, const hipstr_gt_req
     gt.run(pb->log_aln_probs + ll_off, pb->read_weight + r0, post.data(), totals.data(), map_gt.data());
     gt.extract(rq->n_variants[l], rq->hap_to_allele + map_off, rq, o, samp_off, g, pg);
     samp_off += S; map_off += A; ll_off += (int64_t)(r1-r0)*A;
+  }
+  return 0;
+}
+
+/* ---- EM stutter training: EMStutterGenotyper::train on the reference's own class ---- */
+namespace {
+class EMProbe : public EMStutterGenotyper {       // reads the protected per-sample totals the last E-step left behind
+ public:
+  EMProbe(bool haploid, int motif, const std::vector< std::vector<int> >& bps, const std::vector< std::vector<double> >& p1,
+          const std::vector< std::vector<double> >& p2, const std::vector<std::string>& names, int ref_allele)
+    : EMStutterGenotyper(haploid, motif, bps, p1, p2, names, ref_allele) {}
+  double last_total() const { double t = 0; for (int s = 0; s < num_samples_; s++) t += sample_total_LLs_[s]; return t; }   // genotyper.cpp:75
+};
+}
+extern "C" int ref_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, double* stutter, int32_t* n_iter, double* final_ll){
+  ensure_ready();
+  for (int l = 0; l < eb->n_loci; l++){
+    const int S = eb->n_samples[l], r0 = eb->read_off[l], r1 = eb->read_off[l+1];
+    std::vector< std::vector<int> > bps(S);
+    std::vector< std::vector<double> > p1(S), p2(S);
+    std::vector<std::string> names;
+    for (int s = 0; s < S; s++){ char buf[32]; snprintf(buf, sizeof buf, "S%d", s); names.push_back(buf); }
+    for (int r = r0; r < r1; r++){
+      const int s = eb->sample_label[r];
+      bps[s].push_back(eb->num_bps[r]); p1[s].push_back(eb->log_p1[r]); p2[s].push_back(eb->log_p2[r]);
+    }
+    EMProbe g(eb->haploid ? eb->haploid[l] != 0 : false, eb->period[l], bps, p1, p2, names, eb->ref_allele);
+    std::ostringstream log;
+    const bool ok = g.train(eb->max_iter, eb->min_ll_abs_change, eb->min_ll_frac_change, true, log);
+    trained[l] = ok ? 1 : 0;
+    StutterModel* m = g.get_stutter_model();
+    stutter[6*l+0] = m->get_parameter(true, 'P');  stutter[6*l+1] = m->get_parameter(true, 'U');  stutter[6*l+2] = m->get_parameter(true, 'D');
+    stutter[6*l+3] = m->get_parameter(false, 'P'); stutter[6*l+4] = m->get_parameter(false, 'U'); stutter[6*l+5] = m->get_parameter(false, 'D');
+    // iteration count and last LL: train() keeps them in locals but prints them when disp_stats is on ("Iteration k: LL = x")
+    int it = 0; double ll = 0;
+    const std::string txt = log.str();
+    for (size_t pos = txt.find("Iteration "); pos != std::string::npos; pos = txt.find("Iteration ", pos + 1)){
+      int k; double v;
+      if (sscanf(txt.c_str() + pos, "Iteration %d: LL = %lf", &k, &v) == 2){ it = k; ll = v; }
+    }
+    n_iter[l] = it;
+    // the stream prints 6 significant digits; the exact value of the last E-step is still in the object (genotyper.cpp:75)
+    final_ll[l] = g.last_total(); (void)ll;
   }
   return 0;
 }

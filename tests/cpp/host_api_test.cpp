@@ -3,6 +3,7 @@
 //   host_api_test --gpu      + HapAligner::process_reads, calc_hap_aln_probs, Genotyper posteriors on the device
 // Prints "key value..." lines that tests/test_host_api.py compares with the golden vectors of SURVEY.md §8(c).
 #include <cstdio>
+#include <iostream>
 #include <cstring>
 #include "hipstr_hmm.hpp"
 using namespace hipstr_amd;
@@ -118,5 +119,20 @@ int main(int argc, char** argv){
   p1[0] = std::vector<double>{0, -0.01, 0}; p2[0] = std::vector<double>{0, -5, 0}; p1[1] = std::vector<double>{0, 0}; p2[1] = std::vector<double>{0, 0};
   ProbeGenotyper g(false, names, p1, p2, 3, LL);
   g.run();
+
+  // de novo stutter model from read lengths (EMStutterGenotyper): 4 samples, period 4
+  {
+    const int sizes[4][8] = {{0,0,4,4,0,-4,4,0}, {8,8,8,4,8,0,0,0}, {-4,-4,-8,-4,0,0,1,0}, {0,4,0,4,8,4,0,-4}};
+    const int cnt[4] = {8, 6, 7, 8};
+    std::vector< std::vector<int> > bps(4); std::vector< std::vector<double> > e1(4), e2(4); std::vector<std::string> nm;
+    for (int s = 0; s < 4; s++){
+      nm.push_back("s");
+      for (int j = 0; j < cnt[s]; j++){ bps[s].push_back(sizes[s][j]); e1[s].push_back(j % 3 == 0 ? -0.02 : 0.0); e2[s].push_back(j % 3 == 0 ? -3.5 : 0.0); }
+    }
+    EMStutterGenotyper em(false, 4, bps, e1, e2, nm, 0);
+    const bool ok = em.train(100, 0.01, 0.001, false, std::cerr);
+    const double* q = em.get_stutter_model()->parameters();
+    printf("em %d %d %.15f %.15f %.15f %.15f %.15f %.15f %.12f\n", ok ? 1 : 0, em.num_iterations(), q[0], q[1], q[2], q[3], q[4], q[5], em.final_LL());
+  }
   return 0;
 }

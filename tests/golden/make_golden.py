@@ -108,6 +108,17 @@ def main():
         np.savez_compressed(os.path.join(HERE, "gt_%s.npz" % name), **out)
         print("gt", name, "samples", len(e["gl_diff"]), "GLs", sum(len(x) for x in e["gls"]))
 
+    # de novo stutter EM (EMStutterGenotyper::train) on seeded length data
+    from em_cases import em_case
+    for name, kw in dict(small=em_case(1, n_loci=6), haploid_mix=em_case(2, n_loci=6, haploid_rate=0.6),
+                         deep=em_case(3, n_loci=3, samples=(40, 60), reads_per_sample=(4, 10)),
+                         no_snps=em_case(4, n_loci=5, snp_rate=0.0), few_iter=dict(em_case(5, n_loci=4), max_iter=3)).items():
+        tr, st, it, ll = capi.run_em(ref, "ref_", **kw)
+        out = {k: np.asarray(v) for k, v in kw.items()}
+        out.update(expect_trained=tr, expect_stutter=st, expect_n_iter=it, expect_final_ll=ll)
+        np.savez_compressed(os.path.join(HERE, "em_%s.npz" % name), **out)
+        print("em", name, "loci", len(it), "iterations", list(it), "trained", list(tr.astype(int)))
+
     # scalar probes: constant tables and the float log-sum-exp approximations
     f64p = capi._f64p
     vals = {}

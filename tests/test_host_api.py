@@ -72,3 +72,13 @@ def test_device_parts(_native_built):
             exp += [g, p]
         exp += list(want["phased_gls"][s])
         assert len(vals) == len(exp) and all(abs(a - b) < 1e-9 * max(1, abs(b)) for a, b in zip(vals, exp))
+    # EMStutterGenotyper through the C++ class against the oracle on the same reads
+    sizes = [[0, 0, 4, 4, 0, -4, 4, 0], [8, 8, 8, 4, 8, 0], [-4, -4, -8, -4, 0, 0, 1], [0, 4, 0, 4, 8, 4, 0, -4]]
+    lab, bps, p1, p2 = [], [], [], []
+    for s, row in enumerate(sizes):
+        for j, b in enumerate(row):
+            lab.append(s); bps.append(b); p1.append(-0.02 if j % 3 == 0 else 0.0); p2.append(-3.5 if j % 3 == 0 else 0.0)
+    tr, st, it, ll = capi.run_em(capi.load_oracle(), "oracle_", [4], [4], [0, len(lab)], lab, bps, p1, p2, haploid=[0])
+    row = kv["em"][0]
+    assert int(row[0]) == int(tr[0]) and int(row[1]) == int(it[0])
+    assert all(abs(float(a) - b) < 1e-9 for a, b in zip(row[2:8], st[0])) and abs(float(row[8]) - ll[0]) < 1e-9 * max(1, abs(ll[0]))
