@@ -42,6 +42,50 @@ class HipstrPostBatch(C.Structure):
     ]
 
 
+class HipstrNwBatch(C.Structure):
+    _fields_ = [("n_pairs", C.c_int32), ("ref_off", _i32p), ("ref_seqs", C.c_char_p), ("read_off", _i32p), ("read_seqs", C.c_char_p),
+                ("use_ref_end_penalty", C.c_int32)]
+
+
+class HipstrNwOut(C.Structure):
+    _fields_ = [("score", C.POINTER(C.c_float)), ("ok", _u8p), ("aln_off", C.POINTER(C.c_int64)), ("ref_al", C.c_char_p), ("read_al", C.c_char_p),
+                ("cigar_off", C.POINTER(C.c_int64)), ("cigar_op", C.c_char_p), ("cigar_len", _i32p), ("cap_aln", C.c_int64), ("cap_cigar", C.c_int64)]
+
+
+def run_nw(lib, prefix, pairs, use_ref_end_penalty=False, unpack=True, timing=None):
+    """<prefix>nw_align on [(ref, read), ...] (str) -> list of (score, ok, ref_al, read_al, cigar string)."""
+    import time
+    n = len(pairs)
+    refs = [r.encode() for r, _ in pairs]; reads = [q.encode() for _, q in pairs]
+    ro = np.concatenate([[0], np.cumsum([len(r) for r in refs])]).astype(np.int32)
+    qo = np.concatenate([[0], np.cumsum([len(q) for q in reads])]).astype(np.int32)
+    rb = b"".join(refs); qb = b"".join(reads)
+    nb = HipstrNwBatch(n, ro.ctypes.data_as(_i32p), rb, qo.ctypes.data_as(_i32p), qb, int(use_ref_end_penalty))
+    cap = int(ro[-1] + qo[-1] + 16)
+    score = np.zeros(max(n, 1), np.float32); ok = np.zeros(max(n, 1), np.uint8)
+    ao = np.zeros(n + 1, np.int64); co = np.zeros(n + 1, np.int64)
+    ra = C.create_string_buffer(cap); qa = C.create_string_buffer(cap); cop = C.create_string_buffer(cap); cl = np.zeros(cap, np.int32)
+    i64p = C.POINTER(C.c_int64)
+    o = HipstrNwOut(score.ctypes.data_as(C.POINTER(C.c_float)), ok.ctypes.data_as(_u8p), ao.ctypes.data_as(i64p), C.cast(ra, C.c_char_p),
+                    C.cast(qa, C.c_char_p), co.ctypes.data_as(i64p), C.cast(cop, C.c_char_p), cl.ctypes.data_as(_i32p), cap, cap)
+    fn = getattr(lib, prefix + "nw_align")
+    fn.restype = C.c_int; fn.argtypes = [C.POINTER(HipstrNwBatch), C.POINTER(HipstrNwOut)]
+    t0 = time.perf_counter()
+    rc = fn(C.byref(nb), C.byref(o))
+    if timing is not None:
+        timing["call_s"] = timing.get("call_s", 0.0) + time.perf_counter() - t0
+    if rc != 0:
+        why = lib.hipstr_last_error().decode() if prefix == "hipstr_" else ""
+        raise RuntimeError("%snw_align failed rc=%d %s" % (prefix, rc, why))
+    if not unpack:
+        return None
+    out = []
+    for i in range(n):
+        cig = "".join("%d%s" % (cl[k], cop.raw[k:k + 1].decode()) for k in range(co[i], co[i + 1]))
+        out.append((float(score[i]), bool(ok[i]), ra.raw[ao[i]:ao[i + 1]].decode(), qa.raw[ao[i]:ao[i + 1]].decode(), cig))
+    return out
+
+
 class HipstrEmBatch(C.Structure):
     _fields_ = [("n_loci", C.c_int32), ("period", _i32p), ("haploid", _u8p), ("n_samples", _i32p), ("read_off", _i32p), ("sample_label", _i32p),
                 ("num_bps", _i32p), ("log_p1", _f64p), ("log_p2", _f64p), ("ref_allele", C.c_int32), ("max_iter", C.c_int32),
@@ -206,6 +250,19 @@ def ref_hap_aln_info(ref, bptr, n_alleles, cap=1 << 20):
     if rc != 0:
         raise RuntimeError("ref_hap_aln_info rc=%d" % rc)
     return [buf.raw[offs[k]:offs[k + 1] - 1] for k in range(n_alleles)]
+
+
+def hap_aln_info(lib, prefix, bptr, cap=1 << 22):
+    """<prefix>hap_aln_info: Haplotype::get_aln_info() of every haplotype of every locus of a batch (list of bytes)."""
+    b = bptr.contents if hasattr(bptr, "contents") else (bptr._obj if hasattr(bptr, "_obj") else bptr)
+    n = int(np.ctypeslib.as_array(b.hap_off, shape=(b.n_loci + 1,))[-1])
+    fn = getattr(lib, prefix + "hap_aln_info")
+    fn.restype = C.c_int; fn.argtypes = [_BP, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]
+    buf = C.create_string_buffer(cap); offs = np.zeros(n + 1, np.int64)
+    rc = fn(bptr, buf, cap, offs.ctypes.data_as(C.POINTER(C.c_int64)))
+    if rc != 0:
+        raise RuntimeError("%shap_aln_info failed rc=%d" % (prefix, rc))
+    return [buf.raw[offs[k]:offs[k + 1] - 1] for k in range(n)]
 
 
 def _ptr(a, typ):

@@ -246,6 +246,42 @@ typedef struct hipstr_em_batch {
 int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, double* stutter, int32_t* n_iter, double* final_ll);
 
 /*
+ * Needleman-Wunsch with affine gaps: NeedlemanWunsch::Align (NeedlemanWunsch.cpp:370-420: initMatrices 326-367, nw_helper 195-245,
+ * findOptimalStop 142-171 / findOptimalStopEndPenalty 173-193, traceAlignment 247-324) for a batch of (reference, read) pairs —
+ * the step before the HMM: realign() aligns every unique read to its reference window (AlignmentOps.cpp:14-26,
+ * genotyper_bam_processor.cpp:68) and Haplotype::aln_haps_to_ref aligns every haplotype to the reference haplotype with the
+ * end penalty (Haplotype.cpp:58-86).  Scores are float sums of 2, -2, -5 and -0.125, exact in any order; ties are broken as
+ * bestIndex does (NeedlemanWunsch.cpp:120-140).  Limits: second sequence <= 1536 bases, reference <= 4095.
+ */
+typedef struct hipstr_nw_batch {
+  int32_t        n_pairs;
+  const int32_t* ref_off;        /* [n_pairs+1] into ref_seqs                                                        */
+  const char*    ref_seqs;
+  const int32_t* read_off;       /* [n_pairs+1] into read_seqs                                                       */
+  const char*    read_seqs;
+  int32_t        use_ref_end_penalty;
+} hipstr_nw_batch_t;
+typedef struct hipstr_nw_out {
+  float*   score;                /* [n_pairs]                                                                         */
+  uint8_t* ok;                   /* [n_pairs] the return value of Align                                               */
+  int64_t* aln_off;              /* [n_pairs+1]: ref_seq_al / read_seq_al of pair i occupy [aln_off[i], aln_off[i+1])  */
+  char*    ref_al;
+  char*    read_al;
+  int64_t* cigar_off;            /* [n_pairs+1]                                                                       */
+  char*    cigar_op;             /* '=', 'X', 'I', 'D'                                                                */
+  int32_t* cigar_len;
+  int64_t  cap_aln, cap_cigar;   /* capacities of the pools                                                           */
+} hipstr_nw_out_t;
+int hipstr_nw_align(const hipstr_nw_batch_t* nb, hipstr_nw_out_t* out);
+
+/* Haplotype::get_aln_info() of every haplotype of every locus (Haplotype::aln_haps_to_ref, Haplotype.cpp:58-86): Needleman-Wunsch
+ * of the haplotype against the reference haplotype (all-first-options) with the end penalty, indels in the leading flank pushed
+ * into the repeat (adjust_indels, Haplotype.cpp:8-56), then one of 'M','I','D' per alignment column.  The NUL-terminated string
+ * of haplotype k of locus l starts at out + offs[hap_off[l] + k]; offs has hap_off[n_loci] + 1 entries.  This is the hap_to_ref
+ * input of hipstr_hmm_trace. */
+int hipstr_hap_aln_info(const hipstr_batch_t* batch, char* out, int64_t out_cap, int64_t* offs);
+
+/*
  * Viterbi traceback: HapAligner::trace_optimal_aln (HapAligner.cpp:711-722) = process_read(..., retrace_aln=true) on one
  * fixed haplotype: full M/I/D matrices of both sides, arg-max seed position (compute_aln_logprob's max_index,
  * HapAligner.cpp:184-222), HapAligner::retrace (HapAligner.cpp:363-571) with its 0.001-nat tie tolerances, and — when the

@@ -160,9 +160,9 @@ class Haplotype {
   HapBlock* get_block(int i)   const { return blocks_[i]; }
   HapBlock* get_first_block()  const { return blocks_.front(); }
   HapBlock* get_last_block()   const { return blocks_.back();  }
-  // Haplotype::get_aln_info() (Haplotype.h:65) per haplotype index.  The reference derives these strings while it BUILDS the
-  // haplotype (Needleman-Wunsch of every allele against the reference allele, Haplotype.cpp:58-86) — candidate-allele
-  // generation, outside the alignment hot path — so here they are an input: hand over what that step produced.
+  // Haplotype::get_aln_info() (Haplotype.h:65) per haplotype index.  The reference derives these strings in its constructor
+  // (Needleman-Wunsch of every haplotype against the reference haplotype + adjust_indels, Haplotype.cpp:8-86); here
+  // HapAligner::trace_optimal_alns asks the library for them on first use (hipstr_hap_aln_info).  set_aln_info overrides.
   void set_aln_info(const std::vector<std::string>& hap_aln_info){
     if ((int)hap_aln_info.size() != ncombs_) printErrorAndDie("set_aln_info needs one string per haplotype");
     hap_aln_info_ = hap_aln_info;
@@ -328,6 +328,21 @@ class HapAligner {
     FlatLocus f; f.set_haplotype(fw_haplotype_, realign_to_hap_); f.set_reads(alns, std::vector<bool>(alns.size(), true));
     std::vector<const char*> hap_to_ref;
     size_t chars = 64;
+    if (!fw_haplotype_->has_aln_info()){                     // Haplotype::aln_haps_to_ref (Haplotype.cpp:58-86), once per haplotype set
+      FlatLocus g; g.set_haplotype(fw_haplotype_, realign_to_hap_); g.set_reads(std::vector<Alignment>(), std::vector<bool>());
+      size_t cap = 64;
+      for (int i = 0; i < fw_haplotype_->num_blocks(); i++){
+        size_t longest = 0;
+        for (int o2 = 0; o2 < fw_haplotype_->get_block(i)->num_options(); o2++) longest = std::max(longest, fw_haplotype_->get_block(i)->get_seq(o2).size());
+        cap += 2*longest;
+      }
+      cap = (cap + 1)*(size_t)fw_haplotype_->num_combs();
+      std::vector<char> pool(cap); std::vector<int64_t> offs(fw_haplotype_->num_combs() + 1);
+      if (hipstr_hap_aln_info(g.finish(), pool.data(), (int64_t)cap, offs.data()) != 0) printErrorAndDie(hipstr_last_error());
+      std::vector<std::string> info;
+      for (int k = 0; k < fw_haplotype_->num_combs(); k++) info.push_back(std::string(pool.data() + offs[k]));
+      fw_haplotype_->set_aln_info(info);
+    }
     if (fw_haplotype_->has_aln_info())
       for (int k = 0; k < fw_haplotype_->num_combs(); k++) hap_to_ref.push_back(fw_haplotype_->get_aln_info(k).c_str());
     for (int i = 0; i < n; i++)

@@ -710,6 +710,153 @@ int oracle_posteriors(const hipstr_post_batch_t* pb, double* log_post, double* s
 
 /* test hook: homopolymer index per matrix row (both sides) as in effect when allele k of a one-locus,
  * one-read batch is scored (rows of blocks that were reused keep the values of the allele they were computed under) */
+/* ---------------------------------------------- Needleman-Wunsch (A.11)
+ * NeedlemanWunsch::Align (NeedlemanWunsch.cpp:370-420) and its helpers; float arithmetic as in the reference. */
+static int nw_base(char c){                                       /* base_to_int (NeedlemanWunsch.cpp:98-118) */
+  switch (c){ case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
+}
+static float nw_best(float s1, float s2, float s3, int* c){        /* bestIndex (:120-140) */
+  if (s2 > s1){ if (s2 > s3){ *c = 1; return s2; } *c = 2; return s3; }
+  if (s3 > s1){ *c = 2; return s3; }
+  *c = 0; return s1;
+}
+int oracle_nw_align(const hipstr_nw_batch_t* nb, hipstr_nw_out_t* o){
+  const float MATCH = 2.0f, MISMATCH = -2.0f, GAPOPEN = 5.0f, GAPEXTEND = 0.125f, LARGE = 1000000.0f;
+  o->aln_off[0] = 0; o->cigar_off[0] = 0;
+  for (int p = 0; p < nb->n_pairs; p++){
+    const char* ref = nb->ref_seqs + nb->ref_off[p]; int L1 = nb->ref_off[p+1] - nb->ref_off[p];
+    const char* rd = nb->read_seqs + nb->read_off[p]; int L2 = nb->read_off[p+1] - nb->read_off[p];
+    size_t W = (size_t)L1 + 1, sz = W*((size_t)L2 + 1);
+    float* M = malloc(sizeof(float)*sz); float* R = malloc(sizeof(float)*sz); float* D = malloc(sizeof(float)*sz);
+    int8_t* tM = malloc(sz); int8_t* tR = malloc(sz); int8_t* tD = malloc(sz);
+    M[0] = 0.0f; R[0] = -LARGE; D[0] = -LARGE;                       /* initMatrices (:326-367) */
+    for (int j = 1; j <= L1; j++){
+      R[j] = !nb->use_ref_end_penalty ? 0.0f : -GAPOPEN - (j-1)*GAPEXTEND; tR[j] = 1;
+      D[j] = -LARGE; tD[j] = -1; M[j] = -LARGE; tM[j] = -1;
+    }
+    for (int i = 1; i <= L2; i++){
+      size_t x = (size_t)i*W;
+      D[x] = -GAPOPEN - (i-1)*GAPEXTEND; tD[x] = 2; R[x] = -LARGE; tR[x] = -1; M[x] = -LARGE; tM[x] = -1;
+    }
+    for (int i = 1; i <= L2; i++){                                   /* nw_helper (:195-245) */
+      int rb = nw_base(rd[i-1]);
+      for (int j = 1; j <= L1; j++){
+        size_t n = (size_t)i*W + j, od = n - W - 1, ol = n - 1, ou = n - W;
+        int fb = nw_base(ref[j-1]), c;
+        float sc = (fb == 4 || rb == 4 || fb == rb) ? MATCH : MISMATCH;
+        M[n] = nw_best(M[od], R[od], D[od], &c) + sc; tM[n] = (int8_t)c;
+        R[n] = nw_best(M[ol] - GAPOPEN, R[ol] - GAPEXTEND, D[ol] - GAPOPEN, &c); tR[n] = (int8_t)c;
+        D[n] = nw_best(M[ou] - GAPOPEN, R[ou] - GAPOPEN, D[ou] - GAPEXTEND, &c); tD[n] = (int8_t)c;
+      }
+    }
+    float best_val; int best_col, best_type;
+    if (nb->use_ref_end_penalty){                                    /* findOptimalStopEndPenalty (:173-193) */
+      size_t x = sz - 1; best_col = L1; best_val = M[x]; best_type = 0;
+      if (R[x] > best_val){ best_val = R[x]; best_type = 1; }
+      if (D[x] > best_val){ best_val = D[x]; best_type = 2; }
+    } else {                                                         /* findOptimalStop (:142-171) */
+      best_val = -LARGE; best_col = -1; best_type = -1;
+      for (int j = 0; j <= L1; j++){
+        size_t x = (size_t)L2*W + j;
+        if (M[x] >= best_val){ best_val = M[x]; best_col = j; best_type = 0; }
+        if (R[x] > best_val){ best_val = R[x]; best_col = j; best_type = 1; }
+        if (D[x] > best_val){ best_val = D[x]; best_col = j; best_type = 2; }
+      }
+    }
+    o->score[p] = best_val;
+    /* traceAlignment (:247-324): built back to front */
+    size_t cap = (size_t)L1 + L2 + 2; char* ra = malloc(cap); char* qa = malloc(cap); char* raw = malloc(cap);
+    size_t na = 0, nr = 0;
+    for (int j = L1; j > best_col; j--){ ra[na] = ref[j-1]; qa[na++] = '-'; }
+    int row = L2, col = best_col, type = best_type, bad = 0;
+    while (row > 0){
+      size_t x = (size_t)row*W + col;
+      if (type == 0){
+        ra[na] = ref[col-1]; qa[na++] = rd[row-1];
+        raw[nr++] = nw_base(ref[col-1]) == nw_base(rd[row-1]) ? '=' : 'X';
+        type = tM[x]; row--; col--;
+      } else if (type == 1){ ra[na] = ref[col-1]; qa[na++] = '-'; raw[nr++] = 'D'; type = tR[x]; col--; }
+      else if (type == 2){ ra[na] = '-'; qa[na++] = rd[row-1]; raw[nr++] = 'I'; type = tD[x]; row--; }
+      else { bad = 1; break; }
+    }
+    for (int j = col; j > 0; j--){ ra[na] = ref[j-1]; qa[na++] = '-'; }
+    int rc = 0;
+    if (bad || o->aln_off[p] + (int64_t)na > o->cap_aln) rc = 3;
+    else {
+      for (size_t k = 0; k < na; k++){ o->ref_al[o->aln_off[p] + k] = ra[na-1-k]; o->read_al[o->aln_off[p] + k] = qa[na-1-k]; }
+      o->aln_off[p+1] = o->aln_off[p] + (int64_t)na;
+      int64_t co = o->cigar_off[p];
+      for (size_t k = nr; k > 0; ){                                  /* run-length encode the reversed raw string */
+        char ch = raw[k-1]; int num = 0;
+        while (k > 0 && raw[k-1] == ch){ num++; k--; }
+        if (co >= o->cap_cigar){ rc = 3; break; }
+        o->cigar_op[co] = ch; o->cigar_len[co++] = num;
+      }
+      o->cigar_off[p+1] = co;
+      o->ok[p] = 1;                                                  /* the CIGAR never holds 'S' (:413-415) */
+    }
+    free(M); free(R); free(D); free(tM); free(tR); free(tD); free(ra); free(qa); free(raw);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+/* Haplotype::aln_haps_to_ref + adjust_indels (Haplotype.cpp:8-86) -> get_aln_info() of every haplotype */
+int oracle_hap_aln_info(const hipstr_batch_t* b, char* out, int64_t out_cap, int64_t* offs){
+  int64_t pos = 0; int hi = 0, opt_cursor = 0;
+  offs[0] = 0;
+  for (int l = 0; l < b->n_loci; l++){
+    const int32_t* nopts = b->blk_nopts + 3*l;
+    int base[3]; for (int k = 0; k < 3; k++){ base[k] = opt_cursor; opt_cursor += nopts[k]; }
+    int A = nopts[0]*nopts[1]*nopts[2];
+    int rl = 0; for (int k = 0; k < 3; k++) rl += b->opt_off[base[k]+1] - b->opt_off[base[k]];
+    char* ref = malloc(rl + 1); int rp = 0;
+    for (int k = 0; k < 3; k++){ int n = b->opt_off[base[k]+1] - b->opt_off[base[k]]; memcpy(ref + rp, b->seq + b->opt_off[base[k]], n); rp += n; }
+    for (int k = 0; k < A; k++, hi++){
+      int32_t oi[3]; oracle_allele_options(nopts, k, oi);
+      int al = 0; for (int x = 0; x < 3; x++) al += b->opt_off[base[x]+oi[x]+1] - b->opt_off[base[x]+oi[x]];
+      char* alt = malloc(al + 1); int ap = 0;
+      for (int x = 0; x < 3; x++){ int o = base[x]+oi[x], n = b->opt_off[o+1] - b->opt_off[o]; memcpy(alt + ap, b->seq + b->opt_off[o], n); ap += n; }
+      int32_t ro[2] = { 0, rl }, ao[2] = { 0, al };
+      hipstr_nw_batch_t nb = { 1, ro, ref, ao, alt, 1 };
+      int64_t cap = (int64_t)rl + al + 8;
+      float score; uint8_t ok; int64_t aoff[2], coff[2];
+      char* ra = malloc(cap); char* qa = malloc(cap); char* cop = malloc(cap); int32_t* cl = malloc(sizeof(int32_t)*cap);
+      hipstr_nw_out_t o = { &score, &ok, aoff, ra, qa, coff, cop, cl, cap, cap };
+      int rc = oracle_nw_align(&nb, &o);
+      int64_t n = aoff[1];
+      if (rc == 0){                                                  /* adjust_indels (Haplotype.cpp:8-56) */
+        int32_t ref_pos = b->blk_start[3*l], str_pos = b->blk_start[3*l+1];
+        int64_t x = 0;
+        while (x < n){
+          if (qa[x] == '-' && ref_pos < str_pos){
+            int64_t idx = x; while (idx < n && qa[idx] == '-') idx++;
+            int32_t p2 = ref_pos; int64_t di = x; int32_t dsz = (int32_t)(idx - x);
+            while (idx < n && p2 < str_pos && ra[di] == ra[idx]){ qa[di] = qa[idx]; qa[idx] = '-'; idx++; di++; p2++; }
+            x = idx; ref_pos = p2 + dsz;
+          } else if (ra[x] == '-' && ref_pos < str_pos){
+            int64_t idx = x; while (idx < n && ra[idx] == '-') idx++;
+            int32_t p2 = ref_pos; int64_t ii = x;
+            while (idx < n && p2 < str_pos && qa[ii] == qa[idx]){ ra[ii] = ra[idx]; ra[idx] = '-'; idx++; ii++; p2++; }
+            x = idx; ref_pos = p2;
+          } else { if (ra[x] != '-') ref_pos++; x++; }
+        }
+        if (pos + n + 1 > out_cap) rc = 2;
+        else {
+          offs[hi] = pos;
+          for (int64_t y = 0; y < n; y++) out[pos++] = ra[y] == '-' ? 'I' : (qa[y] == '-' ? 'D' : 'M');
+          out[pos++] = 0;
+        }
+      }
+      free(alt); free(ra); free(qa); free(cop); free(cl);
+      if (rc){ free(ref); return rc; }
+    }
+    free(ref);
+  }
+  offs[hi] = pos;
+  return 0;
+}
+
 /* ---------------------------------------------- de novo stutter EM (A.10)
  * EMStutterGenotyper (em_stutter_genotyper.h:55-102, em_stutter_genotyper.cpp:10-226), one locus at a time. */
 static void stream_update(double lv, double* mx, double* tot);

@@ -31,6 +31,7 @@
 #include "SeqAlignment/HapAligner.h"
 #undef private
 #include "SeqAlignment/HapBlock.h"
+#include "SeqAlignment/NeedlemanWunsch.h"
 #include "SeqAlignment/Haplotype.h"
 #include "SeqAlignment/RepeatBlock.h"
 #include "base_quality.h"
@@ -281,6 +282,24 @@ extern "C" int ref_gt_extract(const hipstr_post_batch_t* pb, const hipstr_gt_req
     gt.run(pb->log_aln_probs + ll_off, pb->read_weight + r0, post.data(), totals.data(), map_gt.data());
     gt.extract(rq->n_variants[l], rq->hap_to_allele + map_off, rq, o, samp_off, g, pg);
     samp_off += S; map_off += A; ll_off += (int64_t)(r1-r0)*A;
+  }
+  return 0;
+}
+
+/* ---- Needleman-Wunsch: NeedlemanWunsch::Align on the reference's own code ---- */
+extern "C" int ref_nw_align(const hipstr_nw_batch_t* nb, hipstr_nw_out_t* o){
+  o->aln_off[0] = 0; o->cigar_off[0] = 0;
+  for (int i = 0; i < nb->n_pairs; i++){
+    const std::string ref(nb->ref_seqs + nb->ref_off[i], nb->ref_off[i+1] - nb->ref_off[i]);
+    const std::string rd(nb->read_seqs + nb->read_off[i], nb->read_off[i+1] - nb->read_off[i]);
+    std::string ra, qa; float score = 0; std::vector<CigarOp> cig;
+    const bool ok = NeedlemanWunsch::Align(ref, rd, ra, qa, &score, cig, nb->use_ref_end_penalty != 0);
+    o->score[i] = score; o->ok[i] = ok ? 1 : 0;
+    if (o->aln_off[i] + (int64_t)ra.size() > o->cap_aln || o->cigar_off[i] + (int64_t)cig.size() > o->cap_cigar) return 3;
+    memcpy(o->ref_al + o->aln_off[i], ra.data(), ra.size()); memcpy(o->read_al + o->aln_off[i], qa.data(), qa.size());
+    o->aln_off[i+1] = o->aln_off[i] + (int64_t)ra.size();
+    for (size_t k = 0; k < cig.size(); k++){ o->cigar_op[o->cigar_off[i] + k] = cig[k].Type; o->cigar_len[o->cigar_off[i] + k] = cig[k].Length; }
+    o->cigar_off[i+1] = o->cigar_off[i] + (int64_t)cig.size();
   }
   return 0;
 }

@@ -110,6 +110,14 @@ int main(int argc, char** argv){
     AlignmentTrace* one = aligner.trace_optimal_aln(alns[0], seeds[0], 1, &bq);
     printf("trace_one %s\n", one->hap_aln().c_str());
     delete one;
+    // the same haplotype set without handing the strings in: the library derives them (NW + adjust_indels)
+    Haplotype hap2(blocks);
+    HapAligner aligner2(&hap2, all_haps);
+    AlignmentTrace* two = aligner2.trace_optimal_aln(alns[0], seeds[0], 2, &bq);
+    printf("aln_info_derived");
+    for (int k = 0; k < 4; k++) printf(" %s", hap2.get_aln_info(k).c_str());
+    printf("\ntrace_two %d %d %s\n", two->traced_aln().get_start(), two->traced_aln().get_stop(), two->traced_aln().getCigarString().c_str());
+    delete two;
   }
 
   // posteriors: SURVEY §8(c) second known-answer vector

@@ -119,6 +119,17 @@ def main():
         np.savez_compressed(os.path.join(HERE, "em_%s.npz" % name), **out)
         print("em", name, "loci", len(it), "iterations", list(it), "trained", list(tr.astype(int)))
 
+    # Needleman-Wunsch (NeedlemanWunsch::Align), both stop rules
+    import json
+    from nw_cases import nw_pairs
+    for name, (pairs, pen) in dict(reads_vs_window=(nw_pairs(1, n=40), False), haps_vs_ref=(nw_pairs(2, n=30, read_len=(80, 250)), True),
+                                   short_and_n=(nw_pairs(3, n=40, ref_len=(20, 90), read_len=(1, 60)), False),
+                                   no_repeats=(nw_pairs(4, n=20, repeats=False, ns=False), True)).items():
+        e = capi.run_nw(ref, "ref_", pairs, pen)
+        np.savez_compressed(os.path.join(HERE, "nw_%s.npz" % name), pairs=np.frombuffer(json.dumps(pairs).encode(), np.uint8).copy(),
+                            end_penalty=np.array([int(pen)]), expect=np.frombuffer(json.dumps(e).encode(), np.uint8).copy())
+        print("nw", name, "pairs", len(pairs), "with indels", sum(("I" in x[4] or "D" in x[4]) for x in e))
+
     # scalar probes: constant tables and the float log-sum-exp approximations
     f64p = capi._f64p
     vals = {}

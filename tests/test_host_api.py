@@ -50,6 +50,8 @@ def test_device_parts(_native_built):
         assert got == [e["hap_aln"], str(e["stutter_size"]), e["str_seq"], e["flank_left"], e["flank_right"], str(e["flank_ins"]), str(e["flank_del"]),
                        str(e["aln_start"]), str(e["aln_stop"]), e["cigar"], e["aln_str"]]
     assert kv["trace_one"] == [[rows[1][0]]]
+    assert kv["aln_info_derived"] == [[x.decode() for x in h2r]]          # Haplotype::aln_haps_to_ref done by the library
+    assert kv["trace_two"] == [[rows[2][7], rows[2][8], rows[2][9]]]
     assert kv["kat_seed"] == [["81"]]
     want = [-7.37582683338, -4.37708234692, -7.35198679536, -9.68433975817]
     assert all(abs(float(a) - b) < 5e-11 for a, b in zip(kv["kat_ll"][0], want))
