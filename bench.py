@@ -66,6 +66,44 @@ def cpu_baseline(capi, wl, budget_s=20.0):
                       % (total_aln, P, A, L, total_t)}
 
 
+def pipeline_stages(capi, hmm, sb, loci, P):
+    """Short, separately timed runs of the other device stages of the path on the same kind of data (not part of `value`):
+    Needleman-Wunsch in front of the HMM, the Viterbi traceback behind it, and the de novo stutter EM of BASELINE configs[2]."""
+    import ctypes as C
+    from hipstr_amd import gen
+    out = {}
+    # Needleman-Wunsch: one 150 bp read against a ~300 bp reference window per pair (realign(), AlignmentOps.cpp:14-26)
+    pairs = gen.nw_pairs(7, n=4000, ref_len=(290, 310), read_len=(140, 150))
+    capi.run_nw(hmm, "hipstr_", pairs[:64], False, unpack=False)
+    t = {}
+    capi.run_nw(hmm, "hipstr_", pairs, False, unpack=False, timing=t)
+    out["needleman_wunsch"] = {"pairs_per_s": len(pairs) / t["call_s"], "cells_per_s": sum(len(r) * len(q) for r, q in pairs) / t["call_s"],
+                               "pairs": len(pairs), "shape": "150 bp read x 300 bp window"}
+    # traceback: every seeded read of the first loci against its source allele, alignment strings from the device NW
+    nl = min(loci, 32)
+    seeds = np.zeros(sb.n_reads, np.int32)
+    hmm.hipstr_calc_seed_bases(sb.ptr, seeds.ctypes.data_as(capi._i32p))
+    src = sb.src_allele()
+    rr = [r for r in range(nl * P) if seeds[r] >= 0]; aa = [int(src[r]) for r in rr]
+    t0 = time.perf_counter()
+    h2r = capi.hap_aln_info(hmm, "hipstr_", sb.ptr, cap=1 << 26)
+    t_info = time.perf_counter() - t0
+    capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, rr[:256], aa[:256], h2r, cap=1 << 24, unpack=False)
+    t = {}
+    capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, rr, aa, h2r, cap=1 << 26, timing=t, unpack=False)
+    out["traceback"] = {"tracebacks_per_s": len(rr) / t["call_s"], "requests": len(rr), "loci": nl,
+                        "hap_aln_info_s_all_loci": t_info, "haplotypes": len(h2r)}
+    # de novo stutter EM (configs[2] shape: ~100 samples at low depth per locus)
+    kw = gen.em_case(5, n_loci=64, samples=(90, 100), reads_per_sample=(4, 8))
+    capi.run_em(hmm, "hipstr_", **gen.em_case(6, n_loci=2))
+    t0 = time.perf_counter()
+    tr, st, it, ll = capi.run_em(hmm, "hipstr_", **kw)
+    dt = time.perf_counter() - t0
+    out["stutter_em"] = {"loci_per_s": 64 / dt, "locus_iterations_per_s": float(it.sum()) / dt, "loci": 64, "trained": int(tr.sum()),
+                         "shape": "90-100 samples x 4-8 reads"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +112,7 @@ def main():
     ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
     ap.add_argument("--loci", type=int, default=0, help="override the number of loci per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the short measurements of the stages around the forward pass")
     args = ap.parse_args()
 
     import torch
@@ -212,6 +251,8 @@ def main():
             "host": {"synth_s": t_gen, "prepare_upload_s": t_upload, "fetch_s": t_fetch,
                      "value_incl_prepare_pcie": total_aln / world / (t_upload + elapsed / args.steps + t_fetch) * world},
         }
+        if args.gpus == 1 and not args.no_pipeline:
+            out["pipeline"] = pipeline_stages(capi, hmm, sb, loci, P)
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(capi, wl)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()

@@ -80,9 +80,10 @@ def run_nw(lib, prefix, pairs, use_ref_end_penalty=False, unpack=True, timing=No
     if not unpack:
         return None
     out = []
+    copr, rar, qar = cop.raw, ra.raw, qa.raw
     for i in range(n):
-        cig = "".join("%d%s" % (cl[k], cop.raw[k:k + 1].decode()) for k in range(co[i], co[i + 1]))
-        out.append((float(score[i]), bool(ok[i]), ra.raw[ao[i]:ao[i + 1]].decode(), qa.raw[ao[i]:ao[i + 1]].decode(), cig))
+        cig = "".join("%d%s" % (cl[k], copr[k:k + 1].decode()) for k in range(co[i], co[i + 1]))
+        out.append((float(score[i]), bool(ok[i]), rar[ao[i]:ao[i + 1]].decode(), qar[ao[i]:ao[i + 1]].decode(), cig))
     return out
 
 
@@ -224,8 +225,9 @@ def run_trace(lib, prefix, bptr, req_read, req_allele, hap_to_ref=None, cap=1 <<
         raise RuntimeError("%strace failed rc=%d%s" % (prefix, rc, why))
     if not unpack:
         return keep
+    raws = {nm: keep[nm].raw for nm in ("hap_aln", "str_seq", "flank_seq", "snp_base", "cigar_op", "aln_str")}     # .raw copies: once per pool
     def piece(pool, off, i):
-        return keep[pool].raw[keep[off][i]:keep[off][i + 1]].decode()
+        return raws[pool][keep[off][i]:keep[off][i + 1]].decode()
     out = []
     for q in range(n):
         out.append(dict(
@@ -234,9 +236,9 @@ def run_trace(lib, prefix, bptr, req_read, req_allele, hap_to_ref=None, cap=1 <<
             flank_left=piece("flank_seq", "flank_seq_off", 2 * q), flank_right=piece("flank_seq", "flank_seq_off", 2 * q + 1),
             flank_ins=int(keep["flank_ins"][q]), flank_del=int(keep["flank_del"][q]),
             indels=[(int(keep["indel_pos"][i]), int(keep["indel_size"][i])) for i in range(keep["indel_off"][q], keep["indel_off"][q + 1])],
-            snps=[(int(keep["snp_pos"][i]), keep["snp_base"].raw[i:i + 1].decode()) for i in range(keep["snp_off"][q], keep["snp_off"][q + 1])],
+            snps=[(int(keep["snp_pos"][i]), raws["snp_base"][i:i + 1].decode()) for i in range(keep["snp_off"][q], keep["snp_off"][q + 1])],
             aln_start=int(keep["aln_start"][q]), aln_stop=int(keep["aln_stop"][q]),
-            cigar="".join("%d%s" % (keep["cigar_len"][i], keep["cigar_op"].raw[i:i + 1].decode()) for i in range(keep["cigar_off"][q], keep["cigar_off"][q + 1])),
+            cigar="".join("%d%s" % (keep["cigar_len"][i], raws["cigar_op"][i:i + 1].decode()) for i in range(keep["cigar_off"][q], keep["cigar_off"][q + 1])),
             aln_str=piece("aln_str", "aln_str_off", q)))
     return out
 
@@ -249,7 +251,8 @@ def ref_hap_aln_info(ref, bptr, n_alleles, cap=1 << 20):
     rc = ref.ref_hap_aln_info(bptr, buf, cap, offs.ctypes.data_as(_i32p))
     if rc != 0:
         raise RuntimeError("ref_hap_aln_info rc=%d" % rc)
-    return [buf.raw[offs[k]:offs[k + 1] - 1] for k in range(n_alleles)]
+    raw = buf.raw
+    return [raw[offs[k]:offs[k + 1] - 1] for k in range(n_alleles)]
 
 
 def hap_aln_info(lib, prefix, bptr, cap=1 << 22):
@@ -262,7 +265,8 @@ def hap_aln_info(lib, prefix, bptr, cap=1 << 22):
     rc = fn(bptr, buf, cap, offs.ctypes.data_as(C.POINTER(C.c_int64)))
     if rc != 0:
         raise RuntimeError("%shap_aln_info failed rc=%d" % (prefix, rc))
-    return [buf.raw[offs[k]:offs[k + 1] - 1] for k in range(n)]
+    raw = buf.raw[:int(offs[n])]          # .raw copies the whole buffer: take it once
+    return [raw[offs[k]:offs[k + 1] - 1] for k in range(n)]
 
 
 def _ptr(a, typ):
