@@ -97,3 +97,71 @@ def run_sharded(arrays, align_fn, rank, world, group=None):
     if rank != 0:
         return None
     return np.concatenate([g[0] for g in gathered]), np.concatenate([g[1] for g in gathered])
+
+
+def _gather_in_rank_order(local, rank, world, group):
+    if world == 1:
+        return [local]
+    import torch.distributed as dist
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(local, gathered, dst=0, group=group)
+    return gathered if rank == 0 else None
+
+
+def em_subset(kw, lo, hi):
+    """Loci [lo, hi) of an EM input (the keyword arguments of capi.run_em), reads re-based."""
+    ro = np.asarray(kw["read_off"])
+    r0, r1 = int(ro[lo]), int(ro[hi])
+    out = dict(kw)
+    for k in ("period", "n_samples", "haploid"):
+        if kw.get(k) is not None:
+            out[k] = np.asarray(kw[k])[lo:hi]
+    out["read_off"] = ro[lo:hi + 1] - r0
+    for k in ("sample_label", "num_bps", "log_p1", "log_p2"):
+        out[k] = np.asarray(kw[k])[r0:r1]
+    return out
+
+
+def run_sharded_em(kw, em_fn, rank, world, group=None):
+    """De novo stutter EM over ranks: contiguous chunks of loci balanced by reads x (distinct sizes)^2; em_fn(**kw) ->
+    (trained, stutter, n_iter, final_ll).  Rank 0 returns the whole batch in locus order."""
+    ro = np.asarray(kw["read_off"]); nb = np.asarray(kw["num_bps"])
+    costs = [max(1.0, float(ro[l + 1] - ro[l]) * (len(set(nb[ro[l]:ro[l + 1]].tolist())) + 1) ** 2) for l in range(len(ro) - 1)]
+    bounds = split_loci(costs, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    local = em_fn(**em_subset(kw, lo, hi)) if hi > lo else (np.zeros(0, bool), np.zeros((0, 6)), np.zeros(0, np.int32), np.zeros(0))
+    parts = _gather_in_rank_order(local, rank, world, group)
+    if parts is None:
+        return None
+    return tuple(np.concatenate([p[i] for p in parts]) for i in range(4))
+
+
+def run_sharded_nw(pairs, nw_fn, rank, world, group=None):
+    """Needleman-Wunsch pairs over ranks, balanced by cells; nw_fn(pairs) -> list of results.  Rank 0 returns them in input order."""
+    bounds = split_loci([len(r) * len(q) for r, q in pairs], world)
+    local = nw_fn(pairs[bounds[rank]:bounds[rank + 1]]) if bounds[rank + 1] > bounds[rank] else []
+    parts = _gather_in_rank_order(local, rank, world, group)
+    return None if parts is None else [x for p in parts for x in p]
+
+
+def run_sharded_trace(arrays, req_read, req_allele, hap_to_ref, trace_fn, rank, world, group=None):
+    """Traceback requests over ranks: the locus shards of run_sharded, every rank tracing the requests that name its reads.
+    trace_fn(batch_ptr, req_read, req_allele, hap_to_ref) -> list of per-request results.  Rank 0 returns them in request order."""
+    bounds = split_loci(locus_costs(arrays), world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    r0, r1 = int(arrays["read_off"][lo]), int(arrays["read_off"][hi])
+    h0, h1 = int(arrays["hap_off"][lo]), int(arrays["hap_off"][hi])
+    mine = [i for i, r in enumerate(req_read) if r0 <= r < r1]
+    if mine:
+        sub = batch_from_arrays(subset_arrays(arrays, lo, hi))
+        res = trace_fn(sub.ptr, [req_read[i] - r0 for i in mine], [req_allele[i] for i in mine], None if hap_to_ref is None else hap_to_ref[h0:h1])
+    else:
+        res = []
+    parts = _gather_in_rank_order((mine, res), rank, world, group)
+    if parts is None:
+        return None
+    out = [None] * len(req_read)
+    for idx, res in parts:
+        for i, x in zip(idx, res):
+            out[i] = x
+    return out
