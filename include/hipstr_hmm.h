@@ -85,6 +85,21 @@ typedef struct hipstr_batch {
  *   (HapAligner.cpp:324); seeds[read] = HapAligner::calc_seed_base (HapAligner.cpp:270-318). */
 int hipstr_batch_out_offsets(const hipstr_batch_t* batch, int64_t* out_off /* [n_loci+1] */);
 
+/*
+ * Flat on-disk / wire form of a batch (host only): what a CPU worker that decoded and filtered the reads of a region shard
+ * (the reference's read_and_filter_reads, bam_processor.cpp:173-473) hands to the process that owns a GPU.  One header, a
+ * section table and the arrays of hipstr_batch_t back to back, checksummed; the reader points a hipstr_batch_t into one
+ * allocation.  hipstr_batch_serialized_size returns -1 on an inconsistent batch.
+ */
+typedef struct hipstr_batch_file hipstr_batch_file_t;
+int64_t hipstr_batch_serialized_size(const hipstr_batch_t* batch);
+int  hipstr_batch_serialize(const hipstr_batch_t* batch, void* out, int64_t cap);
+hipstr_batch_file_t* hipstr_batch_deserialize(const void* data, int64_t size);      /* NULL + hipstr_last_error() on a bad image */
+int  hipstr_batch_write(const char* path, const hipstr_batch_t* batch);
+hipstr_batch_file_t* hipstr_batch_read(const char* path);
+const hipstr_batch_t* hipstr_batch_file_batch(const hipstr_batch_file_t* f);
+void hipstr_batch_file_free(hipstr_batch_file_t* f);
+
 /* Opaque device-resident batch (prepared tables + reads + output buffers in HBM). */
 typedef struct hipstr_dev_batch hipstr_dev_batch_t;
 
