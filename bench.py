@@ -94,12 +94,13 @@ def pipeline_stages(capi, hmm, sb, loci, P):
     out["traceback"] = {"tracebacks_per_s": len(rr) / t["call_s"], "requests": len(rr), "loci": nl,
                         "hap_aln_info_s_all_loci": t_info, "haplotypes": len(h2r)}
     # de novo stutter EM (configs[2] shape: ~100 samples at low depth per locus)
-    kw = gen.em_case(5, n_loci=64, samples=(90, 100), reads_per_sample=(4, 8))
+    n_em = 512
+    kw = gen.em_case(5, n_loci=n_em, samples=(90, 100), reads_per_sample=(4, 8))
     capi.run_em(hmm, "hipstr_", **gen.em_case(6, n_loci=2))
     t0 = time.perf_counter()
     tr, st, it, ll = capi.run_em(hmm, "hipstr_", **kw)
     dt = time.perf_counter() - t0
-    out["stutter_em"] = {"loci_per_s": 64 / dt, "locus_iterations_per_s": float(it.sum()) / dt, "loci": 64, "trained": int(tr.sum()),
+    out["stutter_em"] = {"loci_per_s": n_em / dt, "locus_iterations_per_s": float(it.sum()) / dt, "loci": n_em, "trained": int(tr.sum()),
                          "shape": "90-100 samples x 4-8 reads"}
     return out
 
