@@ -750,7 +750,7 @@ extern "C" void hs_launch_lead(int cls, unsigned gx, hipStream_t st, const hs_de
   }
 }
 #ifndef HS_TRAIL_ROWS
-#define HS_TRAIL_ROWS 16
+#define HS_TRAIL_ROWS 20
 #endif
 extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end){
   hipLaunchKernelGGL((hs_trail_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end);
