@@ -225,11 +225,26 @@ def main():
                 return per_aln * n_alignments, os.path.basename(files[-1])
         return None, None
 
+    def valu_issue_util(kernel_key, n_alignments, kernel_ms_now):
+        """VALU issue-slot utilisation of a kernel: SQ_INSTS_VALU of the newest committed counter pass (profiles/r*_sq_counters.json, an own
+        rocprofv3 --pmc run), scaled to this launch by alignments, x 4 cycles per wave64 instruction / (1024 SIMDs x live kernel duration)."""
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters.json")))
+        if not files or not (kernel_ms_now == kernel_ms_now):
+            return None, None
+        t = json.load(open(files[-1]))
+        for name, v in t["kernels"].items():
+            if name.startswith(kernel_key):
+                insts = v["valu_insts"] / t["alignments_per_launch"] * n_alignments
+                return insts * t["cycles_per_wave64_valu_inst"] / (kernel_ms_now * 1e-3 * t["clock_hz_assumed"] * t["simds"]), os.path.basename(files[-1])
+        return None, None
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_aln * args.steps / elapsed
         achieved = algo.value / (kernel_ms * 1e-3) / 1e9 if kernel_ms == kernel_ms else None
         traffic, traffic_src = pmc_traffic(phase_names[dom].split("<")[0], n_aln.value)
+        util, util_src = valu_issue_util(phase_names[dom].split("<")[0], n_aln.value, kernel_ms)
         fp64_ops_per_cell = 13.0           # 13 FP64 add/max per M/I/D cell triple (hmm_kernels.hip sweep)
         valu_peak = 256 * 4 * 16 * 2.4e9   # FP64 VALU lanes/clk on 256 CUs x 4 SIMD x 16 lanes at 2.4 GHz (ops/s, add or max)
         out = {
@@ -248,7 +263,8 @@ def main():
                          "bytes_per_alignment": algo.value / max(1, n_aln.value)},
             "valu": {"dp_cells_per_launch": cells.value, "cells_per_s": cells.value / (float(phase_ms.sum()) * 1e-3) if n_ms > 0 else None,
                      "fp64_ops_per_cell": fp64_ops_per_cell, "fp64_valu_peak_ops_per_s": valu_peak,
-                     "frac": (cells.value * fp64_ops_per_cell / (float(phase_ms.sum()) * 1e-3) / valu_peak) if n_ms > 0 else None},
+                     "frac": (cells.value * fp64_ops_per_cell / (float(phase_ms.sum()) * 1e-3) / valu_peak) if n_ms > 0 else None,
+                     "issue_utilisation_dominant_kernel": util, "issue_utilisation_source": util_src},
             "host": {"synth_s": t_gen, "prepare_upload_s": t_upload, "fetch_s": t_fetch,
                      "value_incl_prepare_pcie": total_aln / world / (t_upload + elapsed / args.steps + t_fetch) * world},
         }
