@@ -90,9 +90,65 @@ def pipeline_stages(capi, hmm, sb, loci, P):
     t_info = time.perf_counter() - t0
     capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, rr[:256], aa[:256], h2r, cap=1 << 24, unpack=False)
     t = {}
-    capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, rr, aa, h2r, cap=1 << 26, timing=t, unpack=False)
+    capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, rr, aa, h2r, cap=1 << 24, timing=t, unpack=False)
     out["traceback"] = {"tracebacks_per_s": len(rr) / t["call_s"], "requests": len(rr), "loci": nl,
                         "hap_aln_info_s_all_loci": t_info, "haplotypes": len(h2r)}
+    # the whole per-locus chain of SeqStutterGenotyper::genotype + write_vcf_record on one batch of loci: forward pass -> posteriors
+    # -> MAP diplotypes -> best haplotype per read (seq_stutter_genotyper.cpp:823-825) -> tracebacks -> genotype calls (GL/PL/Q)
+    nc = min(loci, 64)
+    cb = capi.SynthBatch(n_loci=nc, reads_per_locus=P, n_str_alleles=int(np.diff(np.ctypeslib.as_array(sb.ptr.contents.hap_off, shape=(loci + 1,)))[0]), seed=4242)
+    A_c = np.diff(np.ctypeslib.as_array(cb.ptr.contents.hap_off, shape=(nc + 1,)))
+    S_c = 5                                                    # samples per locus: reads dealt round-robin-by-block to 5 samples
+    lab = np.tile(np.repeat(np.arange(S_c), P // S_c), nc)
+    h2r_c = capi.hap_aln_info(hmm, "hipstr_", cb.ptr, cap=1 << 26)
+    stage = {}
+    def chain():
+        dev = hmm.hipstr_hmm_upload(cb.ptr)
+        hmm.hipstr_hmm_align(dev, None)
+        pbc = capi.PostBatch(A_c, np.full(nc, S_c, np.int32), np.arange(nc + 1, dtype=np.int32) * P, lab, np.zeros(nc * P), np.zeros(nc * P),
+                             np.ones(nc * P, np.int32), None)
+        pdc = hmm.hipstr_post_upload(pbc.ptr, hmm.hipstr_hmm_dev_aln_probs(dev))
+        hmm.hipstr_post_launch(pdc, None)
+        ll = np.zeros(cb.n_out); sd = np.zeros(cb.n_reads, np.int32)
+        hmm.hipstr_hmm_fetch(dev, ll.ctypes.data_as(capi._f64p), sd.ctypes.data_as(capi._i32p))
+        post = np.zeros(int(pbc.post_off[-1])); tot = np.zeros(nc * S_c); gt = np.zeros(2 * nc * S_c, np.int32); lt = np.zeros(nc)
+        hmm.hipstr_post_fetch(pdc, post.ctypes.data_as(capi._f64p), tot.ctypes.data_as(capi._f64p), gt.ctypes.data_as(capi._i32p), lt.ctypes.data_as(capi._f64p))
+        # best haplotype of every read: the likelier of its sample's two MAP haplotypes
+        gt = gt.reshape(-1, 2)
+        rr_c, aa_c = [], []
+        t_sel = time.perf_counter()
+        for l in range(nc):
+            a = int(A_c[l]); r0 = l * P
+            LLl = ll[cb.out_off[l]:cb.out_off[l + 1]].reshape(P, a)
+            g = gt[l * S_c + lab[r0:r0 + P]]
+            best = np.where(LLl[np.arange(P), g[:, 0]] > LLl[np.arange(P), g[:, 1]], g[:, 0], g[:, 1])
+            ok = sd[r0:r0 + P] >= 0
+            rr_c.append(np.nonzero(ok)[0] + r0); aa_c.append(best[ok])
+        rr_c = np.concatenate(rr_c).astype(np.int32); aa_c = np.concatenate(aa_c).astype(np.int32)
+        stage["select_s"] = time.perf_counter() - t_sel
+        tt = {}
+        capi.run_trace(hmm, "hipstr_hmm_", cb.ptr, rr_c, aa_c, h2r_c, cap=1 << 24, unpack=False, timing=tt)
+        stage["trace_s"] = tt["call_s"]
+        # genotype calls: every haplotype its own variant here (one flank option), GL + PL
+        t_gt = time.perf_counter()
+        h2a = np.concatenate([np.arange(a, dtype=np.int32) for a in A_c]); nvv = A_c.astype(np.int32)
+        rq = capi.HipstrGtRequest(nvv.ctypes.data_as(capi._i32p), h2a.ctypes.data_as(capi._i32p), 1, 1, 0)
+        ns = nc * S_c; ngl = int(sum(int(a) * (int(a) + 1) // 2 for a in A_c)) * S_c
+        k = [np.zeros(2 * ns, np.int32), np.zeros(2 * ns, np.int32)] + [np.zeros(ns) for _ in range(5)] + [np.zeros(ngl), np.zeros(ngl, np.int32), np.zeros(1)]
+        o = capi.HipstrGtOut(*[a.ctypes.data_as(t) for a, (f, t) in zip(k, capi.HipstrGtOut._fields_)])
+        hmm.hipstr_post_extract.restype = C.c_int; hmm.hipstr_post_extract.argtypes = [C.c_void_p, C.POINTER(capi.HipstrGtRequest), C.POINTER(capi.HipstrGtOut)]
+        if hmm.hipstr_post_extract(pdc, C.byref(rq), C.byref(o)) != 0:
+            raise SystemExit("hipstr_post_extract: " + hmm.hipstr_last_error().decode())
+        stage["genotypes_s"] = time.perf_counter() - t_gt
+        hmm.hipstr_post_free(pdc); hmm.hipstr_hmm_free(dev)
+        return len(rr_c)
+    chain()
+    t0 = time.perf_counter()
+    n_tr = chain()
+    dt = time.perf_counter() - t0
+    out["chain"] = {"loci_per_s": nc / dt, "loci": nc, "reads_per_locus": P, "samples_per_locus": S_c, "tracebacks": n_tr, "seconds": dt,
+                    "stage_seconds": stage,
+                    "stages": "upload + forward + posteriors + fetch + best-haplotype pick (numpy) + tracebacks + genotype calls, one batch, python-orchestrated"}
     # de novo stutter EM (configs[2] shape: ~100 samples at low depth per locus)
     n_em = 512
     kw = gen.em_case(5, n_loci=n_em, samples=(90, 100), reads_per_sample=(4, 8))
