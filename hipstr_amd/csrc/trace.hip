@@ -6,10 +6,13 @@
 // stitch_alignment_trace (AlignmentTraceback.cpp:55-144).
 //
 //   hs_trace_fill<C>   one wavefront per (request, side): the same systolic anti-diagonal flank sweep as the forward
-//                      path, but every cell of M/I/D goes to HBM (compact rows: the interior rows of the STR block,
-//                      which nothing ever reads, are not stored); the STR row is evaluated one read column per lane by
-//                      replaying the host-enumerated visiting lists, remembering the best artifact size and position
-//                      (HapAligner.cpp:81-97, StutterAlignerClass.cpp:92-95,138-141).
+//                      path.  The reference keeps the full M/I/D matrices and lets retrace compare neighbours; every such
+//                      comparison only involves operands the sweep has in registers when it computes the cell, so the sweep
+//                      takes retrace's three decisions right there (with its 0.001-nat, direction-dependent tie rules) and
+//                      HBM receives ONE BYTE per cell instead of 24 (compact rows: the interior rows of the STR block, which
+//                      nothing ever reads, do not exist), plus the last column of M for the seed arg-max.  The STR row is
+//                      evaluated one read column per lane by replaying the host-enumerated visiting lists, remembering the
+//                      best artifact size and position (HapAligner.cpp:81-97, StutterAlignerClass.cpp:92-95,138-141).
 //   hs_trace_walk      one wavefront per request: seed arg-max + log-sum-exp over the lanes, then lane 0 walks the
 //                      left matrices and lane 1 the right ones, emitting the operation strings.
 //
@@ -24,6 +27,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <thread>
@@ -45,7 +49,9 @@ struct hs_tside_t {               // one side of one request
   int32_t art_off;                // ints: art_size[n] | art_pos[n]
   int32_t ops_off, ops_cap;
   int32_t pad_;
-  int64_t mat_off;                // doubles: M | I | D planes, each (F0 + 1 + F2) x n; row F0 is the STR block's last row
+  int32_t lc_off;                 // doubles: last column of M per compact row (F0 + 1 + F2; row F0 is the STR block's last row)
+  int32_t pad2_;
+  int64_t dec_off;                // bytes: retrace's decisions per cell, (F0 + 1 + F2) x n: bits 0-1 from M, bit 2 from D, bit 3 from I
 };
 
 struct hs_tdev_t {
@@ -60,7 +66,8 @@ struct hs_tdev_t {
   const char*        quals;
   const double *int_log, *qual_correct, *qual_error, *m2m, *m2i;
   double             log_thresh;
-  double*            mats;
+  uint8_t*           dec;
+  double*            lastcol;
   int32_t*           arts;
   char*              ops;
   double*            side_prob;   // [2*n_req]
@@ -75,19 +82,46 @@ namespace {
 
 constexpr double TRACE_LL_TOL = 0.001;     // HapAligner.cpp:345
 
-struct TraceLds {
-  double blc[HS_MAX_SIDE_LEN], blw[HS_MAX_SIDE_LEN];
-  double prev[HS_MAX_SIDE_LEN];            // M of the row before the STR block
-  double mr[HS_MAX_SIDE_LEN];              // M of the STR block's last row
-  double Mt[HS_MAX_SIDE_LEN];              // StutterAlignerClass match table
-  double Dl[HS_MAX_SIDE_LEN*HS_MAXREP];
-  double In[HS_MAX_SIDE_LEN*HS_MAXREP];
+template <int C> struct TraceLdsStore {     // LDS of one fill wavefront, sized by its columns-per-lane class (n <= 64*C)
+  double blc[64*C], blw[64*C];
+  double prev[64*C];                       // M of the row before the STR block
+  double mr[64*C];                         // M of the STR block's last row
+  double Mt[64*C];                         // StutterAlignerClass match table
+  double Dl[64*C*HS_MAXREP];
+  double In[64*C*HS_MAXREP];
   double terms[HS_NART*64];
-  uint8_t rd[HS_MAX_SIDE_LEN];
+  uint8_t rd[64*C];
   uint8_t blk[1024];
+};
+struct TraceLds {                          // view of a TraceLdsStore<C>
+  double *blc, *blw, *prev, *mr, *Mt, *Dl, *In, *terms;
+  uint8_t *rd, *blk;
 };
 
 __device__ __forceinline__ double emit_l(const TraceLds& L, int x, uint8_t c){ return L.rd[x] == c ? L.blc[x] : L.blw[x]; }
+
+// Closed form for a "simple" visiting list (hs_stropt_t::shape = U0 >= 0, the same evaluator as the forward pass, hmm_kernels.hip
+// simple_eval): every pushed value is lp0 plus a constant.  Pushes, in the reference's order: lp0 | [0 < lim] ln(U0) + lp0 (run of U0
+// equal configurations, only if U0 > 0) | lp0 once per plain offset in [U0, lim) | [stop < tail] ln(tail - stop) + lp0.  The running
+// likelihood never changes along such a list, so the best position is the start (right-aligned) or the last offset visited
+// (left-aligned: ties move it, StutterAlignerClass.cpp:92-95, 138-141) = `stop`.
+__device__ __forceinline__ double trace_simple(const hs_tdev_t& d, double lp0, int lim, int U0, int tail, bool left_align, int& best_pos){
+  const bool skip = (U0 > 0) && (lim > 0);
+  const int nplain = max(0, lim - U0);
+  const int stop = (lim <= 0) ? 0 : ((U0 > 0 && lim <= U0) ? U0 : lim);
+  const bool has_tail = stop < tail;
+  const double v_skip = d.int_log[U0] + lp0;
+  const double v_tail = d.int_log[max(tail - stop, 0)] + lp0;
+  double mx = lp0;
+  if (skip) mx = fmax(mx, v_skip);
+  if (has_tail) mx = fmax(mx, v_tail);
+  double tot = 0.0;
+  { const double dd = lp0 - mx; if (dd > d.log_thresh) tot += (double)(1 + nplain) * (double)f_fasterexp((float)dd); }
+  if (skip){ const double dd = v_skip - mx; if (dd > d.log_thresh) tot += (double)f_fasterexp((float)dd); }
+  if (has_tail){ const double dd = v_tail - mx; if (dd > d.log_thresh) tot += (double)f_fasterexp((float)dd); }
+  best_pos = left_align ? stop : 0;
+  return mx + (double)f_fasterlog((float)tot);
+}
 
 // StutterAlignerClass::align_pcr_insertion_reverse (StutterAlignerClass.cpp:59-104) for one read column.
 __device__ double trace_ins(const hs_tdev_t& d, const TraceLds& L, const hs_stropt_t& so, const double* f64, int n, int len, int j, int D,
@@ -95,6 +129,7 @@ __device__ double trace_ins(const hs_tdev_t& d, const TraceLds& L, const hs_stro
   const int B = so.B, p = so.period, off = n-1-j;
   const double lp0 = f64[HS_NART] + L.In[HS_MAXREP*off + D/p - 1] + (len > D ? L.Mt[off+D] : 0.0);
   const int lim = min(max(len-D, 0), B);
+  if (so.shape[HS_MAXREP] >= 0) return trace_simple(d, lp0, lim, so.shape[HS_MAXREP], B, left_align, best_pos);
   Lse lse;
   double best = lp0; best_pos = 0;
   for (int pass = 0; pass < 2; pass++){
@@ -134,6 +169,7 @@ __device__ double trace_del(const hs_tdev_t& d, const TraceLds& L, const hs_stro
   double lp0 = f64[HS_NART+1+q];
   if (off + D >= 0) lp0 += L.Mt[off+D] - L.Dl[(off+D)*HS_MAXREP + q];
   else for (int k = 0; k > -len; k--) lp0 += emit_l(L, j+k, L.blk[B-1+k+D]);
+  if (so.shape[q] >= 0) return trace_simple(d, lp0, len, so.shape[q], B+D, left_align, best_pos);
   Lse lse;
   double best = lp0; best_pos = 0;
   for (int pass = 0; pass < 2; pass++){
@@ -163,20 +199,32 @@ __device__ double trace_del(const hs_tdev_t& d, const TraceLds& L, const hs_stro
   return lse.finish();
 }
 
-// ------------------------------------------------------------------ matrices of one (request, side)
+__device__ __forceinline__ int tri_idx(bool rev, double v1, double v2, double v3){       // HapAligner.cpp:346-358
+  if (!rev){ if (v1 > v2+TRACE_LL_TOL) return (v1 > v3+TRACE_LL_TOL ? 0 : 2); return (v2 > v3+TRACE_LL_TOL ? 1 : 2); }
+  if (v3 > v2+TRACE_LL_TOL) return (v3 > v1+TRACE_LL_TOL ? 2 : 0);
+  return (v2 > v1+TRACE_LL_TOL ? 1 : 0);
+}
+__device__ __forceinline__ int pair_idx(bool rev, double v1, double v2){                 // HapAligner.cpp:360-361
+  if (!rev) return (v1 > v2+TRACE_LL_TOL ? 0 : 1);
+  return (v2 > v1+TRACE_LL_TOL ? 1 : 0);
+}
+
+// ------------------------------------------------------------------ decisions of one (request, side)
 template <int C>
 __global__ void __launch_bounds__(64) hs_trace_fill(const hs_tdev_t* __restrict__ dp, int item_begin){
-  __shared__ TraceLds L;
+  __shared__ TraceLdsStore<C> store;
+  TraceLds L;
+  L.blc = store.blc; L.blw = store.blw; L.prev = store.prev; L.mr = store.mr; L.Mt = store.Mt; L.Dl = store.Dl; L.In = store.In;
+  L.terms = store.terms; L.rd = store.rd; L.blk = store.blk;
   const hs_tdev_t& d = *dp;
   const int lane = threadIdx.x;
   const int si = uni(d.items[item_begin + blockIdx.x]);
   const hs_tside_t* S = d.sides + si;
   const int n = uni(S->n), len = uni(S->len), base_off = uni(S->base_off), side = uni(S->side);
   const int F0 = uni(S->F0), F2 = uni(S->F2);
-  const int64_t plane = (int64_t)(F0 + 1 + F2) * n;
-  double* M = d.mats + uni(S->mat_off);
-  double* I = M + plane;
-  double* Dm = I + plane;
+  uint8_t* dec = d.dec + uni(S->dec_off);
+  double* lastcol = d.lastcol + uni(S->lc_off);
+  const bool rev = side != 0;
   const int nl = (n + C - 1) / C, lastlane = (n - 1) / C;
 
   uint8_t rd[C]; double blc[C], blw[C];
@@ -220,12 +268,16 @@ __global__ void __launch_bounds__(64) hs_trace_fill(const hs_tdev_t* __restrict_
           const double c0v = ileft + m2i, c1v = mdiag + m2m, c2v = ddiag + m2i;
           double nM = e + fmax(c0v, fmax(c1v, c2v));
           double nI = blc[kk] + fmax(mdiag + T_I2M, ileft + T_I2I);
-          const double nD = fmax(Mrow[kk] + T_D2M, Drow[kk] + T_D2D);
+          const double dm = Mrow[kk] + T_D2M, ddl = Drow[kk] + T_D2D, ii = ileft + T_I2I, im = mdiag + T_I2M;
+          const double nD = fmax(dm, ddl);
+          // retrace's choices at this cell (HapAligner.cpp:536-566): from M among (I left, D diag, M diag), from D and from I
+          const int code = tri_idx(rev, c0v, c2v, c1v) | (pair_idx(rev, ddl, dm) << 2) | (pair_idx(rev, ii, im) << 3);
           if (kk == 0 && lane == 0){ nM = e; nI = blc[kk]; }     // HapAligner.cpp:123-126
           mdiag = Mrow[kk]; ddiag = Drow[kk]; ileft = nI;
           Mrow[kk] = nM; Drow[kk] = nD;
           const int j = lane*C + kk;
-          if (j < n){ M[ro + j] = nM; I[ro + j] = nI; Dm[ro + j] = nD; }
+          if (j < n) dec[ro + j] = (uint8_t)code;
+          if (j == n-1) lastcol[(meta >> 12) & 0xfff] = nM;
         }
         oI = ileft;
       }
@@ -254,8 +306,7 @@ __global__ void __launch_bounds__(64) hs_trace_fill(const hs_tdev_t* __restrict_
     for (int kk = 0; kk < C; kk++){
       Mrow[kk] = ((rd[kk] == c0) ? blc[kk] : blw[kk]) + pre[kk];
       Drow[kk] = IMP;
-      const int j = lane*C + kk;
-      if (j < n){ M[j] = Mrow[kk]; I[j] = blc[kk] + pre[kk]; Dm[j] = IMP; }
+      if (lane*C + kk == n-1) lastcol[0] = Mrow[kk];
     }
     if (lane == lastlane) d.side_prob[si] = carry;
   }
@@ -326,7 +377,7 @@ __global__ void __launch_bounds__(64) hs_trace_fill(const hs_tdev_t* __restrict_
       }
       const double v = lse.finish();
       L.mr[j] = v;
-      M[ro + j] = v; I[ro + j] = IMP; Dm[ro + j] = IMP;
+      if (j == n-1) lastcol[F0] = v;
       art_size[j] = bsize; art_pos[j] = bpos;
     }
   }
@@ -335,40 +386,35 @@ __global__ void __launch_bounds__(64) hs_trace_fill(const hs_tdev_t* __restrict_
   // ---- trailing flank: "stutter block must be followed by a match" (HapAligner.cpp:122-139), then the plain recurrence
   const hs_row_t* trail = d.rows + uni(S->trail_off);
   {
-    const uint8_t c0 = (uint8_t)(uni((int)trail[0]) & 0xff);
+    const int t0row = uni((int)trail[0]);
+    const uint8_t c0 = (uint8_t)(t0row & 0xff);
+    const int h0 = (t0row >> 8) & 15;
+    const double a_m2m = d.m2m[h0], a_m2i = d.m2i[h0];
     const int64_t ro = (int64_t)(F0 + 1) * n;
 #pragma unroll
     for (int kk = 0; kk < C; kk++){
       const int j = min(lane*C + kk, n-1);
       const double e = (rd[kk] == c0) ? blc[kk] : blw[kk];
-      Mrow[kk] = (j == 0) ? e : e + L.mr[max(j - 1, 0)];
+      const double mleft = L.mr[max(j - 1, 0)];                 // M of the STR block's last row, previous column
+      Mrow[kk] = (j == 0) ? e : e + mleft;
       Drow[kk] = IMP;
-      if (lane*C + kk < n){ M[ro + j] = Mrow[kk]; I[ro + j] = IMP; Dm[ro + j] = IMP; }
+      // the neighbours retrace would compare here: I of this row and D of the STR row are IMPOSSIBLE (HapAligner.cpp:130-139)
+      const int code = tri_idx(rev, IMP + a_m2i, IMP + a_m2i, mleft + a_m2m) | (pair_idx(rev, IMP + T_D2D, L.mr[j] + T_D2M) << 2)
+                     | (pair_idx(rev, IMP + T_I2I, mleft + T_I2M) << 3);
+      if (lane*C + kk < n) dec[ro + j] = (uint8_t)code;
+      if (lane*C + kk == n-1) lastcol[F0 + 1] = Mrow[kk];
     }
   }
   if (F2 > 1) sweep(trail + 1, F2 - 1);
 }
 
 // ------------------------------------------------------------------ seed arg-max, total likelihood and the walk
-__device__ __forceinline__ int tri_idx(bool rev, double v1, double v2, double v3){       // HapAligner.cpp:346-358
-  if (!rev){ if (v1 > v2+TRACE_LL_TOL) return (v1 > v3+TRACE_LL_TOL ? 0 : 2); return (v2 > v3+TRACE_LL_TOL ? 1 : 2); }
-  if (v3 > v2+TRACE_LL_TOL) return (v3 > v1+TRACE_LL_TOL ? 2 : 0);
-  return (v2 > v1+TRACE_LL_TOL ? 1 : 0);
-}
-__device__ __forceinline__ int pair_idx(bool rev, double v1, double v2){                 // HapAligner.cpp:360-361
-  if (!rev) return (v1 > v2+TRACE_LL_TOL ? 0 : 1);
-  return (v2 > v1+TRACE_LL_TOL ? 1 : 0);
-}
-
 // HapAligner::retrace (HapAligner.cpp:363-571): only the decisions; the bookkeeping is replayed on the host from `ops`.
 __device__ void trace_walk(const hs_tdev_t& d, int si, int B, int max_index){
   const hs_tside_t* S = d.sides + si;
   const bool rev = S->side != 0;
   const int n = S->n, F0 = S->F0, F2 = S->F2;
-  const int64_t plane = (int64_t)(F0 + 1 + F2) * n;
-  const double* M = d.mats + S->mat_off;
-  const double* I = M + plane;
-  const double* Dm = I + plane;
+  const uint8_t* dec = d.dec + S->dec_off;
   const int32_t* art_size = d.arts + S->art_off;
   const int32_t* art_pos = art_size + n;
   char* ops = d.ops + S->ops_off;
@@ -412,16 +458,15 @@ __device__ void trace_walk(const hs_tdev_t& d, int si, int B, int max_index){
           done = true;
           break;
         }
+        const int code = dec[(int64_t)u*n + c];                  // taken by the sweep when it computed cell (u, c)
         if (type == 0){
-          const int best = tri_idx(rev, I[(int64_t)u*n + c-1] + d.m2i[h], Dm[(int64_t)(u-1)*n + c-1] + d.m2i[h], M[(int64_t)(u-1)*n + c-1] + d.m2m[h]);
+          const int best = code & 3;
           if (best == 0){ type = 2; c -= 1; }
           else { type = (best == 1) ? 1 : 0; u--; c--; }
         } else if (type == 1){
-          const int best = pair_idx(rev, Dm[(int64_t)(u-1)*n + c] + T_D2D, M[(int64_t)(u-1)*n + c] + T_D2M);
-          type = (best == 0) ? 1 : 0; u--;
+          type = ((code >> 2) & 1) == 0 ? 1 : 0; u--;
         } else {
-          const int best = pair_idx(rev, I[(int64_t)u*n + c-1] + T_I2I, M[(int64_t)(u-1)*n + c-1] + T_I2M);
-          if (best == 0) c--;
+          if (((code >> 3) & 1) == 0) c--;
           else { type = 0; u--; c--; }
         }
       }
@@ -442,8 +487,8 @@ __global__ void __launch_bounds__(64) hs_trace_walk(const hs_tdev_t* __restrict_
   const int nL = uni(SL->n), nR = uni(SR->n), F0 = uni(SL->F0), F2 = uni(SL->F2);
   const int B = uni(d.stropts[uni(SL->stropt)].B);
   const int H = F0 + B + F2;
-  const double* LM = d.mats + uni(SL->mat_off);
-  const double* RM = d.mats + uni(SR->mat_off);
+  const double* LM = d.lastcol + uni(SL->lc_off);          // last column of M per compact row
+  const double* RM = d.lastcol + uni(SR->lc_off);
   const int sp = uni(SL->base_off) + uni(SL->seed);
   const uint8_t sc = (uint8_t)d.bases[sp];
   const uint8_t sq = (uint8_t)d.quals[sp];
@@ -455,9 +500,9 @@ __global__ void __launch_bounds__(64) hs_trace_walk(const hs_tdev_t* __restrict_
   auto term = [&](int x){       // compute_aln_logprob (HapAligner.cpp:163-231), one seed position
     const uint32_t rw = x < F0 ? d.rows[SL->lead_off + x] : d.rows[SL->trail_off + x - F0 - B];
     const double pe = prior + (sc == (uint8_t)(rw & 0xff) ? lc : lw);
-    if (x == 0)   return (pe + spL) + RM[(int64_t)cR(H-2)*nR + nR-1];
-    if (x == H-1) return (pe + spR) + LM[(int64_t)cL(H-2)*nL + nL-1];
-    return (pe + LM[(int64_t)cL(x-1)*nL + nL-1]) + RM[(int64_t)cR(H-2-x)*nR + nR-1];
+    if (x == 0)   return (pe + spL) + RM[cR(H-2)];
+    if (x == H-1) return (pe + spR) + LM[cL(H-2)];
+    return (pe + LM[cL(x-1)]) + RM[cR(H-2-x)];
   };
   // the reference pushes x = 0, x = H-1, then the interior positions in order, keeping the FIRST maximum (HapAligner.cpp:184-222)
   double bv = -__builtin_huge_val(); int brank = 0x7fffffff;
@@ -719,8 +764,8 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
   // ---- chunks of requests whose matrices fit the workspace budget
   size_t free_b = 0, total_b = 0;
   TR_HIP(hipMemGetInfo(&free_b, &total_b));
-  int64_t budget = std::min<int64_t>((int64_t)8 << 30, (int64_t)(free_b / 4)) / 8;      // doubles
-  if (const char* e = getenv("HIPSTR_TRACE_WS_MIB")) budget = std::max<int64_t>(1, atoll(e)) * ((1 << 20) / 8);
+  int64_t budget = std::min<int64_t>((int64_t)8 << 30, (int64_t)(free_b / 4));          // bytes of decision matrices per chunk
+  if (const char* e = getenv("HIPSTR_TRACE_WS_MIB")) budget = std::max<int64_t>(1, atoll(e)) << 20;
   std::vector<hs_tside_t> sides(2*(size_t)n_req);
   std::vector<int64_t> need(n_req);
   for (int q = 0; q < n_req; q++){
@@ -737,27 +782,29 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
       S.trail_off = ap.trail_off[sd]; S.F2 = ap.seq[sd][2].size();
       S.stropt = ap.stropt[sd];
       S.ops_cap = S.n + S.F0 + S.F2 + (int)ap.seq[sd][1].size() + 2*HS_MAXREP*b->period[req_locus[q]] + 16;
-      need[q] += 3*(int64_t)(S.F0 + 1 + S.F2)*S.n;
+      need[q] += (int64_t)(S.F0 + 1 + S.F2)*S.n;
     }
     if (need[q] > budget) return api_fail("one traceback needs more workspace than the device offers");
   }
 
   // workspaces are sized for the largest chunk once and reused
-  int64_t max_mat = 0, max_art = 0, max_ops = 0; int max_nq = 0;
+  int64_t max_mat = 0, max_art = 0, max_ops = 0, max_lc = 0; int max_nq = 0;
   {
-    int64_t mat = 0, art = 0, ops = 0; int nq = 0;
+    int64_t mat = 0, art = 0, ops = 0, lc = 0; int nq = 0;
     for (int q = 0; q < n_req; q++){
-      if (mat + need[q] > budget){ mat = art = ops = 0; nq = 0; }
+      if (mat + need[q] > budget){ mat = art = ops = lc = 0; nq = 0; }
       mat += need[q]; art += 2*(int64_t)(sides[2*q].n + sides[2*q+1].n); ops += sides[2*q].ops_cap + sides[2*q+1].ops_cap; nq++;
-      max_mat = std::max(max_mat, mat); max_art = std::max(max_art, art); max_ops = std::max(max_ops, ops); max_nq = std::max(max_nq, nq);
+      lc += 2*(int64_t)(sides[2*q].F0 + 1 + sides[2*q].F2);
+      max_mat = std::max(max_mat, mat); max_art = std::max(max_art, art); max_ops = std::max(max_ops, ops); max_lc = std::max(max_lc, lc);
+      max_nq = std::max(max_nq, nq);
     }
   }
-  if (max_art > 0x7fffffff || max_ops > 0x7fffffff) return api_fail("too many requests for one call; split the request list");
+  if (max_art > 0x7fffffff || max_ops > 0x7fffffff || max_lc > 0x7fffffff) return api_fail("too many requests for one call; split the request list");
   hs_tdev_t hc = h;
   hs_tside_t* d_sides; int32_t* d_items; hs_tdev_t* d_args;
   if (dev.alloc(&d_sides, 2*(size_t)max_nq) || dev.alloc(&d_items, 2*(size_t)max_nq) || dev.alloc(&d_args, 1)) return 1;
   hc.sides = d_sides; hc.items = d_items;
-  if (dev.alloc(&hc.mats, max_mat) || dev.alloc(&hc.arts, max_art) || dev.alloc(&hc.ops, max_ops) || dev.alloc(&hc.side_prob, 2*(size_t)max_nq) ||
+  if (dev.alloc(&hc.dec, max_mat) || dev.alloc(&hc.lastcol, max_lc) || dev.alloc(&hc.arts, max_art) || dev.alloc(&hc.ops, max_ops) || dev.alloc(&hc.side_prob, 2*(size_t)max_nq) ||
       dev.alloc(&hc.ll, max_nq) || dev.alloc(&hc.max_index, max_nq) || dev.alloc(&hc.n_ops, 2*(size_t)max_nq) ||
       dev.alloc(&hc.str_size, 2*(size_t)max_nq) || dev.alloc(&hc.str_pos, 2*(size_t)max_nq)) return 1;
   TR_HIP(hipMemcpy(d_args, &hc, sizeof hc, hipMemcpyHostToDevice));
@@ -766,11 +813,12 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
   double ms_alloc = 0, ms_kernel = 0, ms_d2h = 0, ms_replay = 0;
   for (int q0 = 0; q0 < n_req; ){
     const auto c0 = now();
-    int q1 = q0; int64_t mat = 0; int64_t n_art = 0, n_ops = 0;
+    int q1 = q0; int64_t mat = 0; int64_t n_art = 0, n_ops = 0, n_lc = 0;
     while (q1 < n_req && mat + need[q1] <= budget){
       for (int sd = 0; sd < 2; sd++){
         hs_tside_t& S = sides[2*q1+sd];
-        S.mat_off = mat; mat += 3*(int64_t)(S.F0 + 1 + S.F2)*S.n;
+        S.dec_off = mat; mat += (int64_t)(S.F0 + 1 + S.F2)*S.n;
+        S.lc_off = (int32_t)n_lc; n_lc += S.F0 + 1 + S.F2;
         S.art_off = (int32_t)n_art; n_art += 2*S.n;
         S.ops_off = (int32_t)n_ops; n_ops += S.ops_cap;
       }
@@ -894,48 +942,61 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
         }
       }
     };
-    {
-      int nthreads = 1;
-      if (nq >= 512){
-        nthreads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
-        if (const char* e = getenv("HIPSTR_TRACE_THREADS")) nthreads = std::max(1, atoi(e));
-        nthreads = std::min(nthreads, nq / 128);
-      }
-      if (nthreads <= 1) work(q0, q1);
-      else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nthreads; t++)
-          pool.push_back(std::thread(work, q0 + (int)((int64_t)nq*t/nthreads), q0 + (int)((int64_t)nq*(t+1)/nthreads)));
-        for (std::thread& th : pool) th.join();
-      }
+    int nthreads = 1;
+    if (nq >= 512){
+      nthreads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+      if (const char* e = getenv("HIPSTR_TRACE_THREADS")) nthreads = std::max(1, atoi(e));
+      nthreads = std::max(1, std::min(nthreads, nq / 128));
     }
-    // ---- copy into the caller's flat pools, in request order
+    auto run_parallel = [&](const std::function<void(int,int)>& fn){
+      if (nthreads <= 1){ fn(q0, q1); return; }
+      std::vector<std::thread> pool;
+      for (int t = 0; t < nthreads; t++)
+        pool.push_back(std::thread(fn, q0 + (int)((int64_t)nq*t/nthreads), q0 + (int)((int64_t)nq*(t+1)/nthreads)));
+      for (std::thread& th : pool) th.join();
+    };
+    const auto r0t = now();
+    run_parallel(work);
+    const auto r1t = now();
+    // ---- the caller's flat pools: offsets in request order (serial prefix sums), then the bytes (parallel again)
     for (int q = q0; q < q1; q++){
       const ReqOut& R = res[q-q0];
       if (!R.ok) return api_fail("internal error: inconsistent traceback operation string");
-      o->ll[q] = ll[q-q0]; o->max_index[q] = mxi[q-q0];
-      bool ok = put_pool(o->hap_aln, o->hap_aln_off, q, R.hap_aln, o->cap_chars);
-      o->stutter_size[q] = R.acc.str_set ? R.acc.stutter_size : HIPSTR_NO_STR_DATA;
-      ok = put_pool(o->str_seq, o->str_seq_off, q, R.acc.str_set ? R.acc.str_seq : std::string(), o->cap_chars) && ok;
-      ok = put_pool(o->flank_seq, o->flank_seq_off, 2*q, R.acc.flank[0], o->cap_chars) && ok;
-      ok = put_pool(o->flank_seq, o->flank_seq_off, 2*q+1, R.acc.flank[2], o->cap_chars) && ok;
-      o->flank_ins[q] = R.acc.flank_ins; o->flank_del[q] = R.acc.flank_del;
-      int io = o->indel_off[q];
-      if ((int64_t)io + (int64_t)R.acc.indels.size() > o->cap_chars) ok = false;
-      else for (size_t i = 0; i < R.acc.indels.size(); i++, io++){ o->indel_pos[io] = R.acc.indels[i].first; o->indel_size[io] = R.acc.indels[i].second; }
-      o->indel_off[q+1] = io;
-      int so = o->snp_off[q];
-      if ((int64_t)so + (int64_t)R.acc.snps.size() > o->cap_chars) ok = false;
-      else for (size_t i = 0; i < R.acc.snps.size(); i++, so++){ o->snp_pos[so] = R.acc.snps[i].first; o->snp_base[so] = R.acc.snps[i].second; }
-      o->snp_off[q+1] = so;
-      o->aln_start[q] = R.aln_start; o->aln_stop[q] = R.aln_stop;
-      int co = o->cigar_off[q];
-      if ((int64_t)co + (int64_t)R.cigar.size() > o->cap_chars) ok = false;
-      else for (size_t i = 0; i < R.cigar.size(); i++, co++){ o->cigar_op[co] = R.cigar[i].first; o->cigar_len[co] = R.cigar[i].second; }
-      o->cigar_off[q+1] = co;
-      ok = put_pool(o->aln_str, o->aln_str_off, q, R.aln_str, o->cap_chars) && ok;
-      if (!ok) return api_fail("hipstr_trace_out_t pools are too small (cap_chars)");
+      o->hap_aln_off[q+1] = o->hap_aln_off[q] + (int32_t)R.hap_aln.size();
+      o->str_seq_off[q+1] = o->str_seq_off[q] + (int32_t)(R.acc.str_set ? R.acc.str_seq.size() : 0);
+      o->flank_seq_off[2*q+1] = o->flank_seq_off[2*q] + (int32_t)R.acc.flank[0].size();
+      o->flank_seq_off[2*q+2] = o->flank_seq_off[2*q+1] + (int32_t)R.acc.flank[2].size();
+      o->indel_off[q+1] = o->indel_off[q] + (int32_t)R.acc.indels.size();
+      o->snp_off[q+1] = o->snp_off[q] + (int32_t)R.acc.snps.size();
+      o->cigar_off[q+1] = o->cigar_off[q] + (int32_t)R.cigar.size();
+      o->aln_str_off[q+1] = o->aln_str_off[q] + (int32_t)R.aln_str.size();
+      const int64_t cap = o->cap_chars;
+      if ((int64_t)o->hap_aln_off[q] + (int64_t)R.hap_aln.size() > cap || (int64_t)o->str_seq_off[q] + (int64_t)R.acc.str_seq.size() > cap ||
+          (int64_t)o->flank_seq_off[2*q] + (int64_t)(R.acc.flank[0].size() + R.acc.flank[2].size()) > cap ||
+          (int64_t)o->indel_off[q] + (int64_t)R.acc.indels.size() > cap || (int64_t)o->snp_off[q] + (int64_t)R.acc.snps.size() > cap ||
+          (int64_t)o->cigar_off[q] + (int64_t)R.cigar.size() > cap || (int64_t)o->aln_str_off[q] + (int64_t)R.aln_str.size() > cap)
+        return api_fail("hipstr_trace_out_t pools are too small (cap_chars)");
     }
+    auto copy_out = [&](int qa, int qb){
+      for (int q = qa; q < qb; q++){
+        const ReqOut& R = res[q-q0];
+        o->ll[q] = ll[q-q0]; o->max_index[q] = mxi[q-q0];
+        memcpy(o->hap_aln + o->hap_aln_off[q], R.hap_aln.data(), R.hap_aln.size());
+        o->stutter_size[q] = R.acc.str_set ? R.acc.stutter_size : HIPSTR_NO_STR_DATA;
+        if (R.acc.str_set) memcpy(o->str_seq + o->str_seq_off[q], R.acc.str_seq.data(), R.acc.str_seq.size());
+        memcpy(o->flank_seq + o->flank_seq_off[2*q], R.acc.flank[0].data(), R.acc.flank[0].size());
+        memcpy(o->flank_seq + o->flank_seq_off[2*q+1], R.acc.flank[2].data(), R.acc.flank[2].size());
+        o->flank_ins[q] = R.acc.flank_ins; o->flank_del[q] = R.acc.flank_del;
+        for (size_t i = 0; i < R.acc.indels.size(); i++){ o->indel_pos[o->indel_off[q] + i] = R.acc.indels[i].first; o->indel_size[o->indel_off[q] + i] = R.acc.indels[i].second; }
+        for (size_t i = 0; i < R.acc.snps.size(); i++){ o->snp_pos[o->snp_off[q] + i] = R.acc.snps[i].first; o->snp_base[o->snp_off[q] + i] = R.acc.snps[i].second; }
+        o->aln_start[q] = R.aln_start; o->aln_stop[q] = R.aln_stop;
+        for (size_t i = 0; i < R.cigar.size(); i++){ o->cigar_op[o->cigar_off[q] + i] = R.cigar[i].first; o->cigar_len[o->cigar_off[q] + i] = R.cigar[i].second; }
+        memcpy(o->aln_str + o->aln_str_off[q], R.aln_str.data(), R.aln_str.size());
+      }
+    };
+    const auto r2t = now();
+    run_parallel(copy_out);
+    if (timing) fprintf(stderr, "  replay of %d: setup %.3f work %.3f offsets %.3f copy %.3f (threads %d)\n", nq, ms(c3, r0t), ms(r0t, r1t), ms(r1t, r2t), ms(r2t, now()), nthreads);
     q0 = q1;
     const auto c4 = now();
     ms_alloc += ms(c0, c1); ms_kernel += ms(c1, c2); ms_d2h += ms(c2, c3); ms_replay += ms(c3, c4);
