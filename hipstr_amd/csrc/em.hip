@@ -57,6 +57,7 @@ struct hs_em_dev_t {
   const double*  int_log;
   double*  new_ll;             // [n_loci]
   double*  sums;               // [7*n_loci] in_up, in_down, in_eq, in_diffs, out_up, out_down, out_diffs
+  double*  row_lse;            // scratch: log_sum_exp of every posterior row (s, allele_1), at post_off / A
   double   log_thresh, log_half, log_1p1;
 };
 
@@ -214,15 +215,22 @@ __global__ void __launch_bounds__(256) hs_em_mstep(const hs_em_dev_t* __restrict
 
   // ---- recalc_log_gt_priors (:22-57): thread a owns allele a; the two scans in the reference's order
   __syncthreads();
+  // log_sum_exp of every row (sample, allele_1) first, all rows in parallel (each row summed in allele_2 order as the reference does);
+  // the streaming scans below are sequential per allele by definition
+  double* row_lse = d.row_lse + L.post_off / A;
+  for (int x = tid; x < S*A; x += 256){
+    const double* row = post + (int64_t)x*A;
+    double rm = row[0];
+    for (int j = 1; j < A; j++) rm = fmax(rm, row[j]);
+    double rs = 0.0;
+    for (int j = 0; j < A; j++) rs += exp(row[j] - rm);
+    row_lse[x] = rm + log(rs);
+  }
+  __syncthreads();
   for (int a = tid; a < A; a += 256){
     double m = -DBL_MAX/2, t = 0.0;
     for (int s = 0; s < S; s++){                         // first allele of the diplotype: log_sum_exp of row (s, a)
-      const double* row = post + ((int64_t)s*A + a)*A;
-      double rm = row[0];
-      for (int j = 1; j < A; j++) rm = fmax(rm, row[j]);
-      double rs = 0.0;
-      for (int j = 0; j < A; j++) rs += exp(row[j] - rm);
-      const double lv = rm + log(rs);
+      const double lv = row_lse[(int64_t)s*A + a];
       if (lv <= m) t += exp(lv - m); else { t *= exp(m - lv); t += 1.0; m = lv; }
     }
     for (int s = 0; s < S; s++)                          // second allele
@@ -354,16 +362,16 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
   hs_em_dev_t h; memset(&h, 0, sizeof h);
   hs_post_dev_t ph; memset(&ph, 0, sizeof ph);
   hs_em_locus_t* d_loci; hs_post_unit_t* d_units; int32_t *d_active, *d_unit_active, *d_bps, *d_obs, *d_lab, *d_w, *d_mapgt;
-  double *d_logp, *d_p1, *d_p2, *d_gtp, *d_ll, *d_prior, *d_post, *d_tot, *d_newll, *d_sums;
+  double *d_logp, *d_p1, *d_p2, *d_gtp, *d_ll, *d_prior, *d_post, *d_tot, *d_newll, *d_sums, *d_rowlse;
   std::vector<int32_t> ones(n_reads, 1);
   if (dev.put(&d_loci, loci.data(), loci.size()) || dev.put(&d_units, units.data(), units.size()) || dev.alloc(&d_active, nl) ||
       dev.alloc(&d_unit_active, units.size()) || dev.put(&d_bps, bps.data(), bps.size()) || dev.put(&d_obs, obs.data(), obs.size()) ||
       dev.put(&d_lab, eb->sample_label, n_reads) || dev.put(&d_w, ones.data(), ones.size()) || dev.alloc(&d_mapgt, 2*(size_t)samp_off) ||
       dev.alloc(&d_logp, 9*(size_t)nl) || dev.put(&d_p1, eb->log_p1, n_reads) || dev.put(&d_p2, eb->log_p2, n_reads) ||
       dev.put(&d_gtp, gtp.data(), gtp.size()) || dev.alloc(&d_ll, ll_off) || dev.alloc(&d_prior, prior_off) || dev.alloc(&d_post, post_off) ||
-      dev.alloc(&d_tot, samp_off) || dev.alloc(&d_newll, nl) || dev.alloc(&d_sums, 7*(size_t)nl)) return 1;
+      dev.alloc(&d_tot, samp_off) || dev.alloc(&d_newll, nl) || dev.alloc(&d_sums, 7*(size_t)nl) || dev.alloc(&d_rowlse, post_off)) return 1;
   h.loci = d_loci; h.active = d_active; h.logp = d_logp; h.bps = d_bps; h.obs = d_obs; h.sample_label = d_lab; h.log_p1 = d_p1; h.log_p2 = d_p2;
-  h.gtp = d_gtp; h.ll = d_ll; h.prior = d_prior; h.post = d_post; h.sample_total = d_tot; h.int_log = T.int_log; h.new_ll = d_newll; h.sums = d_sums;
+  h.gtp = d_gtp; h.ll = d_ll; h.prior = d_prior; h.post = d_post; h.sample_total = d_tot; h.int_log = T.int_log; h.new_ll = d_newll; h.sums = d_sums; h.row_lse = d_rowlse;
   h.log_thresh = HT.log_thresh; h.log_half = HT.log_half; h.log_1p1 = log(1.1);
   ph.units = d_units; ph.log_aln_probs = d_ll; ph.log_p1 = d_p1; ph.log_p2 = d_p2; ph.read_weight = d_w; ph.log_prior = d_prior;
   ph.unit_active = d_unit_active; ph.log_post = d_post; ph.sample_total = d_tot; ph.map_gt = d_mapgt;
