@@ -435,13 +435,11 @@ __device__ __forceinline__ double simple_eval(const hs_dev_t& d, const StrLds& L
   double mx = lp0;
   if (skip) mx = fmax(mx, v_skip);
   if (has_tail) mx = fmax(mx, v_tail);
-  double tot = 0.0;
-  {
-    const double dd = lp0 - mx;
-    if (dd > d.log_thresh) tot += (double)(1 + nplain) * (double)f_fasterexp((float)dd);   // equal float terms: the sum is exact
-  }
-  if (skip){ const double dd = v_skip - mx; if (dd > d.log_thresh) tot += (double)f_fasterexp((float)dd); }
-  if (has_tail){ const double dd = v_tail - mx; if (dd > d.log_thresh) tot += (double)f_fasterexp((float)dd); }
+  // branch-free: an absent or thresholded term adds +0.0, which leaves the (non-negative) sum unchanged bit for bit
+  const double d0 = lp0 - mx, d1 = v_skip - mx, d2 = v_tail - mx;
+  double tot = (d0 > d.log_thresh) ? (double)(1 + nplain) * (double)f_fasterexp((float)d0) : 0.0;   // equal float terms: the product is exact
+  tot += (skip && d1 > d.log_thresh) ? (double)f_fasterexp((float)d1) : 0.0;
+  tot += (has_tail && d2 > d.log_thresh) ? (double)f_fasterexp((float)d2) : 0.0;
   return mx + (double)f_fasterlog((float)tot);
 }
 
