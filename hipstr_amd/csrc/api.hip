@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <chrono>
 #include <cstdio>
 #include <algorithm>
 #include <cstring>
@@ -165,7 +166,10 @@ hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){
     if (getenv("HIPSTR_WS_GIB")) budget = (int64_t)(atof(getenv("HIPSTR_WS_GIB"))*134217728.0);
     if (budget < 1024) budget = 1024;
   }
+  const auto t_prep0 = std::chrono::steady_clock::now();
   if (hipstr::prepare_batch(batch, dev->prep, err, budget)){ g_err = err; delete dev; return NULL; }
+  if (getenv("HIPSTR_TIMING"))
+    fprintf(stderr, "hipstr_hmm_upload: prepare_batch %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prep0).count());
   hipstr::Prepared& P = dev->prep;
   {  // SURVEY.md §8(d) algorithmic traffic and flank-cell work of one pass
     int64_t bytes = 0, cells = 0;
