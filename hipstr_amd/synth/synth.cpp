@@ -228,6 +228,7 @@ void* synth_create(int32_t n_loci, int32_t reads_per_locus, int32_t n_str_allele
   Cfg c; c.n_loci = n_loci; c.reads_per_locus = reads_per_locus; c.n_str_alleles = n_str_alleles; c.read_len = read_len;
   c.flank_len = flank_len; c.str_bp = str_bp; c.n_flank_opts = std::max(1, n_flank_opts); c.seed = seed;
   c.sub_rate = 0.005; c.stutter_rate = 0.05; c.indel_rate = 0.01; c.imperfect_rate = 0.05; c.mask_rate = mask_rate;
+  if (const char* e = getenv("HIPSTR_SYNTH_IMPERFECT")) c.imperfect_rate = atof(e);      // experiments: share of alleles with an interrupted repeat
   Synth* s = new Synth();
   s->opt_off.push_back(0); s->hap_off.push_back(0); s->read_off.push_back(0); s->base_off.push_back(0); s->cigar_off.push_back(0);
   for (int l = 0; l < n_loci; l++) gen_locus(c, l, *s);
