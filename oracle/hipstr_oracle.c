@@ -1,12 +1,14 @@
 /*
  * hipstr_oracle.c — TEST INFRASTRUCTURE ONLY.  CPU restatement (plain C11,
  * double precision, single thread) of HipSTR v0.7's read-to-haplotype HMM
- * forward score and diplotype posteriors.  Only tests/, __graft_entry__.smoke()
+ * (forward score and Viterbi traceback), diplotype posteriors and genotype calls,
+ * de novo stutter EM and Needleman-Wunsch.  Only tests/, __graft_entry__.smoke()
  * and bench.py's cpu_baseline leg may load this file's shared object; the
  * product library never does.
  *
- * PARITY STATUS: pinned.  tests/test_oracle_vs_ref.py compares every entry point
- * with the compiled reference (oracle/_ref/libhipstr_ref.so, built by
+ * PARITY STATUS: pinned.  tests/test_oracle_vs_ref.py and the *_oracle.py tests of
+ * the later stages (traceback, genotype calls, EM, Needleman-Wunsch, haplotype
+ * alignment strings) compare every entry point with the compiled reference (oracle/_ref/libhipstr_ref.so, built by
  * oracle/Makefile from the sources under /root/reference) on seeded random loci
  * and on the two known-answer vectors of SURVEY.md §8(c); the committed fixtures
  * under tests/golden/ were produced by that reference build
