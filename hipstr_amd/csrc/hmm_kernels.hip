@@ -259,16 +259,22 @@ __device__ __forceinline__ void band_sweep(const hs_dev_t& d, int lane, bool liv
         upM = e; upD = nD;
       }
     } else {
+      // M and I of this column only read the previous column, so they are computed bottom-up and overwrite in place (row r+1, done
+      // first, was the last reader of row r's old M and D); D, which chains down the column through the new M, follows top-down.
+      // max(I+m2i, M+m2m, D+m2d) with m2d == m2i: adding the same value is monotone, so max(a+x, b+x) == max(a,b)+x exactly
+#pragma unroll
+      for (int r = NR - 1; r >= 0; r--){
+        const double e = (rdj == hc[r]) ? blcj : blwj;
+        const double dM = (r == 0) ? diagM : Mp[r > 0 ? r-1 : 0], dD = (r == 0) ? diagD : Dp[r > 0 ? r-1 : 0];
+        const double nM = e + fmax(dM + m2m[r], fmax(Ip[r], dD) + m2i[r]);
+        const double nI = blcj + fmax(dM + T_I2M, Ip[r] + T_I2I);
+        Mp[r] = nM; Ip[r] = nI;
+      }
 #pragma unroll
       for (int r = 0; r < NR; r++){
-        const double e = (rdj == hc[r]) ? blcj : blwj;
-        // max(I+m2i, M+m2m, D+m2d) with m2d == m2i: adding the same value is monotone, so max(a+x, b+x) == max(a,b)+x exactly
-        const double nM = e + fmax(diagM + m2m[r], fmax(Ip[r], diagD) + m2i[r]);
-        const double nI = blcj + fmax(diagM + T_I2M, Ip[r] + T_I2I);
         const double nD = fmax(upM + T_D2M, upD + T_D2D);
-        diagM = Mp[r]; diagD = Dp[r];          // (row r, column j-1): the diagonal of row r+1
-        Mp[r] = nM; Dp[r] = nD; Ip[r] = nI;
-        upM = nM; upD = nD;
+        Dp[r] = nD;
+        upM = Mp[r]; upD = nD;
       }
     }
     if (!LAST) *(double2*)(bnd + ((size_t)j*64 + lane)*2) = make_double2(upM, upD);
