@@ -278,7 +278,7 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
       hs_launch_trail((unsigned)std::min(dev->trail_waves, ch.trail_end - ch.trail_begin), st, dp,
                       dev->n_lead_items + ch.trail_begin, dev->n_lead_items + ch.trail_end);
     if (mark()) return 1;
-    hipLaunchKernelGGL(hs_combine_kernel, dim3(nact, (dev->max_alleles + 3)/4), dim3(256), 0, st, dp, ch.active_begin);
+    hipLaunchKernelGGL(hs_combine_kernel, dim3(nact), dim3(256), 0, st, dp, ch.active_begin);
     if (mark()) return 1;
     HS_HIP(hipGetLastError());
   }

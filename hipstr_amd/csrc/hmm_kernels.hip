@@ -698,18 +698,22 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
 }
 
 // compute_aln_logprob (HapAligner.cpp:163-231): log-sum-exp over the haplotype positions the seed base can sit on.
-// One wavefront per (active read, realigned allele); 4 per workgroup.
+// One workgroup (4 wavefronts) per active read; a wavefront takes every fourth realigned allele, so what depends on the read only
+// (side views, seed base, leading-flank records) is set up once per wavefront.
 extern "C" __global__ void __launch_bounds__(256)
 hs_combine_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
   const hs_dev_t& d = *dp;
   const int lane = threadIdx.x & 63;
   const int ai = active_begin + blockIdx.x;
-  const int k = blockIdx.y*4 + (threadIdx.x >> 6);
   const SideView vL = side_view(d, ai, 0);
-  if (k >= uni(vL.loc->n_alleles)) return;
-  const hs_allele_t* al = d.alleles + uni(vL.loc->hap_begin) + k;
-  if (!uni(al->realign)) return;
   const SideView vR = side_view(d, ai, 1);
+  const uint8_t seed_c = (uint8_t)d.bases[vL.base_off + vL.nL];
+  const uint8_t seed_q = (uint8_t)d.quals[vL.base_off + vL.nL];
+  const double seed_lc = d.qual_correct[seed_q], seed_lw = d.qual_error[seed_q];
+  const int n_alleles = uni(vL.loc->n_alleles);
+  for (int k = (threadIdx.x >> 6); k < n_alleles; k += 4){
+  const hs_allele_t* al = d.alleles + uni(vL.loc->hap_begin) + k;
+  if (!uni(al->realign)) continue;
   const int N = uni(al->n_flank), ord = uni(al->re_ord);
   const int lead_off = uni(d.rowsets[uni(al->lead_rows[0])].off), F0 = uni(d.rowsets[uni(al->lead_rows[0])].len);
   const int trail_off = uni(d.rowsets[uni(al->trail_rows[0])].off), F2 = N - F0;
@@ -721,26 +725,42 @@ hs_combine_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
   auto lcL = [&](int u){ return u < F0 ? recL[vL.n + u] : (u == F0 ? mr[vL.nL - 1] : lt[u - F0 - 1]); };
   auto lcR = [&](int u){ return u < F2 ? recR[vR.n + u] : (u == F2 ? mr[vL.len - 2] : lt[F2 + (u - F2 - 1)]); };
   const double sideL = recL[vL.n + uni(vL.loc->lead_flank[0])], sideR = recR[vR.n + uni(vL.loc->lead_flank[1])];
-  const uint8_t seed_c = (uint8_t)d.bases[vL.base_off + vL.nL];
-  const uint8_t seed_q = (uint8_t)d.quals[vL.base_off + vL.nL];
-  const double seed_lc = d.qual_correct[seed_q], seed_lw = d.qual_error[seed_q];
   const double prior = -d.int_log[N];
+  auto term = [&](int y){
+    const uint8_t hc = (uint8_t)((y < F0 ? d.rows[lead_off + y] : d.rows[trail_off + y - F0]) & 0xff);
+    const double e = (seed_c == hc) ? seed_lc : seed_lw;
+    double a, b;
+    if (y == 0)        { a = sideL;     b = lcR(N-1); }
+    else if (y == N-1) { a = sideR;     b = lcL(N-1); }
+    else if (y < F0)   { a = lcL(y-1);  b = lcR(N-1-y); }
+    else               { a = lcL(y);    b = lcR(N-2-y); }
+    return ((prior + e) + a) + b;
+  };
   Lse acc;
-  for (int pass = 0; pass < 2; pass++){
-    if (pass == 0) acc.mx = -1.0e300; else acc.tot = 0.0;
-    for (int y = lane; y < N; y += 64){
-      const uint8_t hc = (uint8_t)((y < F0 ? d.rows[lead_off + y] : d.rows[trail_off + y - F0]) & 0xff);
-      const double e = (seed_c == hc) ? seed_lc : seed_lw;
-      double a, b;
-      if (y == 0)        { a = sideL;     b = lcR(N-1); }
-      else if (y == N-1) { a = sideR;     b = lcL(N-1); }
-      else if (y < F0)   { a = lcL(y-1);  b = lcR(N-1-y); }
-      else               { a = lcL(y);    b = lcR(N-2-y); }
-      acc.push(pass, ((prior + e) + a) + b, d.log_thresh);
+  if (N <= 256){
+    // up to four seed positions per lane stay in registers between the max and the sum: the hand-off arrays are read once
+    double t[4];
+    acc.mx = -1.0e300;
+#pragma unroll
+    for (int k = 0; k < 4; k++){
+      const int y = lane + 64*k;
+      t[k] = (y < N) ? term(min(y, N-1)) : -1.0e300;
+      acc.mx = fmax(acc.mx, t[k]);
     }
-    if (pass == 0) acc.mx = wave_max_d(acc.mx); else acc.tot = wave_sum_d(acc.tot);
+    acc.mx = wave_max_d(acc.mx);
+    acc.tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (lane + 64*k < N) acc.push(1, t[k], d.log_thresh);
+    acc.tot = wave_sum_d(acc.tot);
+  } else {
+    for (int pass = 0; pass < 2; pass++){
+      if (pass == 0) acc.mx = -1.0e300; else acc.tot = 0.0;
+      for (int y = lane; y < N; y += 64) acc.push(pass, term(y), d.log_thresh);
+      if (pass == 0) acc.mx = wave_max_d(acc.mx); else acc.tot = wave_sum_d(acc.tot);
+    }
   }
-  if (lane == 0) d.aln_probs[uni(vL.loc->out_off) + (int64_t)(vL.r - uni(vL.loc->read_begin))*uni(vL.loc->n_alleles) + k] = acc.finish();
+  if (lane == 0) d.aln_probs[uni(vL.loc->out_off) + (int64_t)(vL.r - uni(vL.loc->read_begin))*n_alleles + k] = acc.finish();
+  }
 }
 
 // ------------------------------------------------------------------ host-side launch helper (called from api.hip)
