@@ -463,7 +463,7 @@ extern "C" size_t hs_str_lds_bytes(int lds_len, int max_B){
 // Workgroup = one active read: wave 0 the left side, wave 1 the right side (independent; they share only the LDS
 // carve, whose per-column arrays are exactly len-1 long in total).  Writes M of the STR block's last row for every
 // realigned allele of the chunk to the MR workspace.
-extern "C" __global__ void __launch_bounds__(128)
+extern "C" __global__ void __launch_bounds__(128, 4)
 hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
   const hs_dev_t& d = *dp;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -473,12 +473,14 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
   const int o = w ? ((v.nL + 1) & ~1) : 0;
   StrLds L;
   {
-    double2* bq = (double2*)hs_lds_raw;
+    // Dl first: the read-end deletion loop below indexes bq / rd / blk with (start - t) and relies on masking instead of clamping,
+    // so up to n entries BEFORE an array may be touched (never used); everything in front of bq, blk and rd is this workgroup's LDS
+    double* Dl = (double*)hs_lds_raw;
+    double2* bq = (double2*)(Dl + HS_MAXREP*Lc);
     double* rowP = (double*)(bq + Lc);
     double* Mt = rowP + Lc;
-    double* Dl = Mt + Lc;
     const int ilog_len = (d.max_B + 9) & ~1, blk_len = (d.max_B + 19) & ~15;
-    double* ilog = Dl + HS_MAXREP*Lc;
+    double* ilog = Mt + Lc;
     double* ndb = ilog + ilog_len;                          // per wave: nd[6][HS_ND_STRIDE] | cstl[24]
     uint8_t* blkb = (uint8_t*)(ndb + 2*(HS_MAXREP*HS_ND_STRIDE + 24));
     uint8_t* rdb = blkb + 2*blk_len;
@@ -577,10 +579,22 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
         const int j = max(0, n - aD) + off;
         const int len = valid ? min(B - aD, j + 1) : 0;
         double lp = L.cstl[14 + q];
-        for (int t = 0; t < tmax; t++){
-          const int pos = max(j - t, 0);
-          const double e = emit(L.rd[pos], L.blk[max(B-1-aD-t, 0)], L.bq[pos]);
+        // step t pairs read base j - t with block base B-1-aD - t; len <= j + 1 and len <= B - aD, so a step that would leave either
+        // array is masked anyway: no clamps, pointers move in chunks of 4 and the accesses take immediate offsets
+        const uint8_t* prd = L.rd + j; const double2* pbq = L.bq + j; const uint8_t* pbk = L.blk + (B - 1 - aD);
+        int t = 0;
+        for (; t + 4 <= tmax; t += 4){
+          prd -= 4; pbq -= 4; pbk -= 4;
+#pragma unroll
+          for (int k = 0; k < 4; k++){
+            const double e = emit(prd[4-k], pbk[4-k], pbq[4-k]);
+            if (t + k < len) lp += e;
+          }
+        }
+        for (; t < tmax; t++){
+          const double e = emit(*prd, *pbk, *pbq);
           if (t < len) lp += e;
+          prd--; pbq--; pbk--;
         }
         if (valid) L.nd[q*HS_ND_STRIDE + off] = lp;
       }
@@ -603,15 +617,15 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
           terms[HS_MAXREP] = (rdlane(c.cst, HS_MAXREP) + L.Mt[j]) + pre;
         }
         double li = 0.0;
+        const double2* pli_bq = L.bq + j; const uint8_t* pli_rd = L.rd + j; int li_left = j;
 #pragma unroll
         for (int q = 0; q < HS_MAXREP; q++){
           const int D = (q+1)*p;
-          for (int m = 0; m < p; m++){
-            const int t = q*p + m;
-            const int pos = max(j - t, 0);
-            const double2 bq = L.bq[pos];
-            const double e = (m < B) ? emit(L.rd[pos], blk_at(c, B-1-min(m, B-1)), bq) : bq.x;
-            if (t <= j) li += e;
+          for (int m = 0; m < p; m++){               // read position j - t: unclamped (a step with t > j is masked; Dl sits in front of bq)
+            const double2 bq = *pli_bq;
+            const double e = (m < B) ? emit(*pli_rd, blk_at(c, B-1-min(m, B-1)), bq) : bq.x;
+            if (li_left >= 0) li += e;
+            pli_bq--; pli_rd--; li_left--;
           }
           const int len = min(B + D, j + 1);
           const double lp0 = (rdlane(c.cst, 13) + li) + ((len > D) ? L.Mt[max(j - D, 0)] : 0.0);
