@@ -412,7 +412,7 @@ __device__ __forceinline__ double visit_eval(const hs_dev_t& d, const StrLds& L,
       else if (U == 0){
         const uint8_t ca = (uint8_t)(meta >> 32), cb = (uint8_t)(meta >> 40);
         for (int m = 1; m <= nsub; m++){
-          const int pos = max(j - ni - m*stride, 0);
+          const int pos = j - ni - m*stride;            // negative only on lanes that are past their bound (not accumulated)
           const uint8_t r = L.rd[pos]; const double2 bq = L.bq[pos];
           if (act){ lp -= emit(r, ca, bq); lp += emit(r, cb, bq); }
         }
@@ -547,14 +547,17 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
       double lp = (t0 > 0) ? L.Mt[j] : 0.0;
       const int tmax = min(B, n);
       const int ndp = c.nd * p;
+      // read position j - t, unclamped: a step with t > j is masked (Dl sits in front of bq); the "(t+1) is a multiple of p" test of
+      // the deletion table is carried as a counter instead of a division
+      const uint8_t* prd = L.rd + (j - t0); const double2* pbq = L.bq + (j - t0);
+      int left = j - t0, ph = (t0 + 1) % p;
+      double* dl = L.Dl + ((t0 + 1)/p - 1)*L.ld + j;          // row of the deletion table the next multiple of p goes to
       for (int t = t0; t < tmax; t++){
-        const uint8_t bc = blk_at(c, B-1-t);
-        const int pos = max(j - t, 0);
-        const double e = emit(L.rd[pos], bc, L.bq[pos]);
-        if (t <= j){
-          lp += e;
-          if (t < ndp && (t+1) % p == 0) L.Dl[((t+1)/p - 1)*L.ld + j] = lp;
-        }
+        const double e = emit(*prd, blk_at(c, B-1-t), *pbq);
+        if (left >= 0) lp += e;
+        if (ph == 0){ if (t < ndp && left >= 0) *dl = lp; }
+        ph++; if (ph == p){ ph = 0; dl += L.ld; }
+        prd--; pbq--; left--;
       }
       L.Mt[j] = lp;
     }
