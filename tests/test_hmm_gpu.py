@@ -155,3 +155,21 @@ def test_imperfect_repeats_and_long_periods(hmm, oracle):
     got, gs = capi.run_align(hmm, "hipstr_hmm_", b.ptr)
     want, ws = capi.run_align(oracle, "oracle_", b.ptr)
     assert np.array_equal(gs, ws) and np.array_equal(got, want), np.max(np.abs(got - want))
+
+
+def test_random_shapes_match_oracle(hmm, oracle, monkeypatch):
+    """A seeded sweep over generator shapes (read / flank / STR sizes, allele counts, flank options, masks, interrupted repeats): the
+    unclamped pointer-stepped loops of the STR kernel rely on masking, so odd sizes are where a slip would show."""
+    rng = np.random.default_rng(2026)
+    total = 0
+    for _ in range(16):
+        monkeypatch.setenv("HIPSTR_SYNTH_IMPERFECT", str(float(rng.choice([0.0, 0.05, 0.3, 1.0]))))
+        kw = dict(n_loci=int(rng.integers(1, 4)), reads_per_locus=int(rng.integers(1, 30)), n_str_alleles=int(rng.integers(1, 33)),
+                  read_len=int(rng.integers(24, 251)), flank_len=int(rng.integers(8, 161)), str_bp=int(rng.integers(4, 121)),
+                  n_flank_opts=int(rng.integers(1, 4)), seed=int(rng.integers(1, 1 << 30)), mask_rate=float(rng.choice([0.0, 0.3])))
+        sb = capi.SynthBatch(**kw)
+        want, ws = capi.run_align(oracle, "oracle_", sb.ptr, fill=-3.25)
+        got, gs = capi.run_align(hmm, "hipstr_hmm_", sb.ptr, fill=-3.25)
+        assert np.array_equal(gs, ws) and np.array_equal(got, want), kw
+        total += got.size
+    assert total > 10000

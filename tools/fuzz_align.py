@@ -1,0 +1,34 @@
+"""Randomised parity sweep of the forward path (GPU vs oracle) over generator shapes: read length, flank length, STR size, allele
+count, flank options, masks, share of interrupted repeats.  usage: python tools/fuzz_align.py [n_configs] [seed]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hipstr_amd import capi
+
+n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+hmm = capi.load_hmm(); ora = capi.load_oracle()
+assert hmm.hipstr_hmm_init(0) == 0
+bad = 0; total = 0
+for c in range(n_cfg):
+    os.environ["HIPSTR_SYNTH_IMPERFECT"] = str(float(rng.choice([0.0, 0.05, 0.3, 1.0])))
+    read_len = int(rng.integers(24, 251))
+    kw = dict(n_loci=int(rng.integers(1, 5)), reads_per_locus=int(rng.integers(1, 40)), n_str_alleles=int(rng.integers(1, 41)), read_len=read_len,
+              flank_len=int(rng.integers(8, 161)), str_bp=int(rng.integers(4, 121)), n_flank_opts=int(rng.integers(1, 4)),
+              seed=int(rng.integers(1, 1 << 30)), mask_rate=float(rng.choice([0.0, 0.0, 0.3])))
+    try:
+        sb = capi.SynthBatch(**kw)
+        want, ws = capi.run_align(ora, "oracle_", sb.ptr, fill=-3.25)
+    except Exception as e:           # shapes the generator or the oracle refuses are not interesting here
+        print("skip", kw, str(e)[:80]); continue
+    try:
+        got, gs = capi.run_align(hmm, "hipstr_hmm_", sb.ptr, fill=-3.25)
+    except RuntimeError as e:
+        print("GPU refused", kw, str(e)[:100]); continue
+    total += got.size
+    ok = np.array_equal(gs, ws) and np.array_equal(got, want)
+    if not ok:
+        bad += 1
+        d = np.abs(got - want)
+        print("MISMATCH", kw, os.environ["HIPSTR_SYNTH_IMPERFECT"], "n", got.size, "nbad", int((d > 0).sum()), "max", d.max())
+print("configs", n_cfg, "alignments", total, "mismatching configs", bad)
