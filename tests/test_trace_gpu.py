@@ -124,3 +124,23 @@ def test_trace_errors(hmm, oracle):
     with pytest.raises(RuntimeError, match="too small"):
         capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, [0, 1, 2, 3], [0, 0, 0, 0], None, cap=64)
     assert capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, [], [], None) == []
+
+
+def test_random_shapes_match_oracle(hmm, oracle, monkeypatch):
+    """Seeded sweep over generator shapes incl. interrupted repeats (non-simple visiting lists in the traced STR row)."""
+    rng = np.random.default_rng(99)
+    total = 0
+    for _ in range(12):
+        monkeypatch.setenv("HIPSTR_SYNTH_IMPERFECT", str(float(rng.choice([0.0, 0.5, 1.0]))))
+        kw = dict(n_loci=1, reads_per_locus=int(rng.integers(2, 24)), n_str_alleles=int(rng.integers(1, 20)), read_len=int(rng.integers(24, 251)),
+                  flank_len=int(rng.integers(8, 161)), str_bp=int(rng.integers(4, 121)), n_flank_opts=int(rng.integers(1, 4)), seed=int(rng.integers(1, 1 << 30)))
+        sb = capi.SynthBatch(**kw)
+        rr, aa = _requests(oracle, sb, 2, 5)
+        if not rr:
+            continue
+        h2r = capi.hap_aln_info(oracle, "oracle_", sb.ptr)
+        want = capi.run_trace(oracle, "oracle_", sb.ptr, rr, aa, h2r, cap=1 << 21)
+        got = capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, rr, aa, h2r, cap=1 << 21)
+        util.assert_traces_equal(got, want, str(kw))
+        total += len(rr)
+    assert total > 100

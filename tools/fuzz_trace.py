@@ -1,0 +1,38 @@
+"""Randomised parity sweep of the traceback (GPU vs oracle) over generator shapes.  usage: python tools/fuzz_trace.py [n_configs] [seed]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from hipstr_amd import capi
+import util
+
+n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4321)
+hmm = capi.load_hmm(); ora = capi.load_oracle()
+assert hmm.hipstr_hmm_init(0) == 0
+bad = 0; total = 0
+for c in range(n_cfg):
+    os.environ["HIPSTR_SYNTH_IMPERFECT"] = str(float(rng.choice([0.0, 0.05, 0.5, 1.0])))
+    kw = dict(n_loci=1, reads_per_locus=int(rng.integers(1, 30)), n_str_alleles=int(rng.integers(1, 25)), read_len=int(rng.integers(24, 251)),
+              flank_len=int(rng.integers(8, 161)), str_bp=int(rng.integers(4, 121)), n_flank_opts=int(rng.integers(1, 4)), seed=int(rng.integers(1, 1 << 30)))
+    sb = capi.SynthBatch(**kw)
+    _, seeds = capi.run_align(ora, "oracle_", sb.ptr)
+    A = sb.n_out // sb.n_reads
+    rr, aa = [], []
+    for r in range(sb.n_reads):
+        if seeds[r] >= 0:
+            for k in rng.choice(A, size=min(A, 2), replace=False):
+                rr.append(r); aa.append(int(k))
+    if not rr:
+        continue
+    h2r = capi.hap_aln_info(ora, "oracle_", sb.ptr)
+    want = capi.run_trace(ora, "oracle_", sb.ptr, rr, aa, h2r, cap=1 << 21)
+    got = capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, rr, aa, h2r, cap=1 << 21)
+    total += len(rr)
+    if got != want:
+        bad += 1
+        q = next(i for i, (g, w) in enumerate(zip(got, want)) if g != w)
+        print("MISMATCH", kw, os.environ["HIPSTR_SYNTH_IMPERFECT"], "request", q, {f: (got[q][f], want[q][f]) for f in got[q] if got[q][f] != want[q][f]})
+    if capi.hap_aln_info(hmm, "hipstr_", sb.ptr) != h2r:
+        bad += 1; print("MISMATCH hap_aln_info", kw)
+print("configs", n_cfg, "tracebacks", total, "mismatching configs", bad)
