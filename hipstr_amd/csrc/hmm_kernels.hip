@@ -449,6 +449,70 @@ __device__ __forceinline__ double simple_eval(const hs_dev_t& d, const StrLds& L
   return mx + (double)f_fasterlog((float)tot);
 }
 
+// Closed form for a "piecewise simple" visiting list (hs_stropt_t::shape = HS_SHAPE_PIECEWISE; descriptor slots written by prep.cpp):
+//   [run?] break [run?] (break [run?])  plain ... plain  terminal
+// The running likelihood only changes at the (one or two) break entries, so there are at most three levels L0, L1, L2 and the pushes of
+// visit_eval are: L0 | ln U + L of a run entry | L after a break | L of the last level once per plain entry | the tail term — each
+// present only if its offset is below the lane's bound.  Same values, same float log-sum-exp as the replay, without replaying.
+//   pwA/pwB: the 70 descriptor slots of the STR option, one per lane (64 + 6); k: list index (0..5 deletion lists, 6 insertion list)
+__device__ __forceinline__ double pw_eval(const hs_dev_t& d, const StrLds& L, int j, double lp0, int lim, double pwA, double pwB, int k,
+                                          int nsub, int stride, int tail){
+  auto lo = [&](int sl){ const int g = k*HS_PW_SLOTS + sl; return g < 64 ? rdlane(__double2loint(pwA), g) : rdlane(__double2loint(pwB), g - 64); };
+  auto hi = [&](int sl){ const int g = k*HS_PW_SLOTS + sl; return g < 64 ? rdlane(__double2hiint(pwA), g) : rdlane(__double2hiint(pwB), g - 64); };
+  auto dbl = [&](int sl){ return __hiloint2double(hi(sl), lo(sl)); };
+  const int nseg = lo(0), term_ni = hi(0);
+  const int r0 = lo(1), U0 = hi(1), r1 = lo(3), U1 = hi(3), r2 = lo(5), U2 = hi(5);
+  const int b0 = lo(7), c0 = hi(7), b1 = lo(8), c1 = hi(8);
+  const int pa = lo(9), pb = hi(9);
+  // the levels
+  const double L0 = lp0;
+  double L1 = L0;
+  const bool a_b0 = b0 < lim;                              // nseg >= 1 always
+  {
+    const uint8_t ca = (uint8_t)c0, cb = (uint8_t)(c0 >> 8);
+    for (int m = 1; m <= nsub; m++){
+      const int pos = j - b0 - m*stride;
+      const uint8_t r = L.rd[pos]; const double2 bq = L.bq[pos];
+      if (a_b0){ L1 -= emit(r, ca, bq); L1 += emit(r, cb, bq); }
+    }
+  }
+  double L2 = L1;
+  const bool a_b1 = (nseg >= 2) && (b1 < lim);
+  if (nseg >= 2){
+    const uint8_t ca = (uint8_t)c1, cb = (uint8_t)(c1 >> 8);
+    for (int m = 1; m <= nsub; m++){
+      const int pos = j - b1 - m*stride;
+      const uint8_t r = L.rd[pos]; const double2 bq = L.bq[pos];
+      if (a_b1){ L2 -= emit(r, ca, bq); L2 += emit(r, cb, bq); }
+    }
+  }
+  const double Llast = (nseg >= 2) ? L2 : L1;
+  const double Lfin = a_b1 ? L2 : (a_b0 ? L1 : L0);         // what the lane's running value is when its replay stops
+  const bool a_r0 = (U0 > 0) && (r0 < lim), a_r1 = (U1 > 0) && (r1 < lim), a_r2 = (U2 > 0) && (r2 < lim);
+  const double v_r0 = dbl(2) + L0, v_r1 = dbl(4) + L1, v_r2 = dbl(6) + L2;
+  const int np = min(max(lim - pa, 0), pb - pa);
+  // first offset of the list at or beyond the bound (the replay's nistop)
+  int ns = term_ni;
+  if (pb > pa) ns = (lim < pb) ? max(lim, pa) : ns;
+  if (U2 > 0) ns = (r2 >= lim) ? r2 : ns;
+  if (nseg >= 2) ns = (b1 >= lim) ? b1 : ns;
+  if (U1 > 0) ns = (r1 >= lim) ? r1 : ns;
+  ns = (b0 >= lim) ? b0 : ns;
+  if (U0 > 0) ns = (r0 >= lim) ? r0 : ns;
+  const bool a_t = ns < tail;
+  const double v_t = L.ilog[max(tail - ns, 0)] + Lfin;
+  double mx = L0;
+  mx = a_r0 ? fmax(mx, v_r0) : mx;  mx = a_b0 ? fmax(mx, L1) : mx;  mx = a_r1 ? fmax(mx, v_r1) : mx;
+  mx = a_b1 ? fmax(mx, L2) : mx;    mx = a_r2 ? fmax(mx, v_r2) : mx;  mx = (np > 0) ? fmax(mx, Llast) : mx;
+  mx = a_t ? fmax(mx, v_t) : mx;
+  auto term = [&](bool on, double v){ const double dd = v - mx; return (on && dd > d.log_thresh) ? (double)f_fasterexp((float)dd) : 0.0; };
+  double tot = term(true, L0);
+  tot += term(a_r0, v_r0); tot += term(a_b0, L1); tot += term(a_r1, v_r1); tot += term(a_b1, L2); tot += term(a_r2, v_r2);
+  tot += (double)np * term(np > 0, Llast);                   // equal float terms: the product is exact
+  tot += term(a_t, v_t);
+  return mx + (double)f_fasterlog((float)tot);
+}
+
 }  // namespace
 
 extern __shared__ double hs_lds_raw[];
@@ -530,6 +594,9 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
     // deletion sizes larger than the block have no list (shape -1) but are never evaluated
     const bool all_simple = __all((lane > HS_MAXREP) || (shapes >= 0) || (lane < HS_MAXREP && B - (lane+1)*p < 0));
     const hs_visit_t bundle = ins_list[min(lane, max(total, ins_len) - 1)];
+    // descriptor slots of the piecewise-simple lists (only looked at where a shape says so)
+    const double pwA = d.f64pool[uni(c.so->f64_off) + 20 + lane];
+    const double pwB = d.f64pool[uni(c.so->f64_off) + 20 + 64 + min(lane, (HS_MAXREP + 1)*HS_PW_SLOTS - 65)];
 
     {
       const int* src = (const int*)(d.chars + uni(c.so->seq_off));
@@ -677,6 +744,7 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
           const int limmax = min(max(0, min(B + D, jmax + 1) - D), B);
           const int shape = rdlane(shapes, HS_MAXREP);
           const double S = (shape >= 0) ? simple_eval(d, L, lp0, lim, shape, B)
+                         : (shape == HS_SHAPE_PIECEWISE) ? pw_eval(d, L, j, lp0, lim, pwA, pwB, HS_MAXREP, q+1, p, B)
                                         : visit_eval(d, L, j, lp0, lim, limmax, bundle, 0, ins_list, ins_len, q+1, p, B);
           const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
           term = (rdlane(c.cst, HS_MAXREP + 1 + q) + S) + pre;
@@ -693,6 +761,7 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
             const int rel = rdlane(lofs, q);
             const int shape = rdlane(shapes, q);
             const double S = (shape >= 0) ? simple_eval(d, L, lp0, lim, shape, B - aD)
+                           : (shape == HS_SHAPE_PIECEWISE) ? pw_eval(d, L, j, lp0, lim, pwA, pwB, q, 1, 0, B - aD)
                                           : visit_eval(d, L, j, lp0, lim, limmax, bundle, rel, ins_list + rel, rdlane(llen, q), 1, 0, B - aD);
             const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
             term = (rdlane(c.cst, HS_MAXREP - 1 - q) + S) + pre;

@@ -10,6 +10,8 @@
 #pragma once
 #include <stdint.h>
 
+#define HS_PW_SLOTS      10        // 64-bit descriptor slots per piecewise-simple visiting list (prep.cpp emit_stropt)
+#define HS_SHAPE_PIECEWISE (-2)
 #define HS_NART          13        // artifact sizes -6p..+6p (RepeatStutterInfo.h:10-11)
 #define HS_MAXREP        6
 #define HS_MAX_COLS      4         // max read columns per lane in the systolic sweep
@@ -48,13 +50,14 @@ struct hs_stropt_t {
   int32_t B;                 // block length
   int32_t nd;                // num_deletions_ (StutterAlignerClass.h:64-69)
   int32_t period;
-  int32_t f64_off;           // into f64 pool: pmf[13] | -int_log(B+1) | -int_log(B+D+1) for D=-p..-6p
+  int32_t f64_off;           // into f64 pool: pmf[13] | -int_log(B+1) | -int_log(B+D+1) for D=-p..-6p | 7 x HS_PW_SLOTS descriptor slots
   int32_t ins_off, ins_len;  // visiting list shared by all insertion sizes
   int32_t del_off[HS_MAXREP], del_len[HS_MAXREP];
   // Shape of each visiting list (index 0..5: deletion lists, 6: insertion list).  Periodic blocks give "simple" lists —
   // at most one run-skip entry at offset 0 (covering offsets 0..U0-1) followed only by plain entries at consecutive
   // offsets — whose log-sum-exp has a closed form in (lp0, bound); everything else replays the list.
-  //   shape = -1: generic list;  shape = U0 >= 0: simple list, U0 = 0 means "no skip entry, plain entries from offset 0"
+  //   shape = -1: generic list;  shape = U0 >= 0: simple list, U0 = 0 means "no skip entry, plain entries from offset 0";
+  //   shape = HS_SHAPE_PIECEWISE: one or two interruptions, closed form from the ten descriptor slots behind the constants
   int32_t shape[HS_MAXREP + 1];
 };
 

@@ -251,7 +251,47 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
     }
     return -1;
   };
+  // "piecewise simple" lists (a periodic block with one or two interruptions): [run?] break [run?] break [run?] plain... terminal.
+  // Between two emission-update ("break") entries the running likelihood is constant, so such a list has a closed form too.
+  // Ten 64-bit slots per list go to the f64 pool right after the 20 constants (bit patterns: two int32 or one double per slot):
+  //   0: nseg (-1 = not piecewise) | terminal ni    1,3,5: run ni | run U of segment 0,1,2    2,4,6: ln(run U)
+  //   7,8: break ni | ca + 256 cb of break 0,1      9: first plain ni | one past the last plain ni
+  auto piecewise = [&](int off, int len, int limmax, uint64_t slot[HS_PW_SLOTS]){
+    auto pack = [](int lo, int hi){ return (uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)hi << 32); };
+    auto bits = [](double v){ uint64_t u; memcpy(&u, &v, 8); return u; };
+    for (int i = 0; i < HS_PW_SLOTS; i++) slot[i] = 0;
+    slot[0] = pack(-1, 0);
+    const hs_visit_t* E = out.visits.data() + off;
+    auto ni_of = [](const hs_visit_t& e){ return (int)(e.meta & 0xffff); };
+    auto U_of  = [](const hs_visit_t& e){ return (int)((e.meta >> 16) & 0xffff); };
+    auto plain = [](const hs_visit_t& e){ return ((e.meta >> 48) & 1) != 0; };
+    int idx = 0, k = 0;
+    for (;;){
+      if (idx < len && !plain(E[idx]) && U_of(E[idx]) > 0 && ni_of(E[idx]) < limmax){
+        slot[1 + 2*k] = pack(ni_of(E[idx]), U_of(E[idx])); slot[2 + 2*k] = bits(E[idx].logU); idx++;
+      }
+      if (idx < len && !plain(E[idx]) && U_of(E[idx]) == 0 && ni_of(E[idx]) < limmax){
+        if (k == 2) return false;
+        slot[7 + k] = pack(ni_of(E[idx]), (int)((E[idx].meta >> 32) & 0xffff)); idx++; k++;
+        continue;
+      }
+      break;
+    }
+    if (k == 0) return false;                         // no interruption: the simple classifier's business (slot 0 still says "none")
+    int pa = 0, pb = 0;
+    if (idx < len && plain(E[idx]) && ni_of(E[idx]) < limmax){
+      pa = ni_of(E[idx]); pb = pa;
+      while (idx < len && plain(E[idx]) && ni_of(E[idx]) < limmax){ if (ni_of(E[idx]) != pb) return false; pb++; idx++; }
+    }
+    if (idx != len-1 || !plain(E[idx]) || ni_of(E[idx]) < limmax) return false;       // exactly the terminal entry must remain
+    slot[9] = pack(pa, pb);
+    slot[0] = pack(k, ni_of(E[idx]));
+    return true;
+  };
+  uint64_t pw[HS_MAXREP + 1][HS_PW_SLOTS];
+  for (int k = 0; k <= HS_MAXREP; k++) piecewise(0, 0, 0, pw[k]);          // "not piecewise"
   so.shape[HS_MAXREP] = classify(so.ins_off, so.ins_len, B);
+  if (so.shape[HS_MAXREP] < 0 && piecewise(so.ins_off, so.ins_len, B, pw[HS_MAXREP])) so.shape[HS_MAXREP] = HS_SHAPE_PIECEWISE;
   // deletion visiting lists (StutterAlignerClass.cpp:123-142); one per deletion size, shift = |D|
   for (int q = 0; q < HS_MAXREP; q++){
     const int D = -(q+1)*period;
@@ -268,7 +308,10 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
     }
     so.del_len[q] = out.visits.size() - so.del_off[q];
     so.shape[q] = classify(so.del_off[q], so.del_len[q], B+D);
+    if (so.shape[q] < 0 && piecewise(so.del_off[q], so.del_len[q], B+D, pw[q])) so.shape[q] = HS_SHAPE_PIECEWISE;
   }
+  for (int k = 0; k <= HS_MAXREP; k++)
+    for (int i = 0; i < HS_PW_SLOTS; i++){ double v; memcpy(&v, &pw[k][i], 8); out.f64pool.push_back(v); }
   out.stropts.push_back(so);
 }
 
