@@ -593,6 +593,7 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
     const int shapes = (lane <= HS_MAXREP) ? c.so->shape[lane] : -1;
     // deletion sizes larger than the block have no list (shape -1) but are never evaluated
     const bool all_simple = __all((lane > HS_MAXREP) || (shapes >= 0) || (lane < HS_MAXREP && B - (lane+1)*p < 0));
+    const bool all_closed = __all((lane > HS_MAXREP) || (shapes >= 0) || (shapes == HS_SHAPE_PIECEWISE) || (lane < HS_MAXREP && B - (lane+1)*p < 0));
     const hs_visit_t bundle = ins_list[min(lane, max(total, ins_len) - 1)];
     // descriptor slots of the piecewise-simple lists (only looked at where a shape says so)
     const double pwA = d.f64pool[uni(c.so->f64_off) + 20 + lane];
@@ -715,6 +716,49 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
             if (direct) lp0 += L.Mt[min(j + aD, n-1)] - L.Dl[q*L.ld + min(j + aD, n-1)];
             else        lp0 = L.nd[q*HS_ND_STRIDE + min(max(j - max(0, n - aD), 0), HS_ND_STRIDE-1)];
             const double S = simple_eval(d, L, lp0, actj ? len : 0, rdlane(shapes, q), B - aD);
+            const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
+            terms[HS_MAXREP - 1 - q] = (rdlane(c.cst, HS_MAXREP - 1 - q) + S) + pre;
+          }
+        }
+      } else if (all_closed){
+        // simple and piecewise-simple lists only (some allele of the locus has an interrupted repeat): the same unrolled evaluation,
+        // each list taking the closed form its shape names
+        {
+          const int len = min(B, j + 1);
+          const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
+          terms[HS_MAXREP] = (rdlane(c.cst, HS_MAXREP) + L.Mt[j]) + pre;
+        }
+        double li = 0.0;
+        const double2* pli_bq = L.bq + j; const uint8_t* pli_rd = L.rd + j; int li_left = j;
+#pragma unroll
+        for (int q = 0; q < HS_MAXREP; q++){
+          const int D = (q+1)*p;
+          for (int m = 0; m < p; m++){               // read position j - t: unclamped (a step with t > j is masked; Dl sits in front of bq)
+            const double2 bq = *pli_bq;
+            const double e = (m < B) ? emit(*pli_rd, blk_at(c, B-1-min(m, B-1)), bq) : bq.x;
+            if (li_left >= 0) li += e;
+            pli_bq--; pli_rd--; li_left--;
+          }
+          const int len = min(B + D, j + 1);
+          const double lp0 = (rdlane(c.cst, 13) + li) + ((len > D) ? L.Mt[max(j - D, 0)] : 0.0);
+          const int lim = actj ? min(max(0, len - D), B) : 0;
+          const int shp = rdlane(shapes, HS_MAXREP);
+          const double S = (shp >= 0) ? simple_eval(d, L, lp0, lim, shp, B) : pw_eval(d, L, j, lp0, lim, pwA, pwB, HS_MAXREP, q+1, p, B);
+          const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
+          terms[HS_MAXREP + 1 + q] = (rdlane(c.cst, HS_MAXREP + 1 + q) + S) + pre;
+        }
+#pragma unroll
+        for (int q = 0; q < HS_MAXREP; q++){
+          const int aD = (q+1)*p;
+          terms[HS_MAXREP - 1 - q] = IMP;
+          if (B - aD >= 0){
+            const int len = min(B - aD, j + 1);
+            const bool direct = (j + aD <= n - 1);
+            double lp0 = rdlane(c.cst, 14 + q);
+            if (direct) lp0 += L.Mt[min(j + aD, n-1)] - L.Dl[q*L.ld + min(j + aD, n-1)];
+            else        lp0 = L.nd[q*HS_ND_STRIDE + min(max(j - max(0, n - aD), 0), HS_ND_STRIDE-1)];
+            const int shp = rdlane(shapes, q);
+            const double S = (shp >= 0) ? simple_eval(d, L, lp0, actj ? len : 0, shp, B - aD) : pw_eval(d, L, j, lp0, actj ? len : 0, pwA, pwB, q, 1, 0, B - aD);
             const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
             terms[HS_MAXREP - 1 - q] = (rdlane(c.cst, HS_MAXREP - 1 - q) + S) + pre;
           }
