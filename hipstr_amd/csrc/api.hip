@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -78,6 +79,10 @@ int api_device_tables(ApiTables* t){
 }
 }  // namespace hipstr
 
+// failure inside hipstr_hmm_upload: release what the half-built batch already owns
+#define HS_HIP_DEV(call) do { hipError_t e_ = (call); if (e_ != hipSuccess){ \
+  g_err = std::string(#call) + ": " + hipGetErrorString(e_); hipstr_hmm_free(dev); return NULL; } } while (0)
+
 struct hipstr_dev_batch {
   hipstr::Prepared prep;
   hs_dev_t h;             // host copy of the argument block (device pointers inside)
@@ -108,7 +113,10 @@ int hipstr_batch_out_offsets(const hipstr_batch_t* b, int64_t* out_off){
 }
 
 int hipstr_hmm_init(int device_ordinal){
+  static std::mutex init_mutex;             // one device per process; concurrent first calls must not both build the tables
+  std::lock_guard<std::mutex> lock(init_mutex);
   if (g_tab.ready && g_tab.device == device_ordinal) return 0;
+  if (g_tab.ready) return fail("library already initialised on another device (one process per GPU)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail("no HIP device available: this library has no CPU path (build/run on an MI355X)");
@@ -204,8 +212,8 @@ hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){
   if (to_device_bytes(P.quals.data(), P.quals.size(), &p)){ hipstr_hmm_free(dev); return NULL; } dev->allocs.push_back(p); h.quals = p;
   double* out = NULL;
   const size_t out_bytes = (size_t)(P.n_out ? P.n_out : 1) * sizeof(double);
-  HS_HIP_NULL(hipMalloc((void**)&out, out_bytes)); dev->allocs.push_back(out);
-  HS_HIP_NULL(hipMemset(out, 0, out_bytes));
+  HS_HIP_DEV(hipMalloc((void**)&out, out_bytes)); dev->allocs.push_back(out);
+  HS_HIP_DEV(hipMemset(out, 0, out_bytes));
   h.aln_probs = out;
   const hipstr::HostTables& T = hipstr::host_tables();
   h.int_log = g_tab.int_log; h.qual_correct = g_tab.qc; h.qual_error = g_tab.qe; h.m2m = g_tab.m2m; h.m2i = g_tab.m2i;
@@ -221,14 +229,14 @@ hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){
     dev->allocs.push_back(di); dev->allocs.push_back(dw);
     h.items = di; h.ws = dw;
     double* w = NULL;
-    HS_HIP_NULL(hipMalloc((void**)&w, sizeof(double)*(size_t)(P.ws_mr_size ? P.ws_mr_size : 1))); dev->allocs.push_back(w); h.ws_mr = w;
-    HS_HIP_NULL(hipMalloc((void**)&w, sizeof(double)*(size_t)(P.ws_lt_size ? P.ws_lt_size : 1))); dev->allocs.push_back(w); h.ws_lt = w;
-    HS_HIP_NULL(hipMalloc((void**)&w, sizeof(double)*(size_t)(P.ws_lead_size ? P.ws_lead_size : 1))); dev->allocs.push_back(w); h.ws_lead = w;
-    HS_HIP_NULL(hipMalloc((void**)&w, sizeof(double)*(size_t)(P.ws_col_size ? P.ws_col_size : 1))); dev->allocs.push_back(w); h.ws_col = w;
+    HS_HIP_DEV(hipMalloc((void**)&w, sizeof(double)*(size_t)(P.ws_mr_size ? P.ws_mr_size : 1))); dev->allocs.push_back(w); h.ws_mr = w;
+    HS_HIP_DEV(hipMalloc((void**)&w, sizeof(double)*(size_t)(P.ws_lt_size ? P.ws_lt_size : 1))); dev->allocs.push_back(w); h.ws_lt = w;
+    HS_HIP_DEV(hipMalloc((void**)&w, sizeof(double)*(size_t)(P.ws_lead_size ? P.ws_lead_size : 1))); dev->allocs.push_back(w); h.ws_lead = w;
+    HS_HIP_DEV(hipMalloc((void**)&w, sizeof(double)*(size_t)(P.ws_col_size ? P.ws_col_size : 1))); dev->allocs.push_back(w); h.ws_col = w;
     // trailing-flank kernel: persistent wavefronts, each with two band-boundary rows of [max side columns][64 lanes][M,D]
     h.band_cols = P.max_side_len > 0 ? P.max_side_len : 1;
     dev->trail_waves = (int)std::min<size_t>(P.trail_items.size() ? P.trail_items.size() : 1, 256 * 16);
-    HS_HIP_NULL(hipMalloc((void**)&w, sizeof(double)*(size_t)dev->trail_waves*h.band_cols*64*2)); dev->allocs.push_back(w); h.ws_band = w;
+    HS_HIP_DEV(hipMalloc((void**)&w, sizeof(double)*(size_t)dev->trail_waves*h.band_cols*64*2)); dev->allocs.push_back(w); h.ws_band = w;
     hs_tgroup_t* dg = NULL; int32_t* dm = NULL; int32_t* dk = NULL; int32_t* dor = NULL;
     if (to_device(P.tgroups, &dg) || to_device(P.tmembers, &dm) || to_device(P.tpack, &dk) || to_device(P.str_order, &dor)){ hipstr_hmm_free(dev); return NULL; }
     dev->allocs.push_back(dg); dev->allocs.push_back(dm); dev->allocs.push_back(dk); dev->allocs.push_back(dor);
@@ -246,10 +254,10 @@ hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){
   dev->lds_bytes = hs_str_lds_bytes(h.lds_len, h.max_B);
   if (dev->lds_bytes > 160*1024){ g_err = "batch needs more than 160 KiB of LDS per workgroup"; hipstr_hmm_free(dev); return NULL; }
   if (dev->lds_bytes > 48*1024)
-    HS_HIP_NULL(hipFuncSetAttribute((const void*)hs_str_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->lds_bytes));
-  HS_HIP_NULL(hipMalloc((void**)&dev->d_args, sizeof(hs_dev_t))); dev->allocs.push_back(dev->d_args);
-  HS_HIP_NULL(hipMemcpy(dev->d_args, &h, sizeof h, hipMemcpyHostToDevice));
-  HS_HIP_NULL(hipEventCreate(&dev->ev0)); HS_HIP_NULL(hipEventCreate(&dev->ev1));
+    HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->lds_bytes));
+  HS_HIP_DEV(hipMalloc((void**)&dev->d_args, sizeof(hs_dev_t))); dev->allocs.push_back(dev->d_args);
+  HS_HIP_DEV(hipMemcpy(dev->d_args, &h, sizeof h, hipMemcpyHostToDevice));
+  HS_HIP_DEV(hipEventCreate(&dev->ev0)); HS_HIP_DEV(hipEventCreate(&dev->ev1));
   return dev;
 }
 
