@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "hipstr_amd", "csrc")
 HIP_SOURCES = ["api.hip", "hmm_kernels.hip", "post_kernels.hip", "prep.cpp", "trace.hip", "em.hip", "nw.hip", "batch_io.cpp"]
 HIP_HEADERS = ["layout.h", "post_layout.h", "prep.h", "device_common.h", os.path.join("..", "..", "include", "hipstr_hmm.h")]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-Wno-unused-result", "-Wno-unused-value"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans", "-mno-amdgpu-ieee", "-fPIC", "-shared", "-pthread", "-Wno-unused-result", "-Wno-unused-value"]
 
 
 def _stale(target, deps):
@@ -33,7 +33,7 @@ def build_hmm(force=False):
     deps = [os.path.join(CSRC, s) for s in HIP_SOURCES + HIP_HEADERS]
     if force or _stale(out, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        extra = ["-D%s=%s" % (m, os.environ[e]) for m, e in (("HS_MIN_WAVES", "HIPSTR_MIN_WAVES"), ("HS_TRAIL_ROWS", "HIPSTR_TRAIL_ROWS")) if os.environ.get(e)]
+        extra = ["-D%s=%s" % (m, os.environ[e]) for m, e in (("HS_MIN_WAVES", "HIPSTR_MIN_WAVES"), ("HS_TRAIL_ROWS", "HIPSTR_TRAIL_ROWS"), ("HS_ABL", "HIPSTR_ABL")) if os.environ.get(e)]
         _run([hipcc] + HIPCC_FLAGS + extra + ["-o", out] + [os.path.join(CSRC, s) for s in HIP_SOURCES])
     return out
 

@@ -23,6 +23,7 @@
 #include "api_internal.h"
 
 extern "C" __global__ void hs_str_kernel(const hs_dev_t* dp, int active_begin);
+extern "C" __global__ void hs_str_kernel_generic(const hs_dev_t* dp, int active_begin);
 extern "C" __global__ void hs_combine_kernel(const hs_dev_t* dp, int active_begin);
 extern "C" __global__ void hs_posterior_kernel(const hs_post_dev_t* dp);
 extern "C" __global__ void hs_genotype_kernel(const hs_gt_dev_t* dp);
@@ -253,8 +254,15 @@ hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){
   h.max_B = P.max_B;
   dev->lds_bytes = hs_str_lds_bytes(h.lds_len, h.max_B);
   if (dev->lds_bytes > 160*1024){ g_err = "batch needs more than 160 KiB of LDS per workgroup"; hipstr_hmm_free(dev); return NULL; }
-  if (dev->lds_bytes > 48*1024)
+  if (dev->lds_bytes > 48*1024){
     HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->lds_bytes));
+    HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_kernel_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->lds_bytes));
+  }
+  {
+    int32_t* rd = NULL;
+    HS_HIP_DEV(hipMalloc((void**)&rd, sizeof(int32_t)*(size_t)(h.n_active ? h.n_active : 1))); dev->allocs.push_back(rd); h.redo = rd;
+    h.debug_redo = getenv("HIPSTR_DEBUG_REDO") ? atoi(getenv("HIPSTR_DEBUG_REDO")) : 0;
+  }
   HS_HIP_DEV(hipMalloc((void**)&dev->d_args, sizeof(hs_dev_t))); dev->allocs.push_back(dev->d_args);
   HS_HIP_DEV(hipMemcpy(dev->d_args, &h, sizeof h, hipMemcpyHostToDevice));
   HS_HIP_DEV(hipEventCreate(&dev->ev0)); HS_HIP_DEV(hipEventCreate(&dev->ev1));
@@ -272,6 +280,7 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
     HS_HIP(hipEventRecord(dev->prof_pool[dev->prof_used++], st));
     return 0;
   };
+  HS_HIP(hipMemsetAsync(dev->h.redo, 0, sizeof(int32_t)*(size_t)dev->h.n_active, st));
   for (const hipstr::Prepared::Chunk& ch : dev->prep.chunks){
     const unsigned nact = ch.active_end - ch.active_begin;
     if (mark()) return 1;
@@ -281,6 +290,8 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
     }
     if (mark()) return 1;
     hipLaunchKernelGGL(hs_str_kernel, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin);
+    // alleles without a tabulated closed form (interrupted repeats, very long blocks) and whatever hs_str_kernel marked HS_REDO
+    hipLaunchKernelGGL(hs_str_kernel_generic, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin);
     if (mark()) return 1;
     if (ch.trail_end > ch.trail_begin)     // trailing flanks: persistent wavefronts striding over (read side, allele group) items
       hs_launch_trail((unsigned)std::min(dev->trail_waves, ch.trail_end - ch.trail_begin), st, dp,

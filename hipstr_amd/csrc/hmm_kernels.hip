@@ -374,12 +374,14 @@ struct StrLds {     // one side of one read
   double*  Dl;      // [6][ld] StutterAligner del_probs_
   uint8_t* rd;      // [n] read bases
   const double* ilog;   // [HS_ILOG_LDS] LDS copy of int_log(0..): ln of block-length-sized integers
-  double*  nd;      // [6][HS_ND_STRIDE] deletion start values of the columns within |D| of the read end
+  double*  nd;      // [HS_ND_TOTAL] deletion start values of the columns within |D| of the read end, the six sizes back to back
   double*  cstl;    // [20] pmf[13] | prior_ins | prior_del[6] of the current allele
+  double*  tab;     // [3][HS_TAB_CAP] tabulated closed form of the current allele's simple lists: A | G | Bnd (layout.h tab_*)
   uint8_t* blk;     // [blk_len] block bases of the current allele
   int ld;
 };
-#define HS_ND_STRIDE 56
+#define HS_ND_TOTAL 192      // sum over the six deletion sizes of min(|D|, n) <= 21 p <= 189
+#define HS_WAVE_LDS (HS_ND_TOTAL + 24 + 3*HS_TAB_CAP)   // doubles of per-wavefront LDS: nd | cstl | tab
 
 // Marginalisation over the artifact position (StutterAlignerClass.cpp:59-104 insertion, :106-150 deletion).
 // The loop over block offsets is the same for every read column, so the host enumerated it (hs_visit_t) and
@@ -515,21 +517,27 @@ __device__ __forceinline__ double pw_eval(const hs_dev_t& d, const StrLds& L, in
 
 }  // namespace
 
+#ifndef HS_STR_WAVES
+#define HS_STR_WAVES 4      // workgroups (2 wavefronts) per SIMD pair the register allocation aims at
+#endif
 extern __shared__ double hs_lds_raw[];
+
 
 // LDS bytes of one hs_str_kernel workgroup (both sides of a read) for a batch whose longest read has lds_len bases.
 extern "C" size_t hs_str_lds_bytes(int lds_len, int max_B){
   const size_t Lc = ((size_t)lds_len + 3) & ~(size_t)1;
   const size_t ilog_len = ((size_t)max_B + 9) & ~(size_t)1, blk_len = ((size_t)max_B + 19) & ~(size_t)15;
-  return Lc*16 + Lc*8*2 + Lc*8*HS_MAXREP + ilog_len*8 + 2*(HS_MAXREP*HS_ND_STRIDE + 24)*8 + 2*blk_len + ((Lc + 15) & ~(size_t)15);
+  return Lc*16 + Lc*8*2 + Lc*8*HS_MAXREP + ilog_len*8 + 2*HS_WAVE_LDS*8 + 2*blk_len + ((Lc + 15) & ~(size_t)15);
 }
 
 // Workgroup = one active read: wave 0 the left side, wave 1 the right side (independent; they share only the LDS
 // carve, whose per-column arrays are exactly len-1 long in total).  Writes M of the STR block's last row for every
 // realigned allele of the chunk to the MR workspace.
-extern "C" __global__ void __launch_bounds__(128, 4)
-hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
-  const hs_dev_t& d = *dp;
+// Two instantiations share the body, each with the register budget of its own evaluators:
+//   MODE 0 (hs_str_kernel)          alleles whose visiting lists are all simple and tabulated: positions [0, n_tab) of the side's order
+//   MODE 1 (hs_str_kernel_generic)  the other alleles, positions [n_tab, n_re): closed forms the long way and list replay
+template <int MODE>
+__device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const SideView v = side_view(d, active_begin + blockIdx.x, w);
   const int n = v.n;
@@ -545,31 +553,47 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
     double* Mt = rowP + Lc;
     const int ilog_len = (d.max_B + 9) & ~1, blk_len = (d.max_B + 19) & ~15;
     double* ilog = Mt + Lc;
-    double* ndb = ilog + ilog_len;                          // per wave: nd[6][HS_ND_STRIDE] | cstl[24]
-    uint8_t* blkb = (uint8_t*)(ndb + 2*(HS_MAXREP*HS_ND_STRIDE + 24));
+    double* ndb = ilog + ilog_len;                          // per wave: nd[HS_ND_TOTAL] | cstl[24] | tab[3][HS_TAB_CAP]
+    uint8_t* blkb = (uint8_t*)(ndb + 2*HS_WAVE_LDS);
     uint8_t* rdb = blkb + 2*blk_len;
     L.bq = bq + o; L.rowP = rowP + o; L.Mt = Mt + o; L.Dl = Dl + o; L.rd = rdb + o; L.ilog = ilog; L.ld = Lc;
-    L.nd = ndb + w*(HS_MAXREP*HS_ND_STRIDE + 24); L.cstl = L.nd + HS_MAXREP*HS_ND_STRIDE; L.blk = blkb + w*blk_len;
+    L.nd = ndb + w*HS_WAVE_LDS; L.cstl = L.nd + HS_ND_TOTAL; L.tab = L.cstl + 24; L.blk = blkb + w*blk_len;
     for (int i = threadIdx.x; i < ilog_len; i += 128) ilog[i] = d.int_log[i];
   }
   __syncthreads();
+  const int ncyc = (n + 63) / 64;
+  // alleles in the side's processing order (nested STR blocks follow each other); a chunk of positions per workgroup
+  const int n_tab = uni(v.loc->n_tab[w]);
+  const int r_lo = MODE == 0 ? 0 : n_tab, r_hi = MODE == 0 ? n_tab : uni(v.loc->n_re);
+  const int i0 = r_lo + blockIdx.y * d.allele_chunk, i1 = min(r_hi, i0 + d.allele_chunk);
+  const int32_t* order = d.str_order + uni(v.loc->order_off[w]);
+  // MODE 1 also re-does, the long way, the tabulated alleles of this read for which hs_str_kernel left HS_REDO marks (a lane's
+  // lp0 was too large for the table's guarantee): positions [j0, j1) of the tabulated range, looked at only if the read is flagged
+  const int ai = active_begin + blockIdx.x;
+  const bool redo = (MODE == 1) && uni(d.redo[ai]) != 0;
+  const int j0 = blockIdx.y * d.allele_chunk, j1 = redo ? min(n_tab, j0 + d.allele_chunk) : j0;
+  if (i0 >= i1 && j0 >= j1) return;           // nothing of this kind for this side (after the barrier: the other side may have work)
   for (int j = lane; j < n; j += 64){
     const int src = v.base_off + (w ? v.len - 1 - j : j);
     const uint8_t q = (uint8_t)d.quals[src];
     L.rd[j] = (uint8_t)d.bases[src];
     L.bq[j] = make_double2(d.qual_correct[q], d.qual_error[q]);
   }
-  const int ncyc = (n + 63) / 64;
-  // alleles in the side's processing order (nested STR blocks follow each other); a chunk of positions per workgroup
-  const int i0 = blockIdx.y * d.allele_chunk, i1 = min(uni(v.loc->n_re), i0 + d.allele_chunk);
-  const int32_t* order = d.str_order + uni(v.loc->order_off[w]);
   int cur_slot = -1, prev_B = 0;
-  for (int i = i0; i < i1; i++){
+  const int n_own = max(i1 - i0, 0), n_all = n_own + ((MODE == 1) ? max(j1 - j0, 0) : 0);
+  for (int it = 0; it < n_all; it++){
+    const bool own = it < n_own;                      // false: a candidate of the re-do scan
+    const int i = own ? i0 + it : j0 + (it - n_own);
     const int oe = uni(order[i]);
-    const bool chained = (i > i0) && ((oe >> 30) & 1);
+    const bool chained = own && (it > 0) && ((oe >> 30) & 1);
     const hs_allele_t* al = d.alleles + uni(v.loc->hap_begin) + (oe & 0x3fffffff);
     const int slot = uni(al->lead_slot[w]), str_opt = uni(al->str_opt[w]);
     double* mr_out = d.ws_mr + v.ws_mr + (int64_t)uni(al->re_ord)*(v.len-1) + (w ? v.nL : 0);
+    if (MODE == 1 && !own){
+      bool marked = false;
+      for (int kk = 0; kk < ncyc; kk++) marked |= (mr_out[64*kk] == HS_REDO);
+      if (!uni((int)marked)) continue;
+    }
     wave_lds_sync();                // the previous allele's readers of rowP/Mt/Dl are done
     if (slot != cur_slot){          // M of the row before the STR block, from the leading-flank kernel
       const double* rec = lead_record(d, v, slot);
@@ -587,23 +611,25 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
     // 64 entries; list offsets/lengths ride in one lane-indexed register (lane q: deletion list q, lane 6: insertion list)
     const int ins_off = uni(c.so->ins_off), ins_len = uni(c.so->ins_len);
     const hs_visit_t* ins_list = d.visits + ins_off;
-    const int lofs = (lane < HS_MAXREP) ? c.so->del_off[lane] - ins_off : 0;
-    const int llen = (lane < HS_MAXREP) ? c.so->del_len[lane] : 0;
     const int total = uni(c.so->del_off[HS_MAXREP-1]) + uni(c.so->del_len[HS_MAXREP-1]) - ins_off;
     const int shapes = (lane <= HS_MAXREP) ? c.so->shape[lane] : -1;
     // deletion sizes larger than the block have no list (shape -1) but are never evaluated
     const bool all_simple = __all((lane > HS_MAXREP) || (shapes >= 0) || (lane < HS_MAXREP && B - (lane+1)*p < 0));
     const bool all_closed = __all((lane > HS_MAXREP) || (shapes >= 0) || (shapes == HS_SHAPE_PIECEWISE) || (lane < HS_MAXREP && B - (lane+1)*p < 0));
-    const hs_visit_t bundle = ins_list[min(lane, max(total, ins_len) - 1)];
-    // descriptor slots of the piecewise-simple lists (only looked at where a shape says so)
-    const double pwA = d.f64pool[uni(c.so->f64_off) + 20 + lane];
-    const double pwB = d.f64pool[uni(c.so->f64_off) + 20 + 64 + min(lane, (HS_MAXREP + 1)*HS_PW_SLOTS - 65)];
 
     {
       const int* src = (const int*)(d.chars + uni(c.so->seq_off));
       for (int i = lane; i < (B + 3)/4; i += 64) ((int*)L.blk)[i] = src[i];
     }
     if (lane < 20) L.cstl[lane] = c.cst;
+    // tabulated closed form of the simple lists (when prep.cpp could build it): entry bases ride in a lane-indexed register
+    const int tab_len = uni(c.so->tab_len);
+    const bool use_tab = (MODE == 0);          // prep.cpp put exactly the alleles with all_simple && tab_len > 0 into [0, n_tab)
+    const int tbase = (lane <= HS_MAXREP) ? c.so->tab_base[lane] : 0;
+    if (use_tab){
+      const double* src = d.f64pool + uni(c.so->tab_off);
+      for (int i = lane; i < 3*tab_len; i += 64){ const int e = i / 3; L.tab[(i - 3*e)*HS_TAB_CAP + e] = src[i]; }
+    }
     wave_lds_sync();
 
     // --- StutterAlignerClass::load_read (StutterAlignerClass.cpp:12-53): match_probs_ and del_probs_
@@ -636,6 +662,7 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
     // min(|D|, n) such columns per deletion size, so (size, column) pairs are spread over the lanes instead of
     // looping over the block once per deletion size.
     {
+      // size q has min(|D|, n) such columns; the pairs of all sizes are numbered back to back and nd[] is indexed by that number
       int cnt[HS_MAXREP], npairs = 0;
 #pragma unroll
       for (int q = 0; q < HS_MAXREP; q++){ cnt[q] = (B - (q+1)*p >= 0) ? min((q+1)*p, n) : 0; npairs += cnt[q]; }
@@ -667,7 +694,7 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
           if (t < len) lp += e;
           prd--; pbq--; pbk--;
         }
-        if (valid) L.nd[q*HS_ND_STRIDE + off] = lp;
+        if (valid) L.nd[base + lane] = lp;
       }
     }
     wave_lds_sync();
@@ -680,6 +707,86 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
       // The 13 artifact terms are produced by ONE runtime loop (no artifact, insertions +p..+6p, deletions -p..-6p) and
       // kept in a rotating register window; fast_log_sum_exp (mathops.cpp:97-106) does not depend on their order.
       double terms[HS_NART];
+      auto finish_chunk = [&](){                     // fast_log_sum_exp over the 13 artifact terms (mathops.cpp:97-106)
+        Lse acc;
+        for (int pass = 0; pass < 2; pass++){
+          acc.start(pass, terms[0]);
+#pragma unroll
+          for (int t = 0; t < HS_NART; t++) acc.push(pass, terms[t], d.log_thresh);
+        }
+        if (actj) mr_out[j] = acc.finish();
+      };
+      if constexpr (MODE == 0){
+        // every list is simple and tabulated: S = (lp0 + A[e]) + G[e], e from the lane's bound; a lane whose |lp0| is not below
+        // Bnd[e] sends the chunk through the long form below (rare: a float rounding boundary within reach of lp0's rounding error)
+        bool bad = false;
+        auto tab_eval = [&](double lp0, int lim, int k) -> double {
+          const int e = rdlane(tbase, k) + min(lim, 1) + max(lim - rdlane(shapes, k), 0);
+          const double A = L.tab[e], G = L.tab[HS_TAB_CAP + e], Bd = L.tab[2*HS_TAB_CAP + e];
+          bad |= !(fabs(lp0) < Bd);
+          return (lp0 + A) + G;
+        };
+        {
+          const int len = min(B, j + 1);
+          const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
+          terms[HS_MAXREP] = (rdlane(c.cst, HS_MAXREP) + L.Mt[j]) + pre;
+        }
+        double li = 0.0;
+        const double2* pli_bq = L.bq + j; const uint8_t* pli_rd = L.rd + j; int li_left = j;
+#pragma unroll
+        for (int q = 0; q < HS_MAXREP; q++){
+          const int D = (q+1)*p;
+          for (int m = 0; m < p; m++){
+            const double2 bq = *pli_bq;
+            const double e = (m < B) ? emit(*pli_rd, blk_at(c, B-1-min(m, B-1)), bq) : bq.x;
+            if (li_left >= 0) li += e;
+            pli_bq--; pli_rd--; li_left--;
+          }
+          const int len = min(B + D, j + 1);
+          const double lp0 = (rdlane(c.cst, 13) + li) + ((len > D) ? L.Mt[max(j - D, 0)] : 0.0);
+          const int lim = actj ? min(max(0, len - D), B) : 0;
+          const double S = tab_eval(lp0, lim, HS_MAXREP);
+          const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
+          terms[HS_MAXREP + 1 + q] = (rdlane(c.cst, HS_MAXREP + 1 + q) + S) + pre;
+        }
+        int ndo = 0;                                   // number of the first (size q, column) pair: sizes 0..q-1 come first
+#pragma unroll
+        for (int q = 0; q < HS_MAXREP; q++){
+          const int aD = (q+1)*p;
+          terms[HS_MAXREP - 1 - q] = IMP;
+          if (B - aD >= 0){
+            const int cq = min(aD, n);
+            const int len = min(B - aD, j + 1);
+            const bool direct = (j + aD <= n - 1);
+            double lp0 = rdlane(c.cst, 14 + q);
+            if (direct) lp0 += L.Mt[min(j + aD, n-1)] - L.Dl[q*L.ld + min(j + aD, n-1)];
+            else        lp0 = L.nd[ndo + min(max(j - (n - cq), 0), cq - 1)];
+            const double S = tab_eval(lp0, actj ? len : 0, q);
+            const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
+            terms[HS_MAXREP - 1 - q] = (rdlane(c.cst, HS_MAXREP - 1 - q) + S) + pre;
+            ndo += cq;
+          }
+        }
+        if (d.debug_redo > 0) bad |= ((ai*31 + i*7 + kk) % d.debug_redo) == 0;       // tests: exercise the re-do path
+        if (!__any(bad && actj)){ finish_chunk(); continue; }
+        // leave the chunk to hs_str_kernel_generic
+        if (actj) mr_out[j] = HS_REDO;
+        if (lane == 0) d.redo[ai] = 1;
+        continue;
+      }
+      // what only the long forms need is loaded where they run, so that it does not occupy registers across the tabulated path
+      // (per chunk instead of per allele: a handful of L1-resident loads next to >1000 instructions of evaluation)
+      int lofs = 0, llen = 0; hs_visit_t bundle; double pwA = 0.0, pwB = 0.0;
+      bundle.meta = 0; bundle.logU = 0.0;
+      if constexpr (MODE != 0){
+        lofs = (lane < HS_MAXREP) ? c.so->del_off[lane] - ins_off : 0;
+        llen = (lane < HS_MAXREP) ? c.so->del_len[lane] : 0;
+        if (!all_closed) bundle = ins_list[min(lane, max(total, ins_len) - 1)];
+        if (!all_simple){      // descriptor slots of the piecewise-simple lists (only looked at where a shape says so)
+          pwA = d.f64pool[uni(c.so->f64_off) + 20 + lane];
+          pwB = d.f64pool[uni(c.so->f64_off) + 20 + 64 + min(lane, (HS_MAXREP + 1)*HS_PW_SLOTS - 65)];
+        }
+      }
       if (all_simple){
         // every visiting list of this STR option is "simple" (periodic block): closed-form evaluators, statically indexed terms
         {
@@ -705,22 +812,25 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
           const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
           terms[HS_MAXREP + 1 + q] = (rdlane(c.cst, HS_MAXREP + 1 + q) + S) + pre;
         }
+        int ndo = 0;                                   // number of the first (size q, column) pair: sizes 0..q-1 come first
 #pragma unroll
         for (int q = 0; q < HS_MAXREP; q++){
           const int aD = (q+1)*p;
           terms[HS_MAXREP - 1 - q] = IMP;
           if (B - aD >= 0){
+            const int cq = min(aD, n);
             const int len = min(B - aD, j + 1);
             const bool direct = (j + aD <= n - 1);
             double lp0 = rdlane(c.cst, 14 + q);
             if (direct) lp0 += L.Mt[min(j + aD, n-1)] - L.Dl[q*L.ld + min(j + aD, n-1)];
-            else        lp0 = L.nd[q*HS_ND_STRIDE + min(max(j - max(0, n - aD), 0), HS_ND_STRIDE-1)];
+            else        lp0 = L.nd[ndo + min(max(j - (n - cq), 0), cq - 1)];
             const double S = simple_eval(d, L, lp0, actj ? len : 0, rdlane(shapes, q), B - aD);
             const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
             terms[HS_MAXREP - 1 - q] = (rdlane(c.cst, HS_MAXREP - 1 - q) + S) + pre;
+            ndo += cq;
           }
         }
-      } else if (all_closed){
+      } else if (MODE != 0 && all_closed){
         // simple and piecewise-simple lists only (some allele of the locus has an interrupted repeat): the same unrolled evaluation,
         // each list taking the closed form its shape names
         {
@@ -747,26 +857,30 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
           const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
           terms[HS_MAXREP + 1 + q] = (rdlane(c.cst, HS_MAXREP + 1 + q) + S) + pre;
         }
+        int ndo = 0;                                   // number of the first (size q, column) pair: sizes 0..q-1 come first
 #pragma unroll
         for (int q = 0; q < HS_MAXREP; q++){
           const int aD = (q+1)*p;
           terms[HS_MAXREP - 1 - q] = IMP;
           if (B - aD >= 0){
+            const int cq = min(aD, n);
             const int len = min(B - aD, j + 1);
             const bool direct = (j + aD <= n - 1);
             double lp0 = rdlane(c.cst, 14 + q);
             if (direct) lp0 += L.Mt[min(j + aD, n-1)] - L.Dl[q*L.ld + min(j + aD, n-1)];
-            else        lp0 = L.nd[q*HS_ND_STRIDE + min(max(j - max(0, n - aD), 0), HS_ND_STRIDE-1)];
+            else        lp0 = L.nd[ndo + min(max(j - (n - cq), 0), cq - 1)];
             const int shp = rdlane(shapes, q);
             const double S = (shp >= 0) ? simple_eval(d, L, lp0, actj ? len : 0, shp, B - aD) : pw_eval(d, L, j, lp0, actj ? len : 0, pwA, pwB, q, 1, 0, B - aD);
             const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
             terms[HS_MAXREP - 1 - q] = (rdlane(c.cst, HS_MAXREP - 1 - q) + S) + pre;
+            ndo += cq;
           }
         }
       } else {
 #pragma unroll
       for (int t = 0; t < HS_NART; t++) terms[t] = IMP;
       double li = 0.0;                               // running ins_probs_ sum (StutterAlignerClass.cpp:40-51)
+      int ndo = 0;                                   // number of the first (size q, column) pair in nd[]
       for (int itn = 0; itn < HS_NART; itn++){
         double term = IMP;
         if (itn == 0){                               // no artifact (StutterAlignerClass.cpp:55-57)
@@ -795,11 +909,12 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
         } else {                                     // deletion of aD = (q+1) p bases
           const int q = itn - 1 - HS_MAXREP, aD = (q+1)*p;
           if (B - aD >= 0){
+            const int cq = min(aD, n);
             const int len = min(B - aD, j + 1);
             const bool direct = (j + aD <= n - 1);
             double lp0 = rdlane(c.cst, 14 + q);
             if (direct) lp0 += L.Mt[min(j + aD, n-1)] - L.Dl[q*L.ld + min(j + aD, n-1)];
-            else        lp0 = L.nd[q*HS_ND_STRIDE + min(max(j - max(0, n - aD), 0), HS_ND_STRIDE-1)];
+            else        lp0 = L.nd[ndo + min(max(j - (n - cq), 0), cq - 1)];
             const int lim = actj ? len : 0;
             const int limmax = min(B - aD, jmax + 1);
             const int rel = rdlane(lofs, q);
@@ -809,6 +924,7 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
                                           : visit_eval(d, L, j, lp0, lim, limmax, bundle, rel, ins_list + rel, rdlane(llen, q), 1, 0, B - aD);
             const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
             term = (rdlane(c.cst, HS_MAXREP - 1 - q) + S) + pre;
+            ndo += cq;
           }
         }
 #pragma unroll
@@ -816,16 +932,16 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
         terms[HS_NART-1] = term;
       }
       }
-      Lse acc;
-      for (int pass = 0; pass < 2; pass++){
-        acc.start(pass, terms[0]);
-#pragma unroll
-        for (int t = 0; t < HS_NART; t++) acc.push(pass, terms[t], d.log_thresh);
-      }
-      if (actj) mr_out[j] = acc.finish();
+      finish_chunk();
     }
   }
 }
+
+extern "C" __global__ void __launch_bounds__(128, HS_STR_WAVES)
+hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){ str_body<0>(*dp, active_begin); }
+
+extern "C" __global__ void __launch_bounds__(128, HS_STR_WAVES)
+hs_str_kernel_generic(const hs_dev_t* __restrict__ dp, int active_begin){ str_body<1>(*dp, active_begin); }
 
 // compute_aln_logprob (HapAligner.cpp:163-231): log-sum-exp over the haplotype positions the seed base can sit on.
 // One workgroup (4 wavefronts) per active read; a wavefront takes every fourth realigned allele, so what depends on the read only

@@ -12,11 +12,13 @@
 
 #define HS_PW_SLOTS      10        // 64-bit descriptor slots per piecewise-simple visiting list (prep.cpp emit_stropt)
 #define HS_SHAPE_PIECEWISE (-2)
+#define HS_TAB_CAP       48        // closed-form table entries per STR option the STR kernel keeps in LDS (hs_stropt_t::tab_*)
 #define HS_NART          13        // artifact sizes -6p..+6p (RepeatStutterInfo.h:10-11)
 #define HS_MAXREP        6
 #define HS_MAX_COLS      4         // max read columns per lane in the systolic sweep
 #define HS_MAX_SIDE_LEN  (64 * HS_MAX_COLS)
 #define HS_IMPOSSIBLE    (-1000000000.0)   // HapAligner.cpp:20
+#define HS_REDO          (1.0e300)         // mark in the MR workspace: "this chunk of columns is left to hs_str_kernel_generic"
 
 // One haplotype row of a flank block, as it enters the systolic sweep.
 //   bits  0..7   haplotype base (raw char, compared with read chars for equality)
@@ -59,6 +61,14 @@ struct hs_stropt_t {
   //   shape = -1: generic list;  shape = U0 >= 0: simple list, U0 = 0 means "no skip entry, plain entries from offset 0";
   //   shape = HS_SHAPE_PIECEWISE: one or two interruptions, closed form from the ten descriptor slots behind the constants
   int32_t shape[HS_MAXREP + 1];
+  // Tabulated closed form of the simple lists (prep.cpp simple_table): for a simple list the log-sum-exp over the artifact
+  // positions is lp0 + A + G with A, G functions of the lane's bound only — as long as the float conversions inside
+  // fast_log_sum_exp round the way they do for an exact lp0, which holds whenever |lp0| < Bnd (else the kernel evaluates
+  // the closed form the long way).  Entry e of list k sits at f64 pool [tab_off + 3*(tab_base[k] + e)] = {A, G, Bnd};
+  // e = [bound > 0] + max(bound - U0, 0).  tab_len = 0: no table (a list of the option is not simple, or too many entries).
+  int32_t tab_off, tab_len;
+  int32_t tab_base[HS_MAXREP + 1];
+  int32_t pad_;
 };
 
 struct hs_allele_t {
@@ -83,6 +93,7 @@ struct hs_locus_t {
   int32_t tg_begin[2];       // trailing-flank allele groups of this locus per side: range in tgroups[]
   int32_t tg_count[2];
   int32_t order_off[2];      // STR-kernel processing order of the realigned alleles per side: range [order_off, +n_re) in str_order[]
+  int32_t n_tab[2];          // the first n_tab positions of that order are the alleles with a tabulated closed form (hs_stropt_t::tab_len > 0)
 };
 
 struct hs_read_t {
@@ -134,6 +145,7 @@ struct hs_dev_t {
   double*            ws_lt;
   double*            ws_lead;
   double*            aln_probs;
+  int32_t*           redo;       // [n_active] set by hs_str_kernel when it left HS_REDO marks for a read; cleared before every pass
   // constant tables
   const double*      int_log;    // [10000]
   const double*      qual_correct; // [256] indexed by raw quality char (clamps applied)
@@ -147,4 +159,5 @@ struct hs_dev_t {
   int32_t            lds_len;        // max read length in the batch (LDS carve of the STR kernel)
   int32_t            band_cols;      // max columns of one read side (rows of a band-boundary buffer)
   int32_t            max_B;          // longest STR allele of the batch (LDS carve of the STR kernel)
+  int32_t            debug_redo;     // tests (HIPSTR_DEBUG_REDO=k): hs_str_kernel leaves every k-th chunk to the re-do path
 };

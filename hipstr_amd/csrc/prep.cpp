@@ -11,6 +11,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 
@@ -198,6 +200,57 @@ inline hs_visit_t visit(int ni, int U, char ca, char cb, bool plain, double logU
 }
 
 // One STR option in one orientation -> hs_stropt_t (+ its pools)
+static double g_bnd_scale = 1.0;      // read from the environment at the start of every prepare_batch / append_stropt
+
+// ---- host copies of the float bit tricks (fastonebigheader.h:206-218, 348-358), used to tabulate the closed form below
+static float h_fasterexp(float p){
+  const float y = 1.442695040f * p;
+  const float c = (y < -126.0f) ? -126.0f : y;
+  const float z = c + 126.94269504f;
+  const uint32_t u = (uint32_t)(8388608.0f * z);
+  float r; memcpy(&r, &u, 4); return r;
+}
+static float h_fasterlog(float x){
+  uint32_t u; memcpy(&u, &x, 4);
+  float y = (float)u;
+  y = y * 8.2629582881927490e-8f;
+  return y - 87.989971088f;
+}
+
+// One entry {A, G, Bnd} of the tabulated closed form of a simple visiting list (hmm_kernels.hip simple_eval is the long form):
+// the pushed values are lp0 (1 + nplain times), ln(U0) + lp0 and ln(tail - stop) + lp0, so with A = the largest of the added
+// constants the maximum is fl(lp0 + A) (rounding is monotone) and the float arguments of the exponentials are the differences
+// of the constants, off by at most the rounding errors of the sums: |err| <= 2^-52 (|lp0| + 3A).  If every such difference
+// keeps its float rounding and its side of LOG_THRESH under an error of 2^-50 (|lp0| + A + 1), the sum of exponentials and
+// hence G = fasterlog(sum) do not depend on lp0.  Bnd is the largest |lp0| for which that is guaranteed.
+static void simple_table_entry(int lim, int U0, int tail, double ent[3]){
+  const HostTables& T = host_tables();
+  const bool skip = (U0 > 0) && (lim > 0);
+  const int nplain = std::max(0, lim - U0);
+  const int stop = (lim <= 0) ? 0 : ((U0 > 0 && lim <= U0) ? U0 : lim);
+  const bool has_tail = stop < tail;
+  const double a[3] = {0.0, T.int_log[U0], T.int_log[std::max(tail - stop, 0)]};
+  const bool on[3] = {true, skip, has_tail};
+  const double w[3] = {(double)(1 + nplain), 1.0, 1.0};
+  double amax = 0.0;
+  for (int i = 1; i < 3; i++) if (on[i] && a[i] > amax) amax = a[i];
+  double tot = 0.0, delta = 1e300;
+  for (int i = 0; i < 3; i++){
+    if (!on[i]) continue;
+    if (a[i] == amax){ tot += w[i] * (double)h_fasterexp(0.0f); continue; }        // the device difference is exactly zero
+    const double x = a[i] - amax;
+    const float f = (float)x;
+    const double m_lo = 0.5*((double)f + (double)nextafterf(f, -INFINITY)), m_hi = 0.5*((double)f + (double)nextafterf(f, INFINITY));
+    delta = std::min(delta, std::min(x - m_lo, m_hi - x));
+    delta = std::min(delta, fabs(x - T.log_thresh));
+    if (x > T.log_thresh) tot += w[i] * (double)h_fasterexp(f);
+  }
+  ent[0] = amax;
+  ent[1] = (double)h_fasterlog((float)tot);
+  ent[2] = (delta >= 1e300) ? 1e300 : std::max(0.0, delta * 1125899906842624.0 /* 2^50 */ - amax - 1.0);
+  if (ent[2] < 1e300) ent[2] *= g_bnd_scale;      // tests: shrink the guarantee (HIPSTR_DEBUG_BND_SCALE)
+}
+
 void emit_stropt(const std::string& blk, int period, const double* stutter, Prepared& out){
   const HostTables& T = host_tables();
   const int B = blk.size();
@@ -312,6 +365,32 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
   }
   for (int k = 0; k <= HS_MAXREP; k++)
     for (int i = 0; i < HS_PW_SLOTS; i++){ double v; memcpy(&v, &pw[k][i], 8); out.f64pool.push_back(v); }
+  // tabulated closed form: only when every list the kernel can evaluate is simple and the entries fit the LDS budget
+  so.tab_off = out.f64pool.size(); so.tab_len = 0;
+  {
+    bool ok = true; int total = 0;
+    for (int k = 0; k <= HS_MAXREP && ok; k++){
+      const int tail = (k == HS_MAXREP) ? B : B - (k+1)*period;
+      so.tab_base[k] = total;
+      if (tail < 0) continue;                           // this deletion size is never evaluated
+      if (so.shape[k] < 0){ ok = false; break; }
+      total += 2 + std::max(0, tail - so.shape[k]);
+    }
+    if (ok && total <= HS_TAB_CAP){
+      for (int k = 0; k <= HS_MAXREP; k++){
+        const int tail = (k == HS_MAXREP) ? B : B - (k+1)*period;
+        if (tail < 0) continue;
+        const int U0 = so.shape[k], n = 2 + std::max(0, tail - U0);
+        for (int e = 0; e < n; e++){
+          const int lim = (e == 0) ? 0 : (e == 1 ? 1 : U0 + e - 1);      // a bound that maps to entry e (entry 1 is unused when U0 = 0)
+          double ent[3];
+          simple_table_entry(lim, U0, tail, ent);
+          out.f64pool.insert(out.f64pool.end(), ent, ent + 3);
+        }
+      }
+      so.tab_len = total;
+    }
+  }
   out.stropts.push_back(so);
 }
 
@@ -329,6 +408,7 @@ void append_stropt(const std::string& blk, int period, const double* stutter, Pr
 
 int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int64_t ws_budget){
   host_tables();
+  g_bnd_scale = getenv("HIPSTR_DEBUG_BND_SCALE") ? atof(getenv("HIPSTR_DEBUG_BND_SCALE")) : 1.0;
   if (b == NULL || b->n_loci < 0){ err = "null or negative-size batch"; return 1; }
   const int n_reads_total = b->n_loci > 0 ? b->read_off[b->n_loci] : 0;
   out.seeds.assign(n_reads_total, -1);
@@ -445,17 +525,24 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
         if (side) std::reverse(q.begin(), q.end());
         return q;
       };
+      // alleles whose closed form is tabulated come first: they are the business of hs_str_kernel, the rest of hs_str_kernel_generic
+      auto tabbed = [&](int k){ return out.stropts[out.alleles[loc.hap_begin + k].str_opt[side]].tab_len > 0; };
       std::stable_sort(ks.begin(), ks.end(), [&](int x, int y){
+        const bool tx = tabbed(x), ty = tabbed(y);
+        if (tx != ty) return tx;
         const std::string a = block_of(x), b2 = block_of(y);
         if (a.size() != b2.size()) return a.size() < b2.size();
         return a < b2;
       });
       loc.order_off[side] = out.str_order.size();
+      loc.n_tab[side] = 0;
       std::string prev;
       for (size_t i = 0; i < ks.size(); i++){
         const std::string cur = block_of(ks[i]);
-        const bool chained = i > 0 && cur.size() >= prev.size() && cur.compare(cur.size() - prev.size(), prev.size(), prev) == 0;
+        const bool first_of_kind = (i == 0) || (tabbed(ks[i]) != tabbed(ks[i-1]));
+        const bool chained = !first_of_kind && cur.size() >= prev.size() && cur.compare(cur.size() - prev.size(), prev.size(), prev) == 0;
         out.str_order.push_back(ks[i] | (chained ? (1 << 30) : 0));
+        if (tabbed(ks[i])) loc.n_tab[side]++;
         prev = cur;
       }
     }

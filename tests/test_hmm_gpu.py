@@ -173,3 +173,22 @@ def test_random_shapes_match_oracle(hmm, oracle, monkeypatch):
         assert np.array_equal(gs, ws) and np.array_equal(got, want), kw
         total += got.size
     assert total > 10000
+
+
+@pytest.mark.parametrize("env", [("HIPSTR_DEBUG_REDO", "1"), ("HIPSTR_DEBUG_REDO", "3"), ("HIPSTR_DEBUG_BND_SCALE", "1e-6"),
+                                 ("HIPSTR_DEBUG_BND_SCALE", "0")], ids=["redo_all", "redo_third", "bound_1e-6", "bound_0"])
+def test_tabulated_closed_form_and_its_redo_path(hmm, oracle, monkeypatch, env):
+    """hs_str_kernel evaluates simple visiting lists from a table that is exact only while |lp0| stays below a per-entry bound; chunks of
+    columns that cannot promise that are marked and re-done the long way by hs_str_kernel_generic.  Force that path (every chunk, every
+    third chunk, a bound shrunk by 1e6, a bound of zero) on perfect, interrupted and masked inputs: the result must not move."""
+    monkeypatch.setenv("HIPSTR_SYNTH_IMPERFECT", "0.1")
+    cases = [dict(n_loci=5, reads_per_locus=30, n_str_alleles=32, seed=71),
+             dict(n_loci=3, reads_per_locus=20, n_str_alleles=9, n_flank_opts=2, seed=72, mask_rate=0.3),
+             dict(n_loci=2, reads_per_locus=12, n_str_alleles=128, read_len=250, flank_len=120, str_bp=90, seed=73)]
+    for kw in cases:
+        sb = capi.SynthBatch(**kw)
+        want, ws = capi.run_align(oracle, "oracle_", sb.ptr, fill=-3.25)
+        monkeypatch.setenv(*env)
+        got, gs = capi.run_align(hmm, "hipstr_hmm_", sb.ptr, fill=-3.25)
+        monkeypatch.delenv(env[0])
+        assert np.array_equal(gs, ws) and np.array_equal(got, want), (env, kw)
