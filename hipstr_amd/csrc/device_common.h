@@ -39,6 +39,14 @@ __device__ __forceinline__ void wave_lds_sync(){
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+__device__ __forceinline__ int wave_min_i(int v){
+  for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v){
+  for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
+  return v;
+}
 __device__ __forceinline__ double wave_max_d(double v){
   for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
   return v;

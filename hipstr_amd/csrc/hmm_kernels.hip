@@ -604,6 +604,7 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
     StrCtx c;
     c.so = d.stropts + str_opt;
     c.B = uni(c.so->B); c.p = uni(c.so->period); c.nd = uni(c.so->nd);
+    const int nd_eq = uni(c.so->nd_eq);
     c.cst = d.f64pool[uni(c.so->f64_off) + min(lane, 19)];
     c.blk = L.blk;
     const int B = c.B, p = c.p;
@@ -666,33 +667,44 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
       int cnt[HS_MAXREP], npairs = 0;
 #pragma unroll
       for (int q = 0; q < HS_MAXREP; q++){ cnt[q] = (B - (q+1)*p >= 0) ? min((q+1)*p, n) : 0; npairs += cnt[q]; }
-      const int tmax = min(B - p, n);
       for (int base = 0; base < npairs; base += 64){
-        int off = base + lane; const bool valid = off < npairs;
+        // surplus lanes of the last round repeat its last pair (computed, not stored), so that every lane has a real length
+        int off = min(base + lane, npairs - 1); const bool valid = base + lane < npairs;
         int q = 0;
 #pragma unroll
         for (int qq = 0; qq < HS_MAXREP - 1; qq++) if (q == qq && off >= cnt[qq]){ off -= cnt[qq]; q = qq + 1; }
-        if (!valid){ q = 0; off = 0; }
         const int aD = (q+1)*p;
         const int j = max(0, n - aD) + off;
-        const int len = valid ? min(B - aD, j + 1) : 0;
+        const int len = min(B - aD, j + 1);
+        // pairs are numbered size-major, so the lengths within a round are close: the first lmin steps need no mask at all, and the
+        // round stops at its own longest sum
+        const int lmin = uni(wave_min_i(len)), lmax = uni(wave_max_i(len));
         double lp = L.cstl[14 + q];
-        // step t pairs read base j - t with block base B-1-aD - t; len <= j + 1 and len <= B - aD, so a step that would leave either
-        // array is masked anyway: no clamps, pointers move in chunks of 4 and the accesses take immediate offsets
-        const uint8_t* prd = L.rd + j; const double2* pbq = L.bq + j; const uint8_t* pbk = L.blk + (B - 1 - aD);
-        int t = 0;
-        for (; t + 4 <= tmax; t += 4){
-          prd -= 4; pbq -= 4; pbk -= 4;
+        // step t pairs read base j - t with block base B-1-aD - t.  xr / xb: lowest read / block index of the current group of four
+        // steps (opaque to the optimiser, so that the four accesses become one address plus immediate offsets); in the masked loops an
+        // index may fall in front of its array (Dl leads the LDS carve; in front of blk sit the per-wave tables): read, never used
+        int xr = j - 3, xb = (B - 1 - aD) - 3, t = 0;
+        for (; t + 4 <= lmin; t += 4){
+          asm volatile("" : "+v"(xr), "+v"(xb));
+          const uint8_t* prd = L.rd + xr; const double2* pbq = L.bq + xr; const uint8_t* pbk = L.blk + xb;
+#pragma unroll
+          for (int k = 0; k < 4; k++) lp += emit(prd[3-k], pbk[3-k], pbq[3-k]);
+          xr -= 4; xb -= 4;
+        }
+        for (; t + 4 <= lmax; t += 4){
+          asm volatile("" : "+v"(xr), "+v"(xb));
+          const uint8_t* prd = L.rd + xr; const double2* pbq = L.bq + xr; const uint8_t* pbk = L.blk + xb;
 #pragma unroll
           for (int k = 0; k < 4; k++){
-            const double e = emit(prd[4-k], pbk[4-k], pbq[4-k]);
+            const double e = emit(prd[3-k], pbk[3-k], pbq[3-k]);
             if (t + k < len) lp += e;
           }
+          xr -= 4; xb -= 4;
         }
-        for (; t < tmax; t++){
-          const double e = emit(*prd, *pbk, *pbq);
+        for (; t < lmax; t++){
+          const double e = emit(L.rd[xr + 3], L.blk[xb + 3], L.bq[xr + 3]);
           if (t < len) lp += e;
-          prd--; pbq--; pbk--;
+          xr--; xb--;
         }
         if (valid) L.nd[base + lane] = lp;
       }
@@ -731,16 +743,28 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
           const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
           terms[HS_MAXREP] = (rdlane(c.cst, HS_MAXREP) + L.Mt[j]) + pre;
         }
+        // ins_probs_: the first nd_eq repeat units come from the tables (layout.h nd_eq), the loop continues from there
         double li = 0.0;
-        const double2* pli_bq = L.bq + j; const uint8_t* pli_rd = L.rd + j; int li_left = j;
+        const double2* pli_bq = L.bq + (j - nd_eq*p); const uint8_t* pli_rd = L.rd + (j - nd_eq*p); int li_left = j - nd_eq*p;
 #pragma unroll
         for (int q = 0; q < HS_MAXREP; q++){
           const int D = (q+1)*p;
-          for (int m = 0; m < p; m++){
-            const double2 bq = *pli_bq;
-            const double e = (m < B) ? emit(*pli_rd, blk_at(c, B-1-min(m, B-1)), bq) : bq.x;
-            if (li_left >= 0) li += e;
-            pli_bq--; pli_rd--; li_left--;
+          if (q < nd_eq){
+            li = (j >= D - 1) ? L.Dl[q*L.ld + j] : L.Mt[j];
+          } else
+          if (kk > 0){                             // every column of this chunk is >= 64 > 6p - 1: no step leaves the read
+            for (int m = 0; m < p; m++){
+              const double2 bq = *pli_bq;
+              li += (m < B) ? emit(*pli_rd, blk_at(c, B-1-min(m, B-1)), bq) : bq.x;
+              pli_bq--; pli_rd--;
+            }
+          } else {
+            for (int m = 0; m < p; m++){             // read position j - t: unclamped (a step with t > j is masked; Dl sits in front of bq)
+              const double2 bq = *pli_bq;
+              const double e = (m < B) ? emit(*pli_rd, blk_at(c, B-1-min(m, B-1)), bq) : bq.x;
+              if (li_left >= 0) li += e;
+              pli_bq--; pli_rd--; li_left--;
+            }
           }
           const int len = min(B + D, j + 1);
           const double lp0 = (rdlane(c.cst, 13) + li) + ((len > D) ? L.Mt[max(j - D, 0)] : 0.0);

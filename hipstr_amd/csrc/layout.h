@@ -68,7 +68,10 @@ struct hs_stropt_t {
   // e = [bound > 0] + max(bound - U0, 0).  tab_len = 0: no table (a list of the option is not simple, or too many entries).
   int32_t tab_off, tab_len;
   int32_t tab_base[HS_MAXREP + 1];
-  int32_t pad_;
+  // ins_probs_ (StutterAlignerClass.cpp:40-51) cycles through the block's last `period` bases; where the block's right end is
+  // periodic, its first nd_eq repeat units add exactly the terms of del_probs_ / match_probs_, in the same order: the STR kernels
+  // take those sums from the tables they already hold and only loop over the remaining (6 - nd_eq) units.  nd_eq <= nd.
+  int32_t nd_eq;
 };
 
 struct hs_allele_t {

@@ -262,6 +262,11 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
   int nd = HIPSTR_MAX_STUTTER_REPS;
   while (nd*period > B) nd--;
   so.nd = nd;
+  {
+    int per_len = 0;                                       // leading run (from the right end) on which the block repeats with the period
+    while (per_len < B && blk[B-1-per_len] == blk[B-1-(per_len % period)]) per_len++;
+    so.nd_eq = std::min(nd, per_len / period);
+  }
   so.f64_off = out.f64pool.size();
   for (int t = 0; t < HS_NART; t++){
     const int art = (t - HS_MAXREP)*period;
