@@ -819,10 +819,12 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
           terms[HS_MAXREP] = (rdlane(c.cst, HS_MAXREP) + L.Mt[j]) + pre;
         }
         double li = 0.0;
-        const double2* pli_bq = L.bq + j; const uint8_t* pli_rd = L.rd + j; int li_left = j;
+        const double2* pli_bq = L.bq + (j - nd_eq*p); const uint8_t* pli_rd = L.rd + (j - nd_eq*p); int li_left = j - nd_eq*p;
 #pragma unroll
         for (int q = 0; q < HS_MAXREP; q++){
           const int D = (q+1)*p;
+          if (q < nd_eq) li = (j >= D - 1) ? L.Dl[q*L.ld + j] : L.Mt[j];       // layout.h nd_eq
+          else
           for (int m = 0; m < p; m++){               // read position j - t: unclamped (a step with t > j is masked; Dl sits in front of bq)
             const double2 bq = *pli_bq;
             const double e = (m < B) ? emit(*pli_rd, blk_at(c, B-1-min(m, B-1)), bq) : bq.x;
@@ -863,10 +865,12 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
           terms[HS_MAXREP] = (rdlane(c.cst, HS_MAXREP) + L.Mt[j]) + pre;
         }
         double li = 0.0;
-        const double2* pli_bq = L.bq + j; const uint8_t* pli_rd = L.rd + j; int li_left = j;
+        const double2* pli_bq = L.bq + (j - nd_eq*p); const uint8_t* pli_rd = L.rd + (j - nd_eq*p); int li_left = j - nd_eq*p;
 #pragma unroll
         for (int q = 0; q < HS_MAXREP; q++){
           const int D = (q+1)*p;
+          if (q < nd_eq) li = (j >= D - 1) ? L.Dl[q*L.ld + j] : L.Mt[j];       // layout.h nd_eq
+          else
           for (int m = 0; m < p; m++){               // read position j - t: unclamped (a step with t > j is masked; Dl sits in front of bq)
             const double2 bq = *pli_bq;
             const double e = (m < B) ? emit(*pli_rd, blk_at(c, B-1-min(m, B-1)), bq) : bq.x;
@@ -913,6 +917,8 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
           term = (rdlane(c.cst, HS_MAXREP) + L.Mt[j]) + pre;
         } else if (itn <= HS_MAXREP){                // insertion of D = (q+1) p
           const int q = itn - 1, D = (q+1)*p;
+          if (q < nd_eq) li = (j >= D - 1) ? L.Dl[q*L.ld + j] : L.Mt[j];       // layout.h nd_eq
+          else
           for (int m = 0; m < p; m++){               // extend the insertion table by one repeat unit
             const int t = q*p + m;
             const int pos = max(j - t, 0);
