@@ -281,11 +281,11 @@ def main():
         if not files:
             return None, None
         t = json.load(open(files[-1]))
-        for name, v in t["kernels"].items():
-            if name.startswith(kernel_key):
-                per_aln = (2 * v["fetch_bytes_per_launch_raw"] + v["write_bytes_per_launch_raw"]) / t["alignments_per_launch"]
-                return per_aln * n_alignments, os.path.basename(files[-1])
-        return None, None
+        hit = [v for name, v in t["kernels"].items() if name.startswith(kernel_key)]      # a phase may be more than one kernel
+        if not hit:
+            return None, None
+        per_aln = sum(2 * v["fetch_bytes_per_launch_raw"] + v["write_bytes_per_launch_raw"] for v in hit) / t["alignments_per_launch"]
+        return per_aln * n_alignments, os.path.basename(files[-1])
 
     def valu_issue_util(kernel_key, n_alignments, kernel_ms_now):
         """VALU issue-slot utilisation of a kernel: SQ_INSTS_VALU of the newest committed counter pass (profiles/r*_sq_counters.json, an own
@@ -295,11 +295,11 @@ def main():
         if not files or not (kernel_ms_now == kernel_ms_now):
             return None, None
         t = json.load(open(files[-1]))
-        for name, v in t["kernels"].items():
-            if name.startswith(kernel_key):
-                insts = v["valu_insts"] / t["alignments_per_launch"] * n_alignments
-                return insts * t["cycles_per_wave64_valu_inst"] / (kernel_ms_now * 1e-3 * t["clock_hz_assumed"] * t["simds"]), os.path.basename(files[-1])
-        return None, None
+        hit = [v for name, v in t["kernels"].items() if name.startswith(kernel_key)]      # a phase may be more than one kernel
+        if not hit:
+            return None, None
+        insts = sum(v["valu_insts"] for v in hit) / t["alignments_per_launch"] * n_alignments
+        return insts * t["cycles_per_wave64_valu_inst"] / (kernel_ms_now * 1e-3 * t["clock_hz_assumed"] * t["simds"]), os.path.basename(files[-1])
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

@@ -376,12 +376,12 @@ struct StrLds {     // one side of one read
   const double* ilog;   // [HS_ILOG_LDS] LDS copy of int_log(0..): ln of block-length-sized integers
   double*  nd;      // [HS_ND_TOTAL] deletion start values of the columns within |D| of the read end, the six sizes back to back
   double*  cstl;    // [20] pmf[13] | prior_ins | prior_del[6] of the current allele
-  double*  tab;     // [3][HS_TAB_CAP] tabulated closed form of the current allele's simple lists: A | G | Bnd (layout.h tab_*)
+  double*  tab;     // [2][HS_TAB_CAP] tabulated closed form of the current allele's simple lists: A | G (layout.h tab_*)
   uint8_t* blk;     // [blk_len] block bases of the current allele
   int ld;
 };
 #define HS_ND_TOTAL 192      // sum over the six deletion sizes of min(|D|, n) <= 21 p <= 189
-#define HS_WAVE_LDS (HS_ND_TOTAL + 24 + 3*HS_TAB_CAP)   // doubles of per-wavefront LDS: nd | cstl | tab
+#define HS_WAVE_LDS (HS_ND_TOTAL + 24 + 2*HS_TAB_CAP)   // doubles of per-wavefront LDS: nd | cstl | tab
 
 // Marginalisation over the artifact position (StutterAlignerClass.cpp:59-104 insertion, :106-150 deletion).
 // The loop over block offsets is the same for every read column, so the host enumerated it (hs_visit_t) and
@@ -553,7 +553,7 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
     double* Mt = rowP + Lc;
     const int ilog_len = (d.max_B + 9) & ~1, blk_len = (d.max_B + 19) & ~15;
     double* ilog = Mt + Lc;
-    double* ndb = ilog + ilog_len;                          // per wave: nd[HS_ND_TOTAL] | cstl[24] | tab[3][HS_TAB_CAP]
+    double* ndb = ilog + ilog_len;                          // per wave: nd[HS_ND_TOTAL] | cstl[24] | tab[2][HS_TAB_CAP]
     uint8_t* blkb = (uint8_t*)(ndb + 2*HS_WAVE_LDS);
     uint8_t* rdb = blkb + 2*blk_len;
     L.bq = bq + o; L.rowP = rowP + o; L.Mt = Mt + o; L.Dl = Dl + o; L.rd = rdb + o; L.ilog = ilog; L.ld = Lc;
@@ -627,9 +627,11 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
     const int tab_len = uni(c.so->tab_len);
     const bool use_tab = (MODE == 0);          // prep.cpp put exactly the alleles with all_simple && tab_len > 0 into [0, n_tab)
     const int tbase = (lane <= HS_MAXREP) ? c.so->tab_base[lane] : 0;
+    double tab_bmin = 0.0;
     if (use_tab){
       const double* src = d.f64pool + uni(c.so->tab_off);
-      for (int i = lane; i < 3*tab_len; i += 64){ const int e = i / 3; L.tab[(i - 3*e)*HS_TAB_CAP + e] = src[i]; }
+      for (int e = lane; e < tab_len; e += 64){ L.tab[e] = src[3*e]; L.tab[HS_TAB_CAP + e] = src[3*e + 1]; }
+      tab_bmin = uni(src[3*tab_len]);            // min over the entries' Bnd
     }
     wave_lds_sync();
 
@@ -731,11 +733,11 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
       if constexpr (MODE == 0){
         // every list is simple and tabulated: S = (lp0 + A[e]) + G[e], e from the lane's bound; a lane whose |lp0| is not below
         // Bnd[e] sends the chunk through the long form below (rare: a float rounding boundary within reach of lp0's rounding error)
-        bool bad = false;
+        double lp0_max = 0.0;                        // largest |lp0| of the lane's 12 evaluations, against the smallest Bnd of the table
         auto tab_eval = [&](double lp0, int lim, int k) -> double {
           const int e = rdlane(tbase, k) + min(lim, 1) + max(lim - rdlane(shapes, k), 0);
-          const double A = L.tab[e], G = L.tab[HS_TAB_CAP + e], Bd = L.tab[2*HS_TAB_CAP + e];
-          bad |= !(fabs(lp0) < Bd);
+          const double A = L.tab[e], G = L.tab[HS_TAB_CAP + e];
+          lp0_max = fmax(lp0_max, fabs(lp0));
           return (lp0 + A) + G;
         };
         {
@@ -791,6 +793,7 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
             ndo += cq;
           }
         }
+        bool bad = !(lp0_max < tab_bmin);
         if (d.debug_redo > 0) bad |= ((ai*31 + i*7 + kk) % d.debug_redo) == 0;       // tests: exercise the re-do path
         if (!__any(bad && actj)){ finish_chunk(); continue; }
         // leave the chunk to hs_str_kernel_generic

@@ -64,7 +64,8 @@ struct hs_stropt_t {
   // Tabulated closed form of the simple lists (prep.cpp simple_table): for a simple list the log-sum-exp over the artifact
   // positions is lp0 + A + G with A, G functions of the lane's bound only — as long as the float conversions inside
   // fast_log_sum_exp round the way they do for an exact lp0, which holds whenever |lp0| < Bnd (else the kernel evaluates
-  // the closed form the long way).  Entry e of list k sits at f64 pool [tab_off + 3*(tab_base[k] + e)] = {A, G, Bnd};
+  // the closed form the long way).  Entry e of list k sits at f64 pool [tab_off + 3*(tab_base[k] + e)] = {A, G, Bnd}, the smallest
+  // Bnd of the table (what the kernel actually compares with) at [tab_off + 3*tab_len];
   // e = [bound > 0] + max(bound - U0, 0).  tab_len = 0: no table (a list of the option is not simple, or too many entries).
   int32_t tab_off, tab_len;
   int32_t tab_base[HS_MAXREP + 1];

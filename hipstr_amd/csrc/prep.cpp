@@ -394,6 +394,9 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
         }
       }
       so.tab_len = total;
+      double bmin = 1e300;                              // what the kernel compares |lp0| with: the weakest guarantee of the table
+      for (int e = 0; e < total; e++) bmin = std::min(bmin, out.f64pool[so.tab_off + 3*e + 2]);
+      out.f64pool.push_back(bmin);
     }
   }
   out.stropts.push_back(so);

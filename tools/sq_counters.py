@@ -18,9 +18,7 @@ for name, counter, avg in db.execute("select kernel_name,counter_name,avg(value)
         continue
     key = name.split("::")[-1].split("(")[0]
     kern.setdefault(key, {})[names[counter]] = avg
-tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
-kd = [t for t in tabs if "kernel_dispatch" in t][0]; ks = [t for t in tabs if "kernel_symbol" in t][0]
-for name, dur in db.execute("select s.kernel_name, avg(d.end-d.start) from %s d join %s s on d.kernel_id=s.id group by s.kernel_name" % (kd, ks)):
+for name, dur in db.execute("select kernel_name, avg(duration) from (select distinct dispatch_id, kernel_name, duration from counters_collection) group by kernel_name"):
     key = name.split("::")[-1].split("(")[0]
     if key in kern:
         kern[key]["duration_ns"] = dur
