@@ -249,7 +249,7 @@ def main():
     ms = (C.c_float * (4 * args.steps))()
     n_ms = hmm.hipstr_hmm_profile_read(dev, ms, args.steps)
     phase_ms = np.array(ms[:4 * n_ms], dtype=np.float64).reshape(-1, 4).mean(axis=0) if n_ms > 0 else np.full(4, np.nan)
-    phase_names = ["hs_flank_kernel<C,lead>", "hs_str_kernel", "hs_flank_kernel<C,trail>", "hs_combine_kernel"]
+    phase_names = ["hs_lead_kernel", "hs_str_kernel", "hs_trail_kernel", "hs_combine_kernel"]
     dom = int(np.nanargmax(phase_ms)) if n_ms > 0 else 1
     kernel_ms = float(phase_ms[dom])          # average duration of the dominant kernel (group) per pass
 

@@ -28,7 +28,7 @@ extern "C" __global__ void hs_combine_kernel(const hs_dev_t* dp, int active_begi
 extern "C" __global__ void hs_posterior_kernel(const hs_post_dev_t* dp);
 extern "C" __global__ void hs_genotype_kernel(const hs_gt_dev_t* dp);
 extern "C" size_t hs_str_lds_bytes(int lds_len, int max_B);
-extern "C" void hs_launch_lead(int cls, unsigned gx, hipStream_t st, const hs_dev_t* dp, int item_begin);
+extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end);
 extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end);
 
 namespace {
@@ -284,10 +284,8 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
   for (const hipstr::Prepared::Chunk& ch : dev->prep.chunks){
     const unsigned nact = ch.active_end - ch.active_begin;
     if (mark()) return 1;
-    for (int c = 0; c < 4; c++){       // leading flanks, by columns-per-lane class
-      const int cnt = ch.lead_begin[c+1] - ch.lead_begin[c];
-      if (cnt > 0) hs_launch_lead(c+1, cnt, st, dp, ch.lead_begin[c]);
-    }
+    // leading flanks: persistent wavefronts striding over (locus side, distinct flank, 64 reads) items
+    hs_launch_lead2(nact, (unsigned)std::max(1, std::min(dev->trail_waves, ch.lead_end - ch.lead_begin)), st, dp, ch.active_begin, ch.lead_begin, ch.lead_end);
     if (mark()) return 1;
     hipLaunchKernelGGL(hs_str_kernel, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin);
     // alleles without a tabulated closed form (interrupted repeats, very long blocks) and whatever hs_str_kernel marked HS_REDO

@@ -6,21 +6,18 @@
 // The three block kinds have very different register and LDS appetites, so each is its own kernel, tuned
 // separately, handing a few hundred bytes per (read, allele, side) to the next one through HBM workspaces:
 //
-//   hs_flank_kernel<C,true>   leading flank: matrix row 0 + max-plus M/I/D recurrence (HapAligner.cpp:33-42,
-//                             114-156).  Once per read and distinct flank, shared by all alleles (what the
-//                             reference's "reuse_alns" does one allele at a time).        -> rowP, last column
-//   hs_str_kernel             STR block (HapAligner.cpp:62-109 + StutterAlignerClass.cpp): one lane per read
-//                             column, 13 artifact sizes, artifact position marginalised by replaying a
-//                             host-enumerated visiting list broadcast with v_readlane.    -> MR
-//   hs_trail_kernel<R>        trailing flank: the same recurrence, but with ALLELES as lanes: all alleles of a locus
-//                             share the read and (per group) the flank rows, so emissions and transitions are
-//                             wave-uniform scalars and a lane needs no neighbour at all; the matrix is swept in
-//                             bands of R haplotype rows held in registers.                 -> last column
+//   hs_col_kernel             per-column emission logs of every read in side orientation.
+//   hs_lead_kernel<R>         leading flank: matrix row 0 + max-plus M/I/D recurrence (HapAligner.cpp:33-42, 114-156), once
+//                             per read and distinct flank, shared by all alleles (what the reference's "reuse_alns" does one
+//                             allele at a time), with READS as lanes: the flank rows are wave-uniform, a lane carries the
+//                             M/I/D of its own read, the matrix is swept in bands of R rows held in registers.
+//                                                                                          -> rowP, last column, side_prob
+//   hs_str_kernel             STR block (HapAligner.cpp:62-109 + StutterAlignerClass.cpp): one lane per read column, 13
+//   hs_str_kernel_generic     artifact sizes; artifact position marginalised by a tabulated closed form (periodic blocks), a
+//                             closed form evaluated the long way, or a replay of a host-enumerated visiting list. -> MR
+//   hs_trail_kernel<R>        trailing flank: the same banded sweep with ALLELES as lanes: all alleles of a locus share the
+//                             read and (per group) the flank rows, so a lane needs no neighbour at all.   -> last column
 //   hs_combine_kernel         compute_aln_logprob (HapAligner.cpp:163-231): log-sum-exp over seed positions.
-//
-// The flank recurrence is swept along anti-diagonals as a systolic array: lane t owns C consecutive read
-// columns in registers, haplotype rows enter at lane 0 and flow lane-to-lane with v_mov_b32_dpp wave_shr:1
-// together with the three neighbour values; no LDS and no barrier on the critical path.
 //
 // Arithmetic is IEEE double add/max in exactly the reference's operation order; the reference's float
 // log-sum-exp approximations (mathops.cpp:86-106, fastonebigheader.h) are bit-replicated, so results are
@@ -56,151 +53,6 @@ __device__ __forceinline__ double* lead_record(const hs_dev_t& d, const SideView
   return d.ws_lead + v.ws_lead + (int64_t)slot*stride;
 }
 
-// ------------------------------------------------------------------ flank blocks: systolic anti-diagonal sweep
-// IS_LEAD: matrix row 0 + leading flank of one (read, side, distinct flank); otherwise the trailing flank of
-// every realigned allele of the chunk.  One wavefront per workgroup, no LDS.
-template <int C, bool IS_LEAD>
-__global__ void __launch_bounds__(64) hs_flank_kernel(const hs_dev_t* __restrict__ dp, int item_begin){
-  const hs_dev_t& d = *dp;
-  const int lane = threadIdx.x;
-  const hs_item_t* it = d.items + item_begin + blockIdx.x;
-  const SideView v = side_view(d, uni(it->active), uni(it->side));
-  const int n = v.n;
-  const int nl = (n + C - 1) / C, lastlane = (n - 1) / C, klast = (n - 1) % C;
-
-  // this lane's read columns (the right problem runs on the reversed read, HapAligner.cpp:606-609)
-  uint8_t rd[C]; double blc[C], blw[C];
-#pragma unroll
-  for (int k = 0; k < C; k++){
-    const int j = min(lane*C + k, n-1);
-    const int src = v.base_off + (v.side ? v.len - 1 - j : j);
-    const uint8_t q = (uint8_t)d.quals[src];
-    rd[k] = (uint8_t)d.bases[src];
-    blc[k] = d.qual_correct[q]; blw[k] = d.qual_error[q];
-  }
-  const double tab_m2m = d.m2m[lane & 15], tab_m2i = d.m2i[lane & 15];
-  if (IS_LEAD){   // per-column emission logs in side orientation, for the scalar loads of hs_trail_kernel
-    double* col = d.ws_col + v.ws_col + 3*(int64_t)(v.side ? v.nL : 0);
-#pragma unroll
-    for (int k = 0; k < C; k++){
-      const int j = lane*C + k;
-      if (j < n){ col[3*j] = blc[k]; col[3*j+1] = blw[k]; col[3*j+2] = (double)rd[k]; }
-    }
-  }
-
-  const int k0 = IS_LEAD ? 0 : blockIdx.y * d.allele_chunk;
-  const int k1 = IS_LEAD ? 1 : min(uni(v.loc->n_alleles), k0 + d.allele_chunk);
-  for (int k = k0; k < k1; k++){
-    int rowset_id; double* lastcol; const double* mr = NULL; double* lead_rec = NULL;
-    if (IS_LEAD){
-      rowset_id = uni(it->rowset);
-      lead_rec = lead_record(d, v, uni(it->slot));
-      lastcol = lead_rec + n;
-    } else {
-      const hs_allele_t* al = d.alleles + uni(v.loc->hap_begin) + k;
-      if (!uni(al->realign)) continue;
-      rowset_id = uni(al->trail_rows[v.side]);
-      const int ord = uni(al->re_ord);
-      mr = d.ws_mr + v.ws_mr + (int64_t)ord*(v.len-1) + (v.side ? v.nL : 0);
-      // trailing last columns of an alignment: left side first (F2 rows), then right side (F0 rows)
-      const int f_left_trail = uni(d.rowsets[uni(al->trail_rows[0])].len);
-      lastcol = d.ws_lt + v.ws_lt + (int64_t)ord*uni(v.loc->lt_stride) + (v.side ? f_left_trail : 0);
-    }
-    const int rs_off = uni(d.rowsets[rowset_id].off), rs_len = uni(d.rowsets[rowset_id].len);
-    const hs_row_t* rows = d.rows + rs_off;
-    const int row0 = uni((int)rows[0]);
-    const uint8_t c0 = (uint8_t)(row0 & 0xff);
-    const int u0 = (row0 >> 12) & 0xfff;          // compact index of the block's first row
-
-    double Mrow[C], Drow[C];
-    if (IS_LEAD){
-      // matrix row 0 (HapAligner.cpp:33-42).  left_prob is a strictly sequential sum in the reference, so it is
-      // passed lane to lane rather than scanned.
-      double pre[C];
-#pragma unroll
-      for (int kk = 0; kk < C; kk++) pre[kk] = 0.0;
-      double carry = 0.0;
-      for (int t = 0; t < nl; t++){
-        const double cin = shr1(0.0, carry);
-        if (lane == t){
-          double run = (t == 0) ? 0.0 : cin;
-#pragma unroll
-          for (int kk = 0; kk < C; kk++){ pre[kk] = run; if (lane*C + kk < n) run += blc[kk]; }
-          carry = run;
-        }
-      }
-#pragma unroll
-      for (int kk = 0; kk < C; kk++){
-        Mrow[kk] = ((rd[kk] == c0) ? blc[kk] : blw[kk]) + pre[kk];
-        Drow[kk] = IMP;
-      }
-      if (lane == lastlane) lead_rec[n + uni(v.loc->lead_flank[v.side])] = carry;     // side_prob
-    } else {
-      // "stutter block must be followed by a match" (HapAligner.cpp:122-139)
-#pragma unroll
-      for (int kk = 0; kk < C; kk++){
-        const int j = min(lane*C + kk, n-1);
-        const double e = (rd[kk] == c0) ? blc[kk] : blw[kk];
-        Mrow[kk] = (j == 0) ? e : e + mr[max(j - 1, 0)];
-        Drow[kk] = IMP;
-      }
-    }
-    if (lane == lastlane){
-      double val = 0;
-#pragma unroll
-      for (int kk = 0; kk < C; kk++) if (kk == klast) val = Mrow[kk];
-      lastcol[0] = val;
-    }
-
-    // rows 1.. enter at lane 0, one per step; lane t works on row (step - t)
-    const int nrows = rs_len - 1;
-    if (nrows > 0){
-      const hs_row_t* nr = rows + 1;
-      const int steps = nrows + nl - 1;
-      int chunk = 0;
-      uint32_t rowv = (lane < nrows) ? nr[lane] : 0u;
-      double oM = 0, oD = 0, oI = 0, om2m = 0, om2i = 0;
-      int oMeta = 0;
-      for (int st = 0; st < steps; st++){
-        int meta0 = 0; double f_m2m = 0, f_m2i = 0;
-        if (st < nrows){
-          if (st - chunk == 64){ chunk += 64; rowv = (chunk + lane < nrows) ? nr[chunk + lane] : 0u; }
-          meta0 = rdlane((int)rowv, st - chunk);
-          const int h = (meta0 >> 8) & 15;
-          f_m2m = rdlane(tab_m2m, h); f_m2i = rdlane(tab_m2i, h);
-        }
-        const int meta = shr1(meta0, oMeta);
-        const double m2m = shr1(f_m2m, om2m), m2i = shr1(f_m2i, om2i);
-        double mdiag = shr1(0.0, oM), ddiag = shr1(0.0, oD), ileft = shr1(0.0, oI);
-        if (meta < 0){   // valid bit is the sign bit
-          const uint8_t hc = (uint8_t)(meta & 0xff);
-          oM = Mrow[C-1]; oD = Drow[C-1];
-          double mlast = 0;
-#pragma unroll
-          for (int kk = 0; kk < C; kk++){
-            const double e = (rd[kk] == hc) ? blc[kk] : blw[kk];
-            const double c0v = ileft + m2i, c1v = mdiag + m2m, c2v = ddiag + m2i;
-            double nM = e + fmax(c0v, fmax(c1v, c2v));
-            double nI = blc[kk] + fmax(mdiag + T_I2M, ileft + T_I2I);
-            const double nD = fmax(Mrow[kk] + T_D2M, Drow[kk] + T_D2D);
-            if (kk == 0 && lane == 0){ nM = e; nI = blc[kk]; }     // HapAligner.cpp:123-126
-            mdiag = Mrow[kk]; ddiag = Drow[kk]; ileft = nI;
-            Mrow[kk] = nM; Drow[kk] = nD;
-            if (kk == klast) mlast = nM;
-          }
-          oI = ileft;
-          if (lane == lastlane) lastcol[((meta >> 12) & 0xfff) - u0] = mlast;
-        }
-        oMeta = meta; om2m = m2m; om2i = m2i;
-      }
-    }
-    if (IS_LEAD){
-#pragma unroll
-      for (int kk = 0; kk < C; kk++){ const int j = lane*C + kk; if (j < n) lead_rec[j] = Mrow[kk]; }     // rowP
-    }
-  }
-}
-
 // ------------------------------------------------------------------ trailing flank: alleles as lanes, banded sweep
 // Work item = (read side, group of <= 64 alleles sharing the trailing-flank rowset).  Lane = allele.  Every quantity
 // that depends on the read column or on the haplotype row — base, log P(correct/error), flank base, transition
@@ -216,10 +68,15 @@ __global__ void __launch_bounds__(64) hs_flank_kernel(const hs_dev_t* __restrict
 //   LAST:  no bottom boundary is written.
 // Lanes may belong to different reads (packing): n, the column table and the workspaces are per lane; the flank rows
 // (hence bases and transition logs) are wave-uniform.
-template <int NR, bool FIRST, bool LAST>
+//   LEAD:  the block is a leading flank and the lanes are READS of one locus and side (the rows are still wave-uniform): the first
+//          band's top boundary is matrix row 0 (HapAligner.cpp:33-42: emission plus the running sum of log P(correct), which also
+//          yields side_prob at the read's last column), and the last band writes M of its bottom row — rowP, what the STR block
+//          starts from — for every column.
+template <int NR, bool FIRST, bool LAST, bool LEAD = false>
 __device__ __forceinline__ void band_sweep(const hs_dev_t& d, int lane, bool live, int n, int nmax, const double* __restrict__ col,
                                            const hs_row_t* __restrict__ rows, int row0, int c0,
-                                           const double* __restrict__ mr, double* __restrict__ bnd, double* __restrict__ lt){
+                                           const double* __restrict__ mr, double* __restrict__ bnd, double* __restrict__ lt,
+                                           double* __restrict__ rowp = NULL, double* __restrict__ side_out = NULL){
   int hc[NR]; double m2m[NR], m2i[NR];
 #pragma unroll
   for (int r = 0; r < NR; r++){
@@ -233,19 +90,24 @@ __device__ __forceinline__ void band_sweep(const hs_dev_t& d, int lane, bool liv
   double nx_mr = 0.0; double2 nx_b = make_double2(0.0, 0.0);
   if (!FIRST) nx_b = *(const double2*)(bnd + (size_t)lane*2);
   double diagM = 0, diagD = 0;
+  double pre = 0.0;                              // LEAD: left_prob, a strictly sequential sum in the reference
   for (int j = 0; j < nmax; j++){
     const double blcj = nx_blc, blwj = nx_blw; const int rdj = (int)nx_rd;
     const double cur_mr = nx_mr; const double2 cur_b = nx_b;
     {
       const int jn = min(j + 1, n - 1);           // a lane past its own read end keeps re-reading its last column
       nx_blc = col[3*jn]; nx_blw = col[3*jn+1]; nx_rd = col[3*jn+2];
-      if (FIRST) nx_mr = mr[jn - 1 >= 0 ? jn - 1 : 0];
+      if (FIRST){ if (!LEAD) nx_mr = mr[jn - 1 >= 0 ? jn - 1 : 0]; }
       else       nx_b = *(const double2*)(bnd + ((size_t)min(j + 1, nmax - 1)*64 + lane)*2);
     }
     double upM, upD;
     if (FIRST){
       const double e0 = (rdj == c0) ? blcj : blwj;
-      upM = (j == 0) ? e0 : e0 + cur_mr;
+      if (LEAD){
+        upM = e0 + pre;
+        pre += blcj;
+        if (j == n-1 && live) *side_out = pre;                     // side_prob: the whole side hangs off the haplotype
+      } else upM = (j == 0) ? e0 : e0 + cur_mr;
       upD = IMP;
       if (j == n-1 && live) lt[0] = upM;
     } else { upM = cur_b.x; upD = cur_b.y; }
@@ -278,6 +140,7 @@ __device__ __forceinline__ void band_sweep(const hs_dev_t& d, int lane, bool liv
       }
     }
     if (!LAST) *(double2*)(bnd + ((size_t)j*64 + lane)*2) = make_double2(upM, upD);
+    else if (LEAD){ if (j < n && live) rowp[j] = upM; }
     diagM = topM; diagD = topD;                // top boundary of this column = diagonal of the band's first row next column
     if (j == n-1 && live){
 #pragma unroll
@@ -286,13 +149,14 @@ __device__ __forceinline__ void band_sweep(const hs_dev_t& d, int lane, bool liv
   }
 }
 
-template <int NR>
+template <int NR, bool LEAD = false>
 __device__ __forceinline__ void band_dispatch(bool first, bool last, const hs_dev_t& d, int lane, bool live, int n, int nmax, const double* col,
-                                              const hs_row_t* rows, int row0, int c0, const double* mr, double* bnd, double* lt){
-  if (first){ if (last) band_sweep<NR, true, true>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt);
-              else      band_sweep<NR, true, false>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt); }
-  else      { if (last) band_sweep<NR, false, true>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt);
-              else      band_sweep<NR, false, false>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt); }
+                                              const hs_row_t* rows, int row0, int c0, const double* mr, double* bnd, double* lt,
+                                              double* rowp = NULL, double* side_out = NULL){
+  if (first){ if (last) band_sweep<NR, true, true, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt, rowp, side_out);
+              else      band_sweep<NR, true, false, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt, rowp, side_out); }
+  else      { if (last) band_sweep<NR, false, true, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt, rowp, side_out);
+              else      band_sweep<NR, false, false, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt, rowp, side_out); }
 }
 
 template <int R>
@@ -347,6 +211,83 @@ __global__ void __launch_bounds__(64) hs_trail_kernel(const hs_dev_t* __restrict
       if (nr == R) band_dispatch<R>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt);
       else switch (nr){
 #define HS_BAND_CASE(N_) case N_: if (N_ < R) band_dispatch<(N_ < R ? N_ : 1)>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt); break;
+        HS_BAND_CASE(1) HS_BAND_CASE(2) HS_BAND_CASE(3) HS_BAND_CASE(4) HS_BAND_CASE(5) HS_BAND_CASE(6) HS_BAND_CASE(7) HS_BAND_CASE(8)
+        HS_BAND_CASE(9) HS_BAND_CASE(10) HS_BAND_CASE(11) HS_BAND_CASE(12) HS_BAND_CASE(13) HS_BAND_CASE(14) HS_BAND_CASE(15)
+        HS_BAND_CASE(16) HS_BAND_CASE(17) HS_BAND_CASE(18) HS_BAND_CASE(19) HS_BAND_CASE(20) HS_BAND_CASE(21) HS_BAND_CASE(22) HS_BAND_CASE(23)
+#undef HS_BAND_CASE
+        default: break;
+      }
+      row0 += nr;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ leading flank: reads as lanes, the same banded sweep
+// Per-column emission logs of an active read in side orientation (left side columns, then the reversed right side, HapAligner.cpp:606-609):
+// [len-1][3] doubles = log P(correct), log P(error), base.  One wavefront per read; read by hs_lead_kernel and hs_trail_kernel.
+__global__ void __launch_bounds__(64) hs_col_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
+  const hs_dev_t& d = *dp;
+  const int ai = active_begin + blockIdx.x;
+  const hs_read_t rd = d.reads[d.active[ai]];
+  double* col = d.ws_col + d.ws[ai].col;
+  for (int c = threadIdx.x; c < rd.len - 1; c += 64){
+    const int src = rd.base_off + (c < rd.seed ? c : rd.len - 1 - (c - rd.seed));
+    const uint8_t q = (uint8_t)d.quals[src];
+    col[3*c] = d.qual_correct[q]; col[3*c+1] = d.qual_error[q]; col[3*c+2] = (double)(uint8_t)d.bases[src];
+  }
+}
+
+// Work item = (locus, side, distinct leading flank, up to 64 reads sorted by side length).  Lane = read: the flank rows — bases and
+// transition logs — are wave-uniform, a lane carries the M/I/D of its own read, and the sweep is the trailing flank's (no shuffles, no
+// pipeline fill: the systolic sweep this replaces spent half its steps filling and draining 64 lanes for a 60-row flank).
+// This is the reference's `reuse_alns` for all alleles at once: the leading flank is computed once per read and distinct flank.
+// Writes the lead record of every read: rowP[n] | last column of the leading-flank rows | side_prob.
+//   item.active = first entry in tpack, item.side = side | slot << 1, item.rowset = rowset id, item.slot = number of reads
+template <int R>
+__global__ void __launch_bounds__(64) hs_lead_kernel(const hs_dev_t* __restrict__ dp, int item_begin, int item_end){
+  const hs_dev_t& d = *dp;
+  const int lane = threadIdx.x;
+  double* const bnd = d.ws_band + (size_t)blockIdx.x * d.band_cols * 64 * 2;
+  for (int item = item_begin + blockIdx.x; item < item_end; item += gridDim.x){
+    const hs_item_t* it = d.items + item;
+    const int side = uni(it->side) & 1, slot = uni(it->side) >> 1, nreads = uni(it->slot);
+    const bool live = lane < nreads;
+    const int ai = d.tpack[uni(it->active) + min(lane, nreads-1)];
+    const hs_read_t rdv = d.reads[d.active[ai]];
+    const hs_locus_t* loc = d.loci + uni(rdv.locus);
+    const int nL = rdv.seed, n = side ? rdv.len - rdv.seed - 1 : rdv.seed;
+    const int nmax = uni(wave_max_i(n));
+    const hs_ws_t wsr = d.ws[ai];
+    const int lead_flank = uni(loc->lead_flank[side]);
+    double* rec = d.ws_lead + wsr.lead[side] + (int64_t)slot*(n + lead_flank + 1);     // lead_record() of this lane's read
+    double* lastcol = rec + n;
+    double* side_out = rec + n + lead_flank;
+    const double* col = d.ws_col + wsr.col + 3*(int64_t)(side ? nL : 0);
+    const int rowset = uni(it->rowset);
+    const int rs_off = uni(d.rowsets[rowset].off), rs_len = uni(d.rowsets[rowset].len);
+    const hs_row_t* rows = d.rows + rs_off;
+    const int c0 = uni((int)rows[0]) & 0xff;
+    const int nbands = (rs_len - 1 + R - 1) / R;
+    if (nbands == 0){     // a one-base flank: matrix row 0 is all there is
+      double pre = 0.0;
+      for (int j = 0; j < nmax; j++){
+        const int jc = min(j, n - 1);
+        const double blcj = col[3*jc], blwj = col[3*jc+1]; const int rdj = (int)col[3*jc+2];
+        const double m0 = ((rdj == c0) ? blcj : blwj) + pre;
+        pre += blcj;
+        if (j < n && live) rec[j] = m0;
+        if (j == n-1 && live){ lastcol[0] = m0; *side_out = pre; }
+      }
+      continue;
+    }
+    const int nr_base = (rs_len - 1) / nbands, nr_rem = (rs_len - 1) - nr_base*nbands;
+    int row0 = 1;
+    for (int b = 0; b < nbands; b++){
+      const int nr = nr_base + (b < nr_rem ? 1 : 0);
+      const bool first = (b == 0), last = (b + 1 == nbands);
+      if (nr == R) band_dispatch<R, true>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, NULL, bnd, lastcol, rec, side_out);
+      else switch (nr){
+#define HS_BAND_CASE(N_) case N_: if (N_ < R) band_dispatch<(N_ < R ? N_ : 1), true>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, NULL, bnd, lastcol, rec, side_out); break;
         HS_BAND_CASE(1) HS_BAND_CASE(2) HS_BAND_CASE(3) HS_BAND_CASE(4) HS_BAND_CASE(5) HS_BAND_CASE(6) HS_BAND_CASE(7) HS_BAND_CASE(8)
         HS_BAND_CASE(9) HS_BAND_CASE(10) HS_BAND_CASE(11) HS_BAND_CASE(12) HS_BAND_CASE(13) HS_BAND_CASE(14) HS_BAND_CASE(15)
         HS_BAND_CASE(16) HS_BAND_CASE(17) HS_BAND_CASE(18) HS_BAND_CASE(19) HS_BAND_CASE(20) HS_BAND_CASE(21) HS_BAND_CASE(22) HS_BAND_CASE(23)
@@ -990,14 +931,22 @@ hs_combine_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
   const uint8_t seed_q = (uint8_t)d.quals[vL.base_off + vL.nL];
   const double seed_lc = d.qual_correct[seed_q], seed_lw = d.qual_error[seed_q];
   const int n_alleles = uni(vL.loc->n_alleles);
-  for (int k = (threadIdx.x >> 6); k < n_alleles; k += 4){
-  const hs_allele_t* al = d.alleles + uni(vL.loc->hap_begin) + k;
-  if (!uni(al->realign)) continue;
-  const int N = uni(al->n_flank), ord = uni(al->re_ord);
-  const int lead_off = uni(d.rowsets[uni(al->lead_rows[0])].off), F0 = uni(d.rowsets[uni(al->lead_rows[0])].len);
-  const int trail_off = uni(d.rowsets[uni(al->trail_rows[0])].off), F2 = N - F0;
-  const double* recL = lead_record(d, vL, uni(al->lead_slot[0]));
-  const double* recR = lead_record(d, vR, uni(al->lead_slot[1]));
+  const int hap_begin = uni(vL.loc->hap_begin);
+  // allele records and their rowsets are fetched 64 alleles at a time, one allele per lane, and then read lane by lane: two memory
+  // round trips per 64 alleles instead of three dependent scalar loads per allele
+  for (int kb = 0; kb < n_alleles; kb += 64){
+  const int kl = min(kb + lane, n_alleles - 1);
+  const hs_allele_t alv = d.alleles[hap_begin + kl];
+  const hs_rowset_t rsl = d.rowsets[alv.lead_rows[0]], rst = d.rowsets[alv.trail_rows[0]];
+  for (int k = kb + (threadIdx.x >> 6); k < min(n_alleles, kb + 64); k += 4){
+  const int kk = k - kb;
+  if (!rdlane(alv.realign, kk)) continue;
+  const int N = rdlane(alv.n_flank, kk), ord = rdlane(alv.re_ord, kk);
+  const int lead_off = rdlane(rsl.off, kk), F0 = rdlane(rsl.len, kk);
+  const int trail_off = rdlane(rst.off, kk), F2 = N - F0;
+  const int slotL = rdlane(alv.lead_slot[0], kk), slotR = rdlane(alv.lead_slot[1], kk);
+  const double* recL = lead_record(d, vL, slotL);
+  const double* recR = lead_record(d, vR, slotR);
   const double* mr = d.ws_mr + vL.ws_mr + (int64_t)ord*(vL.len-1);
   const double* lt = d.ws_lt + vL.ws_lt + (int64_t)ord*uni(vL.loc->lt_stride);
   // last-column value of compact row u of a side: leading rows 0..Flead-1, the STR block's row at Flead, trailing rows after it
@@ -1040,21 +989,18 @@ hs_combine_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
   }
   if (lane == 0) d.aln_probs[uni(vL.loc->out_off) + (int64_t)(vL.r - uni(vL.loc->read_begin))*n_alleles + k] = acc.finish();
   }
-}
-
-// ------------------------------------------------------------------ host-side launch helper (called from api.hip)
-extern "C" void hs_launch_lead(int cls, unsigned gx, hipStream_t st, const hs_dev_t* dp, int item_begin){
-  const dim3 grid(gx, 1, 1);
-  switch (cls){
-    case 1:  hipLaunchKernelGGL((hs_flank_kernel<1, true>), grid, dim3(64), 0, st, dp, item_begin); break;
-    case 2:  hipLaunchKernelGGL((hs_flank_kernel<2, true>), grid, dim3(64), 0, st, dp, item_begin); break;
-    case 3:  hipLaunchKernelGGL((hs_flank_kernel<3, true>), grid, dim3(64), 0, st, dp, item_begin); break;
-    default: hipLaunchKernelGGL((hs_flank_kernel<4, true>), grid, dim3(64), 0, st, dp, item_begin); break;
   }
 }
+
+// ------------------------------------------------------------------ host-side launch helpers (called from api.hip)
 #ifndef HS_TRAIL_ROWS
 #define HS_TRAIL_ROWS 20
 #endif
+// leading flanks of the reads [active_begin, active_begin + n_active) of a chunk: column tables first, then the reads-as-lanes sweep
+extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end){
+  hipLaunchKernelGGL(hs_col_kernel, dim3(n_active), dim3(64), 0, st, dp, active_begin);
+  if (item_end > item_begin) hipLaunchKernelGGL((hs_lead_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end);
+}
 extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end){
   hipLaunchKernelGGL((hs_trail_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end);
 }

@@ -399,6 +399,11 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
       out.f64pool.push_back(bmin);
     }
   }
+  if (getenv("HIPSTR_DEBUG_SHAPES") && so.tab_len == 0){
+    fprintf(stderr, "nontab B=%d p=%d nd_eq=%d shapes:", B, period, so.nd_eq);
+    for (int k = 0; k <= HS_MAXREP; k++) fprintf(stderr, " %d", so.shape[k]);
+    fprintf(stderr, " lens:"); for (int k = 0; k < HS_MAXREP; k++) fprintf(stderr, " %d", so.del_len[k]); fprintf(stderr, " ins %d  %s\n", so.ins_len, blk.c_str());
+  }
   out.stropts.push_back(so);
 }
 
@@ -599,13 +604,9 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
   out.ws.resize(out.active.size());
   Prepared::Chunk ch; memset(&ch, 0, sizeof ch);
   int64_t mr = 0, lt = 0, lead = 0, col = 0;
-  std::vector<hs_item_t> lead_tmp[4];
   auto flush = [&](int active_end){
     ch.active_end = active_end;
-    for (int c = 0; c < 4; c++){
-      ch.lead_begin[c] = out.lead_items.size(); out.lead_items.insert(out.lead_items.end(), lead_tmp[c].begin(), lead_tmp[c].end()); lead_tmp[c].clear();
-    }
-    ch.lead_begin[4] = out.lead_items.size();
+    ch.lead_begin = out.lead_items.size();
     // trailing-flank items: lanes = alleles of a group; when a group has <= 32 alleles, 64/npad reads of the same locus and
     // side (sorted by side length, so that packed reads finish together) share one wavefront
     ch.trail_begin = out.trail_items.size();
@@ -619,6 +620,17 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
         for (int a = a0; a < a1; a++) order.push_back(a);
         auto side_len = [&](int a){ const hs_read_t& r = out.reads[out.active[a]]; return s ? r.len - r.seed - 1 : r.seed; };
         std::stable_sort(order.begin(), order.end(), [&](int x, int y){ return side_len(x) < side_len(y); });
+        // leading-flank items: lanes = reads (sorted by side length, so that the lanes of a wavefront finish together), one item per
+        // distinct leading flank of the locus and side
+        const std::vector<int>& ls = locus_leads[2*locus + s];
+        for (size_t slot = 0; slot < ls.size(); slot++)
+          for (size_t i = 0; i < order.size(); i += 64){
+            hs_item_t it; it.side = s | ((int32_t)slot << 1); it.rowset = ls[slot];
+            it.active = (int32_t)out.tpack.size();
+            it.slot = (int32_t)std::min<size_t>(64, order.size() - i);
+            out.tpack.insert(out.tpack.end(), order.begin() + i, order.begin() + i + it.slot);
+            out.lead_items.push_back(it);
+          }
         for (int g = 0; g < loc.tg_count[s]; g++){
           const int nm = out.tgroups[loc.tg_begin[s] + g].n_members;
           int npad = 1; while (npad < nm) npad <<= 1;
@@ -635,6 +647,7 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
       a0 = a1;
     }
     ch.trail_end = out.trail_items.size();
+    ch.lead_end = out.lead_items.size();
     out.ws_mr_size = std::max(out.ws_mr_size, mr); out.ws_lt_size = std::max(out.ws_lt_size, lt); out.ws_lead_size = std::max(out.ws_lead_size, lead);
     out.ws_col_size = std::max(out.ws_col_size, col);
     if (ch.active_end > ch.active_begin) out.chunks.push_back(ch);
@@ -652,12 +665,6 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
     hs_ws_t w; w.mr = mr; w.lt = lt; w.col = col;
     for (int s = 0; s < 2; s++){
       w.lead[s] = lead;
-      const std::vector<int>& ls = locus_leads[2*rd.locus + s];
-      const int cls = (n_side[s] + 63)/64 - 1;
-      for (size_t slot = 0; slot < ls.size(); slot++){
-        hs_item_t it; it.active = (int32_t)ai; it.side = s; it.rowset = ls[slot]; it.slot = (int32_t)slot;
-        lead_tmp[cls].push_back(it);
-      }
       out.max_side_len = std::max(out.max_side_len, n_side[s]);
       lead += (int64_t)loc.n_lead[s]*(n_side[s] + loc.lead_flank[s] + 1);
     }

@@ -39,13 +39,14 @@ struct Prepared {
   // ---- launch plan: the batch is cut into chunks of consecutive active reads whose workspaces fit the budget
   struct Chunk {
     int32_t active_begin, active_end;      // range in `active`
-    int32_t lead_begin[5];                 // lead_items range per columns-per-lane class 1..4 (begin[c-1] .. begin[c])
+    int32_t lead_begin, lead_end;          // lead_items range
     int32_t trail_begin, trail_end;        // trail_items range
     int64_t n_alignments;
   };
   std::vector<Chunk>      chunks;
   std::vector<hs_ws_t>    ws;              // per active read, offsets inside its chunk's workspaces
-  std::vector<hs_item_t>  lead_items;      // (active, side, rowset, slot): leading flank to compute once per read
+  std::vector<hs_item_t>  lead_items;      // (first entry in tpack, side | slot << 1, rowset, number of reads): leading flank of one distinct
+                                           // flank for up to 64 reads of one locus and side
   std::vector<hs_item_t>  trail_items;     // (first entry in tpack, side, number of packed reads, group): trailing flank of one
                                            // allele group for up to 64/npad reads of one locus and side
   std::vector<int32_t>    tpack;           // active-read indices of the packed reads
