@@ -258,7 +258,8 @@ def main():
     probs = np.zeros(sb.n_out); seeds = np.zeros(sb.n_reads, np.int32)
     assert hmm.hipstr_hmm_fetch(dev, probs.ctypes.data_as(capi._f64p), seeds.ctypes.data_as(capi._i32p)) == 0
     t_fetch = time.perf_counter() - t0
-    assert np.all(np.isfinite(probs)) and np.all(probs <= 1e-10), "forward scores must be finite log-likelihoods <= 0"
+    if not os.environ.get("HIPSTR_BENCH_NOCHECK"):       # kernel ablation builds (timing only, results invalid) set this
+        assert np.all(np.isfinite(probs)) and np.all(probs <= 1e-10), "forward scores must be finite log-likelihoods <= 0"
 
     if world > 1:
         dev_t = "cpu" if share else "cuda"

@@ -527,7 +527,7 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
     const int i = own ? i0 + it : j0 + (it - n_own);
     const int oe = uni(order[i]);
     const bool chained = own && (it > 0) && ((oe >> 30) & 1);
-    const hs_allele_t* al = d.alleles + uni(v.loc->hap_begin) + (oe & 0x3fffffff);
+    const hs_allele_t* al = d.alleles + uni(v.loc->hap_begin) + (oe & 0x1fffffff);
     const int slot = uni(al->lead_slot[w]), str_opt = uni(al->str_opt[w]);
     double* mr_out = d.ws_mr + v.ws_mr + (int64_t)uni(al->re_ord)*(v.len-1) + (w ? v.nL : 0);
     if (MODE == 1 && !own){
@@ -580,10 +580,11 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
     // (a block that ends with the previous allele's block only appends terms to that allele's sums)
     const int t0 = chained ? min(prev_B, n) : 0;
     prev_B = B;
+    const int tmax = min(B, n);
+    if (t0 < tmax)                      // a continued block that already covered the whole read side adds nothing
     for (int kk = 0; kk < ncyc; kk++){
       const int j = min(lane + 64*kk, n-1);
       double lp = (t0 > 0) ? L.Mt[j] : 0.0;
-      const int tmax = min(B, n);
       const int ndp = c.nd * p;
       // read position j - t, unclamped: a step with t > j is masked (Dl sits in front of bq); the "(t+1) is a multiple of p" test of
       // the deletion table is carried as a counter instead of a division
@@ -606,18 +607,9 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
     // min(|D|, n) such columns per deletion size, so (size, column) pairs are spread over the lanes instead of
     // looping over the block once per deletion size.
     {
-      // size q has min(|D|, n) such columns; the pairs of all sizes are numbered back to back and nd[] is indexed by that number
-      int cnt[HS_MAXREP], npairs = 0;
-#pragma unroll
-      for (int q = 0; q < HS_MAXREP; q++){ cnt[q] = (B - (q+1)*p >= 0) ? min((q+1)*p, n) : 0; npairs += cnt[q]; }
-      for (int base = 0; base < npairs; base += 64){
-        // surplus lanes of the last round repeat its last pair (computed, not stored), so that every lane has a real length
-        int off = min(base + lane, npairs - 1); const bool valid = base + lane < npairs;
-        int q = 0;
-#pragma unroll
-        for (int qq = 0; qq < HS_MAXREP - 1; qq++) if (q == qq && off >= cnt[qq]){ off -= cnt[qq]; q = qq + 1; }
+      // one round: every lane sums its (size q, column j) pair and stores it at nd[dst]
+      auto nd_round = [&](int q, int j, bool valid, int dst){
         const int aD = (q+1)*p;
-        const int j = max(0, n - aD) + off;
         const int len = min(B - aD, j + 1);
         // pairs are numbered size-major, so the lengths within a round are close: the first lmin steps need no mask at all, and the
         // round stops at its own longest sum
@@ -649,7 +641,51 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
           if (t < len) lp += e;
           xr--; xb--;
         }
-        if (valid) L.nd[base + lane] = lp;
+        if (valid) L.nd[dst] = lp;
+      };
+      // A periodic block that extends the previous allele's block by exactly one repeat unit (str_order bit 29), on a side at least as
+      // long as the largest deletion: the sum of (size q, column j) starts from the same prior -ln(B - |D| + 1) and adds the same
+      // emissions in the same order as the previous allele's (size q-1, column j), so the rows move up one size and only the `period`
+      // columns each size gains — and size 0 — are summed: nv p pairs instead of nv (nv + 1) p / 2 (nv = c.nd sizes fit the block).
+      const int nv = c.nd;
+      const bool nd_reuse = (MODE == 0) && chained && ((oe >> 29) & 1) && (n >= nv*p);
+      if (nd_reuse){
+        auto row_off = [&](int q){ return p*((q*(q+1)) >> 1); };           // size q holds (q+1)p columns, sizes back to back
+        const int ncopy = row_off(nv - 1);                                // rows 0..nv-2 -> rows 1..nv-1, read completely before the first write
+        double tmp[3]; int dst[3];
+#pragma unroll
+        for (int rnd = 0; rnd < 3; rnd++){
+          const int e = rnd*64 + lane;
+          int qn = 1;
+#pragma unroll
+          for (int k = 1; k <= 4; k++) qn += (e >= row_off(k)) ? 1 : 0;       // destination row: row_off(qn-1) <= e < row_off(qn)
+          const int idx = e - row_off(qn - 1);
+          dst[rnd] = row_off(qn) + p + idx;
+          tmp[rnd] = (e < ncopy) ? L.nd[row_off(qn - 1) + idx] : 0.0;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int rnd = 0; rnd < 3; rnd++) if (rnd*64 + lane < ncopy) L.nd[dst[rnd]] = tmp[rnd];
+        // the new pairs: the p lowest columns of every size
+        const int e = min(lane, nv*p - 1); const bool valid = lane < nv*p;
+        int q = 0;
+#pragma unroll
+        for (int k = 1; k <= 5; k++) q += (e >= k*p) ? 1 : 0;
+        const int off = e - q*p;
+        nd_round(q, (n - (q+1)*p) + off, valid, row_off(q) + off);
+      } else {
+        // size q has min(|D|, n) such columns; the pairs of all sizes are numbered back to back and nd[] is indexed by that number
+        int cnt[HS_MAXREP], npairs = 0;
+#pragma unroll
+        for (int q = 0; q < HS_MAXREP; q++){ cnt[q] = (B - (q+1)*p >= 0) ? min((q+1)*p, n) : 0; npairs += cnt[q]; }
+        for (int base = 0; base < npairs; base += 64){
+          // surplus lanes of the last round repeat its last pair (computed, not stored), so that every lane has a real length
+          int off = min(base + lane, npairs - 1); const bool valid = base + lane < npairs;
+          int q = 0;
+#pragma unroll
+          for (int qq = 0; qq < HS_MAXREP - 1; qq++) if (q == qq && off >= cnt[qq]){ off -= cnt[qq]; q = qq + 1; }
+          nd_round(q, max(0, n - (q+1)*p) + off, valid, base + lane);
+        }
       }
     }
     wave_lds_sync();

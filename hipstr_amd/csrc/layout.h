@@ -142,7 +142,8 @@ struct hs_dev_t {
   const int32_t*     tmembers;   // allele indices (within the locus) of the trail groups
   const int32_t*     tpack;      // active-read indices of the reads packed into one trail item
   const int32_t*     str_order;  // allele index (within the locus) per processing position; bit 30 set = this allele's STR block,
-                                 // in side orientation, ends with the previous position's block (its tables are continued)
+                                 // in side orientation, ends with the previous position's block (its tables are continued); bit 29
+                                 // set = ... and is that block plus one repeat unit, periodic, with all six deletion sizes
   double*            ws_col;
   double*            ws_band;    // per persistent wavefront: 2 x [band_cols][64 lanes][2] band-boundary rows (M, D)
   double*            ws_mr;

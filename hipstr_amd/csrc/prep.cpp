@@ -554,7 +554,10 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
         const std::string cur = block_of(ks[i]);
         const bool first_of_kind = (i == 0) || (tabbed(ks[i]) != tabbed(ks[i-1]));
         const bool chained = !first_of_kind && cur.size() >= prev.size() && cur.compare(cur.size() - prev.size(), prev.size(), prev) == 0;
-        out.str_order.push_back(ks[i] | (chained ? (1 << 30) : 0));
+        // bit 29: a tabulated (hence periodic) block that extends the previous one by exactly one repeat unit: the read-end deletion
+        // sums of the previous allele move up one size (hs_str_kernel)
+        const bool one_unit = chained && tabbed(ks[i]) && (int)cur.size() == (int)prev.size() + period;
+        out.str_order.push_back(ks[i] | (chained ? (1 << 30) : 0) | (one_unit ? (1 << 29) : 0));
         if (tabbed(ks[i])) loc.n_tab[side]++;
         prev = cur;
       }
