@@ -28,8 +28,8 @@ extern "C" __global__ void hs_combine_kernel(const hs_dev_t* dp, int active_begi
 extern "C" __global__ void hs_posterior_kernel(const hs_post_dev_t* dp);
 extern "C" __global__ void hs_genotype_kernel(const hs_gt_dev_t* dp);
 extern "C" size_t hs_str_lds_bytes(int lds_len, int max_B);
-extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end);
-extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end);
+extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk);
+extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk);
 
 namespace {
 
@@ -260,7 +260,8 @@ hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){
   }
   {
     int32_t* rd = NULL;
-    HS_HIP_DEV(hipMalloc((void**)&rd, sizeof(int32_t)*(size_t)(h.n_active ? h.n_active : 1))); dev->allocs.push_back(rd); h.redo = rd;
+    // [n_active] re-do flags of hs_str_kernel | [2 x chunks] work counters of hs_lead_kernel and hs_trail_kernel
+    HS_HIP_DEV(hipMalloc((void**)&rd, sizeof(int32_t)*((size_t)h.n_active + 2*P.chunks.size() + 2))); dev->allocs.push_back(rd); h.redo = rd;
     h.debug_redo = getenv("HIPSTR_DEBUG_REDO") ? atoi(getenv("HIPSTR_DEBUG_REDO")) : 0;
   }
   HS_HIP_DEV(hipMalloc((void**)&dev->d_args, sizeof(hs_dev_t))); dev->allocs.push_back(dev->d_args);
@@ -280,12 +281,13 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
     HS_HIP(hipEventRecord(dev->prof_pool[dev->prof_used++], st));
     return 0;
   };
-  HS_HIP(hipMemsetAsync(dev->h.redo, 0, sizeof(int32_t)*(size_t)dev->h.n_active, st));
+  HS_HIP(hipMemsetAsync(dev->h.redo, 0, sizeof(int32_t)*((size_t)dev->h.n_active + 2*dev->prep.chunks.size() + 2), st));
+  int chunk_no = 0;
   for (const hipstr::Prepared::Chunk& ch : dev->prep.chunks){
     const unsigned nact = ch.active_end - ch.active_begin;
     if (mark()) return 1;
     // leading flanks: persistent wavefronts striding over (locus side, distinct flank, 64 reads) items
-    hs_launch_lead2(nact, (unsigned)std::max(1, std::min(dev->trail_waves, ch.lead_end - ch.lead_begin)), st, dp, ch.active_begin, ch.lead_begin, ch.lead_end);
+    hs_launch_lead2(nact, (unsigned)std::max(1, std::min(dev->trail_waves, ch.lead_end - ch.lead_begin)), st, dp, ch.active_begin, ch.lead_begin, ch.lead_end, 2*chunk_no);
     if (mark()) return 1;
     hipLaunchKernelGGL(hs_str_kernel, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin);
     // alleles without a tabulated closed form (interrupted repeats, very long blocks) and whatever hs_str_kernel marked HS_REDO
@@ -293,11 +295,12 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
     if (mark()) return 1;
     if (ch.trail_end > ch.trail_begin)     // trailing flanks: persistent wavefronts striding over (read side, allele group) items
       hs_launch_trail((unsigned)std::min(dev->trail_waves, ch.trail_end - ch.trail_begin), st, dp,
-                      dev->n_lead_items + ch.trail_begin, dev->n_lead_items + ch.trail_end);
+                      dev->n_lead_items + ch.trail_begin, dev->n_lead_items + ch.trail_end, 2*chunk_no + 1);
     if (mark()) return 1;
     hipLaunchKernelGGL(hs_combine_kernel, dim3(nact), dim3(256), 0, st, dp, ch.active_begin);
     if (mark()) return 1;
     HS_HIP(hipGetLastError());
+    chunk_no++;
   }
   return 0;
 }

@@ -160,11 +160,16 @@ __device__ __forceinline__ void band_dispatch(bool first, bool last, const hs_de
 }
 
 template <int R>
-__global__ void __launch_bounds__(64) hs_trail_kernel(const hs_dev_t* __restrict__ dp, int item_begin, int item_end){
+__global__ void __launch_bounds__(64) hs_trail_kernel(const hs_dev_t* __restrict__ dp, int item_begin, int item_end, int chunk){
   const hs_dev_t& d = *dp;
   const int lane = threadIdx.x;
   double* const bnd = d.ws_band + (size_t)blockIdx.x * d.band_cols * 64 * 2;
-  for (int item = item_begin + blockIdx.x; item < item_end; item += gridDim.x){
+  int32_t* const ctr = d.redo + d.n_active + chunk;          // items are handed out through a counter, as in hs_lead_kernel
+  for (;;){
+    int item = 0;
+    if (lane == 0) item = atomicAdd(ctr, 1);
+    item = item_begin + uni(item);
+    if (item >= item_end) break;
     const hs_item_t* it = d.items + item;
     const int side = uni(it->side), nreads = uni(it->rowset);
     const hs_tgroup_t* g = d.tgroups + uni(it->slot);
@@ -244,11 +249,18 @@ __global__ void __launch_bounds__(64) hs_col_kernel(const hs_dev_t* __restrict__
 // Writes the lead record of every read: rowP[n] | last column of the leading-flank rows | side_prob.
 //   item.active = first entry in tpack, item.side = side | slot << 1, item.rowset = rowset id, item.slot = number of reads
 template <int R>
-__global__ void __launch_bounds__(64) hs_lead_kernel(const hs_dev_t* __restrict__ dp, int item_begin, int item_end){
+__global__ void __launch_bounds__(64) hs_lead_kernel(const hs_dev_t* __restrict__ dp, int item_begin, int item_end, int chunk){
   const hs_dev_t& d = *dp;
   const int lane = threadIdx.x;
   double* const bnd = d.ws_band + (size_t)blockIdx.x * d.band_cols * 64 * 2;
-  for (int item = item_begin + blockIdx.x; item < item_end; item += gridDim.x){
+  // the items differ a lot in length (side lengths are bimodal) and there are only a few per wavefront: they are handed out through a
+  // counter (cleared with the re-do flags before every pass) instead of by stride
+  int32_t* const ctr = d.redo + d.n_active + chunk;
+  for (;;){
+    int item = 0;
+    if (lane == 0) item = atomicAdd(ctr, 1);
+    item = item_begin + uni(item);
+    if (item >= item_end) break;
     const hs_item_t* it = d.items + item;
     const int side = uni(it->side) & 1, slot = uni(it->side) >> 1, nreads = uni(it->slot);
     const bool live = lane < nreads;
@@ -1033,10 +1045,10 @@ hs_combine_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
 #define HS_TRAIL_ROWS 20
 #endif
 // leading flanks of the reads [active_begin, active_begin + n_active) of a chunk: column tables first, then the reads-as-lanes sweep
-extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end){
+extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk){
   hipLaunchKernelGGL(hs_col_kernel, dim3(n_active), dim3(64), 0, st, dp, active_begin);
-  if (item_end > item_begin) hipLaunchKernelGGL((hs_lead_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end);
+  if (item_end > item_begin) hipLaunchKernelGGL((hs_lead_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end, chunk);
 }
-extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end){
-  hipLaunchKernelGGL((hs_trail_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end);
+extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk){
+  hipLaunchKernelGGL((hs_trail_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end, chunk);
 }
