@@ -998,18 +998,21 @@ hs_combine_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
   const double* mr = d.ws_mr + vL.ws_mr + (int64_t)ord*(vL.len-1);
   const double* lt = d.ws_lt + vL.ws_lt + (int64_t)ord*uni(vL.loc->lt_stride);
   // last-column value of compact row u of a side: leading rows 0..Flead-1, the STR block's row at Flead, trailing rows after it
-  auto lcL = [&](int u){ return u < F0 ? recL[vL.n + u] : (u == F0 ? mr[vL.nL - 1] : lt[u - F0 - 1]); };
-  auto lcR = [&](int u){ return u < F2 ? recR[vR.n + u] : (u == F2 ? mr[vL.len - 2] : lt[F2 + (u - F2 - 1)]); };
+  // (one load through a selected address instead of three loads under branches: this kernel is bound by instruction issue, and the
+  // branches were a third of its instructions)
+  auto lcL = [&](int u){ const double* a = (u < F0) ? recL + (vL.n + u) : ((u == F0) ? mr + (vL.nL - 1) : lt + (u - F0 - 1)); return *a; };
+  auto lcR = [&](int u){ const double* a = (u < F2) ? recR + (vR.n + u) : ((u == F2) ? mr + (vL.len - 2) : lt + (F2 + (u - F2 - 1))); return *a; };
   const double sideL = recL[vL.n + uni(vL.loc->lead_flank[0])], sideR = recR[vR.n + uni(vL.loc->lead_flank[1])];
   const double prior = -d.int_log[N];
   auto term = [&](int y){
     const uint8_t hc = (uint8_t)((y < F0 ? d.rows[lead_off + y] : d.rows[trail_off + y - F0]) & 0xff);
     const double e = (seed_c == hc) ? seed_lc : seed_lw;
-    double a, b;
-    if (y == 0)        { a = sideL;     b = lcR(N-1); }
-    else if (y == N-1) { a = sideR;     b = lcL(N-1); }
-    else if (y < F0)   { a = lcL(y-1);  b = lcR(N-1-y); }
-    else               { a = lcL(y);    b = lcR(N-2-y); }
+    // y == 0: the whole left side hangs off the haplotype; y == N-1: the right side does (HapAligner.cpp:182-189)
+    const int uL = (y == N-1) ? N-1 : ((y < F0) ? max(y-1, 0) : y);
+    const int uR = (y == 0) ? N-1 : ((y < F0) ? N-1-y : max(N-2-y, 0));
+    const double vl = lcL(uL), vr = lcR(uR);
+    const double a = (y == 0) ? sideL : ((y == N-1) ? sideR : vl);
+    const double b = (y == N-1) ? vl : vr;
     return ((prior + e) + a) + b;
   };
   Lse acc;
@@ -1020,8 +1023,11 @@ hs_combine_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
 #pragma unroll
     for (int k = 0; k < 4; k++){
       const int y = lane + 64*k;
-      t[k] = (y < N) ? term(min(y, N-1)) : -1.0e300;
-      acc.mx = fmax(acc.mx, t[k]);
+      t[k] = -1.0e300;
+      if (64*k < N){                              // wave-uniform: rounds past the last position issue nothing
+        if (y < N) t[k] = term(y);
+        acc.mx = fmax(acc.mx, t[k]);
+      }
     }
     acc.mx = wave_max_d(acc.mx);
     acc.tot = 0.0;
