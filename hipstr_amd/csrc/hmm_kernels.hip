@@ -24,6 +24,7 @@
 // bit-identical to the CPU path.  Compile with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "layout.h"
 #include "device_common.h"
@@ -598,17 +599,44 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
       const int j = min(lane + 64*kk, n-1);
       double lp = (t0 > 0) ? L.Mt[j] : 0.0;
       const int ndp = c.nd * p;
-      // read position j - t, unclamped: a step with t > j is masked (Dl sits in front of bq); the "(t+1) is a multiple of p" test of
-      // the deletion table is carried as a counter instead of a division
-      const uint8_t* prd = L.rd + (j - t0); const double2* pbq = L.bq + (j - t0);
-      int left = j - t0, ph = (t0 + 1) % p;
-      double* dl = L.Dl + ((t0 + 1)/p - 1)*L.ld + j;          // row of the deletion table the next multiple of p goes to
-      for (int t = t0; t < tmax; t++){
-        const double e = emit(*prd, blk_at(c, B-1-t), *pbq);
-        if (left >= 0) lp += e;
-        if (ph == 0){ if (t < ndp && left >= 0) *dl = lp; }
-        ph++; if (ph == p){ ph = 0; dl += L.ld; }
-        prd--; pbq--; left--;
+      int t = t0;
+      // the first nd*p steps also fill the deletion table: one step at a time, the "(t+1) is a multiple of p" test carried as a counter.
+      // Read position j - t is not clamped: a step with t > j is masked (Dl sits in front of bq)
+      if (t < min(tmax, ndp)){
+        const uint8_t* prd = L.rd + (j - t); const double2* pbq = L.bq + (j - t);
+        int left = j - t, ph = (t + 1) % p;
+        double* dl = L.Dl + ((t + 1)/p - 1)*L.ld + j;          // row of the deletion table the next multiple of p goes to
+        for (; t < min(tmax, ndp); t++){
+          const double e = emit(*prd, blk_at(c, B-1-t), *pbq);
+          if (left >= 0) lp += e;
+          if (ph == 0){ if (left >= 0) *dl = lp; }
+          ph++; if (ph == p){ ph = 0; dl += L.ld; }
+          prd--; pbq--; left--;
+        }
+      }
+      // the rest only extends match_probs_: groups of four steps sharing one address (index kept opaque to the optimiser, immediate
+      // offsets), without a mask while t <= 64 kk, the smallest column of this chunk
+      auto steps = [&](int tend, auto masked){
+        int xr = j - t - 3, xb = B - 1 - t - 3;
+        for (; t + 4 <= tend; t += 4){
+          asm volatile("" : "+v"(xr));
+          const uint8_t* prd = L.rd + xr; const double2* pbq = L.bq + xr;
+#pragma unroll
+          for (int k = 0; k < 4; k++){
+            const double e = emit(prd[3-k], blk_at(c, xb + 3 - k), pbq[3-k]);
+            if (!decltype(masked)::value || xr + 3 - k >= 0) lp += e;
+          }
+          xr -= 4; xb -= 4;
+        }
+        for (; t < tend; t++){
+          const double e = emit(L.rd[xr + 3], blk_at(c, xb + 3), L.bq[xr + 3]);
+          if (!decltype(masked)::value || xr + 3 >= 0) lp += e;
+          xr--; xb--;
+        }
+      };
+      if (t < tmax){
+        steps(min(tmax, 64*kk + 1), std::false_type());
+        steps(tmax, std::true_type());
       }
       L.Mt[j] = lp;
     }
