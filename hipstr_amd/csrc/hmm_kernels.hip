@@ -770,13 +770,6 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
           const int D = (q+1)*p;
           if (q < nd_eq){
             li = (j >= D - 1) ? L.Dl[q*L.ld + j] : L.Mt[j];
-          } else
-          if (kk > 0){                             // every column of this chunk is >= 64 > 6p - 1: no step leaves the read
-            for (int m = 0; m < p; m++){
-              const double2 bq = *pli_bq;
-              li += (m < B) ? emit(*pli_rd, blk_at(c, B-1-min(m, B-1)), bq) : bq.x;
-              pli_bq--; pli_rd--;
-            }
           } else {
             for (int m = 0; m < p; m++){             // read position j - t: unclamped (a step with t > j is masked; Dl sits in front of bq)
               const double2 bq = *pli_bq;
