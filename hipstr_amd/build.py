@@ -33,7 +33,7 @@ def build_hmm(force=False):
     deps = [os.path.join(CSRC, s) for s in HIP_SOURCES + HIP_HEADERS]
     if force or _stale(out, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        extra = ["-D%s=%s" % (m, os.environ[e]) for m, e in (("HS_MIN_WAVES", "HIPSTR_MIN_WAVES"), ("HS_TRAIL_ROWS", "HIPSTR_TRAIL_ROWS"), ("HS_STR_WAVES", "HIPSTR_STR_WAVES")) if os.environ.get(e)]
+        extra = ["-D%s=%s" % (m, os.environ[e]) for m, e in (("HS_TRAIL_ROWS", "HIPSTR_TRAIL_ROWS"), ("HS_STR_WAVES", "HIPSTR_STR_WAVES")) if os.environ.get(e)]
         _run([hipcc] + HIPCC_FLAGS + extra + ["-o", out] + [os.path.join(CSRC, s) for s in HIP_SOURCES])
     return out
 
