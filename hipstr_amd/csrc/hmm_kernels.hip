@@ -92,9 +92,18 @@ __device__ __forceinline__ void band_sweep(const hs_dev_t& d, int lane, bool liv
   if (!FIRST) nx_b = *(const double2*)(bnd + (size_t)lane*2);
   double diagM = 0, diagD = 0;
   double pre = 0.0;                              // LEAD: left_prob, a strictly sequential sum in the reference
+  // The bottom boundary of column j is stored at the top of iteration j+1, after that iteration has waited for its prefetched
+  // loads: gfx9 counts loads and stores in one counter, so a store issued right before that wait would be waited for as well
+  // (a round trip to L2 per column).  In place: position j-1 was read two iterations ago.
+  double pendM = 0.0, pendD = 0.0;
+  auto flush_pending = [&](int jp){
+    if (!LAST) *(double2*)(bnd + ((size_t)jp*64 + lane)*2) = make_double2(pendM, pendD);
+    else if (LEAD){ if (jp < n && live) rowp[jp] = pendM; }
+  };
   for (int j = 0; j < nmax; j++){
     const double blcj = nx_blc, blwj = nx_blw; const int rdj = (int)nx_rd;
     const double cur_mr = nx_mr; const double2 cur_b = nx_b;
+    if (j > 0) flush_pending(j - 1);
     {
       const int jn = min(j + 1, n - 1);           // a lane past its own read end keeps re-reading its last column
       nx_blc = col[3*jn]; nx_blw = col[3*jn+1]; nx_rd = col[3*jn+2];
@@ -140,14 +149,14 @@ __device__ __forceinline__ void band_sweep(const hs_dev_t& d, int lane, bool liv
         upM = Mp[r]; upD = nD;
       }
     }
-    if (!LAST) *(double2*)(bnd + ((size_t)j*64 + lane)*2) = make_double2(upM, upD);
-    else if (LEAD){ if (j < n && live) rowp[j] = upM; }
+    pendM = upM; pendD = upD;
     diagM = topM; diagD = topD;                // top boundary of this column = diagonal of the band's first row next column
     if (j == n-1 && live){
 #pragma unroll
       for (int r = 0; r < NR; r++) lt[row0 + r] = Mp[r];           // last read column of this lane's read
     }
   }
+  if (nmax > 0) flush_pending(nmax - 1);
 }
 
 template <int NR, bool LEAD = false>
