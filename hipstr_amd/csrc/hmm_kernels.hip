@@ -26,6 +26,9 @@
 #include <stdint.h>
 #include <type_traits>
 
+#ifdef __HIP_DEVICE_COMPILE__
+#define HS_P(T) __attribute__((address_space(1))) T*      // layout.h: the argument block's pointers are global-address-space pointers here
+#endif
 #include "layout.h"
 #include "device_common.h"
 

@@ -122,41 +122,46 @@ struct hs_tgroup_t { int32_t rowset; int32_t member_off; int32_t n_members; int3
 // Work items of the phase kernels (sorted by columns-per-lane class where the kernel is templated on it).
 struct hs_item_t { int32_t active; int32_t side; int32_t rowset; int32_t slot; };
 
-// Kernel argument block (all device pointers).
+// Kernel argument block (all device pointers).  HS_P(T) is `T*`; the kernel translation unit defines it as a pointer into the global
+// address space before including this header, so that loads and stores through these fields are global_* instead of flat_*
+// instructions (a flat access also counts against the LDS wait counter).
+#ifndef HS_P
+#define HS_P(T) T*
+#endif
 struct hs_dev_t {
-  const hs_locus_t*  loci;
-  const hs_allele_t* alleles;
-  const hs_stropt_t* stropts;
-  const hs_rowset_t* rowsets;
-  const hs_row_t*    rows;
-  const hs_visit_t*  visits;
-  const double*      f64pool;
-  const char*        chars;      // STR block sequences
-  const hs_read_t*   reads;
-  const char*        bases;
-  const char*        quals;
-  const int32_t*     active;     // read indices that need alignment (realign && seed >= 0)
-  const hs_ws_t*     ws;         // [n_active] workspace offsets
-  const hs_item_t*   items;      // lead items and trail items, grouped (see api.hip)
-  const hs_tgroup_t* tgroups;
-  const int32_t*     tmembers;   // allele indices (within the locus) of the trail groups
-  const int32_t*     tpack;      // active-read indices of the reads packed into one trail item
-  const int32_t*     str_order;  // allele index (within the locus) per processing position; bit 30 set = this allele's STR block,
+  HS_P(const hs_locus_t) loci;
+  HS_P(const hs_allele_t) alleles;
+  HS_P(const hs_stropt_t) stropts;
+  HS_P(const hs_rowset_t) rowsets;
+  HS_P(const hs_row_t) rows;
+  HS_P(const hs_visit_t) visits;
+  HS_P(const double) f64pool;
+  HS_P(const char) chars;      // STR block sequences
+  HS_P(const hs_read_t) reads;
+  HS_P(const char) bases;
+  HS_P(const char) quals;
+  HS_P(const int32_t) active;     // read indices that need alignment (realign && seed >= 0)
+  HS_P(const hs_ws_t) ws;         // [n_active] workspace offsets
+  HS_P(const hs_item_t) items;      // lead items and trail items, grouped (see api.hip)
+  HS_P(const hs_tgroup_t) tgroups;
+  HS_P(const int32_t) tmembers;   // allele indices (within the locus) of the trail groups
+  HS_P(const int32_t) tpack;      // active-read indices of the reads packed into one trail item
+  HS_P(const int32_t) str_order;  // allele index (within the locus) per processing position; bit 30 set = this allele's STR block,
                                  // in side orientation, ends with the previous position's block (its tables are continued); bit 29
                                  // set = ... and is that block plus one repeat unit, periodic, with all six deletion sizes
-  double*            ws_col;
-  double*            ws_band;    // per persistent wavefront: 2 x [band_cols][64 lanes][2] band-boundary rows (M, D)
-  double*            ws_mr;
-  double*            ws_lt;
-  double*            ws_lead;
-  double*            aln_probs;
-  int32_t*           redo;       // [n_active] set by hs_str_kernel when it left HS_REDO marks for a read; cleared before every pass
+  HS_P(double) ws_col;
+  HS_P(double) ws_band;    // per persistent wavefront: 2 x [band_cols][64 lanes][2] band-boundary rows (M, D)
+  HS_P(double) ws_mr;
+  HS_P(double) ws_lt;
+  HS_P(double) ws_lead;
+  HS_P(double) aln_probs;
+  HS_P(int32_t) redo;       // [n_active] set by hs_str_kernel when it left HS_REDO marks for a read; cleared before every pass
   // constant tables
-  const double*      int_log;    // [10000]
-  const double*      qual_correct; // [256] indexed by raw quality char (clamps applied)
-  const double*      qual_error;   // [256]
-  const double*      m2m;        // [16] LOG_MATCH_TO_MATCH
-  const double*      m2i;        // [16] LOG_MATCH_TO_INS (== LOG_MATCH_TO_DEL, AlignmentModel.cpp:27-28)
+  HS_P(const double) int_log;    // [10000]
+  HS_P(const double) qual_correct; // [256] indexed by raw quality char (clamps applied)
+  HS_P(const double) qual_error;   // [256]
+  HS_P(const double) m2m;        // [16] LOG_MATCH_TO_MATCH
+  HS_P(const double) m2i;        // [16] LOG_MATCH_TO_INS (== LOG_MATCH_TO_DEL, AlignmentModel.cpp:27-28)
   double             log_thresh;   // LOG_THRESH = log(0.001), mathops.h:36 (host libm bits)
   double             log_half;     // LOG_ONE_HALF, mathops.cpp:9
   int32_t            n_active;
