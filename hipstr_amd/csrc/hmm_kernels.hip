@@ -995,7 +995,10 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
 extern "C" __global__ void __launch_bounds__(128, HS_STR_WAVES)
 hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){ str_body<0>(*dp, active_begin); }
 
-extern "C" __global__ void __launch_bounds__(128, HS_STR_WAVES)
+#ifndef HS_STRG_WAVES
+#define HS_STRG_WAVES 3      // the long forms want registers more than wavefronts: 168 VGPRs without spills beat 128 with 160 B of them
+#endif
+extern "C" __global__ void __launch_bounds__(128, HS_STRG_WAVES)
 hs_str_kernel_generic(const hs_dev_t* __restrict__ dp, int active_begin){ str_body<1>(*dp, active_begin); }
 
 // compute_aln_logprob (HapAligner.cpp:163-231): log-sum-exp over the haplotype positions the seed base can sit on.
