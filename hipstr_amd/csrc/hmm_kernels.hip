@@ -774,28 +774,38 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
           const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
           terms[HS_MAXREP] = (rdlane(c.cst, HS_MAXREP) + L.Mt[j]) + pre;
         }
-        // ins_probs_: the first nd_eq repeat units come from the tables (layout.h nd_eq), the loop continues from there
-        double li = 0.0;
-        const double2* pli_bq = L.bq + (j - nd_eq*p); const uint8_t* pli_rd = L.rd + (j - nd_eq*p); int li_left = j - nd_eq*p;
-#pragma unroll
-        for (int q = 0; q < HS_MAXREP; q++){
+        // ins_probs_: the first nd_eq repeat units come from the tables (layout.h nd_eq), a loop continues from there.  The usual case —
+        // all six units from the tables — gets its own copy of the six terms, free of the loop's pointers and merges
+        auto ins_term = [&](int q, double li){
           const int D = (q+1)*p;
-          if (q < nd_eq){
-            li = (j >= D - 1) ? L.Dl[q*L.ld + j] : L.Mt[j];
-          } else {
-            for (int m = 0; m < p; m++){             // read position j - t: unclamped (a step with t > j is masked; Dl sits in front of bq)
-              const double2 bq = *pli_bq;
-              const double e = (m < B) ? emit(*pli_rd, blk_at(c, B-1-min(m, B-1)), bq) : bq.x;
-              if (li_left >= 0) li += e;
-              pli_bq--; pli_rd--; li_left--;
-            }
-          }
           const int len = min(B + D, j + 1);
           const double lp0 = (rdlane(c.cst, 13) + li) + ((len > D) ? L.Mt[max(j - D, 0)] : 0.0);
           const int lim = actj ? min(max(0, len - D), B) : 0;
           const double S = tab_eval(lp0, lim, HS_MAXREP);
           const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
-          terms[HS_MAXREP + 1 + q] = (rdlane(c.cst, HS_MAXREP + 1 + q) + S) + pre;
+          return (rdlane(c.cst, HS_MAXREP + 1 + q) + S) + pre;
+        };
+        if (nd_eq == HS_MAXREP){
+#pragma unroll
+          for (int q = 0; q < HS_MAXREP; q++)
+            terms[HS_MAXREP + 1 + q] = ins_term(q, (j >= (q+1)*p - 1) ? L.Dl[q*L.ld + j] : L.Mt[j]);
+        } else {
+          double li = 0.0;
+          const double2* pli_bq = L.bq + (j - nd_eq*p); const uint8_t* pli_rd = L.rd + (j - nd_eq*p); int li_left = j - nd_eq*p;
+#pragma unroll
+          for (int q = 0; q < HS_MAXREP; q++){
+            if (q < nd_eq){
+              li = (j >= (q+1)*p - 1) ? L.Dl[q*L.ld + j] : L.Mt[j];
+            } else {
+              for (int m = 0; m < p; m++){           // read position j - t: unclamped (a step with t > j is masked; Dl sits in front of bq)
+                const double2 bq = *pli_bq;
+                const double e = (m < B) ? emit(*pli_rd, blk_at(c, B-1-min(m, B-1)), bq) : bq.x;
+                if (li_left >= 0) li += e;
+                pli_bq--; pli_rd--; li_left--;
+              }
+            }
+            terms[HS_MAXREP + 1 + q] = ins_term(q, li);
+          }
         }
         int ndo = 0;                                   // number of the first (size q, column) pair: sizes 0..q-1 come first
 #pragma unroll
