@@ -816,9 +816,11 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
             const int cq = min(aD, n);
             const int len = min(B - aD, j + 1);
             const bool direct = (j + aD <= n - 1);
-            double lp0 = rdlane(c.cst, 14 + q);
-            if (direct) lp0 += L.Mt[min(j + aD, n-1)] - L.Dl[q*L.ld + min(j + aD, n-1)];
-            else        lp0 = L.nd[ndo + min(max(j - (n - cq), 0), cq - 1)];
+            // both candidates are read (clamped indices) and one is selected: cheaper than two exec-masked branches per size
+            const int jd = min(j + aD, n-1);
+            const double dsum = L.Mt[jd] - L.Dl[q*L.ld + jd];
+            const double ndv = L.nd[ndo + min(max(j - (n - cq), 0), cq - 1)];
+            const double lp0 = direct ? rdlane(c.cst, 14 + q) + dsum : ndv;
             const double S = tab_eval(lp0, actj ? len : 0, q);
             const double pre = (j - len < 0) ? 0.0 : L.rowP[max(j - len, 0)];
             terms[HS_MAXREP - 1 - q] = (rdlane(c.cst, HS_MAXREP - 1 - q) + S) + pre;
