@@ -192,3 +192,26 @@ def test_tabulated_closed_form_and_its_redo_path(hmm, oracle, monkeypatch, env):
         got, gs = capi.run_align(hmm, "hipstr_hmm_", sb.ptr, fill=-3.25)
         monkeypatch.delenv(env[0])
         assert np.array_equal(gs, ws) and np.array_equal(got, want), (env, kw)
+
+
+@pytest.mark.parametrize("lf_len,rf_len", [(1, 40), (40, 1), (2, 33), (20, 21), (21, 20), (41, 61)])
+def test_flank_heights_around_the_band_size(hmm, oracle, lf_len, rf_len):
+    """The banded sweeps of hs_lead_kernel / hs_trail_kernel cut a flank into bands of <= 20 rows; a one-base flank is a block with
+    matrix row 0 (or the "must be followed by a match" row) and nothing else.  Flank lengths of 1, 2, exactly one band, one band + 1, two
+    bands + 1 and three bands + 1, on both sides, reads of several lengths sharing a wavefront."""
+    import random
+    rnd = random.Random(1000 * lf_len + rf_len)
+    lf = "".join(rnd.choice("ACGT") for _ in range(lf_len)); rf = "".join(rnd.choice("ACGT") for _ in range(rf_len))
+    strs = ["ACG" * k for k in (6, 5, 7, 9)] + ["ACG" * 3 + "ATG" + "ACG" * 3]
+    hap = lf + strs[0] + rf
+    reads = []
+    for s in range(0, max(1, len(hap) - 24), 3):
+        for ln in (24, 31, len(hap) - s):
+            if s + ln <= len(hap):
+                reads.append((hap[s:s + ln], None, s, True))
+    b, A = simple_locus(lf, strs, rf, 3, reads)
+    b.finalize()
+    want, ws = capi.run_align(oracle, "oracle_", b.ptr, fill=-2.5)
+    got, gs = capi.run_align(hmm, "hipstr_hmm_", b.ptr, fill=-2.5)
+    assert (ws >= 0).sum() > 0, "no read of this shape has a seed: the case tests nothing"
+    assert np.array_equal(gs, ws) and np.array_equal(got, want), np.max(np.abs(got - want))
