@@ -385,8 +385,8 @@ int hipstr_hmm_process_reads(const hipstr_batch_t* batch, double* aln_probs, int
   return rc;
 }
 
-// Diagnostics for the host preparation (no device needed): the haplotype rows, as they enter the
-// systolic sweep, of allele k / side / block (0 = leading flank, 1 = trailing flank) of a ONE-locus batch.
+// Diagnostics for the host preparation (no device needed): the haplotype rows, as the flank sweeps
+// consume them, of allele k / side / block (0 = leading flank, 1 = trailing flank) of a ONE-locus batch.
 int hipstr_debug_rows(const hipstr_batch_t* batch, int k, int side, int which, uint32_t* rows, int cap){
   hipstr::Prepared P; std::string err;
   if (hipstr::prepare_batch(batch, P, err)){ g_err = err; return -1; }

@@ -15,12 +15,12 @@
 #define HS_TAB_CAP       48        // closed-form table entries per STR option the STR kernel keeps in LDS (hs_stropt_t::tab_*)
 #define HS_NART          13        // artifact sizes -6p..+6p (RepeatStutterInfo.h:10-11)
 #define HS_MAXREP        6
-#define HS_MAX_COLS      4         // max read columns per lane in the systolic sweep
+#define HS_MAX_COLS      4         // max read columns per lane in the systolic sweep of the traceback fill (trace.hip)
 #define HS_MAX_SIDE_LEN  (64 * HS_MAX_COLS)
 #define HS_IMPOSSIBLE    (-1000000000.0)   // HapAligner.cpp:20
 #define HS_REDO          (1.0e300)         // mark in the MR workspace: "this chunk of columns is left to hs_str_kernel_generic"
 
-// One haplotype row of a flank block, as it enters the systolic sweep.
+// One haplotype row of a flank block, as the flank sweeps consume it.
 //   bits  0..7   haplotype base (raw char, compared with read chars for equality)
 //   bits  8..11  min(15, homopolymer length) -> index into LOG_MATCH_TO_* (HapAligner.cpp:119-120)
 //   bits 12..23  compact row index u (see lastcol layout below)

@@ -3,7 +3,7 @@
 // window (AlignmentOps.cpp:14-26) and Haplotype::aln_haps_to_ref for every haplotype against the reference haplotype
 // (Haplotype.cpp:58-86, with the end penalty).
 //
-//   hs_nw_fill<C>   one wavefront per pair, the same systolic sweep as the flank kernels: lane k owns C consecutive read
+//   hs_nw_fill<C>   one wavefront per pair, the same systolic sweep as the traceback fill (trace.hip): lane k owns C consecutive read
 //                   positions (rows), reference columns enter at lane 0 and move down one lane per step together with the
 //                   three scores of the lane's last row at the current and the previous column (v_mov_b32_dpp wave_shr:1).
 //                   Scores live in registers only; what goes to HBM is one traceback byte per cell (three 2-bit choices) and

@@ -5,8 +5,8 @@
 // arg-max seed position (HapAligner.cpp:163-231), HapAligner::retrace (HapAligner.cpp:363-571) from that position, and
 // stitch_alignment_trace (AlignmentTraceback.cpp:55-144).
 //
-//   hs_trace_fill<C>   one wavefront per (request, side): the same systolic anti-diagonal flank sweep as the forward
-//                      path.  The reference keeps the full M/I/D matrices and lets retrace compare neighbours; every such
+//   hs_trace_fill<C>   one wavefront per (request, side) runs a systolic anti-diagonal flank sweep (a traceback is one
+//                      read against one allele: nothing but its own columns to put on the lanes).  The reference keeps the full M/I/D matrices and lets retrace compare neighbours; every such
 //                      comparison only involves operands the sweep has in registers when it computes the cell, so the sweep
 //                      takes retrace's three decisions right there (with its 0.001-nat, direction-dependent tie rules) and
 //                      HBM receives ONE BYTE per cell instead of 24 (compact rows: the interior rows of the STR block, which
