@@ -57,6 +57,9 @@ __device__ __forceinline__ double* lead_record(const hs_dev_t& d, const SideView
   return d.ws_lead + v.ws_lead + (int64_t)slot*stride;
 }
 
+#ifndef HS_FLANK_WAVES
+#define HS_FLANK_WAVES 2      // wavefronts per SIMD the flank kernels are register-allocated for (20 rows x M/I/D = 120 VGPRs of state)
+#endif
 // ------------------------------------------------------------------ trailing flank: alleles as lanes, banded sweep
 // Work item = (read side, group of <= 64 alleles sharing the trailing-flank rowset).  Lane = allele.  Every quantity
 // that depends on the read column or on the haplotype row — base, log P(correct/error), flank base, transition
@@ -173,7 +176,7 @@ __device__ __forceinline__ void band_dispatch(bool first, bool last, const hs_de
 }
 
 template <int R>
-__global__ void __launch_bounds__(64) hs_trail_kernel(const hs_dev_t* __restrict__ dp, int item_begin, int item_end, int chunk){
+__global__ void __launch_bounds__(64, HS_FLANK_WAVES) hs_trail_kernel(const hs_dev_t* __restrict__ dp, int item_begin, int item_end, int chunk){
   const hs_dev_t& d = *dp;
   const int lane = threadIdx.x;
   double* const bnd = d.ws_band + (size_t)blockIdx.x * d.band_cols * 64 * 2;
@@ -262,7 +265,7 @@ __global__ void __launch_bounds__(64) hs_col_kernel(const hs_dev_t* __restrict__
 // Writes the lead record of every read: rowP[n] | last column of the leading-flank rows | side_prob.
 //   item.active = first entry in tpack, item.side = side | slot << 1, item.rowset = rowset id, item.slot = number of reads
 template <int R>
-__global__ void __launch_bounds__(64) hs_lead_kernel(const hs_dev_t* __restrict__ dp, int item_begin, int item_end, int chunk){
+__global__ void __launch_bounds__(64, HS_FLANK_WAVES) hs_lead_kernel(const hs_dev_t* __restrict__ dp, int item_begin, int item_end, int chunk){
   const hs_dev_t& d = *dp;
   const int lane = threadIdx.x;
   double* const bnd = d.ws_band + (size_t)blockIdx.x * d.band_cols * 64 * 2;
