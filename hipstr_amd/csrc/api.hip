@@ -398,6 +398,12 @@ int hipstr_debug_rows(const hipstr_batch_t* batch, int k, int side, int which, u
   return rs.len;
 }
 
+int hipstr_debug_simple_table(int bound, int U0, int tail, double entry[3]){
+  if (!entry || bound < 0 || U0 < 0 || tail < 0 || tail >= 10000 || U0 >= 10000) return fail("bad argument");
+  hipstr::debug_simple_table(bound, U0, tail, entry);
+  return 0;
+}
+
 // ----------------------------------------------------------------------------- posteriors
 int hipstr_post_offsets(const hipstr_post_batch_t* pb, int64_t* post_off, int64_t* samp_off){
   if (!pb || !post_off || !samp_off) return fail("null argument");

@@ -418,6 +418,7 @@ void fresh_flank_rows(const std::string side_seqs[3], std::vector<hs_row_t>& lea
   trail = flank_rows(h, 2, (int)h.s[0].size() + 1);
 }
 void append_stropt(const std::string& blk, int period, const double* stutter, Prepared& out){ emit_stropt(blk, period, stutter, out); }
+void debug_simple_table(int lim, int U0, int tail, double ent[3]){ g_bnd_scale = 1.0; simple_table_entry(lim, U0, tail, ent); }
 
 int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int64_t ws_budget){
   host_tables();

@@ -77,6 +77,9 @@ void fresh_flank_rows(const std::string side_seqs[3], std::vector<hs_row_t>& lea
 // Appends one hs_stropt_t (+ visiting lists, f64 constants, block bytes) for a block sequence given in side orientation.
 void append_stropt(const std::string& blk, int period, const double* stutter, Prepared& out);
 
+// One {A, G, Bnd} entry of the tabulated closed form of a simple visiting list (diagnostics / tests).
+void debug_simple_table(int lim, int U0, int tail, double ent[3]);
+
 // StutterModel::log_stutter_pmf (stutter_model.cpp:29-53) from the six constructor parameters.
 double log_stutter_pmf(const double* sp, int period, int sample_bps, int read_bps);
 

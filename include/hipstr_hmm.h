@@ -349,6 +349,12 @@ int hipstr_hmm_trace(const hipstr_batch_t* batch, int32_t n_req, const int32_t* 
  * count (0 if the allele is not realigned, -1 on error).  Used by tests/test_prep.py. */
 int hipstr_debug_rows(const hipstr_batch_t* batch, int k, int side, int which, uint32_t* rows, int cap);
 
+/* Diagnostics (host only): one entry {A, G, Bnd} of the tabulated closed form the STR kernel uses for a "simple" visiting
+ * list (StutterAlignerClass.cpp:59-150 for a periodic block): with `bound` columns of the block in reach, a run of U0 equal
+ * configurations at the block's right end and `tail` configurations in total, fast_log_sum_exp over the pushed values is
+ * (lp0 + A) + G bit for bit whenever |lp0| < Bnd.  Used by tests/test_prep.py to check exactly that against the oracle. */
+int hipstr_debug_simple_table(int bound, int U0, int tail, double entry[3]);
+
 const char* hipstr_last_error(void);
 
 #ifdef __cplusplus

@@ -99,3 +99,45 @@ def test_haplotype_rows_match_oracle(hmm_host, oracle, name):
                 assert np.array_equal((rows[1:n] >> 8) & 15, hh[row0 + 1:row0 + n])     # row 0 of a block carries no transition
                 u0 = 0 if which == 0 else len(lead) + 1
                 assert np.array_equal((rows[:n] >> 12) & 0xfff, np.arange(u0, u0 + n))
+
+
+def test_tabulated_closed_form_is_exact_below_its_bound(hmm_host, oracle):
+    """hs_str_kernel evaluates a simple visiting list as (lp0 + A) + G from a table entry {A, G, Bnd} (prep.cpp simple_table_entry).
+    The claim: for |lp0| < Bnd that is bit for bit what fast_log_sum_exp (mathops.cpp:97-106) returns for the values the reference
+    pushes — lp0 once per plain offset (+1), ln(U0) + lp0 for the run at the block's end, ln(tail - stop) + lp0 for the equal-likelihood
+    rest.  Checked against the oracle's fast_lse_vec on random lists, bounds and lp0 — most of them far below Bnd as in real data, a
+    share right below it, where the margin of the error model is thinnest."""
+    oracle.oracle_fast_lse_vec.restype = C.c_double
+    oracle.oracle_fast_lse_vec.argtypes = [C.POINTER(C.c_double), C.c_int]
+    oracle.oracle_int_log.restype = C.c_double
+    oracle.oracle_int_log.argtypes = [C.c_int]
+    rng = np.random.default_rng(77)
+    ent = (C.c_double * 3)()
+    checked = near = 0
+    for _ in range(4000):
+        tail = int(rng.integers(0, 400))
+        U0 = int(rng.integers(0, tail + 1)) if rng.random() < 0.8 else 0
+        lim = int(rng.integers(0, tail + 1))
+        assert hmm_host.hipstr_debug_simple_table(lim, U0, tail, ent) == 0
+        A, G, bnd = ent[0], ent[1], ent[2]
+        skip = U0 > 0 and lim > 0
+        nplain = max(0, lim - U0)
+        stop = 0 if lim <= 0 else (U0 if (U0 > 0 and lim <= U0) else lim)
+        for rep in range(12):
+            if bnd <= 0:
+                break
+            mag = min(bnd, 1e12) * (1.0 - 2.0 ** -20) * (1.0 if rep < 2 else 0.0) or float(10.0 ** rng.uniform(-1, 5))
+            if mag >= bnd:
+                continue
+            lp0 = -mag if rng.random() < 0.9 else mag
+            vals = [lp0] * (1 + nplain)
+            if skip:
+                vals.append(oracle.oracle_int_log(U0) + lp0)
+            if stop < tail:
+                vals.append(oracle.oracle_int_log(tail - stop) + lp0)
+            arr = (C.c_double * len(vals))(*vals)
+            want = oracle.oracle_fast_lse_vec(arr, len(vals))
+            got = (lp0 + A) + G
+            assert got == want, (lim, U0, tail, lp0, got, want, bnd)
+            checked += 1; near += rep < 2
+    assert checked > 30000 and near > 5000
