@@ -24,6 +24,7 @@
 // bit-identical to the CPU path.  Compile with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstddef>
 #include <type_traits>
 
 #ifdef __HIP_DEVICE_COMPILE__
@@ -572,14 +573,26 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
 
     StrCtx c;
     c.so = d.stropts + str_opt;
-    c.B = uni(c.so->B); c.p = uni(c.so->period); c.nd = uni(c.so->nd);
-    const int nd_eq = uni(c.so->nd_eq);
-    c.cst = d.f64pool[uni(c.so->f64_off) + min(lane, 19)];
+    // the option's scalars come through the scalar cache in three loads (the record is wave-uniform and read-only; the compiler cannot
+    // prove the latter next to this kernel's stores and would fetch every field with a vector load and a v_readfirstlane)
+    typedef int hs_i8v __attribute__((ext_vector_type(8)));
+    typedef int hs_i2v __attribute__((ext_vector_type(2)));
+    hs_i8v so_head; hs_i2v so_tab; int so_ndeq;
+    {
+      const uint64_t sop = (uint64_t)(uintptr_t)(const hs_stropt_t*)c.so;
+      asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx2 %1, %3, 0x68\n\ts_load_dword %2, %3, 0x8c\n\ts_waitcnt lgkmcnt(0)"
+                   : "=s"(so_head), "=s"(so_tab), "=s"(so_ndeq) : "s"(sop) : "memory");
+    }
+    static_assert(offsetof(hs_stropt_t, tab_off) == 0x68 && offsetof(hs_stropt_t, nd_eq) == 0x8c && offsetof(hs_stropt_t, ins_len) == 24, "hs_stropt_t layout");
+    const int so_seq_off = so_head[0], so_f64_off = so_head[4];
+    c.B = so_head[1]; c.nd = so_head[2]; c.p = so_head[3];
+    const int nd_eq = so_ndeq;
+    c.cst = d.f64pool[so_f64_off + min(lane, 19)];
     c.blk = L.blk;
     const int B = c.B, p = c.p;
     // all seven visiting lists of the option sit back to back in memory: one coalesced 16 B/lane load brings the first
     // 64 entries; list offsets/lengths ride in one lane-indexed register (lane q: deletion list q, lane 6: insertion list)
-    const int ins_off = uni(c.so->ins_off), ins_len = uni(c.so->ins_len);
+    const int ins_off = so_head[5], ins_len = so_head[6];
     const hs_visit_t* ins_list = d.visits + ins_off;
     const int total = uni(c.so->del_off[HS_MAXREP-1]) + uni(c.so->del_len[HS_MAXREP-1]) - ins_off;
     const int shapes = (lane <= HS_MAXREP) ? c.so->shape[lane] : -1;
@@ -588,17 +601,17 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
     const bool all_closed = __all((lane > HS_MAXREP) || (shapes >= 0) || (shapes == HS_SHAPE_PIECEWISE) || (lane < HS_MAXREP && B - (lane+1)*p < 0));
 
     {
-      const int* src = (const int*)(d.chars + uni(c.so->seq_off));
+      const int* src = (const int*)(d.chars + so_seq_off);
       for (int i = lane; i < (B + 3)/4; i += 64) ((int*)L.blk)[i] = src[i];
     }
     if (lane < 20) L.cstl[lane] = c.cst;
     // tabulated closed form of the simple lists (when prep.cpp could build it): entry bases ride in a lane-indexed register
-    const int tab_len = uni(c.so->tab_len);
+    const int tab_len = so_tab[1];
     const bool use_tab = (MODE == 0);          // prep.cpp put exactly the alleles with all_simple && tab_len > 0 into [0, n_tab)
     const int tbase = (lane <= HS_MAXREP) ? c.so->tab_base[lane] : 0;
     double tab_bmin = 0.0;
     if (use_tab){
-      const double* src = d.f64pool + uni(c.so->tab_off);
+      const double* src = d.f64pool + so_tab[0];
       for (int e = lane; e < tab_len; e += 64){ L.tab[e] = src[3*e]; L.tab[HS_TAB_CAP + e] = src[3*e + 1]; }
       tab_bmin = uni(src[3*tab_len]);            // min over the entries' Bnd
     }
@@ -847,8 +860,8 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
         llen = (lane < HS_MAXREP) ? c.so->del_len[lane] : 0;
         if (!all_closed) bundle = ins_list[min(lane, max(total, ins_len) - 1)];
         if (!all_simple){      // descriptor slots of the piecewise-simple lists (only looked at where a shape says so)
-          pwA = d.f64pool[uni(c.so->f64_off) + 20 + lane];
-          pwB = d.f64pool[uni(c.so->f64_off) + 20 + 64 + min(lane, (HS_MAXREP + 1)*HS_PW_SLOTS - 65)];
+          pwA = d.f64pool[so_f64_off + 20 + lane];
+          pwB = d.f64pool[so_f64_off + 20 + 64 + min(lane, (HS_MAXREP + 1)*HS_PW_SLOTS - 65)];
         }
       }
       if (all_simple){
