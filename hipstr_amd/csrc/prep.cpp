@@ -399,11 +399,6 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
       out.f64pool.push_back(bmin);
     }
   }
-  if (getenv("HIPSTR_DEBUG_SHAPES") && so.tab_len == 0){
-    fprintf(stderr, "nontab B=%d p=%d nd_eq=%d shapes:", B, period, so.nd_eq);
-    for (int k = 0; k <= HS_MAXREP; k++) fprintf(stderr, " %d", so.shape[k]);
-    fprintf(stderr, " lens:"); for (int k = 0; k < HS_MAXREP; k++) fprintf(stderr, " %d", so.del_len[k]); fprintf(stderr, " ins %d  %s\n", so.ins_len, blk.c_str());
-  }
   out.stropts.push_back(so);
 }
 
