@@ -215,3 +215,19 @@ def test_flank_heights_around_the_band_size(hmm, oracle, lf_len, rf_len):
     got, gs = capi.run_align(hmm, "hipstr_hmm_", b.ptr, fill=-2.5)
     assert (ws >= 0).sum() > 0, "no read of this shape has a seed: the case tests nothing"
     assert np.array_equal(gs, ws) and np.array_equal(got, want), np.max(np.abs(got - want))
+
+
+@pytest.mark.parametrize("mask", [[0, 0, 0], [1, 0, 0], [0, 0, 1], [0, 1, 1]])
+def test_allele_masks_down_to_none(hmm, oracle, mask):
+    """realign_to_haplotype masks (HapAligner.cpp:615-619) including the empty one: the kernels of every phase must cope with a locus that
+    has no allele to align (no STR work, no trailing-flank groups), and masked entries keep the caller's values."""
+    lf = "ACGTTGCATGCATGACCTTGACGGT"; rf = "TTGACCGTAGGCTAGGCATTACGGA"
+    strs = ["GA" * 6, "GA" * 7, "GA" * 5]
+    hap = lf + strs[0] + rf
+    reads = [(hap[s:s + 40], None, s, True) for s in (0, 3, 8, 15)]
+    b, A = simple_locus(lf, strs, rf, 2, reads, realign_hap=mask)
+    b.finalize()
+    want, ws = capi.run_align(oracle, "oracle_", b.ptr, fill=-7.5)
+    got, gs = capi.run_align(hmm, "hipstr_hmm_", b.ptr, fill=-7.5)
+    assert np.array_equal(gs, ws) and np.array_equal(got, want)
+    assert np.all((got == -7.5).reshape(-1, 3)[:, [i for i, m in enumerate(mask) if not m]])
