@@ -462,6 +462,7 @@ def have_ref():
 def load_synth():
     lib = C.CDLL(SYNTH_LIB)
     _sig(lib.synth_create, C.c_void_p, [C.c_int32] * 7 + [C.c_uint64, C.c_double])
+    _sig(lib.synth_create_at, C.c_void_p, [C.c_int32] * 8 + [C.c_uint64, C.c_double])
     _sig(lib.synth_batch, _BP, [C.c_void_p])
     _sig(lib.synth_src_allele, _i32p, [C.c_void_p])
     _sig(lib.synth_free, None, [C.c_void_p])
@@ -472,9 +473,9 @@ class SynthBatch:
     """Seeded synthetic loci (hipstr_amd/synth/synth.cpp).  .ptr is a hipstr_batch_t*."""
 
     def __init__(self, n_loci, reads_per_locus, n_str_alleles, read_len=150, flank_len=60, str_bp=40, n_flank_opts=1,
-                 seed=20260928, mask_rate=0.0):
+                 seed=20260928, mask_rate=0.0, first_locus=0):
         self.lib = load_synth()
-        self.h = self.lib.synth_create(n_loci, reads_per_locus, n_str_alleles, read_len, flank_len, str_bp, n_flank_opts, seed, mask_rate)
+        self.h = self.lib.synth_create_at(first_locus, n_loci, reads_per_locus, n_str_alleles, read_len, flank_len, str_bp, n_flank_opts, seed, mask_rate)
         self.ptr = self.lib.synth_batch(self.h)
         self.n_reads, self.n_out, self.out_off = batch_dims(self.ptr)
         self.n_loci = n_loci

@@ -6,6 +6,7 @@
 // section payloads in the same order, each padded to 8 bytes.  Sections are the arrays of hipstr_batch_t by field order; absent
 // optional arrays (realign_hap, realign_read) have count 0.  A reader maps the file into one allocation and points a
 // hipstr_batch_t into it — no per-array copies.
+#include <climits>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -50,6 +51,54 @@ int sections_of(const hipstr_batch_t* b, View v[N_SECTIONS], std::string& err){
     { b->cigar_off, 4, (uint64_t)(n_reads + 1) }, { b->cigar_op, 1, (uint64_t)n_cig }, { b->cigar_len, 4, (uint64_t)n_cig },
     { b->realign_read, 1, b->realign_read ? (uint64_t)n_reads : 0 } };
   memcpy(v, t, sizeof t);
+  return 0;
+}
+
+// offsets[0..n] must start at 0, be non-decreasing and end at `total`
+bool offsets_ok(const int32_t* off, uint64_t n, uint64_t total){
+  if (off[0] != 0) return false;
+  for (uint64_t i = 0; i < n; i++) if (off[i+1] < off[i]) return false;
+  return (uint64_t)(int64_t)off[n] == total;
+}
+
+// Consistency of a deserialized image, using only the section counts as trusted sizes (sec[] itself was bounds-checked against
+// the image).  Order matters: an array is read only after its own count has been checked.
+int validate_image(const hipstr_batch_t& b, const Section* sec, std::string& err){
+  const int64_t n = b.n_loci;
+  if (n < 0){ err = "negative locus count"; return 1; }
+  const uint64_t un = (uint64_t)n;
+  static const int per_locus3[] = { 0, 1, 2 };
+  for (int s : per_locus3) if (sec[s].count != 3*un){ err = "block table size"; return 1; }
+  if (sec[3].count != un || sec[4].count != 6*un){ err = "period / stutter size"; return 1; }
+  if (n == 0){
+    for (int s = 5; s < N_SECTIONS; s++) if (sec[s].count > 1){ err = "data without loci"; return 1; }
+    return 0;
+  }
+  if (sec[7].count != un + 1 || sec[9].count != un + 1){ err = "hap_off / read_off size"; return 1; }
+  uint64_t n_opts = 0;
+  for (uint64_t i = 0; i < 3*un; i++){
+    if (b.blk_nopts[i] < 1){ err = "haplotype block without options"; return 1; }
+    n_opts += (uint64_t)b.blk_nopts[i];
+  }
+  if (sec[5].count != n_opts + 1){ err = "opt_off size"; return 1; }
+  if (!offsets_ok(b.opt_off, n_opts, sec[6].count)){ err = "opt_off is not a prefix sum of seq"; return 1; }
+  // hap_off: prefix sums of num_combs = product of the block option counts
+  if (b.hap_off[0] != 0){ err = "hap_off"; return 1; }
+  for (uint64_t l = 0; l < un; l++){
+    const int64_t combs = (int64_t)b.blk_nopts[3*l]*b.blk_nopts[3*l+1]*b.blk_nopts[3*l+2];
+    if (combs > INT32_MAX || (int64_t)b.hap_off[l+1] - b.hap_off[l] != combs){ err = "hap_off is not the prefix sum of num_combs"; return 1; }
+    if (b.blk_end[3*l] < b.blk_start[3*l] || b.blk_end[3*l+1] < b.blk_start[3*l+1] || b.blk_end[3*l+2] < b.blk_start[3*l+2]){ err = "block coordinates"; return 1; }
+  }
+  const uint64_t n_haps = (uint64_t)b.hap_off[un];
+  if (sec[8].count != 0 && sec[8].count != n_haps){ err = "realign_hap size"; return 1; }
+  if (b.read_off[0] != 0){ err = "read_off"; return 1; }
+  for (uint64_t l = 0; l < un; l++) if (b.read_off[l+1] < b.read_off[l]){ err = "read_off decreases"; return 1; }
+  const uint64_t n_reads = (uint64_t)b.read_off[un];
+  if (sec[10].count != n_reads + 1 || sec[14].count != n_reads + 1 || sec[13].count != n_reads){ err = "per-read table size"; return 1; }
+  if (sec[17].count != 0 && sec[17].count != n_reads){ err = "realign_read size"; return 1; }
+  if (sec[11].count != sec[12].count || sec[15].count != sec[16].count){ err = "bases/quals or cigar op/len size"; return 1; }
+  if (!offsets_ok(b.base_off, n_reads, sec[11].count)){ err = "base_off is not a prefix sum of bases"; return 1; }
+  if (!offsets_ok(b.cigar_off, n_reads, sec[15].count)){ err = "cigar_off is not a prefix sum of the CIGAR pool"; return 1; }
   return 0;
 }
 
@@ -119,14 +168,11 @@ hipstr_batch_file_t* hipstr_batch_deserialize(const void* data, int64_t size){
   b.realign_hap = (const uint8_t*)ptr[8]; b.read_off = (const int32_t*)ptr[9]; b.base_off = (const int32_t*)ptr[10];
   b.bases = (const char*)ptr[11]; b.quals = (const char*)ptr[12]; b.read_start = (const int32_t*)ptr[13]; b.cigar_off = (const int32_t*)ptr[14];
   b.cigar_op = (const char*)ptr[15]; b.cigar_len = (const int32_t*)ptr[16]; b.realign_read = (const uint8_t*)ptr[17];
-  // the arrays must describe each other consistently (same derivation the writer used)
-  View v[N_SECTIONS]; std::string err;
-  bool ok = b.n_loci >= 0 && (b.n_loci == 0 || (b.blk_nopts && b.hap_off && b.read_off && b.opt_off && b.base_off && b.cigar_off));
-  if (ok && b.n_loci > 0 && sections_of(&b, v, err) == 0){
-    for (int s = 0; s < N_SECTIONS && ok; s++)
-      if (v[s].count != sec[s].count && !(v[s].ptr == NULL && sec[s].count == 0)) ok = false;
-  } else if (b.n_loci > 0) ok = false;
-  if (!ok){ delete f; hipstr::api_fail("hipstr batch arrays do not match their offset tables"); return NULL; }
+  // The arrays must describe each other.  The image is untrusted: every array is checked against the section counts BEFORE an
+  // entry of it is used as an index or a size, and every offset array must start at 0, never decrease and end at the count of
+  // the section it indexes — so nothing downstream (prepare_batch) can be driven to a negative length or out of the image.
+  std::string err;
+  if (validate_image(b, sec, err)){ delete f; hipstr::api_fail("hipstr batch arrays do not match their offset tables: " + err); return NULL; }
   return f;
 }
 

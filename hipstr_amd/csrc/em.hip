@@ -57,7 +57,7 @@ struct hs_em_dev_t {
   const double*  int_log;
   double*  new_ll;             // [n_loci]
   double*  sums;               // [7*n_loci] in_up, in_down, in_eq, in_diffs, out_up, out_down, out_diffs
-  double*  row_lse;            // scratch: log_sum_exp of every posterior row (s, allele_1), at post_off / A
+  double*  row_lse;            // scratch: log_sum_exp of every posterior row (s, allele_1); a locus uses [post_off, post_off + S*A)
   double   log_thresh, log_half, log_1p1;
 };
 
@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(256) hs_em_mstep(const hs_em_dev_t* __restrict
   __syncthreads();
   // log_sum_exp of every row (sample, allele_1) first, all rows in parallel (each row summed in allele_2 order as the reference does);
   // the streaming scans below are sequential per allele by definition
-  double* row_lse = d.row_lse + L.post_off / A;
+  double* row_lse = d.row_lse + L.post_off;     // S*A values in this locus' own S*A*A region: disjoint between loci whatever their A
   for (int x = tid; x < S*A; x += 256){
     const double* row = post + (int64_t)x*A;
     double rm = row[0];

@@ -93,8 +93,11 @@ hs_posterior_kernel(const hs_post_dev_t* __restrict__ dp){
   }
   if (tid == 0){
     d.sample_total[u.samp_index] = total;
-    d.map_gt[2*u.samp_index]   = red_i[0] / A;
-    d.map_gt[2*u.samp_index+1] = red_i[0] % A;
+    // no diplotype above -DBL_MAX (all -inf / NaN: bad custom priors or NaN likelihoods): the reference's scan leaves its
+    // initial pair (-1,-1) (genotyper.cpp:84)
+    const bool none = red_i[0] == 0x7fffffff;
+    d.map_gt[2*u.samp_index]   = none ? -1 : red_i[0] / A;
+    d.map_gt[2*u.samp_index+1] = none ? -1 : red_i[0] % A;
   }
 }
 
@@ -134,6 +137,15 @@ hs_genotype_kernel(const hs_gt_dev_t* __restrict__ dp){
 
   const int s = u.samp_index;
   const int ha = d.map_gt[2*s], hb = d.map_gt[2*s+1];
+  if (ha < 0 || hb < 0){      // sample without a MAP diplotype (see hs_posterior_kernel): the reference would index gts (-1,-1); report it
+    if (tid == 0){
+      d.best_gt[2*s] = -1; d.best_gt[2*s+1] = -1;
+      const double nan = __longlong_as_double(0x7ff8000000000000ll);
+      d.hap_log_phased[s] = nan; d.hap_log_unphased[s] = nan; d.log_phased[s] = nan; d.log_unphased[s] = nan;
+      if (d.calc_any) d.gl_diff[s] = nan;
+    }
+    return;
+  }
   const int ga = h2a[ha], gb = h2a[hb];
   if (tid == 0){
     d.best_gt[2*s] = ga; d.best_gt[2*s+1] = gb;

@@ -3,14 +3,19 @@ de novo stutter EM, and (reference window, read) pairs for Needleman-Wunsch."""
 import numpy as np
 
 
-def em_case(seed, n_loci=3, samples=(8, 30), reads_per_sample=(2, 9), haploid_rate=0.25, snp_rate=0.3):
+def em_case(seed, n_loci=3, samples=(8, 30), reads_per_sample=(2, 9), haploid_rate=0.25, snp_rate=0.3, allele_counts=None):
+    """allele_counts: optional per-locus number of true alleles (default: 2..5 drawn per locus)."""
     rng = np.random.default_rng(seed)
     period, n_samples, read_off, lab, bps, p1, p2, hap = [], [], [0], [], [], [], [], []
     for l in range(n_loci):
         p = int(rng.choice([2, 3, 4, 5, 6], p=[.35, .2, .3, .1, .05]))
         S = int(rng.integers(samples[0], samples[1] + 1))
         h = rng.random() < haploid_rate
-        alleles = p * rng.integers(-4, 5, size=int(rng.integers(2, 6)))
+        if allele_counts is None:
+            alleles = p * rng.integers(-4, 5, size=int(rng.integers(2, 6)))
+        else:
+            nal = int(allele_counts[l])
+            alleles = p * rng.permutation(np.arange(-(nal // 2), nal - nal // 2))
         up, down, oof = rng.uniform(0.01, 0.08), rng.uniform(0.02, 0.12), rng.uniform(0.0, 0.02)
         n = 0
         for s in range(S):

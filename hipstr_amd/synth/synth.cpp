@@ -223,15 +223,17 @@ void gen_locus(const Cfg& c, int l, Synth& out){
 
 extern "C" {
 
-void* synth_create(int32_t n_loci, int32_t reads_per_locus, int32_t n_str_alleles, int32_t read_len, int32_t flank_len,
-                   int32_t str_bp, int32_t n_flank_opts, uint64_t seed, double mask_rate){
+// Loci [first_locus, first_locus + n_loci) of the seeded set: a locus depends on (seed, its index) only, so any slice of a
+// large set can be regenerated alone (parity samples of a full-size batch, shards of one set across ranks).
+void* synth_create_at(int32_t first_locus, int32_t n_loci, int32_t reads_per_locus, int32_t n_str_alleles, int32_t read_len, int32_t flank_len,
+                      int32_t str_bp, int32_t n_flank_opts, uint64_t seed, double mask_rate){
   Cfg c; c.n_loci = n_loci; c.reads_per_locus = reads_per_locus; c.n_str_alleles = n_str_alleles; c.read_len = read_len;
   c.flank_len = flank_len; c.str_bp = str_bp; c.n_flank_opts = std::max(1, n_flank_opts); c.seed = seed;
   c.sub_rate = 0.005; c.stutter_rate = 0.05; c.indel_rate = 0.01; c.imperfect_rate = 0.05; c.mask_rate = mask_rate;
   if (const char* e = getenv("HIPSTR_SYNTH_IMPERFECT")) c.imperfect_rate = atof(e);      // experiments: share of alleles with an interrupted repeat
   Synth* s = new Synth();
   s->opt_off.push_back(0); s->hap_off.push_back(0); s->read_off.push_back(0); s->base_off.push_back(0); s->cigar_off.push_back(0);
-  for (int l = 0; l < n_loci; l++) gen_locus(c, l, *s);
+  for (int l = 0; l < n_loci; l++) gen_locus(c, first_locus + l, *s);
   hipstr_batch_t& b = s->b;
   b.n_loci = n_loci;
   b.blk_start = s->blk_start.data(); b.blk_end = s->blk_end.data(); b.blk_nopts = s->blk_nopts.data();
@@ -241,6 +243,11 @@ void* synth_create(int32_t n_loci, int32_t reads_per_locus, int32_t n_str_allele
   b.read_start = s->read_start.data(); b.cigar_off = s->cigar_off.data(); b.cigar_op = s->cigar_op.data();
   b.cigar_len = s->cigar_len.data(); b.realign_read = mask_rate > 0 ? s->realign_read.data() : NULL;
   return s;
+}
+
+void* synth_create(int32_t n_loci, int32_t reads_per_locus, int32_t n_str_alleles, int32_t read_len, int32_t flank_len,
+                   int32_t str_bp, int32_t n_flank_opts, uint64_t seed, double mask_rate){
+  return synth_create_at(0, n_loci, reads_per_locus, n_str_alleles, read_len, flank_len, str_bp, n_flank_opts, seed, mask_rate);
 }
 
 const hipstr_batch_t* synth_batch(void* h){ return &((Synth*)h)->b; }

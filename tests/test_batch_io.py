@@ -52,6 +52,49 @@ def test_damaged_images_are_rejected(hmm_host):
         assert not lib.hipstr_batch_deserialize(bad, len(bad)) and why in lib.hipstr_last_error()
 
 
+def _refresh_checksum(img):
+    h = 1469598103934665603
+    for byte in img[64:]:
+        h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return img[:32] + h.to_bytes(8, "little") + img[40:]
+
+
+def test_forged_images_with_valid_checksum_are_rejected(hmm_host):
+    """The checksum is unkeyed: an image whose arrays contradict each other but whose checksum was recomputed must still be
+    refused before any of its entries is used as an index (sizes come from the section table only)."""
+    lib = _api(hmm_host)
+    sb = capi.SynthBatch(n_loci=2, reads_per_locus=4, n_str_alleles=3, seed=3)
+    n = lib.hipstr_batch_serialized_size(sb.ptr)
+    buf = (C.c_uint8 * n)()
+    assert lib.hipstr_batch_serialize(sb.ptr, buf, n) == 0
+    good = bytes(buf)
+    elem = [4, 4, 4, 4, 8, 4, 1, 4, 1, 4, 4, 1, 1, 4, 4, 1, 4, 1]
+    counts = [int.from_bytes(good[64 + 16 * s + 8:64 + 16 * s + 16], "little") for s in range(18)]
+    start, q = [], 64 + 16 * 18
+    for s in range(18):
+        start.append(q); q += (elem[s] * counts[s] + 7) & ~7
+
+    def poke(sec, index, value):
+        at = start[sec] + 4 * index
+        return _refresh_checksum(good[:at] + int(value).to_bytes(4, "little", signed=True) + good[at + 4:])
+
+    forged = {
+        "huge option count": poke(2, 1, 1 << 28),          # blk_nopts -> would index far past opt_off
+        "zero option count": poke(2, 0, 0),
+        "hap_off end": poke(7, 2, 1 << 20),                # hap_off[n] -> realign_hap size
+        "read_off decreases": poke(9, 1, -5),
+        "read_off end": poke(9, 2, 1 << 20),               # read_off[n] -> would index past base_off
+        "base_off non-monotone": poke(10, 2, 1),
+        "base_off negative start": poke(10, 0, -1),
+        "cigar_off end": poke(14, counts[14] - 1, 7),
+        "opt_off end": poke(5, counts[5] - 1, 1 << 24),
+    }
+    assert lib.hipstr_batch_deserialize(_refresh_checksum(good), n)       # the helper itself produces acceptable images
+    for name, img in forged.items():
+        assert not lib.hipstr_batch_deserialize(img, len(img)), name
+        assert b"do not match" in lib.hipstr_last_error(), name
+
+
 def test_empty_batch(hmm_host):
     lib = _api(hmm_host)
     b = capi.Batch().finalize()

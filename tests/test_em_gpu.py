@@ -41,6 +41,19 @@ def test_config3_shape_against_oracle(hmm, oracle):
     assert got[0].all() and np.all(got[1][:, [0, 3]] <= 0.999) and np.all(got[1] > 0)
 
 
+def test_many_loci_increasing_allele_counts(hmm, oracle):
+    """Every locus of a batch whose allele counts grow from locus to locus, compared with the oracle.  The M-step scratch of a
+    locus (row log-sum-exps) must not overlap its neighbours' whatever their allele counts (one workgroup per locus, all
+    concurrent) — an overlap shows up as run-to-run differences in the allele-frequency priors, so the batch is also run twice."""
+    counts = [2 + (l * 13) // 47 for l in range(48)]
+    kw = em_case(99, n_loci=48, samples=(14, 16), reads_per_sample=(3, 5), allele_counts=counts)
+    got = capi.run_em(hmm, "hipstr_", **kw)
+    again = capi.run_em(hmm, "hipstr_", **kw)
+    assert all(np.array_equal(a, b) for a, b in zip(got, again))
+    want = capi.run_em(oracle, "oracle_", **kw)
+    assert _same(got, want)
+
+
 def test_empty_batch_and_errors(hmm):
     assert all(len(x) == 0 for x in capi.run_em(hmm, "hipstr_", [], [], [0], [], [], [], []))
     with pytest.raises(RuntimeError, match="ascending sample"):

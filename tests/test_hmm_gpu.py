@@ -114,6 +114,36 @@ def test_full_size_properties(hmm, oracle):
         seen[key] = r
 
 
+def test_north_star_batch_full_size(hmm, oracle):
+    """The whole BASELINE configs[1] / north-star batch — 1000 loci x 500 reads x 32 alleles, 15.9 M alignments in one call:
+      * every log-likelihood finite and <= 0 (compute_aln_logprob's assert, HapAligner.cpp:229), every seed as the host computes it;
+      * rows do not depend on batch composition: ten loci spread over the batch, each re-run ALONE, give identical rows;
+      * a strided 1 % sample — locus 7, 107, 207, ... regenerated alone from (seed, index) — agrees with the oracle bit for bit;
+      * running the resident batch a second time reproduces the first result bit for bit."""
+    NL, P, A = 1000, 500, 32
+    big = capi.SynthBatch(n_loci=NL, reads_per_locus=P, n_str_alleles=A, seed=20260928)
+    dev = hmm.hipstr_hmm_upload(big.ptr); assert dev, hmm.hipstr_last_error()
+    runs = []
+    for _ in range(2):
+        assert hmm.hipstr_hmm_align(dev, None) == 0
+        p = np.zeros(big.n_out); s = np.zeros(big.n_reads, np.int32)
+        assert hmm.hipstr_hmm_fetch(dev, p.ctypes.data_as(capi._f64p), s.ctypes.data_as(capi._i32p)) == 0
+        runs.append((p, s))
+    hmm.hipstr_hmm_free(dev)
+    got, seeds = runs[0]
+    assert np.array_equal(got, runs[1][0]) and np.array_equal(seeds, runs[1][1])
+    assert np.all(np.isfinite(got)) and np.all(got <= 1e-10)
+    host_seeds = np.zeros(big.n_reads, np.int32)
+    assert hmm.hipstr_calc_seed_bases(big.ptr, host_seeds.ctypes.data_as(capi._i32p)) == 0 and np.array_equal(seeds, host_seeds)
+    for l in range(7, NL, 100):
+        one = capi.SynthBatch(n_loci=1, reads_per_locus=P, n_str_alleles=A, seed=20260928, first_locus=l)
+        lo, hi = int(big.out_off[l]), int(big.out_off[l + 1])
+        alone, s1 = capi.run_align(hmm, "hipstr_hmm_", one.ptr)
+        assert np.array_equal(alone, got[lo:hi]) and np.array_equal(s1, seeds[l * P:(l + 1) * P]), "locus %d depends on its batch" % l
+        want, ws = capi.run_align(oracle, "oracle_", one.ptr)
+        assert np.array_equal(want, got[lo:hi]) and np.array_equal(ws, s1), "locus %d differs from the oracle" % l
+
+
 def test_dropin_adapter_against_reference_objects(hmm):
     """integration/HapAlignerMI355X — HapAligner's interface on the reference's own Haplotype/Alignment objects — next to
     the reference's CPU HapAligner in one process (oracle/_ref/dropin_check, prebuilt where the HipSTR tree is mounted)."""
