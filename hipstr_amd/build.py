@@ -56,6 +56,8 @@ def build_dropin():
     """integration/HapAlignerMI355X (the reference-side binding) + its equivalence check, only where the HipSTR tree exists."""
     if os.path.isdir("/root/reference/src"):
         _run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "dropin"])
+        # the reference's own SeqStutterGenotyper::genotype() on top of the adapter (integration/genotype_flow.cpp)
+        _run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "flow", "-j8"])
 
 
 def build_all(force=False):

@@ -185,7 +185,7 @@ class HipstrTraceOut(C.Structure):
                 ("cap_chars", C.c_int32)]
 
 
-def run_trace(lib, prefix, bptr, req_read, req_allele, hap_to_ref=None, cap=1 << 16, timing=None, unpack=True):
+def run_trace(lib, prefix, bptr, req_read, req_allele, hap_to_ref=None, cap=1 << 16, timing=None, unpack=True, req_seed=None):
     """Call <prefix>trace on a one-locus batch; returns a list of dicts (one per request) with python-typed fields.
     hap_to_ref: list of bytes (one per allele) or None.  The reference probe (prefix 'ref_') always stitches."""
     n = len(req_read)
@@ -203,18 +203,22 @@ def run_trace(lib, prefix, bptr, req_read, req_allele, hap_to_ref=None, cap=1 <<
         chars(nm)
     o.cap_chars = cap
     rr = np.ascontiguousarray(np.asarray(req_read, np.int32)); aa = np.ascontiguousarray(np.asarray(req_allele, np.int32))
-    fn = getattr(lib, prefix + "trace")
+    fn = getattr(lib, prefix + ("trace" if req_seed is None else "trace_seeded"))
     import time
     t_call = time.perf_counter()
+    extra, extra_t = [], []
+    if req_seed is not None:        # trace_optimal_aln's seed_base argument (HapAligner.h:93)
+        ss = np.ascontiguousarray(np.asarray(req_seed, np.int32)); keep["req_seed"] = ss
+        extra, extra_t = [ss.ctypes.data_as(_i32p)], [_i32p]
     if prefix == "ref_":
-        fn.restype = C.c_int; fn.argtypes = [_BP, C.c_int32, _i32p, _i32p, C.POINTER(HipstrTraceOut)]
-        rc = fn(bptr, n, rr.ctypes.data_as(_i32p), aa.ctypes.data_as(_i32p), C.byref(o))
+        fn.restype = C.c_int; fn.argtypes = [_BP, C.c_int32, _i32p, _i32p] + extra_t + [C.POINTER(HipstrTraceOut)]
+        rc = fn(bptr, n, rr.ctypes.data_as(_i32p), aa.ctypes.data_as(_i32p), *(extra + [C.byref(o)]))
     else:
-        fn.restype = C.c_int; fn.argtypes = [_BP, C.c_int32, _i32p, _i32p, C.POINTER(C.c_char_p), C.POINTER(HipstrTraceOut)]
+        fn.restype = C.c_int; fn.argtypes = [_BP, C.c_int32, _i32p, _i32p] + extra_t + [C.POINTER(C.c_char_p), C.POINTER(HipstrTraceOut)]
         h2r = None
         if hap_to_ref is not None:
             h2r = (C.c_char_p * len(hap_to_ref))(*hap_to_ref)
-        rc = fn(bptr, n, rr.ctypes.data_as(_i32p), aa.ctypes.data_as(_i32p), h2r, C.byref(o))
+        rc = fn(bptr, n, rr.ctypes.data_as(_i32p), aa.ctypes.data_as(_i32p), *(extra + [h2r, C.byref(o)]))
     if timing is not None:
         timing["call_s"] = timing.get("call_s", 0.0) + time.perf_counter() - t_call
     if rc != 0:
@@ -511,6 +515,8 @@ def load_hmm():
     _sig(lib.hipstr_hmm_fetch, C.c_int, [C.c_void_p, _f64p, _i32p])
     _sig(lib.hipstr_hmm_dev_aln_probs, C.c_void_p, [C.c_void_p])
     _sig(lib.hipstr_hmm_process_reads, C.c_int, [_BP, _f64p, _i32p])
+    _sig(lib.hipstr_hmm_process_reads_seeded, C.c_int, [_BP, _i32p, _f64p, _i32p])
+    _sig(lib.hipstr_hmm_upload_seeded, C.c_void_p, [_BP, _i32p])
     _sig(lib.hipstr_calc_seed_bases, C.c_int, [_BP, _i32p])
     _sig(lib.hipstr_post_offsets, C.c_int, [_PBP, C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
     _sig(lib.hipstr_post_run, C.c_int, [_PBP, C.c_void_p, _f64p, _f64p, _i32p, _f64p])
@@ -527,12 +533,21 @@ def load_hmm():
     return lib
 
 
-def run_align(lib, prefix, bptr, fill=np.nan):
+def run_align(lib, prefix, bptr, fill=np.nan, seed_in=None):
     """Call <prefix>process_reads on a batch; returns (aln_probs, seeds) numpy arrays.
-    Entries the callee leaves untouched keep `fill`."""
+    Entries the callee leaves untouched keep `fill`.  seed_in: per-read seed bases chosen by the caller
+    (<prefix>process_reads_seeded = HapAligner::process_read's seed_base argument; -2 = compute)."""
     n_reads, n_out, _ = batch_dims(bptr)
     probs = np.full(max(n_out, 1), fill, dtype=np.float64)
     seeds = np.full(max(n_reads, 1), -7, dtype=np.int32)
+    if seed_in is not None:
+        si = np.ascontiguousarray(np.asarray(seed_in, np.int32))
+        fn = getattr(lib, prefix + "process_reads_seeded")
+        fn.restype = C.c_int; fn.argtypes = [_BP, _i32p, _f64p, _i32p]
+        rc = fn(bptr, si.ctypes.data_as(_i32p), probs.ctypes.data_as(_f64p), seeds.ctypes.data_as(_i32p))
+        if rc != 0:
+            raise RuntimeError("%sprocess_reads_seeded failed rc=%d" % (prefix, rc))
+        return probs[:n_out], seeds[:n_reads]
     rc = getattr(lib, prefix + "process_reads")(bptr, probs.ctypes.data_as(_f64p), seeds.ctypes.data_as(_i32p))
     if rc != 0:
         raise RuntimeError("%sprocess_reads failed rc=%d" % (prefix, rc))

@@ -163,7 +163,9 @@ void hipstr_hmm_free(hipstr_dev_batch_t* dev){
   delete dev;
 }
 
-hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){
+hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){ return hipstr_hmm_upload_seeded(batch, NULL); }
+
+hipstr_dev_batch_t* hipstr_hmm_upload_seeded(const hipstr_batch_t* batch, const int32_t* seed_base){
   if (ensure_init()) return NULL;
   hipstr_dev_batch_t* dev = new hipstr_dev_batch_t();
   std::string err;
@@ -176,7 +178,7 @@ hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){
     if (budget < 1024) budget = 1024;
   }
   const auto t_prep0 = std::chrono::steady_clock::now();
-  if (hipstr::prepare_batch(batch, dev->prep, err, budget)){ g_err = err; delete dev; return NULL; }
+  if (hipstr::prepare_batch(batch, dev->prep, err, budget, seed_base)){ g_err = err; delete dev; return NULL; }
   if (getenv("HIPSTR_TIMING"))
     fprintf(stderr, "hipstr_hmm_upload: prepare_batch %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prep0).count());
   hipstr::Prepared& P = dev->prep;
@@ -377,7 +379,11 @@ int hipstr_hmm_fetch(hipstr_dev_batch_t* dev, double* aln_probs, int32_t* seeds)
 }
 
 int hipstr_hmm_process_reads(const hipstr_batch_t* batch, double* aln_probs, int32_t* seeds){
-  hipstr_dev_batch_t* dev = hipstr_hmm_upload(batch);
+  return hipstr_hmm_process_reads_seeded(batch, NULL, aln_probs, seeds);
+}
+
+int hipstr_hmm_process_reads_seeded(const hipstr_batch_t* batch, const int32_t* seed_base, double* aln_probs, int32_t* seeds){
+  hipstr_dev_batch_t* dev = hipstr_hmm_upload_seeded(batch, seed_base);
   if (!dev) return 1;
   int rc = hipstr_hmm_align(dev, NULL);
   if (!rc) rc = hipstr_hmm_fetch(dev, aln_probs, seeds);

@@ -415,7 +415,7 @@ void fresh_flank_rows(const std::string side_seqs[3], std::vector<hs_row_t>& lea
 void append_stropt(const std::string& blk, int period, const double* stutter, Prepared& out){ emit_stropt(blk, period, stutter, out); }
 void debug_simple_table(int lim, int U0, int tail, double ent[3]){ g_bnd_scale = 1.0; simple_table_entry(lim, U0, tail, ent); }
 
-int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int64_t ws_budget){
+int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int64_t ws_budget, const int32_t* seed_in){
   host_tables();
   g_bnd_scale = getenv("HIPSTR_DEBUG_BND_SCALE") ? atof(getenv("HIPSTR_DEBUG_BND_SCALE")) : 1.0;
   if (b == NULL || b->n_loci < 0){ err = "null or negative-size batch"; return 1; }
@@ -581,8 +581,10 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
       const bool realign = b->realign_read ? b->realign_read[r] != 0 : true;
       out.realign_read[r] = realign ? 1 : 0;
       if (realign){
-        const int s = calc_seed_base(b, l, r);
+        const bool given = seed_in && seed_in[r] != HIPSTR_SEED_AUTO;
+        const int s = given ? seed_in[r] : calc_seed_base(b, l, r);
         if (s == -2){ err = "Invalid alignment seed or unrecognized CIGAR char (HapAligner.cpp:309,316)"; return 1; }
+        if (given && s != -1 && (s < 1 || s > rd.len - 2)){ err = "seed base must leave at least one base on either side (HapAligner.cpp:316)"; return 1; }
         rd.seed = s;
         out.seeds[r] = s;
         if (s >= 0){

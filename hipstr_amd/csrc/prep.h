@@ -63,7 +63,9 @@ struct Prepared {
 };
 
 // Returns 0 on success; otherwise fills err.
-int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int64_t ws_budget_doubles = (int64_t)3 << 30);
+// seed_in: optional [n_reads] seeds chosen by the caller (HapAligner::process_read's seed_base argument, HapAligner.h:83);
+// HIPSTR_SEED_AUTO entries are computed with calc_seed_base.
+int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int64_t ws_budget_doubles = (int64_t)3 << 30, const int32_t* seed_in = NULL);
 
 // HapAligner::calc_seed_base (HapAligner.cpp:238-318).  Returns -2 on the inputs the reference dies on.
 int calc_seed_base(const hipstr_batch_t* b, int locus, int read);

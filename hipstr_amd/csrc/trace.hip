@@ -673,6 +673,11 @@ struct ReqOut {                    // one request's results, built by a worker t
 
 extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const int32_t* req_read, const int32_t* req_allele,
                                 const char* const* hap_to_ref, hipstr_trace_out_t* o){
+  return hipstr_hmm_trace_seeded(b, n_req, req_read, req_allele, NULL, hap_to_ref, o);
+}
+
+extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, const int32_t* req_read, const int32_t* req_allele,
+                                       const int32_t* req_seed, const char* const* hap_to_ref, hipstr_trace_out_t* o){
   using hipstr::api_fail;
   if (!b || !o || n_req < 0 || (n_req > 0 && (!req_read || !req_allele))) return api_fail("null argument");
   if (b->n_loci < 1) return api_fail("hipstr_hmm_trace needs at least one locus");
@@ -712,10 +717,12 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
     const int32_t* nopts = b->blk_nopts + 3*l;
     const int A = nopts[0]*nopts[1]*nopts[2];
     if (k < 0 || k >= A) return api_fail("request names an allele outside its locus");
-    const int s = hipstr::calc_seed_base(b, l, r);
+    const bool given = req_seed && req_seed[q] != HIPSTR_SEED_AUTO;       // trace_optimal_aln's seed_base argument (HapAligner.h:93)
+    const int s = given ? req_seed[q] : hipstr::calc_seed_base(b, l, r);
     if (s == -2) return api_fail("Invalid alignment seed or unrecognized CIGAR char (HapAligner.cpp:309,316)");
     if (s < 0) return api_fail("read without a seed base cannot be traced (HapAligner.cpp:586-594)");
     const int len = b->base_off[r+1] - b->base_off[r];
+    if (given && (s < 1 || s > len - 2)) return api_fail("seed base must leave at least one base on either side (HapAligner.cpp:316)");
     if (s > HS_MAX_SIDE_LEN || len-s-1 > HS_MAX_SIDE_LEN) return api_fail("read side longer than 256 bases is not supported");
     seeds[q] = s; req_locus[q] = l;
     const int64_t key = ((int64_t)l << 32) | (uint32_t)k;

@@ -155,6 +155,14 @@ double* hipstr_hmm_dev_aln_probs(hipstr_dev_batch_t* dev);
  * HapAligner::process_reads (HapAligner.h:86-87). */
 int hipstr_hmm_process_reads(const hipstr_batch_t* batch, double* aln_probs, int32_t* seeds);
 
+/* The same with seeds chosen by the caller: HapAligner::process_read takes the seed base as an argument (HapAligner.h:83,
+ * HapAligner.cpp:573-575) and so does trace_optimal_aln (HapAligner.h:93); process_reads is the one caller that derives it
+ * with calc_seed_base.  seed_base[r] >= 1 is used as given (it must leave a base on either side, HapAligner.cpp:316),
+ * -1 marks a read without a seed (row of zeros), HIPSTR_SEED_AUTO asks for calc_seed_base; seed_base == NULL = all auto. */
+#define HIPSTR_SEED_AUTO (-2)
+hipstr_dev_batch_t* hipstr_hmm_upload_seeded(const hipstr_batch_t* batch, const int32_t* seed_base /* [n_reads] or NULL */);
+int hipstr_hmm_process_reads_seeded(const hipstr_batch_t* batch, const int32_t* seed_base, double* aln_probs, int32_t* seeds);
+
 /* HapAligner::calc_seed_base (HapAligner.cpp:270-318) for every read of a batch,
  * host only (no device needed): seeds[r] = read offset of the seed base or -1.
  * Returns non-zero on the inputs the reference dies on ("Invalid alignment
@@ -341,6 +349,10 @@ typedef struct hipstr_trace_out {
  * the haplotype against the reference haplotype): hap_to_ref[hap_off[locus] + k], [hap_off[n_loci]] pointers. */
 int hipstr_hmm_trace(const hipstr_batch_t* batch, int32_t n_req, const int32_t* req_read, const int32_t* req_allele,
                      const char* const* hap_to_ref, hipstr_trace_out_t* out);
+/* req_seed: the seed_base argument of trace_optimal_aln per request (HapAligner.h:93), or NULL / HIPSTR_SEED_AUTO entries to
+ * have it computed with calc_seed_base as process_reads does. */
+int hipstr_hmm_trace_seeded(const hipstr_batch_t* batch, int32_t n_req, const int32_t* req_read, const int32_t* req_allele,
+                            const int32_t* req_seed, const char* const* hap_to_ref, hipstr_trace_out_t* out);
 
 /* Diagnostics (host only, no device): the haplotype rows of allele k of a ONE-locus batch as the
  * device sweep consumes them — side 0 = forward/left problem, 1 = reversed/right problem; which 0 =

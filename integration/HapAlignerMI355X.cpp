@@ -91,16 +91,46 @@ void HapAlignerMI355X::process_reads(const std::vector<Alignment>& alignments, i
     printErrorAndDie(hipstr_last_error());
 }
 
+void HapAlignerMI355X::process_read(const Alignment& aln, int seed_base, const BaseQuality* base_quality, bool retrace_aln,
+				    double* prob_ptr, AlignmentTrace& traced_aln){
+  assert(seed_base != -1);
+  assert(aln.get_sequence().size() == aln.get_base_qualities().size());
+  (void)base_quality;
+  // the haplotypes the reference's do/while visits (HapAligner.cpp:613-692): from the current one to the last, one if fixed
+  std::vector<int> visited;
+  do { visited.push_back(fw_haplotype_->cur_index()); } while (fw_haplotype_->next());
+  fw_haplotype_->reset();
+  FlatReads r(std::vector<Alignment>(1, aln), std::vector<bool>(1, true));
+  FILL_BATCH(b, r)
+  std::vector<uint8_t> mask(realign_hap_.size(), 0);
+  for (size_t i = 0; i < visited.size(); i++) mask[visited[i]] = realign_hap_[visited[i]];
+  b.realign_hap = mask.data();
+  std::vector<double> row(realign_hap_.size(), 0.0);
+  int32_t seed_in = seed_base, seed_out = -1;
+  if (hipstr_hmm_process_reads_seeded(&b, &seed_in, row.data(), &seed_out) != 0)
+    printErrorAndDie(hipstr_last_error());
+  double max_LL = -100000000;
+  for (size_t i = 0; i < visited.size(); i++, prob_ptr++){
+    const int k = visited[i];
+    if (!mask[k]) continue;
+    *prob_ptr = row[k];
+    if (row[k] > max_LL){
+      max_LL = row[k];
+      if (retrace_aln)      // filled through the same public mutators the reference's retrace uses (HapAligner.cpp:642-684)
+	run_traces(std::vector<Alignment>(1, aln), std::vector<int>(1, seed_base), std::vector<int>(1, k), std::vector<AlignmentTrace*>(1, &traced_aln));
+    }
+  }
+}
+
 AlignmentTrace* HapAlignerMI355X::trace_optimal_aln(const Alignment& orig_aln, int seed_base, int best_haplotype, const BaseQuality* base_quality){
-  (void)seed_base;        // recomputed by the library; the reference passes calc_seed_base's value back in (seq_stutter_genotyper.cpp:831)
   std::vector<AlignmentTrace*> traces;
-  trace_optimal_alns(std::vector<Alignment>(1, orig_aln), std::vector<int>(1, best_haplotype), base_quality, traces);
+  trace_optimal_alns(std::vector<Alignment>(1, orig_aln), std::vector<int>(1, seed_base), std::vector<int>(1, best_haplotype), base_quality, traces);
   return traces[0];
 }
 
-void HapAlignerMI355X::trace_optimal_alns(const std::vector<Alignment>& alignments, const std::vector<int>& best_haplotypes,
+void HapAlignerMI355X::trace_optimal_alns(const std::vector<Alignment>& alignments, const std::vector<int>& seed_bases, const std::vector<int>& best_haplotypes,
 					  const BaseQuality* base_quality, std::vector<AlignmentTrace*>& traces){
-  assert(alignments.size() == best_haplotypes.size());
+  assert(alignments.size() == best_haplotypes.size() && (seed_bases.empty() || seed_bases.size() == alignments.size()));
   (void)base_quality;
   traces.clear();
   // A haplotype the aligner was told not to realign to is skipped by process_read (HapAligner.cpp:614-618), which leaves the
@@ -109,16 +139,26 @@ void HapAlignerMI355X::trace_optimal_alns(const std::vector<Alignment>& alignmen
     bool any_masked = false;
     for (size_t i = 0; i < best_haplotypes.size(); i++) any_masked |= !realign_to_hap_[best_haplotypes[i]];
     if (any_masked){
-      std::vector<Alignment> sub_alns; std::vector<int> sub_haps;
+      std::vector<Alignment> sub_alns; std::vector<int> sub_haps, sub_seeds;
       for (size_t i = 0; i < alignments.size(); i++)
-        if (realign_to_hap_[best_haplotypes[i]]){ sub_alns.push_back(alignments[i]); sub_haps.push_back(best_haplotypes[i]); }
+        if (realign_to_hap_[best_haplotypes[i]]){
+	  sub_alns.push_back(alignments[i]); sub_haps.push_back(best_haplotypes[i]);
+	  if (!seed_bases.empty()) sub_seeds.push_back(seed_bases[i]);
+	}
       std::vector<AlignmentTrace*> sub;
-      trace_optimal_alns(sub_alns, sub_haps, base_quality, sub);
+      trace_optimal_alns(sub_alns, sub_seeds, sub_haps, base_quality, sub);
       for (size_t i = 0, k = 0; i < alignments.size(); i++)
         traces.push_back(realign_to_hap_[best_haplotypes[i]] ? sub[k++] : new AlignmentTrace(fw_haplotype_->num_blocks()));
       return;
     }
   }
+  for (size_t i = 0; i < alignments.size(); i++) traces.push_back(new AlignmentTrace(fw_haplotype_->num_blocks()));
+  run_traces(alignments, seed_bases, best_haplotypes, traces);
+}
+
+// One hipstr_hmm_trace_seeded call for all requests; targets[i] receives request i.
+void HapAlignerMI355X::run_traces(const std::vector<Alignment>& alignments, const std::vector<int>& seed_bases, const std::vector<int>& best_haplotypes,
+				  const std::vector<AlignmentTrace*>& targets){
   const int n = (int)alignments.size();
   if (n == 0) return;
   FlatReads r(alignments, std::vector<bool>(alignments.size(), true));
@@ -132,9 +172,12 @@ void HapAlignerMI355X::trace_optimal_alns(const std::vector<Alignment>& alignmen
   std::vector<const char*> hap_to_ref;
   for (size_t k = 0; k < aln_info.size(); k++) hap_to_ref.push_back(aln_info[k].c_str());
 
-  std::vector<int32_t> req_read(n), req_allele(best_haplotypes.begin(), best_haplotypes.end());
+  std::vector<int32_t> req_read(n), req_allele(best_haplotypes.begin(), best_haplotypes.end()), req_seed(n, HIPSTR_SEED_AUTO);
   size_t chars = 64;
-  for (int i = 0; i < n; i++){ req_read[i] = i; chars += 2*alignments[i].get_sequence().size() + 2*aln_info[best_haplotypes[i]].size() + 64; }
+  for (int i = 0; i < n; i++){
+    req_read[i] = i; chars += 2*alignments[i].get_sequence().size() + 2*aln_info[best_haplotypes[i]].size() + 64;
+    if (!seed_bases.empty()) req_seed[i] = seed_bases[i];           // the caller's seed_base (HapAligner.h:93), not a recomputed one
+  }
   const int32_t cap = (int32_t)chars;
   std::vector<double> ll(n);
   std::vector<int32_t> max_index(n), hap_aln_off(n+1), stutter_size(n), str_seq_off(n+1), flank_seq_off(2*n+1), flank_ins(n), flank_del(n),
@@ -148,32 +191,29 @@ void HapAlignerMI355X::trace_optimal_alns(const std::vector<Alignment>& alignmen
   o.snp_off = snp_off.data(); o.snp_pos = snp_pos.data(); o.snp_base = snp_base.data();
   o.aln_start = aln_start.data(); o.aln_stop = aln_stop.data(); o.cigar_off = cigar_off.data(); o.cigar_op = cigar_op.data(); o.cigar_len = cigar_len.data();
   o.aln_str_off = aln_str_off.data(); o.aln_str = aln_str.data(); o.cap_chars = cap;
-  if (hipstr_hmm_trace(&b, n, req_read.data(), req_allele.data(), hap_to_ref.data(), &o) != 0)
+  if (hipstr_hmm_trace_seeded(&b, n, req_read.data(), req_allele.data(), req_seed.data(), hap_to_ref.data(), &o) != 0)
     printErrorAndDie(hipstr_last_error());
+  for (int i = 0; i < n; i++) fill_trace(i, &o, alignments[i], *targets[i]);
+}
 
-  // the same AlignmentTrace the reference's process_read fills (HapAligner.cpp:642-707), through its public mutators
-  for (int i = 0; i < n; i++){
-    AlignmentTrace* t = new AlignmentTrace(fw_haplotype_->num_blocks());
-    std::string s(hap_aln.data() + hap_aln_off[i], hap_aln_off[i+1] - hap_aln_off[i]);
-    t->set_hap_aln(s);
-    if (stutter_size[i] != HIPSTR_NO_STR_DATA){
-      std::string ss(str_seq.data() + str_seq_off[i], str_seq_off[i+1] - str_seq_off[i]);
-      t->add_str_data(1, stutter_size[i], ss);
-    }
-    for (int side = 0; side < 2; side++){
-      std::string fs(flank_seq.data() + flank_seq_off[2*i+side], flank_seq_off[2*i+side+1] - flank_seq_off[2*i+side]);
-      t->add_flank_data(side == 0 ? 0 : 2, fs);
-    }
-    for (int k = 0; k < flank_ins[i]; k++) t->inc_flank_ins();
-    for (int k = 0; k < flank_del[i]; k++) t->inc_flank_del();
-    for (int k = indel_off[i]; k < indel_off[i+1]; k++) t->add_flank_indel(std::pair<int32_t,int32_t>(indel_pos[k], indel_size[k]));
-    for (int k = snp_off[i]; k < snp_off[i+1]; k++) t->add_flank_snp(snp_pos[k], snp_base[k]);
-    const Alignment& orig = alignments[i];
-    t->traced_aln() = Alignment(aln_start[i], aln_stop[i], false, "TRACE", orig.get_base_qualities(), orig.get_sequence(),
-				std::string(aln_str.data() + aln_str_off[i], aln_str_off[i+1] - aln_str_off[i]));
-    std::vector<CigarElement> cigar_list;
-    for (int k = cigar_off[i]; k < cigar_off[i+1]; k++) cigar_list.push_back(CigarElement(cigar_op[k], cigar_len[k]));
-    t->traced_aln().set_cigar_list(cigar_list);
-    traces.push_back(t);
+void HapAlignerMI355X::fill_trace(int i, const hipstr_trace_out_t* o, const Alignment& orig, AlignmentTrace& t) const {
+  std::string s(o->hap_aln + o->hap_aln_off[i], o->hap_aln_off[i+1] - o->hap_aln_off[i]);
+  t.set_hap_aln(s);
+  if (o->stutter_size[i] != HIPSTR_NO_STR_DATA){
+    std::string ss(o->str_seq + o->str_seq_off[i], o->str_seq_off[i+1] - o->str_seq_off[i]);
+    t.add_str_data(1, o->stutter_size[i], ss);
   }
+  for (int side = 0; side < 2; side++){
+    std::string fs(o->flank_seq + o->flank_seq_off[2*i+side], o->flank_seq_off[2*i+side+1] - o->flank_seq_off[2*i+side]);
+    t.add_flank_data(side == 0 ? 0 : 2, fs);
+  }
+  for (int k = 0; k < o->flank_ins[i]; k++) t.inc_flank_ins();
+  for (int k = 0; k < o->flank_del[i]; k++) t.inc_flank_del();
+  for (int k = o->indel_off[i]; k < o->indel_off[i+1]; k++) t.add_flank_indel(std::pair<int32_t,int32_t>(o->indel_pos[k], o->indel_size[k]));
+  for (int k = o->snp_off[i]; k < o->snp_off[i+1]; k++) t.add_flank_snp(o->snp_pos[k], o->snp_base[k]);
+  t.traced_aln() = Alignment(o->aln_start[i], o->aln_stop[i], false, "TRACE", orig.get_base_qualities(), orig.get_sequence(),
+			      std::string(o->aln_str + o->aln_str_off[i], o->aln_str_off[i+1] - o->aln_str_off[i]));
+  std::vector<CigarElement> cigar_list;
+  for (int k = o->cigar_off[i]; k < o->cigar_off[i+1]; k++) cigar_list.push_back(CigarElement(o->cigar_op[k], o->cigar_len[k]));
+  t.traced_aln().set_cigar_list(cigar_list);
 }

@@ -1,9 +1,17 @@
 // HapAlignerMI355X.h — the reference-side binding a HipSTR maintainer adds to src/SeqAlignment/.
 //
 // A class with HapAligner's public interface (HapAligner.h:56-93) written against the REFERENCE's
-// own types (Haplotype, HapBlock, RepeatBlock, Alignment, BaseQuality, AlignmentTrace), so that
-// seq_stutter_genotyper.cpp keeps compiling unchanged apart from the type name at its three
-// construction sites (seq_stutter_genotyper.cpp:522, :814, :1076) — see INTEGRATION.md.
+// own types (Haplotype, HapBlock, RepeatBlock, Alignment, BaseQuality, AlignmentTrace).
+//
+// Two ways in:
+//   * ONE include switch, no source edit: compile seq_stutter_genotyper.cpp with
+//         -include SeqAlignment/HapAlignerMI355X.h -DHIPSTR_MI355X_AS_HAPALIGNER
+//     This header pulls in the reference's HapAligner.h first (so the CPU class keeps its name and
+//     its include guard is spent) and then renames every later mention of `HapAligner` to this class:
+//     the three construction sites (seq_stutter_genotyper.cpp:522, :814, :1076) compile unedited.
+//     oracle/Makefile target `flow` does exactly that and runs the reference's own
+//     SeqStutterGenotyper::genotype() on the MI355X (integration/genotype_flow.cpp).
+//   * or name the class explicitly at those three sites.
 //
 //   process_reads / calc_seed_base  ->  libhipstr_hmm.so  (include/hipstr_hmm.h, MI355X kernels)
 //   trace_optimal_aln               ->  hipstr_hmm_trace (one request), same AlignmentTrace the reference builds
@@ -45,16 +53,37 @@ class HapAlignerMI355X {
 
   int calc_seed_base(const Alignment& alignment);
 
+  // HapAligner::process_read (HapAligner.h:83, HapAligner.cpp:573-709): one read against every haplotype from the
+  // haplotype's CURRENT position to the last one (a fixed haplotype: just that one), with the seed the caller names.
+  // *prob_ptr advances one entry per haplotype visited; entries of haplotypes that are not realigned are left untouched.
+  // With retrace_aln, every haplotype that improves on the best likelihood so far is traced into traced_aln, as the
+  // reference does (its only caller with retrace_aln = true, trace_optimal_aln, fixes the haplotype first).
+  void process_read(const Alignment& aln, int seed_base, const BaseQuality* base_quality, bool retrace_aln,
+		    double* prob_ptr, AlignmentTrace& traced_aln);
+
   void process_reads(const std::vector<Alignment>& alignments, int init_read_index, const BaseQuality* base_quality,
 		     const std::vector<bool>& realign_read, double* aln_probs, int* seed_positions);
 
   // HapAligner::trace_optimal_aln (HapAligner.h:88-92).  The caller owns the returned object, as with the reference.
   AlignmentTrace* trace_optimal_aln(const Alignment& orig_aln, int seed_base, int best_haplotype, const BaseQuality* base_quality);
 
-  // Batched form: request i traces alignments[i] against haplotype best_haplotypes[i]; traces[i] is a new AlignmentTrace.
-  // The seed of every read is recomputed on the way (calc_seed_base is a pure function of the read and the haplotype).
-  void trace_optimal_alns(const std::vector<Alignment>& alignments, const std::vector<int>& best_haplotypes,
+  // Batched form: request i traces alignments[i], split at seed_bases[i], against haplotype best_haplotypes[i];
+  // traces[i] is a new AlignmentTrace.  seed_bases may be empty: calc_seed_base's value is used then.
+  void trace_optimal_alns(const std::vector<Alignment>& alignments, const std::vector<int>& seed_bases, const std::vector<int>& best_haplotypes,
 			  const BaseQuality* base_quality, std::vector<AlignmentTrace*>& traces);
+  void trace_optimal_alns(const std::vector<Alignment>& alignments, const std::vector<int>& best_haplotypes,
+			  const BaseQuality* base_quality, std::vector<AlignmentTrace*>& traces){
+    trace_optimal_alns(alignments, std::vector<int>(), best_haplotypes, base_quality, traces);
+  }
+
+ private:
+  void run_traces(const std::vector<Alignment>& alignments, const std::vector<int>& seed_bases, const std::vector<int>& best_haplotypes,
+		  const std::vector<AlignmentTrace*>& targets);
+  void fill_trace(int i, const struct hipstr_trace_out* o, const Alignment& orig, AlignmentTrace& t) const;
 };
+
+#ifdef HIPSTR_MI355X_AS_HAPALIGNER
+#define HapAligner HapAlignerMI355X
+#endif
 
 #endif

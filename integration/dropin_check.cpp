@@ -70,6 +70,33 @@ int main(int argc, char** argv){
       if (memcmp(&want[i], &got[i], 8) != 0){ n_bad++; if (fabs(want[i]-got[i]) > max_diff) max_diff = fabs(want[i]-got[i]); }
     }
     if (!alns.empty() && wseed[0] >= 0 && gpu.calc_seed_base(alns[0]) != cpu.calc_seed_base(alns[0])) n_bad++;
+    // process_read (HapAligner.h:83) with seeds of the CALLER's choosing: calc_seed_base's value and values off it
+    for (size_t i = 0; i < alns.size() && i < 6; i++){
+      if (wseed[i] < 0) continue;
+      const int len = (int)alns[i].get_sequence().size();
+      const int shifts[3] = { 0, -7, 11 };
+      for (int sh = 0; sh < 3; sh++){
+        int seed = wseed[i] + shifts[sh];
+        if (seed < 1) seed = 1;
+        if (seed > len - 2) seed = len - 2;
+        std::vector<double> wrow(A, -4.5), grow(A, -4.5);
+        AlignmentTrace wt(hap.num_blocks()), gt(hap.num_blocks());
+        cpu.process_read(alns[i], seed, &bq, false, wrow.data(), wt);
+        gpu.process_read(alns[i], seed, &bq, false, grow.data(), gt);
+        for (int k = 0; k < A; k++){ n_cmp++; if (memcmp(&wrow[k], &grow[k], 8) != 0){ n_bad++; if (n_bad <= 3) fprintf(stderr, "process_read mismatch locus %d read %zu seed %d hap %d: %.17g vs %.17g\n", l, i, seed, k, wrow[k], grow[k]); } }
+        // and the traceback from that seed (trace_optimal_aln's seed_base argument, HapAligner.h:93)
+        const int best = (int)((i + sh) % A);
+        AlignmentTrace* w = cpu.trace_optimal_aln(alns[i], seed, best, &bq);
+        AlignmentTrace* g = gpu.trace_optimal_aln(alns[i], seed, best, &bq);
+        n_trace++;
+        if (w->hap_aln() != g->hap_aln() || w->traced_aln().getCigarString() != g->traced_aln().getCigarString() || w->traced_aln().get_start() != g->traced_aln().get_start()
+            || w->flank_seq(0) != g->flank_seq(0) || w->flank_seq(2) != g->flank_seq(2) || w->has_stutter() != g->has_stutter()){
+          n_bad++;
+          if (n_bad <= 3) fprintf(stderr, "seeded trace mismatch locus %d read %zu seed %d hap %d\n  want %s\n  got  %s\n", l, i, seed, best, w->hap_aln().c_str(), g->hap_aln().c_str());
+        }
+        delete w; delete g;
+      }
+    }
     // Viterbi traceback: the reference's trace_optimal_aln per read vs one batched call on the MI355X
     {
       std::vector<Alignment> t_alns; std::vector<int> t_haps;

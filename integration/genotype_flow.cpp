@@ -1,0 +1,231 @@
+// genotype_flow.cpp — the reference's OWN caller of the hot path, unedited, end to end:
+//
+//   SeqStutterGenotyper::SeqStutterGenotyper  -> init (ReadPooler, mates; seq_stutter_genotyper.cpp:490-511) + build_haplotype (:422-488)
+//   SeqStutterGenotyper::genotype             -> calc_hap_aln_probs + calc_log_sample_posteriors                       (:603-640)
+//                                                id_and_align_to_stutter_alleles: retrace, new alleles, align ONLY them  (:570-601, :324-415)
+//                                                get_unused_alleles / remove_alleles, twice                            (:229-315, :417-420)
+//                                                assemble_flanks: flank variants, realign a subset of pools/reads       (:40-217)
+//   [--recompute] recompute_stutter_models    -> EMStutterGenotyper::train on the traced stutter sizes, then genotype() again (:1542-)
+//
+// on seeded synthetic reads of one STR locus, then a dump of everything the rounds produced.  This file is compiled TWICE by
+// `make -C oracle flow`, from the same source:
+//   oracle/_ref/libflow_ref.so     — against the reference's translation units only (CPU HapAligner, CPU Genotyper);
+//   oracle/_ref/libflow_mi355x.so  — seq_stutter_genotyper.cpp compiled, unedited, with
+//                              `-include SeqAlignment/HapAlignerMI355X.h -DHIPSTR_MI355X_AS_HAPALIGNER`, genotyper.cpp with the body of
+//                              calc_log_sample_posteriors replaced by integration/genotyper_posteriors_mi355x.inc, linked with
+//                              libhipstr_hmm.so: every HMM alignment, traceback and posterior of the flow runs on the MI355X.
+// tests/test_genotype_flow.py requires the two dumps to agree (log-likelihoods bit for bit, posteriors to 1e-9).
+//
+// The parts of SeqStutterGenotyper that need htslib (write_vcf_record, VCF input) are never called; their symbols stay unresolved
+// in both libraries (libflow_ref.so / libflow_mi355x.so, loaded with lazy binding by integration/flow_launcher.c), exactly like
+// FastaReader in oracle/_ref/libhipstr_ref.so.  TEST INFRASTRUCTURE, not product.
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <set>
+#include <sstream>
+#include <string>
+#include <vector>
+
+// read the genotyper's private state after genotype(); access specifiers do not change the layout (test-only TU)
+#define private public
+#define protected public
+#include "seq_stutter_genotyper.h"
+#undef private
+#undef protected
+#include "SeqAlignment/AlignmentModel.h"
+#include "mathops.h"
+#include "null_ostream.h"
+
+namespace {
+
+struct Rng {
+  uint64_t s;
+  explicit Rng(uint64_t seed) : s(seed*0x9E3779B97F4A7C15ull + 0x1234567ull) {}
+  uint64_t next(){ s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+  double uni(){ return (next() >> 11) * (1.0/9007199254740992.0); }
+  int below(int n){ return (int)(next() % (uint64_t)n); }
+  int range(int lo, int hi){ return lo + below(hi - lo + 1); }
+  char base(){ return "ACGT"[next() & 3]; }
+  char other(char c){ char b; do { b = base(); } while (b == c); return b; }
+};
+
+struct SimRead { std::string name; int sample; int strand; };
+
+// one read of `hap` (a haplotype = left context + STR allele + right context laid over the chromosome), left-aligned against the
+// reference: the repeat-count difference becomes one I or D at the start of the repeat, substitutions become X
+Alignment make_read(Rng& rng, const std::string& chrom, int str_start, int str_len, const std::string& motif, int copies, int snp_pos, char snp_base,
+                    int read_start, int read_len, const std::string& name){
+  const int p = (int)motif.size();
+  std::string allele; for (int i = 0; i < copies; i++) allele += motif;
+  const int delta = (int)allele.size() - str_len;
+  // haplotype sequence and, per haplotype base, its reference coordinate (-1 = inserted)
+  std::string hap = chrom.substr(0, str_start) + allele + chrom.substr(str_start + str_len);
+  if (snp_pos >= 0) hap[snp_pos < str_start ? snp_pos : snp_pos + delta] = snp_base;
+  std::vector<int> coord(hap.size());
+  for (int i = 0; i < str_start; i++) coord[i] = i;
+  if (delta >= 0){
+    for (int i = 0; i < delta; i++) coord[str_start + i] = -1;                         // insertion right at the start of the repeat
+    for (size_t i = str_start + delta; i < hap.size(); i++) coord[i] = (int)i - delta;
+  } else
+    for (size_t i = str_start; i < hap.size(); i++) coord[i] = (int)i - delta;         // deletion of -delta reference bases at the start
+  std::string seq, aln, qual;
+  std::vector<CigarElement> cigar;
+  auto push = [&](char op, int n){
+    if (!cigar.empty() && cigar.back().get_type() == op) cigar.back().set_num(cigar.back().get_num() + n);
+    else cigar.push_back(CigarElement(op, n));
+  };
+  int32_t start = -1, last = -1;
+  for (int i = read_start; i < read_start + read_len && i < (int)hap.size(); i++){
+    char b = hap[i];
+    if (rng.uni() < 0.004) b = rng.other(b);
+    const int c = coord[i];
+    if (c < 0){ if (start < 0) continue; push('I', 1); }
+    else {
+      if (start < 0) start = c;
+      if (last >= 0 && c > last + 1){ push('D', c - last - 1); aln += std::string(c - last - 1, '-'); }
+      push(b == chrom[c] ? '=' : 'X', 1);
+      last = c;
+    }
+    seq += b; aln += b;
+    const double u = rng.uni();
+    qual += u < 0.02 ? '#' : u < 0.10 ? ',' : u < 0.30 ? ':' : 'F';
+  }
+  Alignment a(start, last + 1, rng.uni() < 0.5, name, qual, seq, aln);
+  a.set_cigar_list(cigar);
+  a.set_hap_gen_info(std::vector<bool>(1, true));
+  (void)p;
+  return a;
+}
+
+void dump_doubles(FILE* f, const char* key, const double* v, size_t n, bool hex){
+  fprintf(f, "%s %zu", key, n);
+  for (size_t i = 0; i < n; i++){
+    if (hex){ uint64_t u; memcpy(&u, &v[i], 8); fprintf(f, " %016llx", (unsigned long long)u); }
+    else fprintf(f, " %.17g", v[i]);
+  }
+  fprintf(f, "\n");
+}
+
+}  // namespace
+
+extern "C" int flow_main(int argc, char** argv){
+  uint64_t seed = 1; int n_samples = 10, reads_per_sample = 9, period = 4; bool recompute = false, reassemble = true; const char* out_path = NULL;
+  for (int i = 1; i < argc; i++){
+    if (!strcmp(argv[i], "--seed")) seed = strtoull(argv[++i], NULL, 10);
+    else if (!strcmp(argv[i], "--samples")) n_samples = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--reads")) reads_per_sample = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--period")) period = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--recompute")) recompute = true;
+    else if (!strcmp(argv[i], "--no-flanks")) reassemble = false;
+    else if (!strcmp(argv[i], "--out")) out_path = argv[++i];
+    else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
+  }
+  precompute_integer_logs();                 // hipstr_main.cpp:352
+  Rng rng(seed);
+
+  // ---- a chromosome with one pure repeat, flanks that do not continue it
+  std::string motif;
+  do { motif.clear(); for (int i = 0; i < period; i++) motif += rng.base(); }
+  while (period > 1 && motif == std::string(period, motif[0]));
+  const int c0 = std::max(3, 40/period), str_start = 600, str_len = c0*period;
+  std::string chrom;
+  for (int i = 0; i < 1400; i++) chrom += rng.base();
+  for (int i = 0; i < str_len; i++) chrom[str_start + i] = motif[i % period];
+  if (chrom[str_start - 1] == motif[period - 1]) chrom[str_start - 1] = rng.other(motif[period - 1]);
+  if (chrom[str_start + str_len] == motif[0]) chrom[str_start + str_len] = rng.other(motif[0]);
+  const int snp_pos = str_start - 18; const char snp_base = rng.other(chrom[snp_pos]);      // a flank variant some haplotypes carry
+
+  // ---- samples, genotypes, reads (grouped by sample; mates share a name and follow each other, seq_stutter_genotyper.cpp:499)
+  std::vector<std::string> sample_names;
+  std::vector<Alignment> alns;
+  std::vector< std::vector<double> > log_p1(n_samples), log_p2(n_samples);
+  const int deltas[5] = { 0, -1, 1, 2, -2 };
+  for (int s = 0; s < n_samples; s++){
+    std::stringstream nm; nm << "S" << s; sample_names.push_back(nm.str());
+    int cp[2], snp[2];
+    for (int h = 0; h < 2; h++){ cp[h] = c0 + deltas[rng.below(rng.uni() < 0.7 ? 3 : 5)]; snp[h] = (s % 2 == 0 && h == 1) ? 1 : 0; }
+    const int n_reads = reads_per_sample + rng.range(-2, 2);
+    for (int r = 0; r < n_reads; r++){
+      const int h = rng.below(2);
+      int copies = cp[h];
+      const double u = rng.uni();
+      if (u < 0.06) copies += 1; else if (u < 0.14) copies -= 1;                           // PCR stutter
+      if (copies < 1) copies = 1;
+      const bool spanning = rng.uni() < 0.8;
+      // starts and lengths from a coarse grid, so that identical reads occur and ReadPooler has pools to form (read_pooler.cpp:3-20)
+      const int read_len = 100 + 5*rng.range(0, 5);
+      const int read_start = spanning ? str_start - 22 - 6*rng.range(0, 6) : (rng.uni() < 0.5 ? str_start - rng.range(70, 95) : str_start + rng.range(4, 20));
+      std::stringstream rn; rn << "r" << s << "_" << r;
+      const bool paired = rng.uni() < 0.2;
+      for (int mate = 0; mate < (paired ? 2 : 1); mate++){
+        const int st = mate == 0 ? read_start : str_start - rng.range(25, 55);
+        alns.push_back(make_read(rng, chrom, str_start, str_len, motif, copies, snp[h] ? snp_pos : -1, snp_base, st, mate == 0 ? read_len : rng.range(100, 120), rn.str()));
+        if (rng.uni() < 0.35){ const double good = -rng.uni()*0.05, bad = -2 - rng.uni()*6; log_p1[s].push_back(h == 0 ? good : bad); log_p2[s].push_back(h == 0 ? bad : good); }
+        else { log_p1[s].push_back(0.0); log_p2[s].push_back(0.0); }
+      }
+    }
+  }
+
+  Region region("chr1", str_start, str_start + str_len, period, "LOCUS");
+  RegionGroup group(region);
+  StutterModel model(0.9, 0.05, 0.05, 0.7, 0.005, 0.005, period);
+  std::vector<StutterModel*> models(1, &model);
+  std::stringstream log;
+  SeqStutterGenotyper g(group, false, reassemble, alns, log_p1, log_p2, sample_names, chrom, models, NULL, log);
+  const bool ok = g.genotype(1000, 4, 0.15, log);
+  bool ok2 = true;
+  if (ok && recompute) ok2 = g.recompute_stutter_models(log, 1000, 4, 0.15, 100, 0.01, 0.001);
+
+  FILE* f = out_path ? fopen(out_path, "w") : stdout;
+  if (!f){ perror(out_path); return 2; }
+  fprintf(f, "genotype_ok %d\nrecompute_ok %d\n", ok ? 1 : 0, ok2 ? 1 : 0);
+  fprintf(f, "num_reads %u\nnum_samples %d\nnum_pools %d\n", g.num_reads_, g.num_samples_, g.pooler_.num_pools());
+  if (ok){
+    fprintf(f, "num_alleles %d\n", g.num_alleles_);
+    for (int b = 0; b < g.haplotype_->num_blocks(); b++){
+      HapBlock* blk = g.haplotype_->get_block(b);
+      fprintf(f, "block %d %d %d %d", b, blk->start(), blk->end(), blk->num_options());
+      for (int o = 0; o < blk->num_options(); o++) fprintf(f, " %s", blk->get_seq(o).c_str());
+      fprintf(f, "\n");
+    }
+    fprintf(f, "pool_index %u", g.num_reads_); for (unsigned i = 0; i < g.num_reads_; i++) fprintf(f, " %d", g.pool_index_[i]); fprintf(f, "\n");
+    fprintf(f, "second_mate %u", g.num_reads_); for (unsigned i = 0; i < g.num_reads_; i++) fprintf(f, " %d", g.second_mate_[i] ? 1 : 0); fprintf(f, "\n");
+    fprintf(f, "seed_positions %u", g.num_reads_); for (unsigned i = 0; i < g.num_reads_; i++) fprintf(f, " %d", g.seed_positions_[i]); fprintf(f, "\n");
+    std::vector<Alignment>& pooled = g.pooler_.get_alignments();
+    for (size_t i = 0; i < pooled.size(); i++) fprintf(f, "pool_qual %zu %s\n", i, pooled[i].get_base_qualities().c_str());
+    dump_doubles(f, "log_aln_probs", g.log_aln_probs_, (size_t)g.num_reads_*g.num_alleles_, true);
+    dump_doubles(f, "log_sample_posteriors", g.log_sample_posteriors_, (size_t)g.num_samples_*g.num_alleles_*g.num_alleles_, false);
+    dump_doubles(f, "sample_total_LLs", g.sample_total_LLs_, (size_t)g.num_samples_, false);
+    std::vector< std::pair<int,int> > gts;
+    g.get_optimal_haplotypes(gts);
+    fprintf(f, "map_haplotypes %zu", gts.size()); for (size_t i = 0; i < gts.size(); i++) fprintf(f, " %d|%d", gts[i].first, gts[i].second); fprintf(f, "\n");
+    // the tracebacks the last round left in the cache: (pool, haplotype) -> alignment
+    for (std::map<std::pair<int,int>, AlignmentTrace*>::iterator it = g.trace_cache_.begin(); it != g.trace_cache_.end(); ++it){
+      AlignmentTrace* t = it->second;
+      fprintf(f, "trace %d %d %s %d %s %d %d %s\n", it->first.first, it->first.second, t->hap_aln().c_str(),
+              t->str_data_[1] != NULL ? t->stutter_size(1) : -100000, t->traced_aln().getCigarString().c_str(), t->traced_aln().get_start(), t->traced_aln().get_stop(),
+              t->str_data_[1] != NULL ? t->str_seq(1).c_str() : "-");
+    }
+    if (recompute && ok2){
+      StutterModel* m = g.hap_blocks_[1]->get_repeat_info()->get_stutter_model();
+      double sp[6] = { m->get_parameter(true, 'P'), m->get_parameter(true, 'U'), m->get_parameter(true, 'D'), m->get_parameter(false, 'P'), m->get_parameter(false, 'U'), m->get_parameter(false, 'D') };
+      dump_doubles(f, "stutter_model", sp, 6, false);
+    }
+  }
+  // what the rounds did, from the genotyper's own log (counts only: "Recomputing sample posteriors after removing N ...")
+  {
+    std::string line; std::istringstream in(log.str()); int n = 0;
+    while (std::getline(in, line))
+      if (line.find("Recomputing") != std::string::npos || line.find("Identified") != std::string::npos || line.find("Aborting") != std::string::npos || line.find("candidate") != std::string::npos)
+        fprintf(f, "log %d %s\n", n++, line.c_str());
+  }
+  if (out_path) fclose(f);
+  return ok ? 0 : 1;
+}

@@ -607,7 +607,14 @@ int oracle_allele_options(const int32_t* nopts, int k, int32_t* opts){
 }
 
 /* ---------------------------------------------- process_reads (A.1) */
-int oracle_process_reads(const hipstr_batch_t* b, double* aln_probs, int32_t* seeds){
+static int process_reads_impl(const hipstr_batch_t* b, const int32_t* seed_in, double* aln_probs, int32_t* seeds);
+int oracle_process_reads(const hipstr_batch_t* b, double* aln_probs, int32_t* seeds){ return process_reads_impl(b, NULL, aln_probs, seeds); }
+/* HapAligner::process_read with the caller's seed_base (HapAligner.h:83, HapAligner.cpp:573-709): seed_in[r] >= 0 replaces
+ * calc_seed_base for read r; HIPSTR_SEED_AUTO (-2) computes it. */
+int oracle_process_reads_seeded(const hipstr_batch_t* b, const int32_t* seed_in, double* aln_probs, int32_t* seeds){
+  return process_reads_impl(b, seed_in, aln_probs, seeds);
+}
+static int process_reads_impl(const hipstr_batch_t* b, const int32_t* seed_in, double* aln_probs, int32_t* seeds){
   oracle_init();
   int opt_cursor = 0;
   int64_t out_off = 0;
@@ -633,8 +640,8 @@ int oracle_process_reads(const hipstr_batch_t* b, double* aln_probs, int32_t* se
     for (int r = b->read_off[l]; r < b->read_off[l+1]; r++){
       double* out = aln_probs + out_off + (int64_t)(r-b->read_off[l])*A;
       if (b->realign_read && !b->realign_read[r]) continue;
-      int sb = seed_base(b, l, r);
-      if (sb == -2){ free(pmf); side_free(&fw); side_free(&rv); return 1; }
+      int sb = (seed_in && seed_in[r] != -2) ? seed_in[r] : seed_base(b, l, r);
+      if (sb == -2 || (seed_in && seed_in[r] != -2 && sb != -1 && (sb < 1 || sb > b->base_off[r+1]-b->base_off[r]-2))){ free(pmf); side_free(&fw); side_free(&rv); return 1; }
       seeds[r] = sb;
       if (sb == -1){ for (int k = 0; k < A; k++) out[k] = 0; continue; }     /* HapAligner.cpp:333-337 */
       int len = b->base_off[r+1]-b->base_off[r];
@@ -1222,8 +1229,15 @@ static int put_pool(char* pool, int32_t* off, int idx, const char* s, int n, int
   memcpy(pool + off[idx], s, n); off[idx+1] = off[idx] + n; return 0;
 }
 
+int oracle_trace_seeded(const hipstr_batch_t* b, int32_t n_req, const int32_t* req_read, const int32_t* req_allele,
+                        const int32_t* req_seed, const char* const* hap_to_ref, hipstr_trace_out_t* o);
 int oracle_trace(const hipstr_batch_t* b, int32_t n_req, const int32_t* req_read, const int32_t* req_allele,
                  const char* const* hap_to_ref, hipstr_trace_out_t* o){
+  return oracle_trace_seeded(b, n_req, req_read, req_allele, NULL, hap_to_ref, o);
+}
+/* trace_optimal_aln with the caller's seed_base (HapAligner.h:93); NULL / -2 entries: calc_seed_base */
+int oracle_trace_seeded(const hipstr_batch_t* b, int32_t n_req, const int32_t* req_read, const int32_t* req_allele,
+                        const int32_t* req_seed, const char* const* hap_to_ref, hipstr_trace_out_t* o){
   oracle_init();
   if (b->n_loci != 1) return 1;
   int period = b->period[0];
@@ -1244,7 +1258,7 @@ int oracle_trace(const hipstr_batch_t* b, int32_t n_req, const int32_t* req_read
   o->cigar_off[0] = o->aln_str_off[0] = 0;
   for (int q = 0; q < n_req && rc == 0; q++){
     int r = req_read[q];
-    int sb = seed_base(b, 0, r);
+    int sb = (req_seed && req_seed[q] != -2) ? req_seed[q] : seed_base(b, 0, r);
     if (sb < 0){ rc = 2; break; }
     iter_reset(&it);
     while (it.counter < req_allele[q]) if (!iter_next(&it)){ rc = 4; break; }

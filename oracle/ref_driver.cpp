@@ -128,6 +128,35 @@ int ref_process_reads(const hipstr_batch_t* b, double* aln_probs, int32_t* seeds
   return 0;
 }
 
+/* HapAligner::process_read (HapAligner.h:83) per read with the seed the caller names: seed_in[r] >= 0 is passed as seed_base,
+ * -1 gives the row of zeros process_reads writes for such reads, HIPSTR_SEED_AUTO calls calc_seed_base first. */
+int ref_process_reads_seeded(const hipstr_batch_t* b, const int32_t* seed_in, double* aln_probs, int32_t* seeds){
+  ensure_ready();
+  BaseQuality bq;
+  int opt_cursor = 0;
+  int64_t out_off = 0;
+  for (int l = 0; l < b->n_loci; l++){
+    RefLocus loc;
+    build_locus(b, l, opt_cursor, loc);
+    int A = loc.hap->num_combs();
+    std::vector<bool> realign_hap(A, true);
+    if (b->realign_hap) for (int k = 0; k < A; k++) realign_hap[k] = b->realign_hap[b->hap_off[l]+k] != 0;
+    HapAligner aligner(loc.hap, realign_hap);
+    for (int r = b->read_off[l]; r < b->read_off[l+1]; r++){
+      double* row = aln_probs + out_off + (int64_t)(r - b->read_off[l])*A;
+      if (b->realign_read && !b->realign_read[r]) continue;
+      Alignment aln = make_alignment(b, r);
+      int seed = (seed_in && seed_in[r] != HIPSTR_SEED_AUTO) ? seed_in[r] : aligner.calc_seed_base(aln);
+      seeds[r] = seed;
+      if (seed == -1){ for (int k = 0; k < A; k++) row[k] = 0; continue; }
+      AlignmentTrace trace(loc.hap->num_blocks());
+      aligner.process_read(aln, seed, &bq, false, row, trace);
+    }
+    out_off += (int64_t)(b->read_off[l+1] - b->read_off[l])*A;
+  }
+  return 0;
+}
+
 /* Haplotype sequence of allele k of locus l in Haplotype::next() order, NUL terminated (for pinning the Gray code). */
 int ref_hap_sequences(const hipstr_batch_t* b, int l_want, char* out, int out_cap, int32_t* lens){
   ensure_ready();
@@ -357,8 +386,15 @@ bool put_str(char* pool, int32_t* off, int idx, const std::string& s, int cap){
 }
 }
 
+extern "C" int ref_trace_seeded(const hipstr_batch_t* b, int32_t n_req, const int32_t* req_read, const int32_t* req_allele,
+                                const int32_t* req_seed, hipstr_trace_out_t* o);
 extern "C" int ref_trace(const hipstr_batch_t* b, int32_t n_req, const int32_t* req_read, const int32_t* req_allele,
                          hipstr_trace_out_t* o){
+  return ref_trace_seeded(b, n_req, req_read, req_allele, NULL, o);
+}
+/* req_seed: trace_optimal_aln's seed_base argument (HapAligner.h:93); NULL / HIPSTR_SEED_AUTO entries use calc_seed_base */
+extern "C" int ref_trace_seeded(const hipstr_batch_t* b, int32_t n_req, const int32_t* req_read, const int32_t* req_allele,
+                                const int32_t* req_seed, hipstr_trace_out_t* o){
   ensure_ready();
   if (b->n_loci != 1) return 1;
   BaseQuality bq;
@@ -372,7 +408,7 @@ extern "C" int ref_trace(const hipstr_batch_t* b, int32_t n_req, const int32_t* 
   o->cigar_off[0] = o->aln_str_off[0] = 0;
   for (int q = 0; q < n_req; q++){
     Alignment aln = make_alignment(b, req_read[q]);
-    int seed = aligner.calc_seed_base(aln);
+    int seed = (req_seed && req_seed[q] != HIPSTR_SEED_AUTO) ? req_seed[q] : aligner.calc_seed_base(aln);
     if (seed < 0) return 2;
     AlignmentTrace* tr = aligner.trace_optimal_aln(aln, seed, req_allele[q], &bq);
     {   /* the score of the same alignment: haplotypes positioned as trace_optimal_aln does (HapAligner.cpp:711-722) */

@@ -17,8 +17,48 @@ from util import batch_to_dict   # noqa: E402
 SENTINEL = -12345.678
 
 
+def seeded(ref):
+    """process_read / trace_optimal_aln with seeds the CALLER chooses (HapAligner.h:83, :93) instead of calc_seed_base's."""
+    import json
+    from hipstr_amd import shard
+    rng = np.random.default_rng(20260930)
+    sb = capi.SynthBatch(n_loci=3, reads_per_locus=30, n_str_alleles=6, n_flank_opts=2, seed=5, mask_rate=0.1)
+    from util import synth_to_batch
+    b = synth_to_batch(sb)
+    _, auto = capi.run_align(ref, "ref_", b.ptr, fill=SENTINEL)
+    lens = np.diff(b.arrays["base_off"])
+    seed_in = np.full(len(auto), -2, np.int32)
+    for r in range(len(auto)):
+        if auto[r] >= 0 and r % 3 != 2:            # two reads in three get a seed of the caller's: anywhere that leaves a base either side
+            seed_in[r] = int(rng.integers(1, lens[r] - 1)) if r % 3 == 0 else int(np.clip(auto[r] + rng.integers(-9, 10), 1, lens[r] - 2))
+        elif auto[r] == -7 or r % 11 == 5:
+            seed_in[r] = -1 if r % 11 == 5 else -2
+    probs, seeds = capi.run_align(ref, "ref_", b.ptr, fill=SENTINEL, seed_in=seed_in)
+    d = batch_to_dict(b)
+    d["seed_in"] = seed_in; d["expect_aln_probs"] = probs; d["expect_seeds"] = seeds; d["sentinel"] = np.array([SENTINEL])
+    # tracebacks of locus 0 with the same seeds
+    a = b.arrays
+    one = shard.batch_from_arrays(shard.subset_arrays(a, 0, 1))
+    A = int(a["hap_off"][1]); n0 = int(a["read_off"][1])
+    rr = [r for r in range(n0) if seeds[r] >= 0 and (a["realign_read"] is None or a["realign_read"][r])][:16]
+    aa = [int(rng.integers(A)) for _ in rr]
+    exp = capi.run_trace(ref, "ref_", one.ptr, rr, aa, cap=1 << 20, req_seed=[int(seeds[r]) for r in rr])
+    d["trace_read"] = np.array(rr, np.int32); d["trace_allele"] = np.array(aa, np.int32)
+    d["trace_h2r"] = np.frombuffer(b"\n".join(capi.ref_hap_aln_info(ref, one.ptr, A)), dtype=np.uint8).copy()
+    d["trace_expect"] = np.frombuffer(json.dumps(exp).encode(), dtype=np.uint8).copy()
+    np.savez_compressed(os.path.join(HERE, "seeded_align_trace.npz"), **d)
+    print("seeded: reads", len(seeds), "caller seeds", int((seed_in >= 0).sum()), "changed rows vs auto", int((seeds != auto).sum()), "traces", len(rr))
+
+
+SECTIONS = {"seeded": seeded}
+
+
 def main():
     ref = capi.load_ref()
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":       # python make_golden.py --only seeded [...]: just the named sections
+        for name in sys.argv[2:]:
+            SECTIONS[name](ref)
+        return
     for name, make in CASES.items():
         b = make()
         probs, seeds = capi.run_align(ref, "ref_", b.ptr, fill=SENTINEL)
@@ -155,6 +195,8 @@ def main():
     vals["log_thresh"] = np.array([ref.ref_log_thresh()]); vals["log_half"] = np.array([ref.ref_log_one_half()])
     np.savez_compressed(os.path.join(HERE, "scalars.npz"), **vals)
     print("scalars written")
+    for fn in SECTIONS.values():
+        fn(ref)
 
 
 if __name__ == "__main__":

@@ -176,21 +176,41 @@ def load_gt_fixture(path):
     return pb, d["n_variants"], d["hap_to_allele"], exp
 
 
+FLOAT_STEP = 3e-6
+
+
 def assert_genotypes_close(got, want, tol, what=""):
-    """tol = 0 demands identical bits.  PLs are truncated integers of -10*(GL - maxGL): with tol > 0 a PL may differ by one
-    only where that product sits within 1e-6 of an integer."""
+    """tol = 0 demands identical bits.  With tol > 0 (device exp/log in the exact log-sum-exps: posteriors carry ~1e-13 of
+    rounding noise):
+      * values are compared with |d| <= tol * max(1, |x|);
+      * the values that pass through the reference's FLOAT pair log-sum-exp (fast_log_sum_exp(a, b), mathops.cpp:86-95:
+        hap_log_unphased_post, every GL, hence GLDIFF) may in addition sit one float rounding step away: that function casts the
+        difference of its arguments to float and runs bit-trick exp/log on it, so noise of 1e-13 in an argument flips the
+        float rounding with probability ~1e-4 and moves the result by up to 2^-17 ln 2 / 2 = 2.7e-6 nats.  Such steps must be
+        <= FLOAT_STEP and rare (< 1 % of the compared values);
+      * PLs are truncated integers of -10*(GL - maxGL): a PL may differ by one only where that product sits within
+        10*FLOAT_STEP of an integer."""
     assert np.array_equal(got["best_hap"], want["best_hap"]), what
     assert np.array_equal(got["best_gt"], want["best_gt"]), what
-    def close(a, b):
+    steps = [0, 0]          # float steps seen, values compared
+    def close(a, b, float_lse=False, nstep=1):
         a = np.asarray(a, float); b = np.asarray(b, float)
         if tol == 0:
             return np.array_equal(a, b)
         fin = np.isfinite(b)
-        return np.array_equal(np.isfinite(a), fin) and np.all(np.abs(a[fin] - b[fin]) <= tol * np.maximum(1, np.abs(b[fin])))
-    for k in ("log_phased_post", "log_unphased_post", "hap_log_phased_post", "hap_log_unphased_post", "gl_diff"):
+        if not np.array_equal(np.isfinite(a), fin):
+            return False
+        d = np.abs(a[fin] - b[fin]); ok = d <= tol * np.maximum(1, np.abs(b[fin]))
+        if float_lse:
+            steps[0] += int((~ok).sum()); steps[1] += int(ok.size)
+            ok = ok | (d <= nstep * FLOAT_STEP)
+        return bool(np.all(ok))
+    for k in ("log_phased_post", "log_unphased_post", "hap_log_phased_post"):
         assert close(got[k], want[k]), "%s %s" % (what, k)
+    assert close(got["hap_log_unphased_post"], want["hap_log_unphased_post"], True), "%s hap_log_unphased_post" % what
+    assert close(got["gl_diff"], want["gl_diff"], True, 2), "%s gl_diff" % what          # a difference of two GLs
     for s in range(len(want["gls"])):
-        assert close(got["gls"][s], want["gls"][s]), "%s gls of sample %d" % (what, s)
+        assert close(got["gls"][s], want["gls"][s], True), "%s gls of sample %d" % (what, s)
         assert close(got["phased_gls"][s], want["phased_gls"][s]), "%s phased gls of sample %d" % (what, s)
         gp, wp = np.asarray(got["pls"][s]), np.asarray(want["pls"][s])
         if tol == 0:
@@ -198,4 +218,5 @@ def assert_genotypes_close(got, want, tol, what=""):
         else:
             bad = np.nonzero(gp != wp)[0]
             g = np.asarray(want["gls"][s]); x = -10 * (g - g.max())
-            assert np.all(np.abs(gp[bad] - wp[bad]) <= 1) and np.all(np.abs(x[bad] - np.round(x[bad])) < 1e-6), "%s pls of sample %d" % (what, s)
+            assert np.all(np.abs(gp[bad] - wp[bad]) <= 1) and np.all(np.abs(x[bad] - np.round(x[bad])) < 10 * FLOAT_STEP), "%s pls of sample %d" % (what, s)
+    assert steps[0] <= max(1, 0.01 * steps[1]), "%s: %d of %d values a float step away from the reference" % (what, steps[0], steps[1])
