@@ -35,6 +35,7 @@
 #include "SeqAlignment/Haplotype.h"
 #include "SeqAlignment/RepeatBlock.h"
 #include "base_quality.h"
+#include "read_pooler.h"
 #include "genotyper.h"
 #include "em_stutter_genotyper.h"
 #include "mathops.h"
@@ -474,5 +475,64 @@ extern "C" int ref_hap_aln_info(const hipstr_batch_t* b, char* out, int out_cap,
     pos += s.size() + 1;
   } while (loc.hap->next());
   offs[k] = pos;
+  return 0;
+}
+
+/* ---- ReadPooler (read_pooler.h:13-53, read_pooler.cpp:3-20) and the pool -> read scatter + mate sums of
+ * SeqStutterGenotyper::calc_hap_aln_probs (seq_stutter_genotyper.cpp:519-568).  The pooler and the aligner are the reference's
+ * classes; the scatter / mate loops are a private member of SeqStutterGenotyper and are restated here line for line
+ * (:531-543 and :551-564) — the whole member function is pinned through integration/genotype_flow.cpp as well. ---- */
+extern "C" int ref_pool(const hipstr_batch_t* b, int32_t* pool_index, int32_t* n_pools, char* pool_quals, int32_t* pool_qual_off, int32_t cap){
+  ensure_ready();
+  if (b->n_loci != 1) return 1;
+  BaseQuality bq;
+  ReadPooler pooler;
+  for (int r = 0; r < b->read_off[1]; r++){ Alignment a = make_alignment(b, r); pool_index[r] = pooler.add_alignment(a); }
+  pooler.pool(bq);
+  *n_pools = pooler.num_pools();
+  std::vector<Alignment>& pooled = pooler.get_alignments();
+  pool_qual_off[0] = 0;
+  for (size_t i = 0; i < pooled.size(); i++)
+    if (!put_str(pool_quals, pool_qual_off, (int)i, pooled[i].get_base_qualities(), cap)) return 3;
+  return 0;
+}
+
+extern "C" int ref_pool_scatter(const hipstr_batch_t* b, const uint8_t* second_mate, const uint8_t* realign_pool, const uint8_t* copy_read,
+                                double* log_aln_probs, int32_t* seed_positions){
+  ensure_ready();
+  if (b->n_loci != 1) return 1;
+  BaseQuality bq;
+  int opt_cursor = 0;
+  RefLocus loc;
+  build_locus(b, 0, opt_cursor, loc);
+  const int num_alleles = loc.hap->num_combs(), num_reads = b->read_off[1];
+  std::vector<bool> realign_to_haplotype(num_alleles, true);
+  if (b->realign_hap) for (int k = 0; k < num_alleles; k++) realign_to_haplotype[k] = b->realign_hap[k] != 0;
+  ReadPooler pooler;
+  std::vector<int> pool_index(num_reads);
+  for (int r = 0; r < num_reads; r++){ Alignment a = make_alignment(b, r); pool_index[r] = pooler.add_alignment(a); }
+  pooler.pool(bq);
+  std::vector<bool> realign(pooler.num_pools(), true);
+  if (realign_pool) for (int i = 0; i < pooler.num_pools(); i++) realign[i] = realign_pool[i] != 0;
+  HapAligner hap_aligner(loc.hap, realign_to_haplotype);                                  /* :522 */
+  std::vector<Alignment>& pooled_alns = pooler.get_alignments();
+  std::vector<double> log_pool_aln_probs(pooled_alns.size()*(size_t)num_alleles);
+  std::vector<int> pool_seed_positions(pooled_alns.size());
+  hap_aligner.process_reads(pooled_alns, 0, &bq, realign, log_pool_aln_probs.data(), pool_seed_positions.data());   /* :528 */
+  double* log_aln_ptr = log_aln_probs;                                                    /* :531-543 */
+  for (int i = 0; i < num_reads; i++){
+    if (copy_read && !copy_read[i]){ log_aln_ptr += num_alleles; continue; }
+    seed_positions[i] = pool_seed_positions[pool_index[i]];
+    double* src_ptr = log_pool_aln_probs.data() + (size_t)num_alleles*pool_index[i];
+    for (int j = 0; j < num_alleles; ++j, ++log_aln_ptr, ++src_ptr)
+      if (realign_to_haplotype[j]) *log_aln_ptr = *src_ptr;
+  }
+  for (int i = 0; i < num_reads; ++i){                                                    /* :551-564 */
+    if (!second_mate[i] || (copy_read && !copy_read[i])) continue;
+    double* mate_one_ptr = log_aln_probs + (size_t)(i-1)*num_alleles;
+    double* mate_two_ptr = log_aln_probs + (size_t)i*num_alleles;
+    for (int j = 0; j < num_alleles; ++j, ++mate_one_ptr, ++mate_two_ptr)
+      if (realign_to_haplotype[j]){ double total = *mate_one_ptr + *mate_two_ptr; *mate_one_ptr = total; *mate_two_ptr = total; }
+  }
   return 0;
 }

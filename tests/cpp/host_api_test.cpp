@@ -38,7 +38,66 @@ class ProbeGenotyper : public Genotyper {   // the reference's derived genotyper
   }
 };
 
+// --pool / --scatter <batch file> <side file>: ReadPooler and calc_hap_aln_probs of hipstr_hmm.hpp on a case stored by
+// tests/golden/make_golden.py::pool_scatter (the batch in the library's flat format, masks and the pre-filled matrix as text);
+// prints pool indices, pooled qualities and — with --scatter, on the device — the matrix and seeds after the call.
+static int pool_scatter_mode(bool scatter, const char* batch_path, const char* side_path){
+  hipstr_batch_file_t* bf = hipstr_batch_read(batch_path);
+  if (!bf){ fprintf(stderr, "%s\n", hipstr_last_error()); return 1; }
+  const hipstr_batch_t* b = hipstr_batch_file_batch(bf);
+  StutterModel model(b->stutter[0], b->stutter[1], b->stutter[2], b->stutter[3], b->stutter[4], b->stutter[5], b->period[0]);
+  std::vector<HapBlock*> blocks;
+  int opt = 0;
+  for (int k = 0; k < 3; k++){
+    std::vector<std::string> seqs;
+    for (int o = 0; o < b->blk_nopts[k]; o++, opt++) seqs.push_back(std::string(b->seq + b->opt_off[opt], b->opt_off[opt+1] - b->opt_off[opt]));
+    HapBlock* hb = k == 1 ? new RepeatBlock(b->blk_start[k], b->blk_end[k], seqs[0], b->period[0], &model) : new HapBlock(b->blk_start[k], b->blk_end[k], seqs[0]);
+    for (size_t o = 1; o < seqs.size(); o++) hb->add_alternate(seqs[o]);
+    blocks.push_back(hb);
+  }
+  Haplotype hap(blocks);
+  const int R = b->read_off[1], A = hap.num_combs();
+  BaseQuality bq;
+  ReadPooler pooler;
+  std::vector<int> pool_index(R);
+  for (int r = 0; r < R; r++){
+    const int len = b->base_off[r+1] - b->base_off[r];
+    Alignment a(b->read_start[r], 0, false, "R", std::string(b->quals + b->base_off[r], len), std::string(b->bases + b->base_off[r], len), "");
+    for (int c = b->cigar_off[r]; c < b->cigar_off[r+1]; c++) a.add_cigar_element(CigarElement(b->cigar_op[c], b->cigar_len[c]));
+    pool_index[r] = pooler.add_alignment(a);          // seq_stutter_genotyper.cpp:498
+  }
+  pooler.pool(bq);                                    // :633
+  printf("n_pools %d\npool_index", pooler.num_pools());
+  for (int r = 0; r < R; r++) printf(" %d", pool_index[r]);
+  printf("\n");
+  for (size_t i = 0; i < pooler.get_alignments().size(); i++) printf("pool_qual %s\n", pooler.get_alignments()[i].get_base_qualities().c_str());
+  if (scatter){
+    std::vector<bool> second_mate, realign_pool, copy_read, realign_hap(A, true);
+    std::vector<double> ll;
+    FILE* f = fopen(side_path, "r");
+    if (!f){ perror(side_path); return 1; }
+    char key[64]; int n;
+    while (fscanf(f, "%63s %d", key, &n) == 2){
+      for (int i = 0; i < n; i++){
+        if (!strcmp(key, "prefill")){ unsigned long long u; if (fscanf(f, "%llx", &u) != 1) return 1; double v; memcpy(&v, &u, 8); ll.push_back(v); }
+        else { int x; if (fscanf(f, "%d", &x) != 1) return 1; (!strcmp(key, "second_mate") ? second_mate : !strcmp(key, "realign_pool") ? realign_pool : copy_read).push_back(x != 0); }
+      }
+    }
+    fclose(f);
+    if (b->realign_hap) for (int k = 0; k < A; k++) realign_hap[k] = b->realign_hap[k] != 0;
+    std::vector<int> seeds(R, -9);
+    std::vector<char> mate_flags(second_mate.begin(), second_mate.end());
+    calc_hap_aln_probs(&hap, pooler, bq, pool_index.data(), (const bool*)mate_flags.data(), (unsigned)R, realign_hap, realign_pool, copy_read, ll.data(), seeds.data());
+    printf("seeds"); for (int r = 0; r < R; r++) printf(" %d", seeds[r]); printf("\n");
+    printf("ll"); for (size_t i = 0; i < ll.size(); i++){ unsigned long long u; memcpy(&u, &ll[i], 8); printf(" %016llx", u); } printf("\n");
+  }
+  for (size_t k = 0; k < blocks.size(); k++) delete blocks[k];
+  hipstr_batch_file_free(bf);
+  return 0;
+}
+
 int main(int argc, char** argv){
+  if (argc > 3 && (!strcmp(argv[1], "--pool") || !strcmp(argv[1], "--scatter"))) return pool_scatter_mode(!strcmp(argv[1], "--scatter"), argv[2], argv[3]);
   const bool gpu = argc > 1 && strcmp(argv[1], "--gpu") == 0;
   const std::string lf = "ACGTTGCATGCATGACCTGAGTCCATGACTTGACA", rf = "TTGACCGTAGGCTAGGCTTAACGGATCCGATTAGC";
   std::string gata10, gata11, gata12, gata9;

@@ -50,7 +50,69 @@ def seeded(ref):
     print("seeded: reads", len(seeds), "caller seeds", int((seed_in >= 0).sum()), "changed rows vs auto", int((seeds != auto).sum()), "traces", len(rr))
 
 
-SECTIONS = {"seeded": seeded}
+def _unpooled_case(seed, n_reads, n_str, n_flank, hap_mask_rate):
+    """One locus whose reads repeat (same sequence, other qualities) and come partly in mate pairs: what SeqStutterGenotyper::init
+    sees before pooling (seq_stutter_genotyper.cpp:490-511)."""
+    from util import synth_to_batch
+    rng = np.random.default_rng(seed)
+    a = synth_to_batch(capi.SynthBatch(n_loci=1, reads_per_locus=n_reads, n_str_alleles=n_str, n_flank_opts=n_flank, seed=seed)).arrays
+    nopt = a["blk_nopts"]; seqs = [bytes(a["seq"][a["opt_off"][i]:a["opt_off"][i + 1]]).decode() for i in range(int(nopt.sum()))]
+    blocks, c = [], 0
+    for k in range(3):
+        blocks.append((int(a["blk_start"][k]), int(a["blk_end"][k]), seqs[c:c + nopt[k]])); c += nopt[k]
+    reads, second_mate = [], []
+    for r in range(n_reads):
+        lo, hi = int(a["base_off"][r]), int(a["base_off"][r + 1])
+        rd = dict(seq=bytes(a["bases"][lo:hi]).decode(), qual=bytes(a["quals"][lo:hi]).decode(), start=int(a["read_start"][r]),
+                  cigar=[(chr(a["cigar_op"][i]), int(a["cigar_len"][i])) for i in range(a["cigar_off"][r], a["cigar_off"][r + 1])])
+        copies = 1 + (rng.random() < 0.4) + (rng.random() < 0.15)
+        for c in range(copies):                      # the same read seen again with other base qualities: one pool, median qualities
+            q = rd["qual"] if c == 0 else "".join(rng.choice(list("#,:FI5"), p=[.05, .1, .2, .45, .1, .1]) for _ in rd["qual"])
+            reads.append(dict(rd, qual=q)); second_mate.append(0)
+    order = rng.permutation(len(reads)); reads = [reads[i] for i in order]
+    for i in range(1, len(reads)):                   # mates follow each other and share a name (:499): mark some pairs
+        if not second_mate[i - 1] and rng.random() < 0.2:
+            second_mate[i] = 1
+    A = int(np.prod(nopt))
+    mask = [1] + [int(rng.random() >= hap_mask_rate) for _ in range(A - 1)] if hap_mask_rate > 0 else None
+    b = capi.Batch(); b.add_locus(blocks, int(a["period"][0]), list(a["stutter"][:6]), reads, realign_hap=mask); b.finalize()
+    return b, np.array(second_mate, np.uint8), A
+
+
+def pool_scatter(ref):
+    """ReadPooler (read_pooler.cpp:3-20, read_pooler.h:42-48) and SeqStutterGenotyper::calc_hap_aln_probs' scatter + mate sums
+    (seq_stutter_genotyper.cpp:519-568) on the reference's classes: first round (everything realigned) and a later round (some
+    haplotypes kept, some pools and reads skipped, old values in the matrix)."""
+    import ctypes as C
+    u8p = capi._u8p
+    ref.ref_pool.restype = C.c_int; ref.ref_pool.argtypes = [capi._BP, capi._i32p, capi._i32p, C.c_char_p, capi._i32p, C.c_int32]
+    ref.ref_pool_scatter.restype = C.c_int; ref.ref_pool_scatter.argtypes = [capi._BP, u8p, u8p, u8p, capi._f64p, capi._i32p]
+    for name, (seed, n_reads, n_str, n_flank, hmask, partial) in dict(first_round=(11, 30, 5, 1, 0.0, False), later_round=(12, 36, 6, 2, 0.45, True),
+                                                                       multiflank_all=(13, 24, 4, 2, 0.0, False)).items():
+        rng = np.random.default_rng(seed)
+        b, mates, A = _unpooled_case(seed, n_reads, n_str, n_flank, hmask)
+        R = int(b.arrays["read_off"][1])
+        pool_index = np.zeros(R, np.int32); n_pools = np.zeros(1, np.int32); cap = 1 << 20
+        pq = C.create_string_buffer(cap); pqo = np.zeros(R + 1, np.int32)
+        assert ref.ref_pool(b.ptr, pool_index.ctypes.data_as(capi._i32p), n_pools.ctypes.data_as(capi._i32p), pq, pqo.ctypes.data_as(capi._i32p), cap) == 0
+        P = int(n_pools[0])
+        realign_pool = (rng.random(P) > 0.3).astype(np.uint8) if partial else np.ones(P, np.uint8)
+        copy_read = (rng.random(R) > 0.2).astype(np.uint8) if partial else np.ones(R, np.uint8)
+        if partial:
+            realign_pool[pool_index[copy_read == 1]] = 1       # the caller never copies from a pool it did not realign (:95-121 of assemble_flanks)
+        ll = -rng.random(R * A) * 50 - 1; seeds = np.full(R, -9, np.int32)
+        before = ll.copy()
+        assert ref.ref_pool_scatter(b.ptr, mates.ctypes.data_as(u8p), realign_pool.ctypes.data_as(u8p), copy_read.ctypes.data_as(u8p),
+                                    ll.ctypes.data_as(capi._f64p), seeds.ctypes.data_as(capi._i32p)) == 0
+        d = batch_to_dict(b)
+        d.update(second_mate=mates, realign_pool=realign_pool, copy_read=copy_read, prefill=before, expect_pool_index=pool_index,
+                 expect_n_pools=n_pools, expect_pool_quals=np.frombuffer(pq.raw[:pqo[P]], np.uint8).copy(), expect_pool_qual_off=pqo[:P + 1],
+                 expect_log_aln_probs=ll, expect_seeds=seeds)
+        np.savez_compressed(os.path.join(HERE, "pool_scatter_%s.npz" % name), **d)
+        print("pool_scatter", name, "reads", R, "pools", P, "mates", int(mates.sum()), "alleles", A, "untouched", int((ll == before).sum()), "of", ll.size)
+
+
+SECTIONS = {"seeded": seeded, "pool_scatter": pool_scatter}
 
 
 def main():

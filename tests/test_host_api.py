@@ -84,3 +84,50 @@ def test_device_parts(_native_built):
     row = kv["em"][0]
     assert int(row[0]) == int(tr[0]) and int(row[1]) == int(it[0])
     assert all(abs(float(a) - b) < 1e-9 for a, b in zip(row[2:8], st[0])) and abs(float(row[8]) - ll[0]) < 1e-9 * max(1, abs(ll[0]))
+
+
+# ---- ReadPooler / calc_hap_aln_probs of hipstr_hmm.hpp against the reference's classes (tests/golden/pool_scatter_*.npz)
+import glob
+import numpy as np
+
+POOL = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "pool_scatter_*.npz")))
+
+
+def _pool_case(path, tmp_path, scatter):
+    import ctypes as C
+    from hipstr_amd import capi
+    import util
+    d = np.load(path)
+    b = util.batch_from_dict(d)
+    lib = capi.load_hmm()
+    lib.hipstr_batch_write.restype = C.c_int; lib.hipstr_batch_write.argtypes = [C.c_char_p, capi._BP]
+    bpath = str(tmp_path / "case.hsb"); spath = str(tmp_path / "side.txt")
+    assert lib.hipstr_batch_write(bpath.encode(), b.ptr) == 0
+    with open(spath, "w") as f:
+        for k in ("second_mate", "realign_pool", "copy_read"):
+            f.write("%s %d %s\n" % (k, len(d[k]), " ".join(str(int(x)) for x in d[k])))
+        f.write("prefill %d %s\n" % (len(d["prefill"]), " ".join("%016x" % x for x in d["prefill"].view(np.uint64))))
+    kv = _run("--scatter" if scatter else "--pool", bpath, spath)
+    assert int(kv["n_pools"][0][0]) == int(d["expect_n_pools"][0])
+    assert [int(x) for x in kv["pool_index"][0]] == d["expect_pool_index"].tolist()
+    off = d["expect_pool_qual_off"]; q = bytes(d["expect_pool_quals"])
+    assert [r[0] for r in kv["pool_qual"]] == [q[off[i]:off[i + 1]].decode() for i in range(len(off) - 1)]
+    return d, kv
+
+
+@pytest.mark.parametrize("path", POOL, ids=[os.path.basename(p)[13:-4] for p in POOL])
+def test_read_pooler_matches_reference(_native_built, tmp_path, path):
+    """Pool index of every read and the per-position upper-median qualities of every pool (read_pooler.cpp:3-20, base_quality.cpp:11-28)."""
+    assert len(POOL) >= 3
+    _pool_case(path, tmp_path, scatter=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", POOL, ids=[os.path.basename(p)[13:-4] for p in POOL])
+def test_calc_hap_aln_probs_matches_reference(_native_built, tmp_path, path):
+    """The read-level matrix after the scatter and mate sums, bit for bit, incl. entries that must stay untouched
+    (masked haplotypes, copy_read false) and seeds (seq_stutter_genotyper.cpp:519-568)."""
+    d, kv = _pool_case(path, tmp_path, scatter=True)
+    assert [int(x) for x in kv["seeds"][0]] == d["expect_seeds"].tolist()
+    got = np.array([int(x, 16) for x in kv["ll"][0]], np.uint64)
+    assert np.array_equal(got, d["expect_log_aln_probs"].view(np.uint64))
