@@ -12,8 +12,10 @@
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/hipstr_hmm.h"
@@ -41,61 +43,155 @@ int fail(const std::string& m){ g_err = m; return 1; }
 #define HS_HIP_NULL(call) do { hipError_t e_ = (call); if (e_ != hipSuccess){ \
   g_err = std::string(#call) + ": " + hipGetErrorString(e_); return NULL; } } while (0)
 
-struct DevTables {
-  bool ready = false;
-  int device = -1;
-  double *int_log = NULL, *qc = NULL, *qe = NULL, *m2m = NULL, *m2i = NULL;
-  hipStream_t stream = NULL;
-} g_tab;
-
-template <typename T> int to_device(const std::vector<T>& v, T** out){
-  *out = NULL;
-  const size_t bytes = (v.size() ? v.size() : 1) * sizeof(T);
-  HS_HIP(hipMalloc((void**)out, bytes));
-  if (!v.empty()) HS_HIP(hipMemcpy(*out, v.data(), v.size()*sizeof(T), hipMemcpyHostToDevice));
-  return 0;
-}
-int to_device_bytes(const void* p, size_t n, char** out){
-  *out = NULL;
-  HS_HIP(hipMalloc((void**)out, n ? n : 1));
-  if (n) HS_HIP(hipMemcpy(*out, p, n, hipMemcpyHostToDevice));
-  return 0;
-}
-
-int ensure_init(){
-  if (g_tab.ready) return 0;
-  return hipstr_hmm_init(0);
-}
+// Free lists of device / pinned blocks (see api_internal.h).  Sizes are rounded up to 256 B below 1 MiB and to 1/16 of the
+// next power of two above, so that batches of similar size hit the same classes.
+struct BlockCache {
+  bool pinned = false;
+  std::mutex m;
+  std::multimap<size_t, void*> free_;
+  std::unordered_map<void*, size_t> size_;
+  size_t cached = 0, cap = 0;
+  static size_t round_up(size_t n){
+    if (n < 256) return 256;
+    if (n <= ((size_t)1 << 20)) return (n + 255) & ~(size_t)255;
+    size_t p2 = (size_t)1 << 20; while (p2 < n) p2 <<= 1;
+    const size_t step = p2 >> 4;
+    return (n + step - 1) / step * step;
+  }
+  void* get(size_t bytes){
+    const size_t want = round_up(bytes);
+    {
+      std::lock_guard<std::mutex> g(m);
+      auto it = free_.lower_bound(want);
+      if (it != free_.end() && it->first <= want + want/4){ void* p = it->second; cached -= it->first; free_.erase(it); return p; }
+    }
+    void* p = NULL;
+    hipError_t e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+    if (e != hipSuccess){            // give cached blocks back to the driver and try once more
+      release();
+      e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+    }
+    if (e != hipSuccess){ g_err = std::string(pinned ? "hipHostMalloc: " : "hipMalloc: ") + hipGetErrorString(e); return NULL; }
+    std::lock_guard<std::mutex> g(m);
+    size_[p] = want;
+    return p;
+  }
+  void put(void* p){
+    if (!p) return;
+    std::unique_lock<std::mutex> g(m);
+    auto it = size_.find(p);
+    if (it == size_.end()) return;
+    const size_t n = it->second;
+    if (cached + n > cap){ size_.erase(it); g.unlock(); if (pinned) hipHostFree(p); else hipFree(p); return; }
+    free_.insert(std::make_pair(n, p)); cached += n;
+  }
+  void release(){
+    std::vector<void*> v;
+    { std::lock_guard<std::mutex> g(m); for (auto& kv : free_){ v.push_back(kv.second); size_.erase(kv.second); } free_.clear(); cached = 0; }
+    for (void* p : v){ if (pinned) hipHostFree(p); else hipFree(p); }
+  }
+};
 
 }  // namespace
 
-// what the other translation units of the library (trace.hip) need from this one: api_internal.h
 namespace hipstr {
-int api_fail(const std::string& m){ return fail(m); }
-int api_device_tables(ApiTables* t){
-  if (ensure_init()) return 1;
-  t->int_log = g_tab.int_log; t->qual_correct = g_tab.qc; t->qual_error = g_tab.qe; t->m2m = g_tab.m2m; t->m2i = g_tab.m2i;
-  t->stream = g_tab.stream;
-  return 0;
-}
+struct Ctx {
+  int device = -1;
+  double *int_log = NULL, *qc = NULL, *qe = NULL, *m2m = NULL, *m2i = NULL;
+  hipStream_t stream = NULL;
+  BlockCache dev_cache, pin_cache;
+};
 }  // namespace hipstr
 
-// failure inside hipstr_hmm_upload: release what the half-built batch already owns
-#define HS_HIP_DEV(call) do { hipError_t e_ = (call); if (e_ != hipSuccess){ \
-  g_err = std::string(#call) + ": " + hipGetErrorString(e_); hipstr_hmm_free(dev); return NULL; } } while (0)
+namespace {
+using hipstr::Ctx;
+std::mutex g_ctx_mutex;
+std::map<int, Ctx*> g_ctxs;                 // by device ordinal; contexts live until hipstr_hmm_shutdown
+thread_local Ctx* t_ctx = NULL;             // what hipstr_hmm_init selected on this thread
+
+int upload_table(const std::vector<double>& v, double** out){
+  *out = NULL;
+  HS_HIP(hipMalloc((void**)out, v.size()*sizeof(double)));
+  HS_HIP(hipMemcpy(*out, v.data(), v.size()*sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+Ctx* ctx_for_device(int device_ordinal){
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);          // concurrent first calls must not both build the tables
+  auto it = g_ctxs.find(device_ordinal);
+  if (it != g_ctxs.end()){ if (hipSetDevice(device_ordinal) != hipSuccess){ g_err = "hipSetDevice failed"; return NULL; } return it->second; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0){
+    g_err = "no HIP device available: this library has no CPU path (build/run on an MI355X)"; return NULL; }
+  if (device_ordinal < 0 || device_ordinal >= ndev){ g_err = "device ordinal out of range"; return NULL; }
+  HS_HIP_NULL(hipSetDevice(device_ordinal));
+  hipDeviceProp_t prop;
+  HS_HIP_NULL(hipGetDeviceProperties(&prop, device_ordinal));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0){
+    g_err = std::string("kernels are built for gfx950 only; device is ") + prop.gcnArchName; return NULL; }
+  const hipstr::HostTables& T = hipstr::host_tables();
+  std::vector<double> m2m(T.m2m, T.m2m+16), m2i(T.m2i, T.m2i+16);
+  Ctx* c = new Ctx();
+  c->device = device_ordinal;
+  c->pin_cache.pinned = true;
+  c->dev_cache.cap = (size_t)(getenv("HIPSTR_DEV_CACHE_GIB") ? atof(getenv("HIPSTR_DEV_CACHE_GIB")) : 64.0) << 30;
+  c->pin_cache.cap = (size_t)(getenv("HIPSTR_PIN_CACHE_GIB") ? atof(getenv("HIPSTR_PIN_CACHE_GIB")) : 8.0) << 30;
+  if (upload_table(T.int_log, &c->int_log) || upload_table(T.qual_correct, &c->qc) || upload_table(T.qual_error, &c->qe) ||
+      upload_table(m2m, &c->m2m) || upload_table(m2i, &c->m2i) ||
+      hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess){
+    if (g_err.empty()) g_err = "hipStreamCreate failed";
+    delete c; return NULL;
+  }
+  g_ctxs[device_ordinal] = c;
+  return c;
+}
+
+Ctx* current_ctx(){
+  if (t_ctx) return t_ctx;
+  {     // a thread that never called hipstr_hmm_init uses the process' first context, or device 0
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    if (!g_ctxs.empty()) t_ctx = g_ctxs.begin()->second;
+  }
+  if (!t_ctx) t_ctx = ctx_for_device(0);
+  return t_ctx;
+}
+
+int bind(Ctx* c){ HS_HIP(hipSetDevice(c->device)); return 0; }
+
+}  // namespace
+
+// what the other translation units of the library (trace.hip, em.hip, nw.hip) need from this one: api_internal.h
+namespace hipstr {
+int api_fail(const std::string& m){ return fail(m); }
+Ctx* api_current_ctx(){ Ctx* c = current_ctx(); if (c && bind(c)) return NULL; return c; }
+int api_bind(Ctx* c){ return bind(c); }
+int api_device_tables(ApiTables* t){
+  Ctx* c = api_current_ctx();
+  if (!c) return 1;
+  t->int_log = c->int_log; t->qual_correct = c->qc; t->qual_error = c->qe; t->m2m = c->m2m; t->m2i = c->m2i;
+  t->stream = c->stream; t->ctx = c;
+  return 0;
+}
+void* dev_alloc(Ctx* c, size_t bytes){ return c->dev_cache.get(bytes); }
+void  dev_free(Ctx* c, void* p){ c->dev_cache.put(p); }
+void* pin_alloc(Ctx* c, size_t bytes){ return c->pin_cache.get(bytes); }
+void  pin_free(Ctx* c, void* p){ c->pin_cache.put(p); }
+}  // namespace hipstr
 
 struct hipstr_dev_batch {
+  Ctx* ctx = NULL;
   hipstr::Prepared prep;
   hs_dev_t h;             // host copy of the argument block (device pointers inside)
   hs_dev_t* d_args = NULL;
-  std::vector<void*> allocs;
+  std::vector<void*> dev_blocks, pin_blocks;      // from the context's caches
   int grid_y = 1, max_alleles = 1, n_lead_items = 0, trail_waves = 1;
   size_t lds_bytes = 0;
   hipEvent_t ev0 = NULL, ev1 = NULL;
-  bool profiling = false;
+  bool profiling = false, foreign_stream = false;
   std::vector<hipEvent_t> prof_pool;        // reusable events; every pass records 5 per chunk (phase boundaries)
   size_t prof_used = 0;
   int64_t algo_bytes = 0, dp_cells = 0;
+  double t_prepare = 0, t_stage = 0;        // seconds spent in the host preparation / in packing the staging buffer
 };
 
 extern "C" {
@@ -114,34 +210,25 @@ int hipstr_batch_out_offsets(const hipstr_batch_t* b, int64_t* out_off){
 }
 
 int hipstr_hmm_init(int device_ordinal){
-  static std::mutex init_mutex;             // one device per process; concurrent first calls must not both build the tables
-  std::lock_guard<std::mutex> lock(init_mutex);
-  if (g_tab.ready && g_tab.device == device_ordinal) return 0;
-  if (g_tab.ready) return fail("library already initialised on another device (one process per GPU)");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-    return fail("no HIP device available: this library has no CPU path (build/run on an MI355X)");
-  if (device_ordinal < 0 || device_ordinal >= ndev) return fail("device ordinal out of range");
-  HS_HIP(hipSetDevice(device_ordinal));
-  hipDeviceProp_t prop;
-  HS_HIP(hipGetDeviceProperties(&prop, device_ordinal));
-  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(std::string("kernels are built for gfx950 only; device is ") + prop.gcnArchName);
-  const hipstr::HostTables& T = hipstr::host_tables();
-  std::vector<double> m2m(T.m2m, T.m2m+16), m2i(T.m2i, T.m2i+16);
-  if (to_device(T.int_log, &g_tab.int_log) || to_device(T.qual_correct, &g_tab.qc) || to_device(T.qual_error, &g_tab.qe) ||
-      to_device(m2m, &g_tab.m2m) || to_device(m2i, &g_tab.m2i)) return 1;
-  HS_HIP(hipStreamCreateWithFlags(&g_tab.stream, hipStreamNonBlocking));
-  g_tab.device = device_ordinal;
-  g_tab.ready = true;
+  Ctx* c = ctx_for_device(device_ordinal);
+  if (!c) return 1;
+  t_ctx = c;
   return 0;
 }
 
 void hipstr_hmm_shutdown(void){
-  if (!g_tab.ready) return;
-  hipFree(g_tab.int_log); hipFree(g_tab.qc); hipFree(g_tab.qe); hipFree(g_tab.m2m); hipFree(g_tab.m2i);
-  hipStreamDestroy(g_tab.stream);
-  g_tab = DevTables();
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  for (auto& kv : g_ctxs){
+    Ctx* c = kv.second;
+    if (hipSetDevice(c->device) != hipSuccess) continue;
+    hipDeviceSynchronize();
+    c->dev_cache.release(); c->pin_cache.release();
+    hipFree(c->int_log); hipFree(c->qc); hipFree(c->qe); hipFree(c->m2m); hipFree(c->m2i);
+    hipStreamDestroy(c->stream);
+    delete c;
+  }
+  g_ctxs.clear();
+  t_ctx = NULL;
 }
 
 int hipstr_calc_seed_bases(const hipstr_batch_t* b, int32_t* seeds){
@@ -156,7 +243,12 @@ int hipstr_calc_seed_bases(const hipstr_batch_t* b, int32_t* seeds){
 
 void hipstr_hmm_free(hipstr_dev_batch_t* dev){
   if (!dev) return;
-  for (void* p : dev->allocs) hipFree(p);
+  if (dev->ctx && bind(dev->ctx) == 0){
+    // blocks go back to the cache, which hands them to the next batch: whatever still runs on them must have finished
+    if (!dev->dev_blocks.empty() || !dev->pin_blocks.empty()) hipStreamSynchronize(dev->ctx->stream);
+    for (void* p : dev->dev_blocks) dev->ctx->dev_cache.put(p);
+    for (void* p : dev->pin_blocks) dev->ctx->pin_cache.put(p);
+  }
   if (dev->ev0) hipEventDestroy(dev->ev0);
   if (dev->ev1) hipEventDestroy(dev->ev1);
   for (hipEvent_t e : dev->prof_pool) hipEventDestroy(e);
@@ -165,22 +257,24 @@ void hipstr_hmm_free(hipstr_dev_batch_t* dev){
 
 hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){ return hipstr_hmm_upload_seeded(batch, NULL); }
 
+// failure inside hipstr_hmm_upload: release what the half-built batch already owns
+#define HS_HIP_DEV(call) do { hipError_t e_ = (call); if (e_ != hipSuccess){ \
+  g_err = std::string(#call) + ": " + hipGetErrorString(e_); hipstr_hmm_free(dev); return NULL; } } while (0)
+
 hipstr_dev_batch_t* hipstr_hmm_upload_seeded(const hipstr_batch_t* batch, const int32_t* seed_base){
-  if (ensure_init()) return NULL;
+  Ctx* ctx = hipstr::api_current_ctx();
+  if (!ctx) return NULL;
   hipstr_dev_batch_t* dev = new hipstr_dev_batch_t();
+  dev->ctx = ctx;
   std::string err;
   // workspace budget (doubles per workspace; there are two large ones): HIPSTR_WS_GIB, else a fifth of the free HBM, at most 24 GiB
   int64_t budget = (int64_t)3 << 30;
-  {
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) budget = std::min<int64_t>(budget, (int64_t)(free_b / 5 / sizeof(double)));
-    if (getenv("HIPSTR_WS_GIB")) budget = (int64_t)(atof(getenv("HIPSTR_WS_GIB"))*134217728.0);
-    if (budget < 1024) budget = 1024;
-  }
+  if (getenv("HIPSTR_WS_GIB")) budget = (int64_t)(atof(getenv("HIPSTR_WS_GIB"))*134217728.0);
+  if (budget < 1024) budget = 1024;
   const auto t_prep0 = std::chrono::steady_clock::now();
   if (hipstr::prepare_batch(batch, dev->prep, err, budget, seed_base)){ g_err = err; delete dev; return NULL; }
-  if (getenv("HIPSTR_TIMING"))
-    fprintf(stderr, "hipstr_hmm_upload: prepare_batch %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prep0).count());
+  dev->t_prepare = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_prep0).count();
+  if (getenv("HIPSTR_TIMING")) fprintf(stderr, "hipstr_hmm_upload: prepare_batch %.3f ms\n", 1e3*dev->t_prepare);
   hipstr::Prepared& P = dev->prep;
   {  // SURVEY.md §8(d) algorithmic traffic and flank-cell work of one pass
     int64_t bytes = 0, cells = 0;
@@ -205,46 +299,56 @@ hipstr_dev_batch_t* hipstr_hmm_upload_seeded(const hipstr_batch_t* batch, const 
   }
   hs_dev_t& h = dev->h;
   memset(&h, 0, sizeof h);
-#define UP(field, vec, T) do { T* p_ = NULL; if (to_device(vec, &p_)){ hipstr_hmm_free(dev); return NULL; } dev->allocs.push_back(p_); h.field = p_; } while (0)
-  UP(loci, P.loci, hs_locus_t); UP(alleles, P.alleles, hs_allele_t); UP(stropts, P.stropts, hs_stropt_t);
-  UP(rowsets, P.rowsets, hs_rowset_t); UP(rows, P.rows, hs_row_t); UP(visits, P.visits, hs_visit_t);
-  UP(f64pool, P.f64pool, double); UP(chars, P.chars, char); UP(reads, P.reads, hs_read_t); UP(active, P.active, int32_t);
-#undef UP
-  char* p = NULL;
-  if (to_device_bytes(P.bases.data(), P.bases.size(), &p)){ hipstr_hmm_free(dev); return NULL; } dev->allocs.push_back(p); h.bases = p;
-  if (to_device_bytes(P.quals.data(), P.quals.size(), &p)){ hipstr_hmm_free(dev); return NULL; } dev->allocs.push_back(p); h.quals = p;
-  double* out = NULL;
+  // ---- one device block for everything the host fills, one pinned block to stage it, one copy
+  const auto t_stage0 = std::chrono::steady_clock::now();
+  struct Piece { const void* src; size_t bytes, off; };
+  std::vector<Piece> pieces;
+  size_t total = 0;
+  auto place = [&](const void* src, size_t bytes){ total = (total + 255) & ~(size_t)255; pieces.push_back(Piece{src, bytes, total}); total += bytes ? bytes : 1; return pieces.size() - 1; };
+  std::vector<hs_item_t> items(P.lead_items);
+  items.insert(items.end(), P.trail_items.begin(), P.trail_items.end());
+  dev->n_lead_items = (int)P.lead_items.size();
+#define PL(vec) place((vec).data(), (vec).size()*sizeof((vec)[0]))
+  const size_t i_loci = PL(P.loci), i_alleles = PL(P.alleles), i_stropts = PL(P.stropts), i_rowsets = PL(P.rowsets), i_rows = PL(P.rows),
+    i_visits = PL(P.visits), i_f64 = PL(P.f64pool), i_chars = PL(P.chars), i_reads = PL(P.reads), i_active = PL(P.active), i_items = PL(items),
+    i_ws = PL(P.ws), i_tg = PL(P.tgroups), i_tm = PL(P.tmembers), i_tp = PL(P.tpack), i_ord = PL(P.str_order);
+#undef PL
+  const size_t n_bases = P.reads.empty() ? 0 : (size_t)batch->base_off[P.reads.size()];
+  const size_t i_bases = place(batch->bases, n_bases), i_quals = place(batch->quals, n_bases);
+  const size_t i_args = place(&h, sizeof h);
+  char* dblk = (char*)ctx->dev_cache.get(total);
+  if (!dblk){ hipstr_hmm_free(dev); return NULL; }
+  dev->dev_blocks.push_back(dblk);
+  char* stage = (char*)ctx->pin_cache.get(total);
+  if (!stage){ hipstr_hmm_free(dev); return NULL; }
+  dev->pin_blocks.push_back(stage);
+  auto at = [&](size_t i){ return dblk + pieces[i].off; };
+  h.loci = (const hs_locus_t*)at(i_loci); h.alleles = (const hs_allele_t*)at(i_alleles); h.stropts = (const hs_stropt_t*)at(i_stropts);
+  h.rowsets = (const hs_rowset_t*)at(i_rowsets); h.rows = (const hs_row_t*)at(i_rows); h.visits = (const hs_visit_t*)at(i_visits);
+  h.f64pool = (const double*)at(i_f64); h.chars = (const char*)at(i_chars); h.reads = (const hs_read_t*)at(i_reads);
+  h.active = (const int32_t*)at(i_active); h.items = (const hs_item_t*)at(i_items); h.ws = (const hs_ws_t*)at(i_ws);
+  h.tgroups = (const hs_tgroup_t*)at(i_tg); h.tmembers = (const int32_t*)at(i_tm); h.tpack = (const int32_t*)at(i_tp);
+  h.str_order = (const int32_t*)at(i_ord); h.bases = at(i_bases); h.quals = at(i_quals);
+  dev->d_args = (hs_dev_t*)at(i_args);
+  // ---- output + workspaces (device only)
+  auto dalloc = [&](size_t bytes) -> void* { void* p = ctx->dev_cache.get(bytes ? bytes : 1); if (p) dev->dev_blocks.push_back(p); return p; };
   const size_t out_bytes = (size_t)(P.n_out ? P.n_out : 1) * sizeof(double);
-  HS_HIP_DEV(hipMalloc((void**)&out, out_bytes)); dev->allocs.push_back(out);
-  HS_HIP_DEV(hipMemset(out, 0, out_bytes));
-  h.aln_probs = out;
-  const hipstr::HostTables& T = hipstr::host_tables();
-  h.int_log = g_tab.int_log; h.qual_correct = g_tab.qc; h.qual_error = g_tab.qe; h.m2m = g_tab.m2m; h.m2i = g_tab.m2i;
-  h.log_thresh = T.log_thresh; h.log_half = T.log_half;
+  h.aln_probs = (double*)dalloc(out_bytes);
+  h.ws_mr = (double*)dalloc(sizeof(double)*(size_t)P.ws_mr_size); h.ws_lt = (double*)dalloc(sizeof(double)*(size_t)P.ws_lt_size);
+  h.ws_lead = (double*)dalloc(sizeof(double)*(size_t)P.ws_lead_size); h.ws_col = (double*)dalloc(sizeof(double)*(size_t)P.ws_col_size);
+  // trailing-flank kernel: persistent wavefronts, each with two band-boundary rows of [max side columns][64 lanes][M,D]
+  h.band_cols = P.max_side_len > 0 ? P.max_side_len : 1;
+  dev->trail_waves = (int)std::min<size_t>(P.trail_items.size() ? P.trail_items.size() : 1, 256 * 16);
+  h.ws_band = (double*)dalloc(sizeof(double)*(size_t)dev->trail_waves*h.band_cols*64*2);
   h.n_active = (int32_t)P.active.size();
+  // [n_active] re-do flags of hs_str_kernel | [2 x chunks] work counters of hs_lead_kernel and hs_trail_kernel
+  h.redo = (int32_t*)dalloc(sizeof(int32_t)*((size_t)h.n_active + 2*P.chunks.size() + 2));
+  if (!h.aln_probs || !h.ws_mr || !h.ws_lt || !h.ws_lead || !h.ws_col || !h.ws_band || !h.redo){ hipstr_hmm_free(dev); return NULL; }
+  const hipstr::HostTables& T = hipstr::host_tables();
+  h.int_log = ctx->int_log; h.qual_correct = ctx->qc; h.qual_error = ctx->qe; h.m2m = ctx->m2m; h.m2i = ctx->m2i;
+  h.log_thresh = T.log_thresh; h.log_half = T.log_half;
   h.lds_len = P.max_read_len;
-  {  // work items (leading-flank items first, then side items), workspace offsets and the workspaces themselves
-    std::vector<hs_item_t> items(P.lead_items);
-    items.insert(items.end(), P.trail_items.begin(), P.trail_items.end());
-    dev->n_lead_items = (int)P.lead_items.size();
-    hs_item_t* di = NULL; hs_ws_t* dw = NULL;
-    if (to_device(items, &di) || to_device(P.ws, &dw)){ hipstr_hmm_free(dev); return NULL; }
-    dev->allocs.push_back(di); dev->allocs.push_back(dw);
-    h.items = di; h.ws = dw;
-    double* w = NULL;
-    HS_HIP_DEV(hipMalloc((void**)&w, sizeof(double)*(size_t)(P.ws_mr_size ? P.ws_mr_size : 1))); dev->allocs.push_back(w); h.ws_mr = w;
-    HS_HIP_DEV(hipMalloc((void**)&w, sizeof(double)*(size_t)(P.ws_lt_size ? P.ws_lt_size : 1))); dev->allocs.push_back(w); h.ws_lt = w;
-    HS_HIP_DEV(hipMalloc((void**)&w, sizeof(double)*(size_t)(P.ws_lead_size ? P.ws_lead_size : 1))); dev->allocs.push_back(w); h.ws_lead = w;
-    HS_HIP_DEV(hipMalloc((void**)&w, sizeof(double)*(size_t)(P.ws_col_size ? P.ws_col_size : 1))); dev->allocs.push_back(w); h.ws_col = w;
-    // trailing-flank kernel: persistent wavefronts, each with two band-boundary rows of [max side columns][64 lanes][M,D]
-    h.band_cols = P.max_side_len > 0 ? P.max_side_len : 1;
-    dev->trail_waves = (int)std::min<size_t>(P.trail_items.size() ? P.trail_items.size() : 1, 256 * 16);
-    HS_HIP_DEV(hipMalloc((void**)&w, sizeof(double)*(size_t)dev->trail_waves*h.band_cols*64*2)); dev->allocs.push_back(w); h.ws_band = w;
-    hs_tgroup_t* dg = NULL; int32_t* dm = NULL; int32_t* dk = NULL; int32_t* dor = NULL;
-    if (to_device(P.tgroups, &dg) || to_device(P.tmembers, &dm) || to_device(P.tpack, &dk) || to_device(P.str_order, &dor)){ hipstr_hmm_free(dev); return NULL; }
-    dev->allocs.push_back(dg); dev->allocs.push_back(dm); dev->allocs.push_back(dk); dev->allocs.push_back(dor);
-    h.tgroups = dg; h.tmembers = dm; h.tpack = dk; h.str_order = dor;
-  }
+  h.debug_redo = getenv("HIPSTR_DEBUG_REDO") ? atoi(getenv("HIPSTR_DEBUG_REDO")) : 0;
   // Workgroups: one per (active read[, side]), times enough allele chunks to put >= ~8192 wavefronts on the 256 CUs
   int maxA = 1;
   for (const hs_locus_t& l : P.loci) maxA = l.n_alleles > maxA ? l.n_alleles : maxA;
@@ -260,14 +364,18 @@ hipstr_dev_batch_t* hipstr_hmm_upload_seeded(const hipstr_batch_t* batch, const 
     HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->lds_bytes));
     HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_kernel_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->lds_bytes));
   }
+  // ---- pack (large pieces cut into 4 MiB spans so that the copy is shared by the host threads) and send
   {
-    int32_t* rd = NULL;
-    // [n_active] re-do flags of hs_str_kernel | [2 x chunks] work counters of hs_lead_kernel and hs_trail_kernel
-    HS_HIP_DEV(hipMalloc((void**)&rd, sizeof(int32_t)*((size_t)h.n_active + 2*P.chunks.size() + 2))); dev->allocs.push_back(rd); h.redo = rd;
-    h.debug_redo = getenv("HIPSTR_DEBUG_REDO") ? atoi(getenv("HIPSTR_DEBUG_REDO")) : 0;
+    struct Span { char* dst; const char* src; size_t n; };
+    std::vector<Span> spans;
+    for (const Piece& pc : pieces)
+      for (size_t o = 0; o < pc.bytes; o += (size_t)4 << 20)
+        spans.push_back(Span{stage + pc.off + o, (const char*)pc.src + o, std::min<size_t>((size_t)4 << 20, pc.bytes - o)});
+    hipstr::parallel_for((int)spans.size(), total > ((size_t)8 << 20) ? hipstr::host_threads() : 1, [&](int i){ memcpy(spans[i].dst, spans[i].src, spans[i].n); });
   }
-  HS_HIP_DEV(hipMalloc((void**)&dev->d_args, sizeof(hs_dev_t))); dev->allocs.push_back(dev->d_args);
-  HS_HIP_DEV(hipMemcpy(dev->d_args, &h, sizeof h, hipMemcpyHostToDevice));
+  dev->t_stage = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_stage0).count();
+  HS_HIP_DEV(hipMemcpyAsync(dblk, stage, total, hipMemcpyHostToDevice, ctx->stream));
+  HS_HIP_DEV(hipMemsetAsync(h.aln_probs, 0, out_bytes, ctx->stream));
   HS_HIP_DEV(hipEventCreate(&dev->ev0)); HS_HIP_DEV(hipEventCreate(&dev->ev1));
   return dev;
 }
@@ -275,7 +383,9 @@ hipstr_dev_batch_t* hipstr_hmm_upload_seeded(const hipstr_batch_t* batch, const 
 int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
   if (!dev) return fail("null device batch");
   if (dev->h.n_active == 0) return 0;
-  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_tab.stream;
+  if (bind(dev->ctx)) return 1;
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : dev->ctx->stream;
+  if (hip_stream && (hipStream_t)hip_stream != dev->ctx->stream) dev->foreign_stream = true;
   const hs_dev_t* dp = dev->d_args;
   auto mark = [&]() -> int {
     if (!dev->profiling) return 0;
@@ -344,7 +454,8 @@ int hipstr_hmm_workload(hipstr_dev_batch_t* dev, int64_t* n_alignments, int64_t*
 
 int hipstr_hmm_align_timed(hipstr_dev_batch_t* dev, int reps, float* ms_total, float* ms_kernel){
   if (!dev || reps < 1 || !ms_total) return fail("bad argument");
-  hipStream_t st = g_tab.stream;
+  if (bind(dev->ctx)) return 1;
+  hipStream_t st = dev->ctx->stream;
   HS_HIP(hipEventRecord(dev->ev0, st));
   for (int i = 0; i < reps; i++) if (hipstr_hmm_align(dev, st)) return 1;
   HS_HIP(hipEventRecord(dev->ev1, st));
@@ -358,23 +469,36 @@ double* hipstr_hmm_dev_aln_probs(hipstr_dev_batch_t* dev){ return dev ? dev->h.a
 
 int hipstr_hmm_fetch(hipstr_dev_batch_t* dev, double* aln_probs, int32_t* seeds){
   if (!dev || !aln_probs || !seeds) return fail("null argument");
-  HS_HIP(hipStreamSynchronize(g_tab.stream));
-  HS_HIP(hipDeviceSynchronize());
+  if (bind(dev->ctx)) return 1;
   const hipstr::Prepared& P = dev->prep;
-  std::vector<double> tmp((size_t)P.n_out);
-  if (P.n_out) HS_HIP(hipMemcpy(tmp.data(), dev->h.aln_probs, (size_t)P.n_out*sizeof(double), hipMemcpyDeviceToHost));
-  for (const hs_locus_t& loc : P.loci){
+  Ctx* ctx = dev->ctx;
+  if (dev->foreign_stream) HS_HIP(hipDeviceSynchronize());         // a pass was launched on a stream of the caller's
+  double* tmp = NULL;
+  if (P.n_out){
+    tmp = (double*)ctx->pin_cache.get((size_t)P.n_out*sizeof(double));
+    if (!tmp) return 1;
+    if (hipMemcpyAsync(tmp, dev->h.aln_probs, (size_t)P.n_out*sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess){
+      ctx->pin_cache.put(tmp); return fail("hipMemcpyAsync (device to host) failed"); }
+  }
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess){ ctx->pin_cache.put(tmp); return fail("hipStreamSynchronize failed"); }
+  // the reference's output contract, locus by locus (loci are independent: shared among the host threads)
+  auto scatter = [&](int li){
+    const hs_locus_t& loc = P.loci[li];
     const int A = loc.n_alleles;
+    const bool all_haps = loc.n_re == A;
     for (int i = 0; i < loc.n_reads; i++){
       const int r = loc.read_begin + i;
       if (!P.realign_read[r]) continue;                       // HapAligner.cpp:326-329
       seeds[r] = P.seeds[r];
       double* dst = aln_probs + loc.out_off + (int64_t)i*A;
-      const double* src = tmp.data() + loc.out_off + (int64_t)i*A;
+      const double* src = tmp + loc.out_off + (int64_t)i*A;
       if (P.seeds[r] == -1){ for (int k = 0; k < A; k++) dst[k] = 0; continue; }   // HapAligner.cpp:333-337
-      for (int k = 0; k < A; k++) if (P.realign_hap[loc.hap_begin + k]) dst[k] = src[k];   // HapAligner.cpp:615-619
+      if (all_haps) memcpy(dst, src, sizeof(double)*(size_t)A);
+      else for (int k = 0; k < A; k++) if (P.realign_hap[loc.hap_begin + k]) dst[k] = src[k];   // HapAligner.cpp:615-619
     }
-  }
+  };
+  hipstr::parallel_for((int)P.loci.size(), P.n_out > (1 << 20) ? hipstr::host_threads() : 1, scatter);
+  ctx->pin_cache.put(tmp);
   return 0;
 }
 
@@ -404,6 +528,32 @@ int hipstr_debug_rows(const hipstr_batch_t* batch, int k, int side, int which, u
   return rs.len;
 }
 
+// Diagnostics (host only): runs the host preparation of a batch with `threads` host threads (0 = default) and returns its wall time
+// and a digest of everything it produced — the digest must not depend on the thread count.
+int hipstr_debug_prepare(const hipstr_batch_t* batch, int threads, double* seconds, uint64_t* digest){
+  hipstr::Prepared P; std::string err;
+  hipstr::set_host_threads(threads);
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = hipstr::prepare_batch(batch, P, err);
+  const auto t1 = std::chrono::steady_clock::now();
+  hipstr::set_host_threads(0);
+  if (rc){ g_err = err; return 1; }
+  if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+  if (digest){
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n){ const uint8_t* q = (const uint8_t*)p; for (size_t i = 0; i < n; i++){ h ^= q[i]; h *= 1099511628211ull; } };
+#define HS_MIX(v) mix((v).data(), (v).size()*sizeof((v)[0]))
+    HS_MIX(P.loci); HS_MIX(P.alleles); HS_MIX(P.stropts); HS_MIX(P.rowsets); HS_MIX(P.rows); HS_MIX(P.visits); HS_MIX(P.f64pool); HS_MIX(P.chars);
+    HS_MIX(P.reads); HS_MIX(P.active); HS_MIX(P.seeds); HS_MIX(P.realign_read); HS_MIX(P.realign_hap); HS_MIX(P.ws); HS_MIX(P.lead_items);
+    HS_MIX(P.trail_items); HS_MIX(P.tpack); HS_MIX(P.str_order); HS_MIX(P.tgroups); HS_MIX(P.tmembers); HS_MIX(P.chunks);
+#undef HS_MIX
+    const int64_t tail[8] = { P.ws_mr_size, P.ws_lt_size, P.ws_lead_size, P.ws_col_size, P.max_side_len, P.max_B, P.n_out, P.n_alignments };
+    mix(tail, sizeof tail);
+    *digest = h;
+  }
+  return 0;
+}
+
 int hipstr_debug_simple_table(int bound, int U0, int tail, double entry[3]){
   if (!entry || bound < 0 || U0 < 0 || tail < 0 || tail >= 10000 || U0 >= 10000) return fail("bad argument");
   hipstr::debug_simple_table(bound, U0, tail, entry);
@@ -425,17 +575,23 @@ int hipstr_post_offsets(const hipstr_post_batch_t* pb, int64_t* post_off, int64_
 
 namespace {
 struct PostRun {
+  Ctx* ctx = NULL;
   std::vector<hs_post_unit_t> units;
-  std::vector<void*> allocs;
+  std::vector<void*> allocs;        // device blocks from the context's cache
   hs_post_dev_t h;
   hs_post_dev_t* d_args = NULL;
   int64_t n_post = 0, n_samp = 0, n_ll = 0;
   int n_reads = 0;
-  ~PostRun(){ for (void* p : allocs) hipFree(p); }
+  ~PostRun(){
+    if (!ctx || allocs.empty() || bind(ctx)) return;
+    hipStreamSynchronize(ctx->stream);           // the blocks are handed to the next user
+    for (void* p : allocs) ctx->dev_cache.put(p);
+  }
 };
 
 int post_setup(const hipstr_post_batch_t* pb, const double* dev_ll, PostRun& R){
   const hipstr::HostTables& T = hipstr::host_tables();
+  Ctx* ctx = R.ctx;
   int64_t po = 0, so = 0, lo = 0;
   for (int l = 0; l < pb->n_loci; l++){
     const int A = pb->n_alleles[l], S = pb->n_samples[l];
@@ -459,17 +615,15 @@ int post_setup(const hipstr_post_batch_t* pb, const double* dev_ll, PostRun& R){
   }
   R.n_post = po; R.n_samp = so; R.n_ll = lo; R.n_reads = pb->n_loci ? pb->read_off[pb->n_loci] : 0;
   memset(&R.h, 0, sizeof R.h);
-  hs_post_unit_t* du = NULL;
-  if (to_device(R.units, &du)) return 1;
-  R.allocs.push_back(du); R.h.units = du;
   auto up = [&](const void* src, size_t bytes, void** out){
-    *out = NULL;
-    if (hipMalloc(out, bytes ? bytes : 1) != hipSuccess) return fail("hipMalloc failed");
+    *out = ctx->dev_cache.get(bytes ? bytes : 1);
+    if (!*out) return 1;
     R.allocs.push_back(*out);
-    if (src && bytes && hipMemcpy(*out, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
+    if (src && bytes && hipMemcpyAsync(*out, src, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail("hipMemcpy failed");
     return 0;
   };
   void* p;
+  if (up(R.units.data(), R.units.size()*sizeof(hs_post_unit_t), &p)) return 1; R.h.units = (const hs_post_unit_t*)p;
   if (up(pb->log_p1, sizeof(double)*R.n_reads, &p)) return 1; R.h.log_p1 = (const double*)p;
   if (up(pb->log_p2, sizeof(double)*R.n_reads, &p)) return 1; R.h.log_p2 = (const double*)p;
   if (up(pb->read_weight, sizeof(int32_t)*R.n_reads, &p)) return 1; R.h.read_weight = (const int32_t*)p;
@@ -484,16 +638,19 @@ int post_setup(const hipstr_post_batch_t* pb, const double* dev_ll, PostRun& R){
   if (up(NULL, sizeof(int32_t)*2*R.n_samp, &p)) return 1; R.h.map_gt = (int32_t*)p;
   R.h.log_thresh = T.log_thresh; R.h.log_half = T.log_half;
   if (up(&R.h, sizeof R.h, &p)) return 1; R.d_args = (hs_post_dev_t*)p;
+  HS_HIP(hipStreamSynchronize(ctx->stream));       // the sources are the caller's (pageable) arrays: done with them before returning
   return 0;
 }
 }  // namespace
 
-struct hipstr_post_dev { PostRun R; std::vector<int32_t> n_samples, n_alleles; std::vector<uint8_t> haploid; };
+struct hipstr_post_dev { PostRun R; std::vector<int32_t> n_samples, n_alleles; std::vector<uint8_t> haploid; bool foreign_stream = false; };
 
 hipstr_post_dev_t* hipstr_post_upload(const hipstr_post_batch_t* pb, const double* dev_log_aln_probs){
   if (!pb){ g_err = "null argument"; return NULL; }
-  if (ensure_init()) return NULL;
+  Ctx* ctx = hipstr::api_current_ctx();
+  if (!ctx) return NULL;
   hipstr_post_dev_t* pd = new hipstr_post_dev_t();
+  pd->R.ctx = ctx;
   if (post_setup(pb, dev_log_aln_probs, pd->R)){ delete pd; return NULL; }
   pd->n_samples.assign(pb->n_samples, pb->n_samples + pb->n_loci);
   pd->n_alleles.assign(pb->n_alleles, pb->n_alleles + pb->n_loci);
@@ -505,7 +662,9 @@ hipstr_post_dev_t* hipstr_post_upload(const hipstr_post_batch_t* pb, const doubl
 int hipstr_post_launch(hipstr_post_dev_t* pd, void* hip_stream){
   if (!pd) return fail("null argument");
   if (pd->R.units.empty()) return 0;
-  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_tab.stream;
+  if (bind(pd->R.ctx)) return 1;
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : pd->R.ctx->stream;
+  if (hip_stream && st != pd->R.ctx->stream) pd->foreign_stream = true;
   hipLaunchKernelGGL(hs_posterior_kernel, dim3((unsigned)pd->R.units.size()), dim3(256), 0, st, (const hs_post_dev_t*)pd->R.d_args);
   HS_HIP(hipGetLastError());
   return 0;
@@ -514,7 +673,9 @@ int hipstr_post_launch(hipstr_post_dev_t* pd, void* hip_stream){
 int hipstr_post_fetch(hipstr_post_dev_t* pd, double* log_post, double* sample_total_ll, int32_t* map_gt, double* locus_total_ll){
   if (!pd || !log_post || !sample_total_ll || !map_gt || !locus_total_ll) return fail("null argument");
   PostRun& R = pd->R;
-  HS_HIP(hipDeviceSynchronize());
+  if (bind(R.ctx)) return 1;
+  if (pd->foreign_stream) HS_HIP(hipDeviceSynchronize());
+  HS_HIP(hipStreamSynchronize(R.ctx->stream));
   if (!R.units.empty()){
     HS_HIP(hipMemcpy(log_post, R.h.log_post, sizeof(double)*R.n_post, hipMemcpyDeviceToHost));
     HS_HIP(hipMemcpy(sample_total_ll, R.h.sample_total, sizeof(double)*R.n_samp, hipMemcpyDeviceToHost));
@@ -588,9 +749,11 @@ int hipstr_post_extract(hipstr_post_dev_t* pd, const hipstr_gt_request_t* rq, hi
     po += (int64_t)S*A*A; map_off += A;
   }
   if (units.empty()) return 0;
+  if (bind(R.ctx)) return 1;
+  Ctx* ctx = R.ctx;
   std::vector<void*> tmp;
-  struct Free { std::vector<void*>& v; ~Free(){ for (void* p : v) hipFree(p); } } guard{tmp};
-  auto dalloc = [&](size_t bytes, void** outp) -> int { *outp = NULL; HS_HIP(hipMalloc(outp, bytes ? bytes : 1)); tmp.push_back(*outp); return 0; };
+  struct Free { Ctx* c; std::vector<void*>& v; ~Free(){ hipStreamSynchronize(c->stream); for (void* p : v) c->dev_cache.put(p); } } guard{ctx, tmp};
+  auto dalloc = [&](size_t bytes, void** outp) -> int { *outp = ctx->dev_cache.get(bytes ? bytes : 1); if (!*outp) return 1; tmp.push_back(*outp); return 0; };
   hs_gt_dev_t h; memset(&h, 0, sizeof h);
   void* p;
   if (dalloc(units.size()*sizeof(hs_gt_unit_t), &p)) return 1; HS_HIP(hipMemcpy(p, units.data(), units.size()*sizeof(hs_gt_unit_t), hipMemcpyHostToDevice)); h.units = (const hs_gt_unit_t*)p;
@@ -609,10 +772,10 @@ int hipstr_post_extract(hipstr_post_dev_t* pd, const hipstr_gt_request_t* rq, hi
   h.calc_any = any; h.calc_gls = rq->calc_gls; h.calc_pls = rq->calc_pls; h.calc_pgls = rq->calc_phased_gls;
   h.log_thresh = T.log_thresh;
   if (dalloc(sizeof h, &p)) return 1; HS_HIP(hipMemcpy(p, &h, sizeof h, hipMemcpyHostToDevice));
-  HS_HIP(hipDeviceSynchronize());          // the posterior kernel may still be running on another stream
-  hipLaunchKernelGGL(hs_genotype_kernel, dim3((unsigned)units.size()), dim3(256), 0, g_tab.stream, (const hs_gt_dev_t*)p);
+  if (pd->foreign_stream) HS_HIP(hipDeviceSynchronize());          // the posterior kernel may still be running on a stream of the caller's
+  hipLaunchKernelGGL(hs_genotype_kernel, dim3((unsigned)units.size()), dim3(256), 0, ctx->stream, (const hs_gt_dev_t*)p);
   HS_HIP(hipGetLastError());
-  HS_HIP(hipStreamSynchronize(g_tab.stream));
+  HS_HIP(hipStreamSynchronize(ctx->stream));
   HS_HIP(hipMemcpy(out->best_hap, R.h.map_gt, (size_t)so*2*4, hipMemcpyDeviceToHost));
   HS_HIP(hipMemcpy(out->best_gt, h.best_gt, (size_t)so*2*4, hipMemcpyDeviceToHost));
   HS_HIP(hipMemcpy(out->log_phased_post, h.log_phased, (size_t)so*8, hipMemcpyDeviceToHost));

@@ -5,11 +5,26 @@
 
 namespace hipstr {
 
-struct ApiTables {                 // device copies of HostTables, owned by api.hip (hipstr_hmm_init)
+// One context per device the process uses: constant tables, the library's stream, and two block caches (device memory and pinned
+// host memory).  hipstr_hmm_init(d) makes device d the calling thread's current context; every object created afterwards
+// (device batches, posterior runs) belongs to that context and may be used from any thread.
+struct Ctx;
+Ctx* api_current_ctx();                       // the calling thread's context; initialises device 0 on first use; NULL + last error on failure
+int  api_bind(Ctx* ctx);                      // hipSetDevice(ctx's device) for the calling thread
+
+struct ApiTables {                 // device copies of HostTables, owned by the context
   const double *int_log, *qual_correct, *qual_error, *m2m, *m2i;
   hipStream_t stream;
+  Ctx* ctx;
 };
-int api_device_tables(ApiTables* t);          // initialises device 0 on first use; 1 + hipstr_last_error() on failure
+int api_device_tables(ApiTables* t);          // tables of the calling thread's current context; 1 + hipstr_last_error() on failure
 int api_fail(const std::string& message);     // records hipstr_last_error(); returns 1
+
+// Cached blocks: a freed block goes back to its context's free list instead of hipFree / hipHostFree (both synchronise the
+// device and cost 0.1-10 ms); a request is served from the list when a block of at most 1.25x the size is there.
+void* dev_alloc(Ctx* ctx, size_t bytes);      // NULL + last error on failure
+void  dev_free(Ctx* ctx, void* p);
+void* pin_alloc(Ctx* ctx, size_t bytes);
+void  pin_free(Ctx* ctx, void* p);
 
 }  // namespace hipstr

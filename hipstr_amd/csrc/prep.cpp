@@ -10,6 +10,9 @@
 #include "prep.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +20,31 @@
 #include <map>
 
 namespace hipstr {
+
+static std::atomic<int> g_thread_override(0);
+void set_host_threads(int n){ g_thread_override = n > 0 ? n : 0; }
+
+int host_threads(){
+  if (const int o = g_thread_override.load()) return o;
+  static const int n = [](){
+    if (const char* e = getenv("HIPSTR_HOST_THREADS")){ const int v = atoi(e); if (v >= 1) return v; }
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(hw ? hw : 1u, 32u));
+  }();
+  return n;
+}
+
+void parallel_for(int n, int max_threads, const std::function<void(int)>& fn){
+  const int nt = std::max(1, std::min(n, max_threads));
+  if (nt == 1){ for (int i = 0; i < n; i++) fn(i); return; }
+  std::atomic<int> next(0);
+  auto work = [&](){ for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nt; t++) pool.emplace_back(work);
+  work();
+  for (std::thread& t : pool) t.join();
+}
+
 
 static const int MIN_SEED_DIST = 5;          // HapAligner.cpp:17
 static const double LARGE_NEGATIVE = -10e6;  // RepeatStutterInfo.h:12
@@ -415,21 +443,18 @@ void fresh_flank_rows(const std::string side_seqs[3], std::vector<hs_row_t>& lea
 void append_stropt(const std::string& blk, int period, const double* stutter, Prepared& out){ emit_stropt(blk, period, stutter, out); }
 void debug_simple_table(int lim, int U0, int tail, double ent[3]){ g_bnd_scale = 1.0; simple_table_entry(lim, U0, tail, ent); }
 
-int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int64_t ws_budget, const int32_t* seed_in){
-  host_tables();
-  g_bnd_scale = getenv("HIPSTR_DEBUG_BND_SCALE") ? atof(getenv("HIPSTR_DEBUG_BND_SCALE")) : 1.0;
-  if (b == NULL || b->n_loci < 0){ err = "null or negative-size batch"; return 1; }
-  const int n_reads_total = b->n_loci > 0 ? b->read_off[b->n_loci] : 0;
-  out.seeds.assign(n_reads_total, -1);
-  out.realign_read.assign(n_reads_total, 1);
-  out.reads.resize(n_reads_total);
-  const int total_bases = n_reads_total > 0 ? b->base_off[n_reads_total] : 0;
-  out.bases.assign(b->bases ? b->bases : "", total_bases);
-  out.quals.assign(b->quals ? b->quals : "", total_bases);
-  int opt_cursor = 0;
-  int64_t out_off = 0;
-  std::vector< std::vector<int> > locus_leads;      // [2*locus + side] -> rowset ids by slot
-  for (int l = 0; l < b->n_loci; l++){
+// Everything prepare_batch derives from ONE locus, appended to `out` — a fragment holding a run of consecutive loci whose pool
+// offsets are local to the fragment (merge_fragment rebases them).  Per-read records go straight to the batch-wide arrays in
+// `sh` (disjoint ranges per locus), so fragments can be built by different threads.
+struct PrepShared {
+  hs_read_t* reads; int32_t* seeds; uint8_t* realign_read;
+  const int64_t* out_off;          // [n_loci] start of every locus' block in aln_probs
+  const int32_t* seed_in;
+};
+
+static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const PrepShared& sh, Prepared& out,
+                         std::vector< std::vector<int> >& locus_leads, std::string& err){
+  const int32_t* seed_in = sh.seed_in;
     const int period = b->period[l];
     if (period < 1 || period > 9){ err = "STR period must be in [1,9] (stutter_model.h:38)"; return 1; }
     int32_t nopts[3];
@@ -452,7 +477,7 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
     if (A != b->hap_off[l+1]-b->hap_off[l]){ err = "hap_off does not match the product of block options"; return 1; }
 
     hs_locus_t loc;
-    loc.out_off = out_off; loc.hap_begin = out.alleles.size(); loc.n_alleles = A;
+    loc.out_off = sh.out_off[l]; loc.hap_begin = out.alleles.size(); loc.n_alleles = A;
     loc.read_begin = b->read_off[l]; loc.n_reads = b->read_off[l+1]-b->read_off[l];
 
     // STR options: forward then reversed orientation
@@ -579,14 +604,14 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
       hs_read_t rd;
       rd.base_off = b->base_off[r]; rd.len = b->base_off[r+1]-b->base_off[r]; rd.locus = l; rd.seed = -1;
       const bool realign = b->realign_read ? b->realign_read[r] != 0 : true;
-      out.realign_read[r] = realign ? 1 : 0;
+      sh.realign_read[r] = realign ? 1 : 0;
       if (realign){
         const bool given = seed_in && seed_in[r] != HIPSTR_SEED_AUTO;
         const int s = given ? seed_in[r] : calc_seed_base(b, l, r);
         if (s == -2){ err = "Invalid alignment seed or unrecognized CIGAR char (HapAligner.cpp:309,316)"; return 1; }
         if (given && s != -1 && (s < 1 || s > rd.len - 2)){ err = "seed base must leave at least one base on either side (HapAligner.cpp:316)"; return 1; }
         rd.seed = s;
-        out.seeds[r] = s;
+        sh.seeds[r] = s;
         if (s >= 0){
           if (s > HS_MAX_SIDE_LEN || rd.len-s-1 > HS_MAX_SIDE_LEN){ err = "read side longer than 256 bases is not supported"; return 1; }
           out.active.push_back(r);
@@ -594,11 +619,118 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
           out.max_read_len = std::max(out.max_read_len, rd.len);
         }
       }
-      out.reads[r] = rd;
+      sh.reads[r] = rd;
     }
     out.loci.push_back(loc);
-    out_off += (int64_t)loc.n_reads * A;
+    return 0;
+}
+
+// Sizes of the pools of a fragment = where the next fragment starts in the merged batch.
+struct FragBase { size_t loci, alleles, stropts, rowsets, rows, visits, f64, chars, active, realign_hap, order, tgroups, tmembers, leads; };
+static FragBase frag_sizes(const Prepared& f, size_t n_leads){
+  return FragBase{ f.loci.size(), f.alleles.size(), f.stropts.size(), f.rowsets.size(), f.rows.size(), f.visits.size(), f.f64pool.size(), f.chars.size(),
+                   f.active.size(), f.realign_hap.size(), f.str_order.size(), f.tgroups.size(), f.tmembers.size(), n_leads };
+}
+
+// Copies fragment `f` to its place in `out` (whose pools are already sized), turning fragment-local pool offsets into batch-wide
+// ones.  Fragments write disjoint ranges: safe to run for several fragments at once.
+static void place_fragment(Prepared& out, Prepared& f, const FragBase& at, std::vector< std::vector<int> >& leads_out, std::vector< std::vector<int> >& leads_f){
+  const int32_t allele_base = (int32_t)at.alleles, stropt_base = (int32_t)at.stropts, rowset_base = (int32_t)at.rowsets;
+  const int32_t rows_base = (int32_t)at.rows, visits_base = (int32_t)at.visits, f64_base = (int32_t)at.f64;
+  const int32_t chars_base = (int32_t)at.chars, tg_base = (int32_t)at.tgroups, tm_base = (int32_t)at.tmembers, order_base = (int32_t)at.order;
+  for (hs_locus_t& L : f.loci){
+    L.hap_begin += allele_base;
+    for (int s = 0; s < 2; s++){ L.tg_begin[s] += tg_base; L.order_off[s] += order_base; }
   }
+  for (hs_allele_t& a : f.alleles)
+    if (a.realign) for (int s = 0; s < 2; s++){ a.lead_rows[s] += rowset_base; a.trail_rows[s] += rowset_base; a.str_opt[s] += stropt_base; }
+  for (hs_rowset_t& r : f.rowsets) r.off += rows_base;
+  for (hs_stropt_t& o : f.stropts){
+    o.seq_off += chars_base; o.f64_off += f64_base; o.ins_off += visits_base; o.tab_off += f64_base;
+    for (int q = 0; q < HS_MAXREP; q++) o.del_off[q] += visits_base;
+  }
+  for (hs_tgroup_t& g : f.tgroups){ g.rowset += rowset_base; g.member_off += tm_base; }
+  for (std::vector<int>& ls : leads_f) for (int& id : ls) id += rowset_base;
+#define HS_PLACE(field, base) std::copy(f.field.begin(), f.field.end(), out.field.begin() + (base))
+  HS_PLACE(loci, at.loci); HS_PLACE(alleles, at.alleles); HS_PLACE(stropts, at.stropts); HS_PLACE(rowsets, at.rowsets); HS_PLACE(rows, at.rows);
+  HS_PLACE(visits, at.visits); HS_PLACE(f64pool, at.f64); HS_PLACE(chars, at.chars); HS_PLACE(active, at.active); HS_PLACE(realign_hap, at.realign_hap);
+  HS_PLACE(str_order, at.order); HS_PLACE(tgroups, at.tgroups); HS_PLACE(tmembers, at.tmembers);
+#undef HS_PLACE
+  for (size_t i = 0; i < leads_f.size(); i++) leads_out[at.leads + i].swap(leads_f[i]);
+}
+
+int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int64_t ws_budget, const int32_t* seed_in){
+  host_tables();
+  const bool timing = getenv("HIPSTR_TIMING") != NULL;
+  auto now = [](){ return std::chrono::steady_clock::now(); };
+  auto lap = [&](const char* what, std::chrono::steady_clock::time_point& t){
+    if (timing){ const auto t2 = now(); fprintf(stderr, "prepare_batch: %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t2 - t).count()); t = t2; }
+  };
+  auto t_lap = now();
+  g_bnd_scale = getenv("HIPSTR_DEBUG_BND_SCALE") ? atof(getenv("HIPSTR_DEBUG_BND_SCALE")) : 1.0;
+  if (b == NULL || b->n_loci < 0){ err = "null or negative-size batch"; return 1; }
+  const int n_reads_total = b->n_loci > 0 ? b->read_off[b->n_loci] : 0;
+  out.seeds.assign(n_reads_total, -1);
+  out.realign_read.assign(n_reads_total, 1);
+  out.reads.resize(n_reads_total);
+  std::vector< std::vector<int> > locus_leads;      // [2*locus + side] -> rowset ids by slot
+  // per-locus starts in the option table and in the output, and a cost estimate to cut the loci into balanced fragments
+  std::vector<int> opt_start(b->n_loci + 1, 0);
+  std::vector<int64_t> out_off_v(b->n_loci + 1, 0), cost(b->n_loci + 1, 0);
+  for (int l = 0; l < b->n_loci; l++){
+    int64_t A = 1; int no = 0;
+    for (int k = 0; k < 3; k++){
+      const int n = b->blk_nopts[3*l+k];
+      if (n < 1){ err = "haplotype block without options"; return 1; }
+      no += n; A *= n;
+    }
+    opt_start[l+1] = opt_start[l] + no;
+    const int64_t P = b->read_off[l+1] - b->read_off[l];
+    if (P < 0){ err = "read_off must not decrease"; return 1; }
+    out_off_v[l+1] = out_off_v[l] + P*A;
+    cost[l+1] = cost[l] + 64*(int64_t)b->blk_nopts[3*l+1] + 4*A + P;
+  }
+  const int64_t out_off = out_off_v[b->n_loci];
+  lap("setup", t_lap);
+  PrepShared sh; sh.reads = out.reads.data(); sh.seeds = out.seeds.data(); sh.realign_read = out.realign_read.data();
+  sh.out_off = out_off_v.data(); sh.seed_in = seed_in;
+  int n_threads = std::min(host_threads(), std::max(1, b->n_loci / 4));
+  if (n_threads <= 1){
+    for (int l = 0; l < b->n_loci; l++)
+      if (prepare_locus(b, l, opt_start[l], sh, out, locus_leads, err)) return 1;
+  } else {
+    // fragments of consecutive loci with near-equal cost, a few per thread so that a slow fragment does not stall the rest
+    const int n_frag = std::min(b->n_loci, n_threads*4);
+    std::vector<int> cut(n_frag + 1, 0);
+    for (int f = 1; f < n_frag; f++)
+      cut[f] = std::max(cut[f-1], (int)(std::lower_bound(cost.begin(), cost.end(), cost[b->n_loci]*f/n_frag) - cost.begin()));
+    cut[n_frag] = b->n_loci;
+    std::vector<Prepared> frag(n_frag);
+    std::vector< std::vector< std::vector<int> > > frag_leads(n_frag);
+    std::vector<std::string> frag_err(n_frag);
+    std::vector<int> frag_rc(n_frag, 0);
+    parallel_for(n_frag, n_threads, [&](int f){
+      for (int l = cut[f]; l < cut[f+1] && !frag_rc[f]; l++)
+        frag_rc[f] = prepare_locus(b, l, opt_start[l], sh, frag[f], frag_leads[f], frag_err[f]);
+    });
+    lap("fragments", t_lap);
+    for (int f = 0; f < n_frag; f++) if (frag_rc[f]){ err = frag_err[f]; return 1; }
+    std::vector<FragBase> at(n_frag + 1);
+    memset(&at[0], 0, sizeof(FragBase));
+    for (int f = 0; f < n_frag; f++){
+      const FragBase sz = frag_sizes(frag[f], frag_leads[f].size());
+      const size_t* a = (const size_t*)&at[f]; const size_t* z = (const size_t*)&sz; size_t* n = (size_t*)&at[f+1];
+      for (size_t i = 0; i < sizeof(FragBase)/sizeof(size_t); i++) n[i] = a[i] + z[i];
+      out.max_B = std::max(out.max_B, frag[f].max_B); out.max_flank = std::max(out.max_flank, frag[f].max_flank);
+      out.max_read_len = std::max(out.max_read_len, frag[f].max_read_len); out.n_alignments += frag[f].n_alignments;
+    }
+    const FragBase& tot = at[n_frag];
+    out.loci.resize(tot.loci); out.alleles.resize(tot.alleles); out.stropts.resize(tot.stropts); out.rowsets.resize(tot.rowsets); out.rows.resize(tot.rows);
+    out.visits.resize(tot.visits); out.f64pool.resize(tot.f64); out.chars.resize(tot.chars); out.active.resize(tot.active); out.realign_hap.resize(tot.realign_hap);
+    out.str_order.resize(tot.order); out.tgroups.resize(tot.tgroups); out.tmembers.resize(tot.tmembers); locus_leads.resize(tot.leads);
+    parallel_for(n_frag, n_threads, [&](int f){ place_fragment(out, frag[f], at[f], locus_leads, frag_leads[f]); });
+  }
+  lap("loci", t_lap);
   out.n_out = out_off;
 
   // ---- launch plan: workspaces + work items, chunked so that the workspaces stay within the budget
@@ -611,10 +743,21 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
     // trailing-flank items: lanes = alleles of a group; when a group has <= 32 alleles, 64/npad reads of the same locus and
     // side (sorted by side length, so that packed reads finish together) share one wavefront
     ch.trail_begin = out.trail_items.size();
+    // the (locus, range of active reads) runs of this chunk; their items are built independently (host threads) and appended
+    // in locus order with their offsets into the packed-read table rebased
+    struct Run { int a0, a1; std::vector<hs_item_t> lead, trail; std::vector<int32_t> tpack; };
+    std::vector<Run> runs;
     for (int a0 = ch.active_begin; a0 < active_end; ){
       const int locus = out.reads[out.active[a0]].locus;
       int a1 = a0;
       while (a1 < active_end && out.reads[out.active[a1]].locus == locus) a1++;
+      runs.push_back(Run{a0, a1, {}, {}, {}});
+      a0 = a1;
+    }
+    parallel_for((int)runs.size(), runs.size() >= 16 ? host_threads() : 1, [&](int ri){
+      Run& R = runs[ri];
+      const int a0 = R.a0, a1 = R.a1;
+      const int locus = out.reads[out.active[a0]].locus;
       const hs_locus_t& loc = out.loci[locus];
       for (int s = 0; s < 2; s++){
         std::vector<int> order;
@@ -627,10 +770,10 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
         for (size_t slot = 0; slot < ls.size(); slot++)
           for (size_t i = 0; i < order.size(); i += 64){
             hs_item_t it; it.side = s | ((int32_t)slot << 1); it.rowset = ls[slot];
-            it.active = (int32_t)out.tpack.size();
+            it.active = (int32_t)R.tpack.size();
             it.slot = (int32_t)std::min<size_t>(64, order.size() - i);
-            out.tpack.insert(out.tpack.end(), order.begin() + i, order.begin() + i + it.slot);
-            out.lead_items.push_back(it);
+            R.tpack.insert(R.tpack.end(), order.begin() + i, order.begin() + i + it.slot);
+            R.lead.push_back(it);
           }
         for (int g = 0; g < loc.tg_count[s]; g++){
           const int nm = out.tgroups[loc.tg_begin[s] + g].n_members;
@@ -638,14 +781,21 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
           const int per_wave = 64 / npad;
           for (size_t i = 0; i < order.size(); i += per_wave){
             hs_item_t it; it.side = s; it.slot = loc.tg_begin[s] + g;
-            it.active = (int32_t)out.tpack.size();
+            it.active = (int32_t)R.tpack.size();
             it.rowset = (int32_t)std::min<size_t>(per_wave, order.size() - i);
-            out.tpack.insert(out.tpack.end(), order.begin() + i, order.begin() + i + it.rowset);
-            out.trail_items.push_back(it);
+            R.tpack.insert(R.tpack.end(), order.begin() + i, order.begin() + i + it.rowset);
+            R.trail.push_back(it);
           }
         }
       }
-      a0 = a1;
+    });
+    for (Run& R : runs){
+      const int32_t base = (int32_t)out.tpack.size();
+      for (hs_item_t& it : R.lead) it.active += base;
+      for (hs_item_t& it : R.trail) it.active += base;
+      out.tpack.insert(out.tpack.end(), R.tpack.begin(), R.tpack.end());
+      out.lead_items.insert(out.lead_items.end(), R.lead.begin(), R.lead.end());
+      out.trail_items.insert(out.trail_items.end(), R.trail.begin(), R.trail.end());
     }
     ch.trail_end = out.trail_items.size();
     ch.lead_end = out.lead_items.size();
@@ -674,6 +824,7 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
     ch.n_alignments += loc.n_re;
   }
   flush((int)out.active.size());
+  lap("plan", t_lap);
   return 0;
 }
 

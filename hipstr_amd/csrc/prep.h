@@ -1,6 +1,7 @@
 // prep.h — host-side preparation of a hipstr_batch_t into the flat HBM layout of layout.h.
 #pragma once
 #include <stdint.h>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -8,6 +9,12 @@
 #include "layout.h"
 
 namespace hipstr {
+
+// Host-side work sharing: the number of threads the library may use for host work of one call (HIPSTR_HOST_THREADS, default
+// min(hardware threads, 32)) and a loop that hands indices [0, n) to up to max_threads threads through a counter.
+int host_threads();
+void set_host_threads(int n);      // 0 = back to the default
+void parallel_for(int n, int max_threads, const std::function<void(int)>& fn);
 
 // Constant tables the reference keeps in globals; computed once with the host libm so they
 // carry exactly the bits the reference computes (mathops.cpp:13-21, AlignmentModel.cpp:20-32,
@@ -35,7 +42,6 @@ struct Prepared {
   std::vector<int32_t>     seeds;          // per read (valid only where realign_read)
   std::vector<uint8_t>     realign_read;   // per read
   std::vector<uint8_t>     realign_hap;    // per global allele
-  std::string              bases, quals;
   // ---- launch plan: the batch is cut into chunks of consecutive active reads whose workspaces fit the budget
   struct Chunk {
     int32_t active_begin, active_end;      // range in `active`

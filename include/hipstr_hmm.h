@@ -361,6 +361,12 @@ int hipstr_hmm_trace_seeded(const hipstr_batch_t* batch, int32_t n_req, const in
  * count (0 if the allele is not realigned, -1 on error).  Used by tests/test_prep.py. */
 int hipstr_debug_rows(const hipstr_batch_t* batch, int k, int side, int which, uint32_t* rows, int cap);
 
+/* Diagnostics (host only): the host preparation of a batch (flatten, reuse replay, visiting lists, closed-form tables, launch plan
+ * — what hipstr_hmm_upload does before any byte moves) run with `threads` host threads (0 = the library default,
+ * HIPSTR_HOST_THREADS or min(hardware threads, 32)); *seconds = its wall time, *digest = a hash of everything it produced, which
+ * must not depend on the thread count.  Used by tests/test_prep.py and bench.py. */
+int hipstr_debug_prepare(const hipstr_batch_t* batch, int threads, double* seconds, uint64_t* digest);
+
 /* Diagnostics (host only): one entry {A, G, Bnd} of the tabulated closed form the STR kernel uses for a "simple" visiting
  * list (StutterAlignerClass.cpp:59-150 for a periodic block): with `bound` columns of the block in reach, a run of U0 equal
  * configurations at the block's right end and `tail` configurations in total, fast_log_sum_exp over the pushed values is

@@ -141,3 +141,19 @@ def test_tabulated_closed_form_is_exact_below_its_bound(hmm_host, oracle):
             assert got == want, (lim, U0, tail, lp0, got, want, bnd)
             checked += 1; near += rep < 2
     assert checked > 30000 and near > 5000
+
+
+def test_host_preparation_does_not_depend_on_thread_count(hmm_host):
+    """prepare_batch builds fragments of consecutive loci on several host threads and merges them (prep.cpp); every pool,
+    offset and work item must come out exactly as in the single-threaded pass — also with masks and alternative flanks."""
+    import ctypes as C
+    for kw in (dict(n_loci=37, reads_per_locus=23, n_str_alleles=9, seed=3),
+               dict(n_loci=50, reads_per_locus=11, n_str_alleles=6, n_flank_opts=2, seed=4, mask_rate=0.25),
+               dict(n_loci=5, reads_per_locus=40, n_str_alleles=12, seed=5)):
+        sb = capi.SynthBatch(**kw)
+        digests = set()
+        for threads in (1, 2, 3, 8, 13):
+            sec = C.c_double(); dig = C.c_uint64()
+            assert hmm_host.hipstr_debug_prepare(sb.ptr, threads, C.byref(sec), C.byref(dig)) == 0
+            digests.add(dig.value)
+        assert len(digests) == 1, kw
