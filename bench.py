@@ -167,6 +167,59 @@ def pipeline_stages(capi, hmm, sb, loci, P):
     return out
 
 
+def end_to_end(capi, hmm, sb, loci, steps, device):
+    """SURVEY §8(d)'s metric taken literally — wall time from host arrays in to aln_probs/seeds out (host flatten, H2D, kernels, D2H,
+    the reference's output contract) — through the streaming C-ABI, fed the way the reference's caller produces work: ONE locus per
+    submission (bam_processor.cpp:550-617).  `steps` passes over the batch go through one open stream back to back, a feeder
+    thread submitting while this thread collects in order; reported beside `value`, never as `value` (inputs are host-resident)."""
+    import threading
+    from hipstr_amd import shard
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util
+    a = util.synth_to_batch(sb).arrays
+    pieces = [shard.batch_from_arrays(shard.subset_arrays(a, l, l + 1)) for l in range(loci)]
+    sizes = [(int(sb.out_off[l + 1] - sb.out_off[l]), int(a["read_off"][l + 1] - a["read_off"][l])) for l in range(loci)]
+    st = capi.Stream(hmm, device=device, slots=3, batch_alignments=4 << 20)
+    probs = np.zeros(max(max(z[0] for z in sizes), 1)); seeds = np.zeros(max(max(z[1] for z in sizes), 1), np.int32)
+    def one_pass_set(n):
+        def feed():
+            for _ in range(n):
+                for p in pieces:
+                    st.submit(p.ptr)
+            st.flush()
+        th = threading.Thread(target=feed); th.start()
+        got = 0
+        while got < n * loci:
+            r = st.next(into=(probs, seeds))
+            if r is None:
+                time.sleep(0.0002); continue
+            got += 1
+        th.join()
+    one_pass_set(1)                                  # warm-up: block caches, kernels
+    s0 = st.stats()
+    t0 = time.perf_counter()
+    one_pass_set(steps)
+    dt = time.perf_counter() - t0
+    s1 = st.stats()
+    st.close()
+    # one-locus latency: a 30x locus (40 reads x 32 alleles) and an NS locus through the one-shot call, median of 30
+    lat = {}
+    for name, (pp, aa) in (("40x32", (40, 32)), ("500x32", (500, 32)), ("50x4", (50, 4))):
+        one = capi.SynthBatch(n_loci=1, reads_per_locus=pp, n_str_alleles=aa, seed=77)
+        pr = np.zeros(one.n_out); sd = np.zeros(one.n_reads, np.int32)
+        ts = []
+        for _ in range(33):
+            t1 = time.perf_counter()
+            assert hmm.hipstr_hmm_process_reads(one.ptr, pr.ctypes.data_as(capi._f64p), sd.ctypes.data_as(capi._i32p)) == 0
+            ts.append(time.perf_counter() - t1)
+        lat[name] = {"median_ms": 1e3 * float(np.median(ts[3:])), "min_ms": 1e3 * float(np.min(ts[3:]))}
+    return {"seconds": dt, "passes": steps, "ms_per_pass": 1e3 * dt / steps, "submissions": steps * loci, "loci_per_submission": 1,
+            "batches": s1["batches"] - s0["batches"], "worker_host_seconds": s1["host_seconds"] - s0["host_seconds"],
+            "collector_wait_seconds": s1["wait_seconds"] - s0["wait_seconds"],
+            "one_locus_process_reads_latency": lat,
+            "path": "hipstr_stream_submit (1 locus each) -> batches of ~4 Mi alignments -> prepare on host threads + H2D + kernels + D2H, 3 slots -> hipstr_stream_next in order"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -332,6 +385,10 @@ def main():
                      "value_incl_prepare_pcie": total_aln / world / (t_upload + elapsed / args.steps + t_fetch) * world},
         }
         if args.gpus == 1 and not args.no_pipeline:
+            e2e = end_to_end(capi, hmm, sb, loci, max(2, min(args.steps, 5)), local)
+            e2e["alignments_per_s"] = n_aln.value * e2e["passes"] / e2e["seconds"]
+            e2e["fraction_of_resident_rate"] = e2e["alignments_per_s"] / value
+            out["end_to_end"] = e2e
             out["pipeline"] = pipeline_stages(capi, hmm, sb, loci, P)
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(capi, wl)

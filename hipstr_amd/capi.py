@@ -555,6 +555,72 @@ def run_align(lib, prefix, bptr, fill=np.nan, seed_in=None):
     return probs[:n_out], seeds[:n_reads]
 
 
+class HipstrStreamOpts(C.Structure):
+    _fields_ = [("device", C.c_int32), ("slots", C.c_int32), ("batch_alignments", C.c_int64)]
+
+
+class HipstrStreamStats(C.Structure):
+    _fields_ = [("batches", C.c_int64), ("tickets", C.c_int64), ("alignment_slots", C.c_int64), ("host_seconds", C.c_double),
+                ("wait_seconds", C.c_double), ("open_seconds", C.c_double)]
+
+
+class Stream:
+    """hipstr_stream_*: loci in, results out in submission order (include/hipstr_hmm.h)."""
+
+    def __init__(self, lib, device=0, slots=0, batch_alignments=0):
+        self.lib = lib
+        _sig(lib.hipstr_stream_open, C.c_void_p, [C.POINTER(HipstrStreamOpts)])
+        _sig(lib.hipstr_stream_submit, C.c_int64, [C.c_void_p, _BP])
+        _sig(lib.hipstr_stream_flush, C.c_int, [C.c_void_p])
+        _sig(lib.hipstr_stream_next_size, C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
+        _sig(lib.hipstr_stream_next, C.c_int, [C.c_void_p, C.POINTER(C.c_int64), _f64p, C.c_int64, _i32p, C.c_int64])
+        _sig(lib.hipstr_stream_stats, C.c_int, [C.c_void_p, C.POINTER(HipstrStreamStats)])
+        _sig(lib.hipstr_stream_close, C.c_int, [C.c_void_p])
+        o = HipstrStreamOpts(device, slots, batch_alignments)
+        self.h = lib.hipstr_stream_open(C.byref(o))
+        if not self.h:
+            raise RuntimeError("hipstr_stream_open failed: " + lib.hipstr_last_error().decode())
+
+    def submit(self, bptr):
+        t = self.lib.hipstr_stream_submit(self.h, bptr)
+        if t < 0:
+            raise RuntimeError("hipstr_stream_submit failed: " + self.lib.hipstr_last_error().decode())
+        return t
+
+    def flush(self):
+        assert self.lib.hipstr_stream_flush(self.h) == 0
+
+    def next(self, fill=np.nan, into=None):
+        """(ticket, aln_probs, seeds) of the next submission in order, or None when nothing is outstanding."""
+        t = C.c_int64(); n_out = C.c_int64(); n_reads = C.c_int64()
+        if self.lib.hipstr_stream_next_size(self.h, C.byref(t), C.byref(n_out), C.byref(n_reads)) == 2:
+            return None
+        if into is None:
+            probs = np.full(max(n_out.value, 1), fill); seeds = np.full(max(n_reads.value, 1), -7, np.int32)
+        else:
+            probs, seeds = into
+        rc = self.lib.hipstr_stream_next(self.h, C.byref(t), probs.ctypes.data_as(_f64p), probs.size, seeds.ctypes.data_as(_i32p), seeds.size)
+        if rc != 0:
+            raise RuntimeError("hipstr_stream_next failed: " + self.lib.hipstr_last_error().decode())
+        return t.value, probs[:n_out.value], seeds[:n_reads.value]
+
+    def stats(self):
+        st = HipstrStreamStats()
+        assert self.lib.hipstr_stream_stats(self.h, C.byref(st)) == 0
+        return {k: getattr(st, k) for k, _ in HipstrStreamStats._fields_}
+
+    def close(self):
+        if self.h:
+            self.lib.hipstr_stream_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def run_posteriors(lib, prefix, pb):
     S = int(pb.samp_off[-1])
     post = np.zeros(max(int(pb.post_off[-1]), 1)); tot = np.zeros(max(S, 1)); gt = np.zeros(max(2 * S, 2), dtype=np.int32)

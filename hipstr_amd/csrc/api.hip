@@ -187,6 +187,9 @@ struct hipstr_dev_batch {
   int grid_y = 1, max_alleles = 1, n_lead_items = 0, trail_waves = 1;
   size_t lds_bytes = 0;
   hipEvent_t ev0 = NULL, ev1 = NULL;
+  hipEvent_t ev_h2d = NULL, ev_done = NULL, ev_d2h = NULL;     // upload finished / last pass finished / results in host_out (pipelined use)
+  hipStream_t h2d_stream = NULL, d2h_stream = NULL;
+  double* host_out = NULL;                  // pinned copy of aln_probs (fetch_begin)
   bool profiling = false, foreign_stream = false;
   std::vector<hipEvent_t> prof_pool;        // reusable events; every pass records 5 per chunk (phase boundaries)
   size_t prof_used = 0;
@@ -245,12 +248,19 @@ void hipstr_hmm_free(hipstr_dev_batch_t* dev){
   if (!dev) return;
   if (dev->ctx && bind(dev->ctx) == 0){
     // blocks go back to the cache, which hands them to the next batch: whatever still runs on them must have finished
-    if (!dev->dev_blocks.empty() || !dev->pin_blocks.empty()) hipStreamSynchronize(dev->ctx->stream);
+    if (!dev->dev_blocks.empty() || !dev->pin_blocks.empty()){
+      hipStreamSynchronize(dev->ctx->stream);
+      if (dev->h2d_stream && dev->h2d_stream != dev->ctx->stream) hipStreamSynchronize(dev->h2d_stream);
+      if (dev->d2h_stream && dev->d2h_stream != dev->ctx->stream) hipStreamSynchronize(dev->d2h_stream);
+    }
     for (void* p : dev->dev_blocks) dev->ctx->dev_cache.put(p);
     for (void* p : dev->pin_blocks) dev->ctx->pin_cache.put(p);
   }
   if (dev->ev0) hipEventDestroy(dev->ev0);
   if (dev->ev1) hipEventDestroy(dev->ev1);
+  if (dev->ev_h2d) hipEventDestroy(dev->ev_h2d);
+  if (dev->ev_done) hipEventDestroy(dev->ev_done);
+  if (dev->ev_d2h) hipEventDestroy(dev->ev_d2h);
   for (hipEvent_t e : dev->prof_pool) hipEventDestroy(e);
   delete dev;
 }
@@ -264,8 +274,18 @@ hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){ return hipst
 hipstr_dev_batch_t* hipstr_hmm_upload_seeded(const hipstr_batch_t* batch, const int32_t* seed_base){
   Ctx* ctx = hipstr::api_current_ctx();
   if (!ctx) return NULL;
+  return hipstr::upload_on(ctx, batch, seed_base, ctx->stream);
+}
+
+}  // extern "C"
+
+// The upload with the copy on a stream of the caller's choice (the pipelined path copies on its own stream so that the next
+// batch's tables travel while the previous batch's kernels run); hipstr_hmm_align waits for it through an event.
+hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, const int32_t* seed_base, hipStream_t copy_stream){
+  if (bind(ctx)) return NULL;
   hipstr_dev_batch_t* dev = new hipstr_dev_batch_t();
   dev->ctx = ctx;
+  dev->h2d_stream = copy_stream;
   std::string err;
   // workspace budget (doubles per workspace; there are two large ones): HIPSTR_WS_GIB, else a fifth of the free HBM, at most 24 GiB
   int64_t budget = (int64_t)3 << 30;
@@ -374,11 +394,72 @@ hipstr_dev_batch_t* hipstr_hmm_upload_seeded(const hipstr_batch_t* batch, const 
     hipstr::parallel_for((int)spans.size(), total > ((size_t)8 << 20) ? hipstr::host_threads() : 1, [&](int i){ memcpy(spans[i].dst, spans[i].src, spans[i].n); });
   }
   dev->t_stage = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_stage0).count();
-  HS_HIP_DEV(hipMemcpyAsync(dblk, stage, total, hipMemcpyHostToDevice, ctx->stream));
-  HS_HIP_DEV(hipMemsetAsync(h.aln_probs, 0, out_bytes, ctx->stream));
+  HS_HIP_DEV(hipMemcpyAsync(dblk, stage, total, hipMemcpyHostToDevice, copy_stream));
+  HS_HIP_DEV(hipMemsetAsync(h.aln_probs, 0, out_bytes, copy_stream));
   HS_HIP_DEV(hipEventCreate(&dev->ev0)); HS_HIP_DEV(hipEventCreate(&dev->ev1));
+  HS_HIP_DEV(hipEventCreateWithFlags(&dev->ev_h2d, hipEventDisableTiming)); HS_HIP_DEV(hipEventCreateWithFlags(&dev->ev_done, hipEventDisableTiming));
+  HS_HIP_DEV(hipEventCreateWithFlags(&dev->ev_d2h, hipEventDisableTiming));
+  HS_HIP_DEV(hipEventRecord(dev->ev_h2d, copy_stream));
   return dev;
 }
+
+// Pipelined fetch: the device-to-host copy of aln_probs queued on `copy_stream` behind the batch's last pass; results_wait blocks
+// until it has landed in the batch's pinned buffer; scatter_loci then applies the reference's output contract for a range of loci.
+int hipstr::fetch_begin(hipstr_dev_batch_t* dev, hipStream_t compute_stream, hipStream_t copy_stream){
+  if (bind(dev->ctx)) return 1;
+  const hipstr::Prepared& P = dev->prep;
+  HS_HIP(hipEventRecord(dev->ev_done, compute_stream));
+  if (P.n_out && !dev->host_out){
+    dev->host_out = (double*)dev->ctx->pin_cache.get((size_t)P.n_out*sizeof(double));
+    if (!dev->host_out) return 1;
+    dev->pin_blocks.push_back(dev->host_out);
+  }
+  dev->d2h_stream = copy_stream;
+  HS_HIP(hipStreamWaitEvent(copy_stream, dev->ev_done, 0));
+  if (P.n_out) HS_HIP(hipMemcpyAsync(dev->host_out, dev->h.aln_probs, (size_t)P.n_out*sizeof(double), hipMemcpyDeviceToHost, copy_stream));
+  HS_HIP(hipEventRecord(dev->ev_d2h, copy_stream));
+  return 0;
+}
+int hipstr::results_wait(hipstr_dev_batch_t* dev){
+  if (bind(dev->ctx)) return 1;
+  HS_HIP(hipEventSynchronize(dev->ev_d2h));
+  return 0;
+}
+void hipstr::scatter_loci(const hipstr_dev_batch_t* dev, int l0, int l1, double* aln_probs, int32_t* seeds){
+  const hipstr::Prepared& P = dev->prep;
+  if (l1 <= l0) return;
+  const int64_t out0 = P.loci[l0].out_off; const int r0 = P.loci[l0].read_begin;
+  for (int li = l0; li < l1; li++){
+    const hs_locus_t& loc = P.loci[li];
+    const int A = loc.n_alleles;
+    const bool all_haps = loc.n_re == A;
+    for (int i = 0; i < loc.n_reads; i++){
+      const int r = loc.read_begin + i;
+      if (!P.realign_read[r]) continue;                       // HapAligner.cpp:326-329
+      seeds[r - r0] = P.seeds[r];
+      double* dst = aln_probs + (loc.out_off - out0) + (int64_t)i*A;
+      const double* src = dev->host_out + loc.out_off + (int64_t)i*A;
+      if (P.seeds[r] == -1){ for (int k = 0; k < A; k++) dst[k] = 0; continue; }   // HapAligner.cpp:333-337
+      if (all_haps) memcpy(dst, src, sizeof(double)*(size_t)A);
+      else for (int k = 0; k < A; k++) if (P.realign_hap[loc.hap_begin + k]) dst[k] = src[k];   // HapAligner.cpp:615-619
+    }
+  }
+}
+// Releases a batch whose results have landed on the host (its D2H event completed, hence every kernel that touched its blocks):
+// the blocks can go back to the cache without synchronising the stream, which would stall the batches queued behind it.
+void hipstr::free_landed(hipstr_dev_batch_t* dev, bool landed){
+  if (!dev) return;
+  if (landed && dev->ctx && bind(dev->ctx) == 0){
+    for (void* p : dev->dev_blocks) dev->ctx->dev_cache.put(p);
+    for (void* p : dev->pin_blocks) dev->ctx->pin_cache.put(p);
+    dev->dev_blocks.clear(); dev->pin_blocks.clear();
+  }
+  hipstr_hmm_free(dev);
+}
+hipStream_t hipstr::ctx_stream(Ctx* c){ return c->stream; }
+int hipstr::ctx_device(Ctx* c){ return c->device; }
+
+extern "C" {
 
 int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
   if (!dev) return fail("null device batch");
@@ -386,6 +467,7 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
   if (bind(dev->ctx)) return 1;
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : dev->ctx->stream;
   if (hip_stream && (hipStream_t)hip_stream != dev->ctx->stream) dev->foreign_stream = true;
+  if (dev->h2d_stream != st) HS_HIP(hipStreamWaitEvent(st, dev->ev_h2d, 0));          // the tables were sent on another stream
   const hs_dev_t* dp = dev->d_args;
   auto mark = [&]() -> int {
     if (!dev->profiling) return 0;

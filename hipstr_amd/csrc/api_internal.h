@@ -1,6 +1,7 @@
 // api_internal.h — state of api.hip shared with the other translation units of libhipstr_hmm.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 #include <string>
 
 namespace hipstr {
@@ -26,5 +27,18 @@ void* dev_alloc(Ctx* ctx, size_t bytes);      // NULL + last error on failure
 void  dev_free(Ctx* ctx, void* p);
 void* pin_alloc(Ctx* ctx, size_t bytes);
 void  pin_free(Ctx* ctx, void* p);
+
+
+// ---- the pieces of hipstr_hmm_process_reads, split for pipelined use (stream.hip)
+}  // namespace hipstr
+struct hipstr_batch; struct hipstr_dev_batch;
+namespace hipstr {
+hipstr_dev_batch* upload_on(Ctx* ctx, const hipstr_batch* batch, const int32_t* seed_base, hipStream_t copy_stream);
+int  fetch_begin(hipstr_dev_batch* dev, hipStream_t compute_stream, hipStream_t copy_stream);
+int  results_wait(hipstr_dev_batch* dev);
+void scatter_loci(const hipstr_dev_batch* dev, int l0, int l1, double* aln_probs, int32_t* seeds);   // outputs based at locus l0
+void free_landed(hipstr_dev_batch* dev, bool landed);
+hipStream_t ctx_stream(Ctx* c);
+int ctx_device(Ctx* c);
 
 }  // namespace hipstr

@@ -443,6 +443,40 @@ void fresh_flank_rows(const std::string side_seqs[3], std::vector<hs_row_t>& lea
 void append_stropt(const std::string& blk, int period, const double* stutter, Prepared& out){ emit_stropt(blk, period, stutter, out); }
 void debug_simple_table(int lim, int U0, int tail, double ent[3]){ g_bnd_scale = 1.0; simple_table_entry(lim, U0, tail, ent); }
 
+// The conditions under which prepare_batch refuses a batch, without building anything (same order, same messages): used where a
+// bad locus must be turned away before it is merged with others (hipstr_stream_submit).
+int check_batch(const hipstr_batch_t* b, std::string& err){
+  if (b == NULL || b->n_loci < 0){ err = "null or negative-size batch"; return 1; }
+  int opt_cursor = 0;
+  for (int l = 0; l < b->n_loci; l++){
+    const int period = b->period[l];
+    if (period < 1 || period > 9){ err = "STR period must be in [1,9] (stutter_model.h:38)"; return 1; }
+    int64_t A = 1;
+    for (int k = 0; k < 3; k++){
+      const int n = b->blk_nopts[3*l+k];
+      if (n < 1){ err = "haplotype block without options"; return 1; }
+      A *= n;
+      for (int o = 0; o < n; o++, opt_cursor++){
+        const int len = b->opt_off[opt_cursor+1] - b->opt_off[opt_cursor];
+        if (len < 0){ err = "opt_off must not decrease"; return 1; }
+        if (k != 1 && len == 0){ err = "empty flank sequence"; return 1; }
+        if (k == 1 && len == 0){ err = "empty STR allele is not supported"; return 1; }
+        if (k == 1 && len > 1024){ err = "STR allele longer than 1024 bp is not supported"; return 1; }
+      }
+    }
+    if (A != b->hap_off[l+1]-b->hap_off[l]){ err = "hap_off does not match the product of block options"; return 1; }
+    if (b->read_off[l+1] < b->read_off[l]){ err = "read_off must not decrease"; return 1; }
+    for (int r = b->read_off[l]; r < b->read_off[l+1]; r++){
+      if (b->realign_read && !b->realign_read[r]) continue;
+      const int len = b->base_off[r+1] - b->base_off[r];
+      const int s = calc_seed_base(b, l, r);
+      if (s == -2){ err = "Invalid alignment seed or unrecognized CIGAR char (HapAligner.cpp:309,316)"; return 1; }
+      if (s >= 0 && (s > HS_MAX_SIDE_LEN || len-s-1 > HS_MAX_SIDE_LEN)){ err = "read side longer than 256 bases is not supported"; return 1; }
+    }
+  }
+  return 0;
+}
+
 // Everything prepare_batch derives from ONE locus, appended to `out` — a fragment holding a run of consecutive loci whose pool
 // offsets are local to the fragment (merge_fragment rebases them).  Per-read records go straight to the batch-wide arrays in
 // `sh` (disjoint ranges per locus), so fragments can be built by different threads.

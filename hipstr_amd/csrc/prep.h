@@ -73,6 +73,9 @@ struct Prepared {
 // HIPSTR_SEED_AUTO entries are computed with calc_seed_base.
 int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int64_t ws_budget_doubles = (int64_t)3 << 30, const int32_t* seed_in = NULL);
 
+// Returns 0 if prepare_batch would accept the batch; otherwise its error message in err.
+int check_batch(const hipstr_batch_t* b, std::string& err);
+
 // HapAligner::calc_seed_base (HapAligner.cpp:238-318).  Returns -2 on the inputs the reference dies on.
 int calc_seed_base(const hipstr_batch_t* b, int locus, int read);
 

@@ -1,0 +1,288 @@
+// stream.hip — the host pipeline in front of the batched kernels: loci are submitted as they arrive — one
+// region at a time is how the reference's caller produces them (bam_processor.cpp:550-617, genotyper_bam_processor.cpp:229-243) —
+// and results come back in submission order, which is region order, the order the VCF writer needs (vcf_writer.cpp:7-36).
+//
+//   submit ──► pending batch ──(threshold / flush)──► ready queue ──► worker thread: prepare_batch on the host threads, tables to a
+//   pinned staging block, H2D on the copy stream, the phase kernels on the compute stream, D2H of aln_probs on the copy stream
+//   ──► in-flight queue ──► hipstr_stream_next: waits for the front batch's D2H event, applies the reference's output contract
+//   for the ticket's loci into the caller's arrays.
+//
+// While batch k runs on the device the worker prepares and uploads batch k+1 (launches are asynchronous), so with two or more
+// slots the device only idles when the host cannot keep up.  Host code only; every byte of arithmetic is in the kernels.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/hipstr_hmm.h"
+#include "api_internal.h"
+#include "prep.h"
+
+namespace {
+
+// A batch the library owns: deep copies of the submitted arrays, concatenated.
+struct OwnedBatch {
+  std::vector<int32_t> blk_start, blk_end, blk_nopts, period, opt_off, hap_off, read_off, base_off, read_start, cigar_off, cigar_len;
+  std::vector<double> stutter;
+  std::vector<uint8_t> realign_hap, realign_read;
+  std::string seq, bases, quals, cigar_op;
+  hipstr_batch_t view;
+  struct Ticket { int64_t id; int32_t l0, l1, r0, r1; int64_t out0, out1; };
+  std::vector<Ticket> tickets;
+  int64_t n_out = 0, work = 0;          // doubles of output; (reads x haplotypes) submitted
+  OwnedBatch(){ opt_off.push_back(0); hap_off.push_back(0); read_off.push_back(0); base_off.push_back(0); cigar_off.push_back(0); }
+
+  // 0 or an error message
+  const char* append(const hipstr_batch_t* b, int64_t ticket){
+    if (b->n_loci < 0) return "negative locus count";
+    const int n = b->n_loci;
+    int64_t n_opts = 0;
+    for (int i = 0; i < 3*n; i++){ if (b->blk_nopts[i] < 1) return "haplotype block without options"; n_opts += b->blk_nopts[i]; }
+    const int32_t n_haps = n ? b->hap_off[n] : 0, n_reads = n ? b->read_off[n] : 0;
+    const int32_t n_seq = n_opts ? b->opt_off[n_opts] : 0, n_bases = n_reads ? b->base_off[n_reads] : 0, n_cig = n_reads ? b->cigar_off[n_reads] : 0;
+    if ((int64_t)bases.size() + n_bases > INT32_MAX || (int64_t)seq.size() + n_seq > INT32_MAX) return "pending batch exceeds 2 GiB of bases";
+    Ticket t; t.id = ticket; t.l0 = (int32_t)period.size(); t.l1 = t.l0 + n; t.r0 = read_off.back(); t.r1 = t.r0 + n_reads; t.out0 = n_out;
+    blk_start.insert(blk_start.end(), b->blk_start, b->blk_start + 3*n); blk_end.insert(blk_end.end(), b->blk_end, b->blk_end + 3*n);
+    blk_nopts.insert(blk_nopts.end(), b->blk_nopts, b->blk_nopts + 3*n); period.insert(period.end(), b->period, b->period + n);
+    stutter.insert(stutter.end(), b->stutter, b->stutter + 6*n);
+    const int32_t seq0 = (int32_t)seq.size(), hap0 = hap_off.back(), rd0 = read_off.back(), base0 = (int32_t)bases.size(), cig0 = (int32_t)cigar_op.size();
+    for (int64_t i = 1; i <= n_opts; i++) opt_off.push_back(seq0 + b->opt_off[i]);
+    seq.append(b->seq, n_seq);
+    for (int l = 1; l <= n; l++){ hap_off.push_back(hap0 + b->hap_off[l]); read_off.push_back(rd0 + b->read_off[l]); }
+    for (int l = 0; l < n; l++){
+      const int64_t P = b->read_off[l+1] - b->read_off[l], A = b->hap_off[l+1] - b->hap_off[l];
+      if (P < 0 || A < 1) return "inconsistent read_off / hap_off";
+      n_out += P*A; work += P*A;
+    }
+    if (b->realign_hap) realign_hap.insert(realign_hap.end(), b->realign_hap, b->realign_hap + n_haps); else realign_hap.insert(realign_hap.end(), n_haps, 1);
+    for (int r = 1; r <= n_reads; r++){ base_off.push_back(base0 + b->base_off[r]); cigar_off.push_back(cig0 + b->cigar_off[r]); }
+    bases.append(b->bases, n_bases); quals.append(b->quals, n_bases);
+    read_start.insert(read_start.end(), b->read_start, b->read_start + n_reads);
+    cigar_op.append(b->cigar_op, n_cig); cigar_len.insert(cigar_len.end(), b->cigar_len, b->cigar_len + n_cig);
+    if (b->realign_read) realign_read.insert(realign_read.end(), b->realign_read, b->realign_read + n_reads); else realign_read.insert(realign_read.end(), n_reads, 1);
+    t.out1 = n_out;
+    tickets.push_back(t);
+    return NULL;
+  }
+  const hipstr_batch_t* finish(){
+    if (cigar_len.empty()) cigar_len.push_back(0);
+    view.n_loci = (int32_t)period.size();
+    view.blk_start = blk_start.data(); view.blk_end = blk_end.data(); view.blk_nopts = blk_nopts.data(); view.period = period.data();
+    view.stutter = stutter.data(); view.opt_off = opt_off.data(); view.seq = seq.data(); view.hap_off = hap_off.data();
+    view.realign_hap = realign_hap.data(); view.read_off = read_off.data(); view.base_off = base_off.data(); view.bases = bases.data();
+    view.quals = quals.data(); view.read_start = read_start.data(); view.cigar_off = cigar_off.data(); view.cigar_op = cigar_op.data();
+    view.cigar_len = cigar_len.data(); view.realign_read = realign_read.data();
+    return &view;
+  }
+};
+
+struct InFlight {
+  OwnedBatch* ob = NULL;
+  hipstr_dev_batch_t* dev = NULL;
+  size_t next_ticket = 0;         // index into ob->tickets of the next one to deliver
+  bool failed = false, landed = false;
+  std::string err;
+};
+
+}  // namespace
+
+struct hipstr_stream {
+  hipstr::Ctx* ctx = NULL;
+  hipStream_t copy_stream = NULL, d2h_stream = NULL;     // tables to the device / results back: neither waits for the other
+  int slots = 3;
+  int64_t batch_work = (int64_t)4 << 20;
+  std::mutex m;
+  std::condition_variable cv_work, cv_done, cv_slots;
+  OwnedBatch* pending = NULL;
+  std::deque<OwnedBatch*> ready;
+  std::deque<InFlight*> flying;   // launched (or failed), in submission order
+  int in_worker = 0;              // batches the worker has popped but not yet pushed to `flying`
+  int64_t next_ticket = 0, next_deliver = 0;
+  std::vector< std::pair<int64_t,int64_t> > sizes;     // per ticket not yet delivered: (n_out, n_reads), indexed by ticket - sizes_base
+  int64_t sizes_base = 0;
+  bool closing = false;
+  std::thread worker;
+  hipstr_stream_stats_t stats;
+  std::chrono::steady_clock::time_point t_open;
+};
+
+namespace {
+
+void worker_loop(hipstr_stream* s){
+  hipstr::api_bind(s->ctx);
+  for (;;){
+    OwnedBatch* ob = NULL;
+    {
+      std::unique_lock<std::mutex> g(s->m);
+      s->cv_work.wait(g, [&]{ return s->closing || (!s->ready.empty() && (int)s->flying.size() + s->in_worker < s->slots); });
+      if (s->closing) return;
+      ob = s->ready.front(); s->ready.pop_front(); s->in_worker++;
+    }
+    InFlight* f = new InFlight(); f->ob = ob;
+    const auto t0 = std::chrono::steady_clock::now();
+    f->dev = hipstr::upload_on(s->ctx, ob->finish(), NULL, s->copy_stream);
+    if (!f->dev){ f->failed = true; f->err = hipstr_last_error(); }
+    else if (hipstr_hmm_align(f->dev, NULL) != 0 || hipstr::fetch_begin(f->dev, hipstr::ctx_stream(s->ctx), s->d2h_stream) != 0){
+      f->failed = true; f->err = hipstr_last_error();
+    }
+    const double host_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    {
+      std::lock_guard<std::mutex> g(s->m);
+      s->flying.push_back(f); s->in_worker--;
+      s->stats.batches++; s->stats.host_seconds += host_s; s->stats.alignment_slots += ob->work;
+    }
+    s->cv_done.notify_all();
+  }
+}
+
+void flush_locked(hipstr_stream* s){
+  if (s->pending && !s->pending->tickets.empty()){ s->ready.push_back(s->pending); s->pending = NULL; s->cv_work.notify_one(); }
+}
+
+}  // namespace
+
+extern "C" {
+
+hipstr_stream_t* hipstr_stream_open(const hipstr_stream_opts_t* opts){
+  const int device = opts ? opts->device : 0;
+  if (hipstr_hmm_init(device) != 0) return NULL;
+  hipstr_stream* s = new hipstr_stream();
+  s->ctx = hipstr::api_current_ctx();
+  if (!s->ctx){ delete s; return NULL; }
+  if (opts && opts->slots > 0) s->slots = opts->slots;
+  if (opts && opts->batch_alignments > 0) s->batch_work = opts->batch_alignments;
+  if (hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s->d2h_stream, hipStreamNonBlocking) != hipSuccess){
+    hipstr::api_fail("hipStreamCreate failed"); delete s; return NULL; }
+  memset(&s->stats, 0, sizeof s->stats);
+  s->t_open = std::chrono::steady_clock::now();
+  s->worker = std::thread(worker_loop, s);
+  return s;
+}
+
+int64_t hipstr_stream_submit(hipstr_stream_t* s, const hipstr_batch_t* loci){
+  if (!s || !loci){ hipstr::api_fail("null argument"); return -1; }
+  {       // a submission that prepare_batch would refuse is turned away here, before it shares a batch with others
+    std::string why;
+    if (hipstr::check_batch(loci, why)){ hipstr::api_fail(why); return -1; }
+  }
+  std::lock_guard<std::mutex> g(s->m);
+  if (s->closing){ hipstr::api_fail("stream is closing"); return -1; }
+  if (!s->pending) s->pending = new OwnedBatch();
+  const int64_t ticket = s->next_ticket;
+  const int64_t out_before = s->pending->n_out; const int32_t reads_before = s->pending->read_off.back();
+  if (const char* why = s->pending->append(loci, ticket)){ hipstr::api_fail(why); return -1; }
+  s->next_ticket++;
+  s->sizes.push_back(std::make_pair(s->pending->n_out - out_before, (int64_t)(s->pending->read_off.back() - reads_before)));
+  if (s->pending->work >= s->batch_work) flush_locked(s);
+  return ticket;
+}
+
+int hipstr_stream_flush(hipstr_stream_t* s){
+  if (!s) return hipstr::api_fail("null argument");
+  std::lock_guard<std::mutex> g(s->m);
+  flush_locked(s);
+  return 0;
+}
+
+int hipstr_stream_next_size(hipstr_stream_t* s, int64_t* ticket, int64_t* n_out, int64_t* n_reads){
+  if (!s) return hipstr::api_fail("null argument");
+  std::lock_guard<std::mutex> g(s->m);
+  if (s->next_deliver >= s->next_ticket) return 2;
+  const std::pair<int64_t,int64_t>& z = s->sizes[(size_t)(s->next_deliver - s->sizes_base)];
+  if (ticket) *ticket = s->next_deliver;
+  if (n_out) *n_out = z.first;
+  if (n_reads) *n_reads = z.second;
+  return 0;
+}
+
+int hipstr_stream_next(hipstr_stream_t* s, int64_t* ticket, double* aln_probs, int64_t cap_probs, int32_t* seeds, int64_t cap_seeds){
+  if (!s) return hipstr::api_fail("null argument");
+  InFlight* f = NULL;
+  {
+    std::unique_lock<std::mutex> g(s->m);
+    if (s->next_deliver >= s->next_ticket) return 2;                     // nothing outstanding
+    // the ticket may still sit in the pending batch: send it on its way
+    if (s->pending && !s->pending->tickets.empty() && s->pending->tickets.front().id <= s->next_deliver) flush_locked(s);
+    s->cv_done.wait(g, [&]{ return !s->flying.empty(); });
+    f = s->flying.front();
+  }
+  const OwnedBatch::Ticket& t = f->ob->tickets[f->next_ticket];
+  int rc = 0;
+  if (f->failed) rc = hipstr::api_fail("batch failed: " + f->err);
+  else if (t.out1 - t.out0 > cap_probs || t.r1 - t.r0 > cap_seeds) return hipstr::api_fail("output buffers are too small for the next ticket (hipstr_stream_next_size)");
+  else {
+    if (!f->landed){
+      const auto t0 = std::chrono::steady_clock::now();
+      if (hipstr::results_wait(f->dev) != 0){ f->failed = true; f->err = hipstr_last_error(); rc = 1; }
+      f->landed = true;
+      std::lock_guard<std::mutex> g(s->m);
+      s->stats.wait_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (!rc){
+      if ((t.out1 - t.out0) > ((int64_t)1 << 20) && t.l1 - t.l0 >= 8){       // a big ticket: loci are independent, share them among the host threads
+        const hipstr_dev_batch_t* dev = f->dev;
+        const int nl = t.l1 - t.l0, parts = std::min(nl, hipstr::host_threads()*2);
+        const OwnedBatch* ob = f->ob;
+        hipstr::parallel_for(parts, hipstr::host_threads(), [&](int p){
+          const int a = t.l0 + (int)((int64_t)nl*p/parts), b = t.l0 + (int)((int64_t)nl*(p+1)/parts);
+          if (b <= a) return;
+          int64_t out_a = t.out0;       // output offset of locus a relative to the ticket: sum of P*A of the loci before it
+          for (int l = t.l0; l < a; l++) out_a += (int64_t)(ob->read_off[l+1] - ob->read_off[l])*(ob->hap_off[l+1] - ob->hap_off[l]);
+          hipstr::scatter_loci(dev, a, b, aln_probs + (out_a - t.out0), seeds + (ob->read_off[a] - t.r0));
+        });
+      } else hipstr::scatter_loci(f->dev, t.l0, t.l1, aln_probs, seeds);
+    }
+  }
+  if (ticket) *ticket = t.id;
+  bool retire = false;
+  {
+    std::lock_guard<std::mutex> g(s->m);
+    s->next_deliver = t.id + 1;
+    f->next_ticket++;
+    s->stats.tickets++;
+    if (f->next_ticket == f->ob->tickets.size()){ s->flying.pop_front(); retire = true; }
+    // drop delivered entries of the size table now and then
+    if (s->next_deliver - s->sizes_base > 4096){ s->sizes.erase(s->sizes.begin(), s->sizes.begin() + (size_t)(s->next_deliver - s->sizes_base)); s->sizes_base = s->next_deliver; }
+  }
+  if (retire){
+    if (f->dev) hipstr::free_landed(f->dev, f->landed && !f->failed);
+    delete f->ob; delete f;
+    s->cv_work.notify_one();           // a slot is free
+  }
+  return rc;
+}
+
+int hipstr_stream_stats(hipstr_stream_t* s, hipstr_stream_stats_t* out){
+  if (!s || !out) return hipstr::api_fail("null argument");
+  std::lock_guard<std::mutex> g(s->m);
+  *out = s->stats;
+  out->open_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - s->t_open).count();
+  return 0;
+}
+
+int hipstr_stream_close(hipstr_stream_t* s){
+  if (!s) return 0;
+  {
+    std::lock_guard<std::mutex> g(s->m);
+    s->closing = true;
+    for (OwnedBatch* ob : s->ready) delete ob;          // undelivered work is dropped
+    s->ready.clear();
+    delete s->pending; s->pending = NULL;
+  }
+  s->cv_work.notify_all();
+  if (s->worker.joinable()) s->worker.join();
+  hipstr::api_bind(s->ctx);
+  for (InFlight* f : s->flying){ if (f->dev) hipstr::free_landed(f->dev, false); delete f->ob; delete f; }
+  hipStreamSynchronize(s->copy_stream); hipStreamSynchronize(s->d2h_stream);
+  hipStreamDestroy(s->copy_stream); hipStreamDestroy(s->d2h_stream);
+  delete s;
+  return 0;
+}
+
+}  // extern "C"

@@ -163,6 +163,42 @@ int hipstr_hmm_process_reads(const hipstr_batch_t* batch, double* aln_probs, int
 hipstr_dev_batch_t* hipstr_hmm_upload_seeded(const hipstr_batch_t* batch, const int32_t* seed_base /* [n_reads] or NULL */);
 int hipstr_hmm_process_reads_seeded(const hipstr_batch_t* batch, const int32_t* seed_base, double* aln_probs, int32_t* seeds);
 
+/*
+ * Streaming form of hipstr_hmm_process_reads: the host pipeline between a caller that produces loci one region at a time — as
+ * the reference's does (BamProcessor::process_regions, bam_processor.cpp:550-617 -> GenotyperBamProcessor::analyze_reads_and_phasing,
+ * genotyper_bam_processor.cpp:229-243) — and kernels that want ~10^6-10^7 alignments per launch.  Submitted loci are copied, collected
+ * into batches of about `batch_alignments` (reads x haplotypes), prepared on the host threads and sent while the previous batch
+ * still runs on the device (`slots` batches may be in flight), and results are handed back STRICTLY IN SUBMISSION ORDER: with
+ * loci submitted in region order that is the order the VCF writer needs (vcf_writer.cpp:7-36), i.e. the per-GPU ordered gather.
+ * One stream per device; a stream may be fed from one thread and drained from another.
+ */
+typedef struct hipstr_stream hipstr_stream_t;
+typedef struct hipstr_stream_opts {
+  int32_t device;             /* ordinal; hipstr_stream_open initialises it like hipstr_hmm_init                              */
+  int32_t slots;              /* batches in flight (prepared / running / waiting to be collected); 0 = 3                      */
+  int64_t batch_alignments;   /* a pending batch is sent once it holds this many (read x haplotype) pairs; 0 = 4 Mi           */
+} hipstr_stream_opts_t;
+typedef struct hipstr_stream_stats {
+  int64_t batches, tickets, alignment_slots;  /* batches launched, tickets delivered, (read x haplotype) pairs submitted       */
+  double  host_seconds;       /* worker thread: prepare + staging + launches, summed over batches                              */
+  double  wait_seconds;       /* hipstr_stream_next: time spent waiting for a batch to land                                    */
+  double  open_seconds;       /* since hipstr_stream_open                                                                      */
+} hipstr_stream_stats_t;
+hipstr_stream_t* hipstr_stream_open(const hipstr_stream_opts_t* opts /* NULL = defaults on device 0 */);
+/* Queues the loci of `loci` (1..n loci; arrays are copied).  Returns the submission's ticket (0, 1, 2, ...) or -1. */
+int64_t hipstr_stream_submit(hipstr_stream_t* s, const hipstr_batch_t* loci);
+/* Sends the pending batch now, whatever its size. */
+int hipstr_stream_flush(hipstr_stream_t* s);
+/* Sizes of the next submission to be delivered: n_out doubles of aln_probs, n_reads seeds.  Returns 2 when nothing is outstanding. */
+int hipstr_stream_next_size(hipstr_stream_t* s, int64_t* ticket, int64_t* n_out, int64_t* n_reads);
+/* Blocks until the next submission (in submission order) is done and writes its results exactly as hipstr_hmm_process_reads
+ * would have for that submission alone: aln_probs / seeds laid out as hipstr_batch_out_offsets of the submitted batch, entries of
+ * reads / haplotypes that were not realigned left untouched.  Returns 0, 1 on error, 2 when nothing is outstanding. */
+int hipstr_stream_next(hipstr_stream_t* s, int64_t* ticket, double* aln_probs, int64_t cap_probs, int32_t* seeds, int64_t cap_seeds);
+int hipstr_stream_stats(hipstr_stream_t* s, hipstr_stream_stats_t* out);
+/* Drops whatever has not been delivered and releases the stream. */
+int hipstr_stream_close(hipstr_stream_t* s);
+
 /* HapAligner::calc_seed_base (HapAligner.cpp:270-318) for every read of a batch,
  * host only (no device needed): seeds[r] = read offset of the seed base or -1.
  * Returns non-zero on the inputs the reference dies on ("Invalid alignment

@@ -1,0 +1,103 @@
+"""GPU: hipstr_stream_* — loci submitted one region at a time (the way the reference's caller produces them,
+bam_processor.cpp:550-617), batched and pipelined by the library, results handed back in submission order.  Every submission
+must come back exactly as hipstr_hmm_process_reads would have answered it alone (bit-identical rows and seeds, untouched
+entries untouched), whatever batching the stream chose."""
+import numpy as np
+import pytest
+
+from hipstr_amd import capi, shard
+import util
+
+pytestmark = pytest.mark.gpu
+FILL = -4.25
+
+
+def _pieces(sb, cuts):
+    a = util.synth_to_batch(sb).arrays
+    return [shard.batch_from_arrays(shard.subset_arrays(a, lo, hi)) for lo, hi in zip(cuts[:-1], cuts[1:])]
+
+
+@pytest.mark.parametrize("threshold,slots", [(1, 2), (3000, 3), (1 << 40, 2)])
+def test_stream_matches_one_shot_calls(hmm, threshold, slots):
+    """40 loci with masks, submitted as 1-3 loci per ticket; thresholds from 'every ticket its own batch' to 'one batch, flushed
+    by next()'."""
+    sb = capi.SynthBatch(n_loci=40, reads_per_locus=25, n_str_alleles=7, n_flank_opts=2, seed=9, mask_rate=0.2)
+    rng = np.random.default_rng(1)
+    cuts = [0]
+    while cuts[-1] < 40:
+        cuts.append(min(40, cuts[-1] + int(rng.integers(1, 4))))
+    pieces = _pieces(sb, cuts)
+    want = [capi.run_align(hmm, "hipstr_hmm_", p.ptr, fill=FILL) for p in pieces]
+    st = capi.Stream(hmm, slots=slots, batch_alignments=threshold)
+    got = []
+    tickets = []
+    for i, p in enumerate(pieces):          # interleave submission and collection
+        tickets.append(st.submit(p.ptr))
+        if i % 5 == 4:
+            got.append(st.next(fill=FILL))
+    while True:
+        r = st.next(fill=FILL)
+        if r is None:
+            break
+        got.append(r)
+    assert tickets == list(range(len(pieces))) and [g[0] for g in got] == tickets
+    for (t, probs, seeds), (wp, ws) in zip(got, want):
+        assert np.array_equal(probs, wp) and np.array_equal(seeds, ws), "ticket %d" % t
+    s = st.stats()
+    assert s["tickets"] == len(pieces) and s["batches"] >= (len(pieces) if threshold == 1 else 1)
+    st.close()
+
+
+def test_stream_against_the_oracle_and_empty_cases(hmm, oracle):
+    sb = capi.SynthBatch(n_loci=6, reads_per_locus=30, n_str_alleles=10, seed=21)
+    st = capi.Stream(hmm, batch_alignments=500)
+    assert st.next() is None                                   # nothing outstanding
+    empty = capi.Batch().finalize()
+    pieces = _pieces(sb, list(range(7)))
+    t0 = st.submit(pieces[0].ptr); te = st.submit(empty.ptr)   # an empty submission is a ticket like any other
+    for p in pieces[1:]:
+        st.submit(p.ptr)
+    res = []
+    while True:
+        r = st.next()
+        if r is None:
+            break
+        res.append(r)
+    assert [r[0] for r in res] == list(range(7)) and res[te][1].size == 0 and t0 == 0
+    want, wseeds = capi.run_align(oracle, "oracle_", sb.ptr)
+    assert np.array_equal(np.concatenate([r[1] for r in res]), want) and np.array_equal(np.concatenate([r[2] for r in res]), wseeds)
+    st.close()
+
+
+def test_bad_submission_is_refused_alone(hmm):
+    """A locus prepare_batch would refuse is turned away at submit; its neighbours are unaffected."""
+    good = capi.SynthBatch(n_loci=2, reads_per_locus=10, n_str_alleles=4, seed=2)
+    bad, _ = util.simple_locus("ACGTTGCATGCATGACC", ["GA" * 6, ""], "TTGACCGTAGGCTAGG", 2, [])
+    bad.finalize()
+    st = capi.Stream(hmm)
+    st.submit(good.ptr)
+    with pytest.raises(RuntimeError, match="empty STR allele"):
+        st.submit(bad.ptr)
+    st.submit(good.ptr)
+    a = st.next(); b = st.next()
+    assert a[0] == 0 and b[0] == 1 and np.array_equal(a[1], b[1]) and st.next() is None
+    st.close()
+
+
+def test_large_stream_full_rate(hmm):
+    """200 NS-shaped loci through the stream in tickets of 10: identical to the one-shot result of the whole batch."""
+    sb = capi.SynthBatch(n_loci=200, reads_per_locus=500, n_str_alleles=32, seed=20260928)
+    want, wseeds = capi.run_align(hmm, "hipstr_hmm_", sb.ptr)
+    pieces = _pieces(sb, list(range(0, 201, 10)))
+    st = capi.Stream(hmm, slots=3, batch_alignments=1 << 20)
+    for p in pieces:
+        st.submit(p.ptr)
+    out, seeds = [], []
+    while True:
+        r = st.next()
+        if r is None:
+            break
+        out.append(r[1]); seeds.append(r[2])
+    assert np.array_equal(np.concatenate(out), want) and np.array_equal(np.concatenate(seeds), wseeds)
+    assert st.stats()["batches"] >= 3
+    st.close()
