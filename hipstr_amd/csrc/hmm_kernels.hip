@@ -24,7 +24,9 @@
 // bit-identical to the CPU path.  Compile with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <cstddef>
+#include <cstdlib>
 #include <type_traits>
 
 #ifdef __HIP_DEVICE_COMPILE__
@@ -325,6 +327,264 @@ __global__ void __launch_bounds__(64, HS_FLANK_WAVES) hs_lead_kernel(const hs_de
       }
       row0 += nr;
     }
+  }
+}
+
+// ------------------------------------------------------------------ flank blocks, cooperative form: bands as the wavefronts of one workgroup
+// The banded sweep above runs the bands of an item one after the other and hands the boundary row of every column from band to band
+// through an HBM scratch row (1 KB per column per hand-over: ~150 KB per item at the north-star shape, the largest traffic of the
+// whole pass).  Here the HS_COOP_WAVES wavefronts of a workgroup take one band each and run them as a pipeline, wavefront w working
+// on column t - w at step t: the boundary of a column travels through a two-slot LDS ring (16 B x 64 lanes), a workgroup barrier
+// per step keeps the wavefronts one column apart, and an item takes nmax + nb - 1 steps instead of nb * nmax.  Fewer rows per
+// wavefront also means the row constants fit the SGPR file and the state fits 3 wavefronts per SIMD.  Same cells, same operation
+// order per cell: bit-identical to the serial sweep.  Blocks with more rows than HS_COOP_WAVES x HS_COOP_ROWS run in rounds of
+// HS_COOP_WAVES bands, the boundary between rounds going through the scratch row as before.
+#ifndef HS_COOP_WAVES
+#define HS_COOP_WAVES 4
+#endif
+#ifndef HS_COOP_ROWS
+#define HS_COOP_ROWS 15
+#endif
+#ifndef HS_COOP_VGPR_CONSTS
+#define HS_COOP_VGPR_CONSTS 0     // measured (profiles/r02_notes.md): 16 instead of 18 instructions per cell, but 2 wavefronts per SIMD instead of 3: 5 % slower
+#endif
+#ifndef HS_COOP_OCC
+#define HS_COOP_OCC (HS_COOP_VGPR_CONSTS ? 2 : 3)         // wavefronts per SIMD the register allocation aims at
+#endif
+
+// LDS operations of this wavefront are complete (and its global stores, when it hands a boundary over through memory), then the
+// workgroup barrier.  Unlike __syncthreads() this does not wait for the global LOADS in flight — the next column's prefetch.
+__device__ __forceinline__ void coop_barrier(bool drain_stores){
+  if (drain_stores) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int NR, bool FIRST, bool LAST, bool LEAD>
+__device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, bool live, int n, int nmax, const double* __restrict__ col,
+                                                const hs_row_t* __restrict__ rows, int row0, int c0, const double* __restrict__ mr,
+                                                double* __restrict__ bnd, bool topg, bool botg, const double2* lds_top, double2* lds_bot,
+                                                double* __restrict__ lt, double* __restrict__ rowp, double* __restrict__ side_out,
+                                                int skew, int nsteps){
+  int hc[NR]; double m2m[NR], m2i[NR];
+#pragma unroll
+  for (int r = 0; r < NR; r++){
+    const int meta = uni((int)rows[row0 + r]);
+    hc[r] = meta & 0xff;
+    m2m[r] = uni(d.m2m[(meta >> 8) & 15]); m2i[r] = uni(d.m2i[(meta >> 8) & 15]);
+#if HS_COOP_VGPR_CONSTS
+    // The transition logs of NR rows do not fit the SGPR file next to everything else: the compiler parks them in VGPR lanes and pays
+    // two v_readlane_b32 (4 cycles each, profiles/*_valu_microbench.json) per cell to get them back.  Held in VGPRs on purpose they
+    // cost registers (2 wavefronts per SIMD instead of 3) but no instructions — which measured slower: the serial D chain down a
+    // column (2 dependent FP64 operations per row) needs the third wavefront to hide its latency.
+    asm volatile("" : "+v"(m2m[r]), "+v"(m2i[r]));
+#endif
+  }
+  double Mp[NR], Dp[NR], Ip[NR];
+  double nx_blc = col[0], nx_blw = col[1], nx_rd = col[2];
+  double nx_mr = 0.0;
+  double diagM = 0, diagD = 0;
+  double pre = 0.0;                              // LEAD: left_prob, a strictly sequential sum in the reference
+  for (int t = 0; t < nsteps; t++){
+    const int j = t - skew;
+    if (j >= 0 && j < nmax){
+      const double blcj = nx_blc, blwj = nx_blw; const int rdj = (int)nx_rd;
+      const double cur_mr = nx_mr;
+      double2 cur_b = make_double2(0.0, 0.0);
+      if (!FIRST) cur_b = topg ? *(const double2*)(bnd + ((size_t)j*64 + lane)*2) : lds_top[(j & 1)*64 + lane];
+      {
+        const int jn = min(j + 1, n - 1);           // a lane past its own read end keeps re-reading its last column
+        nx_blc = col[3*jn]; nx_blw = col[3*jn+1]; nx_rd = col[3*jn+2];
+        if (FIRST && !LEAD) nx_mr = mr[jn - 1 >= 0 ? jn - 1 : 0];
+      }
+      double upM, upD;
+      if (FIRST){
+        const double e0 = (rdj == c0) ? blcj : blwj;
+        if (LEAD){
+          upM = e0 + pre;
+          pre += blcj;
+          if (j == n-1 && live) *side_out = pre;                     // side_prob: the whole side hangs off the haplotype
+        } else upM = (j == 0) ? e0 : e0 + cur_mr;
+        upD = IMP;
+        if (j == n-1 && live) lt[0] = upM;
+      } else { upM = cur_b.x; upD = cur_b.y; }
+      const double topM = upM, topD = upD;
+      if (j == 0){
+#pragma unroll
+        for (int r = 0; r < NR; r++){           // first read column (HapAligner.cpp:123-126)
+          const double e = (rdj == hc[r]) ? blcj : blwj;
+          const double nD = fmax(upM + T_D2M, upD + T_D2D);
+          Mp[r] = e; Ip[r] = blcj; Dp[r] = nD;
+          upM = e; upD = nD;
+        }
+      } else {
+        // as in band_sweep: M and I bottom-up in place, then D top-down through the new M
+#pragma unroll
+        for (int r = NR - 1; r >= 0; r--){
+          const double e = (rdj == hc[r]) ? blcj : blwj;
+          const double dM = (r == 0) ? diagM : Mp[r > 0 ? r-1 : 0], dD = (r == 0) ? diagD : Dp[r > 0 ? r-1 : 0];
+          const double nM = e + fmax(dM + m2m[r], fmax(Ip[r], dD) + m2i[r]);
+          const double nI = blcj + fmax(dM + T_I2M, Ip[r] + T_I2I);
+          Mp[r] = nM; Ip[r] = nI;
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++){
+          const double nD = fmax(upM + T_D2M, upD + T_D2D);
+          Dp[r] = nD;
+          upM = Mp[r]; upD = nD;
+        }
+      }
+      if (!LAST){
+        if (botg) *(double2*)(bnd + ((size_t)j*64 + lane)*2) = make_double2(upM, upD);
+        else lds_bot[(j & 1)*64 + lane] = make_double2(upM, upD);
+      } else if (LEAD){ if (j < n && live) rowp[j] = upM; }
+      diagM = topM; diagD = topD;                // top boundary of this column = diagonal of the band's first row next column
+      if (j == n-1 && live){
+#pragma unroll
+        for (int r = 0; r < NR; r++) lt[row0 + r] = Mp[r];           // last read column of this lane's read
+      }
+    }
+    coop_barrier(botg);
+  }
+}
+
+template <int NR, bool LEAD>
+__device__ __forceinline__ void band_dispatch_coop(bool first, bool last, const hs_dev_t& d, int lane, bool live, int n, int nmax, const double* col,
+                                                   const hs_row_t* rows, int row0, int c0, const double* mr, double* bnd, bool topg, bool botg,
+                                                   const double2* lds_top, double2* lds_bot, double* lt, double* rowp, double* side_out, int skew, int nsteps){
+  if (first){ if (last) band_sweep_coop<NR, true, true, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps);
+              else      band_sweep_coop<NR, true, false, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps); }
+  else      { if (last) band_sweep_coop<NR, false, true, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps);
+              else      band_sweep_coop<NR, false, false, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps); }
+}
+
+// The rounds of one item: `n_rows` haplotype rows (after the block's first row) cut into bands, HS_COOP_WAVES bands per round, one per wavefront.
+template <int R, bool LEAD>
+__device__ __forceinline__ void coop_rounds(const hs_dev_t& d, int w, int lane, bool live, int n, int nmax, const double* col, const hs_row_t* rows, int n_rows, int c0,
+                                            const double* mr, double* bnd, double2 (*ring)[2*64], double* lt, double* rowp, double* side_out){
+  // as many bands as there are wavefronts whenever the rows allow it (all wavefronts busy), more rounds only for blocks deeper than one round holds
+  const int rounds = (n_rows + R*HS_COOP_WAVES - 1) / (R*HS_COOP_WAVES);
+  const int nbands = min(n_rows, rounds*HS_COOP_WAVES);
+  const int nr_base = n_rows / nbands, nr_rem = n_rows - nr_base*nbands;
+  for (int g = 0; g < rounds; g++){
+    const int nb_round = min(HS_COOP_WAVES, nbands - g*HS_COOP_WAVES);
+    const int nsteps = nmax + nb_round - 1;
+    const int b = g*HS_COOP_WAVES + w;
+    if (w < nb_round){
+      const int nr = nr_base + (b < nr_rem ? 1 : 0);
+      const int row0 = 1 + b*nr_base + min(b, nr_rem);
+      const bool first = (b == 0), last = (b + 1 == nbands);
+      const bool topg = (w == 0) && (g > 0), botg = (w + 1 == nb_round) && !last;
+      const double2* lds_top = ring[w > 0 ? w - 1 : 0]; double2* lds_bot = ring[w];
+      switch (nr){
+#define HS_COOP_CASE(N_) case N_: if (N_ <= R) band_dispatch_coop<(N_ <= R ? N_ : 1), LEAD>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, nsteps); break;
+        HS_COOP_CASE(1) HS_COOP_CASE(2) HS_COOP_CASE(3) HS_COOP_CASE(4) HS_COOP_CASE(5) HS_COOP_CASE(6) HS_COOP_CASE(7) HS_COOP_CASE(8)
+        HS_COOP_CASE(9) HS_COOP_CASE(10) HS_COOP_CASE(11) HS_COOP_CASE(12) HS_COOP_CASE(13) HS_COOP_CASE(14) HS_COOP_CASE(15) HS_COOP_CASE(16)
+        HS_COOP_CASE(17) HS_COOP_CASE(18) HS_COOP_CASE(19) HS_COOP_CASE(20)
+#undef HS_COOP_CASE
+        default: for (int t = 0; t < nsteps; t++) coop_barrier(false); break;
+      }
+    } else for (int t = 0; t < nsteps; t++) coop_barrier(false);       // a wavefront without a band in this round keeps the step count
+  }
+}
+
+template <int R>
+__global__ void __launch_bounds__(64*HS_COOP_WAVES, HS_COOP_OCC) hs_trail_kernel_coop(const hs_dev_t* __restrict__ dp, int item_begin, int item_end, int chunk){
+  const hs_dev_t& d = *dp;
+  const int lane = threadIdx.x & 63, w = uni((int)(threadIdx.x >> 6));
+  __shared__ double2 ring[HS_COOP_WAVES][2*64];
+  __shared__ int s_item;
+  double* const bnd = d.ws_band + (size_t)blockIdx.x * d.band_cols * 64 * 2;
+  int32_t* const ctr = d.redo + d.n_active + chunk;
+  for (;;){
+    if (threadIdx.x == 0) s_item = atomicAdd(ctr, 1);
+    __syncthreads();
+    const int item = item_begin + uni(s_item);
+    __syncthreads();
+    if (item >= item_end) break;
+    const hs_item_t* it = d.items + item;
+    const int side = uni(it->side), nreads = uni(it->rowset);
+    const hs_tgroup_t* g = d.tgroups + uni(it->slot);
+    const int nm = uni(g->n_members);
+    int npad = 1; while (npad < nm) npad <<= 1;
+    const int sub = lane / npad, slot = lane - sub*npad;
+    const bool live = (sub < nreads) && (slot < nm);
+    const int ai = d.tpack[uni(it->active) + min(sub, nreads-1)];
+    const int r = d.active[ai];
+    const hs_read_t rdv = d.reads[r];
+    const hs_locus_t* loc = d.loci + uni(rdv.locus);
+    const int nL = rdv.seed, n = side ? rdv.len - rdv.seed - 1 : rdv.seed;
+    const int nmax = uni(wave_max_i(n));
+    const hs_ws_t wsr = d.ws[ai];
+    const int k = d.tmembers[uni(g->member_off) + min(slot, nm-1)];
+    const hs_allele_t* al = d.alleles + uni(loc->hap_begin) + k;
+    const int ord = al->re_ord;
+    const double* mr = d.ws_mr + wsr.mr + (int64_t)ord*(rdv.len-1) + (side ? nL : 0);
+    double* lt = d.ws_lt + wsr.lt + (int64_t)ord*uni(loc->lt_stride) + (side ? d.rowsets[al->trail_rows[0]].len : 0);
+    const double* col = d.ws_col + wsr.col + 3*(int64_t)(side ? nL : 0);
+    const int rowset = uni(g->rowset);
+    const int rs_off = uni(d.rowsets[rowset].off), rs_len = uni(d.rowsets[rowset].len);
+    const hs_row_t* rows = d.rows + rs_off;
+    const int c0 = uni((int)rows[0]) & 0xff;
+    if (rs_len - 1 == 0){     // the block is the single "must be followed by a match" row (HapAligner.cpp:130-139)
+      if (w == 0){
+        const int j = n - 1;
+        const double blcj = col[3*j], blwj = col[3*j+1]; const int rdj = (int)col[3*j+2];
+        const double e0 = (rdj == c0) ? blcj : blwj;
+        if (live) lt[0] = (j == 0) ? e0 : e0 + mr[max(j-1, 0)];
+      }
+      continue;
+    }
+    coop_rounds<R, false>(d, w, lane, live, n, nmax, col, rows, rs_len - 1, c0, mr, bnd, ring, lt, NULL, NULL);
+  }
+}
+
+template <int R>
+__global__ void __launch_bounds__(64*HS_COOP_WAVES, HS_COOP_OCC) hs_lead_kernel_coop(const hs_dev_t* __restrict__ dp, int item_begin, int item_end, int chunk){
+  const hs_dev_t& d = *dp;
+  const int lane = threadIdx.x & 63, w = uni((int)(threadIdx.x >> 6));
+  __shared__ double2 ring[HS_COOP_WAVES][2*64];
+  __shared__ int s_item;
+  double* const bnd = d.ws_band + (size_t)blockIdx.x * d.band_cols * 64 * 2;
+  int32_t* const ctr = d.redo + d.n_active + chunk;
+  for (;;){
+    if (threadIdx.x == 0) s_item = atomicAdd(ctr, 1);
+    __syncthreads();
+    const int item = item_begin + uni(s_item);
+    __syncthreads();
+    if (item >= item_end) break;
+    const hs_item_t* it = d.items + item;
+    const int side = uni(it->side) & 1, slot = uni(it->side) >> 1, nreads = uni(it->slot);
+    const bool live = lane < nreads;
+    const int ai = d.tpack[uni(it->active) + min(lane, nreads-1)];
+    const hs_read_t rdv = d.reads[d.active[ai]];
+    const hs_locus_t* loc = d.loci + uni(rdv.locus);
+    const int nL = rdv.seed, n = side ? rdv.len - rdv.seed - 1 : rdv.seed;
+    const int nmax = uni(wave_max_i(n));
+    const hs_ws_t wsr = d.ws[ai];
+    const int lead_flank = uni(loc->lead_flank[side]);
+    double* rec = d.ws_lead + wsr.lead[side] + (int64_t)slot*(n + lead_flank + 1);     // lead_record() of this lane's read
+    double* lastcol = rec + n;
+    double* side_out = rec + n + lead_flank;
+    const double* col = d.ws_col + wsr.col + 3*(int64_t)(side ? nL : 0);
+    const int rowset = uni(it->rowset);
+    const int rs_off = uni(d.rowsets[rowset].off), rs_len = uni(d.rowsets[rowset].len);
+    const hs_row_t* rows = d.rows + rs_off;
+    const int c0 = uni((int)rows[0]) & 0xff;
+    if (rs_len - 1 == 0){     // a one-base flank: matrix row 0 is all there is
+      if (w == 0){
+        double pre = 0.0;
+        for (int j = 0; j < nmax; j++){
+          const int jc = min(j, n - 1);
+          const double blcj = col[3*jc], blwj = col[3*jc+1]; const int rdj = (int)col[3*jc+2];
+          const double m0 = ((rdj == c0) ? blcj : blwj) + pre;
+          pre += blcj;
+          if (j < n && live) rec[j] = m0;
+          if (j == n-1 && live){ lastcol[0] = m0; *side_out = pre; }
+        }
+      }
+      continue;
+    }
+    coop_rounds<R, true>(d, w, lane, live, n, nmax, col, rows, rs_len - 1, c0, NULL, bnd, ring, lastcol, rec, side_out);
   }
 }
 
@@ -1115,10 +1375,16 @@ hs_combine_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
 #define HS_TRAIL_ROWS 20
 #endif
 // leading flanks of the reads [active_begin, active_begin + n_active) of a chunk: column tables first, then the reads-as-lanes sweep
+// HIPSTR_FLANK_COOP=0 selects the serial banded sweep (one wavefront per item, boundary rows through HBM scratch) for comparison
+static bool flank_coop(){ static const bool v = !(getenv("HIPSTR_FLANK_COOP") && atoi(getenv("HIPSTR_FLANK_COOP")) == 0); return v; }
+extern "C" int hs_flank_waves_per_group(){ return flank_coop() ? HS_COOP_WAVES : 1; }
 extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk){
   hipLaunchKernelGGL(hs_col_kernel, dim3(n_active), dim3(64), 0, st, dp, active_begin);
-  if (item_end > item_begin) hipLaunchKernelGGL((hs_lead_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end, chunk);
+  if (item_end <= item_begin) return;
+  if (flank_coop()) hipLaunchKernelGGL((hs_lead_kernel_coop<HS_COOP_ROWS>), dim3(std::max(1u, std::min(n_wavefronts, 256u*HS_COOP_OCC*4/HS_COOP_WAVES))), dim3(64*HS_COOP_WAVES), 0, st, dp, item_begin, item_end, chunk);
+  else hipLaunchKernelGGL((hs_lead_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end, chunk);
 }
 extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk){
-  hipLaunchKernelGGL((hs_trail_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end, chunk);
+  if (flank_coop()) hipLaunchKernelGGL((hs_trail_kernel_coop<HS_COOP_ROWS>), dim3(std::max(1u, std::min(n_wavefronts, 256u*HS_COOP_OCC*4/HS_COOP_WAVES))), dim3(64*HS_COOP_WAVES), 0, st, dp, item_begin, item_end, chunk);
+  else hipLaunchKernelGGL((hs_trail_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end, chunk);
 }

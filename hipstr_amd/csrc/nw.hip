@@ -171,10 +171,14 @@ __global__ void __launch_bounds__(64) hs_nw_walk(const hs_nw_dev_t* __restrict__
 
 struct NwBufs {
   std::vector<void*> p;
-  ~NwBufs(){ for (void* x : p) hipFree(x); }
+  hipstr::Ctx* ctx = NULL;          // blocks come from (and return to) the context's cache: no hipMalloc / hipFree per call
+  ~NwBufs(){ if (ctx) for (void* x : p) hipstr::dev_free(ctx, x); }
   template <typename T> int alloc(T** out, size_t count){
     *out = NULL;
-    NW_HIP(hipMalloc((void**)out, (count ? count : 1)*sizeof(T)));
+    if (!ctx) ctx = hipstr::api_current_ctx();
+    if (!ctx) return 1;
+    *out = (T*)hipstr::dev_alloc(ctx, (count ? count : 1)*sizeof(T));
+    if (!*out) return 1;
     p.push_back(*out);
     return 0;
   }

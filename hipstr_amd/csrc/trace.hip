@@ -533,10 +533,14 @@ __global__ void __launch_bounds__(64) hs_trace_walk(const hs_tdev_t* __restrict_
 
 struct DevBufs {
   std::vector<void*> p;
-  ~DevBufs(){ for (void* x : p) hipFree(x); }
+  hipstr::Ctx* ctx = NULL;          // blocks come from (and return to) the context's cache: no hipMalloc / hipFree per call
+  ~DevBufs(){ if (ctx) for (void* x : p) hipstr::dev_free(ctx, x); }
   template <typename T> int alloc(T** out, size_t count){
     *out = NULL;
-    TR_HIP(hipMalloc((void**)out, (count ? count : 1)*sizeof(T)));
+    if (!ctx) ctx = hipstr::api_current_ctx();
+    if (!ctx) return 1;
+    *out = (T*)hipstr::dev_alloc(ctx, (count ? count : 1)*sizeof(T));
+    if (!*out) return 1;
     p.push_back(*out);
     return 0;
   }
