@@ -3,20 +3,26 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is one pass of the hot path over one resident batch of synthetic loci: the forward-HMM kernel
-(every pooled read x every candidate allele) followed by the diplotype-posterior kernel.  STR loci are
-independent, so ranks hold disjoint loci (different seeds), no collective touches the data path, and the
-run is weak-scaling: per-GPU work is fixed.  `value` = alignments of all ranks x K / max-over-ranks wall
-time of the K timed steps, with inputs already resident in HBM (host preparation + PCIe are reported
-separately under "host").
+A "step" is one pass of the hot path over one resident batch of synthetic loci: the forward-HMM kernels
+(every pooled read x every candidate allele) followed by the diplotype-posterior kernel (workload c3: plus the
+de novo stutter EM and the genotype calls of BASELINE configs[2]).  STR loci are independent, so ranks hold
+disjoint loci of one seeded set, no collective touches the data path.  Default: weak scaling (per-GPU work
+fixed, rank r takes loci [r*n, (r+1)*n)); --scaling strong splits the workload's loci over the ranks.
+`value` = alignments of all ranks x K / max-over-ranks wall time of the K timed steps, with inputs already
+resident in HBM; the host-inclusive figure (SURVEY §8d's metric taken literally: host arrays in, results out,
+through the streaming C-ABI) is reported beside it under "end_to_end".
 
 Also printed in the same JSON line:
-  roofline      forward kernel: ALGORITHMIC bytes per launch (SURVEY.md §8d formula, computed from the batch)
-                / average launch duration measured with HIP events on the launch stream, vs the 8 TB/s HBM peak.
-                The kernel is a latency/issue-bound FP64 max-plus recurrence, so the fraction is ~1e-5 by
-                construction; "valu" reports the limiter that actually binds (DP cell updates vs FP64 VALU issue).
-  cpu_baseline  the compiled reference (oracle/_ref, kind "reference") or, if absent, the C oracle (kind
-                "port") timed single-threaded on this host on a bounded sample of the same workload; rank 0, N=1.
+  roofline      dominant kernel: ALGORITHMIC bytes per launch (SURVEY.md §8d formula, computed from the batch)
+                / average launch duration measured with HIP events on the launch stream, vs the 8 TB/s HBM peak;
+                traffic = L2<->fabric bytes from the committed rocprofv3 --pmc passes (profiles/).  The path is an
+                issue-bound FP64 max-plus recurrence, so the HBM fraction is ~4e-4 by construction.
+  valu          the limiter that binds, from the committed counter passes of THIS build (profiles/*_sq_counters.json,
+                checked against the kernel source hash): executed FP64 instructions against the FP64-VALU peak and
+                the VALU pipe occupancy with measured per-class issue costs (profiles/*_valu_microbench.json).
+  cpu_baseline  the compiled reference (oracle/_ref, kind "reference") or, if absent, the C oracle (kind "port")
+                on this host: N = all host cores, one process per core on its own loci — the reference's documented
+                scale-out mode (README.md:167-171) — and the single-core figure beside it; bounded sample; rank 0, N=1.
 """
 import argparse
 import ctypes as C
@@ -35,35 +41,56 @@ WORKLOADS = {
     "ns": (1000, 500, 32, 150, 60, 40, "north-star shape of BASELINE configs[1] (SURVEY §8d NS): 1000 STR loci x 500 pooled 150bp reads x 32 candidate alleles"),
     "c1": (1, 50, 4, 150, 60, 40, "BASELINE configs[0]: 1 locus x 50 reads x 4 alleles"),
     "c2": (1000, 40, 32, 150, 60, 40, "BASELINE configs[1] at literal 30x depth: 1000 loci x 40 reads x 32 alleles"),
+    "c3": (10000, 600, 32, 150, 60, 40, "BASELINE configs[2] (SURVEY §8d C3-like): 10k loci x 600 reads (100 samples x 6) x 32 alleles, stutter EM + posteriors + genotype calls in the step"),
     "c5": (256, 200, 128, 250, 110, 100, "BASELINE configs[4] stress: 256 loci x 200 250bp reads x 128 alleles, ~100bp STR blocks"),
 }
 
 
-def cpu_baseline(capi, wl, budget_s=20.0):
-    """Single-thread CPU time of the same hot path on a bounded sample (a few loci of the same generator)."""
-    loci, P, A, L, F, sbp, _ = wl
+def _cpu_worker(argv):
+    """`bench.py --cpu-worker <workload> <first_locus> <n_loci>`: one process of the CPU baseline — the compiled reference (or the C
+    oracle) on its own loci; prints alignments and seconds."""
+    from hipstr_amd import capi
+    loci, P, A, L, F, sbp, _ = WORKLOADS[argv[0]]
+    first, n = int(argv[1]), int(argv[2])
     if capi.have_ref():
-        lib, pfx, kind = capi.load_ref(), "ref_", "reference"
+        lib, pfx = capi.load_ref(), "ref_"
     else:
-        lib, pfx, kind = capi.load_oracle(), "oracle_", "port"
-    n_loci = 1
-    total_aln, total_t = 0, 0.0
-    seed = 977
-    while total_t < budget_s * 0.5 and n_loci <= 64:
-        sb = capi.SynthBatch(n_loci=min(n_loci, loci), reads_per_locus=P, n_str_alleles=A, read_len=L, flank_len=F, str_bp=sbp, seed=seed)
-        probs = np.zeros(sb.n_out); seeds = np.zeros(sb.n_reads, np.int32)
+        lib, pfx = capi.load_oracle(), "oracle_"
+    sb = capi.SynthBatch(n_loci=n, reads_per_locus=P, n_str_alleles=A, read_len=L, flank_len=F, str_bp=sbp, seed=977, first_locus=first)
+    probs = np.zeros(sb.n_out); seeds = np.zeros(sb.n_reads, np.int32)
+    t0 = time.perf_counter()
+    rc = getattr(lib, pfx + "process_reads")(sb.ptr, probs.ctypes.data_as(capi._f64p), seeds.ctypes.data_as(capi._i32p))
+    dt = time.perf_counter() - t0
+    assert rc == 0
+    print(json.dumps({"alignments": int((seeds >= 0).sum()) * (sb.n_out // sb.n_reads), "seconds": dt}))
+
+
+def cpu_baseline(capi, wl_name, budget_s=20.0):
+    """The same hot path on the host CPU, bounded sample: (i) one core, (ii) every core — N independent processes, one per core,
+    each on its own contiguous loci: the reference's documented way to use a multi-core box (README.md:167-171; it is single-threaded)."""
+    import subprocess
+    loci, P, A, L, F, sbp, _ = WORKLOADS[wl_name]
+    kind = "reference" if capi.have_ref() else "port"
+    def run_procs(n_procs, loci_each, first0):
         t0 = time.perf_counter()
-        rc = getattr(lib, pfx + "process_reads")(sb.ptr, probs.ctypes.data_as(capi._f64p), seeds.ctypes.data_as(capi._i32p))
-        dt = time.perf_counter() - t0
-        assert rc == 0
-        total_aln += int((seeds >= 0).sum()) * (sb.n_out // sb.n_reads)
-        total_t += dt
-        if dt * 2 > budget_s:
-            break
-        n_loci *= 2; seed += 1
-    return {"value": total_aln / total_t, "unit": "alignments/s", "cores": 1, "kind": kind,
-            "sample": "%d alignments of the same generator/shape (%d reads x %d alleles x %dbp per locus), %.1f s, HapAligner::process_reads only"
-                      % (total_aln, P, A, L, total_t)}
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", wl_name, str(first0 + i * loci_each), str(loci_each)],
+                                  stdout=subprocess.PIPE, universal_newlines=True) for i in range(n_procs)]
+        outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
+        wall = time.perf_counter() - t0
+        return sum(o["alignments"] for o in outs), max(o["seconds"] for o in outs), wall
+    # one core: size the sample from a single locus
+    a1, s1, _ = run_procs(1, 1, 100000)
+    per_locus = s1
+    n1 = max(1, min(16, int(budget_s * 0.5 / max(per_locus, 1e-3))))
+    a1, s1, _ = run_procs(1, n1, 100100)
+    cores = os.cpu_count() or 1
+    each = max(1, min(16, int(budget_s * 0.6 / max(per_locus, 1e-3))))
+    aN, sN, wallN = run_procs(cores, each, 200000)
+    return {"value": aN / sN, "unit": "alignments/s", "cores": cores, "kind": kind,
+            "sample": "%d processes x %d loci of the same generator/shape (%d reads x %d alleles x %dbp per locus) = %d alignments; slowest process %.1f s (wall incl. start-up %.1f s); HapAligner::process_reads only"
+                      % (cores, each, P, A, L, aN, sN, wallN),
+            "single_core": {"value": a1 / s1, "cores": 1, "sample": "%d alignments, %.1f s" % (a1, s1)},
+            "host_cores_available": cores}
 
 
 def _profile_key(path):
@@ -221,12 +248,15 @@ def end_to_end(capi, hmm, sb, loci, steps, device):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        return _cpu_worker(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
-    ap.add_argument("--loci", type=int, default=0, help="override the number of loci per GPU")
+    ap.add_argument("--loci", type=int, default=0, help="override the number of loci (per GPU with weak scaling, in total with strong scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: every rank takes the workload's loci; strong: they are split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the short measurements of the stages around the forward pass")
     args = ap.parse_args()
@@ -259,9 +289,14 @@ def main():
     loci, P, A, L, F, sbp, desc = wl
     if args.loci:
         loci = args.loci
-    # --- synthetic batch of this rank (disjoint loci per rank: rank-specific seed), prepared and made resident
+    # --- this rank's loci of the ONE seeded set (a locus depends on (seed, index) only): weak scaling gives every rank `loci` of them,
+    # strong scaling splits `loci` over the ranks; either way contiguous index ranges, rank order = locus order
+    if args.scaling == "strong":
+        first = loci * rank // world; loci = loci * (rank + 1) // world - first
+    else:
+        first = loci * rank
     t0 = time.perf_counter()
-    sb = capi.SynthBatch(n_loci=loci, reads_per_locus=P, n_str_alleles=A, read_len=L, flank_len=F, str_bp=sbp, seed=20260928 + 1000 * rank)
+    sb = capi.SynthBatch(n_loci=loci, reads_per_locus=P, n_str_alleles=A, read_len=L, flank_len=F, str_bp=sbp, seed=20260928, first_locus=first)
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
     dev = hmm.hipstr_hmm_upload(sb.ptr)
@@ -271,17 +306,55 @@ def main():
     t_upload = time.perf_counter() - t0
     n_aln = C.c_int64(0); algo = C.c_int64(0); cells = C.c_int64(0)
     hmm.hipstr_hmm_workload(dev, C.byref(n_aln), C.byref(algo), C.byref(cells))
-    # posteriors: one sample per locus (configs[1]: "1 sample"), every pooled read its own read, no SNP phasing information
     hap_off = np.ctypeslib.as_array(sb.ptr.contents.hap_off, shape=(loci + 1,))
-    pb = capi.PostBatch(np.diff(hap_off), np.ones(loci, np.int32), np.arange(loci + 1, dtype=np.int32) * P, np.zeros(loci * P, np.int32),
-                        np.zeros(loci * P), np.zeros(loci * P), np.ones(loci * P, np.int32), None)
+    A_l = np.diff(hap_off)
+    if args.workload == "c3":
+        # configs[2]: 100 samples per locus, the locus' reads dealt to them in blocks; a step = stutter EM on the observed STR sizes
+        # (EMStutterGenotyper::train, all loci in lock step) + forward HMM + posteriors + genotype calls (GL, PL)
+        S = 100
+        lab = np.tile(np.repeat(np.arange(S), P // S), loci).astype(np.int32)
+        pb = capi.PostBatch(A_l, np.full(loci, S, np.int32), np.arange(loci + 1, dtype=np.int32) * P, lab, np.zeros(loci * P), np.zeros(loci * P),
+                            np.ones(loci * P, np.int32), None)
+        b = sb.ptr.contents
+        nopt = np.ctypeslib.as_array(b.blk_nopts, shape=(3 * loci,)).reshape(loci, 3)
+        opt_len = np.diff(np.ctypeslib.as_array(b.opt_off, shape=(int(nopt.sum()) + 1,)))
+        period = np.ctypeslib.as_array(b.period, shape=(loci,))
+        src = sb.src_allele().reshape(loci, P)
+        opt_base = np.concatenate([[0], np.cumsum(nopt.sum(axis=1))])[:-1] + nopt[:, 0]          # first STR option of every locus
+        rng = np.random.default_rng(5)
+        size = np.stack([opt_len[opt_base[l] + src[l]] - opt_len[opt_base[l]] for l in range(loci)])       # bp difference from the reference allele
+        u = rng.random(size.shape)
+        size = size + np.where(u < 0.05, 1, np.where(u < 0.12, -1, 0)) * period[:, None]                    # PCR stutter on the observed sizes
+        em_kw = dict(period=period, n_samples=np.full(loci, S, np.int32), read_off=np.arange(loci + 1, dtype=np.int32) * P, sample_label=lab,
+                     num_bps=size.ravel().astype(np.int32), log_p1=np.zeros(loci * P), log_p2=np.zeros(loci * P), haploid=np.zeros(loci, np.uint8))
+        h2a = np.concatenate([np.arange(a, dtype=np.int32) for a in A_l]); nvv = A_l.astype(np.int32)
+        rq = capi.HipstrGtRequest(nvv.ctypes.data_as(capi._i32p), h2a.ctypes.data_as(capi._i32p), 1, 1, 0)
+        ns = loci * S; ngl = int(sum(int(a) * (int(a) + 1) // 2 for a in A_l)) * S
+        gt_k = [np.zeros(2 * ns, np.int32), np.zeros(2 * ns, np.int32)] + [np.zeros(ns) for _ in range(5)] + [np.zeros(ngl), np.zeros(ngl, np.int32), np.zeros(1)]
+        gt_o = capi.HipstrGtOut(*[a.ctypes.data_as(t) for a, (f, t) in zip(gt_k, capi.HipstrGtOut._fields_)])
+        hmm.hipstr_post_extract.restype = C.c_int; hmm.hipstr_post_extract.argtypes = [C.c_void_p, C.POINTER(capi.HipstrGtRequest), C.POINTER(capi.HipstrGtOut)]
+    else:
+        # posteriors: one sample per locus (configs[1]: "1 sample"), every pooled read its own read, no SNP phasing information
+        pb = capi.PostBatch(A_l, np.ones(loci, np.int32), np.arange(loci + 1, dtype=np.int32) * P, np.zeros(loci * P, np.int32),
+                            np.zeros(loci * P), np.zeros(loci * P), np.ones(loci * P, np.int32), None)
     pd = hmm.hipstr_post_upload(pb.ptr, hmm.hipstr_hmm_dev_aln_probs(dev))
     if not pd:
         raise SystemExit("posterior upload failed: " + hmm.hipstr_last_error().decode())
+    em_stats = {}
 
     def step():
+        if args.workload == "c3":
+            t_em = time.perf_counter()
+            tr, st_, it_, ll_ = capi.run_em(hmm, "hipstr_", **em_kw)
+            em_stats["em_s"] = em_stats.get("em_s", 0.0) + time.perf_counter() - t_em
+            em_stats["trained"] = int(tr.sum()); em_stats["iterations"] = int(it_.sum())
         if hmm.hipstr_hmm_align(dev, None) != 0 or hmm.hipstr_post_launch(pd, None) != 0:
             raise SystemExit("launch failed: " + hmm.hipstr_last_error().decode())
+        if args.workload == "c3":
+            t_gt = time.perf_counter()
+            if hmm.hipstr_post_extract(pd, C.byref(rq), C.byref(gt_o)) != 0:
+                raise SystemExit("hipstr_post_extract: " + hmm.hipstr_last_error().decode())
+            em_stats["calls_s"] = em_stats.get("calls_s", 0.0) + time.perf_counter() - t_gt
 
     def fence():
         torch.cuda.synchronize()
@@ -292,6 +365,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    em_stats.clear()
     hmm.hipstr_hmm_profile(dev, 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -341,34 +415,58 @@ def main():
         per_aln = sum(2 * v["fetch_bytes_per_launch_raw"] + v["write_bytes_per_launch_raw"] for v in hit) / t["alignments_per_launch"]
         return per_aln * n_alignments, os.path.basename(files[-1])
 
-    def valu_issue_util(kernel_key, n_alignments, kernel_ms_now):
-        """VALU issue-slot utilisation of a kernel: SQ_INSTS_VALU of the newest committed counter pass (profiles/r*_sq_counters.json, an own
-        rocprofv3 --pmc run), scaled to this launch by alignments, x 4 cycles per wave64 instruction / (1024 SIMDs x live kernel duration)."""
+    def valu_block(phase_ms_now, n_alignments):
+        """The limiter that binds, per phase, from the newest committed counter passes (profiles/r*_sq_counters.json: two rocprofv3 --pmc
+        runs, tools/profile_pass.sh + tools/sq_counters.py) scaled to this launch by alignments and divided by the LIVE phase durations:
+          fp64_frac_of_peak  executed FP64 add/max instructions x 4 cycles / (1024 SIMDs x 2.4 GHz x duration) = executed FP64 ops against
+                             the 39.3 T FP64-VALU-op/s peak (256 CU x 4 SIMD x 16 lanes x 2.4 GHz)
+          pipe_occupancy_*   VALU pipe time of ALL executed VALU instructions with the measured per-class issue costs
+                             (profiles/r*_valu_microbench.json): low = every non-FP64 instruction 2 cycles, high = 4 cycles, est = split
+                             by the kernel's static instruction histogram (profiles/r*_isa_histogram.json).
+        profile_matches_build says whether the counters were collected on the kernel source this library was built from."""
         import glob
+        import hashlib
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters.json")), key=_profile_key)
-        if not files or not (kernel_ms_now == kernel_ms_now):
-            return None, None
+        files = [f for f in files if "kernel_source_sha1" in open(f).read()]
+        if not files:
+            return None
         t = json.load(open(files[-1]))
-        hit = [v for name, v in t["kernels"].items() if name.startswith(kernel_key)]      # a phase may be more than one kernel
-        if not hit:
-            return None, None
-        insts = sum(v["valu_insts"] for v in hit) / t["alignments_per_launch"] * n_alignments
-        return insts * t["cycles_per_wave64_valu_inst"] / (kernel_ms_now * 1e-3 * t["clock_hz_assumed"] * t["simds"]), os.path.basename(files[-1])
+        src = os.path.join(ROOT, "hipstr_amd", "csrc", "hmm_kernels.hip")
+        same = os.path.exists(src) and hashlib.sha1(open(src, "rb").read()).hexdigest() == t.get("kernel_source_sha1")
+        denom_per_ms = t["simds"] * t["clock_hz"] * 1e-3
+        cyc = t["cycles_per_wave64_instruction"]
+        phases = {}
+        for ph, ms_now in phase_ms_now.items():
+            hit = [v for name, v in t["kernels"].items() if name.startswith(ph)]      # a phase may be more than one kernel (hs_str_kernel + _generic)
+            if not hit or not (ms_now == ms_now) or ms_now <= 0:
+                continue
+            sc = n_alignments / t["alignments_per_launch"]
+            f64 = sum(v["fp64_arith_insts"] for v in hit) * sc; rest = sum(v["other_valu_insts"] for v in hit) * sc
+            wide = sum(v["other_valu_insts"] * (v["static_histogram"]["wide_share_of_non_fp64"] or 1.0) for v in hit) * sc
+            d = denom_per_ms * ms_now
+            phases[ph] = {"valu_insts": f64 + rest, "fp64_insts": f64, "fp64_ops_per_s": f64 * 64 / (ms_now * 1e-3),
+                          "fp64_frac_of_peak": f64 * cyc["fp64"] / d,
+                          "pipe_occupancy_low": (f64 * cyc["fp64"] + rest * cyc["simple32"]) / d,
+                          "pipe_occupancy_est": (f64 * cyc["fp64"] + wide * cyc["other"] + (rest - wide) * cyc["simple32"]) / d,
+                          "pipe_occupancy_high": (f64 * cyc["fp64"] + rest * cyc["other"]) / d}
+        tot_ms = sum(ms for ph, ms in phase_ms_now.items() if ph in phases)
+        allf = sum(v["fp64_insts"] for v in phases.values())
+        return {"fp64_valu_peak_ops_per_s": 256 * 4 * 16 * 2.4e9, "cycles_per_wave64_instruction": cyc,
+                "pass_fp64_frac_of_peak": (allf * cyc["fp64"] / (denom_per_ms * tot_ms)) if tot_ms > 0 else None,
+                "phases": phases, "source": os.path.basename(files[-1]), "profile_matches_build": bool(same)}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_aln * args.steps / elapsed
         achieved = algo.value / (kernel_ms * 1e-3) / 1e9 if kernel_ms == kernel_ms else None
         traffic, traffic_src = pmc_traffic(phase_names[dom].split("<")[0], n_aln.value)
-        util, util_src = valu_issue_util(phase_names[dom].split("<")[0], n_aln.value, kernel_ms)
-        fp64_ops_per_cell = 13.0           # 13 FP64 add/max per M/I/D cell triple (hmm_kernels.hip sweep)
-        valu_peak = 256 * 4 * 16 * 2.4e9   # FP64 VALU lanes/clk on 256 CUs x 4 SIMD x 16 lanes at 2.4 GHz (ops/s, add or max)
+        valu = valu_block(dict(zip(phase_names, [float(x) for x in phase_ms])), n_aln.value) if n_ms > 0 else None
         out = {
             "metric": "read x allele HMM alignments/sec", "value": value, "unit": "alignments/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %s" % (args.workload, desc) if not args.loci else "%s with %d loci/GPU: %s" % (args.workload, loci, desc),
-                       "loci_per_gpu": loci, "reads_per_locus": P, "alleles_per_locus": A, "read_len": L,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %s" % (args.workload, desc) if not args.loci else "%s with %d loci%s: %s" % (args.workload, args.loci, "/GPU" if args.scaling == "weak" else " in total", desc),
+                       "loci_per_gpu": loci, "first_locus_rank0": first, "reads_per_locus": P, "alleles_per_locus": A, "read_len": L,
                        "alignments_per_step_per_gpu": n_aln.value, "sharding": "loci across ranks, no collective on the data path"},
             "loci_per_sec": total_loci * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
@@ -377,10 +475,7 @@ def main():
                          "kernel": phase_names[dom], "kernel_ms": kernel_ms,
                          "phase_ms": dict(zip(phase_names, [float(x) for x in phase_ms])), "algorithmic_bytes_per_launch": algo.value,
                          "bytes_per_alignment": algo.value / max(1, n_aln.value)},
-            "valu": {"dp_cells_per_launch": cells.value, "cells_per_s": cells.value / (float(phase_ms.sum()) * 1e-3) if n_ms > 0 else None,
-                     "fp64_ops_per_cell": fp64_ops_per_cell, "fp64_valu_peak_ops_per_s": valu_peak,
-                     "frac": (cells.value * fp64_ops_per_cell / (float(phase_ms.sum()) * 1e-3) / valu_peak) if n_ms > 0 else None,
-                     "issue_utilisation_dominant_kernel": util, "issue_utilisation_source": util_src},
+            "valu": valu,
             "host": {"synth_s": t_gen, "prepare_upload_s": t_upload, "fetch_s": t_fetch,
                      "value_incl_prepare_pcie": total_aln / world / (t_upload + elapsed / args.steps + t_fetch) * world},
         }
@@ -391,8 +486,10 @@ def main():
             out["end_to_end"] = e2e
             out["pipeline"] = pipeline_stages(capi, hmm, sb, loci, P)
         if args.gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(capi, wl)
-            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            out["cpu_baseline"] = cpu_baseline(capi, args.workload)
+        if em_stats:
+            out["c3_step"] = {"stutter_em_s_per_step": em_stats.get("em_s", 0.0) / args.steps, "genotype_calls_s_per_step": em_stats.get("calls_s", 0.0) / args.steps,
+                              "em_trained_loci": em_stats.get("trained"), "em_iterations": em_stats.get("iterations"), "samples_per_locus": 100}
         print(json.dumps(out), flush=True)
     hmm.hipstr_post_free(pd)
     hmm.hipstr_hmm_free(dev)

@@ -1,0 +1,50 @@
+"""GPU: bench.py's contract — one JSON line with the fields the driver reads — and its N > 1 path, exercised on a one-GPU box by letting
+two ranks share GPU 0 (HIPSTR_BENCH_SHARE_GPU=1: gloo rendezvous, same code path otherwise): weak scaling doubles the work, strong
+scaling splits the same loci, and the ranks' loci are disjoint slices of one seeded set."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, nproc=1, port=29531):
+    env = dict(os.environ, HIPSTR_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + args
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_every_contract_field():
+    d = _bench(["--steps", "2", "--warmup", "1", "--loci", "24", "--no-cpu-baseline"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "end_to_end", "valu"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f64" and d["value"] > 0 and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert d["end_to_end"]["alignments_per_s"] > 0 and d["valu"]["profile_matches_build"] in (True, False)
+
+
+def test_two_ranks_weak_and_strong():
+    one = _bench(["--steps", "2", "--warmup", "1", "--loci", "16", "--no-cpu-baseline", "--no-pipeline"])
+    weak = _bench(["--steps", "2", "--warmup", "1", "--loci", "16", "--no-cpu-baseline", "--no-pipeline"], nproc=2, port=29533)
+    strong = _bench(["--steps", "2", "--warmup", "1", "--loci", "16", "--scaling", "strong", "--no-cpu-baseline", "--no-pipeline"], nproc=2, port=29535)
+    a1 = one["config"]["alignments_per_step_per_gpu"]
+    assert weak["n_gpus"] == 2 and weak["scaling"] == "weak" and weak["config"]["loci_per_gpu"] == 16
+    assert strong["scaling"] == "strong" and strong["config"]["loci_per_gpu"] == 8
+    # alignments per step over all ranks: value x seconds per step
+    tot = lambda d: d["value"] * d["ms_per_step"] * 1e-3
+    assert abs(tot(strong) - a1) < 1e-6 * a1                  # the same 16 loci, split
+    assert tot(weak) > 1.7 * a1                               # 32 different loci
