@@ -65,6 +65,18 @@ def _cpu_worker(argv):
     print(json.dumps({"alignments": int((seeds >= 0).sum()) * (sb.n_out // sb.n_reads), "seconds": dt}))
 
 
+def usable_cores():
+    """CPUs this process may actually use: the affinity mask, capped by the container's cgroup v2 quota (cpu.max = "<quota> <period>")."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(capi, wl_name, budget_s=20.0):
     """The same hot path on the host CPU, bounded sample: (i) one core, (ii) every core — N independent processes, one per core,
     each on its own contiguous loci: the reference's documented way to use a multi-core box (README.md:167-171; it is single-threaded)."""
@@ -83,14 +95,14 @@ def cpu_baseline(capi, wl_name, budget_s=20.0):
     per_locus = s1
     n1 = max(1, min(16, int(budget_s * 0.5 / max(per_locus, 1e-3))))
     a1, s1, _ = run_procs(1, n1, 100100)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     each = max(1, min(16, int(budget_s * 0.6 / max(per_locus, 1e-3))))
     aN, sN, wallN = run_procs(cores, each, 200000)
     return {"value": aN / sN, "unit": "alignments/s", "cores": cores, "kind": kind,
             "sample": "%d processes x %d loci of the same generator/shape (%d reads x %d alleles x %dbp per locus) = %d alignments; slowest process %.1f s (wall incl. start-up %.1f s); HapAligner::process_reads only"
                       % (cores, each, P, A, L, aN, sN, wallN),
             "single_core": {"value": a1 / s1, "cores": 1, "sample": "%d alignments, %.1f s" % (a1, s1)},
-            "host_cores_available": cores}
+            "host_cores_visible": os.cpu_count(), "host_cores_usable": cores}
 
 
 def _profile_key(path):

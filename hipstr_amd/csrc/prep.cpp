@@ -28,8 +28,15 @@ int host_threads(){
   if (const int o = g_thread_override.load()) return o;
   static const int n = [](){
     if (const char* e = getenv("HIPSTR_HOST_THREADS")){ const int v = atoi(e); if (v >= 1) return v; }
-    const unsigned hw = std::thread::hardware_concurrency();
-    return (int)std::max(1u, std::min(hw ? hw : 1u, 32u));
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 1;
+    // a container may be allowed fewer CPUs than it sees: cgroup v2 cpu.max = "<quota> <period>" (or "max")
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")){
+      long long quota = 0, period = 0;
+      if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) hw = std::min<unsigned>(hw, (unsigned)((quota + period - 1) / period));
+      fclose(f);
+    }
+    return (int)std::max(1u, std::min(hw, 32u));
   }();
   return n;
 }
