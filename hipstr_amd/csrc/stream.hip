@@ -285,4 +285,84 @@ int hipstr_stream_close(hipstr_stream_t* s){
   return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------- several GPUs, one process
+// The region list cut into contiguous blocks, block i on device i mod n (one hipstr_stream_t per device), results handed back in GLOBAL
+// submission order: the in-process form of SURVEY §8(e) — loci are independent, so nothing crosses between devices but the order.
+}  // extern "C"
+
+struct hipstr_multi {
+  std::vector<hipstr_stream_t*> streams;
+  int64_t block_work = (int64_t)16 << 20;
+  std::mutex m;
+  std::deque<int> owner;          // device slot of every ticket not yet delivered, in submission order
+  int cur = 0;                    // slot receiving the current block
+  int64_t cur_work = 0, next_ticket = 0;
+};
+
+extern "C" {
+
+hipstr_multi_t* hipstr_multi_open(int32_t n_devices, const int32_t* devices, int64_t block_alignments, const hipstr_stream_opts_t* per_stream){
+  if (n_devices < 1){ hipstr::api_fail("at least one device"); return NULL; }
+  hipstr_multi* mm = new hipstr_multi();
+  if (block_alignments > 0) mm->block_work = block_alignments;
+  for (int i = 0; i < n_devices; i++){
+    hipstr_stream_opts_t o; memset(&o, 0, sizeof o);
+    if (per_stream) o = *per_stream;
+    o.device = devices ? devices[i] : i;
+    hipstr_stream_t* s = hipstr_stream_open(&o);
+    if (!s){ for (hipstr_stream_t* t : mm->streams) hipstr_stream_close(t); delete mm; return NULL; }
+    mm->streams.push_back(s);
+  }
+  return mm;
+}
+
+int64_t hipstr_multi_submit(hipstr_multi_t* mm, const hipstr_batch_t* loci){
+  if (!mm || !loci){ hipstr::api_fail("null argument"); return -1; }
+  std::lock_guard<std::mutex> g(mm->m);
+  int64_t work = 0;
+  for (int l = 0; l < loci->n_loci; l++) work += (int64_t)(loci->read_off[l+1] - loci->read_off[l])*(loci->hap_off[l+1] - loci->hap_off[l]);
+  if (mm->cur_work > 0 && mm->cur_work + work > mm->block_work){        // the block is full: send it, the next block goes to the next device
+    hipstr_stream_flush(mm->streams[mm->cur]);
+    mm->cur = (mm->cur + 1) % (int)mm->streams.size(); mm->cur_work = 0;
+  }
+  if (hipstr_stream_submit(mm->streams[mm->cur], loci) < 0) return -1;
+  mm->cur_work += work;
+  mm->owner.push_back(mm->cur);
+  return mm->next_ticket++;
+}
+
+int hipstr_multi_flush(hipstr_multi_t* mm){
+  if (!mm) return hipstr::api_fail("null argument");
+  std::lock_guard<std::mutex> g(mm->m);
+  for (hipstr_stream_t* s : mm->streams) hipstr_stream_flush(s);
+  return 0;
+}
+
+int hipstr_multi_next_size(hipstr_multi_t* mm, int64_t* ticket, int64_t* n_out, int64_t* n_reads){
+  if (!mm) return hipstr::api_fail("null argument");
+  int slot; int64_t t;
+  { std::lock_guard<std::mutex> g(mm->m); if (mm->owner.empty()) return 2; slot = mm->owner.front(); t = mm->next_ticket - (int64_t)mm->owner.size(); }
+  if (ticket) *ticket = t;
+  return hipstr_stream_next_size(mm->streams[slot], NULL, n_out, n_reads);
+}
+
+int hipstr_multi_next(hipstr_multi_t* mm, int64_t* ticket, double* aln_probs, int64_t cap_probs, int32_t* seeds, int64_t cap_seeds){
+  if (!mm) return hipstr::api_fail("null argument");
+  int slot; int64_t t;
+  { std::lock_guard<std::mutex> g(mm->m); if (mm->owner.empty()) return 2; slot = mm->owner.front(); t = mm->next_ticket - (int64_t)mm->owner.size(); }
+  const int rc = hipstr_stream_next(mm->streams[slot], NULL, aln_probs, cap_probs, seeds, cap_seeds);     // that device's next = the globally next
+  if (rc == 2) return hipstr::api_fail("internal error: device stream has nothing outstanding");
+  { std::lock_guard<std::mutex> g(mm->m); mm->owner.pop_front(); }
+  if (ticket) *ticket = t;
+  return rc;
+}
+
+int hipstr_multi_close(hipstr_multi_t* mm){
+  if (!mm) return 0;
+  for (hipstr_stream_t* s : mm->streams) hipstr_stream_close(s);
+  delete mm;
+  return 0;
+}
+
 }  // extern "C"

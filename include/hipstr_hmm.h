@@ -199,6 +199,36 @@ int hipstr_stream_stats(hipstr_stream_t* s, hipstr_stream_stats_t* out);
 /* Drops whatever has not been delivered and releases the stream. */
 int hipstr_stream_close(hipstr_stream_t* s);
 
+/*
+ * Several GPUs from one process (STR loci are independent, the region list shards across the GPUs of a node with no
+ * collective on the data path).  One hipstr_stream_t per device; submissions fill contiguous blocks of about `block_alignments`
+ * (read x haplotype) pairs, block i on device i mod n; hipstr_multi_next hands results back in GLOBAL submission order.
+ * devices == NULL: ordinals 0..n_devices-1.  (One process per GPU — torch.distributed / MPI launchers — needs nothing of this:
+ * every process opens its own stream on its own device.)
+ */
+typedef struct hipstr_multi hipstr_multi_t;
+hipstr_multi_t* hipstr_multi_open(int32_t n_devices, const int32_t* devices, int64_t block_alignments /* 0 = 16 Mi */, const hipstr_stream_opts_t* per_stream);
+int64_t hipstr_multi_submit(hipstr_multi_t* m, const hipstr_batch_t* loci);
+int hipstr_multi_flush(hipstr_multi_t* m);
+int hipstr_multi_next_size(hipstr_multi_t* m, int64_t* ticket, int64_t* n_out, int64_t* n_reads);
+int hipstr_multi_next(hipstr_multi_t* m, int64_t* ticket, double* aln_probs, int64_t cap_probs, int32_t* seeds, int64_t cap_seeds);
+int hipstr_multi_close(hipstr_multi_t* m);
+
+/*
+ * Host-side ordered gather of per-worker record streams: the reference's VCF writer accepts out-of-order positions
+ * only within MAX_RECORD_PAD = 50 bp (vcf_writer.h:53, vcf_writer.cpp:7-36), so the records produced by the workers of a sharded
+ * region list are merged back by (chromosome index, position).  Every stream pushes its records in order and ends; a record is
+ * released once it is the smallest pending one and no unfinished stream is empty.  Host only.
+ * hipstr_gather_pop: 0 = record released; 2 = not yet (an unfinished stream has nothing pending); 3 = all streams ended and
+ * drained; 1 = error (*bytes holds the size needed when the buffer was too small; the record stays queued).
+ */
+typedef struct hipstr_gather hipstr_gather_t;
+hipstr_gather_t* hipstr_gather_open(int32_t n_streams);
+int hipstr_gather_push(hipstr_gather_t* g, int32_t stream, int32_t chrom_index, int32_t pos, const void* record, int64_t bytes);
+int hipstr_gather_end(hipstr_gather_t* g, int32_t stream);
+int hipstr_gather_pop(hipstr_gather_t* g, int32_t* stream, int32_t* chrom_index, int32_t* pos, void* out, int64_t cap, int64_t* bytes);
+void hipstr_gather_close(hipstr_gather_t* g);
+
 /* HapAligner::calc_seed_base (HapAligner.cpp:270-318) for every read of a batch,
  * host only (no device needed): seeds[r] = read offset of the seed base or -1.
  * Returns non-zero on the inputs the reference dies on ("Invalid alignment

@@ -101,3 +101,32 @@ def test_large_stream_full_rate(hmm):
     assert np.array_equal(np.concatenate(out), want) and np.array_equal(np.concatenate(seeds), wseeds)
     assert st.stats()["batches"] >= 3
     st.close()
+
+
+def test_multi_device_blocks_in_global_order(hmm):
+    """hipstr_multi_*: contiguous blocks of loci dealt to several device streams, results in global submission order.  On a one-GPU
+    box both streams sit on device 0 — the dispatch and ordering logic is the same."""
+    import ctypes as C
+    lib = hmm
+    lib.hipstr_multi_open.restype = C.c_void_p; lib.hipstr_multi_open.argtypes = [C.c_int32, capi._i32p, C.c_int64, C.c_void_p]
+    lib.hipstr_multi_submit.restype = C.c_int64; lib.hipstr_multi_submit.argtypes = [C.c_void_p, capi._BP]
+    lib.hipstr_multi_flush.restype = C.c_int; lib.hipstr_multi_flush.argtypes = [C.c_void_p]
+    lib.hipstr_multi_next_size.restype = C.c_int; lib.hipstr_multi_next_size.argtypes = [C.c_void_p] + [C.POINTER(C.c_int64)] * 3
+    lib.hipstr_multi_next.restype = C.c_int; lib.hipstr_multi_next.argtypes = [C.c_void_p, C.POINTER(C.c_int64), capi._f64p, C.c_int64, capi._i32p, C.c_int64]
+    lib.hipstr_multi_close.restype = C.c_int; lib.hipstr_multi_close.argtypes = [C.c_void_p]
+    sb = capi.SynthBatch(n_loci=30, reads_per_locus=20, n_str_alleles=6, seed=31, mask_rate=0.1)
+    pieces = _pieces(sb, list(range(31)))
+    want = [capi.run_align(hmm, "hipstr_hmm_", p.ptr, fill=FILL) for p in pieces]
+    devs = np.zeros(3, np.int32)
+    m = lib.hipstr_multi_open(3, devs.ctypes.data_as(capi._i32p), 600, None)          # blocks of ~5 loci, three streams
+    assert m, lib.hipstr_last_error()
+    for i, p in enumerate(pieces):
+        assert lib.hipstr_multi_submit(m, p.ptr) == i
+    for i, (wp, ws) in enumerate(want):
+        t = C.c_int64(); no = C.c_int64(); nr = C.c_int64()
+        assert lib.hipstr_multi_next_size(m, C.byref(t), C.byref(no), C.byref(nr)) == 0 and t.value == i and no.value == wp.size
+        probs = np.full(max(no.value, 1), FILL); seeds = np.full(max(nr.value, 1), -7, np.int32)
+        assert lib.hipstr_multi_next(m, C.byref(t), probs.ctypes.data_as(capi._f64p), probs.size, seeds.ctypes.data_as(capi._i32p), seeds.size) == 0, lib.hipstr_last_error()
+        assert t.value == i and np.array_equal(probs[:no.value], wp) and np.array_equal(seeds[:nr.value], ws)
+    assert lib.hipstr_multi_next(m, None, None, 0, None, 0) == 2
+    lib.hipstr_multi_close(m)
