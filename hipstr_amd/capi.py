@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HMM_LIB = os.path.join(ROOT, "hipstr_amd", "csrc", "libhipstr_hmm.so")
+HMM_LIB = os.environ.get("HIPSTR_HMM_LIB") or os.path.join(ROOT, "hipstr_amd", "csrc", "libhipstr_hmm.so")     # the override: kernel ablation builds (tools/ablate_str.sh)
 SYNTH_LIB = os.path.join(ROOT, "hipstr_amd", "synth", "libhipstr_synth.so")
 ORACLE_LIB = os.path.join(ROOT, "oracle", "libhipstr_oracle.so")
 REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libhipstr_ref.so")

@@ -879,7 +879,10 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
 
     // --- StutterAlignerClass::load_read (StutterAlignerClass.cpp:12-53): match_probs_ and del_probs_
     // (a block that ends with the previous allele's block only appends terms to that allele's sums)
-    const int t0 = chained ? min(prev_B, n) : 0;
+#ifndef HS_ABLATE
+#define HS_ABLATE 0          // timing experiments only (tools/ablate_str.sh): 1 no final LSE, 2 no artifact terms, 3 no match/deletion tables, 4 no read-end deletion sums, 6 first chunk only
+#endif
+    const int t0 = (HS_ABLATE == 3) ? min(B, n) : (chained ? min(prev_B, n) : 0);
     prev_B = B;
     const int tmax = min(B, n);
     if (t0 < tmax)                      // a continued block that already covered the whole read side adds nothing
@@ -977,6 +980,7 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
       // columns each size gains — and size 0 — are summed: nv p pairs instead of nv (nv + 1) p / 2 (nv = c.nd sizes fit the block).
       const int nv = c.nd;
       const bool nd_reuse = (MODE == 0) && chained && ((oe >> 29) & 1) && (n >= nv*p);
+      if (HS_ABLATE == 4){} else
       if (nd_reuse){
         auto row_off = [&](int q){ return p*((q*(q+1)) >> 1); };           // size q holds (q+1)p columns, sizes back to back
         const int ncopy = row_off(nv - 1);                                // rows 0..nv-2 -> rows 1..nv-1, read completely before the first write
@@ -1018,7 +1022,7 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
     }
     wave_lds_sync();
 
-    for (int kk = 0; kk < ncyc; kk++){
+    for (int kk = 0; kk < ((HS_ABLATE == 6) ? 1 : ncyc); kk++){
       const int jraw = lane + 64*kk;
       const bool actj = jraw < n;
       const int j = min(jraw, n-1);
@@ -1027,6 +1031,7 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
       // kept in a rotating register window; fast_log_sum_exp (mathops.cpp:97-106) does not depend on their order.
       double terms[HS_NART];
       auto finish_chunk = [&](){                     // fast_log_sum_exp over the 13 artifact terms (mathops.cpp:97-106)
+        if (HS_ABLATE == 1){ double sx = 0; for (int t = 0; t < HS_NART; t++) sx = fmax(sx, terms[t]); if (actj) mr_out[j] = sx; return; }
         Lse acc;
         for (int pass = 0; pass < 2; pass++){
           acc.start(pass, terms[0]);
@@ -1040,6 +1045,7 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
         // Bnd[e] sends the chunk through the long form below (rare: a float rounding boundary within reach of lp0's rounding error)
         double lp0_max = 0.0;                        // largest |lp0| of the lane's 12 evaluations, against the smallest Bnd of the table
         auto tab_eval = [&](double lp0, int lim, int k) -> double {
+          if (HS_ABLATE == 2) return lp0 + (double)lim;
           const int e = rdlane(tbase, k) + min(lim, 1) + max(lim - rdlane(shapes, k), 0);
           const double A = L.tab[e], G = L.tab[HS_TAB_CAP + e];
           lp0_max = fmax(lp0_max, fabs(lp0));

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 
 namespace hipstr {
 
@@ -58,8 +59,8 @@ static const double LARGE_NEGATIVE = -10e6;  // RepeatStutterInfo.h:12
 
 const HostTables& host_tables(){
   static HostTables t;
-  static bool ready = false;
-  if (!ready){
+  static std::once_flag once;
+  std::call_once(once, [](){
     t.int_log.resize(10000);
     t.int_log[0] = -1000;
     for (int i = 1; i < 10000; i++) t.int_log[i] = log((double)i);
@@ -84,8 +85,7 @@ const HostTables& host_tables(){
     }
     t.log_thresh = log(0.001);
     t.log_half   = log(0.5);
-    ready = true;
-  }
+  });
   return t;
 }
 
@@ -235,7 +235,7 @@ inline hs_visit_t visit(int ni, int U, char ca, char cb, bool plain, double logU
 }
 
 // One STR option in one orientation -> hs_stropt_t (+ its pools)
-static double g_bnd_scale = 1.0;      // read from the environment at the start of every prepare_batch / append_stropt
+static std::atomic<double> g_bnd_scale(1.0);      // tests only (HIPSTR_DEBUG_BND_SCALE): re-read from the environment at the start of every prepare_batch; concurrent calls store the same value
 
 // ---- host copies of the float bit tricks (fastonebigheader.h:206-218, 348-358), used to tabulate the closed form below
 static float h_fasterexp(float p){
@@ -283,7 +283,7 @@ static void simple_table_entry(int lim, int U0, int tail, double ent[3]){
   ent[0] = amax;
   ent[1] = (double)h_fasterlog((float)tot);
   ent[2] = (delta >= 1e300) ? 1e300 : std::max(0.0, delta * 1125899906842624.0 /* 2^50 */ - amax - 1.0);
-  if (ent[2] < 1e300) ent[2] *= g_bnd_scale;      // tests: shrink the guarantee (HIPSTR_DEBUG_BND_SCALE)
+  if (ent[2] < 1e300) ent[2] *= g_bnd_scale.load();      // tests: shrink the guarantee (HIPSTR_DEBUG_BND_SCALE)
 }
 
 void emit_stropt(const std::string& blk, int period, const double* stutter, Prepared& out){

@@ -144,11 +144,14 @@ int hipstr_hmm_workload(hipstr_dev_batch_t* dev, int64_t* n_alignments, int64_t*
 
 /* Copies results back.  Entries whose read or allele was not realigned are left
  * untouched in the caller's buffers, as process_reads does (HapAligner.cpp:326-329,
- * 615-619); reads with seed -1 get 0 for every realigned allele (HapAligner.cpp:333-337). */
+ * 615-619); a realigned read without a seed (-1) gets 0 for EVERY allele of its row, realigned or
+ * not, as in the reference (HapAligner.cpp:333-337). */
 int hipstr_hmm_fetch(hipstr_dev_batch_t* dev, double* aln_probs, int32_t* seeds);
 
 /* Device pointer to the batch's aln_probs buffer (same layout), for chaining
- * into hipstr_post_run without a host round trip. */
+ * into hipstr_post_run without a host round trip.  The device buffer holds 0 where the host contract
+ * says "untouched" (reads or alleles that were not realigned): chain it only for batches that realign
+ * everything, or merge on the host (hipstr_hmm_fetch) when earlier values must survive. */
 double* hipstr_hmm_dev_aln_probs(hipstr_dev_batch_t* dev);
 
 /* One-shot convenience = upload + align + fetch + free: the drop-in for
