@@ -41,6 +41,7 @@ WORKLOADS = {
     "ns": (1000, 500, 32, 150, 60, 40, "north-star shape of BASELINE configs[1] (SURVEY §8d NS): 1000 STR loci x 500 pooled 150bp reads x 32 candidate alleles"),
     "c1": (1, 50, 4, 150, 60, 40, "BASELINE configs[0]: 1 locus x 50 reads x 4 alleles"),
     "c2": (1000, 40, 32, 150, 60, 40, "BASELINE configs[1] at literal 30x depth: 1000 loci x 40 reads x 32 alleles"),
+    "p30": (4000, 40, 8, 150, 35, 40, "production-like shape (SURVEY §8: flanks <= 35 bp, HaplotypeGenerator.cpp:349-361; ~10 alleles; 30x depth): 4000 loci x 40 reads x 8 alleles"),
     "c3": (10000, 600, 32, 150, 60, 40, "BASELINE configs[2] (SURVEY §8d C3-like): 10k loci x 600 reads (100 samples x 6) x 32 alleles, stutter EM + posteriors + genotype calls in the step"),
     "c5": (256, 200, 128, 250, 110, 100, "BASELINE configs[4] stress: 256 loci x 200 250bp reads x 128 alleles, ~100bp STR blocks"),
 }
@@ -212,27 +213,24 @@ def end_to_end(capi, hmm, sb, loci, steps, device):
     submission (bam_processor.cpp:550-617).  `steps` passes over the batch go through one open stream back to back, a feeder
     thread submitting while this thread collects in order; reported beside `value`, never as `value` (inputs are host-resident)."""
     import threading
-    from hipstr_amd import shard
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import util
-    a = util.synth_to_batch(sb).arrays
-    pieces = [shard.batch_from_arrays(shard.subset_arrays(a, l, l + 1)) for l in range(loci)]
-    sizes = [(int(sb.out_off[l + 1] - sb.out_off[l]), int(a["read_off"][l + 1] - a["read_off"][l])) for l in range(loci)]
     st = capi.Stream(hmm, device=device, slots=3, batch_alignments=4 << 20)
-    probs = np.zeros(max(max(z[0] for z in sizes), 1)); seeds = np.zeros(max(max(z[1] for z in sizes), 1), np.int32)
+    probs = np.zeros(max(sb.n_out, 1)); seeds = np.zeros(max(sb.n_reads, 1), np.int32)
     def one_pass_set(n):
+        # feeder: every locus its own submission (hipstr_stream_submit_each: the per-region loop in C, as the reference's caller is C++);
+        # collector: the results of a pass, in order, into one buffer (hipstr_stream_collect)
         def feed():
             for _ in range(n):
-                for p in pieces:
-                    st.submit(p.ptr)
+                st.submit_each(sb.ptr)
             st.flush()
         th = threading.Thread(target=feed); th.start()
-        got = 0
-        while got < n * loci:
-            r = st.next(into=(probs, seeds))
-            if r is None:
-                time.sleep(0.0002); continue
-            got += 1
+        for _ in range(n):
+            got = 0
+            while got < loci:                      # the feeder may be behind: collect what is outstanding
+                k = min(loci - got, 256)
+                try:
+                    st.collect(k, probs, seeds); got += k
+                except RuntimeError:
+                    time.sleep(0.0002)
         th.join()
     one_pass_set(1)                                  # warm-up: block caches, kernels
     s0 = st.stats()
@@ -256,7 +254,7 @@ def end_to_end(capi, hmm, sb, loci, steps, device):
             "batches": s1["batches"] - s0["batches"], "worker_host_seconds": s1["host_seconds"] - s0["host_seconds"],
             "collector_wait_seconds": s1["wait_seconds"] - s0["wait_seconds"],
             "one_locus_process_reads_latency": lat,
-            "path": "hipstr_stream_submit (1 locus each) -> batches of ~4 Mi alignments -> prepare on host threads + H2D + kernels + D2H, 3 slots -> hipstr_stream_next in order"}
+            "path": "hipstr_stream_submit_each (1 locus per submission) -> batches of ~4 Mi alignments -> prepare on host threads + H2D + kernels + D2H, 3 slots -> hipstr_stream_collect in order"}
 
 
 def main():

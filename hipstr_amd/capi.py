@@ -572,6 +572,8 @@ class Stream:
         _sig(lib.hipstr_stream_open, C.c_void_p, [C.POINTER(HipstrStreamOpts)])
         _sig(lib.hipstr_stream_submit, C.c_int64, [C.c_void_p, _BP])
         _sig(lib.hipstr_stream_flush, C.c_int, [C.c_void_p])
+        _sig(lib.hipstr_stream_submit_each, C.c_int, [C.c_void_p, _BP, C.POINTER(C.c_int64)])
+        _sig(lib.hipstr_stream_collect, C.c_int, [C.c_void_p, C.c_int64, _f64p, C.c_int64, _i32p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
         _sig(lib.hipstr_stream_next_size, C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
         _sig(lib.hipstr_stream_next, C.c_int, [C.c_void_p, C.POINTER(C.c_int64), _f64p, C.c_int64, _i32p, C.c_int64])
         _sig(lib.hipstr_stream_stats, C.c_int, [C.c_void_p, C.POINTER(HipstrStreamStats)])
@@ -589,6 +591,21 @@ class Stream:
 
     def flush(self):
         assert self.lib.hipstr_stream_flush(self.h) == 0
+
+    def submit_each(self, bptr):
+        """Every locus of the batch as its own submission; returns the first ticket."""
+        t = C.c_int64(-1)
+        if self.lib.hipstr_stream_submit_each(self.h, bptr, C.byref(t)) != 0:
+            raise RuntimeError("hipstr_stream_submit_each failed: " + self.lib.hipstr_last_error().decode())
+        return t.value
+
+    def collect(self, n_tickets, probs, seeds):
+        """The next n_tickets submissions in order, back to back into probs / seeds; returns (doubles, seeds) written."""
+        a = C.c_int64(); b = C.c_int64()
+        if self.lib.hipstr_stream_collect(self.h, n_tickets, probs.ctypes.data_as(_f64p), probs.size, seeds.ctypes.data_as(_i32p), seeds.size,
+                                          C.byref(a), C.byref(b)) != 0:
+            raise RuntimeError("hipstr_stream_collect failed: " + self.lib.hipstr_last_error().decode())
+        return a.value, b.value
 
     def next(self, fill=np.nan, into=None):
         """(ticket, aln_probs, seeds) of the next submission in order, or None when nothing is outstanding."""

@@ -322,15 +322,28 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   // ---- one device block for everything the host fills, one pinned block to stage it, one copy
   const auto t_stage0 = std::chrono::steady_clock::now();
   struct Piece { const void* src; size_t bytes, off; };
-  std::vector<Piece> pieces;
+  std::vector<Piece> pieces;        // what is copied where; a pool gathered from fragments contributes one piece per fragment
   size_t total = 0;
   auto place = [&](const void* src, size_t bytes){ total = (total + 255) & ~(size_t)255; pieces.push_back(Piece{src, bytes, total}); total += bytes ? bytes : 1; return pieces.size() - 1; };
+  // a large pool: the batch's own vector (single-threaded preparation) followed by the fragments' (threaded), back to back
+  auto place_pool = [&](const void* own, size_t own_bytes, auto frag_ptr, size_t elem){
+    total = (total + 255) & ~(size_t)255;
+    const size_t first = pieces.size();
+    pieces.push_back(Piece{own, own_bytes, total}); total += own_bytes;
+    for (const hipstr::Prepared& f : P.frags){ const auto& v = f.*frag_ptr; pieces.push_back(Piece{v.data(), v.size()*elem, total}); total += v.size()*elem; }
+    total += 1;
+    return first;
+  };
   std::vector<hs_item_t> items(P.lead_items);
   items.insert(items.end(), P.trail_items.begin(), P.trail_items.end());
   dev->n_lead_items = (int)P.lead_items.size();
 #define PL(vec) place((vec).data(), (vec).size()*sizeof((vec)[0]))
-  const size_t i_loci = PL(P.loci), i_alleles = PL(P.alleles), i_stropts = PL(P.stropts), i_rowsets = PL(P.rowsets), i_rows = PL(P.rows),
-    i_visits = PL(P.visits), i_f64 = PL(P.f64pool), i_chars = PL(P.chars), i_reads = PL(P.reads), i_active = PL(P.active), i_items = PL(items),
+  const size_t i_loci = PL(P.loci), i_alleles = PL(P.alleles), i_stropts = PL(P.stropts), i_rowsets = PL(P.rowsets),
+    i_rows = place_pool(P.rows.data(), P.rows.size()*sizeof(hs_row_t), &hipstr::Prepared::rows, sizeof(hs_row_t)),
+    i_visits = place_pool(P.visits.data(), P.visits.size()*sizeof(hs_visit_t), &hipstr::Prepared::visits, sizeof(hs_visit_t)),
+    i_f64 = place_pool(P.f64pool.data(), P.f64pool.size()*sizeof(double), &hipstr::Prepared::f64pool, sizeof(double)),
+    i_chars = place_pool(P.chars.data(), P.chars.size(), &hipstr::Prepared::chars, 1),
+    i_reads = PL(P.reads), i_active = PL(P.active), i_items = PL(items),
     i_ws = PL(P.ws), i_tg = PL(P.tgroups), i_tm = PL(P.tmembers), i_tp = PL(P.tpack), i_ord = PL(P.str_order);
 #undef PL
   const size_t n_bases = P.reads.empty() ? 0 : (size_t)batch->base_off[P.reads.size()];
@@ -400,6 +413,9 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   HS_HIP_DEV(hipEventCreateWithFlags(&dev->ev_h2d, hipEventDisableTiming)); HS_HIP_DEV(hipEventCreateWithFlags(&dev->ev_done, hipEventDisableTiming));
   HS_HIP_DEV(hipEventCreateWithFlags(&dev->ev_d2h, hipEventDisableTiming));
   HS_HIP_DEV(hipEventRecord(dev->ev_h2d, copy_stream));
+  if (getenv("HIPSTR_TIMING"))
+    fprintf(stderr, "hipstr_hmm_upload: total %.3f ms (prepare %.3f, blocks + staging %.3f), %zu B of tables, %lld alignments\n",
+            1e3*std::chrono::duration<double>(std::chrono::steady_clock::now() - t_prep0).count(), 1e3*dev->t_prepare, 1e3*dev->t_stage, total, (long long)P.n_alignments);
   return dev;
 }
 
@@ -625,7 +641,11 @@ int hipstr_debug_prepare(const hipstr_batch_t* batch, int threads, double* secon
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](const void* p, size_t n){ const uint8_t* q = (const uint8_t*)p; for (size_t i = 0; i < n; i++){ h ^= q[i]; h *= 1099511628211ull; } };
 #define HS_MIX(v) mix((v).data(), (v).size()*sizeof((v)[0]))
-    HS_MIX(P.loci); HS_MIX(P.alleles); HS_MIX(P.stropts); HS_MIX(P.rowsets); HS_MIX(P.rows); HS_MIX(P.visits); HS_MIX(P.f64pool); HS_MIX(P.chars);
+    HS_MIX(P.loci); HS_MIX(P.alleles); HS_MIX(P.stropts); HS_MIX(P.rowsets);
+    HS_MIX(P.rows); for (const hipstr::Prepared& f : P.frags) HS_MIX(f.rows);
+    HS_MIX(P.visits); for (const hipstr::Prepared& f : P.frags) HS_MIX(f.visits);
+    HS_MIX(P.f64pool); for (const hipstr::Prepared& f : P.frags) HS_MIX(f.f64pool);
+    HS_MIX(P.chars); for (const hipstr::Prepared& f : P.frags) HS_MIX(f.chars);
     HS_MIX(P.reads); HS_MIX(P.active); HS_MIX(P.seeds); HS_MIX(P.realign_read); HS_MIX(P.realign_hap); HS_MIX(P.ws); HS_MIX(P.lead_items);
     HS_MIX(P.trail_items); HS_MIX(P.tpack); HS_MIX(P.str_order); HS_MIX(P.tgroups); HS_MIX(P.tmembers); HS_MIX(P.chunks);
 #undef HS_MIX

@@ -1125,7 +1125,7 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
         lofs = (lane < HS_MAXREP) ? c.so->del_off[lane] - ins_off : 0;
         llen = (lane < HS_MAXREP) ? c.so->del_len[lane] : 0;
         if (!all_closed) bundle = ins_list[min(lane, max(total, ins_len) - 1)];
-        if (!all_simple){      // descriptor slots of the piecewise-simple lists (only looked at where a shape says so)
+        if (!all_simple && __any((lane <= HS_MAXREP) && (shapes == HS_SHAPE_PIECEWISE))){      // descriptor slots of the piecewise-simple lists (present only where a shape says so: prep.cpp)
           pwA = d.f64pool[so_f64_off + 20 + lane];
           pwB = d.f64pool[so_f64_off + 20 + 64 + min(lane, (HS_MAXREP + 1)*HS_PW_SLOTS - 65)];
         }

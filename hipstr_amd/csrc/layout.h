@@ -52,7 +52,7 @@ struct hs_stropt_t {
   int32_t B;                 // block length
   int32_t nd;                // num_deletions_ (StutterAlignerClass.h:64-69)
   int32_t period;
-  int32_t f64_off;           // into f64 pool: pmf[13] | -int_log(B+1) | -int_log(B+D+1) for D=-p..-6p | 7 x HS_PW_SLOTS descriptor slots
+  int32_t f64_off;           // into f64 pool: pmf[13] | -int_log(B+1) | -int_log(B+D+1) for D=-p..-6p | [7 x HS_PW_SLOTS descriptor slots, only if some list's shape is HS_SHAPE_PIECEWISE]
   int32_t ins_off, ins_len;  // visiting list shared by all insertion sizes
   int32_t del_off[HS_MAXREP], del_len[HS_MAXREP];
   // Shape of each visiting list (index 0..5: deletion lists, 6: insertion list).  Periodic blocks give "simple" lists —

@@ -403,8 +403,13 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
     so.shape[q] = classify(so.del_off[q], so.del_len[q], B+D);
     if (so.shape[q] < 0 && piecewise(so.del_off[q], so.del_len[q], B+D, pw[q])) so.shape[q] = HS_SHAPE_PIECEWISE;
   }
-  for (int k = 0; k <= HS_MAXREP; k++)
-    for (int i = 0; i < HS_PW_SLOTS; i++){ double v; memcpy(&v, &pw[k][i], 8); out.f64pool.push_back(v); }
+  // the descriptor slots are read only where a shape says "piecewise" (hs_str_kernel_generic): 560 bytes that the periodic blocks —
+  // nearly all of them — do not need
+  bool any_pw = false;
+  for (int k = 0; k <= HS_MAXREP; k++) any_pw |= (so.shape[k] == HS_SHAPE_PIECEWISE);
+  if (any_pw)
+    for (int k = 0; k <= HS_MAXREP; k++)
+      for (int i = 0; i < HS_PW_SLOTS; i++){ double v; memcpy(&v, &pw[k][i], 8); out.f64pool.push_back(v); }
   // tabulated closed form: only when every list the kernel can evaluate is simple and the entries fit the LDS budget
   so.tab_off = out.f64pool.size(); so.tab_len = 0;
   {
@@ -693,9 +698,10 @@ static void place_fragment(Prepared& out, Prepared& f, const FragBase& at, std::
   for (hs_tgroup_t& g : f.tgroups){ g.rowset += rowset_base; g.member_off += tm_base; }
   for (std::vector<int>& ls : leads_f) for (int& id : ls) id += rowset_base;
 #define HS_PLACE(field, base) std::copy(f.field.begin(), f.field.end(), out.field.begin() + (base))
-  HS_PLACE(loci, at.loci); HS_PLACE(alleles, at.alleles); HS_PLACE(stropts, at.stropts); HS_PLACE(rowsets, at.rowsets); HS_PLACE(rows, at.rows);
-  HS_PLACE(visits, at.visits); HS_PLACE(f64pool, at.f64); HS_PLACE(chars, at.chars); HS_PLACE(active, at.active); HS_PLACE(realign_hap, at.realign_hap);
+  HS_PLACE(loci, at.loci); HS_PLACE(alleles, at.alleles); HS_PLACE(stropts, at.stropts); HS_PLACE(rowsets, at.rowsets);
+  HS_PLACE(active, at.active); HS_PLACE(realign_hap, at.realign_hap);
   HS_PLACE(str_order, at.order); HS_PLACE(tgroups, at.tgroups); HS_PLACE(tmembers, at.tmembers);
+  // rows, visits, f64pool, chars stay in the fragment (Prepared::frags): the upload gathers them
 #undef HS_PLACE
   for (size_t i = 0; i < leads_f.size(); i++) leads_out[at.leads + i].swap(leads_f[i]);
 }
@@ -766,10 +772,15 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
       out.max_read_len = std::max(out.max_read_len, frag[f].max_read_len); out.n_alignments += frag[f].n_alignments;
     }
     const FragBase& tot = at[n_frag];
-    out.loci.resize(tot.loci); out.alleles.resize(tot.alleles); out.stropts.resize(tot.stropts); out.rowsets.resize(tot.rowsets); out.rows.resize(tot.rows);
-    out.visits.resize(tot.visits); out.f64pool.resize(tot.f64); out.chars.resize(tot.chars); out.active.resize(tot.active); out.realign_hap.resize(tot.realign_hap);
+    out.loci.resize(tot.loci); out.alleles.resize(tot.alleles); out.stropts.resize(tot.stropts); out.rowsets.resize(tot.rowsets);
+    out.active.resize(tot.active); out.realign_hap.resize(tot.realign_hap);
     out.str_order.resize(tot.order); out.tgroups.resize(tot.tgroups); out.tmembers.resize(tot.tmembers); locus_leads.resize(tot.leads);
     parallel_for(n_frag, n_threads, [&](int f){ place_fragment(out, frag[f], at[f], locus_leads, frag_leads[f]); });
+    for (Prepared& f : frag){      // keep only the large pools of the fragments
+      f.loci.clear(); f.alleles.clear(); f.stropts.clear(); f.rowsets.clear(); f.active.clear(); f.realign_hap.clear(); f.str_order.clear();
+      f.tgroups.clear(); f.tmembers.clear();
+    }
+    out.frags = std::move(frag);
   }
   lap("loci", t_lap);
   out.n_out = out_off;

@@ -66,6 +66,14 @@ struct Prepared {
   int64_t n_alignments = 0;   // (active read) x (realigned allele) pairs = HMM alignments per pass
   int32_t max_read_len = 0;
   int32_t max_flank    = 0;   // max n_flank over alleles
+  // Threaded preparation (prep.cpp): the four LARGE pools — rows, visits, f64pool, chars — are not merged on the host; they stay in
+  // the fragments that built them (offsets inside the small pools are already batch-wide) and the upload gathers them straight into
+  // the staging block.  Empty when the batch was prepared by one thread: then the pools above hold everything.
+  std::vector<Prepared> frags;
+  size_t n_rows() const { size_t n = rows.size(); for (const Prepared& f : frags) n += f.rows.size(); return n; }
+  size_t n_visits() const { size_t n = visits.size(); for (const Prepared& f : frags) n += f.visits.size(); return n; }
+  size_t n_f64() const { size_t n = f64pool.size(); for (const Prepared& f : frags) n += f.f64pool.size(); return n; }
+  size_t n_chars() const { size_t n = chars.size(); for (const Prepared& f : frags) n += f.chars.size(); return n; }
 };
 
 // Returns 0 on success; otherwise fills err.

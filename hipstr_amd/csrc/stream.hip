@@ -183,6 +183,54 @@ int64_t hipstr_stream_submit(hipstr_stream_t* s, const hipstr_batch_t* loci){
   return ticket;
 }
 
+// Every locus of `loci` as its own submission, in order (what a region loop does, without a call per region crossing a language
+// boundary): *first_ticket = the ticket of locus 0, the rest follow consecutively.  Stops at the first locus that is refused.
+int hipstr_stream_submit_each(hipstr_stream_t* s, const hipstr_batch_t* loci, int64_t* first_ticket){
+  if (!s || !loci) return hipstr::api_fail("null argument");
+  int opt = 0;
+  for (int l = 0; l < loci->n_loci; l++){
+    hipstr_batch_t one = *loci;
+    const int nopt = loci->blk_nopts[3*l] + loci->blk_nopts[3*l+1] + loci->blk_nopts[3*l+2];
+    const int r0 = loci->read_off[l], r1 = loci->read_off[l+1], h0 = loci->hap_off[l];
+    // a one-locus view into the caller's arrays: offsets are re-based copies, payload pointers are shifted
+    std::vector<int32_t> opt_off(nopt + 1), read_off(2), hap_off(2), base_off(r1 - r0 + 1), cigar_off(r1 - r0 + 1);
+    for (int i = 0; i <= nopt; i++) opt_off[i] = loci->opt_off[opt + i] - loci->opt_off[opt];
+    read_off[0] = 0; read_off[1] = r1 - r0; hap_off[0] = 0; hap_off[1] = loci->hap_off[l+1] - h0;
+    for (int r = r0; r <= r1; r++){ base_off[r - r0] = loci->base_off[r] - loci->base_off[r0]; cigar_off[r - r0] = loci->cigar_off[r] - loci->cigar_off[r0]; }
+    one.n_loci = 1;
+    one.blk_start = loci->blk_start + 3*l; one.blk_end = loci->blk_end + 3*l; one.blk_nopts = loci->blk_nopts + 3*l; one.period = loci->period + l;
+    one.stutter = loci->stutter + 6*l; one.opt_off = opt_off.data(); one.seq = loci->seq + loci->opt_off[opt]; one.hap_off = hap_off.data();
+    one.realign_hap = loci->realign_hap ? loci->realign_hap + h0 : NULL; one.read_off = read_off.data(); one.base_off = base_off.data();
+    one.bases = loci->bases + loci->base_off[r0]; one.quals = loci->quals + loci->base_off[r0]; one.read_start = loci->read_start + r0;
+    one.cigar_off = cigar_off.data(); one.cigar_op = loci->cigar_op + loci->cigar_off[r0]; one.cigar_len = loci->cigar_len + loci->cigar_off[r0];
+    one.realign_read = loci->realign_read ? loci->realign_read + r0 : NULL;
+    const int64_t t = hipstr_stream_submit(s, &one);
+    if (t < 0) return 1;
+    if (l == 0 && first_ticket) *first_ticket = t;
+    opt += nopt;
+  }
+  return 0;
+}
+
+// Collects the next `n_tickets` submissions in order into back-to-back buffers (ticket i's piece starts where ticket i-1's ends);
+// *n_out / *n_reads = what was written.  The counterpart of hipstr_stream_submit_each for callers that want a shard's results at once.
+int hipstr_stream_collect(hipstr_stream_t* s, int64_t n_tickets, double* aln_probs, int64_t cap_probs, int32_t* seeds, int64_t cap_seeds,
+                          int64_t* n_out, int64_t* n_reads){
+  if (!s || n_tickets < 0) return hipstr::api_fail("bad argument");
+  int64_t po = 0, ro = 0;
+  for (int64_t i = 0; i < n_tickets; i++){
+    int64_t t, a, b;
+    const int rs = hipstr_stream_next_size(s, &t, &a, &b);
+    if (rs != 0) return rs == 2 ? hipstr::api_fail("fewer submissions outstanding than asked for") : 1;
+    if (po + a > cap_probs || ro + b > cap_seeds) return hipstr::api_fail("output buffers are too small");
+    if (hipstr_stream_next(s, NULL, aln_probs + po, cap_probs - po, seeds + ro, cap_seeds - ro) != 0) return 1;
+    po += a; ro += b;
+  }
+  if (n_out) *n_out = po;
+  if (n_reads) *n_reads = ro;
+  return 0;
+}
+
 int hipstr_stream_flush(hipstr_stream_t* s){
   if (!s) return hipstr::api_fail("null argument");
   std::lock_guard<std::mutex> g(s->m);

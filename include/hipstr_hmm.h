@@ -190,6 +190,11 @@ typedef struct hipstr_stream_stats {
 hipstr_stream_t* hipstr_stream_open(const hipstr_stream_opts_t* opts /* NULL = defaults on device 0 */);
 /* Queues the loci of `loci` (1..n loci; arrays are copied).  Returns the submission's ticket (0, 1, 2, ...) or -1. */
 int64_t hipstr_stream_submit(hipstr_stream_t* s, const hipstr_batch_t* loci);
+/* Every locus of `loci` as its own submission, in order; *first_ticket = the ticket of locus 0 (the others follow consecutively). */
+int hipstr_stream_submit_each(hipstr_stream_t* s, const hipstr_batch_t* loci, int64_t* first_ticket);
+/* The next n_tickets submissions, in order, into back-to-back buffers; *n_out / *n_reads = doubles / seeds written. */
+int hipstr_stream_collect(hipstr_stream_t* s, int64_t n_tickets, double* aln_probs, int64_t cap_probs, int32_t* seeds, int64_t cap_seeds,
+                          int64_t* n_out, int64_t* n_reads);
 /* Sends the pending batch now, whatever its size. */
 int hipstr_stream_flush(hipstr_stream_t* s);
 /* Sizes of the next submission to be delivered: n_out doubles of aln_probs, n_reads seeds.  Returns 2 when nothing is outstanding. */

@@ -130,3 +130,17 @@ def test_multi_device_blocks_in_global_order(hmm):
         assert t.value == i and np.array_equal(probs[:no.value], wp) and np.array_equal(seeds[:nr.value], ws)
     assert lib.hipstr_multi_next(m, None, None, 0, None, 0) == 2
     lib.hipstr_multi_close(m)
+
+
+def test_submit_each_and_collect(hmm):
+    """The C-side region loop: every locus of a shard its own submission, a shard's results collected back to back."""
+    sb = capi.SynthBatch(n_loci=25, reads_per_locus=18, n_str_alleles=5, seed=41, mask_rate=0.15)
+    want, wseeds = capi.run_align(hmm, "hipstr_hmm_", sb.ptr, fill=FILL)
+    st = capi.Stream(hmm, batch_alignments=700)
+    assert st.submit_each(sb.ptr) == 0 and st.submit_each(sb.ptr) == 25
+    for _ in range(2):
+        probs = np.full(sb.n_out, FILL); seeds = np.full(sb.n_reads, -7, np.int32)
+        assert st.collect(25, probs, seeds) == (sb.n_out, sb.n_reads)
+        assert np.array_equal(probs, want) and np.array_equal(seeds, wseeds)
+    assert st.next() is None
+    st.close()
