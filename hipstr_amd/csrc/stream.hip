@@ -16,6 +16,7 @@
 #include <cstring>
 #include <deque>
 #include <mutex>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -85,8 +86,11 @@ struct OwnedBatch {
 struct InFlight {
   OwnedBatch* ob = NULL;
   hipstr_dev_batch_t* dev = NULL;
-  size_t next_ticket = 0;         // index into ob->tickets of the next one to deliver
+  std::vector<uint8_t> taken;     // per ticket of the batch
+  size_t n_taken = 0;
+  int busy = 0;                   // collectors currently copying out of this batch
   bool failed = false, landed = false;
+  std::mutex land_m;              // the first collector waits for the copy back; the others wait for it
   std::string err;
 };
 
@@ -103,7 +107,9 @@ struct hipstr_stream {
   std::deque<OwnedBatch*> ready;
   std::deque<InFlight*> flying;   // launched (or failed), in submission order
   int in_worker = 0;              // batches the worker has popped but not yet pushed to `flying`
-  int64_t next_ticket = 0, next_deliver = 0;
+  int waiting = 0;                // collectors blocked on a ticket that has not been launched yet
+  int64_t next_ticket = 0, next_deliver = 0;      // next_deliver: the lowest ticket not collected yet
+  std::set<int64_t> taken_ahead;                  // tickets above next_deliver that were collected out of order (hipstr_stream_take)
   std::vector< std::pair<int64_t,int64_t> > sizes;     // per ticket not yet delivered: (n_out, n_reads), indexed by ticket - sizes_base
   int64_t sizes_base = 0;
   bool closing = false;
@@ -114,17 +120,23 @@ struct hipstr_stream {
 
 namespace {
 
+void flush_locked(hipstr_stream* s);
+
 void worker_loop(hipstr_stream* s){
   hipstr::api_bind(s->ctx);
   for (;;){
     OwnedBatch* ob = NULL;
     {
       std::unique_lock<std::mutex> g(s->m);
-      s->cv_work.wait(g, [&]{ return s->closing || (!s->ready.empty() && (int)s->flying.size() + s->in_worker < s->slots); });
+      // work = a batch that was sent, or — when a collector is waiting for a ticket that still sits in the pending batch — the pending
+      // batch as it is: whatever accumulated while the previous batch was being prepared goes out together
+      auto have_work = [&]{ return !s->ready.empty() || (s->waiting > 0 && s->pending && !s->pending->tickets.empty()); };
+      s->cv_work.wait(g, [&]{ return s->closing || (have_work() && (int)s->flying.size() + s->in_worker < s->slots); });
       if (s->closing) return;
+      if (s->ready.empty()) flush_locked(s);
       ob = s->ready.front(); s->ready.pop_front(); s->in_worker++;
     }
-    InFlight* f = new InFlight(); f->ob = ob;
+    InFlight* f = new InFlight(); f->ob = ob; f->taken.assign(ob->tickets.size(), 0);
     const auto t0 = std::chrono::steady_clock::now();
     f->dev = hipstr::upload_on(s->ctx, ob->finish(), NULL, s->copy_stream);
     if (!f->dev){ f->failed = true; f->err = hipstr_last_error(); }
@@ -249,54 +261,77 @@ int hipstr_stream_next_size(hipstr_stream_t* s, int64_t* ticket, int64_t* n_out,
   return 0;
 }
 
-int hipstr_stream_next(hipstr_stream_t* s, int64_t* ticket, double* aln_probs, int64_t cap_probs, int32_t* seeds, int64_t cap_seeds){
+// Collects ONE submission, whichever: blocks until its batch has run.  This is what lets many loci be in flight at once — the
+// reference's genotype() is a per-locus state machine (align, posteriors, tracebacks, new alleles, align again ...): one host thread
+// per locus submits its round and waits for ITS ticket while the rounds of the other loci share the batches.
+int hipstr_stream_take(hipstr_stream_t* s, int64_t ticket, double* aln_probs, int64_t cap_probs, int32_t* seeds, int64_t cap_seeds){
   if (!s) return hipstr::api_fail("null argument");
-  InFlight* f = NULL;
+  InFlight* f = NULL; size_t idx = 0;
   {
     std::unique_lock<std::mutex> g(s->m);
-    if (s->next_deliver >= s->next_ticket) return 2;                     // nothing outstanding
-    // the ticket may still sit in the pending batch: send it on its way
-    if (s->pending && !s->pending->tickets.empty() && s->pending->tickets.front().id <= s->next_deliver) flush_locked(s);
-    s->cv_done.wait(g, [&]{ return !s->flying.empty(); });
-    f = s->flying.front();
+    if (ticket < 0 || ticket >= s->next_ticket) return hipstr::api_fail("no such ticket");
+    if (ticket < s->next_deliver || s->taken_ahead.count(ticket)) return hipstr::api_fail("ticket was collected already");
+    for (;;){
+      for (InFlight* c : s->flying){
+        const int64_t first = c->ob->tickets.front().id;
+        if (ticket >= first && ticket < first + (int64_t)c->ob->tickets.size()){ f = c; idx = (size_t)(ticket - first); break; }
+      }
+      if (f) break;
+      // not launched yet: tell the worker somebody is waiting (it sends the pending batch as soon as it is free), then wait for it
+      s->waiting++;
+      s->cv_work.notify_one();
+      s->cv_done.wait(g);
+      s->waiting--;
+    }
+    if (f->taken[idx]) return hipstr::api_fail("ticket was collected already");
+    f->busy++;
   }
-  const OwnedBatch::Ticket& t = f->ob->tickets[f->next_ticket];
-  int rc = 0;
-  if (f->failed) rc = hipstr::api_fail("batch failed: " + f->err);
-  else if (t.out1 - t.out0 > cap_probs || t.r1 - t.r0 > cap_seeds) return hipstr::api_fail("output buffers are too small for the next ticket (hipstr_stream_next_size)");
+  const OwnedBatch::Ticket& t = f->ob->tickets[idx];
+  int rc = 0; bool small = false;
+  if (t.out1 - t.out0 > cap_probs || t.r1 - t.r0 > cap_seeds){ rc = hipstr::api_fail("output buffers are too small for this ticket (hipstr_stream_next_size)"); small = true; }
   else {
-    if (!f->landed){
-      const auto t0 = std::chrono::steady_clock::now();
-      if (hipstr::results_wait(f->dev) != 0){ f->failed = true; f->err = hipstr_last_error(); rc = 1; }
-      f->landed = true;
-      std::lock_guard<std::mutex> g(s->m);
-      s->stats.wait_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    {
+      std::lock_guard<std::mutex> lg(f->land_m);
+      if (!f->landed && !f->failed){
+        const auto t0 = std::chrono::steady_clock::now();
+        if (hipstr::results_wait(f->dev) != 0){ f->failed = true; f->err = hipstr_last_error(); }
+        f->landed = true;
+        std::lock_guard<std::mutex> g(s->m);
+        s->stats.wait_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      }
     }
-    if (!rc){
-      if ((t.out1 - t.out0) > ((int64_t)1 << 20) && t.l1 - t.l0 >= 8){       // a big ticket: loci are independent, share them among the host threads
-        const hipstr_dev_batch_t* dev = f->dev;
-        const int nl = t.l1 - t.l0, parts = std::min(nl, hipstr::host_threads()*2);
-        const OwnedBatch* ob = f->ob;
-        hipstr::parallel_for(parts, hipstr::host_threads(), [&](int p){
-          const int a = t.l0 + (int)((int64_t)nl*p/parts), b = t.l0 + (int)((int64_t)nl*(p+1)/parts);
-          if (b <= a) return;
-          int64_t out_a = t.out0;       // output offset of locus a relative to the ticket: sum of P*A of the loci before it
-          for (int l = t.l0; l < a; l++) out_a += (int64_t)(ob->read_off[l+1] - ob->read_off[l])*(ob->hap_off[l+1] - ob->hap_off[l]);
-          hipstr::scatter_loci(dev, a, b, aln_probs + (out_a - t.out0), seeds + (ob->read_off[a] - t.r0));
-        });
-      } else hipstr::scatter_loci(f->dev, t.l0, t.l1, aln_probs, seeds);
-    }
+    if (f->failed) rc = hipstr::api_fail("batch failed: " + f->err);
+    else if ((t.out1 - t.out0) > ((int64_t)1 << 20) && t.l1 - t.l0 >= 8){       // a big ticket: loci are independent, share them among the host threads
+      const hipstr_dev_batch_t* dev = f->dev;
+      const int nl = t.l1 - t.l0, parts = std::min(nl, hipstr::host_threads()*2);
+      const OwnedBatch* ob = f->ob;
+      hipstr::parallel_for(parts, hipstr::host_threads(), [&](int p){
+        const int a = t.l0 + (int)((int64_t)nl*p/parts), b = t.l0 + (int)((int64_t)nl*(p+1)/parts);
+        if (b <= a) return;
+        int64_t out_a = t.out0;       // output offset of locus a relative to the ticket: sum of P*A of the loci before it
+        for (int l = t.l0; l < a; l++) out_a += (int64_t)(ob->read_off[l+1] - ob->read_off[l])*(ob->hap_off[l+1] - ob->hap_off[l]);
+        hipstr::scatter_loci(dev, a, b, aln_probs + (out_a - t.out0), seeds + (ob->read_off[a] - t.r0));
+      });
+    } else hipstr::scatter_loci(f->dev, t.l0, t.l1, aln_probs, seeds);
   }
-  if (ticket) *ticket = t.id;
   bool retire = false;
   {
     std::lock_guard<std::mutex> g(s->m);
-    s->next_deliver = t.id + 1;
-    f->next_ticket++;
-    s->stats.tickets++;
-    if (f->next_ticket == f->ob->tickets.size()){ s->flying.pop_front(); retire = true; }
-    // drop delivered entries of the size table now and then
-    if (s->next_deliver - s->sizes_base > 4096){ s->sizes.erase(s->sizes.begin(), s->sizes.begin() + (size_t)(s->next_deliver - s->sizes_base)); s->sizes_base = s->next_deliver; }
+    f->busy--;
+    if (!small){          // a failed batch consumes its tickets too; only "buffer too small" leaves the ticket for another try
+      f->taken[idx] = 1; f->n_taken++;
+      s->stats.tickets++;
+      if (ticket == s->next_deliver){
+        s->next_deliver++;
+        while (!s->taken_ahead.empty() && *s->taken_ahead.begin() == s->next_deliver){ s->taken_ahead.erase(s->taken_ahead.begin()); s->next_deliver++; }
+      } else s->taken_ahead.insert(ticket);
+      // drop delivered entries of the size table now and then
+      if (s->next_deliver - s->sizes_base > 4096){ s->sizes.erase(s->sizes.begin(), s->sizes.begin() + (size_t)(s->next_deliver - s->sizes_base)); s->sizes_base = s->next_deliver; }
+    }
+    if (f->n_taken == f->ob->tickets.size() && f->busy == 0){
+      for (std::deque<InFlight*>::iterator it = s->flying.begin(); it != s->flying.end(); ++it) if (*it == f){ s->flying.erase(it); break; }
+      retire = true;
+    }
   }
   if (retire){
     if (f->dev) hipstr::free_landed(f->dev, f->landed && !f->failed);
@@ -304,6 +339,18 @@ int hipstr_stream_next(hipstr_stream_t* s, int64_t* ticket, double* aln_probs, i
     s->cv_work.notify_one();           // a slot is free
   }
   return rc;
+}
+
+int hipstr_stream_next(hipstr_stream_t* s, int64_t* ticket, double* aln_probs, int64_t cap_probs, int32_t* seeds, int64_t cap_seeds){
+  if (!s) return hipstr::api_fail("null argument");
+  int64_t t;
+  {
+    std::lock_guard<std::mutex> g(s->m);
+    if (s->next_deliver >= s->next_ticket) return 2;                     // nothing outstanding
+    t = s->next_deliver;
+  }
+  if (ticket) *ticket = t;
+  return hipstr_stream_take(s, t, aln_probs, cap_probs, seeds, cap_seeds);
 }
 
 int hipstr_stream_stats(hipstr_stream_t* s, hipstr_stream_stats_t* out){

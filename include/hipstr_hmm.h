@@ -203,6 +203,11 @@ int hipstr_stream_next_size(hipstr_stream_t* s, int64_t* ticket, int64_t* n_out,
  * would have for that submission alone: aln_probs / seeds laid out as hipstr_batch_out_offsets of the submitted batch, entries of
  * reads / haplotypes that were not realigned left untouched.  Returns 0, 1 on error, 2 when nothing is outstanding. */
 int hipstr_stream_next(hipstr_stream_t* s, int64_t* ticket, double* aln_probs, int64_t cap_probs, int32_t* seeds, int64_t cap_seeds);
+/* Collects ONE submission by its ticket, in any order (each ticket once): blocks until its batch has run.  For callers that keep
+ * many loci in flight, one host thread per locus: SeqStutterGenotyper::genotype is a per-locus state machine (align, posteriors,
+ * tracebacks, new alleles, align only those ... seq_stutter_genotyper.cpp:603-671), and the rounds of different loci share batches.
+ * hipstr_stream_next(s, ...) == hipstr_stream_take(s, lowest ticket not collected yet, ...). */
+int hipstr_stream_take(hipstr_stream_t* s, int64_t ticket, double* aln_probs, int64_t cap_probs, int32_t* seeds, int64_t cap_seeds);
 int hipstr_stream_stats(hipstr_stream_t* s, hipstr_stream_stats_t* out);
 /* Drops whatever has not been delivered and releases the stream. */
 int hipstr_stream_close(hipstr_stream_t* s);

@@ -81,12 +81,22 @@ int HapAlignerMI355X::calc_seed_base(const Alignment& alignment){
   return seed;
 }
 
+static hipstr_stream_t* g_shared_stream = NULL;
+void HapAlignerMI355X::use_stream(hipstr_stream* stream){ g_shared_stream = stream; }
+
 void HapAlignerMI355X::process_reads(const std::vector<Alignment>& alignments, int init_read_index, const BaseQuality* base_quality,
 				     const std::vector<bool>& realign_read, double* aln_probs, int* seed_positions){
   assert(alignments.size() == realign_read.size());
   (void)base_quality;     // BaseQuality's tables are constants of the model; the device holds the same values
   FlatReads r(alignments, realign_read);
   FILL_BATCH(b, r)
+  if (g_shared_stream != NULL){      // this locus' round joins whatever the other loci in flight submitted
+    const int64_t ticket = hipstr_stream_submit(g_shared_stream, &b);
+    if (ticket < 0 || hipstr_stream_take(g_shared_stream, ticket, aln_probs + (size_t)init_read_index*fw_haplotype_->num_combs(),
+					 (int64_t)alignments.size()*fw_haplotype_->num_combs(), seed_positions + init_read_index, (int64_t)alignments.size()) != 0)
+      printErrorAndDie(hipstr_last_error());
+    return;
+  }
   if (hipstr_hmm_process_reads(&b, aln_probs + (size_t)init_read_index*fw_haplotype_->num_combs(), seed_positions + init_read_index) != 0)
     printErrorAndDie(hipstr_last_error());
 }

@@ -51,6 +51,11 @@ class HapAlignerMI355X {
  public:
   HapAlignerMI355X(Haplotype* haplotype, std::vector<bool>& realign_to_haplotype);
 
+  // Optional: route process_reads through a shared hipstr_stream_t (include/hipstr_hmm.h) instead of a one-shot call.  With several
+  // loci in flight — one host thread per SeqStutterGenotyper — their alignment rounds then share device batches: each call submits its
+  // locus and waits for its own ticket (hipstr_stream_take).  NULL (the default) = one-shot calls.
+  static void use_stream(struct hipstr_stream* stream);
+
   int calc_seed_base(const Alignment& alignment);
 
   // HapAligner::process_read (HapAligner.h:83, HapAligner.cpp:573-709): one read against every haplotype from the

@@ -115,19 +115,11 @@ void dump_doubles(FILE* f, const char* key, const double* v, size_t n, bool hex)
 
 }  // namespace
 
-extern "C" int flow_main(int argc, char** argv){
-  uint64_t seed = 1; int n_samples = 10, reads_per_sample = 9, period = 4; bool recompute = false, reassemble = true; const char* out_path = NULL;
-  for (int i = 1; i < argc; i++){
-    if (!strcmp(argv[i], "--seed")) seed = strtoull(argv[++i], NULL, 10);
-    else if (!strcmp(argv[i], "--samples")) n_samples = atoi(argv[++i]);
-    else if (!strcmp(argv[i], "--reads")) reads_per_sample = atoi(argv[++i]);
-    else if (!strcmp(argv[i], "--period")) period = atoi(argv[++i]);
-    else if (!strcmp(argv[i], "--recompute")) recompute = true;
-    else if (!strcmp(argv[i], "--no-flanks")) reassemble = false;
-    else if (!strcmp(argv[i], "--out")) out_path = argv[++i];
-    else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
-  }
-  precompute_integer_logs();                 // hipstr_main.cpp:352
+// one locus: seeded reads -> SeqStutterGenotyper -> genotype() [-> recompute_stutter_models()] -> dump to `f`
+struct LocusParams { uint64_t seed; int n_samples, reads_per_sample, period; bool recompute, reassemble; };
+static int run_locus(const LocusParams& lp, FILE* f){
+  const uint64_t seed = lp.seed; const int n_samples = lp.n_samples, reads_per_sample = lp.reads_per_sample, period = lp.period;
+  const bool recompute = lp.recompute, reassemble = lp.reassemble;
   Rng rng(seed);
 
   // ---- a chromosome with one pure repeat, flanks that do not continue it
@@ -183,8 +175,6 @@ extern "C" int flow_main(int argc, char** argv){
   bool ok2 = true;
   if (ok && recompute) ok2 = g.recompute_stutter_models(log, 1000, 4, 0.15, 100, 0.01, 0.001);
 
-  FILE* f = out_path ? fopen(out_path, "w") : stdout;
-  if (!f){ perror(out_path); return 2; }
   fprintf(f, "genotype_ok %d\nrecompute_ok %d\n", ok ? 1 : 0, ok2 ? 1 : 0);
   fprintf(f, "num_reads %u\nnum_samples %d\nnum_pools %d\n", g.num_reads_, g.num_samples_, g.pooler_.num_pools());
   if (ok){
@@ -226,6 +216,90 @@ extern "C" int flow_main(int argc, char** argv){
       if (line.find("Recomputing") != std::string::npos || line.find("Identified") != std::string::npos || line.find("Aborting") != std::string::npos || line.find("candidate") != std::string::npos)
         fprintf(f, "log %d %s\n", n++, line.c_str());
   }
-  if (out_path) fclose(f);
   return ok ? 0 : 1;
+}
+
+#ifdef FLOW_MI355X
+#include "hipstr_hmm.h"
+#include "SeqAlignment/HapAlignerMI355X.h"
+#endif
+#include <atomic>
+#include <chrono>
+#include <thread>
+
+extern "C" int flow_main(int argc, char** argv){
+  LocusParams lp; lp.seed = 1; lp.n_samples = 10; lp.reads_per_sample = 9; lp.period = 4; lp.recompute = false; lp.reassemble = true;
+  const char* out_path = NULL; int n_loci = 0, n_threads = 1; bool use_stream = false;
+  for (int i = 1; i < argc; i++){
+    if (!strcmp(argv[i], "--seed")) lp.seed = strtoull(argv[++i], NULL, 10);
+    else if (!strcmp(argv[i], "--samples")) lp.n_samples = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--reads")) lp.reads_per_sample = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--period")) lp.period = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--recompute")) lp.recompute = true;
+    else if (!strcmp(argv[i], "--no-flanks")) lp.reassemble = false;
+    else if (!strcmp(argv[i], "--out")) out_path = argv[++i];
+    else if (!strcmp(argv[i], "--loci")) n_loci = atoi(argv[++i]);          // many loci (seeds seed, seed+1, ...; periods cycling 2..5) ...
+    else if (!strcmp(argv[i], "--threads")) n_threads = atoi(argv[++i]);    // ... one SeqStutterGenotyper per host thread at a time
+    else if (!strcmp(argv[i], "--stream")) use_stream = true;               // MI355X build: alignment rounds of the loci in flight share batches
+    else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
+  }
+  precompute_integer_logs();                 // hipstr_main.cpp:352
+  init_alignment_model();
+  if (n_loci <= 0){
+    FILE* f = out_path ? fopen(out_path, "w") : stdout;
+    if (!f){ perror(out_path); return 2; }
+    const int rc = run_locus(lp, f);
+    if (out_path) fclose(f);
+    return rc;
+  }
+  // ---- throughput form: n_loci loci through genotype(), n_threads at a time; per-locus dumps are kept and hashed in locus order
+#ifdef FLOW_MI355X
+  hipstr_stream_t* stream = NULL;
+  if (use_stream){
+    hipstr_stream_opts_t o; memset(&o, 0, sizeof o);
+    stream = hipstr_stream_open(&o);
+    if (!stream){ fprintf(stderr, "%s\n", hipstr_last_error()); return 2; }
+    HapAlignerMI355X::use_stream(stream);
+  }
+#else
+  (void)use_stream;
+#endif
+  std::vector<std::string> dumps(n_loci);
+  std::vector<int> rcs(n_loci, 0);
+  std::atomic<int> next(0);
+  const auto t0 = std::chrono::steady_clock::now();
+  auto work = [&](){
+    for (int l = next.fetch_add(1); l < n_loci; l = next.fetch_add(1)){
+      LocusParams q = lp; q.seed = lp.seed + (uint64_t)l; q.period = 2 + (l % 4);
+      char* buf = NULL; size_t len = 0;
+      FILE* f = open_memstream(&buf, &len);
+      rcs[l] = run_locus(q, f);
+      fclose(f);
+      dumps[l].assign(buf, len); free(buf);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < n_threads; t++) pool.emplace_back(work);
+  work();
+  for (std::thread& t : pool) t.join();
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+#ifdef FLOW_MI355X
+  if (stream){ HapAlignerMI355X::use_stream(NULL); hipstr_stream_close(stream); }
+#endif
+  // digest of what cannot differ between the CPU and the MI355X run: everything except the posterior lines (device exp/log: 1e-13)
+  uint64_t h = 1469598103934665603ull; int n_ok = 0;
+  for (int l = 0; l < n_loci; l++){
+    n_ok += rcs[l] == 0;
+    std::istringstream in(dumps[l]); std::string line;
+    while (std::getline(in, line)){
+      if (line.compare(0, 21, "log_sample_posteriors") == 0 || line.compare(0, 16, "sample_total_LLs") == 0) continue;
+      for (char ch : line){ h ^= (uint8_t)ch; h *= 1099511628211ull; }
+    }
+  }
+  FILE* f = out_path ? fopen(out_path, "w") : stdout;
+  if (!f){ perror(out_path); return 2; }
+  fprintf(f, "{\"loci\": %d, \"genotyped\": %d, \"threads\": %d, \"stream\": %d, \"seconds\": %.6f, \"loci_per_s\": %.3f, \"digest\": \"%016llx\"}\n",
+          n_loci, n_ok, n_threads, use_stream ? 1 : 0, dt, n_loci / dt, (unsigned long long)h);
+  if (out_path) fclose(f);
+  return 0;
 }

@@ -95,6 +95,35 @@ def test_mi355x_flow_matches_reference(name, tmp_path):
     _compare(_run("libflow_mi355x.so", CASES[name], tmp_path), _gold(name), loose_ll=name.endswith("recompute"))
 
 
+MANY = ["--loci", "48", "--seed", "100"]
+MANY_DIGEST = "783a92ad2753011a"      # of the CPU run (libflow_ref.so, any thread count): everything but the posterior lines, all 48 dumps in order
+
+
+def _many(lib, extra):
+    r = subprocess.run([LAUNCH, os.path.join(REFDIR, lib)] + MANY + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=900)
+    assert r.returncode == 0, r.stdout
+    import json
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "libflow_ref.so")), reason="reference flow not built (needs the HipSTR tree)")
+def test_reference_many_loci_digest():
+    d = _many("libflow_ref.so", ["--threads", "3"])
+    assert d["genotyped"] == 48 and d["digest"] == MANY_DIGEST
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--threads", "1"], ["--threads", "8", "--stream"]], ids=["one_shot_calls", "eight_loci_in_flight_shared_stream"])
+def test_mi355x_many_loci_in_flight(extra):
+    """48 loci through the reference's genotype(): one-shot device calls, and eight genotypers at a time whose alignment rounds
+    share batches through one hipstr_stream_t (HapAlignerMI355X::use_stream + hipstr_stream_take).  Alleles, pools, seeds,
+    log-likelihood matrices, MAP haplotypes and tracebacks of all 48 loci hash to the CPU run's digest."""
+    if not os.path.exists(os.path.join(REFDIR, "libflow_mi355x.so")):
+        pytest.skip("oracle/_ref/libflow_mi355x.so not built (needs the HipSTR tree at build time)")
+    d = _many("libflow_mi355x.so", extra)
+    assert d["genotyped"] == 48 and d["digest"] == MANY_DIGEST, d
+
+
 if __name__ == "__main__" and "--regen" in sys.argv:
     import tempfile
     for n, a in CASES.items():
