@@ -158,6 +158,19 @@ Ctx* current_ctx(){
 
 int bind(Ctx* c){ HS_HIP(hipSetDevice(c->device)); return 0; }
 
+// One stream per (host thread, device) for the one-shot and resident entry points: calls made from different host threads — several
+// loci in flight, one thread each — neither queue behind one another nor wait for each other's work when they synchronise.
+// Objects remember the stream of the thread that created them; streams live until the process ends.
+hipStream_t thread_stream(Ctx* c){
+  thread_local std::map<Ctx*, hipStream_t> mine;
+  auto it = mine.find(c);
+  if (it != mine.end()) return it->second;
+  hipStream_t st = NULL;
+  if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = c->stream;
+  mine[c] = st;
+  return st;
+}
+
 }  // namespace
 
 // what the other translation units of the library (trace.hip, em.hip, nw.hip) need from this one: api_internal.h
@@ -169,7 +182,7 @@ int api_device_tables(ApiTables* t){
   Ctx* c = api_current_ctx();
   if (!c) return 1;
   t->int_log = c->int_log; t->qual_correct = c->qc; t->qual_error = c->qe; t->m2m = c->m2m; t->m2i = c->m2i;
-  t->stream = c->stream; t->ctx = c;
+  t->stream = thread_stream(c); t->ctx = c;
   return 0;
 }
 void* dev_alloc(Ctx* c, size_t bytes){ return c->dev_cache.get(bytes); }
@@ -188,6 +201,7 @@ struct hipstr_dev_batch {
   size_t lds_bytes = 0;
   hipEvent_t ev0 = NULL, ev1 = NULL;
   hipEvent_t ev_h2d = NULL, ev_done = NULL, ev_d2h = NULL;     // upload finished / last pass finished / results in host_out (pipelined use)
+  hipStream_t stream = NULL;                // launches, copies and waits of this batch default to it (the creating thread's stream)
   hipStream_t h2d_stream = NULL, d2h_stream = NULL;
   double* host_out = NULL;                  // pinned copy of aln_probs (fetch_begin)
   bool profiling = false, foreign_stream = false;
@@ -249,9 +263,9 @@ void hipstr_hmm_free(hipstr_dev_batch_t* dev){
   if (dev->ctx && bind(dev->ctx) == 0){
     // blocks go back to the cache, which hands them to the next batch: whatever still runs on them must have finished
     if (!dev->dev_blocks.empty() || !dev->pin_blocks.empty()){
-      hipStreamSynchronize(dev->ctx->stream);
-      if (dev->h2d_stream && dev->h2d_stream != dev->ctx->stream) hipStreamSynchronize(dev->h2d_stream);
-      if (dev->d2h_stream && dev->d2h_stream != dev->ctx->stream) hipStreamSynchronize(dev->d2h_stream);
+      hipStreamSynchronize(dev->stream);
+      if (dev->h2d_stream && dev->h2d_stream != dev->stream) hipStreamSynchronize(dev->h2d_stream);
+      if (dev->d2h_stream && dev->d2h_stream != dev->stream) hipStreamSynchronize(dev->d2h_stream);
     }
     for (void* p : dev->dev_blocks) dev->ctx->dev_cache.put(p);
     for (void* p : dev->pin_blocks) dev->ctx->pin_cache.put(p);
@@ -274,18 +288,20 @@ hipstr_dev_batch_t* hipstr_hmm_upload(const hipstr_batch_t* batch){ return hipst
 hipstr_dev_batch_t* hipstr_hmm_upload_seeded(const hipstr_batch_t* batch, const int32_t* seed_base){
   Ctx* ctx = hipstr::api_current_ctx();
   if (!ctx) return NULL;
-  return hipstr::upload_on(ctx, batch, seed_base, ctx->stream);
+  hipStream_t st = thread_stream(ctx);
+  return hipstr::upload_on(ctx, batch, seed_base, st, st);
 }
 
 }  // extern "C"
 
 // The upload with the copy on a stream of the caller's choice (the pipelined path copies on its own stream so that the next
 // batch's tables travel while the previous batch's kernels run); hipstr_hmm_align waits for it through an event.
-hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, const int32_t* seed_base, hipStream_t copy_stream){
+hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, const int32_t* seed_base, hipStream_t copy_stream, hipStream_t compute_stream){
   if (bind(ctx)) return NULL;
   hipstr_dev_batch_t* dev = new hipstr_dev_batch_t();
   dev->ctx = ctx;
   dev->h2d_stream = copy_stream;
+  dev->stream = compute_stream;
   std::string err;
   // workspace budget (doubles per workspace; there are two large ones): HIPSTR_WS_GIB, else a fifth of the free HBM, at most 24 GiB
   int64_t budget = (int64_t)3 << 30;
@@ -481,8 +497,8 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
   if (!dev) return fail("null device batch");
   if (dev->h.n_active == 0) return 0;
   if (bind(dev->ctx)) return 1;
-  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : dev->ctx->stream;
-  if (hip_stream && (hipStream_t)hip_stream != dev->ctx->stream) dev->foreign_stream = true;
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : dev->stream;
+  if (hip_stream && (hipStream_t)hip_stream != dev->stream) dev->foreign_stream = true;
   if (dev->h2d_stream != st) HS_HIP(hipStreamWaitEvent(st, dev->ev_h2d, 0));          // the tables were sent on another stream
   const hs_dev_t* dp = dev->d_args;
   auto mark = [&]() -> int {
@@ -553,7 +569,7 @@ int hipstr_hmm_workload(hipstr_dev_batch_t* dev, int64_t* n_alignments, int64_t*
 int hipstr_hmm_align_timed(hipstr_dev_batch_t* dev, int reps, float* ms_total, float* ms_kernel){
   if (!dev || reps < 1 || !ms_total) return fail("bad argument");
   if (bind(dev->ctx)) return 1;
-  hipStream_t st = dev->ctx->stream;
+  hipStream_t st = dev->stream;
   HS_HIP(hipEventRecord(dev->ev0, st));
   for (int i = 0; i < reps; i++) if (hipstr_hmm_align(dev, st)) return 1;
   HS_HIP(hipEventRecord(dev->ev1, st));
@@ -575,10 +591,10 @@ int hipstr_hmm_fetch(hipstr_dev_batch_t* dev, double* aln_probs, int32_t* seeds)
   if (P.n_out){
     tmp = (double*)ctx->pin_cache.get((size_t)P.n_out*sizeof(double));
     if (!tmp) return 1;
-    if (hipMemcpyAsync(tmp, dev->h.aln_probs, (size_t)P.n_out*sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess){
+    if (hipMemcpyAsync(tmp, dev->h.aln_probs, (size_t)P.n_out*sizeof(double), hipMemcpyDeviceToHost, dev->stream) != hipSuccess){
       ctx->pin_cache.put(tmp); return fail("hipMemcpyAsync (device to host) failed"); }
   }
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess){ ctx->pin_cache.put(tmp); return fail("hipStreamSynchronize failed"); }
+  if (hipStreamSynchronize(dev->stream) != hipSuccess){ ctx->pin_cache.put(tmp); return fail("hipStreamSynchronize failed"); }
   // the reference's output contract, locus by locus (loci are independent: shared among the host threads)
   auto scatter = [&](int li){
     const hs_locus_t& loc = P.loci[li];
@@ -678,6 +694,7 @@ int hipstr_post_offsets(const hipstr_post_batch_t* pb, int64_t* post_off, int64_
 namespace {
 struct PostRun {
   Ctx* ctx = NULL;
+  hipStream_t stream = NULL;        // the creating thread's stream
   std::vector<hs_post_unit_t> units;
   std::vector<void*> allocs;        // device blocks from the context's cache
   hs_post_dev_t h;
@@ -686,7 +703,7 @@ struct PostRun {
   int n_reads = 0;
   ~PostRun(){
     if (!ctx || allocs.empty() || bind(ctx)) return;
-    hipStreamSynchronize(ctx->stream);           // the blocks are handed to the next user
+    hipStreamSynchronize(stream);           // the blocks are handed to the next user
     for (void* p : allocs) ctx->dev_cache.put(p);
   }
 };
@@ -721,7 +738,7 @@ int post_setup(const hipstr_post_batch_t* pb, const double* dev_ll, PostRun& R){
     *out = ctx->dev_cache.get(bytes ? bytes : 1);
     if (!*out) return 1;
     R.allocs.push_back(*out);
-    if (src && bytes && hipMemcpyAsync(*out, src, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail("hipMemcpy failed");
+    if (src && bytes && hipMemcpyAsync(*out, src, bytes, hipMemcpyHostToDevice, R.stream) != hipSuccess) return fail("hipMemcpy failed");
     return 0;
   };
   void* p;
@@ -740,7 +757,7 @@ int post_setup(const hipstr_post_batch_t* pb, const double* dev_ll, PostRun& R){
   if (up(NULL, sizeof(int32_t)*2*R.n_samp, &p)) return 1; R.h.map_gt = (int32_t*)p;
   R.h.log_thresh = T.log_thresh; R.h.log_half = T.log_half;
   if (up(&R.h, sizeof R.h, &p)) return 1; R.d_args = (hs_post_dev_t*)p;
-  HS_HIP(hipStreamSynchronize(ctx->stream));       // the sources are the caller's (pageable) arrays: done with them before returning
+  HS_HIP(hipStreamSynchronize(R.stream));       // the sources are the caller's (pageable) arrays: done with them before returning
   return 0;
 }
 }  // namespace
@@ -753,6 +770,7 @@ hipstr_post_dev_t* hipstr_post_upload(const hipstr_post_batch_t* pb, const doubl
   if (!ctx) return NULL;
   hipstr_post_dev_t* pd = new hipstr_post_dev_t();
   pd->R.ctx = ctx;
+  pd->R.stream = thread_stream(ctx);
   if (post_setup(pb, dev_log_aln_probs, pd->R)){ delete pd; return NULL; }
   pd->n_samples.assign(pb->n_samples, pb->n_samples + pb->n_loci);
   pd->n_alleles.assign(pb->n_alleles, pb->n_alleles + pb->n_loci);
@@ -765,8 +783,8 @@ int hipstr_post_launch(hipstr_post_dev_t* pd, void* hip_stream){
   if (!pd) return fail("null argument");
   if (pd->R.units.empty()) return 0;
   if (bind(pd->R.ctx)) return 1;
-  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : pd->R.ctx->stream;
-  if (hip_stream && st != pd->R.ctx->stream) pd->foreign_stream = true;
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : pd->R.stream;
+  if (hip_stream && st != pd->R.stream) pd->foreign_stream = true;
   hipLaunchKernelGGL(hs_posterior_kernel, dim3((unsigned)pd->R.units.size()), dim3(256), 0, st, (const hs_post_dev_t*)pd->R.d_args);
   HS_HIP(hipGetLastError());
   return 0;
@@ -777,7 +795,7 @@ int hipstr_post_fetch(hipstr_post_dev_t* pd, double* log_post, double* sample_to
   PostRun& R = pd->R;
   if (bind(R.ctx)) return 1;
   if (pd->foreign_stream) HS_HIP(hipDeviceSynchronize());
-  HS_HIP(hipStreamSynchronize(R.ctx->stream));
+  HS_HIP(hipStreamSynchronize(R.stream));
   if (!R.units.empty()){
     HS_HIP(hipMemcpy(log_post, R.h.log_post, sizeof(double)*R.n_post, hipMemcpyDeviceToHost));
     HS_HIP(hipMemcpy(sample_total_ll, R.h.sample_total, sizeof(double)*R.n_samp, hipMemcpyDeviceToHost));
@@ -854,7 +872,7 @@ int hipstr_post_extract(hipstr_post_dev_t* pd, const hipstr_gt_request_t* rq, hi
   if (bind(R.ctx)) return 1;
   Ctx* ctx = R.ctx;
   std::vector<void*> tmp;
-  struct Free { Ctx* c; std::vector<void*>& v; ~Free(){ hipStreamSynchronize(c->stream); for (void* p : v) c->dev_cache.put(p); } } guard{ctx, tmp};
+  struct Free { Ctx* c; hipStream_t st; std::vector<void*>& v; ~Free(){ hipStreamSynchronize(st); for (void* p : v) c->dev_cache.put(p); } } guard{ctx, R.stream, tmp};
   auto dalloc = [&](size_t bytes, void** outp) -> int { *outp = ctx->dev_cache.get(bytes ? bytes : 1); if (!*outp) return 1; tmp.push_back(*outp); return 0; };
   hs_gt_dev_t h; memset(&h, 0, sizeof h);
   void* p;
@@ -875,9 +893,9 @@ int hipstr_post_extract(hipstr_post_dev_t* pd, const hipstr_gt_request_t* rq, hi
   h.log_thresh = T.log_thresh;
   if (dalloc(sizeof h, &p)) return 1; HS_HIP(hipMemcpy(p, &h, sizeof h, hipMemcpyHostToDevice));
   if (pd->foreign_stream) HS_HIP(hipDeviceSynchronize());          // the posterior kernel may still be running on a stream of the caller's
-  hipLaunchKernelGGL(hs_genotype_kernel, dim3((unsigned)units.size()), dim3(256), 0, ctx->stream, (const hs_gt_dev_t*)p);
+  hipLaunchKernelGGL(hs_genotype_kernel, dim3((unsigned)units.size()), dim3(256), 0, R.stream, (const hs_gt_dev_t*)p);
   HS_HIP(hipGetLastError());
-  HS_HIP(hipStreamSynchronize(ctx->stream));
+  HS_HIP(hipStreamSynchronize(R.stream));
   HS_HIP(hipMemcpy(out->best_hap, R.h.map_gt, (size_t)so*2*4, hipMemcpyDeviceToHost));
   HS_HIP(hipMemcpy(out->best_gt, h.best_gt, (size_t)so*2*4, hipMemcpyDeviceToHost));
   HS_HIP(hipMemcpy(out->log_phased_post, h.log_phased, (size_t)so*8, hipMemcpyDeviceToHost));

@@ -33,7 +33,7 @@ void  pin_free(Ctx* ctx, void* p);
 }  // namespace hipstr
 struct hipstr_batch; struct hipstr_dev_batch;
 namespace hipstr {
-hipstr_dev_batch* upload_on(Ctx* ctx, const hipstr_batch* batch, const int32_t* seed_base, hipStream_t copy_stream);
+hipstr_dev_batch* upload_on(Ctx* ctx, const hipstr_batch* batch, const int32_t* seed_base, hipStream_t copy_stream, hipStream_t compute_stream);
 int  fetch_begin(hipstr_dev_batch* dev, hipStream_t compute_stream, hipStream_t copy_stream);
 int  results_wait(hipstr_dev_batch* dev);
 void scatter_loci(const hipstr_dev_batch* dev, int l0, int l1, double* aln_probs, int32_t* seeds);   // outputs based at locus l0

@@ -138,7 +138,7 @@ void worker_loop(hipstr_stream* s){
     }
     InFlight* f = new InFlight(); f->ob = ob; f->taken.assign(ob->tickets.size(), 0);
     const auto t0 = std::chrono::steady_clock::now();
-    f->dev = hipstr::upload_on(s->ctx, ob->finish(), NULL, s->copy_stream);
+    f->dev = hipstr::upload_on(s->ctx, ob->finish(), NULL, s->copy_stream, hipstr::ctx_stream(s->ctx));
     if (!f->dev){ f->failed = true; f->err = hipstr_last_error(); }
     else if (hipstr_hmm_align(f->dev, NULL) != 0 || hipstr::fetch_begin(f->dev, hipstr::ctx_stream(s->ctx), s->d2h_stream) != 0){
       f->failed = true; f->err = hipstr_last_error();

@@ -113,6 +113,16 @@ def test_reference_many_loci_digest():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["s1p3", "s5p2", "s3p5_24samples"])
+def test_mi355x_flow_with_batched_retrace(name, tmp_path):
+    """The optional second edit of INTEGRATION.md §2 (retrace_alignments -> one trace_optimal_alns call per locus) leaves every
+    result where it was."""
+    if not os.path.exists(os.path.join(REFDIR, "libflow_mi355x_batched.so")):
+        pytest.skip("oracle/_ref/libflow_mi355x_batched.so not built (needs the HipSTR tree at build time)")
+    _compare(_run("libflow_mi355x_batched.so", CASES[name], tmp_path), _gold(name), loose_ll=False)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("extra", [["--threads", "1"], ["--threads", "8", "--stream"]], ids=["one_shot_calls", "eight_loci_in_flight_shared_stream"])
 def test_mi355x_many_loci_in_flight(extra):
     """48 loci through the reference's genotype(): one-shot device calls, and eight genotypers at a time whose alignment rounds
@@ -120,8 +130,9 @@ def test_mi355x_many_loci_in_flight(extra):
     log-likelihood matrices, MAP haplotypes and tracebacks of all 48 loci hash to the CPU run's digest."""
     if not os.path.exists(os.path.join(REFDIR, "libflow_mi355x.so")):
         pytest.skip("oracle/_ref/libflow_mi355x.so not built (needs the HipSTR tree at build time)")
-    d = _many("libflow_mi355x.so", extra)
-    assert d["genotyped"] == 48 and d["digest"] == MANY_DIGEST, d
+    for lib in ("libflow_mi355x.so", "libflow_mi355x_batched.so"):
+        d = _many(lib, extra)
+        assert d["genotyped"] == 48 and d["digest"] == MANY_DIGEST, (lib, d)
 
 
 if __name__ == "__main__" and "--regen" in sys.argv:
