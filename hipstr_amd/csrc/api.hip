@@ -158,6 +158,21 @@ Ctx* current_ctx(){
 
 int bind(Ctx* c){ HS_HIP(hipSetDevice(c->device)); return 0; }
 
+// Device-to-host copy into the caller's (pageable) array: small ones directly, large ones through a pinned block from the cache
+// (the driver stages pageable copies itself at a fraction of the link rate) and onto the caller's pages by the host threads.
+int fetch_array(Ctx* c, hipStream_t st, void* dst, const void* src, size_t bytes){
+  if (bytes == 0) return 0;
+  if (bytes < ((size_t)4 << 20)){ HS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st)); HS_HIP(hipStreamSynchronize(st)); return 0; }
+  char* pin = (char*)c->pin_cache.get(bytes);
+  if (!pin) return 1;
+  if (hipMemcpyAsync(pin, src, bytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess){
+    c->pin_cache.put(pin); return fail("device-to-host copy failed"); }
+  const size_t span = (size_t)8 << 20; const int n = (int)((bytes + span - 1)/span);
+  hipstr::parallel_for(n, hipstr::host_threads(), [&](int i){ const size_t o = (size_t)i*span; memcpy((char*)dst + o, pin + o, std::min(span, bytes - o)); });
+  c->pin_cache.put(pin);
+  return 0;
+}
+
 // One stream per (host thread, device) for the one-shot and resident entry points: calls made from different host threads — several
 // loci in flight, one thread each — neither queue behind one another nor wait for each other's work when they synchronise.
 // Objects remember the stream of the thread that created them; streams live until the process ends.
@@ -797,9 +812,9 @@ int hipstr_post_fetch(hipstr_post_dev_t* pd, double* log_post, double* sample_to
   if (pd->foreign_stream) HS_HIP(hipDeviceSynchronize());
   HS_HIP(hipStreamSynchronize(R.stream));
   if (!R.units.empty()){
-    HS_HIP(hipMemcpy(log_post, R.h.log_post, sizeof(double)*R.n_post, hipMemcpyDeviceToHost));
-    HS_HIP(hipMemcpy(sample_total_ll, R.h.sample_total, sizeof(double)*R.n_samp, hipMemcpyDeviceToHost));
-    HS_HIP(hipMemcpy(map_gt, R.h.map_gt, sizeof(int32_t)*2*R.n_samp, hipMemcpyDeviceToHost));
+    if (fetch_array(R.ctx, R.stream, log_post, R.h.log_post, sizeof(double)*R.n_post) ||
+        fetch_array(R.ctx, R.stream, sample_total_ll, R.h.sample_total, sizeof(double)*R.n_samp) ||
+        fetch_array(R.ctx, R.stream, map_gt, R.h.map_gt, sizeof(int32_t)*2*R.n_samp)) return 1;
   }
   int64_t so = 0;
   for (size_t l = 0; l < pd->n_samples.size(); l++){     // sum(sample_total_LLs_) in sample order (genotyper.cpp:75)
@@ -903,9 +918,9 @@ int hipstr_post_extract(hipstr_post_dev_t* pd, const hipstr_gt_request_t* rq, hi
   HS_HIP(hipMemcpy(out->hap_log_phased_post, h.hap_log_phased, (size_t)so*8, hipMemcpyDeviceToHost));
   HS_HIP(hipMemcpy(out->hap_log_unphased_post, h.hap_log_unphased, (size_t)so*8, hipMemcpyDeviceToHost));
   if (any) HS_HIP(hipMemcpy(out->gl_diff, h.gl_diff, (size_t)so*8, hipMemcpyDeviceToHost));
-  if (rq->calc_gls) HS_HIP(hipMemcpy(out->gls, h.gls, (size_t)g*8, hipMemcpyDeviceToHost));
-  if (rq->calc_pls) HS_HIP(hipMemcpy(out->pls, h.pls, (size_t)g*4, hipMemcpyDeviceToHost));
-  if (rq->calc_phased_gls) HS_HIP(hipMemcpy(out->phased_gls, h.pgls, (size_t)pg*8, hipMemcpyDeviceToHost));
+  if (rq->calc_gls && fetch_array(ctx, R.stream, out->gls, h.gls, (size_t)g*8)) return 1;
+  if (rq->calc_pls && fetch_array(ctx, R.stream, out->pls, h.pls, (size_t)g*4)) return 1;
+  if (rq->calc_phased_gls && fetch_array(ctx, R.stream, out->phased_gls, h.pgls, (size_t)pg*8)) return 1;
   return 0;
 }
 

@@ -58,8 +58,13 @@ struct hs_em_dev_t {
   double*  new_ll;             // [n_loci]
   double*  sums;               // [7*n_loci] in_up, in_down, in_eq, in_diffs, out_up, out_down, out_diffs
   double*  row_lse;            // scratch: log_sum_exp of every posterior row (s, allele_1); a locus uses [post_off, post_off + S*A)
+  int32_t* cat;                // [R*A per locus, at ll_off] what a read of this size says about the stutter model if it came from this allele:
+                               //   category (0 in_up, 1 in_down, 2 in_eq, 4 out_up, 5 out_down) | diffs vector (3 in, 6 out, 255 none) << 8
+  double*  leff;               // same layout: ln |effective difference| (the addend of the diffs vectors), 0 where there is none
+  double*  part;               // [n_loci][HS_EM_PARTS][7] partial maxima, then partial sums, of the seven M-step vectors
   double   log_thresh, log_half, log_1p1;
 };
+#define HS_EM_PARTS 8          // workgroups per locus in the two big M-step reductions
 
 namespace {
 
@@ -119,7 +124,18 @@ __global__ void __launch_bounds__(256) hs_em_fill(const hs_em_dev_t* __restrict_
   const int A = L.A;
   for (int x = threadIdx.x; x < L.R*A; x += 256){
     const int r = x / A, a = x - r*A;
-    d.ll[L.ll_off + x] = em_pmf(lp, L.period, bps[a], bps[d.obs[L.read_begin + r]]);
+    const int ob = bps[d.obs[L.read_begin + r]];
+    d.ll[L.ll_off + x] = em_pmf(lp, L.period, bps[a], ob);
+    // recalc_stutter_model's bookkeeping for (read, source allele) (:76-104): it does not depend on the iteration, but it is cheap
+    // next to the pmf and keeps the M-step free of integer divisions
+    const int bd = ob - bps[a];
+    int cat = 2, dcat = 255; double le = 0.0;
+    if (bd != 0){
+      if (bd % L.period != 0){ const int eff = bd - bd/L.period; cat = bd > 0 ? 4 : 5; dcat = 6; le = d.int_log[abs(eff)]; }
+      else { const int eff = bd/L.period; cat = bd > 0 ? 0 : 1; dcat = 3; le = d.int_log[abs(eff)]; }
+    }
+    d.cat[L.ll_off + x] = cat | (dcat << 8);
+    d.leff[L.ll_off + x] = le;
   }
   for (int x = threadIdx.x; x < A*A; x += 256){          // EMStutterGenotyper::init_log_sample_priors (:129-144)
     const int i1 = x / A, i2 = x - i1*A;
@@ -143,17 +159,81 @@ __device__ __forceinline__ double block_sum(double v, double* red){
   return out;
 }
 
-__global__ void __launch_bounds__(256) hs_em_mstep(const hs_em_dev_t* __restrict__ dp){
+// recalc_stutter_model (:64-127): seven log-sum-exps over factor = log P(diplotype | sample) + log P(phase | read, diplotype), one term per
+// (read, diplotype, phase) — R x A^2 x 2 of them, the only large loop of the EM.  fast_log_sum_exp needs the maximum first, so the loop
+// runs twice, as two kernels; each locus is cut into HS_EM_PARTS slices (one workgroup each) whose partial maxima / partial sums are
+// combined afterwards: a maximum is order-independent, and the sums are sums of float terms taken in double, exact in any order.
+//   PASS 0: part[l][k][0..6] = maxima of slice k;  hs_em_mstep_keepmax: keep[l][0..6] = their maximum (with the pseudocount entries, :69-71);
+//   PASS 1: part[l][k][0..6] = sums of slice k relative to keep[l]
+template <int PASS>
+__global__ void __launch_bounds__(256) hs_em_mstep_part(const hs_em_dev_t* __restrict__ dp, const double* __restrict__ keep){
+  const hs_em_dev_t& d = *dp;
+  const int l = blockIdx.x, k_part = blockIdx.y, tid = threadIdx.x;
+  if (!d.active[l]) return;
+  const hs_em_locus_t L = d.loci[l];
+  const int A = L.A, nd = A*A;
+  const double* post = d.post + L.post_off;
+  const double* ll = d.ll + L.ll_off;
+  const int32_t* catv = d.cat + L.ll_off;
+  const double* leff = d.leff + L.ll_off;
+  double* part = d.part + ((size_t)l*HS_EM_PARTS)*7;
+  __shared__ double red[256];
+  double mx[7];
+  if (PASS == 1) for (int k = 0; k < 7; k++) mx[k] = keep[7*l + k];      // the maxima over all slices and the pseudocount entries (hs_em_mstep_keepmax)
+  double acc[7];
+  for (int k = 0; k < 7; k++) acc[k] = (PASS == 0) ? ((k == 3 || k == 6) ? d.log_1p1 : 0.0) : 0.0;
+  const int64_t total = (int64_t)L.R*nd;
+  const int64_t x0 = total*k_part/HS_EM_PARTS, x1 = total*(k_part + 1)/HS_EM_PARTS;
+  for (int64_t x = x0 + tid; x < x1; x += 256){
+    const int r = (int)(x / nd), idx = (int)(x - (int64_t)r*nd);
+    const int i1 = idx / A, i2 = idx - i1*A;
+    const int g = L.read_begin + r;
+    // recalc_log_read_phase_posteriors (:152-169); the pmf values are the E-step's log_aln_probs
+    const double one = (d.log_half + d.log_p1[g]) + ll[r*A + i1];
+    const double two = (d.log_half + d.log_p2[g]) + ll[r*A + i2];
+    const double both = e_fast_lse2(one, two, d.log_thresh);
+    const double gp = post[(int64_t)d.sample_label[g]*nd + idx];
+#pragma unroll
+    for (int ph = 0; ph < 2; ph++){
+      const double f = gp + ((ph == 0 ? one : two) - both);
+      const int ia = r*A + (ph == 0 ? i1 : i2);
+      const int c2 = catv[ia];
+      const int cat = c2 & 0xff, dcat = c2 >> 8;
+      const double fd = f + leff[ia];
+#pragma unroll
+      for (int k = 0; k < 7; k++){
+        const bool hit = (k == cat), hitd = (k == dcat);
+        if (hit || hitd){
+          const double v = hit ? f : fd;
+          if (PASS == 0) acc[k] = fmax(acc[k], v);
+          else { const double df = v - mx[k]; if (df > d.log_thresh) acc[k] += (double)e_fasterexp((float)df); }
+        }
+      }
+    }
+  }
+  double out[7];
+  for (int k = 0; k < 7; k++) out[k] = (PASS == 0) ? block_max(acc[k], red) : block_sum(acc[k], red);
+  if (tid == 0) for (int k = 0; k < 7; k++) part[k_part*7 + k] = out[k];
+}
+
+__global__ void __launch_bounds__(64) hs_em_mstep_keepmax(const hs_em_dev_t* __restrict__ dp, double* __restrict__ keep){
+  const hs_em_dev_t& d = *dp;
+  const int l = blockIdx.x;
+  if (!d.active[l] || threadIdx.x >= 7) return;
+  const double* part = d.part + ((size_t)l*HS_EM_PARTS)*7;
+  double m = (threadIdx.x == 3 || threadIdx.x == 6) ? d.log_1p1 : 0.0;
+  for (int q = 0; q < HS_EM_PARTS; q++) m = fmax(m, part[q*7 + threadIdx.x]);
+  keep[7*l + threadIdx.x] = m;
+}
+
+__global__ void __launch_bounds__(256) hs_em_mstep(const hs_em_dev_t* __restrict__ dp, const double* __restrict__ keep){
   const hs_em_dev_t& d = *dp;
   const int l = blockIdx.x, tid = threadIdx.x;
   if (!d.active[l]) return;
   const hs_em_locus_t L = d.loci[l];
-  const int A = L.A, S = L.S, nd = A*A;
+  const int A = L.A, S = L.S;
   const double* post = d.post + L.post_off;
-  const double* lp = d.logp + 9*l;
-  const int32_t* bps = d.bps + L.bps_off;
   double* gtp = d.gtp + L.bps_off;
-  __shared__ double red[256];
 
   // total log-likelihood of the E-step: sum of the sample totals in sample order (genotyper.cpp:75)
   if (tid == 0){
@@ -161,55 +241,16 @@ __global__ void __launch_bounds__(256) hs_em_mstep(const hs_em_dev_t* __restrict
     for (int s = 0; s < S; s++) t += d.sample_total[L.samp_begin + s];
     d.new_ll[l] = t;
   }
-
-  // ---- recalc_stutter_model (:64-127): seven log-sum-exps over factor = log P(diplotype | sample) + log P(phase | read, diplotype)
-  // category of (read, gt allele): 0 in_up, 1 in_down, 2 in_eq, 4 out_up, 5 out_down; diffs (3 in, 6 out) take factor + ln|eff|
-  double mx[7], tot[7];
-  for (int pass = 0; pass < 2; pass++){
-    double acc[7];
-    if (pass == 0){ for (int k = 0; k < 7; k++) acc[k] = 0.0; acc[3] = d.log_1p1; acc[6] = d.log_1p1; }   // pseudocounts (:69-71): maxima
-    else for (int k = 0; k < 7; k++) acc[k] = 0.0;
-    for (int64_t x = tid; x < (int64_t)L.R*nd; x += 256){
-      const int r = (int)(x / nd), idx = (int)(x - (int64_t)r*nd);
-      const int i1 = idx / A, i2 = idx - i1*A;
-      const int g = L.read_begin + r;
-      const int ob = bps[d.obs[g]];
-      // recalc_log_read_phase_posteriors (:152-169)
-      const double one = (d.log_half + d.log_p1[g]) + em_pmf(lp, L.period, bps[i1], ob);
-      const double two = (d.log_half + d.log_p2[g]) + em_pmf(lp, L.period, bps[i2], ob);
-      const double both = e_fast_lse2(one, two, d.log_thresh);
-      const double gp = post[(int64_t)d.sample_label[g]*nd + idx];
-#pragma unroll
-      for (int ph = 0; ph < 2; ph++){
-        const double f = gp + ((ph == 0 ? one : two) - both);
-        const int bd = ob - bps[ph == 0 ? i1 : i2];
-        int cat, dcat = -1; double fd = 0.0;
-        if (bd == 0) cat = 2;
-        else if (bd % L.period != 0){ const int eff = bd - bd/L.period; cat = bd > 0 ? 4 : 5; dcat = 6; fd = f + d.int_log[abs(eff)]; }
-        else { const int eff = bd/L.period; cat = bd > 0 ? 0 : 1; dcat = 3; fd = f + d.int_log[abs(eff)]; }
-#pragma unroll
-        for (int k = 0; k < 7; k++){
-          const bool hit = (k == cat), hitd = (k == dcat);
-          if (hit || hitd){
-            const double v = hit ? f : fd;
-            if (pass == 0) acc[k] = fmax(acc[k], v);
-            else { const double df = v - mx[k]; if (df > d.log_thresh) acc[k] += (double)e_fasterexp((float)df); }
-          }
-        }
-      }
-    }
-    for (int k = 0; k < 7; k++){
-      if (pass == 0) mx[k] = block_max(acc[k], red);
-      else tot[k] = block_sum(acc[k], red);
-    }
-  }
   if (tid == 0){
+    const double* part = d.part + ((size_t)l*HS_EM_PARTS)*7;
     for (int k = 0; k < 7; k++){
-      double t = tot[k];
+      const double mxk = keep[7*l + k];
+      double t = 0.0;
+      for (int q = 0; q < HS_EM_PARTS; q++) t += part[q*7 + k];
       // the pseudocount entries: 0.0 in every vector, ln 1.1 in the two diffs vectors
-      { const double df = 0.0 - mx[k]; if (df > d.log_thresh) t += (double)e_fasterexp((float)df); }
-      if (k == 3 || k == 6){ const double df = d.log_1p1 - mx[k]; if (df > d.log_thresh) t += (double)e_fasterexp((float)df); }
-      d.sums[7*l + k] = mx[k] + (double)e_fasterlog((float)t);
+      { const double df = 0.0 - mxk; if (df > d.log_thresh) t += (double)e_fasterexp((float)df); }
+      if (k == 3 || k == 6){ const double df = d.log_1p1 - mxk; if (df > d.log_thresh) t += (double)e_fasterexp((float)df); }
+      d.sums[7*l + k] = mxk + (double)e_fasterlog((float)t);
     }
   }
 
@@ -366,16 +407,17 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
   hs_em_dev_t h; memset(&h, 0, sizeof h);
   hs_post_dev_t ph; memset(&ph, 0, sizeof ph);
   hs_em_locus_t* d_loci; hs_post_unit_t* d_units; int32_t *d_active, *d_unit_active, *d_bps, *d_obs, *d_lab, *d_w, *d_mapgt;
-  double *d_logp, *d_p1, *d_p2, *d_gtp, *d_ll, *d_prior, *d_post, *d_tot, *d_newll, *d_sums, *d_rowlse;
+  double *d_logp, *d_p1, *d_p2, *d_gtp, *d_ll, *d_prior, *d_post, *d_tot, *d_newll, *d_sums, *d_rowlse, *d_leff, *d_part, *d_keep; int32_t* d_cat;
   std::vector<int32_t> ones(n_reads, 1);
   if (dev.put(&d_loci, loci.data(), loci.size()) || dev.put(&d_units, units.data(), units.size()) || dev.alloc(&d_active, nl) ||
       dev.alloc(&d_unit_active, units.size()) || dev.put(&d_bps, bps.data(), bps.size()) || dev.put(&d_obs, obs.data(), obs.size()) ||
       dev.put(&d_lab, eb->sample_label, n_reads) || dev.put(&d_w, ones.data(), ones.size()) || dev.alloc(&d_mapgt, 2*(size_t)samp_off) ||
       dev.alloc(&d_logp, 9*(size_t)nl) || dev.put(&d_p1, eb->log_p1, n_reads) || dev.put(&d_p2, eb->log_p2, n_reads) ||
       dev.put(&d_gtp, gtp.data(), gtp.size()) || dev.alloc(&d_ll, ll_off) || dev.alloc(&d_prior, prior_off) || dev.alloc(&d_post, post_off) ||
-      dev.alloc(&d_tot, samp_off) || dev.alloc(&d_newll, nl) || dev.alloc(&d_sums, 7*(size_t)nl) || dev.alloc(&d_rowlse, post_off)) return 1;
+      dev.alloc(&d_tot, samp_off) || dev.alloc(&d_newll, nl) || dev.alloc(&d_sums, 7*(size_t)nl) || dev.alloc(&d_rowlse, post_off) ||
+      dev.alloc(&d_cat, ll_off) || dev.alloc(&d_leff, ll_off) || dev.alloc(&d_part, 7*(size_t)HS_EM_PARTS*nl) || dev.alloc(&d_keep, 7*(size_t)nl)) return 1;
   h.loci = d_loci; h.active = d_active; h.logp = d_logp; h.bps = d_bps; h.obs = d_obs; h.sample_label = d_lab; h.log_p1 = d_p1; h.log_p2 = d_p2;
-  h.gtp = d_gtp; h.ll = d_ll; h.prior = d_prior; h.post = d_post; h.sample_total = d_tot; h.int_log = T.int_log; h.new_ll = d_newll; h.sums = d_sums; h.row_lse = d_rowlse;
+  h.gtp = d_gtp; h.ll = d_ll; h.prior = d_prior; h.post = d_post; h.sample_total = d_tot; h.int_log = T.int_log; h.new_ll = d_newll; h.sums = d_sums; h.row_lse = d_rowlse; h.cat = d_cat; h.leff = d_leff; h.part = d_part;
   h.log_thresh = HT.log_thresh; h.log_half = HT.log_half; h.log_1p1 = log(1.1);
   ph.units = d_units; ph.log_aln_probs = d_ll; ph.log_p1 = d_p1; ph.log_p2 = d_p2; ph.read_weight = d_w; ph.log_prior = d_prior;
   ph.unit_active = d_unit_active; ph.log_post = d_post; ph.sample_total = d_tot; ph.map_gt = d_mapgt;
@@ -413,7 +455,10 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
     EM_HIP(hipMemcpy(d_logp, logp.data(), logp.size()*sizeof(double), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(hs_em_fill, dim3(nl), dim3(256), 0, T.stream, d_h);
     hipLaunchKernelGGL(hs_posterior_kernel, dim3((unsigned)units.size()), dim3(256), 0, T.stream, (const hs_post_dev_t*)d_ph);
-    hipLaunchKernelGGL(hs_em_mstep, dim3(nl), dim3(256), 0, T.stream, d_h);
+    hipLaunchKernelGGL(hs_em_mstep_part<0>, dim3(nl, HS_EM_PARTS), dim3(256), 0, T.stream, d_h, (const double*)NULL);
+    hipLaunchKernelGGL(hs_em_mstep_keepmax, dim3(nl), dim3(64), 0, T.stream, d_h, d_keep);
+    hipLaunchKernelGGL(hs_em_mstep_part<1>, dim3(nl, HS_EM_PARTS), dim3(256), 0, T.stream, d_h, (const double*)d_keep);
+    hipLaunchKernelGGL(hs_em_mstep, dim3(nl), dim3(256), 0, T.stream, d_h, (const double*)d_keep);
     EM_HIP(hipGetLastError());
     EM_HIP(hipStreamSynchronize(T.stream));
     EM_HIP(hipMemcpy(newll.data(), d_newll, nl*sizeof(double), hipMemcpyDeviceToHost));
