@@ -853,6 +853,9 @@ int hipstr_post_extract(hipstr_post_dev_t* pd, const hipstr_gt_request_t* rq, hi
   PostRun& R = pd->R;
   const hipstr::HostTables& T = hipstr::host_tables();
   const size_t n_loci = pd->n_samples.size();
+  const bool timing = getenv("HIPSTR_TIMING") != NULL;
+  auto t_lap = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what){ if (timing){ const auto t2 = std::chrono::steady_clock::now(); fprintf(stderr, "hipstr_post_extract: %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t2 - t_lap).count()); t_lap = t2; } };
   std::vector<hs_gt_unit_t> units;
   std::vector<int32_t> gmem, goff;
   int64_t po = 0, tot = 0, g = 0, pg = 0; int so = 0, map_off = 0;
@@ -884,6 +887,7 @@ int hipstr_post_extract(hipstr_post_dev_t* pd, const hipstr_gt_request_t* rq, hi
     po += (int64_t)S*A*A; map_off += A;
   }
   if (units.empty()) return 0;
+  lap("units");
   if (bind(R.ctx)) return 1;
   Ctx* ctx = R.ctx;
   std::vector<void*> tmp;
@@ -910,7 +914,9 @@ int hipstr_post_extract(hipstr_post_dev_t* pd, const hipstr_gt_request_t* rq, hi
   if (pd->foreign_stream) HS_HIP(hipDeviceSynchronize());          // the posterior kernel may still be running on a stream of the caller's
   hipLaunchKernelGGL(hs_genotype_kernel, dim3((unsigned)units.size()), dim3(256), 0, R.stream, (const hs_gt_dev_t*)p);
   HS_HIP(hipGetLastError());
+  lap("setup");
   HS_HIP(hipStreamSynchronize(R.stream));
+  lap("kernel");
   HS_HIP(hipMemcpy(out->best_hap, R.h.map_gt, (size_t)so*2*4, hipMemcpyDeviceToHost));
   HS_HIP(hipMemcpy(out->best_gt, h.best_gt, (size_t)so*2*4, hipMemcpyDeviceToHost));
   HS_HIP(hipMemcpy(out->log_phased_post, h.log_phased, (size_t)so*8, hipMemcpyDeviceToHost));
@@ -921,6 +927,7 @@ int hipstr_post_extract(hipstr_post_dev_t* pd, const hipstr_gt_request_t* rq, hi
   if (rq->calc_gls && fetch_array(ctx, R.stream, out->gls, h.gls, (size_t)g*8)) return 1;
   if (rq->calc_pls && fetch_array(ctx, R.stream, out->pls, h.pls, (size_t)g*4)) return 1;
   if (rq->calc_phased_gls && fetch_array(ctx, R.stream, out->phased_gls, h.pgls, (size_t)pg*8)) return 1;
+  lap("fetch");
   return 0;
 }
 

@@ -159,6 +159,62 @@ __device__ __forceinline__ double block_sum(double v, double* red){
   return out;
 }
 
+// recalc_log_gt_priors (:22-57) of one locus by one workgroup: thread a owns allele a; the two scans in the reference's order.
+// Independent of the stutter reductions, so it rides in their first launch as one more slice (blockIdx.y == HS_EM_PARTS).
+__device__ void em_gt_priors(const hs_em_dev_t& d, const hs_em_locus_t& L, int tid){
+  const int A = L.A, S = L.S;
+  const double* post = d.post + L.post_off;
+  double* gtp = d.gtp + L.bps_off;
+  // log_sum_exp of every row (sample, allele_1) first, all rows in parallel (each row summed in allele_2 order as the reference does);
+  // the streaming scans below are sequential per allele by definition
+  double* row_lse = d.row_lse + L.post_off;     // S*A values in this locus' own S*A*A region: disjoint between loci whatever their A
+  for (int x = tid; x < S*A; x += 256){
+    const double* row = post + (int64_t)x*A;
+    double rm = row[0];
+    for (int j = 1; j < A; j++) rm = fmax(rm, row[j]);
+    double rs = 0.0;
+    for (int j = 0; j < A; j++) rs += exp(row[j] - rm);
+    row_lse[x] = rm + log(rs);
+  }
+  __syncthreads();
+  // The scans are one dependent chain per allele; the values they eat are fetched eight at a time ahead of the chain, or every step
+  // would wait out a trip to L2.
+#define EM_SCAN_STEP(lv) do { if ((lv) <= m) t += exp((lv) - m); else { t *= exp(m - (lv)); t += 1.0; m = (lv); } } while (0)
+  for (int a = tid; a < A; a += 256){
+    double m = -DBL_MAX/2, t = 0.0;
+    int s = 0;
+    for (; s + 8 <= S; s += 8){                          // first allele of the diplotype: log_sum_exp of row (s, a)
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) v[q] = row_lse[(int64_t)(s + q)*A + a];
+#pragma unroll
+      for (int q = 0; q < 8; q++) EM_SCAN_STEP(v[q]);
+    }
+    for (; s < S; s++){ const double lv = row_lse[(int64_t)s*A + a]; EM_SCAN_STEP(lv); }
+    const int64_t n2 = (int64_t)S*A;                     // second allele: (s, i1) in order is one run of stride A from post[a]
+    int64_t y = 0;
+    for (; y + 8 <= n2; y += 8){
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) v[q] = post[(y + q)*A + a];
+#pragma unroll
+      for (int q = 0; q < 8; q++) EM_SCAN_STEP(v[q]);
+    }
+    for (; y < n2; y++){ const double lv = post[y*A + a]; EM_SCAN_STEP(lv); }
+    gtp[a] = m + log(t);
+  }
+#undef EM_SCAN_STEP
+  __syncthreads();
+  if (tid == 0){                                          // normalise: exact log_sum_exp in allele order
+    double m = gtp[0];
+    for (int a = 1; a < A; a++) m = fmax(m, gtp[a]);
+    double t = 0.0;
+    for (int a = 0; a < A; a++) t += exp(gtp[a] - m);
+    const double lt = m + log(t);
+    for (int a = 0; a < A; a++) gtp[a] -= lt;
+  }
+}
+
 // recalc_stutter_model (:64-127): seven log-sum-exps over factor = log P(diplotype | sample) + log P(phase | read, diplotype), one term per
 // (read, diplotype, phase) — R x A^2 x 2 of them, the only large loop of the EM.  fast_log_sum_exp needs the maximum first, so the loop
 // runs twice, as two kernels; each locus is cut into HS_EM_PARTS slices (one workgroup each) whose partial maxima / partial sums are
@@ -171,6 +227,7 @@ __global__ void __launch_bounds__(256) hs_em_mstep_part(const hs_em_dev_t* __res
   const int l = blockIdx.x, k_part = blockIdx.y, tid = threadIdx.x;
   if (!d.active[l]) return;
   const hs_em_locus_t L = d.loci[l];
+  if (PASS == 0 && k_part == HS_EM_PARTS){ em_gt_priors(d, L, tid); return; }
   const int A = L.A, nd = A*A;
   const double* post = d.post + L.post_off;
   const double* ll = d.ll + L.ll_off;
@@ -182,32 +239,59 @@ __global__ void __launch_bounds__(256) hs_em_mstep_part(const hs_em_dev_t* __res
   if (PASS == 1) for (int k = 0; k < 7; k++) mx[k] = keep[7*l + k];      // the maxima over all slices and the pseudocount entries (hs_em_mstep_keepmax)
   double acc[7];
   for (int k = 0; k < 7; k++) acc[k] = (PASS == 0) ? ((k == 3 || k == 6) ? d.log_1p1 : 0.0) : 0.0;
-  const int64_t total = (int64_t)L.R*nd;
-  const int64_t x0 = total*k_part/HS_EM_PARTS, x1 = total*(k_part + 1)/HS_EM_PARTS;
-  for (int64_t x = x0 + tid; x < x1; x += 256){
-    const int r = (int)(x / nd), idx = (int)(x - (int64_t)r*nd);
-    const int i1 = idx / A, i2 = idx - i1*A;
+  // A thread owns (read r, source allele a) and walks the other allele j: both phases' terms with source a — phase 0 of diplotype
+  // (a, j) and phase 1 of (j, a) — feed the same two vectors (the category and diffs vector of (r, a), hs_em_fill), so the
+  // seven-way choice is made once per (r, a) and the walk itself is branch-free.
+  const int total = L.R*A;
+  const int x0 = (int)((int64_t)total*k_part/HS_EM_PARTS), x1 = (int)((int64_t)total*(k_part + 1)/HS_EM_PARTS);
+  for (int x = x0 + tid; x < x1; x += 256){
+    const int r = x / A, a = x - r*A;
     const int g = L.read_begin + r;
     // recalc_log_read_phase_posteriors (:152-169); the pmf values are the E-step's log_aln_probs
-    const double one = (d.log_half + d.log_p1[g]) + ll[r*A + i1];
-    const double two = (d.log_half + d.log_p2[g]) + ll[r*A + i2];
-    const double both = e_fast_lse2(one, two, d.log_thresh);
-    const double gp = post[(int64_t)d.sample_label[g]*nd + idx];
-#pragma unroll
-    for (int ph = 0; ph < 2; ph++){
-      const double f = gp + ((ph == 0 ? one : two) - both);
-      const int ia = r*A + (ph == 0 ? i1 : i2);
-      const int c2 = catv[ia];
-      const int cat = c2 & 0xff, dcat = c2 >> 8;
-      const double fd = f + leff[ia];
+    const double b1 = d.log_half + d.log_p1[g], b2 = d.log_half + d.log_p2[g];
+    const double one_a = b1 + ll[x], two_a = b2 + ll[x];
+    const double* gp = post + (int64_t)d.sample_label[g]*nd;
+    const double* llr = ll + r*A;
+    const int c2 = catv[x];
+    const int cat = c2 & 0xff, dcat = c2 >> 8;
+    const double le = leff[x];
+    const bool same = (b1 == b2);                         // no phasing information: the two mixtures of a pair are the same number
+    if (PASS == 0){
+      double m = -DBL_MAX;
+      for (int j = 0; j < A; j++){
+        const double lj = llr[j];
+        const double both0 = e_fast_lse2(one_a, b2 + lj, d.log_thresh);                       // diplotype (a, j)
+        const double both1 = same ? both0 : e_fast_lse2(b1 + lj, two_a, d.log_thresh);        // diplotype (j, a)
+        m = fmax(m, fmax(gp[a*A + j] + (one_a - both0), gp[j*A + a] + (two_a - both1)));
+      }
+      const double md = m + le;                           // adding one number keeps the order: max(f) + le == max(f + le)
 #pragma unroll
       for (int k = 0; k < 7; k++){
-        const bool hit = (k == cat), hitd = (k == dcat);
-        if (hit || hitd){
-          const double v = hit ? f : fd;
-          if (PASS == 0) acc[k] = fmax(acc[k], v);
-          else { const double df = v - mx[k]; if (df > d.log_thresh) acc[k] += (double)e_fasterexp((float)df); }
+        if (k == cat) acc[k] = fmax(acc[k], m);
+        if (k == dcat) acc[k] = fmax(acc[k], md);
+      }
+    } else {
+      double mc = 0.0, md = 0.0;
+#pragma unroll
+      for (int k = 0; k < 7; k++){ if (k == cat) mc = mx[k]; if (k == dcat) md = mx[k]; }
+      const bool has_d = dcat < 7;
+      double sc = 0.0, sd = 0.0;
+      for (int j = 0; j < A; j++){
+        const double lj = llr[j];
+        const double both0 = e_fast_lse2(one_a, b2 + lj, d.log_thresh);
+        const double both1 = same ? both0 : e_fast_lse2(b1 + lj, two_a, d.log_thresh);
+        const double f0 = gp[a*A + j] + (one_a - both0), f1 = gp[j*A + a] + (two_a - both1);
+        { const double df = f0 - mc; if (df > d.log_thresh) sc += (double)e_fasterexp((float)df); }
+        { const double df = f1 - mc; if (df > d.log_thresh) sc += (double)e_fasterexp((float)df); }
+        if (has_d){
+          { const double df = (f0 + le) - md; if (df > d.log_thresh) sd += (double)e_fasterexp((float)df); }
+          { const double df = (f1 + le) - md; if (df > d.log_thresh) sd += (double)e_fasterexp((float)df); }
         }
+      }
+#pragma unroll
+      for (int k = 0; k < 7; k++){
+        if (k == cat) acc[k] += sc;
+        if (k == dcat) acc[k] += sd;
       }
     }
   }
@@ -231,9 +315,7 @@ __global__ void __launch_bounds__(256) hs_em_mstep(const hs_em_dev_t* __restrict
   const int l = blockIdx.x, tid = threadIdx.x;
   if (!d.active[l]) return;
   const hs_em_locus_t L = d.loci[l];
-  const int A = L.A, S = L.S;
-  const double* post = d.post + L.post_off;
-  double* gtp = d.gtp + L.bps_off;
+  const int S = L.S;
 
   // total log-likelihood of the E-step: sum of the sample totals in sample order (genotyper.cpp:75)
   if (tid == 0){
@@ -252,43 +334,6 @@ __global__ void __launch_bounds__(256) hs_em_mstep(const hs_em_dev_t* __restrict
       if (k == 3 || k == 6){ const double df = d.log_1p1 - mxk; if (df > d.log_thresh) t += (double)e_fasterexp((float)df); }
       d.sums[7*l + k] = mxk + (double)e_fasterlog((float)t);
     }
-  }
-
-  // ---- recalc_log_gt_priors (:22-57): thread a owns allele a; the two scans in the reference's order
-  __syncthreads();
-  // log_sum_exp of every row (sample, allele_1) first, all rows in parallel (each row summed in allele_2 order as the reference does);
-  // the streaming scans below are sequential per allele by definition
-  double* row_lse = d.row_lse + L.post_off;     // S*A values in this locus' own S*A*A region: disjoint between loci whatever their A
-  for (int x = tid; x < S*A; x += 256){
-    const double* row = post + (int64_t)x*A;
-    double rm = row[0];
-    for (int j = 1; j < A; j++) rm = fmax(rm, row[j]);
-    double rs = 0.0;
-    for (int j = 0; j < A; j++) rs += exp(row[j] - rm);
-    row_lse[x] = rm + log(rs);
-  }
-  __syncthreads();
-  for (int a = tid; a < A; a += 256){
-    double m = -DBL_MAX/2, t = 0.0;
-    for (int s = 0; s < S; s++){                         // first allele of the diplotype: log_sum_exp of row (s, a)
-      const double lv = row_lse[(int64_t)s*A + a];
-      if (lv <= m) t += exp(lv - m); else { t *= exp(m - lv); t += 1.0; m = lv; }
-    }
-    for (int s = 0; s < S; s++)                          // second allele
-      for (int i1 = 0; i1 < A; i1++){
-        const double lv = post[((int64_t)s*A + i1)*A + a];
-        if (lv <= m) t += exp(lv - m); else { t *= exp(m - lv); t += 1.0; m = lv; }
-      }
-    gtp[a] = m + log(t);
-  }
-  __syncthreads();
-  if (tid == 0){                                          // normalise: exact log_sum_exp in allele order
-    double m = gtp[0];
-    for (int a = 1; a < A; a++) m = fmax(m, gtp[a]);
-    double t = 0.0;
-    for (int a = 0; a < A; a++) t += exp(gtp[a] - m);
-    const double lt = m + log(t);
-    for (int a = 0; a < A; a++) gtp[a] -= lt;
   }
 }
 
@@ -455,7 +500,7 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
     EM_HIP(hipMemcpy(d_logp, logp.data(), logp.size()*sizeof(double), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(hs_em_fill, dim3(nl), dim3(256), 0, T.stream, d_h);
     hipLaunchKernelGGL(hs_posterior_kernel, dim3((unsigned)units.size()), dim3(256), 0, T.stream, (const hs_post_dev_t*)d_ph);
-    hipLaunchKernelGGL(hs_em_mstep_part<0>, dim3(nl, HS_EM_PARTS), dim3(256), 0, T.stream, d_h, (const double*)NULL);
+    hipLaunchKernelGGL(hs_em_mstep_part<0>, dim3(nl, HS_EM_PARTS + 1), dim3(256), 0, T.stream, d_h, (const double*)NULL);     // slice HS_EM_PARTS: the allele-frequency priors
     hipLaunchKernelGGL(hs_em_mstep_keepmax, dim3(nl), dim3(64), 0, T.stream, d_h, d_keep);
     hipLaunchKernelGGL(hs_em_mstep_part<1>, dim3(nl, HS_EM_PARTS), dim3(256), 0, T.stream, d_h, (const double*)d_keep);
     hipLaunchKernelGGL(hs_em_mstep, dim3(nl), dim3(256), 0, T.stream, d_h, (const double*)d_keep);
