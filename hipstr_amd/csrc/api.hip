@@ -30,6 +30,8 @@ extern "C" __global__ void hs_combine_kernel(const hs_dev_t* dp, int active_begi
 extern "C" __global__ void hs_posterior_kernel(const hs_post_dev_t* dp);
 extern "C" __global__ void hs_genotype_kernel(const hs_gt_dev_t* dp);
 extern "C" size_t hs_str_lds_bytes(int lds_len, int max_B);
+extern "C" __global__ void hs_str_group_kernel(const hs_dev_t* dp, int item_begin);
+extern "C" size_t hs_str_group_lds_bytes(int max_B);
 extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk);
 extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk);
 
@@ -212,7 +214,8 @@ struct hipstr_dev_batch {
   hs_dev_t h;             // host copy of the argument block (device pointers inside)
   hs_dev_t* d_args = NULL;
   std::vector<void*> dev_blocks, pin_blocks;      // from the context's caches
-  int grid_y = 1, max_alleles = 1, n_lead_items = 0, trail_waves = 1;
+  int grid_y = 1, max_alleles = 1, n_lead_items = 0, n_trail_items = 0, trail_waves = 1;
+  size_t grp_lds_bytes = 0;
   size_t lds_bytes = 0;
   hipEvent_t ev0 = NULL, ev1 = NULL;
   hipEvent_t ev_h2d = NULL, ev_done = NULL, ev_d2h = NULL;     // upload finished / last pass finished / results in host_out (pipelined use)
@@ -367,7 +370,9 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   };
   std::vector<hs_item_t> items(P.lead_items);
   items.insert(items.end(), P.trail_items.begin(), P.trail_items.end());
+  items.insert(items.end(), P.str_items.begin(), P.str_items.end());
   dev->n_lead_items = (int)P.lead_items.size();
+  dev->n_trail_items = (int)P.trail_items.size();
 #define PL(vec) place((vec).data(), (vec).size()*sizeof((vec)[0]))
   const size_t i_loci = PL(P.loci), i_alleles = PL(P.alleles), i_stropts = PL(P.stropts), i_rowsets = PL(P.rowsets),
     i_rows = place_pool(P.rows.data(), P.rows.size()*sizeof(hs_row_t), &hipstr::Prepared::rows, sizeof(hs_row_t)),
@@ -424,6 +429,8 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   h.max_B = P.max_B;
   dev->lds_bytes = hs_str_lds_bytes(h.lds_len, h.max_B);
   if (dev->lds_bytes > 160*1024){ g_err = "batch needs more than 160 KiB of LDS per workgroup"; hipstr_hmm_free(dev); return NULL; }
+  dev->grp_lds_bytes = hs_str_group_lds_bytes(h.max_B);
+  if (dev->grp_lds_bytes > 48*1024) HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->grp_lds_bytes));
   if (dev->lds_bytes > 48*1024){
     HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->lds_bytes));
     HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_kernel_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->lds_bytes));
@@ -530,7 +537,12 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
     // leading flanks: persistent wavefronts striding over (locus side, distinct flank, 64 reads) items
     hs_launch_lead2(nact, (unsigned)std::max(1, std::min(dev->trail_waves, ch.lead_end - ch.lead_begin)), st, dp, ch.active_begin, ch.lead_begin, ch.lead_end, 2*chunk_no);
     if (mark()) return 1;
-    hipLaunchKernelGGL(hs_str_kernel, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin);
+    // tabulated alleles: reads of a locus side packed into workgroups (HIPSTR_STR_GROUP=0: one workgroup per read, for comparison)
+    static const bool str_group = !(getenv("HIPSTR_STR_GROUP") && atoi(getenv("HIPSTR_STR_GROUP")) == 0);
+    if (!str_group) hipLaunchKernelGGL(hs_str_kernel, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin);
+    else if (ch.str_end > ch.str_begin)
+      hipLaunchKernelGGL(hs_str_group_kernel, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), dev->grp_lds_bytes, st, dp,
+                         dev->n_lead_items + dev->n_trail_items + ch.str_begin);
     // alleles without a tabulated closed form (interrupted repeats, very long blocks) and whatever hs_str_kernel marked HS_REDO
     hipLaunchKernelGGL(hs_str_kernel_generic, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin);
     if (mark()) return 1;
@@ -678,7 +690,7 @@ int hipstr_debug_prepare(const hipstr_batch_t* batch, int threads, double* secon
     HS_MIX(P.f64pool); for (const hipstr::Prepared& f : P.frags) HS_MIX(f.f64pool);
     HS_MIX(P.chars); for (const hipstr::Prepared& f : P.frags) HS_MIX(f.chars);
     HS_MIX(P.reads); HS_MIX(P.active); HS_MIX(P.seeds); HS_MIX(P.realign_read); HS_MIX(P.realign_hap); HS_MIX(P.ws); HS_MIX(P.lead_items);
-    HS_MIX(P.trail_items); HS_MIX(P.tpack); HS_MIX(P.str_order); HS_MIX(P.tgroups); HS_MIX(P.tmembers); HS_MIX(P.chunks);
+    HS_MIX(P.trail_items); HS_MIX(P.str_items); HS_MIX(P.tpack); HS_MIX(P.str_order); HS_MIX(P.tgroups); HS_MIX(P.tmembers); HS_MIX(P.chunks);
 #undef HS_MIX
     const int64_t tail[8] = { P.ws_mr_size, P.ws_lt_size, P.ws_lead_size, P.ws_col_size, P.max_side_len, P.max_B, P.n_out, P.n_alignments };
     mix(tail, sizeof tail);

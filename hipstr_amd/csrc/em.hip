@@ -22,6 +22,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <chrono>
 
 #include "../../include/hipstr_hmm.h"
 #include "post_layout.h"
@@ -397,6 +398,15 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
   if (hipstr::api_device_tables(&T)) return 1;
   const hipstr::HostTables& HT = hipstr::host_tables();
   const int n_reads = eb->read_off[nl];
+  const bool timing = getenv("HIPSTR_TIMING") != NULL;
+  auto t_prev = std::chrono::steady_clock::now();
+  double t_gpu = 0.0, t_host = 0.0;
+  auto lap = [&](const char* what, double* into){
+    const auto now = std::chrono::steady_clock::now();
+    const double dt = std::chrono::duration<double>(now - t_prev).count();
+    t_prev = now;
+    if (into) *into += dt; else if (timing) fprintf(stderr, "hipstr_em_train: %s %.3f ms\n", what, 1e3*dt);
+  };
 
   // ---- alleles, read -> allele index, initial allele frequencies (em_stutter_genotyper.h:55-100, .cpp:10-20)
   std::vector<hs_em_locus_t> loci(nl);
@@ -447,6 +457,7 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
     post_off += (int64_t)S*A*A; ll_off += (int64_t)R*A; prior_off += (int64_t)A*A; samp_off += S;
   }
 
+  lap("alleles and units", NULL);
   // ---- device state
   EmBufs dev;
   hs_em_dev_t h; memset(&h, 0, sizeof h);
@@ -470,6 +481,7 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
   hs_em_dev_t* d_h; hs_post_dev_t* d_ph;
   if (dev.put(&d_h, &h, 1) || dev.put(&d_ph, &ph, 1)) return 1;
 
+  lap("device state", NULL);
   // ---- the EM loop of train() (:171-226), all loci in lock step, converged loci masked out
   struct State { double sp[6]; double LL; int it; bool done, ok; };
   std::vector<State> st(nl);
@@ -495,6 +507,7 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
     }
     if (n_active == 0) break;
     for (size_t u = 0; u < units.size(); u++) unit_active[u] = active[unit_locus[u]];
+    lap("", &t_host);
     EM_HIP(hipMemcpy(d_active, active.data(), nl*sizeof(int32_t), hipMemcpyHostToDevice));
     EM_HIP(hipMemcpy(d_unit_active, unit_active.data(), units.size()*sizeof(int32_t), hipMemcpyHostToDevice));
     EM_HIP(hipMemcpy(d_logp, logp.data(), logp.size()*sizeof(double), hipMemcpyHostToDevice));
@@ -508,6 +521,7 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
     EM_HIP(hipStreamSynchronize(T.stream));
     EM_HIP(hipMemcpy(newll.data(), d_newll, nl*sizeof(double), hipMemcpyDeviceToHost));
     EM_HIP(hipMemcpy(sums.data(), d_sums, sums.size()*sizeof(double), hipMemcpyDeviceToHost));
+    lap("", &t_gpu);
     for (int l = 0; l < nl; l++){
       State& s = st[l];
       if (!active[l]) continue;
@@ -534,6 +548,7 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
       s.LL = new_LL; s.it++;
     }
   }
+  if (timing) fprintf(stderr, "hipstr_em_train: iterations: copies + kernels %.3f ms, host updates %.3f ms\n", 1e3*t_gpu, 1e3*t_host);
   for (int l = 0; l < nl; l++){
     trained[l] = st[l].ok ? 1 : 0;
     memcpy(stutter + 6*(size_t)l, st[l].sp, 6*sizeof(double));

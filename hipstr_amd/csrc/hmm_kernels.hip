@@ -820,9 +820,9 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
     const int slot = uni(al->lead_slot[w]), str_opt = uni(al->str_opt[w]);
     double* mr_out = d.ws_mr + v.ws_mr + (int64_t)uni(al->re_ord)*(v.len-1) + (w ? v.nL : 0);
     if (MODE == 1 && !own){
-      bool marked = false;
-      for (int kk = 0; kk < ncyc; kk++) marked |= (mr_out[64*kk] == HS_REDO);
-      if (!uni((int)marked)) continue;
+      bool marked = false;                            // hs_str_group_kernel marks the columns of a wavefront, which may be any stretch of the side
+      for (int kk = 0; kk < ncyc; kk++){ const int jj = lane + 64*kk; marked |= (jj < n) && (mr_out[min(jj, n-1)] == HS_REDO); }
+      if (!__any(marked)) continue;
     }
     wave_lds_sync();                // the previous allele's readers of rowP/Mt/Dl are done
     if (slot != cur_slot){          // M of the row before the STR block, from the leading-flank kernel
@@ -1294,6 +1294,379 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){ str_body<0>(*d
 #endif
 extern "C" __global__ void __launch_bounds__(128, HS_STRG_WAVES)
 hs_str_kernel_generic(const hs_dev_t* __restrict__ dp, int active_begin){ str_body<1>(*dp, active_begin); }
+
+// ------------------------------------------------------------------ the STR block of tabulated alleles, grouped form
+// hs_str_kernel gives every read side its own wavefront: a 150-base read seeded in the middle has ~75 columns per side, two passes of
+// 64 lanes with 11 live lanes in the second, and the read-end deletion sums of a chained allele fill 24 lanes (profiles/r02_notes.md:
+// 29 % and 21 % of the phase).  Here a workgroup takes a GROUP of reads of one locus and side (prep.cpp packs them so that their
+// columns fill HS_GRP_COLS) and lays their columns end to end over its lanes: lane x = column j of read g, the per-column tables of all
+// reads back to back in LDS, the alleles still one after the other (they are the same for every read of the locus, in the same order).
+// What was wave-uniform per read (side length, workspace rows) becomes a per-lane value; what a column reads from its neighbours
+// (Mt[j - D], Dl[q][j + |D|], rowP[j - len]) stays inside its own read's stretch by the same clamps as before.  Same operations in the same
+// order per column as str_body<0>: bit-identical.  Two workgroup barriers per allele separate the table phase from the evaluation;
+// the allele's block, constants and closed-form table are double-buffered so that loading the next allele needs no third one.
+#define HS_GRP_MAXREADS 16
+#ifndef HS_GABL
+#define HS_GABL 0          // timing experiments only (results invalid): 1 no read-end sums, 2 no evaluation, 3 no table phase, 4 no barriers
+#endif
+#define HS_GRP_NDCAP 768       // doubles per read-end deletion table of a group (two of them): sum over the group's reads of 21 p
+struct GrpLds {
+  double2* bq; double* rowP; double* Mt; double* Dl; uint8_t* rd; const double* ilog;
+  double* nd[2]; double* cstl[2]; double* tab[2]; uint8_t* blk[2];
+  int ld;
+};
+extern "C" size_t hs_str_group_lds_bytes(int max_B){
+  const size_t XC = HS_GRP_COLS;
+  const size_t ilog_len = ((size_t)max_B + 9) & ~(size_t)1, blk_len = ((size_t)max_B + 19) & ~(size_t)15;
+  return XC*8*HS_MAXREP + XC*16 + XC*8*2 + ilog_len*8 + 2*HS_GRP_NDCAP*8 + 2*24*8 + 2*2*HS_TAB_CAP*8 + 2*blk_len + XC + 16;
+}
+
+__device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin){
+  constexpr int XC = HS_GRP_COLS, NT = HS_GRP_COLS;
+  const int lane = threadIdx.x & 63, x = threadIdx.x;
+  const hs_item_t* item = d.items + item_begin + blockIdx.x;
+  const int side = uni(item->side), G = uni(item->slot), tp = uni(item->active);
+  __shared__ int s_off[HS_GRP_MAXREADS + 1], s_n[HS_GRP_MAXREADS], s_ai[HS_GRP_MAXREADS];
+  GrpLds L;
+  {
+    double* Dl = (double*)hs_lds_raw;                       // first: masked steps may touch up to B entries in front of bq / rd
+    double2* bq = (double2*)(Dl + HS_MAXREP*XC);
+    double* rowP = (double*)(bq + XC);
+    double* Mt = rowP + XC;
+    const int ilog_len = (d.max_B + 9) & ~1, blk_len = (d.max_B + 19) & ~15;
+    double* ilog = Mt + XC;
+    double* ndb = ilog + ilog_len;
+    double* cst = ndb + 2*HS_GRP_NDCAP;
+    double* tab = cst + 2*24;
+    uint8_t* blkb = (uint8_t*)(tab + 2*2*HS_TAB_CAP);
+    uint8_t* rdb = blkb + 2*blk_len;
+    L.bq = bq; L.rowP = rowP; L.Mt = Mt; L.Dl = Dl; L.rd = rdb; L.ilog = ilog; L.ld = XC;
+    for (int b = 0; b < 2; b++){ L.nd[b] = ndb + b*HS_GRP_NDCAP; L.cstl[b] = cst + b*24; L.tab[b] = tab + b*2*HS_TAB_CAP; L.blk[b] = blkb + b*blk_len; }
+    for (int i = x; i < ilog_len; i += NT) ilog[i] = d.int_log[i];
+  }
+  if (x < G){
+    const int ai = d.tpack[tp + x];
+    const hs_read_t r = d.reads[d.active[ai]];
+    s_ai[x] = ai; s_n[x] = side ? r.len - r.seed - 1 : r.seed;
+  }
+  __syncthreads();
+  if (x == 0){ int o = 0; for (int g = 0; g < G; g++){ s_off[g] = o; o += s_n[g]; } s_off[G] = o; }
+  __syncthreads();
+  const int X = s_off[G];
+  // this lane's column: read g, column j of n (lanes past the last column repeat it and write nothing)
+  const bool actj = x < X;
+  const bool wave_act = (x & ~63) < X;            // a wavefront without columns only helps with the read-end sums
+  const int xx = min(x, X - 1);
+  int g = 0;
+  for (int k = 1; k < G; k++) g += (xx >= s_off[k]) ? 1 : 0;
+  const int offg = s_off[g], n = s_n[g], j = xx - offg, ai = s_ai[g];
+  const hs_read_t rdv = d.reads[d.active[ai]];
+  const hs_locus_t* loc = d.loci + uni(rdv.locus);
+  const hs_ws_t wsr = d.ws[ai];
+  const int lenm1 = rdv.len - 1;
+  double* const mr_base = d.ws_mr + wsr.mr + (side ? rdv.seed : 0) + j;               // + re_ord*(len-1): this column in the allele's MR row
+  const int lead_stride = n + uni(loc->lead_flank[side]) + 1;
+  const double* const lead_base = d.ws_lead + wsr.lead[side] + j;                     // + slot*lead_stride: rowP of this column
+  {
+    const int src = rdv.base_off + (side ? rdv.len - 1 - j : j);
+    const uint8_t q = (uint8_t)d.quals[src];
+    if (actj){ L.rd[xx] = (uint8_t)d.bases[src]; L.bq[xx] = make_double2(d.qual_correct[q], d.qual_error[q]); }
+  }
+  const int n_tab = uni(loc->n_tab[side]);
+  const int i0 = blockIdx.y * d.allele_chunk, i1 = min(n_tab, i0 + d.allele_chunk);
+  const int32_t* order = d.str_order + uni(loc->order_off[side]);
+  const int jmaxw = uni(wave_max_i(j)), jminw = uni(wave_min_i(j));
+  const int nh_l = s_n[min(lane, G - 1)];                       // lane h < G: columns of read h
+  // The alleles' records are fetched 64 at a time, one allele per lane (order entry -> allele -> STR option: three dependent loads, paid
+  // once), and read lane by lane; what an allele needs beyond them (constants, block, closed-form table) is requested one allele ahead.
+  int a_oe = 0, a_slot = 0, a_reord = 0, a_sopt = 0, a_seq = 0, a_B = 0, a_nv = 0, a_p = 1, a_f64 = 0, a_taboff = 0, a_tablen = 0, a_ndeq = 0;
+  auto fetch_alleles = [&](int first){
+    const int k = min(first + lane, i1 - 1);
+    a_oe = order[k];
+    const hs_allele_t* al = d.alleles + uni(loc->hap_begin) + (a_oe & 0x1fffffff);
+    a_slot = al->lead_slot[side]; a_reord = al->re_ord; a_sopt = al->str_opt[side];
+    const hs_stropt_t* so = d.stropts + a_sopt;
+    a_seq = so->seq_off; a_B = so->B; a_nv = so->nd; a_p = so->period; a_f64 = so->f64_off; a_taboff = so->tab_off; a_tablen = so->tab_len; a_ndeq = so->nd_eq;
+  };
+  double nx_cst = 0.0, nx_bmin = 0.0, nx_tabA = 0.0, nx_tabG = 0.0; int nx_shapes = -1, nx_tbase = 0, nx_blkw = 0;
+  auto request = [&](int k){                          // k: lane of the allele in the fetched batch
+    const int f64o = rdlane(a_f64, k), sopt = rdlane(a_sopt, k), tl = rdlane(a_tablen, k), Bk = rdlane(a_B, k);
+    const double* tsrc = d.f64pool + rdlane(a_taboff, k);
+    nx_cst = d.f64pool[f64o + min(lane, 19)];        // lane t < 20: pmf[13] | prior_ins | prior_del[6]
+    nx_shapes = (lane <= HS_MAXREP) ? d.stropts[sopt].shape[lane] : -1;
+    nx_tbase = (lane <= HS_MAXREP) ? d.stropts[sopt].tab_base[lane] : 0;
+    nx_bmin = tsrc[3*tl];
+    nx_blkw = (x < (Bk + 3)/4) ? ((const int*)(d.chars + rdlane(a_seq, k)))[x] : 0;
+    if (x < tl){ nx_tabA = tsrc[3*x]; nx_tabG = tsrc[3*x + 1]; }
+  };
+  if (i0 < i1){ fetch_alleles(i0); request(0); }
+  int cur_slot = -1, prev_B = 0;
+  for (int i = i0; i < i1; i++){
+    const int par = (i - i0) & 1;
+    const int k = (i - i0) & 63;
+    const int oe = rdlane(a_oe, k);
+    const bool chained = (i > i0) && ((oe >> 30) & 1);
+    const int slot = rdlane(a_slot, k), re_ord = rdlane(a_reord, k);
+    double* const mr_out = mr_base + (int64_t)re_ord*lenm1;
+    const int B = rdlane(a_B, k), nv = rdlane(a_nv, k), p = rdlane(a_p, k), nd_eq = rdlane(a_ndeq, k), tab_len = rdlane(a_tablen, k);
+    const int nds = 21*p;                                     // read-end deletion sums of one read: sizes back to back, at most (q+1)p columns each
+    const int ndb = g*nds;
+    const double cst = nx_cst;
+    const int shapes = nx_shapes, tbase = nx_tbase;
+    const double tab_bmin = uni(nx_bmin);
+    if (slot != cur_slot){          // M of the row before the STR block, from the leading-flank kernel: the previous allele's readers first
+      if (HS_GABL != 4) __syncthreads();
+      if (actj) L.rowP[xx] = lead_base[(int64_t)slot*lead_stride];
+      cur_slot = slot;
+    }
+    // this allele's block, constants and table go to the buffers the allele before the previous one used
+    if (x < (B + 3)/4) ((int*)L.blk[par])[x] = nx_blkw;
+    if (x < 20) L.cstl[par][x] = cst;
+    if (x < tab_len){ L.tab[par][x] = nx_tabA; L.tab[par][HS_TAB_CAP + x] = nx_tabG; }
+    if (i + 1 < i1){
+      if (k == 63) fetch_alleles(i + 1);
+      request((k + 1) & 63);
+    }
+    if (HS_GABL != 4) __syncthreads();                // ... and every wavefront is done with the previous allele's Mt / Dl
+    const uint8_t* blk = L.blk[par];
+    const double* cstl = L.cstl[par];
+    const double* tab = L.tab[par];
+    double* nd = L.nd[par];
+    const double* nd_prev = L.nd[par ^ 1];
+
+    // --- StutterAlignerClass::load_read (StutterAlignerClass.cpp:12-53): match_probs_ and del_probs_ of this lane's column
+    const int t0 = chained ? prev_B : 0;
+    prev_B = B;
+    const int tmax = min(B, jmaxw + 1);          // a step t > j is masked: no lane of this wavefront goes past its largest column
+    if (wave_act && t0 < tmax && HS_GABL != 3){
+      double lp = (t0 > 0) ? L.Mt[xx] : 0.0;
+      const int ndp = nv * p;
+      int t = t0;
+      if (t < min(tmax, ndp)){
+        const uint8_t* prd = L.rd + (xx - t); const double2* pbq = L.bq + (xx - t);
+        int left = j - t, ph = (t + 1) % p;
+        double* dl = L.Dl + ((t + 1)/p - 1)*L.ld + xx;
+        for (; t < min(tmax, ndp); t++){
+          const double e = emit(*prd, blk[B-1-t], *pbq);
+          if (left >= 0) lp += e;
+          if (ph == 0){ if (left >= 0 && actj) *dl = lp; }
+          ph++; if (ph == p){ ph = 0; dl += L.ld; }
+          prd--; pbq--; left--;
+        }
+      }
+      auto steps = [&](int tend, auto masked){
+        int xr = xx - t - 3, xb = B - 1 - t - 3;
+        for (; t + 4 <= tend; t += 4){
+          asm volatile("" : "+v"(xr));
+          const uint8_t* prd = L.rd + xr; const double2* pbq = L.bq + xr;
+#pragma unroll
+          for (int k = 0; k < 4; k++){
+            const double e = emit(prd[3-k], blk[xb + 3 - k], pbq[3-k]);
+            if (!decltype(masked)::value || xr + 3 - k >= offg) lp += e;
+          }
+          xr -= 4; xb -= 4;
+        }
+        for (; t < tend; t++){
+          const double e = emit(L.rd[xr + 3], blk[xb + 3], L.bq[xr + 3]);
+          if (!decltype(masked)::value || xr + 3 >= offg) lp += e;
+          xr--; xb--;
+        }
+      };
+      if (t < tmax){
+        steps(min(tmax, jminw + 1), std::false_type());
+        steps(tmax, std::true_type());
+      }
+      if (actj) L.Mt[xx] = lp;
+    }
+
+    // --- deletion start values of the columns whose segment reaches the read end (the `else` branch of StutterAlignerClass.cpp:117-120),
+    // (size, column) pairs of all reads of the group spread over the workgroup's lanes; layout per read as in str_body
+    {
+      auto nd_sum = [&](int q, int xcol, int jcol, bool valid, int dst){
+        const int aD = (q+1)*p;
+        const int len = min(B - aD, jcol + 1);
+        const int lmin = uni(wave_min_i(len)), lmax = uni(wave_max_i(len));
+        double lp = cstl[14 + q];
+        int xr = xcol - 3, xb = (B - 1 - aD) - 3, t = 0;
+        for (; t + 4 <= lmin; t += 4){
+          asm volatile("" : "+v"(xr), "+v"(xb));
+          const uint8_t* prd = L.rd + xr; const double2* pbq = L.bq + xr; const uint8_t* pbk = blk + xb;
+#pragma unroll
+          for (int k = 0; k < 4; k++) lp += emit(prd[3-k], pbk[3-k], pbq[3-k]);
+          xr -= 4; xb -= 4;
+        }
+        for (; t + 4 <= lmax; t += 4){
+          asm volatile("" : "+v"(xr), "+v"(xb));
+          const uint8_t* prd = L.rd + xr; const double2* pbq = L.bq + xr; const uint8_t* pbk = blk + xb;
+#pragma unroll
+          for (int k = 0; k < 4; k++){
+            const double e = emit(prd[3-k], pbk[3-k], pbq[3-k]);
+            if (t + k < len) lp += e;
+          }
+          xr -= 4; xb -= 4;
+        }
+        for (; t < lmax; t++){
+          const double e = emit(L.rd[xr + 3], blk[xb + 3], L.bq[xr + 3]);
+          if (t < len) lp += e;
+          xr--; xb--;
+        }
+        if (valid) nd[dst] = lp;
+      };
+      auto row_off = [&](int q){ return p*((q*(q+1)) >> 1); };
+      const bool reuse_al = chained && ((oe >> 29) & 1);
+      const int ncopy = row_off(nv - 1);
+      // per read: rows move up one size (reuse) + the new pairs, or every pair of the read.  Lane h < G counts read h's work, a
+      // prefix sum over those lanes numbers the work of all reads back to back, and every lane finds its own item by the prefix
+      int c_l = 0, cc_l = 0;
+      {
+        const bool ru = reuse_al && (nh_l >= nv*p);
+        int np_l = 0;
+#pragma unroll
+        for (int q = 0; q < HS_MAXREP; q++) np_l += (B - (q+1)*p >= 0) ? min((q+1)*p, nh_l) : 0;
+        if (lane < G){ c_l = ru ? nv*p : np_l; cc_l = ru ? ncopy : 0; }
+      }
+      int pc = c_l, pcc = cc_l;                               // inclusive prefix sums over lanes 0..15
+#pragma unroll
+      for (int dd = 1; dd < HS_GRP_MAXREADS; dd <<= 1){
+        const int t1 = __shfl_up(pc, dd), t2 = __shfl_up(pcc, dd);
+        if (lane >= dd){ pc += t1; pcc += t2; }
+      }
+      const int n_sums = rdlane(pc, HS_GRP_MAXREADS - 1), n_copies = rdlane(pcc, HS_GRP_MAXREADS - 1);
+      auto find = [&](int pref, int e, int& hh, int& loc_e){   // read hh holds item e: prefix(hh-1) <= e < prefix(hh)
+        hh = 0; loc_e = e;
+        for (int h = 0; h + 1 < G; h++){
+          const int ph = rdlane(pref, h);
+          if (e >= ph){ hh = h + 1; loc_e = e - ph; }
+        }
+      };
+      for (int base = 0; base < ((HS_GABL == 1) ? 0 : n_copies); base += NT){
+        const int e = base + x;
+        if (e < n_copies){
+          int hh, idx0; find(pcc, e, hh, idx0);
+          int qn = 1;
+#pragma unroll
+          for (int k = 1; k <= 4; k++) qn += (idx0 >= row_off(k)) ? 1 : 0;
+          const int idx = idx0 - row_off(qn - 1);
+          nd[hh*nds + row_off(qn) + p + idx] = nd_prev[hh*nds + row_off(qn - 1) + idx];
+        }
+      }
+      for (int base = 0; base < ((HS_GABL == 1) ? 0 : n_sums); base += NT){
+        const int wbase = base + (x & ~63);
+        if (wbase >= n_sums) break;                           // whole wavefront past the end (wave-uniform)
+        const int e = min(base + x, n_sums - 1);
+        const bool valid = base + x < n_sums;
+        int hh, loc_e; find(pc, e, hh, loc_e);
+        const int nh = s_n[hh], offh = s_off[hh];
+        const bool ruh = reuse_al && (nh >= nv*p);
+        int q = 0, off = loc_e, jcol, dst;
+        if (ruh){
+#pragma unroll
+          for (int k = 1; k <= 5; k++) q += (loc_e >= k*p) ? 1 : 0;
+          off = loc_e - q*p;
+          jcol = (nh - (q+1)*p) + off;
+          dst = row_off(q) + off;
+        } else {
+          int cnt[HS_MAXREP];
+#pragma unroll
+          for (int qq = 0; qq < HS_MAXREP; qq++) cnt[qq] = (B - (qq+1)*p >= 0) ? min((qq+1)*p, nh) : 0;
+#pragma unroll
+          for (int qq = 0; qq < HS_MAXREP - 1; qq++) if (q == qq && off >= cnt[qq]){ off -= cnt[qq]; q = qq + 1; }
+          jcol = max(0, nh - (q+1)*p) + off;
+          dst = loc_e;
+        }
+        nd_sum(q, offh + jcol, jcol, valid, hh*nds + dst);
+      }
+    }
+    if (HS_GABL != 4) __syncthreads();
+
+    // --- the 13 artifact terms of this lane's column (HapAligner.cpp:62-109) and their fast_log_sum_exp
+    if (wave_act && HS_GABL != 2){
+      double terms[HS_NART];
+      double lp0_max = 0.0;
+      auto tab_eval = [&](double lp0, int lim, int k) -> double {
+        const int e = rdlane(tbase, k) + min(lim, 1) + max(lim - rdlane(shapes, k), 0);
+        const double A = tab[e], Gv = tab[HS_TAB_CAP + e];
+        lp0_max = fmax(lp0_max, fabs(lp0));
+        return (lp0 + A) + Gv;
+      };
+      {
+        const int len = min(B, j + 1);
+        const double pre = (j - len < 0) ? 0.0 : L.rowP[xx - min(len, j)];
+        terms[HS_MAXREP] = (rdlane(cst, HS_MAXREP) + L.Mt[xx]) + pre;
+      }
+      auto ins_term = [&](int q, double li){
+        const int D = (q+1)*p;
+        const int len = min(B + D, j + 1);
+        const double lp0 = (rdlane(cst, 13) + li) + ((len > D) ? L.Mt[xx - min(D, j)] : 0.0);
+        const int lim = actj ? min(max(0, len - D), B) : 0;
+        const double S = tab_eval(lp0, lim, HS_MAXREP);
+        const double pre = (j - len < 0) ? 0.0 : L.rowP[xx - min(len, j)];
+        return (rdlane(cst, HS_MAXREP + 1 + q) + S) + pre;
+      };
+      if (nd_eq == HS_MAXREP){
+#pragma unroll
+        for (int q = 0; q < HS_MAXREP; q++)
+          terms[HS_MAXREP + 1 + q] = ins_term(q, (j >= (q+1)*p - 1) ? L.Dl[q*L.ld + xx] : L.Mt[xx]);
+      } else {
+        double li = 0.0;
+        const double2* pli_bq = L.bq + (xx - nd_eq*p); const uint8_t* pli_rd = L.rd + (xx - nd_eq*p); int li_left = j - nd_eq*p;
+#pragma unroll
+        for (int q = 0; q < HS_MAXREP; q++){
+          if (q < nd_eq){
+            li = (j >= (q+1)*p - 1) ? L.Dl[q*L.ld + xx] : L.Mt[xx];
+          } else {
+            for (int m = 0; m < p; m++){
+              const double2 bq = *pli_bq;
+              const double e = (m < B) ? emit(*pli_rd, blk[B-1-min(m, B-1)], bq) : bq.x;
+              if (li_left >= 0) li += e;
+              pli_bq--; pli_rd--; li_left--;
+            }
+          }
+          terms[HS_MAXREP + 1 + q] = ins_term(q, li);
+        }
+      }
+      int ndo = ndb;                                  // first (size q, column) pair of this lane's read: sizes 0..q-1 come first
+#pragma unroll
+      for (int q = 0; q < HS_MAXREP; q++){
+        const int aD = (q+1)*p;
+        terms[HS_MAXREP - 1 - q] = IMP;
+        if (B - aD >= 0){
+          const int cq = min(aD, n);
+          const int len = min(B - aD, j + 1);
+          const bool direct = (j + aD <= n - 1);
+          const int xd = xx + min(aD, n - 1 - j);
+          const double dsum = L.Mt[xd] - L.Dl[q*L.ld + xd];
+          const double ndv = nd[ndo + min(max(j - (n - cq), 0), cq - 1)];
+          const double lp0 = direct ? rdlane(cst, 14 + q) + dsum : ndv;
+          const double S = tab_eval(lp0, actj ? len : 0, q);
+          const double pre = (j - len < 0) ? 0.0 : L.rowP[xx - min(len, j)];
+          terms[HS_MAXREP - 1 - q] = (rdlane(cst, HS_MAXREP - 1 - q) + S) + pre;
+          ndo += cq;
+        }
+      }
+      bool bad = !(lp0_max < tab_bmin);
+      if (d.debug_redo > 0) bad |= ((ai*31 + i*7 + (j >> 6)) % d.debug_redo) == 0;       // tests: exercise the re-do path
+      if (!__any(bad && actj)){
+        Lse acc;
+        for (int pass = 0; pass < 2; pass++){
+          acc.start(pass, terms[0]);
+#pragma unroll
+          for (int t = 0; t < HS_NART; t++) acc.push(pass, terms[t], d.log_thresh);
+        }
+        if (actj) mr_out[0] = acc.finish();
+      } else if (actj){                              // leave these columns to hs_str_kernel_generic
+        mr_out[0] = HS_REDO;
+        d.redo[ai] = 1;
+      }
+    }
+  }
+}
+
+#ifndef HS_GRP_OCC
+#define HS_GRP_OCC HS_STR_WAVES      // wavefronts per SIMD the register allocation aims at
+#endif
+extern "C" __global__ void __launch_bounds__(HS_GRP_COLS, HS_GRP_OCC)
+hs_str_group_kernel(const hs_dev_t* __restrict__ dp, int item_begin){ str_group_body(*dp, item_begin); }
 
 // compute_aln_logprob (HapAligner.cpp:163-231): log-sum-exp over the haplotype positions the seed base can sit on.
 // One workgroup (4 wavefronts) per active read; a wavefront takes every fourth realigned allele, so what depends on the read only

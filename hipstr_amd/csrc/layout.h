@@ -13,6 +13,9 @@
 #define HS_PW_SLOTS      10        // 64-bit descriptor slots per piecewise-simple visiting list (prep.cpp emit_stropt)
 #define HS_SHAPE_PIECEWISE (-2)
 #define HS_TAB_CAP       48        // closed-form table entries per STR option the STR kernel keeps in LDS (hs_stropt_t::tab_*)
+#ifndef HS_GRP_COLS
+#define HS_GRP_COLS      256       // lanes (= read columns) of one hs_str_group_kernel workgroup; prep.cpp packs reads of a locus side up to this many columns
+#endif
 #define HS_NART          13        // artifact sizes -6p..+6p (RepeatStutterInfo.h:10-11)
 #define HS_MAXREP        6
 #define HS_MAX_COLS      4         // max read columns per lane in the systolic sweep of the traceback fill (trace.hip)

@@ -795,15 +795,16 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
     // trailing-flank items: lanes = alleles of a group; when a group has <= 32 alleles, 64/npad reads of the same locus and
     // side (sorted by side length, so that packed reads finish together) share one wavefront
     ch.trail_begin = out.trail_items.size();
+    ch.str_begin = out.str_items.size();
     // the (locus, range of active reads) runs of this chunk; their items are built independently (host threads) and appended
     // in locus order with their offsets into the packed-read table rebased
-    struct Run { int a0, a1; std::vector<hs_item_t> lead, trail; std::vector<int32_t> tpack; };
+    struct Run { int a0, a1; std::vector<hs_item_t> lead, trail, str; std::vector<int32_t> tpack; };
     std::vector<Run> runs;
     for (int a0 = ch.active_begin; a0 < active_end; ){
       const int locus = out.reads[out.active[a0]].locus;
       int a1 = a0;
       while (a1 < active_end && out.reads[out.active[a1]].locus == locus) a1++;
-      runs.push_back(Run{a0, a1, {}, {}, {}});
+      runs.push_back(Run{a0, a1, {}, {}, {}, {}});
       a0 = a1;
     }
     parallel_for((int)runs.size(), runs.size() >= 16 ? host_threads() : 1, [&](int ri){
@@ -827,6 +828,30 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
             R.tpack.insert(R.tpack.end(), order.begin() + i, order.begin() + i + it.slot);
             R.lead.push_back(it);
           }
+        // STR-block items (hs_str_group_kernel): reads of this locus and side whose columns, laid end to end, fill one workgroup's
+        // lanes.  First fit, longest side first; a group holds at most HS_GRP_MAXREADS reads and 768 read-end deletion sums
+        // (21 period per read).  item.active = first entry in tpack, item.slot = number of reads, item.rowset = their columns
+        if (loc.n_tab[s] > 0){
+          const int period = out.stropts[out.alleles[loc.hap_begin + (out.str_order[loc.order_off[s]] & 0x1fffffff)].str_opt[s]].period;
+          const int max_reads = std::max(1, std::min(16, 768 / (21*period)));
+          struct Bin { int cols; std::vector<int> members; };
+          std::vector<Bin> bins; size_t first_open = 0;
+          for (size_t i = order.size(); i-- > 0; ){
+            const int a = order[i], nc = side_len(a);
+            if (nc <= 0) continue;
+            size_t b = first_open;
+            for (; b < bins.size(); b++) if (bins[b].cols + nc <= HS_GRP_COLS && (int)bins[b].members.size() < max_reads) break;
+            if (b == bins.size()) bins.push_back(Bin{0, {}});
+            bins[b].cols += nc; bins[b].members.push_back(a);
+            while (first_open < bins.size() && (bins[first_open].cols >= HS_GRP_COLS || (int)bins[first_open].members.size() >= max_reads)) first_open++;
+          }
+          for (const Bin& bn : bins){
+            hs_item_t it; it.side = s; it.rowset = bn.cols; it.slot = (int32_t)bn.members.size();
+            it.active = (int32_t)R.tpack.size();
+            R.tpack.insert(R.tpack.end(), bn.members.begin(), bn.members.end());
+            R.str.push_back(it);
+          }
+        }
         for (int g = 0; g < loc.tg_count[s]; g++){
           const int nm = out.tgroups[loc.tg_begin[s] + g].n_members;
           int npad = 1; while (npad < nm) npad <<= 1;
@@ -845,11 +870,14 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
       const int32_t base = (int32_t)out.tpack.size();
       for (hs_item_t& it : R.lead) it.active += base;
       for (hs_item_t& it : R.trail) it.active += base;
+      for (hs_item_t& it : R.str) it.active += base;
       out.tpack.insert(out.tpack.end(), R.tpack.begin(), R.tpack.end());
       out.lead_items.insert(out.lead_items.end(), R.lead.begin(), R.lead.end());
       out.trail_items.insert(out.trail_items.end(), R.trail.begin(), R.trail.end());
+      out.str_items.insert(out.str_items.end(), R.str.begin(), R.str.end());
     }
     ch.trail_end = out.trail_items.size();
+    ch.str_end = out.str_items.size();
     ch.lead_end = out.lead_items.size();
     out.ws_mr_size = std::max(out.ws_mr_size, mr); out.ws_lt_size = std::max(out.ws_lt_size, lt); out.ws_lead_size = std::max(out.ws_lead_size, lead);
     out.ws_col_size = std::max(out.ws_col_size, col);

@@ -47,6 +47,7 @@ struct Prepared {
     int32_t active_begin, active_end;      // range in `active`
     int32_t lead_begin, lead_end;          // lead_items range
     int32_t trail_begin, trail_end;        // trail_items range
+    int32_t str_begin, str_end;            // str_items range
     int64_t n_alignments;
   };
   std::vector<Chunk>      chunks;
@@ -55,6 +56,8 @@ struct Prepared {
                                            // flank for up to 64 reads of one locus and side
   std::vector<hs_item_t>  trail_items;     // (first entry in tpack, side, number of packed reads, group): trailing flank of one
                                            // allele group for up to 64/npad reads of one locus and side
+  std::vector<hs_item_t>  str_items;       // (first entry in tpack, side, columns, number of reads): STR block of the tabulated alleles for a
+                                           // group of reads of one locus and side whose columns fill a workgroup (hs_str_group_kernel)
   std::vector<int32_t>    tpack;           // active-read indices of the packed reads
   std::vector<int32_t>    str_order;       // per locus and side: realigned alleles sorted so that nested STR blocks follow each other
   std::vector<hs_tgroup_t> tgroups;
