@@ -31,7 +31,7 @@ extern "C" __global__ void hs_posterior_kernel(const hs_post_dev_t* dp);
 extern "C" __global__ void hs_genotype_kernel(const hs_gt_dev_t* dp);
 extern "C" size_t hs_str_lds_bytes(int lds_len, int max_B);
 extern "C" __global__ void hs_str_group_kernel(const hs_dev_t* dp, int item_begin);
-extern "C" size_t hs_str_group_lds_bytes(int max_B);
+extern "C" size_t hs_str_group_lds_bytes(int max_B, int nd_cap);
 extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk);
 extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk);
 
@@ -429,7 +429,9 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   h.max_B = P.max_B;
   dev->lds_bytes = hs_str_lds_bytes(h.lds_len, h.max_B);
   if (dev->lds_bytes > 160*1024){ g_err = "batch needs more than 160 KiB of LDS per workgroup"; hipstr_hmm_free(dev); return NULL; }
-  dev->grp_lds_bytes = hs_str_group_lds_bytes(h.max_B);
+  h.grp_nd_cap = std::max(2, (P.grp_nd_cap + 1) & ~1);
+  dev->grp_lds_bytes = hs_str_group_lds_bytes(h.max_B, h.grp_nd_cap);
+  if (getenv("HIPSTR_TIMING")) fprintf(stderr, "hipstr_hmm_upload: STR group kernel LDS %zu bytes (max block %d, read-end table %d doubles, %zu groups)\n", dev->grp_lds_bytes, h.max_B, h.grp_nd_cap, P.str_items.size());
   if (dev->grp_lds_bytes > 48*1024) HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->grp_lds_bytes));
   if (dev->lds_bytes > 48*1024){
     HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->lds_bytes));

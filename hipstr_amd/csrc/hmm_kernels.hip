@@ -1309,16 +1309,18 @@ hs_str_kernel_generic(const hs_dev_t* __restrict__ dp, int active_begin){ str_bo
 #ifndef HS_GABL
 #define HS_GABL 0          // timing experiments only (results invalid): 1 no read-end sums, 2 no evaluation, 3 no table phase, 4 no barriers
 #endif
-#define HS_GRP_NDCAP 768       // doubles per read-end deletion table of a group (two of them): sum over the group's reads of 21 p
 struct GrpLds {
-  double2* bq; double* rowP; double* Mt; double* Dl; uint8_t* rd; const double* ilog;
-  double* nd[2]; double* cstl[2]; double* tab[2]; uint8_t* blk[2];
+  double* rowP; double* Mt; double* Dl; const double* ilog;
+  double* E;            // [4][XC] emission log of every column against A, C, T, G (code = (char >> 1) & 3): one read instead of base + qualities + compare
+  double* nd[2]; double* cstl[2]; double2* tab[2];
+  int* boff[2];         // [blk_len] byte offset of the block base's plane of E (valid offsets, zeros, in front of the first one: masked steps may look there)
   int ld;
 };
-extern "C" size_t hs_str_group_lds_bytes(int max_B){
+// nd_cap: doubles of one read-end deletion table of a group = the largest (reads x 21 period) of the batch's groups (prep.cpp)
+extern "C" size_t hs_str_group_lds_bytes(int max_B, int nd_cap){
   const size_t XC = HS_GRP_COLS;
   const size_t ilog_len = ((size_t)max_B + 9) & ~(size_t)1, blk_len = ((size_t)max_B + 19) & ~(size_t)15;
-  return XC*8*HS_MAXREP + XC*16 + XC*8*2 + ilog_len*8 + 2*HS_GRP_NDCAP*8 + 2*24*8 + 2*2*HS_TAB_CAP*8 + 2*blk_len + XC + 16;
+  return XC*8*HS_MAXREP + (XC + HS_GRP_MAXREADS + 2)*8 + XC*8 + XC*32 + ilog_len*8 + 2*(size_t)nd_cap*8 + 2*24*8 + 2*HS_TAB_CAP*16 + 3*blk_len*4 + 16;
 }
 
 __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin){
@@ -1329,19 +1331,19 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
   __shared__ int s_off[HS_GRP_MAXREADS + 1], s_n[HS_GRP_MAXREADS], s_ai[HS_GRP_MAXREADS];
   GrpLds L;
   {
-    double* Dl = (double*)hs_lds_raw;                       // first: masked steps may touch up to B entries in front of bq / rd
-    double2* bq = (double2*)(Dl + HS_MAXREP*XC);
-    double* rowP = (double*)(bq + XC);
-    double* Mt = rowP + XC;
+    double* Dl = (double*)hs_lds_raw;                       // first: masked steps may touch up to B entries in front of E
+    double* rowP = Dl + HS_MAXREP*XC;                       // read g's stretch is shifted by g + 1: a 0.0 sits in front of every read's first column
+    double* Mt = rowP + (XC + HS_GRP_MAXREADS + 2);
     const int ilog_len = (d.max_B + 9) & ~1, blk_len = (d.max_B + 19) & ~15;
-    double* ilog = Mt + XC;
+    double* E = Mt + XC;
+    double* ilog = E + 4*XC;
     double* ndb = ilog + ilog_len;
-    double* cst = ndb + 2*HS_GRP_NDCAP;
-    double* tab = cst + 2*24;
-    uint8_t* blkb = (uint8_t*)(tab + 2*2*HS_TAB_CAP);
-    uint8_t* rdb = blkb + 2*blk_len;
-    L.bq = bq; L.rowP = rowP; L.Mt = Mt; L.Dl = Dl; L.rd = rdb; L.ilog = ilog; L.ld = XC;
-    for (int b = 0; b < 2; b++){ L.nd[b] = ndb + b*HS_GRP_NDCAP; L.cstl[b] = cst + b*24; L.tab[b] = tab + b*2*HS_TAB_CAP; L.blk[b] = blkb + b*blk_len; }
+    double* cst = ndb + 2*d.grp_nd_cap;
+    double2* tab = (double2*)(cst + 2*24);
+    int* boffb = (int*)(tab + 2*HS_TAB_CAP) + blk_len;
+    for (int i = x; i < blk_len; i += NT) boffb[i - blk_len] = 0;
+    L.rowP = rowP; L.Mt = Mt; L.Dl = Dl; L.ilog = ilog; L.E = E; L.ld = XC;
+    for (int b = 0; b < 2; b++){ L.nd[b] = ndb + b*d.grp_nd_cap; L.cstl[b] = cst + b*24; L.tab[b] = tab + b*HS_TAB_CAP; L.boff[b] = boffb + b*blk_len; }
     for (int i = x; i < ilog_len; i += NT) ilog[i] = d.int_log[i];
   }
   if (x < G){
@@ -1370,8 +1372,15 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
   {
     const int src = rdv.base_off + (side ? rdv.len - 1 - j : j);
     const uint8_t q = (uint8_t)d.quals[src];
-    if (actj){ L.rd[xx] = (uint8_t)d.bases[src]; L.bq[xx] = make_double2(d.qual_correct[q], d.qual_error[q]); }
+    if (actj){
+      const uint8_t r = (uint8_t)d.bases[src];
+      const double qc = d.qual_correct[q], qe = d.qual_error[q];
+      L.E[xx] = (r == 'A') ? qc : qe; L.E[XC + xx] = (r == 'C') ? qc : qe;
+      L.E[2*XC + xx] = (r == 'T') ? qc : qe; L.E[3*XC + xx] = (r == 'G') ? qc : qe;
+      if (j == 0) L.rowP[xx + g] = 0.0;
+    }
   }
+  const int xrp = xx + g + 1;                       // this column in rowP: rowP[xrp - len] is M of column j - len, or the 0.0 in front when len = j + 1
   const int n_tab = uni(loc->n_tab[side]);
   const int i0 = blockIdx.y * d.allele_chunk, i1 = min(n_tab, i0 + d.allele_chunk);
   const int32_t* order = d.str_order + uni(loc->order_off[side]);
@@ -1416,21 +1425,26 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     const double tab_bmin = uni(nx_bmin);
     if (slot != cur_slot){          // M of the row before the STR block, from the leading-flank kernel: the previous allele's readers first
       if (HS_GABL != 4) __syncthreads();
-      if (actj) L.rowP[xx] = lead_base[(int64_t)slot*lead_stride];
+      if (actj) L.rowP[xrp] = lead_base[(int64_t)slot*lead_stride];
       cur_slot = slot;
     }
     // this allele's block, constants and table go to the buffers the allele before the previous one used
-    if (x < (B + 3)/4) ((int*)L.blk[par])[x] = nx_blkw;
+    if (x < (B + 3)/4){
+      int4 bo;                                      // A, C, T, G -> plane 0, 1, 2, 3 (prep.cpp tabulates only blocks made of these four)
+      bo.x = ((nx_blkw >> 1) & 3) * (XC*8); bo.y = ((nx_blkw >> 9) & 3) * (XC*8); bo.z = ((nx_blkw >> 17) & 3) * (XC*8); bo.w = ((nx_blkw >> 25) & 3) * (XC*8);
+      ((int4*)L.boff[par])[x] = bo;
+    }
     if (x < 20) L.cstl[par][x] = cst;
-    if (x < tab_len){ L.tab[par][x] = nx_tabA; L.tab[par][HS_TAB_CAP + x] = nx_tabG; }
+    if (x < tab_len) L.tab[par][x] = make_double2(nx_tabA, nx_tabG);
     if (i + 1 < i1){
       if (k == 63) fetch_alleles(i + 1);
       request((k + 1) & 63);
     }
     if (HS_GABL != 4) __syncthreads();                // ... and every wavefront is done with the previous allele's Mt / Dl
-    const uint8_t* blk = L.blk[par];
     const double* cstl = L.cstl[par];
-    const double* tab = L.tab[par];
+    const double2* tab = L.tab[par];
+    const int* boff = L.boff[par];
+    auto Eat = [&](int col, int bo) -> double { return *(const double*)((const char*)L.E + col*8 + bo); };   // column col against the block base with plane offset bo
     double* nd = L.nd[par];
     const double* nd_prev = L.nd[par ^ 1];
 
@@ -1443,31 +1457,30 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       const int ndp = nv * p;
       int t = t0;
       if (t < min(tmax, ndp)){
-        const uint8_t* prd = L.rd + (xx - t); const double2* pbq = L.bq + (xx - t);
+        int col = xx - t;
         int left = j - t, ph = (t + 1) % p;
         double* dl = L.Dl + ((t + 1)/p - 1)*L.ld + xx;
         for (; t < min(tmax, ndp); t++){
-          const double e = emit(*prd, blk[B-1-t], *pbq);
+          const double e = Eat(col, boff[B-1-t]);
           if (left >= 0) lp += e;
           if (ph == 0){ if (left >= 0 && actj) *dl = lp; }
           ph++; if (ph == p){ ph = 0; dl += L.ld; }
-          prd--; pbq--; left--;
+          col--; left--;
         }
       }
       auto steps = [&](int tend, auto masked){
         int xr = xx - t - 3, xb = B - 1 - t - 3;
         for (; t + 4 <= tend; t += 4){
           asm volatile("" : "+v"(xr));
-          const uint8_t* prd = L.rd + xr; const double2* pbq = L.bq + xr;
 #pragma unroll
           for (int k = 0; k < 4; k++){
-            const double e = emit(prd[3-k], blk[xb + 3 - k], pbq[3-k]);
+            const double e = Eat(xr + 3 - k, boff[xb + 3 - k]);
             if (!decltype(masked)::value || xr + 3 - k >= offg) lp += e;
           }
           xr -= 4; xb -= 4;
         }
         for (; t < tend; t++){
-          const double e = emit(L.rd[xr + 3], blk[xb + 3], L.bq[xr + 3]);
+          const double e = Eat(xr + 3, boff[xb + 3]);
           if (!decltype(masked)::value || xr + 3 >= offg) lp += e;
           xr--; xb--;
         }
@@ -1490,23 +1503,23 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
         int xr = xcol - 3, xb = (B - 1 - aD) - 3, t = 0;
         for (; t + 4 <= lmin; t += 4){
           asm volatile("" : "+v"(xr), "+v"(xb));
-          const uint8_t* prd = L.rd + xr; const double2* pbq = L.bq + xr; const uint8_t* pbk = blk + xb;
+          const int* pbo = boff + xb;
 #pragma unroll
-          for (int k = 0; k < 4; k++) lp += emit(prd[3-k], pbk[3-k], pbq[3-k]);
+          for (int k = 0; k < 4; k++) lp += Eat(xr + 3 - k, pbo[3-k]);
           xr -= 4; xb -= 4;
         }
         for (; t + 4 <= lmax; t += 4){
           asm volatile("" : "+v"(xr), "+v"(xb));
-          const uint8_t* prd = L.rd + xr; const double2* pbq = L.bq + xr; const uint8_t* pbk = blk + xb;
+          const int* pbo = boff + xb;
 #pragma unroll
           for (int k = 0; k < 4; k++){
-            const double e = emit(prd[3-k], pbk[3-k], pbq[3-k]);
+            const double e = Eat(xr + 3 - k, pbo[3-k]);
             if (t + k < len) lp += e;
           }
           xr -= 4; xb -= 4;
         }
         for (; t < lmax; t++){
-          const double e = emit(L.rd[xr + 3], blk[xb + 3], L.bq[xr + 3]);
+          const double e = Eat(xr + 3, boff[xb + 3]);
           if (t < len) lp += e;
           xr--; xb--;
         }
@@ -1585,13 +1598,13 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       double lp0_max = 0.0;
       auto tab_eval = [&](double lp0, int lim, int k) -> double {
         const int e = rdlane(tbase, k) + min(lim, 1) + max(lim - rdlane(shapes, k), 0);
-        const double A = tab[e], Gv = tab[HS_TAB_CAP + e];
+        const double2 ag = tab[e];
         lp0_max = fmax(lp0_max, fabs(lp0));
-        return (lp0 + A) + Gv;
+        return (lp0 + ag.x) + ag.y;
       };
       {
         const int len = min(B, j + 1);
-        const double pre = (j - len < 0) ? 0.0 : L.rowP[xx - min(len, j)];
+        const double pre = L.rowP[xrp - len];
         terms[HS_MAXREP] = (rdlane(cst, HS_MAXREP) + L.Mt[xx]) + pre;
       }
       auto ins_term = [&](int q, double li){
@@ -1600,7 +1613,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
         const double lp0 = (rdlane(cst, 13) + li) + ((len > D) ? L.Mt[xx - min(D, j)] : 0.0);
         const int lim = actj ? min(max(0, len - D), B) : 0;
         const double S = tab_eval(lp0, lim, HS_MAXREP);
-        const double pre = (j - len < 0) ? 0.0 : L.rowP[xx - min(len, j)];
+        const double pre = L.rowP[xrp - len];
         return (rdlane(cst, HS_MAXREP + 1 + q) + S) + pre;
       };
       if (nd_eq == HS_MAXREP){
@@ -1609,17 +1622,16 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
           terms[HS_MAXREP + 1 + q] = ins_term(q, (j >= (q+1)*p - 1) ? L.Dl[q*L.ld + xx] : L.Mt[xx]);
       } else {
         double li = 0.0;
-        const double2* pli_bq = L.bq + (xx - nd_eq*p); const uint8_t* pli_rd = L.rd + (xx - nd_eq*p); int li_left = j - nd_eq*p;
+        int li_col = xx - nd_eq*p, li_left = j - nd_eq*p;
 #pragma unroll
         for (int q = 0; q < HS_MAXREP; q++){
           if (q < nd_eq){
             li = (j >= (q+1)*p - 1) ? L.Dl[q*L.ld + xx] : L.Mt[xx];
           } else {
-            for (int m = 0; m < p; m++){
-              const double2 bq = *pli_bq;
-              const double e = (m < B) ? emit(*pli_rd, blk[B-1-min(m, B-1)], bq) : bq.x;
+            for (int m = 0; m < p; m++){           // m < period <= B for a tabulated block (prep.cpp)
+              const double e = Eat(li_col, boff[B-1-m]);
               if (li_left >= 0) li += e;
-              pli_bq--; pli_rd--; li_left--;
+              li_col--; li_left--;
             }
           }
           terms[HS_MAXREP + 1 + q] = ins_term(q, li);
@@ -1639,7 +1651,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
           const double ndv = nd[ndo + min(max(j - (n - cq), 0), cq - 1)];
           const double lp0 = direct ? rdlane(cst, 14 + q) + dsum : ndv;
           const double S = tab_eval(lp0, actj ? len : 0, q);
-          const double pre = (j - len < 0) ? 0.0 : L.rowP[xx - min(len, j)];
+          const double pre = L.rowP[xrp - len];
           terms[HS_MAXREP - 1 - q] = (rdlane(cst, HS_MAXREP - 1 - q) + S) + pre;
           ndo += cq;
         }
