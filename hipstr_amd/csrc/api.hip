@@ -24,7 +24,7 @@
 #include "prep.h"
 #include "api_internal.h"
 
-extern "C" __global__ void hs_str_kernel(const hs_dev_t* dp, int active_begin);
+extern "C" __global__ void hs_str_kernel(const hs_dev_t* dp, int active_begin, int only_long);
 extern "C" __global__ void hs_str_kernel_generic(const hs_dev_t* dp, int active_begin);
 extern "C" __global__ void hs_combine_kernel(const hs_dev_t* dp, int active_begin);
 extern "C" __global__ void hs_posterior_kernel(const hs_post_dev_t* dp);
@@ -541,10 +541,14 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
     if (mark()) return 1;
     // tabulated alleles: reads of a locus side packed into workgroups (HIPSTR_STR_GROUP=0: one workgroup per read, for comparison)
     static const bool str_group = !(getenv("HIPSTR_STR_GROUP") && atoi(getenv("HIPSTR_STR_GROUP")) == 0);
-    if (!str_group) hipLaunchKernelGGL(hs_str_kernel, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin);
-    else if (ch.str_end > ch.str_begin)
-      hipLaunchKernelGGL(hs_str_group_kernel, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), dev->grp_lds_bytes, st, dp,
-                         dev->n_lead_items + dev->n_trail_items + ch.str_begin);
+    if (!str_group) hipLaunchKernelGGL(hs_str_kernel, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin, 0);
+    else {
+      if (ch.str_end > ch.str_begin)
+        hipLaunchKernelGGL(hs_str_group_kernel, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), dev->grp_lds_bytes, st, dp,
+                           dev->n_lead_items + dev->n_trail_items + ch.str_begin);
+      if (ch.n_long_sides > 0)        // sides with more columns than a group holds: one workgroup per read as before
+        hipLaunchKernelGGL(hs_str_kernel, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin, 1);
+    }
     // alleles without a tabulated closed form (interrupted repeats, very long blocks) and whatever hs_str_kernel marked HS_REDO
     hipLaunchKernelGGL(hs_str_kernel_generic, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin);
     if (mark()) return 1;

@@ -767,7 +767,7 @@ extern "C" size_t hs_str_lds_bytes(int lds_len, int max_B){
 //   MODE 0 (hs_str_kernel)          alleles whose visiting lists are all simple and tabulated: positions [0, n_tab) of the side's order
 //   MODE 1 (hs_str_kernel_generic)  the other alleles, positions [n_tab, n_re): closed forms the long way and list replay
 template <int MODE>
-__device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
+__device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin, int only_long){
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const SideView v = side_view(d, active_begin + blockIdx.x, w);
   const int n = v.n;
@@ -803,6 +803,7 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
   const bool redo = (MODE == 1) && uni(d.redo[ai]) != 0;
   const int j0 = blockIdx.y * d.allele_chunk, j1 = redo ? min(n_tab, j0 + d.allele_chunk) : j0;
   if (i0 >= i1 && j0 >= j1) return;           // nothing of this kind for this side (after the barrier: the other side may have work)
+  if (MODE == 0 && only_long && n <= HS_GRP_COLS) return;     // this side's columns fit a group: hs_str_group_kernel has it
   for (int j = lane; j < n; j += 64){
     const int src = v.base_off + (w ? v.len - 1 - j : j);
     const uint8_t q = (uint8_t)d.quals[src];
@@ -1287,13 +1288,13 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin){
 }
 
 extern "C" __global__ void __launch_bounds__(128, HS_STR_WAVES)
-hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin){ str_body<0>(*dp, active_begin); }
+hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin, int only_long){ str_body<0>(*dp, active_begin, only_long); }
 
 #ifndef HS_STRG_WAVES
 #define HS_STRG_WAVES 3      // the long forms want registers more than wavefronts: 168 VGPRs without spills beat 128 with 160 B of them
 #endif
 extern "C" __global__ void __launch_bounds__(128, HS_STRG_WAVES)
-hs_str_kernel_generic(const hs_dev_t* __restrict__ dp, int active_begin){ str_body<1>(*dp, active_begin); }
+hs_str_kernel_generic(const hs_dev_t* __restrict__ dp, int active_begin){ str_body<1>(*dp, active_begin, 0); }
 
 // ------------------------------------------------------------------ the STR block of tabulated alleles, grouped form
 // hs_str_kernel gives every read side its own wavefront: a 150-base read seeded in the middle has ~75 columns per side, two passes of
@@ -1307,24 +1308,25 @@ hs_str_kernel_generic(const hs_dev_t* __restrict__ dp, int active_begin){ str_bo
 // the allele's block, constants and closed-form table are double-buffered so that loading the next allele needs no third one.
 #define HS_GRP_MAXREADS 16
 #ifndef HS_GABL
-#define HS_GABL 0          // timing experiments only (results invalid): 1 no read-end sums, 2 no evaluation, 3 no table phase, 4 no barriers
+#define HS_GABL 0          // timing experiments only (results invalid): 1 no read-end sums, 2 no evaluation, 3 no table phase, 4 no barriers, 5 no chains; valid results: 6 read-end sums twice, 7 evaluation twice
 #endif
 struct GrpLds {
-  double* rowP; double* Mt; double* Dl; const double* ilog;
+  double* rowP; double* Mt; double* Dl;
   double* E;            // [4][XC] emission log of every column against A, C, T, G (code = (char >> 1) & 3): one read instead of base + qualities + compare
   double* nd[2]; double* cstl[2]; double2* tab[2];
-  int* boff[2];         // [blk_len] byte offset of the block base's plane of E (valid offsets, zeros, in front of the first one: masked steps may look there)
+  uint16_t* boff[2];         // [blk_len] byte offset of the block base's plane of E (valid offsets, zeros, in front of the first one: masked steps may look there)
   int ld;
 };
 // nd_cap: doubles of one read-end deletion table of a group = the largest (reads x 21 period) of the batch's groups (prep.cpp)
 extern "C" size_t hs_str_group_lds_bytes(int max_B, int nd_cap){
   const size_t XC = HS_GRP_COLS;
-  const size_t ilog_len = ((size_t)max_B + 9) & ~(size_t)1, blk_len = ((size_t)max_B + 19) & ~(size_t)15;
-  return XC*8*HS_MAXREP + (XC + HS_GRP_MAXREADS + 2)*8 + XC*8 + XC*32 + ilog_len*8 + 2*(size_t)nd_cap*8 + 2*24*8 + 2*HS_TAB_CAP*16 + 3*blk_len*4 + 16;
+  const size_t blk_len = ((size_t)max_B + 19) & ~(size_t)15;
+  return XC*8*HS_MAXREP + (XC + HS_GRP_MAXREADS + 2)*8 + XC*8 + XC*32 + 2*(size_t)nd_cap*8 + 2*24*8 + 2*HS_TAB_CAP*16 + 3*blk_len*2 + 16;
 }
 
 __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin){
   constexpr int XC = HS_GRP_COLS, NT = HS_GRP_COLS;
+  static_assert((NT & (NT - 1)) == 0 && NT >= 128 && 4*XC*8 < 65536, "the wavefronts' turns at the read-end sums assume a power-of-two workgroup; plane offsets are 16 bits");
   const int lane = threadIdx.x & 63, x = threadIdx.x;
   const hs_item_t* item = d.items + item_begin + blockIdx.x;
   const int side = uni(item->side), G = uni(item->slot), tp = uni(item->active);
@@ -1334,17 +1336,15 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     double* Dl = (double*)hs_lds_raw;                       // first: masked steps may touch up to B entries in front of E
     double* rowP = Dl + HS_MAXREP*XC;                       // read g's stretch is shifted by g + 1: a 0.0 sits in front of every read's first column
     double* Mt = rowP + (XC + HS_GRP_MAXREADS + 2);
-    const int ilog_len = (d.max_B + 9) & ~1, blk_len = (d.max_B + 19) & ~15;
+    const int blk_len = (d.max_B + 19) & ~15;
     double* E = Mt + XC;
-    double* ilog = E + 4*XC;
-    double* ndb = ilog + ilog_len;
+    double* ndb = E + 4*XC;
     double* cst = ndb + 2*d.grp_nd_cap;
     double2* tab = (double2*)(cst + 2*24);
-    int* boffb = (int*)(tab + 2*HS_TAB_CAP) + blk_len;
+    uint16_t* boffb = (uint16_t*)(tab + 2*HS_TAB_CAP) + blk_len;
     for (int i = x; i < blk_len; i += NT) boffb[i - blk_len] = 0;
-    L.rowP = rowP; L.Mt = Mt; L.Dl = Dl; L.ilog = ilog; L.E = E; L.ld = XC;
+    L.rowP = rowP; L.Mt = Mt; L.Dl = Dl; L.E = E; L.ld = XC;
     for (int b = 0; b < 2; b++){ L.nd[b] = ndb + b*d.grp_nd_cap; L.cstl[b] = cst + b*24; L.tab[b] = tab + b*HS_TAB_CAP; L.boff[b] = boffb + b*blk_len; }
-    for (int i = x; i < ilog_len; i += NT) ilog[i] = d.int_log[i];
   }
   if (x < G){
     const int ai = d.tpack[tp + x];
@@ -1386,20 +1386,24 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
   const int32_t* order = d.str_order + uni(loc->order_off[side]);
   const int jmaxw = uni(wave_max_i(j)), jminw = uni(wave_min_i(j));
   const int nh_l = s_n[min(lane, G - 1)];                       // lane h < G: columns of read h
+  const int nmin_g = uni(wave_min_i(nh_l));                      // shortest side of the group
   // The alleles' records are fetched 64 at a time, one allele per lane (order entry -> allele -> STR option: three dependent loads, paid
   // once), and read lane by lane; what an allele needs beyond them (constants, block, closed-form table) is requested one allele ahead.
-  int a_oe = 0, a_slot = 0, a_reord = 0, a_sopt = 0, a_seq = 0, a_B = 0, a_nv = 0, a_p = 1, a_f64 = 0, a_taboff = 0, a_tablen = 0, a_ndeq = 0;
+  // a_pk1 = lead slot | nd << 8 | period << 12 | nd_eq << 16 | tab_len << 20;  a_pk2 = re_ord | B << 16
+  int a_oe = 0, a_pk1 = 0, a_pk2 = 0, a_sopt = 0, a_seq = 0, a_f64 = 0, a_taboff = 0;
   auto fetch_alleles = [&](int first){
     const int k = min(first + lane, i1 - 1);
     a_oe = order[k];
     const hs_allele_t* al = d.alleles + uni(loc->hap_begin) + (a_oe & 0x1fffffff);
-    a_slot = al->lead_slot[side]; a_reord = al->re_ord; a_sopt = al->str_opt[side];
+    a_sopt = al->str_opt[side];
     const hs_stropt_t* so = d.stropts + a_sopt;
-    a_seq = so->seq_off; a_B = so->B; a_nv = so->nd; a_p = so->period; a_f64 = so->f64_off; a_taboff = so->tab_off; a_tablen = so->tab_len; a_ndeq = so->nd_eq;
+    a_pk1 = (al->lead_slot[side] & 0xff) | (so->nd << 8) | (so->period << 12) | (so->nd_eq << 16) | (so->tab_len << 20);
+    a_pk2 = (al->re_ord & 0xffff) | (so->B << 16);
+    a_seq = so->seq_off; a_f64 = so->f64_off; a_taboff = so->tab_off;
   };
   double nx_cst = 0.0, nx_bmin = 0.0, nx_tabA = 0.0, nx_tabG = 0.0; int nx_shapes = -1, nx_tbase = 0, nx_blkw = 0;
   auto request = [&](int k){                          // k: lane of the allele in the fetched batch
-    const int f64o = rdlane(a_f64, k), sopt = rdlane(a_sopt, k), tl = rdlane(a_tablen, k), Bk = rdlane(a_B, k);
+    const int f64o = rdlane(a_f64, k), sopt = rdlane(a_sopt, k), tl = (rdlane(a_pk1, k) >> 20) & 0xff, Bk = (rdlane(a_pk2, k) >> 16) & 0xffff;
     const double* tsrc = d.f64pool + rdlane(a_taboff, k);
     nx_cst = d.f64pool[f64o + min(lane, 19)];        // lane t < 20: pmf[13] | prior_ins | prior_del[6]
     nx_shapes = (lane <= HS_MAXREP) ? d.stropts[sopt].shape[lane] : -1;
@@ -1415,9 +1419,10 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     const int k = (i - i0) & 63;
     const int oe = rdlane(a_oe, k);
     const bool chained = (i > i0) && ((oe >> 30) & 1);
-    const int slot = rdlane(a_slot, k), re_ord = rdlane(a_reord, k);
+    const int pk1 = rdlane(a_pk1, k), pk2 = rdlane(a_pk2, k);
+    const int slot = pk1 & 0xff, re_ord = pk2 & 0xffff;
     double* const mr_out = mr_base + (int64_t)re_ord*lenm1;
-    const int B = rdlane(a_B, k), nv = rdlane(a_nv, k), p = rdlane(a_p, k), nd_eq = rdlane(a_ndeq, k), tab_len = rdlane(a_tablen, k);
+    const int B = (pk2 >> 16) & 0xffff, nv = (pk1 >> 8) & 15, p = (pk1 >> 12) & 15, nd_eq = (pk1 >> 16) & 15, tab_len = (pk1 >> 20) & 0xff;
     const int nds = 21*p;                                     // read-end deletion sums of one read: sizes back to back, at most (q+1)p columns each
     const int ndb = g*nds;
     const double cst = nx_cst;
@@ -1430,9 +1435,10 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     }
     // this allele's block, constants and table go to the buffers the allele before the previous one used
     if (x < (B + 3)/4){
-      int4 bo;                                      // A, C, T, G -> plane 0, 1, 2, 3 (prep.cpp tabulates only blocks made of these four)
-      bo.x = ((nx_blkw >> 1) & 3) * (XC*8); bo.y = ((nx_blkw >> 9) & 3) * (XC*8); bo.z = ((nx_blkw >> 17) & 3) * (XC*8); bo.w = ((nx_blkw >> 25) & 3) * (XC*8);
-      ((int4*)L.boff[par])[x] = bo;
+      int2 bo;                                      // A, C, T, G -> plane 0, 1, 2, 3 (prep.cpp tabulates only blocks made of these four), two 16-bit offsets per word
+      bo.x = (((nx_blkw >> 1) & 3) * (XC*8)) | ((((nx_blkw >> 9) & 3) * (XC*8)) << 16);
+      bo.y = (((nx_blkw >> 17) & 3) * (XC*8)) | ((((nx_blkw >> 25) & 3) * (XC*8)) << 16);
+      ((int2*)L.boff[par])[x] = bo;
     }
     if (x < 20) L.cstl[par][x] = cst;
     if (x < tab_len) L.tab[par][x] = make_double2(nx_tabA, nx_tabG);
@@ -1443,7 +1449,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     if (HS_GABL != 4) __syncthreads();                // ... and every wavefront is done with the previous allele's Mt / Dl
     const double* cstl = L.cstl[par];
     const double2* tab = L.tab[par];
-    const int* boff = L.boff[par];
+    const uint16_t* boff = L.boff[par];
     auto Eat = [&](int col, int bo) -> double { return *(const double*)((const char*)L.E + col*8 + bo); };   // column col against the block base with plane offset bo
     double* nd = L.nd[par];
     const double* nd_prev = L.nd[par ^ 1];
@@ -1494,42 +1500,100 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
 
     // --- deletion start values of the columns whose segment reaches the read end (the `else` branch of StutterAlignerClass.cpp:117-120),
     // (size, column) pairs of all reads of the group spread over the workgroup's lanes; layout per read as in str_body
-    {
+    for (int rep = 0; rep < ((HS_GABL == 6) ? 2 : 1); rep++){
+      asm volatile("" ::: "memory");
       auto nd_sum = [&](int q, int xcol, int jcol, bool valid, int dst){
         const int aD = (q+1)*p;
         const int len = min(B - aD, jcol + 1);
-        const int lmin = uni(wave_min_i(len)), lmax = uni(wave_max_i(len));
+        const int lmin = (HS_GABL == 5) ? 0 : uni(wave_min_i(len)), lmax = (HS_GABL == 5) ? 0 : uni(wave_max_i(len));
         double lp = cstl[14 + q];
+        // step t pairs read column xcol - t with block base B-1-aD - t, four steps per group.  The chain of additions is the critical
+        // path of the allele, so its operands run ahead of it: plane offsets two groups ahead, emissions one group ahead.
         int xr = xcol - 3, xb = (B - 1 - aD) - 3, t = 0;
+        int bo[4]; double ev[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) bo[k] = boff[xb + 3 - k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) ev[k] = Eat(xr + 3 - k, bo[k]);
+        xr -= 4; xb -= 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) bo[k] = boff[xb + 3 - k];          // in front of the table: zeros (a valid plane), never used
+        auto advance = [&](){
+          asm volatile("" : "+v"(xr), "+v"(xb));
+#pragma unroll
+          for (int k = 0; k < 4; k++) ev[k] = Eat(xr + 3 - k, bo[k]);
+          xr -= 4; xb -= 4;
+#pragma unroll
+          for (int k = 0; k < 4; k++) bo[k] = boff[xb + 3 - k];
+        };
         for (; t + 4 <= lmin; t += 4){
-          asm volatile("" : "+v"(xr), "+v"(xb));
-          const int* pbo = boff + xb;
-#pragma unroll
-          for (int k = 0; k < 4; k++) lp += Eat(xr + 3 - k, pbo[3-k]);
-          xr -= 4; xb -= 4;
+          const double e0 = ev[0], e1 = ev[1], e2 = ev[2], e3 = ev[3];
+          advance();
+          lp += e0; lp += e1; lp += e2; lp += e3;
         }
-        for (; t + 4 <= lmax; t += 4){
-          asm volatile("" : "+v"(xr), "+v"(xb));
-          const int* pbo = boff + xb;
-#pragma unroll
-          for (int k = 0; k < 4; k++){
-            const double e = Eat(xr + 3 - k, pbo[3-k]);
-            if (t + k < len) lp += e;
-          }
-          xr -= 4; xb -= 4;
-        }
-        for (; t < lmax; t++){
-          const double e = Eat(xr + 3, boff[xb + 3]);
-          if (t < len) lp += e;
-          xr--; xb--;
+        for (; t < lmax; t += 4){
+          const double e0 = ev[0], e1 = ev[1], e2 = ev[2], e3 = ev[3];
+          advance();
+          if (t < len) lp += e0;
+          if (t + 1 < len) lp += e1;
+          if (t + 2 < len) lp += e2;
+          if (t + 3 < len) lp += e3;
         }
         if (valid) nd[dst] = lp;
       };
       auto row_off = [&](int q){ return p*((q*(q+1)) >> 1); };
       const bool reuse_al = chained && ((oe >> 29) & 1);
       const int ncopy = row_off(nv - 1);
-      // per read: rows move up one size (reuse) + the new pairs, or every pair of the read.  Lane h < G counts read h's work, a
-      // prefix sum over those lanes numbers the work of all reads back to back, and every lane finds its own item by the prefix
+      // Work of the group for this allele.  Usual case (every side of the group holds all six deletion sizes, so all reads count
+      // alike): closed-form numbering, size-major so that the sums of a wavefront have (nearly) the same length.  Otherwise lane
+      // h < G counts read h's work, a prefix sum over those lanes numbers it back to back and every lane searches the prefix.
+      const bool all_long = nmin_g >= HS_MAXREP*p;
+      auto udiv = [&](int e, int c, float rc) -> int {            // e / c for small non-negative e, rc ~ 1/c
+        int h = (int)((float)e * rc);
+        h -= (h*c > e) ? 1 : 0; h += ((h + 1)*c <= e) ? 1 : 0;
+        return h;
+      };
+      const int xw = (x + (NT/2)*(i - i0)) & (NT - 1);               // the sums rarely fill the workgroup: the wavefronts take turns at them (a wavefront's SIMD is fixed)
+      if (all_long){
+        const int Gp = G*p;
+        const float rc_p = 1.0f/(float)p;
+        if (reuse_al){
+          const float rc_copy = 1.0f/(float)max(ncopy, 1);
+          for (int base = 0; base < ((HS_GABL == 1) ? 0 : G*ncopy); base += NT){
+            const int e = base + xw;
+            if (e < G*ncopy){
+              const int hh = udiv(e, ncopy, rc_copy), idx0 = e - hh*ncopy;
+              int qn = 1;
+#pragma unroll
+              for (int k = 1; k <= 4; k++) qn += (idx0 >= row_off(k)) ? 1 : 0;
+              const int idx = idx0 - row_off(qn - 1);
+              nd[hh*nds + row_off(qn) + p + idx] = nd_prev[hh*nds + row_off(qn - 1) + idx];
+            }
+          }
+          const int n_sums = nv*Gp;                                // e = (q G + h) p + off
+          const float rc_gp = 1.0f/(float)Gp;
+          for (int base = 0; base < ((HS_GABL == 1) ? 0 : n_sums); base += NT){
+            if (base + (xw & ~63) >= n_sums) continue;             // whole wavefront past the end (wave-uniform)
+            const int e = min(base + xw, n_sums - 1);
+            const int q = udiv(e, Gp, rc_gp), r = e - q*Gp, hh = udiv(r, p, rc_p), off = r - hh*p;
+            const int jcol = (s_n[hh] - (q+1)*p) + off;
+            nd_sum(q, s_off[hh] + jcol, jcol, base + xw < n_sums, hh*nds + row_off(q) + off);
+          }
+        } else {
+          const int n_sums = G*row_off(nv);                        // size q: G reads x (q+1)p columns, sizes back to back from G row_off(q)
+          for (int base = 0; base < ((HS_GABL == 1) ? 0 : n_sums); base += NT){
+            if (base + (xw & ~63) >= n_sums) continue;
+            const int e = min(base + xw, n_sums - 1);
+            int q = 0;
+#pragma unroll
+            for (int k = 1; k <= 5; k++) q += (e >= G*row_off(k)) ? 1 : 0;
+            const int r = e - G*row_off(q), w = (q+1)*p;
+            const int hh = udiv(r, w, 1.0f/(float)w), off = r - hh*w;
+            const int jcol = (s_n[hh] - w) + off;
+            nd_sum(q, s_off[hh] + jcol, jcol, base + xw < n_sums, hh*nds + row_off(q) + off);
+          }
+        }
+      } else {
       int c_l = 0, cc_l = 0;
       {
         const bool ru = reuse_al && (nh_l >= nv*p);
@@ -1553,7 +1617,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
         }
       };
       for (int base = 0; base < ((HS_GABL == 1) ? 0 : n_copies); base += NT){
-        const int e = base + x;
+        const int e = base + xw;
         if (e < n_copies){
           int hh, idx0; find(pcc, e, hh, idx0);
           int qn = 1;
@@ -1564,10 +1628,10 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
         }
       }
       for (int base = 0; base < ((HS_GABL == 1) ? 0 : n_sums); base += NT){
-        const int wbase = base + (x & ~63);
-        if (wbase >= n_sums) break;                           // whole wavefront past the end (wave-uniform)
-        const int e = min(base + x, n_sums - 1);
-        const bool valid = base + x < n_sums;
+        const int wbase = base + (xw & ~63);
+        if (wbase >= n_sums) continue;                        // whole wavefront past the end (wave-uniform)
+        const int e = min(base + xw, n_sums - 1);
+        const bool valid = base + xw < n_sums;
         int hh, loc_e; find(pc, e, hh, loc_e);
         const int nh = s_n[hh], offh = s_off[hh];
         const bool ruh = reuse_al && (nh >= nv*p);
@@ -1589,11 +1653,14 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
         }
         nd_sum(q, offh + jcol, jcol, valid, hh*nds + dst);
       }
+      }
     }
     if (HS_GABL != 4) __syncthreads();
 
     // --- the 13 artifact terms of this lane's column (HapAligner.cpp:62-109) and their fast_log_sum_exp
+    for (int rep3 = 0; rep3 < ((HS_GABL == 7) ? 2 : 1); rep3++)
     if (wave_act && HS_GABL != 2){
+      asm volatile("" ::: "memory");
       double terms[HS_NART];
       double lp0_max = 0.0;
       auto tab_eval = [&](double lp0, int lim, int k) -> double {

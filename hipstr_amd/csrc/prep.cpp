@@ -800,13 +800,13 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
     ch.str_begin = out.str_items.size();
     // the (locus, range of active reads) runs of this chunk; their items are built independently (host threads) and appended
     // in locus order with their offsets into the packed-read table rebased
-    struct Run { int a0, a1; std::vector<hs_item_t> lead, trail, str; std::vector<int32_t> tpack; int nd_cap = 0; };
+    struct Run { int a0, a1; std::vector<hs_item_t> lead, trail, str; std::vector<int32_t> tpack; int nd_cap = 0, n_long = 0; };
     std::vector<Run> runs;
     for (int a0 = ch.active_begin; a0 < active_end; ){
       const int locus = out.reads[out.active[a0]].locus;
       int a1 = a0;
       while (a1 < active_end && out.reads[out.active[a1]].locus == locus) a1++;
-      runs.push_back(Run{a0, a1, {}, {}, {}, {}, 0});
+      runs.push_back(Run{a0, a1, {}, {}, {}, {}, 0, 0});
       a0 = a1;
     }
     parallel_for((int)runs.size(), runs.size() >= 16 ? host_threads() : 1, [&](int ri){
@@ -831,16 +831,17 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
             R.lead.push_back(it);
           }
         // STR-block items (hs_str_group_kernel): reads of this locus and side whose columns, laid end to end, fill one workgroup's
-        // lanes.  First fit, longest side first; a group holds at most HS_GRP_MAXREADS reads and 512 read-end deletion sums
+        // lanes.  First fit, longest side first; a group holds at most HS_GRP_MAXREADS reads and 2 HS_GRP_COLS read-end deletion sums
         // (21 period per read).  item.active = first entry in tpack, item.slot = number of reads, item.rowset = their columns
         if (loc.n_tab[s] > 0){
           const int period = out.stropts[out.alleles[loc.hap_begin + (out.str_order[loc.order_off[s]] & 0x1fffffff)].str_opt[s]].period;
-          const int max_reads = std::max(1, std::min(16, 512 / (21*period)));
+          const int max_reads = std::max(1, std::min(16, 2*HS_GRP_COLS / (21*period)));
           struct Bin { int cols; std::vector<int> members; };
           std::vector<Bin> bins; size_t first_open = 0;
           for (size_t i = order.size(); i-- > 0; ){
             const int a = order[i], nc = side_len(a);
             if (nc <= 0) continue;
+            if (nc > HS_GRP_COLS){ R.n_long++; continue; }
             size_t b = first_open;
             for (; b < bins.size(); b++) if (bins[b].cols + nc <= HS_GRP_COLS && (int)bins[b].members.size() < max_reads) break;
             if (b == bins.size()) bins.push_back(Bin{0, {}});
@@ -875,6 +876,7 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
       for (hs_item_t& it : R.trail) it.active += base;
       for (hs_item_t& it : R.str) it.active += base;
       out.grp_nd_cap = std::max(out.grp_nd_cap, R.nd_cap);
+      ch.n_long_sides += R.n_long;
       out.tpack.insert(out.tpack.end(), R.tpack.begin(), R.tpack.end());
       out.lead_items.insert(out.lead_items.end(), R.lead.begin(), R.lead.end());
       out.trail_items.insert(out.trail_items.end(), R.trail.begin(), R.trail.end());

@@ -48,6 +48,7 @@ struct Prepared {
     int32_t lead_begin, lead_end;          // lead_items range
     int32_t trail_begin, trail_end;        // trail_items range
     int32_t str_begin, str_end;            // str_items range
+    int32_t n_long_sides;                  // read sides with more than HS_GRP_COLS columns (hs_str_kernel takes them)
     int64_t n_alignments;
   };
   std::vector<Chunk>      chunks;
