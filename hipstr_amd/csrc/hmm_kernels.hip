@@ -359,10 +359,15 @@ __device__ __forceinline__ void coop_barrier(bool drain_stores){
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// The ring is addressed through LDS-typed pointers: with generic ones the compiler folds "boundary from the scratch row or from the
+// ring" into one flat_load of a selected address, which counts against the vector-memory counter and makes every column wait for
+// the next column's prefetch.
+typedef const __attribute__((address_space(3))) double* hs_lds_cd2;      // (M, D) pairs, read and written as doubles
+typedef __attribute__((address_space(3))) double* hs_lds_d2;
 template <int NR, bool FIRST, bool LAST, bool LEAD>
 __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, bool live, int n, int nmax, const double* __restrict__ col,
                                                 const hs_row_t* __restrict__ rows, int row0, int c0, const double* __restrict__ mr,
-                                                double* __restrict__ bnd, bool topg, bool botg, const double2* lds_top, double2* lds_bot,
+                                                double* __restrict__ bnd, bool topg, bool botg, hs_lds_cd2 lds_top, hs_lds_d2 lds_bot,
                                                 double* __restrict__ lt, double* __restrict__ rowp, double* __restrict__ side_out,
                                                 int skew, int nsteps){
   int hc[NR]; double m2m[NR], m2i[NR];
@@ -390,7 +395,10 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
       const double blcj = nx_blc, blwj = nx_blw; const int rdj = (int)nx_rd;
       const double cur_mr = nx_mr;
       double2 cur_b = make_double2(0.0, 0.0);
-      if (!FIRST) cur_b = topg ? *(const double2*)(bnd + ((size_t)j*64 + lane)*2) : lds_top[(j & 1)*64 + lane];
+      if (!FIRST){
+        if (topg) cur_b = *(const double2*)(bnd + ((size_t)j*64 + lane)*2);
+        else { const int e = 2*((j & 1)*64 + lane); cur_b = make_double2(lds_top[e], lds_top[e + 1]); }
+      }
       {
         const int jn = min(j + 1, n - 1);           // a lane past its own read end keeps re-reading its last column
         nx_blc = col[3*jn]; nx_blw = col[3*jn+1]; nx_rd = col[3*jn+2];
@@ -435,7 +443,7 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
       }
       if (!LAST){
         if (botg) *(double2*)(bnd + ((size_t)j*64 + lane)*2) = make_double2(upM, upD);
-        else lds_bot[(j & 1)*64 + lane] = make_double2(upM, upD);
+        else { const int e = 2*((j & 1)*64 + lane); lds_bot[e] = upM; lds_bot[e + 1] = upD; }
       } else if (LEAD){ if (j < n && live) rowp[j] = upM; }
       diagM = topM; diagD = topD;                // top boundary of this column = diagonal of the band's first row next column
       if (j == n-1 && live){
@@ -450,7 +458,7 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
 template <int NR, bool LEAD>
 __device__ __forceinline__ void band_dispatch_coop(bool first, bool last, const hs_dev_t& d, int lane, bool live, int n, int nmax, const double* col,
                                                    const hs_row_t* rows, int row0, int c0, const double* mr, double* bnd, bool topg, bool botg,
-                                                   const double2* lds_top, double2* lds_bot, double* lt, double* rowp, double* side_out, int skew, int nsteps){
+                                                   hs_lds_cd2 lds_top, hs_lds_d2 lds_bot, double* lt, double* rowp, double* side_out, int skew, int nsteps){
   if (first){ if (last) band_sweep_coop<NR, true, true, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps);
               else      band_sweep_coop<NR, true, false, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps); }
   else      { if (last) band_sweep_coop<NR, false, true, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps);
@@ -474,7 +482,7 @@ __device__ __forceinline__ void coop_rounds(const hs_dev_t& d, int w, int lane, 
       const int row0 = 1 + b*nr_base + min(b, nr_rem);
       const bool first = (b == 0), last = (b + 1 == nbands);
       const bool topg = (w == 0) && (g > 0), botg = (w + 1 == nb_round) && !last;
-      const double2* lds_top = ring[w > 0 ? w - 1 : 0]; double2* lds_bot = ring[w];
+      hs_lds_cd2 lds_top = (hs_lds_cd2)ring[w > 0 ? w - 1 : 0]; hs_lds_d2 lds_bot = (hs_lds_d2)ring[w];
       switch (nr){
 #define HS_COOP_CASE(N_) case N_: if (N_ <= R) band_dispatch_coop<(N_ <= R ? N_ : 1), LEAD>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, nsteps); break;
         HS_COOP_CASE(1) HS_COOP_CASE(2) HS_COOP_CASE(3) HS_COOP_CASE(4) HS_COOP_CASE(5) HS_COOP_CASE(6) HS_COOP_CASE(7) HS_COOP_CASE(8)
@@ -1313,8 +1321,10 @@ hs_str_kernel_generic(const hs_dev_t* __restrict__ dp, int active_begin){ str_bo
 struct GrpLds {
   double* rowP; double* Mt; double* Dl;
   double* E;            // [4][XC] emission log of every column against A, C, T, G (code = (char >> 1) & 3): one read instead of base + qualities + compare
-  double* nd[2]; double* cstl[2]; double2* tab[2];
-  uint16_t* boff[2];         // [blk_len] byte offset of the block base's plane of E (valid offsets, zeros, in front of the first one: masked steps may look there)
+  // two of each, used alternately from allele to allele; addressed as base + parity * stride (a pointer picked from an array loses its
+  // address space and every access through it becomes a flat_load)
+  double* nd0; double* cstl0; double2* tab0;
+  uint16_t* boff0;         // [blk_len] byte offset of the block base's plane of E (valid offsets, zeros, in front of the first one: masked steps may look there)
   int ld;
 };
 // nd_cap: doubles of one read-end deletion table of a group = the largest (reads x 21 period) of the batch's groups (prep.cpp)
@@ -1344,7 +1354,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     uint16_t* boffb = (uint16_t*)(tab + 2*HS_TAB_CAP) + blk_len;
     for (int i = x; i < blk_len; i += NT) boffb[i - blk_len] = 0;
     L.rowP = rowP; L.Mt = Mt; L.Dl = Dl; L.E = E; L.ld = XC;
-    for (int b = 0; b < 2; b++){ L.nd[b] = ndb + b*d.grp_nd_cap; L.cstl[b] = cst + b*24; L.tab[b] = tab + b*HS_TAB_CAP; L.boff[b] = boffb + b*blk_len; }
+    L.nd0 = ndb; L.cstl0 = cst; L.tab0 = tab; L.boff0 = boffb;
   }
   if (x < G){
     const int ai = d.tpack[tp + x];
@@ -1380,6 +1390,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       if (j == 0) L.rowP[xx + g] = 0.0;
     }
   }
+  const int blk_len = (d.max_B + 19) & ~15, nd_cap = d.grp_nd_cap;
   const int xrp = xx + g + 1;                       // this column in rowP: rowP[xrp - len] is M of column j - len, or the 0.0 in front when len = j + 1
   const int n_tab = uni(loc->n_tab[side]);
   const int i0 = blockIdx.y * d.allele_chunk, i1 = min(n_tab, i0 + d.allele_chunk);
@@ -1438,21 +1449,21 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       int2 bo;                                      // A, C, T, G -> plane 0, 1, 2, 3 (prep.cpp tabulates only blocks made of these four), two 16-bit offsets per word
       bo.x = (((nx_blkw >> 1) & 3) * (XC*8)) | ((((nx_blkw >> 9) & 3) * (XC*8)) << 16);
       bo.y = (((nx_blkw >> 17) & 3) * (XC*8)) | ((((nx_blkw >> 25) & 3) * (XC*8)) << 16);
-      ((int2*)L.boff[par])[x] = bo;
+      ((int2*)(L.boff0 + par*blk_len))[x] = bo;
     }
-    if (x < 20) L.cstl[par][x] = cst;
-    if (x < tab_len) L.tab[par][x] = make_double2(nx_tabA, nx_tabG);
+    if (x < 20) (L.cstl0 + par*24)[x] = cst;
+    if (x < tab_len) (L.tab0 + par*HS_TAB_CAP)[x] = make_double2(nx_tabA, nx_tabG);
     if (i + 1 < i1){
       if (k == 63) fetch_alleles(i + 1);
       request((k + 1) & 63);
     }
     if (HS_GABL != 4) __syncthreads();                // ... and every wavefront is done with the previous allele's Mt / Dl
-    const double* cstl = L.cstl[par];
-    const double2* tab = L.tab[par];
-    const uint16_t* boff = L.boff[par];
+    const double* cstl = L.cstl0 + par*24;
+    const double2* tab = L.tab0 + par*HS_TAB_CAP;
+    const uint16_t* boff = L.boff0 + par*blk_len;
     auto Eat = [&](int col, int bo) -> double { return *(const double*)((const char*)L.E + col*8 + bo); };   // column col against the block base with plane offset bo
-    double* nd = L.nd[par];
-    const double* nd_prev = L.nd[par ^ 1];
+    double* nd = L.nd0 + par*nd_cap;
+    const double* nd_prev = L.nd0 + (par ^ 1)*nd_cap;
 
     // --- StutterAlignerClass::load_read (StutterAlignerClass.cpp:12-53): match_probs_ and del_probs_ of this lane's column
     const int t0 = chained ? prev_B : 0;
