@@ -425,6 +425,8 @@ def main():
         if not files:
             return None, None
         t = json.load(open(files[-1]))
+        if kernel_key.startswith("hs_str"):
+            kernel_key = "hs_str_"                                                        # the STR phase: hs_str_group_kernel + hs_str_kernel + hs_str_kernel_generic
         hit = [v for name, v in t["kernels"].items() if name.startswith(kernel_key)]      # a phase may be more than one kernel
         if not hit:
             return None, None
@@ -453,7 +455,8 @@ def main():
         cyc = t["cycles_per_wave64_instruction"]
         phases = {}
         for ph, ms_now in phase_ms_now.items():
-            hit = [v for name, v in t["kernels"].items() if name.startswith(ph)]      # a phase may be more than one kernel (hs_str_kernel + _generic)
+            key = "hs_str_" if ph.startswith("hs_str") else ph
+            hit = [v for name, v in t["kernels"].items() if name.startswith(key)]     # a phase may be more than one kernel (the STR phase: group + per-read + generic)
             if not hit or not (ms_now == ms_now) or ms_now <= 0:
                 continue
             sc = n_alignments / t["alignments_per_launch"]

@@ -224,6 +224,25 @@ def test_tabulated_closed_form_and_its_redo_path(hmm, oracle, monkeypatch, env):
         assert np.array_equal(gs, ws) and np.array_equal(got, want), (env, kw)
 
 
+@pytest.mark.parametrize("kw,env", [
+    (dict(n_loci=3, reads_per_locus=40, n_str_alleles=12, read_len=257, flank_len=120, str_bp=40, seed=81), None),     # sides up to the supported 256 columns: one read fills a group
+    (dict(n_loci=4, reads_per_locus=90, n_str_alleles=20, read_len=60, flank_len=28, str_bp=24, seed=82), None),       # short sides: many reads per group, some under six periods
+    (dict(n_loci=3, reads_per_locus=64, n_str_alleles=32, read_len=200, flank_len=90, str_bp=48, seed=83), None),      # one long and one or two short sides per group
+    (dict(n_loci=6, reads_per_locus=50, n_str_alleles=32, seed=84), ("HIPSTR_STR_GROUP", "0")),                       # one workgroup per read for every side
+], ids=["longest_sides", "short_sides", "mixed_sides", "per_read_kernel"])
+def test_str_groups_and_their_fallback(hmm, oracle, monkeypatch, kw, env):
+    """hs_str_group_kernel packs the columns of several reads of a locus side into one workgroup; a side with more columns than a
+    group holds would stay with hs_str_kernel (one workgroup per read; the library accepts sides up to 256 columns, exactly a group,
+    so that path is reached only through HIPSTR_STR_GROUP=0, which selects it for every side)."""
+    monkeypatch.setenv("HIPSTR_SYNTH_IMPERFECT", "0.05")
+    sb = capi.SynthBatch(**kw)
+    want, ws = capi.run_align(oracle, "oracle_", sb.ptr, fill=-3.25)
+    if env:
+        monkeypatch.setenv(*env)
+    got, gs = capi.run_align(hmm, "hipstr_hmm_", sb.ptr, fill=-3.25)
+    assert np.array_equal(gs, ws) and np.array_equal(got, want), kw
+
+
 @pytest.mark.parametrize("lf_len,rf_len", [(1, 40), (40, 1), (2, 33), (20, 21), (21, 20), (41, 61)])
 def test_flank_heights_around_the_band_size(hmm, oracle, lf_len, rf_len):
     """The banded sweeps of hs_lead_kernel / hs_trail_kernel cut a flank into bands of <= 20 rows; a one-base flank is a block with
