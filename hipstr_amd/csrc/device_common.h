@@ -39,14 +39,20 @@ __device__ __forceinline__ void wave_lds_sync(){
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ int wave_min_i(int v){
-  for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m));
-  return v;
-}
-__device__ __forceinline__ int wave_max_i(int v){
-  for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
-  return v;
-}
+// Integer minimum / maximum over the wavefront with DPP row shifts and row broadcasts (six VALU operations and a v_readlane) instead of
+// six ds_bpermute round trips: these sit on the critical path of the STR kernels' read-end sums.  A lane without a source keeps its own
+// value (old = v), which min and max do not mind.
+#define HS_DPP_RED(OP) \
+  v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false)); /* row_shr:1 */ \
+  v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false)); /* row_shr:2 */ \
+  v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false)); /* row_shr:4 */ \
+  v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false)); /* row_shr:8: lane 15 of every row holds the row */ \
+  v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false)); /* row_bcast:15 into rows 1 and 3 */ \
+  v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false)); /* row_bcast:31 into rows 2 and 3: lane 63 holds the wavefront */ \
+  return __builtin_amdgcn_readlane(v, 63);
+__device__ __forceinline__ int wave_min_i(int v){ HS_DPP_RED(min) }
+__device__ __forceinline__ int wave_max_i(int v){ HS_DPP_RED(max) }
+#undef HS_DPP_RED
 __device__ __forceinline__ double wave_max_d(double v){
   for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
   return v;

@@ -1315,6 +1315,11 @@ hs_str_kernel_generic(const hs_dev_t* __restrict__ dp, int active_begin){ str_bo
 // order per column as str_body<0>: bit-identical.  Two workgroup barriers per allele separate the table phase from the evaluation;
 // the allele's block, constants and closed-form table are double-buffered so that loading the next allele needs no third one.
 #define HS_GRP_MAXREADS 16
+#ifdef HS_GTIME       // timing experiment: cycles per section of the allele loop, printed by a few workgroups
+#define HS_TICK(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[k] += now_ - tprev; tprev = now_; } while (0)
+#else
+#define HS_TICK(k) do {} while (0)
+#endif
 #ifndef HS_GABL
 #define HS_GABL 0          // timing experiments only (results invalid): 1 no read-end sums, 2 no evaluation, 3 no table phase, 4 no barriers, 5 no chains; valid results: 6 read-end sums twice, 7 evaluation twice
 #endif
@@ -1331,7 +1336,7 @@ struct GrpLds {
 extern "C" size_t hs_str_group_lds_bytes(int max_B, int nd_cap){
   const size_t XC = HS_GRP_COLS;
   const size_t blk_len = ((size_t)max_B + 19) & ~(size_t)15;
-  return XC*8*HS_MAXREP + (XC + HS_GRP_MAXREADS + 2)*8 + XC*8 + XC*32 + 2*(size_t)nd_cap*8 + 2*24*8 + 2*HS_TAB_CAP*16 + 3*blk_len*2 + 16;
+  return XC*8*HS_MAXREP + (XC + HS_GRP_MAXREADS + 2)*8 + XC*8 + XC*32 + 2*(size_t)nd_cap*8 + 2*24*8 + 2*HS_TAB_CAP*16 + (3*blk_len + 64)*2 + 16;
 }
 
 __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin){
@@ -1351,8 +1356,8 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     double* ndb = E + 4*XC;
     double* cst = ndb + 2*d.grp_nd_cap;
     double2* tab = (double2*)(cst + 2*24);
-    uint16_t* boffb = (uint16_t*)(tab + 2*HS_TAB_CAP) + blk_len;
-    for (int i = x; i < blk_len; i += NT) boffb[i - blk_len] = 0;
+    uint16_t* boffb = (uint16_t*)(tab + 2*HS_TAB_CAP) + blk_len + 64;        // zeros in front: the read-end chains fetch ahead of themselves
+    for (int i = x; i < blk_len + 64; i += NT) boffb[i - blk_len - 64] = 0;
     L.rowP = rowP; L.Mt = Mt; L.Dl = Dl; L.E = E; L.ld = XC;
     L.nd0 = ndb; L.cstl0 = cst; L.tab0 = tab; L.boff0 = boffb;
   }
@@ -1425,6 +1430,9 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
   };
   if (i0 < i1){ fetch_alleles(i0); request(0); }
   int cur_slot = -1, prev_B = 0;
+#ifdef HS_GTIME
+  unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#endif
   for (int i = i0; i < i1; i++){
     const int par = (i - i0) & 1;
     const int k = (i - i0) & 63;
@@ -1457,7 +1465,9 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       if (k == 63) fetch_alleles(i + 1);
       request((k + 1) & 63);
     }
+    HS_TICK(0);   // phase 3 of the previous allele + setup
     if (HS_GABL != 4) __syncthreads();                // ... and every wavefront is done with the previous allele's Mt / Dl
+    HS_TICK(1);   // barrier 1 wait
     const double* cstl = L.cstl0 + par*24;
     const double2* tab = L.tab0 + par*HS_TAB_CAP;
     const uint16_t* boff = L.boff0 + par*blk_len;
@@ -1509,6 +1519,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       if (actj) L.Mt[xx] = lp;
     }
 
+    HS_TICK(2);   // phase 1
     // --- deletion start values of the columns whose segment reaches the read end (the `else` branch of StutterAlignerClass.cpp:117-120),
     // (size, column) pairs of all reads of the group spread over the workgroup's lanes; layout per read as in str_body
     for (int rep = 0; rep < ((HS_GABL == 6) ? 2 : 1); rep++){
@@ -1520,35 +1531,39 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
         double lp = cstl[14 + q];
         // step t pairs read column xcol - t with block base B-1-aD - t, four steps per group.  The chain of additions is the critical
         // path of the allele, so its operands run ahead of it: plane offsets two groups ahead, emissions one group ahead.
-        int xr = xcol - 3, xb = (B - 1 - aD) - 3, t = 0;
-        int bo[4]; double ev[4];
+        constexpr int GS = 4;                             // steps per group
+        int xr = xcol - (GS - 1), xb = (B - 1 - aD) - (GS - 1), t = 0;
+        int bo[GS]; double ev[GS];
 #pragma unroll
-        for (int k = 0; k < 4; k++) bo[k] = boff[xb + 3 - k];
+        for (int k = 0; k < GS; k++) bo[k] = boff[xb + GS - 1 - k];
 #pragma unroll
-        for (int k = 0; k < 4; k++) ev[k] = Eat(xr + 3 - k, bo[k]);
-        xr -= 4; xb -= 4;
+        for (int k = 0; k < GS; k++) ev[k] = Eat(xr + GS - 1 - k, bo[k]);
+        xr -= GS; xb -= GS;
 #pragma unroll
-        for (int k = 0; k < 4; k++) bo[k] = boff[xb + 3 - k];          // in front of the table: zeros (a valid plane), never used
+        for (int k = 0; k < GS; k++) bo[k] = boff[xb + GS - 1 - k];    // in front of the table: zeros (a valid plane), never used
         auto advance = [&](){
           asm volatile("" : "+v"(xr), "+v"(xb));
 #pragma unroll
-          for (int k = 0; k < 4; k++) ev[k] = Eat(xr + 3 - k, bo[k]);
-          xr -= 4; xb -= 4;
+          for (int k = 0; k < GS; k++) ev[k] = Eat(xr + GS - 1 - k, bo[k]);
+          xr -= GS; xb -= GS;
 #pragma unroll
-          for (int k = 0; k < 4; k++) bo[k] = boff[xb + 3 - k];
+          for (int k = 0; k < GS; k++) bo[k] = boff[xb + GS - 1 - k];
         };
-        for (; t + 4 <= lmin; t += 4){
-          const double e0 = ev[0], e1 = ev[1], e2 = ev[2], e3 = ev[3];
+        for (; t + GS <= lmin; t += GS){
+          double e[GS];
+#pragma unroll
+          for (int k = 0; k < GS; k++) e[k] = ev[k];
           advance();
-          lp += e0; lp += e1; lp += e2; lp += e3;
+#pragma unroll
+          for (int k = 0; k < GS; k++) lp += e[k];
         }
-        for (; t < lmax; t += 4){
-          const double e0 = ev[0], e1 = ev[1], e2 = ev[2], e3 = ev[3];
+        for (; t < lmax; t += GS){
+          double e[GS];
+#pragma unroll
+          for (int k = 0; k < GS; k++) e[k] = ev[k];
           advance();
-          if (t < len) lp += e0;
-          if (t + 1 < len) lp += e1;
-          if (t + 2 < len) lp += e2;
-          if (t + 3 < len) lp += e3;
+#pragma unroll
+          for (int k = 0; k < GS; k++) if (t + k < len) lp += e[k];
         }
         if (valid) nd[dst] = lp;
       };
@@ -1666,8 +1681,10 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       }
       }
     }
+    HS_TICK(3);   // nd section
     if (HS_GABL != 4) __syncthreads();
 
+    HS_TICK(4);   // barrier 2 wait
     // --- the 13 artifact terms of this lane's column (HapAligner.cpp:62-109) and their fast_log_sum_exp
     for (int rep3 = 0; rep3 < ((HS_GABL == 7) ? 2 : 1); rep3++)
     if (wave_act && HS_GABL != 2){
@@ -1750,6 +1767,12 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       }
     }
   }
+#ifdef HS_GTIME
+  { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[0] += now_ - tprev; }
+  if ((blockIdx.x % 20000) == 7 && lane == 0)
+    printf("grp %d wave %d G %d X %d alleles %d: ph3+setup %llu  wait1 %llu  ph1 %llu  nd %llu  wait2 %llu\n", (int)blockIdx.x, (int)(x >> 6), G, X, i1 - i0,
+           tacc[0], tacc[1], tacc[2], tacc[3], tacc[4]);
+#endif
 }
 
 #ifndef HS_GRP_OCC
