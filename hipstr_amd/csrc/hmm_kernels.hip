@@ -1405,7 +1405,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
   const int nmin_g = uni(wave_min_i(nh_l));                      // shortest side of the group
   // The alleles' records are fetched 64 at a time, one allele per lane (order entry -> allele -> STR option: three dependent loads, paid
   // once), and read lane by lane; what an allele needs beyond them (constants, block, closed-form table) is requested one allele ahead.
-  // a_pk1 = lead slot | nd << 8 | period << 12 | nd_eq << 16 | tab_len << 20;  a_pk2 = re_ord | B << 16
+  // a_pk1 = lead slot (10 bits) | nd << 10 | period << 13 | nd_eq << 17 | B << 20 (B <= 1024: prep.cpp);  a_pk2 = re_ord (24 bits) | tab_len << 24
   int a_oe = 0, a_pk1 = 0, a_pk2 = 0, a_sopt = 0, a_seq = 0, a_f64 = 0, a_taboff = 0;
   auto fetch_alleles = [&](int first){
     const int k = min(first + lane, i1 - 1);
@@ -1413,13 +1413,13 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     const hs_allele_t* al = d.alleles + uni(loc->hap_begin) + (a_oe & 0x1fffffff);
     a_sopt = al->str_opt[side];
     const hs_stropt_t* so = d.stropts + a_sopt;
-    a_pk1 = (al->lead_slot[side] & 0xff) | (so->nd << 8) | (so->period << 12) | (so->nd_eq << 16) | (so->tab_len << 20);
-    a_pk2 = (al->re_ord & 0xffff) | (so->B << 16);
+    a_pk1 = (al->lead_slot[side] & 0x3ff) | (so->nd << 10) | (so->period << 13) | (so->nd_eq << 17) | (so->B << 20);
+    a_pk2 = (al->re_ord & 0xffffff) | (so->tab_len << 24);
     a_seq = so->seq_off; a_f64 = so->f64_off; a_taboff = so->tab_off;
   };
   double nx_cst = 0.0, nx_bmin = 0.0, nx_tabA = 0.0, nx_tabG = 0.0; int nx_shapes = -1, nx_tbase = 0, nx_blkw = 0;
   auto request = [&](int k){                          // k: lane of the allele in the fetched batch
-    const int f64o = rdlane(a_f64, k), sopt = rdlane(a_sopt, k), tl = (rdlane(a_pk1, k) >> 20) & 0xff, Bk = (rdlane(a_pk2, k) >> 16) & 0xffff;
+    const int f64o = rdlane(a_f64, k), sopt = rdlane(a_sopt, k), tl = (rdlane(a_pk2, k) >> 24) & 0xff, Bk = (rdlane(a_pk1, k) >> 20) & 0x7ff;
     const double* tsrc = d.f64pool + rdlane(a_taboff, k);
     nx_cst = d.f64pool[f64o + min(lane, 19)];        // lane t < 20: pmf[13] | prior_ins | prior_del[6]
     nx_shapes = (lane <= HS_MAXREP) ? d.stropts[sopt].shape[lane] : -1;
@@ -1439,9 +1439,9 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     const int oe = rdlane(a_oe, k);
     const bool chained = (i > i0) && ((oe >> 30) & 1);
     const int pk1 = rdlane(a_pk1, k), pk2 = rdlane(a_pk2, k);
-    const int slot = pk1 & 0xff, re_ord = pk2 & 0xffff;
+    const int slot = pk1 & 0x3ff, re_ord = pk2 & 0xffffff;
     double* const mr_out = mr_base + (int64_t)re_ord*lenm1;
-    const int B = (pk2 >> 16) & 0xffff, nv = (pk1 >> 8) & 15, p = (pk1 >> 12) & 15, nd_eq = (pk1 >> 16) & 15, tab_len = (pk1 >> 20) & 0xff;
+    const int B = (pk1 >> 20) & 0x7ff, nv = (pk1 >> 10) & 7, p = (pk1 >> 13) & 15, nd_eq = (pk1 >> 17) & 7, tab_len = (pk2 >> 24) & 0xff;
     const int nds = 21*p;                                     // read-end deletion sums of one read: sizes back to back, at most (q+1)p columns each
     const int ndb = g*nds;
     const double cst = nx_cst;

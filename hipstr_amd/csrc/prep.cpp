@@ -469,6 +469,7 @@ int check_batch(const hipstr_batch_t* b, std::string& err){
     for (int k = 0; k < 3; k++){
       const int n = b->blk_nopts[3*l+k];
       if (n < 1){ err = "haplotype block without options"; return 1; }
+      if (n > 1024){ err = "more than 1024 options for a haplotype block are not supported"; return 1; }
       A *= n;
       for (int o = 0; o < n; o++, opt_cursor++){
         const int len = b->opt_off[opt_cursor+1] - b->opt_off[opt_cursor];
@@ -479,6 +480,7 @@ int check_batch(const hipstr_batch_t* b, std::string& err){
       }
     }
     if (A != b->hap_off[l+1]-b->hap_off[l]){ err = "hap_off does not match the product of block options"; return 1; }
+    if (A >= (1 << 24)){ err = "more than 16 M candidate haplotypes for a locus are not supported"; return 1; }
     if (b->read_off[l+1] < b->read_off[l]){ err = "read_off must not decrease"; return 1; }
     for (int r = b->read_off[l]; r < b->read_off[l+1]; r++){
       if (b->realign_read && !b->realign_read[r]) continue;
@@ -523,6 +525,7 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
     }
     const int A = nopts[0]*nopts[1]*nopts[2];
     if (A != b->hap_off[l+1]-b->hap_off[l]){ err = "hap_off does not match the product of block options"; return 1; }
+    if (A >= (1 << 24)){ err = "more than 16 M candidate haplotypes for a locus are not supported"; return 1; }
 
     hs_locus_t loc;
     loc.out_off = sh.out_off[l]; loc.hap_begin = out.alleles.size(); loc.n_alleles = A;
