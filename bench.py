@@ -149,16 +149,20 @@ def pipeline_stages(capi, hmm, sb, loci, P):
     h2r_c = capi.hap_aln_info(hmm, "hipstr_", cb.ptr, cap=1 << 26)
     stage = {}
     def chain():
+        t_a = time.perf_counter()
         dev = hmm.hipstr_hmm_upload(cb.ptr)
         hmm.hipstr_hmm_align(dev, None)
         pbc = capi.PostBatch(A_c, np.full(nc, S_c, np.int32), np.arange(nc + 1, dtype=np.int32) * P, lab, np.zeros(nc * P), np.zeros(nc * P),
                              np.ones(nc * P, np.int32), None)
         pdc = hmm.hipstr_post_upload(pbc.ptr, hmm.hipstr_hmm_dev_aln_probs(dev))
         hmm.hipstr_post_launch(pdc, None)
+        stage["submit_s"] = time.perf_counter() - t_a          # prepare + upload + launches (asynchronous)
+        t_a = time.perf_counter()
         ll = np.zeros(cb.n_out); sd = np.zeros(cb.n_reads, np.int32)
         hmm.hipstr_hmm_fetch(dev, ll.ctypes.data_as(capi._f64p), sd.ctypes.data_as(capi._i32p))
         post = np.zeros(int(pbc.post_off[-1])); tot = np.zeros(nc * S_c); gt = np.zeros(2 * nc * S_c, np.int32); lt = np.zeros(nc)
         hmm.hipstr_post_fetch(pdc, post.ctypes.data_as(capi._f64p), tot.ctypes.data_as(capi._f64p), gt.ctypes.data_as(capi._i32p), lt.ctypes.data_as(capi._f64p))
+        stage["forward_and_fetch_s"] = time.perf_counter() - t_a   # waits for the forward pass and the posteriors, copies them back
         # best haplotype of every read: the likelier of its sample's two MAP haplotypes
         gt = gt.reshape(-1, 2)
         rr_c, aa_c = [], []

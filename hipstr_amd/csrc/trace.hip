@@ -860,14 +860,22 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
     TR_HIP(hipGetLastError());
     TR_HIP(hipStreamSynchronize(T.stream));
     const auto c2 = now();
-    std::vector<double> ll(nq); std::vector<int32_t> mxi(nq), nops(2*(size_t)nq), ssz(2*(size_t)nq), spos(2*(size_t)nq);
-    std::vector<char> opsbuf(n_ops ? n_ops : 1);
-    TR_HIP(hipMemcpy(ll.data(), hc.ll, nq*sizeof(double), hipMemcpyDeviceToHost));
-    TR_HIP(hipMemcpy(mxi.data(), hc.max_index, nq*sizeof(int32_t), hipMemcpyDeviceToHost));
-    TR_HIP(hipMemcpy(nops.data(), hc.n_ops, 2*(size_t)nq*sizeof(int32_t), hipMemcpyDeviceToHost));
-    TR_HIP(hipMemcpy(ssz.data(), hc.str_size, 2*(size_t)nq*sizeof(int32_t), hipMemcpyDeviceToHost));
-    TR_HIP(hipMemcpy(spos.data(), hc.str_pos, 2*(size_t)nq*sizeof(int32_t), hipMemcpyDeviceToHost));
-    TR_HIP(hipMemcpy(opsbuf.data(), hc.ops, n_ops, hipMemcpyDeviceToHost));
+    // results through one pinned block (a pageable destination costs a staging copy per call and per array)
+    const size_t o_ll = 0, o_mxi = o_ll + (size_t)nq*8, o_nops = o_mxi + (size_t)nq*4, o_ssz = o_nops + 2*(size_t)nq*4, o_spos = o_ssz + 2*(size_t)nq*4,
+                 o_ops = (o_spos + 2*(size_t)nq*4 + 15) & ~(size_t)15, o_end = o_ops + (n_ops ? n_ops : 1);
+    char* hostblk = (char*)hipstr::pin_alloc(T.ctx, o_end);
+    if (!hostblk) return api_fail("out of pinned host memory");
+    struct PinGuard { hipstr::Ctx* c; void* p; ~PinGuard(){ hipstr::pin_free(c, p); } } pin_guard{T.ctx, hostblk};
+    TR_HIP(hipMemcpyAsync(hostblk + o_ll, hc.ll, nq*sizeof(double), hipMemcpyDeviceToHost, T.stream));
+    TR_HIP(hipMemcpyAsync(hostblk + o_mxi, hc.max_index, nq*sizeof(int32_t), hipMemcpyDeviceToHost, T.stream));
+    TR_HIP(hipMemcpyAsync(hostblk + o_nops, hc.n_ops, 2*(size_t)nq*sizeof(int32_t), hipMemcpyDeviceToHost, T.stream));
+    TR_HIP(hipMemcpyAsync(hostblk + o_ssz, hc.str_size, 2*(size_t)nq*sizeof(int32_t), hipMemcpyDeviceToHost, T.stream));
+    TR_HIP(hipMemcpyAsync(hostblk + o_spos, hc.str_pos, 2*(size_t)nq*sizeof(int32_t), hipMemcpyDeviceToHost, T.stream));
+    if (n_ops) TR_HIP(hipMemcpyAsync(hostblk + o_ops, hc.ops, n_ops, hipMemcpyDeviceToHost, T.stream));
+    TR_HIP(hipStreamSynchronize(T.stream));
+    const double* ll = (const double*)(hostblk + o_ll); const int32_t* mxi = (const int32_t*)(hostblk + o_mxi);
+    const int32_t* nops = (const int32_t*)(hostblk + o_nops); const int32_t* ssz = (const int32_t*)(hostblk + o_ssz); const int32_t* spos = (const int32_t*)(hostblk + o_spos);
+    const char* opsbuf_p = hostblk + o_ops;
     const auto c3 = now();
 
     // ---- replay (HapAligner.cpp:642-707) + stitch, request by request; independent, so spread over host threads
@@ -891,7 +899,7 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
           const hs_tside_t& S = sides[2*q+sd];
           const int cnt = nops[2*(q-q0)+sd];
           if (cnt > S.ops_cap){ R.ok = false; break; }
-          side_ops[sd].assign(opsbuf.data() + S.ops_off, cnt);
+          side_ops[sd].assign(opsbuf_p + S.ops_off, cnt);
           if (sd == 1 && seed_block != 1) R.acc.flank[seed_block].push_back(bases[sb]);
           const int mx = sd ? H-1-max_index : max_index;
           if (mx == 0) continue;                         // this side is all soft clips
@@ -1005,7 +1013,10 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
     };
     const auto r2t = now();
     run_parallel(copy_out);
-    if (timing) fprintf(stderr, "  replay of %d: setup %.3f work %.3f offsets %.3f copy %.3f (threads %d)\n", nq, ms(c3, r0t), ms(r0t, r1t), ms(r1t, r2t), ms(r2t, now()), nthreads);
+    const auto r3t = now();
+    // a request's results are a dozen small heap blocks: let the threads that made them give them back, not this one at scope exit
+    run_parallel([&](int qa, int qb){ for (int q = qa; q < qb; q++){ ReqOut none; std::swap(none, res[q-q0]); } });
+    if (timing) fprintf(stderr, "  replay of %d: setup %.3f work %.3f offsets %.3f copy %.3f release %.3f (threads %d)\n", nq, ms(c3, r0t), ms(r0t, r1t), ms(r1t, r2t), ms(r2t, r3t), ms(r3t, now()), nthreads);
     q0 = q1;
     const auto c4 = now();
     ms_alloc += ms(c0, c1); ms_kernel += ms(c1, c2); ms_d2h += ms(c2, c3); ms_replay += ms(c3, c4);
