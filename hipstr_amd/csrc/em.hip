@@ -413,50 +413,62 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
   std::vector<hs_post_unit_t> units;
   std::vector<int32_t> bps, obs(n_reads), unit_locus;
   std::vector<double> gtp;
-  int64_t post_off = 0, ll_off = 0, prior_off = 0; int samp_off = 0;
-  for (int l = 0; l < nl; l++){
-    const int S = eb->n_samples[l], r0 = eb->read_off[l], r1 = eb->read_off[l+1], R = r1 - r0;
-    if (eb->period[l] < 1 || eb->period[l] > 9) return api_fail("STR period must be in [1,9] (stutter_model.h:38)");
-    if (S < 1) return api_fail("locus without samples");
-    std::vector<int> sizes;
+  // per locus, independent of the others (host threads): allele sizes, the reads' allele indices, the initial allele frequencies
+  struct LocusPrep { std::vector<int> sizes; std::vector<double> gtp; std::vector<int32_t> reads_of_sample; const char* err = NULL; };
+  std::vector<LocusPrep> lp(nl);
+  hipstr::parallel_for(nl, nl >= 64 ? hipstr::host_threads() : 1, [&](int l){
+    LocusPrep& Q = lp[l];
+    const int S = eb->n_samples[l], r0 = eb->read_off[l], r1 = eb->read_off[l+1];
+    if (eb->period[l] < 1 || eb->period[l] > 9){ Q.err = "STR period must be in [1,9] (stutter_model.h:38)"; return; }
+    if (S < 1){ Q.err = "locus without samples"; return; }
+    std::vector<int>& sizes = Q.sizes;
     for (int r = r0; r < r1; r++) if (eb->num_bps[r] != eb->ref_allele) sizes.push_back(eb->num_bps[r]);
     std::sort(sizes.begin(), sizes.end());
     sizes.erase(std::unique(sizes.begin(), sizes.end()), sizes.end());
     sizes.insert(sizes.begin(), eb->ref_allele);
     const int A = (int)sizes.size();
-    if (A + 1 >= 10000) return api_fail("too many distinct allele sizes");
+    if (A + 1 >= 10000){ Q.err = "too many distinct allele sizes"; return; }
+    Q.reads_of_sample.assign(S, 0);
+    int prev = 0;
+    for (int r = r0; r < r1; r++){
+      const int s = eb->sample_label[r];
+      if (s < prev || s >= S){ Q.err = "reads of a locus must be grouped by ascending sample label (genotyper.h:112-119)"; return; }
+      prev = s; Q.reads_of_sample[s]++;
+      obs[r] = (int32_t)(std::lower_bound(sizes.begin() + 1, sizes.end(), eb->num_bps[r]) - sizes.begin());
+      if (eb->num_bps[r] == eb->ref_allele) obs[r] = 0;
+    }
+    std::vector<double> g(A, 1.0);                                     // init_log_gt_priors (:10-20)
+    for (int r = r0; r < r1; r++) g[obs[r]] += 1.0/Q.reads_of_sample[eb->sample_label[r]];
+    double tot = 0.0; for (int a = 0; a < A; a++) tot += g[a];
+    const double lt = log(tot);
+    Q.gtp.resize(A);
+    for (int a = 0; a < A; a++) Q.gtp[a] = log(g[a]) - lt;
+  });
+  int64_t post_off = 0, ll_off = 0, prior_off = 0; int samp_off = 0;
+  for (int l = 0; l < nl; l++){
+    const LocusPrep& Q = lp[l];
+    if (Q.err) return api_fail(Q.err);
+    const int S = eb->n_samples[l], r0 = eb->read_off[l], r1 = eb->read_off[l+1], R = r1 - r0;
+    const int A = (int)Q.sizes.size();
     hs_em_locus_t& L = loci[l];
     memset(&L, 0, sizeof L);
     L.A = A; L.S = S; L.R = R; L.period = eb->period[l]; L.haploid = (eb->haploid && eb->haploid[l]) ? 1 : 0;
     L.read_begin = r0; L.samp_begin = samp_off; L.bps_off = (int32_t)bps.size();
     L.post_off = post_off; L.ll_off = ll_off; L.prior_off = prior_off;
-    std::vector<int> per_sample(S, 0);
-    int prev = 0;
-    for (int r = r0; r < r1; r++){
-      const int s = eb->sample_label[r];
-      if (s < prev || s >= S) return api_fail("reads of a locus must be grouped by ascending sample label (genotyper.h:112-119)");
-      prev = s; per_sample[s]++;
-      obs[r] = (int32_t)(std::lower_bound(sizes.begin() + 1, sizes.end(), eb->num_bps[r]) - sizes.begin());
-      if (eb->num_bps[r] == eb->ref_allele) obs[r] = 0;
-    }
-    std::vector<double> g(A, 1.0);                                     // init_log_gt_priors (:10-20)
-    for (int r = r0; r < r1; r++) g[obs[r]] += 1.0/per_sample[eb->sample_label[r]];
-    double tot = 0.0; for (int a = 0; a < A; a++) tot += g[a];
-    const double lt = log(tot);
-    for (int a = 0; a < A; a++) gtp.push_back(log(g[a]) - lt);
-    bps.insert(bps.end(), sizes.begin(), sizes.end());
+    gtp.insert(gtp.end(), Q.gtp.begin(), Q.gtp.end());
+    bps.insert(bps.end(), Q.sizes.begin(), Q.sizes.end());
     int r = r0;
     for (int s = 0; s < S; s++){                                       // posterior-kernel units: (locus, sample)
       hs_post_unit_t u; memset(&u, 0, sizeof u);
       u.post_off = post_off + (int64_t)s*A*A; u.prior_off = prior_off; u.n_alleles = A; u.samp_index = samp_off + s;
       u.read_begin = r; u.ll_off = ll_off + (int64_t)(r - r0)*A;
-      while (r < r1 && eb->sample_label[r] == s) r++;
+      r += Q.reads_of_sample[s];
       u.n_reads = r - u.read_begin;
       units.push_back(u); unit_locus.push_back(l);
     }
     post_off += (int64_t)S*A*A; ll_off += (int64_t)R*A; prior_off += (int64_t)A*A; samp_off += S;
   }
-
+  std::vector<LocusPrep>().swap(lp);
   lap("alleles and units", NULL);
   // ---- device state
   EmBufs dev;
