@@ -1431,7 +1431,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
   if (i0 < i1){ fetch_alleles(i0); request(0); }
   int cur_slot = -1, prev_B = 0;
 #ifdef HS_GTIME
-  unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+  unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime(), nrounds = 0;
 #endif
   for (int i = i0; i < i1; i++){
     const int par = (i - i0) & 1;
@@ -1549,6 +1549,12 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
 #pragma unroll
           for (int k = 0; k < GS; k++) bo[k] = boff[xb + GS - 1 - k];
         };
+        // the chain is the allele's critical path (the other wavefronts of the workgroup wait for it at the barrier) and a handful of
+        // instructions per step: it goes first whenever it is ready
+#ifdef HS_GTIME
+        const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
+#endif
+        __builtin_amdgcn_s_setprio(3);
         for (; t + GS <= lmin; t += GS){
           double e[GS];
 #pragma unroll
@@ -1565,6 +1571,10 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
 #pragma unroll
           for (int k = 0; k < GS; k++) if (t + k < len) lp += e[k];
         }
+        __builtin_amdgcn_s_setprio(0);
+#ifdef HS_GTIME
+        tacc[5] += __builtin_amdgcn_s_memtime() - tc0; tacc[6] += lmax; nrounds++;
+#endif
         if (valid) nd[dst] = lp;
       };
       auto row_off = [&](int q){ return p*((q*(q+1)) >> 1); };
@@ -1582,9 +1592,9 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       const int xw = (x + (NT/2)*(i - i0)) & (NT - 1);               // the sums rarely fill the workgroup: the wavefronts take turns at them (a wavefront's SIMD is fixed)
       if (all_long){
         const int Gp = G*p;
-        const float rc_p = 1.0f/(float)p;
+        const float rc_p = __builtin_amdgcn_rcpf((float)p);        // approximate: udiv corrects by one either way
         if (reuse_al){
-          const float rc_copy = 1.0f/(float)max(ncopy, 1);
+          const float rc_copy = __builtin_amdgcn_rcpf((float)max(ncopy, 1));
           for (int base = 0; base < ((HS_GABL == 1) ? 0 : G*ncopy); base += NT){
             const int e = base + xw;
             if (e < G*ncopy){
@@ -1597,7 +1607,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
             }
           }
           const int n_sums = nv*Gp;                                // e = (q G + h) p + off
-          const float rc_gp = 1.0f/(float)Gp;
+          const float rc_gp = __builtin_amdgcn_rcpf((float)Gp);
           for (int base = 0; base < ((HS_GABL == 1) ? 0 : n_sums); base += NT){
             if (base + (xw & ~63) >= n_sums) continue;             // whole wavefront past the end (wave-uniform)
             const int e = min(base + xw, n_sums - 1);
@@ -1614,7 +1624,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
 #pragma unroll
             for (int k = 1; k <= 5; k++) q += (e >= G*row_off(k)) ? 1 : 0;
             const int r = e - G*row_off(q), w = (q+1)*p;
-            const int hh = udiv(r, w, 1.0f/(float)w), off = r - hh*w;
+            const int hh = udiv(r, w, __builtin_amdgcn_rcpf((float)w)), off = r - hh*w;
             const int jcol = (s_n[hh] - w) + off;
             nd_sum(q, s_off[hh] + jcol, jcol, base + xw < n_sums, hh*nds + row_off(q) + off);
           }
@@ -1770,8 +1780,8 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
 #ifdef HS_GTIME
   { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[0] += now_ - tprev; }
   if ((blockIdx.x % 20000) == 7 && lane == 0)
-    printf("grp %d wave %d G %d X %d alleles %d: ph3+setup %llu  wait1 %llu  ph1 %llu  nd %llu  wait2 %llu\n", (int)blockIdx.x, (int)(x >> 6), G, X, i1 - i0,
-           tacc[0], tacc[1], tacc[2], tacc[3], tacc[4]);
+    printf("grp %d wave %d G %d X %d alleles %d: ph3+setup %llu  wait1 %llu  ph1 %llu  nd %llu  wait2 %llu | chains %llu in %llu rounds, %llu steps\n", (int)blockIdx.x, (int)(x >> 6), G, X, i1 - i0,
+           tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5], nrounds, tacc[6]);
 #endif
 }
 
