@@ -1326,17 +1326,17 @@ hs_str_kernel_generic(const hs_dev_t* __restrict__ dp, int active_begin){ str_bo
 struct GrpLds {
   double* rowP; double* Mt; double* Dl;
   double* E;            // [4][XC] emission log of every column against A, C, T, G (code = (char >> 1) & 3): one read instead of base + qualities + compare
-  // two of each, used alternately from allele to allele; addressed as base + parity * stride (a pointer picked from an array loses its
+  // two of each but nd, used alternately from allele to allele; addressed as base + parity * stride (a pointer picked from an array loses its
   // address space and every access through it becomes a flat_load)
   double* nd0; double* cstl0; double2* tab0;
   uint16_t* boff0;         // [blk_len] byte offset of the block base's plane of E (valid offsets, zeros, in front of the first one: masked steps may look there)
   int ld;
 };
-// nd_cap: doubles of one read-end deletion table of a group = the largest (reads x 21 period) of the batch's groups (prep.cpp)
+// nd_cap: doubles of the read-end deletion table of a group = the largest (reads x 36 period) of the batch's groups (prep.cpp)
 extern "C" size_t hs_str_group_lds_bytes(int max_B, int nd_cap){
   const size_t XC = HS_GRP_COLS;
   const size_t blk_len = ((size_t)max_B + 19) & ~(size_t)15;
-  return XC*8*HS_MAXREP + (XC + HS_GRP_MAXREADS + 2)*8 + XC*8 + XC*32 + 2*(size_t)nd_cap*8 + 2*24*8 + 2*HS_TAB_CAP*16 + (3*blk_len + 64)*2 + 16;
+  return XC*8*HS_MAXREP + (XC + HS_GRP_MAXREADS + 2)*8 + XC*8 + XC*32 + (size_t)nd_cap*8 + 2*24*8 + 2*HS_TAB_CAP*16 + (3*blk_len + 64)*2 + 16;
 }
 
 __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin){
@@ -1354,7 +1354,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     const int blk_len = (d.max_B + 19) & ~15;
     double* E = Mt + XC;
     double* ndb = E + 4*XC;
-    double* cst = ndb + 2*d.grp_nd_cap;
+    double* cst = ndb + d.grp_nd_cap;
     double2* tab = (double2*)(cst + 2*24);
     uint16_t* boffb = (uint16_t*)(tab + 2*HS_TAB_CAP) + blk_len + 64;        // zeros in front: the read-end chains fetch ahead of themselves
     for (int i = x; i < blk_len + 64; i += NT) boffb[i - blk_len - 64] = 0;
@@ -1395,7 +1395,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       if (j == 0) L.rowP[xx + g] = 0.0;
     }
   }
-  const int blk_len = (d.max_B + 19) & ~15, nd_cap = d.grp_nd_cap;
+  const int blk_len = (d.max_B + 19) & ~15;
   const int xrp = xx + g + 1;                       // this column in rowP: rowP[xrp - len] is M of column j - len, or the 0.0 in front when len = j + 1
   const int n_tab = uni(loc->n_tab[side]);
   const int i0 = blockIdx.y * d.allele_chunk, i1 = min(n_tab, i0 + d.allele_chunk);
@@ -1429,7 +1429,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     if (x < tl){ nx_tabA = tsrc[3*x]; nx_tabG = tsrc[3*x + 1]; }
   };
   if (i0 < i1){ fetch_alleles(i0); request(0); }
-  int cur_slot = -1, prev_B = 0;
+  int cur_slot = -1, prev_B = 0, nd_base = 0;
 #ifdef HS_GTIME
   unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime(), nrounds = 0;
 #endif
@@ -1442,7 +1442,11 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     const int slot = pk1 & 0x3ff, re_ord = pk2 & 0xffffff;
     double* const mr_out = mr_base + (int64_t)re_ord*lenm1;
     const int B = (pk1 >> 20) & 0x7ff, nv = (pk1 >> 10) & 7, p = (pk1 >> 13) & 15, nd_eq = (pk1 >> 17) & 7, tab_len = (pk2 >> 24) & 0xff;
-    const int nds = 21*p;                                     // read-end deletion sums of one read: sizes back to back, at most (q+1)p columns each
+    // Read-end deletion sums of one read: six row slots of 6p entries, entry = distance of the column from the read end.  Size q lives in
+    // slot (nd_base + q) mod 6.  Where the block extends the previous allele's by one repeat unit, the sums of (size q, column) are the
+    // previous allele's (size q-1, column): the base steps back by one, every row is the next size without moving, each gains the p
+    // columns farthest from the end, and the slot of the old largest size becomes the new size 0 — nothing is copied.
+    const int sixp = HS_MAXREP*p, nds = HS_MAXREP*sixp;
     const int ndb = g*nds;
     const double cst = nx_cst;
     const int shapes = nx_shapes, tbase = nx_tbase;
@@ -1472,8 +1476,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     const double2* tab = L.tab0 + par*HS_TAB_CAP;
     const uint16_t* boff = L.boff0 + par*blk_len;
     auto Eat = [&](int col, int bo) -> double { return *(const double*)((const char*)L.E + col*8 + bo); };   // column col against the block base with plane offset bo
-    double* nd = L.nd0 + par*nd_cap;
-    const double* nd_prev = L.nd0 + (par ^ 1)*nd_cap;
+    double* nd = L.nd0;
 
     // --- StutterAlignerClass::load_read (StutterAlignerClass.cpp:12-53): match_probs_ and del_probs_ of this lane's column
     const int t0 = chained ? prev_B : 0;
@@ -1579,7 +1582,8 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       };
       auto row_off = [&](int q){ return p*((q*(q+1)) >> 1); };
       const bool reuse_al = chained && ((oe >> 29) & 1);
-      const int ncopy = row_off(nv - 1);
+      if (reuse_al && rep == 0) nd_base = (nd_base + HS_MAXREP - 1) % HS_MAXREP;
+      auto slot_of = [&](int q){ int sl = nd_base + q; sl -= (sl >= HS_MAXREP) ? HS_MAXREP : 0; return sl*sixp; };     // row of size q
       // Work of the group for this allele.  Usual case (every side of the group holds all six deletion sizes, so all reads count
       // alike): closed-form numbering, size-major so that the sums of a wavefront have (nearly) the same length.  Otherwise lane
       // h < G counts read h's work, a prefix sum over those lanes numbers it back to back and every lane searches the prefix.
@@ -1594,18 +1598,6 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
         const int Gp = G*p;
         const float rc_p = __builtin_amdgcn_rcpf((float)p);        // approximate: udiv corrects by one either way
         if (reuse_al){
-          const float rc_copy = __builtin_amdgcn_rcpf((float)max(ncopy, 1));
-          for (int base = 0; base < ((HS_GABL == 1) ? 0 : G*ncopy); base += NT){
-            const int e = base + xw;
-            if (e < G*ncopy){
-              const int hh = udiv(e, ncopy, rc_copy), idx0 = e - hh*ncopy;
-              int qn = 1;
-#pragma unroll
-              for (int k = 1; k <= 4; k++) qn += (idx0 >= row_off(k)) ? 1 : 0;
-              const int idx = idx0 - row_off(qn - 1);
-              nd[hh*nds + row_off(qn) + p + idx] = nd_prev[hh*nds + row_off(qn - 1) + idx];
-            }
-          }
           const int n_sums = nv*Gp;                                // e = (q G + h) p + off
           const float rc_gp = __builtin_amdgcn_rcpf((float)Gp);
           for (int base = 0; base < ((HS_GABL == 1) ? 0 : n_sums); base += NT){
@@ -1613,7 +1605,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
             const int e = min(base + xw, n_sums - 1);
             const int q = udiv(e, Gp, rc_gp), r = e - q*Gp, hh = udiv(r, p, rc_p), off = r - hh*p;
             const int jcol = (s_n[hh] - (q+1)*p) + off;
-            nd_sum(q, s_off[hh] + jcol, jcol, base + xw < n_sums, hh*nds + row_off(q) + off);
+            nd_sum(q, s_off[hh] + jcol, jcol, base + xw < n_sums, hh*nds + slot_of(q) + ((q+1)*p - 1 - off));
           }
         } else {
           const int n_sums = G*row_off(nv);                        // size q: G reads x (q+1)p columns, sizes back to back from G row_off(q)
@@ -1626,25 +1618,25 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
             const int r = e - G*row_off(q), w = (q+1)*p;
             const int hh = udiv(r, w, __builtin_amdgcn_rcpf((float)w)), off = r - hh*w;
             const int jcol = (s_n[hh] - w) + off;
-            nd_sum(q, s_off[hh] + jcol, jcol, base + xw < n_sums, hh*nds + row_off(q) + off);
+            nd_sum(q, s_off[hh] + jcol, jcol, base + xw < n_sums, hh*nds + slot_of(q) + (w - 1 - off));
           }
         }
       } else {
-      int c_l = 0, cc_l = 0;
+      int c_l = 0;
       {
         const bool ru = reuse_al && (nh_l >= nv*p);
         int np_l = 0;
 #pragma unroll
         for (int q = 0; q < HS_MAXREP; q++) np_l += (B - (q+1)*p >= 0) ? min((q+1)*p, nh_l) : 0;
-        if (lane < G){ c_l = ru ? nv*p : np_l; cc_l = ru ? ncopy : 0; }
+        if (lane < G) c_l = ru ? nv*p : np_l;
       }
-      int pc = c_l, pcc = cc_l;                               // inclusive prefix sums over lanes 0..15
+      int pc = c_l;                                           // inclusive prefix sums over lanes 0..15
 #pragma unroll
       for (int dd = 1; dd < HS_GRP_MAXREADS; dd <<= 1){
-        const int t1 = __shfl_up(pc, dd), t2 = __shfl_up(pcc, dd);
-        if (lane >= dd){ pc += t1; pcc += t2; }
+        const int t1 = __shfl_up(pc, dd);
+        if (lane >= dd) pc += t1;
       }
-      const int n_sums = rdlane(pc, HS_GRP_MAXREADS - 1), n_copies = rdlane(pcc, HS_GRP_MAXREADS - 1);
+      const int n_sums = rdlane(pc, HS_GRP_MAXREADS - 1);
       auto find = [&](int pref, int e, int& hh, int& loc_e){   // read hh holds item e: prefix(hh-1) <= e < prefix(hh)
         hh = 0; loc_e = e;
         for (int h = 0; h + 1 < G; h++){
@@ -1652,17 +1644,6 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
           if (e >= ph){ hh = h + 1; loc_e = e - ph; }
         }
       };
-      for (int base = 0; base < ((HS_GABL == 1) ? 0 : n_copies); base += NT){
-        const int e = base + xw;
-        if (e < n_copies){
-          int hh, idx0; find(pcc, e, hh, idx0);
-          int qn = 1;
-#pragma unroll
-          for (int k = 1; k <= 4; k++) qn += (idx0 >= row_off(k)) ? 1 : 0;
-          const int idx = idx0 - row_off(qn - 1);
-          nd[hh*nds + row_off(qn) + p + idx] = nd_prev[hh*nds + row_off(qn - 1) + idx];
-        }
-      }
       for (int base = 0; base < ((HS_GABL == 1) ? 0 : n_sums); base += NT){
         const int wbase = base + (xw & ~63);
         if (wbase >= n_sums) continue;                        // whole wavefront past the end (wave-uniform)
@@ -1677,7 +1658,6 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
           for (int k = 1; k <= 5; k++) q += (loc_e >= k*p) ? 1 : 0;
           off = loc_e - q*p;
           jcol = (nh - (q+1)*p) + off;
-          dst = row_off(q) + off;
         } else {
           int cnt[HS_MAXREP];
 #pragma unroll
@@ -1685,8 +1665,8 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
 #pragma unroll
           for (int qq = 0; qq < HS_MAXREP - 1; qq++) if (q == qq && off >= cnt[qq]){ off -= cnt[qq]; q = qq + 1; }
           jcol = max(0, nh - (q+1)*p) + off;
-          dst = loc_e;
         }
+        dst = slot_of(q) + (nh - 1 - jcol);
         nd_sum(q, offh + jcol, jcol, valid, hh*nds + dst);
       }
       }
@@ -1742,7 +1722,6 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
           terms[HS_MAXREP + 1 + q] = ins_term(q, li);
         }
       }
-      int ndo = ndb;                                  // first (size q, column) pair of this lane's read: sizes 0..q-1 come first
 #pragma unroll
       for (int q = 0; q < HS_MAXREP; q++){
         const int aD = (q+1)*p;
@@ -1753,12 +1732,12 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
           const bool direct = (j + aD <= n - 1);
           const int xd = xx + min(aD, n - 1 - j);
           const double dsum = L.Mt[xd] - L.Dl[q*L.ld + xd];
-          const double ndv = nd[ndo + min(max(j - (n - cq), 0), cq - 1)];
+          int slq = nd_base + q; slq -= (slq >= HS_MAXREP) ? HS_MAXREP : 0;
+          const double ndv = nd[ndb + slq*sixp + min(n - 1 - j, cq - 1)];
           const double lp0 = direct ? rdlane(cst, 14 + q) + dsum : ndv;
           const double S = tab_eval(lp0, actj ? len : 0, q);
           const double pre = L.rowP[xrp - len];
           terms[HS_MAXREP - 1 - q] = (rdlane(cst, HS_MAXREP - 1 - q) + S) + pre;
-          ndo += cq;
         }
       }
       bool bad = !(lp0_max < tab_bmin);

@@ -169,7 +169,7 @@ struct hs_dev_t {
   double             log_half;     // LOG_ONE_HALF, mathops.cpp:9
   int32_t            n_active;
   int32_t            allele_chunk;   // alleles per workgroup
-  int32_t            grp_nd_cap;     // hs_str_group_kernel: doubles of one read-end deletion table = max over the groups of reads x 21 period
+  int32_t            grp_nd_cap;     // hs_str_group_kernel: doubles of the read-end deletion table = max over the groups of reads x 36 period
   int32_t            lds_len;        // max read length in the batch (LDS carve of the STR kernel)
   int32_t            band_cols;      // max columns of one read side (rows of a band-boundary buffer)
   int32_t            max_B;          // longest STR allele of the batch (LDS carve of the STR kernel)

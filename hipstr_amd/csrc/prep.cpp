@@ -856,7 +856,7 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
             it.active = (int32_t)R.tpack.size();
             R.tpack.insert(R.tpack.end(), bn.members.begin(), bn.members.end());
             R.str.push_back(it);
-            R.nd_cap = std::max(R.nd_cap, it.slot*21*period);
+            R.nd_cap = std::max(R.nd_cap, it.slot*36*period);
           }
         }
         for (int g = 0; g < loc.tg_count[s]; g++){

@@ -59,7 +59,7 @@ struct Prepared {
                                            // allele group for up to 64/npad reads of one locus and side
   std::vector<hs_item_t>  str_items;       // (first entry in tpack, side, columns, number of reads): STR block of the tabulated alleles for a
                                            // group of reads of one locus and side whose columns fill a workgroup (hs_str_group_kernel)
-  int32_t                 grp_nd_cap = 0;  // largest (reads x 21 period) of the str_items
+  int32_t                 grp_nd_cap = 0;  // largest (reads x 36 period) of the str_items
   std::vector<int32_t>    tpack;           // active-read indices of the packed reads
   std::vector<int32_t>    str_order;       // per locus and side: realigned alleles sorted so that nested STR blocks follow each other
   std::vector<hs_tgroup_t> tgroups;
