@@ -178,6 +178,7 @@ __device__ void em_gt_priors(const hs_em_dev_t& d, const hs_em_locus_t& L, int t
     row_lse[x] = rm + log(rs);
   }
   __syncthreads();
+  if (A <= 64 && tid >= 64) return;              // the scans are one lane per allele: the other wavefronts give their slots back (they end here; the barriers below count the rest)
   // The scans are one dependent chain per allele; the values they eat are fetched eight at a time ahead of the chain, or every step
   // would wait out a trip to L2.
 #define EM_SCAN_STEP(lv) do { if ((lv) <= m) t += exp((lv) - m); else { t *= exp(m - (lv)); t += 1.0; m = (lv); } } while (0)
@@ -225,10 +226,11 @@ __device__ void em_gt_priors(const hs_em_dev_t& d, const hs_em_locus_t& L, int t
 template <int PASS>
 __global__ void __launch_bounds__(256) hs_em_mstep_part(const hs_em_dev_t* __restrict__ dp, const double* __restrict__ keep){
   const hs_em_dev_t& d = *dp;
-  const int l = blockIdx.x, k_part = blockIdx.y, tid = threadIdx.x;
+  // PASS 0 has one more slice, the allele-frequency scans: it is the longest-running workgroup of the launch, so it goes first (y = 0)
+  const int l = blockIdx.x, k_part = (PASS == 0) ? (int)blockIdx.y - 1 : (int)blockIdx.y, tid = threadIdx.x;
   if (!d.active[l]) return;
   const hs_em_locus_t L = d.loci[l];
-  if (PASS == 0 && k_part == HS_EM_PARTS){ em_gt_priors(d, L, tid); return; }
+  if (PASS == 0 && k_part < 0){ em_gt_priors(d, L, tid); return; }
   const int A = L.A, nd = A*A;
   const double* post = d.post + L.post_off;
   const double* ll = d.ll + L.ll_off;
@@ -525,7 +527,7 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
     EM_HIP(hipMemcpy(d_logp, logp.data(), logp.size()*sizeof(double), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(hs_em_fill, dim3(nl), dim3(256), 0, T.stream, d_h);
     hipLaunchKernelGGL(hs_posterior_kernel, dim3((unsigned)units.size()), dim3(256), 0, T.stream, (const hs_post_dev_t*)d_ph);
-    hipLaunchKernelGGL(hs_em_mstep_part<0>, dim3(nl, HS_EM_PARTS + 1), dim3(256), 0, T.stream, d_h, (const double*)NULL);     // slice HS_EM_PARTS: the allele-frequency priors
+    hipLaunchKernelGGL(hs_em_mstep_part<0>, dim3(nl, HS_EM_PARTS + 1), dim3(256), 0, T.stream, d_h, (const double*)NULL);     // slice 0: the allele-frequency priors
     hipLaunchKernelGGL(hs_em_mstep_keepmax, dim3(nl), dim3(64), 0, T.stream, d_h, d_keep);
     hipLaunchKernelGGL(hs_em_mstep_part<1>, dim3(nl, HS_EM_PARTS), dim3(256), 0, T.stream, d_h, (const double*)d_keep);
     hipLaunchKernelGGL(hs_em_mstep, dim3(nl), dim3(256), 0, T.stream, d_h, (const double*)d_keep);
