@@ -12,9 +12,10 @@
 //                             allele at a time), with READS as lanes: the flank rows are wave-uniform, a lane carries the
 //                             M/I/D of its own read, the matrix is swept in bands of R rows held in registers.
 //                                                                                          -> rowP, last column, side_prob
-//   hs_str_kernel             STR block (HapAligner.cpp:62-109 + StutterAlignerClass.cpp): one lane per read column, 13
-//   hs_str_kernel_generic     artifact sizes; artifact position marginalised by a tabulated closed form (periodic blocks), a
-//                             closed form evaluated the long way, or a replay of a host-enumerated visiting list. -> MR
+//   hs_str_group_kernel       STR block (HapAligner.cpp:62-109 + StutterAlignerClass.cpp): one lane per read column, 13
+//   hs_str_kernel_generic     artifact sizes; artifact position marginalised by a tabulated closed form (periodic blocks: the group
+//   (hs_str_kernel)           kernel, reads of a locus side packed into one workgroup's lanes), a closed form evaluated the long
+//                             way, or a replay of a host-enumerated visiting list (the generic kernel, a workgroup per read). -> MR
 //   hs_trail_kernel<R>        trailing flank: the same banded sweep with ALLELES as lanes: all alleles of a locus share the
 //                             read and (per group) the flank rows, so a lane needs no neighbour at all.   -> last column
 //   hs_combine_kernel         compute_aln_logprob (HapAligner.cpp:163-231): log-sum-exp over seed positions.
