@@ -365,18 +365,46 @@ __device__ __forceinline__ void coop_barrier(bool drain_stores){
 // the next column's prefetch.
 typedef const __attribute__((address_space(3))) double* hs_lds_cd2;      // (M, D) pairs, read and written as doubles
 typedef __attribute__((address_space(3))) double* hs_lds_d2;
+// The transition logs of the band's rows (m2m, m2i: 4 SGPRs per row, 60 for 15 rows) do not fit the SGPR file next to everything else;
+// left to the compiler they are parked in VGPR lanes and cost two v_readlane_b32 (8 VALU cycles) and a few v_mov per cell.  With
+// HS_COOP_LDS_CONSTS the wavefront keeps them in an LDS table (16 B per row) and reads a row's pair back as one broadcast
+// ds_read_b128, issued two rows ahead of its use: the LDS pipe is idle in this kernel, the VALU is what binds.  The loads are inline
+// assembly (volatile: not hoisted back out of the column loop into registers) with their own s_waitcnt; LDS operations of a wavefront
+// complete in order, so the compiler's own counts for the ring accesses only ever wait longer, never less.
+#ifndef HS_COOP_LDS_CONSTS
+#define HS_COOP_LDS_CONSTS 1
+#endif
+#ifndef HS_COOP_LDS_DEPTH
+#define HS_COOP_LDS_DEPTH 3       // rows between a pair's request and its use (<= 6)
+#endif
+typedef double hs_d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ hs_d2v kload(uint32_t addr, int off){      // off: a constant once the row loop is unrolled
+  hs_d2v q;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q) : "v"(addr), "i"(off) : "memory");
+  return q;
+}
+template <int CNT> __device__ __forceinline__ void kwait(hs_d2v& q){ asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(q) : "n"(CNT)); }
 template <int NR, bool FIRST, bool LAST, bool LEAD>
 __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, bool live, int n, int nmax, const double* __restrict__ col,
                                                 const hs_row_t* __restrict__ rows, int row0, int c0, const double* __restrict__ mr,
                                                 double* __restrict__ bnd, bool topg, bool botg, hs_lds_cd2 lds_top, hs_lds_d2 lds_bot,
                                                 double* __restrict__ lt, double* __restrict__ rowp, double* __restrict__ side_out,
-                                                int skew, int nsteps){
-  int hc[NR]; double m2m[NR], m2i[NR];
+                                                int skew, int nsteps, hs_lds_d2 ktab){
+  constexpr bool KL = HS_COOP_LDS_CONSTS != 0;
+  int hc[NR]; double m2m[KL ? 1 : NR], m2i[KL ? 1 : NR];
+  const uint32_t kaddr = (uint32_t)(uintptr_t)ktab;           // LDS byte address of this wavefront's table
+  if (KL){
+    const int rr = min(lane, NR - 1);
+    const int meta_l = (int)rows[row0 + rr];
+    const double vm = d.m2m[(meta_l >> 8) & 15], vi = d.m2i[(meta_l >> 8) & 15];
+    if (lane < NR){ ktab[2*rr] = vm; ktab[2*rr + 1] = vi; }
+    wave_lds_sync();
+  }
 #pragma unroll
   for (int r = 0; r < NR; r++){
     const int meta = uni((int)rows[row0 + r]);
     hc[r] = meta & 0xff;
-    m2m[r] = uni(d.m2m[(meta >> 8) & 15]); m2i[r] = uni(d.m2i[(meta >> 8) & 15]);
+    if (!KL){ m2m[KL ? 0 : r] = uni(d.m2m[(meta >> 8) & 15]); m2i[KL ? 0 : r] = uni(d.m2i[(meta >> 8) & 15]); }
 #if HS_COOP_VGPR_CONSTS
     // The transition logs of NR rows do not fit the SGPR file next to everything else: the compiler parks them in VGPR lanes and pays
     // two v_readlane_b32 (4 cycles each, profiles/*_valu_microbench.json) per cell to get them back.  Held in VGPRs on purpose they
@@ -427,13 +455,34 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
         }
       } else {
         // as in band_sweep: M and I bottom-up in place, then D top-down through the new M
+        if (KL){
+          // rows NR-1 .. 0; the pair of row r is requested while row r + KD is computed
+          constexpr int KD = HS_COOP_LDS_DEPTH, KM = KD + 1;
+          hs_d2v kq[KM];
+#pragma unroll
+          for (int a = 0; a < KD; a++) if (NR - 1 - a >= 0) kq[(NR - 1 - a) % KM] = kload(kaddr, 16*(NR - 1 - a >= 0 ? NR - 1 - a : 0));
+#pragma unroll
+          for (int r = NR - 1; r >= 0; r--){
+            if (r >= KD){ kq[(r - KD) % KM] = kload(kaddr, 16*(r - KD)); kwait<KD>(kq[r % KM]); }
+            else switch (r){                      // the last rows: r younger requests are outstanding
+              case 0: kwait<0>(kq[r % KM]); break; case 1: kwait<1>(kq[r % KM]); break; case 2: kwait<2>(kq[r % KM]); break;
+              case 3: kwait<3>(kq[r % KM]); break; case 4: kwait<4>(kq[r % KM]); break; default: kwait<5>(kq[r % KM]); break;
+            }
+            const double e = (rdj == hc[r]) ? blcj : blwj;
+            const double dM = (r == 0) ? diagM : Mp[r > 0 ? r-1 : 0], dD = (r == 0) ? diagD : Dp[r > 0 ? r-1 : 0];
+            const double nM = e + fmax(dM + kq[r % KM].x, fmax(Ip[r], dD) + kq[r % KM].y);
+            const double nI = blcj + fmax(dM + T_I2M, Ip[r] + T_I2I);
+            Mp[r] = nM; Ip[r] = nI;
+          }
+        } else {
 #pragma unroll
         for (int r = NR - 1; r >= 0; r--){
           const double e = (rdj == hc[r]) ? blcj : blwj;
           const double dM = (r == 0) ? diagM : Mp[r > 0 ? r-1 : 0], dD = (r == 0) ? diagD : Dp[r > 0 ? r-1 : 0];
-          const double nM = e + fmax(dM + m2m[r], fmax(Ip[r], dD) + m2i[r]);
+          const double nM = e + fmax(dM + m2m[KL ? 0 : r], fmax(Ip[r], dD) + m2i[KL ? 0 : r]);
           const double nI = blcj + fmax(dM + T_I2M, Ip[r] + T_I2I);
           Mp[r] = nM; Ip[r] = nI;
+        }
         }
 #pragma unroll
         for (int r = 0; r < NR; r++){
@@ -459,17 +508,17 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
 template <int NR, bool LEAD>
 __device__ __forceinline__ void band_dispatch_coop(bool first, bool last, const hs_dev_t& d, int lane, bool live, int n, int nmax, const double* col,
                                                    const hs_row_t* rows, int row0, int c0, const double* mr, double* bnd, bool topg, bool botg,
-                                                   hs_lds_cd2 lds_top, hs_lds_d2 lds_bot, double* lt, double* rowp, double* side_out, int skew, int nsteps){
-  if (first){ if (last) band_sweep_coop<NR, true, true, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps);
-              else      band_sweep_coop<NR, true, false, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps); }
-  else      { if (last) band_sweep_coop<NR, false, true, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps);
-              else      band_sweep_coop<NR, false, false, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps); }
+                                                   hs_lds_cd2 lds_top, hs_lds_d2 lds_bot, double* lt, double* rowp, double* side_out, int skew, int nsteps, hs_lds_d2 ktab){
+  if (first){ if (last) band_sweep_coop<NR, true, true, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps, ktab);
+              else      band_sweep_coop<NR, true, false, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps, ktab); }
+  else      { if (last) band_sweep_coop<NR, false, true, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps, ktab);
+              else      band_sweep_coop<NR, false, false, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps, ktab); }
 }
 
 // The rounds of one item: `n_rows` haplotype rows (after the block's first row) cut into bands, HS_COOP_WAVES bands per round, one per wavefront.
 template <int R, bool LEAD>
 __device__ __forceinline__ void coop_rounds(const hs_dev_t& d, int w, int lane, bool live, int n, int nmax, const double* col, const hs_row_t* rows, int n_rows, int c0,
-                                            const double* mr, double* bnd, double2 (*ring)[2*64], double* lt, double* rowp, double* side_out){
+                                            const double* mr, double* bnd, double2 (*ring)[2*64], double* lt, double* rowp, double* side_out, double2 (*ktabs)[24]){
   // as many bands as there are wavefronts whenever the rows allow it (all wavefronts busy), more rounds only for blocks deeper than one round holds
   const int rounds = (n_rows + R*HS_COOP_WAVES - 1) / (R*HS_COOP_WAVES);
   const int nbands = min(n_rows, rounds*HS_COOP_WAVES);
@@ -484,8 +533,9 @@ __device__ __forceinline__ void coop_rounds(const hs_dev_t& d, int w, int lane, 
       const bool first = (b == 0), last = (b + 1 == nbands);
       const bool topg = (w == 0) && (g > 0), botg = (w + 1 == nb_round) && !last;
       hs_lds_cd2 lds_top = (hs_lds_cd2)ring[w > 0 ? w - 1 : 0]; hs_lds_d2 lds_bot = (hs_lds_d2)ring[w];
+      hs_lds_d2 ktab = (hs_lds_d2)ktabs[w];
       switch (nr){
-#define HS_COOP_CASE(N_) case N_: if (N_ <= R) band_dispatch_coop<(N_ <= R ? N_ : 1), LEAD>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, nsteps); break;
+#define HS_COOP_CASE(N_) case N_: if (N_ <= R) band_dispatch_coop<(N_ <= R ? N_ : 1), LEAD>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, nsteps, ktab); break;
         HS_COOP_CASE(1) HS_COOP_CASE(2) HS_COOP_CASE(3) HS_COOP_CASE(4) HS_COOP_CASE(5) HS_COOP_CASE(6) HS_COOP_CASE(7) HS_COOP_CASE(8)
         HS_COOP_CASE(9) HS_COOP_CASE(10) HS_COOP_CASE(11) HS_COOP_CASE(12) HS_COOP_CASE(13) HS_COOP_CASE(14) HS_COOP_CASE(15) HS_COOP_CASE(16)
         HS_COOP_CASE(17) HS_COOP_CASE(18) HS_COOP_CASE(19) HS_COOP_CASE(20)
@@ -501,6 +551,7 @@ __global__ void __launch_bounds__(64*HS_COOP_WAVES, HS_COOP_OCC) hs_trail_kernel
   const hs_dev_t& d = *dp;
   const int lane = threadIdx.x & 63, w = uni((int)(threadIdx.x >> 6));
   __shared__ double2 ring[HS_COOP_WAVES][2*64];
+  __shared__ double2 ktabs[HS_COOP_WAVES][24];          // per wavefront: (m2m, m2i) of its band's rows (HS_COOP_LDS_CONSTS)
   __shared__ int s_item;
   double* const bnd = d.ws_band + (size_t)blockIdx.x * d.band_cols * 64 * 2;
   int32_t* const ctr = d.redo + d.n_active + chunk;
@@ -543,7 +594,7 @@ __global__ void __launch_bounds__(64*HS_COOP_WAVES, HS_COOP_OCC) hs_trail_kernel
       }
       continue;
     }
-    coop_rounds<R, false>(d, w, lane, live, n, nmax, col, rows, rs_len - 1, c0, mr, bnd, ring, lt, NULL, NULL);
+    coop_rounds<R, false>(d, w, lane, live, n, nmax, col, rows, rs_len - 1, c0, mr, bnd, ring, lt, NULL, NULL, ktabs);
   }
 }
 
@@ -552,6 +603,7 @@ __global__ void __launch_bounds__(64*HS_COOP_WAVES, HS_COOP_OCC) hs_lead_kernel_
   const hs_dev_t& d = *dp;
   const int lane = threadIdx.x & 63, w = uni((int)(threadIdx.x >> 6));
   __shared__ double2 ring[HS_COOP_WAVES][2*64];
+  __shared__ double2 ktabs[HS_COOP_WAVES][24];          // per wavefront: (m2m, m2i) of its band's rows (HS_COOP_LDS_CONSTS)
   __shared__ int s_item;
   double* const bnd = d.ws_band + (size_t)blockIdx.x * d.band_cols * 64 * 2;
   int32_t* const ctr = d.redo + d.n_active + chunk;
@@ -593,7 +645,7 @@ __global__ void __launch_bounds__(64*HS_COOP_WAVES, HS_COOP_OCC) hs_lead_kernel_
       }
       continue;
     }
-    coop_rounds<R, true>(d, w, lane, live, n, nmax, col, rows, rs_len - 1, c0, NULL, bnd, ring, lastcol, rec, side_out);
+    coop_rounds<R, true>(d, w, lane, live, n, nmax, col, rows, rs_len - 1, c0, NULL, bnd, ring, lastcol, rec, side_out, ktabs);
   }
 }
 
