@@ -374,6 +374,9 @@ typedef __attribute__((address_space(3))) double* hs_lds_d2;
 #ifndef HS_COOP_LDS_CONSTS
 #define HS_COOP_LDS_CONSTS 1
 #endif
+#ifndef HS_COOP_LDS_EMIT
+#define HS_COOP_LDS_EMIT 1        // trailing flank: emissions from a per-column LDS table instead of a compare and two selects per cell
+#endif
 #ifndef HS_COOP_LDS_DEPTH
 #define HS_COOP_LDS_DEPTH 3       // rows between a pair's request and its use (<= 6)
 #endif
@@ -384,12 +387,25 @@ __device__ __forceinline__ hs_d2v kload(uint32_t addr, int off){      // off: a 
   return q;
 }
 template <int CNT> __device__ __forceinline__ void kwait(hs_d2v& q){ asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(q) : "n"(CNT)); }
-template <int NR, bool FIRST, bool LAST, bool LEAD>
+// Trailing flank, emission of a cell: (read base == haplotype base) ? log P(correct) : log P(error) is one of a handful of numbers per
+// column and read — per read five of them, for A, C, G, T, N.  With EL the lanes of a read write them to a small LDS table once per
+// column (one column ahead, from the prefetched column values) and a cell reads its own with one ds_read_b64 at
+// [the lane's read][the row's base code]: a v_add_u32 for the address instead of v_cmp + 2 v_cndmask (2 instead of 12 VALU cycles).
+// Needs >= 8 lanes per read (allele groups of 8 and more) and rows made of A, C, G, T, N; otherwise the select stays.
+__device__ __forceinline__ double eload(uint32_t addr){
+  double e;
+  asm volatile("ds_read_b64 %0, %1" : "=v"(e) : "v"(addr) : "memory");
+  return e;
+}
+template <int CNT> __device__ __forceinline__ void ewait(double& e, hs_d2v& q){ asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(e), "+v"(q) : "n"(CNT)); }
+template <int CNT> __device__ __forceinline__ void ewait1(double& e){ asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(e) : "n"(CNT)); }
+template <int NR, bool FIRST, bool LAST, bool LEAD, bool EL>
 __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, bool live, int n, int nmax, const double* __restrict__ col,
                                                 const hs_row_t* __restrict__ rows, int row0, int c0, const double* __restrict__ mr,
                                                 double* __restrict__ bnd, bool topg, bool botg, hs_lds_cd2 lds_top, hs_lds_d2 lds_bot,
                                                 double* __restrict__ lt, double* __restrict__ rowp, double* __restrict__ side_out,
-                                                int skew, int nsteps, hs_lds_d2 ktab){
+                                                int skew, int nsteps, hs_lds_d2 ktab, hs_lds_d2 etab, int npad){
+  static_assert(!EL || (HS_COOP_LDS_CONSTS != 0 && !LEAD), "the emission table rides on the constants' request pipeline");
   constexpr bool KL = HS_COOP_LDS_CONSTS != 0;
   int hc[NR]; double m2m[KL ? 1 : NR], m2i[KL ? 1 : NR];
   const uint32_t kaddr = (uint32_t)(uintptr_t)ktab;           // LDS byte address of this wavefront's table
@@ -403,7 +419,7 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
 #pragma unroll
   for (int r = 0; r < NR; r++){
     const int meta = uni((int)rows[row0 + r]);
-    hc[r] = meta & 0xff;
+    hc[r] = EL ? (((meta & 0xff) >> 1) & 7) << 3 : (meta & 0xff);      // EL: byte offset of the base's entry in a read's eight-entry row
     if (!KL){ m2m[KL ? 0 : r] = uni(d.m2m[(meta >> 8) & 15]); m2i[KL ? 0 : r] = uni(d.m2i[(meta >> 8) & 15]); }
 #if HS_COOP_VGPR_CONSTS
     // The transition logs of NR rows do not fit the SGPR file next to everything else: the compiler parks them in VGPR lanes and pays
@@ -416,6 +432,14 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
   double Mp[NR], Dp[NR], Ip[NR];
   double nx_blc = col[0], nx_blw = col[1], nx_rd = col[2];
   double nx_mr = 0.0;
+  // EL: table of two column parities x (64 / npad reads) x 8 entries; lane `slot` < 8 of a read writes the entry of base code `slot`
+  const int e_sub = EL ? lane / npad : 0, e_slot = EL ? lane - e_sub*npad : 0;
+  const int e_char = (e_slot == 0) ? 'A' : (e_slot == 1) ? 'C' : (e_slot == 2) ? 'T' : (e_slot == 3) ? 'G' : (e_slot == 7) ? 'N' : -1;
+  const uint32_t e_rd = EL ? (uint32_t)(uintptr_t)etab + 64u*(uint32_t)e_sub : 0;            // + parity * 512 + row's code offset
+  auto e_write = [&](int par, double rdv, double blc, double blw){
+    if (e_slot < 8) etab[par*64 + e_sub*8 + e_slot] = ((int)rdv == e_char) ? blc : blw;
+  };
+  if (EL){ e_write(0, nx_rd, nx_blc, nx_blw); wave_lds_sync(); }
   double diagM = 0, diagD = 0;
   double pre = 0.0;                              // LEAD: left_prob, a strictly sequential sum in the reference
   for (int t = 0; t < nsteps; t++){
@@ -448,7 +472,9 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
       if (j == 0){
 #pragma unroll
         for (int r = 0; r < NR; r++){           // first read column (HapAligner.cpp:123-126)
-          const double e = (rdj == hc[r]) ? blcj : blwj;
+          double e;
+          if (EL){ e = eload(e_rd + (uint32_t)hc[r]); ewait1<0>(e); }      // column 0: parity 0
+          else e = (rdj == hc[r]) ? blcj : blwj;
           const double nD = fmax(upM + T_D2M, upD + T_D2D);
           Mp[r] = e; Ip[r] = blcj; Dp[r] = nD;
           upM = e; upD = nD;
@@ -456,19 +482,34 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
       } else {
         // as in band_sweep: M and I bottom-up in place, then D top-down through the new M
         if (KL){
-          // rows NR-1 .. 0; the pair of row r is requested while row r + KD is computed
-          constexpr int KD = HS_COOP_LDS_DEPTH, KM = KD + 1;
-          hs_d2v kq[KM];
+          // rows NR-1 .. 0; the pair of row r (and, EL, its emission) is requested while row r + KD is computed
+          constexpr int KD = HS_COOP_LDS_DEPTH, KM = KD + 1, PER = EL ? 2 : 1;       // PER: requests per row
+          hs_d2v kq[KM]; double eq[EL ? KM : 1];
+          const uint32_t e_col = EL ? e_rd + 512u*(uint32_t)(j & 1) : 0;
 #pragma unroll
-          for (int a = 0; a < KD; a++) if (NR - 1 - a >= 0) kq[(NR - 1 - a) % KM] = kload(kaddr, 16*(NR - 1 - a >= 0 ? NR - 1 - a : 0));
+          for (int a = 0; a < KD; a++) if (NR - 1 - a >= 0){
+            const int r = NR - 1 - a >= 0 ? NR - 1 - a : 0;
+            kq[r % KM] = kload(kaddr, 16*r);
+            if (EL) eq[EL ? r % KM : 0] = eload(e_col + (uint32_t)hc[r]);
+          }
 #pragma unroll
           for (int r = NR - 1; r >= 0; r--){
-            if (r >= KD){ kq[(r - KD) % KM] = kload(kaddr, 16*(r - KD)); kwait<KD>(kq[r % KM]); }
-            else switch (r){                      // the last rows: r younger requests are outstanding
-              case 0: kwait<0>(kq[r % KM]); break; case 1: kwait<1>(kq[r % KM]); break; case 2: kwait<2>(kq[r % KM]); break;
-              case 3: kwait<3>(kq[r % KM]); break; case 4: kwait<4>(kq[r % KM]); break; default: kwait<5>(kq[r % KM]); break;
+            if (r >= KD){
+              kq[(r - KD) % KM] = kload(kaddr, 16*(r - KD));
+              if (EL) eq[EL ? (r - KD) % KM : 0] = eload(e_col + (uint32_t)hc[r - KD]);
             }
-            const double e = (rdj == hc[r]) ? blcj : blwj;
+            const int young = (r >= KD ? KD : r) * PER;             // requests issued after this row's
+            if (EL) switch (young){
+              case 0: ewait<0>(eq[EL ? r % KM : 0], kq[r % KM]); break; case 2: ewait<2>(eq[EL ? r % KM : 0], kq[r % KM]); break;
+              case 4: ewait<4>(eq[EL ? r % KM : 0], kq[r % KM]); break; case 6: ewait<6>(eq[EL ? r % KM : 0], kq[r % KM]); break;
+              case 8: ewait<8>(eq[EL ? r % KM : 0], kq[r % KM]); break; case 10: ewait<10>(eq[EL ? r % KM : 0], kq[r % KM]); break;
+              default: ewait<12>(eq[EL ? r % KM : 0], kq[r % KM]); break;
+            } else switch (young){
+              case 0: kwait<0>(kq[r % KM]); break; case 1: kwait<1>(kq[r % KM]); break; case 2: kwait<2>(kq[r % KM]); break;
+              case 3: kwait<3>(kq[r % KM]); break; case 4: kwait<4>(kq[r % KM]); break; case 5: kwait<5>(kq[r % KM]); break;
+              default: kwait<6>(kq[r % KM]); break;
+            }
+            const double e = EL ? eq[EL ? r % KM : 0] : ((rdj == hc[r]) ? blcj : blwj);
             const double dM = (r == 0) ? diagM : Mp[r > 0 ? r-1 : 0], dD = (r == 0) ? diagD : Dp[r > 0 ? r-1 : 0];
             const double nM = e + fmax(dM + kq[r % KM].x, fmax(Ip[r], dD) + kq[r % KM].y);
             const double nI = blcj + fmax(dM + T_I2M, Ip[r] + T_I2I);
@@ -495,6 +536,7 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
         if (botg) *(double2*)(bnd + ((size_t)j*64 + lane)*2) = make_double2(upM, upD);
         else { const int e = 2*((j & 1)*64 + lane); lds_bot[e] = upM; lds_bot[e + 1] = upD; }
       } else if (LEAD){ if (j < n && live) rowp[j] = upM; }
+      if (EL) e_write((j + 1) & 1, nx_rd, nx_blc, nx_blw);       // the next column's emissions (its values were requested at the top of this one)
       diagM = topM; diagD = topD;                // top boundary of this column = diagonal of the band's first row next column
       if (j == n-1 && live){
 #pragma unroll
@@ -505,20 +547,21 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
   }
 }
 
-template <int NR, bool LEAD>
+template <int NR, bool LEAD, bool EL>
 __device__ __forceinline__ void band_dispatch_coop(bool first, bool last, const hs_dev_t& d, int lane, bool live, int n, int nmax, const double* col,
                                                    const hs_row_t* rows, int row0, int c0, const double* mr, double* bnd, bool topg, bool botg,
-                                                   hs_lds_cd2 lds_top, hs_lds_d2 lds_bot, double* lt, double* rowp, double* side_out, int skew, int nsteps, hs_lds_d2 ktab){
-  if (first){ if (last) band_sweep_coop<NR, true, true, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps, ktab);
-              else      band_sweep_coop<NR, true, false, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps, ktab); }
-  else      { if (last) band_sweep_coop<NR, false, true, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps, ktab);
-              else      band_sweep_coop<NR, false, false, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps, ktab); }
+                                                   hs_lds_cd2 lds_top, hs_lds_d2 lds_bot, double* lt, double* rowp, double* side_out, int skew, int nsteps, hs_lds_d2 ktab,
+                                                   hs_lds_d2 etab, int npad){
+  if (first){ if (last) band_sweep_coop<NR, true, true, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps, ktab, etab, npad);
+              else      band_sweep_coop<NR, true, false, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps, ktab, etab, npad); }
+  else      { if (last) band_sweep_coop<NR, false, true, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps, ktab, etab, npad);
+              else      band_sweep_coop<NR, false, false, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps, ktab, etab, npad); }
 }
 
 // The rounds of one item: `n_rows` haplotype rows (after the block's first row) cut into bands, HS_COOP_WAVES bands per round, one per wavefront.
-template <int R, bool LEAD>
+template <int R, bool LEAD, bool EL = false>
 __device__ __forceinline__ void coop_rounds(const hs_dev_t& d, int w, int lane, bool live, int n, int nmax, const double* col, const hs_row_t* rows, int n_rows, int c0,
-                                            const double* mr, double* bnd, double2 (*ring)[2*64], double* lt, double* rowp, double* side_out, double2 (*ktabs)[24]){
+                                            const double* mr, double* bnd, double2 (*ring)[2*64], double* lt, double* rowp, double* side_out, double2 (*ktabs)[24], double (*etabs)[128] = NULL, int npad = 64){
   // as many bands as there are wavefronts whenever the rows allow it (all wavefronts busy), more rounds only for blocks deeper than one round holds
   const int rounds = (n_rows + R*HS_COOP_WAVES - 1) / (R*HS_COOP_WAVES);
   const int nbands = min(n_rows, rounds*HS_COOP_WAVES);
@@ -534,8 +577,9 @@ __device__ __forceinline__ void coop_rounds(const hs_dev_t& d, int w, int lane, 
       const bool topg = (w == 0) && (g > 0), botg = (w + 1 == nb_round) && !last;
       hs_lds_cd2 lds_top = (hs_lds_cd2)ring[w > 0 ? w - 1 : 0]; hs_lds_d2 lds_bot = (hs_lds_d2)ring[w];
       hs_lds_d2 ktab = (hs_lds_d2)ktabs[w];
+      hs_lds_d2 etab = EL ? (hs_lds_d2)etabs[w] : (hs_lds_d2)ktabs[w];
       switch (nr){
-#define HS_COOP_CASE(N_) case N_: if (N_ <= R) band_dispatch_coop<(N_ <= R ? N_ : 1), LEAD>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, nsteps, ktab); break;
+#define HS_COOP_CASE(N_) case N_: if (N_ <= R) band_dispatch_coop<(N_ <= R ? N_ : 1), LEAD, EL>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, nsteps, ktab, etab, npad); break;
         HS_COOP_CASE(1) HS_COOP_CASE(2) HS_COOP_CASE(3) HS_COOP_CASE(4) HS_COOP_CASE(5) HS_COOP_CASE(6) HS_COOP_CASE(7) HS_COOP_CASE(8)
         HS_COOP_CASE(9) HS_COOP_CASE(10) HS_COOP_CASE(11) HS_COOP_CASE(12) HS_COOP_CASE(13) HS_COOP_CASE(14) HS_COOP_CASE(15) HS_COOP_CASE(16)
         HS_COOP_CASE(17) HS_COOP_CASE(18) HS_COOP_CASE(19) HS_COOP_CASE(20)
@@ -552,6 +596,7 @@ __global__ void __launch_bounds__(64*HS_COOP_WAVES, HS_COOP_OCC) hs_trail_kernel
   const int lane = threadIdx.x & 63, w = uni((int)(threadIdx.x >> 6));
   __shared__ double2 ring[HS_COOP_WAVES][2*64];
   __shared__ double2 ktabs[HS_COOP_WAVES][24];          // per wavefront: (m2m, m2i) of its band's rows (HS_COOP_LDS_CONSTS)
+  __shared__ double etabs[HS_COOP_WAVES][128];          // per wavefront: emissions of the current and the next column per (read, base code)
   __shared__ int s_item;
   double* const bnd = d.ws_band + (size_t)blockIdx.x * d.band_cols * 64 * 2;
   int32_t* const ctr = d.redo + d.n_active + chunk;
@@ -594,6 +639,15 @@ __global__ void __launch_bounds__(64*HS_COOP_WAVES, HS_COOP_OCC) hs_trail_kernel
       }
       continue;
     }
+    // emissions through the LDS table: 8 lanes per read to write a column's entries, and rows of A, C, G, T, N only
+    bool el_ok = (HS_COOP_LDS_EMIT != 0) && (npad >= 8);
+    if (el_ok){
+      bool bad = false;
+      for (int q = lane; q < rs_len; q += 64){ const int ch = (int)rows[q] & 0xff; bad |= !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == 'N'); }
+      el_ok = !__any(bad);
+    }
+    if (el_ok) coop_rounds<R, false, true>(d, w, lane, live, n, nmax, col, rows, rs_len - 1, c0, mr, bnd, ring, lt, NULL, NULL, ktabs, etabs, npad);
+    else
     coop_rounds<R, false>(d, w, lane, live, n, nmax, col, rows, rs_len - 1, c0, mr, bnd, ring, lt, NULL, NULL, ktabs);
   }
 }
