@@ -53,13 +53,23 @@ __device__ __forceinline__ void wave_lds_sync(){
 __device__ __forceinline__ int wave_min_i(int v){ HS_DPP_RED(min) }
 __device__ __forceinline__ int wave_max_i(int v){ HS_DPP_RED(max) }
 #undef HS_DPP_RED
+// The same for doubles: two DPP moves and one FP64 operation per step.  The sum is used for log-sum-exp totals only: every term is a
+// float (2^-10 <= term <= 1, LOG_THRESH = ln 0.001) converted to double, so any order of additions is exact and gives the same bits.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_d(double v, double old){
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_max_d(double v){
-  for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
-  return v;
+  v = fmax(v, dpp_d<0x111, 0xf>(v, v)); v = fmax(v, dpp_d<0x112, 0xf>(v, v)); v = fmax(v, dpp_d<0x114, 0xf>(v, v)); v = fmax(v, dpp_d<0x118, 0xf>(v, v));
+  v = fmax(v, dpp_d<0x142, 0xa>(v, v)); v = fmax(v, dpp_d<0x143, 0xc>(v, v));
+  return rdlane(v, 63);
 }
 __device__ __forceinline__ double wave_sum_d(double v){
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-  return v;
+  v += dpp_d<0x111, 0xf>(v, 0.0); v += dpp_d<0x112, 0xf>(v, 0.0); v += dpp_d<0x114, 0xf>(v, 0.0); v += dpp_d<0x118, 0xf>(v, 0.0);   // lane 15 of a row: the row
+  v += dpp_d<0x142, 0xa>(v, 0.0);                    // rows 1 and 3 take lane 15 of the row before
+  v += dpp_d<0x143, 0xc>(v, 0.0);                    // rows 2 and 3 take lane 31: lane 63 holds the wavefront
+  return rdlane(v, 63);
 }
 
 // ------------------------------------------------------------------ float approximations (bit-exact)
