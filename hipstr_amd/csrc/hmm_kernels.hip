@@ -1803,7 +1803,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
         const int D = (q+1)*p;
         const int len = min(B + D, j + 1);
         const double lp0 = (rdlane(cst, 13) + li) + ((len > D) ? L.Mt[xx - min(D, j)] : 0.0);
-        const int lim = actj ? min(max(0, len - D), B) : 0;
+        const int lim = min(max(0, len - D), B);            // a lane past the group's last column repeats it: its bound is a real one
         const double S = tab_eval(lp0, lim, HS_MAXREP);
         const double pre = L.rowP[xrp - len];
         return (rdlane(cst, HS_MAXREP + 1 + q) + S) + pre;
@@ -1842,7 +1842,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
           int slq = nd_base + q; slq -= (slq >= HS_MAXREP) ? HS_MAXREP : 0;
           const double ndv = nd[ndb + slq*sixp + min(n - 1 - j, cq - 1)];
           const double lp0 = direct ? rdlane(cst, 14 + q) + dsum : ndv;
-          const double S = tab_eval(lp0, actj ? len : 0, q);
+          const double S = tab_eval(lp0, len, q);
           const double pre = L.rowP[xrp - len];
           terms[HS_MAXREP - 1 - q] = (rdlane(cst, HS_MAXREP - 1 - q) + S) + pre;
         }
