@@ -529,6 +529,7 @@ def load_hmm():
     _sig(lib.hipstr_hmm_workload, C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
     _sig(lib.hipstr_debug_rows, C.c_int, [_BP, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_int])
     _sig(lib.hipstr_debug_prepare, C.c_int, [_BP, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)])
+    _sig(lib.hipstr_debug_str_groups, C.c_int, [_BP, _i32p, _i32p, _i32p, C.c_int, _i32p, C.c_int, _i32p])
     _sig(lib.hipstr_debug_simple_table, C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)])
     _sig(lib.hipstr_last_error, C.c_char_p, [])
     return lib

@@ -705,6 +705,26 @@ int hipstr_debug_prepare(const hipstr_batch_t* batch, int threads, double* secon
   return 0;
 }
 
+int hipstr_debug_str_groups(const hipstr_batch_t* batch, int32_t* side, int32_t* columns, int32_t* read_off, int cap_groups,
+                            int32_t* reads, int cap_reads, int32_t* max_columns){
+  if (!batch || !side || !columns || !read_off || !reads) return -1;
+  hipstr::Prepared P; std::string err;
+  if (hipstr::prepare_batch(batch, P, err)){ g_err = err; return -1; }
+  if (max_columns) *max_columns = HS_GRP_COLS;
+  const int ng = (int)P.str_items.size();
+  if (ng > cap_groups) return -1;
+  int nr = 0;
+  read_off[0] = 0;
+  for (int g = 0; g < ng; g++){
+    const hs_item_t& it = P.str_items[g];
+    side[g] = it.side; columns[g] = it.rowset;
+    if (nr + it.slot > cap_reads) return -1;
+    for (int k = 0; k < it.slot; k++) reads[nr++] = P.active[P.tpack[it.active + k]];
+    read_off[g + 1] = nr;
+  }
+  return ng;
+}
+
 int hipstr_debug_simple_table(int bound, int U0, int tail, double entry[3]){
   if (!entry || bound < 0 || U0 < 0 || tail < 0 || tail >= 10000 || U0 >= 10000) return fail("bad argument");
   hipstr::debug_simple_table(bound, U0, tail, entry);

@@ -446,6 +446,13 @@ int hipstr_debug_rows(const hipstr_batch_t* batch, int k, int side, int which, u
  * must not depend on the thread count.  Used by tests/test_prep.py and bench.py. */
 int hipstr_debug_prepare(const hipstr_batch_t* batch, int threads, double* seconds, uint64_t* digest);
 
+/* Diagnostics (host only): the STR-block groups of the launch plan — reads of one locus and side whose columns are laid end to end over
+ * one workgroup's lanes (hs_str_group_kernel).  Group g: side[g], reads[read_off[g] .. read_off[g+1]) (read indices of the batch),
+ * columns[g] = the sum of their side lengths.  Returns the number of groups (-1 on error or if a capacity is too small); *max_columns =
+ * lanes of a workgroup.  Used by tests/test_prep.py. */
+int hipstr_debug_str_groups(const hipstr_batch_t* batch, int32_t* side, int32_t* columns, int32_t* read_off, int cap_groups,
+                            int32_t* reads, int cap_reads, int32_t* max_columns);
+
 /* Diagnostics (host only): one entry {A, G, Bnd} of the tabulated closed form the STR kernel uses for a "simple" visiting
  * list (StutterAlignerClass.cpp:59-150 for a periodic block): with `bound` columns of the block in reach, a run of U0 equal
  * configurations at the block's right end and `tail` configurations in total, fast_log_sum_exp over the pushed values is

@@ -157,3 +157,40 @@ def test_host_preparation_does_not_depend_on_thread_count(hmm_host):
             assert hmm_host.hipstr_debug_prepare(sb.ptr, threads, C.byref(sec), C.byref(dig)) == 0
             digests.add(dig.value)
         assert len(digests) == 1, kw
+
+
+def test_str_groups_cover_every_read_side_once(hmm_host):
+    """The launch plan packs the read sides of a locus into groups whose columns fill one workgroup (hs_str_group_kernel): every seeded
+    read appears once per side that has columns, a group stays within the workgroup's lanes, within one locus, and is not empty."""
+    import ctypes as C
+    for kw in (dict(n_loci=6, reads_per_locus=57, n_str_alleles=9, seed=11),
+               dict(n_loci=3, reads_per_locus=200, n_str_alleles=32, read_len=250, flank_len=110, str_bp=60, seed=12),
+               dict(n_loci=9, reads_per_locus=30, n_str_alleles=5, read_len=60, flank_len=25, str_bp=20, seed=13, mask_rate=0.2)):
+        sb = capi.SynthBatch(**kw)
+        b = sb.ptr.contents
+        seeds = np.zeros(sb.n_reads, np.int32)
+        hmm_host.hipstr_calc_seed_bases(sb.ptr, seeds.ctypes.data_as(capi._i32p))
+        lens = np.diff(np.ctypeslib.as_array(b.base_off, shape=(sb.n_reads + 1,)))
+        read_off_l = np.ctypeslib.as_array(b.read_off, shape=(sb.n_loci + 1,))
+        locus_of = np.searchsorted(read_off_l, np.arange(sb.n_reads), side="right") - 1
+        cap_g, cap_r = 4 * sb.n_reads + 8, 4 * sb.n_reads + 8
+        side = np.zeros(cap_g, np.int32); cols = np.zeros(cap_g, np.int32); roff = np.zeros(cap_g + 1, np.int32); reads = np.zeros(cap_r, np.int32)
+        mx = C.c_int32()
+        ng = hmm_host.hipstr_debug_str_groups(sb.ptr, side.ctypes.data_as(capi._i32p), cols.ctypes.data_as(capi._i32p), roff.ctypes.data_as(capi._i32p),
+                                              cap_g, reads.ctypes.data_as(capi._i32p), cap_r, C.byref(mx))
+        assert ng > 0 and mx.value >= 128
+        seen = {}
+        for g in range(ng):
+            rs = reads[roff[g]:roff[g + 1]]
+            assert 1 <= len(rs) <= 16 and len(set(locus_of[rs])) == 1
+            n = [int(seeds[r]) if side[g] == 0 else int(lens[r] - seeds[r] - 1) for r in rs]
+            assert all(x > 0 for x in n) and sum(n) == cols[g] <= mx.value
+            for r in rs:
+                assert (int(r), int(side[g])) not in seen
+                seen[(int(r), int(side[g]))] = g
+        realign = np.ctypeslib.as_array(b.realign_read, shape=(sb.n_reads,)) if b.realign_read else np.ones(sb.n_reads, np.uint8)
+        for r in range(sb.n_reads):
+            if seeds[r] < 0 or not realign[r]:
+                continue
+            for sd, n in ((0, int(seeds[r])), (1, int(lens[r] - seeds[r] - 1))):
+                assert ((r, sd) in seen) == (n > 0), (r, sd, n)
