@@ -559,17 +559,17 @@ __device__ __forceinline__ void band_dispatch_coop(bool first, bool last, const 
 }
 
 // The rounds of one item: `n_rows` haplotype rows (after the block's first row) cut into bands, HS_COOP_WAVES bands per round, one per wavefront.
-template <int R, bool LEAD, bool EL = false>
+template <int R, int W, bool LEAD, bool EL = false>
 __device__ __forceinline__ void coop_rounds(const hs_dev_t& d, int w, int lane, bool live, int n, int nmax, const double* col, const hs_row_t* rows, int n_rows, int c0,
                                             const double* mr, double* bnd, double2 (*ring)[2*64], double* lt, double* rowp, double* side_out, double2 (*ktabs)[24], double (*etabs)[128] = NULL, int npad = 64){
   // as many bands as there are wavefronts whenever the rows allow it (all wavefronts busy), more rounds only for blocks deeper than one round holds
-  const int rounds = (n_rows + R*HS_COOP_WAVES - 1) / (R*HS_COOP_WAVES);
-  const int nbands = min(n_rows, rounds*HS_COOP_WAVES);
+  const int rounds = (n_rows + R*W - 1) / (R*W);
+  const int nbands = min(n_rows, rounds*W);
   const int nr_base = n_rows / nbands, nr_rem = n_rows - nr_base*nbands;
   for (int g = 0; g < rounds; g++){
-    const int nb_round = min(HS_COOP_WAVES, nbands - g*HS_COOP_WAVES);
+    const int nb_round = min(W, nbands - g*W);
     const int nsteps = nmax + nb_round - 1;
-    const int b = g*HS_COOP_WAVES + w;
+    const int b = g*W + w;
     if (w < nb_round){
       const int nr = nr_base + (b < nr_rem ? 1 : 0);
       const int row0 = 1 + b*nr_base + min(b, nr_rem);
@@ -590,13 +590,13 @@ __device__ __forceinline__ void coop_rounds(const hs_dev_t& d, int w, int lane, 
   }
 }
 
-template <int R>
-__global__ void __launch_bounds__(64*HS_COOP_WAVES, HS_COOP_OCC) hs_trail_kernel_coop(const hs_dev_t* __restrict__ dp, int item_begin, int item_end, int chunk){
+template <int R, int W, int OCC>
+__global__ void __launch_bounds__(64*W, OCC) hs_trail_kernel_coop(const hs_dev_t* __restrict__ dp, int item_begin, int item_end, int chunk){
   const hs_dev_t& d = *dp;
   const int lane = threadIdx.x & 63, w = uni((int)(threadIdx.x >> 6));
-  __shared__ double2 ring[HS_COOP_WAVES][2*64];
-  __shared__ double2 ktabs[HS_COOP_WAVES][24];          // per wavefront: (m2m, m2i) of its band's rows (HS_COOP_LDS_CONSTS)
-  __shared__ double etabs[HS_COOP_WAVES][128];          // per wavefront: emissions of the current and the next column per (read, base code)
+  __shared__ double2 ring[W][2*64];
+  __shared__ double2 ktabs[W][24];          // per wavefront: (m2m, m2i) of its band's rows (HS_COOP_LDS_CONSTS)
+  __shared__ double etabs[W][128];          // per wavefront: emissions of the current and the next column per (read, base code)
   __shared__ int s_item;
   double* const bnd = d.ws_band + (size_t)blockIdx.x * d.band_cols * 64 * 2;
   int32_t* const ctr = d.redo + d.n_active + chunk;
@@ -646,18 +646,18 @@ __global__ void __launch_bounds__(64*HS_COOP_WAVES, HS_COOP_OCC) hs_trail_kernel
       for (int q = lane; q < rs_len; q += 64){ const int ch = (int)rows[q] & 0xff; bad |= !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == 'N'); }
       el_ok = !__any(bad);
     }
-    if (el_ok) coop_rounds<R, false, true>(d, w, lane, live, n, nmax, col, rows, rs_len - 1, c0, mr, bnd, ring, lt, NULL, NULL, ktabs, etabs, npad);
+    if (el_ok) coop_rounds<R, W, false, true>(d, w, lane, live, n, nmax, col, rows, rs_len - 1, c0, mr, bnd, ring, lt, NULL, NULL, ktabs, etabs, npad);
     else
-    coop_rounds<R, false>(d, w, lane, live, n, nmax, col, rows, rs_len - 1, c0, mr, bnd, ring, lt, NULL, NULL, ktabs);
+    coop_rounds<R, W, false>(d, w, lane, live, n, nmax, col, rows, rs_len - 1, c0, mr, bnd, ring, lt, NULL, NULL, ktabs);
   }
 }
 
-template <int R>
-__global__ void __launch_bounds__(64*HS_COOP_WAVES, HS_COOP_OCC) hs_lead_kernel_coop(const hs_dev_t* __restrict__ dp, int item_begin, int item_end, int chunk){
+template <int R, int W, int OCC>
+__global__ void __launch_bounds__(64*W, OCC) hs_lead_kernel_coop(const hs_dev_t* __restrict__ dp, int item_begin, int item_end, int chunk){
   const hs_dev_t& d = *dp;
   const int lane = threadIdx.x & 63, w = uni((int)(threadIdx.x >> 6));
-  __shared__ double2 ring[HS_COOP_WAVES][2*64];
-  __shared__ double2 ktabs[HS_COOP_WAVES][24];          // per wavefront: (m2m, m2i) of its band's rows (HS_COOP_LDS_CONSTS)
+  __shared__ double2 ring[W][2*64];
+  __shared__ double2 ktabs[W][24];          // per wavefront: (m2m, m2i) of its band's rows (HS_COOP_LDS_CONSTS)
   __shared__ int s_item;
   double* const bnd = d.ws_band + (size_t)blockIdx.x * d.band_cols * 64 * 2;
   int32_t* const ctr = d.redo + d.n_active + chunk;
@@ -699,7 +699,7 @@ __global__ void __launch_bounds__(64*HS_COOP_WAVES, HS_COOP_OCC) hs_lead_kernel_
       }
       continue;
     }
-    coop_rounds<R, true>(d, w, lane, live, n, nmax, col, rows, rs_len - 1, c0, NULL, bnd, ring, lastcol, rec, side_out, ktabs);
+    coop_rounds<R, W, true>(d, w, lane, live, n, nmax, col, rows, rs_len - 1, c0, NULL, bnd, ring, lastcol, rec, side_out, ktabs);
   }
 }
 
@@ -1964,15 +1964,33 @@ hs_combine_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
 #endif
 // leading flanks of the reads [active_begin, active_begin + n_active) of a chunk: column tables first, then the reads-as-lanes sweep
 // HIPSTR_FLANK_COOP=0 selects the serial banded sweep (one wavefront per item, boundary rows through HBM scratch) for comparison
+#ifndef HS_LAT_WAVES
+#define HS_LAT_WAVES 8
+#endif
+#ifndef HS_LAT_ROWS
+#define HS_LAT_ROWS 8
+#endif
+#ifndef HS_LAT_ITEMS
+#define HS_LAT_ITEMS 128u        // launches with at most this many flank items take the latency shape
+#endif
+static bool lat_shape(){ static const bool v = !(getenv("HIPSTR_FLANK_LATENCY_SHAPE") && atoi(getenv("HIPSTR_FLANK_LATENCY_SHAPE")) == 0); return v; }
 static bool flank_coop(){ static const bool v = !(getenv("HIPSTR_FLANK_COOP") && atoi(getenv("HIPSTR_FLANK_COOP")) == 0); return v; }
 extern "C" int hs_flank_waves_per_group(){ return flank_coop() ? HS_COOP_WAVES : 1; }
 extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk){
   hipLaunchKernelGGL(hs_col_kernel, dim3(n_active), dim3(64), 0, st, dp, active_begin);
   if (item_end <= item_begin) return;
-  if (flank_coop()) hipLaunchKernelGGL((hs_lead_kernel_coop<HS_COOP_ROWS>), dim3(std::max(1u, std::min(n_wavefronts, 256u*HS_COOP_OCC*4/HS_COOP_WAVES))), dim3(64*HS_COOP_WAVES), 0, st, dp, item_begin, item_end, chunk);
+  // few items (a locus or two per call): the chip is far from full and what counts is the serial length of a sweep, so the bands are
+  // half as tall and twice as many (HS_LAT_WAVES x HS_LAT_ROWS: a step is shorter, the pipeline four steps longer): -10 % per sweep
+  if (flank_coop() && lat_shape() && (unsigned)(item_end - item_begin) <= HS_LAT_ITEMS)
+    hipLaunchKernelGGL((hs_lead_kernel_coop<HS_LAT_ROWS, HS_LAT_WAVES, 2>), dim3(std::max(1u, std::min(n_wavefronts, 256u))), dim3(64*HS_LAT_WAVES), 0, st, dp, item_begin, item_end, chunk);
+  else
+  if (flank_coop()) hipLaunchKernelGGL((hs_lead_kernel_coop<HS_COOP_ROWS, HS_COOP_WAVES, HS_COOP_OCC>), dim3(std::max(1u, std::min(n_wavefronts, 256u*HS_COOP_OCC*4/HS_COOP_WAVES))), dim3(64*HS_COOP_WAVES), 0, st, dp, item_begin, item_end, chunk);
   else hipLaunchKernelGGL((hs_lead_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end, chunk);
 }
 extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk){
-  if (flank_coop()) hipLaunchKernelGGL((hs_trail_kernel_coop<HS_COOP_ROWS>), dim3(std::max(1u, std::min(n_wavefronts, 256u*HS_COOP_OCC*4/HS_COOP_WAVES))), dim3(64*HS_COOP_WAVES), 0, st, dp, item_begin, item_end, chunk);
+  if (flank_coop() && lat_shape() && (unsigned)(item_end - item_begin) <= HS_LAT_ITEMS)
+    hipLaunchKernelGGL((hs_trail_kernel_coop<HS_LAT_ROWS, HS_LAT_WAVES, 2>), dim3(std::max(1u, std::min(n_wavefronts, 256u))), dim3(64*HS_LAT_WAVES), 0, st, dp, item_begin, item_end, chunk);
+  else
+  if (flank_coop()) hipLaunchKernelGGL((hs_trail_kernel_coop<HS_COOP_ROWS, HS_COOP_WAVES, HS_COOP_OCC>), dim3(std::max(1u, std::min(n_wavefronts, 256u*HS_COOP_OCC*4/HS_COOP_WAVES))), dim3(64*HS_COOP_WAVES), 0, st, dp, item_begin, item_end, chunk);
   else hipLaunchKernelGGL((hs_trail_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end, chunk);
 }
