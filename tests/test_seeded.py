@@ -53,3 +53,22 @@ def test_seed_must_leave_a_base_on_either_side(hmm):
     with pytest.raises(RuntimeError):
         capi.run_align(hmm, "hipstr_hmm_", b.ptr, seed_in=bad)
     assert b"either side" in hmm.hipstr_last_error()
+
+
+@pytest.mark.gpu
+def test_extreme_seeds_against_the_oracle(hmm, oracle):
+    """Seeds one base from either read end (sides of 1 and len-2 columns), mixed with ordinary ones: read sides of very different
+    lengths in one locus — the STR groups then pack a dozen one-column sides next to full-length ones."""
+    sb = capi.SynthBatch(n_loci=4, reads_per_locus=48, n_str_alleles=16, seed=77)
+    lens = np.diff(np.ctypeslib.as_array(sb.ptr.contents.base_off, shape=(sb.n_reads + 1,)))
+    rng = np.random.default_rng(7)
+    seed_in = np.full(sb.n_reads, -2, np.int32)                       # -2: compute (HIPSTR_SEED_AUTO)
+    pick = rng.random(sb.n_reads)
+    seed_in[pick < 0.25] = 1
+    hi = (pick >= 0.25) & (pick < 0.5)
+    seed_in[hi] = lens[hi] - 2
+    mid = (pick >= 0.5) & (pick < 0.75)
+    seed_in[mid] = rng.integers(2, lens[mid] - 2)
+    want, ws = capi.run_align(oracle, "oracle_", sb.ptr, fill=-3.25, seed_in=seed_in)
+    got, gs = capi.run_align(hmm, "hipstr_hmm_", sb.ptr, fill=-3.25, seed_in=seed_in)
+    assert np.array_equal(gs, ws) and np.array_equal(got, want)
