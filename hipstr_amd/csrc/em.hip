@@ -226,11 +226,9 @@ __device__ void em_gt_priors(const hs_em_dev_t& d, const hs_em_locus_t& L, int t
 template <int PASS>
 __global__ void __launch_bounds__(256) hs_em_mstep_part(const hs_em_dev_t* __restrict__ dp, const double* __restrict__ keep){
   const hs_em_dev_t& d = *dp;
-  // PASS 0 has one more slice, the allele-frequency scans: it is the longest-running workgroup of the launch, so it goes first (y = 0)
-  const int l = blockIdx.x, k_part = (PASS == 0) ? (int)blockIdx.y - 1 : (int)blockIdx.y, tid = threadIdx.x;
+  const int l = blockIdx.x, k_part = blockIdx.y, tid = threadIdx.x;
   if (!d.active[l]) return;
   const hs_em_locus_t L = d.loci[l];
-  if (PASS == 0 && k_part < 0){ em_gt_priors(d, L, tid); return; }
   const int A = L.A, nd = A*A;
   const double* post = d.post + L.post_off;
   const double* ll = d.ll + L.ll_off;
@@ -301,6 +299,16 @@ __global__ void __launch_bounds__(256) hs_em_mstep_part(const hs_em_dev_t* __res
   double out[7];
   for (int k = 0; k < 7; k++) out[k] = (PASS == 0) ? block_max(acc[k], red) : block_sum(acc[k], red);
   if (tid == 0) for (int k = 0; k < 7; k++) part[k_part*7 + k] = out[k];
+}
+
+// recalc_log_gt_priors of every active locus: long dependent scans on a few lanes.  Nothing in the stutter reductions needs their result
+// (the next iteration's hs_em_fill does), so the kernel runs beside them on a second stream.
+__global__ void __launch_bounds__(256) hs_em_gt_priors(const hs_em_dev_t* __restrict__ dp){
+  const hs_em_dev_t& d = *dp;
+  const int l = blockIdx.x;
+  if (!d.active[l]) return;
+  const hs_em_locus_t L = d.loci[l];
+  em_gt_priors(d, L, threadIdx.x);
 }
 
 __global__ void __launch_bounds__(64) hs_em_mstep_keepmax(const hs_em_dev_t* __restrict__ dp, double* __restrict__ keep){
@@ -496,6 +504,13 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
   if (dev.put(&d_h, &h, 1) || dev.put(&d_ph, &ph, 1)) return 1;
 
   lap("device state", NULL);
+  struct SideStream {                 // a second stream for the allele-frequency scans of an iteration
+    hipStream_t stream = NULL; hipEvent_t ev_fork = NULL, ev_join = NULL;
+    ~SideStream(){ if (ev_fork) hipEventDestroy(ev_fork); if (ev_join) hipEventDestroy(ev_join); if (stream) hipStreamDestroy(stream); }
+  } side;
+  EM_HIP(hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking));
+  EM_HIP(hipEventCreateWithFlags(&side.ev_fork, hipEventDisableTiming));
+  EM_HIP(hipEventCreateWithFlags(&side.ev_join, hipEventDisableTiming));
   // ---- the EM loop of train() (:171-226), all loci in lock step, converged loci masked out
   struct State { double sp[6]; double LL; int it; bool done, ok; };
   std::vector<State> st(nl);
@@ -527,10 +542,15 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
     EM_HIP(hipMemcpy(d_logp, logp.data(), logp.size()*sizeof(double), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(hs_em_fill, dim3(nl), dim3(256), 0, T.stream, d_h);
     hipLaunchKernelGGL(hs_posterior_kernel, dim3((unsigned)units.size()), dim3(256), 0, T.stream, (const hs_post_dev_t*)d_ph);
-    hipLaunchKernelGGL(hs_em_mstep_part<0>, dim3(nl, HS_EM_PARTS + 1), dim3(256), 0, T.stream, d_h, (const double*)NULL);     // slice 0: the allele-frequency priors
+    EM_HIP(hipEventRecord(side.ev_fork, T.stream));                      // posteriors are in place: the allele-frequency scans branch off
+    EM_HIP(hipStreamWaitEvent(side.stream, side.ev_fork, 0));
+    hipLaunchKernelGGL(hs_em_gt_priors, dim3(nl), dim3(256), 0, side.stream, d_h);
+    EM_HIP(hipEventRecord(side.ev_join, side.stream));
+    hipLaunchKernelGGL(hs_em_mstep_part<0>, dim3(nl, HS_EM_PARTS), dim3(256), 0, T.stream, d_h, (const double*)NULL);
     hipLaunchKernelGGL(hs_em_mstep_keepmax, dim3(nl), dim3(64), 0, T.stream, d_h, d_keep);
     hipLaunchKernelGGL(hs_em_mstep_part<1>, dim3(nl, HS_EM_PARTS), dim3(256), 0, T.stream, d_h, (const double*)d_keep);
     hipLaunchKernelGGL(hs_em_mstep, dim3(nl), dim3(256), 0, T.stream, d_h, (const double*)d_keep);
+    EM_HIP(hipStreamWaitEvent(T.stream, side.ev_join, 0));                // ... and join before the host reads this iteration's results
     EM_HIP(hipGetLastError());
     EM_HIP(hipStreamSynchronize(T.stream));
     EM_HIP(hipMemcpy(newll.data(), d_newll, nl*sizeof(double), hipMemcpyDeviceToHost));
