@@ -12,8 +12,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "hipstr_amd", "csrc")
 HIP_SOURCES = ["api.hip", "hmm_kernels.hip", "post_kernels.hip", "prep.cpp", "trace.hip", "em.hip", "nw.hip", "batch_io.cpp", "stream.hip", "gather.cpp"]
-HIP_HEADERS = ["layout.h", "post_layout.h", "prep.h", "device_common.h", "api_internal.h", os.path.join("..", "..", "include", "hipstr_hmm.h")]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans", "-mno-amdgpu-ieee", "-fPIC", "-shared", "-pthread", "-Wno-unused-result", "-Wno-unused-value"]
+HIP_HEADERS = ["exports.map", "layout.h", "post_layout.h", "prep.h", "device_common.h", "api_internal.h", os.path.join("..", "..", "include", "hipstr_hmm.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans", "-mno-amdgpu-ieee", "-fPIC", "-shared", "-pthread", "-fvisibility=hidden", "-Wno-unused-result", "-Wno-unused-value"]
 
 
 def _stale(target, deps):
@@ -34,7 +34,7 @@ def build_hmm(force=False):
     if force or _stale(out, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         extra = ["-D%s=%s" % (m, os.environ[e]) for m, e in (("HS_TRAIL_ROWS", "HIPSTR_TRAIL_ROWS"), ("HS_STR_WAVES", "HIPSTR_STR_WAVES")) if os.environ.get(e)]
-        _run([hipcc] + HIPCC_FLAGS + extra + ["-o", out] + [os.path.join(CSRC, s) for s in HIP_SOURCES])
+        _run([hipcc] + HIPCC_FLAGS + extra + ["-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", out] + [os.path.join(CSRC, s) for s in HIP_SOURCES])
     return out
 
 

@@ -30,7 +30,8 @@ extern "C" __global__ void hs_combine_kernel(const hs_dev_t* dp, int active_begi
 extern "C" __global__ void hs_posterior_kernel(const hs_post_dev_t* dp);
 extern "C" __global__ void hs_genotype_kernel(const hs_gt_dev_t* dp);
 extern "C" size_t hs_str_lds_bytes(int lds_len, int max_B);
-extern "C" __global__ void hs_str_group_kernel(const hs_dev_t* dp, int item_begin);
+extern "C" __global__ void hs_str_group_kernel(const hs_dev_t* dp, int item_begin, int short_only);
+extern "C" __global__ void hs_str_group_kernel_p(const hs_dev_t* dp, int item_begin);
 extern "C" size_t hs_str_group_lds_bytes(int max_B, int nd_cap);
 extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk);
 extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk);
@@ -379,6 +380,7 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
     i_visits = place_pool(P.visits.data(), P.visits.size()*sizeof(hs_visit_t), &hipstr::Prepared::visits, sizeof(hs_visit_t)),
     i_f64 = place_pool(P.f64pool.data(), P.f64pool.size()*sizeof(double), &hipstr::Prepared::f64pool, sizeof(double)),
     i_chars = place_pool(P.chars.data(), P.chars.size(), &hipstr::Prepared::chars, 1),
+    i_recs = place_pool(P.grp_recs.data(), P.grp_recs.size()*sizeof(int32_t), &hipstr::Prepared::grp_recs, sizeof(int32_t)),
     i_reads = PL(P.reads), i_active = PL(P.active), i_items = PL(items),
     i_ws = PL(P.ws), i_tg = PL(P.tgroups), i_tm = PL(P.tmembers), i_tp = PL(P.tpack), i_ord = PL(P.str_order);
 #undef PL
@@ -397,7 +399,7 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   h.f64pool = (const double*)at(i_f64); h.chars = (const char*)at(i_chars); h.reads = (const hs_read_t*)at(i_reads);
   h.active = (const int32_t*)at(i_active); h.items = (const hs_item_t*)at(i_items); h.ws = (const hs_ws_t*)at(i_ws);
   h.tgroups = (const hs_tgroup_t*)at(i_tg); h.tmembers = (const int32_t*)at(i_tm); h.tpack = (const int32_t*)at(i_tp);
-  h.str_order = (const int32_t*)at(i_ord); h.bases = at(i_bases); h.quals = at(i_quals);
+  h.str_order = (const int32_t*)at(i_ord); h.grp_recs = (const int32_t*)at(i_recs); h.bases = at(i_bases); h.quals = at(i_quals);
   dev->d_args = (hs_dev_t*)at(i_args);
   // ---- output + workspaces (device only)
   auto dalloc = [&](size_t bytes) -> void* { void* p = ctx->dev_cache.get(bytes ? bytes : 1); if (p) dev->dev_blocks.push_back(p); return p; };
@@ -432,7 +434,10 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   h.grp_nd_cap = std::max(2, (P.grp_nd_cap + 1) & ~1);
   dev->grp_lds_bytes = hs_str_group_lds_bytes(h.max_B, h.grp_nd_cap);
   if (getenv("HIPSTR_TIMING")) fprintf(stderr, "hipstr_hmm_upload: STR group kernel LDS %zu bytes (max block %d, read-end table %d doubles, %zu groups)\n", dev->grp_lds_bytes, h.max_B, h.grp_nd_cap, P.str_items.size());
-  if (dev->grp_lds_bytes > 48*1024) HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->grp_lds_bytes));
+  if (dev->grp_lds_bytes > 48*1024){
+    HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->grp_lds_bytes));
+    HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_group_kernel_p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->grp_lds_bytes));
+  }
   if (dev->lds_bytes > 48*1024){
     HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->lds_bytes));
     HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_kernel_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->lds_bytes));
@@ -519,11 +524,13 @@ extern "C" {
 
 int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
   if (!dev) return fail("null device batch");
-  if (dev->h.n_active == 0) return 0;
   if (bind(dev->ctx)) return 1;
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : dev->stream;
   if (hip_stream && (hipStream_t)hip_stream != dev->stream) dev->foreign_stream = true;
-  if (dev->h2d_stream != st) HS_HIP(hipStreamWaitEvent(st, dev->ev_h2d, 0));          // the tables were sent on another stream
+  // the tables were sent on another stream.  Also with nothing to align: what follows on `st` (the copy back, the events that release the
+  // batch's blocks to the cache) must come after the upload that is still writing into those blocks
+  if (dev->h2d_stream != st) HS_HIP(hipStreamWaitEvent(st, dev->ev_h2d, 0));
+  if (dev->h.n_active == 0) return 0;
   const hs_dev_t* dp = dev->d_args;
   auto mark = [&]() -> int {
     if (!dev->profiling) return 0;
@@ -543,9 +550,15 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
     const bool str_group = !(getenv("HIPSTR_STR_GROUP") && atoi(getenv("HIPSTR_STR_GROUP")) == 0);
     if (!str_group) hipLaunchKernelGGL(hs_str_kernel, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin, 0);
     else {
-      if (ch.str_end > ch.str_begin)
+      // blocks of at least six repeat units (nearly all) through the kernel with a compile-time period, the shorter ones as before
+      // (HIPSTR_STR_GROUP_P=0: all of them as before, for comparison)
+      static const bool group_p = !(getenv("HIPSTR_STR_GROUP_P") && atoi(getenv("HIPSTR_STR_GROUP_P")) == 0);
+      if (ch.str_end > ch.str_begin){
+        if (group_p) hipLaunchKernelGGL(hs_str_group_kernel_p, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), dev->grp_lds_bytes, st, dp,
+                                        dev->n_lead_items + dev->n_trail_items + ch.str_begin);
         hipLaunchKernelGGL(hs_str_group_kernel, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), dev->grp_lds_bytes, st, dp,
-                           dev->n_lead_items + dev->n_trail_items + ch.str_begin);
+                           dev->n_lead_items + dev->n_trail_items + ch.str_begin, group_p ? 1 : 0);
+      }
       if (ch.n_long_sides > 0)        // sides with more columns than a group holds: one workgroup per read as before
         hipLaunchKernelGGL(hs_str_kernel, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin, 1);
     }
@@ -695,6 +708,7 @@ int hipstr_debug_prepare(const hipstr_batch_t* batch, int threads, double* secon
     HS_MIX(P.visits); for (const hipstr::Prepared& f : P.frags) HS_MIX(f.visits);
     HS_MIX(P.f64pool); for (const hipstr::Prepared& f : P.frags) HS_MIX(f.f64pool);
     HS_MIX(P.chars); for (const hipstr::Prepared& f : P.frags) HS_MIX(f.chars);
+    HS_MIX(P.grp_recs); for (const hipstr::Prepared& f : P.frags) HS_MIX(f.grp_recs);
     HS_MIX(P.reads); HS_MIX(P.active); HS_MIX(P.seeds); HS_MIX(P.realign_read); HS_MIX(P.realign_hap); HS_MIX(P.ws); HS_MIX(P.lead_items);
     HS_MIX(P.trail_items); HS_MIX(P.str_items); HS_MIX(P.tpack); HS_MIX(P.str_order); HS_MIX(P.tgroups); HS_MIX(P.tmembers); HS_MIX(P.chunks);
 #undef HS_MIX

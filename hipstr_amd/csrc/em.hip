@@ -178,7 +178,8 @@ __device__ void em_gt_priors(const hs_em_dev_t& d, const hs_em_locus_t& L, int t
     row_lse[x] = rm + log(rs);
   }
   __syncthreads();
-  if (A <= 64 && tid >= 64) return;              // the scans are one lane per allele: the other wavefronts give their slots back (they end here; the barriers below count the rest)
+  // (the scans are one lane per allele; a wavefront without alleles walks through to the barrier below — every thread of the workgroup
+  // reaches every barrier)
   // The scans are one dependent chain per allele; the values they eat are fetched eight at a time ahead of the chain, or every step
   // would wait out a trip to L2.
 #define EM_SCAN_STEP(lv) do { if ((lv) <= m) t += exp((lv) - m); else { t *= exp(m - (lv)); t += 1.0; m = (lv); } } while (0)
@@ -355,7 +356,9 @@ __global__ void __launch_bounds__(256) hs_em_mstep(const hs_em_dev_t* __restrict
 struct EmBufs {
   std::vector<void*> p;
   hipstr::Ctx* ctx = NULL;          // blocks come from (and return to) the context's cache: no hipMalloc / hipFree per call
-  ~EmBufs(){ if (ctx) for (void* x : p) hipstr::dev_free(ctx, x); }
+  // the blocks go back to a cache other host threads draw from: nothing launched by this call may still be running (error paths leave early)
+  hipStream_t stream = NULL;        // the stream the call's kernels run on
+  ~EmBufs(){ if (ctx){ if (stream) hipStreamSynchronize(stream); for (void* x : p) hipstr::dev_free(ctx, x); } }
   template <typename T> int alloc(T** out, size_t count){
     *out = NULL;
     if (!ctx) ctx = hipstr::api_current_ctx();
@@ -482,6 +485,7 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
   lap("alleles and units", NULL);
   // ---- device state
   EmBufs dev;
+  dev.stream = T.stream;
   hs_em_dev_t h; memset(&h, 0, sizeof h);
   hs_post_dev_t ph; memset(&ph, 0, sizeof ph);
   hs_em_locus_t* d_loci; hs_post_unit_t* d_units; int32_t *d_active, *d_unit_active, *d_bps, *d_obs, *d_lab, *d_w, *d_mapgt;
@@ -506,7 +510,7 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
   lap("device state", NULL);
   struct SideStream {                 // a second stream for the allele-frequency scans of an iteration
     hipStream_t stream = NULL; hipEvent_t ev_fork = NULL, ev_join = NULL;
-    ~SideStream(){ if (ev_fork) hipEventDestroy(ev_fork); if (ev_join) hipEventDestroy(ev_join); if (stream) hipStreamDestroy(stream); }
+    ~SideStream(){ if (stream) hipStreamSynchronize(stream); if (ev_fork) hipEventDestroy(ev_fork); if (ev_join) hipEventDestroy(ev_join); if (stream) hipStreamDestroy(stream); }
   } side;
   EM_HIP(hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking));
   EM_HIP(hipEventCreateWithFlags(&side.ev_fork, hipEventDisableTiming));

@@ -957,7 +957,7 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin, in
     {
       const uint64_t sop = (uint64_t)(uintptr_t)(const hs_stropt_t*)c.so;
       asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx2 %1, %3, 0x68\n\ts_load_dword %2, %3, 0x8c\n\ts_waitcnt lgkmcnt(0)"
-                   : "=s"(so_head), "=s"(so_tab), "=s"(so_ndeq) : "s"(sop) : "memory");
+                   : "=&s"(so_head), "=&s"(so_tab), "=&s"(so_ndeq) : "s"(sop) : "memory");
     }
     static_assert(offsetof(hs_stropt_t, tab_off) == 0x68 && offsetof(hs_stropt_t, nd_eq) == 0x8c && offsetof(hs_stropt_t, ins_len) == 24, "hs_stropt_t layout");
     const int so_seq_off = so_head[0], so_f64_off = so_head[4];
@@ -1443,10 +1443,12 @@ struct GrpLds {
 extern "C" size_t hs_str_group_lds_bytes(int max_B, int nd_cap){
   const size_t XC = HS_GRP_COLS;
   const size_t blk_len = ((size_t)max_B + 19) & ~(size_t)15;
-  return XC*8*HS_MAXREP + (XC + HS_GRP_MAXREADS + 2)*8 + XC*8 + XC*32 + (size_t)nd_cap*8 + 2*24*8 + 2*HS_TAB_CAP*16 + (3*blk_len + 64)*2 + 16;
+  // (+ HS_GRP_MAXREADS + 2 doubles: hs_str_group_kernel_p keeps a 0.0 in front of every read in match_probs_ as well)
+  // (+ 3 HS_GRP_MAXREADS + 1 ints: that kernel keeps its per-read tables behind the carve instead of in static LDS)
+  return XC*8*HS_MAXREP + 2*(XC + HS_GRP_MAXREADS + 2)*8 + XC*32 + (size_t)nd_cap*8 + 2*24*8 + 2*HS_TAB_CAP*16 + (3*blk_len + 64)*2 + (3*HS_GRP_MAXREADS + 1)*4 + 16;
 }
 
-__device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin){
+__device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin, int short_only){
   constexpr int XC = HS_GRP_COLS, NT = HS_GRP_COLS;
   static_assert((NT & (NT - 1)) == 0 && NT >= 128 && 4*XC*8 < 65536, "the wavefronts' turns at the read-end sums assume a power-of-two workgroup; plane offsets are 16 bits");
   const int lane = threadIdx.x & 63, x = threadIdx.x;
@@ -1504,8 +1506,9 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
   }
   const int blk_len = (d.max_B + 19) & ~15;
   const int xrp = xx + g + 1;                       // this column in rowP: rowP[xrp - len] is M of column j - len, or the 0.0 in front when len = j + 1
-  const int n_tab = uni(loc->n_tab[side]);
+  const int n_tab = short_only ? uni(loc->n_short[side]) : uni(loc->n_tab[side]);      // short_only: hs_str_group_kernel_p has the rest
   const int i0 = blockIdx.y * d.allele_chunk, i1 = min(n_tab, i0 + d.allele_chunk);
+  if (i0 >= i1) return;                              // the same for every lane of the workgroup
   const int32_t* order = d.str_order + uni(loc->order_off[side]);
   const int jmaxw = uni(wave_max_i(j)), jminw = uni(wave_min_i(j));
   const int nh_l = s_n[min(lane, G - 1)];                       // lane h < G: columns of read h
@@ -1875,7 +1878,470 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
 #define HS_GRP_OCC HS_STR_WAVES      // wavefronts per SIMD the register allocation aims at
 #endif
 extern "C" __global__ void __launch_bounds__(HS_GRP_COLS, HS_GRP_OCC)
-hs_str_group_kernel(const hs_dev_t* __restrict__ dp, int item_begin){ str_group_body(*dp, item_begin); }
+hs_str_group_kernel(const hs_dev_t* __restrict__ dp, int item_begin, int short_only){ str_group_body(*dp, item_begin, short_only); }
+
+// ------------------------------------------------------------------ the STR block of tabulated alleles, grouped form, period known at compile time
+// hs_str_group_kernel_p<P> takes the tabulated alleles whose blocks hold at least six repeat units of period P (positions
+// [n_short, n_tab) of a side's order: nearly all of them) — the same lane layout, LDS tables, allele loop and operations per column as
+// str_group_body, with what a compile-time period and a periodic block allow:
+//   * the 13 artifact terms are evaluated branch-free with every allele-independent quantity of a lane — its LDS addresses into the match /
+//     deletion tables for the six insertion and six deletion sizes, its distance from the read end — computed once before the allele loop,
+//     the table offsets of the sizes as immediates, and the per-allele constants as scalars: 10-11 integer operations per term instead of ~25
+//     plus six v_readlane;
+//   * the insertion table is the deletion table: with six repeat units in the block (nd_eq = 6) ins_probs_[q] of a column is del_probs_[q]
+//     or, for a column closer than (q+1)P to the read start, the truncated sum — which the table phase now stores in that row as well;
+//   * a read-end deletion sum pairs read column xcol - t with block base B-1-|D| - t, and in a periodic block that base is base (t mod P)
+//     from the right end whatever the allele and the size: the plane of the emission table is a scalar per step (sp[t mod P], the loop
+//     unrolled over a period), the addresses of a chain are arithmetic, and its emissions are requested three groups ahead of the additions
+//     instead of waiting for a plane-offset lookup per group (the chain is the allele's critical path: the other wavefronts wait for it).
+// Same values added in the same order: bit-identical to str_group_body (tools/fuzz_align.py).
+#ifndef HS_PEXP
+#define HS_PEXP 0        // compile-time experiments (register pressure, timing; results invalid): 1 no evaluation, 2 no read-end sums, 3 no table phase
+#endif
+template <int P>
+__device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_begin){
+  constexpr int XC = HS_GRP_COLS, NT = HS_GRP_COLS;
+  constexpr int SIXP = HS_MAXREP*P, NDS = HS_MAXREP*SIXP;            // a row slot / the six row slots of one read's read-end sums
+  const int lane = threadIdx.x & 63, x = threadIdx.x;
+  const hs_item_t* item = d.items + item_begin + blockIdx.x;
+  const int side = uni(item->side), G = uni(item->slot), tp = uni(item->active);
+  // LDS carve of str_group_body (same size function), addressed as offsets in doubles from the start.  No static LDS in this kernel: the
+  // dynamic block starts at address 0 and the offsets below are the addresses (the compiler adds the base to every access otherwise)
+  const int blk_len = (d.max_B + 19) & ~15;
+  // (match_probs_ is indexed like rowP here: a 0.0 in front of every read's first column)
+  constexpr int oDl = 0, oRowP = HS_MAXREP*XC, oMt = oRowP + (XC + HS_GRP_MAXREADS + 2), oE = oMt + (XC + HS_GRP_MAXREADS + 2), oNd = oE + 4*XC;
+  const int oCst = oNd + d.grp_nd_cap, oTab = oCst + 2*24;           // tab: per parity A[HS_TAB_CAP] | G[HS_TAB_CAP]
+  double* const lds = (double*)hs_lds_raw;
+  uint16_t* const boff0 = (uint16_t*)(lds + oTab + 4*HS_TAB_CAP) + blk_len + 64;
+  int* const s_off = (int*)(boff0 + 2*blk_len);                       // [HS_GRP_MAXREADS + 1] first column of every read | [..] columns | [..] active-read index
+  int* const s_n = s_off + (HS_GRP_MAXREADS + 1);
+  int* const s_ai = s_n + HS_GRP_MAXREADS;
+  for (int i = x; i < blk_len + 64; i += NT) boff0[i - blk_len - 64] = 0;
+  // LDS reads by byte ADDRESS: lds0 (the address of the carve: 0, there is no static LDS in this kernel — but it is not assumed) is part of
+  // every per-lane and per-allele base below, so that an access is one ds_read with an immediate offset and no addition of the base
+  const int lds0 = (int)(uintptr_t)(__attribute__((address_space(3))) char*)hs_lds_raw;
+  auto ldb = [&](int byte_addr) -> double { return *(const __attribute__((address_space(3))) double*)(uintptr_t)(uint32_t)byte_addr; };
+  if (x < G){
+    const int ai = d.tpack[tp + x];
+    const hs_read_t r = d.reads[d.active[ai]];
+    s_ai[x] = ai; s_n[x] = side ? r.len - r.seed - 1 : r.seed;
+  }
+  __syncthreads();
+  if (x == 0){ int o = 0; for (int g = 0; g < G; g++){ s_off[g] = o; o += s_n[g]; } s_off[G] = o; }
+  __syncthreads();
+  const int X = s_off[G];
+  const bool actj = x < X;
+  const bool wave_act = (x & ~63) < X;
+  const int xx = min(x, X - 1);
+  int g = 0;
+  for (int k = 1; k < G; k++) g += (xx >= s_off[k]) ? 1 : 0;
+  const int offg = s_off[g], n = s_n[g], j = xx - offg, ai = s_ai[g];
+  const hs_read_t rdv = d.reads[d.active[ai]];
+  const hs_locus_t* loc = d.loci + uni(rdv.locus);
+  const int n_tab = uni(loc->n_tab[side]);
+  const int i0 = uni(uni(loc->n_short[side]) + (int)blockIdx.y * d.allele_chunk), i1 = uni(min(n_tab, i0 + d.allele_chunk));
+  if (i0 >= i1) return;                              // the same for every lane of the workgroup
+  const int lenm1 = rdv.len - 1;
+  double* const mr_base = d.ws_mr + d.ws[ai].mr + (side ? rdv.seed : 0) + j;          // (field by field: a local copy of the record, indexed by `side`, would live in scratch memory)
+  const int lead_stride = n + uni(loc->lead_flank[side]) + 1;
+  const double* const lead_base = d.ws_lead + (side ? d.ws[ai].lead[1] : d.ws[ai].lead[0]) + j;
+  {
+    const int src = rdv.base_off + (side ? rdv.len - 1 - j : j);
+    const uint8_t q = (uint8_t)d.quals[src];
+    if (actj){
+      const uint8_t r = (uint8_t)d.bases[src];
+      const double qc = d.qual_correct[q], qe = d.qual_error[q];
+      lds[oE + xx] = (r == 'A') ? qc : qe; lds[oE + XC + xx] = (r == 'C') ? qc : qe;
+      lds[oE + 2*XC + xx] = (r == 'T') ? qc : qe; lds[oE + 3*XC + xx] = (r == 'G') ? qc : qe;
+      if (j == 0){ lds[oRowP + xx + g] = 0.0; lds[oMt + xx + g] = 0.0; }
+    }
+  }
+  const int xrp = xx + g + 1;
+  const int32_t* order = d.str_order + uni(loc->order_off[side]);
+  const int jmaxw = uni(wave_max_i(j)), jminw = uni(wave_min_i(j));
+  const int nh_l = s_n[min(lane, G - 1)];
+  const int nmin_g = uni(wave_min_i(nh_l));
+  // ---- what a lane needs of its column for the 13 terms, whatever the allele (byte offsets into the LDS carve)
+  int rj = n - 1 - j;                                  // distance from the read end
+  int j8p8 = 8*(j + 1);
+  int aM = lds0 + 8*xrp;                               // + 8 oRowP - 8 len: M of column j - len before the block, or the 0.0 in front of the read;  + 8 oMt: match_probs_ of this column
+  int aCol = lds0 + 8*xx;                              // + 8 oDl + q XC 8: del_probs_[q] of this column
+  int aZ = lds0 + 8*(offg + g);                        // the 0.0 in front of this lane's read (rowP and match_probs_ alike)
+  const int aNd = lds0 + 8*(oNd + g*NDS + min(rj, SIXP - 1));                 // + 8 SIXP slot: this column's read-end sum of the size in that slot
+  // ---- what an allele needs that is the same for every lane comes from its record (layout.h HS_GRP_REC_DWORDS) by scalar loads: the header of
+  // the NEXT allele while this one is evaluated (its table and block are requested one allele ahead), the constants when they are needed
+  typedef int hs_i16v __attribute__((ext_vector_type(16)));
+  typedef int hs_i8v_ __attribute__((ext_vector_type(8)));
+  typedef int hs_i4v_ __attribute__((ext_vector_type(4)));
+  typedef int hs_i2v_ __attribute__((ext_vector_type(2)));
+  const int32_t* const recs = d.grp_recs + (int64_t)uni(loc->rec_off[side])*HS_GRP_REC_DWORDS;
+  auto rec_addr = [&](int i){ return (uint64_t)(uintptr_t)(recs + (int64_t)i*HS_GRP_REC_DWORDS); };
+  // (the scalar loads below are inline assembly, several per block: their destinations are early-clobber operands, or the first load's
+  // destination may be given the registers that hold the address the following loads still need)
+  auto load_header = [&](int i) -> hs_i8v_ {
+    hs_i8v_ hd; const uint64_t ra = rec_addr(i);
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(hd) : "s"(ra) : "memory");
+    return hd;
+  };
+  double nx_tab = 0.0; int nx_blkw = 0;               // lanes 0.. of wavefront 0 the table's A, of wavefront 1 its G;  the block, four bases per lane
+  auto request = [&](const hs_i8v_& hd){
+    const int tl = (hd[0] >> 10) & 0xff, Bk = hd[2];
+    const double* tsrc = d.f64pool + hd[4];
+    nx_blkw = (x < (Bk + 3)/4) ? ((const int*)(d.chars + hd[5]))[x] : 0;
+    if (lane < tl && x < 128) nx_tab = tsrc[3*lane + (x >> 6)];
+  };
+  hs_i8v_ hd_next = load_header(i0);
+  request(hd_next);
+  int cur_slot = -1, prev_B = 0, nd_base = 0;
+#ifdef HS_GTIME
+  unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#endif
+  for (int i = i0; i < i1; i++){
+    const int par = (i - i0) & 1;
+    const hs_i8v_ hd = hd_next;
+    const bool chained = (i > i0) && ((hd[0] >> 30) & 1);
+    const int slot = hd[0] & 0x3ff, re_ord = hd[1];
+    double* const mr_out = mr_base + (int64_t)re_ord*lenm1;
+    const int B = hd[2], tab_len = (hd[0] >> 10) & 0xff;
+    const int tail = hd[3];
+    if (slot != cur_slot){
+      __syncthreads();
+      if (actj) lds[oRowP + xrp] = lead_base[(int64_t)slot*lead_stride];
+      cur_slot = slot;
+    }
+    if (x < (B + 3)/4){
+      int2 bo;
+      bo.x = (((nx_blkw >> 1) & 3) * (XC*8)) | ((((nx_blkw >> 9) & 3) * (XC*8)) << 16);
+      bo.y = (((nx_blkw >> 17) & 3) * (XC*8)) | ((((nx_blkw >> 25) & 3) * (XC*8)) << 16);
+      ((int2*)(boff0 + par*blk_len))[x] = bo;
+    }
+    if (lane < tab_len && x < 128) lds[oTab + par*2*HS_TAB_CAP + (x >> 6)*HS_TAB_CAP + lane] = nx_tab;
+    if (x < 64){       // the position priors of the six deletion sizes (StutterAlignerClass.cpp:112; record dwords 44..55): the read-end sums start from them, each lane from its size's
+      hs_i8v_ pdA; hs_i4v_ pdB;
+      const uint64_t ra = rec_addr(i);
+      asm volatile("s_load_dwordx8 %0, %2, 0xb0\n\ts_load_dwordx4 %1, %2, 0xd0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(pdA), "=&s"(pdB) : "s"(ra) : "memory");
+      double* pdl = lds + oCst + par*8;
+      if (x == 0) pdl[0] = __hiloint2double(pdA[1], pdA[0]);
+      if (x == 1) pdl[1] = __hiloint2double(pdA[3], pdA[2]);
+      if (x == 2) pdl[2] = __hiloint2double(pdA[5], pdA[4]);
+      if (x == 3) pdl[3] = __hiloint2double(pdA[7], pdA[6]);
+      if (x == 4) pdl[4] = __hiloint2double(pdB[1], pdB[0]);
+      if (x == 5) pdl[5] = __hiloint2double(pdB[3], pdB[2]);
+    }
+    if (i + 1 < i1){ hd_next = load_header(i + 1); request(hd_next); }
+    HS_TICK(0);   // evaluation of the previous allele + setup
+    __syncthreads();
+    HS_TICK(1);   // barrier 1 wait
+    const uint16_t* boff = boff0 + par*blk_len;
+    auto Eat = [&](int col, int bo) -> double { return ldb(lds0 + 8*oE + col*8 + bo); };
+
+    // --- StutterAlignerClass::load_read (StutterAlignerClass.cpp:12-53): match_probs_ and del_probs_ of this lane's column.  Row q of the
+    // deletion table also takes the truncated sum of a column closer than (q+1)P to the read start (the running value no longer changes
+    // there): that is ins_probs_[q] of the column (StutterAlignerClass.cpp:40-51), and the deletions only read rows of columns >= (q+1)P
+    const int t0 = chained ? prev_B : 0;
+    prev_B = B;
+    const int tmax = min(B, max(jmaxw + 1, SIXP));          // B >= SIXP here: every row of the deletion table is reached
+    if (wave_act && t0 < tmax && HS_PEXP != 3){
+      double lp = (t0 > 0) ? lds[oMt + xrp] : 0.0;
+      int t = t0;
+      if (t < SIXP){
+        int col = xx - t;
+        int left = j - t, ph = (t + 1) % P;
+        int dl = oDl + ((t + 1)/P - 1)*XC + xx;
+        for (; t < SIXP; t++){
+          const double e = Eat(col, boff[B-1-t]);
+          if (left >= 0) lp += e;
+          if (ph == 0){ if (actj) lds[dl] = lp; }
+          ph++; if (ph == P){ ph = 0; dl += XC; }
+          col--; left--;
+        }
+      }
+      auto steps = [&](int tend, auto masked){
+        int xr = xx - t - 3, xb = B - 1 - t - 3;
+        for (; t + 4 <= tend; t += 4){
+          asm volatile("" : "+v"(xr));
+#pragma unroll
+          for (int k = 0; k < 4; k++){
+            const double e = Eat(xr + 3 - k, boff[xb + 3 - k]);
+            if (!decltype(masked)::value || xr + 3 - k >= offg) lp += e;
+          }
+          xr -= 4; xb -= 4;
+        }
+        for (; t < tend; t++){
+          const double e = Eat(xr + 3, boff[xb + 3]);
+          if (!decltype(masked)::value || xr + 3 >= offg) lp += e;
+          xr--; xb--;
+        }
+      };
+      if (t < tmax){
+        steps(min(tmax, jminw + 1), std::false_type());
+        steps(tmax, std::true_type());
+      }
+      if (actj) lds[oMt + xrp] = lp;
+    }
+
+    HS_TICK(2);   // table phase
+    // --- deletion start values of the columns whose segment reaches the read end (the `else` branch of StutterAlignerClass.cpp:117-120)
+    {
+      // plane (byte offset into the emission table) of the block base t mod P from the right end: a scalar, extracted where it is used
+      auto spk = [&](int r) -> int { return ((tail >> (2*r)) & 3) * (XC*8); };
+      const int aPd = lds0 + 8*(oCst + par*8);
+      auto nd_sum = [&](int q, int xcol, int jcol, bool valid, int dst){
+        const int aD = (q+1)*P;
+        const int len = min(B - aD, jcol + 1);
+        const int lmin = uni(wave_min_i(len)), lmax = uni(wave_max_i(len));
+        double lp = ldb(aPd + 8*q);
+        constexpr int UN = (P >= 4) ? P : ((P == 3) ? 6 : 4);       // steps per group: a multiple of the period
+#ifndef HS_CHAIN_DEP
+#define HS_CHAIN_DEP 3
+#endif
+        constexpr int DEP = HS_CHAIN_DEP;                           // groups in flight
+        int a = lds0 + 8*(oE + xcol) - 8*(UN - 1);                         // the group's lowest address; step k of it sits (UN-1-k) entries above
+        double ev[DEP][UN];
+        auto load = [&](double* dst_){
+#pragma unroll
+          for (int k = 0; k < UN; k++) dst_[k] = ldb((a + spk(k % P)) + 8*(UN - 1 - k));
+          a -= 8*UN;
+        };
+#pragma unroll
+        for (int s = 0; s < DEP; s++) load(ev[s]);
+        __builtin_amdgcn_s_setprio(3);
+        int t = 0;
+        while (t + DEP*UN <= lmin){
+#pragma unroll
+          for (int s = 0; s < DEP; s++){
+#pragma unroll
+            for (int k = 0; k < UN; k++) lp += ev[s][k];
+            load(ev[s]);
+          }
+          t += DEP*UN;
+        }
+        while (t < lmax){
+#pragma unroll
+          for (int s = 0; s < DEP; s++){
+            if (t < lmax){                              // wave-uniform
+#pragma unroll
+              for (int k = 0; k < UN; k++){ const double v = lp + ev[s][k]; lp = (t + k < len) ? v : lp; }
+              load(ev[s]);
+              t += UN;
+            }
+          }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (valid) lds[oNd + dst] = lp;
+      };
+      auto row_off = [&](int q){ return P*((q*(q+1)) >> 1); };
+      const bool reuse_al = chained && ((hd[0] >> 29) & 1);
+      if (reuse_al) nd_base = (nd_base + HS_MAXREP - 1) % HS_MAXREP;
+      auto slot_of = [&](int q){ int sl = nd_base + q; sl -= (sl >= HS_MAXREP) ? HS_MAXREP : 0; return sl*SIXP; };
+      const bool all_long = nmin_g >= SIXP;
+      auto udiv = [&](int e, int c, float rc) -> int {
+        int h = (int)((float)e * rc);
+        h -= (h*c > e) ? 1 : 0; h += ((h + 1)*c <= e) ? 1 : 0;
+        return h;
+      };
+      const int xw = (x + (NT/2)*(i - i0)) & (NT - 1);
+      if (HS_PEXP == 2){} else
+      if (all_long){
+        const int Gp = G*P;
+        if (reuse_al){
+          const int n_sums = HS_MAXREP*Gp;
+          const float rc_gp = __builtin_amdgcn_rcpf((float)Gp);
+          for (int base = 0; base < n_sums; base += NT){
+            if (base + (xw & ~63) >= n_sums) continue;
+            const int e = min(base + xw, n_sums - 1);
+            const int q = udiv(e, Gp, rc_gp), r = e - q*Gp, hh = r / P, off = r - hh*P;
+            const int jcol = (s_n[hh] - (q+1)*P) + off;
+            nd_sum(q, s_off[hh] + jcol, jcol, base + xw < n_sums, hh*NDS + slot_of(q) + ((q+1)*P - 1 - off));
+          }
+        } else {
+          const int n_sums = G*row_off(HS_MAXREP);
+          for (int base = 0; base < n_sums; base += NT){
+            if (base + (xw & ~63) >= n_sums) continue;
+            const int e = min(base + xw, n_sums - 1);
+            int q = 0;
+#pragma unroll
+            for (int k = 1; k <= 5; k++) q += (e >= G*row_off(k)) ? 1 : 0;
+            const int r = e - G*row_off(q), w = (q+1)*P;
+            const int hh = udiv(r, w, __builtin_amdgcn_rcpf((float)w)), off = r - hh*w;
+            const int jcol = (s_n[hh] - w) + off;
+            nd_sum(q, s_off[hh] + jcol, jcol, base + xw < n_sums, hh*NDS + slot_of(q) + (w - 1 - off));
+          }
+        }
+      } else {
+        int c_l = 0;
+        {
+          const bool ru = reuse_al && (nh_l >= SIXP);
+          int np_l = 0;
+#pragma unroll
+          for (int q = 0; q < HS_MAXREP; q++) np_l += min((q+1)*P, nh_l);
+          if (lane < G) c_l = ru ? SIXP : np_l;
+        }
+        int pc = c_l;
+#pragma unroll
+        for (int dd = 1; dd < HS_GRP_MAXREADS; dd <<= 1){
+          const int t1 = __shfl_up(pc, dd);
+          if (lane >= dd) pc += t1;
+        }
+        const int n_sums = rdlane(pc, HS_GRP_MAXREADS - 1);
+        auto find = [&](int pref, int e, int& hh, int& loc_e){
+          hh = 0; loc_e = e;
+          for (int h = 0; h + 1 < G; h++){
+            const int ph = rdlane(pref, h);
+            if (e >= ph){ hh = h + 1; loc_e = e - ph; }
+          }
+        };
+        for (int base = 0; base < n_sums; base += NT){
+          const int wbase = base + (xw & ~63);
+          if (wbase >= n_sums) continue;
+          const int e = min(base + xw, n_sums - 1);
+          const bool valid = base + xw < n_sums;
+          int hh, loc_e; find(pc, e, hh, loc_e);
+          const int nh = s_n[hh], offh = s_off[hh];
+          const bool ruh = reuse_al && (nh >= SIXP);
+          int q = 0, off = loc_e, jcol, dst;
+          if (ruh){
+#pragma unroll
+            for (int k = 1; k <= 5; k++) q += (loc_e >= k*P) ? 1 : 0;
+            off = loc_e - q*P;
+            jcol = (nh - (q+1)*P) + off;
+          } else {
+            int cnt[HS_MAXREP];
+#pragma unroll
+            for (int qq = 0; qq < HS_MAXREP; qq++) cnt[qq] = min((qq+1)*P, nh);
+#pragma unroll
+            for (int qq = 0; qq < HS_MAXREP - 1; qq++) if (q == qq && off >= cnt[qq]){ off -= cnt[qq]; q = qq + 1; }
+            jcol = max(0, nh - (q+1)*P) + off;
+          }
+          dst = slot_of(q) + (nh - 1 - jcol);
+          nd_sum(q, offh + jcol, jcol, valid, hh*NDS + dst);
+        }
+      }
+    }
+    HS_TICK(3);   // read-end sums
+    __syncthreads();
+    HS_TICK(4);   // barrier 2 wait
+
+    // --- the 13 artifact terms of this lane's column (HapAligner.cpp:62-109) and their fast_log_sum_exp
+    if (wave_act && HS_PEXP != 1){
+      double terms[HS_NART];
+      double lp0_max = 0.0;
+      const int B8 = 8*B;
+      const int aTab = uni(lds0 + 8*(oTab + par*2*HS_TAB_CAP));
+      const int nd_slot0 = uni(nd_base);                   // (wave-uniform by construction; the compiler keeps the counters of this loop in vector registers)
+      // the lane's column constants, opaque from here on: otherwise every address below that does not depend on the allele is computed once
+      // in front of the allele loop and kept — in more registers than there are (they went to scratch memory)
+      asm volatile("" : "+v"(aM), "+v"(aCol), "+v"(aZ), "+v"(j8p8), "+v"(rj));
+      // (lp0 + A[e]) + G[e], e = tab_base + [bound > 0] + max(bound - U0, 0), everything in bytes
+      // the allele's constants, in two stages of scalar loads (the scalar registers do not hold all of them next to everything else): the
+      // lists' table bases and shapes (record dwords 8..15), the table's smallest Bnd (56..57), pmf[6..12] | prior_ins (28..43) for the
+      // unchanged size and the insertions; then pmf[0..5] (16..27) | prior_del[6] (44..55) for the deletions
+      hs_i16v cA; hs_i8v_ cS; hs_i2v_ cD;
+      const uint64_t ra = rec_addr(i);
+      asm volatile("s_load_dwordx16 %0, %3, 0x70\n\ts_load_dwordx8 %1, %3, 0x20\n\ts_load_dwordx2 %2, %3, 0xe0\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&s"(cA), "=&s"(cS), "=&s"(cD) : "s"(ra) : "memory");
+      auto pmf_hi = [&](int t) -> double { return __hiloint2double(cA[2*(t - 6) + 1], cA[2*(t - 6)]); };      // t = 6..13, a constant once unrolled
+      const double tab_bmin = __hiloint2double(cD[1], cD[0]);
+      auto tab_eval = [&](double lp0, int lim8, int k) -> double {
+        const int stk = cS[k];
+        const int tb8 = aTab + 8*(stk >> 16), u8 = 8*(stk & 0xffff);
+        const int e8 = (min(lim8, 8) + max(lim8 - u8, 0)) + tb8;
+        const double A = ldb(e8), Gv = ldb(e8 + 8*HS_TAB_CAP);
+        lp0_max = fmax(lp0_max, fabs(lp0));
+        return (lp0 + A) + Gv;
+      };
+      {
+        const int len8 = min(B8, j8p8);
+        terms[HS_MAXREP] = (pmf_hi(HS_MAXREP) + ldb(8*oMt + aM)) + ldb(8*oRowP + aM - len8);
+      }
+      const double prior_ins = pmf_hi(13);
+#pragma unroll
+      for (int q = 0; q < HS_MAXREP; q++){                 // insertion of D = (q+1) P (StutterAlignerClass.cpp:59-104)
+        const int D8 = 8*(q+1)*P;
+        const int len8 = min(B8 + D8, j8p8);
+        const double li = ldb(8*oDl + 8*q*XC + aCol);      // ins_probs_[q] of this column (table phase above)
+        // match_probs_ of column j - D if the segment is longer than the insertion (StutterAlignerClass.cpp:66), else the 0.0 in front of the read
+        const double lp0 = (prior_ins + li) + ldb(8*oMt + max(aM - D8, aZ));
+        const int lim8 = min(max(j8p8 - D8, 0), B8);       // min(max(0, len - D), B)
+        const double S = tab_eval(lp0, lim8, HS_MAXREP);
+        terms[HS_MAXREP + 1 + q] = (pmf_hi(HS_MAXREP + 1 + q) + S) + ldb(8*oRowP + aM - len8);
+        __builtin_amdgcn_sched_barrier(0);                // one term at a time: the scheduler otherwise requests every table value of the 13 terms up front, in more registers than there are
+      }
+      hs_i8v_ cE, cP; hs_i4v_ cF, cQ;
+      asm volatile("s_load_dwordx8 %0, %4, 0x40\n\ts_load_dwordx4 %1, %4, 0x60\n\ts_load_dwordx8 %2, %4, 0xb0\n\ts_load_dwordx4 %3, %4, 0xd0\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&s"(cP), "=&s"(cQ), "=&s"(cE), "=&s"(cF) : "s"(ra) : "memory");
+      auto pmf_lo = [&](int t) -> double { return t < 4 ? __hiloint2double(cP[2*t + 1], cP[2*t]) : __hiloint2double(cQ[2*(t - 4) + 1], cQ[2*(t - 4)]); };   // t = 0..5
+      auto pd_at = [&](int q) -> double { return q < 4 ? __hiloint2double(cE[2*q + 1], cE[2*q]) : __hiloint2double(cF[2*(q - 4) + 1], cF[2*(q - 4)]); };
+#pragma unroll
+      for (int q = 0; q < HS_MAXREP; q++){                 // deletion of aD = (q+1) P (StutterAlignerClass.cpp:106-150)
+        const int aD = (q+1)*P;
+        const int len8 = min(B8 - 8*aD, j8p8);
+        // column j + |D|: past the read end the values are another read's (or nothing's) and not used
+        const double dsum = ldb(8*oMt + 8*aD + aM) - ldb(8*oDl + 8*q*XC + 8*aD + aCol);
+        int slq = nd_slot0 + q; slq -= (slq >= HS_MAXREP) ? HS_MAXREP : 0;
+        const double ndv = ldb(aNd + 8*SIXP*slq);
+        const double dv = pd_at(q) + dsum;
+        const double lp0 = (rj >= aD) ? dv : ndv;          // the segment ends inside the read: from the tables; else the read-end sum
+        const double S = tab_eval(lp0, len8, q);
+        terms[HS_MAXREP - 1 - q] = (pmf_lo(HS_MAXREP - 1 - q) + S) + ldb(8*oRowP + aM - len8);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      bool bad = !(lp0_max < tab_bmin);
+      if (d.debug_redo > 0) bad |= ((ai*31 + i*7 + (j >> 6)) % d.debug_redo) == 0;
+      if (!__any(bad && actj)){
+        double mx = terms[0];
+#pragma unroll
+        for (int t = 1; t < HS_NART; t++) mx = fmax(mx, terms[t]);
+        // fast_log_sum_exp (mathops.cpp:97-106), branch-free.  A term that passes the threshold has 1.44 dd > -10: fasterexp's clamp at -126
+        // (fastonebigheader.h:210) cannot act on it and is left out; a term that does not contributes 0.0, whatever its bits would have been
+        double tot = 0.0;
+#pragma unroll
+        for (int t = 0; t < HS_NART; t++){
+          const double dd = terms[t] - mx;
+          const float z = __fmul_rn(8388608.0f, __fadd_rn(__fmul_rn(1.442695040f, (float)dd), 126.94269504f));
+          const float fe = (dd > d.log_thresh) ? __uint_as_float(__float2uint_rz(z)) : 0.0f;
+          tot += (double)fe;
+        }
+        if (actj) mr_out[0] = mx + (double)f_fasterlog((float)tot);
+      } else if (actj){
+        mr_out[0] = HS_REDO;
+        d.redo[ai] = 1;
+      }
+    }
+  }
+#ifdef HS_GTIME
+  { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[0] += now_ - tprev; }
+  if ((blockIdx.x % 20000) == 7 && lane == 0)
+    printf("grp_p<%d> %d wave %d G %d X %d alleles %d: eval+setup %llu  wait1 %llu  table %llu  nd %llu  wait2 %llu\n", P, (int)blockIdx.x, (int)(x >> 6), G, X, i1 - i0,
+           tacc[0], tacc[1], tacc[2], tacc[3], tacc[4]);
+#endif
+}
+
+extern "C" __global__ void __launch_bounds__(HS_GRP_COLS, HS_GRP_OCC)
+hs_str_group_kernel_p(const hs_dev_t* __restrict__ dp, int item_begin){
+  const hs_dev_t& d = *dp;
+  // the period of the group's locus (every allele of a locus has the same): read through the first tabulated allele of the side
+  const hs_item_t* item = d.items + item_begin + blockIdx.x;
+  const int side = uni(item->side);
+  const hs_locus_t* loc = d.loci + uni(d.reads[d.active[d.tpack[uni(item->active)]]].locus);
+  if (uni(loc->n_short[side]) >= uni(loc->n_tab[side])) return;
+  const int oe = uni(d.str_order[uni(loc->order_off[side]) + uni(loc->n_short[side])]);
+  const int p = uni(d.stropts[d.alleles[uni(loc->hap_begin) + (oe & 0x1fffffff)].str_opt[side]].period);
+  switch (p){
+#ifdef HS_GRP_ONLYP       // compile-time experiments: one instantiation only
+    case HS_GRP_ONLYP: str_group_body_p<HS_GRP_ONLYP>(d, item_begin); break;
+#else
+    case 1: str_group_body_p<1>(d, item_begin); break;
+    case 2: str_group_body_p<2>(d, item_begin); break;
+    case 3: str_group_body_p<3>(d, item_begin); break;
+    case 4: str_group_body_p<4>(d, item_begin); break;
+    case 5: str_group_body_p<5>(d, item_begin); break;
+    case 6: str_group_body_p<6>(d, item_begin); break;
+#endif
+    default: break;                                  // prep.cpp: n_short == n_tab for longer periods
+  }
+}
+
 
 // compute_aln_logprob (HapAligner.cpp:163-231): log-sum-exp over the haplotype positions the seed base can sit on.
 // One workgroup (4 wavefronts) per active read; a wavefront takes every fourth realigned allele, so what depends on the read only

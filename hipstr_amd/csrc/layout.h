@@ -16,6 +16,7 @@
 #ifndef HS_GRP_COLS
 #define HS_GRP_COLS      256       // lanes (= read columns) of one hs_str_group_kernel workgroup; prep.cpp packs reads of a locus side up to this many columns
 #endif
+#define HS_GRP_MAXP      6         // hs_str_group_kernel_p is instantiated for the periods 1..HS_GRP_MAXP
 #define HS_NART          13        // artifact sizes -6p..+6p (RepeatStutterInfo.h:10-11)
 #define HS_MAXREP        6
 #define HS_MAX_COLS      4         // max read columns per lane in the systolic sweep of the traceback fill (trace.hip)
@@ -76,6 +77,9 @@ struct hs_stropt_t {
   // periodic, its first nd_eq repeat units add exactly the terms of del_probs_ / match_probs_, in the same order: the STR kernels
   // take those sums from the tables they already hold and only loop over the remaining (6 - nd_eq) units.  nd_eq <= nd.
   int32_t nd_eq;
+  // Base codes ((char >> 1) & 3: A, C, T, G -> 0, 1, 2, 3) of the block's last 16 bases, two bits each, the last base in bits 0-1: a
+  // tabulated block is periodic, so base t from its right end is code (t mod period) of this word (hs_str_group_kernel_p).
+  int32_t tail_codes;
 };
 
 struct hs_allele_t {
@@ -101,7 +105,18 @@ struct hs_locus_t {
   int32_t tg_count[2];
   int32_t order_off[2];      // STR-kernel processing order of the realigned alleles per side: range [order_off, +n_re) in str_order[]
   int32_t n_tab[2];          // the first n_tab positions of that order are the alleles with a tabulated closed form (hs_stropt_t::tab_len > 0)
+  int32_t n_short[2];        // ... and the first n_short <= n_tab of those have blocks of fewer than six repeat units (or a period above HS_GRP_MAXP):
+                             // hs_str_group_kernel takes them, hs_str_group_kernel_p the positions [n_short, n_tab)
+  int32_t rec_off[2];        // first record (of n_tab, in the side's order) in grp_recs[], in records
 };
+
+// hs_str_group_kernel_p reads everything an allele needs that is the same for all lanes — block length, flags, table indices, the 20
+// constants — with scalar loads from ONE record per (locus, side, position in the side's order), HS_GRP_REC_DWORDS dwords:
+//   [0] lead slot (10 bits) | tab_len << 10 (8 bits) | bit 29: block = the previous position's plus one repeat unit | bit 30: ... ends with it
+//   [1] re_ord   [2] B   [3] tail_codes   [4] tab_off (f64 pool)   [5] seq_off (char pool)
+//   [8..14] per visiting list k (0..5 deletion sizes, 6 insertions): shape U0 | tab_base << 16        [6, 7, 15] unused
+//   [16..55] 20 doubles: pmf[13] | prior_ins | prior_del[6]    [56..57] the table's smallest Bnd    [58..63] unused
+#define HS_GRP_REC_DWORDS 64
 
 struct hs_read_t {
   int32_t base_off;          // into bases/quals pools
@@ -149,6 +164,7 @@ struct hs_dev_t {
   HS_P(const hs_tgroup_t) tgroups;
   HS_P(const int32_t) tmembers;   // allele indices (within the locus) of the trail groups
   HS_P(const int32_t) tpack;      // active-read indices of the reads packed into one trail item
+  HS_P(const int32_t) grp_recs;   // hs_str_group_kernel_p: HS_GRP_REC_DWORDS dwords per tabulated position of a locus side's order (hs_locus_t::rec_off)
   HS_P(const int32_t) str_order;  // allele index (within the locus) per processing position; bit 30 set = this allele's STR block,
                                  // in side orientation, ends with the previous position's block (its tables are continued); bit 29
                                  // set = ... and is that block plus one repeat unit, periodic, with all six deletion sizes

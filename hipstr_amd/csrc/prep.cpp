@@ -302,6 +302,7 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
     while (per_len < B && blk[B-1-per_len] == blk[B-1-(per_len % period)]) per_len++;
     so.nd_eq = std::min(nd, per_len / period);
   }
+  for (int r = 0; r < 16 && r < B; r++) so.tail_codes |= (int32_t)(((uint32_t)(uint8_t)blk[B-1-r] >> 1) & 3u) << (2*r);
   so.f64_off = out.f64pool.size();
   for (int t = 0; t < HS_NART; t++){
     const int art = (t - HS_MAXREP)*period;
@@ -620,7 +621,8 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
         return a < b2;
       });
       loc.order_off[side] = out.str_order.size();
-      loc.n_tab[side] = 0;
+      loc.n_tab[side] = 0; loc.n_short[side] = 0;
+      loc.rec_off[side] = (int32_t)(out.grp_recs.size() / HS_GRP_REC_DWORDS);
       std::string prev;
       for (size_t i = 0; i < ks.size(); i++){
         const std::string cur = block_of(ks[i]);
@@ -630,7 +632,22 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
         // sums of the previous allele move up one size (hs_str_kernel)
         const bool one_unit = chained && tabbed(ks[i]) && (int)cur.size() == (int)prev.size() + period;
         out.str_order.push_back(ks[i] | (chained ? (1 << 30) : 0) | (one_unit ? (1 << 29) : 0));
-        if (tabbed(ks[i])) loc.n_tab[side]++;
+        if (tabbed(ks[i])){
+          loc.n_tab[side]++;
+          {   // the position's record for hs_str_group_kernel_p (layout.h)
+            const hs_allele_t& al = out.alleles[loc.hap_begin + ks[i]];
+            const hs_stropt_t& so = out.stropts[al.str_opt[side]];
+            int32_t rec[HS_GRP_REC_DWORDS]; memset(rec, 0, sizeof rec);
+            rec[0] = (al.lead_slot[side] & 0x3ff) | (so.tab_len << 10) | (chained ? (1 << 30) : 0) | (one_unit ? (1 << 29) : 0);
+            rec[1] = al.re_ord; rec[2] = so.B; rec[3] = so.tail_codes; rec[4] = so.tab_off; rec[5] = so.seq_off;
+            for (int k = 0; k <= HS_MAXREP; k++) rec[8 + k] = (so.shape[k] & 0xffff) | (so.tab_base[k] << 16);
+            memcpy(rec + 16, out.f64pool.data() + so.f64_off, 20*sizeof(double));
+            memcpy(rec + 56, out.f64pool.data() + so.tab_off + 3*so.tab_len, sizeof(double));
+            out.grp_recs.insert(out.grp_recs.end(), rec, rec + HS_GRP_REC_DWORDS);
+          }
+          // sorted by length: the blocks of fewer than six repeat units come first
+          if (period > HS_GRP_MAXP || (int)cur.size() < HS_MAXREP*period) loc.n_short[side]++;
+        }
         prev = cur;
       }
     }
@@ -677,10 +694,10 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
 }
 
 // Sizes of the pools of a fragment = where the next fragment starts in the merged batch.
-struct FragBase { size_t loci, alleles, stropts, rowsets, rows, visits, f64, chars, active, realign_hap, order, tgroups, tmembers, leads; };
+struct FragBase { size_t loci, alleles, stropts, rowsets, rows, visits, f64, chars, active, realign_hap, order, tgroups, tmembers, leads, recs; };
 static FragBase frag_sizes(const Prepared& f, size_t n_leads){
   return FragBase{ f.loci.size(), f.alleles.size(), f.stropts.size(), f.rowsets.size(), f.rows.size(), f.visits.size(), f.f64pool.size(), f.chars.size(),
-                   f.active.size(), f.realign_hap.size(), f.str_order.size(), f.tgroups.size(), f.tmembers.size(), n_leads };
+                   f.active.size(), f.realign_hap.size(), f.str_order.size(), f.tgroups.size(), f.tmembers.size(), n_leads, f.grp_recs.size() / HS_GRP_REC_DWORDS };
 }
 
 // Copies fragment `f` to its place in `out` (whose pools are already sized), turning fragment-local pool offsets into batch-wide
@@ -691,8 +708,9 @@ static void place_fragment(Prepared& out, Prepared& f, const FragBase& at, std::
   const int32_t chars_base = (int32_t)at.chars, tg_base = (int32_t)at.tgroups, tm_base = (int32_t)at.tmembers, order_base = (int32_t)at.order;
   for (hs_locus_t& L : f.loci){
     L.hap_begin += allele_base;
-    for (int s = 0; s < 2; s++){ L.tg_begin[s] += tg_base; L.order_off[s] += order_base; }
+    for (int s = 0; s < 2; s++){ L.tg_begin[s] += tg_base; L.order_off[s] += order_base; L.rec_off[s] += (int32_t)at.recs; }
   }
+  for (size_t r = 0; r < f.grp_recs.size(); r += HS_GRP_REC_DWORDS){ f.grp_recs[r + 4] += f64_base; f.grp_recs[r + 5] += chars_base; }
   for (hs_allele_t& a : f.alleles)
     if (a.realign) for (int s = 0; s < 2; s++){ a.lead_rows[s] += rowset_base; a.trail_rows[s] += rowset_base; a.str_opt[s] += stropt_base; }
   for (hs_rowset_t& r : f.rowsets) r.off += rows_base;

@@ -62,6 +62,7 @@ struct Prepared {
   int32_t                 grp_nd_cap = 0;  // largest (reads x 36 period) of the str_items
   std::vector<int32_t>    tpack;           // active-read indices of the packed reads
   std::vector<int32_t>    str_order;       // per locus and side: realigned alleles sorted so that nested STR blocks follow each other
+  std::vector<int32_t>    grp_recs;        // HS_GRP_REC_DWORDS dwords per tabulated position of a side's order (layout.h); a large pool like rows / f64pool
   std::vector<hs_tgroup_t> tgroups;
   std::vector<int32_t>    tmembers;
   int64_t ws_mr_size = 0, ws_lt_size = 0, ws_lead_size = 0, ws_col_size = 0;   // doubles, max over chunks
@@ -79,6 +80,7 @@ struct Prepared {
   size_t n_visits() const { size_t n = visits.size(); for (const Prepared& f : frags) n += f.visits.size(); return n; }
   size_t n_f64() const { size_t n = f64pool.size(); for (const Prepared& f : frags) n += f.f64pool.size(); return n; }
   size_t n_chars() const { size_t n = chars.size(); for (const Prepared& f : frags) n += f.chars.size(); return n; }
+  size_t n_recs() const { size_t n = grp_recs.size(); for (const Prepared& f : frags) n += f.grp_recs.size(); return n; }
 };
 
 // Returns 0 on success; otherwise fills err.

@@ -131,7 +131,9 @@ void worker_loop(hipstr_stream* s){
       // work = a batch that was sent, or — when a collector is waiting for a ticket that still sits in the pending batch — the pending
       // batch as it is: whatever accumulated while the previous batch was being prepared goes out together
       auto have_work = [&]{ return !s->ready.empty() || (s->waiting > 0 && s->pending && !s->pending->tickets.empty()); };
-      s->cv_work.wait(g, [&]{ return s->closing || (have_work() && (int)s->flying.size() + s->in_worker < s->slots); });
+      // `slots` bounds the batches in flight — unless a collector waits for a ticket that is not launched yet while every slot is held
+      // by batches with uncollected EARLIER tickets (tickets may be taken in any order): then the batch goes out all the same
+      s->cv_work.wait(g, [&]{ return s->closing || (have_work() && ((int)s->flying.size() + s->in_worker < s->slots || s->waiting > 0)); });
       if (s->closing) return;
       if (s->ready.empty()) flush_locked(s);
       ob = s->ready.front(); s->ready.pop_front(); s->in_worker++;
@@ -278,17 +280,20 @@ int hipstr_stream_take(hipstr_stream_t* s, int64_t ticket, double* aln_probs, in
       }
       if (f) break;
       // not launched yet: tell the worker somebody is waiting (it sends the pending batch as soon as it is free), then wait for it
+      if (s->closing) return hipstr::api_fail("stream is closing");
       s->waiting++;
       s->cv_work.notify_one();
       s->cv_done.wait(g);
       s->waiting--;
+      if (s->closing){ s->cv_done.notify_all(); return hipstr::api_fail("stream is closing"); }
     }
     if (f->taken[idx]) return hipstr::api_fail("ticket was collected already");
+    f->taken[idx] = 2;               // claimed: a second collector of the same ticket is turned away while this one copies
     f->busy++;
   }
   const OwnedBatch::Ticket& t = f->ob->tickets[idx];
   int rc = 0; bool small = false;
-  if (t.out1 - t.out0 > cap_probs || t.r1 - t.r0 > cap_seeds){ rc = hipstr::api_fail("output buffers are too small for this ticket (hipstr_stream_next_size)"); small = true; }
+  if (t.out1 - t.out0 > cap_probs || t.r1 - t.r0 > cap_seeds){ hipstr::api_fail("output buffers are too small for this ticket (hipstr_stream_next_size)"); rc = 3; small = true; }
   else {
     {
       std::lock_guard<std::mutex> lg(f->land_m);
@@ -318,7 +323,8 @@ int hipstr_stream_take(hipstr_stream_t* s, int64_t ticket, double* aln_probs, in
   {
     std::lock_guard<std::mutex> g(s->m);
     f->busy--;
-    if (!small){          // a failed batch consumes its tickets too; only "buffer too small" leaves the ticket for another try
+    if (small) f->taken[idx] = 0;        // "buffers too small" (return code 3) leaves the ticket for another try; a failed batch consumes its tickets
+    else {
       f->taken[idx] = 1; f->n_taken++;
       s->stats.tickets++;
       if (ticket == s->next_deliver){
@@ -364,11 +370,14 @@ int hipstr_stream_stats(hipstr_stream_t* s, hipstr_stream_stats_t* out){
 int hipstr_stream_close(hipstr_stream_t* s){
   if (!s) return 0;
   {
-    std::lock_guard<std::mutex> g(s->m);
+    std::unique_lock<std::mutex> g(s->m);
     s->closing = true;
     for (OwnedBatch* ob : s->ready) delete ob;          // undelivered work is dropped
     s->ready.clear();
     delete s->pending; s->pending = NULL;
+    // collectors blocked on a ticket that will never be launched return with an error before the stream goes away
+    s->cv_done.notify_all();
+    s->cv_done.wait(g, [&]{ return s->waiting == 0; });
   }
   s->cv_work.notify_all();
   if (s->worker.joinable()) s->worker.join();
@@ -448,8 +457,9 @@ int hipstr_multi_next(hipstr_multi_t* mm, int64_t* ticket, double* aln_probs, in
   { std::lock_guard<std::mutex> g(mm->m); if (mm->owner.empty()) return 2; slot = mm->owner.front(); t = mm->next_ticket - (int64_t)mm->owner.size(); }
   const int rc = hipstr_stream_next(mm->streams[slot], NULL, aln_probs, cap_probs, seeds, cap_seeds);     // that device's next = the globally next
   if (rc == 2) return hipstr::api_fail("internal error: device stream has nothing outstanding");
-  { std::lock_guard<std::mutex> g(mm->m); mm->owner.pop_front(); }
   if (ticket) *ticket = t;
+  if (rc == 3) return rc;               // buffers too small: the device stream kept the ticket, so does the owner queue (retry with larger ones)
+  { std::lock_guard<std::mutex> g(mm->m); if (!mm->owner.empty()) mm->owner.pop_front(); }
   return rc;
 }
 

@@ -31,6 +31,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The functions declared here — and nothing else — are the library's ABI: libhipstr_hmm.so is built with -fvisibility=hidden. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define HIPSTR_NUM_BLOCKS        3   /* Haplotype.cpp:12 */
 #define HIPSTR_MAX_STUTTER_REPS  6   /* RepeatStutterInfo.h:10-11 (MAX_STUTTER_REPEAT_INS / _DEL) */
@@ -201,12 +205,16 @@ int hipstr_stream_flush(hipstr_stream_t* s);
 int hipstr_stream_next_size(hipstr_stream_t* s, int64_t* ticket, int64_t* n_out, int64_t* n_reads);
 /* Blocks until the next submission (in submission order) is done and writes its results exactly as hipstr_hmm_process_reads
  * would have for that submission alone: aln_probs / seeds laid out as hipstr_batch_out_offsets of the submitted batch, entries of
- * reads / haplotypes that were not realigned left untouched.  Returns 0, 1 on error, 2 when nothing is outstanding. */
+ * reads / haplotypes that were not realigned left untouched.  Returns 0, 1 on error (the submission is consumed: its batch failed),
+ * 2 when nothing is outstanding, 3 when the buffers are too small for it (hipstr_stream_next_size) — the submission stays
+ * outstanding and the call can be repeated with larger ones. */
 int hipstr_stream_next(hipstr_stream_t* s, int64_t* ticket, double* aln_probs, int64_t cap_probs, int32_t* seeds, int64_t cap_seeds);
 /* Collects ONE submission by its ticket, in any order (each ticket once): blocks until its batch has run.  For callers that keep
  * many loci in flight, one host thread per locus: SeqStutterGenotyper::genotype is a per-locus state machine (align, posteriors,
  * tracebacks, new alleles, align only those ... seq_stutter_genotyper.cpp:603-671), and the rounds of different loci share batches.
- * hipstr_stream_next(s, ...) == hipstr_stream_take(s, lowest ticket not collected yet, ...). */
+ * hipstr_stream_next(s, ...) == hipstr_stream_take(s, lowest ticket not collected yet, ...), same return codes.  A ticket whose batch
+ * has not been launched yet is sent out even when all `slots` are held by batches with uncollected earlier tickets; two collectors
+ * asking for the same ticket: the second is refused; hipstr_stream_close makes blocked collectors return with an error. */
 int hipstr_stream_take(hipstr_stream_t* s, int64_t ticket, double* aln_probs, int64_t cap_probs, int32_t* seeds, int64_t cap_seeds);
 int hipstr_stream_stats(hipstr_stream_t* s, hipstr_stream_stats_t* out);
 /* Drops whatever has not been delivered and releases the stream. */
@@ -461,6 +469,9 @@ int hipstr_debug_simple_table(int bound, int U0, int tail, double entry[3]);
 
 const char* hipstr_last_error(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

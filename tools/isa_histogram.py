@@ -52,8 +52,8 @@ for src in ("hmm_kernels.hip", "post_kernels.hip"):
         if not m:
             continue
         body = m.group(1)
-        short = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", name)
-        short = re.sub(r"ILi(\d+)EE.*$", r"<\1>", short) if "ILi" in short else re.sub(r"EPK.*$", "", short)
+        # the key is the name rocprofv3 reports, without namespaces and arguments: hs_trail_kernel_coop<15, 4, 3> (tools/sq_counters.py key_of)
+        short = subprocess.check_output(["c++filt", name]).decode().strip().split("::")[-1].split("(")[0]
         mn = collections.Counter()
         cls = collections.Counter()
         for line in body.split("\n"):

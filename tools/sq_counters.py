@@ -63,7 +63,11 @@ for k in sorted(k1):
     if not dur:
         continue
     valu = c.get("SQ_INSTS_VALU", 0.0)
-    h = hist.get(k, {})
+    h = hist.get(k)
+    if h is None:
+        # without the static histogram the FP64 maxima are not counted and every other instruction is priced at 4 cycles: refuse instead
+        sys.exit("tools/sq_counters.py: no static instruction histogram for kernel %r in %s (keys: %s) — regenerate it with tools/isa_histogram.py"
+                 % (k, hfiles[-1] if hfiles else "profiles/", ", ".join(sorted(hist))))
     f64_counted = c.get("SQ_INSTS_VALU_ADD_F64", 0.0) + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) + c.get("SQ_INSTS_VALU_FMA_F64", 0.0)
     f64 = f64_counted * (1.0 + h.get("fp64_maxmin_per_addmulfma", 0.0))
     rest = max(valu - f64, 0.0)
