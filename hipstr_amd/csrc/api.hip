@@ -217,6 +217,7 @@ struct hipstr_dev_batch {
   std::vector<void*> dev_blocks, pin_blocks;      // from the context's caches
   int grid_y = 1, max_alleles = 1, n_lead_items = 0, n_trail_items = 0, trail_waves = 1;
   size_t grp_lds_bytes = 0;
+  bool any_short = false;        // some locus has tabulated alleles hs_str_group_kernel_p does not take (period above HS_GRP_MAXP)
   size_t lds_bytes = 0;
   hipEvent_t ev0 = NULL, ev1 = NULL;
   hipEvent_t ev_h2d = NULL, ev_done = NULL, ev_d2h = NULL;     // upload finished / last pass finished / results in host_out (pipelined use)
@@ -432,6 +433,8 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   dev->lds_bytes = hs_str_lds_bytes(h.lds_len, h.max_B);
   if (dev->lds_bytes > 160*1024){ g_err = "batch needs more than 160 KiB of LDS per workgroup"; hipstr_hmm_free(dev); return NULL; }
   h.grp_nd_cap = std::max(2, (P.grp_nd_cap + 1) & ~1);
+  dev->any_short = false;
+  for (const hs_locus_t& l : P.loci) dev->any_short |= (l.n_short[0] > 0 || l.n_short[1] > 0);
   dev->grp_lds_bytes = hs_str_group_lds_bytes(h.max_B, h.grp_nd_cap);
   if (getenv("HIPSTR_TIMING")) fprintf(stderr, "hipstr_hmm_upload: STR group kernel LDS %zu bytes (max block %d, read-end table %d doubles, %zu groups)\n", dev->grp_lds_bytes, h.max_B, h.grp_nd_cap, P.str_items.size());
   if (dev->grp_lds_bytes > 48*1024){
@@ -556,8 +559,9 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
       if (ch.str_end > ch.str_begin){
         if (group_p) hipLaunchKernelGGL(hs_str_group_kernel_p, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), dev->grp_lds_bytes, st, dp,
                                         dev->n_lead_items + dev->n_trail_items + ch.str_begin);
-        hipLaunchKernelGGL(hs_str_group_kernel, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), dev->grp_lds_bytes, st, dp,
-                           dev->n_lead_items + dev->n_trail_items + ch.str_begin, group_p ? 1 : 0);
+        if (!group_p || dev->any_short)      // (periods above HS_GRP_MAXP only, once hs_str_group_kernel_p is on)
+          hipLaunchKernelGGL(hs_str_group_kernel, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), dev->grp_lds_bytes, st, dp,
+                             dev->n_lead_items + dev->n_trail_items + ch.str_begin, group_p ? 1 : 0);
       }
       if (ch.n_long_sides > 0)        // sides with more columns than a group holds: one workgroup per read as before
         hipLaunchKernelGGL(hs_str_kernel, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin, 1);

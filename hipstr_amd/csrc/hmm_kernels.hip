@@ -2038,23 +2038,33 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
     // --- StutterAlignerClass::load_read (StutterAlignerClass.cpp:12-53): match_probs_ and del_probs_ of this lane's column.  Row q of the
     // deletion table also takes the truncated sum of a column closer than (q+1)P to the read start (the running value no longer changes
     // there): that is ins_probs_[q] of the column (StutterAlignerClass.cpp:40-51), and the deletions only read rows of columns >= (q+1)P
+    // Where a chain of alleles starts (t0 = 0) the six rows are built in 6P steps whatever the block length, the block base cycling through
+    // the block's last P bases (that is how ins_probs_ continues past a block of fewer than six units, and in a periodic block it is the
+    // base itself), match_probs_ being the running value after min(B, j + 1) steps; a block that continues the previous one only adds steps.
     const int t0 = chained ? prev_B : 0;
     prev_B = B;
-    const int tmax = min(B, max(jmaxw + 1, SIXP));          // B >= SIXP here: every row of the deletion table is reached
-    if (wave_act && t0 < tmax && HS_PEXP != 3){
+    const int nv = min(HS_MAXREP, B / P);                   // deletion sizes the block holds (num_deletions_, StutterAlignerClass.h:64-69)
+    const int tmax = min(B, jmaxw + 1);
+    if (wave_act && (t0 == 0 || t0 < tmax) && HS_PEXP != 3){
       double lp = (t0 > 0) ? lds[oMt + xrp] : 0.0;
       int t = t0;
-      if (t < SIXP){
-        int col = xx - t;
-        int left = j - t, ph = (t + 1) % P;
-        int dl = oDl + ((t + 1)/P - 1)*XC + xx;
-        for (; t < SIXP; t++){
-          const double e = Eat(col, boff[B-1-t]);
-          if (left >= 0) lp += e;
-          if (ph == 0){ if (actj) lds[dl] = lp; }
-          ph++; if (ph == P){ ph = 0; dl += XC; }
-          col--; left--;
+      if (t0 == 0){
+        double lpB = 0.0;
+        int col = xx, left = j, dl = oDl + xx;
+#pragma unroll 1
+        for (int u = 0; u < HS_MAXREP; u++){
+#pragma unroll
+          for (int r = 0; r < P; r++){
+            const double e = Eat(col, boff[B-1-r]);
+            if (left >= 0) lp += e;
+            if (u*P + r + 1 == B) lpB = lp;                 // (wave-uniform) the block ends here: match_probs_
+            col--; left--;
+          }
+          if (actj) lds[dl] = lp;
+          dl += XC;
         }
+        if (B <= SIXP) lp = lpB;
+        t = (B > SIXP) ? SIXP : B;                          // B > 6P: the sum goes on from step 6P;  else it is complete
       }
       auto steps = [&](int tend, auto masked){
         int xr = xx - t - 3, xb = B - 1 - t - 3;
@@ -2145,7 +2155,7 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
       if (all_long){
         const int Gp = G*P;
         if (reuse_al){
-          const int n_sums = HS_MAXREP*Gp;
+          const int n_sums = nv*Gp;
           const float rc_gp = __builtin_amdgcn_rcpf((float)Gp);
           for (int base = 0; base < n_sums; base += NT){
             if (base + (xw & ~63) >= n_sums) continue;
@@ -2155,7 +2165,7 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
             nd_sum(q, s_off[hh] + jcol, jcol, base + xw < n_sums, hh*NDS + slot_of(q) + ((q+1)*P - 1 - off));
           }
         } else {
-          const int n_sums = G*row_off(HS_MAXREP);
+          const int n_sums = G*row_off(nv);
           for (int base = 0; base < n_sums; base += NT){
             if (base + (xw & ~63) >= n_sums) continue;
             const int e = min(base + xw, n_sums - 1);
@@ -2171,11 +2181,11 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
       } else {
         int c_l = 0;
         {
-          const bool ru = reuse_al && (nh_l >= SIXP);
+          const bool ru = reuse_al && (nh_l >= nv*P);
           int np_l = 0;
 #pragma unroll
-          for (int q = 0; q < HS_MAXREP; q++) np_l += min((q+1)*P, nh_l);
-          if (lane < G) c_l = ru ? SIXP : np_l;
+          for (int q = 0; q < HS_MAXREP; q++) np_l += (q < nv) ? min((q+1)*P, nh_l) : 0;
+          if (lane < G) c_l = ru ? nv*P : np_l;
         }
         int pc = c_l;
 #pragma unroll
@@ -2198,7 +2208,7 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
           const bool valid = base + xw < n_sums;
           int hh, loc_e; find(pc, e, hh, loc_e);
           const int nh = s_n[hh], offh = s_off[hh];
-          const bool ruh = reuse_al && (nh >= SIXP);
+          const bool ruh = reuse_al && (nh >= nv*P);
           int q = 0, off = loc_e, jcol, dst;
           if (ruh){
 #pragma unroll
@@ -2208,7 +2218,7 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
           } else {
             int cnt[HS_MAXREP];
 #pragma unroll
-            for (int qq = 0; qq < HS_MAXREP; qq++) cnt[qq] = min((qq+1)*P, nh);
+            for (int qq = 0; qq < HS_MAXREP; qq++) cnt[qq] = (qq < nv) ? min((qq+1)*P, nh) : 0;
 #pragma unroll
             for (int qq = 0; qq < HS_MAXREP - 1; qq++) if (q == qq && off >= cnt[qq]){ off -= cnt[qq]; q = qq + 1; }
             jcol = max(0, nh - (q+1)*P) + off;
@@ -2275,6 +2285,7 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
 #pragma unroll
       for (int q = 0; q < HS_MAXREP; q++){                 // deletion of aD = (q+1) P (StutterAlignerClass.cpp:106-150)
         const int aD = (q+1)*P;
+        if (q >= nv){ terms[HS_MAXREP - 1 - q] = IMP; continue; }          // (wave-uniform) the block is shorter than this deletion (HapAligner.cpp:75-77)
         const int len8 = min(B8 - 8*aD, j8p8);
         // column j + |D|: past the read end the values are another read's (or nothing's) and not used
         const double dsum = ldb(8*oMt + 8*aD + aM) - ldb(8*oDl + 8*q*XC + 8*aD + aCol);

@@ -105,8 +105,8 @@ struct hs_locus_t {
   int32_t tg_count[2];
   int32_t order_off[2];      // STR-kernel processing order of the realigned alleles per side: range [order_off, +n_re) in str_order[]
   int32_t n_tab[2];          // the first n_tab positions of that order are the alleles with a tabulated closed form (hs_stropt_t::tab_len > 0)
-  int32_t n_short[2];        // ... and the first n_short <= n_tab of those have blocks of fewer than six repeat units (or a period above HS_GRP_MAXP):
-                             // hs_str_group_kernel takes them, hs_str_group_kernel_p the positions [n_short, n_tab)
+  int32_t n_short[2];        // hs_str_group_kernel_p takes the positions [n_short, n_tab) of that order, hs_str_group_kernel the first n_short:
+                             // all n_tab of them where the period is above HS_GRP_MAXP, none otherwise
   int32_t rec_off[2];        // first record (of n_tab, in the side's order) in grp_recs[], in records
 };
 

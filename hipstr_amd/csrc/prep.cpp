@@ -645,8 +645,7 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
             memcpy(rec + 56, out.f64pool.data() + so.tab_off + 3*so.tab_len, sizeof(double));
             out.grp_recs.insert(out.grp_recs.end(), rec, rec + HS_GRP_REC_DWORDS);
           }
-          // sorted by length: the blocks of fewer than six repeat units come first
-          if (period > HS_GRP_MAXP || (int)cur.size() < HS_MAXREP*period) loc.n_short[side]++;
+          if (period > HS_GRP_MAXP) loc.n_short[side]++;              // no instantiation of hs_str_group_kernel_p for this period
         }
         prev = cur;
       }
