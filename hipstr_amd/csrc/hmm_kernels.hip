@@ -1916,7 +1916,6 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
   int* const s_off = (int*)(boff0 + 2*blk_len);                       // [HS_GRP_MAXREADS + 1] first column of every read | [..] columns | [..] active-read index
   int* const s_n = s_off + (HS_GRP_MAXREADS + 1);
   int* const s_ai = s_n + HS_GRP_MAXREADS;
-  for (int i = x; i < blk_len + 64; i += NT) boff0[i - blk_len - 64] = 0;
   // LDS reads by byte ADDRESS: lds0 (the address of the carve: 0, there is no static LDS in this kernel — but it is not assumed) is part of
   // every per-lane and per-allele base below, so that an access is one ds_read with an immediate offset and no addition of the base
   const int lds0 = (int)(uintptr_t)(__attribute__((address_space(3))) char*)hs_lds_raw;
@@ -1967,7 +1966,16 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
   int aM = lds0 + 8*xrp;                               // + 8 oRowP - 8 len: M of column j - len before the block, or the 0.0 in front of the read;  + 8 oMt: match_probs_ of this column
   int aCol = lds0 + 8*xx;                              // + 8 oDl + q XC 8: del_probs_[q] of this column
   int aZ = lds0 + 8*(offg + g);                        // the 0.0 in front of this lane's read (rowP and match_probs_ alike)
-  const int aNd = lds0 + 8*(oNd + g*NDS + min(rj, SIXP - 1));                 // + 8 SIXP slot: this column's read-end sum of the size in that slot
+  const int aNd = lds0 + 8*(oNd + g*NDS + min(rj, SIXP - 1));
+#ifndef HS_PHOIST
+#define HS_PHOIST 1        // the insertions' two allele-independent lane values per size kept in registers (12) instead of recomputed per allele (3 operations each)
+#endif
+  int aInsM[HS_MAXREP], c8[HS_MAXREP];
+#pragma unroll
+  for (int q = 0; q < HS_MAXREP; q++){
+    aInsM[q] = 8*oMt + max(aM - 8*(q+1)*P, aZ);       // match_probs_ of column j - D if the segment is longer than the insertion (StutterAlignerClass.cpp:66), else the 0.0 in front of the read
+    c8[q] = max(j8p8 - 8*(q+1)*P, 0);                 // 8 max(0, j + 1 - D)
+  }                 // + 8 SIXP slot: this column's read-end sum of the size in that slot
   // ---- what an allele needs that is the same for every lane comes from its record (layout.h HS_GRP_REC_DWORDS) by scalar loads: the header of
   // the NEXT allele while this one is evaluated (its table and block are requested one allele ahead), the constants when they are needed
   typedef int hs_i16v __attribute__((ext_vector_type(16)));
@@ -1978,42 +1986,38 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
   auto rec_addr = [&](int i){ return (uint64_t)(uintptr_t)(recs + (int64_t)i*HS_GRP_REC_DWORDS); };
   // (the scalar loads below are inline assembly, several per block: their destinations are early-clobber operands, or the first load's
   // destination may be given the registers that hold the address the following loads still need)
-  auto load_header = [&](int i) -> hs_i8v_ {
-    hs_i8v_ hd; const uint64_t ra = rec_addr(i);
-    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(hd) : "s"(ra) : "memory");
+  // The header (four dwords) of the allele after the next is requested while this one is worked on, together with one dword of each
+  // of the record's other three cache lines: by the time the constants are wanted they sit in the scalar cache (a miss costs a trip to
+  // L2 at each of the three places that wait for them, with all four wavefronts of the workgroup waiting at the same time).
+  auto load_header = [&](int i) -> hs_i4v_ {
+    hs_i4v_ hd; const uint64_t ra = rec_addr(i);
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(hd) : "s"(ra) : "memory");
     return hd;
   };
-  double nx_tab = 0.0; int nx_blkw = 0;               // lanes 0.. of wavefront 0 the table's A, of wavefront 1 its G;  the block, four bases per lane
-  auto request = [&](const hs_i8v_& hd){
-    const int tl = (hd[0] >> 10) & 0xff, Bk = hd[2];
-    const double* tsrc = d.f64pool + hd[4];
-    nx_blkw = (x < (Bk + 3)/4) ? ((const int*)(d.chars + hd[5]))[x] : 0;
+  double nx_tab = 0.0;                                // lanes 0.. of wavefront 0 the table's A, of wavefront 1 its G
+  auto request = [&](const hs_i4v_& hd){
+    const int tl = (hd[0] >> 10) & 0xff;
+    const double* tsrc = d.f64pool + hd[3];
     if (lane < tl && x < 128) nx_tab = tsrc[3*lane + (x >> 6)];
   };
-  hs_i8v_ hd_next = load_header(i0);
-  request(hd_next);
+  hs_i4v_ hd_cur = load_header(i0), hd_nx1 = load_header(min(i0 + 1, i1 - 1));
+  request(hd_cur);
   int cur_slot = -1, prev_B = 0, nd_base = 0;
 #ifdef HS_GTIME
   unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #endif
   for (int i = i0; i < i1; i++){
     const int par = (i - i0) & 1;
-    const hs_i8v_ hd = hd_next;
+    const hs_i4v_ hd = hd_cur;
     const bool chained = (i > i0) && ((hd[0] >> 30) & 1);
     const int slot = hd[0] & 0x3ff, re_ord = hd[1];
     double* const mr_out = mr_base + (int64_t)re_ord*lenm1;
-    const int B = hd[2], tab_len = (hd[0] >> 10) & 0xff;
-    const int tail = hd[3];
+    const int B = hd[2] >> 12, tab_len = (hd[0] >> 10) & 0xff;
+    const int tail = hd[2] & 0xfff;
     if (slot != cur_slot){
       __syncthreads();
       if (actj) lds[oRowP + xrp] = lead_base[(int64_t)slot*lead_stride];
       cur_slot = slot;
-    }
-    if (x < (B + 3)/4){
-      int2 bo;
-      bo.x = (((nx_blkw >> 1) & 3) * (XC*8)) | ((((nx_blkw >> 9) & 3) * (XC*8)) << 16);
-      bo.y = (((nx_blkw >> 17) & 3) * (XC*8)) | ((((nx_blkw >> 25) & 3) * (XC*8)) << 16);
-      ((int2*)(boff0 + par*blk_len))[x] = bo;
     }
     if (lane < tab_len && x < 128) lds[oTab + par*2*HS_TAB_CAP + (x >> 6)*HS_TAB_CAP + lane] = nx_tab;
     if (x < 64){       // the position priors of the six deletion sizes (StutterAlignerClass.cpp:112; record dwords 44..55): the read-end sums start from them, each lane from its size's
@@ -2028,12 +2032,17 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
       if (x == 4) pdl[4] = __hiloint2double(pdB[1], pdB[0]);
       if (x == 5) pdl[5] = __hiloint2double(pdB[3], pdB[2]);
     }
-    if (i + 1 < i1){ hd_next = load_header(i + 1); request(hd_next); }
+    if (i + 1 < i1) request(hd_nx1);
+    hs_i4v_ hd_nx2; int touch1, touch2, touch3;
+    { const uint64_t ra2 = rec_addr(min(i + 2, i1 - 1));
+      asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0"
+                   : "=&s"(hd_nx2), "=&s"(touch1), "=&s"(touch2), "=&s"(touch3) : "s"(ra2) : "memory"); }
     HS_TICK(0);   // evaluation of the previous allele + setup
     __syncthreads();
     HS_TICK(1);   // barrier 1 wait
-    const uint16_t* boff = boff0 + par*blk_len;
-    auto Eat = [&](int col, int bo) -> double { return ldb(lds0 + 8*oE + col*8 + bo); };
+    // plane (byte offset into the emission table) of the block base r = t mod P from the right end — the block is periodic, so that is
+    // base t from the right end: a scalar, extracted from the record's tail codes where it is used
+    auto spk = [&](int r) -> int { return ((tail >> (2*r)) & 3) * (XC*8); };
 
     // --- StutterAlignerClass::load_read (StutterAlignerClass.cpp:12-53): match_probs_ and del_probs_ of this lane's column.  Row q of the
     // deletion table also takes the truncated sum of a column closer than (q+1)P to the read start (the running value no longer changes
@@ -2050,42 +2059,48 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
       int t = t0;
       if (t0 == 0){
         double lpB = 0.0;
-        int col = xx, left = j, dl = oDl + xx;
+        int cb = lds0 + 8*(oE + xx - (P - 1)), left = j, dl = oDl + xx;
 #pragma unroll 1
         for (int u = 0; u < HS_MAXREP; u++){
+          double e[P];
+#pragma unroll
+          for (int r = 0; r < P; r++) e[r] = ldb(cb + spk(r) + 8*(P - 1 - r));
 #pragma unroll
           for (int r = 0; r < P; r++){
-            const double e = Eat(col, boff[B-1-r]);
-            if (left >= 0) lp += e;
+            if (left - r >= 0) lp += e[r];
             if (u*P + r + 1 == B) lpB = lp;                 // (wave-uniform) the block ends here: match_probs_
-            col--; left--;
           }
+          cb -= 8*P; left -= P;
           if (actj) lds[dl] = lp;
           dl += XC;
         }
         if (B <= SIXP) lp = lpB;
         t = (B > SIXP) ? SIXP : B;                          // B > 6P: the sum goes on from step 6P;  else it is complete
       }
-      auto steps = [&](int tend, auto masked){
-        int xr = xx - t - 3, xb = B - 1 - t - 3;
-        for (; t + 4 <= tend; t += 4){
-          asm volatile("" : "+v"(xr));
-#pragma unroll
-          for (int k = 0; k < 4; k++){
-            const double e = Eat(xr + 3 - k, boff[xb + 3 - k]);
-            if (!decltype(masked)::value || xr + 3 - k >= offg) lp += e;
-          }
-          xr -= 4; xb -= 4;
-        }
-        for (; t < tend; t++){
-          const double e = Eat(xr + 3, boff[xb + 3]);
-          if (!decltype(masked)::value || xr + 3 >= offg) lp += e;
-          xr--; xb--;
-        }
-      };
       if (t < tmax){
-        steps(min(tmax, jminw + 1), std::false_type());
-        steps(tmax, std::true_type());
+        // steps t .. tmax-1 in units of P: step t + r pairs with base (t + r) mod P from the right end = code r of the tail rotated by t mod P
+        const int rem = t % P;
+        const int t2 = tail & ((1 << (2*P)) - 1);
+        const int tailR = (t2 | (t2 << (2*P))) >> (2*rem);
+        auto spR = [&](int r) -> int { return ((tailR >> (2*r)) & 3) * (XC*8); };
+        int cb = lds0 + 8*(oE + xx - t - (P - 1)), left = j - t;
+        const int t_all = min(tmax, jminw + 1);             // up to here every lane of the wavefront has the column
+        for (; t + P <= t_all; t += P){
+          double e[P];
+#pragma unroll
+          for (int r = 0; r < P; r++) e[r] = ldb(cb + spR(r) + 8*(P - 1 - r));
+#pragma unroll
+          for (int r = 0; r < P; r++) lp += e[r];
+          cb -= 8*P; left -= P;
+        }
+        for (; t < tmax; t += P){
+          double e[P];
+#pragma unroll
+          for (int r = 0; r < P; r++) e[r] = ldb(cb + spR(r) + 8*(P - 1 - r));
+#pragma unroll
+          for (int r = 0; r < P; r++) if (left - r >= 0 && t + r < tmax) lp += e[r];
+          cb -= 8*P; left -= P;
+        }
       }
       if (actj) lds[oMt + xrp] = lp;
     }
@@ -2093,8 +2108,6 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
     HS_TICK(2);   // table phase
     // --- deletion start values of the columns whose segment reaches the read end (the `else` branch of StutterAlignerClass.cpp:117-120)
     {
-      // plane (byte offset into the emission table) of the block base t mod P from the right end: a scalar, extracted where it is used
-      auto spk = [&](int r) -> int { return ((tail >> (2*r)) & 3) * (XC*8); };
       const int aPd = lds0 + 8*(oCst + par*8);
       auto nd_sum = [&](int q, int xcol, int jcol, bool valid, int dst){
         const int aD = (q+1)*P;
@@ -2271,8 +2284,8 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
         const int len8 = min(B8 + D8, j8p8);
         const double li = ldb(8*oDl + 8*q*XC + aCol);      // ins_probs_[q] of this column (table phase above)
         // match_probs_ of column j - D if the segment is longer than the insertion (StutterAlignerClass.cpp:66), else the 0.0 in front of the read
-        const double lp0 = (prior_ins + li) + ldb(8*oMt + max(aM - D8, aZ));
-        const int lim8 = min(max(j8p8 - D8, 0), B8);       // min(max(0, len - D), B)
+        const double lp0 = (prior_ins + li) + (HS_PHOIST ? ldb(aInsM[q]) : ldb(8*oMt + max(aM - D8, aZ)));
+        const int lim8 = min(HS_PHOIST ? c8[q] : max(j8p8 - D8, 0), B8);       // min(max(0, len - D), B)
         const double S = tab_eval(lp0, lim8, HS_MAXREP);
         terms[HS_MAXREP + 1 + q] = (pmf_hi(HS_MAXREP + 1 + q) + S) + ldb(8*oRowP + aM - len8);
         __builtin_amdgcn_sched_barrier(0);                // one term at a time: the scheduler otherwise requests every table value of the 13 terms up front, in more registers than there are
@@ -2305,13 +2318,21 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
         for (int t = 1; t < HS_NART; t++) mx = fmax(mx, terms[t]);
         // fast_log_sum_exp (mathops.cpp:97-106), branch-free.  A term that passes the threshold has 1.44 dd > -10: fasterexp's clamp at -126
         // (fastonebigheader.h:210) cannot act on it and is left out; a term that does not contributes 0.0, whatever its bits would have been
+        // (two terms per float operation: packed multiplies and adds, each rounded on its own like the scalar ones)
+        typedef float hs_f2 __attribute__((ext_vector_type(2)));
         double tot = 0.0;
 #pragma unroll
-        for (int t = 0; t < HS_NART; t++){
-          const double dd = terms[t] - mx;
-          const float z = __fmul_rn(8388608.0f, __fadd_rn(__fmul_rn(1.442695040f, (float)dd), 126.94269504f));
-          const float fe = (dd > d.log_thresh) ? __uint_as_float(__float2uint_rz(z)) : 0.0f;
-          tot += (double)fe;
+        for (int t = 0; t < HS_NART; t += 2){
+          const int t1 = (t + 1 < HS_NART) ? t + 1 : t;
+          const double dd0 = terms[t] - mx, dd1 = terms[t1] - mx;
+          hs_f2 x; x.x = (float)dd0; x.y = (float)dd1;
+          const hs_f2 z = (x * 1.442695040f + 126.94269504f) * 8388608.0f;
+          const float fe0 = (dd0 > d.log_thresh) ? __uint_as_float(__float2uint_rz(z.x)) : 0.0f;
+          tot += (double)fe0;
+          if (t + 1 < HS_NART){
+            const float fe1 = (dd1 > d.log_thresh) ? __uint_as_float(__float2uint_rz(z.y)) : 0.0f;
+            tot += (double)fe1;
+          }
         }
         if (actj) mr_out[0] = mx + (double)f_fasterlog((float)tot);
       } else if (actj){
@@ -2319,6 +2340,8 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
         d.redo[ai] = 1;
       }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(hd_nx2), "+s"(touch1), "+s"(touch2), "+s"(touch3) :: "memory");      // (long since there)
+    hd_cur = hd_nx1; hd_nx1 = hd_nx2;
   }
 #ifdef HS_GTIME
   { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[0] += now_ - tprev; }

@@ -113,8 +113,8 @@ struct hs_locus_t {
 // hs_str_group_kernel_p reads everything an allele needs that is the same for all lanes — block length, flags, table indices, the 20
 // constants — with scalar loads from ONE record per (locus, side, position in the side's order), HS_GRP_REC_DWORDS dwords:
 //   [0] lead slot (10 bits) | tab_len << 10 (8 bits) | bit 29: block = the previous position's plus one repeat unit | bit 30: ... ends with it
-//   [1] re_ord   [2] B   [3] tail_codes   [4] tab_off (f64 pool)   [5] seq_off (char pool)
-//   [8..14] per visiting list k (0..5 deletion sizes, 6 insertions): shape U0 | tab_base << 16        [6, 7, 15] unused
+//   [1] re_ord   [2] tail_codes (12 bits: six bases) | B << 12   [3] tab_off (f64 pool)
+//   [8..14] per visiting list k (0..5 deletion sizes, 6 insertions): shape U0 | tab_base << 16        [4..7, 15] unused
 //   [16..55] 20 doubles: pmf[13] | prior_ins | prior_del[6]    [56..57] the table's smallest Bnd    [58..63] unused
 #define HS_GRP_REC_DWORDS 64
 

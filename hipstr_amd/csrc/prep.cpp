@@ -639,7 +639,7 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
             const hs_stropt_t& so = out.stropts[al.str_opt[side]];
             int32_t rec[HS_GRP_REC_DWORDS]; memset(rec, 0, sizeof rec);
             rec[0] = (al.lead_slot[side] & 0x3ff) | (so.tab_len << 10) | (chained ? (1 << 30) : 0) | (one_unit ? (1 << 29) : 0);
-            rec[1] = al.re_ord; rec[2] = so.B; rec[3] = so.tail_codes; rec[4] = so.tab_off; rec[5] = so.seq_off;
+            rec[1] = al.re_ord; rec[2] = (so.tail_codes & 0xfff) | (so.B << 12); rec[3] = so.tab_off;
             for (int k = 0; k <= HS_MAXREP; k++) rec[8 + k] = (so.shape[k] & 0xffff) | (so.tab_base[k] << 16);
             memcpy(rec + 16, out.f64pool.data() + so.f64_off, 20*sizeof(double));
             memcpy(rec + 56, out.f64pool.data() + so.tab_off + 3*so.tab_len, sizeof(double));
@@ -709,7 +709,7 @@ static void place_fragment(Prepared& out, Prepared& f, const FragBase& at, std::
     L.hap_begin += allele_base;
     for (int s = 0; s < 2; s++){ L.tg_begin[s] += tg_base; L.order_off[s] += order_base; L.rec_off[s] += (int32_t)at.recs; }
   }
-  for (size_t r = 0; r < f.grp_recs.size(); r += HS_GRP_REC_DWORDS){ f.grp_recs[r + 4] += f64_base; f.grp_recs[r + 5] += chars_base; }
+  for (size_t r = 0; r < f.grp_recs.size(); r += HS_GRP_REC_DWORDS) f.grp_recs[r + 3] += f64_base;
   for (hs_allele_t& a : f.alleles)
     if (a.realign) for (int s = 0; s < 2; s++){ a.lead_rows[s] += rowset_base; a.trail_rows[s] += rowset_base; a.str_opt[s] += stropt_base; }
   for (hs_rowset_t& r : f.rowsets) r.off += rows_base;
