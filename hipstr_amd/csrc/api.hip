@@ -32,7 +32,9 @@ extern "C" __global__ void hs_genotype_kernel(const hs_gt_dev_t* dp);
 extern "C" size_t hs_str_lds_bytes(int lds_len, int max_B);
 extern "C" __global__ void hs_str_group_kernel(const hs_dev_t* dp, int item_begin, int short_only);
 extern "C" __global__ void hs_str_group_kernel_p(const hs_dev_t* dp, int item_begin);
+extern "C" __global__ void hs_nd_kernel(const hs_dev_t* dp, int active_begin);
 extern "C" size_t hs_str_group_lds_bytes(int max_B, int nd_cap);
+extern "C" size_t hs_str_group_p_lds_bytes();
 extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk);
 extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk);
 
@@ -383,7 +385,7 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
     i_chars = place_pool(P.chars.data(), P.chars.size(), &hipstr::Prepared::chars, 1),
     i_recs = place_pool(P.grp_recs.data(), P.grp_recs.size()*sizeof(int32_t), &hipstr::Prepared::grp_recs, sizeof(int32_t)),
     i_reads = PL(P.reads), i_active = PL(P.active), i_items = PL(items),
-    i_ws = PL(P.ws), i_tg = PL(P.tgroups), i_tm = PL(P.tmembers), i_tp = PL(P.tpack), i_ord = PL(P.str_order);
+    i_ws = PL(P.ws), i_tg = PL(P.tgroups), i_tm = PL(P.tmembers), i_tp = PL(P.tpack), i_ord = PL(P.str_order), i_ndr = PL(P.nd_rows);
 #undef PL
   const size_t n_bases = P.reads.empty() ? 0 : (size_t)batch->base_off[P.reads.size()];
   const size_t i_bases = place(batch->bases, n_bases), i_quals = place(batch->quals, n_bases);
@@ -400,7 +402,7 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   h.f64pool = (const double*)at(i_f64); h.chars = (const char*)at(i_chars); h.reads = (const hs_read_t*)at(i_reads);
   h.active = (const int32_t*)at(i_active); h.items = (const hs_item_t*)at(i_items); h.ws = (const hs_ws_t*)at(i_ws);
   h.tgroups = (const hs_tgroup_t*)at(i_tg); h.tmembers = (const int32_t*)at(i_tm); h.tpack = (const int32_t*)at(i_tp);
-  h.str_order = (const int32_t*)at(i_ord); h.grp_recs = (const int32_t*)at(i_recs); h.bases = at(i_bases); h.quals = at(i_quals);
+  h.str_order = (const int32_t*)at(i_ord); h.grp_recs = (const int32_t*)at(i_recs); h.nd_rows = (const hs_ndrow_t*)at(i_ndr); h.bases = at(i_bases); h.quals = at(i_quals);
   dev->d_args = (hs_dev_t*)at(i_args);
   // ---- output + workspaces (device only)
   auto dalloc = [&](size_t bytes) -> void* { void* p = ctx->dev_cache.get(bytes ? bytes : 1); if (p) dev->dev_blocks.push_back(p); return p; };
@@ -408,6 +410,7 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   h.aln_probs = (double*)dalloc(out_bytes);
   h.ws_mr = (double*)dalloc(sizeof(double)*(size_t)P.ws_mr_size); h.ws_lt = (double*)dalloc(sizeof(double)*(size_t)P.ws_lt_size);
   h.ws_lead = (double*)dalloc(sizeof(double)*(size_t)P.ws_lead_size); h.ws_col = (double*)dalloc(sizeof(double)*(size_t)P.ws_col_size);
+  h.ws_nd = (double*)dalloc(sizeof(double)*(size_t)P.ws_nd_size);
   // trailing-flank kernel: persistent wavefronts, each with two band-boundary rows of [max side columns][64 lanes][M,D]
   h.band_cols = P.max_side_len > 0 ? P.max_side_len : 1;
   dev->trail_waves = (int)std::min<size_t>(P.trail_items.size() ? P.trail_items.size() : 1, 256 * 16);
@@ -415,7 +418,7 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   h.n_active = (int32_t)P.active.size();
   // [n_active] re-do flags of hs_str_kernel | [2 x chunks] work counters of hs_lead_kernel and hs_trail_kernel
   h.redo = (int32_t*)dalloc(sizeof(int32_t)*((size_t)h.n_active + 2*P.chunks.size() + 2));
-  if (!h.aln_probs || !h.ws_mr || !h.ws_lt || !h.ws_lead || !h.ws_col || !h.ws_band || !h.redo){ hipstr_hmm_free(dev); return NULL; }
+  if (!h.aln_probs || !h.ws_mr || !h.ws_lt || !h.ws_lead || !h.ws_col || !h.ws_nd || !h.ws_band || !h.redo){ hipstr_hmm_free(dev); return NULL; }
   const hipstr::HostTables& T = hipstr::host_tables();
   h.int_log = ctx->int_log; h.qual_correct = ctx->qc; h.qual_error = ctx->qe; h.m2m = ctx->m2m; h.m2i = ctx->m2i;
   h.log_thresh = T.log_thresh; h.log_half = T.log_half;
@@ -439,7 +442,6 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   if (getenv("HIPSTR_TIMING")) fprintf(stderr, "hipstr_hmm_upload: STR group kernel LDS %zu bytes (max block %d, read-end table %d doubles, %zu groups)\n", dev->grp_lds_bytes, h.max_B, h.grp_nd_cap, P.str_items.size());
   if (dev->grp_lds_bytes > 48*1024){
     HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->grp_lds_bytes));
-    HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_group_kernel_p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->grp_lds_bytes));
   }
   if (dev->lds_bytes > 48*1024){
     HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->lds_bytes));
@@ -557,7 +559,9 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
       // (HIPSTR_STR_GROUP_P=0: all of them as before, for comparison)
       static const bool group_p = !(getenv("HIPSTR_STR_GROUP_P") && atoi(getenv("HIPSTR_STR_GROUP_P")) == 0);
       if (ch.str_end > ch.str_begin){
-        if (group_p) hipLaunchKernelGGL(hs_str_group_kernel_p, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), dev->grp_lds_bytes, st, dp,
+        if (group_p && dev->prep.ws_nd_size > 0)       // read-end deletion sums of the tabulated alleles, every (row, column) a lane
+          hipLaunchKernelGGL(hs_nd_kernel, dim3(nact, 2), dim3(256), 0, st, dp, ch.active_begin);
+        if (group_p) hipLaunchKernelGGL(hs_str_group_kernel_p, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), hs_str_group_p_lds_bytes(), st, dp,
                                         dev->n_lead_items + dev->n_trail_items + ch.str_begin);
         if (!group_p || dev->any_short)      // (periods above HS_GRP_MAXP only, once hs_str_group_kernel_p is on)
           hipLaunchKernelGGL(hs_str_group_kernel, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), dev->grp_lds_bytes, st, dp,
@@ -714,7 +718,7 @@ int hipstr_debug_prepare(const hipstr_batch_t* batch, int threads, double* secon
     HS_MIX(P.chars); for (const hipstr::Prepared& f : P.frags) HS_MIX(f.chars);
     HS_MIX(P.grp_recs); for (const hipstr::Prepared& f : P.frags) HS_MIX(f.grp_recs);
     HS_MIX(P.reads); HS_MIX(P.active); HS_MIX(P.seeds); HS_MIX(P.realign_read); HS_MIX(P.realign_hap); HS_MIX(P.ws); HS_MIX(P.lead_items);
-    HS_MIX(P.trail_items); HS_MIX(P.str_items); HS_MIX(P.tpack); HS_MIX(P.str_order); HS_MIX(P.tgroups); HS_MIX(P.tmembers); HS_MIX(P.chunks);
+    HS_MIX(P.trail_items); HS_MIX(P.str_items); HS_MIX(P.tpack); HS_MIX(P.str_order); HS_MIX(P.tgroups); HS_MIX(P.tmembers); HS_MIX(P.chunks); HS_MIX(P.nd_rows);
 #undef HS_MIX
     const int64_t tail[8] = { P.ws_mr_size, P.ws_lt_size, P.ws_lead_size, P.ws_col_size, P.max_side_len, P.max_B, P.n_out, P.n_alignments };
     mix(tail, sizeof tail);

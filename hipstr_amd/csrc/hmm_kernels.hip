@@ -1895,6 +1895,57 @@ hs_str_group_kernel(const hs_dev_t* __restrict__ dp, int item_begin, int short_o
 //     unrolled over a period), the addresses of a chain are arithmetic, and its emissions are requested three groups ahead of the additions
 //     instead of waiting for a plane-offset lookup per group (the chain is the allele's critical path: the other wavefronts wait for it).
 // Same values added in the same order: bit-identical to str_group_body (tools/fuzz_align.py).
+// LDS of one hs_str_group_kernel_p workgroup: deletion table | rowP | match_probs_ | emission table | closed-form table x 2 | per-read ints
+#define HS_GRP_P_LDS_BYTES ((HS_MAXREP*HS_GRP_COLS + 2*(HS_GRP_COLS + HS_GRP_MAXREADS + 2) + 4*HS_GRP_COLS + 4*HS_TAB_CAP)*8 + (3*HS_GRP_MAXREADS + 1)*4 + 12)
+extern "C" size_t hs_str_group_p_lds_bytes(){ return HS_GRP_P_LDS_BYTES; }
+
+// ------------------------------------------------------------------ read-end deletion sums of the tabulated alleles, all of a locus side at once
+// A deletion whose segment reaches past the read end cannot take its start value from the match / deletion tables: it is the position
+// prior plus the emissions of the read's last bases against the block remainder, a strictly sequential sum (the `else` branch of
+// StutterAlignerClass.cpp:117-120).  It depends on the remainder's length B - |D| and the column only, so an allele whose block is the
+// previous one's plus a repeat unit inherits all but one row of sums (hs_ndrow_t, layout.h).  Inside the allele loop of the group kernel
+// these sums were its critical path — 50 to 150 dependent additions on a quarter of a workgroup's lanes while the other wavefronts waited
+// at a barrier.  Here every (row, column) pair of a read side is a lane of its own, rows of near-equal length next to each other, and
+// the latency is hidden by the other workgroups; the group kernel fetches its six values per column (hs_ws_t::nd).
+extern "C" __global__ void __launch_bounds__(256)
+hs_nd_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
+  const hs_dev_t& d = *dp;
+  const int ai = active_begin + blockIdx.x, side = blockIdx.y, tid = threadIdx.x;
+  const hs_read_t rd = d.reads[d.active[ai]];
+  const hs_locus_t* loc = d.loci + uni(rd.locus);
+  const int nrows = uni(loc->n_ndrows[side]);
+  if (nrows == 0) return;
+  const int p = uni(loc->period), sixp = HS_MAXREP*p;
+  const int n = uni(side ? rd.len - rd.seed - 1 : rd.seed);
+  __shared__ double E[4][HS_MAX_SIDE_LEN];              // emission log of every column against A, C, T, G (code = (char >> 1) & 3)
+  for (int c = tid; c < n; c += 256){
+    const int src = rd.base_off + (side ? rd.len - 1 - c : c);
+    const uint8_t q = (uint8_t)d.quals[src], r = (uint8_t)d.bases[src];
+    const double qc = d.qual_correct[q], qe = d.qual_error[q];
+    E[0][c] = (r == 'A') ? qc : qe; E[1][c] = (r == 'C') ? qc : qe; E[2][c] = (r == 'T') ? qc : qe; E[3][c] = (r == 'G') ? qc : qe;
+  }
+  __syncthreads();
+  const hs_ndrow_t* rows = d.nd_rows + uni(loc->ndrow_off[side]);
+  double* out = d.ws_nd + uni(side ? d.ws[ai].nd[1] : d.ws[ai].nd[0]);
+  const int total = nrows*sixp;
+  for (int e = tid; e < total; e += 256){
+    const int r = e / sixp, off = e - r*sixp;
+    const hs_ndrow_t rw = rows[r];
+    const int j = n - 1 - off;
+    if (rw.len < 0 || j < 0) continue;                  // no allele has this size / the read side has no such column
+    const int len = min(rw.len, j + 1);
+    double lp = -d.int_log[rw.len + 1];                 // the position prior (StutterAlignerClass.cpp:112)
+    const double* Ej = &E[0][0] + j;
+    const int codes = rw.tail_codes; int t = 0;         // step t pairs column j - t with the block base (t mod p) from the right end
+    for (; t + p <= len; t += p){
+      int c = codes;
+      for (int k = 0; k < p; k++){ lp += Ej[(c & 3)*HS_MAX_SIDE_LEN - t - k]; c >>= 2; }
+    }
+    for (int c = codes; t < len; t++){ lp += Ej[(c & 3)*HS_MAX_SIDE_LEN - t]; c >>= 2; }
+    out[e] = lp;
+  }
+}
+
 #ifndef HS_PEXP
 #define HS_PEXP 0        // compile-time experiments (register pressure, timing; results invalid): 1 no evaluation, 2 no read-end sums, 3 no table phase
 #endif
@@ -1907,13 +1958,12 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
   const int side = uni(item->side), G = uni(item->slot), tp = uni(item->active);
   // LDS carve of str_group_body (same size function), addressed as offsets in doubles from the start.  No static LDS in this kernel: the
   // dynamic block starts at address 0 and the offsets below are the addresses (the compiler adds the base to every access otherwise)
-  const int blk_len = (d.max_B + 19) & ~15;
   // (match_probs_ is indexed like rowP here: a 0.0 in front of every read's first column)
-  constexpr int oDl = 0, oRowP = HS_MAXREP*XC, oMt = oRowP + (XC + HS_GRP_MAXREADS + 2), oE = oMt + (XC + HS_GRP_MAXREADS + 2), oNd = oE + 4*XC;
-  const int oCst = oNd + d.grp_nd_cap, oTab = oCst + 2*24;           // tab: per parity A[HS_TAB_CAP] | G[HS_TAB_CAP]
+  constexpr int oDl = 0, oRowP = HS_MAXREP*XC, oMt = oRowP + (XC + HS_GRP_MAXREADS + 2), oE = oMt + (XC + HS_GRP_MAXREADS + 2);
+  constexpr int oTab = oE + 4*XC, oInts = oTab + 4*HS_TAB_CAP;        // tab: per parity A[HS_TAB_CAP] | G[HS_TAB_CAP]
+  static_assert(oInts*8 + (3*HS_GRP_MAXREADS + 1)*4 <= HS_GRP_P_LDS_BYTES, "LDS carve of hs_str_group_kernel_p");
   double* const lds = (double*)hs_lds_raw;
-  uint16_t* const boff0 = (uint16_t*)(lds + oTab + 4*HS_TAB_CAP) + blk_len + 64;
-  int* const s_off = (int*)(boff0 + 2*blk_len);                       // [HS_GRP_MAXREADS + 1] first column of every read | [..] columns | [..] active-read index
+  int* const s_off = (int*)(lds + oInts);                             // [HS_GRP_MAXREADS + 1] first column of every read | [..] columns | [..] active-read index
   int* const s_n = s_off + (HS_GRP_MAXREADS + 1);
   int* const s_ai = s_n + HS_GRP_MAXREADS;
   // LDS reads by byte ADDRESS: lds0 (the address of the carve: 0, there is no static LDS in this kernel — but it is not assumed) is part of
@@ -1966,9 +2016,11 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
   int aM = lds0 + 8*xrp;                               // + 8 oRowP - 8 len: M of column j - len before the block, or the 0.0 in front of the read;  + 8 oMt: match_probs_ of this column
   int aCol = lds0 + 8*xx;                              // + 8 oDl + q XC 8: del_probs_[q] of this column
   int aZ = lds0 + 8*(offg + g);                        // the 0.0 in front of this lane's read (rowP and match_probs_ alike)
-  const int aNd = lds0 + 8*(oNd + g*NDS + min(rj, SIXP - 1));
+  // this column's read-end deletion sums (hs_nd_kernel): row r of the side's block + the column's distance from the read end
+  const double* const ndp = d.ws_nd + (side ? d.ws[ai].nd[1] : d.ws[ai].nd[0]) + min(rj, SIXP - 1);
+  const bool nd_lane = rj < SIXP;                      // (a column farther than the largest deletion from the read end takes every start value from the tables)
 #ifndef HS_PHOIST
-#define HS_PHOIST 1        // the insertions' two allele-independent lane values per size kept in registers (12) instead of recomputed per allele (3 operations each)
+#define HS_PHOIST 0        // the insertions' two allele-independent lane values per size kept in registers (12) instead of recomputed per allele (3 operations each)
 #endif
   int aInsM[HS_MAXREP], c8[HS_MAXREP];
 #pragma unroll
@@ -2000,9 +2052,15 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
     const double* tsrc = d.f64pool + hd[3];
     if (lane < tl && x < 128) nx_tab = tsrc[3*lane + (x >> 6)];
   };
+  auto load_row = [&](int i) -> int {
+    int r; const uint64_t ra = rec_addr(i);
+    asm volatile("s_load_dword %0, %1, 0x10\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(ra) : "memory");
+    return r;
+  };
   hs_i4v_ hd_cur = load_header(i0), hd_nx1 = load_header(min(i0 + 1, i1 - 1));
+  int row_cur = load_row(i0), row_nx1 = load_row(min(i0 + 1, i1 - 1));
   request(hd_cur);
-  int cur_slot = -1, prev_B = 0, nd_base = 0;
+  int cur_slot = -1, prev_B = 0;
 #ifdef HS_GTIME
   unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #endif
@@ -2020,23 +2078,11 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
       cur_slot = slot;
     }
     if (lane < tab_len && x < 128) lds[oTab + par*2*HS_TAB_CAP + (x >> 6)*HS_TAB_CAP + lane] = nx_tab;
-    if (x < 64){       // the position priors of the six deletion sizes (StutterAlignerClass.cpp:112; record dwords 44..55): the read-end sums start from them, each lane from its size's
-      hs_i8v_ pdA; hs_i4v_ pdB;
-      const uint64_t ra = rec_addr(i);
-      asm volatile("s_load_dwordx8 %0, %2, 0xb0\n\ts_load_dwordx4 %1, %2, 0xd0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(pdA), "=&s"(pdB) : "s"(ra) : "memory");
-      double* pdl = lds + oCst + par*8;
-      if (x == 0) pdl[0] = __hiloint2double(pdA[1], pdA[0]);
-      if (x == 1) pdl[1] = __hiloint2double(pdA[3], pdA[2]);
-      if (x == 2) pdl[2] = __hiloint2double(pdA[5], pdA[4]);
-      if (x == 3) pdl[3] = __hiloint2double(pdA[7], pdA[6]);
-      if (x == 4) pdl[4] = __hiloint2double(pdB[1], pdB[0]);
-      if (x == 5) pdl[5] = __hiloint2double(pdB[3], pdB[2]);
-    }
     if (i + 1 < i1) request(hd_nx1);
-    hs_i4v_ hd_nx2; int touch1, touch2, touch3;
+    hs_i4v_ hd_nx2; int row_nx2, touch1, touch2, touch3;
     { const uint64_t ra2 = rec_addr(min(i + 2, i1 - 1));
-      asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0"
-                   : "=&s"(hd_nx2), "=&s"(touch1), "=&s"(touch2), "=&s"(touch3) : "s"(ra2) : "memory"); }
+      asm volatile("s_load_dwordx4 %0, %5, 0x0\n\ts_load_dword %1, %5, 0x10\n\ts_load_dword %2, %5, 0x40\n\ts_load_dword %3, %5, 0x80\n\ts_load_dword %4, %5, 0xc0"
+                   : "=&s"(hd_nx2), "=&s"(row_nx2), "=&s"(touch1), "=&s"(touch2), "=&s"(touch3) : "s"(ra2) : "memory"); }
     HS_TICK(0);   // evaluation of the previous allele + setup
     __syncthreads();
     HS_TICK(1);   // barrier 1 wait
@@ -2106,142 +2152,6 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
     }
 
     HS_TICK(2);   // table phase
-    // --- deletion start values of the columns whose segment reaches the read end (the `else` branch of StutterAlignerClass.cpp:117-120)
-    {
-      const int aPd = lds0 + 8*(oCst + par*8);
-      auto nd_sum = [&](int q, int xcol, int jcol, bool valid, int dst){
-        const int aD = (q+1)*P;
-        const int len = min(B - aD, jcol + 1);
-        const int lmin = uni(wave_min_i(len)), lmax = uni(wave_max_i(len));
-        double lp = ldb(aPd + 8*q);
-        constexpr int UN = (P >= 4) ? P : ((P == 3) ? 6 : 4);       // steps per group: a multiple of the period
-#ifndef HS_CHAIN_DEP
-#define HS_CHAIN_DEP 3
-#endif
-        constexpr int DEP = HS_CHAIN_DEP;                           // groups in flight
-        int a = lds0 + 8*(oE + xcol) - 8*(UN - 1);                         // the group's lowest address; step k of it sits (UN-1-k) entries above
-        double ev[DEP][UN];
-        auto load = [&](double* dst_){
-#pragma unroll
-          for (int k = 0; k < UN; k++) dst_[k] = ldb((a + spk(k % P)) + 8*(UN - 1 - k));
-          a -= 8*UN;
-        };
-#pragma unroll
-        for (int s = 0; s < DEP; s++) load(ev[s]);
-        __builtin_amdgcn_s_setprio(3);
-        int t = 0;
-        while (t + DEP*UN <= lmin){
-#pragma unroll
-          for (int s = 0; s < DEP; s++){
-#pragma unroll
-            for (int k = 0; k < UN; k++) lp += ev[s][k];
-            load(ev[s]);
-          }
-          t += DEP*UN;
-        }
-        while (t < lmax){
-#pragma unroll
-          for (int s = 0; s < DEP; s++){
-            if (t < lmax){                              // wave-uniform
-#pragma unroll
-              for (int k = 0; k < UN; k++){ const double v = lp + ev[s][k]; lp = (t + k < len) ? v : lp; }
-              load(ev[s]);
-              t += UN;
-            }
-          }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if (valid) lds[oNd + dst] = lp;
-      };
-      auto row_off = [&](int q){ return P*((q*(q+1)) >> 1); };
-      const bool reuse_al = chained && ((hd[0] >> 29) & 1);
-      if (reuse_al) nd_base = (nd_base + HS_MAXREP - 1) % HS_MAXREP;
-      auto slot_of = [&](int q){ int sl = nd_base + q; sl -= (sl >= HS_MAXREP) ? HS_MAXREP : 0; return sl*SIXP; };
-      const bool all_long = nmin_g >= SIXP;
-      auto udiv = [&](int e, int c, float rc) -> int {
-        int h = (int)((float)e * rc);
-        h -= (h*c > e) ? 1 : 0; h += ((h + 1)*c <= e) ? 1 : 0;
-        return h;
-      };
-      const int xw = (x + (NT/2)*(i - i0)) & (NT - 1);
-      if (HS_PEXP == 2){} else
-      if (all_long){
-        const int Gp = G*P;
-        if (reuse_al){
-          const int n_sums = nv*Gp;
-          const float rc_gp = __builtin_amdgcn_rcpf((float)Gp);
-          for (int base = 0; base < n_sums; base += NT){
-            if (base + (xw & ~63) >= n_sums) continue;
-            const int e = min(base + xw, n_sums - 1);
-            const int q = udiv(e, Gp, rc_gp), r = e - q*Gp, hh = r / P, off = r - hh*P;
-            const int jcol = (s_n[hh] - (q+1)*P) + off;
-            nd_sum(q, s_off[hh] + jcol, jcol, base + xw < n_sums, hh*NDS + slot_of(q) + ((q+1)*P - 1 - off));
-          }
-        } else {
-          const int n_sums = G*row_off(nv);
-          for (int base = 0; base < n_sums; base += NT){
-            if (base + (xw & ~63) >= n_sums) continue;
-            const int e = min(base + xw, n_sums - 1);
-            int q = 0;
-#pragma unroll
-            for (int k = 1; k <= 5; k++) q += (e >= G*row_off(k)) ? 1 : 0;
-            const int r = e - G*row_off(q), w = (q+1)*P;
-            const int hh = udiv(r, w, __builtin_amdgcn_rcpf((float)w)), off = r - hh*w;
-            const int jcol = (s_n[hh] - w) + off;
-            nd_sum(q, s_off[hh] + jcol, jcol, base + xw < n_sums, hh*NDS + slot_of(q) + (w - 1 - off));
-          }
-        }
-      } else {
-        int c_l = 0;
-        {
-          const bool ru = reuse_al && (nh_l >= nv*P);
-          int np_l = 0;
-#pragma unroll
-          for (int q = 0; q < HS_MAXREP; q++) np_l += (q < nv) ? min((q+1)*P, nh_l) : 0;
-          if (lane < G) c_l = ru ? nv*P : np_l;
-        }
-        int pc = c_l;
-#pragma unroll
-        for (int dd = 1; dd < HS_GRP_MAXREADS; dd <<= 1){
-          const int t1 = __shfl_up(pc, dd);
-          if (lane >= dd) pc += t1;
-        }
-        const int n_sums = rdlane(pc, HS_GRP_MAXREADS - 1);
-        auto find = [&](int pref, int e, int& hh, int& loc_e){
-          hh = 0; loc_e = e;
-          for (int h = 0; h + 1 < G; h++){
-            const int ph = rdlane(pref, h);
-            if (e >= ph){ hh = h + 1; loc_e = e - ph; }
-          }
-        };
-        for (int base = 0; base < n_sums; base += NT){
-          const int wbase = base + (xw & ~63);
-          if (wbase >= n_sums) continue;
-          const int e = min(base + xw, n_sums - 1);
-          const bool valid = base + xw < n_sums;
-          int hh, loc_e; find(pc, e, hh, loc_e);
-          const int nh = s_n[hh], offh = s_off[hh];
-          const bool ruh = reuse_al && (nh >= nv*P);
-          int q = 0, off = loc_e, jcol, dst;
-          if (ruh){
-#pragma unroll
-            for (int k = 1; k <= 5; k++) q += (loc_e >= k*P) ? 1 : 0;
-            off = loc_e - q*P;
-            jcol = (nh - (q+1)*P) + off;
-          } else {
-            int cnt[HS_MAXREP];
-#pragma unroll
-            for (int qq = 0; qq < HS_MAXREP; qq++) cnt[qq] = (qq < nv) ? min((qq+1)*P, nh) : 0;
-#pragma unroll
-            for (int qq = 0; qq < HS_MAXREP - 1; qq++) if (q == qq && off >= cnt[qq]){ off -= cnt[qq]; q = qq + 1; }
-            jcol = max(0, nh - (q+1)*P) + off;
-          }
-          dst = slot_of(q) + (nh - 1 - jcol);
-          nd_sum(q, offh + jcol, jcol, valid, hh*NDS + dst);
-        }
-      }
-    }
-    HS_TICK(3);   // read-end sums
     __syncthreads();
     HS_TICK(4);   // barrier 2 wait
 
@@ -2251,7 +2161,15 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
       double lp0_max = 0.0;
       const int B8 = 8*B;
       const int aTab = uni(lds0 + 8*(oTab + par*2*HS_TAB_CAP));
-      const int nd_slot0 = uni(nd_base);                   // (wave-uniform by construction; the compiler keeps the counters of this loop in vector registers)
+      // the column's read-end deletion sums for the six sizes, requested now (from L2: hs_nd_kernel wrote them) and used after the insertions
+      double ndv[HS_MAXREP];
+#pragma unroll
+      for (int q = 0; q < HS_MAXREP; q++) ndv[q] = 0.0;
+      if (nd_lane){
+        const double* pr = ndp + (int64_t)row_cur*SIXP;
+#pragma unroll
+        for (int q = 0; q < HS_MAXREP; q++) ndv[q] = pr[-q*SIXP];       // size q: row (size-0 row) - q
+      }
       // the lane's column constants, opaque from here on: otherwise every address below that does not depend on the allele is computed once
       // in front of the allele loop and kept — in more registers than there are (they went to scratch memory)
       asm volatile("" : "+v"(aM), "+v"(aCol), "+v"(aZ), "+v"(j8p8), "+v"(rj));
@@ -2302,10 +2220,8 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
         const int len8 = min(B8 - 8*aD, j8p8);
         // column j + |D|: past the read end the values are another read's (or nothing's) and not used
         const double dsum = ldb(8*oMt + 8*aD + aM) - ldb(8*oDl + 8*q*XC + 8*aD + aCol);
-        int slq = nd_slot0 + q; slq -= (slq >= HS_MAXREP) ? HS_MAXREP : 0;
-        const double ndv = ldb(aNd + 8*SIXP*slq);
         const double dv = pd_at(q) + dsum;
-        const double lp0 = (rj >= aD) ? dv : ndv;          // the segment ends inside the read: from the tables; else the read-end sum
+        const double lp0 = (rj >= aD) ? dv : ndv[q];       // the segment ends inside the read: from the tables; else the read-end sum
         const double S = tab_eval(lp0, len8, q);
         terms[HS_MAXREP - 1 - q] = (pmf_lo(HS_MAXREP - 1 - q) + S) + ldb(8*oRowP + aM - len8);
         __builtin_amdgcn_sched_barrier(0);
@@ -2340,8 +2256,8 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
         d.redo[ai] = 1;
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(hd_nx2), "+s"(touch1), "+s"(touch2), "+s"(touch3) :: "memory");      // (long since there)
-    hd_cur = hd_nx1; hd_nx1 = hd_nx2;
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(hd_nx2), "+s"(row_nx2), "+s"(touch1), "+s"(touch2), "+s"(touch3) :: "memory");      // (long since there)
+    hd_cur = hd_nx1; hd_nx1 = hd_nx2; row_cur = row_nx1; row_nx1 = row_nx2;
   }
 #ifdef HS_GTIME
   { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[0] += now_ - tprev; }

@@ -108,13 +108,23 @@ struct hs_locus_t {
   int32_t n_short[2];        // hs_str_group_kernel_p takes the positions [n_short, n_tab) of that order, hs_str_group_kernel the first n_short:
                              // all n_tab of them where the period is above HS_GRP_MAXP, none otherwise
   int32_t rec_off[2];        // first record (of n_tab, in the side's order) in grp_recs[], in records
+  int32_t ndrow_off[2];      // read-end deletion sums of the side's alleles in [n_short, n_tab) (hs_nd_kernel): first row descriptor in nd_rows[] ...
+  int32_t n_ndrows[2];       // ... and their number; a read side's block in the ws_nd workspace is n_ndrows x 6 period doubles
+  int32_t period;            // the locus' STR period (the same for all of its alleles)
+  int32_t pad_;
 };
+
+// One row of read-end deletion sums (hs_nd_kernel): the start values of StutterAlignerClass.cpp:117-120 for the columns within six repeat
+// units of the read end against a block remainder of `len` bases (block length minus deletion size) whose bases, from the right end, are
+// the tail codes repeated.  A family of alleles whose blocks grow by one repeat unit shares rows: size q of the family's allele k is row
+// (k - q + 5) of the family, which is how the sums are inherited from allele to allele (a row is computed once).  len < 0: unused row.
+struct hs_ndrow_t { int32_t len; int32_t tail_codes; };
 
 // hs_str_group_kernel_p reads everything an allele needs that is the same for all lanes — block length, flags, table indices, the 20
 // constants — with scalar loads from ONE record per (locus, side, position in the side's order), HS_GRP_REC_DWORDS dwords:
 //   [0] lead slot (10 bits) | tab_len << 10 (8 bits) | bit 29: block = the previous position's plus one repeat unit | bit 30: ... ends with it
-//   [1] re_ord   [2] tail_codes (12 bits: six bases) | B << 12   [3] tab_off (f64 pool)
-//   [8..14] per visiting list k (0..5 deletion sizes, 6 insertions): shape U0 | tab_base << 16        [4..7, 15] unused
+//   [1] re_ord   [2] tail_codes (12 bits: six bases) | B << 12   [3] tab_off (f64 pool)   [4] row of the allele's size-0 read-end sums (size q: [4] - q)
+//   [8..14] per visiting list k (0..5 deletion sizes, 6 insertions): shape U0 | tab_base << 16        [5..7, 15] unused
 //   [16..55] 20 doubles: pmf[13] | prior_ins | prior_del[6]    [56..57] the table's smallest Bnd    [58..63] unused
 #define HS_GRP_REC_DWORDS 64
 
@@ -131,7 +141,7 @@ struct hs_read_t {
 //   lead : per side [n_lead][n_side + lead_flank + 1]: rowP (M of the row before the STR block) | last column of the
 //          leading-flank rows | side_prob
 //   col  : [len-1][3] per read column, left side then right side: log P(correct), log P(error), base (as a double)
-struct hs_ws_t { int64_t mr, lt, lead[2], col; };
+struct hs_ws_t { int64_t mr, lt, lead[2], col, nd[2]; };       // nd: per side [n_ndrows][6 period] read-end deletion sums (hs_nd_kernel -> hs_str_group_kernel_p)
 
 // Alleles of one locus and side that share a trailing-flank rowset (identical rows incl. homopolymer context):
 // the trailing-flank kernel runs them as the 64 lanes of one wavefront.
@@ -165,6 +175,7 @@ struct hs_dev_t {
   HS_P(const int32_t) tmembers;   // allele indices (within the locus) of the trail groups
   HS_P(const int32_t) tpack;      // active-read indices of the reads packed into one trail item
   HS_P(const int32_t) grp_recs;   // hs_str_group_kernel_p: HS_GRP_REC_DWORDS dwords per tabulated position of a locus side's order (hs_locus_t::rec_off)
+  HS_P(const hs_ndrow_t) nd_rows; // row descriptors of the read-end deletion sums, per locus side (hs_locus_t::ndrow_off)
   HS_P(const int32_t) str_order;  // allele index (within the locus) per processing position; bit 30 set = this allele's STR block,
                                  // in side orientation, ends with the previous position's block (its tables are continued); bit 29
                                  // set = ... and is that block plus one repeat unit, periodic, with all six deletion sizes
@@ -173,6 +184,7 @@ struct hs_dev_t {
   HS_P(double) ws_mr;
   HS_P(double) ws_lt;
   HS_P(double) ws_lead;
+  HS_P(double) ws_nd;
   HS_P(double) aln_probs;
   HS_P(int32_t) redo;       // [n_active] set by hs_str_kernel when it left HS_REDO marks for a read; cleared before every pass
   // constant tables

@@ -531,6 +531,7 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
     hs_locus_t loc;
     loc.out_off = sh.out_off[l]; loc.hap_begin = out.alleles.size(); loc.n_alleles = A;
     loc.read_begin = b->read_off[l]; loc.n_reads = b->read_off[l+1]-b->read_off[l];
+    loc.period = period; loc.pad_ = 0;
 
     // STR options: forward then reversed orientation
     const int so_base = out.stropts.size();
@@ -623,6 +624,8 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
       loc.order_off[side] = out.str_order.size();
       loc.n_tab[side] = 0; loc.n_short[side] = 0;
       loc.rec_off[side] = (int32_t)(out.grp_recs.size() / HS_GRP_REC_DWORDS);
+      loc.ndrow_off[side] = (int32_t)out.nd_rows.size(); loc.n_ndrows[side] = 0;
+      int fam_row0 = 0, fam_k = 0;                     // first row of the current family of alleles (blocks growing by one repeat unit), position in it
       std::string prev;
       for (size_t i = 0; i < ks.size(); i++){
         const std::string cur = block_of(ks[i]);
@@ -640,6 +643,17 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
             int32_t rec[HS_GRP_REC_DWORDS]; memset(rec, 0, sizeof rec);
             rec[0] = (al.lead_slot[side] & 0x3ff) | (so.tab_len << 10) | (chained ? (1 << 30) : 0) | (one_unit ? (1 << 29) : 0);
             rec[1] = al.re_ord; rec[2] = (so.tail_codes & 0xfff) | (so.B << 12); rec[3] = so.tab_off;
+            if (period <= HS_GRP_MAXP){
+              // rows of read-end deletion sums (layout.h hs_ndrow_t): a new family opens with five rows for the first allele's larger sizes
+              if (!one_unit){
+                fam_row0 = loc.n_ndrows[side]; fam_k = 0;
+                for (int m = 0; m < HS_MAXREP - 1; m++) out.nd_rows.push_back(hs_ndrow_t{ so.B + (m - HS_MAXREP)*period, so.tail_codes });
+                loc.n_ndrows[side] += HS_MAXREP - 1;
+              } else fam_k++;
+              out.nd_rows.push_back(hs_ndrow_t{ so.B - period, so.tail_codes });       // row fam_k + 5: this allele's size 0
+              loc.n_ndrows[side]++;
+              rec[4] = fam_row0 + fam_k + HS_MAXREP - 1;
+            }
             for (int k = 0; k <= HS_MAXREP; k++) rec[8 + k] = (so.shape[k] & 0xffff) | (so.tab_base[k] << 16);
             memcpy(rec + 16, out.f64pool.data() + so.f64_off, 20*sizeof(double));
             memcpy(rec + 56, out.f64pool.data() + so.tab_off + 3*so.tab_len, sizeof(double));
@@ -693,10 +707,10 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
 }
 
 // Sizes of the pools of a fragment = where the next fragment starts in the merged batch.
-struct FragBase { size_t loci, alleles, stropts, rowsets, rows, visits, f64, chars, active, realign_hap, order, tgroups, tmembers, leads, recs; };
+struct FragBase { size_t loci, alleles, stropts, rowsets, rows, visits, f64, chars, active, realign_hap, order, tgroups, tmembers, leads, recs, ndrows; };
 static FragBase frag_sizes(const Prepared& f, size_t n_leads){
   return FragBase{ f.loci.size(), f.alleles.size(), f.stropts.size(), f.rowsets.size(), f.rows.size(), f.visits.size(), f.f64pool.size(), f.chars.size(),
-                   f.active.size(), f.realign_hap.size(), f.str_order.size(), f.tgroups.size(), f.tmembers.size(), n_leads, f.grp_recs.size() / HS_GRP_REC_DWORDS };
+                   f.active.size(), f.realign_hap.size(), f.str_order.size(), f.tgroups.size(), f.tmembers.size(), n_leads, f.grp_recs.size() / HS_GRP_REC_DWORDS, f.nd_rows.size() };
 }
 
 // Copies fragment `f` to its place in `out` (whose pools are already sized), turning fragment-local pool offsets into batch-wide
@@ -707,7 +721,7 @@ static void place_fragment(Prepared& out, Prepared& f, const FragBase& at, std::
   const int32_t chars_base = (int32_t)at.chars, tg_base = (int32_t)at.tgroups, tm_base = (int32_t)at.tmembers, order_base = (int32_t)at.order;
   for (hs_locus_t& L : f.loci){
     L.hap_begin += allele_base;
-    for (int s = 0; s < 2; s++){ L.tg_begin[s] += tg_base; L.order_off[s] += order_base; L.rec_off[s] += (int32_t)at.recs; }
+    for (int s = 0; s < 2; s++){ L.tg_begin[s] += tg_base; L.order_off[s] += order_base; L.rec_off[s] += (int32_t)at.recs; L.ndrow_off[s] += (int32_t)at.ndrows; }
   }
   for (size_t r = 0; r < f.grp_recs.size(); r += HS_GRP_REC_DWORDS) f.grp_recs[r + 3] += f64_base;
   for (hs_allele_t& a : f.alleles)
@@ -722,7 +736,7 @@ static void place_fragment(Prepared& out, Prepared& f, const FragBase& at, std::
 #define HS_PLACE(field, base) std::copy(f.field.begin(), f.field.end(), out.field.begin() + (base))
   HS_PLACE(loci, at.loci); HS_PLACE(alleles, at.alleles); HS_PLACE(stropts, at.stropts); HS_PLACE(rowsets, at.rowsets);
   HS_PLACE(active, at.active); HS_PLACE(realign_hap, at.realign_hap);
-  HS_PLACE(str_order, at.order); HS_PLACE(tgroups, at.tgroups); HS_PLACE(tmembers, at.tmembers);
+  HS_PLACE(str_order, at.order); HS_PLACE(tgroups, at.tgroups); HS_PLACE(tmembers, at.tmembers); HS_PLACE(nd_rows, at.ndrows);
   // rows, visits, f64pool, chars stay in the fragment (Prepared::frags): the upload gathers them
 #undef HS_PLACE
   for (size_t i = 0; i < leads_f.size(); i++) leads_out[at.leads + i].swap(leads_f[i]);
@@ -797,10 +811,11 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
     out.loci.resize(tot.loci); out.alleles.resize(tot.alleles); out.stropts.resize(tot.stropts); out.rowsets.resize(tot.rowsets);
     out.active.resize(tot.active); out.realign_hap.resize(tot.realign_hap);
     out.str_order.resize(tot.order); out.tgroups.resize(tot.tgroups); out.tmembers.resize(tot.tmembers); locus_leads.resize(tot.leads);
+    out.nd_rows.resize(tot.ndrows);
     parallel_for(n_frag, n_threads, [&](int f){ place_fragment(out, frag[f], at[f], locus_leads, frag_leads[f]); });
     for (Prepared& f : frag){      // keep only the large pools of the fragments
       f.loci.clear(); f.alleles.clear(); f.stropts.clear(); f.rowsets.clear(); f.active.clear(); f.realign_hap.clear(); f.str_order.clear();
-      f.tgroups.clear(); f.tmembers.clear();
+      f.tgroups.clear(); f.tmembers.clear(); f.nd_rows.clear();
     }
     out.frags = std::move(frag);
   }
@@ -810,7 +825,7 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
   // ---- launch plan: workspaces + work items, chunked so that the workspaces stay within the budget
   out.ws.resize(out.active.size());
   Prepared::Chunk ch; memset(&ch, 0, sizeof ch);
-  int64_t mr = 0, lt = 0, lead = 0, col = 0;
+  int64_t mr = 0, lt = 0, lead = 0, col = 0, nd = 0;
   auto flush = [&](int active_end){
     ch.active_end = active_end;
     ch.lead_begin = out.lead_items.size();
@@ -906,10 +921,10 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
     ch.str_end = out.str_items.size();
     ch.lead_end = out.lead_items.size();
     out.ws_mr_size = std::max(out.ws_mr_size, mr); out.ws_lt_size = std::max(out.ws_lt_size, lt); out.ws_lead_size = std::max(out.ws_lead_size, lead);
-    out.ws_col_size = std::max(out.ws_col_size, col);
+    out.ws_col_size = std::max(out.ws_col_size, col); out.ws_nd_size = std::max(out.ws_nd_size, nd);
     if (ch.active_end > ch.active_begin) out.chunks.push_back(ch);
     memset(&ch, 0, sizeof ch); ch.active_begin = active_end;
-    mr = lt = lead = col = 0;
+    mr = lt = lead = col = nd = 0;
   };
   for (size_t ai = 0; ai < out.active.size(); ai++){
     const hs_read_t& rd = out.reads[out.active[ai]];
@@ -918,8 +933,14 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
     const int64_t need_mr = (int64_t)loc.n_re*(rd.len-1), need_lt = (int64_t)loc.n_re*loc.lt_stride;
     int64_t need_lead = 0;
     for (int s = 0; s < 2; s++) need_lead += (int64_t)loc.n_lead[s]*(n_side[s] + loc.lead_flank[s] + 1);
-    if (ch.active_begin < (int)ai && (mr + need_mr > ws_budget || lt + need_lt > ws_budget || lead + need_lead > ws_budget)) flush((int)ai);
+    int64_t need_nd = 0, per6 = 0;
+    if (loc.n_ndrows[0] + loc.n_ndrows[1] > 0){
+      per6 = HS_MAXREP*(int64_t)loc.period;
+      need_nd = (loc.n_ndrows[0] + loc.n_ndrows[1])*per6;
+    }
+    if (ch.active_begin < (int)ai && (mr + need_mr > ws_budget || lt + need_lt > ws_budget || lead + need_lead > ws_budget || nd + need_nd > ws_budget)) flush((int)ai);
     hs_ws_t w; w.mr = mr; w.lt = lt; w.col = col;
+    w.nd[0] = nd; w.nd[1] = nd + loc.n_ndrows[0]*per6; nd += need_nd;
     for (int s = 0; s < 2; s++){
       w.lead[s] = lead;
       out.max_side_len = std::max(out.max_side_len, n_side[s]);

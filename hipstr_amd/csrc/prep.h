@@ -62,10 +62,11 @@ struct Prepared {
   int32_t                 grp_nd_cap = 0;  // largest (reads x 36 period) of the str_items
   std::vector<int32_t>    tpack;           // active-read indices of the packed reads
   std::vector<int32_t>    str_order;       // per locus and side: realigned alleles sorted so that nested STR blocks follow each other
+ std::vector<hs_ndrow_t>  nd_rows;         // row descriptors of the read-end deletion sums per locus side (layout.h); a small pool
   std::vector<int32_t>    grp_recs;        // HS_GRP_REC_DWORDS dwords per tabulated position of a side's order (layout.h); a large pool like rows / f64pool
   std::vector<hs_tgroup_t> tgroups;
   std::vector<int32_t>    tmembers;
-  int64_t ws_mr_size = 0, ws_lt_size = 0, ws_lead_size = 0, ws_col_size = 0;   // doubles, max over chunks
+  int64_t ws_mr_size = 0, ws_lt_size = 0, ws_lead_size = 0, ws_col_size = 0, ws_nd_size = 0;   // doubles, max over chunks
   int32_t max_side_len = 0;
   int32_t max_B = 1;          // longest STR allele
   int64_t n_out        = 0;
