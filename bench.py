@@ -43,6 +43,7 @@ WORKLOADS = {
     "c2": (1000, 40, 32, 150, 60, 40, "BASELINE configs[1] at literal 30x depth: 1000 loci x 40 reads x 32 alleles"),
     "p30": (4000, 40, 8, 150, 35, 40, "production-like shape (SURVEY §8: flanks <= 35 bp, HaplotypeGenerator.cpp:349-361; ~10 alleles; 30x depth): 4000 loci x 40 reads x 8 alleles"),
     "c3": (10000, 600, 32, 150, 60, 40, "BASELINE configs[2] (SURVEY §8d C3-like): 10k loci x 600 reads (100 samples x 6) x 32 alleles, stutter EM + posteriors + genotype calls in the step"),
+    "c4": (100, 5000, 32, 150, 60, 40, "BASELINE configs[3] per-locus shape (one GPU's shard): 100 loci x 1000 samples x 5 reads x 32 alleles; forward HMM + R x A^2 posteriors + genotype calls in the step"),
     "c5": (256, 200, 128, 250, 110, 100, "BASELINE configs[4] stress: 256 loci x 200 250bp reads x 128 alleles, ~100bp STR blocks"),
 }
 
@@ -327,7 +328,20 @@ def main():
     hmm.hipstr_hmm_workload(dev, C.byref(n_aln), C.byref(algo), C.byref(cells))
     hap_off = np.ctypeslib.as_array(sb.ptr.contents.hap_off, shape=(loci + 1,))
     A_l = np.diff(hap_off)
-    if args.workload == "c3":
+    if args.workload == "c4":
+        # configs[3]: 1000 samples per locus, the locus' reads dealt to them in blocks of P / S; a step = forward HMM + posteriors of every
+        # (sample, diplotype) + genotype calls (GL, PL) — seq_stutter_genotyper.cpp:603-671 without the allele rounds
+        S = 1000
+        lab = np.tile(np.repeat(np.arange(S), P // S), loci).astype(np.int32)
+        pb = capi.PostBatch(A_l, np.full(loci, S, np.int32), np.arange(loci + 1, dtype=np.int32) * P, lab, np.zeros(loci * P), np.zeros(loci * P),
+                            np.ones(loci * P, np.int32), None)
+        h2a = np.concatenate([np.arange(a, dtype=np.int32) for a in A_l]); nvv = A_l.astype(np.int32)
+        rq = capi.HipstrGtRequest(nvv.ctypes.data_as(capi._i32p), h2a.ctypes.data_as(capi._i32p), 1, 1, 0)
+        ns = loci * S; ngl = int(sum(int(a) * (int(a) + 1) // 2 for a in A_l)) * S
+        gt_k = [np.zeros(2 * ns, np.int32), np.zeros(2 * ns, np.int32)] + [np.zeros(ns) for _ in range(5)] + [np.zeros(ngl), np.zeros(ngl, np.int32), np.zeros(1)]
+        gt_o = capi.HipstrGtOut(*[a.ctypes.data_as(t) for a, (f, t) in zip(gt_k, capi.HipstrGtOut._fields_)])
+        hmm.hipstr_post_extract.restype = C.c_int; hmm.hipstr_post_extract.argtypes = [C.c_void_p, C.POINTER(capi.HipstrGtRequest), C.POINTER(capi.HipstrGtOut)]
+    elif args.workload == "c3":
         # configs[2]: 100 samples per locus, the locus' reads dealt to them in blocks; a step = stutter EM on the observed STR sizes
         # (EMStutterGenotyper::train, all loci in lock step) + forward HMM + posteriors + genotype calls (GL, PL)
         S = 100
@@ -369,6 +383,9 @@ def main():
             em_stats["trained"] = int(tr.sum()); em_stats["iterations"] = int(it_.sum())
         if hmm.hipstr_hmm_align(dev, None) != 0 or hmm.hipstr_post_launch(pd, None) != 0:
             raise SystemExit("launch failed: " + hmm.hipstr_last_error().decode())
+        if args.workload == "c4":
+            if hmm.hipstr_post_extract(pd, C.byref(rq), C.byref(gt_o)) != 0:
+                raise SystemExit("hipstr_post_extract: " + hmm.hipstr_last_error().decode())
         if args.workload == "c3":
             torch.cuda.synchronize()               # the forward and posterior kernels are in flight: do not charge them to the calls
             t_gt = time.perf_counter()
@@ -419,6 +436,21 @@ def main():
     else:
         total_aln, total_loci = float(n_aln.value), float(loci)
 
+    def profile_for(files):
+        """The newest committed profile summary collected on THIS workload (its `command` names it: bench.py --workload X, default ns; a run
+        with a HIPSTR_SYNTH_* override is nobody's profile): counters of one workload are not scaled onto another."""
+        import re
+        if any(k.startswith("HIPSTR_SYNTH") for k in os.environ):
+            return None, None
+        for f in reversed(files):
+            t = json.load(open(f))
+            m = re.search(r"--workload\s+(\w+)", t.get("command", ""))
+            if (m.group(1) if m else "ns") == args.workload:
+                return t, f
+        return None, None
+
+    STR_KERNELS = ("hs_str_", "hs_nd_")          # the STR phase: read-end sums + group kernels + per-read / generic kernels
+
     def pmc_traffic(kernel_key, n_alignments):
         """HBM-side traffic of the dominant kernel from the newest committed rocprofv3 PMC summary (profiles/*_pmc_traffic.json:
         FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, tools/pmc_traffic.py), scaled to this launch by alignments.
@@ -426,16 +458,15 @@ def main():
         narrow accesses of these kernels; WRITE_SIZE is uncalibrated and taken raw."""
         import glob
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), key=_profile_key)
-        if not files:
+        t, src = profile_for(files)
+        if t is None:
             return None, None
-        t = json.load(open(files[-1]))
-        if kernel_key.startswith("hs_str"):
-            kernel_key = "hs_str_"                                                        # the STR phase: hs_str_group_kernel + hs_str_kernel + hs_str_kernel_generic
-        hit = [v for name, v in t["kernels"].items() if name.startswith(kernel_key)]      # a phase may be more than one kernel
+        keys = STR_KERNELS if kernel_key.startswith("hs_str") else (kernel_key,)
+        hit = [v for name, v in t["kernels"].items() if name.startswith(keys)]            # a phase may be more than one kernel
         if not hit:
             return None, None
         per_aln = sum(2 * v["fetch_bytes_per_launch_raw"] + v["write_bytes_per_launch_raw"] for v in hit) / t["alignments_per_launch"]
-        return per_aln * n_alignments, os.path.basename(files[-1])
+        return per_aln * n_alignments, os.path.basename(src)
 
     def valu_block(phase_ms_now, n_alignments):
         """The limiter that binds, per phase, from the newest committed counter passes (profiles/r*_sq_counters.json: two rocprofv3 --pmc
@@ -450,17 +481,17 @@ def main():
         import hashlib
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters.json")), key=_profile_key)
         files = [f for f in files if "kernel_source_sha1" in open(f).read()]
-        if not files:
+        t, src_file = profile_for(files)
+        if t is None:
             return None
-        t = json.load(open(files[-1]))
         src = os.path.join(ROOT, "hipstr_amd", "csrc", "hmm_kernels.hip")
         same = os.path.exists(src) and hashlib.sha1(open(src, "rb").read()).hexdigest() == t.get("kernel_source_sha1")
         denom_per_ms = t["simds"] * t["clock_hz"] * 1e-3
         cyc = t["cycles_per_wave64_instruction"]
         phases = {}
         for ph, ms_now in phase_ms_now.items():
-            key = "hs_str_" if ph.startswith("hs_str") else ph
-            hit = [v for name, v in t["kernels"].items() if name.startswith(key)]     # a phase may be more than one kernel (the STR phase: group + per-read + generic)
+            key = STR_KERNELS if ph.startswith("hs_str") else (ph,)
+            hit = [v for name, v in t["kernels"].items() if name.startswith(key)]     # a phase may be more than one kernel (the STR phase: read-end sums + group + generic)
             if not hit or not (ms_now == ms_now) or ms_now <= 0:
                 continue
             sc = n_alignments / t["alignments_per_launch"]
@@ -476,7 +507,7 @@ def main():
         allf = sum(v["fp64_insts"] for v in phases.values())
         return {"fp64_valu_peak_ops_per_s": 256 * 4 * 16 * 2.4e9, "cycles_per_wave64_instruction": cyc,
                 "pass_fp64_frac_of_peak": (allf * cyc["fp64"] / (denom_per_ms * tot_ms)) if tot_ms > 0 else None,
-                "phases": phases, "source": os.path.basename(files[-1]), "profile_matches_build": bool(same)}
+                "phases": phases, "source": os.path.basename(src_file), "profile_matches_build": bool(same)}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -507,9 +538,22 @@ def main():
             e2e["alignments_per_s"] = n_aln.value * e2e["passes"] / e2e["seconds"]
             e2e["fraction_of_resident_rate"] = e2e["alignments_per_s"] / value
             out["end_to_end"] = e2e
+            # SURVEY §8(d)'s metric taken literally (host arrays in -> results out: host flatten + H2D + kernels + D2H), beside `value`
+            # (inputs resident, as the bench contract defines it)
+            out["value_end_to_end"] = e2e["alignments_per_s"]
             out["pipeline"] = pipeline_stages(capi, hmm, sb, loci, P)
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(capi, args.workload)
+        if args.workload == "c4":
+            # shares of the step: the stages once more, each waited for (not part of the timed region)
+            torch.cuda.synchronize(); t_a = time.perf_counter()
+            hmm.hipstr_hmm_align(dev, None); torch.cuda.synchronize(); t_b = time.perf_counter()
+            hmm.hipstr_post_launch(pd, None); torch.cuda.synchronize(); t_c = time.perf_counter()
+            hmm.hipstr_post_extract(pd, C.byref(rq), C.byref(gt_o)); t_d = time.perf_counter()
+            tot = t_d - t_a
+            out["c4_step"] = {"samples_per_locus": 1000, "forward_hmm_s": t_b - t_a, "posterior_kernel_s": t_c - t_b, "genotype_calls_s": t_d - t_c,
+                              "posterior_share": (t_c - t_b) / tot, "genotype_calls_share": (t_d - t_c) / tot,
+                              "note": "hipstr_post_launch = hs_posterior_kernel (R x A^2 pair log-sum-exps per sample); genotype calls = hs_genotype_kernel + GL/PL copy back"}
         if em_stats:
             out["c3_step"] = {"stutter_em_s_per_step": em_stats.get("em_s", 0.0) / args.steps, "genotype_calls_s_per_step": em_stats.get("calls_s", 0.0) / args.steps,
                               "em_trained_loci": em_stats.get("trained"), "em_iterations": em_stats.get("iterations"), "samples_per_locus": 100}

@@ -860,8 +860,40 @@ int hipstr_post_launch(hipstr_post_dev_t* pd, void* hip_stream){
   if (bind(pd->R.ctx)) return 1;
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : pd->R.stream;
   if (hip_stream && st != pd->R.stream) pd->foreign_stream = true;
+  // HIPSTR_DEBUG_HOST_LIBM=1 (tests/test_genotypes_gpu.py): the three places where the device's exp / log enter — the per-sample
+  // log-sum-exp over the diplotypes, the streaming log-sum-exps per genotype and the exact pair log-sum-exp of the unphased posterior —
+  // are evaluated on the host with its libm, in the reference's order, on the device's accumulated values.  It shows where the
+  // one-float-step differences of GL / GLDIFF / PL against the reference come from (they vanish); it is not a way to run the path.
+  const bool host_libm = getenv("HIPSTR_DEBUG_HOST_LIBM") && atoi(getenv("HIPSTR_DEBUG_HOST_LIBM")) != 0;
+  if (host_libm != (pd->R.h.raw != 0)){
+    pd->R.h.raw = host_libm ? 1 : 0;
+    HS_HIP(hipMemcpy(pd->R.d_args, &pd->R.h, sizeof pd->R.h, hipMemcpyHostToDevice));
+  }
   hipLaunchKernelGGL(hs_posterior_kernel, dim3((unsigned)pd->R.units.size()), dim3(256), 0, st, (const hs_post_dev_t*)pd->R.d_args);
   HS_HIP(hipGetLastError());
+  if (host_libm){
+    PostRun& R = pd->R;
+    HS_HIP(hipStreamSynchronize(st));
+    std::vector<double> post((size_t)R.n_post), total((size_t)R.n_samp, 0.0);
+    std::vector<int32_t> mapgt(2*(size_t)R.n_samp, -1);
+    HS_HIP(hipMemcpy(post.data(), R.h.log_post, sizeof(double)*R.n_post, hipMemcpyDeviceToHost));
+    for (const hs_post_unit_t& u : R.units){
+      double* v = post.data() + u.post_off;
+      const int nd = u.n_alleles*u.n_alleles;
+      double mx = v[0];                                   // log_sum_exp (mathops.cpp:44-50)
+      for (int i = 1; i < nd; i++) mx = std::max(mx, v[i]);
+      double tot = 0.0;
+      for (int i = 0; i < nd; i++) tot += exp(v[i] - mx);
+      const double lse = mx + log(tot);
+      double bv = -1.7976931348623157e308; int bi = -1;   // first maximum, a1-major (genotyper.cpp:88-95)
+      for (int i = 0; i < nd; i++){ v[i] -= lse; if (v[i] > bv){ bv = v[i]; bi = i; } }
+      total[u.samp_index] = lse;
+      if (bi >= 0){ mapgt[2*u.samp_index] = bi / u.n_alleles; mapgt[2*u.samp_index+1] = bi % u.n_alleles; }
+    }
+    HS_HIP(hipMemcpy(R.h.log_post, post.data(), sizeof(double)*R.n_post, hipMemcpyHostToDevice));
+    HS_HIP(hipMemcpy(R.h.sample_total, total.data(), sizeof(double)*R.n_samp, hipMemcpyHostToDevice));
+    HS_HIP(hipMemcpy(R.h.map_gt, mapgt.data(), sizeof(int32_t)*2*R.n_samp, hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
@@ -971,6 +1003,29 @@ int hipstr_post_extract(hipstr_post_dev_t* pd, const hipstr_gt_request_t* rq, hi
   h.calc_any = any; h.calc_gls = rq->calc_gls; h.calc_pls = rq->calc_pls; h.calc_pgls = rq->calc_phased_gls;
   h.log_thresh = T.log_thresh;
   if (dalloc(sizeof h, &p)) return 1; HS_HIP(hipMemcpy(p, &h, sizeof h, hipMemcpyHostToDevice));
+  const bool host_libm = getenv("HIPSTR_DEBUG_HOST_LIBM") && atoi(getenv("HIPSTR_DEBUG_HOST_LIBM")) != 0;      // see hipstr_post_launch
+  std::vector<double> h_tot;
+  if (host_libm){
+    HS_HIP(hipDeviceSynchronize());
+    std::vector<double> post((size_t)R.n_post);
+    HS_HIP(hipMemcpy(post.data(), R.h.log_post, sizeof(double)*R.n_post, hipMemcpyDeviceToHost));
+    h_tot.resize((size_t)tot);
+    for (const hs_gt_unit_t& u : units){                  // total_log_phased_posteriors, streamed as genotyper.cpp:148-170 does (mathops.cpp:72-80)
+      const int A = u.n_alleles, V = u.n_variants;
+      const int32_t* gm = gmem.data() + u.map_off; const int32_t* go = goff.data() + u.goff_off;
+      for (int v1 = 0; v1 < V; v1++) for (int v2 = 0; v2 < V; v2++){
+        double mx = -1.7976931348623157e308/2, t = 0.0;
+        for (int x = go[v1]; x < go[v1+1]; x++) for (int y = go[v2]; y < go[v2+1]; y++){
+          const double lv = post[u.post_off + (int64_t)gm[x]*A + gm[y]];
+          if (lv <= mx) t += exp(lv - mx); else { t *= exp(mx - lv); t += 1.0; mx = lv; }
+        }
+        h_tot[u.tot_off + (int64_t)v1*V + v2] = mx + log(t);
+      }
+    }
+    HS_HIP(hipMemcpy(h.tot, h_tot.data(), sizeof(double)*(size_t)tot, hipMemcpyHostToDevice));
+    h.tot_given = 1;
+    HS_HIP(hipMemcpy(p, &h, sizeof h, hipMemcpyHostToDevice));
+  }
   if (pd->foreign_stream) HS_HIP(hipDeviceSynchronize());          // the posterior kernel may still be running on a stream of the caller's
   hipLaunchKernelGGL(hs_genotype_kernel, dim3((unsigned)units.size()), dim3(256), 0, R.stream, (const hs_gt_dev_t*)p);
   HS_HIP(hipGetLastError());
@@ -981,6 +1036,13 @@ int hipstr_post_extract(hipstr_post_dev_t* pd, const hipstr_gt_request_t* rq, hi
   HS_HIP(hipMemcpy(out->best_gt, h.best_gt, (size_t)so*2*4, hipMemcpyDeviceToHost));
   HS_HIP(hipMemcpy(out->log_phased_post, h.log_phased, (size_t)so*8, hipMemcpyDeviceToHost));
   HS_HIP(hipMemcpy(out->log_unphased_post, h.log_unphased, (size_t)so*8, hipMemcpyDeviceToHost));
+  if (host_libm)                                          // the exact pair log_sum_exp of the two phasings (mathops.cpp:52-57) with the host libm
+    for (const hs_gt_unit_t& u : units){
+      const int ga = out->best_gt[2*u.samp_index], gb = out->best_gt[2*u.samp_index+1];
+      if (ga < 0 || gb < 0 || ga == gb) continue;
+      const double lp = h_tot[u.tot_off + (int64_t)u.n_variants*ga + gb], alt = h_tot[u.tot_off + (int64_t)u.n_variants*gb + ga];
+      out->log_unphased_post[u.samp_index] = (lp > alt) ? lp + log(1 + exp(alt - lp)) : alt + log(1 + exp(lp - alt));
+    }
   HS_HIP(hipMemcpy(out->hap_log_phased_post, h.hap_log_phased, (size_t)so*8, hipMemcpyDeviceToHost));
   HS_HIP(hipMemcpy(out->hap_log_unphased_post, h.hap_log_unphased, (size_t)so*8, hipMemcpyDeviceToHost));
   if (any) HS_HIP(hipMemcpy(out->gl_diff, h.gl_diff, (size_t)so*8, hipMemcpyDeviceToHost));

@@ -67,6 +67,7 @@ hs_posterior_kernel(const hs_post_dev_t* __restrict__ dp){
     post[idx] = v;
     lmax = fmax(lmax, v);
   }
+  if (d.raw) return;          // (debug) the host normalises
   // ---- exact log-sum-exp over diplotypes (genotyper.cpp:63-72)
   red_v[tid] = lmax; __syncthreads();
   for (int s = 128; s > 0; s >>= 1){ if (tid < s) red_v[tid] = fmax(red_v[tid], red_v[tid+s]); __syncthreads(); }
@@ -120,6 +121,7 @@ hs_genotype_kernel(const hs_gt_dev_t* __restrict__ dp){
   const double TOLERANCE = 1e-10;                      // mathops.cpp:10
   __shared__ double red_v[256];
 
+  if (!d.tot_given)
   for (int gt = tid; gt < V*V; gt += 256){
     const int v1 = gt / V, v2 = gt - v1*V;
     double mx = -1.7976931348623157e308/2, tot = 0.0;   // -DBL_MAX/2 (genotyper.cpp:152)

@@ -27,6 +27,7 @@ struct hs_post_dev_t {
   double*        sample_total;
   int32_t*       map_gt;
   double         log_thresh, log_half;
+  int32_t        raw;            // HIPSTR_DEBUG_HOST_LIBM: leave the accumulated log P(reads, diplotype) unnormalised — the host takes the log-sum-exp with its libm
 };
 
 // One (locus, sample) pair of the genotype extraction (Genotyper::extract_genotypes_and_likelihoods, genotyper.cpp:129-251).
@@ -57,4 +58,5 @@ struct hs_gt_dev_t {
   double*  gls;  int32_t* pls;  double* pgls;
   int32_t  calc_any, calc_gls, calc_pls, calc_pgls;
   double   log_thresh;
+  int32_t  tot_given;            // HIPSTR_DEBUG_HOST_LIBM: `tot` (and log_unphased) come from the host
 };

@@ -144,3 +144,102 @@ def test_submit_each_and_collect(hmm):
         assert np.array_equal(probs, want) and np.array_equal(seeds, wseeds)
     assert st.next() is None
     st.close()
+
+
+def _multi_sigs(lib):
+    import ctypes as C
+    lib.hipstr_multi_open.restype = C.c_void_p; lib.hipstr_multi_open.argtypes = [C.c_int32, capi._i32p, C.c_int64, C.c_void_p]
+    lib.hipstr_multi_submit.restype = C.c_int64; lib.hipstr_multi_submit.argtypes = [C.c_void_p, capi._BP]
+    lib.hipstr_multi_flush.restype = C.c_int; lib.hipstr_multi_flush.argtypes = [C.c_void_p]
+    lib.hipstr_multi_next_size.restype = C.c_int; lib.hipstr_multi_next_size.argtypes = [C.c_void_p] + [C.POINTER(C.c_int64)] * 3
+    lib.hipstr_multi_next.restype = C.c_int; lib.hipstr_multi_next.argtypes = [C.c_void_p, C.POINTER(C.c_int64), capi._f64p, C.c_int64, capi._i32p, C.c_int64]
+    lib.hipstr_multi_close.restype = C.c_int; lib.hipstr_multi_close.argtypes = [C.c_void_p]
+
+
+def test_multi_retry_after_too_small_buffer_keeps_the_order(hmm):
+    """A hipstr_multi_next that fails because the caller's buffers are too small (return code 3) consumes nothing: neither the
+    device stream's ticket nor the entry of the global order.  The retry and everything after it still pair ticket and result."""
+    import ctypes as C
+    lib = hmm; _multi_sigs(lib)
+    sb = capi.SynthBatch(n_loci=12, reads_per_locus=15, n_str_alleles=5, seed=51)
+    pieces = _pieces(sb, list(range(13)))
+    want = [capi.run_align(hmm, "hipstr_hmm_", p.ptr, fill=FILL) for p in pieces]
+    devs = np.zeros(2, np.int32)
+    m = lib.hipstr_multi_open(2, devs.ctypes.data_as(capi._i32p), 200, None)          # blocks of ~3 loci alternate between two streams
+    assert m, lib.hipstr_last_error()
+    for i, p in enumerate(pieces):
+        assert lib.hipstr_multi_submit(m, p.ptr) == i
+    for i, (wp, ws) in enumerate(want):
+        t = C.c_int64(); no = C.c_int64(); nr = C.c_int64()
+        assert lib.hipstr_multi_next_size(m, C.byref(t), C.byref(no), C.byref(nr)) == 0 and t.value == i
+        probs = np.full(max(no.value, 1), FILL); seeds = np.full(max(nr.value, 1), -7, np.int32)
+        if i in (1, 4, 5, 9):               # first try with buffers one element short (incl. a ticket that is the last of its block)
+            assert lib.hipstr_multi_next(m, C.byref(t), probs.ctypes.data_as(capi._f64p), probs.size - 1, seeds.ctypes.data_as(capi._i32p), seeds.size) == 3
+            assert b"too small" in lib.hipstr_last_error()
+        assert lib.hipstr_multi_next(m, C.byref(t), probs.ctypes.data_as(capi._f64p), probs.size, seeds.ctypes.data_as(capi._i32p), seeds.size) == 0, lib.hipstr_last_error()
+        assert t.value == i and np.array_equal(probs[:no.value], wp) and np.array_equal(seeds[:nr.value], ws), "ticket %d" % i
+    assert lib.hipstr_multi_next(m, None, None, 0, None, 0) == 2
+    lib.hipstr_multi_close(m)
+
+
+def test_take_in_any_order_beyond_the_slots(hmm):
+    """One thread submits more batches than the stream has slots and takes the LAST ticket first: the batch of a ticket somebody waits
+    for goes out even though every slot is held by batches with uncollected earlier tickets (it used to wait forever).  A ticket can
+    be taken once; a too-small buffer leaves it takeable."""
+    import ctypes as C
+    lib = hmm
+    lib.hipstr_stream_take.restype = C.c_int; lib.hipstr_stream_take.argtypes = [C.c_void_p, C.c_int64, capi._f64p, C.c_int64, capi._i32p, C.c_int64]
+    sb = capi.SynthBatch(n_loci=8, reads_per_locus=12, n_str_alleles=4, seed=61)
+    pieces = _pieces(sb, list(range(9)))
+    want = [capi.run_align(hmm, "hipstr_hmm_", p.ptr, fill=FILL) for p in pieces]
+    st = capi.Stream(hmm, slots=2, batch_alignments=1)          # every ticket its own batch, two slots
+    for p in pieces:
+        st.submit(p.ptr)
+    def take(t, short=0):
+        wp, ws = want[t]
+        probs = np.full(max(wp.size, 1), FILL); seeds = np.full(max(ws.size, 1), -7, np.int32)
+        rc = lib.hipstr_stream_take(st.h, t, probs.ctypes.data_as(capi._f64p), probs.size - short, seeds.ctypes.data_as(capi._i32p), seeds.size)
+        return rc, probs[:wp.size], seeds[:ws.size]
+    for t in (7, 3, 6):
+        rc, probs, seeds = take(t)
+        assert rc == 0, lib.hipstr_last_error()
+        assert np.array_equal(probs, want[t][0]) and np.array_equal(seeds, want[t][1])
+    assert take(7)[0] == 1 and b"collected already" in lib.hipstr_last_error()
+    assert take(5, short=1)[0] == 3                           # too small: the ticket stays
+    rc, probs, seeds = take(5)
+    assert rc == 0 and np.array_equal(probs, want[5][0])
+    got = []
+    while True:                                               # the rest in order
+        r = st.next(fill=FILL)
+        if r is None:
+            break
+        got.append(r[0]); assert np.array_equal(r[1], want[r[0]][0]) and np.array_equal(r[2], want[r[0]][1])
+    assert got == [0, 1, 2, 4]
+    st.close()
+
+
+def test_multi_on_every_visible_device(hmm):
+    """hipstr_multi_* with one stream per physical device (skipped on a one-GPU box): blocks dealt round robin, results in global order,
+    each identical to the one-shot call on device 0."""
+    import ctypes as C
+    import torch
+    n_dev = torch.cuda.device_count()
+    if n_dev < 2:
+        pytest.skip("one GPU visible")
+    lib = hmm; _multi_sigs(lib)
+    sb = capi.SynthBatch(n_loci=6 * n_dev, reads_per_locus=20, n_str_alleles=6, seed=71, mask_rate=0.1)
+    pieces = _pieces(sb, list(range(6 * n_dev + 1)))
+    want = [capi.run_align(hmm, "hipstr_hmm_", p.ptr, fill=FILL) for p in pieces]
+    devs = np.arange(n_dev, dtype=np.int32)
+    m = lib.hipstr_multi_open(n_dev, devs.ctypes.data_as(capi._i32p), 300, None)
+    assert m, lib.hipstr_last_error()
+    for i, p in enumerate(pieces):
+        assert lib.hipstr_multi_submit(m, p.ptr) == i
+    for i, (wp, ws) in enumerate(want):
+        t = C.c_int64(); no = C.c_int64(); nr = C.c_int64()
+        assert lib.hipstr_multi_next_size(m, C.byref(t), C.byref(no), C.byref(nr)) == 0
+        probs = np.full(max(no.value, 1), FILL); seeds = np.full(max(nr.value, 1), -7, np.int32)
+        assert lib.hipstr_multi_next(m, C.byref(t), probs.ctypes.data_as(capi._f64p), probs.size, seeds.ctypes.data_as(capi._i32p), seeds.size) == 0, lib.hipstr_last_error()
+        assert t.value == i and np.array_equal(probs[:no.value], wp) and np.array_equal(seeds[:nr.value], ws)
+    lib.hipstr_multi_close(m)
+    assert lib.hipstr_hmm_init(0) == 0        # back to device 0 for the tests that follow

@@ -177,6 +177,7 @@ def load_gt_fixture(path):
 
 
 FLOAT_STEP = 3e-6
+FLOAT_STEPS_SEEN = [0, 0]      # over the session: values that needed the widened window, values compared
 
 
 def assert_genotypes_close(got, want, tol, what=""):
@@ -220,3 +221,10 @@ def assert_genotypes_close(got, want, tol, what=""):
             g = np.asarray(want["gls"][s]); x = -10 * (g - g.max())
             assert np.all(np.abs(gp[bad] - wp[bad]) <= 1) and np.all(np.abs(x[bad] - np.round(x[bad])) < 10 * FLOAT_STEP), "%s pls of sample %d" % (what, s)
     assert steps[0] <= max(1, 0.01 * steps[1]), "%s: %d of %d values a float step away from the reference" % (what, steps[0], steps[1])
+    FLOAT_STEPS_SEEN[0] += steps[0]; FLOAT_STEPS_SEEN[1] += steps[1]
+    if steps[0]:            # reported in the pytest summary: how many values needed the widened window
+        import warnings
+        warnings.warn("%s: %d of %d GL / GLDIFF / unphased-posterior values one float step (<= %g) from the reference "
+                      "(device exp/log; they vanish with HIPSTR_DEBUG_HOST_LIBM=1: test_float_steps_vanish_with_host_libm)"
+                      % (what or "genotype calls", steps[0], steps[1], FLOAT_STEP))
+    return steps
