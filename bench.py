@@ -212,7 +212,7 @@ def pipeline_stages(capi, hmm, sb, loci, P):
     return out
 
 
-def end_to_end(capi, hmm, sb, loci, steps, device):
+def end_to_end(capi, hmm, sb, loci, steps, device, latency=True):
     """SURVEY §8(d)'s metric taken literally — wall time from host arrays in to aln_probs/seeds out (host flatten, H2D, kernels, D2H,
     the reference's output contract) — through the streaming C-ABI, fed the way the reference's caller produces work: ONE locus per
     submission (bam_processor.cpp:550-617).  `steps` passes over the batch go through one open stream back to back, a feeder
@@ -246,7 +246,7 @@ def end_to_end(capi, hmm, sb, loci, steps, device):
     st.close()
     # one-locus latency: a 30x locus (40 reads x 32 alleles) and an NS locus through the one-shot call, median of 30
     lat = {}
-    for name, (pp, aa) in (("40x32", (40, 32)), ("500x32", (500, 32)), ("50x4", (50, 4))):
+    for name, (pp, aa) in ((("40x32", (40, 32)), ("500x32", (500, 32)), ("50x4", (50, 4))) if latency else ()):
         one = capi.SynthBatch(n_loci=1, reads_per_locus=pp, n_str_alleles=aa, seed=77)
         pr = np.zeros(one.n_out); sd = np.zeros(one.n_reads, np.int32)
         ts = []
@@ -295,6 +295,11 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
+    # host threads of the library per rank: the usable cores of the node are shared by the ranks on it (each rank prepares its own batches)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    host_threads = max(1, usable_cores() // max(1, local_world))
+    if world > 1:
+        os.environ.setdefault("HIPSTR_HOST_THREADS", str(host_threads))
     from hipstr_amd import capi
     hmm = capi.load_hmm()
     if hmm.hipstr_hmm_init(local) != 0:
@@ -425,8 +430,21 @@ def main():
     if not os.environ.get("HIPSTR_BENCH_NOCHECK"):       # kernel ablation builds (timing only, results invalid) set this
         assert np.all(np.isfinite(probs)) and np.all(probs <= 1e-10), "forward scores must be finite log-likelihoods <= 0"
 
+    per_rank = None; e2e_multi = None
     if world > 1:
         dev_t = "cpu" if share else "cuda"
+        # every rank's own resident rate, and the end-to-end rate (host arrays in -> results out through the stream) of all ranks at once
+        mine = torch.tensor([float(n_aln.value) * args.steps / elapsed], dtype=torch.float64, device=dev_t)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [float(x.item()) for x in allr]
+        if not args.no_pipeline:
+            dist.barrier()
+            e = end_to_end(capi, hmm, sb, loci, max(2, min(args.steps, 3)), local, latency=False)
+            te = torch.tensor([e["seconds"]], dtype=torch.float64, device=dev_t); dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            ae = torch.tensor([float(n_aln.value) * e["passes"]], dtype=torch.float64, device=dev_t); dist.all_reduce(ae, op=dist.ReduceOp.SUM)
+            e2e_multi = {"alignments_per_s": float(ae.item()) / float(te.item()), "seconds_max_over_ranks": float(te.item()), "passes": e["passes"],
+                         "host_threads_per_rank": int(os.environ.get("HIPSTR_HOST_THREADS", host_threads))}
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -542,6 +560,12 @@ def main():
             # (inputs resident, as the bench contract defines it)
             out["value_end_to_end"] = e2e["alignments_per_s"]
             out["pipeline"] = pipeline_stages(capi, hmm, sb, loci, P)
+        if per_rank is not None:
+            out["per_rank_alignments_per_s"] = per_rank
+            out["host_threads_per_rank"] = int(os.environ.get("HIPSTR_HOST_THREADS", host_threads))
+        if e2e_multi is not None:
+            out["end_to_end"] = e2e_multi
+            out["value_end_to_end"] = e2e_multi["alignments_per_s"]
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(capi, args.workload)
         if args.workload == "c4":

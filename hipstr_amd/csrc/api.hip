@@ -105,6 +105,18 @@ struct Ctx {
   double *int_log = NULL, *qc = NULL, *qe = NULL, *m2m = NULL, *m2i = NULL;
   hipStream_t stream = NULL;
   BlockCache dev_cache, pin_cache;
+  // events are pooled like the blocks: a device batch needs five (hipEventCreate / Destroy cost ~10 us each: a tenth of a one-locus call)
+  std::mutex ev_m;
+  std::vector<hipEvent_t> ev_timing, ev_plain;
+  hipEvent_t get_event(bool timing){
+    { std::lock_guard<std::mutex> g(ev_m);
+      std::vector<hipEvent_t>& v = timing ? ev_timing : ev_plain;
+      if (!v.empty()){ hipEvent_t e = v.back(); v.pop_back(); return e; } }
+    hipEvent_t e = NULL;
+    if ((timing ? hipEventCreate(&e) : hipEventCreateWithFlags(&e, hipEventDisableTiming)) != hipSuccess) return NULL;
+    return e;
+  }
+  void put_event(hipEvent_t e, bool timing){ if (!e) return; std::lock_guard<std::mutex> g(ev_m); (timing ? ev_timing : ev_plain).push_back(e); }
 };
 }  // namespace hipstr
 
@@ -292,11 +304,10 @@ void hipstr_hmm_free(hipstr_dev_batch_t* dev){
     for (void* p : dev->dev_blocks) dev->ctx->dev_cache.put(p);
     for (void* p : dev->pin_blocks) dev->ctx->pin_cache.put(p);
   }
-  if (dev->ev0) hipEventDestroy(dev->ev0);
-  if (dev->ev1) hipEventDestroy(dev->ev1);
-  if (dev->ev_h2d) hipEventDestroy(dev->ev_h2d);
-  if (dev->ev_done) hipEventDestroy(dev->ev_done);
-  if (dev->ev_d2h) hipEventDestroy(dev->ev_d2h);
+  if (dev->ctx){         // back to the context's pool (an event that is still pending is simply recorded again by its next user)
+    dev->ctx->put_event(dev->ev0, true); dev->ctx->put_event(dev->ev1, true);
+    dev->ctx->put_event(dev->ev_h2d, false); dev->ctx->put_event(dev->ev_done, false); dev->ctx->put_event(dev->ev_d2h, false);
+  }
   for (hipEvent_t e : dev->prof_pool) hipEventDestroy(e);
   delete dev;
 }
@@ -459,9 +470,9 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   dev->t_stage = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_stage0).count();
   HS_HIP_DEV(hipMemcpyAsync(dblk, stage, total, hipMemcpyHostToDevice, copy_stream));
   HS_HIP_DEV(hipMemsetAsync(h.aln_probs, 0, out_bytes, copy_stream));
-  HS_HIP_DEV(hipEventCreate(&dev->ev0)); HS_HIP_DEV(hipEventCreate(&dev->ev1));
-  HS_HIP_DEV(hipEventCreateWithFlags(&dev->ev_h2d, hipEventDisableTiming)); HS_HIP_DEV(hipEventCreateWithFlags(&dev->ev_done, hipEventDisableTiming));
-  HS_HIP_DEV(hipEventCreateWithFlags(&dev->ev_d2h, hipEventDisableTiming));
+  dev->ev0 = ctx->get_event(true); dev->ev1 = ctx->get_event(true);
+  dev->ev_h2d = ctx->get_event(false); dev->ev_done = ctx->get_event(false); dev->ev_d2h = ctx->get_event(false);
+  if (!dev->ev0 || !dev->ev1 || !dev->ev_h2d || !dev->ev_done || !dev->ev_d2h){ g_err = "hipEventCreate failed"; hipstr_hmm_free(dev); return NULL; }
   HS_HIP_DEV(hipEventRecord(dev->ev_h2d, copy_stream));
   if (getenv("HIPSTR_TIMING"))
     fprintf(stderr, "hipstr_hmm_upload: total %.3f ms (prepare %.3f, blocks + staging %.3f), %zu B of tables, %lld alignments\n",

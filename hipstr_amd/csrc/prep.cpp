@@ -13,12 +13,14 @@
 #include <atomic>
 #include <thread>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <unordered_map>
 
 namespace hipstr {
 
@@ -42,15 +44,75 @@ int host_threads(){
   return n;
 }
 
+// Work sharing on a persistent pool: the library's host work comes in bursts of a few milliseconds (fragments of a batch, its launch
+// plan, the staging copy, the scatter of results), several per batch — starting and joining 15 threads for each of them cost as much
+// as some of the bursts.  The pool's threads (host_threads() - 1, started on first use) sleep on a condition variable; a caller posts
+// a job — a loop body and a counter that hands out its indices —, works on it itself and returns when every index is done.  Several
+// callers may post at once (the stream's worker thread, a collector scattering results): jobs are served oldest first.
+namespace {
+struct PoolJob {
+  const std::function<void(int)>* fn; int n, max_workers;
+  std::atomic<int> next{0}, done{0}, workers{0};
+};
+struct Pool {
+  std::mutex m;
+  std::condition_variable cv;
+  std::vector<PoolJob*> jobs;
+  std::vector<std::thread> threads;
+  bool stop = false;
+  ~Pool(){
+    { std::lock_guard<std::mutex> g(m); stop = true; }
+    cv.notify_all();
+    for (std::thread& t : threads) t.join();
+  }
+  void ensure(int n_workers){
+    std::lock_guard<std::mutex> g(m);
+    while ((int)threads.size() < n_workers) threads.emplace_back([this]{ serve(); });
+  }
+  static void run(PoolJob* j){
+    for (int i = j->next.fetch_add(1); i < j->n; i = j->next.fetch_add(1)){ (*j->fn)(i); j->done.fetch_add(1, std::memory_order_release); }
+  }
+  void serve(){
+    std::unique_lock<std::mutex> g(m);
+    for (;;){
+      PoolJob* pick = NULL;
+      for (PoolJob* j : jobs)
+        if (j->next.load(std::memory_order_relaxed) < j->n && j->workers.load(std::memory_order_relaxed) < j->max_workers){ pick = j; break; }
+      if (!pick){ if (stop) return; cv.wait(g); continue; }
+      pick->workers.fetch_add(1);
+      g.unlock();
+      run(pick);
+      g.lock();
+      pick->workers.fetch_sub(1);
+      cv.notify_all();                 // the poster may be waiting for the last helper to leave its job
+    }
+  }
+};
+Pool& pool(){ static Pool p; return p; }
+}  // namespace
+
 void parallel_for(int n, int max_threads, const std::function<void(int)>& fn){
   const int nt = std::max(1, std::min(n, max_threads));
   if (nt == 1){ for (int i = 0; i < n; i++) fn(i); return; }
-  std::atomic<int> next(0);
-  auto work = [&](){ for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
-  std::vector<std::thread> pool;
-  for (int t = 1; t < nt; t++) pool.emplace_back(work);
-  work();
-  for (std::thread& t : pool) t.join();
+  static const bool no_pool = getenv("HIPSTR_HOST_POOL") && atoi(getenv("HIPSTR_HOST_POOL")) == 0;      // threads per call, as before (for comparison)
+  if (no_pool){
+    std::atomic<int> next(0);
+    auto work = [&](){ for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (std::thread& t : th) t.join();
+    return;
+  }
+  Pool& P = pool();
+  P.ensure(std::max(host_threads(), nt) - 1);
+  PoolJob job; job.fn = &fn; job.n = n; job.max_workers = nt - 1;
+  { std::lock_guard<std::mutex> g(P.m); P.jobs.push_back(&job); }
+  P.cv.notify_all();
+  Pool::run(&job);
+  std::unique_lock<std::mutex> g(P.m);       // indices are handed out; wait for the helpers still inside the body, then retire the job
+  P.cv.wait(g, [&]{ return job.done.load(std::memory_order_acquire) == n && job.workers.load() == 0; });
+  P.jobs.erase(std::find(P.jobs.begin(), P.jobs.end(), &job));
 }
 
 
@@ -286,7 +348,7 @@ static void simple_table_entry(int lim, int U0, int tail, double ent[3]){
   if (ent[2] < 1e300) ent[2] *= g_bnd_scale.load();      // tests: shrink the guarantee (HIPSTR_DEBUG_BND_SCALE)
 }
 
-void emit_stropt(const std::string& blk, int period, const double* stutter, Prepared& out){
+void emit_stropt(const std::string& blk, int period, const double* stutter, Prepared& out, bool forward_only = false){
   const HostTables& T = host_tables();
   const int B = blk.size();
   hs_stropt_t so; memset(&so, 0, sizeof so);
@@ -313,6 +375,7 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
     const int D = -(q+1)*period;
     out.f64pool.push_back(B+D >= 0 ? -T.int_log[B+D+1] : 0.0);              // StutterAlignerClass.cpp:112
   }
+  const size_t visits_begin = out.visits.size();
   // insertion visiting list (StutterAlignerClass.cpp:74-96); uses the shift-`period` run table
   {
     const std::vector<int> up = upstream_runs(blk, period);
@@ -404,6 +467,21 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
     so.shape[q] = classify(so.del_off[q], so.del_len[q], B+D);
     if (so.shape[q] < 0 && piecewise(so.del_off[q], so.del_len[q], B+D, pw[q])) so.shape[q] = HS_SHAPE_PIECEWISE;
   }
+  // The forward kernels read a visiting list only where it has no closed form (shape -1: replayed entry by entry; the traceback also
+  // replays the piecewise-simple ones).  An option whose lists all have one — periodic and, for the forward pass, once-or-twice
+  // interrupted blocks: nearly all — keeps none of them (they were 20 % of a batch's table bytes).
+  {
+    bool any_generic = false;
+    for (int k = 0; k <= HS_MAXREP; k++){
+      const int tail = (k == HS_MAXREP) ? B : B - (k+1)*period;
+      any_generic |= (tail >= 0 && (so.shape[k] == -1 || (!forward_only && so.shape[k] < 0)));
+    }
+    if (!any_generic){
+      out.visits.resize(visits_begin);
+      so.ins_off = (int32_t)visits_begin; so.ins_len = 0;
+      for (int q = 0; q < HS_MAXREP; q++){ so.del_off[q] = (int32_t)visits_begin; so.del_len[q] = 0; }
+    }
+  }
   // the descriptor slots are read only where a shape says "piecewise" (hs_str_kernel_generic): 560 bytes that the periodic blocks —
   // nearly all of them — do not need
   bool any_pw = false;
@@ -445,6 +523,42 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
   out.stropts.push_back(so);
 }
 
+// Everything emit_stropt derives from (block, period, stutter model) — visiting lists, their shapes, the closed-form table, the 20
+// constants — is a function of those three alone, and the same STR options come back all the time: every round of
+// SeqStutterGenotyper::genotype() re-sends a locus with one or two alleles more (seq_stutter_genotyper.cpp:603-671), both sides of
+// a palindromic motif, neighbouring loci of a panel with the same motif.  A per-thread cache keyed by the three holds the option
+// record with its pool slices relative to their start; a hit appends copies (about 2 KB) instead of rebuilding them.
+struct StroptCached { hs_stropt_t so; std::vector<hs_visit_t> visits; std::vector<double> f64; std::vector<char> chars; };
+void emit_stropt_cached(const std::string& blk, int period, const double* stutter, Prepared& out){
+  static const bool off = getenv("HIPSTR_STROPT_CACHE") && atoi(getenv("HIPSTR_STROPT_CACHE")) == 0;
+  if (off || g_bnd_scale.load() != 1.0){ emit_stropt(blk, period, stutter, out, true); return; }
+  thread_local std::unordered_map<std::string, StroptCached> cache;
+  thread_local std::string key;
+  key.assign((const char*)stutter, 6*sizeof(double)); key.push_back((char)period); key.append(blk);
+  auto it = cache.find(key);
+  if (it == cache.end()){
+    const size_t v0 = out.visits.size(), f0 = out.f64pool.size(), c0 = out.chars.size();
+    emit_stropt(blk, period, stutter, out, true);
+    if (cache.size() >= 8192) cache.clear();
+    StroptCached& e = cache[key];
+    e.so = out.stropts.back();
+    e.visits.assign(out.visits.begin() + v0, out.visits.end()); e.f64.assign(out.f64pool.begin() + f0, out.f64pool.end());
+    e.chars.assign(out.chars.begin() + c0, out.chars.end());
+    e.so.seq_off -= (int32_t)c0; e.so.f64_off -= (int32_t)f0; e.so.tab_off -= (int32_t)f0; e.so.ins_off -= (int32_t)v0;
+    for (int q = 0; q < HS_MAXREP; q++) e.so.del_off[q] -= (int32_t)v0;
+    return;
+  }
+  const StroptCached& e = it->second;
+  const int32_t v0 = (int32_t)out.visits.size(), f0 = (int32_t)out.f64pool.size(), c0 = (int32_t)out.chars.size();
+  out.visits.insert(out.visits.end(), e.visits.begin(), e.visits.end());
+  out.f64pool.insert(out.f64pool.end(), e.f64.begin(), e.f64.end());
+  out.chars.insert(out.chars.end(), e.chars.begin(), e.chars.end());
+  hs_stropt_t so = e.so;
+  so.seq_off += c0; so.f64_off += f0; so.tab_off += f0; so.ins_off += v0;
+  for (int q = 0; q < HS_MAXREP; q++) so.del_off[q] += v0;
+  out.stropts.push_back(so);
+}
+
 }  // namespace
 
 // ---- helpers shared with the traceback path (trace.hip)
@@ -463,7 +577,15 @@ void debug_simple_table(int lim, int U0, int tail, double ent[3]){ g_bnd_scale =
 int check_batch(const hipstr_batch_t* b, std::string& err){
   if (b == NULL || b->n_loci < 0){ err = "null or negative-size batch"; return 1; }
   int opt_cursor = 0;
-  for (int l = 0; l < b->n_loci; l++){
+  for (int l = 0; l < b->n_loci; l++)
+    if (check_locus(b, l, &opt_cursor, err)) return 1;
+  return 0;
+}
+
+// One locus of check_batch; *opt_cursor = index of the locus' first block option in opt_off, advanced past the locus.
+int check_locus(const hipstr_batch_t* b, int l, int* opt_cursor_io, std::string& err){
+  int opt_cursor = *opt_cursor_io;
+  {
     const int period = b->period[l];
     if (period < 1 || period > 9){ err = "STR period must be in [1,9] (stutter_model.h:38)"; return 1; }
     int64_t A = 1;
@@ -491,6 +613,7 @@ int check_batch(const hipstr_batch_t* b, std::string& err){
       if (s >= 0 && (s > HS_MAX_SIDE_LEN || len-s-1 > HS_MAX_SIDE_LEN)){ err = "read side longer than 256 bases is not supported"; return 1; }
     }
   }
+  *opt_cursor_io = opt_cursor;
   return 0;
 }
 
@@ -535,12 +658,16 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
 
     // STR options: forward then reversed orientation
     const int so_base = out.stropts.size();
+    std::vector<std::string> sblk[2];                  // the STR options in side orientation
     for (int side = 0; side < 2; side++)
       for (int o = 0; o < nopts[1]; o++){
         std::string s = opt[1][o];
         if (side) std::reverse(s.begin(), s.end());
-        emit_stropt(s, period, b->stutter + 6*l, out);
+        emit_stropt_cached(s, period, b->stutter + 6*l, out);
+        sblk[side].push_back(std::move(s));
       }
+    std::vector<int32_t> str_opt_of(A);                // STR option of every allele
+    for (int k = 0; k < A; k++){ int32_t o3[3]; allele_options(nopts, k, o3); str_opt_of[k] = o3[1]; }
 
     // alleles in visit order, replaying the reference's row reuse (HapAligner.cpp:54-60, 612-634):
     // the lead block of a side is (re)computed only when reuse is off or it is the block that changed;
@@ -556,6 +683,21 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
       rowset_ids[rows] = id;
       return id;
     };
+    // boundary signature of every STR option per side: first base and HapBlock's right-run length there, last base and left-run length
+    // there (HapBlock.cpp:7-30, with its counter carried from the forward into the backward pass)
+    struct EndSig { char c_first, c_last; int run_first, run_last; };
+    struct RowsKey { int opt; char c; int run; int aux; int id; };
+    std::vector<EndSig> end_sig[2];
+    std::vector<RowsKey> lead_tab[2], trail_tab[2];
+    for (int side = 0; side < 2; side++)
+      for (int o = 0; o < nopts[1]; o++){
+        const std::string& q = sblk[side][o];
+        const int n = (int)q.size();
+        int count = 0, lr_last = 0, rr_first = 0;
+        for (int j = 1; j < n; j++){ count = (q[j-1] == q[j]) ? count+1 : 0; if (j == n-1) lr_last = count; }
+        for (int j = n-2; j >= 0; j--){ count = (q[j+1] == q[j]) ? count+1 : 0; if (j == 0) rr_first = count; }
+        end_sig[side].push_back(EndSig{ q[0], q[n-1], rr_first, lr_last });
+      }
     bool reuse = false;
     int lead_id[2] = {-1, -1};
     int n_realigned = 0;
@@ -575,23 +717,40 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
       loc.lt_stride = std::max(loc.lt_stride, al.n_flank);
       const int cb = k == 0 ? -1 : changed_block(nopts, k);
       for (int side = 0; side < 2; side++){
-        SideSeqs h;
-        for (int j = 0; j < 3; j++){
-          h.s[j] = opt[side ? 2-j : j][o3[side ? 2-j : j]];
-          if (side) std::reverse(h.s[j].begin(), h.s[j].end());
-        }
-        h.index();
+        // The rows of a flank block depend on the block and, through the homopolymer run that may cross the block boundary, on the
+        // STR block's first base and the run it starts (leading flank) or its last base and the run it ends (trailing flank) — never on
+        // more: the reference's extension stops after one non-empty neighbour (Haplotype.cpp:239-275).  The alleles of a locus mostly
+        // share flanks and motif, so the rows are built once per (flank option, boundary signature) and looked up afterwards.
+        const int o_lead = side ? o3[2] : o3[0], o_trail = side ? o3[0] : o3[2];
+        const int lead_len = (int)opt[side ? 2 : 0][o_lead].size();
+        const EndSig& es = end_sig[side][o3[1]];
+        SideSeqs h; bool have_h = false;
+        auto need_h = [&](){
+          if (have_h) return;
+          for (int j = 0; j < 3; j++){
+            h.s[j] = opt[side ? 2-j : j][o3[side ? 2-j : j]];
+            if (side) std::reverse(h.s[j].begin(), h.s[j].end());
+          }
+          h.index(); have_h = true;
+        };
+        auto cached = [&](std::vector<RowsKey>& tab, const RowsKey& key, int bi, int u0) -> int {
+          for (const RowsKey& e : tab) if (e.opt == key.opt && e.c == key.c && e.run == key.run && e.aux == key.aux) return e.id;
+          need_h();
+          RowsKey e = key; e.id = intern(flank_rows(h, bi, u0));
+          tab.push_back(e);
+          return e.id;
+        };
         const int side_changed = cb < 0 ? -1 : (side ? 2-cb : cb);
-        if (!reuse || side_changed <= 0) lead_id[side] = intern(flank_rows(h, 0, 0));
+        if (!reuse || side_changed <= 0) lead_id[side] = cached(lead_tab[side], RowsKey{o_lead, es.c_first, es.run_first, 0, 0}, 0, 0);
         al.lead_rows[side]  = lead_id[side];
         {
           std::vector<int>& ls = lead_sets[side];
           size_t slot = std::find(ls.begin(), ls.end(), lead_id[side]) - ls.begin();
           if (slot == ls.size()) ls.push_back(lead_id[side]);
           al.lead_slot[side] = (int32_t)slot;
-          loc.lead_flank[side] = std::max(loc.lead_flank[side], (int32_t)h.s[0].size());
+          loc.lead_flank[side] = std::max(loc.lead_flank[side], (int32_t)lead_len);
         }
-        al.trail_rows[side] = intern(flank_rows(h, 2, (int)h.s[0].size() + 1));
+        al.trail_rows[side] = cached(trail_tab[side], RowsKey{o_trail, es.c_last, es.run_last, lead_len, 0}, 2, lead_len + 1);
         al.str_opt[side]    = so_base + side*nopts[1] + o3[1];
       }
       reuse = true;
@@ -606,29 +765,38 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
       // from the block's right end, so a longer block with the same tail only appends terms)
       std::vector<int> ks;
       for (int k = 0; k < A; k++) if (out.alleles[loc.hap_begin + k].realign) ks.push_back(k);
-      auto block_of = [&](int k){
-        int32_t o3[3]; allele_options(nopts, k, o3);
-        std::string q = opt[1][o3[1]];
-        if (side) std::reverse(q.begin(), q.end());
-        return q;
-      };
+      auto block_of = [&](int k) -> const std::string& { return sblk[side][str_opt_of[k]]; };
       // alleles whose closed form is tabulated come first: they are the business of hs_str_kernel, the rest of hs_str_kernel_generic
-      auto tabbed = [&](int k){ return out.stropts[out.alleles[loc.hap_begin + k].str_opt[side]].tab_len > 0; };
-      std::stable_sort(ks.begin(), ks.end(), [&](int x, int y){
-        const bool tx = tabbed(x), ty = tabbed(y);
-        if (tx != ty) return tx;
-        const std::string a = block_of(x), b2 = block_of(y);
-        if (a.size() != b2.size()) return a.size() < b2.size();
-        return a < b2;
-      });
+      auto tabbed = [&](int k){ return out.stropts[so_base + side*nopts[1] + str_opt_of[k]].tab_len > 0; };
+      // (the STR options are ranked once — tabulated first, then by length, then by sequence — and the alleles sorted by their option's rank)
+      std::vector<int> opt_rank(nopts[1]);
+      {
+        std::vector<int> os(nopts[1]);
+        for (int o = 0; o < nopts[1]; o++) os[o] = o;
+        std::stable_sort(os.begin(), os.end(), [&](int x, int y){
+          const bool tx = out.stropts[so_base + side*nopts[1] + x].tab_len > 0, ty = out.stropts[so_base + side*nopts[1] + y].tab_len > 0;
+          if (tx != ty) return tx;
+          const std::string& a = sblk[side][x]; const std::string& b2 = sblk[side][y];
+          if (a.size() != b2.size()) return a.size() < b2.size();
+          return a < b2;
+        });
+        int rank = 0;
+        for (int i = 0; i < nopts[1]; i++){
+          if (i > 0 && sblk[side][os[i]] != sblk[side][os[i-1]]) rank++;        // equal sequences compare equal, as before
+          opt_rank[os[i]] = rank;
+        }
+      }
+      std::stable_sort(ks.begin(), ks.end(), [&](int x, int y){ return opt_rank[str_opt_of[x]] < opt_rank[str_opt_of[y]]; });
       loc.order_off[side] = out.str_order.size();
       loc.n_tab[side] = 0; loc.n_short[side] = 0;
       loc.rec_off[side] = (int32_t)(out.grp_recs.size() / HS_GRP_REC_DWORDS);
       loc.ndrow_off[side] = (int32_t)out.nd_rows.size(); loc.n_ndrows[side] = 0;
       int fam_row0 = 0, fam_k = 0;                     // first row of the current family of alleles (blocks growing by one repeat unit), position in it
-      std::string prev;
+      static const std::string no_block;
+      const std::string* prev_p = &no_block;
       for (size_t i = 0; i < ks.size(); i++){
-        const std::string cur = block_of(ks[i]);
+        const std::string& prev = *prev_p;
+        const std::string& cur = block_of(ks[i]);
         const bool first_of_kind = (i == 0) || (tabbed(ks[i]) != tabbed(ks[i-1]));
         const bool chained = !first_of_kind && cur.size() >= prev.size() && cur.compare(cur.size() - prev.size(), prev.size(), prev) == 0;
         // bit 29: a tabulated (hence periodic) block that extends the previous one by exactly one repeat unit: the read-end deletion
@@ -661,7 +829,7 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
           }
           if (period > HS_GRP_MAXP) loc.n_short[side]++;              // no instantiation of hs_str_group_kernel_p for this period
         }
-        prev = cur;
+        prev_p = &cur;
       }
     }
     for (int side = 0; side < 2; side++){      // alleles sharing a trailing-flank rowset run as lanes of one wavefront (<= 64 each)
@@ -905,17 +1073,34 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
         }
       }
     });
-    for (Run& R : runs){
-      const int32_t base = (int32_t)out.tpack.size();
-      for (hs_item_t& it : R.lead) it.active += base;
-      for (hs_item_t& it : R.trail) it.active += base;
-      for (hs_item_t& it : R.str) it.active += base;
-      out.grp_nd_cap = std::max(out.grp_nd_cap, R.nd_cap);
-      ch.n_long_sides += R.n_long;
-      out.tpack.insert(out.tpack.end(), R.tpack.begin(), R.tpack.end());
-      out.lead_items.insert(out.lead_items.end(), R.lead.begin(), R.lead.end());
-      out.trail_items.insert(out.trail_items.end(), R.trail.begin(), R.trail.end());
-      out.str_items.insert(out.str_items.end(), R.str.begin(), R.str.end());
+    {   // append the runs' pieces in locus order: where every piece goes follows from the sizes, the copies are shared by the host threads
+      struct At { size_t tp, le, tr, st; };
+      std::vector<At> at(runs.size() + 1);
+      at[0] = At{ out.tpack.size(), out.lead_items.size(), out.trail_items.size(), out.str_items.size() };
+      for (size_t i = 0; i < runs.size(); i++){
+        const Run& R = runs[i];
+        at[i+1] = At{ at[i].tp + R.tpack.size(), at[i].le + R.lead.size(), at[i].tr + R.trail.size(), at[i].st + R.str.size() };
+        out.grp_nd_cap = std::max(out.grp_nd_cap, R.nd_cap);
+        ch.n_long_sides += R.n_long;
+      }
+      const At& end = at[runs.size()];
+      out.tpack.resize(end.tp); out.lead_items.resize(end.le); out.trail_items.resize(end.tr); out.str_items.resize(end.st);
+      const int nblk = (int)std::min<size_t>(runs.size(), (size_t)host_threads()*4);
+      parallel_for(nblk, runs.size() >= 64 ? host_threads() : 1, [&](int blk){
+        const size_t i0 = runs.size()*blk/nblk, i1 = runs.size()*(blk + 1)/nblk;
+        for (size_t i = i0; i < i1; i++){
+          Run& R = runs[i];
+          const int32_t base = (int32_t)at[i].tp;
+          for (hs_item_t& it : R.lead) it.active += base;
+          for (hs_item_t& it : R.trail) it.active += base;
+          for (hs_item_t& it : R.str) it.active += base;
+          std::copy(R.tpack.begin(), R.tpack.end(), out.tpack.begin() + at[i].tp);
+          std::copy(R.lead.begin(), R.lead.end(), out.lead_items.begin() + at[i].le);
+          std::copy(R.trail.begin(), R.trail.end(), out.trail_items.begin() + at[i].tr);
+          std::copy(R.str.begin(), R.str.end(), out.str_items.begin() + at[i].st);
+          std::vector<hs_item_t>().swap(R.lead); std::vector<hs_item_t>().swap(R.trail); std::vector<hs_item_t>().swap(R.str); std::vector<int32_t>().swap(R.tpack);
+        }
+      });
     }
     ch.trail_end = out.trail_items.size();
     ch.str_end = out.str_items.size();
@@ -926,7 +1111,51 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
     memset(&ch, 0, sizeof ch); ch.active_begin = active_end;
     mr = lt = lead = col = nd = 0;
   };
-  for (size_t ai = 0; ai < out.active.size(); ai++){
+  // Workspace offsets are running sums over the active reads.  The usual case — everything fits one chunk — is done in blocks of reads:
+  // block totals in parallel, their prefix, then the offsets in parallel; a batch that needs cutting takes the read-by-read loop below.
+  bool ws_done = false;
+  if (out.active.size() >= 4096){
+    struct Sum { int64_t mr, lt, lead, col, nd, aln; int max_side; };
+    auto need_of = [&](size_t ai, Sum& z, hs_ws_t* w){
+      const hs_read_t& rd = out.reads[out.active[ai]];
+      const hs_locus_t& loc = out.loci[rd.locus];
+      const int n_side[2] = { rd.seed, rd.len - rd.seed - 1 };
+      const int64_t per6 = HS_MAXREP*(int64_t)loc.period;
+      if (w){ w->mr = z.mr; w->lt = z.lt; w->col = z.col; w->nd[0] = z.nd; w->nd[1] = z.nd + loc.n_ndrows[0]*per6; }
+      z.mr += (int64_t)loc.n_re*(rd.len-1); z.lt += (int64_t)loc.n_re*loc.lt_stride; z.col += 3*(int64_t)(rd.len-1);
+      z.nd += (loc.n_ndrows[0] + loc.n_ndrows[1])*per6;
+      for (int s = 0; s < 2; s++){
+        if (w) w->lead[s] = z.lead;
+        z.lead += (int64_t)loc.n_lead[s]*(n_side[s] + loc.lead_flank[s] + 1);
+        z.max_side = std::max(z.max_side, n_side[s]);
+      }
+      z.aln += loc.n_re;
+    };
+    const int nblk = host_threads()*4;
+    const size_t n = out.active.size();
+    std::vector<Sum> tot(nblk + 1);
+    parallel_for(nblk, host_threads(), [&](int b){
+      Sum z; memset(&z, 0, sizeof z);
+      for (size_t ai = n*b/nblk; ai < n*(b + 1)/nblk; ai++) need_of(ai, z, NULL);
+      tot[b + 1] = z;
+    });
+    memset(&tot[0], 0, sizeof(Sum));
+    for (int b = 1; b <= nblk; b++){
+      Sum& z = tot[b]; const Sum& y = tot[b - 1];
+      z.mr += y.mr; z.lt += y.lt; z.lead += y.lead; z.col += y.col; z.nd += y.nd; z.aln += y.aln; z.max_side = std::max(z.max_side, y.max_side);
+    }
+    const Sum& all = tot[nblk];
+    if (all.mr <= ws_budget && all.lt <= ws_budget && all.lead <= ws_budget && all.nd <= ws_budget){
+      parallel_for(nblk, host_threads(), [&](int b){
+        Sum z = tot[b]; z.max_side = 0;
+        for (size_t ai = n*b/nblk; ai < n*(b + 1)/nblk; ai++){ hs_ws_t w; need_of(ai, z, &w); out.ws[ai] = w; }
+      });
+      mr = all.mr; lt = all.lt; lead = all.lead; col = all.col; nd = all.nd;
+      ch.n_alignments = all.aln; out.max_side_len = std::max(out.max_side_len, all.max_side);
+      ws_done = true;
+    }
+  }
+  for (size_t ai = 0; !ws_done && ai < out.active.size(); ai++){
     const hs_read_t& rd = out.reads[out.active[ai]];
     const hs_locus_t& loc = out.loci[rd.locus];
     const int n_side[2] = { rd.seed, rd.len - rd.seed - 1 };

@@ -13,6 +13,7 @@
 
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -71,6 +72,34 @@ struct OwnedBatch {
     tickets.push_back(t);
     return NULL;
   }
+  // Locus l of `b` (whose first block option is opt0 in opt_off) as a submission of its own: what append() does for a one-locus batch,
+  // straight from the caller's arrays.
+  const char* append_locus(const hipstr_batch_t* b, int l, int opt0, int64_t ticket){
+    const int nopt = b->blk_nopts[3*l] + b->blk_nopts[3*l+1] + b->blk_nopts[3*l+2];
+    const int r0 = b->read_off[l], r1 = b->read_off[l+1], h0 = b->hap_off[l], h1 = b->hap_off[l+1];
+    const int32_t s0 = b->opt_off[opt0], s1 = b->opt_off[opt0 + nopt], b0 = b->base_off[r0], b1 = b->base_off[r1], c0 = b->cigar_off[r0], c1 = b->cigar_off[r1];
+    const int64_t P = r1 - r0, A = h1 - h0;
+    if (P < 0 || A < 1) return "inconsistent read_off / hap_off";
+    if ((int64_t)bases.size() + (b1 - b0) > INT32_MAX || (int64_t)seq.size() + (s1 - s0) > INT32_MAX) return "pending batch exceeds 2 GiB of bases";
+    Ticket t; t.id = ticket; t.l0 = (int32_t)period.size(); t.l1 = t.l0 + 1; t.r0 = read_off.back(); t.r1 = t.r0 + (int32_t)P; t.out0 = n_out;
+    blk_start.insert(blk_start.end(), b->blk_start + 3*l, b->blk_start + 3*l + 3); blk_end.insert(blk_end.end(), b->blk_end + 3*l, b->blk_end + 3*l + 3);
+    blk_nopts.insert(blk_nopts.end(), b->blk_nopts + 3*l, b->blk_nopts + 3*l + 3); period.push_back(b->period[l]);
+    stutter.insert(stutter.end(), b->stutter + 6*l, b->stutter + 6*l + 6);
+    const int32_t seq0 = (int32_t)seq.size() - s0, base0 = (int32_t)bases.size() - b0, cig0 = (int32_t)cigar_op.size() - c0;
+    for (int i = 1; i <= nopt; i++) opt_off.push_back(seq0 + b->opt_off[opt0 + i]);
+    seq.append(b->seq + s0, s1 - s0);
+    hap_off.push_back(hap_off.back() + (int32_t)A); read_off.push_back(read_off.back() + (int32_t)P);
+    n_out += P*A; work += P*A;
+    if (b->realign_hap) realign_hap.insert(realign_hap.end(), b->realign_hap + h0, b->realign_hap + h1); else realign_hap.insert(realign_hap.end(), (size_t)A, 1);
+    for (int r = r0 + 1; r <= r1; r++){ base_off.push_back(base0 + b->base_off[r]); cigar_off.push_back(cig0 + b->cigar_off[r]); }
+    bases.append(b->bases + b0, b1 - b0); quals.append(b->quals + b0, b1 - b0);
+    read_start.insert(read_start.end(), b->read_start + r0, b->read_start + r1);
+    cigar_op.append(b->cigar_op + c0, c1 - c0); cigar_len.insert(cigar_len.end(), b->cigar_len + c0, b->cigar_len + c1);
+    if (b->realign_read) realign_read.insert(realign_read.end(), b->realign_read + r0, b->realign_read + r1); else realign_read.insert(realign_read.end(), (size_t)P, 1);
+    t.out1 = n_out;
+    tickets.push_back(t);
+    return NULL;
+  }
   const hipstr_batch_t* finish(){
     if (cigar_len.empty()) cigar_len.push_back(0);
     view.n_loci = (int32_t)period.size();
@@ -99,7 +128,7 @@ struct InFlight {
 struct hipstr_stream {
   hipstr::Ctx* ctx = NULL;
   hipStream_t copy_stream = NULL, d2h_stream = NULL;     // tables to the device / results back: neither waits for the other
-  int slots = 3;
+  int slots = 4;
   int64_t batch_work = (int64_t)4 << 20;
   std::mutex m;
   std::condition_variable cv_work, cv_done, cv_slots;
@@ -113,7 +142,7 @@ struct hipstr_stream {
   std::vector< std::pair<int64_t,int64_t> > sizes;     // per ticket not yet delivered: (n_out, n_reads), indexed by ticket - sizes_base
   int64_t sizes_base = 0;
   bool closing = false;
-  std::thread worker;
+  std::vector<std::thread> workers;              // each prepares, uploads and launches whole batches; their kernels share the context's stream
   hipstr_stream_stats_t stats;
   std::chrono::steady_clock::time_point t_open;
 };
@@ -130,7 +159,8 @@ void worker_loop(hipstr_stream* s){
       std::unique_lock<std::mutex> g(s->m);
       // work = a batch that was sent, or — when a collector is waiting for a ticket that still sits in the pending batch — the pending
       // batch as it is: whatever accumulated while the previous batch was being prepared goes out together
-      auto have_work = [&]{ return !s->ready.empty() || (s->waiting > 0 && s->pending && !s->pending->tickets.empty()); };
+      // (only when no other worker is preparing a batch: the ticket waited for is most likely in that one, and the pending batch keeps filling)
+      auto have_work = [&]{ return !s->ready.empty() || (s->waiting > 0 && s->in_worker == 0 && s->pending && !s->pending->tickets.empty()); };
       // `slots` bounds the batches in flight — unless a collector waits for a ticket that is not launched yet while every slot is held
       // by batches with uncollected EARLIER tickets (tickets may be taken in any order): then the batch goes out all the same
       s->cv_work.wait(g, [&]{ return s->closing || (have_work() && ((int)s->flying.size() + s->in_worker < s->slots || s->waiting > 0)); });
@@ -146,6 +176,9 @@ void worker_loop(hipstr_stream* s){
       f->failed = true; f->err = hipstr_last_error();
     }
     const double host_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (getenv("HIPSTR_TIMING"))
+      fprintf(stderr, "stream: batch of %zu tickets (%lld pairs) prepared + launched %.3f .. %.3f ms after open\n", ob->tickets.size(), (long long)ob->work,
+              1e3*std::chrono::duration<double>(t0 - s->t_open).count(), 1e3*std::chrono::duration<double>(std::chrono::steady_clock::now() - s->t_open).count());
     {
       std::lock_guard<std::mutex> g(s->m);
       s->flying.push_back(f); s->in_worker--;
@@ -175,7 +208,12 @@ hipstr_stream_t* hipstr_stream_open(const hipstr_stream_opts_t* opts){
     hipstr::api_fail("hipStreamCreate failed"); delete s; return NULL; }
   memset(&s->stats, 0, sizeof s->stats);
   s->t_open = std::chrono::steady_clock::now();
-  s->worker = std::thread(worker_loop, s);
+  // Three workers by default (HIPSTR_STREAM_WORKERS): preparing a batch has serial stretches between its parallel ones (merging the
+  // fragments, the launch plan, packing the staging block), during which a second batch's parallel stretches keep the host threads
+  // busy; with small loci (30x, ten alleles) the host side is what bounds the stream.
+  int nw = 3;
+  if (const char* e = getenv("HIPSTR_STREAM_WORKERS")){ const int v = atoi(e); if (v >= 1 && v <= 8) nw = v; }
+  for (int w = 0; w < nw; w++) s->workers.emplace_back(worker_loop, s);
   return s;
 }
 
@@ -202,26 +240,29 @@ int64_t hipstr_stream_submit(hipstr_stream_t* s, const hipstr_batch_t* loci){
 int hipstr_stream_submit_each(hipstr_stream_t* s, const hipstr_batch_t* loci, int64_t* first_ticket){
   if (!s || !loci) return hipstr::api_fail("null argument");
   int opt = 0;
-  for (int l = 0; l < loci->n_loci; l++){
-    hipstr_batch_t one = *loci;
-    const int nopt = loci->blk_nopts[3*l] + loci->blk_nopts[3*l+1] + loci->blk_nopts[3*l+2];
-    const int r0 = loci->read_off[l], r1 = loci->read_off[l+1], h0 = loci->hap_off[l];
-    // a one-locus view into the caller's arrays: offsets are re-based copies, payload pointers are shifted
-    std::vector<int32_t> opt_off(nopt + 1), read_off(2), hap_off(2), base_off(r1 - r0 + 1), cigar_off(r1 - r0 + 1);
-    for (int i = 0; i <= nopt; i++) opt_off[i] = loci->opt_off[opt + i] - loci->opt_off[opt];
-    read_off[0] = 0; read_off[1] = r1 - r0; hap_off[0] = 0; hap_off[1] = loci->hap_off[l+1] - h0;
-    for (int r = r0; r <= r1; r++){ base_off[r - r0] = loci->base_off[r] - loci->base_off[r0]; cigar_off[r - r0] = loci->cigar_off[r] - loci->cigar_off[r0]; }
-    one.n_loci = 1;
-    one.blk_start = loci->blk_start + 3*l; one.blk_end = loci->blk_end + 3*l; one.blk_nopts = loci->blk_nopts + 3*l; one.period = loci->period + l;
-    one.stutter = loci->stutter + 6*l; one.opt_off = opt_off.data(); one.seq = loci->seq + loci->opt_off[opt]; one.hap_off = hap_off.data();
-    one.realign_hap = loci->realign_hap ? loci->realign_hap + h0 : NULL; one.read_off = read_off.data(); one.base_off = base_off.data();
-    one.bases = loci->bases + loci->base_off[r0]; one.quals = loci->quals + loci->base_off[r0]; one.read_start = loci->read_start + r0;
-    one.cigar_off = cigar_off.data(); one.cigar_op = loci->cigar_op + loci->cigar_off[r0]; one.cigar_len = loci->cigar_len + loci->cigar_off[r0];
-    one.realign_read = loci->realign_read ? loci->realign_read + r0 : NULL;
-    const int64_t t = hipstr_stream_submit(s, &one);
-    if (t < 0) return 1;
-    if (l == 0 && first_ticket) *first_ticket = t;
-    opt += nopt;
+  const int RUN = 64;                              // loci checked without the stream's lock, then appended under one
+  for (int l0 = 0; l0 < loci->n_loci; l0 += RUN){
+    const int l1 = std::min(loci->n_loci, l0 + RUN);
+    int opt0[RUN]; std::string why; int n_ok = 0;
+    for (int l = l0; l < l1; l++, n_ok++){       // a locus that prepare_batch would refuse is turned away here, before it shares a batch with others
+      opt0[l - l0] = opt;
+      if (hipstr::check_locus(loci, l, &opt, why)) break;
+    }
+    {
+      std::lock_guard<std::mutex> g(s->m);
+      if (s->closing) return hipstr::api_fail("stream is closing");
+      for (int l = l0; l < l0 + n_ok; l++){
+        if (!s->pending) s->pending = new OwnedBatch();
+        const int64_t ticket = s->next_ticket;
+        const int64_t out_before = s->pending->n_out; const int32_t reads_before = s->pending->read_off.back();
+        if (const char* w2 = s->pending->append_locus(loci, l, opt0[l - l0], ticket)) return hipstr::api_fail(w2);
+        s->next_ticket++;
+        s->sizes.push_back(std::make_pair(s->pending->n_out - out_before, (int64_t)(s->pending->read_off.back() - reads_before)));
+        if (s->pending->work >= s->batch_work) flush_locked(s);
+        if (l == 0 && first_ticket) *first_ticket = ticket;
+      }
+    }
+    if (n_ok < l1 - l0) return hipstr::api_fail(why);     // the loci before the refused one are in
   }
   return 0;
 }
@@ -247,6 +288,7 @@ int hipstr_stream_collect(hipstr_stream_t* s, int64_t n_tickets, double* aln_pro
 
 int hipstr_stream_flush(hipstr_stream_t* s){
   if (!s) return hipstr::api_fail("null argument");
+  if (getenv("HIPSTR_TIMING")) fprintf(stderr, "stream: flush called %.3f ms after open\n", 1e3*std::chrono::duration<double>(std::chrono::steady_clock::now() - s->t_open).count());
   std::lock_guard<std::mutex> g(s->m);
   flush_locked(s);
   return 0;
@@ -301,6 +343,9 @@ int hipstr_stream_take(hipstr_stream_t* s, int64_t ticket, double* aln_probs, in
         const auto t0 = std::chrono::steady_clock::now();
         if (hipstr::results_wait(f->dev) != 0){ f->failed = true; f->err = hipstr_last_error(); }
         f->landed = true;
+        if (getenv("HIPSTR_TIMING"))
+          fprintf(stderr, "stream: batch of %zu tickets landed %.3f ms after open (collector waited from %.3f)\n", f->ob->tickets.size(),
+                  1e3*std::chrono::duration<double>(std::chrono::steady_clock::now() - s->t_open).count(), 1e3*std::chrono::duration<double>(t0 - s->t_open).count());
         std::lock_guard<std::mutex> g(s->m);
         s->stats.wait_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       }
@@ -380,7 +425,7 @@ int hipstr_stream_close(hipstr_stream_t* s){
     s->cv_done.wait(g, [&]{ return s->waiting == 0; });
   }
   s->cv_work.notify_all();
-  if (s->worker.joinable()) s->worker.join();
+  for (std::thread& t : s->workers) if (t.joinable()) t.join();
   hipstr::api_bind(s->ctx);
   for (InFlight* f : s->flying){ if (f->dev) hipstr::free_landed(f->dev, false); delete f->ob; delete f; }
   hipStreamSynchronize(s->copy_stream); hipStreamSynchronize(s->d2h_stream);

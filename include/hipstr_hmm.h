@@ -182,7 +182,7 @@ int hipstr_hmm_process_reads_seeded(const hipstr_batch_t* batch, const int32_t* 
 typedef struct hipstr_stream hipstr_stream_t;
 typedef struct hipstr_stream_opts {
   int32_t device;             /* ordinal; hipstr_stream_open initialises it like hipstr_hmm_init                              */
-  int32_t slots;              /* batches in flight (prepared / running / waiting to be collected); 0 = 3                      */
+  int32_t slots;              /* batches in flight (prepared / running / waiting to be collected); 0 = 4                      */
   int64_t batch_alignments;   /* a pending batch is sent once it holds this many (read x haplotype) pairs; 0 = 4 Mi           */
 } hipstr_stream_opts_t;
 typedef struct hipstr_stream_stats {
