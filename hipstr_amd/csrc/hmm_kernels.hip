@@ -1917,6 +1917,7 @@ hs_nd_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
   if (nrows == 0) return;
   const int p = uni(loc->period), sixp = HS_MAXREP*p;
   const int n = uni(side ? rd.len - rd.seed - 1 : rd.seed);
+  if (n > HS_MAX_SIDE_LEN) return;                      // not in a group: hs_str_kernel sums for itself
   __shared__ double E[4][HS_MAX_SIDE_LEN];              // emission log of every column against A, C, T, G (code = (char >> 1) & 3)
   for (int c = tid; c < n; c += 256){
     const int src = rd.base_off + (side ? rd.len - 1 - c : c);

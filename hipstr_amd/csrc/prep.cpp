@@ -599,7 +599,7 @@ int check_locus(const hipstr_batch_t* b, int l, int* opt_cursor_io, std::string&
         if (len < 0){ err = "opt_off must not decrease"; return 1; }
         if (k != 1 && len == 0){ err = "empty flank sequence"; return 1; }
         if (k == 1 && len == 0){ err = "empty STR allele is not supported"; return 1; }
-        if (k == 1 && len > 1024){ err = "STR allele longer than 1024 bp is not supported"; return 1; }
+        if (k == 1 && len > HS_MAX_STR_BP){ err = "STR allele longer than 2047 bp is not supported"; return 1; }
       }
     }
     if (A != b->hap_off[l+1]-b->hap_off[l]){ err = "hap_off does not match the product of block options"; return 1; }
@@ -610,7 +610,7 @@ int check_locus(const hipstr_batch_t* b, int l, int* opt_cursor_io, std::string&
       const int len = b->base_off[r+1] - b->base_off[r];
       const int s = calc_seed_base(b, l, r);
       if (s == -2){ err = "Invalid alignment seed or unrecognized CIGAR char (HapAligner.cpp:309,316)"; return 1; }
-      if (s >= 0 && (s > HS_MAX_SIDE_LEN || len-s-1 > HS_MAX_SIDE_LEN)){ err = "read side longer than 256 bases is not supported"; return 1; }
+      if (s >= 0 && (s > HS_MAX_SIDE_FWD || len-s-1 > HS_MAX_SIDE_FWD)){ err = "read side longer than 1024 bases is not supported"; return 1; }
     }
   }
   *opt_cursor_io = opt_cursor;
@@ -644,7 +644,7 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
         if (opt[k][o].empty()){ err = "empty flank sequence"; return 1; }
     for (size_t o = 0; o < opt[1].size(); o++){
       if (opt[1][o].empty()){ err = "empty STR allele is not supported"; return 1; }
-      if (opt[1][o].size() > 1024){ err = "STR allele longer than 1024 bp is not supported"; return 1; }
+      if (opt[1][o].size() > HS_MAX_STR_BP){ err = "STR allele longer than 2047 bp is not supported"; return 1; }
       out.max_B = std::max(out.max_B, (int32_t)opt[1][o].size());
     }
     const int A = nopts[0]*nopts[1]*nopts[2];
@@ -862,7 +862,7 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
         rd.seed = s;
         sh.seeds[r] = s;
         if (s >= 0){
-          if (s > HS_MAX_SIDE_LEN || rd.len-s-1 > HS_MAX_SIDE_LEN){ err = "read side longer than 256 bases is not supported"; return 1; }
+          if (s > HS_MAX_SIDE_FWD || rd.len-s-1 > HS_MAX_SIDE_FWD){ err = "read side longer than 1024 bases is not supported"; return 1; }
           out.active.push_back(r);
           out.n_alignments += n_realigned;
           out.max_read_len = std::max(out.max_read_len, rd.len);

@@ -286,6 +286,45 @@ int hipstr_stream_collect(hipstr_stream_t* s, int64_t n_tickets, double* aln_pro
   return 0;
 }
 
+// One-shot call that refuses loci one by one (hipstr_hmm.h): the loci that pass check_locus are gathered into a batch of their own,
+// processed by hipstr_hmm_process_reads, and their blocks copied back to where the caller's layout has them.
+int hipstr_hmm_process_reads_each(const hipstr_batch_t* batch, double* aln_probs, int32_t* seeds, int32_t* locus_status){
+  if (!batch || !aln_probs || !seeds || !locus_status) return hipstr::api_fail("null argument");
+  const int n = batch->n_loci;
+  OwnedBatch ob;
+  std::vector<int> good; std::vector<int64_t> out_off(n + 1, 0);
+  std::string first_err;
+  int opt = 0;
+  for (int l = 0; l < n; l++){
+    out_off[l+1] = out_off[l] + (int64_t)(batch->read_off[l+1] - batch->read_off[l])*(batch->hap_off[l+1] - batch->hap_off[l]);
+    const int opt0 = opt; std::string why;
+    int nopt = 0; for (int k = 0; k < 3; k++) nopt += std::max(0, batch->blk_nopts[3*l+k]);
+    int cursor = opt0;
+    const bool bad = hipstr::check_locus(batch, l, &cursor, why) != 0;
+    opt = opt0 + nopt;                                     // (check_locus stops advancing where it refuses)
+    locus_status[l] = bad ? 1 : 0;
+    if (bad){ if (first_err.empty()) first_err = "locus " + std::to_string(l) + ": " + why; continue; }
+    if (const char* w2 = ob.append_locus(batch, l, opt0, (int64_t)good.size())) return hipstr::api_fail(w2);
+    good.push_back(l);
+  }
+  if (!good.empty()){
+    std::vector<double> p((size_t)ob.n_out); std::vector<int32_t> sd((size_t)ob.read_off.back());
+    for (size_t g = 0; g < good.size(); g++){              // entries the library leaves untouched keep the caller's values
+      const int l = good[g]; const OwnedBatch::Ticket& t = ob.tickets[g];
+      std::copy(aln_probs + out_off[l], aln_probs + out_off[l+1], p.begin() + t.out0);
+      std::copy(seeds + batch->read_off[l], seeds + batch->read_off[l+1], sd.begin() + t.r0);
+    }
+    if (hipstr_hmm_process_reads(ob.finish(), p.data(), sd.data()) != 0) return 1;
+    for (size_t g = 0; g < good.size(); g++){
+      const int l = good[g]; const OwnedBatch::Ticket& t = ob.tickets[g];
+      std::copy(p.begin() + t.out0, p.begin() + t.out1, aln_probs + out_off[l]);
+      std::copy(sd.begin() + t.r0, sd.begin() + t.r1, seeds + batch->read_off[l]);
+    }
+  }
+  if (!first_err.empty()) hipstr::api_fail(first_err);
+  return 0;
+}
+
 int hipstr_stream_flush(hipstr_stream_t* s){
   if (!s) return hipstr::api_fail("null argument");
   if (getenv("HIPSTR_TIMING")) fprintf(stderr, "stream: flush called %.3f ms after open\n", 1e3*std::chrono::duration<double>(std::chrono::steady_clock::now() - s->t_open).count());

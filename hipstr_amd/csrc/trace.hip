@@ -91,7 +91,7 @@ template <int C> struct TraceLdsStore {     // LDS of one fill wavefront, sized 
   double In[64*C*HS_MAXREP];
   double terms[HS_NART*64];
   uint8_t rd[64*C];
-  uint8_t blk[1024];
+  uint8_t blk[HS_MAX_STR_BP + 1];
 };
 struct TraceLds {                          // view of a TraceLdsStore<C>
   double *blc, *blw, *prev, *mr, *Mt, *Dl, *In, *terms;
@@ -727,7 +727,7 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
     if (s < 0) return api_fail("read without a seed base cannot be traced (HapAligner.cpp:586-594)");
     const int len = b->base_off[r+1] - b->base_off[r];
     if (given && (s < 1 || s > len - 2)) return api_fail("seed base must leave at least one base on either side (HapAligner.cpp:316)");
-    if (s > HS_MAX_SIDE_LEN || len-s-1 > HS_MAX_SIDE_LEN) return api_fail("read side longer than 256 bases is not supported");
+    if (s > 64*HS_MAX_COLS || len-s-1 > 64*HS_MAX_COLS) return api_fail("traceback of a read side longer than 384 bases is not supported");
     seeds[q] = s; req_locus[q] = l;
     const int64_t key = ((int64_t)l << 32) | (uint32_t)k;
     std::map<int64_t, int>::iterator hit = allele_slot.find(key);
@@ -853,7 +853,9 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
         case 1: hipLaunchKernelGGL(hs_trace_fill<1>, dim3(cnt), dim3(64), 0, T.stream, d_args, cls_begin[cl-1]); break;
         case 2: hipLaunchKernelGGL(hs_trace_fill<2>, dim3(cnt), dim3(64), 0, T.stream, d_args, cls_begin[cl-1]); break;
         case 3: hipLaunchKernelGGL(hs_trace_fill<3>, dim3(cnt), dim3(64), 0, T.stream, d_args, cls_begin[cl-1]); break;
-        default: hipLaunchKernelGGL(hs_trace_fill<4>, dim3(cnt), dim3(64), 0, T.stream, d_args, cls_begin[cl-1]); break;
+        case 4: hipLaunchKernelGGL(hs_trace_fill<4>, dim3(cnt), dim3(64), 0, T.stream, d_args, cls_begin[cl-1]); break;
+        case 5: hipLaunchKernelGGL(hs_trace_fill<5>, dim3(cnt), dim3(64), 0, T.stream, d_args, cls_begin[cl-1]); break;
+        default: hipLaunchKernelGGL(hs_trace_fill<6>, dim3(cnt), dim3(64), 0, T.stream, d_args, cls_begin[cl-1]); break;
       }
     }
     hipLaunchKernelGGL(hs_trace_walk, dim3(nq), dim3(64), 0, T.stream, d_args, 0);

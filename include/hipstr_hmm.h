@@ -161,6 +161,11 @@ double* hipstr_hmm_dev_aln_probs(hipstr_dev_batch_t* dev);
 /* One-shot convenience = upload + align + fetch + free: the drop-in for
  * HapAligner::process_reads (HapAligner.h:86-87). */
 int hipstr_hmm_process_reads(const hipstr_batch_t* batch, double* aln_probs, int32_t* seeds);
+/* The same, locus by locus as far as failures go: a locus the library cannot take (an input HapAligner::process_reads would die on —
+ * an invalid seed or CIGAR, HapAligner.cpp:309,316 — or one beyond the library's limits) is left out, its part of aln_probs / seeds
+ * stays untouched and locus_status[l] = 1; every other locus is processed as if it had been submitted alone (status 0).  Returns 0
+ * unless the call itself failed (device, memory); hipstr_last_error() holds the message of the first refused locus. */
+int hipstr_hmm_process_reads_each(const hipstr_batch_t* batch, double* aln_probs, int32_t* seeds, int32_t* locus_status /* [n_loci] */);
 
 /* The same with seeds chosen by the caller: HapAligner::process_read takes the seed base as an argument (HapAligner.h:83,
  * HapAligner.cpp:573-575) and so does trace_optimal_aln (HapAligner.h:93); process_reads is the one caller that derives it
