@@ -25,15 +25,16 @@
 #include "api_internal.h"
 
 extern "C" __global__ void hs_str_kernel(const hs_dev_t* dp, int active_begin, int only_long);
-extern "C" __global__ void hs_str_kernel_generic(const hs_dev_t* dp, int active_begin);
+extern "C" __global__ void hs_str_kernel_generic(const hs_dev_t* dp, int active_begin, int pw_grouped);
 extern "C" __global__ void hs_combine_kernel(const hs_dev_t* dp, int active_begin);
 extern "C" __global__ void hs_posterior_kernel(const hs_post_dev_t* dp);
 extern "C" __global__ void hs_genotype_kernel(const hs_gt_dev_t* dp);
 extern "C" size_t hs_str_lds_bytes(int lds_len, int max_B);
 extern "C" __global__ void hs_str_group_kernel(const hs_dev_t* dp, int item_begin, int short_only);
+extern "C" __global__ void hs_str_group_kernel_pw(const hs_dev_t* dp, int item_begin);
 extern "C" __global__ void hs_str_group_kernel_p(const hs_dev_t* dp, int item_begin);
 extern "C" __global__ void hs_nd_kernel(const hs_dev_t* dp, int active_begin);
-extern "C" size_t hs_str_group_lds_bytes(int max_B, int nd_cap);
+extern "C" size_t hs_str_group_lds_bytes(int max_B, int nd_cap, int with_ilog);
 extern "C" size_t hs_str_group_p_lds_bytes();
 extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk);
 extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk);
@@ -230,7 +231,8 @@ struct hipstr_dev_batch {
   hs_dev_t* d_args = NULL;
   std::vector<void*> dev_blocks, pin_blocks;      // from the context's caches
   int grid_y = 1, max_alleles = 1, n_lead_items = 0, n_trail_items = 0, trail_waves = 1;
-  size_t grp_lds_bytes = 0;
+  size_t grp_lds_bytes = 0, grp_pw_lds_bytes = 0;
+  bool any_pw = false;           // some locus has alleles with piecewise simple lists (hs_str_group_kernel_pw)
   bool any_short = false;        // some locus has tabulated alleles hs_str_group_kernel_p does not take (period above HS_GRP_MAXP)
   size_t lds_bytes = 0;
   hipEvent_t ev0 = NULL, ev1 = NULL;
@@ -449,7 +451,13 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   h.grp_nd_cap = std::max(2, (P.grp_nd_cap + 1) & ~1);
   dev->any_short = false;
   for (const hs_locus_t& l : P.loci) dev->any_short |= (l.n_short[0] > 0 || l.n_short[1] > 0);
-  dev->grp_lds_bytes = hs_str_group_lds_bytes(h.max_B, h.grp_nd_cap);
+  dev->any_pw = false;
+  for (const hs_locus_t& l : P.loci) dev->any_pw |= (l.n_pw[0] > l.n_tab[0] || l.n_pw[1] > l.n_tab[1]);
+  dev->grp_lds_bytes = hs_str_group_lds_bytes(h.max_B, h.grp_nd_cap, 0);
+  dev->grp_pw_lds_bytes = hs_str_group_lds_bytes(h.max_B, h.grp_nd_cap, 1);
+  if (dev->grp_pw_lds_bytes > 48*1024){
+    HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_group_kernel_pw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->grp_pw_lds_bytes));
+  }
   if (getenv("HIPSTR_TIMING")) fprintf(stderr, "hipstr_hmm_upload: STR group kernel LDS %zu bytes (max block %d, read-end table %d doubles, %zu groups)\n", dev->grp_lds_bytes, h.max_B, h.grp_nd_cap, P.str_items.size());
   if (dev->grp_lds_bytes > 48*1024){
     HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->grp_lds_bytes));
@@ -578,11 +586,14 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
           hipLaunchKernelGGL(hs_str_group_kernel, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), dev->grp_lds_bytes, st, dp,
                              dev->n_lead_items + dev->n_trail_items + ch.str_begin, group_p ? 1 : 0);
       }
+      if (dev->any_pw && ch.str_end > ch.str_begin)       // interrupted repeats: the piecewise simple lists' closed forms, grouped like the tabulated ones
+        hipLaunchKernelGGL(hs_str_group_kernel_pw, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), dev->grp_pw_lds_bytes, st, dp,
+                           dev->n_lead_items + dev->n_trail_items + ch.str_begin);
       if (ch.n_long_sides > 0)        // sides with more columns than a group holds: one workgroup per read as before
         hipLaunchKernelGGL(hs_str_kernel, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin, 1);
     }
     // alleles without a tabulated closed form (interrupted repeats, very long blocks) and whatever hs_str_kernel marked HS_REDO
-    hipLaunchKernelGGL(hs_str_kernel_generic, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin);
+    hipLaunchKernelGGL(hs_str_kernel_generic, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin, str_group ? 1 : 0);
     if (mark()) return 1;
     if (ch.trail_end > ch.trail_begin)     // trailing flanks: persistent wavefronts striding over (read side, allele group) items
       hs_launch_trail((unsigned)std::min(dev->trail_waves, ch.trail_end - ch.trail_begin), st, dp,

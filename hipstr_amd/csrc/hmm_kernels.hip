@@ -860,6 +860,88 @@ __device__ __forceinline__ double pw_eval(const hs_dev_t& d, const StrLds& L, in
   return mx + (double)f_fasterlog((float)tot);
 }
 
+
+// pw_eval for the grouped layout (hs_str_group_kernel_pw): the same values pushed into the same float log-sum-exp, with
+//   * the list's ten descriptor slots in scalar registers (`pws`: scalar loads from the f64 pool, the option is the same for every lane);
+//   * the emission of read column c against block base b = the column's entry of base b's plane of the group's emission table
+//     (E[plane][column]: what emit() picks from the read base and the two quality logs);
+//   * the terms a descriptor rules out for every lane (no run in a segment, one break only, no plain entries) skipped by scalar branches —
+//     an absent term adds +0.0 to the non-negative sum in pw_eval.
+// xx: the lane's column in the group's tables;  Eb: byte address (LDS) of E[0][0];  plane stride XC*8 bytes.
+struct PwSlots { int v[2*HS_PW_SLOTS]; };
+template <int XC>
+__device__ __forceinline__ double pw_eval_grp(const PwSlots& S, const double* ilog, double log_thresh, int Eb, int xx, double lp0, int lim, int nsub, int stride, int tail){
+  auto lo = [&](int sl){ return S.v[2*sl]; };
+  auto hi = [&](int sl){ return S.v[2*sl + 1]; };
+  auto dbl = [&](int sl){ return __hiloint2double(S.v[2*sl + 1], S.v[2*sl]); };
+  auto ldb = [&](int byte_addr) -> double { return *(const __attribute__((address_space(3))) double*)(uintptr_t)(uint32_t)byte_addr; };
+  const int nseg = lo(0), term_ni = hi(0);
+  const int r0 = lo(1), U0 = hi(1), r1 = lo(3), U1 = hi(3), r2 = lo(5), U2 = hi(5);
+  const int b0 = lo(7), c0 = hi(7), b1 = lo(8), c1 = hi(8);
+  const int pa = lo(9), pb = hi(9);
+  auto plane = [&](int ch){ return ((ch >> 1) & 3) * (XC*8); };
+  const double L0 = lp0;
+  double L1 = L0;
+  const bool a_b0 = b0 < lim;
+  {
+    const int pla = plane(c0), plb = plane(c0 >> 8);
+    double t = L0;
+#pragma unroll
+    for (int m = 1; m <= nsub; m++){
+      const int ca = Eb + 8*max(xx - b0 - m*stride, 0);        // a lane past its bound may point in front of its read: not used
+      const double ea = ldb(ca + pla), eb = ldb(ca + plb);
+      t -= ea; t += eb;
+    }
+    L1 = a_b0 ? t : L0;                                        // (below its bound a lane takes every step, beyond it none)
+  }
+  double L2 = L1;
+  bool a_b1 = false;
+  if (nseg >= 2){
+    a_b1 = b1 < lim;
+    const int pla = plane(c1), plb = plane(c1 >> 8);
+    double t = L1;
+#pragma unroll
+    for (int m = 1; m <= nsub; m++){
+      const int ca = Eb + 8*max(xx - b1 - m*stride, 0);
+      const double ea = ldb(ca + pla), eb = ldb(ca + plb);
+      t -= ea; t += eb;
+    }
+    L2 = a_b1 ? t : L1;
+  }
+  const double Llast = L2;                                     // nseg == 1: L2 = L1
+  const double Lfin = L2;                                      // a_b1 ? L2 : (a_b0 ? L1 : L0): the selects above already did that
+  const bool a_r0 = (U0 > 0) && (r0 < lim), a_r1 = (U1 > 0) && (r1 < lim), a_r2 = (U2 > 0) && (r2 < lim);
+  const double v_r0 = dbl(2) + L0, v_r1 = dbl(4) + L1, v_r2 = dbl(6) + L2;
+  const int np = min(max(lim - pa, 0), pb - pa);
+  int ns = term_ni;
+  if (pb > pa) ns = (lim < pb) ? max(lim, pa) : ns;
+  if (U2 > 0) ns = (r2 >= lim) ? r2 : ns;
+  if (nseg >= 2) ns = (b1 >= lim) ? b1 : ns;
+  if (U1 > 0) ns = (r1 >= lim) ? r1 : ns;
+  ns = (b0 >= lim) ? b0 : ns;
+  if (U0 > 0) ns = (r0 >= lim) ? r0 : ns;
+  const bool a_t = ns < tail;
+  const double v_t = ilog[max(tail - ns, 0)] + Lfin;
+  double mx = L0;
+  if (U0 > 0) mx = a_r0 ? fmax(mx, v_r0) : mx;
+  mx = a_b0 ? fmax(mx, L1) : mx;
+  if (U1 > 0) mx = a_r1 ? fmax(mx, v_r1) : mx;
+  if (nseg >= 2) mx = a_b1 ? fmax(mx, L2) : mx;
+  if (U2 > 0) mx = a_r2 ? fmax(mx, v_r2) : mx;
+  if (pb > pa) mx = (np > 0) ? fmax(mx, Llast) : mx;
+  mx = a_t ? fmax(mx, v_t) : mx;
+  auto term = [&](bool on, double v){ const double dd = v - mx; return (on && dd > log_thresh) ? (double)f_fasterexp((float)dd) : 0.0; };
+  double tot = term(true, L0);
+  if (U0 > 0) tot += term(a_r0, v_r0);
+  tot += term(a_b0, L1);
+  if (U1 > 0) tot += term(a_r1, v_r1);
+  if (nseg >= 2) tot += term(a_b1, L2);
+  if (U2 > 0) tot += term(a_r2, v_r2);
+  if (pb > pa) tot += (double)np * term(np > 0, Llast);        // equal float terms: the product is exact
+  tot += term(a_t, v_t);
+  return mx + (double)f_fasterlog((float)tot);
+}
+
 }  // namespace
 
 #ifndef HS_STR_WAVES
@@ -909,14 +991,16 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin, in
   const int ncyc = (n + 63) / 64;
   // alleles in the side's processing order (nested STR blocks follow each other); a chunk of positions per workgroup
   const int n_tab = uni(v.loc->n_tab[w]);
-  const int r_lo = MODE == 0 ? 0 : n_tab, r_hi = MODE == 0 ? n_tab : uni(v.loc->n_re);
+  // MODE 1: the piecewise alleles [n_tab, n_pw) of a side that fits a group are hs_str_group_kernel_pw's (pw_grouped)
+  const int n_gen = (MODE == 1 && only_long /* = pw_grouped */ && n <= HS_GRP_COLS) ? uni(v.loc->n_pw[w]) : n_tab;
+  const int r_lo = MODE == 0 ? 0 : n_gen, r_hi = MODE == 0 ? n_tab : uni(v.loc->n_re);
   const int i0 = r_lo + blockIdx.y * d.allele_chunk, i1 = min(r_hi, i0 + d.allele_chunk);
   const int32_t* order = d.str_order + uni(v.loc->order_off[w]);
   // MODE 1 also re-does, the long way, the tabulated alleles of this read for which hs_str_kernel left HS_REDO marks (a lane's
   // lp0 was too large for the table's guarantee): positions [j0, j1) of the tabulated range, looked at only if the read is flagged
   const int ai = active_begin + blockIdx.x;
   const bool redo = (MODE == 1) && uni(d.redo[ai]) != 0;
-  const int j0 = blockIdx.y * d.allele_chunk, j1 = redo ? min(n_tab, j0 + d.allele_chunk) : j0;
+  const int j0 = blockIdx.y * d.allele_chunk, j1 = redo ? min(MODE == 1 ? n_gen : n_tab, j0 + d.allele_chunk) : j0;
   if (i0 >= i1 && j0 >= j1) return;           // nothing of this kind for this side (after the barrier: the other side may have work)
   if (MODE == 0 && only_long && n <= HS_GRP_COLS) return;     // this side's columns fit a group: hs_str_group_kernel has it
   for (int j = lane; j < n; j += 64){
@@ -1409,7 +1493,7 @@ hs_str_kernel(const hs_dev_t* __restrict__ dp, int active_begin, int only_long){
 #define HS_STRG_WAVES 3      // the long forms want registers more than wavefronts: 168 VGPRs without spills beat 128 with 160 B of them
 #endif
 extern "C" __global__ void __launch_bounds__(128, HS_STRG_WAVES)
-hs_str_kernel_generic(const hs_dev_t* __restrict__ dp, int active_begin){ str_body<1>(*dp, active_begin, 0); }
+hs_str_kernel_generic(const hs_dev_t* __restrict__ dp, int active_begin, int pw_grouped){ str_body<1>(*dp, active_begin, pw_grouped); }
 
 // ------------------------------------------------------------------ the STR block of tabulated alleles, grouped form
 // hs_str_kernel gives every read side its own wavefront: a 150-base read seeded in the middle has ~75 columns per side, two passes of
@@ -1436,18 +1520,26 @@ struct GrpLds {
   // two of each but nd, used alternately from allele to allele; addressed as base + parity * stride (a pointer picked from an array loses its
   // address space and every access through it becomes a flat_load)
   double* nd0; double* cstl0; double2* tab0;
+  const double* ilog;      // KIND 1: [max_B + 9] int_log
   uint16_t* boff0;         // [blk_len] byte offset of the block base's plane of E (valid offsets, zeros, in front of the first one: masked steps may look there)
   int ld;
 };
 // nd_cap: doubles of the read-end deletion table of a group = the largest (reads x 36 period) of the batch's groups (prep.cpp)
-extern "C" size_t hs_str_group_lds_bytes(int max_B, int nd_cap){
+// with_ilog: hs_str_group_kernel_pw keeps int_log(0 .. max_B + 8) in LDS as well (the tail terms of the piecewise lists)
+extern "C" size_t hs_str_group_lds_bytes(int max_B, int nd_cap, int with_ilog){
   const size_t XC = HS_GRP_COLS;
   const size_t blk_len = ((size_t)max_B + 19) & ~(size_t)15;
+  const size_t ilog_bytes = with_ilog ? (((size_t)max_B + 9) & ~(size_t)1)*8 : 0;
   // (+ HS_GRP_MAXREADS + 2 doubles: hs_str_group_kernel_p keeps a 0.0 in front of every read in match_probs_ as well)
   // (+ 3 HS_GRP_MAXREADS + 1 ints: that kernel keeps its per-read tables behind the carve instead of in static LDS)
-  return XC*8*HS_MAXREP + 2*(XC + HS_GRP_MAXREADS + 2)*8 + XC*32 + (size_t)nd_cap*8 + 2*24*8 + 2*HS_TAB_CAP*16 + (3*blk_len + 64)*2 + (3*HS_GRP_MAXREADS + 1)*4 + 16;
+  return XC*8*HS_MAXREP + 2*(XC + HS_GRP_MAXREADS + 2)*8 + XC*32 + (size_t)nd_cap*8 + 2*24*8 + 2*HS_TAB_CAP*16 + (3*blk_len + 64)*2 + (3*HS_GRP_MAXREADS + 1)*4 + 16 + ilog_bytes;
 }
 
+// KIND 0: tabulated alleles, positions [0, n_tab) (or [0, n_short)) of the side's order.  KIND 1 (hs_str_group_kernel_pw): the alleles with
+// piecewise simple lists, positions [n_tab, n_pw) — interrupted repeats: the same table phase and read-end sums (their blocks are
+// not periodic: nothing is inherited from allele to allele but the match / deletion tables of a block that ends with the previous one),
+// every list evaluated by the closed form its shape names (table entry or pw_eval_grp).
+template <int KIND>
 __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin, int short_only){
   constexpr int XC = HS_GRP_COLS, NT = HS_GRP_COLS;
   static_assert((NT & (NT - 1)) == 0 && NT >= 128 && 4*XC*8 < 65536, "the wavefronts' turns at the read-end sums assume a power-of-two workgroup; plane offsets are 16 bits");
@@ -1464,7 +1556,11 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     double* E = Mt + XC;
     double* ndb = E + 4*XC;
     double* cst = ndb + d.grp_nd_cap;
-    double2* tab = (double2*)(cst + 2*24);
+    const int ilog_len = KIND == 1 ? ((d.max_B + 9) & ~1) : 0;
+    double* ilogb = cst + 2*24;
+    double2* tab = (double2*)(ilogb + ilog_len);
+    for (int i = x; i < ilog_len; i += NT) ilogb[i] = d.int_log[i];
+    L.ilog = ilogb;
     uint16_t* boffb = (uint16_t*)(tab + 2*HS_TAB_CAP) + blk_len + 64;        // zeros in front: the read-end chains fetch ahead of themselves
     for (int i = x; i < blk_len + 64; i += NT) boffb[i - blk_len - 64] = 0;
     L.rowP = rowP; L.Mt = Mt; L.Dl = Dl; L.E = E; L.ld = XC;
@@ -1506,8 +1602,8 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
   }
   const int blk_len = (d.max_B + 19) & ~15;
   const int xrp = xx + g + 1;                       // this column in rowP: rowP[xrp - len] is M of column j - len, or the 0.0 in front when len = j + 1
-  const int n_tab = short_only ? uni(loc->n_short[side]) : uni(loc->n_tab[side]);      // short_only: hs_str_group_kernel_p has the rest
-  const int i0 = blockIdx.y * d.allele_chunk, i1 = min(n_tab, i0 + d.allele_chunk);
+  const int n_tab = KIND == 1 ? uni(loc->n_pw[side]) : (short_only ? uni(loc->n_short[side]) : uni(loc->n_tab[side]));      // short_only: hs_str_group_kernel_p has the rest
+  const int i0 = (KIND == 1 ? uni(loc->n_tab[side]) : 0) + blockIdx.y * d.allele_chunk, i1 = min(n_tab, i0 + d.allele_chunk);
   if (i0 >= i1) return;                              // the same for every lane of the workgroup
   const int32_t* order = d.str_order + uni(loc->order_off[side]);
   const int jmaxw = uni(wave_max_i(j)), jminw = uni(wave_min_i(j));
@@ -1552,6 +1648,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     const int slot = pk1 & 0x3ff, re_ord = pk2 & 0xffffff;
     double* const mr_out = mr_base + (int64_t)re_ord*lenm1;
     const int B = (pk1 >> 20) & 0x7ff, nv = (pk1 >> 10) & 7, p = (pk1 >> 13) & 15, nd_eq = (pk1 >> 17) & 7, tab_len = (pk2 >> 24) & 0xff;
+    const double* const pw_desc = d.f64pool + rdlane(a_f64, k) + 20;          // KIND 1: the option's 7 x HS_PW_SLOTS descriptor slots
     // Read-end deletion sums of one read: six row slots of 6p entries, entry = distance of the column from the read end.  Size q lives in
     // slot (nd_base + q) mod 6.  Where the block extends the previous allele's by one repeat unit, the sums of (size q, column) are the
     // previous allele's (size q-1, column): the base steps back by one, every row is the next size without moving, each gains the p
@@ -1791,8 +1888,23 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       asm volatile("" ::: "memory");
       double terms[HS_NART];
       double lp0_max = 0.0;
-      auto tab_eval = [&](double lp0, int lim, int k) -> double {
-        const int e = rdlane(tbase, k) + min(lim, 1) + max(lim - rdlane(shapes, k), 0);
+      const int Eb = (int)(uintptr_t)(__attribute__((address_space(3))) char*)L.E;
+      auto tab_eval = [&](double lp0, int lim, int k, int nsub, int stride, int tail) -> double {
+        const int shp = rdlane(shapes, k);
+        if (KIND == 1 && shp == HS_SHAPE_PIECEWISE){          // (the same for every lane)
+          PwSlots S;
+          typedef int hs_i2w __attribute__((ext_vector_type(2)));
+          hs_i2w q0, q1, q2, q3, q4, q5, q6, q7, q8, q9;
+          const uint64_t pa = (uint64_t)(uintptr_t)(pw_desc + k*HS_PW_SLOTS);
+          asm volatile("s_load_dwordx2 %0, %10, 0x0\n\ts_load_dwordx2 %1, %10, 0x8\n\ts_load_dwordx2 %2, %10, 0x10\n\ts_load_dwordx2 %3, %10, 0x18\n\t"
+                       "s_load_dwordx2 %4, %10, 0x20\n\ts_load_dwordx2 %5, %10, 0x28\n\ts_load_dwordx2 %6, %10, 0x30\n\ts_load_dwordx2 %7, %10, 0x38\n\t"
+                       "s_load_dwordx2 %8, %10, 0x40\n\ts_load_dwordx2 %9, %10, 0x48\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&s"(q0), "=&s"(q1), "=&s"(q2), "=&s"(q3), "=&s"(q4), "=&s"(q5), "=&s"(q6), "=&s"(q7), "=&s"(q8), "=&s"(q9) : "s"(pa) : "memory");
+          S.v[0] = q0.x; S.v[1] = q0.y; S.v[2] = q1.x; S.v[3] = q1.y; S.v[4] = q2.x; S.v[5] = q2.y; S.v[6] = q3.x; S.v[7] = q3.y; S.v[8] = q4.x; S.v[9] = q4.y;
+          S.v[10] = q5.x; S.v[11] = q5.y; S.v[12] = q6.x; S.v[13] = q6.y; S.v[14] = q7.x; S.v[15] = q7.y; S.v[16] = q8.x; S.v[17] = q8.y; S.v[18] = q9.x; S.v[19] = q9.y;
+          return pw_eval_grp<XC>(S, L.ilog, d.log_thresh, Eb, xx, lp0, lim, nsub, stride, tail);
+        }
+        const int e = rdlane(tbase, k) + min(lim, 1) + max(lim - shp, 0);
         const double2 ag = tab[e];
         lp0_max = fmax(lp0_max, fabs(lp0));
         return (lp0 + ag.x) + ag.y;
@@ -1807,7 +1919,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
         const int len = min(B + D, j + 1);
         const double lp0 = (rdlane(cst, 13) + li) + ((len > D) ? L.Mt[xx - min(D, j)] : 0.0);
         const int lim = min(max(0, len - D), B);            // a lane past the group's last column repeats it: its bound is a real one
-        const double S = tab_eval(lp0, lim, HS_MAXREP);
+        const double S = tab_eval(lp0, lim, HS_MAXREP, q + 1, p, B);
         const double pre = L.rowP[xrp - len];
         return (rdlane(cst, HS_MAXREP + 1 + q) + S) + pre;
       };
@@ -1845,7 +1957,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
           int slq = nd_base + q; slq -= (slq >= HS_MAXREP) ? HS_MAXREP : 0;
           const double ndv = nd[ndb + slq*sixp + min(n - 1 - j, cq - 1)];
           const double lp0 = direct ? rdlane(cst, 14 + q) + dsum : ndv;
-          const double S = tab_eval(lp0, len, q);
+          const double S = tab_eval(lp0, len, q, 1, 0, B - aD);
           const double pre = L.rowP[xrp - len];
           terms[HS_MAXREP - 1 - q] = (rdlane(cst, HS_MAXREP - 1 - q) + S) + pre;
         }
@@ -1878,7 +1990,12 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
 #define HS_GRP_OCC HS_STR_WAVES      // wavefronts per SIMD the register allocation aims at
 #endif
 extern "C" __global__ void __launch_bounds__(HS_GRP_COLS, HS_GRP_OCC)
-hs_str_group_kernel(const hs_dev_t* __restrict__ dp, int item_begin, int short_only){ str_group_body(*dp, item_begin, short_only); }
+hs_str_group_kernel(const hs_dev_t* __restrict__ dp, int item_begin, int short_only){ str_group_body<0>(*dp, item_begin, short_only); }
+#ifndef HS_GRP_PW_OCC
+#define HS_GRP_PW_OCC 3      // wavefronts per SIMD of the piecewise form: eight float exponentials per list want registers more than wavefronts
+#endif
+extern "C" __global__ void __launch_bounds__(HS_GRP_COLS, HS_GRP_PW_OCC)
+hs_str_group_kernel_pw(const hs_dev_t* __restrict__ dp, int item_begin){ str_group_body<1>(*dp, item_begin, 0); }
 
 // ------------------------------------------------------------------ the STR block of tabulated alleles, grouped form, period known at compile time
 // hs_str_group_kernel_p<P> takes the tabulated alleles whose blocks hold at least six repeat units of period P (positions

@@ -82,6 +82,10 @@ struct hs_stropt_t {
   // Base codes ((char >> 1) & 3: A, C, T, G -> 0, 1, 2, 3) of the block's last 16 bases, two bits each, the last base in bits 0-1: a
   // tabulated block is periodic, so base t from its right end is code (t mod period) of this word (hs_str_group_kernel_p).
   int32_t tail_codes;
+  // Which forward kernel evaluates the option.  1: every list simple and tabulated (tab_len > 0): the grouped kernels with the table;
+  // 2: every list simple (tabulated: tab_len entries) or piecewise simple (descriptor slots), block of A/C/G/T: hs_str_group_kernel_pw;
+  // 0: neither (hs_str_kernel_generic).  A kind-2 option's table holds the entries of its simple lists only.
+  int32_t kind;
 };
 
 struct hs_allele_t {
@@ -112,6 +116,8 @@ struct hs_locus_t {
   int32_t rec_off[2];        // first record (of n_tab, in the side's order) in grp_recs[], in records
   int32_t ndrow_off[2];      // read-end deletion sums of the side's alleles in [n_short, n_tab) (hs_nd_kernel): first row descriptor in nd_rows[] ...
   int32_t n_ndrows[2];       // ... and their number; a read side's block in the ws_nd workspace is n_ndrows x 6 period doubles
+  int32_t n_pw[2];           // positions [n_tab, n_pw) of the order: alleles whose lists are simple or piecewise simple (hs_stropt_t::kind 2),
+                             // hs_str_group_kernel_pw's; the rest, [n_pw, n_re), is hs_str_kernel_generic's
   int32_t period;            // the locus' STR period (the same for all of its alleles)
   int32_t pad_;
 };

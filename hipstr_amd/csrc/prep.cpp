@@ -492,6 +492,7 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
   // tabulated closed form: only when every list the kernel can evaluate is simple and the entries fit the LDS budget
   so.tab_off = out.f64pool.size(); so.tab_len = 0;
   {
+    static const bool no_pw_group = getenv("HIPSTR_STR_GROUP_PW") && atoi(getenv("HIPSTR_STR_GROUP_PW")) == 0;     // comparison runs: piecewise lists stay with hs_str_kernel_generic
     bool ok = true; int total = 0;
     for (char c : blk) ok &= (c == 'A' || c == 'C' || c == 'G' || c == 'T');      // hs_str_group_kernel looks emissions up by base code
     ok &= (B >= period);                                                          // ... and lets ins_probs_ cycle through block bases only
@@ -499,13 +500,15 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
       const int tail = (k == HS_MAXREP) ? B : B - (k+1)*period;
       so.tab_base[k] = total;
       if (tail < 0) continue;                           // this deletion size is never evaluated
+      if (so.shape[k] == HS_SHAPE_PIECEWISE && !no_pw_group) continue;      // evaluated from its descriptor slots (hs_str_group_kernel_pw)
       if (so.shape[k] < 0){ ok = false; break; }
       total += 2 + std::max(0, tail - so.shape[k]);
     }
     if (ok && total <= HS_TAB_CAP){
+      so.kind = any_pw ? 2 : 1;
       for (int k = 0; k <= HS_MAXREP; k++){
         const int tail = (k == HS_MAXREP) ? B : B - (k+1)*period;
-        if (tail < 0) continue;
+        if (tail < 0 || so.shape[k] < 0) continue;
         const int U0 = so.shape[k], n = 2 + std::max(0, tail - U0);
         for (int e = 0; e < n; e++){
           const int lim = (e == 0) ? 0 : (e == 1 ? 1 : U0 + e - 1);      // a bound that maps to entry e (entry 1 is unused when U0 = 0)
@@ -767,15 +770,17 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
       for (int k = 0; k < A; k++) if (out.alleles[loc.hap_begin + k].realign) ks.push_back(k);
       auto block_of = [&](int k) -> const std::string& { return sblk[side][str_opt_of[k]]; };
       // alleles whose closed form is tabulated come first: they are the business of hs_str_kernel, the rest of hs_str_kernel_generic
-      auto tabbed = [&](int k){ return out.stropts[so_base + side*nopts[1] + str_opt_of[k]].tab_len > 0; };
+      auto kind_of = [&](int k){ return out.stropts[so_base + side*nopts[1] + str_opt_of[k]].kind; };
+      auto tabbed = [&](int k){ return kind_of(k) == 1; };
       // (the STR options are ranked once — tabulated first, then by length, then by sequence — and the alleles sorted by their option's rank)
       std::vector<int> opt_rank(nopts[1]);
       {
         std::vector<int> os(nopts[1]);
         for (int o = 0; o < nopts[1]; o++) os[o] = o;
         std::stable_sort(os.begin(), os.end(), [&](int x, int y){
-          const bool tx = out.stropts[so_base + side*nopts[1] + x].tab_len > 0, ty = out.stropts[so_base + side*nopts[1] + y].tab_len > 0;
-          if (tx != ty) return tx;
+          static const int kind_rank[3] = {2, 0, 1};                  // tabulated, then piecewise, then the rest
+          const int tx = kind_rank[out.stropts[so_base + side*nopts[1] + x].kind], ty = kind_rank[out.stropts[so_base + side*nopts[1] + y].kind];
+          if (tx != ty) return tx < ty;
           const std::string& a = sblk[side][x]; const std::string& b2 = sblk[side][y];
           if (a.size() != b2.size()) return a.size() < b2.size();
           return a < b2;
@@ -788,7 +793,7 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
       }
       std::stable_sort(ks.begin(), ks.end(), [&](int x, int y){ return opt_rank[str_opt_of[x]] < opt_rank[str_opt_of[y]]; });
       loc.order_off[side] = out.str_order.size();
-      loc.n_tab[side] = 0; loc.n_short[side] = 0;
+      loc.n_tab[side] = 0; loc.n_short[side] = 0; loc.n_pw[side] = 0;
       loc.rec_off[side] = (int32_t)(out.grp_recs.size() / HS_GRP_REC_DWORDS);
       loc.ndrow_off[side] = (int32_t)out.nd_rows.size(); loc.n_ndrows[side] = 0;
       int fam_row0 = 0, fam_k = 0;                     // first row of the current family of alleles (blocks growing by one repeat unit), position in it
@@ -797,7 +802,7 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
       for (size_t i = 0; i < ks.size(); i++){
         const std::string& prev = *prev_p;
         const std::string& cur = block_of(ks[i]);
-        const bool first_of_kind = (i == 0) || (tabbed(ks[i]) != tabbed(ks[i-1]));
+        const bool first_of_kind = (i == 0) || (kind_of(ks[i]) != kind_of(ks[i-1]));
         const bool chained = !first_of_kind && cur.size() >= prev.size() && cur.compare(cur.size() - prev.size(), prev.size(), prev) == 0;
         // bit 29: a tabulated (hence periodic) block that extends the previous one by exactly one repeat unit: the read-end deletion
         // sums of the previous allele move up one size (hs_str_kernel)
@@ -829,6 +834,7 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
           }
           if (period > HS_GRP_MAXP) loc.n_short[side]++;              // no instantiation of hs_str_group_kernel_p for this period
         }
+        if (kind_of(ks[i]) != 0) loc.n_pw[side]++;      // (kinds 1 and 2 come first: n_pw counts both, the piecewise ones are [n_tab, n_pw))
         prev_p = &cur;
       }
     }
@@ -1036,7 +1042,7 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
         // STR-block items (hs_str_group_kernel): reads of this locus and side whose columns, laid end to end, fill one workgroup's
         // lanes.  First fit, longest side first; a group holds at most HS_GRP_MAXREADS reads and 2 HS_GRP_COLS read-end deletion sums
         // (21 period per read).  item.active = first entry in tpack, item.slot = number of reads, item.rowset = their columns
-        if (loc.n_tab[s] > 0){
+        if (loc.n_pw[s] > 0){
           const int period = out.stropts[out.alleles[loc.hap_begin + (out.str_order[loc.order_off[s]] & 0x1fffffff)].str_opt[s]].period;
           const int max_reads = std::max(1, std::min(16, 2*HS_GRP_COLS / (21*period)));
           struct Bin { int cols; std::vector<int> members; };
