@@ -131,7 +131,7 @@ def pipeline_stages(capi, hmm, sb, loci, P):
     seeds = np.zeros(sb.n_reads, np.int32)
     hmm.hipstr_calc_seed_bases(sb.ptr, seeds.ctypes.data_as(capi._i32p))
     src = sb.src_allele()
-    rr = [r for r in range(nl * P) if seeds[r] >= 0]; aa = [int(src[r]) for r in rr]
+    rr = [r for r in range(nl * P) if seeds[r] >= 0][:20000]; aa = [int(src[r]) for r in rr]          # (bounded: the output pools below hold 16 Mi characters)
     t0 = time.perf_counter()
     h2r = capi.hap_aln_info(hmm, "hipstr_", sb.ptr, cap=1 << 26)
     t_info = time.perf_counter() - t0

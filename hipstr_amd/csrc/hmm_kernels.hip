@@ -911,7 +911,6 @@ __device__ __forceinline__ double pw_eval_grp(const PwSlots& S, const double* il
   const double Llast = L2;                                     // nseg == 1: L2 = L1
   const double Lfin = L2;                                      // a_b1 ? L2 : (a_b0 ? L1 : L0): the selects above already did that
   const bool a_r0 = (U0 > 0) && (r0 < lim), a_r1 = (U1 > 0) && (r1 < lim), a_r2 = (U2 > 0) && (r2 < lim);
-  const double v_r0 = dbl(2) + L0, v_r1 = dbl(4) + L1, v_r2 = dbl(6) + L2;
   const int np = min(max(lim - pa, 0), pb - pa);
   int ns = term_ni;
   if (pb > pa) ns = (lim < pb) ? max(lim, pa) : ns;
@@ -921,24 +920,34 @@ __device__ __forceinline__ double pw_eval_grp(const PwSlots& S, const double* il
   ns = (b0 >= lim) ? b0 : ns;
   if (U0 > 0) ns = (r0 >= lim) ? r0 : ns;
   const bool a_t = ns < tail;
-  const double v_t = ilog[max(tail - ns, 0)] + Lfin;
-  double mx = L0;
-  if (U0 > 0) mx = a_r0 ? fmax(mx, v_r0) : mx;
-  mx = a_b0 ? fmax(mx, L1) : mx;
-  if (U1 > 0) mx = a_r1 ? fmax(mx, v_r1) : mx;
-  if (nseg >= 2) mx = a_b1 ? fmax(mx, L2) : mx;
-  if (U2 > 0) mx = a_r2 ? fmax(mx, v_r2) : mx;
-  if (pb > pa) mx = (np > 0) ? fmax(mx, Llast) : mx;
-  mx = a_t ? fmax(mx, v_t) : mx;
-  auto term = [&](bool on, double v){ const double dd = v - mx; return (on && dd > log_thresh) ? (double)f_fasterexp((float)dd) : 0.0; };
-  double tot = term(true, L0);
-  if (U0 > 0) tot += term(a_r0, v_r0);
-  tot += term(a_b0, L1);
-  if (U1 > 0) tot += term(a_r1, v_r1);
-  if (nseg >= 2) tot += term(a_b1, L2);
-  if (U2 > 0) tot += term(a_r2, v_r2);
-  if (pb > pa) tot += (double)np * term(np > 0, Llast);        // equal float terms: the product is exact
-  tot += term(a_t, v_t);
+  // The eight pushed values; one that is absent for this lane is -1e300: it loses every maximum and fails the threshold, i.e. adds the
+  // +0.0 pw_eval adds for it.  Branch-free, two float exponentials per packed operation (each half rounded on its own, like the scalar
+  // ones); a term that passes the threshold has 1.44 dd > -10, so fasterexp's clamp at -126 (fastonebigheader.h:210) cannot act on it.
+  constexpr double NEG = -1.0e300;
+  double v[8];
+  v[0] = L0;
+  v[1] = a_r0 ? dbl(2) + L0 : NEG;
+  v[2] = a_b0 ? L1 : NEG;
+  v[3] = a_r1 ? dbl(4) + L1 : NEG;
+  v[4] = a_b1 ? L2 : NEG;
+  v[5] = a_r2 ? dbl(6) + L2 : NEG;
+  v[6] = (np > 0) ? Llast : NEG;
+  v[7] = a_t ? ilog[max(tail - ns, 0)] + Lfin : NEG;
+  double mx = v[0];
+#pragma unroll
+  for (int t = 1; t < 8; t++) mx = fmax(mx, v[t]);
+  typedef float hs_f2 __attribute__((ext_vector_type(2)));
+  double tot = 0.0;
+#pragma unroll
+  for (int t = 0; t < 8; t += 2){
+    const double dd0 = v[t] - mx, dd1 = v[t + 1] - mx;
+    hs_f2 x; x.x = (float)dd0; x.y = (float)dd1;
+    const hs_f2 z = (x * 1.442695040f + 126.94269504f) * 8388608.0f;
+    const float fe0 = (dd0 > log_thresh) ? __uint_as_float(__float2uint_rz(z.x)) : 0.0f;
+    const float fe1 = (dd1 > log_thresh) ? __uint_as_float(__float2uint_rz(z.y)) : 0.0f;
+    tot += (t == 6) ? (double)np * (double)fe0 : (double)fe0;        // equal float terms: the product is exact
+    tot += (double)fe1;
+  }
   return mx + (double)f_fasterlog((float)tot);
 }
 
@@ -1672,9 +1681,22 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     }
     if (x < 20) (L.cstl0 + par*24)[x] = cst;
     if (x < tab_len) (L.tab0 + par*HS_TAB_CAP)[x] = make_double2(nx_tabA, nx_tabG);
+    int pw_touch;
     if (i + 1 < i1){
       if (k == 63) fetch_alleles(i + 1);
       request((k + 1) & 63);
+    }
+    {
+      if (KIND == 1){
+        // the next allele's descriptor slots (560 bytes, nine cache lines) on their way to the scalar cache: a miss at the point of use is a
+        // trip to L2 per list with every wavefront of the workgroup waiting (one destination: the values are not used)
+        const int kn = (i + 1 < i1) ? ((k + 1) & 63) : k;
+        const uint64_t ta0 = (uint64_t)(uintptr_t)(d.f64pool + rdlane(a_f64, kn) + 20);
+        const uint64_t ta = ((uint64_t)(uint32_t)uni((int)(ta0 >> 32)) << 32) | (uint32_t)uni((int)ta0);
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x40\n\ts_load_dword %0, %1, 0x80\n\ts_load_dword %0, %1, 0xc0\n\ts_load_dword %0, %1, 0x100\n\t"
+                     "s_load_dword %0, %1, 0x140\n\ts_load_dword %0, %1, 0x180\n\ts_load_dword %0, %1, 0x1c0\n\ts_load_dword %0, %1, 0x200"
+                     : "=&s"(pw_touch) : "s"(ta) : "memory");
+      }
     }
     HS_TICK(0);   // phase 3 of the previous allele + setup
     if (HS_GABL != 4) __syncthreads();                // ... and every wavefront is done with the previous allele's Mt / Dl
@@ -1882,6 +1904,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     if (HS_GABL != 4) __syncthreads();
 
     HS_TICK(4);   // barrier 2 wait
+    if (KIND == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pw_touch) :: "memory");      // (long since there; the register is free again)
     // --- the 13 artifact terms of this lane's column (HapAligner.cpp:62-109) and their fast_log_sum_exp
     for (int rep3 = 0; rep3 < ((HS_GABL == 7) ? 2 : 1); rep3++)
     if (wave_act && HS_GABL != 2){
@@ -1889,9 +1912,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       double terms[HS_NART];
       double lp0_max = 0.0;
       const int Eb = (int)(uintptr_t)(__attribute__((address_space(3))) char*)L.E;
-      auto tab_eval = [&](double lp0, int lim, int k, int nsub, int stride, int tail) -> double {
-        const int shp = rdlane(shapes, k);
-        if (KIND == 1 && shp == HS_SHAPE_PIECEWISE){          // (the same for every lane)
+      auto load_pw = [&](int k) -> PwSlots {                  // the ten descriptor slots of list k into scalar registers
           PwSlots S;
           typedef int hs_i2w __attribute__((ext_vector_type(2)));
           hs_i2w q0, q1, q2, q3, q4, q5, q6, q7, q8, q9;
@@ -1902,6 +1923,13 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
                        : "=&s"(q0), "=&s"(q1), "=&s"(q2), "=&s"(q3), "=&s"(q4), "=&s"(q5), "=&s"(q6), "=&s"(q7), "=&s"(q8), "=&s"(q9) : "s"(pa) : "memory");
           S.v[0] = q0.x; S.v[1] = q0.y; S.v[2] = q1.x; S.v[3] = q1.y; S.v[4] = q2.x; S.v[5] = q2.y; S.v[6] = q3.x; S.v[7] = q3.y; S.v[8] = q4.x; S.v[9] = q4.y;
           S.v[10] = q5.x; S.v[11] = q5.y; S.v[12] = q6.x; S.v[13] = q6.y; S.v[14] = q7.x; S.v[15] = q7.y; S.v[16] = q8.x; S.v[17] = q8.y; S.v[18] = q9.x; S.v[19] = q9.y;
+          return S;
+      };
+      auto tab_eval = [&](double lp0, int lim, int k, int nsub, int stride, int tail, const PwSlots* pre) -> double {
+        const int shp = rdlane(shapes, k);
+        if (KIND == 1 && shp == HS_SHAPE_PIECEWISE){          // (the same for every lane)
+          if (pre) return pw_eval_grp<XC>(*pre, L.ilog, d.log_thresh, Eb, xx, lp0, lim, nsub, stride, tail);
+          const PwSlots S = load_pw(k);
           return pw_eval_grp<XC>(S, L.ilog, d.log_thresh, Eb, xx, lp0, lim, nsub, stride, tail);
         }
         const int e = rdlane(tbase, k) + min(lim, 1) + max(lim - shp, 0);
@@ -1914,12 +1942,15 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
         const double pre = L.rowP[xrp - len];
         terms[HS_MAXREP] = (rdlane(cst, HS_MAXREP) + L.Mt[xx]) + pre;
       }
+      PwSlots Sins;                                           // the insertion list serves all six sizes: its slots are fetched once
+      if (KIND == 1) Sins = load_pw(HS_MAXREP);               // (a kind-2 option has the slots of all seven lists: "not piecewise" where the list is simple)
+      else { for (int t = 0; t < 2*HS_PW_SLOTS; t++) Sins.v[t] = 0; }
       auto ins_term = [&](int q, double li){
         const int D = (q+1)*p;
         const int len = min(B + D, j + 1);
         const double lp0 = (rdlane(cst, 13) + li) + ((len > D) ? L.Mt[xx - min(D, j)] : 0.0);
         const int lim = min(max(0, len - D), B);            // a lane past the group's last column repeats it: its bound is a real one
-        const double S = tab_eval(lp0, lim, HS_MAXREP, q + 1, p, B);
+        const double S = tab_eval(lp0, lim, HS_MAXREP, q + 1, p, B, &Sins);
         const double pre = L.rowP[xrp - len];
         return (rdlane(cst, HS_MAXREP + 1 + q) + S) + pre;
       };
@@ -1957,7 +1988,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
           int slq = nd_base + q; slq -= (slq >= HS_MAXREP) ? HS_MAXREP : 0;
           const double ndv = nd[ndb + slq*sixp + min(n - 1 - j, cq - 1)];
           const double lp0 = direct ? rdlane(cst, 14 + q) + dsum : ndv;
-          const double S = tab_eval(lp0, len, q, 1, 0, B - aD);
+          const double S = tab_eval(lp0, len, q, 1, 0, B - aD, (const PwSlots*)0);
           const double pre = L.rowP[xrp - len];
           terms[HS_MAXREP - 1 - q] = (rdlane(cst, HS_MAXREP - 1 - q) + S) + pre;
         }
@@ -1992,7 +2023,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
 extern "C" __global__ void __launch_bounds__(HS_GRP_COLS, HS_GRP_OCC)
 hs_str_group_kernel(const hs_dev_t* __restrict__ dp, int item_begin, int short_only){ str_group_body<0>(*dp, item_begin, short_only); }
 #ifndef HS_GRP_PW_OCC
-#define HS_GRP_PW_OCC 3      // wavefronts per SIMD of the piecewise form: eight float exponentials per list want registers more than wavefronts
+#define HS_GRP_PW_OCC 4      // wavefronts per SIMD the register allocation aims at (measured: 3 with 141 registers is 17 % slower than 4 with 128 and four spilled)
 #endif
 extern "C" __global__ void __launch_bounds__(HS_GRP_COLS, HS_GRP_PW_OCC)
 hs_str_group_kernel_pw(const hs_dev_t* __restrict__ dp, int item_begin){ str_group_body<1>(*dp, item_begin, 0); }
