@@ -40,6 +40,7 @@
 #undef private
 #undef protected
 #include "SeqAlignment/AlignmentModel.h"
+#include "SeqAlignment/NeedlemanWunsch.h"
 #include "mathops.h"
 #include "null_ostream.h"
 
@@ -116,7 +117,7 @@ void dump_doubles(FILE* f, const char* key, const double* v, size_t n, bool hex)
 }  // namespace
 
 // one locus: seeded reads -> SeqStutterGenotyper -> genotype() [-> recompute_stutter_models()] -> dump to `f`
-struct LocusParams { uint64_t seed; int n_samples, reads_per_sample, period; bool recompute, reassemble; };
+struct LocusParams { uint64_t seed; int n_samples, reads_per_sample, period; bool recompute, reassemble, nw; };
 static int run_locus(const LocusParams& lp, FILE* f){
   const uint64_t seed = lp.seed; const int n_samples = lp.n_samples, reads_per_sample = lp.reads_per_sample, period = lp.period;
   const bool recompute = lp.recompute, reassemble = lp.reassemble;
@@ -165,6 +166,22 @@ static int run_locus(const LocusParams& lp, FILE* f){
     }
   }
 
+  // ---- [--nw] the Needleman-Wunsch call of realign() (AlignmentOps.cpp:14-26) for every simulated read: the read against its reference
+  // window of ALIGN_WINDOW_WIDTH = 75 bases either side, no end penalty.  (realign() itself takes a BamAlignment, whose constructor
+  // needs htslib — not built here; its NeedlemanWunsch::Align call is reproduced with the arguments :15-25 derive.)
+  if (lp.nw){
+    for (size_t i = 0; i < alns.size(); i++){
+      const int32_t start = std::max(alns[i].get_start() - 75 - 1, 0), stop = std::min(alns[i].get_stop() + 75 - 1, (int32_t)(chrom.size() - 1));
+      const std::string ref_seq = chrom.substr(start, stop - start + 1), read_seq = alns[i].get_sequence();
+      std::string ref_al, read_al; float score = 0; std::vector<CigarOp> cigar_list;
+      const bool aligned = NeedlemanWunsch::Align(ref_seq, read_seq, ref_al, read_al, &score, cigar_list);
+      uint32_t sbits; memcpy(&sbits, &score, 4);
+      fprintf(f, "realign %zu %d %08x ", i, aligned ? 1 : 0, sbits);
+      for (size_t c = 0; c < cigar_list.size(); c++) fprintf(f, "%d%c", cigar_list[c].Length, cigar_list[c].Type);
+      fprintf(f, " %s %s\n", ref_al.c_str(), read_al.c_str());
+    }
+  }
+
   Region region("chr1", str_start, str_start + str_len, period, "LOCUS");
   RegionGroup group(region);
   StutterModel model(0.9, 0.05, 0.05, 0.7, 0.005, 0.005, period);
@@ -185,6 +202,8 @@ static int run_locus(const LocusParams& lp, FILE* f){
       for (int o = 0; o < blk->num_options(); o++) fprintf(f, " %s", blk->get_seq(o).c_str());
       fprintf(f, "\n");
     }
+    if (lp.nw)        // Haplotype::aln_haps_to_ref (Haplotype.cpp:58-86): every haplotype against the reference haplotype, end penalty on
+      for (size_t h = 0; h < g.haplotype_->hap_aln_info_.size(); h++) fprintf(f, "hap_aln_info %zu %s\n", h, g.haplotype_->hap_aln_info_[h].c_str());
     fprintf(f, "pool_index %u", g.num_reads_); for (unsigned i = 0; i < g.num_reads_; i++) fprintf(f, " %d", g.pool_index_[i]); fprintf(f, "\n");
     fprintf(f, "second_mate %u", g.num_reads_); for (unsigned i = 0; i < g.num_reads_; i++) fprintf(f, " %d", g.second_mate_[i] ? 1 : 0); fprintf(f, "\n");
     fprintf(f, "seed_positions %u", g.num_reads_); for (unsigned i = 0; i < g.num_reads_; i++) fprintf(f, " %d", g.seed_positions_[i]); fprintf(f, "\n");
@@ -228,7 +247,7 @@ static int run_locus(const LocusParams& lp, FILE* f){
 #include <thread>
 
 extern "C" int flow_main(int argc, char** argv){
-  LocusParams lp; lp.seed = 1; lp.n_samples = 10; lp.reads_per_sample = 9; lp.period = 4; lp.recompute = false; lp.reassemble = true;
+  LocusParams lp; lp.seed = 1; lp.n_samples = 10; lp.reads_per_sample = 9; lp.period = 4; lp.recompute = false; lp.reassemble = true; lp.nw = false;
   const char* out_path = NULL; int n_loci = 0, n_threads = 1; bool use_stream = false;
   for (int i = 1; i < argc; i++){
     if (!strcmp(argv[i], "--seed")) lp.seed = strtoull(argv[++i], NULL, 10);
@@ -237,6 +256,7 @@ extern "C" int flow_main(int argc, char** argv){
     else if (!strcmp(argv[i], "--period")) lp.period = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--recompute")) lp.recompute = true;
     else if (!strcmp(argv[i], "--no-flanks")) lp.reassemble = false;
+    else if (!strcmp(argv[i], "--nw")) lp.nw = true;                        // also dump the Needleman-Wunsch results of the locus (realign()'s call, aln_haps_to_ref)
     else if (!strcmp(argv[i], "--out")) out_path = argv[++i];
     else if (!strcmp(argv[i], "--loci")) n_loci = atoi(argv[++i]);          // many loci (seeds seed, seed+1, ...; periods cycling 2..5) ...
     else if (!strcmp(argv[i], "--threads")) n_threads = atoi(argv[++i]);    // ... one SeqStutterGenotyper per host thread at a time

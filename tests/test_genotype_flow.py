@@ -30,6 +30,10 @@ CASES = {
     "s4p3_noflank": ["--seed", "4", "--period", "3", "--no-flanks"],
     "s3p5_24samples": ["--seed", "3", "--period", "5", "--samples", "24", "--reads", "12"],
     "s5p2_recompute": ["--seed", "5", "--period", "2", "--samples", "30", "--recompute"],
+    "s1p3_recompute": ["--seed", "1", "--period", "3", "--samples", "30", "--recompute"],
+    # --nw: also dumps the Needleman-Wunsch results of the locus — realign()'s call for every read, aln_haps_to_ref's strings
+    "s5p2_nw": ["--seed", "5", "--period", "2", "--nw"],
+    "s7p4_nw": ["--seed", "7", "--period", "4", "--nw"],
 }
 
 
@@ -123,6 +127,32 @@ def test_mi355x_flow_with_batched_retrace(name, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["s5p2_recompute", "s1p3_recompute", "s5p2"])
+def test_mi355x_flow_with_em_on_the_device(name, tmp_path):
+    """EMStutterGenotyper::train bound to hipstr_em_train (integration/em_train_mi355x.inc: one function body of
+    em_stutter_genotyper.cpp): recompute_stutter_models() (seq_stutter_genotyper.cpp:1569-1577) trains on the device and genotype()
+    runs again under the learned model.  Parameters and everything downstream within 1e-9 of the CPU run."""
+    if not os.path.exists(os.path.join(REFDIR, "libflow_mi355x_em.so")):
+        pytest.skip("oracle/_ref/libflow_mi355x_em.so not built (needs the HipSTR tree at build time)")
+    _compare(_run("libflow_mi355x_em.so", CASES[name], tmp_path), _gold(name), loose_ll=name.endswith("recompute"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["s5p2_nw", "s7p4_nw", "s1p3", "s5p2_recompute"])
+def test_mi355x_flow_with_needleman_wunsch_on_the_device(name, tmp_path):
+    """NeedlemanWunsch::Align bound to hipstr_nw_align (integration/nw_align_mi355x.inc) — the call realign() makes for every read
+    (AlignmentOps.cpp:25) and the one Haplotype::aln_haps_to_ref makes per haplotype (Haplotype.cpp:66), the latter batched per
+    locus (integration/aln_haps_to_ref_mi355x.inc): scores, CIGARs, alignment strings and the haplotype alignment strings the
+    tracebacks are stitched with, identical to the CPU run's."""
+    if not os.path.exists(os.path.join(REFDIR, "libflow_mi355x_nw.so")):
+        pytest.skip("oracle/_ref/libflow_mi355x_nw.so not built (needs the HipSTR tree at build time)")
+    got = _run("libflow_mi355x_nw.so", CASES[name], tmp_path)
+    if name.endswith("_nw"):
+        assert sum(l.startswith("realign ") for l in got.splitlines()) > 50 and "hap_aln_info " in got
+    _compare(got, _gold(name), loose_ll=name.endswith("recompute"))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("extra", [["--threads", "1"], ["--threads", "8", "--stream"]], ids=["one_shot_calls", "eight_loci_in_flight_shared_stream"])
 def test_mi355x_many_loci_in_flight(extra):
     """48 loci through the reference's genotype(): one-shot device calls, and eight genotypers at a time whose alignment rounds
@@ -130,7 +160,7 @@ def test_mi355x_many_loci_in_flight(extra):
     log-likelihood matrices, MAP haplotypes and tracebacks of all 48 loci hash to the CPU run's digest."""
     if not os.path.exists(os.path.join(REFDIR, "libflow_mi355x.so")):
         pytest.skip("oracle/_ref/libflow_mi355x.so not built (needs the HipSTR tree at build time)")
-    for lib in ("libflow_mi355x.so", "libflow_mi355x_batched.so"):
+    for lib in ("libflow_mi355x.so", "libflow_mi355x_batched.so", "libflow_mi355x_nw.so"):
         d = _many(lib, extra)
         assert d["genotyped"] == 48 and d["digest"] == MANY_DIGEST, (lib, d)
 
