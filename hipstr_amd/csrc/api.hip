@@ -5,6 +5,7 @@
 // output contract.  There is no CPU compute path here: without a gfx950 device every entry
 // point fails and hipstr_last_error() says so.
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <cfloat>
 #include <chrono>
@@ -285,6 +286,7 @@ void hipstr_hmm_shutdown(void){
 }
 
 int hipstr_calc_seed_bases(const hipstr_batch_t* b, int32_t* seeds){
+  hipstr::ApiTimer prof_t(hipstr::PB_SEED_BASES);
   if (!b || !seeds) return fail("null argument");
   for (int l = 0; l < b->n_loci; l++)
     for (int r = b->read_off[l]; r < b->read_off[l+1]; r++){
@@ -697,12 +699,51 @@ int hipstr_hmm_process_reads(const hipstr_batch_t* batch, double* aln_probs, int
 }
 
 int hipstr_hmm_process_reads_seeded(const hipstr_batch_t* batch, const int32_t* seed_base, double* aln_probs, int32_t* seeds){
+  hipstr::ApiTimer whole(hipstr::PB_PROCESS_READS);
+  const bool prof = hipstr::api_profile_on();
+  const double t0 = prof ? hipstr::ApiTimer::now() : 0;
   hipstr_dev_batch_t* dev = hipstr_hmm_upload_seeded(batch, seed_base);
   if (!dev) return 1;
+  const double t1 = prof ? hipstr::ApiTimer::now() : 0;
   int rc = hipstr_hmm_align(dev, NULL);
+  const double t2 = prof ? hipstr::ApiTimer::now() : 0;
   if (!rc) rc = hipstr_hmm_fetch(dev, aln_probs, seeds);
+  const double t3 = prof ? hipstr::ApiTimer::now() : 0;
+  if (prof){
+    hipstr::api_profile_add(hipstr::PB_PR_PREPARE, dev->t_prepare); hipstr::api_profile_add(hipstr::PB_PR_STAGE, dev->t_stage);
+    hipstr::api_profile_add(hipstr::PB_PR_UPLOAD_REST, (t1 - t0) - dev->t_prepare - dev->t_stage);
+    hipstr::api_profile_add(hipstr::PB_PR_LAUNCH, t2 - t1); hipstr::api_profile_add(hipstr::PB_PR_FETCH, t3 - t2);
+  }
   hipstr_hmm_free(dev);
+  if (prof) hipstr::api_profile_add(hipstr::PB_PR_FREE, hipstr::ApiTimer::now() - t3);
   return rc;
+}
+
+// ---- hipstr_debug_api_profile
+extern "C++" {
+namespace hipstr {
+static std::atomic<bool> g_prof_on(false);
+static std::atomic<int64_t> g_prof_ns[PB_COUNT], g_prof_calls[PB_COUNT];
+bool api_profile_on(){ return g_prof_on.load(std::memory_order_relaxed); }
+void api_profile_add(int bucket, double seconds, int calls){
+  g_prof_ns[bucket].fetch_add((int64_t)(seconds*1e9), std::memory_order_relaxed); g_prof_calls[bucket].fetch_add(calls, std::memory_order_relaxed);
+}
+double ApiTimer::now(){ return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}
+}
+int hipstr_debug_api_profile(int mode, int cap, const char** names, double* seconds, int64_t* calls){
+  static const char* const kNames[hipstr::PB_COUNT] = {
+    "hipstr_hmm_process_reads[_seeded]", "  prepare_batch", "  pack staging buffer", "  blocks + H2D enqueue", "  kernel launches", "  wait + D2H + scatter", "  release",
+    "hipstr_hmm_trace[_seeded]", "  replay + string work (host)", "hipstr_post_run", "hipstr_post_extract", "hipstr_em_train", "hipstr_nw_align",
+    "hipstr_stream_submit", "hipstr_stream_take", "hipstr_calc_seed_bases" };
+  if (mode == 1){ for (int i = 0; i < hipstr::PB_COUNT; i++){ hipstr::g_prof_ns[i] = 0; hipstr::g_prof_calls[i] = 0; } hipstr::g_prof_on = true; }
+  else if (mode == 0) hipstr::g_prof_on = false;
+  for (int i = 0; i < hipstr::PB_COUNT && i < cap; i++){
+    if (names) names[i] = kNames[i];
+    if (seconds) seconds[i] = 1e-9*(double)hipstr::g_prof_ns[i].load();
+    if (calls) calls[i] = hipstr::g_prof_calls[i].load();
+  }
+  return hipstr::PB_COUNT;
 }
 
 // Diagnostics for the host preparation (no device needed): the haplotype rows, as the flank sweeps
@@ -958,6 +999,7 @@ int hipstr_gt_offsets(const hipstr_post_batch_t* pb, const hipstr_gt_request_t* 
 }
 
 int hipstr_post_extract(hipstr_post_dev_t* pd, const hipstr_gt_request_t* rq, hipstr_gt_out_t* out){
+  hipstr::ApiTimer prof_t(hipstr::PB_POST_EXTRACT);
   if (!pd || !rq || !out || !rq->n_variants || !rq->hap_to_allele) return fail("null argument");
   if (!out->best_hap || !out->best_gt || !out->log_phased_post || !out->log_unphased_post || !out->hap_log_phased_post || !out->hap_log_unphased_post)
     return fail("null output array");
@@ -1077,6 +1119,7 @@ int hipstr_post_extract(hipstr_post_dev_t* pd, const hipstr_gt_request_t* rq, hi
 
 int hipstr_post_run(const hipstr_post_batch_t* pb, const double* dev_log_aln_probs,
                     double* log_post, double* sample_total_ll, int32_t* map_gt, double* locus_total_ll){
+  hipstr::ApiTimer prof_t(hipstr::PB_POST_RUN);
   if (!pb || !log_post || !sample_total_ll || !map_gt || !locus_total_ll) return fail("null argument");
   hipstr_post_dev_t* pd = hipstr_post_upload(pb, dev_log_aln_probs);
   if (!pd) return 1;

@@ -29,6 +29,19 @@ void* pin_alloc(Ctx* ctx, size_t bytes);
 void  pin_free(Ctx* ctx, void* p);
 
 
+// ---- where the host time of the entry points goes (hipstr_debug_api_profile, include/hipstr_hmm.h): wall-clock seconds and calls per
+// bucket, summed over all threads while enabled.  Buckets nest: the indented ones are parts of the entry point above them.
+enum ApiBucket { PB_PROCESS_READS, PB_PR_PREPARE, PB_PR_STAGE, PB_PR_UPLOAD_REST, PB_PR_LAUNCH, PB_PR_FETCH, PB_PR_FREE,
+                 PB_TRACE, PB_TRACE_REPLAY, PB_POST_RUN, PB_POST_EXTRACT, PB_EM_TRAIN, PB_NW_ALIGN, PB_STREAM_SUBMIT, PB_STREAM_TAKE, PB_SEED_BASES, PB_COUNT };
+bool api_profile_on();
+void api_profile_add(int bucket, double seconds, int calls = 1);
+struct ApiTimer {                  // adds its lifetime to a bucket
+  int bucket; bool on; double t0;
+  static double now();
+  explicit ApiTimer(int b) : bucket(b), on(api_profile_on()), t0(on ? now() : 0.0) {}
+  ~ApiTimer(){ if (on) api_profile_add(bucket, now() - t0); }
+};
+
 // ---- the pieces of hipstr_hmm_process_reads, split for pipelined use (stream.hip)
 }  // namespace hipstr
 struct hipstr_batch; struct hipstr_dev_batch;

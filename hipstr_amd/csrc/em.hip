@@ -402,6 +402,7 @@ double h_lse2(double a, double b){ return a > b ? a + log(1 + exp(b - a)) : b + 
 }  // namespace
 
 extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, double* stutter, int32_t* n_iter, double* final_ll){
+  hipstr::ApiTimer prof_t(hipstr::PB_EM_TRAIN);
   using hipstr::api_fail;
   if (!eb || !trained || !stutter || !n_iter || !final_ll) return api_fail("null argument");
   const int nl = eb->n_loci;

@@ -192,6 +192,7 @@ struct NwBufs {
 }  // namespace
 
 extern "C" int hipstr_nw_align(const hipstr_nw_batch_t* nb, hipstr_nw_out_t* o){
+  hipstr::ApiTimer prof_t(hipstr::PB_NW_ALIGN);
   using hipstr::api_fail;
   if (!nb || !o || nb->n_pairs < 0) return api_fail("null argument");
   const int n = nb->n_pairs;

@@ -218,6 +218,7 @@ hipstr_stream_t* hipstr_stream_open(const hipstr_stream_opts_t* opts){
 }
 
 int64_t hipstr_stream_submit(hipstr_stream_t* s, const hipstr_batch_t* loci){
+  hipstr::ApiTimer prof_t(hipstr::PB_STREAM_SUBMIT);
   if (!s || !loci){ hipstr::api_fail("null argument"); return -1; }
   {       // a submission that prepare_batch would refuse is turned away here, before it shares a batch with others
     std::string why;
@@ -348,6 +349,7 @@ int hipstr_stream_next_size(hipstr_stream_t* s, int64_t* ticket, int64_t* n_out,
 // reference's genotype() is a per-locus state machine (align, posteriors, tracebacks, new alleles, align again ...): one host thread
 // per locus submits its round and waits for ITS ticket while the rounds of the other loci share the batches.
 int hipstr_stream_take(hipstr_stream_t* s, int64_t ticket, double* aln_probs, int64_t cap_probs, int32_t* seeds, int64_t cap_seeds){
+  hipstr::ApiTimer prof_t(hipstr::PB_STREAM_TAKE);
   if (!s) return hipstr::api_fail("null argument");
   InFlight* f = NULL; size_t idx = 0;
   {

@@ -682,6 +682,7 @@ extern "C" int hipstr_hmm_trace(const hipstr_batch_t* b, int32_t n_req, const in
 
 extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, const int32_t* req_read, const int32_t* req_allele,
                                        const int32_t* req_seed, const char* const* hap_to_ref, hipstr_trace_out_t* o){
+  hipstr::ApiTimer prof_t(hipstr::PB_TRACE);
   using hipstr::api_fail;
   if (!b || !o || n_req < 0 || (n_req > 0 && (!req_read || !req_allele))) return api_fail("null argument");
   if (b->n_loci < 1) return api_fail("hipstr_hmm_trace needs at least one locus");
@@ -977,6 +978,7 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
     const auto r0t = now();
     run_parallel(work);
     const auto r1t = now();
+    if (hipstr::api_profile_on()) hipstr::api_profile_add(hipstr::PB_TRACE_REPLAY, std::chrono::duration<double>(r1t - r0t).count());
     // ---- the caller's flat pools: offsets in request order (serial prefix sums), then the bytes (parallel again)
     for (int q = q0; q < q1; q++){
       const ReqOut& R = res[q-q0];

@@ -472,6 +472,11 @@ int hipstr_debug_str_groups(const hipstr_batch_t* batch, int32_t* side, int32_t*
  * (lp0 + A) + G bit for bit whenever |lp0| < Bnd.  Used by tests/test_prep.py to check exactly that against the oracle. */
 int hipstr_debug_simple_table(int bound, int U0, int tail, double entry[3]);
 
+/* Diagnostics: where the calling process' host time inside the library goes.  mode 1 = reset and start, 0 = stop, anything else =
+ * read only.  Fills up to `cap` entries of names / seconds (wall clock, summed over threads) / calls and returns the number of
+ * buckets; names indented by two spaces are parts of the entry point above them.  Used by integration/genotype_flow.cpp --profile. */
+int hipstr_debug_api_profile(int mode, int cap, const char** names, double* seconds, int64_t* calls);
+
 const char* hipstr_last_error(void);
 
 #if defined(__GNUC__)

@@ -81,6 +81,25 @@ int HapAlignerMI355X::calc_seed_base(const Alignment& alignment){
   return seed;
 }
 
+// ---- where the adapter's own host time goes (genotype_flow --profile): seconds summed over threads
+#include <atomic>
+#include <chrono>
+static std::atomic<long long> g_adapter_ns[3];       // 0 flatten (FlatReads + batch struct)  1 fill AlignmentTrace objects  2 haplotype strings for the traces
+static std::atomic<bool> g_adapter_prof(false);
+namespace {
+struct AdapterTimer {
+  int k; std::chrono::steady_clock::time_point t0; bool on;
+  explicit AdapterTimer(int k_) : k(k_), on(g_adapter_prof.load()) { if (on) t0 = std::chrono::steady_clock::now(); }
+  void stop(){ if (on){ g_adapter_ns[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); on = false; } }
+  ~AdapterTimer(){ stop(); }
+};
+}
+void HapAlignerMI355X::profile(bool enable, double seconds[3]){
+  if (seconds) for (int i = 0; i < 3; i++) seconds[i] = 1e-9*(double)g_adapter_ns[i].load();
+  if (enable) for (int i = 0; i < 3; i++) g_adapter_ns[i] = 0;
+  g_adapter_prof = enable;
+}
+
 static hipstr_stream_t* g_shared_stream = NULL;
 void HapAlignerMI355X::use_stream(hipstr_stream* stream){ g_shared_stream = stream; }
 
@@ -88,8 +107,10 @@ void HapAlignerMI355X::process_reads(const std::vector<Alignment>& alignments, i
 				     const std::vector<bool>& realign_read, double* aln_probs, int* seed_positions){
   assert(alignments.size() == realign_read.size());
   (void)base_quality;     // BaseQuality's tables are constants of the model; the device holds the same values
+  AdapterTimer t_flat(0);
   FlatReads r(alignments, realign_read);
   FILL_BATCH(b, r)
+  t_flat.stop();
   if (g_shared_stream != NULL){      // this locus' round joins whatever the other loci in flight submitted
     const int64_t ticket = hipstr_stream_submit(g_shared_stream, &b);
     if (ticket < 0 || hipstr_stream_take(g_shared_stream, ticket, aln_probs + (size_t)init_read_index*fw_haplotype_->num_combs(),
@@ -171,8 +192,11 @@ void HapAlignerMI355X::run_traces(const std::vector<Alignment>& alignments, cons
 				  const std::vector<AlignmentTrace*>& targets){
   const int n = (int)alignments.size();
   if (n == 0) return;
+  AdapterTimer t_flat(0);
   FlatReads r(alignments, std::vector<bool>(alignments.size(), true));
   FILL_BATCH(b, r)
+  t_flat.stop();
+  AdapterTimer t_info(2);
 
   // Haplotype::get_aln_info() of every haplotype, in the order the reference visits them (Haplotype::next)
   std::vector<std::string> aln_info;
@@ -182,6 +206,7 @@ void HapAlignerMI355X::run_traces(const std::vector<Alignment>& alignments, cons
   std::vector<const char*> hap_to_ref;
   for (size_t k = 0; k < aln_info.size(); k++) hap_to_ref.push_back(aln_info[k].c_str());
 
+  t_info.stop();
   std::vector<int32_t> req_read(n), req_allele(best_haplotypes.begin(), best_haplotypes.end()), req_seed(n, HIPSTR_SEED_AUTO);
   size_t chars = 64;
   for (int i = 0; i < n; i++){
@@ -203,6 +228,7 @@ void HapAlignerMI355X::run_traces(const std::vector<Alignment>& alignments, cons
   o.aln_str_off = aln_str_off.data(); o.aln_str = aln_str.data(); o.cap_chars = cap;
   if (hipstr_hmm_trace_seeded(&b, n, req_read.data(), req_allele.data(), req_seed.data(), hap_to_ref.data(), &o) != 0)
     printErrorAndDie(hipstr_last_error());
+  AdapterTimer t_fill(1);
   for (int i = 0; i < n; i++) fill_trace(i, &o, alignments[i], *targets[i]);
 }
 

@@ -55,6 +55,8 @@ class HapAlignerMI355X {
   // loci in flight — one host thread per SeqStutterGenotyper — their alignment rounds then share device batches: each call submits its
   // locus and waits for its own ticket (hipstr_stream_take).  NULL (the default) = one-shot calls.
   static void use_stream(struct hipstr_stream* stream);
+  // genotype_flow --profile: seconds[0..2] = flatten, fill AlignmentTrace objects, haplotype strings, summed over threads; then reset and switch on / off
+  static void profile(bool enable, double seconds[3]);
 
   int calc_seed_base(const Alignment& alignment);
 

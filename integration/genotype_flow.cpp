@@ -248,7 +248,7 @@ static int run_locus(const LocusParams& lp, FILE* f){
 
 extern "C" int flow_main(int argc, char** argv){
   LocusParams lp; lp.seed = 1; lp.n_samples = 10; lp.reads_per_sample = 9; lp.period = 4; lp.recompute = false; lp.reassemble = true; lp.nw = false;
-  const char* out_path = NULL; int n_loci = 0, n_threads = 1; bool use_stream = false;
+  const char* out_path = NULL; int n_loci = 0, n_threads = 1; bool use_stream = false, profile = false;
   for (int i = 1; i < argc; i++){
     if (!strcmp(argv[i], "--seed")) lp.seed = strtoull(argv[++i], NULL, 10);
     else if (!strcmp(argv[i], "--samples")) lp.n_samples = atoi(argv[++i]);
@@ -260,6 +260,7 @@ extern "C" int flow_main(int argc, char** argv){
     else if (!strcmp(argv[i], "--out")) out_path = argv[++i];
     else if (!strcmp(argv[i], "--loci")) n_loci = atoi(argv[++i]);          // many loci (seeds seed, seed+1, ...; periods cycling 2..5) ...
     else if (!strcmp(argv[i], "--threads")) n_threads = atoi(argv[++i]);    // ... one SeqStutterGenotyper per host thread at a time
+    else if (!strcmp(argv[i], "--profile")) profile = true;                 // many-loci form: where the host threads' time went (MI355X build: library and adapter buckets)
     else if (!strcmp(argv[i], "--stream")) use_stream = true;               // MI355X build: alignment rounds of the loci in flight share batches
     else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
   }
@@ -283,6 +284,13 @@ extern "C" int flow_main(int argc, char** argv){
   }
 #else
   (void)use_stream;
+#endif
+#ifdef FLOW_MI355X
+  if (profile){
+    // one locus first, outside the measurement: device initialisation, module load, the first allocations
+    LocusParams q = lp; q.period = 2; char* buf = NULL; size_t len = 0; FILE* wf = open_memstream(&buf, &len); run_locus(q, wf); fclose(wf); free(buf);
+    hipstr_debug_api_profile(1, 0, NULL, NULL, NULL); HapAlignerMI355X::profile(true, NULL);
+  }
 #endif
   std::vector<std::string> dumps(n_loci);
   std::vector<int> rcs(n_loci, 0);
@@ -315,6 +323,24 @@ extern "C" int flow_main(int argc, char** argv){
       if (line.compare(0, 21, "log_sample_posteriors") == 0 || line.compare(0, 16, "sample_total_LLs") == 0) continue;
       for (char ch : line){ h ^= (uint8_t)ch; h *= 1099511628211ull; }
     }
+  }
+  if (profile){
+    // thread seconds = threads x wall; what is not inside the library or the adapter is the reference's own host code
+    // (SeqStutterGenotyper, ReadPooler, HaplotypeGenerator, Haplotype ...) and this driver's read simulation
+    fprintf(stderr, "profile: %d loci, %d thread(s), wall %.3f s, thread seconds %.3f\n", n_loci, n_threads, dt, dt*n_threads);
+#ifdef FLOW_MI355X
+    const char* names[32]; double secs[32]; int64_t calls[32]; double ad[3];
+    const int nb = hipstr_debug_api_profile(0, 32, names, secs, calls);
+    HapAlignerMI355X::profile(false, ad);
+    double inside = ad[0] + ad[1] + ad[2];
+    for (int i = 0; i < nb; i++){
+      fprintf(stderr, "profile: %-42s %9.3f ms %8lld calls\n", names[i], 1e3*secs[i], (long long)calls[i]);
+      if (names[i][0] != ' ') inside += secs[i];
+    }
+    fprintf(stderr, "profile: %-42s %9.3f ms\nprofile: %-42s %9.3f ms\nprofile: %-42s %9.3f ms\n", "adapter: flatten reads + batch struct", 1e3*ad[0],
+            "adapter: fill AlignmentTrace objects", 1e3*ad[1], "adapter: haplotype alignment strings", 1e3*ad[2]);
+    fprintf(stderr, "profile: %-42s %9.3f ms\n", "reference host code + read simulation", 1e3*(dt*n_threads - inside));
+#endif
   }
   FILE* f = out_path ? fopen(out_path, "w") : stdout;
   if (!f){ perror(out_path); return 2; }
