@@ -142,7 +142,7 @@ def pipeline_stages(capi, hmm, sb, loci, P):
                         "hap_aln_info_s_all_loci": t_info, "haplotypes": len(h2r)}
     # the whole per-locus chain of SeqStutterGenotyper::genotype + write_vcf_record on one batch of loci: forward pass -> posteriors
     # -> MAP diplotypes -> best haplotype per read (seq_stutter_genotyper.cpp:823-825) -> tracebacks -> genotype calls (GL/PL/Q)
-    nc = min(loci, 64)
+    nc = max(1, min(loci, 64, 40000 // P))                     # (at most ~40000 tracebacks: the output pools below hold 16 Mi characters)
     cb = capi.SynthBatch(n_loci=nc, reads_per_locus=P, n_str_alleles=int(np.diff(np.ctypeslib.as_array(sb.ptr.contents.hap_off, shape=(loci + 1,)))[0]), seed=4242)
     A_c = np.diff(np.ctypeslib.as_array(cb.ptr.contents.hap_off, shape=(nc + 1,)))
     S_c = 5                                                    # samples per locus: reads dealt round-robin-by-block to 5 samples

@@ -3,7 +3,7 @@
 prescribes: FETCH_SIZE/WRITE_SIZE are KB per dispatch derived from TCC_EA0_RDREQ/WRREQ; on gfx950 FETCH_SIZE counts a
 128-B read request of a wide coalesced stream as 64 B, so the read side is reported raw and x2 (upper bound); WRITE_SIZE is
 uncalibrated and reported raw.
-usage: python tools/pmc_traffic.py <fetch.db> <write.db> <alignments_per_launch> > profiles/<name>.json"""
+usage: python tools/pmc_traffic.py <fetch.db> <write.db> <alignments_per_launch> ["<command>"] > profiles/<name>.json"""
 import json
 import sqlite3
 import sys
@@ -21,7 +21,7 @@ def per_kernel(db, counter):
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 n_aln = float(sys.argv[3])
-res = {"alignments_per_launch": n_aln, "kernels": {}}
+res = {"command": sys.argv[4] if len(sys.argv) > 4 else "", "alignments_per_launch": n_aln, "kernels": {}}        # bench.py matches the workload by the command
 tot_f = tot_w = 0.0
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)

@@ -23,5 +23,5 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o v -- python $R/bench.
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o v -- python $R/bench.py $ARGS > $OUT/write.log 2>&1
 db(){ find $OUT/$1 -name '*results.db' | head -1; }
 python $R/tools/sq_counters.py $(db sq1) $(db sq2) $N_ALN "bench.py $ARGS" $R/profiles > $OUT/sq_counters.json
-python $R/tools/pmc_traffic.py $(db fetch) $(db write) $N_ALN > $OUT/pmc_traffic.json
+python $R/tools/pmc_traffic.py $(db fetch) $(db write) $N_ALN "bench.py $ARGS" > $OUT/pmc_traffic.json
 ls -la $OUT | head -30
