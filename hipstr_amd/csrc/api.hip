@@ -770,6 +770,7 @@ int hipstr_debug_prepare(const hipstr_batch_t* batch, int threads, double* secon
   hipstr::set_host_threads(0);
   if (rc){ g_err = err; return 1; }
   if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+  hipstr::prep_profile_print();
   if (digest){
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](const void* p, size_t n){ const uint8_t* q = (const uint8_t*)p; for (size_t i = 0; i < n; i++){ h ^= q[i]; h *= 1099511628211ull; } };

@@ -348,7 +348,11 @@ static void simple_table_entry(int lim, int U0, int tail, double ent[3]){
   if (ent[2] < 1e300) ent[2] *= g_bnd_scale.load();      // tests: shrink the guarantee (HIPSTR_DEBUG_BND_SCALE)
 }
 
+static std::atomic<uint64_t> g_so_cycles[6];
+static const bool g_so_on = getenv("HIPSTR_PREP_PROFILE") != NULL;
+#define HS_SOLAP(k) do { if (g_so_on){ const uint64_t now_ = __builtin_ia32_rdtsc(); g_so_cycles[k] += now_ - so_t; so_t = now_; } } while (0)
 void emit_stropt(const std::string& blk, int period, const double* stutter, Prepared& out, bool forward_only = false){
+  uint64_t so_t = g_so_on ? __builtin_ia32_rdtsc() : 0;
   const HostTables& T = host_tables();
   const int B = blk.size();
   hs_stropt_t so; memset(&so, 0, sizeof so);
@@ -375,6 +379,7 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
     const int D = -(q+1)*period;
     out.f64pool.push_back(B+D >= 0 ? -T.int_log[B+D+1] : 0.0);              // StutterAlignerClass.cpp:112
   }
+  HS_SOLAP(0);
   const size_t visits_begin = out.visits.size();
   // insertion visiting list (StutterAlignerClass.cpp:74-96); uses the shift-`period` run table
   {
@@ -449,6 +454,7 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
   for (int k = 0; k <= HS_MAXREP; k++) piecewise(0, 0, 0, pw[k]);          // "not piecewise"
   so.shape[HS_MAXREP] = classify(so.ins_off, so.ins_len, B);
   if (so.shape[HS_MAXREP] < 0 && piecewise(so.ins_off, so.ins_len, B, pw[HS_MAXREP])) so.shape[HS_MAXREP] = HS_SHAPE_PIECEWISE;
+  HS_SOLAP(1);
   // deletion visiting lists (StutterAlignerClass.cpp:123-142); one per deletion size, shift = |D|
   for (int q = 0; q < HS_MAXREP; q++){
     const int D = -(q+1)*period;
@@ -467,6 +473,7 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
     so.shape[q] = classify(so.del_off[q], so.del_len[q], B+D);
     if (so.shape[q] < 0 && piecewise(so.del_off[q], so.del_len[q], B+D, pw[q])) so.shape[q] = HS_SHAPE_PIECEWISE;
   }
+  HS_SOLAP(2);
   // The forward kernels read a visiting list only where it has no closed form (shape -1: replayed entry by entry; the traceback also
   // replays the piecewise-simple ones).  An option whose lists all have one — periodic and, for the forward pass, once-or-twice
   // interrupted blocks: nearly all — keeps none of them (they were 20 % of a batch's table bytes).
@@ -489,6 +496,7 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
   if (any_pw)
     for (int k = 0; k <= HS_MAXREP; k++)
       for (int i = 0; i < HS_PW_SLOTS; i++){ double v; memcpy(&v, &pw[k][i], 8); out.f64pool.push_back(v); }
+  HS_SOLAP(3);
   // tabulated closed form: only when every list the kernel can evaluate is simple and the entries fit the LDS budget
   so.tab_off = out.f64pool.size(); so.tab_len = 0;
   {
@@ -524,6 +532,7 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
     }
   }
   out.stropts.push_back(so);
+  HS_SOLAP(4);
 }
 
 // Everything emit_stropt derives from (block, period, stutter model) — visiting lists, their shapes, the closed-form table, the 20
@@ -629,9 +638,24 @@ struct PrepShared {
   const int32_t* seed_in;
 };
 
+// HIPSTR_PREP_PROFILE=1: cycles per section of prepare_locus, summed over threads, printed by hipstr_debug_prepare
+static std::atomic<uint64_t> g_lap_cycles[8];
+static const bool g_lap_on = getenv("HIPSTR_PREP_PROFILE") != NULL;
+void prep_profile_print(){
+  if (!g_lap_on) return;
+  static const char* const names[8] = { "options + strings", "STR options (emit_stropt_cached)", "boundary signatures", "allele loop (flank rows, reuse replay)", "STR order + records + read-end rows", "trailing-flank groups", "reads + seeds", "" };
+  uint64_t tot = 0; for (int i = 0; i < 7; i++) tot += g_lap_cycles[i];
+  for (int i = 0; i < 7; i++){ fprintf(stderr, "prepare_locus: %-40s %6.1f %%\n", names[i], tot ? 100.0*g_lap_cycles[i]/tot : 0.0); g_lap_cycles[i] = 0; }
+  static const char* const so_names[5] = { "constants (stutter pmf, priors)", "insertion list", "deletion lists", "list bookkeeping + descriptor slots", "closed-form table" };
+  uint64_t st = 0; for (int i = 0; i < 5; i++) st += g_so_cycles[i];
+  for (int i = 0; i < 5; i++){ fprintf(stderr, "  emit_stropt: %-38s %6.1f %%\n", so_names[i], st ? 100.0*g_so_cycles[i]/st : 0.0); g_so_cycles[i] = 0; }
+}
+#define HS_LAP(k) do { if (g_lap_on){ const uint64_t now_ = __builtin_ia32_rdtsc(); g_lap_cycles[k] += now_ - lap_t; lap_t = now_; } } while (0)
+
 static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const PrepShared& sh, Prepared& out,
                          std::vector< std::vector<int> >& locus_leads, std::string& err){
   const int32_t* seed_in = sh.seed_in;
+  uint64_t lap_t = g_lap_on ? __builtin_ia32_rdtsc() : 0;
     const int period = b->period[l];
     if (period < 1 || period > 9){ err = "STR period must be in [1,9] (stutter_model.h:38)"; return 1; }
     int32_t nopts[3];
@@ -654,6 +678,7 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
     if (A != b->hap_off[l+1]-b->hap_off[l]){ err = "hap_off does not match the product of block options"; return 1; }
     if (A >= (1 << 24)){ err = "more than 16 M candidate haplotypes for a locus are not supported"; return 1; }
 
+    HS_LAP(0);
     hs_locus_t loc;
     loc.out_off = sh.out_off[l]; loc.hap_begin = out.alleles.size(); loc.n_alleles = A;
     loc.read_begin = b->read_off[l]; loc.n_reads = b->read_off[l+1]-b->read_off[l];
@@ -669,6 +694,7 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
         emit_stropt_cached(s, period, b->stutter + 6*l, out);
         sblk[side].push_back(std::move(s));
       }
+    HS_LAP(1);
     std::vector<int32_t> str_opt_of(A);                // STR option of every allele
     for (int k = 0; k < A; k++){ int32_t o3[3]; allele_options(nopts, k, o3); str_opt_of[k] = o3[1]; }
 
@@ -701,6 +727,7 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
         for (int j = n-2; j >= 0; j--){ count = (q[j+1] == q[j]) ? count+1 : 0; if (j == 0) rr_first = count; }
         end_sig[side].push_back(EndSig{ q[0], q[n-1], rr_first, lr_last });
       }
+    HS_LAP(2);
     bool reuse = false;
     int lead_id[2] = {-1, -1};
     int n_realigned = 0;
@@ -760,6 +787,7 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
       out.alleles.push_back(al);
     }
 
+    HS_LAP(3);
     loc.n_re = n_realigned;
     loc.n_lead[0] = lead_sets[0].size(); loc.n_lead[1] = lead_sets[1].size();
     for (int side = 0; side < 2; side++){
@@ -838,6 +866,7 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
         prev_p = &cur;
       }
     }
+    HS_LAP(4);
     for (int side = 0; side < 2; side++){      // alleles sharing a trailing-flank rowset run as lanes of one wavefront (<= 64 each)
       std::map<int, std::vector<int> > by_rowset;
       for (int k = 0; k < A; k++){
@@ -854,6 +883,7 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
         }
       loc.tg_count[side] = out.tgroups.size() - loc.tg_begin[side];
     }
+    HS_LAP(5);
     locus_leads.push_back(lead_sets[0]); locus_leads.push_back(lead_sets[1]);
     for (int r = loc.read_begin; r < loc.read_begin + loc.n_reads; r++){
       hs_read_t rd;
@@ -876,6 +906,7 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
       }
       sh.reads[r] = rd;
     }
+    HS_LAP(6);
     out.loci.push_back(loc);
     return 0;
 }

@@ -91,6 +91,7 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
 
 // Returns 0 if prepare_batch would accept the batch; otherwise its error message in err.
 int check_batch(const hipstr_batch_t* b, std::string& err);
+void prep_profile_print();
 int check_locus(const hipstr_batch_t* b, int locus, int* opt_cursor_io, std::string& err);      // one locus of it; the cursor into opt_off is advanced
 
 // HapAligner::calc_seed_base (HapAligner.cpp:238-318).  Returns -2 on the inputs the reference dies on.

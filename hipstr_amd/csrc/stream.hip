@@ -10,6 +10,7 @@
 // While batch k runs on the device the worker prepares and uploads batch k+1 (launches are asynchronous), so with two or more
 // slots the device only idles when the host cannot keep up.  Host code only; every byte of arithmetic is in the kernels.
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <chrono>
 #include <condition_variable>
@@ -240,31 +241,49 @@ int64_t hipstr_stream_submit(hipstr_stream_t* s, const hipstr_batch_t* loci){
 // boundary): *first_ticket = the ticket of locus 0, the rest follow consecutively.  Stops at the first locus that is refused.
 int hipstr_stream_submit_each(hipstr_stream_t* s, const hipstr_batch_t* loci, int64_t* first_ticket){
   if (!s || !loci) return hipstr::api_fail("null argument");
-  int opt = 0;
-  const int RUN = 64;                              // loci checked without the stream's lock, then appended under one
-  for (int l0 = 0; l0 < loci->n_loci; l0 += RUN){
-    const int l1 = std::min(loci->n_loci, l0 + RUN);
-    int opt0[RUN]; std::string why; int n_ok = 0;
-    for (int l = l0; l < l1; l++, n_ok++){       // a locus that prepare_batch would refuse is turned away here, before it shares a batch with others
-      opt0[l - l0] = opt;
-      if (hipstr::check_locus(loci, l, &opt, why)) break;
-    }
-    {
-      std::lock_guard<std::mutex> g(s->m);
-      if (s->closing) return hipstr::api_fail("stream is closing");
-      for (int l = l0; l < l0 + n_ok; l++){
-        if (!s->pending) s->pending = new OwnedBatch();
-        const int64_t ticket = s->next_ticket;
-        const int64_t out_before = s->pending->n_out; const int32_t reads_before = s->pending->read_off.back();
-        if (const char* w2 = s->pending->append_locus(loci, l, opt0[l - l0], ticket)) return hipstr::api_fail(w2);
-        s->next_ticket++;
-        s->sizes.push_back(std::make_pair(s->pending->n_out - out_before, (int64_t)(s->pending->read_off.back() - reads_before)));
-        if (s->pending->work >= s->batch_work) flush_locked(s);
-        if (l == 0 && first_ticket) *first_ticket = ticket;
+  const int n = loci->n_loci;
+  const auto t_sub0 = std::chrono::steady_clock::now();
+  // A locus that prepare_batch would refuse is turned away here, before it shares a batch with others.  The checks (a seed per read
+  // among them) are independent per locus: a large call spreads them over the host threads; the appends below only copy.
+  std::vector<int> opt0((size_t)n + 1, 0);
+  for (int l = 0; l < n; l++){ int c = 0; for (int k = 0; k < 3; k++) c += std::max(0, loci->blk_nopts[3*l+k]); opt0[l+1] = opt0[l] + c; }
+  std::atomic<int> first_bad(n);
+  std::mutex why_m; std::string why; int why_l = n;
+  const int CH = 128, n_ch = (n + CH - 1)/CH;
+  hipstr::parallel_for(n_ch, n >= 4*CH ? hipstr::host_threads() : 1, [&](int c){
+    for (int l = c*CH; l < std::min(n, (c+1)*CH); l++){
+      if (l > first_bad.load(std::memory_order_relaxed)) return;
+      int cur = opt0[l]; std::string w;
+      if (hipstr::check_locus(loci, l, &cur, w)){
+        std::lock_guard<std::mutex> g(why_m);
+        if (l < why_l){ why_l = l; why = w; }
+        int fb = first_bad.load(); while (l < fb && !first_bad.compare_exchange_weak(fb, l)){}
+        return;
       }
     }
-    if (n_ok < l1 - l0) return hipstr::api_fail(why);     // the loci before the refused one are in
+  });
+  const int n_ok_total = std::min(n, why_l);
+  const auto t_chk = std::chrono::steady_clock::now();
+  const int RUN = 64;                              // loci appended under one hold of the stream's lock
+  for (int l0 = 0; l0 < n_ok_total; l0 += RUN){
+    const int l1 = std::min(n_ok_total, l0 + RUN);
+    std::lock_guard<std::mutex> g(s->m);
+    if (s->closing) return hipstr::api_fail("stream is closing");
+    for (int l = l0; l < l1; l++){
+      if (!s->pending) s->pending = new OwnedBatch();
+      const int64_t ticket = s->next_ticket;
+      const int64_t out_before = s->pending->n_out; const int32_t reads_before = s->pending->read_off.back();
+      if (const char* w2 = s->pending->append_locus(loci, l, opt0[l], ticket)) return hipstr::api_fail(w2);
+      s->next_ticket++;
+      s->sizes.push_back(std::make_pair(s->pending->n_out - out_before, (int64_t)(s->pending->read_off.back() - reads_before)));
+      if (s->pending->work >= s->batch_work) flush_locked(s);
+      if (l == 0 && first_ticket) *first_ticket = ticket;
+    }
   }
+  if (n >= 1024 && getenv("HIPSTR_TIMING"))
+    fprintf(stderr, "stream: submit_each of %d loci: checks %.3f ms, appends %.3f ms\n", n, 1e3*std::chrono::duration<double>(t_chk - t_sub0).count(),
+            1e3*std::chrono::duration<double>(std::chrono::steady_clock::now() - t_chk).count());
+  if (n_ok_total < n) return hipstr::api_fail(why);     // the loci before the refused one are in
   return 0;
 }
 
