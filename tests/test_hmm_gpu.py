@@ -243,6 +243,27 @@ def test_str_groups_and_their_fallback(hmm, oracle, monkeypatch, kw, env):
     assert np.array_equal(gs, ws) and np.array_equal(got, want), kw
 
 
+@pytest.mark.parametrize("kw,env", [
+    (dict(n_loci=4, reads_per_locus=60, n_str_alleles=32, seed=91), None),                                             # NS shape: three reads per group
+    (dict(n_loci=3, reads_per_locus=30, n_str_alleles=24, read_len=100, flank_len=30, str_bp=90, seed=92), None),      # blocks longer than the read sides
+    (dict(n_loci=2, reads_per_locus=24, n_str_alleles=16, read_len=300, flank_len=140, str_bp=50, seed=93), None),     # sides beyond a group's 256 columns: these reads stay with hs_str_kernel_generic
+    (dict(n_loci=3, reads_per_locus=40, n_str_alleles=20, n_flank_opts=3, mask_rate=0.3, seed=94), None),              # several lead slots, masked alleles and reads
+    (dict(n_loci=3, reads_per_locus=40, n_str_alleles=32, seed=95), ("HIPSTR_DEBUG_REDO", "2")),                      # half of the wavefront-alleles re-done by the generic kernel
+    (dict(n_loci=3, reads_per_locus=40, n_str_alleles=32, str_bp=14, seed=96), None),                                  # short blocks: fewer deletion sizes than six
+], ids=["ns", "long_blocks", "long_sides", "flank_options_masks", "redo_half", "short_blocks"])
+def test_interrupted_repeats_in_the_grouped_kernel(hmm, oracle, monkeypatch, kw, env):
+    """hs_str_group_kernel_pw: every alternative allele carries a random substitution (HIPSTR_SYNTH_IMPERFECT=1.0), so its visiting lists are
+    piecewise simple — one or two breaks — and are evaluated by pw_eval_grp from scalar descriptor slots next to the tabulated lists of the
+    same allele.  Against the oracle, bit for bit."""
+    monkeypatch.setenv("HIPSTR_SYNTH_IMPERFECT", "1.0")
+    sb = capi.SynthBatch(**kw)
+    want, ws = capi.run_align(oracle, "oracle_", sb.ptr, fill=-3.25)
+    if env:
+        monkeypatch.setenv(*env)
+    got, gs = capi.run_align(hmm, "hipstr_hmm_", sb.ptr, fill=-3.25)
+    assert np.array_equal(gs, ws) and np.array_equal(got, want), kw
+
+
 @pytest.mark.parametrize("lf_len,rf_len", [(1, 40), (40, 1), (2, 33), (20, 21), (21, 20), (41, 61)])
 def test_flank_heights_around_the_band_size(hmm, oracle, lf_len, rf_len):
     """The banded sweeps of hs_lead_kernel / hs_trail_kernel cut a flank into bands of <= 20 rows; a one-base flank is a block with
