@@ -101,6 +101,51 @@ struct OwnedBatch {
     tickets.push_back(t);
     return NULL;
   }
+  // Loci [l0, l1) of `b`, every one a submission of its own with consecutive tickets from ticket0: what append_locus does l1 - l0
+  // times, but the loci of a batch lie next to each other in every array, so each pool takes ONE copy (the reads' bases and qualities —
+  // 12 KB per 40-read locus — spread over the host threads) and the offset arrays one rebasing pass.  opt0[l] = first block option of locus l.
+  const char* append_run(const hipstr_batch_t* b, int l0, int l1, const int* opt0, int64_t ticket0, std::vector< std::pair<int64_t,int64_t> >& sizes){
+    const int n = l1 - l0;
+    const int r0 = b->read_off[l0], r1 = b->read_off[l1], h0 = b->hap_off[l0], h1 = b->hap_off[l1];
+    const int32_t s0 = b->opt_off[opt0[l0]], s1 = b->opt_off[opt0[l1]], b0 = b->base_off[r0], b1 = b->base_off[r1], c0 = b->cigar_off[r0], c1 = b->cigar_off[r1];
+    if (r1 < r0 || h1 < h0 + n) return "inconsistent read_off / hap_off";
+    if ((int64_t)bases.size() + (b1 - b0) > INT32_MAX || (int64_t)seq.size() + (s1 - s0) > INT32_MAX) return "pending batch exceeds 2 GiB of bases";
+    const int32_t loc_base = (int32_t)period.size();
+    blk_start.insert(blk_start.end(), b->blk_start + 3*l0, b->blk_start + 3*l1); blk_end.insert(blk_end.end(), b->blk_end + 3*l0, b->blk_end + 3*l1);
+    blk_nopts.insert(blk_nopts.end(), b->blk_nopts + 3*l0, b->blk_nopts + 3*l1); period.insert(period.end(), b->period + l0, b->period + l1);
+    stutter.insert(stutter.end(), b->stutter + 6*l0, b->stutter + 6*l1);
+    const int32_t seq0 = (int32_t)seq.size() - s0, base0 = (int32_t)bases.size() - b0, cig0 = (int32_t)cigar_op.size() - c0;
+    for (int i = opt0[l0] + 1; i <= opt0[l1]; i++) opt_off.push_back(seq0 + b->opt_off[i]);
+    seq.append(b->seq + s0, s1 - s0);
+    const int32_t hap0 = hap_off.back() - h0, rd0 = read_off.back() - r0;
+    for (int l = l0; l < l1; l++){
+      const int64_t P = b->read_off[l+1] - b->read_off[l], A = b->hap_off[l+1] - b->hap_off[l];
+      if (P < 0 || A < 1) return "inconsistent read_off / hap_off";
+      Ticket t; t.id = ticket0 + (l - l0); t.l0 = loc_base + (l - l0); t.l1 = t.l0 + 1; t.r0 = rd0 + b->read_off[l]; t.r1 = t.r0 + (int32_t)P; t.out0 = n_out;
+      n_out += P*A; work += P*A; t.out1 = n_out;
+      tickets.push_back(t);
+      sizes.push_back(std::make_pair(P*A, P));
+      hap_off.push_back(hap0 + b->hap_off[l+1]); read_off.push_back(rd0 + b->read_off[l+1]);
+    }
+    if (b->realign_hap) realign_hap.insert(realign_hap.end(), b->realign_hap + h0, b->realign_hap + h1); else realign_hap.insert(realign_hap.end(), (size_t)(h1 - h0), 1);
+    {
+      const size_t at = base_off.size(); base_off.resize(at + (r1 - r0)); cigar_off.resize(at + (r1 - r0));
+      for (int r = r0 + 1; r <= r1; r++){ base_off[at + (r - r0 - 1)] = base0 + b->base_off[r]; cigar_off[at + (r - r0 - 1)] = cig0 + b->cigar_off[r]; }
+    }
+    {
+      const size_t at = bases.size(), nb = (size_t)(b1 - b0);
+      bases.resize(at + nb); quals.resize(at + nb);
+      const size_t CH = (size_t)1 << 20; const int n_ch = (int)((nb + CH - 1)/CH);
+      hipstr::parallel_for(2*n_ch, nb > 4*CH ? hipstr::host_threads() : 1, [&](int i){
+        const size_t o = (size_t)(i >> 1)*CH, m = std::min(CH, nb - o);
+        memcpy(((i & 1) ? &quals[0] : &bases[0]) + at + o, ((i & 1) ? b->quals : b->bases) + b0 + o, m);
+      });
+    }
+    read_start.insert(read_start.end(), b->read_start + r0, b->read_start + r1);
+    cigar_op.append(b->cigar_op + c0, c1 - c0); cigar_len.insert(cigar_len.end(), b->cigar_len + c0, b->cigar_len + c1);
+    if (b->realign_read) realign_read.insert(realign_read.end(), b->realign_read + r0, b->realign_read + r1); else realign_read.insert(realign_read.end(), (size_t)(r1 - r0), 1);
+    return NULL;
+  }
   const hipstr_batch_t* finish(){
     if (cigar_len.empty()) cigar_len.push_back(0);
     view.n_loci = (int32_t)period.size();
@@ -264,21 +309,22 @@ int hipstr_stream_submit_each(hipstr_stream_t* s, const hipstr_batch_t* loci, in
   });
   const int n_ok_total = std::min(n, why_l);
   const auto t_chk = std::chrono::steady_clock::now();
-  const int RUN = 64;                              // loci appended under one hold of the stream's lock
-  for (int l0 = 0; l0 < n_ok_total; l0 += RUN){
-    const int l1 = std::min(n_ok_total, l0 + RUN);
+  // The loci go in as runs: a run ends where the pending batch reaches its size (it is handed to the workers there) or after 1024 loci
+  // (the collectors take the stream's lock between runs).
+  for (int l0 = 0; l0 < n_ok_total; ){
     std::lock_guard<std::mutex> g(s->m);
     if (s->closing) return hipstr::api_fail("stream is closing");
-    for (int l = l0; l < l1; l++){
-      if (!s->pending) s->pending = new OwnedBatch();
-      const int64_t ticket = s->next_ticket;
-      const int64_t out_before = s->pending->n_out; const int32_t reads_before = s->pending->read_off.back();
-      if (const char* w2 = s->pending->append_locus(loci, l, opt0[l], ticket)) return hipstr::api_fail(w2);
-      s->next_ticket++;
-      s->sizes.push_back(std::make_pair(s->pending->n_out - out_before, (int64_t)(s->pending->read_off.back() - reads_before)));
-      if (s->pending->work >= s->batch_work) flush_locked(s);
-      if (l == 0 && first_ticket) *first_ticket = ticket;
+    if (!s->pending) s->pending = new OwnedBatch();
+    int64_t w = s->pending->work; int l1 = l0;
+    while (l1 < n_ok_total && l1 - l0 < 1024 && w < s->batch_work){
+      w += (int64_t)(loci->read_off[l1+1] - loci->read_off[l1])*(loci->hap_off[l1+1] - loci->hap_off[l1]); l1++;
     }
+    const int64_t ticket0 = s->next_ticket;
+    if (const char* w2 = s->pending->append_run(loci, l0, l1, opt0.data(), ticket0, s->sizes)) return hipstr::api_fail(w2);
+    s->next_ticket += l1 - l0;
+    if (l0 == 0 && first_ticket) *first_ticket = ticket0;
+    if (s->pending->work >= s->batch_work) flush_locked(s);
+    l0 = l1;
   }
   if (n >= 1024 && getenv("HIPSTR_TIMING"))
     fprintf(stderr, "stream: submit_each of %d loci: checks %.3f ms, appends %.3f ms\n", n, 1e3*std::chrono::duration<double>(t_chk - t_sub0).count(),
