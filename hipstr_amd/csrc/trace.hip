@@ -551,6 +551,43 @@ struct DevBufs {
   }
 };
 
+// Host arrays that travel together: packed into ONE pinned block and sent with ONE asynchronous copy (a synchronous hipMemcpy from
+// pageable memory costs 10-20 us each, and a traceback call of a locus had ten of them).  add() returns the piece's offset; after
+// send() the piece sits at dev + offset.  The pinned block is released when the arena goes out of scope (after the stream was synchronised).
+struct Arena {
+  struct Piece { const void* src; size_t bytes, off; };
+  std::vector<Piece> pieces; size_t total = 0;
+  hipstr::Ctx* ctx = NULL; char* pin = NULL; char* dev = NULL;
+  ~Arena(){ if (ctx){ if (pin) hipstr::pin_free(ctx, pin); if (dev) hipstr::dev_free(ctx, dev); } }
+  size_t add(const void* src, size_t bytes){
+    const size_t off = total; pieces.push_back(Piece{src, bytes, off}); total = (total + (bytes ? bytes : 1) + 255) & ~(size_t)255; return off;
+  }
+  int send(hipstr::Ctx* c, hipStream_t st){
+    ctx = c;
+    pin = (char*)hipstr::pin_alloc(ctx, total ? total : 256); dev = (char*)hipstr::dev_alloc(ctx, total ? total : 256);
+    if (!pin || !dev) return 1;
+    for (const Piece& pc : pieces) if (pc.bytes) memcpy(pin + pc.off, pc.src, pc.bytes);
+    if (total) TR_HIP(hipMemcpyAsync(dev, pin, total, hipMemcpyHostToDevice, st));
+    return 0;
+  }
+  template <typename T> T* at(size_t off) const { return (T*)(dev + off); }
+};
+
+// two side streams + their events per (host thread, device), created at first use and kept
+struct SideStreams { hipStream_t st[2] = {NULL, NULL}; hipEvent_t ev_up = NULL, ev_done[2] = {NULL, NULL}; bool used[2] = {false, false}; bool ok = false; };
+static SideStreams* side_streams(int device){
+  thread_local SideStreams per_dev[16];
+  if (device < 0 || device >= 16) return NULL;
+  SideStreams& s = per_dev[device];
+  if (!s.ok){
+    if (hipStreamCreateWithFlags(&s.st[0], hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s.st[1], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.ev_done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.ev_done[1], hipEventDisableTiming) != hipSuccess) return NULL;
+    s.ok = true;
+  }
+  return &s;
+}
+
 struct AllelePrep {
   std::string seq[2][3];          // block sequences per orientation, in side order
   int lead_off[2], trail_off[2], stropt[2];
@@ -762,21 +799,34 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
   DevBufs dev;
   hs_tdev_t h; memset(&h, 0, sizeof h);
   const int total_bases = b->base_off[n_reads];
+  Arena st_arena;
   {
-    hs_row_t* d_rows; hs_stropt_t* d_so; hs_visit_t* d_vis; double* d_f64; char *d_chars, *d_bases, *d_quals;
-    if (dev.put(&d_rows, rows.data(), rows.size()) || dev.put(&d_so, P.stropts.data(), P.stropts.size()) ||
-        dev.put(&d_vis, P.visits.data(), P.visits.size()) || dev.put(&d_f64, P.f64pool.data(), P.f64pool.size()) ||
-        dev.put(&d_chars, P.chars.data(), P.chars.size()) || dev.put(&d_bases, b->bases, total_bases) ||
-        dev.put(&d_quals, b->quals, total_bases)) return 1;
-    h.rows = d_rows; h.stropts = d_so; h.visits = d_vis; h.f64pool = d_f64; h.chars = d_chars; h.bases = d_bases; h.quals = d_quals;
+    const size_t o_rows = st_arena.add(rows.data(), rows.size()*sizeof(hs_row_t)), o_so = st_arena.add(P.stropts.data(), P.stropts.size()*sizeof(hs_stropt_t)),
+                 o_vis = st_arena.add(P.visits.data(), P.visits.size()*sizeof(hs_visit_t)), o_f64 = st_arena.add(P.f64pool.data(), P.f64pool.size()*sizeof(double)),
+                 o_chars = st_arena.add(P.chars.data(), P.chars.size()), o_bases = st_arena.add(b->bases, (size_t)total_bases), o_quals = st_arena.add(b->quals, (size_t)total_bases);
+    if (st_arena.send(T.ctx, T.stream)) return api_fail("out of device or pinned host memory");
+    h.rows = st_arena.at<hs_row_t>(o_rows); h.stropts = st_arena.at<hs_stropt_t>(o_so); h.visits = st_arena.at<hs_visit_t>(o_vis);
+    h.f64pool = st_arena.at<double>(o_f64); h.chars = st_arena.at<char>(o_chars); h.bases = st_arena.at<char>(o_bases); h.quals = st_arena.at<char>(o_quals);
   }
   h.int_log = T.int_log; h.qual_correct = T.qual_correct; h.qual_error = T.qual_error; h.m2m = T.m2m; h.m2i = T.m2i;
   h.log_thresh = HT.log_thresh;
 
   // ---- chunks of requests whose matrices fit the workspace budget
-  size_t free_b = 0, total_b = 0;
-  TR_HIP(hipMemGetInfo(&free_b, &total_b));
-  int64_t budget = std::min<int64_t>((int64_t)8 << 30, (int64_t)(free_b / 4));          // bytes of decision matrices per chunk
+  // (the query costs as much as a small call's kernels: only a call whose matrices could exceed 256 MiB asks — an upper bound from the
+  //  longest read and the flank lengths of the first allele is enough to tell)
+  int64_t budget = (int64_t)256 << 20;                                                   // bytes of decision matrices per chunk
+  {
+    int64_t rough = 0;
+    for (int q = 0; q < n_req; q++){
+      const int r = req_read[q]; const AllelePrep& ap = alleles[req_ap[q]];
+      rough += (int64_t)(ap.seq[0][0].size() + ap.seq[0][2].size() + 2)*(b->base_off[r+1] - b->base_off[r]);
+    }
+    if (rough > budget){
+      size_t free_b = 0, total_b = 0;
+      TR_HIP(hipMemGetInfo(&free_b, &total_b));
+      budget = std::min<int64_t>((int64_t)8 << 30, (int64_t)(free_b / 4));
+    }
+  }
   if (const char* e = getenv("HIPSTR_TRACE_WS_MIB")) budget = std::max<int64_t>(1, atoll(e)) << 20;
   std::vector<hs_tside_t> sides(2*(size_t)n_req);
   std::vector<int64_t> need(n_req);
@@ -813,13 +863,15 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
   }
   if (max_art > 0x7fffffff || max_ops > 0x7fffffff || max_lc > 0x7fffffff) return api_fail("too many requests for one call; split the request list");
   hs_tdev_t hc = h;
-  hs_tside_t* d_sides; int32_t* d_items; hs_tdev_t* d_args;
-  if (dev.alloc(&d_sides, 2*(size_t)max_nq) || dev.alloc(&d_items, 2*(size_t)max_nq) || dev.alloc(&d_args, 1)) return 1;
-  hc.sides = d_sides; hc.items = d_items;
-  if (dev.alloc(&hc.dec, max_mat) || dev.alloc(&hc.lastcol, max_lc) || dev.alloc(&hc.arts, max_art) || dev.alloc(&hc.ops, max_ops) || dev.alloc(&hc.side_prob, 2*(size_t)max_nq) ||
-      dev.alloc(&hc.ll, max_nq) || dev.alloc(&hc.max_index, max_nq) || dev.alloc(&hc.n_ops, 2*(size_t)max_nq) ||
-      dev.alloc(&hc.str_size, 2*(size_t)max_nq) || dev.alloc(&hc.str_pos, 2*(size_t)max_nq)) return 1;
-  TR_HIP(hipMemcpy(d_args, &hc, sizeof hc, hipMemcpyHostToDevice));
+  if (dev.alloc(&hc.dec, max_mat) || dev.alloc(&hc.lastcol, max_lc) || dev.alloc(&hc.arts, max_art) || dev.alloc(&hc.side_prob, 2*(size_t)max_nq)) return 1;
+  // what comes back — score, seed position, operation counts, artifact size and position per side, the operation strings — is one
+  // device block with the layout of the pinned block it is copied to: one copy per chunk
+  const size_t o_ll = 0, o_mxi = o_ll + (size_t)max_nq*8, o_nops = o_mxi + (size_t)max_nq*4, o_ssz = o_nops + 2*(size_t)max_nq*4, o_spos = o_ssz + 2*(size_t)max_nq*4,
+               o_ops = (o_spos + 2*(size_t)max_nq*4 + 15) & ~(size_t)15, o_end = o_ops + (size_t)(max_ops ? max_ops : 1);
+  char* d_res;
+  if (dev.alloc(&d_res, o_end)) return 1;
+  hc.ll = (double*)(d_res + o_ll); hc.max_index = (int32_t*)(d_res + o_mxi); hc.n_ops = (int32_t*)(d_res + o_nops);
+  hc.str_size = (int32_t*)(d_res + o_ssz); hc.str_pos = (int32_t*)(d_res + o_spos); hc.ops = d_res + o_ops;
 
   const auto t_static = now();
   double ms_alloc = 0, ms_kernel = 0, ms_d2h = 0, ms_replay = 0;
@@ -844,37 +896,54 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
       for (int si = 2*q0; si < 2*q1; si++) if ((sides[si].n + 63)/64 == cl) items.push_back(si - 2*q0);
     }
     cls_begin[HS_MAX_COLS] = items.size();
-    TR_HIP(hipMemcpy(d_sides, sides.data() + 2*q0, 2*(size_t)nq*sizeof(hs_tside_t), hipMemcpyHostToDevice));
-    TR_HIP(hipMemcpy(d_items, items.data(), items.size()*sizeof(int32_t), hipMemcpyHostToDevice));
+    Arena ch_arena;                                 // this chunk's sides, launch order and argument block
+    hs_tdev_t hcc = hc;
+    const size_t o_sides = ch_arena.add(sides.data() + 2*q0, 2*(size_t)nq*sizeof(hs_tside_t)), o_items = ch_arena.add(items.data(), items.size()*sizeof(int32_t)),
+                 o_args = ch_arena.add(&hcc, sizeof hcc);
+    {   // the argument block points into the arena it travels in: sizes first, then the pointers, then the copy
+      ch_arena.ctx = T.ctx;
+      ch_arena.pin = (char*)hipstr::pin_alloc(T.ctx, ch_arena.total); ch_arena.dev = (char*)hipstr::dev_alloc(T.ctx, ch_arena.total);
+      if (!ch_arena.pin || !ch_arena.dev) return api_fail("out of device or pinned host memory");
+      hcc.sides = ch_arena.at<hs_tside_t>(o_sides); hcc.items = ch_arena.at<int32_t>(o_items);
+      for (const Arena::Piece& pc : ch_arena.pieces) if (pc.bytes) memcpy(ch_arena.pin + pc.off, pc.src, pc.bytes);
+      TR_HIP(hipMemcpyAsync(ch_arena.dev, ch_arena.pin, ch_arena.total, hipMemcpyHostToDevice, T.stream));
+    }
+    const hs_tdev_t* d_args = ch_arena.at<hs_tdev_t>(o_args);
     const auto c1 = now();
+    // The fill kernels of the column classes are independent of each other and, for the requests of one locus, a hundred wavefronts
+    // each: the second and third class run beside the first on two side streams of the calling thread (made once per thread and
+    // device), the walk kernel waits for all of them.  Large calls (many loci) fill the device per class and stay on one stream.
+    int n_cls = 0; for (int cl = 1; cl <= HS_MAX_COLS; cl++) n_cls += (cls_begin[cl] - cls_begin[cl-1]) > 0;
+    SideStreams* side = (n_cls > 1 && nq <= 4096) ? side_streams(hipstr::ctx_device(T.ctx)) : NULL;
+    if (side){ side->used[0] = side->used[1] = false; TR_HIP(hipEventRecord(side->ev_up, T.stream)); }
+    int k_cls = 0;
     for (int cl = 1; cl <= HS_MAX_COLS; cl++){
       const int cnt = cls_begin[cl] - cls_begin[cl-1];
       if (cnt == 0) continue;
+      hipStream_t ks = T.stream;
+      const int slot = side ? k_cls % 3 : 0;              // 0: the call's stream; 1, 2: the side streams
+      if (slot){ ks = side->st[slot-1]; if (!side->used[slot-1]){ TR_HIP(hipStreamWaitEvent(ks, side->ev_up, 0)); side->used[slot-1] = true; } }
+      k_cls++;
       switch (cl){
-        case 1: hipLaunchKernelGGL(hs_trace_fill<1>, dim3(cnt), dim3(64), 0, T.stream, d_args, cls_begin[cl-1]); break;
-        case 2: hipLaunchKernelGGL(hs_trace_fill<2>, dim3(cnt), dim3(64), 0, T.stream, d_args, cls_begin[cl-1]); break;
-        case 3: hipLaunchKernelGGL(hs_trace_fill<3>, dim3(cnt), dim3(64), 0, T.stream, d_args, cls_begin[cl-1]); break;
-        case 4: hipLaunchKernelGGL(hs_trace_fill<4>, dim3(cnt), dim3(64), 0, T.stream, d_args, cls_begin[cl-1]); break;
-        case 5: hipLaunchKernelGGL(hs_trace_fill<5>, dim3(cnt), dim3(64), 0, T.stream, d_args, cls_begin[cl-1]); break;
-        default: hipLaunchKernelGGL(hs_trace_fill<6>, dim3(cnt), dim3(64), 0, T.stream, d_args, cls_begin[cl-1]); break;
+        case 1: hipLaunchKernelGGL(hs_trace_fill<1>, dim3(cnt), dim3(64), 0, ks, d_args, cls_begin[cl-1]); break;
+        case 2: hipLaunchKernelGGL(hs_trace_fill<2>, dim3(cnt), dim3(64), 0, ks, d_args, cls_begin[cl-1]); break;
+        case 3: hipLaunchKernelGGL(hs_trace_fill<3>, dim3(cnt), dim3(64), 0, ks, d_args, cls_begin[cl-1]); break;
+        case 4: hipLaunchKernelGGL(hs_trace_fill<4>, dim3(cnt), dim3(64), 0, ks, d_args, cls_begin[cl-1]); break;
+        case 5: hipLaunchKernelGGL(hs_trace_fill<5>, dim3(cnt), dim3(64), 0, ks, d_args, cls_begin[cl-1]); break;
+        default: hipLaunchKernelGGL(hs_trace_fill<6>, dim3(cnt), dim3(64), 0, ks, d_args, cls_begin[cl-1]); break;
       }
+    }
+    if (side) for (int k = 0; k < 2; k++) if (side->used[k]){
+      TR_HIP(hipEventRecord(side->ev_done[k], side->st[k])); TR_HIP(hipStreamWaitEvent(T.stream, side->ev_done[k], 0)); side->used[k] = false;
     }
     hipLaunchKernelGGL(hs_trace_walk, dim3(nq), dim3(64), 0, T.stream, d_args, 0);
     TR_HIP(hipGetLastError());
-    TR_HIP(hipStreamSynchronize(T.stream));
     const auto c2 = now();
-    // results through one pinned block (a pageable destination costs a staging copy per call and per array)
-    const size_t o_ll = 0, o_mxi = o_ll + (size_t)nq*8, o_nops = o_mxi + (size_t)nq*4, o_ssz = o_nops + 2*(size_t)nq*4, o_spos = o_ssz + 2*(size_t)nq*4,
-                 o_ops = (o_spos + 2*(size_t)nq*4 + 15) & ~(size_t)15, o_end = o_ops + (n_ops ? n_ops : 1);
+    // results through one pinned block (a pageable destination costs a staging copy per call and per array), in one copy behind the kernels
     char* hostblk = (char*)hipstr::pin_alloc(T.ctx, o_end);
     if (!hostblk) return api_fail("out of pinned host memory");
     struct PinGuard { hipstr::Ctx* c; void* p; ~PinGuard(){ hipstr::pin_free(c, p); } } pin_guard{T.ctx, hostblk};
-    TR_HIP(hipMemcpyAsync(hostblk + o_ll, hc.ll, nq*sizeof(double), hipMemcpyDeviceToHost, T.stream));
-    TR_HIP(hipMemcpyAsync(hostblk + o_mxi, hc.max_index, nq*sizeof(int32_t), hipMemcpyDeviceToHost, T.stream));
-    TR_HIP(hipMemcpyAsync(hostblk + o_nops, hc.n_ops, 2*(size_t)nq*sizeof(int32_t), hipMemcpyDeviceToHost, T.stream));
-    TR_HIP(hipMemcpyAsync(hostblk + o_ssz, hc.str_size, 2*(size_t)nq*sizeof(int32_t), hipMemcpyDeviceToHost, T.stream));
-    TR_HIP(hipMemcpyAsync(hostblk + o_spos, hc.str_pos, 2*(size_t)nq*sizeof(int32_t), hipMemcpyDeviceToHost, T.stream));
-    if (n_ops) TR_HIP(hipMemcpyAsync(hostblk + o_ops, hc.ops, n_ops, hipMemcpyDeviceToHost, T.stream));
+    TR_HIP(hipMemcpyAsync(hostblk, d_res, o_ops + (size_t)(n_ops ? n_ops : 1), hipMemcpyDeviceToHost, T.stream));
     TR_HIP(hipStreamSynchronize(T.stream));
     const double* ll = (const double*)(hostblk + o_ll); const int32_t* mxi = (const int32_t*)(hostblk + o_mxi);
     const int32_t* nops = (const int32_t*)(hostblk + o_nops); const int32_t* ssz = (const int32_t*)(hostblk + o_ssz); const int32_t* spos = (const int32_t*)(hostblk + o_spos);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# lat_trace.sh — kernel timeline of ONE-locus calls (40 reads x 32 alleles): what the 0.3 ms of a hipstr_hmm_process_reads call are made of.
+# lat_trace.sh [align|trace] — kernel timeline of ONE-locus calls (forward: 40 reads x 32 alleles; trace: 100 requests): what the 0.3 ms of a hipstr_hmm_process_reads call are made of.
 # Prints, per kernel, its average duration and the average gap to the previous kernel's end within a call (from rocprofv3's kernel trace).
 R=$(pwd); O=$R/gpurun_out/lat; rm -rf $O; mkdir -p $O
 cat > $O/one.py <<'PY'
@@ -7,16 +7,27 @@ import sys, time; sys.path.insert(0, sys.argv[1])
 import numpy as np
 from hipstr_amd import capi
 hmm = capi.load_hmm(); assert hmm.hipstr_hmm_init(0) == 0
-sb = capi.SynthBatch(n_loci=1, reads_per_locus=40, n_str_alleles=32, seed=3)
-for _ in range(5): capi.run_align(hmm, "hipstr_hmm_", sb.ptr)
+mode = sys.argv[2] if len(sys.argv) > 2 else "align"
+if mode == "align":
+    sb = capi.SynthBatch(n_loci=1, reads_per_locus=40, n_str_alleles=32, seed=3)
+    call = lambda: capi.run_align(hmm, "hipstr_hmm_", sb.ptr)
+else:      # one traceback call of a locus: 100 reads, each against its source allele
+    sys.path.insert(0, sys.argv[1] + "/tests")
+    import util
+    sb = capi.SynthBatch(n_loci=1, reads_per_locus=100, n_str_alleles=8, seed=3)
+    seeds = np.zeros(sb.n_reads, np.int32); hmm.hipstr_calc_seed_bases(sb.ptr, seeds.ctypes.data_as(capi._i32p))
+    src = sb.src_allele(); rr = [r for r in range(sb.n_reads) if seeds[r] >= 0]; aa = [int(src[r]) for r in rr]
+    h2r = capi.hap_aln_info(hmm, "hipstr_", sb.ptr, cap=1 << 22)
+    call = lambda: capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, rr, aa, h2r, cap=1 << 20, unpack=False)
+for _ in range(5): call()
 ts = []
 for _ in range(40):
-    t = time.perf_counter(); capi.run_align(hmm, "hipstr_hmm_", sb.ptr); ts.append(time.perf_counter() - t); time.sleep(0.002)
-print("one-shot 40x32: median %.3f ms min %.3f" % (1e3*np.median(ts), 1e3*min(ts)))
+    t = time.perf_counter(); call(); ts.append(time.perf_counter() - t); time.sleep(0.002)
+print("%s, one locus per call: median %.3f ms min %.3f" % (mode, 1e3*np.median(ts), 1e3*min(ts)))
 PY
 cd /tmp && export TMPDIR=/tmp
-python $O/one.py $R
-rocprofv3 --kernel-trace -d $O/trace -o v -- python $O/one.py $R > $O/trace.log 2>&1
+python $O/one.py $R ${1:-align}
+rocprofv3 --kernel-trace -d $O/trace -o v -- python $O/one.py $R ${1:-align} > $O/trace.log 2>&1
 python - $(find $O/trace -name '*results.db' | head -1) <<'PY'
 import sqlite3, sys, collections
 db = sqlite3.connect(sys.argv[1])
