@@ -840,10 +840,14 @@ struct PostRun {
   hs_post_dev_t* d_args = NULL;
   int64_t n_post = 0, n_samp = 0, n_ll = 0;
   int n_reads = 0;
+  // small runs (a locus or a few: everything under 4 MiB): inputs and argument block travel in ONE pinned block with one copy, the three
+  // results sit next to each other in the same device block and come back with one copy
+  void* pin_in = NULL; size_t res_bytes = 0, res_total_off = 0, res_map_off = 0;
   ~PostRun(){
-    if (!ctx || allocs.empty() || bind(ctx)) return;
+    if (!ctx || (allocs.empty() && !pin_in) || bind(ctx)) return;
     hipStreamSynchronize(stream);           // the blocks are handed to the next user
     for (void* p : allocs) ctx->dev_cache.put(p);
+    if (pin_in) ctx->pin_cache.put(pin_in);
   }
 };
 
@@ -873,6 +877,39 @@ int post_setup(const hipstr_post_batch_t* pb, const double* dev_ll, PostRun& R){
   }
   R.n_post = po; R.n_samp = so; R.n_ll = lo; R.n_reads = pb->n_loci ? pb->read_off[pb->n_loci] : 0;
   memset(&R.h, 0, sizeof R.h);
+  if (!dev_ll && !pb->log_aln_probs) return fail("no log_aln_probs given");
+  {
+    struct Piece { const void* src; size_t bytes, off; };
+    std::vector<Piece> in; size_t tot = 0;
+    auto add = [&](const void* src, size_t bytes){ const size_t off = tot; in.push_back(Piece{src, bytes, off}); tot = (tot + (bytes ? bytes : 1) + 255) & ~(size_t)255; return off; };
+    const size_t o_units = add(R.units.data(), R.units.size()*sizeof(hs_post_unit_t)), o_p1 = add(pb->log_p1, sizeof(double)*R.n_reads),
+                 o_p2 = add(pb->log_p2, sizeof(double)*R.n_reads), o_w = add(pb->read_weight, sizeof(int32_t)*R.n_reads),
+                 o_prior = pb->log_prior ? add(pb->log_prior, sizeof(double)*R.n_post) : 0,
+                 o_ll = dev_ll ? 0 : add(pb->log_aln_probs, sizeof(double)*R.n_ll), o_args = add(&R.h, sizeof R.h);
+    const size_t in_total = tot;
+    const size_t o_post = tot; tot += ((size_t)sizeof(double)*R.n_post + 255) & ~(size_t)255;
+    const size_t o_tot = tot;  tot += ((size_t)sizeof(double)*R.n_samp + 255) & ~(size_t)255;
+    const size_t o_map = tot;  tot += ((size_t)sizeof(int32_t)*2*R.n_samp + 255) & ~(size_t)255;
+    if (tot < ((size_t)4 << 20)){
+      char* dblk = (char*)ctx->dev_cache.get(tot);
+      if (!dblk) return 1;
+      R.allocs.push_back(dblk);
+      char* pin = (char*)ctx->pin_cache.get(in_total);
+      if (!pin) return 1;
+      R.pin_in = pin;
+      R.h.units = (const hs_post_unit_t*)(dblk + o_units); R.h.log_p1 = (const double*)(dblk + o_p1); R.h.log_p2 = (const double*)(dblk + o_p2);
+      R.h.read_weight = (const int32_t*)(dblk + o_w);
+      if (pb->log_prior) R.h.log_prior = (const double*)(dblk + o_prior);
+      R.h.log_aln_probs = dev_ll ? dev_ll : (const double*)(dblk + o_ll);
+      R.h.log_post = (double*)(dblk + o_post); R.h.sample_total = (double*)(dblk + o_tot); R.h.map_gt = (int32_t*)(dblk + o_map);
+      R.h.log_thresh = T.log_thresh; R.h.log_half = T.log_half;
+      R.d_args = (hs_post_dev_t*)(dblk + o_args);
+      for (const Piece& pc : in) if (pc.bytes && pc.src) memcpy(pin + pc.off, pc.src, pc.bytes);      // (the argument block last in the list: filled in by now)
+      HS_HIP(hipMemcpyAsync(dblk, pin, in_total, hipMemcpyHostToDevice, R.stream));
+      R.res_bytes = tot - o_post; R.res_total_off = o_tot - o_post; R.res_map_off = o_map - o_post;
+      return 0;
+    }
+  }
   auto up = [&](const void* src, size_t bytes, void** out){
     *out = ctx->dev_cache.get(bytes ? bytes : 1);
     if (!*out) return 1;
@@ -966,8 +1003,16 @@ int hipstr_post_fetch(hipstr_post_dev_t* pd, double* log_post, double* sample_to
   PostRun& R = pd->R;
   if (bind(R.ctx)) return 1;
   if (pd->foreign_stream) HS_HIP(hipDeviceSynchronize());
-  HS_HIP(hipStreamSynchronize(R.stream));
-  if (!R.units.empty()){
+  if (!(R.res_bytes && !pd->foreign_stream)) HS_HIP(hipStreamSynchronize(R.stream));      // (the small form's one copy is ordered behind the kernel on the same stream)
+  if (!R.units.empty() && R.res_bytes){
+    char* pin = (char*)R.ctx->pin_cache.get(R.res_bytes);
+    if (!pin) return 1;
+    if (hipMemcpyAsync(pin, R.h.log_post, R.res_bytes, hipMemcpyDeviceToHost, R.stream) != hipSuccess || hipStreamSynchronize(R.stream) != hipSuccess){
+      R.ctx->pin_cache.put(pin); return fail("device-to-host copy failed"); }
+    memcpy(log_post, pin, sizeof(double)*R.n_post); memcpy(sample_total_ll, pin + R.res_total_off, sizeof(double)*R.n_samp);
+    memcpy(map_gt, pin + R.res_map_off, sizeof(int32_t)*2*R.n_samp);
+    R.ctx->pin_cache.put(pin);
+  } else if (!R.units.empty()){
     if (fetch_array(R.ctx, R.stream, log_post, R.h.log_post, sizeof(double)*R.n_post) ||
         fetch_array(R.ctx, R.stream, sample_total_ll, R.h.sample_total, sizeof(double)*R.n_samp) ||
         fetch_array(R.ctx, R.stream, map_gt, R.h.map_gt, sizeof(int32_t)*2*R.n_samp)) return 1;
