@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <string.h>
 
 namespace hipstr {
 
@@ -28,6 +29,29 @@ void  dev_free(Ctx* ctx, void* p);
 void* pin_alloc(Ctx* ctx, size_t bytes);
 void  pin_free(Ctx* ctx, void* p);
 
+
+// Host arrays that travel together: packed into ONE pinned block and sent with ONE asynchronous copy (a synchronous hipMemcpy from
+// pageable memory costs 10-20 us each; the traceback and Needleman-Wunsch calls of a locus had ten of them).  add() returns a piece's offset;
+// after send() the piece sits at dev + offset.  Both blocks go back to the context's caches when the arena dies — after the stream
+// has been synchronised by its user.
+struct HostArena {
+  struct Piece { const void* src; size_t bytes, off; };
+  Piece pieces[12]; int n_pieces = 0; size_t total = 0;
+  Ctx* ctx = NULL; char* pin = NULL; char* dev = NULL;
+  ~HostArena(){ if (ctx){ if (pin) pin_free(ctx, pin); if (dev) dev_free(ctx, dev); } }
+  size_t add(const void* src, size_t bytes){
+    const size_t off = total; if (n_pieces < 12) pieces[n_pieces++] = Piece{src, bytes, off}; total = (total + (bytes ? bytes : 1) + 255) & ~(size_t)255; return off;
+  }
+  int reserve(Ctx* c){        // blocks only (the caller still has pointers into `dev` to fill in before the pieces are packed)
+    ctx = c; pin = (char*)pin_alloc(ctx, total ? total : 256); dev = (char*)dev_alloc(ctx, total ? total : 256);
+    return (pin && dev) ? 0 : 1;
+  }
+  int send(hipStream_t st){   // pack and copy
+    for (int i = 0; i < n_pieces; i++) if (pieces[i].bytes && pieces[i].src) memcpy(pin + pieces[i].off, pieces[i].src, pieces[i].bytes);
+    return (total && hipMemcpyAsync(dev, pin, total, hipMemcpyHostToDevice, st) != hipSuccess) ? api_fail("hipMemcpyAsync (host to device) failed") : 0;
+  }
+  template <typename T> T* at(size_t off) const { return (T*)(dev + off); }
+};
 
 // ---- where the host time of the entry points goes (hipstr_debug_api_profile, include/hipstr_hmm.h): wall-clock seconds and calls per
 // bucket, summed over all threads while enabled.  Buckets nest: the indented ones are parts of the entry point above them.

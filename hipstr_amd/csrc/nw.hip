@@ -211,14 +211,25 @@ extern "C" int hipstr_nw_align(const hipstr_nw_batch_t* nb, hipstr_nw_out_t* o){
     if (P.L2 > HS_NW_MAX_READ) return api_fail("second sequence longer than 1536 bases is not supported");
     if (P.L1 > HS_NW_MAX_REF) return api_fail("reference longer than 4095 bases is not supported");
   }
-  NwBufs dev;
   hs_nw_dev_t h; memset(&h, 0, sizeof h);
-  char *d_refs, *d_reads;
-  if (dev.put(&d_refs, nb->ref_seqs, (size_t)nb->ref_off[n]) || dev.put(&d_reads, nb->read_seqs, (size_t)nb->read_off[n])) return 1;
-  h.refs = d_refs; h.reads = d_reads; h.end_penalty = nb->use_ref_end_penalty ? 1 : 0;
-  size_t free_b = 0, total_b = 0;
-  NW_HIP(hipMemGetInfo(&free_b, &total_b));
-  int64_t budget = std::min<int64_t>((int64_t)8 << 30, (int64_t)(free_b / 4));        // traceback bytes per chunk
+  hipstr::HostArena seqs;                                     // the two sequence pools: one pinned block, one copy
+  {
+    const size_t o_refs = seqs.add(nb->ref_seqs, (size_t)nb->ref_off[n]), o_reads = seqs.add(nb->read_seqs, (size_t)nb->read_off[n]);
+    if (seqs.reserve(T.ctx)) return api_fail("out of device or pinned host memory");
+    if (seqs.send(T.stream)) return 1;
+    h.refs = seqs.at<char>(o_refs); h.reads = seqs.at<char>(o_reads);
+  }
+  h.end_penalty = nb->use_ref_end_penalty ? 1 : 0;
+  // traceback bytes per chunk; the device is only asked how much it has free when the call could need more than 256 MiB
+  int64_t budget = (int64_t)256 << 20;
+  {
+    int64_t all = 0; for (int i = 0; i < n; i++) all += (int64_t)pairs[i].L1*pairs[i].L2;
+    if (all > budget){
+      size_t free_b = 0, total_b = 0;
+      NW_HIP(hipMemGetInfo(&free_b, &total_b));
+      budget = std::min<int64_t>((int64_t)8 << 30, (int64_t)(free_b / 4));
+    }
+  }
   if (const char* e = getenv("HIPSTR_NW_WS_MIB")) budget = std::max<int64_t>(1, atoll(e)) << 20;
   for (int p0 = 0; p0 < n; ){
     int p1 = p0; int64_t tb = 0, lf = 0, ob = 0;
@@ -243,12 +254,21 @@ extern "C" int hipstr_nw_align(const hipstr_nw_batch_t* nb, hipstr_nw_out_t* o){
     cls_begin[9] = items.size();
     NwBufs ws;
     hs_nw_dev_t hc = h;
-    hs_nw_pair_t* d_pairs; int32_t* d_items; hs_nw_dev_t* d_args;
-    if (ws.put(&d_pairs, pairs.data() + p0, np) || ws.put(&d_items, items.data(), items.size())) return 1;
-    hc.pairs = d_pairs; hc.items = d_items;
-    if (ws.alloc(&hc.trace, tb) || ws.alloc(&hc.last, lf) || ws.alloc(&hc.ops, ob) || ws.alloc(&hc.score, np) || ws.alloc(&hc.best_col, np) ||
-        ws.alloc(&hc.lead_col, np) || ws.alloc(&hc.n_ops, np)) return 1;
-    if (ws.put(&d_args, &hc, 1)) return 1;
+    if (ws.alloc(&hc.trace, tb) || ws.alloc(&hc.last, lf)) return 1;
+    // what comes back — score, stop column, leading columns, operation count per pair and the operation strings — is one device block
+    const size_t r_score = 0, r_bcol = r_score + (size_t)np*4, r_lcol = r_bcol + (size_t)np*4, r_nops = r_lcol + (size_t)np*4, r_ops = r_nops + (size_t)np*4,
+                 r_end = r_ops + (size_t)(ob ? ob : 1);
+    char* d_res;
+    if (ws.alloc(&d_res, r_end)) return 1;
+    hc.score = (float*)(d_res + r_score); hc.best_col = (int32_t*)(d_res + r_bcol); hc.lead_col = (int32_t*)(d_res + r_lcol);
+    hc.n_ops = (int32_t*)(d_res + r_nops); hc.ops = d_res + r_ops;
+    hipstr::HostArena ch;                                     // this chunk's pairs, launch order and argument block
+    const size_t o_pairs = ch.add(pairs.data() + p0, (size_t)np*sizeof(hs_nw_pair_t)), o_items = ch.add(items.data(), items.size()*sizeof(int32_t)),
+                 o_args = ch.add(&hc, sizeof hc);
+    if (ch.reserve(T.ctx)) return api_fail("out of device or pinned host memory");
+    hc.pairs = ch.at<hs_nw_pair_t>(o_pairs); hc.items = ch.at<int32_t>(o_items);
+    if (ch.send(T.stream)) return 1;
+    const hs_nw_dev_t* d_args = ch.at<hs_nw_dev_t>(o_args);
     for (int cl = 0; cl < 9; cl++){
       const int cnt = cls_begin[cl+1] - cls_begin[cl];
       if (cnt == 0) continue;
@@ -262,13 +282,14 @@ extern "C" int hipstr_nw_align(const hipstr_nw_batch_t* nb, hipstr_nw_out_t* o){
     }
     hipLaunchKernelGGL(hs_nw_walk, dim3((np + 63)/64), dim3(64), 0, T.stream, d_args, np);
     NW_HIP(hipGetLastError());
+    char* hostblk = (char*)hipstr::pin_alloc(T.ctx, r_end);
+    if (!hostblk) return api_fail("out of pinned host memory");
+    struct PinGuard { hipstr::Ctx* c; void* p; ~PinGuard(){ hipstr::pin_free(c, p); } } pin_guard{T.ctx, hostblk};
+    NW_HIP(hipMemcpyAsync(hostblk, d_res, r_end, hipMemcpyDeviceToHost, T.stream));
     NW_HIP(hipStreamSynchronize(T.stream));
-    std::vector<float> score(np); std::vector<int32_t> bcol(np), lcol(np), nops(np); std::vector<char> ops(ob ? ob : 1);
-    NW_HIP(hipMemcpy(score.data(), hc.score, np*sizeof(float), hipMemcpyDeviceToHost));
-    NW_HIP(hipMemcpy(bcol.data(), hc.best_col, np*sizeof(int32_t), hipMemcpyDeviceToHost));
-    NW_HIP(hipMemcpy(lcol.data(), hc.lead_col, np*sizeof(int32_t), hipMemcpyDeviceToHost));
-    NW_HIP(hipMemcpy(nops.data(), hc.n_ops, np*sizeof(int32_t), hipMemcpyDeviceToHost));
-    NW_HIP(hipMemcpy(ops.data(), hc.ops, ob, hipMemcpyDeviceToHost));
+    const float* score = (const float*)(hostblk + r_score); const int32_t* bcol = (const int32_t*)(hostblk + r_bcol);
+    const int32_t* lcol = (const int32_t*)(hostblk + r_lcol); const int32_t* nops = (const int32_t*)(hostblk + r_nops);
+    struct { const char* p; const char* data() const { return p; } } ops{hostblk + r_ops};
     // gapped strings and run-length CIGAR (traceAlignment :252-323)
     for (int i = p0; i < p1; i++){
       const hs_nw_pair_t& P = pairs[i];
