@@ -923,30 +923,34 @@ __device__ __forceinline__ double pw_eval_grp(const PwSlots& S, const double* il
   // The eight pushed values; one that is absent for this lane is -1e300: it loses every maximum and fails the threshold, i.e. adds the
   // +0.0 pw_eval adds for it.  Branch-free, two float exponentials per packed operation (each half rounded on its own, like the scalar
   // ones); a term that passes the threshold has 1.44 dd > -10, so fasterexp's clamp at -126 (fastonebigheader.h:210) cannot act on it.
+  // (a level that is not this lane's — L1 without the first break, L2 without the second, the plain entries' level with none in reach —
+  //  equals the level before it: harmless in the maximum, and its term is switched off by its own condition instead of by a select)
   constexpr double NEG = -1.0e300;
-  double v[8];
-  v[0] = L0;
-  v[1] = a_r0 ? dbl(2) + L0 : NEG;
-  v[2] = a_b0 ? L1 : NEG;
-  v[3] = a_r1 ? dbl(4) + L1 : NEG;
-  v[4] = a_b1 ? L2 : NEG;
-  v[5] = a_r2 ? dbl(6) + L2 : NEG;
-  v[6] = (np > 0) ? Llast : NEG;
-  v[7] = a_t ? ilog[max(tail - ns, 0)] + Lfin : NEG;
-  double mx = v[0];
-#pragma unroll
-  for (int t = 1; t < 8; t++) mx = fmax(mx, v[t]);
+  const double v0 = L0, v2 = L1, v4 = L2;
+  const double v1 = a_r0 ? dbl(2) + L0 : NEG;
+  const double v3 = a_r1 ? dbl(4) + L1 : NEG;
+  const double v5 = a_r2 ? dbl(6) + L2 : NEG;
+  const double v7 = a_t ? ilog[max(tail - ns, 0)] + Lfin : NEG;
+  double mx = fmax(fmax(fmax(v0, v1), fmax(v2, v3)), fmax(fmax(v4, v5), v7));       // (the plain entries' level is L2: already in)
   typedef float hs_f2 __attribute__((ext_vector_type(2)));
   double tot = 0.0;
-#pragma unroll
-  for (int t = 0; t < 8; t += 2){
-    const double dd0 = v[t] - mx, dd1 = v[t + 1] - mx;
+  auto pair = [&](double a, bool on_a, double b, bool on_b, double wa){
+    const double dd0 = a - mx, dd1 = b - mx;
     hs_f2 x; x.x = (float)dd0; x.y = (float)dd1;
     const hs_f2 z = (x * 1.442695040f + 126.94269504f) * 8388608.0f;
-    const float fe0 = (dd0 > log_thresh) ? __uint_as_float(__float2uint_rz(z.x)) : 0.0f;
-    const float fe1 = (dd1 > log_thresh) ? __uint_as_float(__float2uint_rz(z.y)) : 0.0f;
-    tot += (t == 6) ? (double)np * (double)fe0 : (double)fe0;        // equal float terms: the product is exact
+    const float fe0 = (on_a && dd0 > log_thresh) ? __uint_as_float(__float2uint_rz(z.x)) : 0.0f;
+    const float fe1 = (on_b && dd1 > log_thresh) ? __uint_as_float(__float2uint_rz(z.y)) : 0.0f;
+    tot += wa * (double)fe0;                                         // (wa = 1.0 except for the plain entries: equal float terms, the product is exact)
     tot += (double)fe1;
+  };
+  pair(v0, true, v1, true, 1.0);
+  pair(v2, a_b0, v3, true, 1.0);
+  pair(v4, a_b1, v5, true, 1.0);
+  if (pb > pa) pair(Llast, np > 0, v7, true, (double)np);            // (the same for every lane: most lists have no plain entries)
+  else {
+    const double dd = v7 - mx;
+    const float zz = ((float)dd * 1.442695040f + 126.94269504f) * 8388608.0f;
+    tot += (double)((dd > log_thresh) ? __uint_as_float(__float2uint_rz(zz)) : 0.0f);
   }
   return mx + (double)f_fasterlog((float)tot);
 }
