@@ -1719,6 +1719,22 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       double lp = (t0 > 0) ? L.Mt[xx] : 0.0;
       const int ndp = nv * p;
       int t = t0;
+      if (KIND == 1 && p <= 6 && t % p == 0 && t + p <= min(tmax, ndp)){
+        // whole repeat units first: a unit's emissions are requested together and added in order, the deletion table's row written once per
+        // unit (an interrupted block rarely continues the previous allele's tables: all its B steps are taken here, one LDS round trip per unit
+        // instead of one per step)
+        int col = xx - t, left = j - t;
+        double* dl = L.Dl + (t/p)*L.ld + xx;
+        for (; t + p <= min(tmax, ndp); t += p){
+          double e[6];
+#pragma unroll
+          for (int r = 0; r < 6; r++) if (r < p) e[r] = Eat(col - r, boff[B-1-t-r]);
+#pragma unroll
+          for (int r = 0; r < 6; r++) if (r < p){ if (left - r >= 0) lp += e[r]; }
+          if (left - (p - 1) >= 0 && actj) *dl = lp;
+          dl += L.ld; col -= p; left -= p;
+        }
+      }
       if (t < min(tmax, ndp)){
         int col = xx - t;
         int left = j - t, ph = (t + 1) % p;

@@ -301,3 +301,26 @@ def test_allele_masks_down_to_none(hmm, oracle, mask):
     got, gs = capi.run_align(hmm, "hipstr_hmm_", b.ptr, fill=-7.5)
     assert np.array_equal(gs, ws) and np.array_equal(got, want)
     assert np.all((got == -7.5).reshape(-1, 3)[:, [i for i, m in enumerate(mask) if not m]])
+
+
+def test_api_profile_buckets(hmm):
+    """hipstr_debug_api_profile: wall time and calls per entry point while switched on (what genotype_flow --profile prints)."""
+    import ctypes as C
+    hmm.hipstr_debug_api_profile.restype = C.c_int
+    hmm.hipstr_debug_api_profile.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    sb = capi.SynthBatch(n_loci=2, reads_per_locus=20, n_str_alleles=6, seed=8)
+    capi.run_align(hmm, "hipstr_hmm_", sb.ptr)
+    names = (C.c_char_p * 32)(); secs = (C.c_double * 32)(); calls = (C.c_int64 * 32)()
+    n = hmm.hipstr_debug_api_profile(1, 32, names, secs, calls)
+    assert 8 <= n <= 32 and all(calls[i] == 0 for i in range(n))
+    for _ in range(3):
+        capi.run_align(hmm, "hipstr_hmm_", sb.ptr)
+    hmm.hipstr_debug_api_profile(0, 32, names, secs, calls)
+    by = {names[i].decode(): (secs[i], calls[i]) for i in range(n)}
+    whole = by["hipstr_hmm_process_reads[_seeded]"]
+    assert whole[1] == 3 and whole[0] > 0
+    parts = sum(v[0] for k, v in by.items() if k.startswith("  ") and v[1] == 3 and "replay" not in k)
+    assert 0.5 * whole[0] < parts <= 1.05 * whole[0]          # the indented buckets are the parts of the entry point above them
+    capi.run_align(hmm, "hipstr_hmm_", sb.ptr)                # switched off: nothing is added
+    hmm.hipstr_debug_api_profile(-1, 32, names, secs, calls)
+    assert calls[0] == 3
