@@ -3,7 +3,7 @@
 # Prints, per kernel, its average duration and the average gap to the previous kernel's end within a call (from rocprofv3's kernel trace).
 R=$(pwd); O=$R/gpurun_out/lat; rm -rf $O; mkdir -p $O
 cat > $O/one.py <<'PY'
-import sys, time; sys.path.insert(0, sys.argv[1])
+import os, sys, time; sys.path.insert(0, sys.argv[1])
 import numpy as np
 from hipstr_amd import capi
 hmm = capi.load_hmm(); assert hmm.hipstr_hmm_init(0) == 0
@@ -19,6 +19,16 @@ else:      # one traceback call of a locus: 100 reads, each against its source a
     src = sb.src_allele(); rr = [r for r in range(sb.n_reads) if seeds[r] >= 0]; aa = [int(src[r]) for r in rr]
     h2r = capi.hap_aln_info(hmm, "hipstr_", sb.ptr, cap=1 << 22)
     call = lambda: capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, rr, aa, h2r, cap=1 << 20, unpack=False)
+if os.environ.get("LAT_BUSY"):      # keep the device busy (and its clocks up) from a second thread while the calls are timed
+    import threading, torch
+    stop = [False]
+    def spin():
+        a = torch.randn(4096, 4096, device="cuda"); s2 = torch.cuda.Stream()
+        with torch.cuda.stream(s2):
+            while not stop[0]:
+                for _ in range(20): a = (a @ a).clamp_(-1, 1)
+                s2.synchronize()
+    th = threading.Thread(target=spin, daemon=True); th.start(); time.sleep(1.0)
 for _ in range(5): call()
 ts = []
 for _ in range(40):
