@@ -552,7 +552,9 @@ def main():
                      "value_incl_prepare_pcie": total_aln / world / (t_upload + elapsed / args.steps + t_fetch) * world},
         }
         if args.gpus == 1 and not args.no_pipeline:
-            e2e = end_to_end(capi, hmm, sb, loci, max(2, min(args.steps, 5)), local)
+            # passes: as many as the resident measurement, but at least ~40 M alignments' worth — a stream that sees two or three small batches
+            # measures its own fill and drain, not its rate
+            e2e = end_to_end(capi, hmm, sb, loci, max(2, min(args.steps, 5), min(48, int(4e7 // max(1.0, float(n_aln.value))))), local)
             e2e["alignments_per_s"] = n_aln.value * e2e["passes"] / e2e["seconds"]
             e2e["fraction_of_resident_rate"] = e2e["alignments_per_s"] / value
             out["end_to_end"] = e2e
