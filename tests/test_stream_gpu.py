@@ -146,6 +146,37 @@ def test_submit_each_and_collect(hmm):
     st.close()
 
 
+def test_submit_each_large_call_with_a_bad_locus(hmm):
+    """A large hipstr_stream_submit_each call checks its loci on the host threads and appends them run by run; a locus prepare_batch
+    would refuse (here: a CIGAR character calc_seed_base does not know, HapAligner.cpp:309) stops the call there — the loci before it
+    are in and come back correct, in order; nothing after it was submitted."""
+    import util
+    from hipstr_amd import shard
+    sb = capi.SynthBatch(n_loci=700, reads_per_locus=4, n_str_alleles=3, seed=43)
+    want, wseeds = capi.run_align(hmm, "hipstr_hmm_", sb.ptr, fill=FILL)
+    a = dict(util.synth_to_batch(sb).arrays)
+    bad_locus = 417
+    ops = bytearray(a["cigar_op"]); ops[int(a["cigar_off"][int(a["read_off"][bad_locus]) + 1])] = ord("S"); a["cigar_op"] = bytes(ops)
+    bad = shard.batch_from_arrays(a)
+    n_reads, n_out, out_off = capi.batch_dims(bad.ptr)
+    st = capi.Stream(hmm, batch_alignments=2000)
+    with pytest.raises(RuntimeError):
+        st.submit_each(bad.ptr)
+    st.flush()
+    ro = a["read_off"]
+    probs = np.full(int(out_off[bad_locus]), FILL); seeds = np.full(int(ro[bad_locus]), -7, np.int32)
+    assert st.collect(bad_locus, probs, seeds) == (int(out_off[bad_locus]), int(ro[bad_locus]))
+    assert np.array_equal(probs, want[:out_off[bad_locus]]) and np.array_equal(seeds, wseeds[:ro[bad_locus]])
+    assert st.next() is None
+    # the whole shard, valid: one call, every locus its own ticket
+    assert st.submit_each(sb.ptr) == bad_locus
+    st.flush()
+    probs = np.full(sb.n_out, FILL); seeds = np.full(sb.n_reads, -7, np.int32)
+    assert st.collect(700, probs, seeds) == (sb.n_out, sb.n_reads)
+    assert np.array_equal(probs, want) and np.array_equal(seeds, wseeds)
+    st.close()
+
+
 def _multi_sigs(lib):
     import ctypes as C
     lib.hipstr_multi_open.restype = C.c_void_p; lib.hipstr_multi_open.argtypes = [C.c_int32, capi._i32p, C.c_int64, C.c_void_p]
