@@ -144,6 +144,33 @@ def test_north_star_batch_full_size(hmm, oracle):
         assert np.array_equal(want, got[lo:hi]) and np.array_equal(ws, s1), "locus %d differs from the oracle" % l
 
 
+def test_config5_stress_batch_full_size(hmm, oracle):
+    """The whole BASELINE configs[4] stress batch as bench.py --workload c5 runs it — 256 loci x 200 reads of 250 bp x 128 alleles,
+    ~100-bp blocks, 110-bp flanks (two rounds of four 15-row bands per sweep), 5.8 M alignments in one call: all finite and <= 0, a
+    second run identical, three loci spread over the batch identical when re-run ALONE, and two of them bit-equal to the oracle."""
+    NL, P, A, kw = 256, 200, 128, dict(read_len=250, flank_len=110, str_bp=100)
+    big = capi.SynthBatch(n_loci=NL, reads_per_locus=P, n_str_alleles=A, seed=20260928, **kw)
+    dev = hmm.hipstr_hmm_upload(big.ptr); assert dev, hmm.hipstr_last_error()
+    runs = []
+    for _ in range(2):
+        assert hmm.hipstr_hmm_align(dev, None) == 0
+        p = np.zeros(big.n_out); s = np.zeros(big.n_reads, np.int32)
+        assert hmm.hipstr_hmm_fetch(dev, p.ctypes.data_as(capi._f64p), s.ctypes.data_as(capi._i32p)) == 0
+        runs.append((p, s))
+    hmm.hipstr_hmm_free(dev)
+    got, seeds = runs[0]
+    assert np.array_equal(got, runs[1][0]) and np.array_equal(seeds, runs[1][1])
+    assert np.all(np.isfinite(got)) and np.all(got <= 1e-10)
+    for n, l in enumerate((5, 130, 251)):
+        one = capi.SynthBatch(n_loci=1, reads_per_locus=P, n_str_alleles=A, seed=20260928, first_locus=l, **kw)
+        lo, hi = int(big.out_off[l]), int(big.out_off[l + 1])
+        alone, s1 = capi.run_align(hmm, "hipstr_hmm_", one.ptr)
+        assert np.array_equal(alone, got[lo:hi]) and np.array_equal(s1, seeds[l * P:(l + 1) * P]), "locus %d depends on its batch" % l
+        if n < 2:
+            want, ws = capi.run_align(oracle, "oracle_", one.ptr)
+            assert np.array_equal(want, got[lo:hi]) and np.array_equal(ws, s1), "locus %d differs from the oracle" % l
+
+
 def test_dropin_adapter_against_reference_objects(hmm):
     """integration/HapAlignerMI355X — HapAligner's interface on the reference's own Haplotype/Alignment objects — next to
     the reference's CPU HapAligner in one process (oracle/_ref/dropin_check, prebuilt where the HipSTR tree is mounted)."""
