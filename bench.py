@@ -237,7 +237,7 @@ def end_to_end(capi, hmm, sb, loci, steps, device, latency=True):
                 except RuntimeError:
                     time.sleep(0.0002)
         th.join()
-    one_pass_set(int(os.environ.get("HIPSTR_BENCH_E2E_WARMUP", "1")))      # warm-up: block caches, kernels
+    one_pass_set(int(os.environ.get("HIPSTR_BENCH_E2E_WARMUP", "4")))      # warm-up: block caches, kernels
     s0 = st.stats()
     t0 = time.perf_counter()
     one_pass_set(steps)
