@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 #include <string.h>
 
 namespace hipstr {
@@ -36,18 +37,18 @@ void  pin_free(Ctx* ctx, void* p);
 // has been synchronised by its user.
 struct HostArena {
   struct Piece { const void* src; size_t bytes, off; };
-  Piece pieces[12]; int n_pieces = 0; size_t total = 0;
+  std::vector<Piece> pieces; size_t total = 0;
   Ctx* ctx = NULL; char* pin = NULL; char* dev = NULL;
   ~HostArena(){ if (ctx){ if (pin) pin_free(ctx, pin); if (dev) dev_free(ctx, dev); } }
   size_t add(const void* src, size_t bytes){
-    const size_t off = total; if (n_pieces < 12) pieces[n_pieces++] = Piece{src, bytes, off}; total = (total + (bytes ? bytes : 1) + 255) & ~(size_t)255; return off;
+    const size_t off = total; pieces.push_back(Piece{src, bytes, off}); total = (total + (bytes ? bytes : 1) + 255) & ~(size_t)255; return off;
   }
   int reserve(Ctx* c){        // blocks only (the caller still has pointers into `dev` to fill in before the pieces are packed)
     ctx = c; pin = (char*)pin_alloc(ctx, total ? total : 256); dev = (char*)dev_alloc(ctx, total ? total : 256);
     return (pin && dev) ? 0 : 1;
   }
   int send(hipStream_t st){   // pack and copy
-    for (int i = 0; i < n_pieces; i++) if (pieces[i].bytes && pieces[i].src) memcpy(pin + pieces[i].off, pieces[i].src, pieces[i].bytes);
+    for (const Piece& pc : pieces) if (pc.bytes && pc.src) memcpy(pin + pc.off, pc.src, pc.bytes);
     return (total && hipMemcpyAsync(dev, pin, total, hipMemcpyHostToDevice, st) != hipSuccess) ? api_fail("hipMemcpyAsync (host to device) failed") : 0;
   }
   template <typename T> T* at(size_t off) const { return (T*)(dev + off); }

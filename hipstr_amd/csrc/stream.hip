@@ -110,6 +110,8 @@ struct OwnedBatch {
     const int32_t s0 = b->opt_off[opt0[l0]], s1 = b->opt_off[opt0[l1]], b0 = b->base_off[r0], b1 = b->base_off[r1], c0 = b->cigar_off[r0], c1 = b->cigar_off[r1];
     if (r1 < r0 || h1 < h0 + n) return "inconsistent read_off / hap_off";
     if ((int64_t)bases.size() + (b1 - b0) > INT32_MAX || (int64_t)seq.size() + (s1 - s0) > INT32_MAX) return "pending batch exceeds 2 GiB of bases";
+    for (int l = l0; l < l1; l++)                       // (nothing is appended unless everything can be)
+      if (b->read_off[l+1] < b->read_off[l] || b->hap_off[l+1] - b->hap_off[l] < 1) return "inconsistent read_off / hap_off";
     const int32_t loc_base = (int32_t)period.size();
     blk_start.insert(blk_start.end(), b->blk_start + 3*l0, b->blk_start + 3*l1); blk_end.insert(blk_end.end(), b->blk_end + 3*l0, b->blk_end + 3*l1);
     blk_nopts.insert(blk_nopts.end(), b->blk_nopts + 3*l0, b->blk_nopts + 3*l1); period.insert(period.end(), b->period + l0, b->period + l1);
@@ -120,7 +122,6 @@ struct OwnedBatch {
     const int32_t hap0 = hap_off.back() - h0, rd0 = read_off.back() - r0;
     for (int l = l0; l < l1; l++){
       const int64_t P = b->read_off[l+1] - b->read_off[l], A = b->hap_off[l+1] - b->hap_off[l];
-      if (P < 0 || A < 1) return "inconsistent read_off / hap_off";
       Ticket t; t.id = ticket0 + (l - l0); t.l0 = loc_base + (l - l0); t.l1 = t.l0 + 1; t.r0 = rd0 + b->read_off[l]; t.r1 = t.r0 + (int32_t)P; t.out0 = n_out;
       n_out += P*A; work += P*A; t.out1 = n_out;
       tickets.push_back(t);

@@ -551,28 +551,6 @@ struct DevBufs {
   }
 };
 
-// Host arrays that travel together: packed into ONE pinned block and sent with ONE asynchronous copy (a synchronous hipMemcpy from
-// pageable memory costs 10-20 us each, and a traceback call of a locus had ten of them).  add() returns the piece's offset; after
-// send() the piece sits at dev + offset.  The pinned block is released when the arena goes out of scope (after the stream was synchronised).
-struct Arena {
-  struct Piece { const void* src; size_t bytes, off; };
-  std::vector<Piece> pieces; size_t total = 0;
-  hipstr::Ctx* ctx = NULL; char* pin = NULL; char* dev = NULL;
-  ~Arena(){ if (ctx){ if (pin) hipstr::pin_free(ctx, pin); if (dev) hipstr::dev_free(ctx, dev); } }
-  size_t add(const void* src, size_t bytes){
-    const size_t off = total; pieces.push_back(Piece{src, bytes, off}); total = (total + (bytes ? bytes : 1) + 255) & ~(size_t)255; return off;
-  }
-  int send(hipstr::Ctx* c, hipStream_t st){
-    ctx = c;
-    pin = (char*)hipstr::pin_alloc(ctx, total ? total : 256); dev = (char*)hipstr::dev_alloc(ctx, total ? total : 256);
-    if (!pin || !dev) return 1;
-    for (const Piece& pc : pieces) if (pc.bytes) memcpy(pin + pc.off, pc.src, pc.bytes);
-    if (total) TR_HIP(hipMemcpyAsync(dev, pin, total, hipMemcpyHostToDevice, st));
-    return 0;
-  }
-  template <typename T> T* at(size_t off) const { return (T*)(dev + off); }
-};
-
 // two side streams + their events per (host thread, device), created at first use and kept
 struct SideStreams { hipStream_t st[2] = {NULL, NULL}; hipEvent_t ev_up = NULL, ev_done[2] = {NULL, NULL}; bool used[2] = {false, false}; bool ok = false; };
 static SideStreams* side_streams(int device){
@@ -799,12 +777,13 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
   DevBufs dev;
   hs_tdev_t h; memset(&h, 0, sizeof h);
   const int total_bases = b->base_off[n_reads];
-  Arena st_arena;
+  hipstr::HostArena st_arena;                     // every table of the call: one pinned block, one copy
   {
     const size_t o_rows = st_arena.add(rows.data(), rows.size()*sizeof(hs_row_t)), o_so = st_arena.add(P.stropts.data(), P.stropts.size()*sizeof(hs_stropt_t)),
                  o_vis = st_arena.add(P.visits.data(), P.visits.size()*sizeof(hs_visit_t)), o_f64 = st_arena.add(P.f64pool.data(), P.f64pool.size()*sizeof(double)),
                  o_chars = st_arena.add(P.chars.data(), P.chars.size()), o_bases = st_arena.add(b->bases, (size_t)total_bases), o_quals = st_arena.add(b->quals, (size_t)total_bases);
-    if (st_arena.send(T.ctx, T.stream)) return api_fail("out of device or pinned host memory");
+    if (st_arena.reserve(T.ctx)) return api_fail("out of device or pinned host memory");
+    if (st_arena.send(T.stream)) return 1;
     h.rows = st_arena.at<hs_row_t>(o_rows); h.stropts = st_arena.at<hs_stropt_t>(o_so); h.visits = st_arena.at<hs_visit_t>(o_vis);
     h.f64pool = st_arena.at<double>(o_f64); h.chars = st_arena.at<char>(o_chars); h.bases = st_arena.at<char>(o_bases); h.quals = st_arena.at<char>(o_quals);
   }
@@ -896,18 +875,14 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
       for (int si = 2*q0; si < 2*q1; si++) if ((sides[si].n + 63)/64 == cl) items.push_back(si - 2*q0);
     }
     cls_begin[HS_MAX_COLS] = items.size();
-    Arena ch_arena;                                 // this chunk's sides, launch order and argument block
+    hipstr::HostArena ch_arena;                     // this chunk's sides, launch order and argument block
     hs_tdev_t hcc = hc;
     const size_t o_sides = ch_arena.add(sides.data() + 2*q0, 2*(size_t)nq*sizeof(hs_tside_t)), o_items = ch_arena.add(items.data(), items.size()*sizeof(int32_t)),
                  o_args = ch_arena.add(&hcc, sizeof hcc);
-    {   // the argument block points into the arena it travels in: sizes first, then the pointers, then the copy
-      ch_arena.ctx = T.ctx;
-      ch_arena.pin = (char*)hipstr::pin_alloc(T.ctx, ch_arena.total); ch_arena.dev = (char*)hipstr::dev_alloc(T.ctx, ch_arena.total);
-      if (!ch_arena.pin || !ch_arena.dev) return api_fail("out of device or pinned host memory");
-      hcc.sides = ch_arena.at<hs_tside_t>(o_sides); hcc.items = ch_arena.at<int32_t>(o_items);
-      for (const Arena::Piece& pc : ch_arena.pieces) if (pc.bytes) memcpy(ch_arena.pin + pc.off, pc.src, pc.bytes);
-      TR_HIP(hipMemcpyAsync(ch_arena.dev, ch_arena.pin, ch_arena.total, hipMemcpyHostToDevice, T.stream));
-    }
+    // (the argument block points into the arena it travels in: sizes first, then the pointers, then the copy)
+    if (ch_arena.reserve(T.ctx)) return api_fail("out of device or pinned host memory");
+    hcc.sides = ch_arena.at<hs_tside_t>(o_sides); hcc.items = ch_arena.at<int32_t>(o_items);
+    if (ch_arena.send(T.stream)) return 1;
     const hs_tdev_t* d_args = ch_arena.at<hs_tdev_t>(o_args);
     const auto c1 = now();
     // The fill kernels of the column classes are independent of each other and, for the requests of one locus, a hundred wavefronts
