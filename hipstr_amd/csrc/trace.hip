@@ -1008,16 +1008,13 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
         }
       }
     };
-    // the replay is ~1.7 us of string work per request: worth sharing from a few hundred requests on (a thread costs ~30 us to start;
-    // measured on a loaded 16-core box: 500 requests 0.85 ms on one thread, 0.68 ms on seven)
-    int nthreads = std::max(1, std::min(hipstr::host_threads(), nq / 128));
+    // the replay is ~1.7 us of string work per request; the host threads are a persistent pool (a few microseconds to wake), so a
+    // locus' hundred requests are already worth sharing: blocks of 24 requests
+    int nthreads = std::max(1, std::min(hipstr::host_threads(), nq / 24));
     if (const char* e = getenv("HIPSTR_TRACE_THREADS")) nthreads = std::max(1, std::min(atoi(e), std::max(1, nq / 16)));
     auto run_parallel = [&](const std::function<void(int,int)>& fn){
       if (nthreads <= 1){ fn(q0, q1); return; }
-      std::vector<std::thread> pool;
-      for (int t = 0; t < nthreads; t++)
-        pool.push_back(std::thread(fn, q0 + (int)((int64_t)nq*t/nthreads), q0 + (int)((int64_t)nq*(t+1)/nthreads)));
-      for (std::thread& th : pool) th.join();
+      hipstr::parallel_for(nthreads, nthreads, [&](int t){ fn(q0 + (int)((int64_t)nq*t/nthreads), q0 + (int)((int64_t)nq*(t+1)/nthreads)); });
     };
     const auto r0t = now();
     run_parallel(work);
