@@ -283,17 +283,31 @@ std::vector<hs_row_t> flank_rows(const SideSeqs& h, int bi, int u0){
   return rows;
 }
 
-std::vector<int> upstream_runs(const std::string& s, int shift){   // StutterAlignerClass.h:35-42
-  std::vector<int> m(s.size(), 0);
-  for (int i = shift; i < (int)s.size(); i++) m[i] = (s[i-shift] != s[i]) ? 0 : 1 + m[i-1];
-  return m;
-}
-
 inline hs_visit_t visit(int ni, int U, char ca, char cb, bool plain, double logU){
   hs_visit_t v;
   v.meta = (uint64_t)(uint16_t)ni | ((uint64_t)(uint16_t)U << 16) | ((uint64_t)(uint8_t)ca << 32) | ((uint64_t)(uint8_t)cb << 40) | ((uint64_t)(plain ? 1 : 0) << 48);
   v.logU = logU;
   return v;
+}
+
+// Scratch of the host preparation, one per host thread: the per-locus path allocates nothing once these have grown.
+struct Scratch {
+  std::vector<int> up;                  // StutterAlignerClass's upstream-match run table of one shift (h:35-42)
+  std::vector<hs_visit_t> vis;          // the visiting lists of the STR option being built
+  std::vector<char> rev;                // reversed block sequences of the locus being prepared
+  std::vector<int> lrun, rrun;          // HapBlock run lengths of the three blocks of one haplotype orientation
+  std::vector<hs_row_t> rows;           // rows of one flank block before they are interned
+};
+static Scratch& scratch(){ thread_local Scratch s; return s; }
+
+// StutterAlignerClass.h:35-42 for one shift, into the thread's scratch
+static const int* upstream_runs(const char* s, int n, int shift){
+  std::vector<int>& m = scratch().up;
+  if ((int)m.size() < n) m.resize(n);
+  int* p = m.data();
+  for (int i = 0; i < shift && i < n; i++) p[i] = 0;
+  for (int i = shift; i < n; i++) p[i] = (s[i-shift] != s[i]) ? 0 : 1 + p[i-1];
+  return p;
 }
 
 // One STR option in one orientation -> hs_stropt_t (+ its pools)
@@ -320,7 +334,7 @@ static float h_fasterlog(float x){
 // of the constants, off by at most the rounding errors of the sums: |err| <= 2^-52 (|lp0| + 3A).  If every such difference
 // keeps its float rounding and its side of LOG_THRESH under an error of 2^-50 (|lp0| + A + 1), the sum of exponentials and
 // hence G = fasterlog(sum) do not depend on lp0.  Bnd is the largest |lp0| for which that is guaranteed.
-static void simple_table_entry(int lim, int U0, int tail, double ent[3]){
+static void simple_table_entry_compute(int lim, int U0, int tail, double ent[3]){
   const HostTables& T = host_tables();
   const bool skip = (U0 > 0) && (lim > 0);
   const int nplain = std::max(0, lim - U0);
@@ -347,60 +361,125 @@ static void simple_table_entry(int lim, int U0, int tail, double ent[3]){
   ent[2] = (delta >= 1e300) ? 1e300 : std::max(0.0, delta * 1125899906842624.0 /* 2^50 */ - amax - 1.0);
   if (ent[2] < 1e300) ent[2] *= g_bnd_scale.load();      // tests: shrink the guarantee (HIPSTR_DEBUG_BND_SCALE)
 }
+// The entries are functions of three small integers and the same ones come back for every allele of every locus (a periodic block's lists
+// have U0 = tail or tail - period): a direct-mapped memo per host thread turns the ~50 float steps of an entry into one probe.
+static void simple_table_entry(int lim, int U0, int tail, double ent[3]){
+  if ((unsigned)lim >= 4096u || (unsigned)U0 >= 4096u || (unsigned)tail >= 4096u || g_bnd_scale.load(std::memory_order_relaxed) != 1.0){
+    simple_table_entry_compute(lim, U0, tail, ent); return;
+  }
+  struct Slot { uint64_t key; double v[3]; };
+  thread_local std::vector<Slot> memo(8192, Slot{0, {0, 0, 0}});
+  const uint64_t key = (uint64_t)lim | ((uint64_t)U0 << 12) | ((uint64_t)tail << 24) | ((uint64_t)1 << 40);
+  Slot& s = memo[(size_t)((key * 0x9E3779B97F4A7C15ull) >> 51)];      // 13 bits
+  if (s.key != key){ simple_table_entry_compute(lim, U0, tail, s.v); s.key = key; }
+  ent[0] = s.v[0]; ent[1] = s.v[1]; ent[2] = s.v[2];
+}
+
+// The 13 values of StutterModel::log_stutter_pmf (stutter_model.cpp:29-53) an STR option needs — artifact sizes of -6..+6 repeat units, all
+// in frame — depend on the stutter model alone, not on the block: computed once per locus (eight logarithms per value otherwise).
+static void stutter_pmf13(const double* sp, int period, double pmf[HS_NART]){
+  for (int t = 0; t < HS_NART; t++) pmf[t] = log_stutter_pmf(sp, period, 0, (t - HS_MAXREP)*period);
+}
 
 static std::atomic<uint64_t> g_so_cycles[6];
 static const bool g_so_on = getenv("HIPSTR_PREP_PROFILE") != NULL;
 #define HS_SOLAP(k) do { if (g_so_on){ const uint64_t now_ = __builtin_ia32_rdtsc(); g_so_cycles[k] += now_ - so_t; so_t = now_; } } while (0)
-void emit_stropt(const std::string& blk, int period, const double* stutter, Prepared& out, bool forward_only = false){
+void emit_stropt(const char* blk, const int B, int period, const double pmf13[HS_NART], Prepared& out, bool forward_only = false){
   uint64_t so_t = g_so_on ? __builtin_ia32_rdtsc() : 0;
   const HostTables& T = host_tables();
-  const int B = blk.size();
   hs_stropt_t so; memset(&so, 0, sizeof so);
   so.seq_off = out.chars.size();
-  out.chars.insert(out.chars.end(), blk.begin(), blk.end());
+  out.chars.insert(out.chars.end(), blk, blk + B);
   while (out.chars.size() % 4) out.chars.push_back(0);
   so.B = B; so.period = period;
   int nd = HIPSTR_MAX_STUTTER_REPS;
   while (nd*period > B) nd--;
   so.nd = nd;
-  {
-    int per_len = 0;                                       // leading run (from the right end) on which the block repeats with the period
-    while (per_len < B && blk[B-1-per_len] == blk[B-1-(per_len % period)]) per_len++;
-    so.nd_eq = std::min(nd, per_len / period);
-  }
+  int per_len = 0;                                         // leading run (from the right end) on which the block repeats with the period
+  while (per_len < B && blk[B-1-per_len] == blk[B-1-(per_len % period)]) per_len++;
+  so.nd_eq = std::min(nd, per_len / period);
   for (int r = 0; r < 16 && r < B; r++) so.tail_codes |= (int32_t)(((uint32_t)(uint8_t)blk[B-1-r] >> 1) & 3u) << (2*r);
   so.f64_off = out.f64pool.size();
-  for (int t = 0; t < HS_NART; t++){
-    const int art = (t - HS_MAXREP)*period;
-    out.f64pool.push_back(B+art < 0 ? LARGE_NEGATIVE : log_stutter_pmf(stutter, period, B, B+art));
-  }
-  out.f64pool.push_back(-T.int_log[B+1]);                                   // StutterAlignerClass.cpp:64
-  for (int q = 0; q < HS_MAXREP; q++){
-    const int D = -(q+1)*period;
-    out.f64pool.push_back(B+D >= 0 ? -T.int_log[B+D+1] : 0.0);              // StutterAlignerClass.cpp:112
+  {
+    out.f64pool.resize(so.f64_off + HS_NART + 1 + HS_MAXREP);
+    double* c = out.f64pool.data() + so.f64_off;
+    for (int t = 0; t < HS_NART; t++) c[t] = (B + (t - HS_MAXREP)*period < 0) ? LARGE_NEGATIVE : pmf13[t];
+    c[HS_NART] = -T.int_log[B+1];                                             // StutterAlignerClass.cpp:64
+    for (int q = 0; q < HS_MAXREP; q++){
+      const int D = -(q+1)*period;
+      c[HS_NART + 1 + q] = B+D >= 0 ? -T.int_log[B+D+1] : 0.0;                // StutterAlignerClass.cpp:112
+    }
   }
   HS_SOLAP(0);
   const size_t visits_begin = out.visits.size();
+  if (per_len == B){
+    // The whole block repeats with the period (nearly every candidate allele): the run tables are up_s[i] = i - s + 1 for every shift s
+    // that is a multiple of the period, so the loops of StutterAlignerClass.cpp:74-96 / 123-142 visit
+    //   insertions:  one run of B - period positions, then the period plain ones, then the end   -> simple list, U0 = B - period
+    //                (a block of at most one unit: plain positions only, U0 = 0)
+    //   deletions of (q+1) units: one run over the whole remainder, then the end                 -> simple list, U0 = remainder
+    // — what the general code below finds by building the seven tables and lists; here it is written down (tests/test_prep.py and the
+    // digests of tests/golden/prep_digests.json hold the two to the same bytes).  No list is kept: every shape has a closed form.
+    so.ins_off = (int32_t)visits_begin; so.ins_len = 0;
+    so.shape[HS_MAXREP] = period < B ? B - period : 0;
+    for (int q = 0; q < HS_MAXREP; q++){
+      const int tail = B - (q+1)*period;
+      so.del_off[q] = (int32_t)visits_begin; so.del_len[q] = 0;
+      so.shape[q] = tail >= 0 ? tail : -1;
+    }
+    HS_SOLAP(1);
+    so.tab_off = out.f64pool.size(); so.tab_len = 0;
+    bool ok = (B >= period);
+    for (int i = 0; i < B; i++){ const char c = blk[i]; ok &= (c == 'A' || c == 'C' || c == 'G' || c == 'T'); }
+    if (ok){
+      int total = 0;
+      for (int k = 0; k <= HS_MAXREP; k++){
+        const int tail = (k == HS_MAXREP) ? B : B - (k+1)*period;
+        so.tab_base[k] = total;
+        if (tail >= 0) total += 2 + (tail - so.shape[k]);
+      }
+      so.kind = 1;                      // (total <= 12 + 2 + 9 entries: always within HS_TAB_CAP)
+      out.f64pool.resize((size_t)so.tab_off + 3*(size_t)total + 1);
+      double* ent = out.f64pool.data() + so.tab_off;
+      double bmin = 1e300;
+      for (int k = 0; k <= HS_MAXREP; k++){
+        const int tail = (k == HS_MAXREP) ? B : B - (k+1)*period;
+        if (tail < 0) continue;
+        const int U0 = so.shape[k], n = 2 + (tail - U0);
+        for (int e = 0; e < n; e++, ent += 3){
+          simple_table_entry((e == 0) ? 0 : (e == 1 ? 1 : U0 + e - 1), U0, tail, ent);
+          bmin = std::min(bmin, ent[2]);
+        }
+      }
+      so.tab_len = total;
+      *ent = bmin;
+    }
+    out.stropts.push_back(so);
+    HS_SOLAP(4);
+    return;
+  }
+  std::vector<hs_visit_t>& V = scratch().vis;             // the option's lists; they go to the visit pool only if the kernels will read them
+  V.clear();
   // insertion visiting list (StutterAlignerClass.cpp:74-96); uses the shift-`period` run table
   {
-    const std::vector<int> up = upstream_runs(blk, period);
-    so.ins_off = out.visits.size();
+    const int* up = upstream_runs(blk, B, period);
+    so.ins_off = (int32_t)(visits_begin + V.size());
     int i = 0;
     for (;;){
       const int ni = -i;
-      if (ni >= B){ out.visits.push_back(visit(ni, 0, 0, 0, true, 0)); break; }
+      if (ni >= B){ V.push_back(visit(ni, 0, 0, 0, true, 0)); break; }
       if (-i + period < B){
         const int U = up[B-1+i];
-        if (U == 0){ out.visits.push_back(visit(ni, 0, blk[B-1+i], blk[B-1+i-period], false, 0)); i -= 1; }
-        else       { out.visits.push_back(visit(ni, U, 0, 0, false, T.int_log[U])); i -= U; }
-      } else { out.visits.push_back(visit(ni, 0, 0, 0, true, 0)); i -= 1; }
+        if (U == 0){ V.push_back(visit(ni, 0, blk[B-1+i], blk[B-1+i-period], false, 0)); i -= 1; }
+        else       { V.push_back(visit(ni, U, 0, 0, false, T.int_log[U])); i -= U; }
+      } else { V.push_back(visit(ni, 0, 0, 0, true, 0)); i -= 1; }
     }
-    so.ins_len = out.visits.size() - so.ins_off;
+    so.ins_len = (int32_t)(visits_begin + V.size()) - so.ins_off;
   }
   auto classify = [&](int off, int len, int limmax) -> int {
     // simple: [optional entry (ni=0, U>0)] then plain entries at consecutive offsets up to the terminal at limmax
     int v = 0, next = 0, U0 = 0;
-    const hs_visit_t* L = out.visits.data() + off;
+    const hs_visit_t* L = V.data() + (off - (int)visits_begin);
     auto ni_of = [](const hs_visit_t& e){ return (int)(e.meta & 0xffff); };
     auto U_of  = [](const hs_visit_t& e){ return (int)((e.meta >> 16) & 0xffff); };
     auto plain = [](const hs_visit_t& e){ return ((e.meta >> 48) & 1) != 0; };
@@ -423,7 +502,7 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
     auto bits = [](double v){ uint64_t u; memcpy(&u, &v, 8); return u; };
     for (int i = 0; i < HS_PW_SLOTS; i++) slot[i] = 0;
     slot[0] = pack(-1, 0);
-    const hs_visit_t* E = out.visits.data() + off;
+    const hs_visit_t* E = V.data() + (off - (int)visits_begin);
     auto ni_of = [](const hs_visit_t& e){ return (int)(e.meta & 0xffff); };
     auto U_of  = [](const hs_visit_t& e){ return (int)((e.meta >> 16) & 0xffff); };
     auto plain = [](const hs_visit_t& e){ return ((e.meta >> 48) & 1) != 0; };
@@ -451,25 +530,25 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
     return true;
   };
   uint64_t pw[HS_MAXREP + 1][HS_PW_SLOTS];
-  for (int k = 0; k <= HS_MAXREP; k++) piecewise(0, 0, 0, pw[k]);          // "not piecewise"
+  for (int k = 0; k <= HS_MAXREP; k++){ for (int i = 0; i < HS_PW_SLOTS; i++) pw[k][i] = 0; pw[k][0] = (uint64_t)(uint32_t)-1; }   // "not piecewise"
   so.shape[HS_MAXREP] = classify(so.ins_off, so.ins_len, B);
   if (so.shape[HS_MAXREP] < 0 && piecewise(so.ins_off, so.ins_len, B, pw[HS_MAXREP])) so.shape[HS_MAXREP] = HS_SHAPE_PIECEWISE;
   HS_SOLAP(1);
   // deletion visiting lists (StutterAlignerClass.cpp:123-142); one per deletion size, shift = |D|
   for (int q = 0; q < HS_MAXREP; q++){
     const int D = -(q+1)*period;
-    so.del_off[q] = out.visits.size();
+    so.del_off[q] = (int32_t)(visits_begin + V.size());
     if (B+D < 0){ so.del_len[q] = 0; so.shape[q] = -1; continue; }
-    const std::vector<int> up = upstream_runs(blk, -D);
+    const int* up = upstream_runs(blk, B, -D);
     int i = 0;
     for (;;){
       const int ni = -i;
-      if (ni >= B+D){ out.visits.push_back(visit(ni, 0, 0, 0, true, 0)); break; }
+      if (ni >= B+D){ V.push_back(visit(ni, 0, 0, 0, true, 0)); break; }
       const int U = up[B-1+i];
-      if (U == 0){ out.visits.push_back(visit(ni, 0, blk[B-1+i+D], blk[B-1+i], false, 0)); i -= 1; }
-      else       { out.visits.push_back(visit(ni, U, 0, 0, false, T.int_log[U])); i -= U; }
+      if (U == 0){ V.push_back(visit(ni, 0, blk[B-1+i+D], blk[B-1+i], false, 0)); i -= 1; }
+      else       { V.push_back(visit(ni, U, 0, 0, false, T.int_log[U])); i -= U; }
     }
-    so.del_len[q] = out.visits.size() - so.del_off[q];
+    so.del_len[q] = (int32_t)(visits_begin + V.size()) - so.del_off[q];
     so.shape[q] = classify(so.del_off[q], so.del_len[q], B+D);
     if (so.shape[q] < 0 && piecewise(so.del_off[q], so.del_len[q], B+D, pw[q])) so.shape[q] = HS_SHAPE_PIECEWISE;
   }
@@ -483,8 +562,8 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
       const int tail = (k == HS_MAXREP) ? B : B - (k+1)*period;
       any_generic |= (tail >= 0 && (so.shape[k] == -1 || (!forward_only && so.shape[k] < 0)));
     }
-    if (!any_generic){
-      out.visits.resize(visits_begin);
+    if (any_generic) out.visits.insert(out.visits.end(), V.begin(), V.end());
+    else {
       so.ins_off = (int32_t)visits_begin; so.ins_len = 0;
       for (int q = 0; q < HS_MAXREP; q++){ so.del_off[q] = (int32_t)visits_begin; so.del_len[q] = 0; }
     }
@@ -493,16 +572,18 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
   // nearly all of them — do not need
   bool any_pw = false;
   for (int k = 0; k <= HS_MAXREP; k++) any_pw |= (so.shape[k] == HS_SHAPE_PIECEWISE);
-  if (any_pw)
-    for (int k = 0; k <= HS_MAXREP; k++)
-      for (int i = 0; i < HS_PW_SLOTS; i++){ double v; memcpy(&v, &pw[k][i], 8); out.f64pool.push_back(v); }
+  if (any_pw){
+    const size_t at = out.f64pool.size();
+    out.f64pool.resize(at + (HS_MAXREP + 1)*HS_PW_SLOTS);
+    memcpy(out.f64pool.data() + at, pw, sizeof pw);
+  }
   HS_SOLAP(3);
   // tabulated closed form: only when every list the kernel can evaluate is simple and the entries fit the LDS budget
   so.tab_off = out.f64pool.size(); so.tab_len = 0;
   {
     static const bool no_pw_group = getenv("HIPSTR_STR_GROUP_PW") && atoi(getenv("HIPSTR_STR_GROUP_PW")) == 0;     // comparison runs: piecewise lists stay with hs_str_kernel_generic
     bool ok = true; int total = 0;
-    for (char c : blk) ok &= (c == 'A' || c == 'C' || c == 'G' || c == 'T');      // hs_str_group_kernel looks emissions up by base code
+    for (int i = 0; i < B; i++){ const char c = blk[i]; ok &= (c == 'A' || c == 'C' || c == 'G' || c == 'T'); }      // hs_str_group_kernel looks emissions up by base code
     ok &= (B >= period);                                                          // ... and lets ins_probs_ cycle through block bases only
     for (int k = 0; k <= HS_MAXREP && ok; k++){
       const int tail = (k == HS_MAXREP) ? B : B - (k+1)*period;
@@ -514,21 +595,21 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
     }
     if (ok && total <= HS_TAB_CAP){
       so.kind = any_pw ? 2 : 1;
+      out.f64pool.resize((size_t)so.tab_off + 3*(size_t)total + 1);
+      double* ent = out.f64pool.data() + so.tab_off;
+      double bmin = 1e300;                              // what the kernel compares |lp0| with: the weakest guarantee of the table
       for (int k = 0; k <= HS_MAXREP; k++){
         const int tail = (k == HS_MAXREP) ? B : B - (k+1)*period;
         if (tail < 0 || so.shape[k] < 0) continue;
         const int U0 = so.shape[k], n = 2 + std::max(0, tail - U0);
-        for (int e = 0; e < n; e++){
+        for (int e = 0; e < n; e++, ent += 3){
           const int lim = (e == 0) ? 0 : (e == 1 ? 1 : U0 + e - 1);      // a bound that maps to entry e (entry 1 is unused when U0 = 0)
-          double ent[3];
           simple_table_entry(lim, U0, tail, ent);
-          out.f64pool.insert(out.f64pool.end(), ent, ent + 3);
+          bmin = std::min(bmin, ent[2]);
         }
       }
       so.tab_len = total;
-      double bmin = 1e300;                              // what the kernel compares |lp0| with: the weakest guarantee of the table
-      for (int e = 0; e < total; e++) bmin = std::min(bmin, out.f64pool[so.tab_off + 3*e + 2]);
-      out.f64pool.push_back(bmin);
+      *ent = bmin;
     }
   }
   out.stropts.push_back(so);
@@ -541,16 +622,18 @@ void emit_stropt(const std::string& blk, int period, const double* stutter, Prep
 // a palindromic motif, neighbouring loci of a panel with the same motif.  A per-thread cache keyed by the three holds the option
 // record with its pool slices relative to their start; a hit appends copies (about 2 KB) instead of rebuilding them.
 struct StroptCached { hs_stropt_t so; std::vector<hs_visit_t> visits; std::vector<double> f64; std::vector<char> chars; };
-void emit_stropt_cached(const std::string& blk, int period, const double* stutter, Prepared& out){
-  static const bool off = getenv("HIPSTR_STROPT_CACHE") && atoi(getenv("HIPSTR_STROPT_CACHE")) == 0;
-  if (off || g_bnd_scale.load() != 1.0){ emit_stropt(blk, period, stutter, out, true); return; }
+void emit_stropt_cached(const char* blk, int B, int period, const double* stutter, const double pmf13[HS_NART], Prepared& out){
+  // (off by default since round 4: building an option now costs about what a hit did — a hash of ~100 bytes and 2 KB of copies;
+  //  HIPSTR_STROPT_CACHE=1 turns it back on for comparison)
+  static const bool on = getenv("HIPSTR_STROPT_CACHE") && atoi(getenv("HIPSTR_STROPT_CACHE")) != 0;
+  if (!on || g_bnd_scale.load() != 1.0){ emit_stropt(blk, B, period, pmf13, out, true); return; }
   thread_local std::unordered_map<std::string, StroptCached> cache;
   thread_local std::string key;
-  key.assign((const char*)stutter, 6*sizeof(double)); key.push_back((char)period); key.append(blk);
+  key.assign((const char*)stutter, 6*sizeof(double)); key.push_back((char)period); key.append(blk, B);
   auto it = cache.find(key);
   if (it == cache.end()){
     const size_t v0 = out.visits.size(), f0 = out.f64pool.size(), c0 = out.chars.size();
-    emit_stropt(blk, period, stutter, out, true);
+    emit_stropt(blk, B, period, pmf13, out, true);
     if (cache.size() >= 8192) cache.clear();
     StroptCached& e = cache[key];
     e.so = out.stropts.back();
@@ -581,7 +664,10 @@ void fresh_flank_rows(const std::string side_seqs[3], std::vector<hs_row_t>& lea
   lead = flank_rows(h, 0, 0);
   trail = flank_rows(h, 2, (int)h.s[0].size() + 1);
 }
-void append_stropt(const std::string& blk, int period, const double* stutter, Prepared& out){ emit_stropt(blk, period, stutter, out); }
+void append_stropt(const std::string& blk, int period, const double* stutter, Prepared& out){
+  double pmf13[HS_NART]; stutter_pmf13(stutter, period, pmf13);
+  emit_stropt(blk.data(), (int)blk.size(), period, pmf13, out);
+}
 void debug_simple_table(int lim, int U0, int tail, double ent[3]){ g_bnd_scale = 1.0; simple_table_entry(lim, U0, tail, ent); }
 
 // The conditions under which prepare_batch refuses a batch, without building anything (same order, same messages): used where a
@@ -687,11 +773,12 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
     // STR options: forward then reversed orientation
     const int so_base = out.stropts.size();
     std::vector<std::string> sblk[2];                  // the STR options in side orientation
+    double pmf13[HS_NART]; stutter_pmf13(b->stutter + 6*l, period, pmf13);
     for (int side = 0; side < 2; side++)
       for (int o = 0; o < nopts[1]; o++){
         std::string s = opt[1][o];
         if (side) std::reverse(s.begin(), s.end());
-        emit_stropt_cached(s, period, b->stutter + 6*l, out);
+        emit_stropt_cached(s.data(), (int)s.size(), period, b->stutter + 6*l, pmf13, out);
         sblk[side].push_back(std::move(s));
       }
     HS_LAP(1);
