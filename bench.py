@@ -52,6 +52,10 @@ def _cpu_worker(argv):
     """`bench.py --cpu-worker <workload> <first_locus> <n_loci>`: one process of the CPU baseline — the compiled reference (or the C
     oracle) on its own loci; prints alignments and seconds."""
     from hipstr_amd import capi
+    try:                                  # (a parent pinned by --host-threads must not pin the CPU baseline)
+        os.sched_setaffinity(0, range(os.cpu_count() or 1))
+    except Exception:
+        pass
     loci, P, A, L, F, sbp, _ = WORKLOADS[argv[0]]
     first, n = int(argv[1]), int(argv[2])
     if capi.have_ref():
@@ -274,7 +278,16 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: every rank takes the workload's loci; strong: they are split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the short measurements of the stages around the forward pass")
+    ap.add_argument("--host-threads", type=int, default=0,
+                    help="give the process N host CPUs: the library's host threads (HIPSTR_HOST_THREADS) AND the affinity mask of every thread of the "
+                         "process (feeder, stream workers, collector included) — what one rank has on a node whose cores are shared by 8 ranks")
+    ap.add_argument("--e2e-only", action="store_true", help="only the end-to-end (stream) measurement; prints its block as one JSON line")
     args = ap.parse_args()
+    if args.host_threads > 0:
+        # before any thread of the process exists (torch, the library's pool, the stream's workers): they inherit the mask
+        cpus = sorted(os.sched_getaffinity(0))[:args.host_threads]
+        os.sched_setaffinity(0, cpus)
+        os.environ["HIPSTR_HOST_THREADS"] = str(args.host_threads)
 
     import torch
     import torch.distributed as dist
@@ -333,6 +346,14 @@ def main():
     hmm.hipstr_hmm_workload(dev, C.byref(n_aln), C.byref(algo), C.byref(cells))
     hap_off = np.ctypeslib.as_array(sb.ptr.contents.hap_off, shape=(loci + 1,))
     A_l = np.diff(hap_off)
+    if args.e2e_only:
+        hmm.hipstr_hmm_free(dev)
+        e = end_to_end(capi, hmm, sb, loci, max(2, min(args.steps, 5), min(48, int(4e7 // max(1.0, float(n_aln.value))))), local, latency=False)
+        e["alignments_per_s"] = n_aln.value * e["passes"] / e["seconds"]
+        e["host_threads"] = args.host_threads or int(os.environ.get("HIPSTR_HOST_THREADS", "0")) or None
+        e["cpus_allowed"] = len(os.sched_getaffinity(0))
+        print(json.dumps(e), flush=True)
+        return
     if args.workload == "c4":
         # configs[3]: 1000 samples per locus, the locus' reads dealt to them in blocks of P / S; a step = forward HMM + posteriors of every
         # (sample, diplotype) + genotype calls (GL, PL) — seq_stutter_genotyper.cpp:603-671 without the allele rounds
@@ -561,6 +582,25 @@ def main():
             # SURVEY §8(d)'s metric taken literally (host arrays in -> results out: host flatten + H2D + kernels + D2H), beside `value`
             # (inputs resident, as the bench contract defines it)
             out["value_end_to_end"] = e2e["alignments_per_s"]
+            out["value_resident"] = value
+            e2e["host_threads"] = int(os.environ.get("HIPSTR_HOST_THREADS", "0")) or usable_cores()
+            # the same measurement with the host share one rank has when 8 ranks share this node's usable cores: a child process pinned
+            # to usable_cores/8 CPUs (all of its threads) with as many library host threads
+            if not args.host_threads and not os.environ.get("HIPSTR_BENCH_NO_SHARE"):
+                import subprocess
+                n8 = max(1, usable_cores() // 8)
+                cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", str(args.steps), "--e2e-only", "--host-threads", str(n8)]
+                if args.loci:
+                    cmd += ["--loci", str(args.loci)]
+                try:
+                    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
+                    sh = json.loads(r.stdout.strip().splitlines()[-1])
+                    sh["fraction_of_resident_rate"] = sh["alignments_per_s"] / value
+                    sh["note"] = "child process of this run pinned to %d of the node's %d usable CPUs (= usable/8: one rank's share at 8 GPUs), HIPSTR_HOST_THREADS=%d" % (n8, usable_cores(), n8)
+                    out["end_to_end_host_share_8gpu"] = sh
+                    out["value_end_to_end_host_share_8gpu"] = sh["alignments_per_s"]
+                except Exception as ex:            # the line must not depend on it
+                    out["end_to_end_host_share_8gpu"] = {"error": repr(ex)[:200]}
             out["pipeline"] = pipeline_stages(capi, hmm, sb, loci, P)
         if per_rank is not None:
             out["per_rank_alignments_per_s"] = per_rank

@@ -62,7 +62,9 @@ struct BlockCache {
     if (n < 256) return 256;
     if (n <= ((size_t)1 << 20)) return (n + 255) & ~(size_t)255;
     size_t p2 = (size_t)1 << 20; while (p2 < n) p2 <<= 1;
-    const size_t step = p2 >> 4;
+    // (large blocks in coarser classes: the workspaces of consecutive stream batches differ by a few per cent, and a miss there is a
+    //  hipMalloc of gigabytes — 0.9 s seen — in the middle of a stream)
+    const size_t step = n > ((size_t)64 << 20) ? p2 >> 3 : p2 >> 4;
     return (n + step - 1) / step * step;
   }
   void* get(size_t bytes){
@@ -313,6 +315,7 @@ void hipstr_hmm_free(hipstr_dev_batch_t* dev){
     dev->ctx->put_event(dev->ev_h2d, false); dev->ctx->put_event(dev->ev_done, false); dev->ctx->put_event(dev->ev_d2h, false);
   }
   for (hipEvent_t e : dev->prof_pool) hipEventDestroy(e);
+  hipstr::recycle_prepared(dev->prep);       // the tables' host storage goes to the next batch (prep.h)
   delete dev;
 }
 
@@ -331,9 +334,33 @@ hipstr_dev_batch_t* hipstr_hmm_upload_seeded(const hipstr_batch_t* batch, const 
 
 }  // extern "C"
 
+// SURVEY.md §8(d) algorithmic traffic and flank-cell work of one pass (hipstr_hmm_workload; computed when asked for)
+static void workload_of(hipstr_dev_batch_t* dev){
+  const hipstr::Prepared& P = dev->prep;
+  int64_t bytes = 0, cells = 0;
+  for (const hs_locus_t& loc : P.loci){
+    int64_t hap_bytes = 0, flank_rows = 0; int n_re = 0;
+    for (int k = 0; k < loc.n_alleles; k++){
+      const hs_allele_t& al = P.alleles[loc.hap_begin + k];
+      if (!al.realign) continue;
+      const int B = P.stropts[al.str_opt[0]].B;
+      hap_bytes += 2*(int64_t)(al.n_flank + B) + 8*13 + 2*6*(int64_t)B + 16;
+      flank_rows += al.n_flank; n_re++;
+    }
+    bytes += hap_bytes;
+    for (int i = 0; i < loc.n_reads; i++){
+      const hs_read_t& rd = P.reads[loc.read_begin + i];
+      if (!P.realign_read[loc.read_begin + i] || rd.seed < 0) continue;
+      bytes += 2*(int64_t)rd.len + 8 + 4 + 8*(int64_t)n_re;
+      cells += (int64_t)(rd.len - 1) * flank_rows;      // (n_L + n_R) x flank rows, leading flank counted per allele as the reference recomputes it without reuse
+    }
+  }
+  dev->algo_bytes = bytes; dev->dp_cells = cells;
+}
+
 // The upload with the copy on a stream of the caller's choice (the pipelined path copies on its own stream so that the next
 // batch's tables travel while the previous batch's kernels run); hipstr_hmm_align waits for it through an event.
-hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, const int32_t* seed_base, hipStream_t copy_stream, hipStream_t compute_stream){
+hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, const int32_t* seed_base, hipStream_t copy_stream, hipStream_t compute_stream, bool reads_pinned){
   if (bind(ctx)) return NULL;
   hipstr_dev_batch_t* dev = new hipstr_dev_batch_t();
   dev->ctx = ctx;
@@ -345,31 +372,11 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   if (getenv("HIPSTR_WS_GIB")) budget = (int64_t)(atof(getenv("HIPSTR_WS_GIB"))*134217728.0);
   if (budget < 1024) budget = 1024;
   const auto t_prep0 = std::chrono::steady_clock::now();
-  if (hipstr::prepare_batch(batch, dev->prep, err, budget, seed_base)){ g_err = err; delete dev; return NULL; }
+  hipstr::adopt_recycled(dev->prep);
+  if (hipstr::prepare_batch(batch, dev->prep, err, budget, seed_base)){ g_err = err; hipstr::recycle_prepared(dev->prep); delete dev; return NULL; }
   dev->t_prepare = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_prep0).count();
   if (getenv("HIPSTR_TIMING")) fprintf(stderr, "hipstr_hmm_upload: prepare_batch %.3f ms\n", 1e3*dev->t_prepare);
   hipstr::Prepared& P = dev->prep;
-  {  // SURVEY.md §8(d) algorithmic traffic and flank-cell work of one pass
-    int64_t bytes = 0, cells = 0;
-    for (const hs_locus_t& loc : P.loci){
-      int64_t hap_bytes = 0, flank_rows = 0; int n_re = 0;
-      for (int k = 0; k < loc.n_alleles; k++){
-        const hs_allele_t& al = P.alleles[loc.hap_begin + k];
-        if (!al.realign) continue;
-        const int B = P.stropts[al.str_opt[0]].B;
-        hap_bytes += 2*(int64_t)(al.n_flank + B) + 8*13 + 2*6*(int64_t)B + 16;
-        flank_rows += al.n_flank; n_re++;
-      }
-      bytes += hap_bytes;
-      for (int i = 0; i < loc.n_reads; i++){
-        const hs_read_t& rd = P.reads[loc.read_begin + i];
-        if (!P.realign_read[loc.read_begin + i] || rd.seed < 0) continue;
-        bytes += 2*(int64_t)rd.len + 8 + 4 + 8*(int64_t)n_re;
-        cells += (int64_t)(rd.len - 1) * flank_rows;      // (n_L + n_R) x flank rows, leading flank counted per allele as the reference recomputes it without reuse
-      }
-    }
-    dev->algo_bytes = bytes; dev->dp_cells = cells;
-  }
   hs_dev_t& h = dev->h;
   memset(&h, 0, sizeof h);
   // ---- one device block for everything the host fills, one pinned block to stage it, one copy
@@ -387,9 +394,6 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
     total += 1;
     return first;
   };
-  std::vector<hs_item_t> items(P.lead_items);
-  items.insert(items.end(), P.trail_items.begin(), P.trail_items.end());
-  items.insert(items.end(), P.str_items.begin(), P.str_items.end());
   dev->n_lead_items = (int)P.lead_items.size();
   dev->n_trail_items = (int)P.trail_items.size();
 #define PL(vec) place((vec).data(), (vec).size()*sizeof((vec)[0]))
@@ -399,16 +403,26 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
     i_f64 = place_pool(P.f64pool.data(), P.f64pool.size()*sizeof(double), &hipstr::Prepared::f64pool, sizeof(double)),
     i_chars = place_pool(P.chars.data(), P.chars.size(), &hipstr::Prepared::chars, 1),
     i_recs = place_pool(P.grp_recs.data(), P.grp_recs.size()*sizeof(int32_t), &hipstr::Prepared::grp_recs, sizeof(int32_t)),
-    i_reads = PL(P.reads), i_active = PL(P.active), i_items = PL(items),
+    i_reads = PL(P.reads), i_active = PL(P.active),
     i_ws = PL(P.ws), i_tg = PL(P.tgroups), i_tm = PL(P.tmembers), i_tp = PL(P.tpack), i_ord = PL(P.str_order), i_ndr = PL(P.nd_rows);
 #undef PL
-  const size_t n_bases = P.reads.empty() ? 0 : (size_t)batch->base_off[P.reads.size()];
-  const size_t i_bases = place(batch->bases, n_bases), i_quals = place(batch->quals, n_bases);
+  // the work items of the three phases, one array on the device: lead | trail | STR
+  total = (total + 255) & ~(size_t)255;
+  const size_t i_items = pieces.size();
+  pieces.push_back(Piece{P.lead_items.data(), P.lead_items.size()*sizeof(hs_item_t), total}); total += P.lead_items.size()*sizeof(hs_item_t);
+  pieces.push_back(Piece{P.trail_items.data(), P.trail_items.size()*sizeof(hs_item_t), total}); total += P.trail_items.size()*sizeof(hs_item_t);
+  pieces.push_back(Piece{P.str_items.data(), P.str_items.size()*sizeof(hs_item_t), total}); total += P.str_items.size()*sizeof(hs_item_t) + 1;
   const size_t i_args = place(&h, sizeof h);
+  // the reads' bases and qualities come last: a caller whose arrays are pinned (the stream's batches) has them copied from where they lie,
+  // without a pass through the staging block
+  const size_t n_bases = P.reads.empty() ? 0 : (size_t)batch->base_off[P.reads.size()];
+  const size_t packed_total = reads_pinned ? ((total + 255) & ~(size_t)255) : 0;
+  const size_t i_bases = place(reads_pinned ? NULL : batch->bases, n_bases), i_quals = place(reads_pinned ? NULL : batch->quals, n_bases);
+  const size_t stage_total = reads_pinned ? packed_total : total;
   char* dblk = (char*)ctx->dev_cache.get(total);
   if (!dblk){ hipstr_hmm_free(dev); return NULL; }
   dev->dev_blocks.push_back(dblk);
-  char* stage = (char*)ctx->pin_cache.get(total);
+  char* stage = (char*)ctx->pin_cache.get(stage_total);
   if (!stage){ hipstr_hmm_free(dev); return NULL; }
   dev->pin_blocks.push_back(stage);
   auto at = [&](size_t i){ return dblk + pieces[i].off; };
@@ -473,12 +487,17 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
     struct Span { char* dst; const char* src; size_t n; };
     std::vector<Span> spans;
     for (const Piece& pc : pieces)
-      for (size_t o = 0; o < pc.bytes; o += (size_t)4 << 20)
+      for (size_t o = 0; pc.src && o < pc.bytes; o += (size_t)4 << 20)
         spans.push_back(Span{stage + pc.off + o, (const char*)pc.src + o, std::min<size_t>((size_t)4 << 20, pc.bytes - o)});
-    hipstr::parallel_for((int)spans.size(), total > ((size_t)8 << 20) ? hipstr::host_threads() : 1, [&](int i){ memcpy(spans[i].dst, spans[i].src, spans[i].n); });
+    hipstr::parallel_for((int)spans.size(), stage_total > ((size_t)8 << 20) ? hipstr::host_threads() : 1, [&](int i){ memcpy(spans[i].dst, spans[i].src, spans[i].n); });
   }
+  { hipstr::Prepared only_frags; only_frags.frags.swap(P.frags); hipstr::recycle_prepared(only_frags); }      // the fragments' pools are packed: their storage can serve the next batch already
   dev->t_stage = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_stage0).count();
-  HS_HIP_DEV(hipMemcpyAsync(dblk, stage, total, hipMemcpyHostToDevice, copy_stream));
+  HS_HIP_DEV(hipMemcpyAsync(dblk, stage, stage_total, hipMemcpyHostToDevice, copy_stream));
+  if (reads_pinned && n_bases){
+    HS_HIP_DEV(hipMemcpyAsync(dblk + pieces[i_bases].off, batch->bases, n_bases, hipMemcpyHostToDevice, copy_stream));
+    HS_HIP_DEV(hipMemcpyAsync(dblk + pieces[i_quals].off, batch->quals, n_bases, hipMemcpyHostToDevice, copy_stream));
+  }
   HS_HIP_DEV(hipMemsetAsync(h.aln_probs, 0, out_bytes, copy_stream));
   dev->ev0 = ctx->get_event(true); dev->ev1 = ctx->get_event(true);
   dev->ev_h2d = ctx->get_event(false); dev->ev_done = ctx->get_event(false); dev->ev_d2h = ctx->get_event(false);
@@ -520,6 +539,14 @@ void hipstr::scatter_loci(const hipstr_dev_batch_t* dev, int l0, int l1, double*
     const hs_locus_t& loc = P.loci[li];
     const int A = loc.n_alleles;
     const bool all_haps = loc.n_re == A;
+    // the usual locus — every read realigned and seeded, every haplotype realigned — is one block in both layouts
+    bool plain = all_haps;
+    for (int i = 0; plain && i < loc.n_reads; i++) plain = P.realign_read[loc.read_begin + i] && P.seeds[loc.read_begin + i] >= 0;
+    if (plain){
+      memcpy(aln_probs + (loc.out_off - out0), dev->host_out + loc.out_off, sizeof(double)*(size_t)loc.n_reads*(size_t)A);
+      memcpy(seeds + (loc.read_begin - r0), P.seeds.data() + loc.read_begin, sizeof(int32_t)*(size_t)loc.n_reads);
+      continue;
+    }
     for (int i = 0; i < loc.n_reads; i++){
       const int r = loc.read_begin + i;
       if (!P.realign_read[r]) continue;                       // HapAligner.cpp:326-329
@@ -639,6 +666,7 @@ int hipstr_hmm_profile_read(hipstr_dev_batch_t* dev, float* ms, int cap){
 int hipstr_hmm_workload(hipstr_dev_batch_t* dev, int64_t* n_alignments, int64_t* algorithmic_bytes, int64_t* dp_cells){
   if (!dev) return fail("null device batch");
   if (n_alignments) *n_alignments = dev->prep.n_alignments;
+  if (dev->algo_bytes == 0 && dev->dp_cells == 0) workload_of(dev);
   if (algorithmic_bytes) *algorithmic_bytes = dev->algo_bytes;
   if (dp_cells) *dp_cells = dev->dp_cells;
   return 0;
@@ -843,7 +871,9 @@ struct PostRun {
   // small runs (a locus or a few: everything under 4 MiB): inputs and argument block travel in ONE pinned block with one copy, the three
   // results sit next to each other in the same device block and come back with one copy
   void* pin_in = NULL; size_t res_bytes = 0, res_total_off = 0, res_map_off = 0;
+  hipEvent_t ev_up = NULL;          // small runs: recorded on `stream` behind the asynchronous upload; a launch on another stream waits for it
   ~PostRun(){
+    if (ctx && ev_up) ctx->put_event(ev_up, false);
     if (!ctx || (allocs.empty() && !pin_in) || bind(ctx)) return;
     hipStreamSynchronize(stream);           // the blocks are handed to the next user
     for (void* p : allocs) ctx->dev_cache.put(p);
@@ -906,6 +936,9 @@ int post_setup(const hipstr_post_batch_t* pb, const double* dev_ll, PostRun& R){
       R.d_args = (hs_post_dev_t*)(dblk + o_args);
       for (const Piece& pc : in) if (pc.bytes && pc.src) memcpy(pin + pc.off, pc.src, pc.bytes);      // (the argument block last in the list: filled in by now)
       HS_HIP(hipMemcpyAsync(dblk, pin, in_total, hipMemcpyHostToDevice, R.stream));
+      R.ev_up = ctx->get_event(false);
+      if (!R.ev_up) return fail("hipEventCreate failed");
+      HS_HIP(hipEventRecord(R.ev_up, R.stream));
       R.res_bytes = tot - o_post; R.res_total_off = o_tot - o_post; R.res_map_off = o_map - o_post;
       return 0;
     }
@@ -961,6 +994,8 @@ int hipstr_post_launch(hipstr_post_dev_t* pd, void* hip_stream){
   if (bind(pd->R.ctx)) return 1;
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : pd->R.stream;
   if (hip_stream && st != pd->R.stream) pd->foreign_stream = true;
+  // a small run's inputs and argument block were sent asynchronously on the run's own stream: a launch elsewhere comes after them
+  if (st != pd->R.stream && pd->R.ev_up) HS_HIP(hipStreamWaitEvent(st, pd->R.ev_up, 0));
   // HIPSTR_DEBUG_HOST_LIBM=1 (tests/test_genotypes_gpu.py): the three places where the device's exp / log enter — the per-sample
   // log-sum-exp over the diplotypes, the streaming log-sum-exps per genotype and the exact pair log-sum-exp of the unphased posterior —
   // are evaluated on the host with its libm, in the reference's order, on the device's accumulated values.  It shows where the

@@ -71,7 +71,8 @@ struct ApiTimer {                  // adds its lifetime to a bucket
 }  // namespace hipstr
 struct hipstr_batch; struct hipstr_dev_batch;
 namespace hipstr {
-hipstr_dev_batch* upload_on(Ctx* ctx, const hipstr_batch* batch, const int32_t* seed_base, hipStream_t copy_stream, hipStream_t compute_stream);
+// reads_pinned: batch->bases / quals lie in pinned host memory that outlives the copy: they are sent from there, not through the staging block
+hipstr_dev_batch* upload_on(Ctx* ctx, const hipstr_batch* batch, const int32_t* seed_base, hipStream_t copy_stream, hipStream_t compute_stream, bool reads_pinned = false);
 int  fetch_begin(hipstr_dev_batch* dev, hipStream_t compute_stream, hipStream_t copy_stream);
 int  results_wait(hipstr_dev_batch* dev);
 void scatter_loci(const hipstr_dev_batch* dev, int l0, int l1, double* aln_probs, int32_t* seeds);   // outputs based at locus l0

@@ -27,7 +27,11 @@ namespace hipstr {
 static std::atomic<int> g_thread_override(0);
 void set_host_threads(int n){ g_thread_override = n > 0 ? n : 0; }
 
+static thread_local int tl_thread_budget = 0;
+void set_thread_budget(int n){ tl_thread_budget = n > 0 ? n : 0; }
+
 int host_threads(){
+  if (tl_thread_budget) return tl_thread_budget;
   if (const int o = g_thread_override.load()) return o;
   static const int n = [](){
     if (const char* e = getenv("HIPSTR_HOST_THREADS")){ const int v = atoi(e); if (v >= 1) return v; }
@@ -117,6 +121,7 @@ void parallel_for(int n, int max_threads, const std::function<void(int)>& fn){
 
 
 static const int MIN_SEED_DIST = 5;          // HapAligner.cpp:17
+#define HIPSTR_MAX_PERIOD_TAB 9               // longest period (stutter_model.h:38): a periodic block's insertion list has period + 2 table entries
 static const double LARGE_NEGATIVE = -10e6;  // RepeatStutterInfo.h:12
 
 const HostTables& host_tables(){
@@ -378,7 +383,12 @@ static void simple_table_entry(int lim, int U0, int tail, double ent[3]){
 // The 13 values of StutterModel::log_stutter_pmf (stutter_model.cpp:29-53) an STR option needs — artifact sizes of -6..+6 repeat units, all
 // in frame — depend on the stutter model alone, not on the block: computed once per locus (eight logarithms per value otherwise).
 static void stutter_pmf13(const double* sp, int period, double pmf[HS_NART]){
-  for (int t = 0; t < HS_NART; t++) pmf[t] = log_stutter_pmf(sp, period, 0, (t - HS_MAXREP)*period);
+  (void)period;                                  // (sizes of whole repeat units: the in-frame branch of log_stutter_pmf, same expressions)
+  const double in_step = log(1-sp[0]), in_nostep = log(sp[0]), in_up = log(sp[1]), in_down = log(sp[2]);
+  for (int t = 0; t < HS_NART; t++){
+    const int rep = t - HS_MAXREP;
+    pmf[t] = rep == 0 ? log(1-sp[1]-sp[2]-sp[4]-sp[5]) : (rep < 0 ? in_down + in_nostep + in_step*(-rep-1) : in_up + in_nostep + in_step*(rep-1));
+  }
 }
 
 static std::atomic<uint64_t> g_so_cycles[6];
@@ -432,27 +442,39 @@ void emit_stropt(const char* blk, const int B, int period, const double pmf13[HS
     bool ok = (B >= period);
     for (int i = 0; i < B; i++){ const char c = blk[i]; ok &= (c == 'A' || c == 'C' || c == 'G' || c == 'T'); }
     if (ok){
-      int total = 0;
-      for (int k = 0; k <= HS_MAXREP; k++){
-        const int tail = (k == HS_MAXREP) ? B : B - (k+1)*period;
-        so.tab_base[k] = total;
-        if (tail >= 0) total += 2 + (tail - so.shape[k]);
+      // the table of such a block is a function of (B, period) alone — 14 + period + [period < B ? 0 : ...] entries — and the same
+      // lengths come back for both orientations, for the alleles of neighbouring loci ...: a direct-mapped memo per host thread
+      struct Tab { int32_t key, total; int32_t tab_base[HS_MAXREP + 1]; double ent[3*(2*HS_MAXREP + 2 + HIPSTR_MAX_PERIOD_TAB) + 1]; };
+      thread_local std::vector<Tab> memo(512);
+      const bool use_memo = g_bnd_scale.load(std::memory_order_relaxed) == 1.0;
+      const int32_t key = (B << 4) | period;                     // (never 0: B >= 1)
+      Tab local; Tab& T2 = use_memo ? memo[((uint32_t)key * 2654435761u) >> 23] : local;
+      if (!use_memo || T2.key != key){
+        int total = 0;
+        for (int k = 0; k <= HS_MAXREP; k++){
+          const int tail = (k == HS_MAXREP) ? B : B - (k+1)*period;
+          T2.tab_base[k] = total;
+          if (tail >= 0) total += 2 + (tail - so.shape[k]);
+        }
+        double* ent = T2.ent;
+        double bmin = 1e300;                              // what the kernel compares |lp0| with: the weakest guarantee of the table
+        for (int k = 0; k <= HS_MAXREP; k++){
+          const int tail = (k == HS_MAXREP) ? B : B - (k+1)*period;
+          if (tail < 0) continue;
+          const int U0 = so.shape[k], n = 2 + (tail - U0);
+          for (int e = 0; e < n; e++, ent += 3){
+            simple_table_entry((e == 0) ? 0 : (e == 1 ? 1 : U0 + e - 1), U0, tail, ent);
+            bmin = std::min(bmin, ent[2]);
+          }
+        }
+        *ent = bmin;
+        T2.total = total; T2.key = key;
       }
       so.kind = 1;                      // (total <= 12 + 2 + 9 entries: always within HS_TAB_CAP)
-      out.f64pool.resize((size_t)so.tab_off + 3*(size_t)total + 1);
-      double* ent = out.f64pool.data() + so.tab_off;
-      double bmin = 1e300;
-      for (int k = 0; k <= HS_MAXREP; k++){
-        const int tail = (k == HS_MAXREP) ? B : B - (k+1)*period;
-        if (tail < 0) continue;
-        const int U0 = so.shape[k], n = 2 + (tail - U0);
-        for (int e = 0; e < n; e++, ent += 3){
-          simple_table_entry((e == 0) ? 0 : (e == 1 ? 1 : U0 + e - 1), U0, tail, ent);
-          bmin = std::min(bmin, ent[2]);
-        }
-      }
-      so.tab_len = total;
-      *ent = bmin;
+      memcpy(so.tab_base, T2.tab_base, sizeof so.tab_base);
+      out.f64pool.resize((size_t)so.tab_off + 3*(size_t)T2.total + 1);
+      memcpy(out.f64pool.data() + so.tab_off, T2.ent, sizeof(double)*(3*(size_t)T2.total + 1));
+      so.tab_len = T2.total;
     }
     out.stropts.push_back(so);
     HS_SOLAP(4);
@@ -681,7 +703,7 @@ int check_batch(const hipstr_batch_t* b, std::string& err){
 }
 
 // One locus of check_batch; *opt_cursor = index of the locus' first block option in opt_off, advanced past the locus.
-int check_locus(const hipstr_batch_t* b, int l, int* opt_cursor_io, std::string& err){
+int check_locus(const hipstr_batch_t* b, int l, int* opt_cursor_io, std::string& err, int32_t* seeds_out){
   int opt_cursor = *opt_cursor_io;
   {
     const int period = b->period[l];
@@ -704,9 +726,10 @@ int check_locus(const hipstr_batch_t* b, int l, int* opt_cursor_io, std::string&
     if (A >= (1 << 24)){ err = "more than 16 M candidate haplotypes for a locus are not supported"; return 1; }
     if (b->read_off[l+1] < b->read_off[l]){ err = "read_off must not decrease"; return 1; }
     for (int r = b->read_off[l]; r < b->read_off[l+1]; r++){
-      if (b->realign_read && !b->realign_read[r]) continue;
+      if (b->realign_read && !b->realign_read[r]){ if (seeds_out) seeds_out[r] = HIPSTR_SEED_AUTO; continue; }
       const int len = b->base_off[r+1] - b->base_off[r];
       const int s = calc_seed_base(b, l, r);
+      if (seeds_out) seeds_out[r] = s;
       if (s == -2){ err = "Invalid alignment seed or unrecognized CIGAR char (HapAligner.cpp:309,316)"; return 1; }
       if (s >= 0 && (s > HS_MAX_SIDE_FWD || len-s-1 > HS_MAX_SIDE_FWD)){ err = "read side longer than 1024 bases is not supported"; return 1; }
     }
@@ -738,276 +761,403 @@ void prep_profile_print(){
 }
 #define HS_LAP(k) do { if (g_lap_on){ const uint64_t now_ = __builtin_ia32_rdtsc(); g_lap_cycles[k] += now_ - lap_t; lap_t = now_; } } while (0)
 
-static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const PrepShared& sh, Prepared& out,
-                         std::vector< std::vector<int> >& locus_leads, std::string& err){
+namespace {
+struct Seq { const char* p; int n; };
+inline bool seq_eq(const Seq& a, const Seq& b){ return a.n == b.n && memcmp(a.p, b.p, (size_t)a.n) == 0; }
+inline bool seq_less(const Seq& a, const Seq& b){        // std::string's order among sequences of one length
+  return memcmp(a.p, b.p, (size_t)a.n) < 0;
+}
+// stable insertion sort for the short lists of a locus (options, reads of a side); longer ones take std::stable_sort
+template <class T, class Less> void stable_small_sort(T* v, int n, Less less){
+  if (n > 48){ std::stable_sort(v, v + n, less); return; }
+  for (int i = 1; i < n; i++){
+    T x = v[i]; int j = i;
+    while (j > 0 && less(x, v[j-1])){ v[j] = v[j-1]; j--; }
+    v[j] = x;
+  }
+}
+// Scratch of prepare_locus, one per host thread (cleared per locus, capacity kept)
+struct LocusScratch {
+  std::vector<char> rev;                       // reversed STR options, then (per cache miss) the reversed flanks of one haplotype
+  std::vector<char> hbuf;
+  std::vector<Seq> sblk[2];                    // STR options in side orientation
+  std::vector<int32_t> str_opt_of, ks, opt_rank, os, cnt;
+  struct EndSig { char c_first, c_last; int run_first, run_last; };
+  struct RowsKey { int opt; char c; int run; int aux; int id; };
+  std::vector<EndSig> end_sig[2];
+  std::vector<RowsKey> lead_tab[2], trail_tab[2];
+  std::vector<int32_t> lead_sets[2];
+  std::vector<int> run;                        // lrun | rrun of the three blocks of one orientation
+  std::vector<int> hl;
+  std::vector<hs_row_t> rows;
+  std::vector<uint64_t> pairs;
+};
+static LocusScratch& locus_scratch(){ thread_local LocusScratch s; return s; }
+
+// One haplotype orientation: the three block sequences + HapBlock's run-length tables (see SideSeqs above; same quirk)
+struct SideView {
+  Seq s[3];
+  const int* lrun[3]; const int* rrun[3];
+};
+static void index_side(SideView& h, std::vector<int>& store){
+  size_t tot = 0; for (int b = 0; b < 3; b++) tot += 2*(size_t)h.s[b].n;
+  if (store.size() < tot) store.resize(tot);
+  int* p = store.data();
+  for (int b = 0; b < 3; b++){
+    const int n = h.s[b].n; const char* q = h.s[b].p;
+    int* lr = p; int* rr = p + n; p += 2*n;
+    h.lrun[b] = lr; h.rrun[b] = rr;
+    if (n == 0) continue;
+    for (int j = 0; j < n; j++){ lr[j] = 0; rr[j] = 0; }
+    int count = 0;
+    for (int j = 1; j < n; j++){ count = (q[j-1] == q[j]) ? count+1 : 0; lr[j] = count; }
+    for (int j = n-2; j >= 0; j--){ count = (q[j+1] == q[j]) ? count+1 : 0; rr[j] = count; }
+  }
+}
+// Haplotype::homopolymer_length with its neighbour-block extensions (Haplotype.cpp:239-287)
+static int homopolymer_len_v(const SideView& h, int bi, int pos){
+  const Seq& q = h.s[bi];
+  const char c = q.p[pos];
+  int l = h.lrun[bi][pos], r = h.rrun[bi][pos];
+  if (pos - l == 0){
+    for (int nb = bi-1; nb >= 0; nb--){
+      const int n = h.s[nb].n;
+      if (n == 0) continue;
+      if (h.s[nb].p[n-1] != c) break;
+      const int ll = h.lrun[nb][n-1];
+      l += 1 + ll;
+      if (ll != n) break;
+    }
+  }
+  if (pos + r == q.n-1){
+    for (int nb = bi+1; nb < 3; nb++){
+      const int n = h.s[nb].n;
+      if (n == 0) continue;
+      if (h.s[nb].p[0] != c) break;
+      const int rl = h.rrun[nb][0];
+      r += 1 + rl;
+      if (rl != n) break;
+    }
+  }
+  return l + r + 1;
+}
+// rows of flank block `bi` (0 = lead, 2 = trail) under context h; u0 = compact index of its first row
+static void flank_rows_v(const SideView& h, int bi, int u0, std::vector<int>& hl, std::vector<hs_row_t>& rows){
+  const Seq& q = h.s[bi];
+  if ((int)hl.size() < q.n) hl.resize(q.n);
+  rows.resize(q.n);
+  for (int i = 0; i < q.n; i++) hl[i] = homopolymer_len_v(h, bi, i);
+  for (int i = 0; i < q.n; i++){
+    const int v = std::min(HIPSTR_MAX_HOMOP_LEN, std::max(hl[i], hl[std::max(0, i-1)]));
+    rows[i] = HS_ROW_VALID | ((uint32_t)(u0+i) << 12) | ((uint32_t)v << 8) | (uint8_t)q.p[i];
+  }
+}
+}  // namespace
+
+static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const PrepShared& sh, Prepared& out, std::string& err){
   const int32_t* seed_in = sh.seed_in;
   uint64_t lap_t = g_lap_on ? __builtin_ia32_rdtsc() : 0;
-    const int period = b->period[l];
-    if (period < 1 || period > 9){ err = "STR period must be in [1,9] (stutter_model.h:38)"; return 1; }
-    int32_t nopts[3];
-    std::vector<std::string> opt[3];
-    for (int k = 0; k < 3; k++){
-      nopts[k] = b->blk_nopts[3*l+k];
-      if (nopts[k] < 1){ err = "haplotype block without options"; return 1; }
-      for (int o = 0; o < nopts[k]; o++, opt_cursor++)
-        opt[k].push_back(std::string(b->seq + b->opt_off[opt_cursor], b->opt_off[opt_cursor+1]-b->opt_off[opt_cursor]));
+  LocusScratch& S = locus_scratch();
+  const int period = b->period[l];
+  if (period < 1 || period > 9){ err = "STR period must be in [1,9] (stutter_model.h:38)"; return 1; }
+  int32_t nopts[3], opt_first[3];
+  for (int k = 0; k < 3; k++){
+    nopts[k] = b->blk_nopts[3*l+k];
+    if (nopts[k] < 1){ err = "haplotype block without options"; return 1; }
+    opt_first[k] = opt_cursor; opt_cursor += nopts[k];
+  }
+  auto O = [&](int k, int o) -> Seq { const int c = opt_first[k] + o; return Seq{ b->seq + b->opt_off[c], b->opt_off[c+1] - b->opt_off[c] }; };
+  for (int k = 0; k < 3; k += 2)
+    for (int o = 0; o < nopts[k]; o++)
+      if (O(k, o).n == 0){ err = "empty flank sequence"; return 1; }
+  size_t str_total = 0;
+  for (int o = 0; o < nopts[1]; o++){
+    const int n = O(1, o).n;
+    if (n == 0){ err = "empty STR allele is not supported"; return 1; }
+    if (n > HS_MAX_STR_BP){ err = "STR allele longer than 2047 bp is not supported"; return 1; }
+    out.max_B = std::max(out.max_B, (int32_t)n);
+    str_total += (size_t)n;
+  }
+  const int64_t A64 = (int64_t)nopts[0]*nopts[1]*nopts[2];
+  if (A64 != b->hap_off[l+1]-b->hap_off[l]){ err = "hap_off does not match the product of block options"; return 1; }
+  if (A64 >= (1 << 24)){ err = "more than 16 M candidate haplotypes for a locus are not supported"; return 1; }
+  const int A = (int)A64;
+
+  HS_LAP(0);
+  hs_locus_t loc;
+  loc.out_off = sh.out_off[l]; loc.hap_begin = out.alleles.size(); loc.n_alleles = A;
+  loc.read_begin = b->read_off[l]; loc.n_reads = b->read_off[l+1]-b->read_off[l];
+  loc.period = period; loc.pad_ = 0;
+
+  // STR options: forward then reversed orientation
+  const int so_base = out.stropts.size();
+  double pmf13[HS_NART]; stutter_pmf13(b->stutter + 6*l, period, pmf13);
+  S.rev.resize(str_total);
+  S.sblk[0].clear(); S.sblk[1].clear();
+  {
+    char* rp = S.rev.data();
+    for (int o = 0; o < nopts[1]; o++){
+      const Seq f = O(1, o);
+      S.sblk[0].push_back(f);
+      for (int i = 0; i < f.n; i++) rp[i] = f.p[f.n-1-i];
+      S.sblk[1].push_back(Seq{rp, f.n});
+      rp += f.n;
     }
-    for (int k = 0; k < 3; k += 2)
-      for (size_t o = 0; o < opt[k].size(); o++)
-        if (opt[k][o].empty()){ err = "empty flank sequence"; return 1; }
-    for (size_t o = 0; o < opt[1].size(); o++){
-      if (opt[1][o].empty()){ err = "empty STR allele is not supported"; return 1; }
-      if (opt[1][o].size() > HS_MAX_STR_BP){ err = "STR allele longer than 2047 bp is not supported"; return 1; }
-      out.max_B = std::max(out.max_B, (int32_t)opt[1][o].size());
+  }
+  for (int side = 0; side < 2; side++)
+    for (int o = 0; o < nopts[1]; o++)
+      emit_stropt_cached(S.sblk[side][o].p, S.sblk[side][o].n, period, b->stutter + 6*l, pmf13, out);
+  HS_LAP(1);
+  S.str_opt_of.resize(A);                            // STR option of every allele
+  for (int k = 0; k < A; k++){ int32_t o3[3]; allele_options(nopts, k, o3); S.str_opt_of[k] = o3[1]; }
+
+  // alleles in visit order, replaying the reference's row reuse (HapAligner.cpp:54-60, 612-634):
+  // the lead block of a side is (re)computed only when reuse is off or it is the block that changed;
+  // otherwise its rows — and the homopolymer context they were computed under — are inherited.
+  const int rowset_first = (int)out.rowsets.size();           // rowsets are shared (by content) within the locus
+  auto intern = [&](const std::vector<hs_row_t>& rows){
+    const int n = (int)rows.size();
+    // (the reference-order map of round 1-3 numbered distinct row vectors in order of first use: so does a scan of the locus' rowsets)
+    for (int id = rowset_first; id < (int)out.rowsets.size(); id++){
+      const hs_rowset_t& rs = out.rowsets[id];
+      if (rs.len == n && memcmp(out.rows.data() + rs.off, rows.data(), sizeof(hs_row_t)*(size_t)n) == 0) return id;
     }
-    const int A = nopts[0]*nopts[1]*nopts[2];
-    if (A != b->hap_off[l+1]-b->hap_off[l]){ err = "hap_off does not match the product of block options"; return 1; }
-    if (A >= (1 << 24)){ err = "more than 16 M candidate haplotypes for a locus are not supported"; return 1; }
-
-    HS_LAP(0);
-    hs_locus_t loc;
-    loc.out_off = sh.out_off[l]; loc.hap_begin = out.alleles.size(); loc.n_alleles = A;
-    loc.read_begin = b->read_off[l]; loc.n_reads = b->read_off[l+1]-b->read_off[l];
-    loc.period = period; loc.pad_ = 0;
-
-    // STR options: forward then reversed orientation
-    const int so_base = out.stropts.size();
-    std::vector<std::string> sblk[2];                  // the STR options in side orientation
-    double pmf13[HS_NART]; stutter_pmf13(b->stutter + 6*l, period, pmf13);
-    for (int side = 0; side < 2; side++)
-      for (int o = 0; o < nopts[1]; o++){
-        std::string s = opt[1][o];
-        if (side) std::reverse(s.begin(), s.end());
-        emit_stropt_cached(s.data(), (int)s.size(), period, b->stutter + 6*l, pmf13, out);
-        sblk[side].push_back(std::move(s));
-      }
-    HS_LAP(1);
-    std::vector<int32_t> str_opt_of(A);                // STR option of every allele
-    for (int k = 0; k < A; k++){ int32_t o3[3]; allele_options(nopts, k, o3); str_opt_of[k] = o3[1]; }
-
-    // alleles in visit order, replaying the reference's row reuse (HapAligner.cpp:54-60, 612-634):
-    // the lead block of a side is (re)computed only when reuse is off or it is the block that changed;
-    // otherwise its rows — and the homopolymer context they were computed under — are inherited.
-    std::map<std::vector<hs_row_t>, int> rowset_ids;
-    auto intern = [&](const std::vector<hs_row_t>& rows){
-      auto it = rowset_ids.find(rows);
-      if (it != rowset_ids.end()) return it->second;
-      hs_rowset_t rs; rs.off = out.rows.size(); rs.len = rows.size();
-      out.rows.insert(out.rows.end(), rows.begin(), rows.end());
-      const int id = out.rowsets.size();
-      out.rowsets.push_back(rs);
-      rowset_ids[rows] = id;
-      return id;
-    };
-    // boundary signature of every STR option per side: first base and HapBlock's right-run length there, last base and left-run length
-    // there (HapBlock.cpp:7-30, with its counter carried from the forward into the backward pass)
-    struct EndSig { char c_first, c_last; int run_first, run_last; };
-    struct RowsKey { int opt; char c; int run; int aux; int id; };
-    std::vector<EndSig> end_sig[2];
-    std::vector<RowsKey> lead_tab[2], trail_tab[2];
-    for (int side = 0; side < 2; side++)
-      for (int o = 0; o < nopts[1]; o++){
-        const std::string& q = sblk[side][o];
-        const int n = (int)q.size();
-        int count = 0, lr_last = 0, rr_first = 0;
-        for (int j = 1; j < n; j++){ count = (q[j-1] == q[j]) ? count+1 : 0; if (j == n-1) lr_last = count; }
-        for (int j = n-2; j >= 0; j--){ count = (q[j+1] == q[j]) ? count+1 : 0; if (j == 0) rr_first = count; }
-        end_sig[side].push_back(EndSig{ q[0], q[n-1], rr_first, lr_last });
-      }
-    HS_LAP(2);
-    bool reuse = false;
-    int lead_id[2] = {-1, -1};
-    int n_realigned = 0;
-    std::vector<int> lead_sets[2];          // distinct leading-flank rowsets per side, in order of first use
-    loc.lt_stride = 0; loc.lead_flank[0] = loc.lead_flank[1] = 0;
-    for (int k = 0; k < A; k++){
-      const bool realign = b->realign_hap ? b->realign_hap[b->hap_off[l]+k] != 0 : true;
-      out.realign_hap.push_back(realign ? 1 : 0);
-      hs_allele_t al; memset(&al, 0, sizeof al);
-      al.realign = realign ? 1 : 0;
-      int32_t o3[3];
-      allele_options(nopts, k, o3);
-      al.n_flank = opt[0][o3[0]].size() + opt[2][o3[2]].size();
-      out.max_flank = std::max(out.max_flank, al.n_flank);
-      if (!realign){ reuse = false; out.alleles.push_back(al); continue; }
-      al.re_ord = n_realigned++;
-      loc.lt_stride = std::max(loc.lt_stride, al.n_flank);
-      const int cb = k == 0 ? -1 : changed_block(nopts, k);
-      for (int side = 0; side < 2; side++){
-        // The rows of a flank block depend on the block and, through the homopolymer run that may cross the block boundary, on the
-        // STR block's first base and the run it starts (leading flank) or its last base and the run it ends (trailing flank) — never on
-        // more: the reference's extension stops after one non-empty neighbour (Haplotype.cpp:239-275).  The alleles of a locus mostly
-        // share flanks and motif, so the rows are built once per (flank option, boundary signature) and looked up afterwards.
-        const int o_lead = side ? o3[2] : o3[0], o_trail = side ? o3[0] : o3[2];
-        const int lead_len = (int)opt[side ? 2 : 0][o_lead].size();
-        const EndSig& es = end_sig[side][o3[1]];
-        SideSeqs h; bool have_h = false;
-        auto need_h = [&](){
-          if (have_h) return;
-          for (int j = 0; j < 3; j++){
-            h.s[j] = opt[side ? 2-j : j][o3[side ? 2-j : j]];
-            if (side) std::reverse(h.s[j].begin(), h.s[j].end());
-          }
-          h.index(); have_h = true;
-        };
-        auto cached = [&](std::vector<RowsKey>& tab, const RowsKey& key, int bi, int u0) -> int {
-          for (const RowsKey& e : tab) if (e.opt == key.opt && e.c == key.c && e.run == key.run && e.aux == key.aux) return e.id;
-          need_h();
-          RowsKey e = key; e.id = intern(flank_rows(h, bi, u0));
-          tab.push_back(e);
-          return e.id;
-        };
-        const int side_changed = cb < 0 ? -1 : (side ? 2-cb : cb);
-        if (!reuse || side_changed <= 0) lead_id[side] = cached(lead_tab[side], RowsKey{o_lead, es.c_first, es.run_first, 0, 0}, 0, 0);
-        al.lead_rows[side]  = lead_id[side];
-        {
-          std::vector<int>& ls = lead_sets[side];
-          size_t slot = std::find(ls.begin(), ls.end(), lead_id[side]) - ls.begin();
-          if (slot == ls.size()) ls.push_back(lead_id[side]);
-          al.lead_slot[side] = (int32_t)slot;
-          loc.lead_flank[side] = std::max(loc.lead_flank[side], (int32_t)lead_len);
-        }
-        al.trail_rows[side] = cached(trail_tab[side], RowsKey{o_trail, es.c_last, es.run_last, lead_len, 0}, 2, lead_len + 1);
-        al.str_opt[side]    = so_base + side*nopts[1] + o3[1];
-      }
-      reuse = true;
-      out.alleles.push_back(al);
+    hs_rowset_t rs; rs.off = out.rows.size(); rs.len = n;
+    out.rows.insert(out.rows.end(), rows.begin(), rows.end());
+    out.rowsets.push_back(rs);
+    return (int)out.rowsets.size() - 1;
+  };
+  // boundary signature of every STR option per side: first base and HapBlock's right-run length there, last base and left-run length
+  // there (HapBlock.cpp:7-30, with its counter carried from the forward into the backward pass)
+  typedef LocusScratch::EndSig EndSig; typedef LocusScratch::RowsKey RowsKey;
+  for (int side = 0; side < 2; side++){
+    S.end_sig[side].clear(); S.lead_tab[side].clear(); S.trail_tab[side].clear(); S.lead_sets[side].clear();
+    for (int o = 0; o < nopts[1]; o++){
+      const Seq& q = S.sblk[side][o];
+      const int n = q.n;
+      int count = 0, lr_last = 0, rr_first = 0;
+      for (int j = 1; j < n; j++){ count = (q.p[j-1] == q.p[j]) ? count+1 : 0; if (j == n-1) lr_last = count; }
+      for (int j = n-2; j >= 0; j--){ count = (q.p[j+1] == q.p[j]) ? count+1 : 0; if (j == 0) rr_first = count; }
+      S.end_sig[side].push_back(EndSig{ q.p[0], q.p[n-1], rr_first, lr_last });
     }
-
-    HS_LAP(3);
-    loc.n_re = n_realigned;
-    loc.n_lead[0] = lead_sets[0].size(); loc.n_lead[1] = lead_sets[1].size();
+  }
+  HS_LAP(2);
+  bool reuse = false;
+  int lead_id[2] = {-1, -1};
+  int n_realigned = 0;
+  loc.lt_stride = 0; loc.lead_flank[0] = loc.lead_flank[1] = 0;
+  const size_t allele_base = out.alleles.size();
+  out.alleles.resize(allele_base + (size_t)A);
+  const size_t rh_base = out.realign_hap.size();
+  out.realign_hap.resize(rh_base + (size_t)A);
+  for (int k = 0; k < A; k++){
+    const bool realign = b->realign_hap ? b->realign_hap[b->hap_off[l]+k] != 0 : true;
+    out.realign_hap[rh_base + k] = realign ? 1 : 0;
+    hs_allele_t al; memset(&al, 0, sizeof al);
+    al.realign = realign ? 1 : 0;
+    int32_t o3[3];
+    allele_options(nopts, k, o3);
+    al.n_flank = O(0, o3[0]).n + O(2, o3[2]).n;
+    out.max_flank = std::max(out.max_flank, al.n_flank);
+    if (!realign){ reuse = false; out.alleles[allele_base + k] = al; continue; }
+    al.re_ord = n_realigned++;
+    loc.lt_stride = std::max(loc.lt_stride, al.n_flank);
+    const int cb = k == 0 ? -1 : changed_block(nopts, k);
     for (int side = 0; side < 2; side++){
-      // STR-kernel order: by STR option, options sorted by length; an option whose block (in side orientation) ends with the
-      // previous option's block continues that option's match/deletion tables (StutterAlignerClass::load_read sums run
-      // from the block's right end, so a longer block with the same tail only appends terms)
-      std::vector<int> ks;
-      for (int k = 0; k < A; k++) if (out.alleles[loc.hap_begin + k].realign) ks.push_back(k);
-      auto block_of = [&](int k) -> const std::string& { return sblk[side][str_opt_of[k]]; };
-      // alleles whose closed form is tabulated come first: they are the business of hs_str_kernel, the rest of hs_str_kernel_generic
-      auto kind_of = [&](int k){ return out.stropts[so_base + side*nopts[1] + str_opt_of[k]].kind; };
-      auto tabbed = [&](int k){ return kind_of(k) == 1; };
-      // (the STR options are ranked once — tabulated first, then by length, then by sequence — and the alleles sorted by their option's rank)
-      std::vector<int> opt_rank(nopts[1]);
+      // The rows of a flank block depend on the block and, through the homopolymer run that may cross the block boundary, on the
+      // STR block's first base and the run it starts (leading flank) or its last base and the run it ends (trailing flank) — never on
+      // more: the reference's extension stops after one non-empty neighbour (Haplotype.cpp:239-275).  The alleles of a locus mostly
+      // share flanks and motif, so the rows are built once per (flank option, boundary signature) and looked up afterwards.
+      const int o_lead = side ? o3[2] : o3[0], o_trail = side ? o3[0] : o3[2];
+      const int lead_len = O(side ? 2 : 0, o_lead).n;
+      const EndSig& es = S.end_sig[side][o3[1]];
+      SideView h; bool have_h = false;
+      auto need_h = [&](){
+        if (have_h) return;
+        if (!side){ h.s[0] = O(0, o3[0]); h.s[1] = S.sblk[0][o3[1]]; h.s[2] = O(2, o3[2]); }
+        else {
+          const Seq f0 = O(2, o3[2]), f2 = O(0, o3[0]);           // side order: [reversed right flank | reversed block | reversed left flank]
+          S.hbuf.resize((size_t)f0.n + f2.n);
+          char* p0 = S.hbuf.data(); char* p2 = p0 + f0.n;
+          for (int i = 0; i < f0.n; i++) p0[i] = f0.p[f0.n-1-i];
+          for (int i = 0; i < f2.n; i++) p2[i] = f2.p[f2.n-1-i];
+          h.s[0] = Seq{p0, f0.n}; h.s[1] = S.sblk[1][o3[1]]; h.s[2] = Seq{p2, f2.n};
+        }
+        index_side(h, S.run); have_h = true;
+      };
+      auto cached = [&](std::vector<RowsKey>& tab, const RowsKey& key, int bi, int u0) -> int {
+        for (const RowsKey& e : tab) if (e.opt == key.opt && e.c == key.c && e.run == key.run && e.aux == key.aux) return e.id;
+        need_h();
+        flank_rows_v(h, bi, u0, S.hl, S.rows);
+        RowsKey e = key; e.id = intern(S.rows);
+        tab.push_back(e);
+        return e.id;
+      };
+      const int side_changed = cb < 0 ? -1 : (side ? 2-cb : cb);
+      if (!reuse || side_changed <= 0) lead_id[side] = cached(S.lead_tab[side], RowsKey{o_lead, es.c_first, es.run_first, 0, 0}, 0, 0);
+      al.lead_rows[side]  = lead_id[side];
       {
-        std::vector<int> os(nopts[1]);
-        for (int o = 0; o < nopts[1]; o++) os[o] = o;
-        std::stable_sort(os.begin(), os.end(), [&](int x, int y){
-          static const int kind_rank[3] = {2, 0, 1};                  // tabulated, then piecewise, then the rest
-          const int tx = kind_rank[out.stropts[so_base + side*nopts[1] + x].kind], ty = kind_rank[out.stropts[so_base + side*nopts[1] + y].kind];
-          if (tx != ty) return tx < ty;
-          const std::string& a = sblk[side][x]; const std::string& b2 = sblk[side][y];
-          if (a.size() != b2.size()) return a.size() < b2.size();
-          return a < b2;
-        });
-        int rank = 0;
-        for (int i = 0; i < nopts[1]; i++){
-          if (i > 0 && sblk[side][os[i]] != sblk[side][os[i-1]]) rank++;        // equal sequences compare equal, as before
-          opt_rank[os[i]] = rank;
-        }
+        std::vector<int32_t>& ls = S.lead_sets[side];
+        size_t slot = std::find(ls.begin(), ls.end(), lead_id[side]) - ls.begin();
+        if (slot == ls.size()) ls.push_back(lead_id[side]);
+        al.lead_slot[side] = (int32_t)slot;
+        loc.lead_flank[side] = std::max(loc.lead_flank[side], (int32_t)lead_len);
       }
-      std::stable_sort(ks.begin(), ks.end(), [&](int x, int y){ return opt_rank[str_opt_of[x]] < opt_rank[str_opt_of[y]]; });
-      loc.order_off[side] = out.str_order.size();
-      loc.n_tab[side] = 0; loc.n_short[side] = 0; loc.n_pw[side] = 0;
-      loc.rec_off[side] = (int32_t)(out.grp_recs.size() / HS_GRP_REC_DWORDS);
-      loc.ndrow_off[side] = (int32_t)out.nd_rows.size(); loc.n_ndrows[side] = 0;
-      int fam_row0 = 0, fam_k = 0;                     // first row of the current family of alleles (blocks growing by one repeat unit), position in it
-      static const std::string no_block;
-      const std::string* prev_p = &no_block;
-      for (size_t i = 0; i < ks.size(); i++){
-        const std::string& prev = *prev_p;
-        const std::string& cur = block_of(ks[i]);
-        const bool first_of_kind = (i == 0) || (kind_of(ks[i]) != kind_of(ks[i-1]));
-        const bool chained = !first_of_kind && cur.size() >= prev.size() && cur.compare(cur.size() - prev.size(), prev.size(), prev) == 0;
-        // bit 29: a tabulated (hence periodic) block that extends the previous one by exactly one repeat unit: the read-end deletion
-        // sums of the previous allele move up one size (hs_str_kernel)
-        const bool one_unit = chained && tabbed(ks[i]) && (int)cur.size() == (int)prev.size() + period;
-        out.str_order.push_back(ks[i] | (chained ? (1 << 30) : 0) | (one_unit ? (1 << 29) : 0));
-        if (tabbed(ks[i])){
-          loc.n_tab[side]++;
-          {   // the position's record for hs_str_group_kernel_p (layout.h)
-            const hs_allele_t& al = out.alleles[loc.hap_begin + ks[i]];
-            const hs_stropt_t& so = out.stropts[al.str_opt[side]];
-            int32_t rec[HS_GRP_REC_DWORDS]; memset(rec, 0, sizeof rec);
-            rec[0] = (al.lead_slot[side] & 0x3ff) | (so.tab_len << 10) | (chained ? (1 << 30) : 0) | (one_unit ? (1 << 29) : 0);
-            rec[1] = al.re_ord; rec[2] = (so.tail_codes & 0xfff) | (so.B << 12); rec[3] = so.tab_off;
-            if (period <= HS_GRP_MAXP){
-              // rows of read-end deletion sums (layout.h hs_ndrow_t): a new family opens with five rows for the first allele's larger sizes
-              if (!one_unit){
-                fam_row0 = loc.n_ndrows[side]; fam_k = 0;
-                for (int m = 0; m < HS_MAXREP - 1; m++) out.nd_rows.push_back(hs_ndrow_t{ so.B + (m - HS_MAXREP)*period, so.tail_codes });
-                loc.n_ndrows[side] += HS_MAXREP - 1;
-              } else fam_k++;
-              out.nd_rows.push_back(hs_ndrow_t{ so.B - period, so.tail_codes });       // row fam_k + 5: this allele's size 0
-              loc.n_ndrows[side]++;
-              rec[4] = fam_row0 + fam_k + HS_MAXREP - 1;
-            }
-            for (int k = 0; k <= HS_MAXREP; k++) rec[8 + k] = (so.shape[k] & 0xffff) | (so.tab_base[k] << 16);
-            memcpy(rec + 16, out.f64pool.data() + so.f64_off, 20*sizeof(double));
-            memcpy(rec + 56, out.f64pool.data() + so.tab_off + 3*so.tab_len, sizeof(double));
-            out.grp_recs.insert(out.grp_recs.end(), rec, rec + HS_GRP_REC_DWORDS);
+      al.trail_rows[side] = cached(S.trail_tab[side], RowsKey{o_trail, es.c_last, es.run_last, lead_len, 0}, 2, lead_len + 1);
+      al.str_opt[side]    = so_base + side*nopts[1] + o3[1];
+    }
+    reuse = true;
+    out.alleles[allele_base + k] = al;
+  }
+
+  HS_LAP(3);
+  loc.n_re = n_realigned;
+  loc.n_lead[0] = S.lead_sets[0].size(); loc.n_lead[1] = S.lead_sets[1].size();
+  for (int side = 0; side < 2; side++){
+    // STR-kernel order: by STR option, options sorted by length; an option whose block (in side orientation) ends with the
+    // previous option's block continues that option's match/deletion tables (StutterAlignerClass::load_read sums run
+    // from the block's right end, so a longer block with the same tail only appends terms)
+    const std::vector<Seq>& blk = S.sblk[side];
+    const hs_stropt_t* so_side = out.stropts.data() + so_base + side*nopts[1];
+    auto block_of = [&](int k) -> const Seq& { return blk[S.str_opt_of[k]]; };
+    // alleles whose closed form is tabulated come first: they are the business of hs_str_kernel, the rest of hs_str_kernel_generic
+    auto kind_of = [&](int k){ return so_side[S.str_opt_of[k]].kind; };
+    auto tabbed = [&](int k){ return kind_of(k) == 1; };
+    // (the STR options are ranked once — tabulated first, then by length, then by sequence — and the alleles sorted by their option's rank)
+    S.opt_rank.resize(nopts[1]); S.os.resize(nopts[1]);
+    for (int o = 0; o < nopts[1]; o++) S.os[o] = o;
+    stable_small_sort(S.os.data(), nopts[1], [&](int x, int y){
+      static const int kind_rank[3] = {2, 0, 1};                  // tabulated, then piecewise, then the rest
+      const int tx = kind_rank[so_side[x].kind], ty = kind_rank[so_side[y].kind];
+      if (tx != ty) return tx < ty;
+      if (blk[x].n != blk[y].n) return blk[x].n < blk[y].n;
+      return seq_less(blk[x], blk[y]);
+    });
+    int n_rank = 0;
+    for (int i = 0; i < nopts[1]; i++){
+      if (i > 0 && !seq_eq(blk[S.os[i]], blk[S.os[i-1]])) n_rank++;        // equal sequences compare equal, as before
+      S.opt_rank[S.os[i]] = n_rank;
+    }
+    n_rank++;
+    // the realigned alleles sorted by their option's rank, ties in allele order (a counting sort)
+    S.cnt.assign((size_t)n_rank + 1, 0);
+    for (int k = 0; k < A; k++) if (out.alleles[allele_base + k].realign) S.cnt[S.opt_rank[S.str_opt_of[k]] + 1]++;
+    for (int r = 0; r < n_rank; r++) S.cnt[r+1] += S.cnt[r];
+    S.ks.resize(n_realigned);
+    for (int k = 0; k < A; k++) if (out.alleles[allele_base + k].realign) S.ks[S.cnt[S.opt_rank[S.str_opt_of[k]]]++] = k;
+    const std::vector<int32_t>& ks = S.ks;
+    loc.order_off[side] = out.str_order.size();
+    loc.n_tab[side] = 0; loc.n_short[side] = 0; loc.n_pw[side] = 0;
+    loc.rec_off[side] = (int32_t)(out.grp_recs.size() / HS_GRP_REC_DWORDS);
+    loc.ndrow_off[side] = (int32_t)out.nd_rows.size(); loc.n_ndrows[side] = 0;
+    int fam_row0 = 0, fam_k = 0;                     // first row of the current family of alleles (blocks growing by one repeat unit), position in it
+    Seq prev{NULL, 0};
+    for (size_t i = 0; i < ks.size(); i++){
+      const Seq& cur = block_of(ks[i]);
+      const bool first_of_kind = (i == 0) || (kind_of(ks[i]) != kind_of(ks[i-1]));
+      const bool chained = !first_of_kind && cur.n >= prev.n && memcmp(cur.p + (cur.n - prev.n), prev.p, (size_t)prev.n) == 0;
+      // bit 29: a tabulated (hence periodic) block that extends the previous one by exactly one repeat unit: the read-end deletion
+      // sums of the previous allele move up one size (hs_str_kernel)
+      const bool one_unit = chained && tabbed(ks[i]) && cur.n == prev.n + period;
+      out.str_order.push_back(ks[i] | (chained ? (1 << 30) : 0) | (one_unit ? (1 << 29) : 0));
+      if (tabbed(ks[i])){
+        loc.n_tab[side]++;
+        {   // the position's record for hs_str_group_kernel_p (layout.h)
+          const hs_allele_t& al = out.alleles[allele_base + ks[i]];
+          const hs_stropt_t& so = out.stropts[al.str_opt[side]];
+          const size_t rec_at = out.grp_recs.size();
+          out.grp_recs.resize(rec_at + HS_GRP_REC_DWORDS);          // (value-initialised: the unused dwords are zero)
+          int32_t* rec = out.grp_recs.data() + rec_at;
+          rec[0] = (al.lead_slot[side] & 0x3ff) | (so.tab_len << 10) | (chained ? (1 << 30) : 0) | (one_unit ? (1 << 29) : 0);
+          rec[1] = al.re_ord; rec[2] = (so.tail_codes & 0xfff) | (so.B << 12); rec[3] = so.tab_off;
+          if (period <= HS_GRP_MAXP){
+            // rows of read-end deletion sums (layout.h hs_ndrow_t): a new family opens with five rows for the first allele's larger sizes
+            if (!one_unit){
+              fam_row0 = loc.n_ndrows[side]; fam_k = 0;
+              for (int m = 0; m < HS_MAXREP - 1; m++) out.nd_rows.push_back(hs_ndrow_t{ so.B + (m - HS_MAXREP)*period, so.tail_codes });
+              loc.n_ndrows[side] += HS_MAXREP - 1;
+            } else fam_k++;
+            out.nd_rows.push_back(hs_ndrow_t{ so.B - period, so.tail_codes });       // row fam_k + 5: this allele's size 0
+            loc.n_ndrows[side]++;
+            rec[4] = fam_row0 + fam_k + HS_MAXREP - 1;
           }
-          if (period > HS_GRP_MAXP) loc.n_short[side]++;              // no instantiation of hs_str_group_kernel_p for this period
+          for (int k = 0; k <= HS_MAXREP; k++) rec[8 + k] = (so.shape[k] & 0xffff) | (so.tab_base[k] << 16);
+          memcpy(rec + 16, out.f64pool.data() + so.f64_off, 20*sizeof(double));
+          memcpy(rec + 56, out.f64pool.data() + so.tab_off + 3*so.tab_len, sizeof(double));
         }
-        if (kind_of(ks[i]) != 0) loc.n_pw[side]++;      // (kinds 1 and 2 come first: n_pw counts both, the piecewise ones are [n_tab, n_pw))
-        prev_p = &cur;
+        if (period > HS_GRP_MAXP) loc.n_short[side]++;              // no instantiation of hs_str_group_kernel_p for this period
+      }
+      if (kind_of(ks[i]) != 0) loc.n_pw[side]++;      // (kinds 1 and 2 come first: n_pw counts both, the piecewise ones are [n_tab, n_pw))
+      prev = cur;
+    }
+  }
+  HS_LAP(4);
+  for (int side = 0; side < 2; side++){      // alleles sharing a trailing-flank rowset run as lanes of one wavefront (<= 64 each)
+    // groups in ascending rowset order, members in allele order: (rowset, allele) pairs, sorted
+    S.pairs.clear();
+    for (int k = 0; k < A; k++){
+      const hs_allele_t& al = out.alleles[allele_base + k];
+      if (al.realign) S.pairs.push_back(((uint64_t)(uint32_t)al.trail_rows[side] << 32) | (uint32_t)k);
+    }
+    bool sorted = true;
+    for (size_t i = 1; i < S.pairs.size() && sorted; i++) sorted = S.pairs[i-1] < S.pairs[i];
+    if (!sorted) std::sort(S.pairs.begin(), S.pairs.end());
+    loc.tg_begin[side] = out.tgroups.size();
+    for (size_t i0 = 0; i0 < S.pairs.size(); ){
+      size_t i1 = i0;
+      while (i1 < S.pairs.size() && (S.pairs[i1] >> 32) == (S.pairs[i0] >> 32)) i1++;
+      for (size_t m0 = i0; m0 < i1; m0 += 64){
+        hs_tgroup_t g; g.rowset = (int32_t)(S.pairs[i0] >> 32); g.member_off = out.tmembers.size(); g.pad = 0;
+        g.n_members = (int32_t)std::min<size_t>(64, i1 - m0);
+        for (int m = 0; m < g.n_members; m++) out.tmembers.push_back((int32_t)(uint32_t)S.pairs[m0 + m]);
+        out.tgroups.push_back(g);
+      }
+      i0 = i1;
+    }
+    loc.tg_count[side] = out.tgroups.size() - loc.tg_begin[side];
+  }
+  HS_LAP(5);
+  for (int side = 0; side < 2; side++){
+    out.lead_off.push_back((int32_t)out.lead_ids.size());
+    out.lead_ids.insert(out.lead_ids.end(), S.lead_sets[side].begin(), S.lead_sets[side].end());
+  }
+  for (int r = loc.read_begin; r < loc.read_begin + loc.n_reads; r++){
+    hs_read_t rd;
+    rd.base_off = b->base_off[r]; rd.len = b->base_off[r+1]-b->base_off[r]; rd.locus = l; rd.seed = -1;
+    const bool realign = b->realign_read ? b->realign_read[r] != 0 : true;
+    sh.realign_read[r] = realign ? 1 : 0;
+    if (realign){
+      const bool given = seed_in && seed_in[r] != HIPSTR_SEED_AUTO;
+      const int s = given ? seed_in[r] : calc_seed_base(b, l, r);
+      if (s == -2){ err = "Invalid alignment seed or unrecognized CIGAR char (HapAligner.cpp:309,316)"; return 1; }
+      if (given && s != -1 && (s < 1 || s > rd.len - 2)){ err = "seed base must leave at least one base on either side (HapAligner.cpp:316)"; return 1; }
+      rd.seed = s;
+      sh.seeds[r] = s;
+      if (s >= 0){
+        if (s > HS_MAX_SIDE_FWD || rd.len-s-1 > HS_MAX_SIDE_FWD){ err = "read side longer than 1024 bases is not supported"; return 1; }
+        out.active.push_back(r);
+        out.n_alignments += n_realigned;
+        out.max_read_len = std::max(out.max_read_len, rd.len);
       }
     }
-    HS_LAP(4);
-    for (int side = 0; side < 2; side++){      // alleles sharing a trailing-flank rowset run as lanes of one wavefront (<= 64 each)
-      std::map<int, std::vector<int> > by_rowset;
-      for (int k = 0; k < A; k++){
-        const hs_allele_t& al = out.alleles[loc.hap_begin + k];
-        if (al.realign) by_rowset[al.trail_rows[side]].push_back(k);
-      }
-      loc.tg_begin[side] = out.tgroups.size();
-      for (std::map<int, std::vector<int> >::iterator it = by_rowset.begin(); it != by_rowset.end(); ++it)
-        for (size_t m0 = 0; m0 < it->second.size(); m0 += 64){
-          hs_tgroup_t g; g.rowset = it->first; g.member_off = out.tmembers.size(); g.pad = 0;
-          g.n_members = (int32_t)std::min<size_t>(64, it->second.size() - m0);
-          out.tmembers.insert(out.tmembers.end(), it->second.begin() + m0, it->second.begin() + m0 + g.n_members);
-          out.tgroups.push_back(g);
-        }
-      loc.tg_count[side] = out.tgroups.size() - loc.tg_begin[side];
-    }
-    HS_LAP(5);
-    locus_leads.push_back(lead_sets[0]); locus_leads.push_back(lead_sets[1]);
-    for (int r = loc.read_begin; r < loc.read_begin + loc.n_reads; r++){
-      hs_read_t rd;
-      rd.base_off = b->base_off[r]; rd.len = b->base_off[r+1]-b->base_off[r]; rd.locus = l; rd.seed = -1;
-      const bool realign = b->realign_read ? b->realign_read[r] != 0 : true;
-      sh.realign_read[r] = realign ? 1 : 0;
-      if (realign){
-        const bool given = seed_in && seed_in[r] != HIPSTR_SEED_AUTO;
-        const int s = given ? seed_in[r] : calc_seed_base(b, l, r);
-        if (s == -2){ err = "Invalid alignment seed or unrecognized CIGAR char (HapAligner.cpp:309,316)"; return 1; }
-        if (given && s != -1 && (s < 1 || s > rd.len - 2)){ err = "seed base must leave at least one base on either side (HapAligner.cpp:316)"; return 1; }
-        rd.seed = s;
-        sh.seeds[r] = s;
-        if (s >= 0){
-          if (s > HS_MAX_SIDE_FWD || rd.len-s-1 > HS_MAX_SIDE_FWD){ err = "read side longer than 1024 bases is not supported"; return 1; }
-          out.active.push_back(r);
-          out.n_alignments += n_realigned;
-          out.max_read_len = std::max(out.max_read_len, rd.len);
-        }
-      }
-      sh.reads[r] = rd;
-    }
-    HS_LAP(6);
-    out.loci.push_back(loc);
-    return 0;
+    sh.reads[r] = rd;
+  }
+  HS_LAP(6);
+  out.loci.push_back(loc);
+  return 0;
 }
 
 // Sizes of the pools of a fragment = where the next fragment starts in the merged batch.
-struct FragBase { size_t loci, alleles, stropts, rowsets, rows, visits, f64, chars, active, realign_hap, order, tgroups, tmembers, leads, recs, ndrows; };
-static FragBase frag_sizes(const Prepared& f, size_t n_leads){
+struct FragBase { size_t loci, alleles, stropts, rowsets, rows, visits, f64, chars, active, realign_hap, order, tgroups, tmembers, leads, recs, ndrows, lead_ids; };
+static FragBase frag_sizes(const Prepared& f){
   return FragBase{ f.loci.size(), f.alleles.size(), f.stropts.size(), f.rowsets.size(), f.rows.size(), f.visits.size(), f.f64pool.size(), f.chars.size(),
-                   f.active.size(), f.realign_hap.size(), f.str_order.size(), f.tgroups.size(), f.tmembers.size(), n_leads, f.grp_recs.size() / HS_GRP_REC_DWORDS, f.nd_rows.size() };
+                   f.active.size(), f.realign_hap.size(), f.str_order.size(), f.tgroups.size(), f.tmembers.size(), f.lead_off.size(), f.grp_recs.size() / HS_GRP_REC_DWORDS, f.nd_rows.size(),
+                   f.lead_ids.size() };
 }
 
 // Copies fragment `f` to its place in `out` (whose pools are already sized), turning fragment-local pool offsets into batch-wide
 // ones.  Fragments write disjoint ranges: safe to run for several fragments at once.
-static void place_fragment(Prepared& out, Prepared& f, const FragBase& at, std::vector< std::vector<int> >& leads_out, std::vector< std::vector<int> >& leads_f){
+static void place_fragment(Prepared& out, Prepared& f, const FragBase& at){
   const int32_t allele_base = (int32_t)at.alleles, stropt_base = (int32_t)at.stropts, rowset_base = (int32_t)at.rowsets;
   const int32_t rows_base = (int32_t)at.rows, visits_base = (int32_t)at.visits, f64_base = (int32_t)at.f64;
   const int32_t chars_base = (int32_t)at.chars, tg_base = (int32_t)at.tgroups, tm_base = (int32_t)at.tmembers, order_base = (int32_t)at.order;
@@ -1024,15 +1174,73 @@ static void place_fragment(Prepared& out, Prepared& f, const FragBase& at, std::
     for (int q = 0; q < HS_MAXREP; q++) o.del_off[q] += visits_base;
   }
   for (hs_tgroup_t& g : f.tgroups){ g.rowset += rowset_base; g.member_off += tm_base; }
-  for (std::vector<int>& ls : leads_f) for (int& id : ls) id += rowset_base;
+  for (int32_t& id : f.lead_ids) id += rowset_base;
+  for (int32_t& o : f.lead_off) o += (int32_t)at.lead_ids;
 #define HS_PLACE(field, base) std::copy(f.field.begin(), f.field.end(), out.field.begin() + (base))
   HS_PLACE(loci, at.loci); HS_PLACE(alleles, at.alleles); HS_PLACE(stropts, at.stropts); HS_PLACE(rowsets, at.rowsets);
   HS_PLACE(active, at.active); HS_PLACE(realign_hap, at.realign_hap);
   HS_PLACE(str_order, at.order); HS_PLACE(tgroups, at.tgroups); HS_PLACE(tmembers, at.tmembers); HS_PLACE(nd_rows, at.ndrows);
+  HS_PLACE(lead_off, at.leads); HS_PLACE(lead_ids, at.lead_ids);
   // rows, visits, f64pool, chars stay in the fragment (Prepared::frags): the upload gathers them
 #undef HS_PLACE
-  for (size_t i = 0; i < leads_f.size(); i++) leads_out[at.leads + i].swap(leads_f[i]);
 }
+
+// ---- recycled storage (prep.h)
+namespace {
+#define HS_PREP_VECTORS(X) X(loci) X(alleles) X(stropts) X(rowsets) X(rows) X(visits) X(f64pool) X(chars) X(reads) X(active) X(seeds) X(realign_read) \
+  X(realign_hap) X(chunks) X(ws) X(lead_items) X(trail_items) X(str_items) X(tpack) X(str_order) X(nd_rows) X(grp_recs) X(tgroups) X(tmembers) X(lead_off) X(lead_ids)
+size_t prepared_capacity_bytes(const Prepared& p){
+  size_t n = 0;
+#define X(v) n += p.v.capacity()*sizeof(p.v[0]);
+  HS_PREP_VECTORS(X)
+#undef X
+  return n;
+}
+void clear_prepared(Prepared& p){          // back to the state of a fresh object, capacities kept
+#define X(v) p.v.clear();
+  HS_PREP_VECTORS(X)
+#undef X
+  p.frags.clear();
+  p.grp_nd_cap = 0; p.ws_mr_size = p.ws_lt_size = p.ws_lead_size = p.ws_col_size = p.ws_nd_size = 0;
+  p.max_side_len = 0; p.max_B = 1; p.n_out = 0; p.n_alignments = 0; p.max_read_len = 0; p.max_flank = 0;
+}
+struct PrepPool {
+  std::mutex m;
+  std::vector<Prepared> top, frag;        // top-level objects and fragments have different large vectors: two free lists
+  size_t bytes = 0, cap_bytes;
+  PrepPool(){
+    const char* e = getenv("HIPSTR_PREP_POOL_MIB");
+    cap_bytes = (size_t)(e ? std::max(0, atoi(e)) : 2048) << 20;
+  }
+  void put(std::vector<Prepared>& list, Prepared&& p){
+    const size_t n = prepared_capacity_bytes(p);
+    if (n == 0) return;
+    clear_prepared(p);
+    std::lock_guard<std::mutex> g(m);
+    if (bytes + n > cap_bytes) return;      // (p's storage is released by the caller's destructor)
+    bytes += n;
+    list.push_back(std::move(p));
+  }
+  bool take(std::vector<Prepared>& list, Prepared& into){
+    std::lock_guard<std::mutex> g(m);
+    if (list.empty()) return false;
+    into = std::move(list.back());
+    list.pop_back();
+    bytes -= std::min(bytes, prepared_capacity_bytes(into));
+    return true;
+  }
+};
+PrepPool& prep_pool(){ static PrepPool* p = new PrepPool(); return *p; }     // (never destroyed: host threads may recycle during process exit)
+}  // namespace
+
+void recycle_prepared(Prepared& p){
+  PrepPool& P = prep_pool();
+  for (Prepared& f : p.frags) P.put(P.frag, std::move(f));
+  p.frags.clear();
+  P.put(P.top, std::move(p));
+  Prepared empty; std::swap(p, empty);
+}
+void adopt_recycled(Prepared& p){ prep_pool().take(prep_pool().top, p); }
 
 int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int64_t ws_budget, const int32_t* seed_in){
   host_tables();
@@ -1048,7 +1256,6 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
   out.seeds.assign(n_reads_total, -1);
   out.realign_read.assign(n_reads_total, 1);
   out.reads.resize(n_reads_total);
-  std::vector< std::vector<int> > locus_leads;      // [2*locus + side] -> rowset ids by slot
   // per-locus starts in the option table and in the output, and a cost estimate to cut the loci into balanced fragments
   std::vector<int> opt_start(b->n_loci + 1, 0);
   std::vector<int64_t> out_off_v(b->n_loci + 1, 0), cost(b->n_loci + 1, 0);
@@ -1072,7 +1279,7 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
   int n_threads = std::min(host_threads(), std::max(1, b->n_loci / 4));
   if (n_threads <= 1){
     for (int l = 0; l < b->n_loci; l++)
-      if (prepare_locus(b, l, opt_start[l], sh, out, locus_leads, err)) return 1;
+      if (prepare_locus(b, l, opt_start[l], sh, out, err)) return 1;
   } else {
     // fragments of consecutive loci with near-equal cost, a few per thread so that a slow fragment does not stall the rest
     const int n_frag = std::min(b->n_loci, n_threads*4);
@@ -1081,19 +1288,19 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
       cut[f] = std::max(cut[f-1], (int)(std::lower_bound(cost.begin(), cost.end(), cost[b->n_loci]*f/n_frag) - cost.begin()));
     cut[n_frag] = b->n_loci;
     std::vector<Prepared> frag(n_frag);
-    std::vector< std::vector< std::vector<int> > > frag_leads(n_frag);
+    for (Prepared& f : frag) prep_pool().take(prep_pool().frag, f);      // recycled storage, if any (cleared)
     std::vector<std::string> frag_err(n_frag);
     std::vector<int> frag_rc(n_frag, 0);
     parallel_for(n_frag, n_threads, [&](int f){
       for (int l = cut[f]; l < cut[f+1] && !frag_rc[f]; l++)
-        frag_rc[f] = prepare_locus(b, l, opt_start[l], sh, frag[f], frag_leads[f], frag_err[f]);
+        frag_rc[f] = prepare_locus(b, l, opt_start[l], sh, frag[f], frag_err[f]);
     });
     lap("fragments", t_lap);
     for (int f = 0; f < n_frag; f++) if (frag_rc[f]){ err = frag_err[f]; return 1; }
     std::vector<FragBase> at(n_frag + 1);
     memset(&at[0], 0, sizeof(FragBase));
     for (int f = 0; f < n_frag; f++){
-      const FragBase sz = frag_sizes(frag[f], frag_leads[f].size());
+      const FragBase sz = frag_sizes(frag[f]);
       const size_t* a = (const size_t*)&at[f]; const size_t* z = (const size_t*)&sz; size_t* n = (size_t*)&at[f+1];
       for (size_t i = 0; i < sizeof(FragBase)/sizeof(size_t); i++) n[i] = a[i] + z[i];
       out.max_B = std::max(out.max_B, frag[f].max_B); out.max_flank = std::max(out.max_flank, frag[f].max_flank);
@@ -1102,12 +1309,12 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
     const FragBase& tot = at[n_frag];
     out.loci.resize(tot.loci); out.alleles.resize(tot.alleles); out.stropts.resize(tot.stropts); out.rowsets.resize(tot.rowsets);
     out.active.resize(tot.active); out.realign_hap.resize(tot.realign_hap);
-    out.str_order.resize(tot.order); out.tgroups.resize(tot.tgroups); out.tmembers.resize(tot.tmembers); locus_leads.resize(tot.leads);
+    out.str_order.resize(tot.order); out.tgroups.resize(tot.tgroups); out.tmembers.resize(tot.tmembers); out.lead_off.resize(tot.leads); out.lead_ids.resize(tot.lead_ids);
     out.nd_rows.resize(tot.ndrows);
-    parallel_for(n_frag, n_threads, [&](int f){ place_fragment(out, frag[f], at[f], locus_leads, frag_leads[f]); });
+    parallel_for(n_frag, n_threads, [&](int f){ place_fragment(out, frag[f], at[f]); });
     for (Prepared& f : frag){      // keep only the large pools of the fragments
       f.loci.clear(); f.alleles.clear(); f.stropts.clear(); f.rowsets.clear(); f.active.clear(); f.realign_hap.clear(); f.str_order.clear();
-      f.tgroups.clear(); f.tmembers.clear(); f.nd_rows.clear();
+      f.tgroups.clear(); f.tmembers.clear(); f.nd_rows.clear(); f.lead_off.clear(); f.lead_ids.clear();
     }
     out.frags = std::move(frag);
   }
@@ -1125,35 +1332,58 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
     // side (sorted by side length, so that packed reads finish together) share one wavefront
     ch.trail_begin = out.trail_items.size();
     ch.str_begin = out.str_items.size();
-    // the (locus, range of active reads) runs of this chunk; their items are built independently (host threads) and appended
-    // in locus order with their offsets into the packed-read table rebased
-    struct Run { int a0, a1; std::vector<hs_item_t> lead, trail, str; std::vector<int32_t> tpack; int nd_cap = 0, n_long = 0; };
+    // the (locus, range of active reads) runs of this chunk; their items are built in blocks of consecutive runs (host threads), each
+    // block into its own buffers, and appended in locus order with their offsets into the packed-read table rebased
+    struct Run { int a0, a1; };
     std::vector<Run> runs;
     for (int a0 = ch.active_begin; a0 < active_end; ){
       const int locus = out.reads[out.active[a0]].locus;
       int a1 = a0;
       while (a1 < active_end && out.reads[out.active[a1]].locus == locus) a1++;
-      runs.push_back(Run{a0, a1, {}, {}, {}, {}, 0, 0});
+      runs.push_back(Run{a0, a1});
       a0 = a1;
     }
-    parallel_for((int)runs.size(), runs.size() >= 16 ? host_threads() : 1, [&](int ri){
-      Run& R = runs[ri];
-      const int a0 = R.a0, a1 = R.a1;
+    lap("plan:runs", t_lap);
+    struct Blk { std::vector<hs_item_t> lead, trail, str; std::vector<int32_t> tpack; int nd_cap = 0, n_long = 0; };
+    const int RUNS_PER_BLK = 64;
+    // one thread (a small batch, or a stream worker on a small allowance): the items go straight to the batch's arrays — one block whose
+    // vectors ARE the batch's (entries of the packed-read table are then batch-wide indices already)
+    const bool direct = (runs.size() < 16 || host_threads() == 1);
+    const int n_blk = direct ? 1 : (int)((runs.size() + RUNS_PER_BLK - 1) / RUNS_PER_BLK);
+    std::vector<Blk> blks(n_blk);
+    if (direct){ blks[0].lead.swap(out.lead_items); blks[0].trail.swap(out.trail_items); blks[0].str.swap(out.str_items); blks[0].tpack.swap(out.tpack); }
+    parallel_for(n_blk, direct ? 1 : host_threads(), [&](int bi){
+      Blk& R = blks[bi];
+      struct Bin { int cols, n; int m[16]; };
+      thread_local std::vector<int> order, lens, slen, cnt;
+      thread_local std::vector<Bin> bins;
+      const size_t r_lo = direct ? 0 : (size_t)bi*RUNS_PER_BLK, r_hi = direct ? runs.size() : std::min(runs.size(), r_lo + RUNS_PER_BLK);
+      for (size_t ri = r_lo; ri < r_hi; ri++){
+      const int a0 = runs[ri].a0, a1 = runs[ri].a1, n_run = a1 - a0;
       const int locus = out.reads[out.active[a0]].locus;
       const hs_locus_t& loc = out.loci[locus];
       for (int s = 0; s < 2; s++){
-        std::vector<int> order;
-        for (int a = a0; a < a1; a++) order.push_back(a);
-        auto side_len = [&](int a){ const hs_read_t& r = out.reads[out.active[a]]; return s ? r.len - r.seed - 1 : r.seed; };
-        std::stable_sort(order.begin(), order.end(), [&](int x, int y){ return side_len(x) < side_len(y); });
+        // the run's reads by side length, ties in read order: a counting sort (side lengths are at most HS_MAX_SIDE_FWD)
+        lens.resize(n_run); order.resize(n_run); slen.resize(n_run);
+        int maxk = 0;
+        for (int a = a0; a < a1; a++){
+          const hs_read_t& r = out.reads[out.active[a]];
+          const int k = s ? r.len - r.seed - 1 : r.seed;
+          lens[a - a0] = k; maxk = std::max(maxk, k);
+        }
+        cnt.assign((size_t)maxk + 2, 0);
+        for (int i = 0; i < n_run; i++) cnt[lens[i] + 1]++;
+        for (int k = 0; k <= maxk; k++) cnt[k + 1] += cnt[k];
+        for (int i = 0; i < n_run; i++){ const int at = cnt[lens[i]]++; order[at] = a0 + i; slen[at] = lens[i]; }
+        auto side_len_at = [&](int i){ return slen[i]; };
         // leading-flank items: lanes = reads (sorted by side length, so that the lanes of a wavefront finish together), one item per
         // distinct leading flank of the locus and side
-        const std::vector<int>& ls = locus_leads[2*locus + s];
-        for (size_t slot = 0; slot < ls.size(); slot++)
-          for (size_t i = 0; i < order.size(); i += 64){
+        const int32_t* ls = out.lead_ids.data() + out.lead_off[2*locus + s];
+        for (int slot = 0; slot < loc.n_lead[s]; slot++)
+          for (int i = 0; i < n_run; i += 64){
             hs_item_t it; it.side = s | ((int32_t)slot << 1); it.rowset = ls[slot];
             it.active = (int32_t)R.tpack.size();
-            it.slot = (int32_t)std::min<size_t>(64, order.size() - i);
+            it.slot = (int32_t)std::min(64, n_run - i);
             R.tpack.insert(R.tpack.end(), order.begin() + i, order.begin() + i + it.slot);
             R.lead.push_back(it);
           }
@@ -1163,22 +1393,21 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
         if (loc.n_pw[s] > 0){
           const int period = out.stropts[out.alleles[loc.hap_begin + (out.str_order[loc.order_off[s]] & 0x1fffffff)].str_opt[s]].period;
           const int max_reads = std::max(1, std::min(16, 2*HS_GRP_COLS / (21*period)));
-          struct Bin { int cols; std::vector<int> members; };
-          std::vector<Bin> bins; size_t first_open = 0;
-          for (size_t i = order.size(); i-- > 0; ){
-            const int a = order[i], nc = side_len(a);
+          bins.clear(); size_t first_open = 0;
+          for (int i = n_run; i-- > 0; ){
+            const int a = order[i], nc = side_len_at(i);
             if (nc <= 0) continue;
             if (nc > HS_GRP_COLS){ R.n_long++; continue; }
-            size_t b = first_open;
-            for (; b < bins.size(); b++) if (bins[b].cols + nc <= HS_GRP_COLS && (int)bins[b].members.size() < max_reads) break;
-            if (b == bins.size()) bins.push_back(Bin{0, {}});
-            bins[b].cols += nc; bins[b].members.push_back(a);
-            while (first_open < bins.size() && (bins[first_open].cols >= HS_GRP_COLS || (int)bins[first_open].members.size() >= max_reads)) first_open++;
+            size_t bn = first_open;
+            for (; bn < bins.size(); bn++) if (bins[bn].cols + nc <= HS_GRP_COLS && bins[bn].n < max_reads) break;
+            if (bn == bins.size()){ bins.emplace_back(); bins.back().cols = 0; bins.back().n = 0; }
+            bins[bn].cols += nc; bins[bn].m[bins[bn].n++] = a;
+            while (first_open < bins.size() && (bins[first_open].cols >= HS_GRP_COLS || bins[first_open].n >= max_reads)) first_open++;
           }
           for (const Bin& bn : bins){
-            hs_item_t it; it.side = s; it.rowset = bn.cols; it.slot = (int32_t)bn.members.size();
+            hs_item_t it; it.side = s; it.rowset = bn.cols; it.slot = (int32_t)bn.n;
             it.active = (int32_t)R.tpack.size();
-            R.tpack.insert(R.tpack.end(), bn.members.begin(), bn.members.end());
+            R.tpack.insert(R.tpack.end(), bn.m, bn.m + bn.n);
             R.str.push_back(it);
             R.nd_cap = std::max(R.nd_cap, it.slot*36*period);
           }
@@ -1187,45 +1416,47 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
           const int nm = out.tgroups[loc.tg_begin[s] + g].n_members;
           int npad = 1; while (npad < nm) npad <<= 1;
           const int per_wave = 64 / npad;
-          for (size_t i = 0; i < order.size(); i += per_wave){
+          for (int i = 0; i < n_run; i += per_wave){
             hs_item_t it; it.side = s; it.slot = loc.tg_begin[s] + g;
             it.active = (int32_t)R.tpack.size();
-            it.rowset = (int32_t)std::min<size_t>(per_wave, order.size() - i);
+            it.rowset = (int32_t)std::min(per_wave, n_run - i);
             R.tpack.insert(R.tpack.end(), order.begin() + i, order.begin() + i + it.rowset);
             R.trail.push_back(it);
           }
         }
       }
+      }
     });
-    {   // append the runs' pieces in locus order: where every piece goes follows from the sizes, the copies are shared by the host threads
+    lap("plan:items", t_lap);
+    if (direct){
+      blks[0].lead.swap(out.lead_items); blks[0].trail.swap(out.trail_items); blks[0].str.swap(out.str_items); blks[0].tpack.swap(out.tpack);
+      out.grp_nd_cap = std::max(out.grp_nd_cap, blks[0].nd_cap); ch.n_long_sides += blks[0].n_long;
+    } else {   // append the blocks' pieces in locus order: where every piece goes follows from the sizes, the copies are shared by the host threads
       struct At { size_t tp, le, tr, st; };
-      std::vector<At> at(runs.size() + 1);
+      std::vector<At> at(blks.size() + 1);
       at[0] = At{ out.tpack.size(), out.lead_items.size(), out.trail_items.size(), out.str_items.size() };
-      for (size_t i = 0; i < runs.size(); i++){
-        const Run& R = runs[i];
+      for (size_t i = 0; i < blks.size(); i++){
+        const Blk& R = blks[i];
         at[i+1] = At{ at[i].tp + R.tpack.size(), at[i].le + R.lead.size(), at[i].tr + R.trail.size(), at[i].st + R.str.size() };
         out.grp_nd_cap = std::max(out.grp_nd_cap, R.nd_cap);
         ch.n_long_sides += R.n_long;
       }
-      const At& end = at[runs.size()];
+      const At& end = at[blks.size()];
       out.tpack.resize(end.tp); out.lead_items.resize(end.le); out.trail_items.resize(end.tr); out.str_items.resize(end.st);
-      const int nblk = (int)std::min<size_t>(runs.size(), (size_t)host_threads()*4);
-      parallel_for(nblk, runs.size() >= 64 ? host_threads() : 1, [&](int blk){
-        const size_t i0 = runs.size()*blk/nblk, i1 = runs.size()*(blk + 1)/nblk;
-        for (size_t i = i0; i < i1; i++){
-          Run& R = runs[i];
-          const int32_t base = (int32_t)at[i].tp;
-          for (hs_item_t& it : R.lead) it.active += base;
-          for (hs_item_t& it : R.trail) it.active += base;
-          for (hs_item_t& it : R.str) it.active += base;
-          std::copy(R.tpack.begin(), R.tpack.end(), out.tpack.begin() + at[i].tp);
-          std::copy(R.lead.begin(), R.lead.end(), out.lead_items.begin() + at[i].le);
-          std::copy(R.trail.begin(), R.trail.end(), out.trail_items.begin() + at[i].tr);
-          std::copy(R.str.begin(), R.str.end(), out.str_items.begin() + at[i].st);
-          std::vector<hs_item_t>().swap(R.lead); std::vector<hs_item_t>().swap(R.trail); std::vector<hs_item_t>().swap(R.str); std::vector<int32_t>().swap(R.tpack);
-        }
+      parallel_for((int)blks.size(), blks.size() >= 4 ? host_threads() : 1, [&](int i){
+        Blk& R = blks[i];
+        const int32_t base = (int32_t)at[i].tp;
+        for (hs_item_t& it : R.lead) it.active += base;
+        for (hs_item_t& it : R.trail) it.active += base;
+        for (hs_item_t& it : R.str) it.active += base;
+        std::copy(R.tpack.begin(), R.tpack.end(), out.tpack.begin() + at[i].tp);
+        std::copy(R.lead.begin(), R.lead.end(), out.lead_items.begin() + at[i].le);
+        std::copy(R.trail.begin(), R.trail.end(), out.trail_items.begin() + at[i].tr);
+        std::copy(R.str.begin(), R.str.end(), out.str_items.begin() + at[i].st);
+        std::vector<hs_item_t>().swap(R.lead); std::vector<hs_item_t>().swap(R.trail); std::vector<hs_item_t>().swap(R.str); std::vector<int32_t>().swap(R.tpack);
       });
     }
+    lap("plan:merge", t_lap);
     ch.trail_end = out.trail_items.size();
     ch.str_end = out.str_items.size();
     ch.lead_end = out.lead_items.size();
@@ -1303,6 +1534,7 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
     mr += need_mr; lt += need_lt; col += 3*(int64_t)(rd.len-1);
     ch.n_alignments += loc.n_re;
   }
+  lap("plan:ws", t_lap);
   flush((int)out.active.size());
   lap("plan", t_lap);
   return 0;

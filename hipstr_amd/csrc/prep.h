@@ -14,6 +14,7 @@ namespace hipstr {
 // min(hardware threads, 32)) and a loop that hands indices [0, n) to up to max_threads threads through a counter.
 int host_threads();
 void set_host_threads(int n);      // 0 = back to the default
+void set_thread_budget(int n);     // the calling thread's own share (what host_threads() returns on it); 0 = none: a stream's workers split the host threads among themselves
 void parallel_for(int n, int max_threads, const std::function<void(int)>& fn);
 
 // Constant tables the reference keeps in globals; computed once with the host libm so they
@@ -65,6 +66,7 @@ struct Prepared {
  std::vector<hs_ndrow_t>  nd_rows;         // row descriptors of the read-end deletion sums per locus side (layout.h); a small pool
   std::vector<int32_t>    grp_recs;        // HS_GRP_REC_DWORDS dwords per tabulated position of a side's order (layout.h); a large pool like rows / f64pool
   std::vector<hs_tgroup_t> tgroups;
+  std::vector<int32_t>    lead_off, lead_ids;   // host only: the distinct leading-flank rowsets of locus l, side s, by slot = lead_ids[lead_off[2 l + s] ...], hs_locus_t::n_lead[s] of them
   std::vector<int32_t>    tmembers;
   int64_t ws_mr_size = 0, ws_lt_size = 0, ws_lead_size = 0, ws_col_size = 0, ws_nd_size = 0;   // doubles, max over chunks
   int32_t max_side_len = 0;
@@ -84,6 +86,13 @@ struct Prepared {
   size_t n_recs() const { size_t n = grp_recs.size(); for (const Prepared& f : frags) n += f.grp_recs.size(); return n; }
 };
 
+// The tables of a batch are tens to hundreds of megabytes of std::vector storage that every batch would otherwise take fresh from the
+// kernel (page faults: a quarter to a half of the preparation's CPU time).  recycle_prepared hands the storage of a finished batch —
+// the object's own vectors and those of its fragments — to a pool (bounded: HIPSTR_PREP_POOL_MIB, default 2048); prepare_batch draws
+// its fragments from it and adopt_recycled lets a fresh top-level object start with pooled capacity.  `p` is left empty.
+void recycle_prepared(Prepared& p);
+void adopt_recycled(Prepared& p);
+
 // Returns 0 on success; otherwise fills err.
 // seed_in: optional [n_reads] seeds chosen by the caller (HapAligner::process_read's seed_base argument, HapAligner.h:83);
 // HIPSTR_SEED_AUTO entries are computed with calc_seed_base.
@@ -92,7 +101,9 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
 // Returns 0 if prepare_batch would accept the batch; otherwise its error message in err.
 int check_batch(const hipstr_batch_t* b, std::string& err);
 void prep_profile_print();
-int check_locus(const hipstr_batch_t* b, int locus, int* opt_cursor_io, std::string& err);      // one locus of it; the cursor into opt_off is advanced
+// one locus of it; the cursor into opt_off is advanced.  seeds_out (optional, indexed by the batch's read index): the seed bases the check computed anyway
+// (HIPSTR_SEED_AUTO for reads that are not realigned), so that prepare_batch does not walk the CIGARs a second time
+int check_locus(const hipstr_batch_t* b, int locus, int* opt_cursor_io, std::string& err, int32_t* seeds_out = NULL);
 
 // HapAligner::calc_seed_base (HapAligner.cpp:238-318).  Returns -2 on the inputs the reference dies on.
 int calc_seed_base(const hipstr_batch_t* b, int locus, int read);

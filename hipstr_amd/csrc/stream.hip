@@ -29,20 +29,56 @@
 
 namespace {
 
+// A growing byte buffer in pinned host memory (from the context's block cache; plain malloc without a context): the reads' bases and
+// qualities of a stream batch are copied ONCE, from the caller's arrays into it, and travel to the device from where they lie.
+struct PinBuf {
+  hipstr::Ctx* ctx = NULL; char* p = NULL; size_t n = 0, cap = 0;
+  PinBuf(){}
+  PinBuf(const PinBuf&) = delete; PinBuf& operator=(const PinBuf&) = delete;
+  ~PinBuf(){ drop(); }
+  void drop(){ if (p){ if (ctx) hipstr::pin_free(ctx, p); else free(p); } p = NULL; n = cap = 0; }
+  bool reserve(size_t want){
+    if (want <= cap) return true;
+    const size_t nc = std::max<size_t>(std::max(want, cap + cap/2), (size_t)1 << 16);
+    if (ctx) hipstr::api_bind(ctx);
+    char* q = ctx ? (char*)hipstr::pin_alloc(ctx, nc) : (char*)malloc(nc);
+    if (!q) return false;
+    if (n) memcpy(q, p, n);
+    if (p){ if (ctx) hipstr::pin_free(ctx, p); else free(p); }
+    p = q; cap = nc;
+    return true;
+  }
+  char* grow(size_t add){ if (!reserve(n + add)) return NULL; char* at = p + n; n += add; return at; }
+  size_t size() const { return n; }
+  const char* data() const { return p ? p : ""; }
+};
+
 // A batch the library owns: deep copies of the submitted arrays, concatenated.
 struct OwnedBatch {
   std::vector<int32_t> blk_start, blk_end, blk_nopts, period, opt_off, hap_off, read_off, base_off, read_start, cigar_off, cigar_len;
+  std::vector<int32_t> seed;            // per read: the seed base the submission's check computed (HIPSTR_SEED_AUTO where it did not)
   std::vector<double> stutter;
   std::vector<uint8_t> realign_hap, realign_read;
-  std::string seq, bases, quals, cigar_op;
+  std::string seq, cigar_op;
+  PinBuf bases, quals;
   hipstr_batch_t view;
   struct Ticket { int64_t id; int32_t l0, l1, r0, r1; int64_t out0, out1; };
   std::vector<Ticket> tickets;
   int64_t n_out = 0, work = 0;          // doubles of output; (reads x haplotypes) submitted
-  OwnedBatch(){ opt_off.push_back(0); hap_off.push_back(0); read_off.push_back(0); base_off.push_back(0); cigar_off.push_back(0); }
+  explicit OwnedBatch(hipstr::Ctx* pin_ctx = NULL){ bases.ctx = pin_ctx; quals.ctx = pin_ctx; reset(); }
+  // empty again, storage kept (the stream recycles its batches: their vectors and pinned buffers are page-faulted and registered once)
+  void reset(){
+    blk_start.clear(); blk_end.clear(); blk_nopts.clear(); period.clear(); opt_off.clear(); hap_off.clear(); read_off.clear(); base_off.clear();
+    read_start.clear(); cigar_off.clear(); cigar_len.clear(); seed.clear(); stutter.clear(); realign_hap.clear(); realign_read.clear();
+    seq.clear(); cigar_op.clear(); bases.n = 0; quals.n = 0; tickets.clear(); n_out = 0; work = 0;
+    opt_off.push_back(0); hap_off.push_back(0); read_off.push_back(0); base_off.push_back(0); cigar_off.push_back(0);
+  }
+  void add_seeds(const int32_t* seeds, int r0, int r1){        // seeds: indexed by the caller's read index, or NULL
+    if (seeds) seed.insert(seed.end(), seeds + r0, seeds + r1); else seed.insert(seed.end(), (size_t)(r1 - r0), HIPSTR_SEED_AUTO);
+  }
 
   // 0 or an error message
-  const char* append(const hipstr_batch_t* b, int64_t ticket){
+  const char* append(const hipstr_batch_t* b, int64_t ticket, const int32_t* seeds = NULL){
     if (b->n_loci < 0) return "negative locus count";
     const int n = b->n_loci;
     int64_t n_opts = 0;
@@ -65,17 +101,20 @@ struct OwnedBatch {
     }
     if (b->realign_hap) realign_hap.insert(realign_hap.end(), b->realign_hap, b->realign_hap + n_haps); else realign_hap.insert(realign_hap.end(), n_haps, 1);
     for (int r = 1; r <= n_reads; r++){ base_off.push_back(base0 + b->base_off[r]); cigar_off.push_back(cig0 + b->cigar_off[r]); }
-    bases.append(b->bases, n_bases); quals.append(b->quals, n_bases);
+    { char* pb = bases.grow((size_t)n_bases); char* pq = quals.grow((size_t)n_bases);
+      if (!pb || !pq) return "out of pinned host memory for the reads";
+      memcpy(pb, b->bases, (size_t)n_bases); memcpy(pq, b->quals, (size_t)n_bases); }
     read_start.insert(read_start.end(), b->read_start, b->read_start + n_reads);
     cigar_op.append(b->cigar_op, n_cig); cigar_len.insert(cigar_len.end(), b->cigar_len, b->cigar_len + n_cig);
     if (b->realign_read) realign_read.insert(realign_read.end(), b->realign_read, b->realign_read + n_reads); else realign_read.insert(realign_read.end(), n_reads, 1);
+    add_seeds(seeds, 0, n_reads);
     t.out1 = n_out;
     tickets.push_back(t);
     return NULL;
   }
   // Locus l of `b` (whose first block option is opt0 in opt_off) as a submission of its own: what append() does for a one-locus batch,
   // straight from the caller's arrays.
-  const char* append_locus(const hipstr_batch_t* b, int l, int opt0, int64_t ticket){
+  const char* append_locus(const hipstr_batch_t* b, int l, int opt0, int64_t ticket, const int32_t* seeds = NULL){
     const int nopt = b->blk_nopts[3*l] + b->blk_nopts[3*l+1] + b->blk_nopts[3*l+2];
     const int r0 = b->read_off[l], r1 = b->read_off[l+1], h0 = b->hap_off[l], h1 = b->hap_off[l+1];
     const int32_t s0 = b->opt_off[opt0], s1 = b->opt_off[opt0 + nopt], b0 = b->base_off[r0], b1 = b->base_off[r1], c0 = b->cigar_off[r0], c1 = b->cigar_off[r1];
@@ -93,10 +132,13 @@ struct OwnedBatch {
     n_out += P*A; work += P*A;
     if (b->realign_hap) realign_hap.insert(realign_hap.end(), b->realign_hap + h0, b->realign_hap + h1); else realign_hap.insert(realign_hap.end(), (size_t)A, 1);
     for (int r = r0 + 1; r <= r1; r++){ base_off.push_back(base0 + b->base_off[r]); cigar_off.push_back(cig0 + b->cigar_off[r]); }
-    bases.append(b->bases + b0, b1 - b0); quals.append(b->quals + b0, b1 - b0);
+    { char* pb = bases.grow((size_t)(b1 - b0)); char* pq = quals.grow((size_t)(b1 - b0));
+      if (!pb || !pq) return "out of pinned host memory for the reads";
+      memcpy(pb, b->bases + b0, (size_t)(b1 - b0)); memcpy(pq, b->quals + b0, (size_t)(b1 - b0)); }
     read_start.insert(read_start.end(), b->read_start + r0, b->read_start + r1);
     cigar_op.append(b->cigar_op + c0, c1 - c0); cigar_len.insert(cigar_len.end(), b->cigar_len + c0, b->cigar_len + c1);
     if (b->realign_read) realign_read.insert(realign_read.end(), b->realign_read + r0, b->realign_read + r1); else realign_read.insert(realign_read.end(), (size_t)P, 1);
+    add_seeds(seeds, r0, r1);
     t.out1 = n_out;
     tickets.push_back(t);
     return NULL;
@@ -104,7 +146,7 @@ struct OwnedBatch {
   // Loci [l0, l1) of `b`, every one a submission of its own with consecutive tickets from ticket0: what append_locus does l1 - l0
   // times, but the loci of a batch lie next to each other in every array, so each pool takes ONE copy (the reads' bases and qualities —
   // 12 KB per 40-read locus — spread over the host threads) and the offset arrays one rebasing pass.  opt0[l] = first block option of locus l.
-  const char* append_run(const hipstr_batch_t* b, int l0, int l1, const int* opt0, int64_t ticket0, std::vector< std::pair<int64_t,int64_t> >& sizes){
+  const char* append_run(const hipstr_batch_t* b, int l0, int l1, const int* opt0, int64_t ticket0, std::vector< std::pair<int64_t,int64_t> >& sizes, const int32_t* seeds = NULL){
     const int n = l1 - l0;
     const int r0 = b->read_off[l0], r1 = b->read_off[l1], h0 = b->hap_off[l0], h1 = b->hap_off[l1];
     const int32_t s0 = b->opt_off[opt0[l0]], s1 = b->opt_off[opt0[l1]], b0 = b->base_off[r0], b1 = b->base_off[r1], c0 = b->cigar_off[r0], c1 = b->cigar_off[r1];
@@ -112,6 +154,7 @@ struct OwnedBatch {
     if ((int64_t)bases.size() + (b1 - b0) > INT32_MAX || (int64_t)seq.size() + (s1 - s0) > INT32_MAX) return "pending batch exceeds 2 GiB of bases";
     for (int l = l0; l < l1; l++)                       // (nothing is appended unless everything can be)
       if (b->read_off[l+1] < b->read_off[l] || b->hap_off[l+1] - b->hap_off[l] < 1) return "inconsistent read_off / hap_off";
+    if (!bases.reserve(bases.size() + (size_t)(b1 - b0)) || !quals.reserve(quals.size() + (size_t)(b1 - b0))) return "out of pinned host memory for the reads";
     const int32_t loc_base = (int32_t)period.size();
     blk_start.insert(blk_start.end(), b->blk_start + 3*l0, b->blk_start + 3*l1); blk_end.insert(blk_end.end(), b->blk_end + 3*l0, b->blk_end + 3*l1);
     blk_nopts.insert(blk_nopts.end(), b->blk_nopts + 3*l0, b->blk_nopts + 3*l1); period.insert(period.end(), b->period + l0, b->period + l1);
@@ -134,17 +177,18 @@ struct OwnedBatch {
       for (int r = r0 + 1; r <= r1; r++){ base_off[at + (r - r0 - 1)] = base0 + b->base_off[r]; cigar_off[at + (r - r0 - 1)] = cig0 + b->cigar_off[r]; }
     }
     {
-      const size_t at = bases.size(), nb = (size_t)(b1 - b0);
-      bases.resize(at + nb); quals.resize(at + nb);
+      const size_t nb = (size_t)(b1 - b0);
+      char* pb = bases.grow(nb); char* pq = quals.grow(nb);          // (reserved above: cannot fail)
       const size_t CH = (size_t)1 << 20; const int n_ch = (int)((nb + CH - 1)/CH);
       hipstr::parallel_for(2*n_ch, nb > 4*CH ? hipstr::host_threads() : 1, [&](int i){
         const size_t o = (size_t)(i >> 1)*CH, m = std::min(CH, nb - o);
-        memcpy(((i & 1) ? &quals[0] : &bases[0]) + at + o, ((i & 1) ? b->quals : b->bases) + b0 + o, m);
+        memcpy(((i & 1) ? pq : pb) + o, ((i & 1) ? b->quals : b->bases) + b0 + o, m);
       });
     }
     read_start.insert(read_start.end(), b->read_start + r0, b->read_start + r1);
     cigar_op.append(b->cigar_op + c0, c1 - c0); cigar_len.insert(cigar_len.end(), b->cigar_len + c0, b->cigar_len + c1);
     if (b->realign_read) realign_read.insert(realign_read.end(), b->realign_read + r0, b->realign_read + r1); else realign_read.insert(realign_read.end(), (size_t)(r1 - r0), 1);
+    add_seeds(seeds, r0, r1);
     return NULL;
   }
   const hipstr_batch_t* finish(){
@@ -180,10 +224,12 @@ struct hipstr_stream {
   std::mutex m;
   std::condition_variable cv_work, cv_done, cv_slots;
   OwnedBatch* pending = NULL;
+  std::vector<OwnedBatch*> spare;  // retired batches, emptied: the next pending batch starts with their storage (vectors, pinned read buffers)
   std::deque<OwnedBatch*> ready;
   std::deque<InFlight*> flying;   // launched (or failed), in submission order
   int in_worker = 0;              // batches the worker has popped but not yet pushed to `flying`
   int waiting = 0;                // collectors blocked on a ticket that has not been launched yet
+  std::multiset<int64_t> wait_tickets;   // ... and the tickets they wait for
   int64_t next_ticket = 0, next_deliver = 0;      // next_deliver: the lowest ticket not collected yet
   std::set<int64_t> taken_ahead;                  // tickets above next_deliver that were collected out of order (hipstr_stream_take)
   std::vector< std::pair<int64_t,int64_t> > sizes;     // per ticket not yet delivered: (n_out, n_reads), indexed by ticket - sizes_base
@@ -198,8 +244,25 @@ namespace {
 
 void flush_locked(hipstr_stream* s);
 
-void worker_loop(hipstr_stream* s){
+// (with s->m held)
+OwnedBatch* new_batch_locked(hipstr_stream* s){
+  if (!s->spare.empty()){ OwnedBatch* ob = s->spare.back(); s->spare.pop_back(); return ob; }
+  return new OwnedBatch(s->ctx);
+}
+void retire_batch(hipstr_stream* s, OwnedBatch* ob){
+  ob->reset();
+  {
+    std::lock_guard<std::mutex> g(s->m);
+    if (!s->closing && (int)s->spare.size() < s->slots + 2){ s->spare.push_back(ob); return; }
+  }
+  delete ob;
+}
+
+void worker_loop(hipstr_stream* s, int n_workers){
   hipstr::api_bind(s->ctx);
+  // the workers prepare different batches at the same time: each takes its share of the host threads (one thread each on a two-core
+  // allowance — then a batch is prepared without fragments, merges or hand-overs to pool threads)
+  hipstr::set_thread_budget(std::max(1, hipstr::host_threads() / std::max(1, n_workers)));
   for (;;){
     OwnedBatch* ob = NULL;
     {
@@ -210,14 +273,22 @@ void worker_loop(hipstr_stream* s){
       auto have_work = [&]{ return !s->ready.empty() || (s->waiting > 0 && s->in_worker == 0 && s->pending && !s->pending->tickets.empty()); };
       // `slots` bounds the batches in flight — unless a collector waits for a ticket that is not launched yet while every slot is held
       // by batches with uncollected EARLIER tickets (tickets may be taken in any order): then the batch goes out all the same
-      s->cv_work.wait(g, [&]{ return s->closing || (have_work() && ((int)s->flying.size() + s->in_worker < s->slots || s->waiting > 0)); });
+      // (only for a batch that brings an awaited ticket closer: one whose first ticket is not beyond the latest awaited one — while the
+      //  awaited ticket sits in a batch another worker is still preparing, nothing overshoots)
+      auto next_first = [&]() -> int64_t {
+        if (!s->ready.empty()) return s->ready.front()->tickets.front().id;
+        if (s->pending && !s->pending->tickets.empty()) return s->pending->tickets.front().id;
+        return INT64_MAX;
+      };
+      auto may_overshoot = [&]{ return !s->wait_tickets.empty() && next_first() <= *s->wait_tickets.rbegin(); };
+      s->cv_work.wait(g, [&]{ return s->closing || (have_work() && ((int)s->flying.size() + s->in_worker < s->slots || may_overshoot())); });
       if (s->closing) return;
       if (s->ready.empty()) flush_locked(s);
       ob = s->ready.front(); s->ready.pop_front(); s->in_worker++;
     }
     InFlight* f = new InFlight(); f->ob = ob; f->taken.assign(ob->tickets.size(), 0);
     const auto t0 = std::chrono::steady_clock::now();
-    f->dev = hipstr::upload_on(s->ctx, ob->finish(), NULL, s->copy_stream, hipstr::ctx_stream(s->ctx));
+    f->dev = hipstr::upload_on(s->ctx, ob->finish(), ob->seed.data(), s->copy_stream, hipstr::ctx_stream(s->ctx), true);
     if (!f->dev){ f->failed = true; f->err = hipstr_last_error(); }
     else if (hipstr_hmm_align(f->dev, NULL) != 0 || hipstr::fetch_begin(f->dev, hipstr::ctx_stream(s->ctx), s->d2h_stream) != 0){
       f->failed = true; f->err = hipstr_last_error();
@@ -260,23 +331,30 @@ hipstr_stream_t* hipstr_stream_open(const hipstr_stream_opts_t* opts){
   // busy; with small loci (30x, ten alleles) the host side is what bounds the stream.
   int nw = 3;
   if (const char* e = getenv("HIPSTR_STREAM_WORKERS")){ const int v = atoi(e); if (v >= 1 && v <= 8) nw = v; }
-  for (int w = 0; w < nw; w++) s->workers.emplace_back(worker_loop, s);
+  for (int w = 0; w < nw; w++) s->workers.emplace_back(worker_loop, s, nw);
   return s;
 }
 
 int64_t hipstr_stream_submit(hipstr_stream_t* s, const hipstr_batch_t* loci){
   hipstr::ApiTimer prof_t(hipstr::PB_STREAM_SUBMIT);
   if (!s || !loci){ hipstr::api_fail("null argument"); return -1; }
-  {       // a submission that prepare_batch would refuse is turned away here, before it shares a batch with others
+  // a submission that prepare_batch would refuse is turned away here, before it shares a batch with others; the seed bases the check
+  // computes go along with the reads
+  thread_local std::vector<int32_t> seeds;
+  {
     std::string why;
-    if (hipstr::check_batch(loci, why)){ hipstr::api_fail(why); return -1; }
+    if (loci->n_loci < 0){ hipstr::api_fail("null or negative-size batch"); return -1; }
+    seeds.resize(loci->n_loci > 0 ? (size_t)std::max(0, loci->read_off[loci->n_loci]) : 0);
+    int cursor = 0;
+    for (int l = 0; l < loci->n_loci; l++)
+      if (hipstr::check_locus(loci, l, &cursor, why, seeds.data())){ hipstr::api_fail(why); return -1; }
   }
   std::lock_guard<std::mutex> g(s->m);
   if (s->closing){ hipstr::api_fail("stream is closing"); return -1; }
-  if (!s->pending) s->pending = new OwnedBatch();
+  if (!s->pending) s->pending = new_batch_locked(s);
   const int64_t ticket = s->next_ticket;
   const int64_t out_before = s->pending->n_out; const int32_t reads_before = s->pending->read_off.back();
-  if (const char* why = s->pending->append(loci, ticket)){ hipstr::api_fail(why); return -1; }
+  if (const char* why = s->pending->append(loci, ticket, seeds.data())){ hipstr::api_fail(why); return -1; }
   s->next_ticket++;
   s->sizes.push_back(std::make_pair(s->pending->n_out - out_before, (int64_t)(s->pending->read_off.back() - reads_before)));
   if (s->pending->work >= s->batch_work) flush_locked(s);
@@ -295,12 +373,13 @@ int hipstr_stream_submit_each(hipstr_stream_t* s, const hipstr_batch_t* loci, in
   for (int l = 0; l < n; l++){ int c = 0; for (int k = 0; k < 3; k++) c += std::max(0, loci->blk_nopts[3*l+k]); opt0[l+1] = opt0[l] + c; }
   std::atomic<int> first_bad(n);
   std::mutex why_m; std::string why; int why_l = n;
+  std::vector<int32_t> seeds(n > 0 ? (size_t)std::max(0, loci->read_off[n]) : 0);        // the checks compute every read's seed base: kept for the preparation
   const int CH = 128, n_ch = (n + CH - 1)/CH;
   hipstr::parallel_for(n_ch, n >= 4*CH ? hipstr::host_threads() : 1, [&](int c){
     for (int l = c*CH; l < std::min(n, (c+1)*CH); l++){
       if (l > first_bad.load(std::memory_order_relaxed)) return;
       int cur = opt0[l]; std::string w;
-      if (hipstr::check_locus(loci, l, &cur, w)){
+      if (hipstr::check_locus(loci, l, &cur, w, seeds.data())){
         std::lock_guard<std::mutex> g(why_m);
         if (l < why_l){ why_l = l; why = w; }
         int fb = first_bad.load(); while (l < fb && !first_bad.compare_exchange_weak(fb, l)){}
@@ -315,13 +394,13 @@ int hipstr_stream_submit_each(hipstr_stream_t* s, const hipstr_batch_t* loci, in
   for (int l0 = 0; l0 < n_ok_total; ){
     std::lock_guard<std::mutex> g(s->m);
     if (s->closing) return hipstr::api_fail("stream is closing");
-    if (!s->pending) s->pending = new OwnedBatch();
+    if (!s->pending) s->pending = new_batch_locked(s);
     int64_t w = s->pending->work; int l1 = l0;
     while (l1 < n_ok_total && l1 - l0 < 1024 && w < s->batch_work){
       w += (int64_t)(loci->read_off[l1+1] - loci->read_off[l1])*(loci->hap_off[l1+1] - loci->hap_off[l1]); l1++;
     }
     const int64_t ticket0 = s->next_ticket;
-    if (const char* w2 = s->pending->append_run(loci, l0, l1, opt0.data(), ticket0, s->sizes)) return hipstr::api_fail(w2);
+    if (const char* w2 = s->pending->append_run(loci, l0, l1, opt0.data(), ticket0, s->sizes, seeds.data())) return hipstr::api_fail(w2);
     s->next_ticket += l1 - l0;
     if (l0 == 0 && first_ticket) *first_ticket = ticket0;
     if (s->pending->work >= s->batch_work) flush_locked(s);
@@ -430,10 +509,10 @@ int hipstr_stream_take(hipstr_stream_t* s, int64_t ticket, double* aln_probs, in
       if (f) break;
       // not launched yet: tell the worker somebody is waiting (it sends the pending batch as soon as it is free), then wait for it
       if (s->closing) return hipstr::api_fail("stream is closing");
-      s->waiting++;
+      s->waiting++; s->wait_tickets.insert(ticket);
       s->cv_work.notify_one();
       s->cv_done.wait(g);
-      s->waiting--;
+      s->waiting--; s->wait_tickets.erase(s->wait_tickets.find(ticket));
       if (s->closing){ s->cv_done.notify_all(); return hipstr::api_fail("stream is closing"); }
     }
     if (f->taken[idx]) return hipstr::api_fail("ticket was collected already");
@@ -493,7 +572,7 @@ int hipstr_stream_take(hipstr_stream_t* s, int64_t ticket, double* aln_probs, in
   }
   if (retire){
     if (f->dev) hipstr::free_landed(f->dev, f->landed && !f->failed);
-    delete f->ob; delete f;
+    retire_batch(s, f->ob); delete f;
     s->cv_work.notify_one();           // a slot is free
   }
   return rc;
@@ -536,6 +615,8 @@ int hipstr_stream_close(hipstr_stream_t* s){
   hipstr::api_bind(s->ctx);
   for (InFlight* f : s->flying){ if (f->dev) hipstr::free_landed(f->dev, false); delete f->ob; delete f; }
   hipStreamSynchronize(s->copy_stream); hipStreamSynchronize(s->d2h_stream);
+  for (OwnedBatch* ob : s->spare) delete ob;
+  s->spare.clear();
   hipStreamDestroy(s->copy_stream); hipStreamDestroy(s->d2h_stream);
   delete s;
   return 0;

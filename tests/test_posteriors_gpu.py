@@ -96,3 +96,35 @@ def test_custom_prior_array(hmm, oracle):
                         log_prior=prior)
     got = _run(hmm, pb); want = capi.run_posteriors(oracle, "oracle_", pb)
     assert _finite_close(got[0], want[0]) and _finite_close(got[1], want[1]) and np.array_equal(got[2], want[2])
+
+
+def test_launch_on_a_stream_of_the_callers(hmm):
+    """include/hipstr_hmm.h allows hipstr_post_launch on a stream of the caller's.  A small run sends its inputs and argument block
+    asynchronously on the run's own stream; the kernel on the other stream must wait for that copy (it read d_args before the copy
+    had landed in round 3: ADVICE r03).  Many small runs back to back, each launched on a fresh non-blocking stream right after its
+    upload, against the same runs on the default path."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    d = np.load(POST[0])
+    kw = dict(n_alleles=d["n_alleles"], n_samples=d["n_samples"], read_off=d["read_off"], sample_label=d["sample_label"], log_p1=d["log_p1"],
+              log_p2=d["log_p2"], read_weight=d["read_weight"], log_aln_probs=d["log_aln_probs"], haploid=d["haploid"])
+    pb = capi.PostBatch(kw["n_alleles"], kw["n_samples"], kw["read_off"], kw["sample_label"], kw["log_p1"], kw["log_p2"], kw["read_weight"],
+                        kw["log_aln_probs"], kw["haploid"])
+    want = _run(hmm, pb)
+    S = int(pb.samp_off[-1])
+    streams = []
+    for _ in range(4):
+        h = C.c_void_p()
+        assert hip.hipStreamCreateWithFlags(C.byref(h), 1) == 0          # hipStreamNonBlocking
+        streams.append(h)
+    for it in range(40):
+        st = streams[it % 4]
+        pd = hmm.hipstr_post_upload(pb.ptr, None); assert pd, hmm.hipstr_last_error()
+        assert hmm.hipstr_post_launch(pd, st) == 0, hmm.hipstr_last_error()
+        post = np.zeros(max(int(pb.post_off[-1]), 1)); tot = np.zeros(max(S, 1)); gt = np.zeros(max(2 * S, 2), np.int32); ltot = np.zeros(max(pb.struct.n_loci, 1))
+        assert hmm.hipstr_post_fetch(pd, post.ctypes.data_as(capi._f64p), tot.ctypes.data_as(capi._f64p), gt.ctypes.data_as(capi._i32p),
+                                     ltot.ctypes.data_as(capi._f64p)) == 0, hmm.hipstr_last_error()
+        hmm.hipstr_post_free(pd)
+        assert np.array_equal(post[:int(pb.post_off[-1])], want[0]) and np.array_equal(tot[:S], want[1]) and np.array_equal(gt[:2 * S].reshape(-1, 2), want[2])
+    for h in streams:
+        hip.hipStreamDestroy(h)

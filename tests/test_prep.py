@@ -194,3 +194,17 @@ def test_str_groups_cover_every_read_side_once(hmm_host):
                 continue
             for sd, n in ((0, int(seeds[r])), (1, int(lens[r] - seeds[r] - 1))):
                 assert ((r, sd) in seen) == (n > 0), (r, sd, n)
+
+
+def test_host_preparation_digests_are_pinned():
+    """Round 4 rewrote the host preparation for speed (no allocations per locus, closed forms for periodic blocks, memoised table
+    entries): every pool, offset and work item must still come out byte for byte as the round-3 code produced them — digests of
+    hipstr_debug_prepare over thirteen generator shapes (interrupted repeats, alternative flanks, masks, tiny and long blocks),
+    stored in tests/golden/prep_digests.json by tools/prep_digests.py from the round-3 library."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "prep_digests.py"), "check", os.path.join(root, "tests", "golden", "prep_digests.json")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert r.returncode == 0, r.stdout
