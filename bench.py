@@ -222,7 +222,7 @@ def end_to_end(capi, hmm, sb, loci, steps, device, latency=True):
     submission (bam_processor.cpp:550-617).  `steps` passes over the batch go through one open stream back to back, a feeder
     thread submitting while this thread collects in order; reported beside `value`, never as `value` (inputs are host-resident)."""
     import threading
-    st = capi.Stream(hmm, device=device, slots=3, batch_alignments=4 << 20)
+    st = capi.Stream(hmm, device=device, slots=int(os.environ.get("HIPSTR_BENCH_SLOTS", "8")), batch_alignments=int(os.environ.get("HIPSTR_BENCH_BATCH", str(2 << 20))))
     probs = np.zeros(max(sb.n_out, 1)); seeds = np.zeros(max(sb.n_reads, 1), np.int32)
     def one_pass_set(n):
         # feeder: every locus its own submission (hipstr_stream_submit_each: the per-region loop in C, as the reference's caller is C++);
@@ -241,11 +241,21 @@ def end_to_end(capi, hmm, sb, loci, steps, device, latency=True):
                 except RuntimeError:
                     time.sleep(0.0002)
         th.join()
-    one_pass_set(int(os.environ.get("HIPSTR_BENCH_E2E_WARMUP", "4")))      # warm-up: block caches, kernels
+    # warm-up: kernels, and the block caches — a miss is a hipMalloc / hipHostMalloc of up to gigabytes (0.9 s seen) in the middle of the
+    # stream; passes are repeated until one goes by without a new block from the driver (at most 12): the steady state of a long run
+    warm = 0
+    for _ in range(12):
+        a0 = hmm.hipstr_debug_driver_allocs()
+        one_pass_set(1); warm += 1
+        if warm >= int(os.environ.get("HIPSTR_BENCH_E2E_WARMUP", "4")) and hmm.hipstr_debug_driver_allocs() == a0:
+            break
     s0 = st.stats()
+    a_timed0 = hmm.hipstr_debug_driver_allocs()
+    c0 = time.process_time()
     t0 = time.perf_counter()
     one_pass_set(steps)
     dt = time.perf_counter() - t0
+    cpu_s = time.process_time() - c0              # CPU seconds of ALL threads of the process over the timed passes
     s1 = st.stats()
     st.close()
     # one-locus latency: a 30x locus (40 reads x 32 alleles) and an NS locus through the one-shot call, median of 30
@@ -262,8 +272,11 @@ def end_to_end(capi, hmm, sb, loci, steps, device, latency=True):
     return {"seconds": dt, "passes": steps, "ms_per_pass": 1e3 * dt / steps, "submissions": steps * loci, "loci_per_submission": 1,
             "batches": s1["batches"] - s0["batches"], "worker_host_seconds": s1["host_seconds"] - s0["host_seconds"],
             "collector_wait_seconds": s1["wait_seconds"] - s0["wait_seconds"],
+            "process_cpu_seconds": cpu_s, "process_cpu_ms_per_pass": 1e3 * cpu_s / steps, "process_cpu_us_per_locus": 1e6 * cpu_s / (steps * loci),
+            "cpu_seconds_by_role": {k[4:-8]: s1[k] - s0[k] for k in ("cpu_submit_seconds", "cpu_prepare_seconds", "cpu_upload_seconds", "cpu_collect_seconds")},
+            "warmup_passes": warm, "driver_allocs_during_timed_passes": int(hmm.hipstr_debug_driver_allocs() - a_timed0),
             "one_locus_process_reads_latency": lat,
-            "path": "hipstr_stream_submit_each (1 locus per submission) -> batches of ~4 Mi alignments -> prepare on host threads + H2D + kernels + D2H, 3 slots -> hipstr_stream_collect in order"}
+            "path": "hipstr_stream_submit_each (1 locus per submission) -> batches of ~2 Mi alignments -> prepare on host threads + H2D + table expansion + kernels + D2H, 8 slots -> hipstr_stream_collect in order"}
 
 
 def main():

@@ -532,6 +532,10 @@ def load_hmm():
     _sig(lib.hipstr_debug_str_groups, C.c_int, [_BP, _i32p, _i32p, _i32p, C.c_int, _i32p, C.c_int, _i32p])
     _sig(lib.hipstr_debug_simple_table, C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)])
     _sig(lib.hipstr_last_error, C.c_char_p, [])
+    _sig(lib.hipstr_debug_driver_allocs, C.c_int64, [])
+    _sig(lib.hipstr_debug_stream_create, C.c_void_p, [])
+    _sig(lib.hipstr_debug_stream_destroy, None, [C.c_void_p])
+    _sig(lib.hipstr_debug_fetch_table, C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64])
     return lib
 
 
@@ -562,7 +566,8 @@ class HipstrStreamOpts(C.Structure):
 
 class HipstrStreamStats(C.Structure):
     _fields_ = [("batches", C.c_int64), ("tickets", C.c_int64), ("alignment_slots", C.c_int64), ("host_seconds", C.c_double),
-                ("wait_seconds", C.c_double), ("open_seconds", C.c_double)]
+                ("wait_seconds", C.c_double), ("open_seconds", C.c_double), ("cpu_submit_seconds", C.c_double), ("cpu_prepare_seconds", C.c_double),
+                ("cpu_upload_seconds", C.c_double), ("cpu_collect_seconds", C.c_double)]
 
 
 class Stream:

@@ -5,6 +5,7 @@
 // output contract.  There is no CPU compute path here: without a gfx950 device every entry
 // point fails and hipstr_last_error() says so.
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 #include <atomic>
 
 #include <cfloat>
@@ -35,6 +36,8 @@ extern "C" __global__ void hs_str_group_kernel(const hs_dev_t* dp, int item_begi
 extern "C" __global__ void hs_str_group_kernel_pw(const hs_dev_t* dp, int item_begin);
 extern "C" __global__ void hs_str_group_kernel_p(const hs_dev_t* dp, int item_begin);
 extern "C" __global__ void hs_nd_kernel(const hs_dev_t* dp, int active_begin);
+extern "C" __global__ void hs_expand_stropts_kernel(const hs_dev_t* dp);
+extern "C" __global__ void hs_expand_recs_kernel(const hs_dev_t* dp);
 extern "C" size_t hs_str_group_lds_bytes(int max_B, int nd_cap, int with_ilog);
 extern "C" size_t hs_str_group_p_lds_bytes();
 extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk);
@@ -52,52 +55,71 @@ int fail(const std::string& m){ g_err = m; return 1; }
 
 // Free lists of device / pinned blocks (see api_internal.h).  Sizes are rounded up to 256 B below 1 MiB and to 1/16 of the
 // next power of two above, so that batches of similar size hit the same classes.
+std::atomic<int64_t> g_driver_allocs(0);
+// Blocks are carved from large chunks taken from the driver (256 MiB at first, doubling up to 16 GiB of device / 2 GiB of pinned memory)
+// and never go back to it one by one: a hipMalloc / hipHostMalloc next to running kernels stalls for 0.1-0.3 s (seen in the middle of a
+// stream: profiles/r04_notes.md), a hipFree synchronises the device.  A freed block goes to a free list by size; a request takes the
+// smallest free block that holds it if that is at most twice as large, else a fresh piece of the current chunk.  No coalescing: the
+// requests of a stream repeat, so the free list saturates after a few batches and the driver is not called again.
 struct BlockCache {
   bool pinned = false;
   std::mutex m;
   std::multimap<size_t, void*> free_;
   std::unordered_map<void*, size_t> size_;
-  size_t cached = 0, cap = 0;
+  struct Chunk { char* base; size_t size, used; };
+  std::vector<Chunk> chunks;
+  size_t next_chunk = (size_t)256 << 20;
+  size_t cached = 0, cap = 0, in_use = 0;
   static size_t round_up(size_t n){
     if (n < 256) return 256;
     if (n <= ((size_t)1 << 20)) return (n + 255) & ~(size_t)255;
     size_t p2 = (size_t)1 << 20; while (p2 < n) p2 <<= 1;
-    // (large blocks in coarser classes: the workspaces of consecutive stream batches differ by a few per cent, and a miss there is a
-    //  hipMalloc of gigabytes — 0.9 s seen — in the middle of a stream)
     const size_t step = n > ((size_t)64 << 20) ? p2 >> 3 : p2 >> 4;
     return (n + step - 1) / step * step;
   }
-  void* get(size_t bytes){
-    const size_t want = round_up(bytes);
-    {
-      std::lock_guard<std::mutex> g(m);
-      auto it = free_.lower_bound(want);
-      if (it != free_.end() && it->first <= want + want/4){ void* p = it->second; cached -= it->first; free_.erase(it); return p; }
-    }
+  void* driver_alloc(size_t bytes){
     void* p = NULL;
-    hipError_t e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
-    if (e != hipSuccess){            // give cached blocks back to the driver and try once more
-      release();
-      e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
-    }
+    g_driver_allocs++;
+    if (getenv("HIPSTR_TIMING")) fprintf(stderr, "block cache: %s chunk of %zu bytes from the driver\n", pinned ? "pinned" : "device", bytes);
+    const hipError_t e = pinned ? hipHostMalloc(&p, bytes, hipHostMallocDefault) : hipMalloc(&p, bytes);
     if (e != hipSuccess){ g_err = std::string(pinned ? "hipHostMalloc: " : "hipMalloc: ") + hipGetErrorString(e); return NULL; }
+    return p;
+  }
+  void* get(size_t bytes){
+    size_t want = round_up(bytes);
     std::lock_guard<std::mutex> g(m);
+    auto it = free_.lower_bound(want);
+    if (it != free_.end() && it->first <= 2*want){ void* p = it->second; cached -= it->first; free_.erase(it); in_use++; return p; }
+    if (want > ((size_t)16 << 20)) want = round_up(want + want/8);        // a new large block comes with headroom for its successors
+    if (chunks.empty() || chunks.back().used + want > chunks.back().size){
+      const size_t max_chunk = pinned ? (size_t)2 << 30 : (size_t)16 << 30;
+      size_t sz = std::max(next_chunk, want);
+      next_chunk = std::min(max_chunk, next_chunk*2);
+      char* base = (char*)driver_alloc(sz);
+      if (!base && sz > want) base = (char*)driver_alloc(sz = want);       // the device is nearly full: just what is needed
+      if (!base) return NULL;
+      chunks.push_back(Chunk{base, sz, 0});
+    }
+    Chunk& c = chunks.back();
+    void* p = c.base + c.used;
+    c.used += (want + 255) & ~(size_t)255;
     size_[p] = want;
+    in_use++;
     return p;
   }
   void put(void* p){
     if (!p) return;
-    std::unique_lock<std::mutex> g(m);
+    std::lock_guard<std::mutex> g(m);
     auto it = size_.find(p);
     if (it == size_.end()) return;
-    const size_t n = it->second;
-    if (cached + n > cap){ size_.erase(it); g.unlock(); if (pinned) hipHostFree(p); else hipFree(p); return; }
-    free_.insert(std::make_pair(n, p)); cached += n;
+    free_.insert(std::make_pair(it->second, p)); cached += it->second;
+    if (in_use > 0) in_use--;
   }
+  // everything back to the driver — only when no block is out (hipstr_hmm_shutdown)
   void release(){
-    std::vector<void*> v;
-    { std::lock_guard<std::mutex> g(m); for (auto& kv : free_){ v.push_back(kv.second); size_.erase(kv.second); } free_.clear(); cached = 0; }
-    for (void* p : v){ if (pinned) hipHostFree(p); else hipFree(p); }
+    std::vector<Chunk> v;
+    { std::lock_guard<std::mutex> g(m); if (in_use > 0) return; v.swap(chunks); free_.clear(); size_.clear(); cached = 0; next_chunk = (size_t)256 << 20; }
+    for (Chunk& c : v){ if (pinned) hipHostFree(c.base); else hipFree(c.base); }
   }
 };
 
@@ -155,8 +177,13 @@ Ctx* ctx_for_device(int device_ordinal){
   Ctx* c = new Ctx();
   c->device = device_ordinal;
   c->pin_cache.pinned = true;
-  c->dev_cache.cap = (size_t)(getenv("HIPSTR_DEV_CACHE_GIB") ? atof(getenv("HIPSTR_DEV_CACHE_GIB")) : 64.0) << 30;
-  c->pin_cache.cap = (size_t)(getenv("HIPSTR_PIN_CACHE_GIB") ? atof(getenv("HIPSTR_PIN_CACHE_GIB")) : 8.0) << 30;
+  // free blocks the caches may hold: every batch in flight returns its workspaces at once when a stream drains (eight 2 Mi-pair batches of
+  // 500-read loci: 60 GB), and a block given back to the driver is a hipFree (which synchronises the device) plus a hipMalloc later —
+  // so: 70 % of the device's memory (288 GB on an MI355X), 24 GiB of pinned host memory
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)96 << 30;
+  c->dev_cache.cap = getenv("HIPSTR_DEV_CACHE_GIB") ? (size_t)(atof(getenv("HIPSTR_DEV_CACHE_GIB"))*1073741824.0) : (size_t)(0.7*(double)total_b);
+  c->pin_cache.cap = (size_t)((getenv("HIPSTR_PIN_CACHE_GIB") ? atof(getenv("HIPSTR_PIN_CACHE_GIB")) : 24.0)*1073741824.0);
   if (upload_table(T.int_log, &c->int_log) || upload_table(T.qual_correct, &c->qc) || upload_table(T.qual_error, &c->qe) ||
       upload_table(m2m, &c->m2m) || upload_table(m2i, &c->m2i) ||
       hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess){
@@ -243,7 +270,7 @@ struct hipstr_dev_batch {
   hipStream_t stream = NULL;                // launches, copies and waits of this batch default to it (the creating thread's stream)
   hipStream_t h2d_stream = NULL, d2h_stream = NULL;
   double* host_out = NULL;                  // pinned copy of aln_probs (fetch_begin)
-  bool profiling = false, foreign_stream = false;
+  bool profiling = false, foreign_stream = false, sleepy_wait = false;
   std::vector<hipEvent_t> prof_pool;        // reusable events; every pass records 5 per chunk (phase boundaries)
   size_t prof_used = 0;
   int64_t algo_bytes = 0, dp_cells = 0;
@@ -386,23 +413,24 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   size_t total = 0;
   auto place = [&](const void* src, size_t bytes){ total = (total + 255) & ~(size_t)255; pieces.push_back(Piece{src, bytes, total}); total += bytes ? bytes : 1; return pieces.size() - 1; };
   // a large pool: the batch's own vector (single-threaded preparation) followed by the fragments' (threaded), back to back
-  auto place_pool = [&](const void* own, size_t own_bytes, auto frag_ptr, size_t elem){
+  // (tail_bytes: room behind the pool that the host does not fill — the generated part of the f64 pool)
+  auto place_pool = [&](const void* own, size_t own_bytes, auto frag_ptr, size_t elem, size_t tail_bytes){
     total = (total + 255) & ~(size_t)255;
     const size_t first = pieces.size();
     pieces.push_back(Piece{own, own_bytes, total}); total += own_bytes;
     for (const hipstr::Prepared& f : P.frags){ const auto& v = f.*frag_ptr; pieces.push_back(Piece{v.data(), v.size()*elem, total}); total += v.size()*elem; }
-    total += 1;
+    total += tail_bytes + 1;
     return first;
   };
   dev->n_lead_items = (int)P.lead_items.size();
   dev->n_trail_items = (int)P.trail_items.size();
 #define PL(vec) place((vec).data(), (vec).size()*sizeof((vec)[0]))
   const size_t i_loci = PL(P.loci), i_alleles = PL(P.alleles), i_stropts = PL(P.stropts), i_rowsets = PL(P.rowsets),
-    i_rows = place_pool(P.rows.data(), P.rows.size()*sizeof(hs_row_t), &hipstr::Prepared::rows, sizeof(hs_row_t)),
-    i_visits = place_pool(P.visits.data(), P.visits.size()*sizeof(hs_visit_t), &hipstr::Prepared::visits, sizeof(hs_visit_t)),
-    i_f64 = place_pool(P.f64pool.data(), P.f64pool.size()*sizeof(double), &hipstr::Prepared::f64pool, sizeof(double)),
-    i_chars = place_pool(P.chars.data(), P.chars.size(), &hipstr::Prepared::chars, 1),
-    i_recs = place_pool(P.grp_recs.data(), P.grp_recs.size()*sizeof(int32_t), &hipstr::Prepared::grp_recs, sizeof(int32_t)),
+    i_rows = place_pool(P.rows.data(), P.rows.size()*sizeof(hs_row_t), &hipstr::Prepared::rows, sizeof(hs_row_t), 0),
+    i_visits = place_pool(P.visits.data(), P.visits.size()*sizeof(hs_visit_t), &hipstr::Prepared::visits, sizeof(hs_visit_t), 0),
+    i_f64 = place_pool(P.f64pool.data(), P.f64pool.size()*sizeof(double), &hipstr::Prepared::f64pool, sizeof(double), sizeof(double)*(size_t)P.gen_f64),
+    i_chars = place_pool(P.chars.data(), P.chars.size(), &hipstr::Prepared::chars, 1, 0),
+    i_recd = PL(P.rec_descs), i_pmf = PL(P.pmf13),
     i_reads = PL(P.reads), i_active = PL(P.active),
     i_ws = PL(P.ws), i_tg = PL(P.tgroups), i_tm = PL(P.tmembers), i_tp = PL(P.tpack), i_ord = PL(P.str_order), i_ndr = PL(P.nd_rows);
 #undef PL
@@ -431,7 +459,7 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   h.f64pool = (const double*)at(i_f64); h.chars = (const char*)at(i_chars); h.reads = (const hs_read_t*)at(i_reads);
   h.active = (const int32_t*)at(i_active); h.items = (const hs_item_t*)at(i_items); h.ws = (const hs_ws_t*)at(i_ws);
   h.tgroups = (const hs_tgroup_t*)at(i_tg); h.tmembers = (const int32_t*)at(i_tm); h.tpack = (const int32_t*)at(i_tp);
-  h.str_order = (const int32_t*)at(i_ord); h.grp_recs = (const int32_t*)at(i_recs); h.nd_rows = (const hs_ndrow_t*)at(i_ndr); h.bases = at(i_bases); h.quals = at(i_quals);
+  h.str_order = (const int32_t*)at(i_ord); h.rec_descs = (const hs_recdesc_t*)at(i_recd); h.pmf13 = (const double*)at(i_pmf); h.nd_rows = (const hs_ndrow_t*)at(i_ndr); h.bases = at(i_bases); h.quals = at(i_quals);
   dev->d_args = (hs_dev_t*)at(i_args);
   // ---- output + workspaces (device only)
   auto dalloc = [&](size_t bytes) -> void* { void* p = ctx->dev_cache.get(bytes ? bytes : 1); if (p) dev->dev_blocks.push_back(p); return p; };
@@ -440,6 +468,8 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   h.ws_mr = (double*)dalloc(sizeof(double)*(size_t)P.ws_mr_size); h.ws_lt = (double*)dalloc(sizeof(double)*(size_t)P.ws_lt_size);
   h.ws_lead = (double*)dalloc(sizeof(double)*(size_t)P.ws_lead_size); h.ws_col = (double*)dalloc(sizeof(double)*(size_t)P.ws_col_size);
   h.ws_nd = (double*)dalloc(sizeof(double)*(size_t)P.ws_nd_size);
+  h.grp_recs = (const int32_t*)dalloc(sizeof(int32_t)*HS_GRP_REC_DWORDS*P.rec_descs.size());        // assembled on the device (hs_expand_recs_kernel)
+  h.n_stropts = (int32_t)P.stropts.size(); h.n_recs = (int32_t)P.rec_descs.size(); h.f64_gen_base = (int64_t)P.n_f64();
   // trailing-flank kernel: persistent wavefronts, each with two band-boundary rows of [max side columns][64 lanes][M,D]
   h.band_cols = P.max_side_len > 0 ? P.max_side_len : 1;
   dev->trail_waves = (int)std::min<size_t>(P.trail_items.size() ? P.trail_items.size() : 1, 256 * 16);
@@ -447,7 +477,7 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   h.n_active = (int32_t)P.active.size();
   // [n_active] re-do flags of hs_str_kernel | [2 x chunks] work counters of hs_lead_kernel and hs_trail_kernel
   h.redo = (int32_t*)dalloc(sizeof(int32_t)*((size_t)h.n_active + 2*P.chunks.size() + 2));
-  if (!h.aln_probs || !h.ws_mr || !h.ws_lt || !h.ws_lead || !h.ws_col || !h.ws_nd || !h.ws_band || !h.redo){ hipstr_hmm_free(dev); return NULL; }
+  if (!h.aln_probs || !h.ws_mr || !h.ws_lt || !h.ws_lead || !h.ws_col || !h.ws_nd || !h.ws_band || !h.redo || !h.grp_recs){ hipstr_hmm_free(dev); return NULL; }
   const hipstr::HostTables& T = hipstr::host_tables();
   h.int_log = ctx->int_log; h.qual_correct = ctx->qc; h.qual_error = ctx->qe; h.m2m = ctx->m2m; h.m2i = ctx->m2i;
   h.log_thresh = T.log_thresh; h.log_half = T.log_half;
@@ -498,8 +528,17 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
     HS_HIP_DEV(hipMemcpyAsync(dblk + pieces[i_bases].off, batch->bases, n_bases, hipMemcpyHostToDevice, copy_stream));
     HS_HIP_DEV(hipMemcpyAsync(dblk + pieces[i_quals].off, batch->quals, n_bases, hipMemcpyHostToDevice, copy_stream));
   }
+  // what the device builds for itself (expand_kernels.hip), behind the copies on the same stream and in front of everything else
+  if (P.gen_f64 > 0) hipLaunchKernelGGL(hs_expand_stropts_kernel, dim3((unsigned)((P.stropts.size() + 255)/256)), dim3(256), 0, copy_stream, (const hs_dev_t*)dev->d_args);
+  if (!P.rec_descs.empty()) hipLaunchKernelGGL(hs_expand_recs_kernel, dim3((unsigned)((P.rec_descs.size()*HS_GRP_REC_DWORDS + 255)/256)), dim3(256), 0, copy_stream, (const hs_dev_t*)dev->d_args);
+  HS_HIP_DEV(hipGetLastError());
   HS_HIP_DEV(hipMemsetAsync(h.aln_probs, 0, out_bytes, copy_stream));
   dev->ev0 = ctx->get_event(true); dev->ev1 = ctx->get_event(true);
+  // The stream's batches take tens of milliseconds and their collectors must not burn a core waiting: hipEventSynchronize spins at 100 %
+  // of a CPU on this stack whatever the event's flags (tools/wait_probe.hip: 41.7 ms of thread CPU per 41.7 ms of waiting, also with
+  // hipEventBlockingSync), a query + usleep loop costs 0.6 ms (results_wait).  HIPSTR_STREAM_SPIN=1: spin all the same (comparison runs).
+  static const bool spin = getenv("HIPSTR_STREAM_SPIN") && atoi(getenv("HIPSTR_STREAM_SPIN")) != 0;
+  dev->sleepy_wait = reads_pinned && !spin;
   dev->ev_h2d = ctx->get_event(false); dev->ev_done = ctx->get_event(false); dev->ev_d2h = ctx->get_event(false);
   if (!dev->ev0 || !dev->ev1 || !dev->ev_h2d || !dev->ev_done || !dev->ev_d2h){ g_err = "hipEventCreate failed"; hipstr_hmm_free(dev); return NULL; }
   HS_HIP_DEV(hipEventRecord(dev->ev_h2d, copy_stream));
@@ -528,6 +567,12 @@ int hipstr::fetch_begin(hipstr_dev_batch_t* dev, hipStream_t compute_stream, hip
 }
 int hipstr::results_wait(hipstr_dev_batch_t* dev){
   if (bind(dev->ctx)) return 1;
+  if (dev->sleepy_wait){
+    hipError_t e;
+    while ((e = hipEventQuery(dev->ev_d2h)) == hipErrorNotReady) usleep(100);
+    if (e != hipSuccess){ g_err = std::string("hipEventQuery: ") + hipGetErrorString(e); return 1; }
+    return 0;
+  }
   HS_HIP(hipEventSynchronize(dev->ev_d2h));
   return 0;
 }
@@ -570,6 +615,7 @@ void hipstr::free_landed(hipstr_dev_batch_t* dev, bool landed){
   }
   hipstr_hmm_free(dev);
 }
+double hipstr::batch_prepare_seconds(const hipstr_dev_batch_t* dev){ return dev ? dev->t_prepare : 0.0; }
 hipStream_t hipstr::ctx_stream(Ctx* c){ return c->stream; }
 int hipstr::ctx_device(Ctx* c){ return c->device; }
 
@@ -759,6 +805,34 @@ void api_profile_add(int bucket, double seconds, int calls){
 double ApiTimer::now(){ return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }
 }
+int64_t hipstr_debug_driver_allocs(void){ return g_driver_allocs.load(); }
+
+// Diagnostics (tests): a non-blocking HIP stream of the calling thread's context, as a caller of its own would create one, and its release.
+void* hipstr_debug_stream_create(void){
+  Ctx* ctx = hipstr::api_current_ctx();
+  if (!ctx) return NULL;
+  hipStream_t st = NULL;
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess){ fail("hipStreamCreate failed"); return NULL; }
+  return (void*)st;
+}
+void hipstr_debug_stream_destroy(void* st){ if (st){ hipStreamSynchronize((hipStream_t)st); hipStreamDestroy((hipStream_t)st); } }
+
+// Diagnostics (tests/test_expand_gpu.py): the device's copy of a batch's option records (what = 0), f64 pool with its generated part (1)
+// or per-allele records (2), after everything queued by the upload has run.  Returns the bytes the table has (-1 on failure); copies at most cap.
+int64_t hipstr_debug_fetch_table(hipstr_dev_batch_t* dev, int what, void* buf, int64_t cap){
+  if (!dev || bind(dev->ctx)) return -1;
+  const hipstr::Prepared& P = dev->prep;
+  const void* src = NULL; int64_t n = 0;
+  if (what == 0){ src = dev->h.stropts; n = (int64_t)P.stropts.size()*sizeof(hs_stropt_t); }
+  else if (what == 1){ src = dev->h.f64pool; n = (int64_t)(dev->h.f64_gen_base + P.gen_f64)*sizeof(double); }
+  else if (what == 2){ src = dev->h.grp_recs; n = (int64_t)P.rec_descs.size()*HS_GRP_REC_DWORDS*sizeof(int32_t); }
+  else { fail("unknown table"); return -1; }
+  if (hipStreamSynchronize(dev->h2d_stream ? dev->h2d_stream : dev->stream) != hipSuccess){ fail("hipStreamSynchronize failed"); return -1; }
+  const int64_t m = std::min(n, cap);
+  if (m > 0 && buf && hipMemcpy(buf, src, (size_t)m, hipMemcpyDeviceToHost) != hipSuccess){ fail("hipMemcpy failed"); return -1; }
+  return n;
+}
+
 int hipstr_debug_api_profile(int mode, int cap, const char** names, double* seconds, int64_t* calls){
   static const char* const kNames[hipstr::PB_COUNT] = {
     "hipstr_hmm_process_reads[_seeded]", "  prepare_batch", "  pack staging buffer", "  blocks + H2D enqueue", "  kernel launches", "  wait + D2H + scatter", "  release",
@@ -808,11 +882,11 @@ int hipstr_debug_prepare(const hipstr_batch_t* batch, int threads, double* secon
     HS_MIX(P.visits); for (const hipstr::Prepared& f : P.frags) HS_MIX(f.visits);
     HS_MIX(P.f64pool); for (const hipstr::Prepared& f : P.frags) HS_MIX(f.f64pool);
     HS_MIX(P.chars); for (const hipstr::Prepared& f : P.frags) HS_MIX(f.chars);
-    HS_MIX(P.grp_recs); for (const hipstr::Prepared& f : P.frags) HS_MIX(f.grp_recs);
+    HS_MIX(P.rec_descs); HS_MIX(P.pmf13);
     HS_MIX(P.reads); HS_MIX(P.active); HS_MIX(P.seeds); HS_MIX(P.realign_read); HS_MIX(P.realign_hap); HS_MIX(P.ws); HS_MIX(P.lead_items);
     HS_MIX(P.trail_items); HS_MIX(P.str_items); HS_MIX(P.tpack); HS_MIX(P.str_order); HS_MIX(P.tgroups); HS_MIX(P.tmembers); HS_MIX(P.chunks); HS_MIX(P.nd_rows);
 #undef HS_MIX
-    const int64_t tail[8] = { P.ws_mr_size, P.ws_lt_size, P.ws_lead_size, P.ws_col_size, P.max_side_len, P.max_B, P.n_out, P.n_alignments };
+    const int64_t tail[9] = { P.ws_mr_size, P.ws_lt_size, P.ws_lead_size, P.ws_col_size, P.max_side_len, P.max_B, P.n_out, P.n_alignments, P.gen_f64 };
     mix(tail, sizeof tail);
     *digest = h;
   }

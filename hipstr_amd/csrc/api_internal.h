@@ -75,6 +75,7 @@ namespace hipstr {
 hipstr_dev_batch* upload_on(Ctx* ctx, const hipstr_batch* batch, const int32_t* seed_base, hipStream_t copy_stream, hipStream_t compute_stream, bool reads_pinned = false);
 int  fetch_begin(hipstr_dev_batch* dev, hipStream_t compute_stream, hipStream_t copy_stream);
 int  results_wait(hipstr_dev_batch* dev);
+double batch_prepare_seconds(const hipstr_dev_batch* dev);      // wall time of the batch's prepare_batch
 void scatter_loci(const hipstr_dev_batch* dev, int l0, int l1, double* aln_probs, int32_t* seeds);   // outputs based at locus l0
 void free_landed(hipstr_dev_batch* dev, bool landed);
 hipStream_t ctx_stream(Ctx* c);

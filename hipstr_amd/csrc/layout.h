@@ -86,7 +86,17 @@ struct hs_stropt_t {
   // 2: every list simple (tabulated: tab_len entries) or piecewise simple (descriptor slots), block of A/C/G/T: hs_str_group_kernel_pw;
   // 0: neither (hs_str_kernel_generic).  A kind-2 option's table holds the entries of its simple lists only.
   int32_t kind;
+  // Round 4: the constants and the closed-form table of an option whose whole block repeats with the period (nearly all) are not built
+  // on the host any more.  gen = 1: f64_off / tab_off count from the start of the GENERATED region of the f64 pool (hs_dev_t::f64_gen_base),
+  // pmf_off = the locus' 13 stutter-pmf values in hs_dev_t::pmf13; hs_expand_stropts_kernel writes the 20 constants and the table there,
+  // makes the two offsets pool-wide and clears the flag before any other kernel runs.  gen = 0: as before (host-written, pool-wide).
+  int32_t gen;
+  int32_t pmf_off;
 };
+
+// What the host says about one record of grp_recs[] (below): hs_expand_recs_kernel assembles the 256-byte record from it, the option
+// record and the option's constants (host-written or generated).  flags = lead slot (10 bits) | bit 29 / bit 30 of the processing order.
+struct hs_recdesc_t { int32_t stropt; int32_t flags; int32_t re_ord; int32_t nd_row; };
 
 struct hs_allele_t {
   int32_t lead_rows[2];      // rowset id per side
@@ -182,7 +192,10 @@ struct hs_dev_t {
   HS_P(const hs_tgroup_t) tgroups;
   HS_P(const int32_t) tmembers;   // allele indices (within the locus) of the trail groups
   HS_P(const int32_t) tpack;      // active-read indices of the reads packed into one trail item
-  HS_P(const int32_t) grp_recs;   // hs_str_group_kernel_p: HS_GRP_REC_DWORDS dwords per tabulated position of a locus side's order (hs_locus_t::rec_off)
+  HS_P(const int32_t) grp_recs;   // hs_str_group_kernel_p: HS_GRP_REC_DWORDS dwords per tabulated position of a locus side's order (hs_locus_t::rec_off);
+                                  // device only: assembled by hs_expand_recs_kernel from rec_descs[]
+  HS_P(const hs_recdesc_t) rec_descs;
+  HS_P(const double) pmf13;       // per locus: log_stutter_pmf of the 13 artifact sizes (host libm), what the generated constants start from
   HS_P(const hs_ndrow_t) nd_rows; // row descriptors of the read-end deletion sums, per locus side (hs_locus_t::ndrow_off)
   HS_P(const int32_t) str_order;  // allele index (within the locus) per processing position; bit 30 set = this allele's STR block,
                                  // in side orientation, ends with the previous position's block (its tables are continued); bit 29
@@ -210,4 +223,6 @@ struct hs_dev_t {
   int32_t            band_cols;      // max columns of one read side (rows of a band-boundary buffer)
   int32_t            max_B;          // longest STR allele of the batch (LDS carve of the STR kernel)
   int32_t            debug_redo;     // tests (HIPSTR_DEBUG_REDO=k): hs_str_kernel leaves every k-th chunk to the re-do path
+  int32_t            n_stropts, n_recs;
+  int64_t            f64_gen_base;   // doubles: the f64 pool is [host-written part | generated part]
 };

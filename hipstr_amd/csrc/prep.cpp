@@ -316,6 +316,7 @@ static const int* upstream_runs(const char* s, int n, int shift){
 }
 
 // One STR option in one orientation -> hs_stropt_t (+ its pools)
+static std::atomic<bool> g_host_tables(false);     // HIPSTR_HOST_TABLES=1 (tests, comparison runs; re-read at the start of every prepare_batch): constants and tables written by the host, as up to round 3
 static std::atomic<double> g_bnd_scale(1.0);      // tests only (HIPSTR_DEBUG_BND_SCALE): re-read from the environment at the start of every prepare_batch; concurrent calls store the same value
 
 // ---- host copies of the float bit tricks (fastonebigheader.h:206-218, 348-358), used to tabulate the closed form below
@@ -394,23 +395,40 @@ static void stutter_pmf13(const double* sp, int period, double pmf[HS_NART]){
 static std::atomic<uint64_t> g_so_cycles[6];
 static const bool g_so_on = getenv("HIPSTR_PREP_PROFILE") != NULL;
 #define HS_SOLAP(k) do { if (g_so_on){ const uint64_t now_ = __builtin_ia32_rdtsc(); g_so_cycles[k] += now_ - so_t; so_t = now_; } } while (0)
-void emit_stropt(const char* blk, const int B, int period, const double pmf13[HS_NART], Prepared& out, bool forward_only = false){
+// pmf_off >= 0: the option may leave its constants and table to the device (hs_stropt_t::gen; the locus' pmf values sit at out.pmf13[pmf_off..])
+// twin >= 0: the option at out.stropts[twin] is this block in the other orientation: what does not depend on the orientation (is the
+// whole block periodic? only A/C/G/T?) is taken from it
+void emit_stropt(const char* blk, const int B, int period, const double pmf13[HS_NART], Prepared& out, bool forward_only = false, int pmf_off = -1, int twin = -1){
   uint64_t so_t = g_so_on ? __builtin_ia32_rdtsc() : 0;
   const HostTables& T = host_tables();
   hs_stropt_t so; memset(&so, 0, sizeof so);
   so.seq_off = out.chars.size();
-  out.chars.insert(out.chars.end(), blk, blk + B);
-  while (out.chars.size() % 4) out.chars.push_back(0);
+  {
+    const size_t padded = ((size_t)B + 3) & ~(size_t)3;
+    out.chars.resize((size_t)so.seq_off + padded);           // (value-initialised: the padding is zero)
+    memcpy(out.chars.data() + so.seq_off, blk, (size_t)B);
+  }
   so.B = B; so.period = period;
   int nd = HIPSTR_MAX_STUTTER_REPS;
   while (nd*period > B) nd--;
   so.nd = nd;
-  int per_len = 0;                                         // leading run (from the right end) on which the block repeats with the period
-  while (per_len < B && blk[B-1-per_len] == blk[B-1-(per_len % period)]) per_len++;
+  // leading run (from the right end) on which the block repeats with the period: base k from the end equals base (k mod period) from
+  // the end — which, while it has held for every earlier k, is the same as "equals the base one period to its right"
+  const hs_stropt_t* tw = twin >= 0 ? &out.stropts[twin] : NULL;
+  const bool twin_periodic = tw && tw->B == B && tw->period == period && tw->nd_eq == tw->nd && tw->shape[HS_MAXREP] == (period < B ? B - period : 0) && tw->kind == 1;
+  int per_len;
+  if (twin_periodic) per_len = B;          // (a tabulated twin whose insertion list is one run over B - period positions: periodic as a whole, and so is its mirror image)
+  else {
+    per_len = std::min(period, B);
+    while (per_len < B && blk[B-1-per_len] == blk[B-1-per_len+period]) per_len++;
+  }
   so.nd_eq = std::min(nd, per_len / period);
   for (int r = 0; r < 16 && r < B; r++) so.tail_codes |= (int32_t)(((uint32_t)(uint8_t)blk[B-1-r] >> 1) & 3u) << (2*r);
-  so.f64_off = out.f64pool.size();
-  {
+  const bool gen = per_len == B && pmf_off >= 0 && !g_host_tables.load(std::memory_order_relaxed) && g_bnd_scale.load(std::memory_order_relaxed) == 1.0;
+  so.gen = gen ? 1 : 0; so.pmf_off = gen ? pmf_off : 0;
+  if (gen){ so.f64_off = (int32_t)out.gen_f64; out.gen_f64 += HS_NART + 1 + HS_MAXREP; }
+  else {
+    so.f64_off = out.f64pool.size();
     out.f64pool.resize(so.f64_off + HS_NART + 1 + HS_MAXREP);
     double* c = out.f64pool.data() + so.f64_off;
     for (int t = 0; t < HS_NART; t++) c[t] = (B + (t - HS_MAXREP)*period < 0) ? LARGE_NEGATIVE : pmf13[t];
@@ -438,10 +456,20 @@ void emit_stropt(const char* blk, const int B, int period, const double pmf13[HS
       so.shape[q] = tail >= 0 ? tail : -1;
     }
     HS_SOLAP(1);
-    so.tab_off = out.f64pool.size(); so.tab_len = 0;
+    so.tab_off = gen ? (int32_t)out.gen_f64 : (int32_t)out.f64pool.size(); so.tab_len = 0;
     bool ok = (B >= period);
-    for (int i = 0; i < B; i++){ const char c = blk[i]; ok &= (c == 'A' || c == 'C' || c == 'G' || c == 'T'); }
-    if (ok){
+    if (!twin_periodic) for (int i = 0; i < B; i++){ const char c = blk[i]; ok &= (c == 'A' || c == 'C' || c == 'G' || c == 'T'); }      // (a twin of kind 1 has passed this)
+    if (ok && gen){
+      // the device writes the entries (expand_kernels.hip): here only their number and where each list's begin
+      int total = 0;
+      for (int k = 0; k <= HS_MAXREP; k++){
+        const int tail = (k == HS_MAXREP) ? B : B - (k+1)*period;
+        so.tab_base[k] = total;
+        if (tail >= 0) total += 2 + (tail - so.shape[k]);
+      }
+      so.kind = 1; so.tab_len = total;
+      out.gen_f64 += 3*(int64_t)total + 1;
+    } else if (ok){
       // the table of such a block is a function of (B, period) alone — 14 + period + [period < B ? 0 : ...] entries — and the same
       // lengths come back for both orientations, for the alleles of neighbouring loci ...: a direct-mapped memo per host thread
       struct Tab { int32_t key, total; int32_t tab_base[HS_MAXREP + 1]; double ent[3*(2*HS_MAXREP + 2 + HIPSTR_MAX_PERIOD_TAB) + 1]; };
@@ -644,11 +672,11 @@ void emit_stropt(const char* blk, const int B, int period, const double pmf13[HS
 // a palindromic motif, neighbouring loci of a panel with the same motif.  A per-thread cache keyed by the three holds the option
 // record with its pool slices relative to their start; a hit appends copies (about 2 KB) instead of rebuilding them.
 struct StroptCached { hs_stropt_t so; std::vector<hs_visit_t> visits; std::vector<double> f64; std::vector<char> chars; };
-void emit_stropt_cached(const char* blk, int B, int period, const double* stutter, const double pmf13[HS_NART], Prepared& out){
+void emit_stropt_cached(const char* blk, int B, int period, const double* stutter, const double pmf13[HS_NART], Prepared& out, int pmf_off, int twin){
   // (off by default since round 4: building an option now costs about what a hit did — a hash of ~100 bytes and 2 KB of copies;
   //  HIPSTR_STROPT_CACHE=1 turns it back on for comparison)
   static const bool on = getenv("HIPSTR_STROPT_CACHE") && atoi(getenv("HIPSTR_STROPT_CACHE")) != 0;
-  if (!on || g_bnd_scale.load() != 1.0){ emit_stropt(blk, B, period, pmf13, out, true); return; }
+  if (!on || g_bnd_scale.load() != 1.0){ emit_stropt(blk, B, period, pmf13, out, true, pmf_off, twin); return; }      // (the cache keeps host-written tables only)
   thread_local std::unordered_map<std::string, StroptCached> cache;
   thread_local std::string key;
   key.assign((const char*)stutter, 6*sizeof(double)); key.push_back((char)period); key.append(blk, B);
@@ -892,6 +920,8 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
   // STR options: forward then reversed orientation
   const int so_base = out.stropts.size();
   double pmf13[HS_NART]; stutter_pmf13(b->stutter + 6*l, period, pmf13);
+  const int pmf_off = (int)out.pmf13.size();
+  out.pmf13.insert(out.pmf13.end(), pmf13, pmf13 + HS_NART);
   S.rev.resize(str_total);
   S.sblk[0].clear(); S.sblk[1].clear();
   {
@@ -906,10 +936,12 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
   }
   for (int side = 0; side < 2; side++)
     for (int o = 0; o < nopts[1]; o++)
-      emit_stropt_cached(S.sblk[side][o].p, S.sblk[side][o].n, period, b->stutter + 6*l, pmf13, out);
+      emit_stropt_cached(S.sblk[side][o].p, S.sblk[side][o].n, period, b->stutter + 6*l, pmf13, out, pmf_off, side ? so_base + o : -1);
   HS_LAP(1);
   S.str_opt_of.resize(A);                            // STR option of every allele
-  for (int k = 0; k < A; k++){ int32_t o3[3]; allele_options(nopts, k, o3); S.str_opt_of[k] = o3[1]; }
+  const bool one_flank = nopts[0] == 1 && nopts[2] == 1;          // (the usual locus: allele k is STR option k, the STR block is what changes)
+  if (one_flank) for (int k = 0; k < A; k++) S.str_opt_of[k] = k;
+  else for (int k = 0; k < A; k++){ int32_t o3[3]; allele_options(nopts, k, o3); S.str_opt_of[k] = o3[1]; }
 
   // alleles in visit order, replaying the reference's row reuse (HapAligner.cpp:54-60, 612-634):
   // the lead block of a side is (re)computed only when reuse is off or it is the block that changed;
@@ -935,9 +967,13 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
     for (int o = 0; o < nopts[1]; o++){
       const Seq& q = S.sblk[side][o];
       const int n = q.n;
-      int count = 0, lr_last = 0, rr_first = 0;
-      for (int j = 1; j < n; j++){ count = (q.p[j-1] == q.p[j]) ? count+1 : 0; if (j == n-1) lr_last = count; }
-      for (int j = n-2; j >= 0; j--){ count = (q.p[j+1] == q.p[j]) ? count+1 : 0; if (j == 0) rr_first = count; }
+      // HapBlock's two passes (forward: count = run so far; backward: the same counter, NOT reset) leave, at the block's ends: the run
+      // ending at the last base and the run starting at the first one, each minus one — unless the block is one run, where the backward pass
+      // keeps counting from what the forward pass left: n - 1 and 2 (n - 1)
+      int run_first = 0, run_last = 0;
+      while (run_first < n-1 && q.p[run_first+1] == q.p[0]) run_first++;
+      while (run_last < n-1 && q.p[n-2-run_last] == q.p[n-1]) run_last++;
+      const int lr_last = run_last, rr_first = (run_first == n-1) ? 2*(n-1) : run_first;
       S.end_sig[side].push_back(EndSig{ q.p[0], q.p[n-1], rr_first, lr_last });
     }
   }
@@ -956,13 +992,13 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
     hs_allele_t al; memset(&al, 0, sizeof al);
     al.realign = realign ? 1 : 0;
     int32_t o3[3];
-    allele_options(nopts, k, o3);
+    if (one_flank){ o3[0] = 0; o3[1] = k; o3[2] = 0; } else allele_options(nopts, k, o3);
     al.n_flank = O(0, o3[0]).n + O(2, o3[2]).n;
     out.max_flank = std::max(out.max_flank, al.n_flank);
     if (!realign){ reuse = false; out.alleles[allele_base + k] = al; continue; }
     al.re_ord = n_realigned++;
     loc.lt_stride = std::max(loc.lt_stride, al.n_flank);
-    const int cb = k == 0 ? -1 : changed_block(nopts, k);
+    const int cb = k == 0 ? -1 : (one_flank ? 1 : changed_block(nopts, k));
     for (int side = 0; side < 2; side++){
       // The rows of a flank block depend on the block and, through the homopolymer run that may cross the block boundary, on the
       // STR block's first base and the run it starts (leading flank) or its last base and the run it ends (trailing flank) — never on
@@ -1048,7 +1084,7 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
     const std::vector<int32_t>& ks = S.ks;
     loc.order_off[side] = out.str_order.size();
     loc.n_tab[side] = 0; loc.n_short[side] = 0; loc.n_pw[side] = 0;
-    loc.rec_off[side] = (int32_t)(out.grp_recs.size() / HS_GRP_REC_DWORDS);
+    loc.rec_off[side] = (int32_t)out.rec_descs.size();
     loc.ndrow_off[side] = (int32_t)out.nd_rows.size(); loc.n_ndrows[side] = 0;
     int fam_row0 = 0, fam_k = 0;                     // first row of the current family of alleles (blocks growing by one repeat unit), position in it
     Seq prev{NULL, 0};
@@ -1062,14 +1098,12 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
       out.str_order.push_back(ks[i] | (chained ? (1 << 30) : 0) | (one_unit ? (1 << 29) : 0));
       if (tabbed(ks[i])){
         loc.n_tab[side]++;
-        {   // the position's record for hs_str_group_kernel_p (layout.h)
+        {   // the position's record for hs_str_group_kernel_p (layout.h): described here, assembled on the device (hs_expand_recs_kernel)
           const hs_allele_t& al = out.alleles[allele_base + ks[i]];
           const hs_stropt_t& so = out.stropts[al.str_opt[side]];
-          const size_t rec_at = out.grp_recs.size();
-          out.grp_recs.resize(rec_at + HS_GRP_REC_DWORDS);          // (value-initialised: the unused dwords are zero)
-          int32_t* rec = out.grp_recs.data() + rec_at;
-          rec[0] = (al.lead_slot[side] & 0x3ff) | (so.tab_len << 10) | (chained ? (1 << 30) : 0) | (one_unit ? (1 << 29) : 0);
-          rec[1] = al.re_ord; rec[2] = (so.tail_codes & 0xfff) | (so.B << 12); rec[3] = so.tab_off;
+          hs_recdesc_t rdsc;
+          rdsc.stropt = al.str_opt[side]; rdsc.re_ord = al.re_ord; rdsc.nd_row = 0;
+          rdsc.flags = (al.lead_slot[side] & 0x3ff) | (chained ? (1 << 30) : 0) | (one_unit ? (1 << 29) : 0);
           if (period <= HS_GRP_MAXP){
             // rows of read-end deletion sums (layout.h hs_ndrow_t): a new family opens with five rows for the first allele's larger sizes
             if (!one_unit){
@@ -1079,11 +1113,9 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
             } else fam_k++;
             out.nd_rows.push_back(hs_ndrow_t{ so.B - period, so.tail_codes });       // row fam_k + 5: this allele's size 0
             loc.n_ndrows[side]++;
-            rec[4] = fam_row0 + fam_k + HS_MAXREP - 1;
+            rdsc.nd_row = fam_row0 + fam_k + HS_MAXREP - 1;
           }
-          for (int k = 0; k <= HS_MAXREP; k++) rec[8 + k] = (so.shape[k] & 0xffff) | (so.tab_base[k] << 16);
-          memcpy(rec + 16, out.f64pool.data() + so.f64_off, 20*sizeof(double));
-          memcpy(rec + 56, out.f64pool.data() + so.tab_off + 3*so.tab_len, sizeof(double));
+          out.rec_descs.push_back(rdsc);
         }
         if (period > HS_GRP_MAXP) loc.n_short[side]++;              // no instantiation of hs_str_group_kernel_p for this period
       }
@@ -1148,11 +1180,11 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
 }
 
 // Sizes of the pools of a fragment = where the next fragment starts in the merged batch.
-struct FragBase { size_t loci, alleles, stropts, rowsets, rows, visits, f64, chars, active, realign_hap, order, tgroups, tmembers, leads, recs, ndrows, lead_ids; };
+struct FragBase { size_t loci, alleles, stropts, rowsets, rows, visits, f64, chars, active, realign_hap, order, tgroups, tmembers, leads, recs, ndrows, lead_ids, gen_f64, pmf; };
 static FragBase frag_sizes(const Prepared& f){
   return FragBase{ f.loci.size(), f.alleles.size(), f.stropts.size(), f.rowsets.size(), f.rows.size(), f.visits.size(), f.f64pool.size(), f.chars.size(),
-                   f.active.size(), f.realign_hap.size(), f.str_order.size(), f.tgroups.size(), f.tmembers.size(), f.lead_off.size(), f.grp_recs.size() / HS_GRP_REC_DWORDS, f.nd_rows.size(),
-                   f.lead_ids.size() };
+                   f.active.size(), f.realign_hap.size(), f.str_order.size(), f.tgroups.size(), f.tmembers.size(), f.lead_off.size(), f.rec_descs.size(), f.nd_rows.size(),
+                   f.lead_ids.size(), (size_t)f.gen_f64, f.pmf13.size() };
 }
 
 // Copies fragment `f` to its place in `out` (whose pools are already sized), turning fragment-local pool offsets into batch-wide
@@ -1165,12 +1197,14 @@ static void place_fragment(Prepared& out, Prepared& f, const FragBase& at){
     L.hap_begin += allele_base;
     for (int s = 0; s < 2; s++){ L.tg_begin[s] += tg_base; L.order_off[s] += order_base; L.rec_off[s] += (int32_t)at.recs; L.ndrow_off[s] += (int32_t)at.ndrows; }
   }
-  for (size_t r = 0; r < f.grp_recs.size(); r += HS_GRP_REC_DWORDS) f.grp_recs[r + 3] += f64_base;
+  for (hs_recdesc_t& r : f.rec_descs) r.stropt += stropt_base;
   for (hs_allele_t& a : f.alleles)
     if (a.realign) for (int s = 0; s < 2; s++){ a.lead_rows[s] += rowset_base; a.trail_rows[s] += rowset_base; a.str_opt[s] += stropt_base; }
   for (hs_rowset_t& r : f.rowsets) r.off += rows_base;
   for (hs_stropt_t& o : f.stropts){
-    o.seq_off += chars_base; o.f64_off += f64_base; o.ins_off += visits_base; o.tab_off += f64_base;
+    if (o.gen){ o.f64_off += (int32_t)at.gen_f64; o.tab_off += (int32_t)at.gen_f64; o.pmf_off += (int32_t)at.pmf; }
+    else { o.f64_off += f64_base; o.tab_off += f64_base; }
+    o.seq_off += chars_base; o.ins_off += visits_base;
     for (int q = 0; q < HS_MAXREP; q++) o.del_off[q] += visits_base;
   }
   for (hs_tgroup_t& g : f.tgroups){ g.rowset += rowset_base; g.member_off += tm_base; }
@@ -1180,7 +1214,7 @@ static void place_fragment(Prepared& out, Prepared& f, const FragBase& at){
   HS_PLACE(loci, at.loci); HS_PLACE(alleles, at.alleles); HS_PLACE(stropts, at.stropts); HS_PLACE(rowsets, at.rowsets);
   HS_PLACE(active, at.active); HS_PLACE(realign_hap, at.realign_hap);
   HS_PLACE(str_order, at.order); HS_PLACE(tgroups, at.tgroups); HS_PLACE(tmembers, at.tmembers); HS_PLACE(nd_rows, at.ndrows);
-  HS_PLACE(lead_off, at.leads); HS_PLACE(lead_ids, at.lead_ids);
+  HS_PLACE(lead_off, at.leads); HS_PLACE(lead_ids, at.lead_ids); HS_PLACE(rec_descs, at.recs); HS_PLACE(pmf13, at.pmf);
   // rows, visits, f64pool, chars stay in the fragment (Prepared::frags): the upload gathers them
 #undef HS_PLACE
 }
@@ -1188,7 +1222,7 @@ static void place_fragment(Prepared& out, Prepared& f, const FragBase& at){
 // ---- recycled storage (prep.h)
 namespace {
 #define HS_PREP_VECTORS(X) X(loci) X(alleles) X(stropts) X(rowsets) X(rows) X(visits) X(f64pool) X(chars) X(reads) X(active) X(seeds) X(realign_read) \
-  X(realign_hap) X(chunks) X(ws) X(lead_items) X(trail_items) X(str_items) X(tpack) X(str_order) X(nd_rows) X(grp_recs) X(tgroups) X(tmembers) X(lead_off) X(lead_ids)
+  X(realign_hap) X(chunks) X(ws) X(lead_items) X(trail_items) X(str_items) X(tpack) X(str_order) X(nd_rows) X(rec_descs) X(pmf13) X(tgroups) X(tmembers) X(lead_off) X(lead_ids)
 size_t prepared_capacity_bytes(const Prepared& p){
   size_t n = 0;
 #define X(v) n += p.v.capacity()*sizeof(p.v[0]);
@@ -1201,7 +1235,7 @@ void clear_prepared(Prepared& p){          // back to the state of a fresh objec
   HS_PREP_VECTORS(X)
 #undef X
   p.frags.clear();
-  p.grp_nd_cap = 0; p.ws_mr_size = p.ws_lt_size = p.ws_lead_size = p.ws_col_size = p.ws_nd_size = 0;
+  p.grp_nd_cap = 0; p.gen_f64 = 0; p.ws_mr_size = p.ws_lt_size = p.ws_lead_size = p.ws_col_size = p.ws_nd_size = 0;
   p.max_side_len = 0; p.max_B = 1; p.n_out = 0; p.n_alignments = 0; p.max_read_len = 0; p.max_flank = 0;
 }
 struct PrepPool {
@@ -1251,6 +1285,7 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
   };
   auto t_lap = now();
   g_bnd_scale = getenv("HIPSTR_DEBUG_BND_SCALE") ? atof(getenv("HIPSTR_DEBUG_BND_SCALE")) : 1.0;
+  g_host_tables = getenv("HIPSTR_HOST_TABLES") && atoi(getenv("HIPSTR_HOST_TABLES")) != 0;
   if (b == NULL || b->n_loci < 0){ err = "null or negative-size batch"; return 1; }
   const int n_reads_total = b->n_loci > 0 ? b->read_off[b->n_loci] : 0;
   out.seeds.assign(n_reads_total, -1);
@@ -1310,11 +1345,12 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
     out.loci.resize(tot.loci); out.alleles.resize(tot.alleles); out.stropts.resize(tot.stropts); out.rowsets.resize(tot.rowsets);
     out.active.resize(tot.active); out.realign_hap.resize(tot.realign_hap);
     out.str_order.resize(tot.order); out.tgroups.resize(tot.tgroups); out.tmembers.resize(tot.tmembers); out.lead_off.resize(tot.leads); out.lead_ids.resize(tot.lead_ids);
+    out.rec_descs.resize(tot.recs); out.pmf13.resize(tot.pmf); out.gen_f64 = (int64_t)tot.gen_f64;
     out.nd_rows.resize(tot.ndrows);
     parallel_for(n_frag, n_threads, [&](int f){ place_fragment(out, frag[f], at[f]); });
     for (Prepared& f : frag){      // keep only the large pools of the fragments
       f.loci.clear(); f.alleles.clear(); f.stropts.clear(); f.rowsets.clear(); f.active.clear(); f.realign_hap.clear(); f.str_order.clear();
-      f.tgroups.clear(); f.tmembers.clear(); f.nd_rows.clear(); f.lead_off.clear(); f.lead_ids.clear();
+      f.tgroups.clear(); f.tmembers.clear(); f.nd_rows.clear(); f.lead_off.clear(); f.lead_ids.clear(); f.rec_descs.clear(); f.pmf13.clear();
     }
     out.frags = std::move(frag);
   }

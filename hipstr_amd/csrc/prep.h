@@ -64,7 +64,9 @@ struct Prepared {
   std::vector<int32_t>    tpack;           // active-read indices of the packed reads
   std::vector<int32_t>    str_order;       // per locus and side: realigned alleles sorted so that nested STR blocks follow each other
  std::vector<hs_ndrow_t>  nd_rows;         // row descriptors of the read-end deletion sums per locus side (layout.h); a small pool
-  std::vector<int32_t>    grp_recs;        // HS_GRP_REC_DWORDS dwords per tabulated position of a side's order (layout.h); a large pool like rows / f64pool
+  std::vector<hs_recdesc_t> rec_descs;     // one per tabulated position of a side's order (layout.h): what the device assembles a grp_recs[] record from
+  std::vector<double>     pmf13;           // 13 doubles per locus: log_stutter_pmf of the artifact sizes (what the device-generated constants start from)
+  int64_t                 gen_f64 = 0;     // doubles of the f64 pool the device fills in (constants + tables of the options marked hs_stropt_t::gen)
   std::vector<hs_tgroup_t> tgroups;
   std::vector<int32_t>    lead_off, lead_ids;   // host only: the distinct leading-flank rowsets of locus l, side s, by slot = lead_ids[lead_off[2 l + s] ...], hs_locus_t::n_lead[s] of them
   std::vector<int32_t>    tmembers;
@@ -83,7 +85,6 @@ struct Prepared {
   size_t n_visits() const { size_t n = visits.size(); for (const Prepared& f : frags) n += f.visits.size(); return n; }
   size_t n_f64() const { size_t n = f64pool.size(); for (const Prepared& f : frags) n += f.f64pool.size(); return n; }
   size_t n_chars() const { size_t n = chars.size(); for (const Prepared& f : frags) n += f.chars.size(); return n; }
-  size_t n_recs() const { size_t n = grp_recs.size(); for (const Prepared& f : frags) n += f.grp_recs.size(); return n; }
 };
 
 // The tables of a batch are tens to hundreds of megabytes of std::vector storage that every batch would otherwise take fresh from the
@@ -115,7 +116,7 @@ void allele_options(const int32_t nopts[3], int k, int32_t opts[3]);
 // (what a non-reusing alignment such as trace_optimal_aln computes); side_seqs = the three block sequences in side order.
 void fresh_flank_rows(const std::string side_seqs[3], std::vector<hs_row_t>& lead, std::vector<hs_row_t>& trail);
 // Appends one hs_stropt_t (+ visiting lists, f64 constants, block bytes) for a block sequence given in side orientation.
-void append_stropt(const std::string& blk, int period, const double* stutter, Prepared& out);
+void append_stropt(const std::string& blk, int period, const double* stutter, Prepared& out);        // (constants and table written by the host: hs_stropt_t::gen = 0)
 
 // One {A, G, Bnd} entry of the tabulated closed form of a simple visiting list (diagnostics / tests).
 void debug_simple_table(int lim, int U0, int tail, double ent[3]);

@@ -21,6 +21,7 @@
 #include <set>
 #include <string>
 #include <thread>
+#include <time.h>
 #include <vector>
 
 #include "../../include/hipstr_hmm.h"
@@ -28,6 +29,8 @@
 #include "prep.h"
 
 namespace {
+
+double thread_cpu_now(){ timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (double)ts.tv_sec + 1e-9*(double)ts.tv_nsec; }
 
 // A growing byte buffer in pinned host memory (from the context's block cache; plain malloc without a context): the reads' bases and
 // qualities of a stream batch are copied ONCE, from the caller's arrays into it, and travel to the device from where they lie.
@@ -65,6 +68,12 @@ struct OwnedBatch {
   struct Ticket { int64_t id; int32_t l0, l1, r0, r1; int64_t out0, out1; };
   std::vector<Ticket> tickets;
   int64_t n_out = 0, work = 0;          // doubles of output; (reads x haplotypes) submitted
+  // Copies of bases / qualities still running OUTSIDE the stream's lock (append_run reserves their place under the lock and copies
+  // afterwards, so that collectors and workers are not held up for the milliseconds a megabyte copy takes).  A buffer is not moved
+  // (grown) and the batch not prepared while this is non-zero.
+  std::atomic<int> writers{0};
+  struct Deferred { char* dst; const char* src; size_t n; };
+  void wait_writers() const { while (writers.load(std::memory_order_acquire) != 0) std::this_thread::yield(); }
   explicit OwnedBatch(hipstr::Ctx* pin_ctx = NULL){ bases.ctx = pin_ctx; quals.ctx = pin_ctx; reset(); }
   // empty again, storage kept (the stream recycles its batches: their vectors and pinned buffers are page-faulted and registered once)
   void reset(){
@@ -101,6 +110,7 @@ struct OwnedBatch {
     }
     if (b->realign_hap) realign_hap.insert(realign_hap.end(), b->realign_hap, b->realign_hap + n_haps); else realign_hap.insert(realign_hap.end(), n_haps, 1);
     for (int r = 1; r <= n_reads; r++){ base_off.push_back(base0 + b->base_off[r]); cigar_off.push_back(cig0 + b->cigar_off[r]); }
+    if (bases.size() + (size_t)n_bases > bases.cap || quals.size() + (size_t)n_bases > quals.cap) wait_writers();
     { char* pb = bases.grow((size_t)n_bases); char* pq = quals.grow((size_t)n_bases);
       if (!pb || !pq) return "out of pinned host memory for the reads";
       memcpy(pb, b->bases, (size_t)n_bases); memcpy(pq, b->quals, (size_t)n_bases); }
@@ -132,6 +142,7 @@ struct OwnedBatch {
     n_out += P*A; work += P*A;
     if (b->realign_hap) realign_hap.insert(realign_hap.end(), b->realign_hap + h0, b->realign_hap + h1); else realign_hap.insert(realign_hap.end(), (size_t)A, 1);
     for (int r = r0 + 1; r <= r1; r++){ base_off.push_back(base0 + b->base_off[r]); cigar_off.push_back(cig0 + b->cigar_off[r]); }
+    if (bases.size() + (size_t)(b1 - b0) > bases.cap || quals.size() + (size_t)(b1 - b0) > quals.cap) wait_writers();
     { char* pb = bases.grow((size_t)(b1 - b0)); char* pq = quals.grow((size_t)(b1 - b0));
       if (!pb || !pq) return "out of pinned host memory for the reads";
       memcpy(pb, b->bases + b0, (size_t)(b1 - b0)); memcpy(pq, b->quals + b0, (size_t)(b1 - b0)); }
@@ -146,7 +157,10 @@ struct OwnedBatch {
   // Loci [l0, l1) of `b`, every one a submission of its own with consecutive tickets from ticket0: what append_locus does l1 - l0
   // times, but the loci of a batch lie next to each other in every array, so each pool takes ONE copy (the reads' bases and qualities —
   // 12 KB per 40-read locus — spread over the host threads) and the offset arrays one rebasing pass.  opt0[l] = first block option of locus l.
-  const char* append_run(const hipstr_batch_t* b, int l0, int l1, const int* opt0, int64_t ticket0, std::vector< std::pair<int64_t,int64_t> >& sizes, const int32_t* seeds = NULL){
+  // (deferred: the two large copies are left to the caller, to be made after it has released the stream's lock — writers was incremented
+  //  for them and is decremented by the caller when they are done)
+  const char* append_run(const hipstr_batch_t* b, int l0, int l1, const int* opt0, int64_t ticket0, std::vector< std::pair<int64_t,int64_t> >& sizes, const int32_t* seeds,
+                         Deferred deferred[2]){
     const int n = l1 - l0;
     const int r0 = b->read_off[l0], r1 = b->read_off[l1], h0 = b->hap_off[l0], h1 = b->hap_off[l1];
     const int32_t s0 = b->opt_off[opt0[l0]], s1 = b->opt_off[opt0[l1]], b0 = b->base_off[r0], b1 = b->base_off[r1], c0 = b->cigar_off[r0], c1 = b->cigar_off[r1];
@@ -154,6 +168,7 @@ struct OwnedBatch {
     if ((int64_t)bases.size() + (b1 - b0) > INT32_MAX || (int64_t)seq.size() + (s1 - s0) > INT32_MAX) return "pending batch exceeds 2 GiB of bases";
     for (int l = l0; l < l1; l++)                       // (nothing is appended unless everything can be)
       if (b->read_off[l+1] < b->read_off[l] || b->hap_off[l+1] - b->hap_off[l] < 1) return "inconsistent read_off / hap_off";
+    if (bases.size() + (size_t)(b1 - b0) > bases.cap || quals.size() + (size_t)(b1 - b0) > quals.cap) wait_writers();      // growing moves the buffer
     if (!bases.reserve(bases.size() + (size_t)(b1 - b0)) || !quals.reserve(quals.size() + (size_t)(b1 - b0))) return "out of pinned host memory for the reads";
     const int32_t loc_base = (int32_t)period.size();
     blk_start.insert(blk_start.end(), b->blk_start + 3*l0, b->blk_start + 3*l1); blk_end.insert(blk_end.end(), b->blk_end + 3*l0, b->blk_end + 3*l1);
@@ -179,11 +194,8 @@ struct OwnedBatch {
     {
       const size_t nb = (size_t)(b1 - b0);
       char* pb = bases.grow(nb); char* pq = quals.grow(nb);          // (reserved above: cannot fail)
-      const size_t CH = (size_t)1 << 20; const int n_ch = (int)((nb + CH - 1)/CH);
-      hipstr::parallel_for(2*n_ch, nb > 4*CH ? hipstr::host_threads() : 1, [&](int i){
-        const size_t o = (size_t)(i >> 1)*CH, m = std::min(CH, nb - o);
-        memcpy(((i & 1) ? pq : pb) + o, ((i & 1) ? b->quals : b->bases) + b0 + o, m);
-      });
+      deferred[0] = Deferred{pb, b->bases + b0, nb}; deferred[1] = Deferred{pq, b->quals + b0, nb};
+      writers.fetch_add(1, std::memory_order_acq_rel);
     }
     read_start.insert(read_start.end(), b->read_start + r0, b->read_start + r1);
     cigar_op.append(b->cigar_op + c0, c1 - c0); cigar_len.insert(cigar_len.end(), b->cigar_len + c0, b->cigar_len + c1);
@@ -219,8 +231,8 @@ struct InFlight {
 struct hipstr_stream {
   hipstr::Ctx* ctx = NULL;
   hipStream_t copy_stream = NULL, d2h_stream = NULL;     // tables to the device / results back: neither waits for the other
-  int slots = 4;
-  int64_t batch_work = (int64_t)4 << 20;
+  int slots = 6;
+  int64_t batch_work = (int64_t)2 << 20;       // (2 Mi pairs: a 30x batch's tables then stay within the last-level cache while they are built and packed)
   std::mutex m;
   std::condition_variable cv_work, cv_done, cv_slots;
   OwnedBatch* pending = NULL;
@@ -286,8 +298,10 @@ void worker_loop(hipstr_stream* s, int n_workers){
       if (s->ready.empty()) flush_locked(s);
       ob = s->ready.front(); s->ready.pop_front(); s->in_worker++;
     }
+    ob->wait_writers();              // copies into the batch that a submitter is still making outside the lock
     InFlight* f = new InFlight(); f->ob = ob; f->taken.assign(ob->tickets.size(), 0);
     const auto t0 = std::chrono::steady_clock::now();
+    const double c0 = thread_cpu_now();
     f->dev = hipstr::upload_on(s->ctx, ob->finish(), ob->seed.data(), s->copy_stream, hipstr::ctx_stream(s->ctx), true);
     if (!f->dev){ f->failed = true; f->err = hipstr_last_error(); }
     else if (hipstr_hmm_align(f->dev, NULL) != 0 || hipstr::fetch_begin(f->dev, hipstr::ctx_stream(s->ctx), s->d2h_stream) != 0){
@@ -301,6 +315,8 @@ void worker_loop(hipstr_stream* s, int n_workers){
       std::lock_guard<std::mutex> g(s->m);
       s->flying.push_back(f); s->in_worker--;
       s->stats.batches++; s->stats.host_seconds += host_s; s->stats.alignment_slots += ob->work;
+      const double cpu = thread_cpu_now() - c0, prep = f->dev ? hipstr::batch_prepare_seconds(f->dev) : 0.0;
+      s->stats.cpu_prepare_seconds += std::min(cpu, prep); s->stats.cpu_upload_seconds += std::max(0.0, cpu - prep);
     }
     s->cv_done.notify_all();
   }
@@ -335,9 +351,13 @@ hipstr_stream_t* hipstr_stream_open(const hipstr_stream_opts_t* opts){
   return s;
 }
 
+namespace { struct CpuAdd { hipstr_stream* s; double* slot; double c0; CpuAdd(hipstr_stream* s_, double* slot_) : s(s_), slot(slot_), c0(thread_cpu_now()) {}
+                    ~CpuAdd(){ const double d = thread_cpu_now() - c0; std::lock_guard<std::mutex> g(s->m); *slot += d; } }; }
+
 int64_t hipstr_stream_submit(hipstr_stream_t* s, const hipstr_batch_t* loci){
   hipstr::ApiTimer prof_t(hipstr::PB_STREAM_SUBMIT);
   if (!s || !loci){ hipstr::api_fail("null argument"); return -1; }
+  CpuAdd cpu_t(s, &s->stats.cpu_submit_seconds);
   // a submission that prepare_batch would refuse is turned away here, before it shares a batch with others; the seed bases the check
   // computes go along with the reads
   thread_local std::vector<int32_t> seeds;
@@ -365,6 +385,7 @@ int64_t hipstr_stream_submit(hipstr_stream_t* s, const hipstr_batch_t* loci){
 // boundary): *first_ticket = the ticket of locus 0, the rest follow consecutively.  Stops at the first locus that is refused.
 int hipstr_stream_submit_each(hipstr_stream_t* s, const hipstr_batch_t* loci, int64_t* first_ticket){
   if (!s || !loci) return hipstr::api_fail("null argument");
+  CpuAdd cpu_t(s, &s->stats.cpu_submit_seconds);
   const int n = loci->n_loci;
   const auto t_sub0 = std::chrono::steady_clock::now();
   // A locus that prepare_batch would refuse is turned away here, before it shares a batch with others.  The checks (a seed per read
@@ -392,18 +413,31 @@ int hipstr_stream_submit_each(hipstr_stream_t* s, const hipstr_batch_t* loci, in
   // The loci go in as runs: a run ends where the pending batch reaches its size (it is handed to the workers there) or after 1024 loci
   // (the collectors take the stream's lock between runs).
   for (int l0 = 0; l0 < n_ok_total; ){
-    std::lock_guard<std::mutex> g(s->m);
-    if (s->closing) return hipstr::api_fail("stream is closing");
-    if (!s->pending) s->pending = new_batch_locked(s);
-    int64_t w = s->pending->work; int l1 = l0;
-    while (l1 < n_ok_total && l1 - l0 < 1024 && w < s->batch_work){
-      w += (int64_t)(loci->read_off[l1+1] - loci->read_off[l1])*(loci->hap_off[l1+1] - loci->hap_off[l1]); l1++;
+    OwnedBatch::Deferred cp[2]; OwnedBatch* ob = NULL; int l1 = l0;
+    {
+      std::lock_guard<std::mutex> g(s->m);
+      if (s->closing) return hipstr::api_fail("stream is closing");
+      if (!s->pending) s->pending = new_batch_locked(s);
+      int64_t w = s->pending->work;
+      while (l1 < n_ok_total && l1 - l0 < 1024 && w < s->batch_work){
+        w += (int64_t)(loci->read_off[l1+1] - loci->read_off[l1])*(loci->hap_off[l1+1] - loci->hap_off[l1]); l1++;
+      }
+      const int64_t ticket0 = s->next_ticket;
+      ob = s->pending;
+      if (const char* w2 = ob->append_run(loci, l0, l1, opt0.data(), ticket0, s->sizes, seeds.data(), cp)) return hipstr::api_fail(w2);
+      s->next_ticket += l1 - l0;
+      if (l0 == 0 && first_ticket) *first_ticket = ticket0;
+      if (s->pending->work >= s->batch_work) flush_locked(s);
     }
-    const int64_t ticket0 = s->next_ticket;
-    if (const char* w2 = s->pending->append_run(loci, l0, l1, opt0.data(), ticket0, s->sizes, seeds.data())) return hipstr::api_fail(w2);
-    s->next_ticket += l1 - l0;
-    if (l0 == 0 && first_ticket) *first_ticket = ticket0;
-    if (s->pending->work >= s->batch_work) flush_locked(s);
+    // the reads' bases and qualities (12 KB per 40-read locus), outside the lock: a worker that picks the batch up waits for `writers`
+    {
+      const size_t CH = (size_t)1 << 20; const size_t nb = cp[0].n; const int n_ch = (int)((nb + CH - 1)/CH);
+      hipstr::parallel_for(2*n_ch, nb > 4*CH ? hipstr::host_threads() : 1, [&](int i){
+        const size_t o = (size_t)(i >> 1)*CH, m = std::min(CH, nb - o);
+        memcpy(cp[i & 1].dst + o, cp[i & 1].src + o, m);
+      });
+      ob->writers.fetch_sub(1, std::memory_order_acq_rel);
+    }
     l0 = l1;
   }
   if (n >= 1024 && getenv("HIPSTR_TIMING"))
@@ -496,6 +530,7 @@ int hipstr_stream_next_size(hipstr_stream_t* s, int64_t* ticket, int64_t* n_out,
 int hipstr_stream_take(hipstr_stream_t* s, int64_t ticket, double* aln_probs, int64_t cap_probs, int32_t* seeds, int64_t cap_seeds){
   hipstr::ApiTimer prof_t(hipstr::PB_STREAM_TAKE);
   if (!s) return hipstr::api_fail("null argument");
+  CpuAdd cpu_t(s, &s->stats.cpu_collect_seconds);
   InFlight* f = NULL; size_t idx = 0;
   {
     std::unique_lock<std::mutex> g(s->m);

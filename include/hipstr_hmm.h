@@ -187,14 +187,19 @@ int hipstr_hmm_process_reads_seeded(const hipstr_batch_t* batch, const int32_t* 
 typedef struct hipstr_stream hipstr_stream_t;
 typedef struct hipstr_stream_opts {
   int32_t device;             /* ordinal; hipstr_stream_open initialises it like hipstr_hmm_init                              */
-  int32_t slots;              /* batches in flight (prepared / running / waiting to be collected); 0 = 4                      */
-  int64_t batch_alignments;   /* a pending batch is sent once it holds this many (read x haplotype) pairs; 0 = 4 Mi           */
+  int32_t slots;              /* batches in flight (prepared / running / waiting to be collected); 0 = 6                      */
+  int64_t batch_alignments;   /* a pending batch is sent once it holds this many (read x haplotype) pairs; 0 = 2 Mi           */
 } hipstr_stream_opts_t;
 typedef struct hipstr_stream_stats {
   int64_t batches, tickets, alignment_slots;  /* batches launched, tickets delivered, (read x haplotype) pairs submitted       */
   double  host_seconds;       /* worker thread: prepare + staging + launches, summed over batches                              */
   double  wait_seconds;       /* hipstr_stream_next: time spent waiting for a batch to land                                    */
   double  open_seconds;       /* since hipstr_stream_open                                                                      */
+  /* CPU seconds (thread CPU clocks, not wall time) by role: what the stream costs the host */
+  double  cpu_submit_seconds;   /* inside hipstr_stream_submit / _submit_each on the callers' threads (checks, seeds, the copy in)  */
+  double  cpu_prepare_seconds;  /* workers: prepare_batch (a worker with a budget of one host thread does all of it itself)         */
+  double  cpu_upload_seconds;   /* workers: packing the staging block, copies and launches queued                                   */
+  double  cpu_collect_seconds;  /* inside hipstr_stream_take / _next / _collect on the callers' threads (wait + copy out)           */
 } hipstr_stream_stats_t;
 hipstr_stream_t* hipstr_stream_open(const hipstr_stream_opts_t* opts /* NULL = defaults on device 0 */);
 /* Queues the loci of `loci` (1..n loci; arrays are copied).  Returns the submission's ticket (0, 1, 2, ...) or -1. */
@@ -476,6 +481,15 @@ int hipstr_debug_simple_table(int bound, int U0, int tail, double entry[3]);
  * read only.  Fills up to `cap` entries of names / seconds (wall clock, summed over threads) / calls and returns the number of
  * buckets; names indented by two spaces are parts of the entry point above them.  Used by integration/genotype_flow.cpp --profile. */
 int hipstr_debug_api_profile(int mode, int cap, const char** names, double* seconds, int64_t* calls);
+/* Diagnostics: how many blocks the library has taken from the driver so far (hipMalloc / hipHostMalloc: misses of its block caches, 0.1 ms to
+ * 1 s each).  A stream is in its steady state once this stops growing from pass to pass. */
+int64_t hipstr_debug_driver_allocs(void);
+/* Diagnostics (tests): a non-blocking HIP stream made by the library's own HIP runtime — what a caller passes as `hip_stream` — and its release. */
+void* hipstr_debug_stream_create(void);
+void hipstr_debug_stream_destroy(void* hip_stream);
+/* Diagnostics: the device's copy of a batch's STR-option records (what = 0: hs_stropt_t of hipstr_amd/csrc/layout.h), its f64 pool incl. the
+ * part the device generated (1) or the per-allele records the device assembled (2).  Returns the table's size in bytes (-1 on failure). */
+int64_t hipstr_debug_fetch_table(hipstr_dev_batch_t* dev, int what, void* buf, int64_t cap_bytes);
 
 const char* hipstr_last_error(void);
 

@@ -104,7 +104,6 @@ def test_launch_on_a_stream_of_the_callers(hmm):
     had landed in round 3: ADVICE r03).  Many small runs back to back, each launched on a fresh non-blocking stream right after its
     upload, against the same runs on the default path."""
     import ctypes as C
-    hip = C.CDLL("libamdhip64.so")
     d = np.load(POST[0])
     kw = dict(n_alleles=d["n_alleles"], n_samples=d["n_samples"], read_off=d["read_off"], sample_label=d["sample_label"], log_p1=d["log_p1"],
               log_p2=d["log_p2"], read_weight=d["read_weight"], log_aln_probs=d["log_aln_probs"], haploid=d["haploid"])
@@ -114,9 +113,9 @@ def test_launch_on_a_stream_of_the_callers(hmm):
     S = int(pb.samp_off[-1])
     streams = []
     for _ in range(4):
-        h = C.c_void_p()
-        assert hip.hipStreamCreateWithFlags(C.byref(h), 1) == 0          # hipStreamNonBlocking
-        streams.append(h)
+        h = hmm.hipstr_debug_stream_create()          # (made by the library's HIP runtime: a second runtime in the process — torch's, or
+        assert h, hmm.hipstr_last_error()             #  libamdhip64 loaded by name — does not see the device)
+        streams.append(C.c_void_p(h))
     for it in range(40):
         st = streams[it % 4]
         pd = hmm.hipstr_post_upload(pb.ptr, None); assert pd, hmm.hipstr_last_error()
@@ -127,4 +126,4 @@ def test_launch_on_a_stream_of_the_callers(hmm):
         hmm.hipstr_post_free(pd)
         assert np.array_equal(post[:int(pb.post_off[-1])], want[0]) and np.array_equal(tot[:S], want[1]) and np.array_equal(gt[:2 * S].reshape(-1, 2), want[2])
     for h in streams:
-        hip.hipStreamDestroy(h)
+        hmm.hipstr_debug_stream_destroy(h)

@@ -198,13 +198,17 @@ def test_str_groups_cover_every_read_side_once(hmm_host):
 
 def test_host_preparation_digests_are_pinned():
     """Round 4 rewrote the host preparation for speed (no allocations per locus, closed forms for periodic blocks, memoised table
-    entries): every pool, offset and work item must still come out byte for byte as the round-3 code produced them — digests of
-    hipstr_debug_prepare over thirteen generator shapes (interrupted repeats, alternative flanks, masks, tiny and long blocks),
-    stored in tests/golden/prep_digests.json by tools/prep_digests.py from the round-3 library."""
-    import json
+    entries, recycled storage) and then moved the constants / tables of periodic STR options and the per-allele records to the device
+    (expand_kernels.hip).  The rewrite was held to the round-3 code byte for byte before the layout changed (digests of
+    hipstr_debug_prepare over thirteen generator shapes: commit "Host preparation: STR options built without allocations ..." and the
+    two after it pass tests/golden/prep_digests.json as generated by the round-3 library); the files checked here pin the layout since —
+    with the device tables (default) and with HIPSTR_HOST_TABLES=1 — against accidental changes of any pool, offset or work item.
+    tests/test_expand_gpu.py holds the device-built tables to the host-built ones."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "prep_digests.py"), "check", os.path.join(root, "tests", "golden", "prep_digests.json")],
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
-    assert r.returncode == 0, r.stdout
+    for name, env in (("prep_digests.json", {}), ("prep_digests_host_tables.json", {"HIPSTR_HOST_TABLES": "1"})):
+        e = dict(os.environ); e.pop("HIPSTR_HOST_TABLES", None); e.update(env)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "prep_digests.py"), "check", os.path.join(root, "tests", "golden", name)],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, env=e)
+        assert r.returncode == 0, (name, r.stdout)

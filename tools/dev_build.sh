@@ -7,7 +7,7 @@ CSRC=$ROOT/hipstr_amd/csrc
 OUT=${OUT:-/tmp/hs_dev}
 mkdir -p $OUT/obj
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-honor-nans -mno-amdgpu-ieee -fPIC -pthread -fvisibility=hidden -Wno-unused-result -Wno-unused-value $EXTRA"
-SRCS="api.hip hmm_kernels.hip post_kernels.hip prep.cpp trace.hip em.hip nw.hip batch_io.cpp stream.hip gather.cpp"
+SRCS="api.hip hmm_kernels.hip expand_kernels.hip post_kernels.hip prep.cpp trace.hip em.hip nw.hip batch_io.cpp stream.hip gather.cpp"
 pids=""
 for s in $SRCS; do
   o=$OUT/obj/${s%.*}.o
