@@ -1,5 +1,7 @@
 // HapAlignerMI355X.cpp — see HapAlignerMI355X.h.  Flattens the reference's objects into the C-ABI batch.
 #include <assert.h>
+#include <string.h>
+#include <stdlib.h>
 
 #include "HapAlignerMI355X.h"
 #include "RepeatBlock.h"
@@ -103,10 +105,71 @@ void HapAlignerMI355X::profile(bool enable, double seconds[3]){
 static hipstr_stream_t* g_shared_stream = NULL;
 void HapAlignerMI355X::use_stream(hipstr_stream* stream){ g_shared_stream = stream; }
 
+// ---- trace_optimal_aln behind an UNEDITED caller.  SeqStutterGenotyper::retrace_alignments (seq_stutter_genotyper.cpp:805-841) asks for
+// one traceback at a time — the read's pool against the likelier of its sample's two MAP haplotypes — from a HapAligner it has just
+// constructed: one device round trip per read (0.4 ms each, 100 per locus) if taken literally.  What the adapter can know: the pooled
+// reads of the locus (process_reads was handed the pooler's vector, seq_stutter_genotyper.cpp:524-528, on this thread) and the
+// haplotypes.  So on the first request after a process_reads it aligns every pool to every haplotype once more (one forward call),
+// traces every seeded pool against its two likeliest haplotypes in ONE hipstr_hmm_trace call and keeps the results by (pool, haplotype);
+// a later request that is not among them is answered by one call that traces ALL pools against the haplotype asked for (the reads of a
+// sample share their MAP haplotypes: a handful of distinct ones per locus).  Nothing is assumed about the caller: the pool of a request
+// is recognised by its address inside the vector process_reads saw and confirmed by content, the haplotypes by a hash of their sequences
+// and stutter model; anything that does not match falls back to the single traceback of round 3.
+#include <map>
+namespace {
+std::atomic<long long> g_tc_hits(0), g_tc_misses(0), g_tc_calls(0), g_tc_ahead(0);
+unsigned long long fnv(const void* p, size_t n, unsigned long long h){ const unsigned char* q = (const unsigned char*)p; for (size_t i = 0; i < n; i++){ h ^= q[i]; h *= 1099511628211ull; } return h; }
+unsigned long long aln_fingerprint(const Alignment& a){
+  unsigned long long h = 1469598103934665603ull;
+  const int32_t st = a.get_start();
+  h = fnv(&st, sizeof st, h);
+  h = fnv(a.get_sequence().data(), a.get_sequence().size(), h);
+  h = fnv(a.get_base_qualities().data(), a.get_base_qualities().size(), h);
+  const std::string cig = a.getCigarString();
+  return fnv(cig.data(), cig.size(), h);
+}
+struct TraceStash {
+  const std::vector<Alignment>* pools; size_t n_pools; unsigned long long hap_hash;
+  std::vector<unsigned long long> prints;            // of every pool, taken when the stash was primed
+  std::vector<int32_t> seeds;                        // calc_seed_base of every pool
+  bool primed;
+  std::map<std::pair<int,int>, AlignmentTrace*> ready;      // computed, not handed out yet: ours to delete
+  TraceStash() : pools(NULL), n_pools(0), hap_hash(0), primed(false) {}
+  void drop(){
+    for (std::map<std::pair<int,int>, AlignmentTrace*>::iterator it = ready.begin(); it != ready.end(); ++it) delete it->second;
+    ready.clear(); prints.clear(); seeds.clear(); primed = false;
+  }
+  ~TraceStash(){ drop(); }
+};
+thread_local TraceStash t_stash;
+// what the patched Genotyper::calc_log_sample_posteriors says about the requests to come (genotyper_posteriors_mi355x.inc)
+struct TraceHint { int n_reads, n_alleles; std::vector<int32_t> best; std::vector<double> rows; TraceHint() : n_reads(0), n_alleles(0) {} };
+thread_local TraceHint t_hint;
+bool g_trace_prefetch = !(getenv("HIPSTR_ADAPTER_PREFETCH") && atoi(getenv("HIPSTR_ADAPTER_PREFETCH")) == 0);     // 0: one device call per request, as in round 3
+}
+void hipstr_mi355x_trace_hint(int n_reads, int n_alleles, const int32_t* best_haplotype, const double* log_aln_probs){
+  TraceHint& H = t_hint;
+  H.n_reads = n_reads; H.n_alleles = n_alleles;
+  H.best.assign(best_haplotype, best_haplotype + n_reads);
+  H.rows.assign(log_aln_probs, log_aln_probs + (size_t)n_reads*n_alleles);
+}
+void HapAlignerMI355X::trace_cache_stats(long long c[4]){ c[0] = g_tc_hits; c[1] = g_tc_misses; c[2] = g_tc_calls; c[3] = g_tc_ahead; }
+
+unsigned long long HapAlignerMI355X::haplotype_hash() const {
+  unsigned long long h = fnv(seq_.data(), seq_.size(), 1469598103934665603ull);
+  h = fnv(opt_off_.data(), opt_off_.size()*sizeof(int32_t), h);
+  h = fnv(blk_start_.data(), blk_start_.size()*sizeof(int32_t), h);
+  h = fnv(stutter_.data(), stutter_.size()*sizeof(double), h);
+  return fnv(&period_, sizeof period_, h);
+}
+
 void HapAlignerMI355X::process_reads(const std::vector<Alignment>& alignments, int init_read_index, const BaseQuality* base_quality,
 				     const std::vector<bool>& realign_read, double* aln_probs, int* seed_positions){
   assert(alignments.size() == realign_read.size());
   (void)base_quality;     // BaseQuality's tables are constants of the model; the device holds the same values
+  // a new round of this thread's locus: tracebacks computed ahead for the previous one are void; remember where the pooled reads live
+  t_stash.drop();
+  t_stash.pools = &alignments; t_stash.n_pools = alignments.size(); t_stash.hap_hash = haplotype_hash();
   AdapterTimer t_flat(0);
   FlatReads r(alignments, realign_read);
   FILL_BATCH(b, r)
@@ -153,7 +216,108 @@ void HapAlignerMI355X::process_read(const Alignment& aln, int seed_base, const B
   }
 }
 
+AlignmentTrace* HapAlignerMI355X::prefetched_trace(const Alignment& orig_aln, int seed_base, int best_haplotype){
+  TraceStash& S = t_stash;
+  if (!g_trace_prefetch || S.pools == NULL || S.pools->size() != S.n_pools || S.n_pools == 0 || S.hap_hash != haplotype_hash()) return NULL;
+  const Alignment* base = &(*S.pools)[0];
+  if (&orig_aln < base || &orig_aln >= base + S.n_pools) return NULL;
+  const int p = (int)(&orig_aln - base);
+  const int A = fw_haplotype_->num_combs();
+  if (best_haplotype < 0 || best_haplotype >= A || !realign_to_hap_[best_haplotype]) return NULL;
+  for (int k = 0; k < A; k++) if (!realign_to_hap_[k]) return NULL;      // (the reference traces with an all-true mask: anything else takes the plain path)
+  const std::vector<Alignment>& pools = *S.pools;
+  if (!S.primed){
+    // the pools as they are now, their seeds, and one forward pass over all of them: which two haplotypes does every pool fit best?
+    S.prints.resize(S.n_pools);
+    for (size_t i = 0; i < S.n_pools; i++) S.prints[i] = aln_fingerprint(pools[i]);
+    FlatReads r(pools, std::vector<bool>(S.n_pools, true));
+    FILL_BATCH(b, r)
+    std::vector<double> ll(S.n_pools*(size_t)A, 0.0);
+    S.seeds.assign(S.n_pools, -1);
+    if (hipstr_hmm_process_reads(&b, ll.data(), S.seeds.data()) != 0) printErrorAndDie(hipstr_last_error());
+    g_tc_calls++;
+    if (S.seeds[p] != seed_base){ S.pools = NULL; S.drop(); return NULL; }       // a caller with seeds of its own: not the loop this is made for
+    std::vector<int32_t> req_read, req_seed, req_hap;
+    std::map<std::pair<int,int>, bool> wanted;
+    auto want = [&](int pool, int hap){
+      if (pool < 0 || hap < 0 || hap >= A || S.seeds[pool] < 0 || wanted.count(std::make_pair(pool, hap))) return;
+      wanted[std::make_pair(pool, hap)] = true;
+      req_read.push_back(pool); req_seed.push_back(S.seeds[pool]); req_hap.push_back(hap);
+    };
+    want(p, best_haplotype);
+    const TraceHint& H = t_hint;
+    bool hinted = false;
+    if (H.n_alleles == A && H.n_reads > 0){
+      // the caller's reads carry their pool's row of likelihoods (seq_stutter_genotyper.cpp:536-541), the second mate of a pair the sum of
+      // the two pools' rows (:551-563): that is how a read of the hint finds its pool(s) among the rows just computed
+      std::map<unsigned long long, int> by_row;
+      for (size_t i = 0; i < S.n_pools; i++) if (S.seeds[i] >= 0) by_row[fnv(ll.data() + i*(size_t)A, sizeof(double)*(size_t)A, 1469598103934665603ull)] = (int)i;
+      int matched = 0;
+      for (int r = 0; r < H.n_reads; r++){
+        if (H.best[r] < 0) continue;
+        const double* row = H.rows.data() + (size_t)r*A;
+        std::map<unsigned long long, int>::const_iterator it = by_row.find(fnv(row, sizeof(double)*(size_t)A, 1469598103934665603ull));
+        if (it != by_row.end() && memcmp(ll.data() + (size_t)it->second*A, row, sizeof(double)*(size_t)A) == 0){ want(it->second, H.best[r]); matched++; continue; }
+        bool found = false;
+        for (size_t i = 0; i < S.n_pools && !found; i++){
+          if (S.seeds[i] < 0) continue;
+          const double* ri = ll.data() + i*(size_t)A;
+          for (size_t j = i; j < S.n_pools && !found; j++){
+            if (S.seeds[j] < 0) continue;
+            const double* rj = ll.data() + j*(size_t)A;
+            bool same = true;
+            for (int k = 0; k < A && same; k++) same = (ri[k] + rj[k] == row[k]);
+            if (same){ want((int)i, H.best[r]); want((int)j, H.best[r]); found = true; matched++; }
+          }
+        }
+      }
+      hinted = matched*2 >= H.n_reads;        // (a hint from another locus or round matches nothing: the likelihood-based choice below takes over)
+    }
+    if (!hinted)
+    for (size_t i = 0; i < S.n_pools; i++){
+      if (S.seeds[i] < 0) continue;
+      int h1 = -1, h2 = -1;
+      const double* row = ll.data() + i*(size_t)A;
+      for (int k = 0; k < A; k++){
+        if (h1 < 0 || row[k] > row[h1]){ h2 = h1; h1 = k; }
+        else if (h2 < 0 || row[k] > row[h2]) h2 = k;
+      }
+      want((int)i, h1); want((int)i, h2);
+    }
+    std::vector<AlignmentTrace*> made;
+    for (size_t i = 0; i < req_read.size(); i++) made.push_back(new AlignmentTrace(fw_haplotype_->num_blocks()));
+    run_trace_requests(pools, req_read, req_seed, req_hap, made);
+    g_tc_calls++; g_tc_ahead += (long long)made.size();
+    for (size_t i = 0; i < made.size(); i++) S.ready[std::make_pair((int)req_read[i], (int)req_hap[i])] = made[i];
+    S.primed = true;
+    g_tc_misses++;
+  }
+  else {
+    if (aln_fingerprint(orig_aln) != S.prints[p] || S.seeds[p] != seed_base){ S.pools = NULL; S.drop(); return NULL; }
+    if (S.ready.find(std::make_pair(p, best_haplotype)) != S.ready.end()) g_tc_hits++;
+    else {
+      // not among the two likeliest of its pool: every pool against this haplotype, in one call (its sample's other reads will ask for it)
+      std::vector<int32_t> req_read, req_seed, req_hap;
+      for (size_t i = 0; i < S.n_pools; i++)
+        if (S.seeds[i] >= 0 && S.ready.find(std::make_pair((int)i, best_haplotype)) == S.ready.end()){
+          req_read.push_back((int32_t)i); req_seed.push_back(S.seeds[i]); req_hap.push_back(best_haplotype);
+        }
+      std::vector<AlignmentTrace*> made;
+      for (size_t i = 0; i < req_read.size(); i++) made.push_back(new AlignmentTrace(fw_haplotype_->num_blocks()));
+      run_trace_requests(pools, req_read, req_seed, req_hap, made);
+      g_tc_calls++; g_tc_ahead += (long long)made.size(); g_tc_misses++;
+      for (size_t i = 0; i < made.size(); i++) S.ready[std::make_pair((int)req_read[i], (int)req_hap[i])] = made[i];
+    }
+  }
+  std::map<std::pair<int,int>, AlignmentTrace*>::iterator it = S.ready.find(std::make_pair(p, best_haplotype));
+  if (it == S.ready.end()) return NULL;
+  AlignmentTrace* t = it->second;        // the caller's from here on (it keeps its traces in a cache of its own and deletes them)
+  S.ready.erase(it);
+  return t;
+}
+
 AlignmentTrace* HapAlignerMI355X::trace_optimal_aln(const Alignment& orig_aln, int seed_base, int best_haplotype, const BaseQuality* base_quality){
+  if (AlignmentTrace* ahead = prefetched_trace(orig_aln, seed_base, best_haplotype)) return ahead;
   std::vector<AlignmentTrace*> traces;
   trace_optimal_alns(std::vector<Alignment>(1, orig_aln), std::vector<int>(1, seed_base), std::vector<int>(1, best_haplotype), base_quality, traces);
   return traces[0];
@@ -191,9 +355,20 @@ void HapAlignerMI355X::trace_optimal_alns(const std::vector<Alignment>& alignmen
 void HapAlignerMI355X::run_traces(const std::vector<Alignment>& alignments, const std::vector<int>& seed_bases, const std::vector<int>& best_haplotypes,
 				  const std::vector<AlignmentTrace*>& targets){
   const int n = (int)alignments.size();
+  std::vector<int32_t> req_read(n), req_seed(n, HIPSTR_SEED_AUTO), req_hap(best_haplotypes.begin(), best_haplotypes.end());
+  for (int i = 0; i < n; i++){
+    req_read[i] = i;
+    if (!seed_bases.empty()) req_seed[i] = seed_bases[i];           // the caller's seed_base (HapAligner.h:93), not a recomputed one
+  }
+  run_trace_requests(alignments, req_read, req_seed, req_hap, targets);
+}
+
+void HapAlignerMI355X::run_trace_requests(const std::vector<Alignment>& reads, const std::vector<int32_t>& req_read_in, const std::vector<int32_t>& req_seed_in,
+					  const std::vector<int32_t>& req_hap, const std::vector<AlignmentTrace*>& targets){
+  const int n = (int)req_read_in.size();
   if (n == 0) return;
   AdapterTimer t_flat(0);
-  FlatReads r(alignments, std::vector<bool>(alignments.size(), true));
+  FlatReads r(reads, std::vector<bool>(reads.size(), true));
   FILL_BATCH(b, r)
   t_flat.stop();
   AdapterTimer t_info(2);
@@ -207,12 +382,9 @@ void HapAlignerMI355X::run_traces(const std::vector<Alignment>& alignments, cons
   for (size_t k = 0; k < aln_info.size(); k++) hap_to_ref.push_back(aln_info[k].c_str());
 
   t_info.stop();
-  std::vector<int32_t> req_read(n), req_allele(best_haplotypes.begin(), best_haplotypes.end()), req_seed(n, HIPSTR_SEED_AUTO);
+  std::vector<int32_t> req_read(req_read_in), req_allele(req_hap), req_seed(req_seed_in);
   size_t chars = 64;
-  for (int i = 0; i < n; i++){
-    req_read[i] = i; chars += 2*alignments[i].get_sequence().size() + 2*aln_info[best_haplotypes[i]].size() + 64;
-    if (!seed_bases.empty()) req_seed[i] = seed_bases[i];           // the caller's seed_base (HapAligner.h:93), not a recomputed one
-  }
+  for (int i = 0; i < n; i++) chars += 2*reads[req_read[i]].get_sequence().size() + 2*aln_info[req_hap[i]].size() + 64;
   const int32_t cap = (int32_t)chars;
   std::vector<double> ll(n);
   std::vector<int32_t> max_index(n), hap_aln_off(n+1), stutter_size(n), str_seq_off(n+1), flank_seq_off(2*n+1), flank_ins(n), flank_del(n),
@@ -229,7 +401,7 @@ void HapAlignerMI355X::run_traces(const std::vector<Alignment>& alignments, cons
   if (hipstr_hmm_trace_seeded(&b, n, req_read.data(), req_allele.data(), req_seed.data(), hap_to_ref.data(), &o) != 0)
     printErrorAndDie(hipstr_last_error());
   AdapterTimer t_fill(1);
-  for (int i = 0; i < n; i++) fill_trace(i, &o, alignments[i], *targets[i]);
+  for (int i = 0; i < n; i++) fill_trace(i, &o, reads[req_read[i]], *targets[i]);
 }
 
 void HapAlignerMI355X::fill_trace(int i, const hipstr_trace_out_t* o, const Alignment& orig, AlignmentTrace& t) const {

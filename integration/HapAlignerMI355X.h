@@ -57,6 +57,9 @@ class HapAlignerMI355X {
   static void use_stream(struct hipstr_stream* stream);
   // genotype_flow --profile: seconds[0..2] = flatten, fill AlignmentTrace objects, haplotype strings, summed over threads; then reset and switch on / off
   static void profile(bool enable, double seconds[3]);
+  // trace_optimal_aln's prefetch (see HapAlignerMI355X.cpp): requests served from it, requests that had to go to the device, device calls
+  // made for them, tracebacks computed ahead — summed over threads since the process started
+  static void trace_cache_stats(long long counts[4]);
 
   int calc_seed_base(const Alignment& alignment);
 
@@ -86,6 +89,11 @@ class HapAlignerMI355X {
  private:
   void run_traces(const std::vector<Alignment>& alignments, const std::vector<int>& seed_bases, const std::vector<int>& best_haplotypes,
 		  const std::vector<AlignmentTrace*>& targets);
+  // the general form: request i = reads[req_read[i]] split at req_seed[i] against haplotype req_hap[i]
+  void run_trace_requests(const std::vector<Alignment>& reads, const std::vector<int32_t>& req_read, const std::vector<int32_t>& req_seed,
+			  const std::vector<int32_t>& req_hap, const std::vector<AlignmentTrace*>& targets);
+  unsigned long long haplotype_hash() const;
+  AlignmentTrace* prefetched_trace(const Alignment& orig_aln, int seed_base, int best_haplotype);
   void fill_trace(int i, const struct hipstr_trace_out* o, const Alignment& orig, AlignmentTrace& t) const;
 };
 
