@@ -216,6 +216,25 @@ def pipeline_stages(capi, hmm, sb, loci, P):
     return out
 
 
+def c3_em_inputs(sb, loci, P, S):
+    """The stutter EM's input for the configs[2] step (EMStutterGenotyper::train, em_stutter_genotyper.cpp:170-226): per read the observed
+    STR size — its source allele's size difference from the reference allele, with PCR stutter of one repeat unit on 12 % of the reads —,
+    reads dealt to S samples in blocks of P / S, no SNP phasing information.  Seeded: the same arrays for the same batch."""
+    lab = np.tile(np.repeat(np.arange(S), P // S), loci).astype(np.int32)
+    b = sb.ptr.contents
+    nopt = np.ctypeslib.as_array(b.blk_nopts, shape=(3 * loci,)).reshape(loci, 3)
+    opt_len = np.diff(np.ctypeslib.as_array(b.opt_off, shape=(int(nopt.sum()) + 1,)))
+    period = np.ctypeslib.as_array(b.period, shape=(loci,))
+    src = sb.src_allele().reshape(loci, P)
+    opt_base = np.concatenate([[0], np.cumsum(nopt.sum(axis=1))])[:-1] + nopt[:, 0]          # first STR option of every locus
+    rng = np.random.default_rng(5)
+    size = np.stack([opt_len[opt_base[l] + src[l]] - opt_len[opt_base[l]] for l in range(loci)])       # bp difference from the reference allele
+    u = rng.random(size.shape)
+    size = size + np.where(u < 0.05, 1, np.where(u < 0.12, -1, 0)) * period[:, None]                    # PCR stutter on the observed sizes
+    return dict(period=period, n_samples=np.full(loci, S, np.int32), read_off=np.arange(loci + 1, dtype=np.int32) * P, sample_label=lab,
+                num_bps=size.ravel().astype(np.int32), log_p1=np.zeros(loci * P), log_p2=np.zeros(loci * P), haploid=np.zeros(loci, np.uint8))
+
+
 def end_to_end(capi, hmm, sb, loci, steps, device, latency=True):
     """SURVEY §8(d)'s metric taken literally — wall time from host arrays in to aln_probs/seeds out (host flatten, H2D, kernels, D2H,
     the reference's output contract) — through the streaming C-ABI, fed the way the reference's caller produces work: ONE locus per
@@ -387,18 +406,7 @@ def main():
         lab = np.tile(np.repeat(np.arange(S), P // S), loci).astype(np.int32)
         pb = capi.PostBatch(A_l, np.full(loci, S, np.int32), np.arange(loci + 1, dtype=np.int32) * P, lab, np.zeros(loci * P), np.zeros(loci * P),
                             np.ones(loci * P, np.int32), None)
-        b = sb.ptr.contents
-        nopt = np.ctypeslib.as_array(b.blk_nopts, shape=(3 * loci,)).reshape(loci, 3)
-        opt_len = np.diff(np.ctypeslib.as_array(b.opt_off, shape=(int(nopt.sum()) + 1,)))
-        period = np.ctypeslib.as_array(b.period, shape=(loci,))
-        src = sb.src_allele().reshape(loci, P)
-        opt_base = np.concatenate([[0], np.cumsum(nopt.sum(axis=1))])[:-1] + nopt[:, 0]          # first STR option of every locus
-        rng = np.random.default_rng(5)
-        size = np.stack([opt_len[opt_base[l] + src[l]] - opt_len[opt_base[l]] for l in range(loci)])       # bp difference from the reference allele
-        u = rng.random(size.shape)
-        size = size + np.where(u < 0.05, 1, np.where(u < 0.12, -1, 0)) * period[:, None]                    # PCR stutter on the observed sizes
-        em_kw = dict(period=period, n_samples=np.full(loci, S, np.int32), read_off=np.arange(loci + 1, dtype=np.int32) * P, sample_label=lab,
-                     num_bps=size.ravel().astype(np.int32), log_p1=np.zeros(loci * P), log_p2=np.zeros(loci * P), haploid=np.zeros(loci, np.uint8))
+        em_kw = c3_em_inputs(sb, loci, P, S)
         h2a = np.concatenate([np.arange(a, dtype=np.int32) for a in A_l]); nvv = A_l.astype(np.int32)
         rq = capi.HipstrGtRequest(nvv.ctypes.data_as(capi._i32p), h2a.ctypes.data_as(capi._i32p), 1, 1, 0)
         ns = loci * S; ngl = int(sum(int(a) * (int(a) + 1) // 2 for a in A_l)) * S

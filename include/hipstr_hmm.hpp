@@ -169,8 +169,18 @@ class Haplotype {
   }
   bool has_aln_info() const { return !hap_aln_info_.empty(); }
   const std::string& get_aln_info(int hap_index) const { return hap_aln_info_[hap_index]; }
+  // The cursor of the reference's Haplotype (Haplotype.h:93-117): haplotypes are visited in index order (the index IS the position in
+  // the reflected Gray code of Haplotype::next); a fixed haplotype has no next one.  HapAligner::process_read runs from the
+  // current haplotype to the last (HapAligner.cpp:613-692).
+  void reset(){ cur_ = 0; }
+  bool next(){ if (fixed_ || cur_ + 1 >= ncombs_) return false; cur_++; return true; }
+  void go_to(int hap_index){ if (hap_index < 0 || hap_index >= ncombs_) printErrorAndDie("Invalid haplotype index"); cur_ = hap_index; }
+  void fix(){ fixed_ = true; }
+  void unfix(){ fixed_ = false; }
+  int cur_index() const { return cur_; }
  private:
   std::vector<std::string> hap_aln_info_;
+  int cur_ = 0; bool fixed_ = false;
 };
 
 class ReadPooler {
@@ -309,21 +319,58 @@ class HapAligner {
       printErrorAndDie(hipstr_last_error());
   }
   // HapAligner::trace_optimal_aln (HapAligner.h:88-92, HapAligner.cpp:711-722); the caller owns the result.
-  AlignmentTrace* trace_optimal_aln(const Alignment& orig_aln, int /*seed_base*/, int best_haplotype, const BaseQuality* base_quality){
+  // The read is split at seed_base, the CALLER's choice (HapAligner.h:93), as in the reference — not at a recomputed seed.
+  AlignmentTrace* trace_optimal_aln(const Alignment& orig_aln, int seed_base, int best_haplotype, const BaseQuality* base_quality){
     std::vector<AlignmentTrace*> traces;
-    trace_optimal_alns(std::vector<Alignment>(1, orig_aln), std::vector<int>(1, best_haplotype), base_quality, traces);
+    trace_optimal_alns(std::vector<Alignment>(1, orig_aln), std::vector<int>(1, seed_base), std::vector<int>(1, best_haplotype), base_quality, traces);
     return traces[0];
+  }
+  // HapAligner::process_read (HapAligner.h:83, HapAligner.cpp:573-709): one read, split at seed_base, against every haplotype from the
+  // haplotype's current position to the last one (a fixed haplotype: just that one); *prob_ptr advances one entry per haplotype
+  // visited, entries of haplotypes that are not realigned are left untouched.  With retrace_aln the likeliest haplotype visited (the
+  // first one among equals, as the reference's strict > keeps it) is traced into traced_aln.
+  void process_read(const Alignment& aln, int seed_base, const BaseQuality* base_quality, bool retrace_aln, double* prob_ptr, AlignmentTrace& traced_aln){
+    assert(seed_base != -1);
+    std::vector<int> visited;
+    do { visited.push_back(fw_haplotype_->cur_index()); } while (fw_haplotype_->next());
+    fw_haplotype_->reset();
+    std::vector<bool> mask(realign_to_hap_.size(), false);
+    for (size_t i = 0; i < visited.size(); i++) mask[visited[i]] = realign_to_hap_[visited[i]];
+    FlatLocus f; f.set_haplotype(fw_haplotype_, mask); f.set_reads(std::vector<Alignment>(1, aln), std::vector<bool>(1, true));
+    std::vector<double> row(realign_to_hap_.size(), 0.0);
+    int32_t seed_in = seed_base, seed_out = -1;
+    if (hipstr_hmm_process_reads_seeded(f.finish(), &seed_in, row.data(), &seed_out) != 0) printErrorAndDie(hipstr_last_error());
+    double max_LL = -100000000; int best = -1;
+    for (size_t i = 0; i < visited.size(); i++, prob_ptr++){
+      const int k = visited[i];
+      if (!mask[k]) continue;
+      *prob_ptr = row[k];
+      if (row[k] > max_LL){ max_LL = row[k]; best = k; }
+    }
+    if (retrace_aln && best >= 0){
+      AlignmentTrace* t = trace_optimal_aln(aln, seed_base, best, base_quality);
+      traced_aln = *t;
+      delete t;
+    }
   }
   // All tracebacks of a locus in one launch: request i = alignments[i] against haplotype best_haplotypes[i] (what
   // SeqStutterGenotyper::retrace_alignments, seq_stutter_genotyper.cpp:805-841, asks for one read at a time).  The stitched
   // alignment against the reference (traced_aln()) is produced when the haplotype carries its get_aln_info() strings.
-  void trace_optimal_alns(const std::vector<Alignment>& alignments, const std::vector<int>& best_haplotypes, const BaseQuality* /*base_quality*/,
+  void trace_optimal_alns(const std::vector<Alignment>& alignments, const std::vector<int>& best_haplotypes, const BaseQuality* base_quality,
                           std::vector<AlignmentTrace*>& traces){
-    assert(alignments.size() == best_haplotypes.size());
+    trace_optimal_alns(alignments, std::vector<int>(), best_haplotypes, base_quality, traces);
+  }
+  // ... with the seed base of every request (empty: calc_seed_base's value, what process_reads uses)
+  void trace_optimal_alns(const std::vector<Alignment>& alignments, const std::vector<int>& seed_bases, const std::vector<int>& best_haplotypes,
+                          const BaseQuality* /*base_quality*/, std::vector<AlignmentTrace*>& traces){
+    assert(alignments.size() == best_haplotypes.size() && (seed_bases.empty() || seed_bases.size() == alignments.size()));
     traces.clear();
-    std::vector<Alignment> alns; std::vector<int32_t> req_read, req_allele;
+    std::vector<Alignment> alns; std::vector<int32_t> req_read, req_allele, req_seed;
     for (size_t i = 0; i < alignments.size(); i++)          // a masked haplotype is skipped by process_read: empty trace (HapAligner.cpp:614-618)
-      if (realign_to_hap_[best_haplotypes[i]]){ req_read.push_back((int32_t)alns.size()); req_allele.push_back(best_haplotypes[i]); alns.push_back(alignments[i]); }
+      if (realign_to_hap_[best_haplotypes[i]]){
+        req_read.push_back((int32_t)alns.size()); req_allele.push_back(best_haplotypes[i]); alns.push_back(alignments[i]);
+        req_seed.push_back(seed_bases.empty() ? HIPSTR_SEED_AUTO : seed_bases[i]);
+      }
     const int n = (int)alns.size();
     FlatLocus f; f.set_haplotype(fw_haplotype_, realign_to_hap_); f.set_reads(alns, std::vector<bool>(alns.size(), true));
     std::vector<const char*> hap_to_ref;
@@ -360,7 +407,7 @@ class HapAligner {
     o.snp_off = snp_off.data(); o.snp_pos = snp_pos.data(); o.snp_base = snp_base.data();
     o.aln_start = aln_start.data(); o.aln_stop = aln_stop.data(); o.cigar_off = cigar_off.data(); o.cigar_op = cigar_op.data(); o.cigar_len = cigar_len.data();
     o.aln_str_off = aln_str_off.data(); o.aln_str = aln_str.data(); o.cap_chars = cap;
-    if (n > 0 && hipstr_hmm_trace(f.finish(), n, req_read.data(), req_allele.data(), hap_to_ref.empty() ? NULL : hap_to_ref.data(), &o) != 0)
+    if (n > 0 && hipstr_hmm_trace_seeded(f.finish(), n, req_read.data(), req_allele.data(), req_seed.data(), hap_to_ref.empty() ? NULL : hap_to_ref.data(), &o) != 0)
       printErrorAndDie(hipstr_last_error());
     for (size_t i = 0, q = 0; i < alignments.size(); i++){
       AlignmentTrace* t = new AlignmentTrace(fw_haplotype_->num_blocks());

@@ -169,6 +169,25 @@ int main(int argc, char** argv){
     AlignmentTrace* one = aligner.trace_optimal_aln(alns[0], seeds[0], 1, &bq);
     printf("trace_one %s\n", one->hap_aln().c_str());
     delete one;
+    // the seed base is the caller's (HapAligner.h:83, :93): a different split point, through process_read and trace_optimal_aln, against the
+    // C-ABI's seeded entry points on the same flat batch
+    {
+      const int seed2 = seeds[0] - 7;
+      double row[4] = {-1, -1, -1, -1}; AlignmentTrace best_trace(hap.num_blocks());
+      hap.reset();
+      aligner.process_read(alns[0], seed2, &bq, true, row, best_trace);
+      printf("seeded_row"); for (int k = 0; k < 4; k++){ unsigned long long u; memcpy(&u, &row[k], 8); printf(" %016llx", u); } printf("\n");
+      int best = 0; for (int k = 1; k < 4; k++) if (row[k] > row[best]) best = k;
+      AlignmentTrace* tr2 = aligner.trace_optimal_aln(alns[0], seed2, best, &bq);
+      printf("seeded_trace %d %s %s\n", best, tr2->hap_aln().c_str(), best_trace.hap_aln().c_str());
+      delete tr2;
+      hap.go_to(2); hap.fix();                       // a fixed haplotype: one entry, the others untouched
+      double one_row[2] = {-5, -5}; AlignmentTrace dummy(hap.num_blocks());
+      aligner.process_read(alns[0], seed2, &bq, false, one_row, dummy);
+      hap.unfix(); hap.reset();
+      unsigned long long u; memcpy(&u, &one_row[0], 8);
+      printf("seeded_fixed %016llx %.1f\n", u, one_row[1]);
+    }
     // the same haplotype set without handing the strings in: the library derives them (NW + adjust_indels)
     Haplotype hap2(blocks);
     HapAligner aligner2(&hap2, all_haps);

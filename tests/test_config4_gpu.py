@@ -48,7 +48,7 @@ def test_posteriors_and_calls_1000_samples_128_haplotypes(hmm, oracle):
     h2a = (np.arange(A) // 2) % V                    # 2 x 32 x 2 flank options around 32 STR alleles
     want_gt = capi.run_gt_extract(oracle, "oracle_", pb, [V], h2a)
     got_gt = capi.run_gt_extract(hmm, "hipstr_", pb, [V], h2a)
-    util.assert_genotypes_close(got_gt, want_gt, TOL)
+    util.assert_genotypes_close(got_gt, want_gt, TOL, verify=(oracle, pb, [V], h2a))
 
 
 def test_posteriors_and_calls_1000_samples_several_loci(hmm, oracle):
@@ -62,7 +62,7 @@ def test_posteriors_and_calls_1000_samples_several_loci(hmm, oracle):
     assert _close(post, want[0]) and _close(tot, want[1]) and np.array_equal(gt.reshape(-1, 2), want[2]) and _close(lt, want[3])
     h2a = np.tile((np.arange(A) // 2) % V, 3)
     util.assert_genotypes_close(capi.run_gt_extract(hmm, "hipstr_", pb, [V] * 3, h2a),
-                                capi.run_gt_extract(oracle, "oracle_", pb, [V] * 3, h2a), TOL)
+                                capi.run_gt_extract(oracle, "oracle_", pb, [V] * 3, h2a), TOL, verify=(oracle, pb, [V] * 3, h2a))
 
 
 def test_stutter_em_1000_samples(hmm, oracle):

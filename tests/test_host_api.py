@@ -50,6 +50,20 @@ def test_device_parts(_native_built):
         assert got == [e["hap_aln"], str(e["stutter_size"]), e["str_seq"], e["flank_left"], e["flank_right"], str(e["flank_ins"]), str(e["flank_del"]),
                        str(e["aln_start"]), str(e["aln_stop"]), e["cigar"], e["aln_str"]]
     assert kv["trace_one"] == [[rows[1][0]]]
+    # the mirror's process_read / trace_optimal_aln with a seed base of the caller's (7 bases left of calc_seed_base's) == the C-ABI's seeded calls
+    import ctypes as C
+    import numpy as np
+    from hipstr_amd import capi as _capi
+    hmm = _capi.load_hmm()
+    assert int(rr[0]) == 0
+    seed2 = np.array([81 - 7], np.int32); row = np.zeros(4); sd = np.zeros(1, np.int32)
+    ptr = b.ptr
+    assert hmm.hipstr_hmm_process_reads_seeded(ptr, seed2.ctypes.data_as(_capi._i32p), row.ctypes.data_as(_capi._f64p), sd.ctypes.data_as(_capi._i32p)) == 0
+    assert [int(x, 16) for x in kv["seeded_row"][0]] == [int(v) for v in row.view(np.uint64)]
+    best = int(np.argmax(row))
+    tr = _capi.run_trace(hmm, "hipstr_hmm_", ptr, [0], [best], h2r, req_seed=[81 - 7])
+    assert kv["seeded_trace"] == [[str(best), tr[0]["hap_aln"], tr[0]["hap_aln"]]]
+    assert int(kv["seeded_fixed"][0][0], 16) == int(row.view(np.uint64)[2]) and kv["seeded_fixed"][0][1] == "-5.0"
     assert kv["aln_info_derived"] == [[x.decode() for x in h2r]]          # Haplotype::aln_haps_to_ref done by the library
     assert kv["trace_two"] == [[rows[2][7], rows[2][8], rows[2][9]]]
     assert kv["kat_seed"] == [["81"]]
