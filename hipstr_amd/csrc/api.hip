@@ -30,6 +30,8 @@ extern "C" __global__ void hs_str_kernel(const hs_dev_t* dp, int active_begin, i
 extern "C" __global__ void hs_str_kernel_generic(const hs_dev_t* dp, int active_begin, int pw_grouped);
 extern "C" __global__ void hs_combine_kernel(const hs_dev_t* dp, int active_begin);
 extern "C" __global__ void hs_posterior_kernel(const hs_post_dev_t* dp);
+extern "C" __global__ void hs_posterior_accumulate_kernel(const hs_post_dev_t* dp);
+extern "C" __global__ void hs_posterior_finish_kernel(const hs_post_dev_t* dp);
 extern "C" __global__ void hs_genotype_kernel(const hs_gt_dev_t* dp);
 extern "C" size_t hs_str_lds_bytes(int lds_len, int max_B);
 extern "C" __global__ void hs_str_group_kernel(const hs_dev_t* dp, int item_begin, int short_only);
@@ -1079,7 +1081,20 @@ int hipstr_post_launch(hipstr_post_dev_t* pd, void* hip_stream){
     pd->R.h.raw = host_libm ? 1 : 0;
     HS_HIP(hipMemcpy(pd->R.d_args, &pd->R.h, sizeof pd->R.h, hipMemcpyHostToDevice));
   }
-  hipLaunchKernelGGL(hs_posterior_kernel, dim3((unsigned)pd->R.units.size()), dim3(256), 0, st, (const hs_post_dev_t*)pd->R.d_args);
+  {
+    // few units with many diplotypes each (one sample per locus, 128 haplotypes): the accumulation of a unit is shared by several
+    // workgroups, to ~2048 in all (post_kernels.hip; bit-identical either way)
+    const size_t n_units = pd->R.units.size();
+    int max_nd = 1;
+    for (const hs_post_unit_t& u : pd->R.units) max_nd = std::max(max_nd, u.n_alleles*u.n_alleles);
+    const int split = (int)std::min<size_t>((size_t)(max_nd + 255)/256, n_units < 1024 ? (2048 + n_units - 1)/n_units : 1);
+    static const bool no_split = getenv("HIPSTR_POST_SPLIT") && atoi(getenv("HIPSTR_POST_SPLIT")) == 0;       // comparison runs
+    if (split > 1 && !no_split){
+      hipLaunchKernelGGL(hs_posterior_accumulate_kernel, dim3((unsigned)n_units, (unsigned)split), dim3(256), 0, st, (const hs_post_dev_t*)pd->R.d_args);
+      hipLaunchKernelGGL(hs_posterior_finish_kernel, dim3((unsigned)n_units), dim3(256), 0, st, (const hs_post_dev_t*)pd->R.d_args);
+    } else
+      hipLaunchKernelGGL(hs_posterior_kernel, dim3((unsigned)n_units), dim3(256), 0, st, (const hs_post_dev_t*)pd->R.d_args);
+  }
   HS_HIP(hipGetLastError());
   if (host_libm){
     PostRun& R = pd->R;

@@ -41,9 +41,13 @@ __device__ __forceinline__ double fast_lse2(double a, double b, double thr){    
 
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(256)
-hs_posterior_kernel(const hs_post_dev_t* __restrict__ dp){
-  const hs_post_dev_t& d = *dp;
+// phase 0: the whole of it, one workgroup per (locus, sample).  With few units and many diplotypes (configs[4]: 256 loci x ONE sample x
+// 128^2 diplotypes x 200 reads: 256 workgroups of 64 sequential diplotypes per thread on 256 CUs) the accumulation is split over
+// gridDim.y workgroups per unit (phase 1: diplotypes idx = 256 (slice + k gridDim.y) + tid) and the rest — maximum, exact log-sum-exp,
+// normalisation, MAP scan — runs as before in a second launch (phase 2) on the stored sums: a diplotype's accumulation does not depend on
+// which thread owns it and phase 2 is phase 0's second half on the same values, so the results are bit-identical however a batch is split.
+template <int PHASE>
+__device__ __forceinline__ void posterior_body(const hs_post_dev_t& d){
   if (d.unit_active && !d.unit_active[blockIdx.x]) return;
   const hs_post_unit_t u = d.units[blockIdx.x];
   const int A = u.n_alleles, nd = A*A, tid = threadIdx.x;
@@ -55,17 +59,23 @@ hs_posterior_kernel(const hs_post_dev_t* __restrict__ dp){
 
   // ---- accumulate (genotyper.cpp:47-61)
   double lmax = -1.0e300;
-  for (int idx = tid; idx < nd; idx += 256){
-    const int a1 = idx / A, a2 = idx - a1*A;
-    double v = d.log_prior ? d.log_prior[u.prior_off + idx] : ((a1 == a2) ? u.log_hom_prior : u.log_het_prior);
-    for (int r = 0; r < u.n_reads; r++){
-      const int g = u.read_begin + r;
-      const double* LL = LL0 + (int64_t)r*A;
-      const double x = fast_lse2((d.log_half + d.log_p1[g]) + LL[a1], (d.log_half + d.log_p2[g]) + LL[a2], d.log_thresh);
-      v += (double)d.read_weight[g] * x;
+  if (PHASE != 2){
+    const int first = PHASE == 1 ? 256*(int)blockIdx.y + tid : tid, step = PHASE == 1 ? 256*(int)gridDim.y : 256;
+    for (int idx = first; idx < nd; idx += step){
+      const int a1 = idx / A, a2 = idx - a1*A;
+      double v = d.log_prior ? d.log_prior[u.prior_off + idx] : ((a1 == a2) ? u.log_hom_prior : u.log_het_prior);
+      for (int r = 0; r < u.n_reads; r++){
+        const int g = u.read_begin + r;
+        const double* LL = LL0 + (int64_t)r*A;
+        const double x = fast_lse2((d.log_half + d.log_p1[g]) + LL[a1], (d.log_half + d.log_p2[g]) + LL[a2], d.log_thresh);
+        v += (double)d.read_weight[g] * x;
+      }
+      post[idx] = v;
+      lmax = fmax(lmax, v);
     }
-    post[idx] = v;
-    lmax = fmax(lmax, v);
+    if (PHASE == 1) return;
+  } else {
+    for (int idx = tid; idx < nd; idx += 256) lmax = fmax(lmax, post[idx]);
   }
   if (d.raw) return;          // (debug) the host normalises
   // ---- exact log-sum-exp over diplotypes (genotyper.cpp:63-72)
@@ -101,6 +111,10 @@ hs_posterior_kernel(const hs_post_dev_t* __restrict__ dp){
     d.map_gt[2*u.samp_index+1] = none ? -1 : red_i[0] % A;
   }
 }
+
+extern "C" __global__ void __launch_bounds__(256) hs_posterior_kernel(const hs_post_dev_t* __restrict__ dp){ posterior_body<0>(*dp); }
+extern "C" __global__ void __launch_bounds__(256) hs_posterior_accumulate_kernel(const hs_post_dev_t* __restrict__ dp){ posterior_body<1>(*dp); }
+extern "C" __global__ void __launch_bounds__(256) hs_posterior_finish_kernel(const hs_post_dev_t* __restrict__ dp){ posterior_body<2>(*dp); }
 
 
 // Genotyper::extract_genotypes_and_likelihoods (genotyper.cpp:129-251), calc_PLs (99-104), calc_gl_diff (106-127).

@@ -127,3 +127,30 @@ def test_launch_on_a_stream_of_the_callers(hmm):
         assert np.array_equal(post[:int(pb.post_off[-1])], want[0]) and np.array_equal(tot[:S], want[1]) and np.array_equal(gt[:2 * S].reshape(-1, 2), want[2])
     for h in streams:
         hmm.hipstr_debug_stream_destroy(h)
+
+
+def test_split_accumulation_is_bit_identical(hmm, oracle):
+    """Few (locus, sample) units with many diplotypes take hs_posterior_accumulate_kernel (several workgroups per unit) +
+    hs_posterior_finish_kernel; many units take the one-launch kernel.  The same three loci — one sample each, 96 haplotypes, 50 reads —
+    alone (split) and in front of 1100 small single-sample loci (not split) must give the same bits, and agree with the oracle."""
+    rng = np.random.default_rng(8)
+    A_big, R_big, n_big = 96, 50, 3
+    A_small, R_small, n_small = 4, 6, 1100
+    def case(n_tail):
+        A = [A_big] * n_big + [A_small] * n_tail; R = [R_big] * n_big + [R_small] * n_tail
+        off = np.concatenate([[0], np.cumsum(R)]).astype(np.int32); n = int(off[-1])
+        return dict(n_alleles=A, n_samples=[1] * len(A), read_off=off, sample_label=np.zeros(n, np.int32)), n, int(np.dot(A, R))
+    r0 = np.random.default_rng(9)
+    head_n = n_big * R_big; head_ll = -r0.random(head_n * A_big) * 30; head_p1 = -r0.random(head_n); head_p2 = -r0.random(head_n)
+    outs = []
+    for n_tail in (0, n_small):
+        kw, n, nll = case(n_tail)
+        p1 = np.concatenate([head_p1, -rng.random(n - head_n)]); p2 = np.concatenate([head_p2, -rng.random(n - head_n)])
+        ll = np.concatenate([head_ll, -rng.random(nll - head_ll.size) * 30])
+        pb = capi.PostBatch(log_p1=p1, log_p2=p2, read_weight=np.ones(n, np.int32), log_aln_probs=ll, **kw)
+        outs.append((_run(hmm, pb), pb))
+    (a, pba), (b, pbb) = outs
+    npost = n_big * A_big * A_big
+    assert np.array_equal(a[0][:npost], b[0][:npost]) and np.array_equal(a[1][:n_big], b[1][:n_big]) and np.array_equal(a[2][:n_big], b[2][:n_big])
+    want = capi.run_posteriors(oracle, "oracle_", pba)
+    assert _finite_close(a[0], want[0]) and _finite_close(a[1], want[1]) and np.array_equal(a[2], want[2])
