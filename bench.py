@@ -378,6 +378,11 @@ def main():
     hmm.hipstr_hmm_workload(dev, C.byref(n_aln), C.byref(algo), C.byref(cells))
     hap_off = np.ctypeslib.as_array(sb.ptr.contents.hap_off, shape=(loci + 1,))
     A_l = np.diff(hap_off)
+    kinds = (C.c_int64 * 3)()
+    hmm.hipstr_debug_allele_kinds(dev, kinds)
+    n_kinds = max(1, kinds[0] + kinds[1] + kinds[2])
+    str_kinds = {"periodic_tabulated": kinds[1] / n_kinds, "one_or_two_interruptions_piecewise": kinds[2] / n_kinds, "replayed_lists": kinds[0] / n_kinds,
+                 "synth_overrides": {k: v for k, v in os.environ.items() if k.startswith("HIPSTR_SYNTH")}}
     if args.e2e_only:
         hmm.hipstr_hmm_free(dev)
         e = end_to_end(capi, hmm, sb, loci, max(2, min(args.steps, 5), min(48, int(4e7 // max(1.0, float(n_aln.value))))), local, latency=False)
@@ -581,7 +586,8 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, desc) if not args.loci else "%s with %d loci%s: %s" % (args.workload, args.loci, "/GPU" if args.scaling == "weak" else " in total", desc),
                        "loci_per_gpu": loci, "first_locus_rank0": first, "reads_per_locus": P, "alleles_per_locus": A, "read_len": L,
-                       "alignments_per_step_per_gpu": n_aln.value, "sharding": "loci across ranks, no collective on the data path"},
+                       "alignments_per_step_per_gpu": n_aln.value, "sharding": "loci across ranks, no collective on the data path",
+                       "str_allele_sides_by_kernel": str_kinds},
             "loci_per_sec": total_loci * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,

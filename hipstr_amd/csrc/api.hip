@@ -809,6 +809,18 @@ double ApiTimer::now(){ return std::chrono::duration<double>(std::chrono::steady
 }
 int64_t hipstr_debug_driver_allocs(void){ return g_driver_allocs.load(); }
 
+// Diagnostics: how the (realigned allele, side) pairs of a batch split over the STR kernels — counts[1]: every visiting list tabulated
+// (periodic blocks: hs_str_group_kernel_p), counts[2]: simple or piecewise-simple lists (one or two interruptions: hs_str_group_kernel_pw),
+// counts[0]: anything else (hs_str_kernel_generic).
+int hipstr_debug_allele_kinds(hipstr_dev_batch_t* dev, int64_t counts[3]){
+  if (!dev || !counts) return fail("null argument");
+  counts[0] = counts[1] = counts[2] = 0;
+  const hipstr::Prepared& P = dev->prep;
+  for (const hs_allele_t& al : P.alleles)
+    if (al.realign) for (int side = 0; side < 2; side++){ const int k = P.stropts[al.str_opt[side]].kind; if (k >= 0 && k <= 2) counts[k]++; }
+  return 0;
+}
+
 // Diagnostics (tests): a non-blocking HIP stream of the calling thread's context, as a caller of its own would create one, and its release.
 void* hipstr_debug_stream_create(void){
   Ctx* ctx = hipstr::api_current_ctx();

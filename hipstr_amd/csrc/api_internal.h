@@ -33,13 +33,15 @@ void  pin_free(Ctx* ctx, void* p);
 
 // Host arrays that travel together: packed into ONE pinned block and sent with ONE asynchronous copy (a synchronous hipMemcpy from
 // pageable memory costs 10-20 us each; the traceback and Needleman-Wunsch calls of a locus had ten of them).  add() returns a piece's offset;
-// after send() the piece sits at dev + offset.  Both blocks go back to the context's caches when the arena dies — after the stream
-// has been synchronised by its user.
+// after send() the piece sits at dev + offset.  Both blocks go back to the context's caches when the arena dies; the caches serve other
+// host threads, so the arena first waits for the stream its copy went to (an error path may leave while the copy is in flight; on the
+// normal path the results were fetched already and the wait costs a few microseconds).
 struct HostArena {
   struct Piece { const void* src; size_t bytes, off; };
   std::vector<Piece> pieces; size_t total = 0;
   Ctx* ctx = NULL; char* pin = NULL; char* dev = NULL;
-  ~HostArena(){ if (ctx){ if (pin) pin_free(ctx, pin); if (dev) dev_free(ctx, dev); } }
+  hipStream_t sent_on = NULL; bool sent = false;
+  ~HostArena(){ if (ctx){ if (sent) hipStreamSynchronize(sent_on); if (pin) pin_free(ctx, pin); if (dev) dev_free(ctx, dev); } }
   size_t add(const void* src, size_t bytes){
     const size_t off = total; pieces.push_back(Piece{src, bytes, off}); total = (total + (bytes ? bytes : 1) + 255) & ~(size_t)255; return off;
   }
@@ -49,6 +51,7 @@ struct HostArena {
   }
   int send(hipStream_t st){   // pack and copy
     for (const Piece& pc : pieces) if (pc.bytes && pc.src) memcpy(pin + pc.off, pc.src, pc.bytes);
+    sent_on = st; sent = true;
     return (total && hipMemcpyAsync(dev, pin, total, hipMemcpyHostToDevice, st) != hipSuccess) ? api_fail("hipMemcpyAsync (host to device) failed") : 0;
   }
   template <typename T> T* at(size_t off) const { return (T*)(dev + off); }

@@ -725,8 +725,7 @@ struct StrLds {     // one side of one read
   uint8_t* blk;     // [blk_len] block bases of the current allele
   int ld;
 };
-#define HS_ND_TOTAL 192      // sum over the six deletion sizes of min(|D|, n) <= 21 p <= 189
-#define HS_WAVE_LDS (HS_ND_TOTAL + 24 + 2*HS_TAB_CAP)   // doubles of per-wavefront LDS: nd | cstl | tab
+// (HS_ND_TOTAL, HS_WAVE_LDS: layout.h — the host checks a locus' LDS need with the same numbers)
 
 // Marginalisation over the artifact position (StutterAlignerClass.cpp:59-104 insertion, :106-150 deletion).
 // The loop over block offsets is the same for every read column, so the host enumerated it (hs_visit_t) and
@@ -964,11 +963,7 @@ extern __shared__ double hs_lds_raw[];
 
 
 // LDS bytes of one hs_str_kernel workgroup (both sides of a read) for a batch whose longest read has lds_len bases.
-extern "C" size_t hs_str_lds_bytes(int lds_len, int max_B){
-  const size_t Lc = ((size_t)lds_len + 3) & ~(size_t)1;
-  const size_t ilog_len = ((size_t)max_B + 9) & ~(size_t)1, blk_len = ((size_t)max_B + 19) & ~(size_t)15;
-  return Lc*16 + Lc*8*2 + Lc*8*HS_MAXREP + ilog_len*8 + 2*HS_WAVE_LDS*8 + 2*blk_len + ((Lc + 15) & ~(size_t)15);
-}
+extern "C" size_t hs_str_lds_bytes(int lds_len, int max_B){ return hs_str_kernel_lds_bytes(lds_len, max_B); }
 
 // Workgroup = one active read: wave 0 the left side, wave 1 the right side (independent; they share only the LDS
 // carve, whose per-column arrays are exactly len-1 long in total).  Writes M of the STR block's last row for every

@@ -9,6 +9,7 @@
 // haplotype) — HapAligner.cpp:606-628.  "side" 0 = left/forward, 1 = right/reversed.
 #pragma once
 #include <stdint.h>
+#include <stddef.h>
 
 #define HS_PW_SLOTS      10        // 64-bit descriptor slots per piecewise-simple visiting list (prep.cpp emit_stropt)
 #define HS_SHAPE_PIECEWISE (-2)
@@ -25,6 +26,16 @@
 #define HS_MAX_STR_BP    2047      // longest STR allele (11-bit block length fields)
 #define HS_IMPOSSIBLE    (-1000000000.0)   // HapAligner.cpp:20
 #define HS_REDO          (1.0e300)         // mark in the MR workspace: "this chunk of columns is left to hs_str_kernel_generic"
+#define HS_ND_TOTAL 192      // sum over the six deletion sizes of min(|D|, n) <= 21 p <= 189
+#define HS_WAVE_LDS (HS_ND_TOTAL + 24 + 2*HS_TAB_CAP)   // doubles of per-wavefront LDS of hs_str_kernel: nd | cstl | tab
+#define HS_LDS_LIMIT (160*1024)
+// LDS bytes of one hs_str_kernel workgroup (both sides of a read) when the longest read has lds_len bases and the longest STR allele
+// max_B: the host refuses a locus whose reads and alleles would not fit (check_locus), before it shares a batch with others.
+static inline size_t hs_str_kernel_lds_bytes(int lds_len, int max_B){
+  const size_t Lc = ((size_t)lds_len + 3) & ~(size_t)1;
+  const size_t ilog_len = ((size_t)max_B + 9) & ~(size_t)1, blk_len = ((size_t)max_B + 19) & ~(size_t)15;
+  return Lc*16 + Lc*8*2 + Lc*8*6 + ilog_len*8 + 2*HS_WAVE_LDS*8 + 2*blk_len + ((Lc + 15) & ~(size_t)15);
+}
 
 // One haplotype row of a flank block, as the flank sweeps consume it.
 //   bits  0..7   haplotype base (raw char, compared with read chars for equality)

@@ -172,7 +172,10 @@ __global__ void __launch_bounds__(64) hs_nw_walk(const hs_nw_dev_t* __restrict__
 struct NwBufs {
   std::vector<void*> p;
   hipstr::Ctx* ctx = NULL;          // blocks come from (and return to) the context's cache: no hipMalloc / hipFree per call
-  ~NwBufs(){ if (ctx) for (void* x : p) hipstr::dev_free(ctx, x); }
+  // the cache serves other host threads: nothing this call queued may still be running on the blocks when they go back (error paths leave early)
+  hipStream_t streams[3] = {NULL, NULL, NULL}; int n_streams = 0;
+  void runs_on(hipStream_t st){ for (int i = 0; i < n_streams; i++) if (streams[i] == st) return; if (n_streams < 3) streams[n_streams++] = st; }
+  ~NwBufs(){ if (ctx){ for (int i = 0; i < n_streams; i++) hipStreamSynchronize(streams[i]); for (void* x : p) hipstr::dev_free(ctx, x); } }
   template <typename T> int alloc(T** out, size_t count){
     *out = NULL;
     if (!ctx) ctx = hipstr::api_current_ctx();
@@ -253,6 +256,7 @@ extern "C" int hipstr_nw_align(const hipstr_nw_batch_t* nb, hipstr_nw_out_t* o){
     }
     cls_begin[9] = items.size();
     NwBufs ws;
+    ws.runs_on(T.stream);
     hs_nw_dev_t hc = h;
     if (ws.alloc(&hc.trace, tb) || ws.alloc(&hc.last, lf)) return 1;
     // what comes back — score, stop column, leading columns, operation count per pair and the operation strings — is one device block

@@ -753,14 +753,20 @@ int check_locus(const hipstr_batch_t* b, int l, int* opt_cursor_io, std::string&
     if (A != b->hap_off[l+1]-b->hap_off[l]){ err = "hap_off does not match the product of block options"; return 1; }
     if (A >= (1 << 24)){ err = "more than 16 M candidate haplotypes for a locus are not supported"; return 1; }
     if (b->read_off[l+1] < b->read_off[l]){ err = "read_off must not decrease"; return 1; }
+    int longest_B = 1, longest_read = 0;
+    for (int o = 0; o < b->blk_nopts[3*l+1]; o++){ const int c = *opt_cursor_io + b->blk_nopts[3*l] + o; longest_B = std::max(longest_B, b->opt_off[c+1] - b->opt_off[c]); }
     for (int r = b->read_off[l]; r < b->read_off[l+1]; r++){
       if (b->realign_read && !b->realign_read[r]){ if (seeds_out) seeds_out[r] = HIPSTR_SEED_AUTO; continue; }
       const int len = b->base_off[r+1] - b->base_off[r];
+      longest_read = std::max(longest_read, len);
       const int s = calc_seed_base(b, l, r);
       if (seeds_out) seeds_out[r] = s;
       if (s == -2){ err = "Invalid alignment seed or unrecognized CIGAR char (HapAligner.cpp:309,316)"; return 1; }
       if (s >= 0 && (s > HS_MAX_SIDE_FWD || len-s-1 > HS_MAX_SIDE_FWD)){ err = "read side longer than 1024 bases is not supported"; return 1; }
     }
+    // the per-read STR kernels keep a read's tables and the allele's block in LDS: a locus whose longest read and longest allele do not fit
+    // is turned away here, alone — not at upload time, where it would take the batch it shares down with it
+    if (hs_str_kernel_lds_bytes(longest_read, longest_B) > HS_LDS_LIMIT){ err = "reads and STR alleles this long need more than 160 KiB of LDS per workgroup (about 1.8 kb reads; less with alleles near 2 kb)"; return 1; }
   }
   *opt_cursor_io = opt_cursor;
   return 0;

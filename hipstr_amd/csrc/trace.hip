@@ -534,7 +534,10 @@ __global__ void __launch_bounds__(64) hs_trace_walk(const hs_tdev_t* __restrict_
 struct DevBufs {
   std::vector<void*> p;
   hipstr::Ctx* ctx = NULL;          // blocks come from (and return to) the context's cache: no hipMalloc / hipFree per call
-  ~DevBufs(){ if (ctx) for (void* x : p) hipstr::dev_free(ctx, x); }
+  // the cache serves other host threads: nothing this call queued may still be running on the blocks when they go back (error paths leave early)
+  hipStream_t streams[3] = {NULL, NULL, NULL}; int n_streams = 0;
+  void runs_on(hipStream_t st){ for (int i = 0; i < n_streams; i++) if (streams[i] == st) return; if (n_streams < 3) streams[n_streams++] = st; }
+  ~DevBufs(){ if (ctx){ for (int i = 0; i < n_streams; i++) hipStreamSynchronize(streams[i]); for (void* x : p) hipstr::dev_free(ctx, x); } }
   template <typename T> int alloc(T** out, size_t count){
     *out = NULL;
     if (!ctx) ctx = hipstr::api_current_ctx();
@@ -775,6 +778,7 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
   const auto t_prep = now();
   // ---- static device data
   DevBufs dev;
+  dev.runs_on(T.stream);
   hs_tdev_t h; memset(&h, 0, sizeof h);
   const int total_bases = b->base_off[n_reads];
   hipstr::HostArena st_arena;                     // every table of the call: one pinned block, one copy
@@ -897,7 +901,7 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
       if (cnt == 0) continue;
       hipStream_t ks = T.stream;
       const int slot = side ? k_cls % 3 : 0;              // 0: the call's stream; 1, 2: the side streams
-      if (slot){ ks = side->st[slot-1]; if (!side->used[slot-1]){ TR_HIP(hipStreamWaitEvent(ks, side->ev_up, 0)); side->used[slot-1] = true; } }
+      if (slot){ ks = side->st[slot-1]; dev.runs_on(ks); if (!side->used[slot-1]){ TR_HIP(hipStreamWaitEvent(ks, side->ev_up, 0)); side->used[slot-1] = true; } }
       k_cls++;
       switch (cl){
         case 1: hipLaunchKernelGGL(hs_trace_fill<1>, dim3(cnt), dim3(64), 0, ks, d_args, cls_begin[cl-1]); break;

@@ -46,6 +46,7 @@ struct Cfg {
   int32_t n_loci, reads_per_locus, n_str_alleles, read_len, flank_len, str_bp, n_flank_opts;
   uint64_t seed;
   double sub_rate, stutter_rate, indel_rate, imperfect_rate, mask_rate;
+  int inherit;      // HIPSTR_SYNTH_INHERIT=k: the REFERENCE allele carries k (1..3) interrupted repeat units, inherited by every candidate allele
 };
 
 struct Synth {
@@ -101,9 +102,25 @@ void gen_locus(const Cfg& c, int l, Synth& out){
     if ((int)copies.size() < c.n_str_alleles-1) copies.push_back(c0+d);
   }
   std::string ref_str = repeat(motif, c0);
+  // HIPSTR_SYNTH_INHERIT=k: what real panels look like more often than not — the reference allele itself is an interrupted repeat, and the
+  // candidates differ from it in the number of units of its LAST pure tract: k of the first units (not the very first) carry a
+  // substitution, in the reference allele and in every candidate long enough to contain them.  (No generator draws when it is off.)
+  std::vector< std::pair<int,char> > inherited;        // (position from the block's left end, base)
+  if (c.inherit > 0){
+    const int zone = std::max(2, c0/2);                 // units 1 .. zone-1
+    std::vector<int> units;
+    for (int t = 0; t < c.inherit && (int)units.size() < zone - 1; t++){
+      int un; do { un = rng.range(1, zone - 1); } while (std::find(units.begin(), units.end(), un) != units.end());
+      units.push_back(un);
+      const int pos = un*p + rng.below(p);
+      inherited.push_back(std::make_pair(pos, rng.other_base(motif[pos % p])));
+    }
+    for (size_t t = 0; t < inherited.size(); t++) ref_str[inherited[t].first] = inherited[t].second;
+  }
   std::vector<std::string> alts;
   for (size_t i = 0; i < copies.size(); i++){
     std::string a = repeat(motif, copies[i]);
+    for (size_t t = 0; t < inherited.size(); t++) if (inherited[t].first + p <= (int)a.size()) a[inherited[t].first] = inherited[t].second;
     if (rng.uni() < c.imperfect_rate && a.size() > 2){
       int pos = rng.range(1, (int)a.size()-2);
       a[pos] = rng.other_base(a[pos]);
@@ -231,6 +248,8 @@ void* synth_create_at(int32_t first_locus, int32_t n_loci, int32_t reads_per_loc
   c.flank_len = flank_len; c.str_bp = str_bp; c.n_flank_opts = std::max(1, n_flank_opts); c.seed = seed;
   c.sub_rate = 0.005; c.stutter_rate = 0.05; c.indel_rate = 0.01; c.imperfect_rate = 0.05; c.mask_rate = mask_rate;
   if (const char* e = getenv("HIPSTR_SYNTH_IMPERFECT")) c.imperfect_rate = atof(e);      // experiments: share of alleles with an interrupted repeat
+  c.inherit = 0;
+  if (const char* e = getenv("HIPSTR_SYNTH_INHERIT")) c.inherit = std::max(0, std::min(3, atoi(e)));
   Synth* s = new Synth();
   s->opt_off.push_back(0); s->hap_off.push_back(0); s->read_off.push_back(0); s->base_off.push_back(0); s->cigar_off.push_back(0);
   for (int l = 0; l < n_loci; l++) gen_locus(c, first_locus + l, *s);

@@ -94,3 +94,43 @@ def test_invalid_middle_locus_fails_alone(hmm, oracle):
         one = shard.batch_from_arrays(shard.subset_arrays(a, l, l + 1))
         wp, ws = capi.run_align(oracle, "oracle_", one.ptr, fill=FILL)
         assert np.array_equal(probs[out_off[l]:out_off[l + 1]], wp) and np.array_equal(seeds[ro[l]:ro[l + 1]], ws)
+
+
+def test_locus_whose_reads_need_too_much_lds_fails_alone(hmm, oracle):
+    """A read of 1950 bases that starts 50 bases in front of the repeat is seeded near its middle (the midpoint of its long repeat-free
+    stretch): both sides pass the per-side limit (1024 columns), but the read's tables and the locus' 1200-bp candidate allele do not fit the 160 KiB of
+    LDS a workgroup of the per-read STR kernels has.  The check of a single locus (check_locus: hipstr_stream_submit,
+    hipstr_hmm_process_reads_each) must turn that locus away ALONE — it used to pass the check and fail the whole shared batch at upload
+     —, the loci around it are computed."""
+    rng = np.random.default_rng(12)
+    def rnd(n): return "".join(rng.choice(list("ACGT"), n))
+    b = capi.Batch()
+    for l in range(3):
+        left, right = rnd(100 if l == 1 else 40), rnd(1900 if l == 1 else 40)
+        ref = "ACAG" * 10
+        L = 1950 if l == 1 else 100
+        hap = left + ref + right
+        reads = []
+        for r in range(4):
+            start = (len(left) - 50) if l == 1 else int(rng.integers(0, 15))
+            seq = hap[start:start + L]
+            reads.append(dict(seq=seq, qual="F" * len(seq), start=1000 + start, cigar=[("=", len(seq))]))
+        blocks = [(1000, 1000 + len(left), [left]), (1000 + len(left), 1000 + len(left) + len(ref), [ref, "ACAG" * (300 if l == 1 else 11)]),
+                  (1000 + len(left) + len(ref), 1000 + len(hap), [right])]
+        b.add_locus(blocks, 4, util.STUTTER, reads)
+    bb = b.finalize()
+    n_reads, n_out, out_off = capi.batch_dims(bb.ptr)
+    probs = np.full(n_out, FILL); seeds = np.full(n_reads, -7, np.int32); status = np.full(3, -1, np.int32)
+    hmm.hipstr_hmm_process_reads_each.restype = C.c_int
+    hmm.hipstr_hmm_process_reads_each.argtypes = [capi._BP, capi._f64p, capi._i32p, capi._i32p]
+    assert hmm.hipstr_hmm_process_reads_each(bb.ptr, probs.ctypes.data_as(capi._f64p), seeds.ctypes.data_as(capi._i32p), status.ctypes.data_as(capi._i32p)) == 0
+    assert list(status) == [0, 1, 0] and b"LDS" in hmm.hipstr_last_error(), hmm.hipstr_last_error()
+    assert np.all(probs[out_off[1]:out_off[2]] == FILL) and np.all(seeds[4:8] == -7)
+    assert np.all(np.isfinite(probs[out_off[0]:out_off[1]])) and np.all(probs[out_off[0]:out_off[1]] != FILL) and np.all(seeds[:4] >= 0) and np.all(seeds[8:] >= 0)
+    # the same through the stream: the locus is refused at submission, the others go through
+    st = capi.Stream(hmm)
+    try:
+        with pytest.raises(RuntimeError, match="LDS"):
+            st.submit_each(bb.ptr)
+    finally:
+        st.close()
