@@ -378,10 +378,11 @@ def main():
     hmm.hipstr_hmm_workload(dev, C.byref(n_aln), C.byref(algo), C.byref(cells))
     hap_off = np.ctypeslib.as_array(sb.ptr.contents.hap_off, shape=(loci + 1,))
     A_l = np.diff(hap_off)
-    kinds = (C.c_int64 * 3)()
+    kinds = (C.c_int64 * 4)()
     hmm.hipstr_debug_allele_kinds(dev, kinds)
-    n_kinds = max(1, kinds[0] + kinds[1] + kinds[2])
-    str_kinds = {"periodic_tabulated": kinds[1] / n_kinds, "one_or_two_interruptions_piecewise": kinds[2] / n_kinds, "replayed_lists": kinds[0] / n_kinds,
+    n_kinds = max(1, kinds[0] + kinds[1] + kinds[2] + kinds[3])
+    str_kinds = {"periodic_tabulated": kinds[1] / n_kinds, "one_or_two_interruptions_piecewise": kinds[2] / n_kinds, "more_interruptions_replayed_in_group": kinds[3] / n_kinds,
+                 "per_read_generic_kernel": kinds[0] / n_kinds,
                  "synth_overrides": {k: v for k, v in os.environ.items() if k.startswith("HIPSTR_SYNTH")}}
     if args.e2e_only:
         hmm.hipstr_hmm_free(dev)

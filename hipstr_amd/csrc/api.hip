@@ -36,6 +36,7 @@ extern "C" __global__ void hs_genotype_kernel(const hs_gt_dev_t* dp);
 extern "C" size_t hs_str_lds_bytes(int lds_len, int max_B);
 extern "C" __global__ void hs_str_group_kernel(const hs_dev_t* dp, int item_begin, int short_only);
 extern "C" __global__ void hs_str_group_kernel_pw(const hs_dev_t* dp, int item_begin);
+extern "C" __global__ void hs_str_group_kernel_rp(const hs_dev_t* dp, int item_begin);
 extern "C" __global__ void hs_str_group_kernel_p(const hs_dev_t* dp, int item_begin);
 extern "C" __global__ void hs_nd_kernel(const hs_dev_t* dp, int active_begin);
 extern "C" __global__ void hs_expand_stropts_kernel(const hs_dev_t* dp);
@@ -265,6 +266,7 @@ struct hipstr_dev_batch {
   int grid_y = 1, max_alleles = 1, n_lead_items = 0, n_trail_items = 0, trail_waves = 1;
   size_t grp_lds_bytes = 0, grp_pw_lds_bytes = 0;
   bool any_pw = false;           // some locus has alleles with piecewise simple lists (hs_str_group_kernel_pw)
+  bool any_rp = false;           // ... with lists replayed in the grouped layout (hs_str_group_kernel_rp)
   bool any_short = false;        // some locus has tabulated alleles hs_str_group_kernel_p does not take (period above HS_GRP_MAXP)
   size_t lds_bytes = 0;
   hipEvent_t ev0 = NULL, ev1 = NULL;
@@ -501,10 +503,13 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   for (const hs_locus_t& l : P.loci) dev->any_short |= (l.n_short[0] > 0 || l.n_short[1] > 0);
   dev->any_pw = false;
   for (const hs_locus_t& l : P.loci) dev->any_pw |= (l.n_pw[0] > l.n_tab[0] || l.n_pw[1] > l.n_tab[1]);
+  dev->any_rp = false;
+  for (const hs_locus_t& l : P.loci) dev->any_rp |= (l.n_rp[0] > l.n_pw[0] || l.n_rp[1] > l.n_pw[1]);
   dev->grp_lds_bytes = hs_str_group_lds_bytes(h.max_B, h.grp_nd_cap, 0);
   dev->grp_pw_lds_bytes = hs_str_group_lds_bytes(h.max_B, h.grp_nd_cap, 1);
   if (dev->grp_pw_lds_bytes > 48*1024){
     HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_group_kernel_pw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->grp_pw_lds_bytes));
+    HS_HIP_DEV(hipFuncSetAttribute((const void*)hs_str_group_kernel_rp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev->grp_pw_lds_bytes));
   }
   if (getenv("HIPSTR_TIMING")) fprintf(stderr, "hipstr_hmm_upload: STR group kernel LDS %zu bytes (max block %d, read-end table %d doubles, %zu groups)\n", dev->grp_lds_bytes, h.max_B, h.grp_nd_cap, P.str_items.size());
   if (dev->grp_lds_bytes > 48*1024){
@@ -666,6 +671,9 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
       if (dev->any_pw && ch.str_end > ch.str_begin)       // interrupted repeats: the piecewise simple lists' closed forms, grouped like the tabulated ones
         hipLaunchKernelGGL(hs_str_group_kernel_pw, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), dev->grp_pw_lds_bytes, st, dp,
                            dev->n_lead_items + dev->n_trail_items + ch.str_begin);
+      if (dev->any_rp && ch.str_end > ch.str_begin)       // three and more interruptions: lists without a closed form, replayed in the grouped layout
+        hipLaunchKernelGGL(hs_str_group_kernel_rp, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), dev->grp_pw_lds_bytes, st, dp,
+                           dev->n_lead_items + dev->n_trail_items + ch.str_begin);
       if (ch.n_long_sides > 0)        // sides with more columns than a group holds: one workgroup per read as before
         hipLaunchKernelGGL(hs_str_kernel, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin, 1);
     }
@@ -811,13 +819,14 @@ int64_t hipstr_debug_driver_allocs(void){ return g_driver_allocs.load(); }
 
 // Diagnostics: how the (realigned allele, side) pairs of a batch split over the STR kernels — counts[1]: every visiting list tabulated
 // (periodic blocks: hs_str_group_kernel_p), counts[2]: simple or piecewise-simple lists (one or two interruptions: hs_str_group_kernel_pw),
+// counts[3]: at least one list replayed inside the grouped layout (three and more interruptions: hs_str_group_kernel_rp),
 // counts[0]: anything else (hs_str_kernel_generic).
-int hipstr_debug_allele_kinds(hipstr_dev_batch_t* dev, int64_t counts[3]){
+int hipstr_debug_allele_kinds(hipstr_dev_batch_t* dev, int64_t counts[4]){
   if (!dev || !counts) return fail("null argument");
-  counts[0] = counts[1] = counts[2] = 0;
+  counts[0] = counts[1] = counts[2] = counts[3] = 0;
   const hipstr::Prepared& P = dev->prep;
   for (const hs_allele_t& al : P.alleles)
-    if (al.realign) for (int side = 0; side < 2; side++){ const int k = P.stropts[al.str_opt[side]].kind; if (k >= 0 && k <= 2) counts[k]++; }
+    if (al.realign) for (int side = 0; side < 2; side++){ const int k = P.stropts[al.str_opt[side]].kind; if (k >= 0 && k <= 3) counts[k]++; }
   return 0;
 }
 

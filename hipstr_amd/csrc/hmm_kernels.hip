@@ -954,6 +954,54 @@ __device__ __forceinline__ double pw_eval_grp(const PwSlots& S, const double* il
   return mx + (double)f_fasterlog((float)tot);
 }
 
+// visit_eval for the grouped layout (round 4): a list that has no closed form — three and more interruptions of the repeat — replayed
+// entry by entry like visit_eval, but inside hs_str_group_kernel_pw: the entries are the same for every lane (scalar loads from the visit
+// pool), the emission of (column, block base) is one LDS read from the group's table, a lane drops out at its own bound.  Same pushes,
+// same float log-sum-exp (two passes: the maximum, then the sum of the float exponentials in double).
+template <int XC>
+__device__ __forceinline__ double visit_eval_grp(const hs_visit_t* __restrict__ list_g, int llen, const double* ilog, double log_thresh, int Eb, int xx,
+                                              double lp0, int lim, int limmax, int nsub, int stride, int tail){
+  auto ldb = [&](int byte_addr) -> double { return *(const __attribute__((address_space(3))) double*)(uintptr_t)(uint32_t)byte_addr; };
+  // the entries through the constant address space: the address is the same for every lane, so these are scalar loads (s_load_dwordx4 from
+  // the scalar cache, shared by the passes and the workgroup's wavefronts) — as vector loads + readfirstlane each entry was a dependent trip to L2
+  typedef const __attribute__((address_space(4))) hs_visit_t* hs_visit_k;
+  const hs_visit_k list = (hs_visit_k)(uintptr_t)list_g;
+  Lse acc;
+  double lp = lp0;
+  int nistop = 0;
+  for (int pass = 0; pass < 2; pass++){
+    lp = lp0;
+    acc.start(pass, lp0);
+    acc.push(pass, lp0, log_thresh);
+    nistop = 0; bool stopped = false;
+    for (int v = 0; v < llen; v++){
+      const uint64_t meta = list[v].meta;
+      const int ni = (int)(meta & 0xffff);
+      if (ni >= limmax){ if (!stopped) nistop = ni; break; }
+      const bool act = ni < lim;
+      if (!act && !stopped){ nistop = ni; stopped = true; }
+      const int U = (int)((meta >> 16) & 0xffff);
+      if ((meta >> 48) & 1){ if (act) acc.push(pass, lp, log_thresh); }
+      else if (U == 0){
+        const int pla = (((int)(meta >> 33)) & 3) * (XC*8), plb = (((int)(meta >> 41)) & 3) * (XC*8);      // base code ((c >> 1) & 3) -> plane of the emission table
+        double t = lp;
+        for (int m = 1; m <= nsub; m++){
+          const int ca = Eb + 8*max(xx - ni - m*stride, 0);        // a lane past its bound may point in front of its read: not used
+          const double ea = ldb(ca + pla), eb = ldb(ca + plb);
+          t -= ea; t += eb;
+        }
+        lp = act ? t : lp;
+        if (act) acc.push(pass, lp, log_thresh);
+      } else {
+        const double logU = list[v].logU;
+        if (act) acc.push(pass, logU + lp, log_thresh);
+      }
+    }
+    if (nistop < tail) acc.push(pass, ilog[max(tail - nistop, 0)] + lp, log_thresh);
+  }
+  return acc.finish();
+}
+
 }  // namespace
 
 #ifndef HS_STR_WAVES
@@ -1000,7 +1048,7 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin, in
   // alleles in the side's processing order (nested STR blocks follow each other); a chunk of positions per workgroup
   const int n_tab = uni(v.loc->n_tab[w]);
   // MODE 1: the piecewise alleles [n_tab, n_pw) of a side that fits a group are hs_str_group_kernel_pw's (pw_grouped)
-  const int n_gen = (MODE == 1 && only_long /* = pw_grouped */ && n <= HS_GRP_COLS) ? uni(v.loc->n_pw[w]) : n_tab;
+  const int n_gen = (MODE == 1 && only_long /* = pw_grouped */ && n <= HS_GRP_COLS) ? uni(v.loc->n_rp[w]) : n_tab;
   const int r_lo = MODE == 0 ? 0 : n_gen, r_hi = MODE == 0 ? n_tab : uni(v.loc->n_re);
   const int i0 = r_lo + blockIdx.y * d.allele_chunk, i1 = min(r_hi, i0 + d.allele_chunk);
   const int32_t* order = d.str_order + uni(v.loc->order_off[w]);
@@ -1564,7 +1612,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     double* E = Mt + XC;
     double* ndb = E + 4*XC;
     double* cst = ndb + d.grp_nd_cap;
-    const int ilog_len = KIND == 1 ? ((d.max_B + 9) & ~1) : 0;
+    const int ilog_len = KIND >= 1 ? ((d.max_B + 9) & ~1) : 0;
     double* ilogb = cst + 2*24;
     double2* tab = (double2*)(ilogb + ilog_len);
     for (int i = x; i < ilog_len; i += NT) ilogb[i] = d.int_log[i];
@@ -1610,8 +1658,8 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
   }
   const int blk_len = (d.max_B + 19) & ~15;
   const int xrp = xx + g + 1;                       // this column in rowP: rowP[xrp - len] is M of column j - len, or the 0.0 in front when len = j + 1
-  const int n_tab = KIND == 1 ? uni(loc->n_pw[side]) : (short_only ? uni(loc->n_short[side]) : uni(loc->n_tab[side]));      // short_only: hs_str_group_kernel_p has the rest
-  const int i0 = (KIND == 1 ? uni(loc->n_tab[side]) : 0) + blockIdx.y * d.allele_chunk, i1 = min(n_tab, i0 + d.allele_chunk);
+  const int n_tab = KIND == 2 ? uni(loc->n_rp[side]) : (KIND >= 1 ? uni(loc->n_pw[side]) : (short_only ? uni(loc->n_short[side]) : uni(loc->n_tab[side])));      // short_only: hs_str_group_kernel_p has the rest
+  const int i0 = (KIND == 2 ? uni(loc->n_pw[side]) : (KIND >= 1 ? uni(loc->n_tab[side]) : 0)) + blockIdx.y * d.allele_chunk, i1 = min(n_tab, i0 + d.allele_chunk);
   if (i0 >= i1) return;                              // the same for every lane of the workgroup
   const int32_t* order = d.str_order + uni(loc->order_off[side]);
   const int jmaxw = uni(wave_max_i(j)), jminw = uni(wave_min_i(j));
@@ -1686,7 +1734,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       request((k + 1) & 63);
     }
     {
-      if (KIND == 1){
+      if (KIND >= 1){
         // the next allele's descriptor slots (560 bytes, nine cache lines) on their way to the scalar cache: a miss at the point of use is a
         // trip to L2 per list with every wavefront of the workgroup waiting (one destination: the values are not used)
         const int kn = (i + 1 < i1) ? ((k + 1) & 63) : k;
@@ -1714,7 +1762,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       double lp = (t0 > 0) ? L.Mt[xx] : 0.0;
       const int ndp = nv * p;
       int t = t0;
-      if (KIND == 1 && p <= 6 && t % p == 0 && t + p <= min(tmax, ndp)){
+      if (KIND >= 1 && p <= 6 && t % p == 0 && t + p <= min(tmax, ndp)){
         // whole repeat units first: a unit's emissions are requested together and added in order, the deletion table's row written once per
         // unit (an interrupted block rarely continues the previous allele's tables: all its B steps are taken here, one LDS round trip per unit
         // instead of one per step)
@@ -1919,7 +1967,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     if (HS_GABL != 4) __syncthreads();
 
     HS_TICK(4);   // barrier 2 wait
-    if (KIND == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pw_touch) :: "memory");      // (long since there; the register is free again)
+    if (KIND >= 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pw_touch) :: "memory");      // (long since there; the register is free again)
     // --- the 13 artifact terms of this lane's column (HapAligner.cpp:62-109) and their fast_log_sum_exp
     for (int rep3 = 0; rep3 < ((HS_GABL == 7) ? 2 : 1); rep3++)
     if (wave_act && HS_GABL != 2){
@@ -1927,6 +1975,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       double terms[HS_NART];
       double lp0_max = 0.0;
       const int Eb = (int)(uintptr_t)(__attribute__((address_space(3))) char*)L.E;
+      const int k_allele = k;                                 // (the allele's lane in the fetched batch: the lambdas below use k for the list)
       auto load_pw = [&](int k) -> PwSlots {                  // the ten descriptor slots of list k into scalar registers
           PwSlots S;
           typedef int hs_i2w __attribute__((ext_vector_type(2)));
@@ -1942,10 +1991,16 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       };
       auto tab_eval = [&](double lp0, int lim, int k, int nsub, int stride, int tail, const PwSlots* pre) -> double {
         const int shp = rdlane(shapes, k);
-        if (KIND == 1 && shp == HS_SHAPE_PIECEWISE){          // (the same for every lane)
+        if (KIND >= 1 && shp == HS_SHAPE_PIECEWISE){          // (the same for every lane)
           if (pre) return pw_eval_grp<XC>(*pre, L.ilog, d.log_thresh, Eb, xx, lp0, lim, nsub, stride, tail);
           const PwSlots S = load_pw(k);
           return pw_eval_grp<XC>(S, L.ilog, d.log_thresh, Eb, xx, lp0, lim, nsub, stride, tail);
+        }
+        if (KIND == 2 && shp == -1){                          // three and more interruptions: the list itself, replayed (the same for every lane)
+          const hs_stropt_t* so = d.stropts + rdlane(a_sopt, k_allele);
+          const int loff = uni(k == HS_MAXREP ? so->ins_off : so->del_off[min(k, HS_MAXREP - 1)]);
+          const int llen = uni(k == HS_MAXREP ? so->ins_len : so->del_len[min(k, HS_MAXREP - 1)]);
+          return visit_eval_grp<XC>((const hs_visit_t*)d.visits + loff, llen, L.ilog, d.log_thresh, Eb, xx, lp0, lim, tail, nsub, stride, tail);
         }
         const int e = rdlane(tbase, k) + min(lim, 1) + max(lim - shp, 0);
         const double2 ag = tab[e];
@@ -1958,7 +2013,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
         terms[HS_MAXREP] = (rdlane(cst, HS_MAXREP) + L.Mt[xx]) + pre;
       }
       PwSlots Sins;                                           // the insertion list serves all six sizes: its slots are fetched once
-      if (KIND == 1) Sins = load_pw(HS_MAXREP);               // (a kind-2 option has the slots of all seven lists: "not piecewise" where the list is simple)
+      if (KIND >= 1) Sins = load_pw(HS_MAXREP);               // (a kind-2 option has the slots of all seven lists: "not piecewise" where the list is simple)
       else { for (int t = 0; t < 2*HS_PW_SLOTS; t++) Sins.v[t] = 0; }
       auto ins_term = [&](int q, double li){
         const int D = (q+1)*p;
@@ -2042,6 +2097,13 @@ hs_str_group_kernel(const hs_dev_t* __restrict__ dp, int item_begin, int short_o
 #endif
 extern "C" __global__ void __launch_bounds__(HS_GRP_COLS, HS_GRP_PW_OCC)
 hs_str_group_kernel_pw(const hs_dev_t* __restrict__ dp, int item_begin){ str_group_body<1>(*dp, item_begin, 0); }
+// ... and the alleles with a list that has to be replayed (three and more interruptions: hs_stropt_t::kind 3), positions [n_pw, n_rp): the same
+// body with visit_eval_grp for those lists; registers before wavefronts (the replay loop sits inside the 13-term evaluation)
+#ifndef HS_GRP_RP_OCC
+#define HS_GRP_RP_OCC 3
+#endif
+extern "C" __global__ void __launch_bounds__(HS_GRP_COLS, HS_GRP_RP_OCC)
+hs_str_group_kernel_rp(const hs_dev_t* __restrict__ dp, int item_begin){ str_group_body<2>(*dp, item_begin, 0); }
 
 // ------------------------------------------------------------------ the STR block of tabulated alleles, grouped form, period known at compile time
 // hs_str_group_kernel_p<P> takes the tabulated alleles whose blocks hold at least six repeat units of period P (positions

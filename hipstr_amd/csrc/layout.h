@@ -95,7 +95,9 @@ struct hs_stropt_t {
   int32_t tail_codes;
   // Which forward kernel evaluates the option.  1: every list simple and tabulated (tab_len > 0): the grouped kernels with the table;
   // 2: every list simple (tabulated: tab_len entries) or piecewise simple (descriptor slots), block of A/C/G/T: hs_str_group_kernel_pw;
-  // 0: neither (hs_str_kernel_generic).  A kind-2 option's table holds the entries of its simple lists only.
+  // 3: like 2 with at least one list that is neither (replayed entry by entry, still in the grouped layout): hs_str_group_kernel_rp;
+  // 0: none of these (blocks with other characters than A/C/G/T, tables too large: hs_str_kernel_generic).  A kind-2/3 option's table holds
+  // the entries of its simple lists only.
   int32_t kind;
   // Round 4: the constants and the closed-form table of an option whose whole block repeats with the period (nearly all) are not built
   // on the host any more.  gen = 1: f64_off / tab_off count from the start of the GENERATED region of the f64 pool (hs_dev_t::f64_gen_base),
@@ -141,6 +143,8 @@ struct hs_locus_t {
                              // hs_str_group_kernel_pw's; the rest, [n_pw, n_re), is hs_str_kernel_generic's
   int32_t period;            // the locus' STR period (the same for all of its alleles)
   int32_t pad_;
+  int32_t n_rp[2];           // positions [n_pw, n_rp) of the order: alleles with a list that has no closed form (three and more interruptions;
+                             // hs_stropt_t::kind 3): hs_str_group_kernel_rp replays it inside the grouped layout; [n_rp, n_re) is hs_str_kernel_generic's
 };
 
 // One row of read-end deletion sums (hs_nd_kernel): the start values of StutterAlignerClass.cpp:117-120 for the columns within six repeat

@@ -620,9 +620,17 @@ void emit_stropt(const char* blk, const int B, int period, const double pmf13[HS
   }
   // the descriptor slots are read only where a shape says "piecewise" (hs_str_kernel_generic): 560 bytes that the periodic blocks —
   // nearly all of them — do not need
-  bool any_pw = false;
-  for (int k = 0; k <= HS_MAXREP; k++) any_pw |= (so.shape[k] == HS_SHAPE_PIECEWISE);
-  if (any_pw){
+  bool any_pw = false, any_replay = false;
+  for (int k = 0; k <= HS_MAXREP; k++){
+    const int tail = (k == HS_MAXREP) ? B : B - (k+1)*period;
+    any_pw |= (so.shape[k] == HS_SHAPE_PIECEWISE);
+    any_replay |= (tail >= 0 && so.shape[k] == -1);
+  }
+  // (round 4: hs_str_group_kernel_pw also replays the lists that have no closed form — three and more interruptions — so an option with
+  //  such lists stays in the grouped layout (kind 2) as long as its block is made of A/C/G/T; HIPSTR_STR_GROUP_REPLAY=0: they go to
+  //  hs_str_kernel_generic as before, for comparison)
+  static const bool group_replay = !(getenv("HIPSTR_STR_GROUP_REPLAY") && atoi(getenv("HIPSTR_STR_GROUP_REPLAY")) == 0);
+  if (any_pw || (any_replay && group_replay)){
     const size_t at = out.f64pool.size();
     out.f64pool.resize(at + (HS_MAXREP + 1)*HS_PW_SLOTS);
     memcpy(out.f64pool.data() + at, pw, sizeof pw);
@@ -640,11 +648,12 @@ void emit_stropt(const char* blk, const int B, int period, const double pmf13[HS
       so.tab_base[k] = total;
       if (tail < 0) continue;                           // this deletion size is never evaluated
       if (so.shape[k] == HS_SHAPE_PIECEWISE && !no_pw_group) continue;      // evaluated from its descriptor slots (hs_str_group_kernel_pw)
+      if (so.shape[k] == -1 && group_replay && !no_pw_group) continue;      // replayed in the grouped layout (visit_eval_grp)
       if (so.shape[k] < 0){ ok = false; break; }
       total += 2 + std::max(0, tail - so.shape[k]);
     }
     if (ok && total <= HS_TAB_CAP){
-      so.kind = any_pw ? 2 : 1;
+      so.kind = any_replay ? 3 : (any_pw ? 2 : 1);
       out.f64pool.resize((size_t)so.tab_off + 3*(size_t)total + 1);
       double* ent = out.f64pool.data() + so.tab_off;
       double bmin = 1e300;                              // what the kernel compares |lp0| with: the weakest guarantee of the table
@@ -1069,7 +1078,7 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
     S.opt_rank.resize(nopts[1]); S.os.resize(nopts[1]);
     for (int o = 0; o < nopts[1]; o++) S.os[o] = o;
     stable_small_sort(S.os.data(), nopts[1], [&](int x, int y){
-      static const int kind_rank[3] = {2, 0, 1};                  // tabulated, then piecewise, then the rest
+      static const int kind_rank[4] = {3, 0, 1, 2};               // tabulated, then piecewise, then replayed in the grouped layout, then the rest
       const int tx = kind_rank[so_side[x].kind], ty = kind_rank[so_side[y].kind];
       if (tx != ty) return tx < ty;
       if (blk[x].n != blk[y].n) return blk[x].n < blk[y].n;
@@ -1089,7 +1098,7 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
     for (int k = 0; k < A; k++) if (out.alleles[allele_base + k].realign) S.ks[S.cnt[S.opt_rank[S.str_opt_of[k]]]++] = k;
     const std::vector<int32_t>& ks = S.ks;
     loc.order_off[side] = out.str_order.size();
-    loc.n_tab[side] = 0; loc.n_short[side] = 0; loc.n_pw[side] = 0;
+    loc.n_tab[side] = 0; loc.n_short[side] = 0; loc.n_pw[side] = 0; loc.n_rp[side] = 0;
     loc.rec_off[side] = (int32_t)out.rec_descs.size();
     loc.ndrow_off[side] = (int32_t)out.nd_rows.size(); loc.n_ndrows[side] = 0;
     int fam_row0 = 0, fam_k = 0;                     // first row of the current family of alleles (blocks growing by one repeat unit), position in it
@@ -1125,7 +1134,8 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
         }
         if (period > HS_GRP_MAXP) loc.n_short[side]++;              // no instantiation of hs_str_group_kernel_p for this period
       }
-      if (kind_of(ks[i]) != 0) loc.n_pw[side]++;      // (kinds 1 and 2 come first: n_pw counts both, the piecewise ones are [n_tab, n_pw))
+      if (kind_of(ks[i]) == 1 || kind_of(ks[i]) == 2) loc.n_pw[side]++;      // (kinds 1 and 2 come first: n_pw counts both, the piecewise ones are [n_tab, n_pw))
+      if (kind_of(ks[i]) != 0) loc.n_rp[side]++;                             // (... then kind 3: [n_pw, n_rp))
       prev = cur;
     }
   }
@@ -1432,7 +1442,7 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
         // STR-block items (hs_str_group_kernel): reads of this locus and side whose columns, laid end to end, fill one workgroup's
         // lanes.  First fit, longest side first; a group holds at most HS_GRP_MAXREADS reads and 2 HS_GRP_COLS read-end deletion sums
         // (21 period per read).  item.active = first entry in tpack, item.slot = number of reads, item.rowset = their columns
-        if (loc.n_pw[s] > 0){
+        if (loc.n_rp[s] > 0){
           const int period = out.stropts[out.alleles[loc.hap_begin + (out.str_order[loc.order_off[s]] & 0x1fffffff)].str_opt[s]].period;
           const int max_reads = std::max(1, std::min(16, 2*HS_GRP_COLS / (21*period)));
           bins.clear(); size_t first_open = 0;

@@ -485,8 +485,9 @@ int hipstr_debug_api_profile(int mode, int cap, const char** names, double* seco
  * 1 s each).  A stream is in its steady state once this stops growing from pass to pass. */
 int64_t hipstr_debug_driver_allocs(void);
 /* Diagnostics: (realigned allele, side) pairs of a batch by the STR kernel that takes them: counts[1] periodic blocks (tabulated closed form),
- * counts[2] blocks with one or two interruptions (piecewise closed form), counts[0] the rest (replayed lists). */
-int hipstr_debug_allele_kinds(hipstr_dev_batch_t* dev, int64_t counts[3]);
+ * counts[2] blocks with one or two interruptions (piecewise closed form), counts[3] more interruptions (lists replayed in the grouped layout),
+ * counts[0] the rest (per-read kernel). */
+int hipstr_debug_allele_kinds(hipstr_dev_batch_t* dev, int64_t counts[4]);
 /* Diagnostics (tests): a non-blocking HIP stream made by the library's own HIP runtime — what a caller passes as `hip_stream` — and its release. */
 void* hipstr_debug_stream_create(void);
 void hipstr_debug_stream_destroy(void* hip_stream);

@@ -12,6 +12,7 @@ assert hmm.hipstr_hmm_init(0) == 0
 bad = 0; total = 0
 for c in range(n_cfg):
     os.environ["HIPSTR_SYNTH_IMPERFECT"] = str(float(rng.choice([0.0, 0.05, 0.3, 1.0])))
+    os.environ["HIPSTR_SYNTH_INHERIT"] = str(int(rng.choice([0, 0, 1, 2, 3])))        # interruptions inherited from the reference allele (round 4)
     read_len = int(rng.integers(24, 251))
     kw = dict(n_loci=int(rng.integers(1, 5)), reads_per_locus=int(rng.integers(1, 40)), n_str_alleles=int(rng.integers(1, 41)), read_len=read_len,
               flank_len=int(rng.integers(8, 161)), str_bp=int(rng.integers(4, 121)), n_flank_opts=int(rng.integers(1, 4)),
@@ -30,5 +31,5 @@ for c in range(n_cfg):
     if not ok:
         bad += 1
         d = np.abs(got - want)
-        print("MISMATCH", kw, os.environ["HIPSTR_SYNTH_IMPERFECT"], "n", got.size, "nbad", int((d > 0).sum()), "max", d.max())
+        print("MISMATCH", kw, os.environ["HIPSTR_SYNTH_IMPERFECT"], os.environ["HIPSTR_SYNTH_INHERIT"], "n", got.size, "nbad", int((d > 0).sum()), "max", d.max())
 print("configs", n_cfg, "alignments", total, "mismatching configs", bad)
