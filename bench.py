@@ -268,14 +268,19 @@ def end_to_end(capi, hmm, sb, loci, steps, device, latency=True):
         one_pass_set(1); warm += 1
         if warm >= int(os.environ.get("HIPSTR_BENCH_E2E_WARMUP", "4")) and hmm.hipstr_debug_driver_allocs() == a0:
             break
-    s0 = st.stats()
-    a_timed0 = hmm.hipstr_debug_driver_allocs()
-    c0 = time.process_time()
-    t0 = time.perf_counter()
-    one_pass_set(steps)
-    dt = time.perf_counter() - t0
-    cpu_s = time.process_time() - c0              # CPU seconds of ALL threads of the process over the timed passes
-    s1 = st.stats()
+    # the timed passes; taken again (at most twice) when a block-cache miss — a hipMalloc / hipHostMalloc next to running kernels, 0.1-0.9 s —
+    # fell into them: how many batches are in flight varies with the box's load, so a new size class can still turn up after the warm-up
+    for attempt in range(3):
+        s0 = st.stats()
+        a_timed0 = hmm.hipstr_debug_driver_allocs()
+        c0 = time.process_time()
+        t0 = time.perf_counter()
+        one_pass_set(steps)
+        dt = time.perf_counter() - t0
+        cpu_s = time.process_time() - c0              # CPU seconds of ALL threads of the process over the timed passes
+        s1 = st.stats()
+        if hmm.hipstr_debug_driver_allocs() == a_timed0:
+            break
     st.close()
     # one-locus latency: a 30x locus (40 reads x 32 alleles) and an NS locus through the one-shot call, median of 30
     lat = {}
@@ -293,7 +298,7 @@ def end_to_end(capi, hmm, sb, loci, steps, device, latency=True):
             "collector_wait_seconds": s1["wait_seconds"] - s0["wait_seconds"],
             "process_cpu_seconds": cpu_s, "process_cpu_ms_per_pass": 1e3 * cpu_s / steps, "process_cpu_us_per_locus": 1e6 * cpu_s / (steps * loci),
             "cpu_seconds_by_role": {k[4:-8]: s1[k] - s0[k] for k in ("cpu_submit_seconds", "cpu_prepare_seconds", "cpu_upload_seconds", "cpu_collect_seconds")},
-            "warmup_passes": warm, "driver_allocs_during_timed_passes": int(hmm.hipstr_debug_driver_allocs() - a_timed0),
+            "warmup_passes": warm, "timed_attempts": attempt + 1, "driver_allocs_during_timed_passes": int(hmm.hipstr_debug_driver_allocs() - a_timed0),
             "one_locus_process_reads_latency": lat,
             "path": "hipstr_stream_submit_each (1 locus per submission) -> batches of ~2 Mi alignments -> prepare on host threads + H2D + table expansion + kernels + D2H, 8 slots -> hipstr_stream_collect in order"}
 

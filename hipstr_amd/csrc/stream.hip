@@ -274,7 +274,11 @@ void worker_loop(hipstr_stream* s, int n_workers){
   hipstr::api_bind(s->ctx);
   // the workers prepare different batches at the same time: each takes its share of the host threads (one thread each on a two-core
   // allowance — then a batch is prepared without fragments, merges or hand-overs to pool threads)
-  hipstr::set_thread_budget(std::max(1, hipstr::host_threads() / std::max(1, n_workers)));
+  {
+    int budget = std::max(1, hipstr::host_threads() / std::max(1, n_workers));
+    if (const char* e = getenv("HIPSTR_STREAM_WORKER_THREADS")){ const int v = atoi(e); if (v >= 1) budget = v; }
+    hipstr::set_thread_budget(budget);
+  }
   for (;;){
     OwnedBatch* ob = NULL;
     {

@@ -40,7 +40,7 @@ def classify(m):
 
 
 out = {}
-for src in ("hmm_kernels.hip", "post_kernels.hip"):
+for src in ("hmm_kernels.hip", "post_kernels.hip", "expand_kernels.hip"):
     with tempfile.TemporaryDirectory() as t:
         asm = os.path.join(t, "k.s")
         flags = [f for f in build.HIPCC_FLAGS if f not in ("-shared", "-fPIC", "-pthread")]
