@@ -31,6 +31,7 @@
 #include <cstdlib>
 #include <iostream>
 #include <map>
+#include <unordered_map>
 #include <string>
 #include <utility>
 #include <vector>
@@ -184,35 +185,43 @@ class Haplotype {
 };
 
 class ReadPooler {
-  std::vector<Alignment> pooled_alns_;
-  std::vector< std::vector<std::string> > qualities_by_pool_;
-  std::map<std::string, int32_t> seq_to_pool_;
-  bool pooled_; int32_t pool_index_;
+  // one record per distinct read sequence, in order of first appearance: the representative alignment and every member's qualities
+  struct Pool { Alignment rep; std::vector<std::string> member_quals; };
+  std::vector<Pool> pools_;
+  std::vector<Alignment> reps_;                                  // filled by pool(): what get_alignments() hands out
+  std::unordered_map<std::string, int32_t> index_of_seq_;
+  bool closed_ = false;
  public:
-  ReadPooler() : pooled_(false), pool_index_(0) {}
-  int32_t num_pools() const { return pool_index_; }
-  int32_t add_alignment(Alignment& aln){                         // read_pooler.cpp:3-20
-    if (pooled_) printErrorAndDie("Cannot call add_alignment function once pool() function has been invoked");
-    std::map<std::string, int32_t>::iterator it = seq_to_pool_.find(aln.get_sequence());
-    if (it == seq_to_pool_.end()){
-      seq_to_pool_[aln.get_sequence()] = pool_index_;
-      pooled_alns_.push_back(Alignment(aln.get_start(), aln.get_stop(), false, "READPOOL", "", aln.get_sequence(), aln.get_alignment()));
-      pooled_alns_.back().set_cigar_list(aln.get_cigar_list());
-      qualities_by_pool_.push_back(std::vector<std::string>(1, aln.get_base_qualities()));
-      return pool_index_++;
+  int32_t num_pools() const { return (int32_t)pools_.size(); }
+  // the pool index of the read's sequence; a sequence seen for the first time opens a pool around a copy of the alignment
+  // (read_pooler.cpp:3-20: same position, cigar and alignment string, name "READPOOL", no qualities until pool())
+  int32_t add_alignment(Alignment& aln){
+    if (closed_) printErrorAndDie("Cannot call add_alignment function once pool() function has been invoked");
+    const std::string& seq = aln.get_sequence();
+    const auto ins = index_of_seq_.emplace(seq, (int32_t)pools_.size());
+    if (ins.second){
+      Pool p{Alignment(aln.get_start(), aln.get_stop(), false, "READPOOL", "", seq, aln.get_alignment()), {}};
+      p.rep.set_cigar_list(aln.get_cigar_list());
+      pools_.push_back(std::move(p));
     }
-    qualities_by_pool_[it->second].push_back(aln.get_base_qualities());
-    return it->second;
+    pools_[ins.first->second].member_quals.push_back(aln.get_base_qualities());
+    return ins.first->second;
   }
-  void pool(const BaseQuality& base_quality){                    // read_pooler.h:42-48
-    for (size_t i = 0; i < pooled_alns_.size(); i++){
-      std::vector<const std::string*> ptrs;
-      for (size_t j = 0; j < qualities_by_pool_[i].size(); j++) ptrs.push_back(&qualities_by_pool_[i][j]);
-      pooled_alns_[i].set_base_qualities(base_quality.median_base_qualities(ptrs));
+  // every pool's representative gets the per-position median of its members' qualities (read_pooler.h:42-48)
+  void pool(const BaseQuality& base_quality){
+    reps_.clear(); reps_.reserve(pools_.size());
+    for (Pool& p : pools_){
+      std::vector<const std::string*> members; members.reserve(p.member_quals.size());
+      for (const std::string& q : p.member_quals) members.push_back(&q);
+      p.rep.set_base_qualities(base_quality.median_base_qualities(members));
+      reps_.push_back(p.rep);
     }
-    pooled_ = true;
+    closed_ = true;
   }
-  std::vector<Alignment>& get_alignments(){ return pooled_alns_; }
+  std::vector<Alignment>& get_alignments(){
+    if (!closed_){ reps_.clear(); for (Pool& p : pools_) reps_.push_back(p.rep); }
+    return reps_;
+  }
 };
 
 // AlignmentTrace (AlignmentTraceback.h:10-108): what a traceback reports about one read.
