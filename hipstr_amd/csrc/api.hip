@@ -29,6 +29,7 @@
 extern "C" __global__ void hs_str_kernel(const hs_dev_t* dp, int active_begin, int only_long);
 extern "C" __global__ void hs_str_kernel_generic(const hs_dev_t* dp, int active_begin, int pw_grouped);
 extern "C" __global__ void hs_combine_kernel(const hs_dev_t* dp, int active_begin);
+extern "C" int hs_combine_waves();
 extern "C" __global__ void hs_posterior_kernel(const hs_post_dev_t* dp);
 extern "C" __global__ void hs_posterior_accumulate_kernel(const hs_post_dev_t* dp);
 extern "C" __global__ void hs_posterior_finish_kernel(const hs_post_dev_t* dp);
@@ -684,7 +685,7 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
       hs_launch_trail((unsigned)std::min(dev->trail_waves, ch.trail_end - ch.trail_begin), st, dp,
                       dev->n_lead_items + ch.trail_begin, dev->n_lead_items + ch.trail_end, 2*chunk_no + 1);
     if (mark()) return 1;
-    hipLaunchKernelGGL(hs_combine_kernel, dim3(nact), dim3(256), 0, st, dp, ch.active_begin);
+    hipLaunchKernelGGL(hs_combine_kernel, dim3(nact), dim3(64*hs_combine_waves()), 0, st, dp, ch.active_begin);
     if (mark()) return 1;
     HS_HIP(hipGetLastError());
     chunk_no++;

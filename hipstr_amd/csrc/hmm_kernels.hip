@@ -2132,6 +2132,49 @@ extern "C" size_t hs_str_group_p_lds_bytes(){ return HS_GRP_P_LDS_BYTES; }
 // these sums were its critical path — 50 to 150 dependent additions on a quarter of a workgroup's lanes while the other wavefronts waited
 // at a barrier.  Here every (row, column) pair of a read side is a lane of its own, rows of near-equal length next to each other, and
 // the latency is hidden by the other workgroups; the group kernel fetches its six values per column (hs_ws_t::nd).
+// The entries of a read side's read-end rows, period P: entry e = (row, distance of the column from the read end).  Step t of an entry's sum
+// pairs column j - t with block base (t mod P) from the right end, so the P LDS addresses of a repeat unit move together: one address
+// per base of the unit, stepped once per group of units, the group's emissions requested together and added in the reference's order
+// (the additions are the same chain as before: bit-identical; the loop was one LDS round trip per step).
+template <int P>
+__device__ __forceinline__ void nd_entries(const hs_dev_t& d, const hs_ndrow_t* __restrict__ rows, double* __restrict__ out, int total, int sixp, int n, int tid, int e_lds){
+  constexpr int M = (P == 1) ? 6 : (P == 2) ? 3 : (P == 3) ? 2 : 1;       // repeat units per group: four to six steps
+  constexpr int GS = M*P;
+  auto ldb = [](int byte_addr) -> double { return *(const __attribute__((address_space(3))) double*)(uintptr_t)(uint32_t)byte_addr; };
+  for (int e = tid; e < total; e += 256){
+    const int r = e / sixp, off = e - r*sixp;
+    const hs_ndrow_t rw = rows[r];
+    const int j = n - 1 - off;
+    if (rw.len < 0 || j < 0) continue;                  // no allele has this size / the read side has no such column
+    const int len = min(rw.len, j + 1);
+    double lp = -d.int_log[rw.len + 1];                 // the position prior (StutterAlignerClass.cpp:112)
+    int a[P];                                           // byte address of column j - t - k against the block base k from the right end
+#pragma unroll
+    for (int k = 0; k < P; k++) a[k] = e_lds + (((rw.tail_codes >> (2*k)) & 3)*HS_MAX_SIDE_LEN + j - k)*8;
+    int t = 0;
+    for (; t + GS <= len; t += GS){
+      double ev[GS];
+      // the group's lowest column is >= 0, so a[k] - (GS-P)*8 is an LDS address: masked to say so, the units' distances become the
+      // instruction's (unsigned) offset field instead of an addition each
+#pragma unroll
+      for (int k = 0; k < P; k++){
+        const int lo = (a[k] - (GS - P)*8) & 0x3ffff;
+#pragma unroll
+        for (int m = 0; m < M; m++) ev[m*P + k] = ldb(lo + (GS - P - m*P)*8);
+      }
+#pragma unroll
+      for (int k = 0; k < P; k++) a[k] -= GS*8;
+#pragma unroll
+      for (int q = 0; q < GS; q++) lp += ev[q];
+    }
+    for (int k = 0; t < len; t++, k = (k + 1 == P) ? 0 : k + 1){      // the last, partial group
+#pragma unroll
+      for (int kk = 0; kk < P; kk++) if (kk == k){ lp += ldb(a[kk]); a[kk] -= P*8; }
+    }
+    out[e] = lp;
+  }
+}
+
 extern "C" __global__ void __launch_bounds__(256)
 hs_nd_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
   const hs_dev_t& d = *dp;
@@ -2154,21 +2197,15 @@ hs_nd_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
   const hs_ndrow_t* rows = d.nd_rows + uni(loc->ndrow_off[side]);
   double* out = d.ws_nd + uni(side ? d.ws[ai].nd[1] : d.ws[ai].nd[0]);
   const int total = nrows*sixp;
-  for (int e = tid; e < total; e += 256){
-    const int r = e / sixp, off = e - r*sixp;
-    const hs_ndrow_t rw = rows[r];
-    const int j = n - 1 - off;
-    if (rw.len < 0 || j < 0) continue;                  // no allele has this size / the read side has no such column
-    const int len = min(rw.len, j + 1);
-    double lp = -d.int_log[rw.len + 1];                 // the position prior (StutterAlignerClass.cpp:112)
-    const double* Ej = &E[0][0] + j;
-    const int codes = rw.tail_codes; int t = 0;         // step t pairs column j - t with the block base (t mod p) from the right end
-    for (; t + p <= len; t += p){
-      int c = codes;
-      for (int k = 0; k < p; k++){ lp += Ej[(c & 3)*HS_MAX_SIDE_LEN - t - k]; c >>= 2; }
-    }
-    for (int c = codes; t < len; t++){ lp += Ej[(c & 3)*HS_MAX_SIDE_LEN - t]; c >>= 2; }
-    out[e] = lp;
+  const int e_lds = (int)(uintptr_t)(__attribute__((address_space(3))) char*)&E[0][0];
+  switch (p){
+    case 1: nd_entries<1>(d, rows, out, total, sixp, n, tid, e_lds); break;
+    case 2: nd_entries<2>(d, rows, out, total, sixp, n, tid, e_lds); break;
+    case 3: nd_entries<3>(d, rows, out, total, sixp, n, tid, e_lds); break;
+    case 4: nd_entries<4>(d, rows, out, total, sixp, n, tid, e_lds); break;
+    case 5: nd_entries<5>(d, rows, out, total, sixp, n, tid, e_lds); break;
+    case 6: nd_entries<6>(d, rows, out, total, sixp, n, tid, e_lds); break;
+    default: break;                                  // HS_MAXREP periods only (prep.cpp: longer periods have no read-end rows)
   }
 }
 
@@ -2520,40 +2557,103 @@ hs_str_group_kernel_p(const hs_dev_t* __restrict__ dp, int item_begin){
 
 
 // compute_aln_logprob (HapAligner.cpp:163-231): log-sum-exp over the haplotype positions the seed base can sit on.
-// One workgroup (4 wavefronts) per active read; a wavefront takes every fourth realigned allele, so what depends on the read only
-// (side views, seed base, leading-flank records) is set up once per wavefront.
-extern "C" __global__ void __launch_bounds__(256)
-hs_combine_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
-  const hs_dev_t& d = *dp;
-  const int lane = threadIdx.x & 63;
-  const int ai = active_begin + blockIdx.x;
-  const SideView vL = side_view(d, ai, 0);
-  const SideView vR = side_view(d, ai, 1);
-  const uint8_t seed_c = (uint8_t)d.bases[vL.base_off + vL.nL];
-  const uint8_t seed_q = (uint8_t)d.quals[vL.base_off + vL.nL];
-  const double seed_lc = d.qual_correct[seed_q], seed_lw = d.qual_error[seed_q];
-  const int n_alleles = uni(vL.loc->n_alleles);
-  const int hap_begin = uni(vL.loc->hap_begin);
-  // allele records and their rowsets are fetched 64 alleles at a time, one allele per lane, and then read lane by lane: two memory
-  // round trips per 64 alleles instead of three dependent scalar loads per allele
-  for (int kb = 0; kb < n_alleles; kb += 64){
-  const int kl = min(kb + lane, n_alleles - 1);
-  const hs_allele_t alv = d.alleles[hap_begin + kl];
-  const hs_rowset_t rsl = d.rowsets[alv.lead_rows[0]], rst = d.rowsets[alv.trail_rows[0]];
-  for (int k = kb + (threadIdx.x >> 6); k < min(n_alleles, kb + 64); k += 4){
-  const int kk = k - kb;
-  if (!rdlane(alv.realign, kk)) continue;
-  const int N = rdlane(alv.n_flank, kk), ord = rdlane(alv.re_ord, kk);
-  const int lead_off = rdlane(rsl.off, kk), F0 = rdlane(rsl.len, kk);
-  const int trail_off = rdlane(rst.off, kk), F2 = N - F0;
-  const int slotL = rdlane(alv.lead_slot[0], kk), slotR = rdlane(alv.lead_slot[1], kk);
+//
+// A term of the sum is ((prior + e(y)) + a) + b (HapAligner.cpp:182-229) where exactly one of a, b comes from the allele's own hand-off
+// rows (the STR block's row in MR, the trailing rows in LT) and the other one from the read's leading-flank record, which the alleles of a
+// locus share.  What does not depend on the allele — prior, emission of the seed base, the shared addend, the ADDRESS of the allele's
+// value for workspace row 0 and its stride per row — is therefore set up once per (read, flank configuration) in registers, lane = seed
+// position (up to HS_CMB_ROUNDS x 64 positions); an allele then costs one address, one load and two additions per position:
+//     term = (X + v) + Y      X = prior + e, Y = shared addend        where the allele's value is the first addend
+//                             X = (prior + e) + shared, Y = -0.0      where it is the second (x + -0.0 == x for every x)
+// Four alleles go through the maximum and the sum together: two lane swaps (v_permlane32_swap, v_permlane16_swap) leave every row of 16
+// lanes with one allele's partial results, so that the row-wise DPP steps reduce four alleles at once and lanes 15/31/47/63 finish and
+// store one allele each.  Haplotypes with an empty flank or more than HS_CMB_ROUNDS x 64 flank bases take the per-allele form below.
+#ifndef HS_CMB_WAVES
+#define HS_CMB_WAVES 1        // wavefronts per active read: a wavefront sets its registers up once and takes every HS_CMB_WAVES-th quad of alleles
+                              // (NS: 1 -> 3.55 ms, 2 -> 3.76, 4 -> 4.86; the kernel reads 15 GB of LT per pass: ~4 TB/s)
+#endif
+#ifndef HS_CMB_ROUNDS
+#define HS_CMB_ROUNDS 4
+#endif
+
+// swap of 32-lane halves / of 16-lane rows between two registers, for doubles (gfx950: v_permlane32_swap, v_permlane16_swap)
+//   halves: a' = [a.lo32 | b.lo32], b' = [a.hi32 | b.hi32]        rows: a' = [a.r0 b.r0 a.r2 b.r2], b' = [a.r1 b.r1 a.r3 b.r3]
+__device__ __forceinline__ void swap_halves(double& a, double& b){
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi[0], (int)lo[0]); b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ void swap_rows(double& a, double& b){
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi[0], (int)lo[0]); b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// four per-lane values, one per allele of a quad -> one register whose 16-lane rows hold the alleles [0, 2, 1, 3], reduced row-wise:
+// lane 15 of a row ends with the row's maximum / sum
+__device__ __forceinline__ double quad_max(double a0, double a1, double a2, double a3){
+  swap_halves(a0, a1); swap_halves(a2, a3);
+  double m01 = fmax(a0, a1), m23 = fmax(a2, a3);          // halves: [allele 0 | allele 1], [allele 2 | allele 3]
+  swap_rows(m01, m23);
+  double v = fmax(m01, m23);                              // rows: alleles 0, 2, 1, 3
+  v = fmax(v, dpp_d<0x111, 0xf>(v, v)); v = fmax(v, dpp_d<0x112, 0xf>(v, v)); v = fmax(v, dpp_d<0x114, 0xf>(v, v)); v = fmax(v, dpp_d<0x118, 0xf>(v, v));
+  return v;
+}
+__device__ __forceinline__ double quad_sum(double a0, double a1, double a2, double a3){
+  swap_halves(a0, a1); swap_halves(a2, a3);
+  double m01 = a0 + a1, m23 = a2 + a3;
+  swap_rows(m01, m23);
+  double v = m01 + m23;
+  v += dpp_d<0x111, 0xf>(v, 0.0); v += dpp_d<0x112, 0xf>(v, 0.0); v += dpp_d<0x114, 0xf>(v, 0.0); v += dpp_d<0x118, 0xf>(v, 0.0);
+  return v;
+}
+
+// the per-position registers of one flank configuration
+template <int NR> struct CmbRegs { double X[NR], Y[NR]; const char* P[NR]; int S[NR]; };
+
+// one quad of alleles (workspace rows ord[0..3]; a slot that is not wanted repeats a wanted one's row and is not stored)
+template <int NR>
+__device__ __forceinline__ void combine_quad(const hs_dev_t& d, const CmbRegs<NR>& g, const int (&ord)[4], int want, double* out_row, int k0, int lane){
+  double t[4][NR], m[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++){
+#pragma unroll
+    for (int k = 0; k < NR; k++){
+      const double v = *(const double*)(g.P[k] + (uint64_t)((uint32_t)ord[q]*(uint32_t)g.S[k]));
+      t[q][k] = (g.X[k] + v) + g.Y[k];
+    }
+    m[q] = t[q][0];
+#pragma unroll
+    for (int k = 1; k < NR; k++) m[q] = fmax(m[q], t[q][k]);
+    m[q] = fmax(m[q], -1.0e300);                          // fast_log_sum_exp starts its maximum there (mathops.cpp:97-106 through Lse)
+  }
+  const double mrow = quad_max(m[0], m[1], m[2], m[3]);   // lane 15 of row r: the maximum of allele [0, 2, 1, 3][r]
+  const double mx[4] = { rdlane(mrow, 15), rdlane(mrow, 47), rdlane(mrow, 31), rdlane(mrow, 63) };
+  double s[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++){
+    s[q] = 0.0;
+#pragma unroll
+    for (int k = 0; k < NR; k++){
+      const double df = t[q][k] - mx[q];
+      const double e = (double)f_fasterexp((float)df);
+      s[q] += (df > d.log_thresh) ? e : 0.0;
+    }
+  }
+  const double tot = quad_sum(s[0], s[1], s[2], s[3]);
+  const double res = mrow + (double)f_fasterlog((float)tot);
+  const int row = lane >> 4, slot = ((row & 1) << 1) | (row >> 1);
+  if ((lane & 15) == 15 && ((want >> slot) & 1)) out_row[k0 + slot] = res;
+}
+
+// the per-allele form: one wavefront, lanes = seed positions, every operand selected per position (any flank lengths)
+__device__ __forceinline__ void combine_one(const hs_dev_t& d, const SideView& vL, const SideView& vR, int lane, uint8_t seed_c, double seed_lc, double seed_lw,
+                                            int N, int ord, int lead_off, int F0, int trail_off, int slotL, int slotR, double* out){
+  const int F2 = N - F0;
   const double* recL = lead_record(d, vL, slotL);
   const double* recR = lead_record(d, vR, slotR);
   const double* mr = d.ws_mr + vL.ws_mr + (int64_t)ord*(vL.len-1);
   const double* lt = d.ws_lt + vL.ws_lt + (int64_t)ord*uni(vL.loc->lt_stride);
   // last-column value of compact row u of a side: leading rows 0..Flead-1, the STR block's row at Flead, trailing rows after it
-  // (one load through a selected address instead of three loads under branches: this kernel is bound by instruction issue, and the
-  // branches were a third of its instructions)
   auto lcL = [&](int u){ const double* a = (u < F0) ? recL + (vL.n + u) : ((u == F0) ? mr + (vL.nL - 1) : lt + (u - F0 - 1)); return *a; };
   auto lcR = [&](int u){ const double* a = (u < F2) ? recR + (vR.n + u) : ((u == F2) ? mr + (vL.len - 2) : lt + (F2 + (u - F2 - 1))); return *a; };
   const double sideL = recL[vL.n + uni(vL.loc->lead_flank[0])], sideR = recR[vR.n + uni(vL.loc->lead_flank[1])];
@@ -2570,33 +2670,116 @@ hs_combine_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
     return ((prior + e) + a) + b;
   };
   Lse acc;
-  if (N <= 256){
-    // up to four seed positions per lane stay in registers between the max and the sum: the hand-off arrays are read once
-    double t[4];
-    acc.mx = -1.0e300;
+  for (int pass = 0; pass < 2; pass++){
+    if (pass == 0) acc.mx = -1.0e300; else acc.tot = 0.0;
+    for (int y = lane; y < N; y += 64) acc.push(pass, term(y), d.log_thresh);
+    if (pass == 0) acc.mx = wave_max_d(acc.mx); else acc.tot = wave_sum_d(acc.tot);
+  }
+  if (lane == 0) *out = acc.finish();
+}
+
+// registers of a configuration: position y = lane + 64 k.  Requires F0 >= 1, F2 >= 1 (so that exactly one addend is the allele's).
+template <int NR>
+__device__ __forceinline__ void combine_setup(const hs_dev_t& d, const SideView& vL, const SideView& vR, int lane, uint8_t seed_c, double seed_lc, double seed_lw,
+                                              int N, int lead_off, int F0, int trail_off, int slotL, int slotR, CmbRegs<NR>& g){
+  const int F2 = N - F0;
+  const double* recL = lead_record(d, vL, slotL);
+  const double* recR = lead_record(d, vR, slotR);
+  const char* mr0 = (const char*)(d.ws_mr + vL.ws_mr);
+  const char* lt0 = (const char*)(d.ws_lt + vL.ws_lt);
+  const int mr_stride = (vL.len - 1)*8, lt_stride = uni(vL.loc->lt_stride)*8;
+  const double sideL = recL[vL.n + uni(vL.loc->lead_flank[0])], sideR = recR[vR.n + uni(vL.loc->lead_flank[1])];
+  const double prior = -d.int_log[N];
 #pragma unroll
-    for (int k = 0; k < 4; k++){
-      const int y = lane + 64*k;
-      t[k] = -1.0e300;
-      if (64*k < N){                              // wave-uniform: rounds past the last position issue nothing
-        if (y < N) t[k] = term(y);
-        acc.mx = fmax(acc.mx, t[k]);
+  for (int k = 0; k < NR; k++){
+    const int y = lane + 64*k;
+    const bool live = y < N;
+    const int yy = live ? y : 0;                                        // a dead lane computes position 0 and is overwritten below
+    const uint8_t hc = (uint8_t)((yy < F0 ? d.rows[lead_off + yy] : d.rows[trail_off + yy - F0]) & 0xff);
+    const double pe = prior + ((seed_c == hc) ? seed_lc : seed_lw);
+    // which compact row of which side the allele's value is: the right side's row uR for positions in the left flank (and the first
+    // position), the left side's row uL for positions in the right flank (and the last one)
+    const bool left_part = yy < F0 && yy != N-1;
+    const int u = left_part ? N-1-yy : yy;                              // right side's row : left side's row
+    const int fl = left_part ? F2 : F0;                                 // the side's leading-flank length: row fl is the STR block's
+    const int mr_col = left_part ? vL.len - 2 : vL.nL - 1;
+    const int lt_col = left_part ? u - 1 : u - F0 - 1;                  // lcR: lt[F2 + (u-F2-1)], lcL: lt[u-F0-1]
+    const bool in_mr = (u == fl);
+    g.P[k] = (in_mr ? mr0 : lt0) + (int64_t)(in_mr ? mr_col : lt_col)*8;
+    g.S[k] = in_mr ? mr_stride : lt_stride;
+    // the shared addend and its place
+    const double sh = (yy == 0) ? sideL : ((yy == N-1) ? sideR : (left_part ? recL[vL.n + yy - 1] : recR[vR.n + (N-2-yy)]));
+    const bool shared_first = left_part || yy == N-1;                   // a is shared: ((prior+e) + shared) + allele's
+    g.X[k] = live ? (shared_first ? pe + sh : pe) : -1.0e300;
+    g.Y[k] = (live && !shared_first) ? sh : -0.0;
+  }
+}
+
+template <int NR>
+__device__ __forceinline__ void combine_config(const hs_dev_t& d, const SideView& vL, const SideView& vR, int lane, uint8_t seed_c, double seed_lc, double seed_lw,
+                                               int N, int lead_off, int F0, int trail_off, int slotL, int slotR,
+                                               const hs_allele_t& alv, uint64_t members, int kb, int n_alleles, double* out_row){
+  CmbRegs<NR> g;
+  combine_setup<NR>(d, vL, vR, lane, seed_c, seed_lc, seed_lw, N, lead_off, F0, trail_off, slotL, slotR, g);
+  const int wave = threadIdx.x >> 6;
+  // the wavefronts of the workgroup share the quads that have a member
+  int seen = 0;
+  for (int q = 0; q < 16 && kb + 4*q < n_alleles; q++){
+    const int want = (int)((members >> (4*q)) & 0xf);
+    if (!want) continue;
+    if ((seen++ % HS_CMB_WAVES) != wave) continue;
+    const int first = __builtin_ctz(want);
+    int ord[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) ord[j] = rdlane(alv.re_ord, 4*q + (((want >> j) & 1) ? j : first));
+    combine_quad<NR>(d, g, ord, want, out_row, kb + 4*q, lane);
+  }
+}
+
+// One workgroup (HS_CMB_WAVES wavefronts) per active read.
+extern "C" __global__ void __launch_bounds__(64*HS_CMB_WAVES)
+hs_combine_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
+  const hs_dev_t& d = *dp;
+  const int lane = threadIdx.x & 63;
+  const int ai = active_begin + blockIdx.x;
+  const SideView vL = side_view(d, ai, 0);
+  const SideView vR = side_view(d, ai, 1);
+  const uint8_t seed_c = (uint8_t)d.bases[vL.base_off + vL.nL];
+  const uint8_t seed_q = (uint8_t)d.quals[vL.base_off + vL.nL];
+  const double seed_lc = d.qual_correct[seed_q], seed_lw = d.qual_error[seed_q];
+  const int n_alleles = uni(vL.loc->n_alleles);
+  const int hap_begin = uni(vL.loc->hap_begin);
+  double* out_row = d.aln_probs + uni(vL.loc->out_off) + (int64_t)(vL.r - uni(vL.loc->read_begin))*n_alleles;
+  // allele records and their rowsets are fetched 64 alleles at a time, one allele per lane
+  for (int kb = 0; kb < n_alleles; kb += 64){
+    const int kl = min(kb + lane, n_alleles - 1);
+    const hs_allele_t alv = d.alleles[hap_begin + kl];
+    const hs_rowset_t rsl = d.rowsets[alv.lead_rows[0]], rst = d.rowsets[alv.trail_rows[0]];
+    uint64_t todo = __ballot(alv.realign != 0 && kb + lane < n_alleles);
+    while (todo){
+      // the flank configuration of the first allele left, and everybody who shares it
+      const int f = __builtin_ctzll(todo);
+      const int N = rdlane(alv.n_flank, f), lr = rdlane(alv.lead_rows[0], f), tr = rdlane(alv.trail_rows[0], f);
+      const int slotL = rdlane(alv.lead_slot[0], f), slotR = rdlane(alv.lead_slot[1], f);
+      const uint64_t members = todo & __ballot(alv.n_flank == N && alv.lead_rows[0] == lr && alv.trail_rows[0] == tr && alv.lead_slot[0] == slotL && alv.lead_slot[1] == slotR);
+      todo &= ~members;
+      const int lead_off = rdlane(rsl.off, f), F0 = rdlane(rsl.len, f), trail_off = rdlane(rst.off, f);
+      if (F0 < 1 || N - F0 < 1 || N > 64*HS_CMB_ROUNDS){
+        int seen = 0;
+        for (uint64_t mm = members; mm; mm &= mm - 1){
+          const int kk = __builtin_ctzll(mm);
+          if ((seen++ % HS_CMB_WAVES) != (int)(threadIdx.x >> 6)) continue;
+          combine_one(d, vL, vR, lane, seed_c, seed_lc, seed_lw, N, rdlane(alv.re_ord, kk), lead_off, F0, trail_off, slotL, slotR, out_row + kb + kk);
+        }
+        continue;
       }
+      if (N <= 64)       combine_config<1>(d, vL, vR, lane, seed_c, seed_lc, seed_lw, N, lead_off, F0, trail_off, slotL, slotR, alv, members, kb, n_alleles, out_row);
+      else if (N <= 128) combine_config<2>(d, vL, vR, lane, seed_c, seed_lc, seed_lw, N, lead_off, F0, trail_off, slotL, slotR, alv, members, kb, n_alleles, out_row);
+#if HS_CMB_ROUNDS >= 4
+      else if (N <= 192) combine_config<3>(d, vL, vR, lane, seed_c, seed_lc, seed_lw, N, lead_off, F0, trail_off, slotL, slotR, alv, members, kb, n_alleles, out_row);
+      else               combine_config<4>(d, vL, vR, lane, seed_c, seed_lc, seed_lw, N, lead_off, F0, trail_off, slotL, slotR, alv, members, kb, n_alleles, out_row);
+#endif
     }
-    acc.mx = wave_max_d(acc.mx);
-    acc.tot = 0.0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) if (lane + 64*k < N) acc.push(1, t[k], d.log_thresh);
-    acc.tot = wave_sum_d(acc.tot);
-  } else {
-    for (int pass = 0; pass < 2; pass++){
-      if (pass == 0) acc.mx = -1.0e300; else acc.tot = 0.0;
-      for (int y = lane; y < N; y += 64) acc.push(pass, term(y), d.log_thresh);
-      if (pass == 0) acc.mx = wave_max_d(acc.mx); else acc.tot = wave_sum_d(acc.tot);
-    }
-  }
-  if (lane == 0) d.aln_probs[uni(vL.loc->out_off) + (int64_t)(vL.r - uni(vL.loc->read_begin))*n_alleles + k] = acc.finish();
-  }
   }
 }
 
@@ -2618,6 +2801,7 @@ hs_combine_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
 static bool lat_shape(){ static const bool v = !(getenv("HIPSTR_FLANK_LATENCY_SHAPE") && atoi(getenv("HIPSTR_FLANK_LATENCY_SHAPE")) == 0); return v; }
 static bool flank_coop(){ static const bool v = !(getenv("HIPSTR_FLANK_COOP") && atoi(getenv("HIPSTR_FLANK_COOP")) == 0); return v; }
 extern "C" int hs_flank_waves_per_group(){ return flank_coop() ? HS_COOP_WAVES : 1; }
+extern "C" int hs_combine_waves(){ return HS_CMB_WAVES; }
 extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk){
   hipLaunchKernelGGL(hs_col_kernel, dim3(n_active), dim3(64), 0, st, dp, active_begin);
   if (item_end <= item_begin) return;
