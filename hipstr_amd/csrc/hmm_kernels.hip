@@ -1603,6 +1603,12 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
   const hs_item_t* item = d.items + item_begin + blockIdx.x;
   const int side = uni(item->side), G = uni(item->slot), tp = uni(item->active);
   __shared__ int s_off[HS_GRP_MAXREADS + 1], s_n[HS_GRP_MAXREADS], s_ai[HS_GRP_MAXREADS];
+  if (KIND >= 1){
+    // most groups have no allele of this kind (a locus whose alleles are all periodic): gone before the tables, the barriers and the LDS fill
+    const hs_locus_t* loc0 = d.loci + uni(d.reads[uni(d.active[uni(d.tpack[tp])])].locus);
+    const int lo = KIND == 2 ? uni(loc0->n_pw[side]) : uni(loc0->n_tab[side]), hi = KIND == 2 ? uni(loc0->n_rp[side]) : uni(loc0->n_pw[side]);
+    if (lo + (int)blockIdx.y * d.allele_chunk >= hi) return;
+  }
   GrpLds L;
   {
     double* Dl = (double*)hs_lds_raw;                       // first: masked steps may touch up to B entries in front of E

@@ -11,7 +11,7 @@ for rep in 1 2; do
 done
 for lib in prev new; do
   L=hipstr_amd/csrc/libhipstr_hmm.so; [ $lib = prev ] && L=hipstr_amd/csrc/libhipstr_hmm_prev.so
-  for wl in p30 c5; do
+  for wl in p30 c2 c5; do
     HIPSTR_HMM_LIB=$PWD/$L timeout 900 python bench.py --workload $wl --no-cpu-baseline --no-pipeline --steps 10 > $out/${wl}_${lib}.json 2> $out/${wl}_${lib}.err
   done
 done
