@@ -1002,6 +1002,89 @@ __device__ __forceinline__ double visit_eval_grp(const hs_visit_t* __restrict__ 
   return acc.finish();
 }
 
+// The piecewise closed form with up to HS_PWK_MAX breaks (round 4; prep.cpp piecewise_k, layout.h HS_PWK_SLOTS): lists of blocks with two
+// or three interruptions — [run?] break [run?] break ... [run?] plain ... plain terminal.  The running likelihood changes only at the breaks,
+// so the pushes of visit_eval_grp are: L0 | ln U_s + L_s of segment s' run | L_{s+1} behind break s | L_nseg once per plain entry | the tail
+// term — each present only if its offset is below the lane's bound.  One pass over the segments builds the levels (kept in registers),
+// the maximum and the first offset at or beyond the bound; a second one sums the float exponentials, two per packed operation.  Same
+// values into the same float log-sum-exp as the replay (the float terms are summed in double: exact in any order).
+// The slots are the same for every lane: scalar loads through the constant address space, the loops over segments unrolled with scalar
+// guards (nseg is the list's, not the lane's).
+template <int XC>
+__device__ __forceinline__ double pwk_eval_grp(const double* __restrict__ slots_g, const double* ilog, double log_thresh, int Eb, int xx, double lp0, int lim,
+                                               int nsub, int stride, int tail){
+  typedef int hs_i2k __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(4))) hs_i2k* hs_slot_k;
+  const hs_slot_k D = (hs_slot_k)(uintptr_t)slots_g;
+  auto ldb = [&](int byte_addr) -> double { return *(const __attribute__((address_space(3))) double*)(uintptr_t)(uint32_t)byte_addr; };
+  auto plane = [&](int ch){ return ((ch >> 1) & 3) * (XC*8); };
+  const hs_i2k h0 = D[0], h1 = D[1];
+  const int nseg = h0.x, term_ni = h0.y, pa = h1.x, pb = h1.y;
+  constexpr double NEG = -1.0e300;
+  double Lv[HS_PWK_MAX + 1], Rv[HS_PWK_MAX + 1];              // levels; run values (NEG where the lane has none)
+  Lv[0] = lp0;
+  double mx = lp0;
+  unsigned u = (unsigned)(term_ni - lim);                     // first offset at or beyond the bound, minus the bound (the terminal entry is one)
+#pragma unroll
+  for (int s = 0; s <= HS_PWK_MAX; s++){
+    Rv[s] = NEG;
+    if (s < HS_PWK_MAX) Lv[s + 1] = Lv[s];
+    if (s <= nseg){
+      const hs_i2k run = D[2 + 3*s];
+      if (run.y > 0){
+        const hs_i2k lu = D[3 + 3*s];
+        const double v = __hiloint2double(lu.y, lu.x) + Lv[s];
+        Rv[s] = (run.x < lim) ? v : NEG;
+        mx = fmax(mx, Rv[s]);
+        u = min(u, (unsigned)(run.x - lim));
+      }
+      if (s < HS_PWK_MAX && s < nseg){
+        const hs_i2k brk = D[4 + 3*s];
+        const int b = brk.x, pla = plane(brk.y), plb = plane(brk.y >> 8);
+        double t = Lv[s];
+        for (int m = 1; m <= nsub; m++){
+          const int ca = Eb + 8*max(xx - b - m*stride, 0);      // a lane past its bound may point in front of its read: not used
+          const double ea = ldb(ca + pla), eb = ldb(ca + plb);
+          t -= ea; t += eb;
+        }
+        Lv[s + 1] = (b < lim) ? t : Lv[s];                       // an unreached level equals the one before it: harmless in the maximum
+        mx = fmax(mx, Lv[s + 1]);
+        u = min(u, (unsigned)(b - lim));
+      }
+    }
+  }
+  double Llast = Lv[0];
+#pragma unroll
+  for (int s = 1; s <= HS_PWK_MAX; s++) Llast = (s <= nseg) ? Lv[s] : Llast;       // (scalar condition)
+  const int np = min(max(lim - pa, 0), pb - pa);
+  if (pb > pa) u = min(u, (lim < pb) ? (unsigned)max(pa - lim, 0) : 0xffffffffu);
+  const int ns = (int)u + lim;
+  const bool a_t = ns < tail;
+  const double v_t = a_t ? ilog[max(tail - ns, 0)] + Llast : NEG;
+  mx = fmax(mx, v_t);
+  typedef float hs_f2 __attribute__((ext_vector_type(2)));
+  double tot = 0.0;
+  auto pair = [&](double a, bool on_a, double b, double wa){       // (b is NEG where its term is absent: it fails the threshold)
+    const double dd0 = a - mx, dd1 = b - mx;
+    hs_f2 x; x.x = (float)dd0; x.y = (float)dd1;
+    const hs_f2 z = (x * 1.442695040f + 126.94269504f) * 8388608.0f;
+    const float fe0 = (on_a && dd0 > log_thresh) ? __uint_as_float(__float2uint_rz(z.x)) : 0.0f;
+    const float fe1 = (dd1 > log_thresh) ? __uint_as_float(__float2uint_rz(z.y)) : 0.0f;
+    tot += wa * (double)fe0;
+    tot += (double)fe1;
+  };
+  pair(Lv[0], true, Rv[0], 1.0);
+#pragma unroll
+  for (int s = 1; s <= HS_PWK_MAX; s++){
+    if (s <= nseg){
+      const hs_i2k brk = D[4 + 3*(s - 1)];
+      pair(Lv[s], brk.x < lim, Rv[s], 1.0);
+    }
+  }
+  pair(Llast, np > 0, v_t, (double)np);                           // equal float terms: the product is exact
+  return mx + (double)f_fasterlog((float)tot);
+}
+
 }  // namespace
 
 #ifndef HS_STR_WAVES
@@ -2002,7 +2085,9 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
           const PwSlots S = load_pw(k);
           return pw_eval_grp<XC>(S, L.ilog, d.log_thresh, Eb, xx, lp0, lim, nsub, stride, tail);
         }
-        if (KIND == 2 && shp == -1){                          // three and more interruptions: the list itself, replayed (the same for every lane)
+        if (KIND == 2 && shp == HS_SHAPE_PWK)                 // three to six breaks: the K-level closed form (the same for every lane)
+          return pwk_eval_grp<XC>(pw_desc + (HS_MAXREP + 1)*HS_PW_SLOTS + k*HS_PWK_SLOTS, L.ilog, d.log_thresh, Eb, xx, lp0, lim, nsub, stride, tail);
+        if (KIND == 2 && shp == -1){                          // more: the list itself, replayed (the same for every lane)
           const hs_stropt_t* so = d.stropts + rdlane(a_sopt, k_allele);
           const int loff = uni(k == HS_MAXREP ? so->ins_off : so->del_off[min(k, HS_MAXREP - 1)]);
           const int llen = uni(k == HS_MAXREP ? so->ins_len : so->del_len[min(k, HS_MAXREP - 1)]);

@@ -13,6 +13,9 @@
 
 #define HS_PW_SLOTS      10        // 64-bit descriptor slots per piecewise-simple visiting list (prep.cpp emit_stropt)
 #define HS_SHAPE_PIECEWISE (-2)
+#define HS_SHAPE_PWK     (-3)      // piecewise with three to HS_PWK_MAX breaks (round 4): closed form from HS_PWK_SLOTS slots per list, behind the ten-slot descriptors
+#define HS_PWK_MAX       6         // breaks per list the K-level closed form takes (three interruptions of the repeat)
+#define HS_PWK_SLOTS     24        // 64-bit slots per list: 0 nseg | terminal ni   1 first plain ni | one past the last   2+3s run ni | run U   3+3s ln(run U)   4+3s break ni | ca + 256 cb   (s = 0..HS_PWK_MAX)
 #define HS_TAB_CAP       48        // closed-form table entries per STR option the STR kernel keeps in LDS (hs_stropt_t::tab_*)
 #ifndef HS_GRP_COLS
 #define HS_GRP_COLS      256       // lanes (= read columns) of one hs_str_group_kernel workgroup; prep.cpp packs reads of a locus side up to this many columns
@@ -69,7 +72,7 @@ struct hs_stropt_t {
   int32_t B;                 // block length
   int32_t nd;                // num_deletions_ (StutterAlignerClass.h:64-69)
   int32_t period;
-  int32_t f64_off;           // into f64 pool: pmf[13] | -int_log(B+1) | -int_log(B+D+1) for D=-p..-6p | [7 x HS_PW_SLOTS descriptor slots, only if some list's shape is HS_SHAPE_PIECEWISE]
+  int32_t f64_off;           // into f64 pool: pmf[13] | -int_log(B+1) | -int_log(B+D+1) for D=-p..-6p | [7 x HS_PW_SLOTS descriptor slots, only if some list's shape is HS_SHAPE_PIECEWISE or the option is of kind 3] | [7 x HS_PWK_SLOTS, only if some list's shape is HS_SHAPE_PWK]
   int32_t ins_off, ins_len;  // visiting list shared by all insertion sizes
   int32_t del_off[HS_MAXREP], del_len[HS_MAXREP];
   // Shape of each visiting list (index 0..5: deletion lists, 6: insertion list).  Periodic blocks give "simple" lists —
@@ -77,6 +80,8 @@ struct hs_stropt_t {
   // offsets — whose log-sum-exp has a closed form in (lp0, bound); everything else replays the list.
   //   shape = -1: generic list;  shape = U0 >= 0: simple list, U0 = 0 means "no skip entry, plain entries from offset 0";
   //   shape = HS_SHAPE_PIECEWISE: one or two interruptions, closed form from the ten descriptor slots behind the constants
+  //   shape = HS_SHAPE_PWK: three to HS_PWK_MAX breaks, closed form from the K-level slots (hs_str_group_kernel_rp); every other consumer
+  //                         treats it like -1 and replays the list, which is kept
   int32_t shape[HS_MAXREP + 1];
   // Tabulated closed form of the simple lists (prep.cpp simple_table): for a simple list the log-sum-exp over the artifact
   // positions is lp0 + A + G with A, G functions of the lane's bound only — as long as the float conversions inside

@@ -579,10 +579,58 @@ void emit_stropt(const char* blk, const int B, int period, const double pmf13[HS
     slot[0] = pack(k, ni_of(E[idx]));
     return true;
   };
+  // The same closed form with more levels (round 4): three to HS_PWK_MAX breaks — two or three interruptions of the repeat, what a
+  // panel's imperfect loci carry in every candidate allele.  Slots (layout.h HS_PWK_SLOTS): 0 nseg | terminal ni, 1 first plain ni | one
+  // past the last, then per segment s = 0..nseg: run ni | run U, ln(run U), break ni | ca + 256 cb (no break behind the last segment).
+  // Only hs_str_group_kernel_rp reads them; every other consumer of such a list replays it (its entries are kept).
+  auto piecewise_k = [&](int off, int len, int limmax, uint64_t slot[HS_PWK_SLOTS]){
+    auto pack = [](int lo, int hi){ return (uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)hi << 32); };
+    auto bits = [](double v){ uint64_t u; memcpy(&u, &v, 8); return u; };
+    for (int i = 0; i < HS_PWK_SLOTS; i++) slot[i] = 0;
+    slot[0] = pack(-1, 0);
+    const hs_visit_t* E = V.data() + (off - (int)visits_begin);
+    auto ni_of = [](const hs_visit_t& e){ return (int)(e.meta & 0xffff); };
+    auto U_of  = [](const hs_visit_t& e){ return (int)((e.meta >> 16) & 0xffff); };
+    auto plain = [](const hs_visit_t& e){ return ((e.meta >> 48) & 1) != 0; };
+    int idx = 0, k = 0;
+    for (;;){
+      if (idx < len && !plain(E[idx]) && U_of(E[idx]) > 0 && ni_of(E[idx]) < limmax){
+        slot[2 + 3*k] = pack(ni_of(E[idx]), U_of(E[idx])); slot[3 + 3*k] = bits(E[idx].logU); idx++;
+      }
+      if (idx < len && !plain(E[idx]) && U_of(E[idx]) == 0 && ni_of(E[idx]) < limmax){
+        if (k == HS_PWK_MAX) return false;
+        slot[4 + 3*k] = pack(ni_of(E[idx]), (int)((E[idx].meta >> 32) & 0xffff)); idx++; k++;
+        continue;
+      }
+      break;
+    }
+    if (k < 3) return false;                          // fewer breaks: the ten-slot form's business
+    int pa = 0, pb = 0;
+    if (idx < len && plain(E[idx]) && ni_of(E[idx]) < limmax){
+      pa = ni_of(E[idx]); pb = pa;
+      while (idx < len && plain(E[idx]) && ni_of(E[idx]) < limmax){ if (ni_of(E[idx]) != pb) return false; pb++; idx++; }
+    }
+    if (idx != len-1 || !plain(E[idx]) || ni_of(E[idx]) < limmax) return false;       // exactly the terminal entry must remain
+    slot[1] = pack(pa, pb);
+    slot[0] = pack(k, ni_of(E[idx]));
+    return true;
+  };
+  // (HIPSTR_STR_PWK=0: such lists are replayed as before, for comparison runs; the form needs the grouped replay kernel)
+  static const bool group_replay = !(getenv("HIPSTR_STR_GROUP_REPLAY") && atoi(getenv("HIPSTR_STR_GROUP_REPLAY")) == 0);
+  static const bool pwk_on = group_replay && !(getenv("HIPSTR_STR_PWK") && atoi(getenv("HIPSTR_STR_PWK")) == 0);
   uint64_t pw[HS_MAXREP + 1][HS_PW_SLOTS];
   for (int k = 0; k <= HS_MAXREP; k++){ for (int i = 0; i < HS_PW_SLOTS; i++) pw[k][i] = 0; pw[k][0] = (uint64_t)(uint32_t)-1; }   // "not piecewise"
+  uint64_t pwk[HS_MAXREP + 1][HS_PWK_SLOTS];
+  for (int k = 0; k <= HS_MAXREP; k++){ for (int i = 0; i < HS_PWK_SLOTS; i++) pwk[k][i] = 0; pwk[k][0] = (uint64_t)(uint32_t)-1; }
+  bool any_pwk = false;
+  auto try_pwk = [&](int k, int off, int len, int limmax){
+    if (!pwk_on || so.shape[k] != -1 || limmax < 0) return;
+    uint64_t tmp[HS_PWK_SLOTS];
+    if (piecewise_k(off, len, limmax, tmp)){ memcpy(pwk[k], tmp, sizeof tmp); so.shape[k] = HS_SHAPE_PWK; any_pwk = true; }
+  };
   so.shape[HS_MAXREP] = classify(so.ins_off, so.ins_len, B);
   if (so.shape[HS_MAXREP] < 0 && piecewise(so.ins_off, so.ins_len, B, pw[HS_MAXREP])) so.shape[HS_MAXREP] = HS_SHAPE_PIECEWISE;
+  try_pwk(HS_MAXREP, so.ins_off, so.ins_len, B);
   HS_SOLAP(1);
   // deletion visiting lists (StutterAlignerClass.cpp:123-142); one per deletion size, shift = |D|
   for (int q = 0; q < HS_MAXREP; q++){
@@ -601,6 +649,7 @@ void emit_stropt(const char* blk, const int B, int period, const double pmf13[HS
     so.del_len[q] = (int32_t)(visits_begin + V.size()) - so.del_off[q];
     so.shape[q] = classify(so.del_off[q], so.del_len[q], B+D);
     if (so.shape[q] < 0 && piecewise(so.del_off[q], so.del_len[q], B+D, pw[q])) so.shape[q] = HS_SHAPE_PIECEWISE;
+    try_pwk(q, so.del_off[q], so.del_len[q], B+D);
   }
   HS_SOLAP(2);
   // The forward kernels read a visiting list only where it has no closed form (shape -1: replayed entry by entry; the traceback also
@@ -610,7 +659,7 @@ void emit_stropt(const char* blk, const int B, int period, const double pmf13[HS
     bool any_generic = false;
     for (int k = 0; k <= HS_MAXREP; k++){
       const int tail = (k == HS_MAXREP) ? B : B - (k+1)*period;
-      any_generic |= (tail >= 0 && (so.shape[k] == -1 || (!forward_only && so.shape[k] < 0)));
+      any_generic |= (tail >= 0 && (so.shape[k] == -1 || so.shape[k] == HS_SHAPE_PWK || (!forward_only && so.shape[k] < 0)));
     }
     if (any_generic) out.visits.insert(out.visits.end(), V.begin(), V.end());
     else {
@@ -624,16 +673,20 @@ void emit_stropt(const char* blk, const int B, int period, const double pmf13[HS
   for (int k = 0; k <= HS_MAXREP; k++){
     const int tail = (k == HS_MAXREP) ? B : B - (k+1)*period;
     any_pw |= (so.shape[k] == HS_SHAPE_PIECEWISE);
-    any_replay |= (tail >= 0 && so.shape[k] == -1);
+    any_replay |= (tail >= 0 && (so.shape[k] == -1 || so.shape[k] == HS_SHAPE_PWK));
   }
   // (round 4: hs_str_group_kernel_pw also replays the lists that have no closed form — three and more interruptions — so an option with
   //  such lists stays in the grouped layout (kind 2) as long as its block is made of A/C/G/T; HIPSTR_STR_GROUP_REPLAY=0: they go to
   //  hs_str_kernel_generic as before, for comparison)
-  static const bool group_replay = !(getenv("HIPSTR_STR_GROUP_REPLAY") && atoi(getenv("HIPSTR_STR_GROUP_REPLAY")) == 0);
   if (any_pw || (any_replay && group_replay)){
     const size_t at = out.f64pool.size();
     out.f64pool.resize(at + (HS_MAXREP + 1)*HS_PW_SLOTS);
     memcpy(out.f64pool.data() + at, pw, sizeof pw);
+  }
+  if (any_pwk){                                       // (any_pwk implies any_replay: the ten-slot region is in front)
+    const size_t at = out.f64pool.size();
+    out.f64pool.resize(at + (HS_MAXREP + 1)*HS_PWK_SLOTS);
+    memcpy(out.f64pool.data() + at, pwk, sizeof pwk);
   }
   HS_SOLAP(3);
   // tabulated closed form: only when every list the kernel can evaluate is simple and the entries fit the LDS budget
@@ -648,7 +701,7 @@ void emit_stropt(const char* blk, const int B, int period, const double pmf13[HS
       so.tab_base[k] = total;
       if (tail < 0) continue;                           // this deletion size is never evaluated
       if (so.shape[k] == HS_SHAPE_PIECEWISE && !no_pw_group) continue;      // evaluated from its descriptor slots (hs_str_group_kernel_pw)
-      if (so.shape[k] == -1 && group_replay && !no_pw_group) continue;      // replayed in the grouped layout (visit_eval_grp)
+      if ((so.shape[k] == -1 || so.shape[k] == HS_SHAPE_PWK) && group_replay && !no_pw_group) continue;      // replayed in the grouped layout (visit_eval_grp) or taken by the K-level closed form
       if (so.shape[k] < 0){ ok = false; break; }
       total += 2 + std::max(0, tail - so.shape[k]);
     }
