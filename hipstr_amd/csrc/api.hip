@@ -6,6 +6,7 @@
 // point fails and hipstr_last_error() says so.
 #include <hip/hip_runtime.h>
 #include <unistd.h>
+#include <sched.h>
 #include <atomic>
 
 #include <cfloat>
@@ -209,15 +210,34 @@ Ctx* current_ctx(){
 }
 
 int bind(Ctx* c){ HS_HIP(hipSetDevice(c->device)); return 0; }
+}  // namespace
+
+hipError_t hipstr::wait_stream(hipStream_t st){
+  static const int mode = []{ const char* e = getenv("HIPSTR_WAIT"); return !e ? 1 : !strcmp(e, "spin") ? 0 : !strcmp(e, "sleep") ? 2 : 1; }();
+  if (mode == 0) return hipStreamSynchronize(st);
+  const auto t0 = std::chrono::steady_clock::now();
+  bool slow = (mode == 2);
+  for (unsigned n = 0;; n++){
+    const hipError_t e = hipStreamQuery(st);
+    if (e != hipErrorNotReady) return e;
+    if (slow) usleep(50);
+    else {
+      sched_yield();
+      if ((n & 15) == 15 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) slow = true;
+    }
+  }
+}
+
+namespace {
 
 // Device-to-host copy into the caller's (pageable) array: small ones directly, large ones through a pinned block from the cache
 // (the driver stages pageable copies itself at a fraction of the link rate) and onto the caller's pages by the host threads.
 int fetch_array(Ctx* c, hipStream_t st, void* dst, const void* src, size_t bytes){
   if (bytes == 0) return 0;
-  if (bytes < ((size_t)4 << 20)){ HS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st)); HS_HIP(hipStreamSynchronize(st)); return 0; }
+  if (bytes < ((size_t)4 << 20)){ HS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st)); HS_HIP(hipstr::wait_stream(st)); return 0; }
   char* pin = (char*)c->pin_cache.get(bytes);
   if (!pin) return 1;
-  if (hipMemcpyAsync(pin, src, bytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess){
+  if (hipMemcpyAsync(pin, src, bytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipstr::wait_stream(st) != hipSuccess){
     c->pin_cache.put(pin); return fail("device-to-host copy failed"); }
   const size_t span = (size_t)8 << 20; const int n = (int)((bytes + span - 1)/span);
   hipstr::parallel_for(n, hipstr::host_threads(), [&](int i){ const size_t o = (size_t)i*span; memcpy((char*)dst + o, pin + o, std::min(span, bytes - o)); });
@@ -757,7 +777,7 @@ int hipstr_hmm_fetch(hipstr_dev_batch_t* dev, double* aln_probs, int32_t* seeds)
     if (hipMemcpyAsync(tmp, dev->h.aln_probs, (size_t)P.n_out*sizeof(double), hipMemcpyDeviceToHost, dev->stream) != hipSuccess){
       ctx->pin_cache.put(tmp); return fail("hipMemcpyAsync (device to host) failed"); }
   }
-  if (hipStreamSynchronize(dev->stream) != hipSuccess){ ctx->pin_cache.put(tmp); return fail("hipStreamSynchronize failed"); }
+  if (hipstr::wait_stream(dev->stream) != hipSuccess){ ctx->pin_cache.put(tmp); return fail("hipStreamSynchronize failed"); }
   // the reference's output contract, locus by locus (loci are independent: shared among the host threads)
   auto scatter = [&](int li){
     const hs_locus_t& loc = P.loci[li];
@@ -1064,7 +1084,7 @@ int post_setup(const hipstr_post_batch_t* pb, const double* dev_ll, PostRun& R){
   if (up(NULL, sizeof(int32_t)*2*R.n_samp, &p)) return 1; R.h.map_gt = (int32_t*)p;
   R.h.log_thresh = T.log_thresh; R.h.log_half = T.log_half;
   if (up(&R.h, sizeof R.h, &p)) return 1; R.d_args = (hs_post_dev_t*)p;
-  HS_HIP(hipStreamSynchronize(R.stream));       // the sources are the caller's (pageable) arrays: done with them before returning
+  HS_HIP(hipstr::wait_stream(R.stream));       // the sources are the caller's (pageable) arrays: done with them before returning
   return 0;
 }
 }  // namespace
@@ -1120,7 +1140,7 @@ int hipstr_post_launch(hipstr_post_dev_t* pd, void* hip_stream){
   HS_HIP(hipGetLastError());
   if (host_libm){
     PostRun& R = pd->R;
-    HS_HIP(hipStreamSynchronize(st));
+    HS_HIP(hipstr::wait_stream(st));
     std::vector<double> post((size_t)R.n_post), total((size_t)R.n_samp, 0.0);
     std::vector<int32_t> mapgt(2*(size_t)R.n_samp, -1);
     HS_HIP(hipMemcpy(post.data(), R.h.log_post, sizeof(double)*R.n_post, hipMemcpyDeviceToHost));
@@ -1149,11 +1169,11 @@ int hipstr_post_fetch(hipstr_post_dev_t* pd, double* log_post, double* sample_to
   PostRun& R = pd->R;
   if (bind(R.ctx)) return 1;
   if (pd->foreign_stream) HS_HIP(hipDeviceSynchronize());
-  if (!(R.res_bytes && !pd->foreign_stream)) HS_HIP(hipStreamSynchronize(R.stream));      // (the small form's one copy is ordered behind the kernel on the same stream)
+  if (!(R.res_bytes && !pd->foreign_stream)) HS_HIP(hipstr::wait_stream(R.stream));      // (the small form's one copy is ordered behind the kernel on the same stream)
   if (!R.units.empty() && R.res_bytes){
     char* pin = (char*)R.ctx->pin_cache.get(R.res_bytes);
     if (!pin) return 1;
-    if (hipMemcpyAsync(pin, R.h.log_post, R.res_bytes, hipMemcpyDeviceToHost, R.stream) != hipSuccess || hipStreamSynchronize(R.stream) != hipSuccess){
+    if (hipMemcpyAsync(pin, R.h.log_post, R.res_bytes, hipMemcpyDeviceToHost, R.stream) != hipSuccess || hipstr::wait_stream(R.stream) != hipSuccess){
       R.ctx->pin_cache.put(pin); return fail("device-to-host copy failed"); }
     memcpy(log_post, pin, sizeof(double)*R.n_post); memcpy(sample_total_ll, pin + R.res_total_off, sizeof(double)*R.n_samp);
     memcpy(map_gt, pin + R.res_map_off, sizeof(int32_t)*2*R.n_samp);
@@ -1286,7 +1306,7 @@ int hipstr_post_extract(hipstr_post_dev_t* pd, const hipstr_gt_request_t* rq, hi
   hipLaunchKernelGGL(hs_genotype_kernel, dim3((unsigned)units.size()), dim3(256), 0, R.stream, (const hs_gt_dev_t*)p);
   HS_HIP(hipGetLastError());
   lap("setup");
-  HS_HIP(hipStreamSynchronize(R.stream));
+  HS_HIP(hipstr::wait_stream(R.stream));
   lap("kernel");
   HS_HIP(hipMemcpy(out->best_hap, R.h.map_gt, (size_t)so*2*4, hipMemcpyDeviceToHost));
   HS_HIP(hipMemcpy(out->best_gt, h.best_gt, (size_t)so*2*4, hipMemcpyDeviceToHost));

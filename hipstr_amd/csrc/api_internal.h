@@ -25,6 +25,14 @@ int api_fail(const std::string& message);     // records hipstr_last_error(); re
 
 // Cached blocks: a freed block goes back to its context's free list instead of hipFree / hipHostFree (both synchronise the
 // device and cost 0.1-10 ms); a request is served from the list when a block of at most 1.25x the size is there.
+// Waiting for a stream from a host thread.  hipStreamSynchronize / hipEventSynchronize spin at 100 % of a core on this stack (tools/wait_probe.hip),
+// which is the fastest way to learn that a 0.2 ms call is done as long as every waiting thread has a core of its own — and the worst one
+// when the caller runs more host threads than cores to keep the device busy (the reference's genotype() over the adapter: 16 threads on 16
+// cores 755 loci/s, 64 threads 291): the waiters keep the cores from the threads that have host work.  wait_stream polls hipStreamQuery and
+// yields the core between polls (sched_yield returns at once when nothing else is runnable: the single-thread latency stays what it was),
+// sleeping 50 us per poll once a wait has lasted 2 ms.  HIPSTR_WAIT=spin: the driver's own wait; =sleep: sleep from the first poll.
+hipError_t wait_stream(hipStream_t st);
+
 void* dev_alloc(Ctx* ctx, size_t bytes);      // NULL + last error on failure
 void  dev_free(Ctx* ctx, void* p);
 void* pin_alloc(Ctx* ctx, size_t bytes);

@@ -557,7 +557,7 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
     hipLaunchKernelGGL(hs_em_mstep, dim3(nl), dim3(256), 0, T.stream, d_h, (const double*)d_keep);
     EM_HIP(hipStreamWaitEvent(T.stream, side.ev_join, 0));                // ... and join before the host reads this iteration's results
     EM_HIP(hipGetLastError());
-    EM_HIP(hipStreamSynchronize(T.stream));
+    EM_HIP(hipstr::wait_stream(T.stream));
     EM_HIP(hipMemcpy(newll.data(), d_newll, nl*sizeof(double), hipMemcpyDeviceToHost));
     EM_HIP(hipMemcpy(sums.data(), d_sums, sums.size()*sizeof(double), hipMemcpyDeviceToHost));
     lap("", &t_gpu);

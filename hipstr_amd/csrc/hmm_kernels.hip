@@ -1021,21 +1021,19 @@ __device__ __forceinline__ double pwk_eval_grp(const double* __restrict__ slots_
   const hs_i2k h0 = D[0], h1 = D[1];
   const int nseg = h0.x, term_ni = h0.y, pa = h1.x, pb = h1.y;
   constexpr double NEG = -1.0e300;
-  double Lv[HS_PWK_MAX + 1], Rv[HS_PWK_MAX + 1];              // levels; run values (NEG where the lane has none)
+  double Lv[HS_PWK_MAX + 1];                                  // levels (the run values are formed again in the second pass: one addition each, seven registers less)
   Lv[0] = lp0;
   double mx = lp0;
   unsigned u = (unsigned)(term_ni - lim);                     // first offset at or beyond the bound, minus the bound (the terminal entry is one)
 #pragma unroll
   for (int s = 0; s <= HS_PWK_MAX; s++){
-    Rv[s] = NEG;
     if (s < HS_PWK_MAX) Lv[s + 1] = Lv[s];
     if (s <= nseg){
       const hs_i2k run = D[2 + 3*s];
       if (run.y > 0){
         const hs_i2k lu = D[3 + 3*s];
         const double v = __hiloint2double(lu.y, lu.x) + Lv[s];
-        Rv[s] = (run.x < lim) ? v : NEG;
-        mx = fmax(mx, Rv[s]);
+        mx = fmax(mx, (run.x < lim) ? v : NEG);
         u = min(u, (unsigned)(run.x - lim));
       }
       if (s < HS_PWK_MAX && s < nseg){
@@ -1073,12 +1071,19 @@ __device__ __forceinline__ double pwk_eval_grp(const double* __restrict__ slots_
     tot += wa * (double)fe0;
     tot += (double)fe1;
   };
-  pair(Lv[0], true, Rv[0], 1.0);
+  auto run_value = [&](int s) -> double {                          // ln U_s + L_s where segment s has a run below the lane's bound, else NEG
+    const hs_i2k run = D[2 + 3*s];
+    if (run.y <= 0) return NEG;                                    // (scalar)
+    const hs_i2k lu = D[3 + 3*s];
+    const double v = __hiloint2double(lu.y, lu.x) + Lv[s];
+    return (run.x < lim) ? v : NEG;
+  };
+  pair(Lv[0], true, run_value(0), 1.0);
 #pragma unroll
   for (int s = 1; s <= HS_PWK_MAX; s++){
     if (s <= nseg){
       const hs_i2k brk = D[4 + 3*(s - 1)];
-      pair(Lv[s], brk.x < lim, Rv[s], 1.0);
+      pair(Lv[s], brk.x < lim, run_value(s), 1.0);
     }
   }
   pair(Llast, np > 0, v_t, (double)np);                           // equal float terms: the product is exact
@@ -2191,7 +2196,7 @@ hs_str_group_kernel_pw(const hs_dev_t* __restrict__ dp, int item_begin){ str_gro
 // ... and the alleles with a list that has to be replayed (three and more interruptions: hs_stropt_t::kind 3), positions [n_pw, n_rp): the same
 // body with visit_eval_grp for those lists; registers before wavefronts (the replay loop sits inside the 13-term evaluation)
 #ifndef HS_GRP_RP_OCC
-#define HS_GRP_RP_OCC 3
+#define HS_GRP_RP_OCC 4      // (measured with the K-level closed form: 4 with 128 registers and 128 B of scratch is 16 % faster than 3 with 158)
 #endif
 extern "C" __global__ void __launch_bounds__(HS_GRP_COLS, HS_GRP_RP_OCC)
 hs_str_group_kernel_rp(const hs_dev_t* __restrict__ dp, int item_begin){ str_group_body<2>(*dp, item_begin, 0); }

@@ -290,7 +290,7 @@ extern "C" int hipstr_nw_align(const hipstr_nw_batch_t* nb, hipstr_nw_out_t* o){
     if (!hostblk) return api_fail("out of pinned host memory");
     struct PinGuard { hipstr::Ctx* c; void* p; ~PinGuard(){ hipstr::pin_free(c, p); } } pin_guard{T.ctx, hostblk};
     NW_HIP(hipMemcpyAsync(hostblk, d_res, r_end, hipMemcpyDeviceToHost, T.stream));
-    NW_HIP(hipStreamSynchronize(T.stream));
+    NW_HIP(hipstr::wait_stream(T.stream));
     const float* score = (const float*)(hostblk + r_score); const int32_t* bcol = (const int32_t*)(hostblk + r_bcol);
     const int32_t* lcol = (const int32_t*)(hostblk + r_lcol); const int32_t* nops = (const int32_t*)(hostblk + r_nops);
     struct { const char* p; const char* data() const { return p; } } ops{hostblk + r_ops};

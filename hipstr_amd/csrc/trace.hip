@@ -923,7 +923,7 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
     if (!hostblk) return api_fail("out of pinned host memory");
     struct PinGuard { hipstr::Ctx* c; void* p; ~PinGuard(){ hipstr::pin_free(c, p); } } pin_guard{T.ctx, hostblk};
     TR_HIP(hipMemcpyAsync(hostblk, d_res, o_ops + (size_t)(n_ops ? n_ops : 1), hipMemcpyDeviceToHost, T.stream));
-    TR_HIP(hipStreamSynchronize(T.stream));
+    TR_HIP(hipstr::wait_stream(T.stream));
     const double* ll = (const double*)(hostblk + o_ll); const int32_t* mxi = (const int32_t*)(hostblk + o_mxi);
     const int32_t* nops = (const int32_t*)(hostblk + o_nops); const int32_t* ssz = (const int32_t*)(hostblk + o_ssz); const int32_t* spos = (const int32_t*)(hostblk + o_spos);
     const char* opsbuf_p = hostblk + o_ops;

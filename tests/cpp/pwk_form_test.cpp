@@ -70,18 +70,16 @@ double pwk_form(const double* slots, const std::vector<double>& ilog, const std:
   auto hi = [&](int sl){ uint64_t u; memcpy(&u, slots + sl, 8); return (int)(uint32_t)(u >> 32); };
   const int nseg = lo(0), term_ni = hi(0), pa = lo(1), pb = hi(1);
   const double NEG = -1.0e300;
-  double Lv[HS_PWK_MAX + 1], Rv[HS_PWK_MAX + 1];
+  double Lv[HS_PWK_MAX + 1];
   Lv[0] = lp0;
   double mx = lp0;
   unsigned u = (unsigned)(term_ni - lim);
   for (int s = 0; s <= HS_PWK_MAX; s++){
-    Rv[s] = NEG;
     if (s < HS_PWK_MAX) Lv[s + 1] = Lv[s];
     if (s <= nseg){
       if (hi(2 + 3*s) > 0){
         const double v = slots[3 + 3*s] + Lv[s];
-        Rv[s] = (lo(2 + 3*s) < lim) ? v : NEG;
-        mx = fmax(mx, Rv[s]);
+        mx = fmax(mx, (lo(2 + 3*s) < lim) ? v : NEG);
         u = std::min(u, (unsigned)(lo(2 + 3*s) - lim));
       }
       if (s < HS_PWK_MAX && s < nseg){
@@ -111,8 +109,13 @@ double pwk_form(const double* slots, const std::vector<double>& ilog, const std:
     tot += wa * (double)fe0;
     tot += (double)fe1;
   };
-  pair(Lv[0], true, Rv[0], 1.0);
-  for (int s = 1; s <= HS_PWK_MAX; s++) if (s <= nseg) pair(Lv[s], lo(4 + 3*(s - 1)) < lim, Rv[s], 1.0);
+  auto run_value = [&](int s) -> double {
+    if (hi(2 + 3*s) <= 0) return NEG;
+    const double v = slots[3 + 3*s] + Lv[s];
+    return (lo(2 + 3*s) < lim) ? v : NEG;
+  };
+  pair(Lv[0], true, run_value(0), 1.0);
+  for (int s = 1; s <= HS_PWK_MAX; s++) if (s <= nseg) pair(Lv[s], lo(4 + 3*(s - 1)) < lim, run_value(s), 1.0);
   pair(Llast, np > 0, v_t, (double)np);
   return mx + (double)fasterlog((float)tot);
 }
