@@ -472,12 +472,15 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   const size_t packed_total = reads_pinned ? ((total + 255) & ~(size_t)255) : 0;
   const size_t i_bases = place(reads_pinned ? NULL : batch->bases, n_bases), i_quals = place(reads_pinned ? NULL : batch->quals, n_bases);
   const size_t stage_total = reads_pinned ? packed_total : total;
+  const bool up_prof = hipstr::api_profile_on();
+  double up_blocks = 0, up_t = up_prof ? hipstr::ApiTimer::now() : 0;
   char* dblk = (char*)ctx->dev_cache.get(total);
   if (!dblk){ hipstr_hmm_free(dev); return NULL; }
   dev->dev_blocks.push_back(dblk);
   char* stage = (char*)ctx->pin_cache.get(stage_total);
   if (!stage){ hipstr_hmm_free(dev); return NULL; }
   dev->pin_blocks.push_back(stage);
+  if (up_prof) up_blocks += hipstr::ApiTimer::now() - up_t;
   auto at = [&](size_t i){ return dblk + pieces[i].off; };
   h.loci = (const hs_locus_t*)at(i_loci); h.alleles = (const hs_allele_t*)at(i_alleles); h.stropts = (const hs_stropt_t*)at(i_stropts);
   h.rowsets = (const hs_rowset_t*)at(i_rowsets); h.rows = (const hs_row_t*)at(i_rows); h.visits = (const hs_visit_t*)at(i_visits);
@@ -488,6 +491,7 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   dev->d_args = (hs_dev_t*)at(i_args);
   // ---- output + workspaces (device only)
   auto dalloc = [&](size_t bytes) -> void* { void* p = ctx->dev_cache.get(bytes ? bytes : 1); if (p) dev->dev_blocks.push_back(p); return p; };
+  if (up_prof) up_t = hipstr::ApiTimer::now();
   const size_t out_bytes = (size_t)(P.n_out ? P.n_out : 1) * sizeof(double);
   h.aln_probs = (double*)dalloc(out_bytes);
   h.ws_mr = (double*)dalloc(sizeof(double)*(size_t)P.ws_mr_size); h.ws_lt = (double*)dalloc(sizeof(double)*(size_t)P.ws_lt_size);
@@ -503,6 +507,7 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   // [n_active] re-do flags of hs_str_kernel | [2 x chunks] work counters of hs_lead_kernel and hs_trail_kernel
   h.redo = (int32_t*)dalloc(sizeof(int32_t)*((size_t)h.n_active + 2*P.chunks.size() + 2));
   if (!h.aln_probs || !h.ws_mr || !h.ws_lt || !h.ws_lead || !h.ws_col || !h.ws_nd || !h.ws_band || !h.redo || !h.grp_recs){ hipstr_hmm_free(dev); return NULL; }
+  if (up_prof){ up_blocks += hipstr::ApiTimer::now() - up_t; hipstr::api_profile_add(hipstr::PB_UP_BLOCKS, up_blocks); }
   const hipstr::HostTables& T = hipstr::host_tables();
   h.int_log = ctx->int_log; h.qual_correct = ctx->qc; h.qual_error = ctx->qe; h.m2m = ctx->m2m; h.m2i = ctx->m2i;
   h.log_thresh = T.log_thresh; h.log_half = T.log_half;
@@ -551,16 +556,19 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   }
   { hipstr::Prepared only_frags; only_frags.frags.swap(P.frags); hipstr::recycle_prepared(only_frags); }      // the fragments' pools are packed: their storage can serve the next batch already
   dev->t_stage = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_stage0).count();
+  if (up_prof) up_t = hipstr::ApiTimer::now();
   HS_HIP_DEV(hipMemcpyAsync(dblk, stage, stage_total, hipMemcpyHostToDevice, copy_stream));
   if (reads_pinned && n_bases){
     HS_HIP_DEV(hipMemcpyAsync(dblk + pieces[i_bases].off, batch->bases, n_bases, hipMemcpyHostToDevice, copy_stream));
     HS_HIP_DEV(hipMemcpyAsync(dblk + pieces[i_quals].off, batch->quals, n_bases, hipMemcpyHostToDevice, copy_stream));
   }
+  if (up_prof){ const double n_ = hipstr::ApiTimer::now(); hipstr::api_profile_add(hipstr::PB_UP_MEMCPY, n_ - up_t); up_t = n_; }
   // what the device builds for itself (expand_kernels.hip), behind the copies on the same stream and in front of everything else
   if (P.gen_f64 > 0) hipLaunchKernelGGL(hs_expand_stropts_kernel, dim3((unsigned)((P.stropts.size() + 255)/256)), dim3(256), 0, copy_stream, (const hs_dev_t*)dev->d_args);
   if (!P.rec_descs.empty()) hipLaunchKernelGGL(hs_expand_recs_kernel, dim3((unsigned)((P.rec_descs.size()*HS_GRP_REC_DWORDS + 255)/256)), dim3(256), 0, copy_stream, (const hs_dev_t*)dev->d_args);
   HS_HIP_DEV(hipGetLastError());
   HS_HIP_DEV(hipMemsetAsync(h.aln_probs, 0, out_bytes, copy_stream));
+  if (up_prof){ const double n_ = hipstr::ApiTimer::now(); hipstr::api_profile_add(hipstr::PB_UP_EXPAND, n_ - up_t); up_t = n_; }
   dev->ev0 = ctx->get_event(true); dev->ev1 = ctx->get_event(true);
   // The stream's batches take tens of milliseconds and their collectors must not burn a core waiting: hipEventSynchronize spins at 100 %
   // of a CPU on this stack whatever the event's flags (tools/wait_probe.hip: 41.7 ms of thread CPU per 41.7 ms of waiting, also with
@@ -570,6 +578,7 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   dev->ev_h2d = ctx->get_event(false); dev->ev_done = ctx->get_event(false); dev->ev_d2h = ctx->get_event(false);
   if (!dev->ev0 || !dev->ev1 || !dev->ev_h2d || !dev->ev_done || !dev->ev_d2h){ g_err = "hipEventCreate failed"; hipstr_hmm_free(dev); return NULL; }
   HS_HIP_DEV(hipEventRecord(dev->ev_h2d, copy_stream));
+  if (up_prof) hipstr::api_profile_add(hipstr::PB_UP_EVENTS, hipstr::ApiTimer::now() - up_t);
   if (getenv("HIPSTR_TIMING"))
     fprintf(stderr, "hipstr_hmm_upload: total %.3f ms (prepare %.3f, blocks + staging %.3f), %zu B of tables, %lld alignments\n",
             1e3*std::chrono::duration<double>(std::chrono::steady_clock::now() - t_prep0).count(), 1e3*dev->t_prepare, 1e3*dev->t_stage, total, (long long)P.n_alignments);
@@ -881,7 +890,8 @@ int hipstr_debug_api_profile(int mode, int cap, const char** names, double* seco
   static const char* const kNames[hipstr::PB_COUNT] = {
     "hipstr_hmm_process_reads[_seeded]", "  prepare_batch", "  pack staging buffer", "  blocks + H2D enqueue", "  kernel launches", "  wait + D2H + scatter", "  release",
     "hipstr_hmm_trace[_seeded]", "  replay + string work (host)", "hipstr_post_run", "hipstr_post_extract", "hipstr_em_train", "hipstr_nw_align",
-    "hipstr_stream_submit", "hipstr_stream_take", "hipstr_calc_seed_bases" };
+    "hipstr_stream_submit", "hipstr_stream_take", "hipstr_calc_seed_bases",
+    "    upload: device + pinned blocks from the caches", "    upload: hipMemcpyAsync (tables, reads)", "    upload: expansion kernels + output memset", "    upload: events" };
   if (mode == 1){ for (int i = 0; i < hipstr::PB_COUNT; i++){ hipstr::g_prof_ns[i] = 0; hipstr::g_prof_calls[i] = 0; } hipstr::g_prof_on = true; }
   else if (mode == 0) hipstr::g_prof_on = false;
   for (int i = 0; i < hipstr::PB_COUNT && i < cap; i++){

@@ -68,7 +68,8 @@ struct HostArena {
 // ---- where the host time of the entry points goes (hipstr_debug_api_profile, include/hipstr_hmm.h): wall-clock seconds and calls per
 // bucket, summed over all threads while enabled.  Buckets nest: the indented ones are parts of the entry point above them.
 enum ApiBucket { PB_PROCESS_READS, PB_PR_PREPARE, PB_PR_STAGE, PB_PR_UPLOAD_REST, PB_PR_LAUNCH, PB_PR_FETCH, PB_PR_FREE,
-                 PB_TRACE, PB_TRACE_REPLAY, PB_POST_RUN, PB_POST_EXTRACT, PB_EM_TRAIN, PB_NW_ALIGN, PB_STREAM_SUBMIT, PB_STREAM_TAKE, PB_SEED_BASES, PB_COUNT };
+                 PB_TRACE, PB_TRACE_REPLAY, PB_POST_RUN, PB_POST_EXTRACT, PB_EM_TRAIN, PB_NW_ALIGN, PB_STREAM_SUBMIT, PB_STREAM_TAKE, PB_SEED_BASES,
+                 PB_UP_BLOCKS, PB_UP_MEMCPY, PB_UP_EXPAND, PB_UP_EVENTS, PB_COUNT };        // (the last four: parts of "blocks + H2D enqueue")
 bool api_profile_on();
 void api_profile_add(int bucket, double seconds, int calls = 1);
 struct ApiTimer {                  // adds its lifetime to a bucket

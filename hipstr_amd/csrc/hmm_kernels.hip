@@ -1010,6 +1010,10 @@ __device__ __forceinline__ double visit_eval_grp(const hs_visit_t* __restrict__ 
 // values into the same float log-sum-exp as the replay (the float terms are summed in double: exact in any order).
 // The slots are the same for every lane: scalar loads through the constant address space, the loops over segments unrolled with scalar
 // guards (nseg is the list's, not the lane's).
+#ifndef HS_PWK_SKIP
+#define HS_PWK_SKIP 0         // 1: a pair of terms that is under the threshold for every lane of the wavefront skips its exponentials — measured 2.5 % SLOWER (2 / 3
+                              // inherited interruptions: STR phase 127 -> 131, 156 -> 160 ms per 400 loci): the columns of a wavefront rarely agree on which levels are dead
+#endif
 template <int XC>
 __device__ __forceinline__ double pwk_eval_grp(const double* __restrict__ slots_g, const double* ilog, double log_thresh, int Eb, int xx, double lp0, int lim,
                                                int nsub, int stride, int tail){
@@ -1064,10 +1068,16 @@ __device__ __forceinline__ double pwk_eval_grp(const double* __restrict__ slots_
   double tot = 0.0;
   auto pair = [&](double a, bool on_a, double b, double wa){       // (b is NEG where its term is absent: it fails the threshold)
     const double dd0 = a - mx, dd1 = b - mx;
+    const bool t0 = on_a && dd0 > log_thresh, t1 = dd1 > log_thresh;
+#if HS_PWK_SKIP
+    // a level one mismatch of a good base below the maximum is under the threshold (ln 0.001): where neither term counts for any lane of the
+    // wavefront the exponentials are left out — they would add +0.0
+    if (!__any(t0 || t1)) return;
+#endif
     hs_f2 x; x.x = (float)dd0; x.y = (float)dd1;
     const hs_f2 z = (x * 1.442695040f + 126.94269504f) * 8388608.0f;
-    const float fe0 = (on_a && dd0 > log_thresh) ? __uint_as_float(__float2uint_rz(z.x)) : 0.0f;
-    const float fe1 = (dd1 > log_thresh) ? __uint_as_float(__float2uint_rz(z.y)) : 0.0f;
+    const float fe0 = t0 ? __uint_as_float(__float2uint_rz(z.x)) : 0.0f;
+    const float fe1 = t1 ? __uint_as_float(__float2uint_rz(z.y)) : 0.0f;
     tot += wa * (double)fe0;
     tot += (double)fe1;
   };

@@ -14,9 +14,9 @@ $L oracle/_ref/libflow_ref.so --loci 96 --seed 100 --threads 16 >> $O/flow_rates
 for lib in libflow_mi355x.so libflow_mi355x_batched.so; do
 for t in 1 4 16; do
   echo "== $lib --threads $t" >> $O/flow_rates.txt
-  $L oracle/_ref/$lib --loci 192 --seed 100 --threads $t >> $O/flow_rates.txt 2>&1
+  $L oracle/_ref/$lib --loci ${FLOW_RATE_LOCI:-768} --seed 100 --threads $t >> $O/flow_rates.txt 2>&1
   echo "== $lib --threads $t --stream" >> $O/flow_rates.txt
-  $L oracle/_ref/$lib --loci 192 --seed 100 --threads $t --stream >> $O/flow_rates.txt 2>&1
+  $L oracle/_ref/$lib --loci ${FLOW_RATE_LOCI:-768} --seed 100 --threads $t --stream >> $O/flow_rates.txt 2>&1
 done
 done
 echo "== libflow_mi355x.so --threads 1 / 16, prefetch off (HIPSTR_ADAPTER_PREFETCH=0: one device call per traced read, as in round 3)" >> $O/flow_rates.txt
