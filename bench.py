@@ -386,7 +386,7 @@ def main():
     kinds = (C.c_int64 * 4)()
     hmm.hipstr_debug_allele_kinds(dev, kinds)
     n_kinds = max(1, kinds[0] + kinds[1] + kinds[2] + kinds[3])
-    str_kinds = {"periodic_tabulated": kinds[1] / n_kinds, "one_or_two_interruptions_piecewise": kinds[2] / n_kinds, "more_interruptions_replayed_in_group": kinds[3] / n_kinds,
+    str_kinds = {"periodic_tabulated": kinds[1] / n_kinds, "one_or_two_interruptions_piecewise": kinds[2] / n_kinds, "more_interruptions_k_level_form_or_replay_in_group": kinds[3] / n_kinds,
                  "per_read_generic_kernel": kinds[0] / n_kinds,
                  "synth_overrides": {k: v for k, v in os.environ.items() if k.startswith("HIPSTR_SYNTH")}}
     if args.e2e_only:

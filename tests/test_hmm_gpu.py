@@ -14,6 +14,7 @@ from hipstr_amd import capi
 from util import batch_from_dict, simple_locus
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ALIGN = sorted(glob.glob(os.path.join(GOLD, "align_*.npz")))
 
@@ -330,6 +331,53 @@ def test_allele_masks_down_to_none(hmm, oracle, mask):
     assert np.all((got == -7.5).reshape(-1, 3)[:, [i for i, m in enumerate(mask) if not m]])
 
 
+@pytest.mark.parametrize("inherit,imperfect,kw", [
+    (2, "0.0", dict(n_loci=4, reads_per_locus=60, n_str_alleles=32, seed=191)),                                        # NS shape, two interruptions in every allele: 3-4 breaks per list
+    (3, "0.0", dict(n_loci=4, reads_per_locus=60, n_str_alleles=32, seed=192)),                                        # three: up to six breaks
+    (3, "1.0", dict(n_loci=3, reads_per_locus=40, n_str_alleles=24, seed=193)),                                        # + a random substitution per alt allele: lists beyond six breaks are replayed
+    (2, "0.3", dict(n_loci=3, reads_per_locus=30, n_str_alleles=24, read_len=100, flank_len=30, str_bp=90, seed=194)), # blocks longer than the read sides
+    (3, "0.0", dict(n_loci=3, reads_per_locus=40, n_str_alleles=20, n_flank_opts=3, mask_rate=0.3, seed=195)),         # lead slots, masks
+    (2, "0.0", dict(n_loci=2, reads_per_locus=24, n_str_alleles=16, read_len=300, flank_len=140, str_bp=60, seed=196)), # sides beyond a group: the per-read kernel replays these lists
+], ids=["inherit2", "inherit3", "inherit3_plus_random", "long_blocks", "flank_options_masks", "long_sides"])
+def test_inherited_interruptions_k_level_closed_form(hmm, oracle, monkeypatch, inherit, imperfect, kw):
+    """hs_str_group_kernel_rp: the reference allele carries two or three interrupted repeat units and every candidate inherits them
+    (HIPSTR_SYNTH_INHERIT), so the visiting lists have three to six breaks and are evaluated by the K-level piecewise closed form
+    (pwk_eval_grp, layout.h HS_SHAPE_PWK) — lists with still more breaks by the entry-by-entry replay in the same kernel.  Against the oracle,
+    bit for bit; the kind-3 share of the batch is checked so that the case keeps exercising the kernel."""
+    import ctypes as C
+    monkeypatch.setenv("HIPSTR_SYNTH_INHERIT", str(inherit))
+    monkeypatch.setenv("HIPSTR_SYNTH_IMPERFECT", imperfect)
+    sb = capi.SynthBatch(**kw)
+    want, ws = capi.run_align(oracle, "oracle_", sb.ptr, fill=-3.25)
+    got, gs = capi.run_align(hmm, "hipstr_hmm_", sb.ptr, fill=-3.25)
+    assert np.array_equal(gs, ws) and np.array_equal(got, want), kw
+    dev = hmm.hipstr_hmm_upload(sb.ptr)
+    assert dev
+    kinds = (C.c_int64 * 4)()
+    hmm.hipstr_debug_allele_kinds(dev, kinds)
+    hmm.hipstr_hmm_free(dev)
+    if kw.get("read_len", 150) <= 257:
+        assert kinds[3] > 0.3 * sum(kinds), list(kinds)
+
+
+@pytest.mark.parametrize("mode", ["spin", "sleep", "yield"])
+def test_wait_modes_of_the_one_shot_calls(mode):
+    """HIPSTR_WAIT (api_internal.h wait_stream): the one-shot entry points poll their stream and yield the core (default), spin in the driver
+    (spin) or sleep between polls (sleep); read once per process, so each mode runs in a process of its own, against the oracle."""
+    import subprocess, sys
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from hipstr_amd import capi\n"
+            "hmm = capi.load_hmm(); ora = capi.load_oracle(); assert hmm.hipstr_hmm_init(0) == 0\n"
+            "sb = capi.SynthBatch(n_loci=3, reads_per_locus=30, n_str_alleles=8, seed=77)\n"
+            "want, ws = capi.run_align(ora, 'oracle_', sb.ptr, fill=-3.25)\n"
+            "for _ in range(5):\n"
+            "    got, gs = capi.run_align(hmm, 'hipstr_hmm_', sb.ptr, fill=-3.25)\n"
+            "    assert np.array_equal(gs, ws) and np.array_equal(got, want)\n"
+            "print('ok')\n") % ROOT
+    env = dict(os.environ, HIPSTR_WAIT=mode)
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout
+
+
 def test_api_profile_buckets(hmm):
     """hipstr_debug_api_profile: wall time and calls per entry point while switched on (what genotype_flow --profile prints)."""
     import ctypes as C
@@ -346,7 +394,9 @@ def test_api_profile_buckets(hmm):
     by = {names[i].decode(): (secs[i], calls[i]) for i in range(n)}
     whole = by["hipstr_hmm_process_reads[_seeded]"]
     assert whole[1] == 3 and whole[0] > 0
-    parts = sum(v[0] for k, v in by.items() if k.startswith("  ") and v[1] == 3 and "replay" not in k)
+    parts = sum(v[0] for k, v in by.items() if k.startswith("  ") and not k.startswith("    ") and v[1] == 3 and "replay" not in k)
+    sub = sum(v[0] for k, v in by.items() if k.startswith("    upload:"))          # parts of the upload (the blocks are taken while the staging clock runs)
+    assert 0 < sub <= 1.05 * (by["  pack staging buffer"][0] + by["  blocks + H2D enqueue"][0])
     assert 0.5 * whole[0] < parts <= 1.05 * whole[0]          # the indented buckets are the parts of the entry point above them
     capi.run_align(hmm, "hipstr_hmm_", sb.ptr)                # switched off: nothing is added
     hmm.hipstr_debug_api_profile(-1, 32, names, secs, calls)
