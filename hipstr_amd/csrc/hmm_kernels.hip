@@ -2315,6 +2315,9 @@ hs_nd_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
   }
 }
 
+#ifndef HS_GTIME_EVERY
+#define HS_GTIME_EVERY 20000
+#endif
 #ifndef HS_PEXP
 #define HS_PEXP 0        // compile-time experiments (register pressure, timing; results invalid): 1 no evaluation, 2 no read-end sums, 3 no table phase
 #endif
@@ -2323,6 +2326,9 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
   constexpr int XC = HS_GRP_COLS, NT = HS_GRP_COLS;
   constexpr int SIXP = HS_MAXREP*P, NDS = HS_MAXREP*SIXP;            // a row slot / the six row slots of one read's read-end sums
   const int lane = threadIdx.x & 63, x = threadIdx.x;
+#ifdef HS_GTIME
+  const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
   const hs_item_t* item = d.items + item_begin + blockIdx.x;
   const int side = uni(item->side), G = uni(item->slot), tp = uni(item->active);
   // LDS carve of str_group_body (same size function), addressed as offsets in doubles from the start.  No static LDS in this kernel: the
@@ -2431,7 +2437,7 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
   request(hd_cur);
   int cur_slot = -1, prev_B = 0;
 #ifdef HS_GTIME
-  unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+  unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime(); const unsigned long long t_loop0 = tprev;
 #endif
   for (int i = i0; i < i1; i++){
     const int par = (i - i0) & 1;
@@ -2630,9 +2636,9 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
   }
 #ifdef HS_GTIME
   { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[0] += now_ - tprev; }
-  if ((blockIdx.x % 20000) == 7 && lane == 0)
-    printf("grp_p<%d> %d wave %d G %d X %d alleles %d: eval+setup %llu  wait1 %llu  table %llu  nd %llu  wait2 %llu\n", P, (int)blockIdx.x, (int)(x >> 6), G, X, i1 - i0,
-           tacc[0], tacc[1], tacc[2], tacc[3], tacc[4]);
+  if ((blockIdx.x % HS_GTIME_EVERY) == 7 && lane == 0)
+    printf("grp_p<%d> %d wave %d G %d X %d alleles %d: prologue %llu  eval+setup %llu  wait1 %llu  table %llu  nd %llu  wait2 %llu\n", P, (int)blockIdx.x, (int)(x >> 6), G, X, i1 - i0,
+           t_loop0 - t_entry, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4]);
 #endif
 }
 
