@@ -23,7 +23,8 @@
 #define HS_GRP_MAXP      6         // hs_str_group_kernel_p is instantiated for the periods 1..HS_GRP_MAXP
 #define HS_NART          13        // artifact sizes -6p..+6p (RepeatStutterInfo.h:10-11)
 #define HS_MAXREP        6
-#define HS_MAX_COLS      6         // max read columns per lane in the systolic sweep of the traceback fill (trace.hip): sides of up to 384 bases
+#define HS_MAX_COLS      16        // max read columns per lane in the systolic sweep of the traceback fill (trace.hip): sides of up to 1024 bases, like the forward pass
+                                   // (1-6 columns per lane: static LDS; 8 / 12 / 16 for the rare longer sides: dynamic LDS up to 146 KiB)
 #define HS_MAX_SIDE_LEN  256       // columns of a read side the grouped STR kernels and hs_nd_kernel hold (longer sides: hs_str_kernel, a workgroup per read)
 #define HS_MAX_SIDE_FWD  1024      // longest read side the forward pass takes (HapAligner sizes its matrices by the read, HapAligner.cpp:593-602)
 #define HS_MAX_STR_BP    2047      // longest STR allele (11-bit block length fields)

@@ -211,8 +211,7 @@ __device__ __forceinline__ int pair_idx(bool rev, double v1, double v2){        
 
 // ------------------------------------------------------------------ decisions of one (request, side)
 template <int C>
-__global__ void __launch_bounds__(64) hs_trace_fill(const hs_tdev_t* __restrict__ dp, int item_begin){
-  __shared__ TraceLdsStore<C> store;
+__device__ __forceinline__ void trace_fill_body(TraceLdsStore<C>& store, const hs_tdev_t* __restrict__ dp, int item_begin){
   TraceLds L;
   L.blc = store.blc; L.blw = store.blw; L.prev = store.prev; L.mr = store.mr; L.Mt = store.Mt; L.Dl = store.Dl; L.In = store.In;
   L.terms = store.terms; L.rd = store.rd; L.blk = store.blk;
@@ -406,6 +405,29 @@ __global__ void __launch_bounds__(64) hs_trace_fill(const hs_tdev_t* __restrict_
     }
   }
   if (F2 > 1) sweep(trail + 1, F2 - 1);
+}
+// sides of up to 384 columns (C <= 6): the wavefront's tables are static LDS (under the 64 KiB a kernel may declare)
+template <int C>
+__global__ void __launch_bounds__(64) hs_trace_fill(const hs_tdev_t* __restrict__ dp, int item_begin){
+  __shared__ TraceLdsStore<C> store;
+  trace_fill_body<C>(store, dp, item_begin);
+}
+// longer sides, up to the forward pass' 1024 columns (C = 8, 12, 16: 75-146 KiB of tables): dynamic LDS, sized by the launch
+// (hipFuncAttributeMaxDynamicSharedMemorySize).  Same body: a read of this length is rare in HipSTR's short-read data and takes the
+// lower occupancy; what matters is that the drop-in does not refuse a read the forward pass accepted.
+extern __shared__ double hs_trace_dyn_lds[];
+template <int C>
+__global__ void __launch_bounds__(64) hs_trace_fill_long(const hs_tdev_t* __restrict__ dp, int item_begin){
+  trace_fill_body<C>(*(TraceLdsStore<C>*)hs_trace_dyn_lds, dp, item_begin);
+}
+template <int C> int launch_fill_long(int cnt, hipStream_t ks, const hs_tdev_t* d_args, int first){
+  static bool sized = false;                    // (per instantiation; racing threads set the same value)
+  if (!sized){
+    if (hipFuncSetAttribute((const void*)hs_trace_fill_long<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TraceLdsStore<C>)) != hipSuccess) return 1;
+    sized = true;
+  }
+  hipLaunchKernelGGL(hs_trace_fill_long<C>, dim3(cnt), dim3(64), sizeof(TraceLdsStore<C>), ks, d_args, first);
+  return 0;
 }
 
 // ------------------------------------------------------------------ seed arg-max, total likelihood and the walk
@@ -746,7 +768,7 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
     if (s < 0) return api_fail("read without a seed base cannot be traced (HapAligner.cpp:586-594)");
     const int len = b->base_off[r+1] - b->base_off[r];
     if (given && (s < 1 || s > len - 2)) return api_fail("seed base must leave at least one base on either side (HapAligner.cpp:316)");
-    if (s > 64*HS_MAX_COLS || len-s-1 > 64*HS_MAX_COLS) return api_fail("traceback of a read side longer than 384 bases is not supported");
+    if (s > 64*HS_MAX_COLS || len-s-1 > 64*HS_MAX_COLS) return api_fail("traceback of a read side longer than 1024 bases is not supported");
     seeds[q] = s; req_locus[q] = l;
     const int64_t key = ((int64_t)l << 32) | (uint32_t)k;
     std::map<int64_t, int>::iterator hit = allele_slot.find(key);
@@ -909,7 +931,10 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
         case 3: hipLaunchKernelGGL(hs_trace_fill<3>, dim3(cnt), dim3(64), 0, ks, d_args, cls_begin[cl-1]); break;
         case 4: hipLaunchKernelGGL(hs_trace_fill<4>, dim3(cnt), dim3(64), 0, ks, d_args, cls_begin[cl-1]); break;
         case 5: hipLaunchKernelGGL(hs_trace_fill<5>, dim3(cnt), dim3(64), 0, ks, d_args, cls_begin[cl-1]); break;
-        default: hipLaunchKernelGGL(hs_trace_fill<6>, dim3(cnt), dim3(64), 0, ks, d_args, cls_begin[cl-1]); break;
+        case 6: hipLaunchKernelGGL(hs_trace_fill<6>, dim3(cnt), dim3(64), 0, ks, d_args, cls_begin[cl-1]); break;
+        case 7: case 8: if (launch_fill_long<8>(cnt, ks, d_args, cls_begin[cl-1])) return api_fail("hipFuncSetAttribute (traceback LDS) failed"); break;
+        case 9: case 10: case 11: case 12: if (launch_fill_long<12>(cnt, ks, d_args, cls_begin[cl-1])) return api_fail("hipFuncSetAttribute (traceback LDS) failed"); break;
+        default: if (launch_fill_long<16>(cnt, ks, d_args, cls_begin[cl-1])) return api_fail("hipFuncSetAttribute (traceback LDS) failed"); break;
       }
     }
     if (side) for (int k = 0; k < 2; k++) if (side->used[k]){

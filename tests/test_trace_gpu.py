@@ -50,6 +50,26 @@ def test_trace_matches_oracle_on_seeded_loci(hmm, oracle, kw):
     util.assert_traces_equal(got, want, str(kw))
 
 
+@pytest.mark.parametrize("kw", [
+    dict(reads_per_locus=8, n_str_alleles=3, read_len=640, flank_len=400, str_bp=40, seed=31),        # sides of up to 527 columns: 7-9 per lane
+    dict(reads_per_locus=6, n_str_alleles=3, read_len=900, flank_len=520, str_bp=36, seed=32),        # up to 788: 10-13 per lane
+    dict(reads_per_locus=8, n_str_alleles=2, read_len=1024, flank_len=600, str_bp=30, seed=33),       # up to 907 of the forward pass' 1024: 11-15 per lane
+])
+def test_trace_of_long_read_sides(hmm, oracle, kw):
+    """Read sides beyond 384 columns (round 4: the traceback takes what the forward pass takes, sides of up to 1024 bases; the fill kernel's
+    tables move to dynamic LDS for 8 / 12 / 16 columns per lane) against the oracle, field by field."""
+    sb = capi.SynthBatch(n_loci=1, **kw)
+    _, seeds = capi.run_align(oracle, "oracle_", sb.ptr)
+    lens = np.diff(np.ctypeslib.as_array(sb.ptr.contents.base_off, shape=(sb.n_reads + 1,)))
+    longest = max(max(int(s), int(l - s - 1)) for s, l in zip(seeds, lens) if s >= 0)
+    assert longest > 384, longest                          # the case is about the new classes
+    rr, aa = _requests(oracle, sb, 2, kw["seed"])
+    h2r = util.synthetic_hap_to_ref(oracle, sb.ptr)
+    want = capi.run_trace(oracle, "oracle_", sb.ptr, rr, aa, h2r, cap=1 << 22)
+    got = capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, rr, aa, h2r, cap=1 << 22)
+    util.assert_traces_equal(got, want, str(kw))
+
+
 def test_trace_without_reference_strings_skips_the_stitch(hmm, oracle):
     sb = capi.SynthBatch(n_loci=1, reads_per_locus=12, n_str_alleles=4, seed=12)
     rr, aa = _requests(oracle, sb, 2, 12)
