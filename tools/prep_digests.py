@@ -18,6 +18,9 @@ CASES = [
     ("tiny", dict(n_loci=60, reads_per_locus=17, n_str_alleles=7, read_len=40, flank_len=12, str_bp=8, seed=21), {}),
     ("long", dict(n_loci=6, reads_per_locus=50, n_str_alleles=20, read_len=300, flank_len=140, str_bp=300, seed=31), {}),
     ("masked", dict(n_loci=70, reads_per_locus=25, n_str_alleles=10, seed=17, mask_rate=0.6), {}),
+    # interruptions inherited from the reference allele: lists with three to six breaks (K-level descriptor slots, layout.h HS_SHAPE_PWK) and beyond
+    ("inh2", dict(n_loci=60, reads_per_locus=30, n_str_alleles=16, seed=41), {"HIPSTR_SYNTH_INHERIT": "2"}),
+    ("inh3", dict(n_loci=40, reads_per_locus=24, n_str_alleles=12, seed=43), {"HIPSTR_SYNTH_INHERIT": "3", "HIPSTR_SYNTH_IMPERFECT": "0.3"}),
 ]
 
 
