@@ -241,7 +241,7 @@ def end_to_end(capi, hmm, sb, loci, steps, device, latency=True):
     submission (bam_processor.cpp:550-617).  `steps` passes over the batch go through one open stream back to back, a feeder
     thread submitting while this thread collects in order; reported beside `value`, never as `value` (inputs are host-resident)."""
     import threading
-    st = capi.Stream(hmm, device=device, slots=int(os.environ.get("HIPSTR_BENCH_SLOTS", "8")), batch_alignments=int(os.environ.get("HIPSTR_BENCH_BATCH", str(2 << 20))))
+    st = capi.Stream(hmm, device=device, slots=int(os.environ.get("HIPSTR_BENCH_SLOTS", "8")), batch_alignments=int(os.environ.get("HIPSTR_BENCH_BATCH", "0")))        # 0: the library's own batch size (2 Mi pairs, up to 8 Mi for batches of few heavy loci)
     probs = np.zeros(max(sb.n_out, 1)); seeds = np.zeros(max(sb.n_reads, 1), np.int32)
     def one_pass_set(n):
         # feeder: every locus its own submission (hipstr_stream_submit_each: the per-region loop in C, as the reference's caller is C++);
@@ -300,7 +300,7 @@ def end_to_end(capi, hmm, sb, loci, steps, device, latency=True):
             "cpu_seconds_by_role": {k[4:-8]: s1[k] - s0[k] for k in ("cpu_submit_seconds", "cpu_prepare_seconds", "cpu_upload_seconds", "cpu_collect_seconds")},
             "warmup_passes": warm, "timed_attempts": attempt + 1, "driver_allocs_during_timed_passes": int(hmm.hipstr_debug_driver_allocs() - a_timed0),
             "one_locus_process_reads_latency": lat,
-            "path": "hipstr_stream_submit_each (1 locus per submission) -> batches of ~2 Mi alignments -> prepare on host threads + H2D + table expansion + kernels + D2H, 8 slots -> hipstr_stream_collect in order"}
+            "path": "hipstr_stream_submit_each (1 locus per submission) -> batches of 2-8 Mi alignments (the library's choice by loci per batch and host threads) -> prepare on host threads + H2D + table expansion + kernels + D2H, 8 slots -> hipstr_stream_collect in order"}
 
 
 def main():

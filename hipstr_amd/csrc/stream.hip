@@ -231,8 +231,26 @@ struct InFlight {
 struct hipstr_stream {
   hipstr::Ctx* ctx = NULL;
   hipStream_t copy_stream = NULL, d2h_stream = NULL;     // tables to the device / results back: neither waits for the other
+  // The kernels of consecutive batches go to alternating streams: a batch is ~2 Mi pairs, a pass of the north-star shape eight of them, and
+  // on ONE stream every kernel of every batch drains before the next one starts — the tails of 60 kernels per pass instead of 8 cost 8 % of
+  // the resident rate (end of round 4: 129.3 ms per pass against 118.8).  On two streams the next batch's kernels fill the tails.
+  // HIPSTR_STREAM_COMPUTE_STREAMS=1: the context's stream for every batch, as before (comparison runs).
+  hipStream_t compute[4] = {NULL, NULL, NULL, NULL};
+  int n_compute = 0;
+  std::atomic<unsigned> launch_seq{0};
   int slots = 6;
   int64_t batch_work = (int64_t)2 << 20;       // (2 Mi pairs: a 30x batch's tables then stay within the last-level cache while they are built and packed)
+  // ... for batches of MANY loci.  What the device sees is pairs: with heavy loci (the north-star shape: 16 000 pairs each) 2 Mi pairs are
+  // 131 loci, every kernel of the batch is a sixth of a millisecond to a few milliseconds long, and the batch runs at 127 M pairs/s where
+  // 1000 loci run at 134 (end of round 4: resident rate by batch size; end to end 129.5 -> 124.4 ms per pass with 8 Mi batches).  A batch
+  // therefore closes at batch_work pairs only once it holds 2048 loci, else at `big_mult` times that; the batches in flight are bounded
+  // by their pairs (slots x batch_work, three batches at least) so that the workspaces in flight do not grow with the batch.
+  // (only where the caller left the batch size to the library; with few host threads — a rank's two at eight GPUs — a batch is prepared
+  //  almost serially and the large ones starve the device: 122.6 -> 120.2 M pairs/s measured, so the factor follows the host threads)
+  bool adaptive = true;
+  int big_mult = 1;
+  bool full(int64_t work, size_t n_loci) const { return work >= batch_work && (!adaptive || n_loci >= 2048 || work >= batch_work * big_mult); }
+  int64_t in_worker_work = 0;       // pairs of the batches the workers have popped but not yet pushed to `flying`
   std::mutex m;
   std::condition_variable cv_work, cv_done, cv_slots;
   OwnedBatch* pending = NULL;
@@ -297,18 +315,28 @@ void worker_loop(hipstr_stream* s, int n_workers){
         return INT64_MAX;
       };
       auto may_overshoot = [&]{ return !s->wait_tickets.empty() && next_first() <= *s->wait_tickets.rbegin(); };
-      s->cv_work.wait(g, [&]{ return s->closing || (have_work() && ((int)s->flying.size() + s->in_worker < s->slots || may_overshoot())); });
+      auto room = [&]{                                   // batches in flight: at most `slots`, and at most slots x batch_work pairs beyond the third batch
+        const int n_fly = (int)s->flying.size() + s->in_worker;
+        if (n_fly >= s->slots) return false;
+        if (n_fly < 3) return true;
+        int64_t w = s->in_worker_work;
+        for (const InFlight* f : s->flying) w += f->ob->work;
+        const int64_t next = !s->ready.empty() ? s->ready.front()->work : (s->pending ? s->pending->work : 0);
+        return w + next <= (int64_t)s->slots * s->batch_work;
+      };
+      s->cv_work.wait(g, [&]{ return s->closing || (have_work() && (room() || may_overshoot())); });
       if (s->closing) return;
       if (s->ready.empty()) flush_locked(s);
-      ob = s->ready.front(); s->ready.pop_front(); s->in_worker++;
+      ob = s->ready.front(); s->ready.pop_front(); s->in_worker++; s->in_worker_work += ob->work;
     }
     ob->wait_writers();              // copies into the batch that a submitter is still making outside the lock
     InFlight* f = new InFlight(); f->ob = ob; f->taken.assign(ob->tickets.size(), 0);
     const auto t0 = std::chrono::steady_clock::now();
     const double c0 = thread_cpu_now();
-    f->dev = hipstr::upload_on(s->ctx, ob->finish(), ob->seed.data(), s->copy_stream, hipstr::ctx_stream(s->ctx), true);
+    const hipStream_t cs = s->n_compute > 0 ? s->compute[s->launch_seq.fetch_add(1) % (unsigned)s->n_compute] : hipstr::ctx_stream(s->ctx);
+    f->dev = hipstr::upload_on(s->ctx, ob->finish(), ob->seed.data(), s->copy_stream, cs, true);
     if (!f->dev){ f->failed = true; f->err = hipstr_last_error(); }
-    else if (hipstr_hmm_align(f->dev, NULL) != 0 || hipstr::fetch_begin(f->dev, hipstr::ctx_stream(s->ctx), s->d2h_stream) != 0){
+    else if (hipstr_hmm_align(f->dev, NULL) != 0 || hipstr::fetch_begin(f->dev, cs, s->d2h_stream) != 0){
       f->failed = true; f->err = hipstr_last_error();
     }
     const double host_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -317,7 +345,7 @@ void worker_loop(hipstr_stream* s, int n_workers){
               1e3*std::chrono::duration<double>(t0 - s->t_open).count(), 1e3*std::chrono::duration<double>(std::chrono::steady_clock::now() - s->t_open).count());
     {
       std::lock_guard<std::mutex> g(s->m);
-      s->flying.push_back(f); s->in_worker--;
+      s->flying.push_back(f); s->in_worker--; s->in_worker_work -= ob->work;
       s->stats.batches++; s->stats.host_seconds += host_s; s->stats.alignment_slots += ob->work;
       const double cpu = thread_cpu_now() - c0, prep = f->dev ? hipstr::batch_prepare_seconds(f->dev) : 0.0;
       s->stats.cpu_prepare_seconds += std::min(cpu, prep); s->stats.cpu_upload_seconds += std::max(0.0, cpu - prep);
@@ -341,9 +369,26 @@ hipstr_stream_t* hipstr_stream_open(const hipstr_stream_opts_t* opts){
   s->ctx = hipstr::api_current_ctx();
   if (!s->ctx){ delete s; return NULL; }
   if (opts && opts->slots > 0) s->slots = opts->slots;
-  if (opts && opts->batch_alignments > 0) s->batch_work = opts->batch_alignments;
+  if (opts && opts->batch_alignments > 0){ s->batch_work = opts->batch_alignments; s->adaptive = false; }
+  {
+    const int ht = hipstr::host_threads();
+    s->big_mult = ht >= 8 ? 4 : (ht >= 4 ? 2 : 1);
+    if (const char* e = getenv("HIPSTR_STREAM_BIG_BATCH")) s->big_mult = std::max(1, atoi(e));
+  }
   if (hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s->d2h_stream, hipStreamNonBlocking) != hipSuccess){
     hipstr::api_fail("hipStreamCreate failed"); delete s; return NULL; }
+  {
+    int nc = 2;
+    if (const char* e = getenv("HIPSTR_STREAM_COMPUTE_STREAMS")) nc = std::max(1, std::min(4, atoi(e)));
+    if (nc > 1) for (int i = 0; i < nc; i++){
+      if (hipStreamCreateWithFlags(&s->compute[i], hipStreamNonBlocking) != hipSuccess){
+        hipstr::api_fail("hipStreamCreate failed");
+        for (int k = 0; k < s->n_compute; k++) hipStreamDestroy(s->compute[k]);
+        hipStreamDestroy(s->copy_stream); hipStreamDestroy(s->d2h_stream); delete s; return NULL;
+      }
+      s->n_compute = i + 1;
+    }
+  }
   memset(&s->stats, 0, sizeof s->stats);
   s->t_open = std::chrono::steady_clock::now();
   // Three workers by default (HIPSTR_STREAM_WORKERS): preparing a batch has serial stretches between its parallel ones (merging the
@@ -381,7 +426,7 @@ int64_t hipstr_stream_submit(hipstr_stream_t* s, const hipstr_batch_t* loci){
   if (const char* why = s->pending->append(loci, ticket, seeds.data())){ hipstr::api_fail(why); return -1; }
   s->next_ticket++;
   s->sizes.push_back(std::make_pair(s->pending->n_out - out_before, (int64_t)(s->pending->read_off.back() - reads_before)));
-  if (s->pending->work >= s->batch_work) flush_locked(s);
+  if (s->full(s->pending->work, s->pending->period.size())) flush_locked(s);
   return ticket;
 }
 
@@ -423,7 +468,8 @@ int hipstr_stream_submit_each(hipstr_stream_t* s, const hipstr_batch_t* loci, in
       if (s->closing) return hipstr::api_fail("stream is closing");
       if (!s->pending) s->pending = new_batch_locked(s);
       int64_t w = s->pending->work;
-      while (l1 < n_ok_total && l1 - l0 < 1024 && w < s->batch_work){
+      const size_t nl0 = s->pending->period.size();
+      while (l1 < n_ok_total && l1 - l0 < 1024 && !s->full(w, nl0 + (size_t)(l1 - l0))){
         w += (int64_t)(loci->read_off[l1+1] - loci->read_off[l1])*(loci->hap_off[l1+1] - loci->hap_off[l1]); l1++;
       }
       const int64_t ticket0 = s->next_ticket;
@@ -431,7 +477,7 @@ int hipstr_stream_submit_each(hipstr_stream_t* s, const hipstr_batch_t* loci, in
       if (const char* w2 = ob->append_run(loci, l0, l1, opt0.data(), ticket0, s->sizes, seeds.data(), cp)) return hipstr::api_fail(w2);
       s->next_ticket += l1 - l0;
       if (l0 == 0 && first_ticket) *first_ticket = ticket0;
-      if (s->pending->work >= s->batch_work) flush_locked(s);
+      if (s->full(s->pending->work, s->pending->period.size())) flush_locked(s);
     }
     // the reads' bases and qualities (12 KB per 40-read locus), outside the lock: a worker that picks the batch up waits for `writers`
     {
@@ -654,6 +700,7 @@ int hipstr_stream_close(hipstr_stream_t* s){
   hipstr::api_bind(s->ctx);
   for (InFlight* f : s->flying){ if (f->dev) hipstr::free_landed(f->dev, false); delete f->ob; delete f; }
   hipStreamSynchronize(s->copy_stream); hipStreamSynchronize(s->d2h_stream);
+  for (int i = 0; i < s->n_compute; i++){ hipStreamSynchronize(s->compute[i]); hipStreamDestroy(s->compute[i]); }
   for (OwnedBatch* ob : s->spare) delete ob;
   s->spare.clear();
   hipStreamDestroy(s->copy_stream); hipStreamDestroy(s->d2h_stream);
