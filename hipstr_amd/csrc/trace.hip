@@ -412,6 +412,23 @@ __global__ void __launch_bounds__(64) hs_trace_fill(const hs_tdev_t* __restrict_
   __shared__ TraceLdsStore<C> store;
   trace_fill_body<C>(store, dp, item_begin);
 }
+// The requests of ONE locus are a hundred wavefronts spread over two or three column classes: as launches of their own on side streams the
+// classes did not reliably run side by side (end of round 4, rocprofv3 timeline of a 100-request call: 143 us | 245 us beside it | 233 us
+// BEHIND it — two of the three streams shared a hardware queue), and a fill kernel is a chain of ~300 dependent steps whatever its size.
+// One launch for the classes 1-6 instead: a workgroup picks its class from the launch order's class boundaries and takes the front of the
+// largest class's LDS block.  Registers and LDS are the largest class's — irrelevant for a call that fills a fraction of the device; calls
+// of many loci keep one launch per class.
+struct hs_tcls_t { int32_t end[6]; };          // launch-order index one past the last side of class 1 .. 6
+__global__ void __launch_bounds__(64) hs_trace_fill_mixed(const hs_tdev_t* __restrict__ dp, hs_tcls_t cls){
+  __shared__ TraceLdsStore<6> store;
+  const int b = (int)blockIdx.x;
+  if (b < cls.end[0])      trace_fill_body<1>(*(TraceLdsStore<1>*)&store, dp, 0);
+  else if (b < cls.end[1]) trace_fill_body<2>(*(TraceLdsStore<2>*)&store, dp, 0);
+  else if (b < cls.end[2]) trace_fill_body<3>(*(TraceLdsStore<3>*)&store, dp, 0);
+  else if (b < cls.end[3]) trace_fill_body<4>(*(TraceLdsStore<4>*)&store, dp, 0);
+  else if (b < cls.end[4]) trace_fill_body<5>(*(TraceLdsStore<5>*)&store, dp, 0);
+  else                     trace_fill_body<6>(store, dp, 0);
+}
 // longer sides, up to the forward pass' 1024 columns (C = 8, 12, 16: 75-146 KiB of tables): dynamic LDS, sized by the launch
 // (hipFuncAttributeMaxDynamicSharedMemorySize).  Same body: a read of this length is rare in HipSTR's short-read data and takes the
 // lower occupancy; what matters is that the drop-in does not refuse a read the forward pass accepted.
@@ -577,20 +594,6 @@ struct DevBufs {
 };
 
 // two side streams + their events per (host thread, device), created at first use and kept
-struct SideStreams { hipStream_t st[2] = {NULL, NULL}; hipEvent_t ev_up = NULL, ev_done[2] = {NULL, NULL}; bool used[2] = {false, false}; bool ok = false; };
-static SideStreams* side_streams(int device){
-  thread_local SideStreams per_dev[16];
-  if (device < 0 || device >= 16) return NULL;
-  SideStreams& s = per_dev[device];
-  if (!s.ok){
-    if (hipStreamCreateWithFlags(&s.st[0], hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s.st[1], hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.ev_done[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s.ev_done[1], hipEventDisableTiming) != hipSuccess) return NULL;
-    s.ok = true;
-  }
-  return &s;
-}
-
 struct AllelePrep {
   std::string seq[2][3];          // block sequences per orientation, in side order
   int lead_off[2], trail_off[2], stropt[2];
@@ -911,20 +914,19 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
     if (ch_arena.send(T.stream)) return 1;
     const hs_tdev_t* d_args = ch_arena.at<hs_tdev_t>(o_args);
     const auto c1 = now();
-    // The fill kernels of the column classes are independent of each other and, for the requests of one locus, a hundred wavefronts
-    // each: the second and third class run beside the first on two side streams of the calling thread (made once per thread and
-    // device), the walk kernel waits for all of them.  Large calls (many loci) fill the device per class and stay on one stream.
-    int n_cls = 0; for (int cl = 1; cl <= HS_MAX_COLS; cl++) n_cls += (cls_begin[cl] - cls_begin[cl-1]) > 0;
-    SideStreams* side = (n_cls > 1 && nq <= 4096) ? side_streams(hipstr::ctx_device(T.ctx)) : NULL;
-    if (side){ side->used[0] = side->used[1] = false; TR_HIP(hipEventRecord(side->ev_up, T.stream)); }
-    int k_cls = 0;
-    for (int cl = 1; cl <= HS_MAX_COLS; cl++){
+    // the fill kernels of the column classes: one launch per class for calls of many loci, ONE launch for the requests of a locus or two (hs_trace_fill_mixed)
+    int n_cls = 0; for (int cl = 1; cl <= 6; cl++) n_cls += (cls_begin[cl] - cls_begin[cl-1]) > 0;
+    static const bool mixed_on = !(getenv("HIPSTR_TRACE_MIXED") && atoi(getenv("HIPSTR_TRACE_MIXED")) == 0);      // 0: one launch per class, as for large calls
+    const bool mixed = mixed_on && n_cls > 1 && nq <= 4096;        // small call, several classes: one launch (hs_trace_fill_mixed)
+    if (mixed){
+      hs_tcls_t cls;
+      for (int cl = 1; cl <= 6; cl++) cls.end[cl-1] = cls_begin[cl];
+      hipLaunchKernelGGL(hs_trace_fill_mixed, dim3(cls_begin[6]), dim3(64), 0, T.stream, d_args, cls);
+    }
+    for (int cl = mixed ? 7 : 1; cl <= HS_MAX_COLS; cl++){
       const int cnt = cls_begin[cl] - cls_begin[cl-1];
       if (cnt == 0) continue;
       hipStream_t ks = T.stream;
-      const int slot = side ? k_cls % 3 : 0;              // 0: the call's stream; 1, 2: the side streams
-      if (slot){ ks = side->st[slot-1]; dev.runs_on(ks); if (!side->used[slot-1]){ TR_HIP(hipStreamWaitEvent(ks, side->ev_up, 0)); side->used[slot-1] = true; } }
-      k_cls++;
       switch (cl){
         case 1: hipLaunchKernelGGL(hs_trace_fill<1>, dim3(cnt), dim3(64), 0, ks, d_args, cls_begin[cl-1]); break;
         case 2: hipLaunchKernelGGL(hs_trace_fill<2>, dim3(cnt), dim3(64), 0, ks, d_args, cls_begin[cl-1]); break;
@@ -936,9 +938,6 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
         case 9: case 10: case 11: case 12: if (launch_fill_long<12>(cnt, ks, d_args, cls_begin[cl-1])) return api_fail("hipFuncSetAttribute (traceback LDS) failed"); break;
         default: if (launch_fill_long<16>(cnt, ks, d_args, cls_begin[cl-1])) return api_fail("hipFuncSetAttribute (traceback LDS) failed"); break;
       }
-    }
-    if (side) for (int k = 0; k < 2; k++) if (side->used[k]){
-      TR_HIP(hipEventRecord(side->ev_done[k], side->st[k])); TR_HIP(hipStreamWaitEvent(T.stream, side->ev_done[k], 0)); side->used[k] = false;
     }
     hipLaunchKernelGGL(hs_trace_walk, dim3(nq), dim3(64), 0, T.stream, d_args, 0);
     TR_HIP(hipGetLastError());
