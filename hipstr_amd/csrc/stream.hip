@@ -249,7 +249,14 @@ struct hipstr_stream {
   //  almost serially and the large ones starve the device: 122.6 -> 120.2 M pairs/s measured, so the factor follows the host threads)
   bool adaptive = true;
   int big_mult = 1;
-  bool full(int64_t work, size_t n_loci) const { return work >= batch_work && (!adaptive || n_loci >= 2048 || work >= batch_work * big_mult); }
+  // (and not for loci of more than batch_work / 64 pairs each — configs[3]'s 1000-sample loci, 160 000 pairs: their batches are a dozen loci
+  //  whose kernels are long already and whose preparation is milliseconds per locus; with 8 Mi batches a pass of 100 such loci is two
+  //  batches and nothing overlaps: 118 -> 97 M pairs/s measured)
+  bool full(int64_t work, size_t n_loci) const {
+    if (work < batch_work) return false;
+    if (!adaptive || n_loci >= 2048 || (int64_t)n_loci * batch_work < 64 * work) return true;
+    return work >= batch_work * big_mult;
+  }
   int64_t in_worker_work = 0;       // pairs of the batches the workers have popped but not yet pushed to `flying`
   std::mutex m;
   std::condition_variable cv_work, cv_done, cv_slots;

@@ -7,7 +7,7 @@ run(){   # $1 = label, $2.. = env
   local label=$1; shift
   local pids=()
   for i in $(seq 1 $NP); do
-    env "$@" python tools/fuzz_align.py $NC $((1000*$i + 17)) > /tmp/fuzz_${label}_$i.txt 2>&1 &
+    env "$@" timeout ${FUZZ_TIMEOUT:-1500} python tools/fuzz_align.py $NC $((1000*$i + 17)) > /tmp/fuzz_${label}_$i.txt 2>&1 &
     pids+=($!)
   done
   for p in "${pids[@]}"; do wait $p; done
