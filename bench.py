@@ -257,7 +257,9 @@ def end_to_end(capi, hmm, sb, loci, steps, device, latency=True):
                 k = min(loci - got, 256)
                 try:
                     st.collect(k, probs, seeds); got += k
-                except RuntimeError:
+                except RuntimeError as ex:
+                    if "fewer submissions outstanding" not in str(ex):     # a failed batch / a refused locus must end the run, not spin here
+                        raise
                     time.sleep(0.0002)
         th.join()
     # warm-up: kernels, and the block caches — a miss is a hipMalloc / hipHostMalloc of up to gigabytes (0.9 s seen) in the middle of the
@@ -621,12 +623,15 @@ def main():
             # to usable_cores/8 CPUs (all of its threads) with as many library host threads
             if not args.host_threads and not os.environ.get("HIPSTR_BENCH_NO_SHARE"):
                 import subprocess
+                hmm.hipstr_hmm_trim()          # what this process' stream cached and no longer uses: the child needs the device memory
                 n8 = max(1, usable_cores() // 8)
                 cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", str(args.steps), "--e2e-only", "--host-threads", str(n8)]
                 if args.loci:
                     cmd += ["--loci", str(args.loci)]
                 try:
-                    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
+                    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=300)
+                    if r.returncode != 0 or not r.stdout.strip():
+                        raise RuntimeError("child rc %d: %s" % (r.returncode, r.stderr.strip().splitlines()[-1] if r.stderr.strip() else ""))
                     sh = json.loads(r.stdout.strip().splitlines()[-1])
                     sh["fraction_of_resident_rate"] = sh["alignments_per_s"] / value
                     sh["note"] = "child process of this run pinned to %d of the node's %d usable CPUs (= usable/8: one rank's share at 8 GPUs), HIPSTR_HOST_THREADS=%d" % (n8, usable_cores(), n8)

@@ -508,6 +508,7 @@ def load_hmm():
     _sig(lib.hipstr_batch_out_offsets, C.c_int, [_BP, C.POINTER(C.c_int64)])
     _sig(lib.hipstr_hmm_init, C.c_int, [C.c_int])
     _sig(lib.hipstr_hmm_shutdown, None, [])
+    _sig(lib.hipstr_hmm_trim, C.c_int64, [])
     _sig(lib.hipstr_hmm_upload, C.c_void_p, [_BP])
     _sig(lib.hipstr_hmm_free, None, [C.c_void_p])
     _sig(lib.hipstr_hmm_align, C.c_int, [C.c_void_p, C.c_void_p])

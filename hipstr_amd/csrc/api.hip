@@ -71,7 +71,7 @@ struct BlockCache {
   std::mutex m;
   std::multimap<size_t, void*> free_;
   std::unordered_map<void*, size_t> size_;
-  struct Chunk { char* base; size_t size, used; };
+  struct Chunk { char* base; size_t size, used; int live = 0; };       // live: blocks of the chunk that are out
   std::vector<Chunk> chunks;
   size_t next_chunk = (size_t)256 << 20;
   size_t cached = 0, cap = 0, in_use = 0;
@@ -94,7 +94,7 @@ struct BlockCache {
     size_t want = round_up(bytes);
     std::lock_guard<std::mutex> g(m);
     auto it = free_.lower_bound(want);
-    if (it != free_.end() && it->first <= 2*want){ void* p = it->second; cached -= it->first; free_.erase(it); in_use++; return p; }
+    if (it != free_.end() && it->first <= 2*want){ void* p = it->second; cached -= it->first; free_.erase(it); in_use++; if (Chunk* c = chunk_of(p)) c->live++; return p; }
     if (want > ((size_t)16 << 20)) want = round_up(want + want/8);        // a new large block comes with headroom for its successors
     if (chunks.empty() || chunks.back().used + want > chunks.back().size){
       const size_t max_chunk = pinned ? (size_t)2 << 30 : (size_t)16 << 30;
@@ -103,15 +103,16 @@ struct BlockCache {
       char* base = (char*)driver_alloc(sz);
       if (!base && sz > want) base = (char*)driver_alloc(sz = want);       // the device is nearly full: just what is needed
       if (!base) return NULL;
-      chunks.push_back(Chunk{base, sz, 0});
+      chunks.push_back(Chunk{base, sz, 0, 0});
     }
     Chunk& c = chunks.back();
     void* p = c.base + c.used;
     c.used += (want + 255) & ~(size_t)255;
     size_[p] = want;
-    in_use++;
+    in_use++; c.live++;
     return p;
   }
+  Chunk* chunk_of(const void* p){ for (Chunk& c : chunks) if ((const char*)p >= c.base && (const char*)p < c.base + c.size) return &c; return NULL; }
   void put(void* p){
     if (!p) return;
     std::lock_guard<std::mutex> g(m);
@@ -119,6 +120,28 @@ struct BlockCache {
     if (it == size_.end()) return;
     free_.insert(std::make_pair(it->second, p)); cached += it->second;
     if (in_use > 0) in_use--;
+    if (Chunk* c = chunk_of(p)) if (c->live > 0) c->live--;
+  }
+  // chunks none of whose blocks is out go back to the driver (hipstr_hmm_trim: after a stream of large batches a process may sit on tens
+  // of gigabytes it no longer needs — another process on the device, a child of this one, then fails its kernel launches with "out of
+  // memory"); returns the bytes released
+  size_t trim(){
+    std::vector<Chunk> gone; size_t bytes = 0;
+    {
+      std::lock_guard<std::mutex> g(m);
+      for (size_t i = 0; i < chunks.size(); ){
+        if (chunks[i].live != 0){ i++; continue; }
+        const Chunk c = chunks[i];
+        for (auto it = free_.begin(); it != free_.end(); ){
+          if ((char*)it->second >= c.base && (char*)it->second < c.base + c.size){ cached -= it->first; size_.erase(it->second); it = free_.erase(it); } else ++it;
+        }
+        gone.push_back(c); bytes += c.size;
+        chunks.erase(chunks.begin() + (long)i);
+      }
+      if (chunks.empty()) next_chunk = (size_t)256 << 20;
+    }
+    for (Chunk& c : gone){ if (pinned) hipHostFree(c.base); else hipFree(c.base); }
+    return bytes;
   }
   // everything back to the driver — only when no block is out (hipstr_hmm_shutdown)
   void release(){
@@ -322,6 +345,17 @@ int hipstr_hmm_init(int device_ordinal){
   if (!c) return 1;
   t_ctx = c;
   return 0;
+}
+
+int64_t hipstr_hmm_trim(void){
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  int64_t bytes = 0;
+  for (auto& kv : g_ctxs){
+    Ctx* c = kv.second;
+    if (hipSetDevice(c->device) != hipSuccess) continue;
+    bytes += (int64_t)c->dev_cache.trim() + (int64_t)c->pin_cache.trim();
+  }
+  return bytes;
 }
 
 void hipstr_hmm_shutdown(void){

@@ -244,7 +244,7 @@ struct hipstr_stream {
   // 131 loci, every kernel of the batch is a sixth of a millisecond to a few milliseconds long, and the batch runs at 127 M pairs/s where
   // 1000 loci run at 134 (end of round 4: resident rate by batch size; end to end 129.5 -> 124.4 ms per pass with 8 Mi batches).  A batch
   // therefore closes at batch_work pairs only once it holds 2048 loci, else at `big_mult` times that; the batches in flight are bounded
-  // by their pairs (slots x batch_work, three batches at least) so that the workspaces in flight do not grow with the batch.
+  // by their pairs (slots x batch_work, two batches at least) so that the workspaces in flight do not grow with the batch.
   // (only where the caller left the batch size to the library; with few host threads — a rank's two at eight GPUs — a batch is prepared
   //  almost serially and the large ones starve the device: 122.6 -> 120.2 M pairs/s measured, so the factor follows the host threads)
   bool adaptive = true;
@@ -255,7 +255,9 @@ struct hipstr_stream {
   bool full(int64_t work, size_t n_loci) const {
     if (work < batch_work) return false;
     if (!adaptive || n_loci >= 2048 || (int64_t)n_loci * batch_work < 64 * work) return true;
-    return work >= batch_work * big_mult;
+    // (at most a third of the pairs allowed in flight: three such batches hold what `slots` small ones did before — a large batch must not
+    //  raise the stream's memory, which at 2.3 KB of workspace per pair is 38 GB for the default 16 Mi pairs in flight)
+    return work >= std::min(batch_work * big_mult, std::max(batch_work, (int64_t)slots * batch_work / 3));
   }
   int64_t in_worker_work = 0;       // pairs of the batches the workers have popped but not yet pushed to `flying`
   std::mutex m;
@@ -322,10 +324,10 @@ void worker_loop(hipstr_stream* s, int n_workers){
         return INT64_MAX;
       };
       auto may_overshoot = [&]{ return !s->wait_tickets.empty() && next_first() <= *s->wait_tickets.rbegin(); };
-      auto room = [&]{                                   // batches in flight: at most `slots`, and at most slots x batch_work pairs beyond the third batch
+      auto room = [&]{                                   // batches in flight: at most `slots`, and at most slots x batch_work pairs beyond the second batch
         const int n_fly = (int)s->flying.size() + s->in_worker;
         if (n_fly >= s->slots) return false;
-        if (n_fly < 3) return true;
+        if (n_fly < 2) return true;
         int64_t w = s->in_worker_work;
         for (const InFlight* f : s->flying) w += f->ob->work;
         const int64_t next = !s->ready.empty() ? s->ready.front()->work : (s->pending ? s->pending->work : 0);

@@ -113,6 +113,11 @@ typedef struct hipstr_dev_batch hipstr_dev_batch_t;
  * init_alignment_model) and BaseQuality's log tables (base_quality.h:29-38). */
 int hipstr_hmm_init(int device_ordinal);
 void hipstr_hmm_shutdown(void);
+/* Device and pinned memory the library holds in its block caches but no object of the caller uses goes back to the driver (whole
+ * chunks only: a chunk with one block still out stays).  The caches exist because a hipMalloc / hipFree next to running kernels stalls
+ * for 0.1-0.9 s; a process that is done with a large stream and stays alive next to other users of the device calls this.  Returns the
+ * bytes released.  (No counterpart in the reference: its matrices are new[]/delete[] per read, HapAligner.cpp:593-602.) */
+int64_t hipstr_hmm_trim(void);
 
 /* Flattens and uploads a batch.  Replaces HapAligner's constructor work
  * (reversed haplotype, StutterAlignerClass tables; HapAligner.h:56-69,

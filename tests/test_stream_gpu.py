@@ -103,6 +103,31 @@ def test_large_stream_full_rate(hmm):
     st.close()
 
 
+def test_trim_gives_unused_chunks_back_and_keeps_what_is_in_use(hmm):
+    """hipstr_hmm_trim: cached chunks without a block in use return to the driver (a closed stream's workspaces), a resident batch keeps its
+    chunks and still works, and the library allocates again afterwards."""
+    sb = capi.SynthBatch(n_loci=40, reads_per_locus=200, n_str_alleles=16, seed=404)
+    want, wseeds = capi.run_align(hmm, "hipstr_hmm_", sb.ptr)
+    dev = hmm.hipstr_hmm_upload(sb.ptr)                      # stays alive across the trim
+    assert dev
+    st = capi.Stream(hmm, slots=3)
+    st.submit(sb.ptr)
+    r = st.next()
+    assert np.array_equal(r[1], want)
+    st.close()
+    freed = hmm.hipstr_hmm_trim()
+    assert freed >= 0
+    assert hmm.hipstr_hmm_align(dev, None) == 0
+    p = np.zeros(sb.n_out); s = np.zeros(sb.n_reads, np.int32)
+    assert hmm.hipstr_hmm_fetch(dev, p.ctypes.data_as(capi._f64p), s.ctypes.data_as(capi._i32p)) == 0
+    assert np.array_equal(p, want) and np.array_equal(s, wseeds)
+    hmm.hipstr_hmm_free(dev)
+    freed2 = hmm.hipstr_hmm_trim()                           # now everything this test took can go
+    assert freed + freed2 > 0
+    got, gs = capi.run_align(hmm, "hipstr_hmm_", sb.ptr)     # and comes back on demand
+    assert np.array_equal(got, want) and np.array_equal(gs, wseeds)
+
+
 def test_multi_device_blocks_in_global_order(hmm):
     """hipstr_multi_*: contiguous blocks of loci dealt to several device streams, results in global submission order.  On a one-GPU
     box both streams sit on device 0 — the dispatch and ordering logic is the same."""
