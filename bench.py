@@ -619,26 +619,6 @@ def main():
             out["value_end_to_end"] = e2e["alignments_per_s"]
             out["value_resident"] = value
             e2e["host_threads"] = int(os.environ.get("HIPSTR_HOST_THREADS", "0")) or usable_cores()
-            # the same measurement with the host share one rank has when 8 ranks share this node's usable cores: a child process pinned
-            # to usable_cores/8 CPUs (all of its threads) with as many library host threads
-            if not args.host_threads and not os.environ.get("HIPSTR_BENCH_NO_SHARE"):
-                import subprocess
-                hmm.hipstr_hmm_trim()          # what this process' stream cached and no longer uses: the child needs the device memory
-                n8 = max(1, usable_cores() // 8)
-                cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", str(args.steps), "--e2e-only", "--host-threads", str(n8)]
-                if args.loci:
-                    cmd += ["--loci", str(args.loci)]
-                try:
-                    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=300)
-                    if r.returncode != 0 or not r.stdout.strip():
-                        raise RuntimeError("child rc %d: %s" % (r.returncode, r.stderr.strip().splitlines()[-1] if r.stderr.strip() else ""))
-                    sh = json.loads(r.stdout.strip().splitlines()[-1])
-                    sh["fraction_of_resident_rate"] = sh["alignments_per_s"] / value
-                    sh["note"] = "child process of this run pinned to %d of the node's %d usable CPUs (= usable/8: one rank's share at 8 GPUs), HIPSTR_HOST_THREADS=%d" % (n8, usable_cores(), n8)
-                    out["end_to_end_host_share_8gpu"] = sh
-                    out["value_end_to_end_host_share_8gpu"] = sh["alignments_per_s"]
-                except Exception as ex:            # the line must not depend on it
-                    out["end_to_end_host_share_8gpu"] = {"error": repr(ex)[:200]}
             out["pipeline"] = pipeline_stages(capi, hmm, sb, loci, P)
         if per_rank is not None:
             out["per_rank_alignments_per_s"] = per_rank
@@ -661,6 +641,27 @@ def main():
         if em_stats:
             out["c3_step"] = {"stutter_em_s_per_step": em_stats.get("em_s", 0.0) / args.steps, "genotype_calls_s_per_step": em_stats.get("calls_s", 0.0) / args.steps,
                               "em_trained_loci": em_stats.get("trained"), "em_iterations": em_stats.get("iterations"), "samples_per_locus": 100}
+        if args.gpus == 1 and not args.no_pipeline and "end_to_end" in out:
+            # the same measurement with the host share one rank has when 8 ranks share this node's usable cores: a child process pinned
+            # to usable_cores/8 CPUs (all of its threads) with as many library host threads
+            if not args.host_threads and not os.environ.get("HIPSTR_BENCH_NO_SHARE"):
+                import subprocess
+                hmm.hipstr_hmm_trim()          # what this process' streams and calls cached and no longer use: the child needs the device memory (last measurement of the line: nothing after it pays for cold caches)
+                n8 = max(1, usable_cores() // 8)
+                cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", str(args.steps), "--e2e-only", "--host-threads", str(n8)]
+                if args.loci:
+                    cmd += ["--loci", str(args.loci)]
+                try:
+                    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=300)
+                    if r.returncode != 0 or not r.stdout.strip():
+                        raise RuntimeError("child rc %d: %s" % (r.returncode, r.stderr.strip().splitlines()[-1] if r.stderr.strip() else ""))
+                    sh = json.loads(r.stdout.strip().splitlines()[-1])
+                    sh["fraction_of_resident_rate"] = sh["alignments_per_s"] / value
+                    sh["note"] = "child process of this run pinned to %d of the node's %d usable CPUs (= usable/8: one rank's share at 8 GPUs), HIPSTR_HOST_THREADS=%d" % (n8, usable_cores(), n8)
+                    out["end_to_end_host_share_8gpu"] = sh
+                    out["value_end_to_end_host_share_8gpu"] = sh["alignments_per_s"]
+                except Exception as ex:            # the line must not depend on it
+                    out["end_to_end_host_share_8gpu"] = {"error": repr(ex)[:200]}
         print(json.dumps(out), flush=True)
     hmm.hipstr_post_free(pd)
     hmm.hipstr_hmm_free(dev)
