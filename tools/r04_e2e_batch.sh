@@ -1,5 +1,5 @@
 #!/bin/bash
-# end-to-end rate by batch size / slots of the pipeline: tools/s5_e2e2.sh <out>
+# end-to-end rate by batch size / slots of the pipeline: tools/r04_e2e_batch.sh <out>
 out=gpurun_out/$1; mkdir -p $out
 for w in ns; do for cfg in "2 8" "4 8" "4 4" "6 4" "8 3" "2 8" "4 6"; do
   set -- $cfg
