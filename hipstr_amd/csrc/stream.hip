@@ -231,10 +231,10 @@ struct InFlight {
 struct hipstr_stream {
   hipstr::Ctx* ctx = NULL;
   hipStream_t copy_stream = NULL, d2h_stream = NULL;     // tables to the device / results back: neither waits for the other
-  // The kernels of consecutive batches go to alternating streams: a batch is ~2 Mi pairs, a pass of the north-star shape eight of them, and
-  // on ONE stream every kernel of every batch drains before the next one starts — the tails of 60 kernels per pass instead of 8 cost 8 % of
-  // the resident rate (end of round 4: 129.3 ms per pass against 118.8).  On two streams the next batch's kernels fill the tails.
-  // HIPSTR_STREAM_COMPUTE_STREAMS=1: the context's stream for every batch, as before (comparison runs).
+  // HIPSTR_STREAM_COMPUTE_STREAMS=2..4: the kernels of consecutive batches on alternating streams instead of the context's one.  Tried at the
+  // end of round 4 against the 8 % a stream of 2 Mi batches loses to the resident rate (the tails and gaps of 60 kernels per pass instead
+  // of 8): no effect, 129.5 ms per pass with 1, 2 and 3 streams — a persistent trailing-flank kernel holds every SIMD's registers until
+  // it ends.  What helped is fewer, larger batches (below).  Default 1; kept switchable for other shapes.
   hipStream_t compute[4] = {NULL, NULL, NULL, NULL};
   int n_compute = 0;
   std::atomic<unsigned> launch_seq{0};
@@ -387,7 +387,7 @@ hipstr_stream_t* hipstr_stream_open(const hipstr_stream_opts_t* opts){
   if (hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s->d2h_stream, hipStreamNonBlocking) != hipSuccess){
     hipstr::api_fail("hipStreamCreate failed"); delete s; return NULL; }
   {
-    int nc = 2;
+    int nc = 1;
     if (const char* e = getenv("HIPSTR_STREAM_COMPUTE_STREAMS")) nc = std::max(1, std::min(4, atoi(e)));
     if (nc > 1) for (int i = 0; i < nc; i++){
       if (hipStreamCreateWithFlags(&s->compute[i], hipStreamNonBlocking) != hipSuccess){
