@@ -598,7 +598,7 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   }
   if (up_prof){ const double n_ = hipstr::ApiTimer::now(); hipstr::api_profile_add(hipstr::PB_UP_MEMCPY, n_ - up_t); up_t = n_; }
   // what the device builds for itself (expand_kernels.hip), behind the copies on the same stream and in front of everything else
-  if (P.gen_f64 > 0) hipLaunchKernelGGL(hs_expand_stropts_kernel, dim3((unsigned)((P.stropts.size() + 255)/256)), dim3(256), 0, copy_stream, (const hs_dev_t*)dev->d_args);
+  if (P.gen_f64 > 0) hipLaunchKernelGGL(hs_expand_stropts_kernel, dim3((unsigned)((P.stropts.size() + 3)/4)), dim3(256), 0, copy_stream, (const hs_dev_t*)dev->d_args);
   if (!P.rec_descs.empty()) hipLaunchKernelGGL(hs_expand_recs_kernel, dim3((unsigned)((P.rec_descs.size()*HS_GRP_REC_DWORDS + 255)/256)), dim3(256), 0, copy_stream, (const hs_dev_t*)dev->d_args);
   HS_HIP_DEV(hipGetLastError());
   HS_HIP_DEV(hipMemsetAsync(h.aln_probs, 0, out_bytes, copy_stream));

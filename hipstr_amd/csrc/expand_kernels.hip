@@ -49,39 +49,51 @@ __device__ void table_entry(const hs_dev_t& d, int lim, int U0, int tail, double
 
 }  // namespace
 
-// One thread per STR option: the 20 constants and the table of every option the host marked `gen` (layout.h hs_stropt_t)
+// One WAVEFRONT per STR option the host marked `gen` (layout.h hs_stropt_t): lanes 0-19 write the 20 constants, every lane one entry of the
+// table (at most HS_TAB_CAP = 48 entries: list and bound class from the lists' entry counts), the smallest Bnd by a wave-wide minimum
+// (exact in any order).  One thread per option did the ~20 entries one after the other: 20 us for the 64 options of a one-locus call,
+// a sixteenth of its device time; the entries are independent.
 extern "C" __global__ void __launch_bounds__(256) hs_expand_stropts_kernel(const hs_dev_t* dp){
   const hs_dev_t& d = *dp;
-  const int s = blockIdx.x*256 + threadIdx.x;
+  const int s = blockIdx.x*4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (s >= d.n_stropts) return;
   hs_stropt_t* so = (hs_stropt_t*)d.stropts + s;
-  if (!so->gen) return;
+  if (!so->gen) return;                                   // (the same for every lane of the wavefront; nobody has cleared it yet: see the end)
   const int B = so->B, period = so->period;
+  const int f64_off = so->f64_off, tab_off = so->tab_off, tab_len = so->tab_len;
   double* pool = (double*)d.f64pool + d.f64_gen_base;
-  double* c = pool + so->f64_off;
+  double* c = pool + f64_off;
   const double* pmf = d.pmf13 + so->pmf_off;
-  for (int t = 0; t < HS_NART; t++) c[t] = (B + (t - HS_MAXREP)*period < 0) ? -10e6 /* LARGE_NEGATIVE, RepeatStutterInfo.h:12 */ : pmf[t];
-  c[HS_NART] = -d.int_log[B+1];                                              // StutterAlignerClass.cpp:64
-  for (int q = 0; q < HS_MAXREP; q++){
-    const int D = -(q+1)*period;
+  if (lane < HS_NART) c[lane] = (B + (lane - HS_MAXREP)*period < 0) ? -10e6 /* LARGE_NEGATIVE, RepeatStutterInfo.h:12 */ : pmf[lane];
+  else if (lane == HS_NART) c[HS_NART] = -d.int_log[B+1];                    // StutterAlignerClass.cpp:64
+  else if (lane <= HS_NART + HS_MAXREP){
+    const int q = lane - HS_NART - 1, D = -(q+1)*period;
     c[HS_NART + 1 + q] = B+D >= 0 ? -d.int_log[B+D+1] : 0.0;                 // StutterAlignerClass.cpp:112
   }
-  if (so->tab_len > 0){
-    double* ent = pool + so->tab_off;
-    double bmin = 1e300;
+  if (tab_len > 0){
+    double* ent0 = pool + tab_off;
+    double bnd = 1e300;
+    // entry `lane` of the table: the lists' entries back to back in list order (the order the host wrote them in)
+    int base = 0;
     for (int k = 0; k <= HS_MAXREP; k++){
       const int tail = (k == HS_MAXREP) ? B : B - (k+1)*period;
       if (tail < 0 || so->shape[k] < 0) continue;
       const int U0 = so->shape[k], n = 2 + (tail - U0 > 0 ? tail - U0 : 0);
-      for (int e = 0; e < n; e++, ent += 3){
+      for (int e = lane - base; e >= 0 && e < n; e += 64){                    // (n <= 48: at most one entry per lane and list)
+        double ent[3];
         table_entry(d, (e == 0) ? 0 : (e == 1 ? 1 : U0 + e - 1), U0, tail, ent);
-        if (ent[2] < bmin) bmin = ent[2];
+        double* dst = ent0 + 3*(base + e);
+        dst[0] = ent[0]; dst[1] = ent[1]; dst[2] = ent[2];
+        if (ent[2] < bnd) bnd = ent[2];
       }
+      base += n;
     }
-    *ent = bmin;
+    for (int o = 32; o > 0; o >>= 1){ const double other = __shfl_xor(bnd, o); if (other < bnd) bnd = other; }
+    if (lane == 0) ent0[3*base] = bnd;
   }
-  so->f64_off += (int32_t)d.f64_gen_base; so->tab_off += (int32_t)d.f64_gen_base;
-  so->gen = 0;
+  // every lane has read the option's fields by now (the loop above is the last reader); one lane makes the offsets pool-wide and clears the flag
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0){ so->f64_off = f64_off + (int32_t)d.f64_gen_base; so->tab_off = tab_off + (int32_t)d.f64_gen_base; so->gen = 0; }
 }
 
 // One thread per dword of grp_recs[]: the record of layout.h HS_GRP_REC_DWORDS from its descriptor, the option and the option's constants
