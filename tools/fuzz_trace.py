@@ -13,8 +13,11 @@ assert hmm.hipstr_hmm_init(0) == 0
 bad = 0; total = 0
 for c in range(n_cfg):
     os.environ["HIPSTR_SYNTH_IMPERFECT"] = str(float(rng.choice([0.0, 0.05, 0.5, 1.0])))
+    os.environ["HIPSTR_SYNTH_INHERIT"] = str(int(rng.choice([0, 0, 1, 2, 3])))        # interruptions inherited from the reference allele
     kw = dict(n_loci=1, reads_per_locus=int(rng.integers(1, 30)), n_str_alleles=int(rng.integers(1, 25)), read_len=int(rng.integers(24, 251)),
               flank_len=int(rng.integers(8, 161)), str_bp=int(rng.integers(4, 121)), n_flank_opts=int(rng.integers(1, 4)), seed=int(rng.integers(1, 1 << 30)))
+    if rng.random() < 0.15:          # long reads: sides of 385-1024 columns (the fill kernel's 8 / 12 / 16 columns per lane on dynamic LDS)
+        kw.update(read_len=int(rng.integers(500, 1025)), flank_len=int(rng.integers(300, 620)), reads_per_locus=int(rng.integers(1, 8)), n_str_alleles=int(rng.integers(1, 5)))
     sb = capi.SynthBatch(**kw)
     _, seeds = capi.run_align(ora, "oracle_", sb.ptr)
     A = sb.n_out // sb.n_reads
@@ -32,7 +35,7 @@ for c in range(n_cfg):
     if got != want:
         bad += 1
         q = next(i for i, (g, w) in enumerate(zip(got, want)) if g != w)
-        print("MISMATCH", kw, os.environ["HIPSTR_SYNTH_IMPERFECT"], "request", q, {f: (got[q][f], want[q][f]) for f in got[q] if got[q][f] != want[q][f]})
+        print("MISMATCH", kw, os.environ["HIPSTR_SYNTH_IMPERFECT"], os.environ["HIPSTR_SYNTH_INHERIT"], "request", q, {f: (got[q][f], want[q][f]) for f in got[q] if got[q][f] != want[q][f]})
     if capi.hap_aln_info(hmm, "hipstr_", sb.ptr) != h2r:
         bad += 1; print("MISMATCH hap_aln_info", kw)
 print("configs", n_cfg, "tracebacks", total, "mismatching configs", bad)
