@@ -328,9 +328,21 @@ def main():
         os.sched_setaffinity(0, cpus)
         os.environ["HIPSTR_HOST_THREADS"] = str(args.host_threads)
 
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    rank_cpus = None
+    if world > 1 and not args.host_threads and not os.environ.get("HIPSTR_BENCH_NO_PIN"):
+        # one process per GPU: every rank keeps to its own slice of the node's usable CPUs — all of its threads (they inherit the mask: this
+        # runs before torch, the library's pool and the stream's workers exist) — so that the ranks' host work does not migrate over each other
+        lw = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        allowed = sorted(os.sched_getaffinity(0))
+        per = max(1, min(usable_cores(), len(allowed)) // max(1, lw))
+        mine = allowed[(local % lw) * per:(local % lw) * per + per] or allowed[:per]
+        try:
+            os.sched_setaffinity(0, mine); rank_cpus = mine
+        except OSError:
+            rank_cpus = None
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
@@ -392,11 +404,21 @@ def main():
                  "per_read_generic_kernel": kinds[0] / n_kinds,
                  "synth_overrides": {k: v for k, v in os.environ.items() if k.startswith("HIPSTR_SYNTH")}}
     if args.e2e_only:
+        # a short resident measurement first (one warm pass, three timed): the child's end-to-end rate is quoted against the resident rate of
+        # the same process on the same box
+        hmm.hipstr_hmm_align(dev, None); torch.cuda.synchronize()
+        t_r = time.perf_counter()
+        for _ in range(3):
+            hmm.hipstr_hmm_align(dev, None)
+        torch.cuda.synchronize()
+        resident = 3.0 * n_aln.value / (time.perf_counter() - t_r)
         hmm.hipstr_hmm_free(dev)
         e = end_to_end(capi, hmm, sb, loci, max(2, min(args.steps, 5), min(48, int(4e7 // max(1.0, float(n_aln.value))))), local, latency=False)
         e["alignments_per_s"] = n_aln.value * e["passes"] / e["seconds"]
         e["host_threads"] = args.host_threads or int(os.environ.get("HIPSTR_HOST_THREADS", "0")) or None
         e["cpus_allowed"] = len(os.sched_getaffinity(0))
+        e["resident_alignments_per_s"] = resident
+        e["fraction_of_resident_rate_same_process"] = e["alignments_per_s"] / resident
         print(json.dumps(e), flush=True)
         return
     if args.workload == "c4":
@@ -485,7 +507,7 @@ def main():
     if not os.environ.get("HIPSTR_BENCH_NOCHECK"):       # kernel ablation builds (timing only, results invalid) set this
         assert np.all(np.isfinite(probs)) and np.all(probs <= 1e-10), "forward scores must be finite log-likelihoods <= 0"
 
-    per_rank = None; e2e_multi = None
+    per_rank = None; e2e_multi = None; rank_info = None
     if world > 1:
         dev_t = "cpu" if share else "cuda"
         # every rank's own resident rate, and the end-to-end rate (host arrays in -> results out through the stream) of all ranks at once
@@ -493,6 +515,10 @@ def main():
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [float(x.item()) for x in allr]
+        info = [None] * world
+        dist.all_gather_object(info, {"rank": rank, "first_locus": int(first), "loci": int(loci), "alignments_per_step": int(n_aln.value),
+                                      "host_threads": int(os.environ.get("HIPSTR_HOST_THREADS", host_threads)), "cpus": rank_cpus, "device": int(local)})
+        rank_info = info
         if not args.no_pipeline:
             dist.barrier()
             e = end_to_end(capi, hmm, sb, loci, max(2, min(args.steps, 3)), local, latency=False)
@@ -622,6 +648,7 @@ def main():
             out["pipeline"] = pipeline_stages(capi, hmm, sb, loci, P)
         if per_rank is not None:
             out["per_rank_alignments_per_s"] = per_rank
+            out["ranks"] = rank_info
             out["host_threads_per_rank"] = int(os.environ.get("HIPSTR_HOST_THREADS", host_threads))
         if e2e_multi is not None:
             out["end_to_end"] = e2e_multi
@@ -662,9 +689,28 @@ def main():
                     out["value_end_to_end_host_share_8gpu"] = sh["alignments_per_s"]
                 except Exception as ex:            # the line must not depend on it
                     out["end_to_end_host_share_8gpu"] = {"error": repr(ex)[:200]}
+                # ... and the shape that is actually host-sensitive: thousands of small loci per batch (--workload p30: 4000 loci x 40 reads x 8
+                # alleles, 35-bp flanks), the same pinned child; its resident rate is measured in the same process
+                if args.workload == "ns" and not args.loci and not os.environ.get("HIPSTR_BENCH_NO_P30_SHARE"):
+                    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "p30", "--steps", "5", "--e2e-only", "--host-threads", str(n8)]
+                    try:
+                        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=300)
+                        if r.returncode != 0 or not r.stdout.strip():
+                            raise RuntimeError("child rc %d: %s" % (r.returncode, r.stderr.strip().splitlines()[-1] if r.stderr.strip() else ""))
+                        sh = json.loads(r.stdout.strip().splitlines()[-1])
+                        sh["fraction_of_resident_rate"] = sh["fraction_of_resident_rate_same_process"]
+                        sh["note"] = "workload p30 (%s) in a child process pinned to %d of the node's %d usable CPUs, HIPSTR_HOST_THREADS=%d; resident rate of the same child" % (WORKLOADS["p30"][6], n8, usable_cores(), n8)
+                        out["end_to_end_host_share_8gpu_p30"] = sh
+                        out["value_end_to_end_host_share_8gpu_p30"] = sh["alignments_per_s"]
+                    except Exception as ex:
+                        out["end_to_end_host_share_8gpu_p30"] = {"error": repr(ex)[:200]}
         print(json.dumps(out), flush=True)
     hmm.hipstr_post_free(pd)
     hmm.hipstr_hmm_free(dev)
+    released = int(hmm.hipstr_hmm_trim())           # the caches' idle chunks back to the driver: a rank leaves the device as it found it
+    if os.environ.get("HIPSTR_BENCH_VERBOSE"):
+        st8 = (C.c_int64 * 8)(); hmm.hipstr_debug_cache_stats(st8)
+        print("rank %d: released %d bytes, still held: device %d, pinned %d" % (rank, released, st8[0], st8[4]), file=sys.stderr, flush=True)
     if world > 1:
         dist.destroy_process_group()
 

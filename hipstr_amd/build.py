@@ -29,12 +29,33 @@ def _run(cmd, cwd=None):
 
 
 def build_hmm(force=False):
+    """One object per source (in parallel, under build/hmm_obj: git-ignored, rebuilt where a source or a header is newer), then the link —
+    the same flags and result as one hipcc call over all sources, in the time of the longest file instead of their sum."""
     out = os.path.join(CSRC, "libhipstr_hmm.so")
-    deps = [os.path.join(CSRC, s) for s in HIP_SOURCES + HIP_HEADERS]
-    if force or _stale(out, deps):
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        extra = ["-D%s=%s" % (m, os.environ[e]) for m, e in (("HS_TRAIL_ROWS", "HIPSTR_TRAIL_ROWS"), ("HS_STR_WAVES", "HIPSTR_STR_WAVES")) if os.environ.get(e)]
-        _run([hipcc] + HIPCC_FLAGS + extra + ["-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", out] + [os.path.join(CSRC, s) for s in HIP_SOURCES])
+    hdrs = [os.path.join(CSRC, s) for s in HIP_HEADERS]
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = ["-D%s=%s" % (m, os.environ[e]) for m, e in (("HS_TRAIL_ROWS", "HIPSTR_TRAIL_ROWS"), ("HS_STR_WAVES", "HIPSTR_STR_WAVES")) if os.environ.get(e)]
+    objdir = os.path.join(ROOT, "build", "hmm_obj" + ("_" + "_".join(extra).replace("-D", "").replace("=", "") if extra else ""))
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    jobs, objs = [], []
+    for s in HIP_SOURCES:
+        o = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
+        objs.append(o)
+        if force or _stale(o, [os.path.join(CSRC, s)] + hdrs):
+            cmd = [hipcc] + cflags + extra + ["-c", "-o", o + ".tmp", os.path.join(CSRC, s)]
+            print("+", " ".join(cmd), flush=True)
+            jobs.append((subprocess.Popen(cmd), o, cmd))
+    failed = []
+    for pr, o, cmd in jobs:
+        if pr.wait() != 0:
+            failed.append(" ".join(cmd))
+        else:
+            os.replace(o + ".tmp", o)
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
+    if force or jobs or _stale(out, objs + [os.path.join(CSRC, "exports.map")]):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", out] + objs)
     return out
 
 

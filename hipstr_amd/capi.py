@@ -534,6 +534,8 @@ def load_hmm():
     _sig(lib.hipstr_debug_simple_table, C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)])
     _sig(lib.hipstr_last_error, C.c_char_p, [])
     _sig(lib.hipstr_debug_driver_allocs, C.c_int64, [])
+    _sig(lib.hipstr_locus_costs, C.c_int, [_BP, _f64p])
+    _sig(lib.hipstr_debug_cache_stats, C.c_int, [C.POINTER(C.c_int64)])
     _sig(lib.hipstr_debug_allele_kinds, C.c_int, [C.c_void_p, C.POINTER(C.c_int64)])
     _sig(lib.hipstr_debug_stream_create, C.c_void_p, [])
     _sig(lib.hipstr_debug_stream_destroy, None, [C.c_void_p])

@@ -65,7 +65,9 @@ std::atomic<int64_t> g_driver_allocs(0);
 // and never go back to it one by one: a hipMalloc / hipHostMalloc next to running kernels stalls for 0.1-0.3 s (seen in the middle of a
 // stream: profiles/r04_notes.md), a hipFree synchronises the device.  A freed block goes to a free list by size; a request takes the
 // smallest free block that holds it if that is at most twice as large, else a fresh piece of the current chunk.  No coalescing: the
-// requests of a stream repeat, so the free list saturates after a few batches and the driver is not called again.
+// requests of a stream repeat, so the free list saturates after a few batches and the driver is not called again.  `cap` bounds the IDLE
+// bytes (free blocks): a put() that leaves more gives the chunks nobody uses back to the driver; when the driver refuses a new chunk,
+// get() falls back to any free block that is large enough, then trims idle chunks and tries once more.
 struct BlockCache {
   bool pinned = false;
   std::mutex m;
@@ -86,15 +88,29 @@ struct BlockCache {
     void* p = NULL;
     g_driver_allocs++;
     if (getenv("HIPSTR_TIMING")) fprintf(stderr, "block cache: %s chunk of %zu bytes from the driver\n", pinned ? "pinned" : "device", bytes);
+    // tests: a driver that runs out at HIPSTR_DEBUG_DRIVER_LIMIT_MIB of device chunks (the recovery paths of get() without filling 288 GB)
+    static const size_t dbg_limit = getenv("HIPSTR_DEBUG_DRIVER_LIMIT_MIB") ? (size_t)atol(getenv("HIPSTR_DEBUG_DRIVER_LIMIT_MIB")) << 20 : 0;
+    if (dbg_limit && !pinned){
+      size_t held = 0; for (const Chunk& c : chunks) held += c.size;
+      if (held + bytes > dbg_limit){ g_err = "hipMalloc: out of memory (HIPSTR_DEBUG_DRIVER_LIMIT_MIB)"; return NULL; }
+    }
     const hipError_t e = pinned ? hipHostMalloc(&p, bytes, hipHostMallocDefault) : hipMalloc(&p, bytes);
     if (e != hipSuccess){ g_err = std::string(pinned ? "hipHostMalloc: " : "hipMalloc: ") + hipGetErrorString(e); return NULL; }
     return p;
   }
+  // (lock held) a free block of at least `want` bytes, the smallest one; `limit`: largest size accepted (0 = any)
+  void* take_free(size_t want, size_t limit){
+    auto it = free_.lower_bound(want);
+    if (it == free_.end() || (limit && it->first > limit)) return NULL;
+    void* p = it->second; cached -= it->first; free_.erase(it); in_use++;
+    if (Chunk* c = chunk_of(p)) c->live++;
+    return p;
+  }
   void* get(size_t bytes){
     size_t want = round_up(bytes);
-    std::lock_guard<std::mutex> g(m);
-    auto it = free_.lower_bound(want);
-    if (it != free_.end() && it->first <= 2*want){ void* p = it->second; cached -= it->first; free_.erase(it); in_use++; if (Chunk* c = chunk_of(p)) c->live++; return p; }
+    std::unique_lock<std::mutex> g(m);
+    if (void* p = take_free(want, 2*want)) return p;
+    const size_t exact = want;
     if (want > ((size_t)16 << 20)) want = round_up(want + want/8);        // a new large block comes with headroom for its successors
     if (chunks.empty() || chunks.back().used + want > chunks.back().size){
       const size_t max_chunk = pinned ? (size_t)2 << 30 : (size_t)16 << 30;
@@ -102,7 +118,18 @@ struct BlockCache {
       next_chunk = std::min(max_chunk, next_chunk*2);
       char* base = (char*)driver_alloc(sz);
       if (!base && sz > want) base = (char*)driver_alloc(sz = want);       // the device is nearly full: just what is needed
-      if (!base) return NULL;
+      if (!base){
+        // the driver has no more: a larger free block, whatever its size, before giving up ...
+        if (void* p = take_free(exact, 0)){ g_err.clear(); return p; }
+        // ... then the chunks without a block in use go back to the driver and the request is tried once more
+        g.unlock();
+        const size_t freed = trim();
+        g.lock();
+        if (void* p = take_free(exact, 0)){ g_err.clear(); return p; }    // (another thread may have returned one meanwhile)
+        if (freed){ g_err.clear(); base = (char*)driver_alloc(sz = exact); }
+        if (!base) return NULL;                                            // (the driver's message is in g_err)
+        want = exact;
+      }
       chunks.push_back(Chunk{base, sz, 0, 0});
     }
     Chunk& c = chunks.back();
@@ -115,12 +142,18 @@ struct BlockCache {
   Chunk* chunk_of(const void* p){ for (Chunk& c : chunks) if ((const char*)p >= c.base && (const char*)p < c.base + c.size) return &c; return NULL; }
   void put(void* p){
     if (!p) return;
-    std::lock_guard<std::mutex> g(m);
+    std::unique_lock<std::mutex> g(m);
     auto it = size_.find(p);
     if (it == size_.end()) return;
-    free_.insert(std::make_pair(it->second, p)); cached += it->second;
-    if (in_use > 0) in_use--;
-    if (Chunk* c = chunk_of(p)) if (c->live > 0) c->live--;
+    bool over;
+    {
+      free_.insert(std::make_pair(it->second, p)); cached += it->second;
+      if (in_use > 0) in_use--;
+      if (Chunk* c = chunk_of(p)) if (c->live > 0) c->live--;
+      over = cap && cached > cap;
+    }
+    // more idle bytes than the cap allows (HIPSTR_DEV_CACHE_GIB / HIPSTR_PIN_CACHE_GIB): the chunks nobody uses go back to the driver
+    if (over){ g.unlock(); trim(); }
   }
   // chunks none of whose blocks is out go back to the driver (hipstr_hmm_trim: after a stream of large batches a process may sit on tens
   // of gigabytes it no longer needs — another process on the device, a child of this one, then fails its kernel launches with "out of
@@ -207,7 +240,8 @@ Ctx* ctx_for_device(int device_ordinal){
   c->pin_cache.pinned = true;
   // free blocks the caches may hold: every batch in flight returns its workspaces at once when a stream drains (eight 2 Mi-pair batches of
   // 500-read loci: 60 GB), and a block given back to the driver is a hipFree (which synchronises the device) plus a hipMalloc later —
-  // so: 70 % of the device's memory (288 GB on an MI355X), 24 GiB of pinned host memory
+  // so: 70 % of the device's memory (288 GB on an MI355X), 24 GiB of pinned host memory as the most IDLE bytes a cache keeps (BlockCache::put
+  // trims the chunks nobody uses beyond that; BlockCache::get reuses any large-enough free block and trims when the driver refuses)
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)96 << 30;
   c->dev_cache.cap = getenv("HIPSTR_DEV_CACHE_GIB") ? (size_t)(atof(getenv("HIPSTR_DEV_CACHE_GIB"))*1073741824.0) : (size_t)(0.7*(double)total_b);
@@ -880,6 +914,17 @@ double ApiTimer::now(){ return std::chrono::duration<double>(std::chrono::steady
 }
 }
 int64_t hipstr_debug_driver_allocs(void){ return g_driver_allocs.load(); }
+int hipstr_debug_cache_stats(int64_t out[8]){
+  Ctx* c = current_ctx();
+  if (!c) return 1;
+  BlockCache* bc[2] = { &c->dev_cache, &c->pin_cache };
+  for (int k = 0; k < 2; k++){
+    std::lock_guard<std::mutex> g(bc[k]->m);
+    size_t held = 0; for (const BlockCache::Chunk& ch : bc[k]->chunks) held += ch.size;
+    out[4*k] = (int64_t)held; out[4*k + 1] = (int64_t)bc[k]->cached; out[4*k + 2] = (int64_t)bc[k]->in_use; out[4*k + 3] = (int64_t)bc[k]->cap;
+  }
+  return 0;
+}
 
 // Diagnostics: how the (realigned allele, side) pairs of a batch split over the STR kernels — counts[1]: every visiting list tabulated
 // (periodic blocks: hs_str_group_kernel_p), counts[2]: simple or piecewise-simple lists (one or two interruptions: hs_str_group_kernel_pw),

@@ -2730,7 +2730,7 @@ __device__ __forceinline__ void combine_quad(const hs_dev_t& d, const CmbRegs<NR
   for (int q = 0; q < 4; q++){
 #pragma unroll
     for (int k = 0; k < NR; k++){
-      const double v = *(const double*)(g.P[k] + (uint64_t)((uint32_t)ord[q]*(uint32_t)g.S[k]));
+      const double v = *(const double*)(g.P[k] + (uint64_t)(uint32_t)ord[q]*(uint64_t)(uint32_t)g.S[k]);     // 64-bit product: 2^24 haplotypes x a row of KBs passes 4 GiB
       t[q][k] = (g.X[k] + v) + g.Y[k];
     }
     m[q] = t[q][0];

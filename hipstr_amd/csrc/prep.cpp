@@ -792,8 +792,36 @@ int check_batch(const hipstr_batch_t* b, std::string& err){
   return 0;
 }
 
+double locus_cost(const hipstr_batch_t* b, int l, int opt0){
+  const int n0 = std::max(0, b->blk_nopts[3*l]), n1 = std::max(0, b->blk_nopts[3*l+1]), n2 = std::max(0, b->blk_nopts[3*l+2]);
+  const int p = std::max(1, b->period[l]);
+  auto len_of = [&](int c){ return (double)(b->opt_off[c+1] - b->opt_off[c]); };
+  double f0 = 0, f2 = 0, str = 0;
+  for (int o = 0; o < n0; o++) f0 += len_of(opt0 + o);
+  for (int o = 0; o < n2; o++) f2 += len_of(opt0 + n0 + n1 + o);
+  for (int o = 0; o < n1; o++){
+    const int c = opt0 + n0 + o;
+    const char* sq = b->seq + b->opt_off[c]; const int B = b->opt_off[c+1] - b->opt_off[c];
+    int brk = 0;
+    for (int i = p; i < B; i++) brk += (sq[i] != sq[i-p]) ? 1 : 0;        // a substituted base breaks the period twice
+    str += 1.0 + 2.4*(0.5*brk);
+  }
+  const double flank = (n0 ? f0/n0 : 0.0) + (n2 ? f2/n2 : 0.0), str_mean = n1 ? str/n1 : 1.0;
+  const int r0 = b->read_off[l], r1 = b->read_off[l+1];
+  int64_t P = 0, bases = 0;
+  for (int r = r0; r < r1; r++){
+    if (b->realign_read && !b->realign_read[r]) continue;
+    P++; bases += b->base_off[r+1] - b->base_off[r];
+  }
+  int64_t A = 0;
+  const int h0 = b->hap_off[l], h1 = b->hap_off[l+1];
+  if (b->realign_hap){ for (int h = h0; h < h1; h++) A += b->realign_hap[h] ? 1 : 0; } else A = h1 - h0;
+  if (P == 0 || A == 0) return 1e-3;
+  return (double)A * ((double)bases/150.0) * (1.4*flank/60.0 + str_mean);
+}
+
 // One locus of check_batch; *opt_cursor = index of the locus' first block option in opt_off, advanced past the locus.
-int check_locus(const hipstr_batch_t* b, int l, int* opt_cursor_io, std::string& err, int32_t* seeds_out){
+int check_locus(const hipstr_batch_t* b, int l, int* opt_cursor_io, std::string& err, int32_t* seeds_out, int* dims_out){
   int opt_cursor = *opt_cursor_io;
   {
     const int period = b->period[l];
@@ -827,7 +855,10 @@ int check_locus(const hipstr_batch_t* b, int l, int* opt_cursor_io, std::string&
       if (s >= 0 && (s > HS_MAX_SIDE_FWD || len-s-1 > HS_MAX_SIDE_FWD)){ err = "read side longer than 1024 bases is not supported"; return 1; }
     }
     // the per-read STR kernels keep a read's tables and the allele's block in LDS: a locus whose longest read and longest allele do not fit
-    // is turned away here, alone — not at upload time, where it would take the batch it shares down with it
+    // is turned away here, alone — not at upload time, where it would take the batch it shares down with it.  (The LDS is sized by the
+    // BATCH's longest read and longest allele: the stream and hipstr_hmm_process_reads_each close a batch before a locus that would push
+    // the combined figure over the limit — dims_out.)
+    if (dims_out){ dims_out[0] = longest_read; dims_out[1] = longest_B; }
     if (hs_str_kernel_lds_bytes(longest_read, longest_B) > HS_LDS_LIMIT){ err = "reads and STR alleles this long need more than 160 KiB of LDS per workgroup (about 1.8 kb reads; less with alleles near 2 kb)"; return 1; }
   }
   *opt_cursor_io = opt_cursor;

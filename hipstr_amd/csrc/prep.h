@@ -104,7 +104,14 @@ int check_batch(const hipstr_batch_t* b, std::string& err);
 void prep_profile_print();
 // one locus of it; the cursor into opt_off is advanced.  seeds_out (optional, indexed by the batch's read index): the seed bases the check computed anyway
 // (HIPSTR_SEED_AUTO for reads that are not realigned), so that prepare_batch does not walk the CIGARs a second time
-int check_locus(const hipstr_batch_t* b, int locus, int* opt_cursor_io, std::string& err, int32_t* seeds_out = NULL);
+// Estimate of the device work of locus l (first block option opt0 in opt_off), in units of one north-star (read, allele) pair: what the
+// shards of a region list are balanced by (sum of P A L H) — reads x realigned alleles x (mean read length / 150) x
+// [flank sweeps ~ flank bases / 60 x 1.4  +  STR block ~ 1 + 2.4 interruptions of the repeat per allele] (the measured ratios of a pass:
+// profiles/r04_ns_kernel_stats.txt, profiles/r04_bench_ns_inherit*.json).  Cheap: one scan of the locus' STR options.
+double locus_cost(const hipstr_batch_t* b, int l, int opt0);
+// dims_out (optional): [0] = the longest realigned read, [1] = the longest STR allele of the locus — what the per-read STR kernels' LDS is
+// sized by, batch-wide (layout.h hs_str_kernel_lds_bytes): whoever puts loci into one batch keeps the combined figure within HS_LDS_LIMIT
+int check_locus(const hipstr_batch_t* b, int locus, int* opt_cursor_io, std::string& err, int32_t* seeds_out = NULL, int* dims_out = NULL);
 
 // HapAligner::calc_seed_base (HapAligner.cpp:238-318).  Returns -2 on the inputs the reference dies on.
 int calc_seed_base(const hipstr_batch_t* b, int locus, int read);

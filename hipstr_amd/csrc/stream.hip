@@ -68,6 +68,11 @@ struct OwnedBatch {
   struct Ticket { int64_t id; int32_t l0, l1, r0, r1; int64_t out0, out1; };
   std::vector<Ticket> tickets;
   int64_t n_out = 0, work = 0;          // doubles of output; (reads x haplotypes) submitted
+  // the longest realigned read and the longest STR allele so far: the per-read STR kernels size their LDS by the batch's maxima, so a locus
+  // that would push the combined need over HS_LDS_LIMIT goes into the next batch (each locus fits alone: check_locus)
+  int max_read = 0, max_B = 1;
+  bool fits(int longest_read, int longest_B) const { return hs_str_kernel_lds_bytes(std::max(max_read, longest_read), std::max(max_B, longest_B)) <= HS_LDS_LIMIT; }
+  void note(int longest_read, int longest_B){ max_read = std::max(max_read, longest_read); max_B = std::max(max_B, longest_B); }
   // Copies of bases / qualities still running OUTSIDE the stream's lock (append_run reserves their place under the lock and copies
   // afterwards, so that collectors and workers are not held up for the milliseconds a megabyte copy takes).  A buffer is not moved
   // (grown) and the batch not prepared while this is non-zero.
@@ -79,7 +84,7 @@ struct OwnedBatch {
   void reset(){
     blk_start.clear(); blk_end.clear(); blk_nopts.clear(); period.clear(); opt_off.clear(); hap_off.clear(); read_off.clear(); base_off.clear();
     read_start.clear(); cigar_off.clear(); cigar_len.clear(); seed.clear(); stutter.clear(); realign_hap.clear(); realign_read.clear();
-    seq.clear(); cigar_op.clear(); bases.n = 0; quals.n = 0; tickets.clear(); n_out = 0; work = 0;
+    seq.clear(); cigar_op.clear(); bases.n = 0; quals.n = 0; tickets.clear(); n_out = 0; work = 0; max_read = 0; max_B = 1;
     opt_off.push_back(0); hap_off.push_back(0); read_off.push_back(0); base_off.push_back(0); cigar_off.push_back(0);
   }
   void add_seeds(const int32_t* seeds, int r0, int r1){        // seeds: indexed by the caller's read index, or NULL
@@ -419,17 +424,25 @@ int64_t hipstr_stream_submit(hipstr_stream_t* s, const hipstr_batch_t* loci){
   // a submission that prepare_batch would refuse is turned away here, before it shares a batch with others; the seed bases the check
   // computes go along with the reads
   thread_local std::vector<int32_t> seeds;
+  int sub_read = 0, sub_B = 1;
   {
     std::string why;
     if (loci->n_loci < 0){ hipstr::api_fail("null or negative-size batch"); return -1; }
     seeds.resize(loci->n_loci > 0 ? (size_t)std::max(0, loci->read_off[loci->n_loci]) : 0);
     int cursor = 0;
-    for (int l = 0; l < loci->n_loci; l++)
-      if (hipstr::check_locus(loci, l, &cursor, why, seeds.data())){ hipstr::api_fail(why); return -1; }
+    for (int l = 0; l < loci->n_loci; l++){
+      int dims[2];
+      if (hipstr::check_locus(loci, l, &cursor, why, seeds.data(), dims)){ hipstr::api_fail(why); return -1; }
+      sub_read = std::max(sub_read, dims[0]); sub_B = std::max(sub_B, dims[1]);
+    }
+    // (a submission is one ticket, hence one batch: its loci must fit the per-read STR kernels' LDS together)
+    if (hs_str_kernel_lds_bytes(sub_read, sub_B) > HS_LDS_LIMIT){ hipstr::api_fail("the loci of this submission together need more than 160 KiB of LDS per workgroup (its longest read with its longest STR allele): submit them separately"); return -1; }
   }
   std::lock_guard<std::mutex> g(s->m);
   if (s->closing){ hipstr::api_fail("stream is closing"); return -1; }
+  if (s->pending && !s->pending->tickets.empty() && !s->pending->fits(sub_read, sub_B)) flush_locked(s);
   if (!s->pending) s->pending = new_batch_locked(s);
+  s->pending->note(sub_read, sub_B);
   const int64_t ticket = s->next_ticket;
   const int64_t out_before = s->pending->n_out; const int32_t reads_before = s->pending->read_off.back();
   if (const char* why = s->pending->append(loci, ticket, seeds.data())){ hipstr::api_fail(why); return -1; }
@@ -453,12 +466,13 @@ int hipstr_stream_submit_each(hipstr_stream_t* s, const hipstr_batch_t* loci, in
   std::atomic<int> first_bad(n);
   std::mutex why_m; std::string why; int why_l = n;
   std::vector<int32_t> seeds(n > 0 ? (size_t)std::max(0, loci->read_off[n]) : 0);        // the checks compute every read's seed base: kept for the preparation
+  std::vector<int> dims(2*(size_t)std::max(n, 0), 0);                                      // per locus: longest realigned read, longest STR allele
   const int CH = 128, n_ch = (n + CH - 1)/CH;
   hipstr::parallel_for(n_ch, n >= 4*CH ? hipstr::host_threads() : 1, [&](int c){
     for (int l = c*CH; l < std::min(n, (c+1)*CH); l++){
       if (l > first_bad.load(std::memory_order_relaxed)) return;
       int cur = opt0[l]; std::string w;
-      if (hipstr::check_locus(loci, l, &cur, w, seeds.data())){
+      if (hipstr::check_locus(loci, l, &cur, w, seeds.data(), &dims[2*(size_t)l])){
         std::lock_guard<std::mutex> g(why_m);
         if (l < why_l){ why_l = l; why = w; }
         int fb = first_bad.load(); while (l < fb && !first_bad.compare_exchange_weak(fb, l)){}
@@ -475,10 +489,13 @@ int hipstr_stream_submit_each(hipstr_stream_t* s, const hipstr_batch_t* loci, in
     {
       std::lock_guard<std::mutex> g(s->m);
       if (s->closing) return hipstr::api_fail("stream is closing");
+      // (a locus that does not fit the pending batch's LDS figure closes it: every locus fits alone)
+      if (s->pending && !s->pending->tickets.empty() && !s->pending->fits(dims[2*(size_t)l0], dims[2*(size_t)l0 + 1])) flush_locked(s);
       if (!s->pending) s->pending = new_batch_locked(s);
       int64_t w = s->pending->work;
       const size_t nl0 = s->pending->period.size();
-      while (l1 < n_ok_total && l1 - l0 < 1024 && !s->full(w, nl0 + (size_t)(l1 - l0))){
+      while (l1 < n_ok_total && l1 - l0 < 1024 && !s->full(w, nl0 + (size_t)(l1 - l0)) && s->pending->fits(dims[2*(size_t)l1], dims[2*(size_t)l1 + 1])){
+        s->pending->note(dims[2*(size_t)l1], dims[2*(size_t)l1 + 1]);
         w += (int64_t)(loci->read_off[l1+1] - loci->read_off[l1])*(loci->hap_off[l1+1] - loci->hap_off[l1]); l1++;
       }
       const int64_t ticket0 = s->next_ticket;
@@ -533,20 +550,10 @@ int hipstr_hmm_process_reads_each(const hipstr_batch_t* batch, double* aln_probs
   OwnedBatch ob;
   std::vector<int> good; std::vector<int64_t> out_off(n + 1, 0);
   std::string first_err;
-  int opt = 0;
-  for (int l = 0; l < n; l++){
-    out_off[l+1] = out_off[l] + (int64_t)(batch->read_off[l+1] - batch->read_off[l])*(batch->hap_off[l+1] - batch->hap_off[l]);
-    const int opt0 = opt; std::string why;
-    int nopt = 0; for (int k = 0; k < 3; k++) nopt += std::max(0, batch->blk_nopts[3*l+k]);
-    int cursor = opt0;
-    const bool bad = hipstr::check_locus(batch, l, &cursor, why) != 0;
-    opt = opt0 + nopt;                                     // (check_locus stops advancing where it refuses)
-    locus_status[l] = bad ? 1 : 0;
-    if (bad){ if (first_err.empty()) first_err = "locus " + std::to_string(l) + ": " + why; continue; }
-    if (const char* w2 = ob.append_locus(batch, l, opt0, (int64_t)good.size())) return hipstr::api_fail(w2);
-    good.push_back(l);
-  }
-  if (!good.empty()){
+  // the gathered loci run as one batch — or as several, where the longest read of one locus and the longest allele of another would not fit
+  // the per-read STR kernels' LDS together (each fits alone: check_locus)
+  auto run_gathered = [&]() -> int {
+    if (good.empty()) return 0;
     std::vector<double> p((size_t)ob.n_out); std::vector<int32_t> sd((size_t)ob.read_off.back());
     for (size_t g = 0; g < good.size(); g++){              // entries the library leaves untouched keep the caller's values
       const int l = good[g]; const OwnedBatch::Ticket& t = ob.tickets[g];
@@ -559,7 +566,25 @@ int hipstr_hmm_process_reads_each(const hipstr_batch_t* batch, double* aln_probs
       std::copy(p.begin() + t.out0, p.begin() + t.out1, aln_probs + out_off[l]);
       std::copy(sd.begin() + t.r0, sd.begin() + t.r1, seeds + batch->read_off[l]);
     }
+    good.clear(); ob.reset();
+    return 0;
+  };
+  for (int l = 0; l < n; l++) out_off[l+1] = out_off[l] + (int64_t)(batch->read_off[l+1] - batch->read_off[l])*(batch->hap_off[l+1] - batch->hap_off[l]);
+  int opt = 0;
+  for (int l = 0; l < n; l++){
+    const int opt0 = opt; std::string why;
+    int nopt = 0; for (int k = 0; k < 3; k++) nopt += std::max(0, batch->blk_nopts[3*l+k]);
+    int cursor = opt0, dims[2] = {0, 1};
+    const bool bad = hipstr::check_locus(batch, l, &cursor, why, NULL, dims) != 0;
+    opt = opt0 + nopt;                                     // (check_locus stops advancing where it refuses)
+    locus_status[l] = bad ? 1 : 0;
+    if (bad){ if (first_err.empty()) first_err = "locus " + std::to_string(l) + ": " + why; continue; }
+    if (!good.empty() && !ob.fits(dims[0], dims[1]) && run_gathered()) return 1;
+    if (const char* w2 = ob.append_locus(batch, l, opt0, (int64_t)good.size())) return hipstr::api_fail(w2);
+    ob.note(dims[0], dims[1]);
+    good.push_back(l);
   }
+  if (run_gathered()) return 1;
   if (!first_err.empty()) hipstr::api_fail(first_err);
   return 0;
 }
@@ -730,6 +755,7 @@ struct hipstr_multi {
   std::deque<int> owner;          // device slot of every ticket not yet delivered, in submission order
   int cur = 0;                    // slot receiving the current block
   int64_t cur_work = 0, next_ticket = 0;
+  std::vector<double> dealt;      // per device slot: estimated work of everything submitted to it so far (hipstr::locus_cost)
 };
 
 extern "C" {
@@ -746,22 +772,53 @@ hipstr_multi_t* hipstr_multi_open(int32_t n_devices, const int32_t* devices, int
     if (!s){ for (hipstr_stream_t* t : mm->streams) hipstr_stream_close(t); delete mm; return NULL; }
     mm->streams.push_back(s);
   }
+  mm->dealt.assign(mm->streams.size(), 0.0);
   return mm;
 }
 
 int64_t hipstr_multi_submit(hipstr_multi_t* mm, const hipstr_batch_t* loci){
   if (!mm || !loci){ hipstr::api_fail("null argument"); return -1; }
   std::lock_guard<std::mutex> g(mm->m);
-  int64_t work = 0;
-  for (int l = 0; l < loci->n_loci; l++) work += (int64_t)(loci->read_off[l+1] - loci->read_off[l])*(loci->hap_off[l+1] - loci->hap_off[l]);
-  if (mm->cur_work > 0 && mm->cur_work + work > mm->block_work){        // the block is full: send it, the next block goes to the next device
+  int64_t work = 0; double cost = 0.0;
+  for (int l = 0, opt0 = 0; l < loci->n_loci; l++){
+    work += (int64_t)(loci->read_off[l+1] - loci->read_off[l])*(loci->hap_off[l+1] - loci->hap_off[l]);
+    int nopt = 0; bool ok = true;
+    for (int k = 0; k < 3; k++){ ok &= loci->blk_nopts[3*l+k] >= 1; nopt += std::max(0, loci->blk_nopts[3*l+k]); }
+    if (ok && loci->read_off[l+1] >= loci->read_off[l]) cost += hipstr::locus_cost(loci, l, opt0);       // (a malformed locus is refused by the stream below)
+    opt0 += nopt;
+  }
+  if (mm->cur_work > 0 && mm->cur_work + work > mm->block_work){        // the block is full: send it ...
     hipstr_stream_flush(mm->streams[mm->cur]);
-    mm->cur = (mm->cur + 1) % (int)mm->streams.size(); mm->cur_work = 0;
+    // ... and the next block goes to the device that has been dealt the least WORK so far (locus_cost: reads x alleles x read length x
+    // [flank rows + STR block by its interruptions]) — not round-robin by pair counts: interrupted-repeat loci cost 3-8x a
+    // periodic one's pairs, and the slowest device sets the pace.  Ties (and the first round) go to the lowest slot.
+    int best = 0;
+    for (int i = 1; i < (int)mm->streams.size(); i++) if (mm->dealt[i] < mm->dealt[best]) best = i;
+    mm->cur = best; mm->cur_work = 0;
   }
   if (hipstr_stream_submit(mm->streams[mm->cur], loci) < 0) return -1;
-  mm->cur_work += work;
+  mm->cur_work += work; mm->dealt[mm->cur] += cost;
   mm->owner.push_back(mm->cur);
   return mm->next_ticket++;
+}
+
+int hipstr_multi_dealt(hipstr_multi_t* mm, double* cost_per_device, int32_t cap){
+  if (!mm) return hipstr::api_fail("null argument");
+  std::lock_guard<std::mutex> g(mm->m);
+  for (int i = 0; i < std::min<int>(cap, (int)mm->dealt.size()); i++) cost_per_device[i] = mm->dealt[i];
+  return (int)mm->dealt.size();
+}
+
+int hipstr_locus_costs(const hipstr_batch_t* batch, double* costs){
+  if (!batch || !costs) return hipstr::api_fail("null argument");
+  for (int l = 0, opt0 = 0; l < batch->n_loci; l++){
+    int nopt = 0;
+    for (int k = 0; k < 3; k++){ if (batch->blk_nopts[3*l+k] < 1) return hipstr::api_fail("haplotype block without options"); nopt += batch->blk_nopts[3*l+k]; }
+    if (batch->read_off[l+1] < batch->read_off[l]) return hipstr::api_fail("read_off must not decrease");
+    costs[l] = hipstr::locus_cost(batch, l, opt0);
+    opt0 += nopt;
+  }
+  return 0;
 }
 
 int hipstr_multi_flush(hipstr_multi_t* mm){

@@ -438,11 +438,9 @@ __global__ void __launch_bounds__(64) hs_trace_fill_long(const hs_tdev_t* __rest
   trace_fill_body<C>(*(TraceLdsStore<C>*)hs_trace_dyn_lds, dp, item_begin);
 }
 template <int C> int launch_fill_long(int cnt, hipStream_t ks, const hs_tdev_t* d_args, int first){
-  static bool sized = false;                    // (per instantiation; racing threads set the same value)
-  if (!sized){
-    if (hipFuncSetAttribute((const void*)hs_trace_fill_long<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TraceLdsStore<C>)) != hipSuccess) return 1;
-    sized = true;
-  }
+  // the attribute belongs to the function on the CURRENT device (hipstr_multi_*: several devices in one process), so it is set on every
+  // launch, like api.hip does for the STR kernels: a host-side call of well under a microsecond next to a rare, long kernel
+  if (hipFuncSetAttribute((const void*)hs_trace_fill_long<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TraceLdsStore<C>)) != hipSuccess) return 1;
   hipLaunchKernelGGL(hs_trace_fill_long<C>, dim3(cnt), dim3(64), sizeof(TraceLdsStore<C>), ks, d_args, first);
   return 0;
 }

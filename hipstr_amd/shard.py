@@ -11,18 +11,14 @@ from .capi import HipstrBatch, _i32p, _f64p, _u8p
 
 
 def locus_costs(a):
-    """DP work estimate per locus: reads x alleles x read length x haplotype length."""
-    n = len(a["period"])
-    P = np.diff(a["read_off"]).astype(np.float64); A = np.diff(a["hap_off"]).astype(np.float64)
-    nb = np.diff(a["base_off"]).astype(np.float64)
-    bases_per_locus = np.array([nb[a["read_off"][l]:a["read_off"][l + 1]].sum() for l in range(n)])
-    opt_len = np.diff(a["opt_off"]).astype(np.float64)
-    nopt = a["blk_nopts"].reshape(n, 3)
-    H = np.zeros(n); c = 0
-    for l in range(n):
-        for k in range(3):
-            H[l] += opt_len[c:c + nopt[l, k]].mean(); c += nopt[l, k]
-    return np.maximum(1.0, bases_per_locus * A * H) + 0 * P
+    """Work estimate per locus — the library's own (hipstr_locus_costs, prep.cpp locus_cost): reads x realigned alleles x read length x
+    [flank rows + STR block priced by its interruptions], what hipstr_multi_submit deals blocks by as well.  Host-only."""
+    hmm = capi.load_hmm()
+    b = batch_from_arrays(dict(a))
+    out = np.zeros(len(a["period"]), np.float64)
+    if hmm.hipstr_locus_costs(b.ptr, out.ctypes.data_as(_f64p)) != 0:
+        raise RuntimeError("hipstr_locus_costs: " + hmm.hipstr_last_error().decode())
+    return np.maximum(out, 1e-3)
 
 
 def split_loci(costs, world):

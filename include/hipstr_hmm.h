@@ -238,7 +238,9 @@ int hipstr_stream_close(hipstr_stream_t* s);
 /*
  * Several GPUs from one process (STR loci are independent, the region list shards across the GPUs of a node with no
  * collective on the data path).  One hipstr_stream_t per device; submissions fill contiguous blocks of about `block_alignments`
- * (read x haplotype) pairs, block i on device i mod n; hipstr_multi_next hands results back in GLOBAL submission order.
+ * (read x haplotype) pairs; a new block goes to the device that has been dealt the least estimated WORK so far (hipstr_locus_costs:
+ * loci with interrupted repeats cost several times a periodic locus' pairs), ties to the lowest slot; hipstr_multi_next hands results
+ * back in GLOBAL submission order.
  * devices == NULL: ordinals 0..n_devices-1.  (One process per GPU — torch.distributed / MPI launchers — needs nothing of this:
  * every process opens its own stream on its own device.)
  */
@@ -249,6 +251,13 @@ int hipstr_multi_flush(hipstr_multi_t* m);
 int hipstr_multi_next_size(hipstr_multi_t* m, int64_t* ticket, int64_t* n_out, int64_t* n_reads);
 int hipstr_multi_next(hipstr_multi_t* m, int64_t* ticket, double* aln_probs, int64_t cap_probs, int32_t* seeds, int64_t cap_seeds);
 int hipstr_multi_close(hipstr_multi_t* m);
+/* Estimated work dealt to every device so far (units of hipstr_locus_costs); returns the number of devices, fills at most `cap` entries. */
+int hipstr_multi_dealt(hipstr_multi_t* m, double* cost_per_device, int32_t cap);
+/* Work estimate per locus, in units of one (150-base read, allele) pair of a periodic repeat with 60 flank bases: reads x realigned alleles
+ * x mean read length / 150 x [1.4 x flank bases / 60 + 1 + 2.4 x interruptions of the repeat per allele] — SURVEY 8(e)'s "sum of P A L H"
+ * with the STR block priced by what it costs on the device.  What the region list is split by across ranks (hipstr_amd/shard.py) and
+ * what hipstr_multi_submit deals blocks by.  Host-only (no device needed). */
+int hipstr_locus_costs(const hipstr_batch_t* batch, double* costs /* [n_loci] */);
 
 /*
  * Host-side ordered gather of per-worker record streams: the reference's VCF writer accepts out-of-order positions
@@ -489,6 +498,12 @@ int hipstr_debug_api_profile(int mode, int cap, const char** names, double* seco
 /* Diagnostics: how many blocks the library has taken from the driver so far (hipMalloc / hipHostMalloc: misses of its block caches, 0.1 ms to
  * 1 s each).  A stream is in its steady state once this stops growing from pass to pass. */
 int64_t hipstr_debug_driver_allocs(void);
+/* Diagnostics (tests): the calling thread's device context's block caches — out[0..3] device: bytes held from the driver, bytes in free
+ * blocks, blocks in use, the cap on idle bytes (HIPSTR_DEV_CACHE_GIB, default 70 % of the device's memory); out[4..7] the same for pinned
+ * host memory (HIPSTR_PIN_CACHE_GIB, default 24).  A release that leaves more idle bytes than the cap gives the chunks without a block in
+ * use back to the driver; when the driver refuses a new chunk a request is served from any free block that is large enough, then after
+ * trimming idle chunks; only then does it fail. */
+int hipstr_debug_cache_stats(int64_t out[8]);
 /* Diagnostics: (realigned allele, side) pairs of a batch by the STR kernel that takes them: counts[1] periodic blocks (tabulated closed form),
  * counts[2] blocks with one or two interruptions (piecewise closed form), counts[3] more interruptions (lists replayed in the grouped layout),
  * counts[0] the rest (per-read kernel). */

@@ -42,12 +42,26 @@ HapAlignerMI355X::HapAlignerMI355X(Haplotype* haplotype, std::vector<bool>& real
     realign_hap_.push_back(realign_to_hap_[k] ? 1 : 0);
 }
 
-namespace {
-struct FlatReads {
+// the reads of a call in the C-ABI's flat form (global name: HapAlignerMI355X.h declares run_trace_requests over it)
+struct HipstrFlatReads {
   std::vector<int32_t> read_off, base_off, read_start, cigar_off, cigar_len;
   std::vector<uint8_t> realign;
   std::string bases, quals, cigar_op;
-  FlatReads(const std::vector<Alignment>& alns, const std::vector<bool>& realign_read){
+  HipstrFlatReads(){}
+  size_t size() const { return read_start.size(); }
+  std::string seq_of(size_t i) const { return bases.substr(base_off[i], base_off[i+1] - base_off[i]); }
+  std::string quals_of(size_t i) const { return quals.substr(base_off[i], base_off[i+1] - base_off[i]); }
+  // read i is `a`, field by field (start, bases, qualities, CIGAR)
+  bool same_read(size_t i, const Alignment& a) const {
+    const size_t n = (size_t)(base_off[i+1] - base_off[i]);
+    if (a.get_start() != read_start[i] || a.get_sequence().size() != n || a.get_base_qualities().size() != n) return false;
+    if (bases.compare(base_off[i], n, a.get_sequence()) != 0 || quals.compare(base_off[i], n, a.get_base_qualities()) != 0) return false;
+    const std::vector<CigarElement>& cig = a.get_cigar_list();
+    if ((size_t)(cigar_off[i+1] - cigar_off[i]) != cig.size()) return false;
+    for (size_t c = 0; c < cig.size(); c++) if (cig[c].get_type() != cigar_op[cigar_off[i] + c] || cig[c].get_num() != cigar_len[cigar_off[i] + c]) return false;
+    return true;
+  }
+  HipstrFlatReads(const std::vector<Alignment>& alns, const std::vector<bool>& realign_read){
     read_off.push_back(0); base_off.push_back(0); cigar_off.push_back(0);
     for (size_t i = 0; i < alns.size(); i++){
       bases += alns[i].get_sequence();
@@ -63,7 +77,7 @@ struct FlatReads {
     if (cigar_len.empty()) cigar_len.push_back(0);
   }
 };
-}
+typedef HipstrFlatReads FlatReads;
 
 #define FILL_BATCH(b, r)                                                                                          \
   hipstr_batch_t b;                                                                                              \
@@ -119,26 +133,21 @@ void HapAlignerMI355X::use_stream(hipstr_stream* stream){ g_shared_stream = stre
 namespace {
 std::atomic<long long> g_tc_hits(0), g_tc_misses(0), g_tc_calls(0), g_tc_ahead(0);
 unsigned long long fnv(const void* p, size_t n, unsigned long long h){ const unsigned char* q = (const unsigned char*)p; for (size_t i = 0; i < n; i++){ h ^= q[i]; h *= 1099511628211ull; } return h; }
-unsigned long long aln_fingerprint(const Alignment& a){
-  unsigned long long h = 1469598103934665603ull;
-  const int32_t st = a.get_start();
-  h = fnv(&st, sizeof st, h);
-  h = fnv(a.get_sequence().data(), a.get_sequence().size(), h);
-  h = fnv(a.get_base_qualities().data(), a.get_base_qualities().size(), h);
-  const std::string cig = a.getCigarString();
-  return fnv(cig.data(), cig.size(), h);
-}
 struct TraceStash {
-  const std::vector<Alignment>* pools; size_t n_pools; unsigned long long hap_hash;
-  std::vector<unsigned long long> prints;            // of every pool, taken when the stash was primed
+  // The pooled reads process_reads saw, as the adapter's OWN flattened copy: nothing below ever dereferences the caller's vector again (it
+  // may be gone by the time a traceback is asked for — another object on this thread calling trace_optimal_aln without a process_reads
+  // before it).  base_addr / n_pools only serve to recognise a request's pool by ADDRESS arithmetic; the content check follows.
+  uintptr_t base_addr; size_t n_pools; unsigned long long hap_hash;
+  FlatReads flat;                                    // every pool, realign mask all true
   std::vector<int32_t> seeds;                        // calc_seed_base of every pool
   bool primed;
   std::map<std::pair<int,int>, AlignmentTrace*> ready;      // computed, not handed out yet: ours to delete
-  TraceStash() : pools(NULL), n_pools(0), hap_hash(0), primed(false) {}
+  TraceStash() : base_addr(0), n_pools(0), hap_hash(0), primed(false) {}
   void drop(){
     for (std::map<std::pair<int,int>, AlignmentTrace*>::iterator it = ready.begin(); it != ready.end(); ++it) delete it->second;
-    ready.clear(); prints.clear(); seeds.clear(); primed = false;
+    ready.clear(); seeds.clear(); primed = false;
   }
+  void forget(){ drop(); base_addr = 0; n_pools = 0; flat = FlatReads(); }
   ~TraceStash(){ drop(); }
 };
 thread_local TraceStash t_stash;
@@ -169,10 +178,13 @@ void HapAlignerMI355X::process_reads(const std::vector<Alignment>& alignments, i
   (void)base_quality;     // BaseQuality's tables are constants of the model; the device holds the same values
   // a new round of this thread's locus: tracebacks computed ahead for the previous one are void; remember where the pooled reads live
   t_stash.drop();
-  t_stash.pools = &alignments; t_stash.n_pools = alignments.size(); t_stash.hap_hash = haplotype_hash();
   AdapterTimer t_flat(0);
   FlatReads r(alignments, realign_read);
   FILL_BATCH(b, r)
+  if (g_trace_prefetch && !alignments.empty()){
+    t_stash.base_addr = (uintptr_t)&alignments[0]; t_stash.n_pools = alignments.size(); t_stash.hap_hash = haplotype_hash();
+    t_stash.flat = r; t_stash.flat.realign.assign(alignments.size(), 1);
+  } else t_stash.forget();
   t_flat.stop();
   if (g_shared_stream != NULL){      // this locus' round joins whatever the other loci in flight submitted
     const int64_t ticket = hipstr_stream_submit(g_shared_stream, &b);
@@ -218,25 +230,26 @@ void HapAlignerMI355X::process_read(const Alignment& aln, int seed_base, const B
 
 AlignmentTrace* HapAlignerMI355X::prefetched_trace(const Alignment& orig_aln, int seed_base, int best_haplotype){
   TraceStash& S = t_stash;
-  if (!g_trace_prefetch || S.pools == NULL || S.pools->size() != S.n_pools || S.n_pools == 0 || S.hap_hash != haplotype_hash()) return NULL;
-  const Alignment* base = &(*S.pools)[0];
-  if (&orig_aln < base || &orig_aln >= base + S.n_pools) return NULL;
-  const int p = (int)(&orig_aln - base);
+  if (!g_trace_prefetch || S.n_pools == 0 || S.hap_hash != haplotype_hash()) return NULL;
+  // the request's pool by address arithmetic (integers: nothing is dereferenced, unrelated objects compare fine) ...
+  const uintptr_t at = (uintptr_t)&orig_aln;
+  if (at < S.base_addr || at >= S.base_addr + S.n_pools*sizeof(Alignment) || (at - S.base_addr) % sizeof(Alignment) != 0) return NULL;
+  const int p = (int)((at - S.base_addr) / sizeof(Alignment));
+  // ... confirmed by content against the adapter's own copy
+  if (!S.flat.same_read((size_t)p, orig_aln)){ S.forget(); return NULL; }
   const int A = fw_haplotype_->num_combs();
   if (best_haplotype < 0 || best_haplotype >= A || !realign_to_hap_[best_haplotype]) return NULL;
   for (int k = 0; k < A; k++) if (!realign_to_hap_[k]) return NULL;      // (the reference traces with an all-true mask: anything else takes the plain path)
-  const std::vector<Alignment>& pools = *S.pools;
+  const FlatReads& pools = S.flat;
   if (!S.primed){
-    // the pools as they are now, their seeds, and one forward pass over all of them: which two haplotypes does every pool fit best?
-    S.prints.resize(S.n_pools);
-    for (size_t i = 0; i < S.n_pools; i++) S.prints[i] = aln_fingerprint(pools[i]);
-    FlatReads r(pools, std::vector<bool>(S.n_pools, true));
+    // the pools, their seeds, and one forward pass over all of them: which two haplotypes does every pool fit best?
+    const FlatReads& r = pools;
     FILL_BATCH(b, r)
     std::vector<double> ll(S.n_pools*(size_t)A, 0.0);
     S.seeds.assign(S.n_pools, -1);
     if (hipstr_hmm_process_reads(&b, ll.data(), S.seeds.data()) != 0) printErrorAndDie(hipstr_last_error());
     g_tc_calls++;
-    if (S.seeds[p] != seed_base){ S.pools = NULL; S.drop(); return NULL; }       // a caller with seeds of its own: not the loop this is made for
+    if (S.seeds[p] != seed_base){ S.forget(); return NULL; }       // a caller with seeds of its own: not the loop this is made for
     std::vector<int32_t> req_read, req_seed, req_hap;
     std::map<std::pair<int,int>, bool> wanted;
     auto want = [&](int pool, int hap){
@@ -293,7 +306,7 @@ AlignmentTrace* HapAlignerMI355X::prefetched_trace(const Alignment& orig_aln, in
     g_tc_misses++;
   }
   else {
-    if (aln_fingerprint(orig_aln) != S.prints[p] || S.seeds[p] != seed_base){ S.pools = NULL; S.drop(); return NULL; }
+    if (S.seeds[p] != seed_base){ S.forget(); return NULL; }
     if (S.ready.find(std::make_pair(p, best_haplotype)) != S.ready.end()) g_tc_hits++;
     else {
       // not among the two likeliest of its pool: every pool against this haplotype, in one call (its sample's other reads will ask for it)
@@ -365,12 +378,18 @@ void HapAlignerMI355X::run_traces(const std::vector<Alignment>& alignments, cons
 
 void HapAlignerMI355X::run_trace_requests(const std::vector<Alignment>& reads, const std::vector<int32_t>& req_read_in, const std::vector<int32_t>& req_seed_in,
 					  const std::vector<int32_t>& req_hap, const std::vector<AlignmentTrace*>& targets){
-  const int n = (int)req_read_in.size();
-  if (n == 0) return;
+  if (req_read_in.empty()) return;
   AdapterTimer t_flat(0);
   FlatReads r(reads, std::vector<bool>(reads.size(), true));
-  FILL_BATCH(b, r)
   t_flat.stop();
+  run_trace_requests(r, req_read_in, req_seed_in, req_hap, targets);
+}
+
+void HapAlignerMI355X::run_trace_requests(const FlatReads& r, const std::vector<int32_t>& req_read_in, const std::vector<int32_t>& req_seed_in,
+					  const std::vector<int32_t>& req_hap, const std::vector<AlignmentTrace*>& targets){
+  const int n = (int)req_read_in.size();
+  if (n == 0) return;
+  FILL_BATCH(b, r)
   AdapterTimer t_info(2);
 
   // Haplotype::get_aln_info() of every haplotype, in the order the reference visits them (Haplotype::next)
@@ -384,7 +403,7 @@ void HapAlignerMI355X::run_trace_requests(const std::vector<Alignment>& reads, c
   t_info.stop();
   std::vector<int32_t> req_read(req_read_in), req_allele(req_hap), req_seed(req_seed_in);
   size_t chars = 64;
-  for (int i = 0; i < n; i++) chars += 2*reads[req_read[i]].get_sequence().size() + 2*aln_info[req_hap[i]].size() + 64;
+  for (int i = 0; i < n; i++) chars += 2*(size_t)(r.base_off[req_read[i] + 1] - r.base_off[req_read[i]]) + 2*aln_info[req_hap[i]].size() + 64;
   const int32_t cap = (int32_t)chars;
   std::vector<double> ll(n);
   std::vector<int32_t> max_index(n), hap_aln_off(n+1), stutter_size(n), str_seq_off(n+1), flank_seq_off(2*n+1), flank_ins(n), flank_del(n),
@@ -401,10 +420,10 @@ void HapAlignerMI355X::run_trace_requests(const std::vector<Alignment>& reads, c
   if (hipstr_hmm_trace_seeded(&b, n, req_read.data(), req_allele.data(), req_seed.data(), hap_to_ref.data(), &o) != 0)
     printErrorAndDie(hipstr_last_error());
   AdapterTimer t_fill(1);
-  for (int i = 0; i < n; i++) fill_trace(i, &o, reads[req_read[i]], *targets[i]);
+  for (int i = 0; i < n; i++) fill_trace(i, &o, r.quals_of((size_t)req_read[i]), r.seq_of((size_t)req_read[i]), *targets[i]);
 }
 
-void HapAlignerMI355X::fill_trace(int i, const hipstr_trace_out_t* o, const Alignment& orig, AlignmentTrace& t) const {
+void HapAlignerMI355X::fill_trace(int i, const hipstr_trace_out_t* o, const std::string& orig_quals, const std::string& orig_seq, AlignmentTrace& t) const {
   std::string s(o->hap_aln + o->hap_aln_off[i], o->hap_aln_off[i+1] - o->hap_aln_off[i]);
   t.set_hap_aln(s);
   if (o->stutter_size[i] != HIPSTR_NO_STR_DATA){
@@ -419,7 +438,7 @@ void HapAlignerMI355X::fill_trace(int i, const hipstr_trace_out_t* o, const Alig
   for (int k = 0; k < o->flank_del[i]; k++) t.inc_flank_del();
   for (int k = o->indel_off[i]; k < o->indel_off[i+1]; k++) t.add_flank_indel(std::pair<int32_t,int32_t>(o->indel_pos[k], o->indel_size[k]));
   for (int k = o->snp_off[i]; k < o->snp_off[i+1]; k++) t.add_flank_snp(o->snp_pos[k], o->snp_base[k]);
-  t.traced_aln() = Alignment(o->aln_start[i], o->aln_stop[i], false, "TRACE", orig.get_base_qualities(), orig.get_sequence(),
+  t.traced_aln() = Alignment(o->aln_start[i], o->aln_stop[i], false, "TRACE", orig_quals, orig_seq,
 			      std::string(o->aln_str + o->aln_str_off[i], o->aln_str_off[i+1] - o->aln_str_off[i]));
   std::vector<CigarElement> cigar_list;
   for (int k = o->cigar_off[i]; k < o->cigar_off[i+1]; k++) cigar_list.push_back(CigarElement(o->cigar_op[k], o->cigar_len[k]));

@@ -92,9 +92,11 @@ class HapAlignerMI355X {
   // the general form: request i = reads[req_read[i]] split at req_seed[i] against haplotype req_hap[i]
   void run_trace_requests(const std::vector<Alignment>& reads, const std::vector<int32_t>& req_read, const std::vector<int32_t>& req_seed,
 			  const std::vector<int32_t>& req_hap, const std::vector<AlignmentTrace*>& targets);
+  void run_trace_requests(const struct HipstrFlatReads& reads, const std::vector<int32_t>& req_read, const std::vector<int32_t>& req_seed,
+			  const std::vector<int32_t>& req_hap, const std::vector<AlignmentTrace*>& targets);
   unsigned long long haplotype_hash() const;
   AlignmentTrace* prefetched_trace(const Alignment& orig_aln, int seed_base, int best_haplotype);
-  void fill_trace(int i, const struct hipstr_trace_out* o, const Alignment& orig, AlignmentTrace& t) const;
+  void fill_trace(int i, const struct hipstr_trace_out* o, const std::string& orig_quals, const std::string& orig_seq, AlignmentTrace& t) const;
 };
 
 #ifdef HIPSTR_MI355X_AS_HAPALIGNER

@@ -48,3 +48,30 @@ def test_two_ranks_weak_and_strong():
     tot = lambda d: d["value"] * d["ms_per_step"] * 1e-3
     assert abs(tot(strong) - a1) < 1e-6 * a1                  # the same 16 loci, split
     assert tot(weak) > 1.7 * a1                               # 32 different loci
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_eight_ranks_on_one_gpu(scaling):
+    """The driver's 8-GPU launch line (torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8) with the 8 ranks sharing GPU 0: one
+    JSON line, rank-disjoint contiguous slices of the one seeded locus set, every rank's host threads = usable cores / 8 and its threads
+    pinned to its own CPUs, the per-rank rates present, the caches trimmed at exit (rc 0 on every rank)."""
+    args = ["--steps", "2", "--warmup", "1", "--loci", "8", "--no-cpu-baseline"] + (["--scaling", "strong"] if scaling == "strong" else [])
+    d = _bench(args, nproc=8, port=29541 if scaling == "weak" else 29543)
+    assert d["n_gpus"] == 8 and d["scaling"] == scaling and len(d["per_rank_alignments_per_s"]) == 8 and all(v > 0 for v in d["per_rank_alignments_per_s"])
+    ranks = sorted(d["ranks"], key=lambda r: r["rank"])
+    assert [r["rank"] for r in ranks] == list(range(8))
+    # contiguous, disjoint, in rank order = locus order
+    nxt = 0
+    for r in ranks:
+        assert r["first_locus"] == nxt and r["loci"] == (8 if scaling == "weak" else 1)
+        nxt += r["loci"]
+    assert nxt == (64 if scaling == "weak" else 8)
+    usable = len(os.sched_getaffinity(0))
+    ht = {r["host_threads"] for r in ranks}
+    assert len(ht) == 1 and 1 <= ht.pop() <= max(1, usable // 8)
+    cpus = [tuple(r["cpus"]) for r in ranks if r["cpus"]]
+    if usable >= 8:
+        assert len(cpus) == 8 and len(set(c for t in cpus for c in t)) == sum(len(t) for t in cpus)          # pinned, and to disjoint CPUs
+    tot = d["value"] * d["ms_per_step"] * 1e-3
+    assert abs(tot - sum(r["alignments_per_step"] for r in ranks)) < 1e-6 * tot
+    assert "end_to_end" in d and d["end_to_end"]["alignments_per_s"] > 0 and d["end_to_end"]["host_threads_per_rank"] >= 1

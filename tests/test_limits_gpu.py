@@ -134,3 +134,77 @@ def test_locus_whose_reads_need_too_much_lds_fails_alone(hmm, oracle):
             st.submit_each(bb.ptr)
     finally:
         st.close()
+
+
+def _lds_partner_loci():
+    """Locus 0: reads of 1750 bases (seeded near the middle) with short alleles; locus 1: short reads with a 2000-bp candidate allele.
+    Each fits the per-read STR kernels' 160 KiB of LDS alone; the longest read of one with the longest allele of the other does not
+    (layout.h hs_str_kernel_lds_bytes: the LDS of a launch is sized by the BATCH's maxima)."""
+    rng = np.random.default_rng(21)
+    def rnd(n): return "".join(rng.choice(list("ACGT"), n))
+    b = capi.Batch()
+    for l in range(3):
+        long_reads = (l == 0)
+        left, right = rnd(100 if long_reads else 40), rnd(1700 if long_reads else 40)
+        ref = "ACAG" * 10
+        hap = left + ref + right
+        L = 1750 if long_reads else 100
+        reads = []
+        for r in range(4):
+            start = (len(left) - 50) if long_reads else int(rng.integers(0, 15))
+            seq = hap[start:start + L]
+            reads.append(dict(seq=seq, qual="F" * len(seq), start=1000 + start, cigar=[("=", len(seq))]))
+        alts = [ref, "ACAG" * (500 if l == 1 else 11)]
+        blocks = [(1000, 1000 + len(left), [left]), (1000 + len(left), 1000 + len(left) + len(ref), alts),
+                  (1000 + len(left) + len(ref), 1000 + len(hap), [right])]
+        b.add_locus(blocks, 4, util.STUTTER, reads)
+    return b.finalize()
+
+
+def test_loci_that_fit_the_lds_alone_but_not_together_go_into_separate_batches(hmm, oracle):
+    """check_locus tests one locus, the upload sizes LDS from the batch-wide longest read and longest allele — a 1.75 kb-read
+    locus and a 2 kb-allele locus each pass and used to fail the batch they shared.  The stream and hipstr_hmm_process_reads_each now close
+    a batch before a locus that would push the combined figure over the limit; the plain one-shot call still refuses the combination."""
+    bb = _lds_partner_loci()
+    a = bb.arrays
+    n_reads, n_out, out_off = capi.batch_dims(bb.ptr)
+    want = []
+    for l in range(3):
+        one = shard.batch_from_arrays(shard.subset_arrays(a, l, l + 1))
+        want.append(capi.run_align(oracle, "oracle_", one.ptr, fill=FILL))
+        gp, gs = capi.run_align(hmm, "hipstr_hmm_", one.ptr, fill=FILL)              # every locus is fine alone
+        assert np.array_equal(gs, want[l][1]) and np.array_equal(gp, want[l][0])
+    with pytest.raises(RuntimeError, match="LDS|shared memory|local"):
+        capi.run_align(hmm, "hipstr_hmm_", bb.ptr, fill=FILL)                        # the caller's own batch of all three: one launch, does not fit
+    # process_reads_each: split where the figure would overflow
+    probs = np.full(n_out, FILL); seeds = np.full(n_reads, -7, np.int32); status = np.full(3, -1, np.int32)
+    hmm.hipstr_hmm_process_reads_each.restype = C.c_int
+    hmm.hipstr_hmm_process_reads_each.argtypes = [capi._BP, capi._f64p, capi._i32p, capi._i32p]
+    assert hmm.hipstr_hmm_process_reads_each(bb.ptr, probs.ctypes.data_as(capi._f64p), seeds.ctypes.data_as(capi._i32p), status.ctypes.data_as(capi._i32p)) == 0, hmm.hipstr_last_error()
+    assert list(status) == [0, 0, 0]
+    ro = a["read_off"]
+    for l in range(3):
+        assert np.array_equal(probs[out_off[l]:out_off[l + 1]], want[l][0]) and np.array_equal(seeds[ro[l]:ro[l + 1]], want[l][1])
+    # the stream, every locus a submission: they share batches only where they fit together
+    for each in (True, False):
+        st = capi.Stream(hmm)
+        try:
+            if each:
+                st.submit_each(bb.ptr)
+            else:
+                for l in range(3):
+                    st.submit(shard.batch_from_arrays(shard.subset_arrays(a, l, l + 1)).ptr)
+            st.flush()
+            for l in range(3):
+                t, gp, gs = st.next(fill=FILL)
+                assert t == l and np.array_equal(gp, want[l][0]) and np.array_equal(gs, want[l][1])
+            assert st.stats()["batches"] >= 2
+        finally:
+            st.close()
+    # one SUBMISSION is one batch: all three loci as one submission is refused with a message that says what to do
+    st = capi.Stream(hmm)
+    try:
+        with pytest.raises(RuntimeError, match="submit them separately"):
+            st.submit(bb.ptr)
+    finally:
+        st.close()

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from hipstr_amd import capi
+import util
 from util import batch_from_dict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -212,3 +213,28 @@ def test_host_preparation_digests_are_pinned():
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "prep_digests.py"), "check", os.path.join(root, "tests", "golden", name)],
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, env=e)
         assert r.returncode == 0, (name, r.stdout)
+
+
+def test_locus_costs_price_interrupted_repeats_and_flanks():
+    """hipstr_locus_costs (prep.cpp locus_cost): what shard.split_loci and hipstr_multi_submit balance by.  Host-only."""
+    import ctypes as C
+    from hipstr_amd import shard
+    hmm = capi.load_hmm()
+    plain = capi.SynthBatch(n_loci=6, reads_per_locus=30, n_str_alleles=8, seed=3)
+    a = util.synth_to_batch(plain).arrays
+    c = shard.locus_costs(a)
+    P = np.diff(a["read_off"]); A = np.diff(a["hap_off"])
+    assert c.shape == (6,) and np.all(c > 0)
+    # periodic loci of one shape: the estimate is close to reads x alleles x (1.4 x flank / 60 + 1) x length / 150
+    assert np.all(c / (P * A) > 1.0) and np.all(c / (P * A) < 6.0)
+    os.environ["HIPSTR_SYNTH_INHERIT"] = "2"
+    try:
+        inter = capi.SynthBatch(n_loci=6, reads_per_locus=30, n_str_alleles=8, seed=3)
+        ci = shard.locus_costs(util.synth_to_batch(inter).arrays)
+    finally:
+        del os.environ["HIPSTR_SYNTH_INHERIT"]
+    assert np.all(ci > 1.5 * c)                                   # two inherited interruptions per allele: priced several times a periodic locus
+    # the split follows the cost, not the pair count
+    both = np.concatenate([c, ci])
+    bounds = shard.split_loci(both, 2)
+    assert bounds[1] > 6                                          # the cheap half holds more loci
