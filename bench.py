@@ -709,7 +709,7 @@ def main():
     hmm.hipstr_hmm_free(dev)
     released = int(hmm.hipstr_hmm_trim())           # the caches' idle chunks back to the driver: a rank leaves the device as it found it
     if os.environ.get("HIPSTR_BENCH_VERBOSE"):
-        st8 = (C.c_int64 * 8)(); hmm.hipstr_debug_cache_stats(st8)
+        st8 = (C.c_int64 * 12)(); hmm.hipstr_debug_cache_stats(st8)
         print("rank %d: released %d bytes, still held: device %d, pinned %d" % (rank, released, st8[0], st8[4]), file=sys.stderr, flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -436,7 +436,25 @@ def load_oracle():
     _sig(lib.oracle_debug_row_h, C.c_int, [_BP, C.c_int, _i32p, _i32p, C.c_int])
     for name, (rt, at) in _scalar_probes.items():
         _sig(getattr(lib, "oracle_" + name), rt, at)
+    _sig(lib.oracle_set_cr_math, None, [C.c_int])
     return lib
+
+
+class oracle_cr_math:
+    """with capi.oracle_cr_math(oracle): ... — the oracle's posterior / genotype-call / EM stages evaluate exp and log with the correctly
+    rounded functions of hipstr_amd/csrc/cr_math.h (what the device kernels use) instead of the host libm: an operation-for-operation CPU
+    restatement of the device path.  Only for those stages: the alignment path's model tables stay the host libm's in the library too."""
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    def __enter__(self):
+        self.lib.oracle_set_cr_math(1)
+        return self.lib
+
+    def __exit__(self, *a):
+        self.lib.oracle_set_cr_math(0)
+        return False
 
 
 def load_ref():
@@ -535,6 +553,7 @@ def load_hmm():
     _sig(lib.hipstr_last_error, C.c_char_p, [])
     _sig(lib.hipstr_debug_driver_allocs, C.c_int64, [])
     _sig(lib.hipstr_locus_costs, C.c_int, [_BP, _f64p])
+    _sig(lib.hipstr_debug_cr_math, C.c_int, [C.c_int, _f64p, _f64p, C.c_int64])
     _sig(lib.hipstr_debug_cache_stats, C.c_int, [C.POINTER(C.c_int64)])
     _sig(lib.hipstr_debug_allele_kinds, C.c_int, [C.c_void_p, C.POINTER(C.c_int64)])
     _sig(lib.hipstr_debug_stream_create, C.c_void_p, [])

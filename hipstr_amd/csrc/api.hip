@@ -35,6 +35,7 @@ extern "C" __global__ void hs_posterior_kernel(const hs_post_dev_t* dp);
 extern "C" __global__ void hs_posterior_accumulate_kernel(const hs_post_dev_t* dp);
 extern "C" __global__ void hs_posterior_finish_kernel(const hs_post_dev_t* dp);
 extern "C" __global__ void hs_genotype_kernel(const hs_gt_dev_t* dp);
+extern "C" __global__ void hs_cr_math_kernel(int which, const double* x, double* y, int64_t n);
 extern "C" size_t hs_str_lds_bytes(int lds_len, int max_B);
 extern "C" __global__ void hs_str_group_kernel(const hs_dev_t* dp, int item_begin, int short_only);
 extern "C" __global__ void hs_str_group_kernel_pw(const hs_dev_t* dp, int item_begin);
@@ -73,10 +74,14 @@ struct BlockCache {
   std::mutex m;
   std::multimap<size_t, void*> free_;
   std::unordered_map<void*, size_t> size_;
-  struct Chunk { char* base; size_t size, used; int live = 0; };       // live: blocks of the chunk that are out
+  struct Chunk { char* base; size_t size, used; int live = 0; bool small = false; };       // live: blocks of the chunk that are out
+  // Requests of up to 1 MiB are carved from chunks of their own (32 MiB each): the handful of small, fixed-size blocks every batch takes
+  // would otherwise be re-used out of every old chunk and keep all of them from ever being trimmed.
+  static constexpr size_t SMALL_MAX = (size_t)1 << 20, SMALL_CHUNK = (size_t)32 << 20;
   std::vector<Chunk> chunks;
   size_t next_chunk = (size_t)256 << 20;
   size_t cached = 0, cap = 0, in_use = 0;
+  int64_t n_fallback = 0, n_trim_retry = 0;       // requests served by a free block beyond the 2x window / by a chunk taken after trimming (driver refusals survived)
   static size_t round_up(size_t n){
     if (n < 256) return 256;
     if (n <= ((size_t)1 << 20)) return (n + 255) & ~(size_t)255;
@@ -112,27 +117,32 @@ struct BlockCache {
     if (void* p = take_free(want, 2*want)) return p;
     const size_t exact = want;
     if (want > ((size_t)16 << 20)) want = round_up(want + want/8);        // a new large block comes with headroom for its successors
-    if (chunks.empty() || chunks.back().used + want > chunks.back().size){
+    const bool small = exact <= SMALL_MAX;
+    int ci = -1;                                         // the newest chunk of this class with room
+    for (int i = (int)chunks.size() - 1; i >= 0; i--) if (chunks[i].small == small){ if (chunks[i].used + want <= chunks[i].size) ci = i; break; }
+    if (ci < 0){
       const size_t max_chunk = pinned ? (size_t)2 << 30 : (size_t)16 << 30;
-      size_t sz = std::max(next_chunk, want);
-      next_chunk = std::min(max_chunk, next_chunk*2);
+      size_t sz = small ? SMALL_CHUNK : std::max(next_chunk, want);
+      if (!small) next_chunk = std::min(max_chunk, next_chunk*2);
       char* base = (char*)driver_alloc(sz);
       if (!base && sz > want) base = (char*)driver_alloc(sz = want);       // the device is nearly full: just what is needed
       if (!base){
         // the driver has no more: a larger free block, whatever its size, before giving up ...
-        if (void* p = take_free(exact, 0)){ g_err.clear(); return p; }
+        if (void* p = take_free(exact, 0)){ g_err.clear(); n_fallback++; return p; }
         // ... then the chunks without a block in use go back to the driver and the request is tried once more
         g.unlock();
         const size_t freed = trim();
         g.lock();
-        if (void* p = take_free(exact, 0)){ g_err.clear(); return p; }    // (another thread may have returned one meanwhile)
-        if (freed){ g_err.clear(); base = (char*)driver_alloc(sz = exact); }
+        if (void* p = take_free(exact, 0)){ g_err.clear(); n_fallback++; return p; }    // (another thread may have returned one meanwhile)
+        if (freed){ g_err.clear(); base = (char*)driver_alloc(sz = exact); if (base) n_trim_retry++; }
         if (!base) return NULL;                                            // (the driver's message is in g_err)
         want = exact;
       }
-      chunks.push_back(Chunk{base, sz, 0, 0});
+      Chunk nc{base, sz, 0, 0}; nc.small = small;
+      chunks.push_back(nc);
+      ci = (int)chunks.size() - 1;
     }
-    Chunk& c = chunks.back();
+    Chunk& c = chunks[ci];
     void* p = c.base + c.used;
     c.used += (want + 255) & ~(size_t)255;
     size_[p] = want;
@@ -914,7 +924,21 @@ double ApiTimer::now(){ return std::chrono::duration<double>(std::chrono::steady
 }
 }
 int64_t hipstr_debug_driver_allocs(void){ return g_driver_allocs.load(); }
-int hipstr_debug_cache_stats(int64_t out[8]){
+int hipstr_debug_cr_math(int which, const double* x, double* y, int64_t n){
+  if (!x || !y || n < 0) return fail("null argument");
+  if (n == 0) return 0;
+  Ctx* c = current_ctx();
+  if (!c || bind(c)) return 1;
+  double* dx = (double*)c->dev_cache.get((size_t)n*8); double* dy = (double*)c->dev_cache.get((size_t)n*8);
+  int rc = 1;
+  if (dx && dy && hipMemcpy(dx, x, (size_t)n*8, hipMemcpyHostToDevice) == hipSuccess){
+    hipLaunchKernelGGL(hs_cr_math_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, c->stream, which, (const double*)dx, dy, n);
+    if (hipstr::wait_stream(c->stream) == hipSuccess && hipMemcpy(y, dy, (size_t)n*8, hipMemcpyDeviceToHost) == hipSuccess) rc = 0;
+  }
+  c->dev_cache.put(dx); c->dev_cache.put(dy);
+  return rc ? fail("hipstr_debug_cr_math: device call failed") : 0;
+}
+int hipstr_debug_cache_stats(int64_t out[12]){
   Ctx* c = current_ctx();
   if (!c) return 1;
   BlockCache* bc[2] = { &c->dev_cache, &c->pin_cache };
@@ -922,6 +946,7 @@ int hipstr_debug_cache_stats(int64_t out[8]){
     std::lock_guard<std::mutex> g(bc[k]->m);
     size_t held = 0; for (const BlockCache::Chunk& ch : bc[k]->chunks) held += ch.size;
     out[4*k] = (int64_t)held; out[4*k + 1] = (int64_t)bc[k]->cached; out[4*k + 2] = (int64_t)bc[k]->in_use; out[4*k + 3] = (int64_t)bc[k]->cap;
+    out[8 + 2*k] = bc[k]->n_fallback; out[9 + 2*k] = bc[k]->n_trim_retry;
   }
   return 0;
 }

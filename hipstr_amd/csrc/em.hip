@@ -11,8 +11,12 @@
 //                     (read, allele_1, allele_2, phase), with the read-phase posteriors of :152-169 evaluated in place — the
 //                     R×A²×2 array log_read_phase_posteriors_ never exists.  fast_log_sum_exp(vector) is a max and a sum of
 //                     float terms, both order-independent, so the reductions are parallel.
-// The host keeps the loop: per iteration it reads back 8 doubles per locus (LL + seven totals), forms the new parameters and
-// the convergence tests with the host libm exactly as the reference does, and masks converged loci out.
+// Round 5: the iteration loop is device-resident.  hs_em_finish forms the new parameters and train()'s convergence tests on the device
+// (the host did, with three synchronous copies in and two out per lock-step round), with the CORRECTLY ROUNDED exp / log of cr_math.h in
+// the reference's operation order — the host libm's bits wherever that is itself correctly rounded, so iteration counts and parameters
+// are the CPU run's; hs_em_compact / hs_em_units rebuild the list of loci (and of their (locus, sample) posterior units) that are still
+// training, so a late round launches and touches only those; the host enqueues round i + 1 while it waits for the 8-byte count of round
+// i - 1 (a bound for the grids, and the stop signal).  HIPSTR_EM_HOST_LOOP=1 selects the round-4 loop (host libm, all loci per round).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -23,11 +27,14 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <sched.h>
+#include <unistd.h>
 
 #include "../../include/hipstr_hmm.h"
 #include "post_layout.h"
 #include "prep.h"
 #include "api_internal.h"
+#include "cr_math.h"
 
 extern "C" __global__ void hs_posterior_kernel(const hs_post_dev_t* dp);
 
@@ -64,8 +71,32 @@ struct hs_em_dev_t {
   double*  leff;               // same layout: ln |effective difference| (the addend of the diffs vectors), 0 where there is none
   double*  part;               // [n_loci][HS_EM_PARTS][7] partial maxima, then partial sums, of the seven M-step vectors
   double   log_thresh, log_half, log_1p1;
+  // ---- device-resident loop (NULL / unused with the host loop): workgroup b of a per-locus kernel takes locus list[b] if b < counts[0]
+  const int32_t* list;         // loci still training, ascending
+  const int32_t* counts;       // [0] loci in `list`, [1] their (locus, sample) units
+  int32_t* next_list;          // the lists of the next round (hs_em_compact / hs_em_units write them; the two argument blocks swap roles)
+  int32_t* next_counts;
+  int32_t* next_units;         // (locus, sample) units of the loci in next_list, in order
+  int32_t* next_unit_begin;    // [n_loci] scratch: first slot of a listed locus' units in next_units
+  const int32_t* unit_first;   // [n_loci] index of the locus' first unit
+  double*  logp_rw;            // = logp, writable (hs_em_finish writes the next round's nine logs)
+  double*  sp;                 // [6*n_loci] current stutter parameters
+  double*  cur_ll;             // [n_loci] LL of the previous round (-DBL_MAX before the first)
+  int32_t* iter;               // [n_loci] 1-based number of the round a locus is in
+  int32_t* state;              // [n_loci] 0 training, 1 converged (train() returned true), 2 out of iterations (false)
+  int32_t* n_iter;             // [n_loci] outputs: rounds run, LL of the last one
+  double*  final_ll;
+  int32_t  max_iter, n_loci;
+  double   min_abs, min_frac;
 };
+// the locus of this workgroup: through the active list (device loop) or the mask (host loop); -1 = nothing to do
+__device__ __forceinline__ int em_locus(const hs_em_dev_t& d){
+  if (d.list) return ((int)blockIdx.x < d.counts[0]) ? d.list[blockIdx.x] : -1;
+  return d.active[blockIdx.x] ? (int)blockIdx.x : -1;
+}
 #define HS_EM_PARTS 8          // workgroups per locus in the two big M-step reductions
+#define HS_EM_CHUNK 64          // positions of the allele-frequency scans per round of prepared exponentials (em_gt_priors)
+#define HS_EM_MAXA_LDS 64      // alleles whose chains run side by side (lanes of the first wavefront); more alleles: several sweeps
 
 namespace {
 
@@ -116,8 +147,8 @@ __device__ __forceinline__ double em_pmf(const double* lp, int period, int sampl
 
 __global__ void __launch_bounds__(256) hs_em_fill(const hs_em_dev_t* __restrict__ dp){
   const hs_em_dev_t& d = *dp;
-  const int l = blockIdx.x;
-  if (!d.active[l]) return;
+  const int l = em_locus(d);
+  if (l < 0) return;
   const hs_em_locus_t L = d.loci[l];
   const double* lp = d.logp + 9*l;
   const int32_t* bps = d.bps + L.bps_off;
@@ -174,46 +205,66 @@ __device__ void em_gt_priors(const hs_em_dev_t& d, const hs_em_locus_t& L, int t
     double rm = row[0];
     for (int j = 1; j < A; j++) rm = fmax(rm, row[j]);
     double rs = 0.0;
-    for (int j = 0; j < A; j++) rs += exp(row[j] - rm);
-    row_lse[x] = rm + log(rs);
+    for (int j = 0; j < A; j++) rs += cr_exp(row[j] - rm);
+    row_lse[x] = rm + cr_log(rs);
   }
   __syncthreads();
-  // (the scans are one lane per allele; a wavefront without alleles walks through to the barrier below — every thread of the workgroup
-  // reaches every barrier)
-  // The scans are one dependent chain per allele; the values they eat are fetched eight at a time ahead of the chain, or every step
-  // would wait out a trip to L2.
-#define EM_SCAN_STEP(lv) do { if ((lv) <= m) t += exp((lv) - m); else { t *= exp(m - (lv)); t += 1.0; m = (lv); } } while (0)
-  for (int a = tid; a < A; a += 256){
-    double m = -DBL_MAX/2, t = 0.0;
-    int s = 0;
-    for (; s + 8 <= S; s += 8){                          // first allele of the diplotype: log_sum_exp of row (s, a)
-      double v[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) v[q] = row_lse[(int64_t)(s + q)*A + a];
-#pragma unroll
-      for (int q = 0; q < 8; q++) EM_SCAN_STEP(v[q]);
+  // The two scans of allele a are ONE dependent chain over S + S A values (update_streaming_log_sum_exp, mathops.cpp:72-80): lane a owns it.
+  // What is expensive in a step is the exponential, and that does not depend on the chain except through the running maximum m, which
+  // changes only a handful of times: so the values are taken HS_EM_CHUNK at a time — every thread of the workgroup forms
+  // exp(v - m_a) for its share of the chunk's (position, allele) pairs with the maxima as they stand at the chunk's start (correctly
+  // rounded, cr_math.h; a value above its allele's maximum gets no exponential), then lane a walks its chunk: where its maximum still is
+  // what the exponentials were formed with it adds the prepared term, where a new maximum appeared it takes the step the long way.
+  // Same values, same operations in the same order as the scalar chain.  (A > 64: alleles beyond the first wavefront's lanes loop.)
+  constexpr int CH = HS_EM_CHUNK;
+  __shared__ double s_m[HS_EM_MAXA_LDS];                 // running maximum per allele (the chunk's snapshot)
+  extern __shared__ double hs_em_dyn[];                  // [CH][Apad] prepared exponentials
+  const int Apad = A;
+  const int64_t n1 = S, n2 = (int64_t)S*A, ntot = n1 + n2;
+  auto value_at = [&](int64_t i, int a) -> double {      // the chain of allele a: row_lse(s, a) for s < S, then post[(s, i1), a]
+    return i < n1 ? row_lse[i*A + a] : post[(i - n1)*A + a];
+  };
+  for (int a0 = 0; a0 < A; a0 += HS_EM_MAXA_LDS){
+    const int na = min(HS_EM_MAXA_LDS, A - a0);
+    double m = -DBL_MAX/2, t = 0.0;                      // lane a - a0 < na of the first wavefront(s): the chain's state
+    if (tid < na) s_m[tid] = m;
+    __syncthreads();
+    for (int64_t c0 = 0; c0 < ntot; c0 += CH){
+      const int cn = (int)min((int64_t)CH, ntot - c0);
+      for (int e = tid; e < cn*na; e += 256){
+        const int i = e / na, al = e - i*na;
+        const double lv = value_at(c0 + i, a0 + al), ms = s_m[al];
+        double ex = 0.0;
+        if (lv <= ms){ const double x_ = lv - ms; ex = (x_ < -37.43) ? -1.0 : cr_exp(x_); }       // -1: "below 2^-54" (see the walk)
+        hs_em_dyn[i*Apad + al] = ex;
+      }
+      __syncthreads();
+      if (tid < na){
+        const double ms = s_m[tid];
+        for (int i = 0; i < cn; i++){
+          const double lv = value_at(c0 + i, a0 + tid);
+          if (lv <= m){
+            if (m == ms){
+              const double ex = hs_em_dyn[i*Apad + tid];
+              // (once a maximum is set the total is >= 1: a term below 2^-54 leaves it as it is, bit for bit; before that — t < 1 only while
+              //  m is still the initial -DBL_MAX/2, where no value is below it — it cannot occur)
+              if (ex >= 0.0) t += ex;
+            } else { const double x_ = lv - m; if (!(t >= 1.0 && x_ < -37.43)) t += cr_exp(x_); }
+          } else { t *= cr_exp(m - lv); t += 1.0; m = lv; }
+        }
+        s_m[tid] = m;
+      }
+      __syncthreads();
     }
-    for (; s < S; s++){ const double lv = row_lse[(int64_t)s*A + a]; EM_SCAN_STEP(lv); }
-    const int64_t n2 = (int64_t)S*A;                     // second allele: (s, i1) in order is one run of stride A from post[a]
-    int64_t y = 0;
-    for (; y + 8 <= n2; y += 8){
-      double v[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) v[q] = post[(y + q)*A + a];
-#pragma unroll
-      for (int q = 0; q < 8; q++) EM_SCAN_STEP(v[q]);
-    }
-    for (; y < n2; y++){ const double lv = post[y*A + a]; EM_SCAN_STEP(lv); }
-    gtp[a] = m + log(t);
+    if (tid < na) gtp[a0 + tid] = m + cr_log(t);
+    __syncthreads();
   }
-#undef EM_SCAN_STEP
-  __syncthreads();
   if (tid == 0){                                          // normalise: exact log_sum_exp in allele order
     double m = gtp[0];
     for (int a = 1; a < A; a++) m = fmax(m, gtp[a]);
     double t = 0.0;
-    for (int a = 0; a < A; a++) t += exp(gtp[a] - m);
-    const double lt = m + log(t);
+    for (int a = 0; a < A; a++) t += cr_exp(gtp[a] - m);
+    const double lt = m + cr_log(t);
     for (int a = 0; a < A; a++) gtp[a] -= lt;
   }
 }
@@ -227,8 +278,8 @@ __device__ void em_gt_priors(const hs_em_dev_t& d, const hs_em_locus_t& L, int t
 template <int PASS>
 __global__ void __launch_bounds__(256) hs_em_mstep_part(const hs_em_dev_t* __restrict__ dp, const double* __restrict__ keep){
   const hs_em_dev_t& d = *dp;
-  const int l = blockIdx.x, k_part = blockIdx.y, tid = threadIdx.x;
-  if (!d.active[l]) return;
+  const int l = em_locus(d), k_part = blockIdx.y, tid = threadIdx.x;
+  if (l < 0) return;
   const hs_em_locus_t L = d.loci[l];
   const int A = L.A, nd = A*A;
   const double* post = d.post + L.post_off;
@@ -306,16 +357,16 @@ __global__ void __launch_bounds__(256) hs_em_mstep_part(const hs_em_dev_t* __res
 // (the next iteration's hs_em_fill does), so the kernel runs beside them on a second stream.
 __global__ void __launch_bounds__(256) hs_em_gt_priors(const hs_em_dev_t* __restrict__ dp){
   const hs_em_dev_t& d = *dp;
-  const int l = blockIdx.x;
-  if (!d.active[l]) return;
+  const int l = em_locus(d);
+  if (l < 0) return;
   const hs_em_locus_t L = d.loci[l];
   em_gt_priors(d, L, threadIdx.x);
 }
 
 __global__ void __launch_bounds__(64) hs_em_mstep_keepmax(const hs_em_dev_t* __restrict__ dp, double* __restrict__ keep){
   const hs_em_dev_t& d = *dp;
-  const int l = blockIdx.x;
-  if (!d.active[l] || threadIdx.x >= 7) return;
+  const int l = em_locus(d);
+  if (l < 0 || threadIdx.x >= 7) return;
   const double* part = d.part + ((size_t)l*HS_EM_PARTS)*7;
   double m = (threadIdx.x == 3 || threadIdx.x == 6) ? d.log_1p1 : 0.0;
   for (int q = 0; q < HS_EM_PARTS; q++) m = fmax(m, part[q*7 + threadIdx.x]);
@@ -324,8 +375,8 @@ __global__ void __launch_bounds__(64) hs_em_mstep_keepmax(const hs_em_dev_t* __r
 
 __global__ void __launch_bounds__(256) hs_em_mstep(const hs_em_dev_t* __restrict__ dp, const double* __restrict__ keep){
   const hs_em_dev_t& d = *dp;
-  const int l = blockIdx.x, tid = threadIdx.x;
-  if (!d.active[l]) return;
+  const int l = em_locus(d), tid = threadIdx.x;
+  if (l < 0) return;
   const hs_em_locus_t L = d.loci[l];
   const int S = L.S;
 
@@ -347,6 +398,111 @@ __global__ void __launch_bounds__(256) hs_em_mstep(const hs_em_dev_t* __restrict
       d.sums[7*l + k] = mxk + (double)e_fasterlog((float)t);
     }
   }
+}
+
+// ---- the device-resident loop (round 5) ---------------------------------------------------------------------------------
+// StutterModel's nine logs (stutter_model.h:44-58) from the six parameters, correctly rounded
+__device__ __forceinline__ void em_logs(const double* sp, double* q){
+  q[0] = cr_log(1-sp[0]); q[1] = cr_log(sp[0]); q[2] = cr_log(sp[1]); q[3] = cr_log(sp[2]);
+  q[4] = cr_log(1-sp[3]); q[5] = cr_log(sp[3]); q[6] = cr_log(sp[4]); q[7] = cr_log(sp[5]);
+  q[8] = cr_log(1-sp[1]-sp[2]-sp[4]-sp[5]);
+}
+__device__ __forceinline__ double em_lse2_exact(double a, double b){      // mathops.cpp:52-57
+  return a > b ? a + cr_log(1 + cr_exp(b - a)) : b + cr_log(1 + cr_exp(a - b));
+}
+
+// init_stutter_model (:59-62) and the loop's starting state, a thread per locus
+__global__ void __launch_bounds__(256) hs_em_init(const hs_em_dev_t* __restrict__ dp){
+  const hs_em_dev_t& d = *dp;
+  const int l = blockIdx.x*256 + threadIdx.x;
+  if (l >= d.n_loci) return;
+  const double init[6] = { 0.9, 0.1, 0.1, 0.8, 0.01, 0.01 };
+  for (int k = 0; k < 6; k++) d.sp[6*l + k] = init[k];
+  em_logs(init, d.logp_rw + 9*(size_t)l);
+  d.cur_ll[l] = -DBL_MAX; d.iter[l] = 1; d.n_iter[l] = 0; d.final_ll[l] = 0.0;
+  d.state[l] = (1 > d.max_iter) ? 2 : 0;                  // no iteration allowed: train() returns false without running one
+}
+
+// The end of a round for one locus (a thread): the E-step's total LL and the seven M-step totals (what hs_em_mstep hands the host loop),
+// then train()'s tests and update (:186-224) in the reference's order, exp / log correctly rounded, and the next round's nine logs.
+__global__ void __launch_bounds__(64) hs_em_finish(const hs_em_dev_t* __restrict__ dp, const double* __restrict__ keep){
+  const hs_em_dev_t& d = *dp;
+  const int l = em_locus(d);
+  if (l < 0 || threadIdx.x != 0) return;
+  const hs_em_locus_t L = d.loci[l];
+  double new_LL = 0.0;
+  for (int s = 0; s < L.S; s++) new_LL += d.sample_total[L.samp_begin + s];     // genotyper.cpp:75
+  double t[7];
+  const double* part = d.part + ((size_t)l*HS_EM_PARTS)*7;
+  for (int k = 0; k < 7; k++){
+    const double mxk = keep[7*l + k];
+    double tt = 0.0;
+    for (int q = 0; q < HS_EM_PARTS; q++) tt += part[q*7 + k];
+    { const double df = 0.0 - mxk; if (df > d.log_thresh) tt += (double)e_fasterexp((float)df); }
+    if (k == 3 || k == 6){ const double df = d.log_1p1 - mxk; if (df > d.log_thresh) tt += (double)e_fasterexp((float)df); }
+    t[k] = mxk + (double)e_fasterlog((float)tt);
+  }
+  const int it = d.iter[l];
+  d.n_iter[l] = it; d.final_ll[l] = new_LL;
+  const double LL = d.cur_ll[l];
+  if (new_LL < LL + 1e-10){ d.state[l] = 1; return; }                           // :190-194 (TOLERANCE = 1e-10)
+  const double out_total = e_fast_lse2(t[4], t[5], d.log_thresh);
+  const double in_pgeom  = fmin(0.999, cr_exp(em_lse2_exact(t[0], t[1]) - t[3]));
+  const double out_pgeom = fmin(0.999, cr_exp(out_total - t[6]));
+  const double m3 = fmax(fmax(t[0], t[1]), t[2]);
+  const double lse3 = m3 + cr_log(cr_exp(t[0]-m3) + cr_exp(t[1]-m3) + cr_exp(t[2]-m3));      // mathops.cpp:59-62
+  const double log_total = em_lse2_exact(lse3, out_total);
+  const double nw[6] = { in_pgeom, cr_exp(t[0] - log_total), cr_exp(t[1] - log_total), out_pgeom, cr_exp(t[4] - log_total), cr_exp(t[5] - log_total) };
+  const double abs_change = new_LL - LL, frac_change = -(new_LL - LL)/LL;
+  bool conv = false;
+  if (abs_change < d.min_abs && frac_change < d.min_frac) conv = true;
+  else {
+    conv = true;
+    for (int k = 0; k < 6; k++) if (!(fabs(d.sp[6*l + k] - nw[k]) < 0.0001)) conv = false;     // parameters_within_threshold (stutter_model.h:62-65)
+  }
+  for (int k = 0; k < 6; k++) d.sp[6*l + k] = nw[k];
+  if (conv){ d.state[l] = 1; return; }
+  d.cur_ll[l] = new_LL; d.iter[l] = it + 1;
+  if (it + 1 > d.max_iter){ d.state[l] = 2; return; }                           // ran out of iterations: train() returns false
+  em_logs(nw, d.logp_rw + 9*(size_t)l);
+}
+
+// The loci still training, ascending, and where their (locus, sample) units go: one workgroup, an exclusive scan over the loci in chunks.
+__global__ void __launch_bounds__(1024) hs_em_compact(const hs_em_dev_t* __restrict__ dp){
+  const hs_em_dev_t& d = *dp;
+  const int tid = threadIdx.x;
+  __shared__ int sc_n[1024], sc_u[1024];
+  __shared__ int base_n, base_u;
+  if (tid == 0){ base_n = 0; base_u = 0; }
+  __syncthreads();
+  for (int l0 = 0; l0 < d.n_loci; l0 += 1024){
+    const int l = l0 + tid;
+    const int on = (l < d.n_loci && d.state[l] == 0) ? 1 : 0;
+    const int nu = on ? d.loci[l].S : 0;
+    sc_n[tid] = on; sc_u[tid] = nu;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1){               // inclusive scan (Hillis-Steele)
+      const int a = (tid >= off) ? sc_n[tid - off] : 0, b = (tid >= off) ? sc_u[tid - off] : 0;
+      __syncthreads();
+      sc_n[tid] += a; sc_u[tid] += b;
+      __syncthreads();
+    }
+    if (on){
+      d.next_list[base_n + sc_n[tid] - 1] = l;
+      d.next_unit_begin[l] = base_u + sc_u[tid] - nu;
+    }
+    __syncthreads();
+    if (tid == 1023){ base_n += sc_n[1023]; base_u += sc_u[1023]; }
+    __syncthreads();
+  }
+  if (tid == 0){ d.next_counts[0] = base_n; d.next_counts[1] = base_u; }
+}
+__global__ void __launch_bounds__(256) hs_em_units(const hs_em_dev_t* __restrict__ dp){
+  const hs_em_dev_t& d = *dp;
+  if ((int)blockIdx.x >= d.next_counts[0]) return;
+  const int l = d.next_list[blockIdx.x];
+  const int S = d.loci[l].S, b = d.next_unit_begin[l], u0 = d.unit_first[l];
+  for (int s = threadIdx.x; s < S; s += 256) d.next_units[b + s] = u0 + s;
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------
@@ -413,6 +569,7 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
   const hipstr::HostTables& HT = hipstr::host_tables();
   const int n_reads = eb->read_off[nl];
   const bool timing = getenv("HIPSTR_TIMING") != NULL;
+  const bool host_loop = getenv("HIPSTR_EM_HOST_LOOP") && atoi(getenv("HIPSTR_EM_HOST_LOOP")) != 0;       // the round-4 loop: host libm, every locus in every round
   auto t_prev = std::chrono::steady_clock::now();
   double t_gpu = 0.0, t_host = 0.0;
   auto lap = [&](const char* what, double* into){
@@ -454,9 +611,11 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
     std::vector<double> g(A, 1.0);                                     // init_log_gt_priors (:10-20)
     for (int r = r0; r < r1; r++) g[obs[r]] += 1.0/Q.reads_of_sample[eb->sample_label[r]];
     double tot = 0.0; for (int a = 0; a < A; a++) tot += g[a];
-    const double lt = log(tot);
+    // (cr_math.h's correctly rounded log on the host as well: every exp / log of the EM is the same function on either side — the host libm's
+    //  bits wherever that is correctly rounded; HIPSTR_EM_HOST_LOOP=1 takes the libm itself, as in round 4)
+    const double lt = host_loop ? log(tot) : cr_log(tot);
     Q.gtp.resize(A);
-    for (int a = 0; a < A; a++) Q.gtp[a] = log(g[a]) - lt;
+    for (int a = 0; a < A; a++) Q.gtp[a] = (host_loop ? log(g[a]) : cr_log(g[a])) - lt;
   });
   int64_t post_off = 0, ll_off = 0, prior_off = 0; int samp_off = 0;
   for (int l = 0; l < nl; l++){
@@ -501,7 +660,7 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
       dev.alloc(&d_cat, ll_off) || dev.alloc(&d_leff, ll_off) || dev.alloc(&d_part, 7*(size_t)HS_EM_PARTS*nl) || dev.alloc(&d_keep, 7*(size_t)nl)) return 1;
   h.loci = d_loci; h.active = d_active; h.logp = d_logp; h.bps = d_bps; h.obs = d_obs; h.sample_label = d_lab; h.log_p1 = d_p1; h.log_p2 = d_p2;
   h.gtp = d_gtp; h.ll = d_ll; h.prior = d_prior; h.post = d_post; h.sample_total = d_tot; h.int_log = T.int_log; h.new_ll = d_newll; h.sums = d_sums; h.row_lse = d_rowlse; h.cat = d_cat; h.leff = d_leff; h.part = d_part;
-  h.log_thresh = HT.log_thresh; h.log_half = HT.log_half; h.log_1p1 = log(1.1);
+  h.log_thresh = HT.log_thresh; h.log_half = HT.log_half; h.log_1p1 = host_loop ? log(1.1) : cr_log(1.1);
   ph.units = d_units; ph.log_aln_probs = d_ll; ph.log_p1 = d_p1; ph.log_p2 = d_p2; ph.read_weight = d_w; ph.log_prior = d_prior;
   ph.unit_active = d_unit_active; ph.log_post = d_post; ph.sample_total = d_tot; ph.map_gt = d_mapgt;
   ph.log_thresh = HT.log_thresh; ph.log_half = HT.log_half;
@@ -516,6 +675,89 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
   EM_HIP(hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking));
   EM_HIP(hipEventCreateWithFlags(&side.ev_fork, hipEventDisableTiming));
   EM_HIP(hipEventCreateWithFlags(&side.ev_join, hipEventDisableTiming));
+  if (!host_loop){
+    // ---- the device-resident loop: state, the two sets of lists (a round reads one and writes the other), two argument blocks each for
+    // the EM kernels and the posterior kernel that differ only in which set is which
+    const size_t n_units = units.size();
+    std::vector<int32_t> unit_first(nl);
+    { int32_t u = 0; for (int l = 0; l < nl; l++){ unit_first[l] = u; u += loci[l].S; } }
+    int32_t *d_list[2], *d_counts[2], *d_ulist[2], *d_ubegin, *d_ufirst, *d_iter, *d_state, *d_niter; double *d_sp, *d_curll, *d_fll;
+    if (dev.alloc(&d_list[0], nl) || dev.alloc(&d_list[1], nl) || dev.alloc(&d_counts[0], 2) || dev.alloc(&d_counts[1], 2) || dev.alloc(&d_ulist[0], n_units) ||
+        dev.alloc(&d_ulist[1], n_units) || dev.alloc(&d_ubegin, nl) || dev.put(&d_ufirst, unit_first.data(), unit_first.size()) || dev.alloc(&d_iter, nl) ||
+        dev.alloc(&d_state, nl) || dev.alloc(&d_niter, nl) || dev.alloc(&d_sp, 6*(size_t)nl) || dev.alloc(&d_curll, nl) || dev.alloc(&d_fll, nl)) return 1;
+    hs_em_dev_t hb[2]; hs_post_dev_t pb2[2];
+    for (int k = 0; k < 2; k++){
+      hb[k] = h; hb[k].active = NULL;
+      hb[k].list = d_list[k]; hb[k].counts = d_counts[k]; hb[k].next_list = d_list[k ^ 1]; hb[k].next_counts = d_counts[k ^ 1]; hb[k].next_units = d_ulist[k ^ 1];
+      hb[k].next_unit_begin = d_ubegin; hb[k].unit_first = d_ufirst; hb[k].logp_rw = d_logp; hb[k].sp = d_sp; hb[k].cur_ll = d_curll; hb[k].iter = d_iter;
+      hb[k].state = d_state; hb[k].n_iter = d_niter; hb[k].final_ll = d_fll; hb[k].max_iter = eb->max_iter; hb[k].n_loci = nl;
+      hb[k].min_abs = eb->min_ll_abs_change; hb[k].min_frac = eb->min_ll_frac_change;
+      pb2[k] = ph; pb2[k].unit_active = NULL; pb2[k].unit_list = d_ulist[k]; pb2[k].n_list = d_counts[k] + 1;
+    }
+    hs_em_dev_t* d_hb; hs_post_dev_t* d_pb;
+    if (dev.put(&d_hb, hb, 2) || dev.put(&d_pb, pb2, 2)) return 1;
+    struct Pinned { hipstr::Ctx* ctx; int32_t* p; ~Pinned(){ if (p) hipstr::pin_free(ctx, p); } } pin{T.ctx, NULL};
+    constexpr int NBUF = 4;
+    pin.p = (int32_t*)hipstr::pin_alloc(T.ctx, NBUF*2*sizeof(int32_t));
+    if (!pin.p) return 1;
+    hipEvent_t ev_cnt[NBUF] = {NULL, NULL, NULL, NULL};
+    struct EvGuard { hipEvent_t* e; int n; ~EvGuard(){ for (int i = 0; i < n; i++) if (e[i]) hipEventDestroy(e[i]); } } evg{ev_cnt, NBUF};
+    for (int i = 0; i < NBUF; i++) EM_HIP(hipEventCreateWithFlags(&ev_cnt[i], hipEventDisableTiming));
+    auto wait_event = [&](hipEvent_t e) -> hipError_t {           // without burning a core (hipEventSynchronize spins: tools/wait_probe.hip)
+      for (unsigned n = 0;; n++){
+        const hipError_t q = hipEventQuery(e);
+        if (q != hipErrorNotReady) return q;
+        if (n < 2000) sched_yield(); else usleep(20);
+      }
+    };
+    lap("device-loop state", NULL);
+    const unsigned g_loci = (unsigned)((nl + 255)/256);
+    // the starting state, and the lists of round 0 (written through block 1, whose "next" set is block 0's current one)
+    hipLaunchKernelGGL(hs_em_init, dim3(g_loci), dim3(256), 0, T.stream, (const hs_em_dev_t*)(d_hb + 1));
+    hipLaunchKernelGGL(hs_em_compact, dim3(1), dim3(1024), 0, T.stream, (const hs_em_dev_t*)(d_hb + 1));
+    hipLaunchKernelGGL(hs_em_units, dim3(nl), dim3(256), 0, T.stream, (const hs_em_dev_t*)(d_hb + 1));
+    unsigned bound_l = (unsigned)nl, bound_u = (unsigned)n_units;
+    int rounds = 0;
+    for (int r = 0; r <= eb->max_iter + 1; r++){
+      const hs_em_dev_t* H = d_hb + (r & 1); const hs_post_dev_t* PH = d_pb + (r & 1);
+      if (bound_l > 0){
+        hipLaunchKernelGGL(hs_em_fill, dim3(bound_l), dim3(256), 0, T.stream, H);
+        hipLaunchKernelGGL(hs_posterior_kernel, dim3(std::max(1u, bound_u)), dim3(256), 0, T.stream, PH);
+        EM_HIP(hipEventRecord(side.ev_fork, T.stream));                  // posteriors are in place: the allele-frequency scans branch off
+        EM_HIP(hipStreamWaitEvent(side.stream, side.ev_fork, 0));
+        hipLaunchKernelGGL(hs_em_gt_priors, dim3(bound_l), dim3(256), HS_EM_CHUNK*HS_EM_MAXA_LDS*sizeof(double), side.stream, H);
+        EM_HIP(hipEventRecord(side.ev_join, side.stream));
+        hipLaunchKernelGGL(hs_em_mstep_part<0>, dim3(bound_l, HS_EM_PARTS), dim3(256), 0, T.stream, H, (const double*)NULL);
+        hipLaunchKernelGGL(hs_em_mstep_keepmax, dim3(bound_l), dim3(64), 0, T.stream, H, d_keep);
+        hipLaunchKernelGGL(hs_em_mstep_part<1>, dim3(bound_l, HS_EM_PARTS), dim3(256), 0, T.stream, H, (const double*)d_keep);
+        hipLaunchKernelGGL(hs_em_finish, dim3(bound_l), dim3(64), 0, T.stream, H, (const double*)d_keep);
+        EM_HIP(hipStreamWaitEvent(T.stream, side.ev_join, 0));            // the next round's hs_em_fill reads the new allele frequencies
+        hipLaunchKernelGGL(hs_em_compact, dim3(1), dim3(1024), 0, T.stream, H);
+        hipLaunchKernelGGL(hs_em_units, dim3(bound_l), dim3(256), 0, T.stream, H);
+        rounds++;
+      }
+      EM_HIP(hipMemcpyAsync(pin.p + 2*(r % NBUF), d_counts[(r & 1) ^ 1], 2*sizeof(int32_t), hipMemcpyDeviceToHost, T.stream));
+      EM_HIP(hipEventRecord(ev_cnt[r % NBUF], T.stream));
+      EM_HIP(hipGetLastError());
+      if (r >= 1){
+        // what round r - 1 left: the loci (and units) of round r — a bound for the grids of round r + 1, and the stop signal — while
+        // round r is already queued
+        EM_HIP(wait_event(ev_cnt[(r - 1) % NBUF]));
+        bound_l = (unsigned)pin.p[2*((r - 1) % NBUF)]; bound_u = (unsigned)pin.p[2*((r - 1) % NBUF) + 1];
+        if (bound_l == 0) break;
+      }
+    }
+    EM_HIP(hipstr::wait_stream(T.stream));
+    lap("device loop", &t_gpu);
+    std::vector<int32_t> state(nl), niter(nl);
+    EM_HIP(hipMemcpy(state.data(), d_state, nl*sizeof(int32_t), hipMemcpyDeviceToHost));
+    EM_HIP(hipMemcpy(niter.data(), d_niter, nl*sizeof(int32_t), hipMemcpyDeviceToHost));
+    EM_HIP(hipMemcpy(final_ll, d_fll, nl*sizeof(double), hipMemcpyDeviceToHost));
+    EM_HIP(hipMemcpy(stutter, d_sp, 6*(size_t)nl*sizeof(double), hipMemcpyDeviceToHost));
+    for (int l = 0; l < nl; l++){ trained[l] = state[l] == 1 ? 1 : 0; n_iter[l] = niter[l]; }
+    if (timing) fprintf(stderr, "hipstr_em_train: device-resident loop, %d rounds queued: %.3f ms\n", rounds, 1e3*t_gpu);
+    return 0;
+  }
   // ---- the EM loop of train() (:171-226), all loci in lock step, converged loci masked out
   struct State { double sp[6]; double LL; int it; bool done, ok; };
   std::vector<State> st(nl);
@@ -549,7 +791,7 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
     hipLaunchKernelGGL(hs_posterior_kernel, dim3((unsigned)units.size()), dim3(256), 0, T.stream, (const hs_post_dev_t*)d_ph);
     EM_HIP(hipEventRecord(side.ev_fork, T.stream));                      // posteriors are in place: the allele-frequency scans branch off
     EM_HIP(hipStreamWaitEvent(side.stream, side.ev_fork, 0));
-    hipLaunchKernelGGL(hs_em_gt_priors, dim3(nl), dim3(256), 0, side.stream, d_h);
+    hipLaunchKernelGGL(hs_em_gt_priors, dim3(nl), dim3(256), HS_EM_CHUNK*HS_EM_MAXA_LDS*sizeof(double), side.stream, d_h);
     EM_HIP(hipEventRecord(side.ev_join, side.stream));
     hipLaunchKernelGGL(hs_em_mstep_part<0>, dim3(nl, HS_EM_PARTS), dim3(256), 0, T.stream, d_h, (const double*)NULL);
     hipLaunchKernelGGL(hs_em_mstep_keepmax, dim3(nl), dim3(64), 0, T.stream, d_h, d_keep);

@@ -5,13 +5,17 @@
 // (a1,a2) and walks the sample's reads in read order, so the scatter-add of the reference
 // becomes a private sequential accumulation with the reference's exact operation order
 // (bit-identical, including the float pair log-sum-exp of mathops.cpp:86-95).  The final
-// exact log-sum-exp over the A^2 diplotypes (mathops.cpp:44-50) is a wavefront + LDS tree
-// reduction; it differs from the reference's sequential libm sum only by rounding
-// (|diff| <~ 1e-13, tolerance stated in tests/test_posteriors_gpu.py).
+// exact log-sum-exp over the A^2 diplotypes (mathops.cpp:44-50) — round 5: the exponentials are CORRECTLY ROUNDED (cr_math.h), computed
+// by all threads, and summed by one thread in the reference's index order, so the total and the normalised posteriors have the host's
+// bits wherever the host's libm is itself correctly rounded (glibc: all but ~8 in 10^4 exp arguments, ~1 in 10^5 log arguments;
+// tests/test_cr_math.py).  What the genotype stage's FLOAT pair log-sum-exps are fed is therefore what the reference feeds them.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "post_layout.h"
+#include "cr_math.h"
+
+#define HS_POST_ECHUNK 2048
 
 namespace {
 
@@ -48,14 +52,17 @@ __device__ __forceinline__ double fast_lse2(double a, double b, double thr){    
 // which thread owns it and phase 2 is phase 0's second half on the same values, so the results are bit-identical however a batch is split.
 template <int PHASE>
 __device__ __forceinline__ void posterior_body(const hs_post_dev_t& d){
-  if (d.unit_active && !d.unit_active[blockIdx.x]) return;
-  const hs_post_unit_t u = d.units[blockIdx.x];
+  int ub = blockIdx.x;
+  if (d.unit_list){ if (ub >= *d.n_list) return; ub = d.unit_list[ub]; }
+  if (d.unit_active && !d.unit_active[ub]) return;
+  const hs_post_unit_t u = d.units[ub];
   const int A = u.n_alleles, nd = A*A, tid = threadIdx.x;
   double* post = d.log_post + u.post_off;
   const double* LL0 = d.log_aln_probs + u.ll_off;      // row of the sample's first read
 
   __shared__ double red_v[256];
   __shared__ int    red_i[256];
+  __shared__ double ebuf[HS_POST_ECHUNK];              // a chunk of exponentials, summed in index order by thread 0
 
   // ---- accumulate (genotyper.cpp:47-61)
   double lmax = -1.0e300;
@@ -78,15 +85,39 @@ __device__ __forceinline__ void posterior_body(const hs_post_dev_t& d){
     for (int idx = tid; idx < nd; idx += 256) lmax = fmax(lmax, post[idx]);
   }
   if (d.raw) return;          // (debug) the host normalises
-  // ---- exact log-sum-exp over diplotypes (genotyper.cpp:63-72)
+  // ---- exact log-sum-exp over diplotypes (genotyper.cpp:63-72, mathops.cpp:44-50): max, then total += exp(v - max) in index order
   red_v[tid] = lmax; __syncthreads();
   for (int s = 128; s > 0; s >>= 1){ if (tid < s) red_v[tid] = fmax(red_v[tid], red_v[tid+s]); __syncthreads(); }
   const double mx = red_v[0]; __syncthreads();
-  double lsum = 0.0;
-  for (int idx = tid; idx < nd; idx += 256) lsum += exp(post[idx] - mx);
-  red_v[tid] = lsum; __syncthreads();
-  for (int s = 128; s > 0; s >>= 1){ if (tid < s) red_v[tid] += red_v[tid+s]; __syncthreads(); }
-  const double total = mx + log(red_v[0]); __syncthreads();
+  // first index that holds the maximum: from there on the running total is >= 1, and a term below 2^-54 (v - max < -37.43) cannot
+  // change it — RN(total + t) = total — so its exponential need not be formed (it is added as +0.0: the same bits).  In front of it every
+  // exponential counts (the running total may still be tiny).
+  int fi = 0x7fffffff;
+  for (int idx = tid; idx < nd; idx += 256) if (post[idx] == mx){ fi = idx; break; }
+  red_i[tid] = fi; __syncthreads();
+  for (int s = 128; s > 0; s >>= 1){ if (tid < s) red_i[tid] = min(red_i[tid], red_i[tid+s]); __syncthreads(); }
+  const int first_max = red_i[0]; __syncthreads();
+  double lsum = 0.0;                                      // (thread 0's)
+  for (int base = 0; base < nd; base += HS_POST_ECHUNK){
+    const int cnt = min(HS_POST_ECHUNK, nd - base);
+    for (int k = tid; k < cnt; k += 256){
+      const double x = post[base + k] - mx;
+      ebuf[k] = (base + k > first_max && x < -37.43) ? 0.0 : cr_exp(x);
+    }
+    __syncthreads();
+    if (tid == 0){
+      int k = 0;
+      for (; k + 8 <= cnt; k += 8){                       // the loads of a group ahead of its (dependent) additions
+        const double e0 = ebuf[k], e1 = ebuf[k+1], e2 = ebuf[k+2], e3 = ebuf[k+3], e4 = ebuf[k+4], e5 = ebuf[k+5], e6 = ebuf[k+6], e7 = ebuf[k+7];
+        lsum += e0; lsum += e1; lsum += e2; lsum += e3; lsum += e4; lsum += e5; lsum += e6; lsum += e7;
+      }
+      for (; k < cnt; k++) lsum += ebuf[k];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) red_v[0] = mx + cr_log(lsum);
+  __syncthreads();
+  const double total = red_v[0]; __syncthreads();
   // ---- normalise + MAP diplotype: first maximum in a1-major order (genotyper.cpp:88-95)
   double bv = -1.7976931348623157e308; int bi = 0x7fffffff;
   for (int idx = tid; idx < nd; idx += 256){
@@ -120,7 +151,7 @@ extern "C" __global__ void __launch_bounds__(256) hs_posterior_finish_kernel(con
 // Genotyper::extract_genotypes_and_likelihoods (genotyper.cpp:129-251), calc_PLs (99-104), calc_gl_diff (106-127).
 // One workgroup per (locus, sample).  A thread owns genotypes (v1, v2) and streams over the haplotype pairs that map to
 // them in the reference's scan order (index_1 ascending, then index_2), so update_streaming_log_sum_exp (mathops.cpp:72-80)
-// sees the same sequence; device exp/log differ from the host libm in the last bits (tolerance in tests/test_genotypes_gpu.py).
+// sees the same sequence; exp / log are the correctly rounded ones of cr_math.h: the host libm's bits wherever that is correctly rounded.
 extern "C" __global__ void __launch_bounds__(256)
 hs_genotype_kernel(const hs_gt_dev_t* __restrict__ dp){
   const hs_gt_dev_t& d = *dp;
@@ -143,11 +174,12 @@ hs_genotype_kernel(const hs_gt_dev_t* __restrict__ dp){
       const double* row = post + (int64_t)gmem[x]*A;
       for (int y = goff[v2]; y < goff[v2+1]; y++){
         const double lv = row[gmem[y]];
-        if (lv <= mx) tot += exp(lv - mx);
-        else { tot *= exp(mx - lv); tot += 1.0; mx = lv; }
+        // (once a maximum has been set the total is >= 1: a term below 2^-54 leaves it as it is, bit for bit — its exponential is not formed)
+        if (lv <= mx){ const double x = lv - mx; if (!(tot >= 1.0 && x < -37.43)) tot += cr_exp(x); }
+        else { tot *= cr_exp(mx - lv); tot += 1.0; mx = lv; }
       }
     }
-    T[gt] = mx + log(tot);
+    T[gt] = mx + cr_log(tot);
   }
   __syncthreads();
 
@@ -173,7 +205,7 @@ hs_genotype_kernel(const hs_gt_dev_t* __restrict__ dp){
     if (ga == gb) d.log_unphased[s] = lp;
     else {
       const double alt = T[V*gb + ga];                 // exact pair log_sum_exp (mathops.cpp:52-57)
-      d.log_unphased[s] = (lp > alt) ? lp + log(1 + exp(alt - lp)) : alt + log(1 + exp(lp - alt));
+      d.log_unphased[s] = (lp > alt) ? lp + cr_log(1 + cr_exp(alt - lp)) : alt + cr_log(1 + cr_exp(lp - alt));
     }
   }
   if (!d.calc_any) return;
@@ -216,4 +248,11 @@ hs_genotype_kernel(const hs_gt_dev_t* __restrict__ dp){
   }
   if (d.calc_pls)
     for (int g = tid; g < ngl; g += 256) d.pls[u.gl_off + g] = min(999, (int)(-10*(gls[g] - max_gl)));
+}
+
+
+// tests: cr_math.h on the device, element by element (tests/test_cr_math_gpu.py compares with the same header compiled for the host)
+extern "C" __global__ void __launch_bounds__(256) hs_cr_math_kernel(int which, const double* __restrict__ x, double* __restrict__ y, int64_t n){
+  const int64_t i = (int64_t)blockIdx.x*256 + threadIdx.x;
+  if (i < n) y[i] = which ? cr_log(x[i]) : cr_exp(x[i]);
 }

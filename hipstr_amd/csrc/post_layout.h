@@ -28,6 +28,10 @@ struct hs_post_dev_t {
   int32_t*       map_gt;
   double         log_thresh, log_half;
   int32_t        raw;            // HIPSTR_DEBUG_HOST_LIBM: leave the accumulated log P(reads, diplotype) unnormalised — the host takes the log-sum-exp with its libm
+  // optional indirection (the device-resident EM loop, em.hip): workgroup b takes unit unit_list[b] if b < *n_list and leaves otherwise —
+  // the launch is sized by a bound the host knows, the live units by a count only the device knows.  NULL = workgroup b takes unit b.
+  const int32_t* unit_list;
+  const int32_t* n_list;
 };
 
 // One (locus, sample) pair of the genotype extraction (Genotyper::extract_genotypes_and_likelihoods, genotyper.cpp:129-251).

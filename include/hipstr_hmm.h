@@ -502,8 +502,13 @@ int64_t hipstr_debug_driver_allocs(void);
  * blocks, blocks in use, the cap on idle bytes (HIPSTR_DEV_CACHE_GIB, default 70 % of the device's memory); out[4..7] the same for pinned
  * host memory (HIPSTR_PIN_CACHE_GIB, default 24).  A release that leaves more idle bytes than the cap gives the chunks without a block in
  * use back to the driver; when the driver refuses a new chunk a request is served from any free block that is large enough, then after
- * trimming idle chunks; only then does it fail. */
-int hipstr_debug_cache_stats(int64_t out[8]);
+ * trimming idle chunks; only then does it fail.  out[8], out[9]: driver refusals the device cache survived by the first / the second way;
+ * out[10], out[11]: the pinned cache's. */
+int hipstr_debug_cache_stats(int64_t out[12]);
+/* Diagnostics (tests): the correctly rounded exp (which = 0) / log (1) of hipstr_amd/csrc/cr_math.h evaluated ON THE DEVICE, element by
+ * element — the functions the posterior, genotype and EM kernels use in place of the device's own exp / log so that they reproduce
+ * the host libm's bits. */
+int hipstr_debug_cr_math(int which, const double* x, double* y, int64_t n);
 /* Diagnostics: (realigned allele, side) pairs of a batch by the STR kernel that takes them: counts[1] periodic blocks (tabulated closed form),
  * counts[2] blocks with one or two interruptions (piecewise closed form), counts[3] more interruptions (lists replayed in the grouped layout),
  * counts[0] the rest (per-read kernel). */

@@ -25,6 +25,7 @@
  */
 #include <float.h>
 #include <math.h>
+#include "../hipstr_amd/csrc/cr_math.h"
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -77,6 +78,16 @@ static int qual_index(char q){            /* base_quality.h:44-75 clamps */
 /* ------------------------------------------- float approximations (A.5) */
 static float bits_to_float(uint32_t u){ float f; memcpy(&f, &u, 4); return f; }
 static uint32_t float_to_bits(float f){ uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* exp / log of the posterior, genotype-call and EM stages: the host libm's (what the reference calls; the default), or — oracle_set_cr_math(1) —
+ * the correctly rounded ones of hipstr_amd/csrc/cr_math.h, the functions the device kernels evaluate.  With the switch on this file is an
+ * operation-for-operation CPU restatement of the device path, and the two settings agree wherever the host libm is itself correctly
+ * rounded (tests/test_cr_math.py: all but ~8 in 10^4 exp and ~1 in 10^5 log arguments with glibc).  The model tables of oracle_init are
+ * the host libm's in either setting (the library builds them on the host as well). */
+static int g_cr_math = 0;
+void oracle_set_cr_math(int on){ g_cr_math = on; }
+#define X_EXP(x) (g_cr_math ? cr_exp(x) : exp(x))
+#define X_LOG(x) (g_cr_math ? cr_log(x) : log(x))
 
 static float o_fasterexp(float p){                   /* fastonebigheader.h:206-218 */
   float y = 1.442695040f * p;
@@ -132,8 +143,8 @@ double oracle_log_sum_exp(const double* v, int n){   /* mathops.cpp:44-50 (exact
   double m = v[0];
   for (int i = 1; i < n; i++) if (v[i] > m) m = v[i];
   double total = 0.0;
-  for (int i = 0; i < n; i++) total += exp(v[i] - m);
-  return m + log(total);
+  for (int i = 0; i < n; i++) total += X_EXP(v[i] - m);
+  return m + X_LOG(total);
 }
 
 double oracle_int_log(int v){ oracle_init(); return g_int_log[v]; }
@@ -146,9 +157,9 @@ double oracle_base_quality(int q, int correct){ oracle_init(); return correct ? 
 
 /* stutter_model.cpp:29-53 + ctor logs (stutter_model.h:31-60) */
 double oracle_stutter_pmf(const double* sp, int period, int sample_bps, int read_bps){
-  double in_step = log(1-sp[0]), in_nostep = log(sp[0]), in_up = log(sp[1]), in_down = log(sp[2]);
-  double out_step = log(1-sp[3]), out_nostep = log(sp[3]), out_up = log(sp[4]), out_down = log(sp[5]);
-  double log_equal = log(1-sp[1]-sp[2]-sp[4]-sp[5]);
+  double in_step = X_LOG(1-sp[0]), in_nostep = X_LOG(sp[0]), in_up = X_LOG(sp[1]), in_down = X_LOG(sp[2]);
+  double out_step = X_LOG(1-sp[3]), out_nostep = X_LOG(sp[3]), out_up = X_LOG(sp[4]), out_down = X_LOG(sp[5]);
+  double log_equal = X_LOG(1-sp[1]-sp[2]-sp[4]-sp[5]);
   int bp_diff = read_bps - sample_bps;
   if (bp_diff % period != 0){
     int eff = bp_diff - (bp_diff/period);
@@ -900,7 +911,7 @@ int oracle_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, double* stutt
     /* init_log_gt_priors (:10-20) */
     for (int a = 0; a < A; a++) gtp[a] = 1;
     for (int r = 0; r < R; r++) gtp[ai[r]] += 1.0/per_sample[lab[r]];
-    { double tot = 0; for (int a = 0; a < A; a++) tot += gtp[a]; double lt = log(tot); for (int a = 0; a < A; a++) gtp[a] = log(gtp[a]) - lt; }
+    { double tot = 0; for (int a = 0; a < A; a++) tot += gtp[a]; double lt = X_LOG(tot); for (int a = 0; a < A; a++) gtp[a] = X_LOG(gtp[a]) - lt; }
     OModel m = { 0.9, 0.1, 0.1, 0.8, 0.01, 0.01 };                       /* init_stutter_model (:59-62) */
     int it = 1, ok = 0, done = 0; double LL = -DBL_MAX, new_LL = 0;
     int32_t one_A = A, one_S = S, roff[2] = { 0, R }; uint8_t hp = (uint8_t)hap;
@@ -930,7 +941,7 @@ int oracle_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, double* stutt
           stream_update(oracle_log_sum_exp(post + ((size_t)s*A + i1)*A, A), &mx[i1], &tt[i1]);
         for (int s = 0; s < S; s++) for (int i1 = 0; i1 < A; i1++) for (int i2 = 0; i2 < A; i2++)
           stream_update(post[((size_t)s*A + i1)*A + i2], &mx[i2], &tt[i2]);
-        for (int a = 0; a < A; a++) gtp[a] = mx[a] + log(tt[a]);
+        for (int a = 0; a < A; a++) gtp[a] = mx[a] + X_LOG(tt[a]);
         double lt = oracle_log_sum_exp(gtp, A);
         for (int a = 0; a < A; a++) gtp[a] -= lt;
         free(mx); free(tt);
@@ -941,8 +952,8 @@ int oracle_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, double* stutt
         size_t cap = (size_t)R*A*A*2 + 4;
         double* v[7]; size_t n[7];                   /* in_up, in_down, in_eq, in_diffs, out_up, out_down, out_diffs */
         for (int k = 0; k < 7; k++){ v[k] = malloc(sizeof(double)*cap); n[k] = 0; }
-        v[0][n[0]++] = 0.0; v[1][n[1]++] = 0.0; v[3][n[3]++] = 0.0; v[3][n[3]++] = log(1.1);
-        v[4][n[4]++] = 0.0; v[5][n[5]++] = 0.0; v[6][n[6]++] = 0.0; v[6][n[6]++] = log(1.1);
+        v[0][n[0]++] = 0.0; v[1][n[1]++] = 0.0; v[3][n[3]++] = 0.0; v[3][n[3]++] = X_LOG(1.1);
+        v[4][n[4]++] = 0.0; v[5][n[5]++] = 0.0; v[6][n[6]++] = 0.0; v[6][n[6]++] = X_LOG(1.1);
         v[2][n[2]++] = 0.0;
         for (int r = 0; r < R; r++){
           const double* gp = post + (size_t)lab[r]*A*A;
@@ -965,13 +976,13 @@ int oracle_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, double* stutt
         double t[7];
         for (int k = 0; k < 7; k++){ t[k] = oracle_fast_lse_vec(v[k], (int)n[k]); free(v[k]); }
         double out_total = oracle_fast_lse2(t[4], t[5]);
-        double in_pgeom = fmin(0.999, exp(exact_lse2(t[0], t[1]) - t[3]));
-        double out_pgeom = fmin(0.999, exp(out_total - t[6]));
+        double in_pgeom = fmin(0.999, X_EXP(exact_lse2(t[0], t[1]) - t[3]));
+        double out_pgeom = fmin(0.999, X_EXP(out_total - t[6]));
         double mx3 = fmax(fmax(t[0], t[1]), t[2]);
-        double lse3 = mx3 + log(exp(t[0]-mx3) + exp(t[1]-mx3) + exp(t[2]-mx3));       /* mathops.cpp:59-62 */
+        double lse3 = mx3 + X_LOG(X_EXP(t[0]-mx3) + X_EXP(t[1]-mx3) + X_EXP(t[2]-mx3));       /* mathops.cpp:59-62 */
         double log_total = exact_lse2(lse3, out_total);
-        m.in_geom = in_pgeom; m.in_up = exp(t[0] - log_total); m.in_down = exp(t[1] - log_total);
-        m.out_geom = out_pgeom; m.out_up = exp(t[4] - log_total); m.out_down = exp(t[5] - log_total);
+        m.in_geom = in_pgeom; m.in_up = X_EXP(t[0] - log_total); m.in_down = X_EXP(t[1] - log_total);
+        m.out_geom = out_pgeom; m.out_up = X_EXP(t[4] - log_total); m.out_down = X_EXP(t[5] - log_total);
       }
       double abs_change = new_LL - LL, frac_change = -(new_LL - LL)/LL;
       int conv = 0;
@@ -993,11 +1004,11 @@ int oracle_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, double* stutt
 /* ---------------------------------------------- genotype calls (A.9)
  * Genotyper::extract_genotypes_and_likelihoods (genotyper.cpp:129-251), calc_PLs (99-104), calc_gl_diff (106-127). */
 static void stream_update(double lv, double* mx, double* tot){          /* mathops.cpp:72-80 */
-  if (lv <= *mx) *tot += exp(lv - *mx);
-  else { *tot *= exp(*mx - lv); *tot += 1.0; *mx = lv; }
+  if (lv <= *mx) *tot += X_EXP(lv - *mx);
+  else { *tot *= X_EXP(*mx - lv); *tot += 1.0; *mx = lv; }
 }
 static double exact_lse2(double a, double b){                           /* mathops.cpp:52-57 */
-  return a > b ? a + log(1 + exp(b - a)) : b + log(1 + exp(a - b));
+  return a > b ? a + X_LOG(1 + X_EXP(b - a)) : b + X_LOG(1 + X_EXP(a - b));
 }
 
 int oracle_gt_extract(const hipstr_post_batch_t* pb, const hipstr_gt_request_t* rq, hipstr_gt_out_t* o){
@@ -1027,7 +1038,7 @@ int oracle_gt_extract(const hipstr_post_batch_t* pb, const hipstr_gt_request_t* 
       for (int i = 0; i < V*V; i++){ mx[i] = -DBL_MAX/2; T[i] = 0.0; }
       for (int i1 = 0; i1 < A; i1++)
         for (int i2 = 0; i2 < A; i2++){ int gi = V*h2a[i1] + h2a[i2]; stream_update(P[(int64_t)i1*A + i2], &mx[gi], &T[gi]); }
-      for (int i = 0; i < V*V; i++) T[i] = mx[i] + log(T[i]);
+      for (int i = 0; i < V*V; i++) T[i] = mx[i] + X_LOG(T[i]);
       int ha = o->best_hap[2*so], hb = o->best_hap[2*so+1];
       int ga = h2a[ha], gb = h2a[hb];
       o->best_gt[2*so] = ga; o->best_gt[2*so+1] = gb;

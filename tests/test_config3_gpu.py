@@ -82,9 +82,15 @@ def test_config3_full_size(hmm, oracle):
         plo = int(pb.post_off[l])
         assert np.array_equal(p1, post[plo:plo + p1.size]) and np.array_equal(t1, tot[l * S:(l + 1) * S]) and np.array_equal(g1.reshape(-1, 2), gt[l * S:(l + 1) * S])
         wp = capi.run_posteriors(oracle, "oracle_", pb1)
-        assert np.array_equal(g1.reshape(-1, 2), wp[2]) and np.all(np.abs(p1 - wp[0]) <= 1e-9 * np.maximum(1, np.abs(wp[0]))) and np.all(np.abs(t1 - wp[1]) <= 1e-9 * np.maximum(1, np.abs(wp[1])))
+        def cr_post():
+            with capi.oracle_cr_math(oracle):
+                return capi.run_posteriors(oracle, "oracle_", pb1)
+        util.assert_arrays_exact((p1, t1, g1.reshape(-1, 2)), wp[:3], cr_post, "configs[2] locus %d posteriors" % l)
         h2a = np.arange(Al, dtype=np.int32)
-        util.assert_genotypes_close(capi.run_gt_extract(hmm, "hipstr_", pb1, [Al], h2a), capi.run_gt_extract(oracle, "oracle_", pb1, [Al], h2a), 1e-9,
+        def cr():
+            with capi.oracle_cr_math(oracle):
+                return capi.run_gt_extract(oracle, "oracle_", pb1, [Al], h2a)
+        util.assert_genotypes_exact(capi.run_gt_extract(hmm, "hipstr_", pb1, [Al], h2a), capi.run_gt_extract(oracle, "oracle_", pb1, [Al], h2a), cr,
                                     "configs[2] locus %d" % l, verify=(oracle, pb1, [Al], h2a))
     # ---- stutter EM: all loci in lock step, twice; every 500th locus alone and against the oracle
     kw = bench.c3_em_inputs(big, NL, P, S)

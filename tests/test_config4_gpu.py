@@ -1,7 +1,7 @@
 """GPU: the per-locus shape of BASELINE configs[3] (1000 samples per locus) — posteriors, genotype calls and the stutter EM at
 S = 1000, and at A = 128 candidate haplotypes with >= 20 reads per sample — against the oracle.  hs_posterior_kernel runs one
 workgroup per (locus, sample): these are the fan-outs (1000-3000 workgroups per locus, 16 K diplotypes per workgroup) the
-smaller tests never reach.  Tolerances as in test_posteriors_gpu.py / test_genotypes_gpu.py / test_em_gpu.py."""
+smaller tests never reach.  Posteriors and genotype calls: bit for bit (util.assert_arrays_exact / assert_genotypes_exact, round 5); EM as in test_em_gpu.py."""
 import numpy as np
 import pytest
 
@@ -43,12 +43,17 @@ def test_posteriors_and_calls_1000_samples_128_haplotypes(hmm, oracle):
         assert hmm.hipstr_post_run(pb.ptr, None, post.ctypes.data_as(capi._f64p), tot.ctypes.data_as(capi._f64p),
                                    gt.ctypes.data_as(capi._i32p), lt.ctypes.data_as(capi._f64p)) == 0, hmm.hipstr_last_error()
         got = (post, tot, gt.reshape(-1, 2), lt)
-    assert _close(got[0], want[0]) and _close(got[1], want[1]) and _close(got[3], want[3])
-    assert np.array_equal(got[2], want[2])
+    def cr_post():
+        with capi.oracle_cr_math(oracle):
+            return capi.run_posteriors(oracle, "oracle_", pb)
+    util.assert_arrays_exact(got, want, cr_post, "posteriors S = 1000, A = 128")
     h2a = (np.arange(A) // 2) % V                    # 2 x 32 x 2 flank options around 32 STR alleles
     want_gt = capi.run_gt_extract(oracle, "oracle_", pb, [V], h2a)
     got_gt = capi.run_gt_extract(hmm, "hipstr_", pb, [V], h2a)
-    util.assert_genotypes_close(got_gt, want_gt, TOL, verify=(oracle, pb, [V], h2a))
+    def cr():
+        with capi.oracle_cr_math(oracle):
+            return capi.run_gt_extract(oracle, "oracle_", pb, [V], h2a)
+    util.assert_genotypes_exact(got_gt, want_gt, cr, "calls S = 1000, A = 128", verify=(oracle, pb, [V], h2a))
 
 
 def test_posteriors_and_calls_1000_samples_several_loci(hmm, oracle):
@@ -59,10 +64,16 @@ def test_posteriors_and_calls_1000_samples_several_loci(hmm, oracle):
     post = np.zeros(int(pb.post_off[-1])); tot = np.zeros(3 * S); gt = np.zeros(6 * S, np.int32); lt = np.zeros(3)
     assert hmm.hipstr_post_run(pb.ptr, None, post.ctypes.data_as(capi._f64p), tot.ctypes.data_as(capi._f64p),
                                gt.ctypes.data_as(capi._i32p), lt.ctypes.data_as(capi._f64p)) == 0, hmm.hipstr_last_error()
-    assert _close(post, want[0]) and _close(tot, want[1]) and np.array_equal(gt.reshape(-1, 2), want[2]) and _close(lt, want[3])
+    def cr_post():
+        with capi.oracle_cr_math(oracle):
+            return capi.run_posteriors(oracle, "oracle_", pb)
+    util.assert_arrays_exact((post, tot, gt.reshape(-1, 2), lt), want, cr_post, "posteriors 3 x 1000 samples")
     h2a = np.tile((np.arange(A) // 2) % V, 3)
-    util.assert_genotypes_close(capi.run_gt_extract(hmm, "hipstr_", pb, [V] * 3, h2a),
-                                capi.run_gt_extract(oracle, "oracle_", pb, [V] * 3, h2a), TOL, verify=(oracle, pb, [V] * 3, h2a))
+    def cr():
+        with capi.oracle_cr_math(oracle):
+            return capi.run_gt_extract(oracle, "oracle_", pb, [V] * 3, h2a)
+    util.assert_genotypes_exact(capi.run_gt_extract(hmm, "hipstr_", pb, [V] * 3, h2a),
+                                capi.run_gt_extract(oracle, "oracle_", pb, [V] * 3, h2a), cr, "calls 3 x 1000 samples", verify=(oracle, pb, [V] * 3, h2a))
 
 
 def test_stutter_em_1000_samples(hmm, oracle):

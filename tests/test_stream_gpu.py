@@ -157,6 +157,49 @@ def test_multi_device_blocks_in_global_order(hmm):
     lib.hipstr_multi_close(m)
 
 
+def test_multi_deals_blocks_by_estimated_work(hmm):
+    """hipstr_multi_submit sends a new block to the device that has been dealt the least WORK (hipstr_locus_costs: interrupted repeats cost
+    several times a periodic locus' pairs), not round robin by pair counts: periodic loci first, then loci whose every allele inherits two
+    interruptions — the expensive blocks spread over the streams, the dealt totals end up close, results in global order and identical."""
+    import ctypes as C
+    import os
+    lib = hmm; _multi_sigs(lib)
+    lib.hipstr_multi_dealt.restype = C.c_int; lib.hipstr_multi_dealt.argtypes = [C.c_void_p, capi._f64p, C.c_int32]
+    cheap = capi.SynthBatch(n_loci=24, reads_per_locus=20, n_str_alleles=6, seed=41)
+    os.environ["HIPSTR_SYNTH_INHERIT"] = "2"
+    try:
+        dear = capi.SynthBatch(n_loci=12, reads_per_locus=20, n_str_alleles=6, seed=42)
+    finally:
+        del os.environ["HIPSTR_SYNTH_INHERIT"]
+    pc, pd = _pieces(cheap, list(range(25))), _pieces(dear, list(range(13)))
+    cc, cd = shard.locus_costs(util.synth_to_batch(cheap).arrays), shard.locus_costs(util.synth_to_batch(dear).arrays)
+    assert cd.mean() > 2.0 * cc.mean()
+    # cheap, cheap, dear, cheap, cheap, dear ...: round robin over three streams would hand every dear locus to the third
+    pieces, costs = [], []
+    for k in range(12):
+        pieces += [pc[2*k], pc[2*k + 1], pd[k]]; costs += [cc[2*k], cc[2*k + 1], cd[k]]
+    costs = np.array(costs)
+    want = [capi.run_align(hmm, "hipstr_hmm_", p.ptr, fill=FILL) for p in pieces]
+    devs = np.zeros(3, np.int32)
+    m = lib.hipstr_multi_open(3, devs.ctypes.data_as(capi._i32p), 100, None)          # every locus (120 pairs) its own block
+    assert m, lib.hipstr_last_error()
+    for i, p in enumerate(pieces):
+        assert lib.hipstr_multi_submit(m, p.ptr) == i
+    dealt = np.zeros(3)
+    assert lib.hipstr_multi_dealt(m, dealt.ctypes.data_as(capi._f64p), 3) == 3
+    assert abs(dealt.sum() - costs.sum()) < 1e-6 * costs.sum()
+    assert dealt.max() - dealt.min() <= costs.max() * (1 + 1e-9), dealt               # greedy by least work: never further apart than one block
+    rr = np.array([costs[k::3].sum() for k in range(3)])                               # what round robin would have dealt
+    assert rr.max() - rr.min() > 3 * (dealt.max() - dealt.min())
+    for i, (wp, ws) in enumerate(want):
+        t = C.c_int64(); no = C.c_int64(); nr = C.c_int64()
+        assert lib.hipstr_multi_next_size(m, C.byref(t), C.byref(no), C.byref(nr)) == 0 and t.value == i
+        probs = np.full(max(no.value, 1), FILL); seeds = np.full(max(nr.value, 1), -7, np.int32)
+        assert lib.hipstr_multi_next(m, C.byref(t), probs.ctypes.data_as(capi._f64p), probs.size, seeds.ctypes.data_as(capi._i32p), seeds.size) == 0, lib.hipstr_last_error()
+        assert np.array_equal(probs[:no.value], wp) and np.array_equal(seeds[:nr.value], ws)
+    lib.hipstr_multi_close(m)
+
+
 def test_submit_each_and_collect(hmm):
     """The C-side region loop: every locus of a shard its own submission, a shard's results collected back to back."""
     sb = capi.SynthBatch(n_loci=25, reads_per_locus=18, n_str_alleles=5, seed=41, mask_rate=0.15)

@@ -11,6 +11,9 @@ done
 echo "== libflow_ref.so (CPU) --loci 96 --threads 1 / 16" >> $O/flow_rates.txt
 $L oracle/_ref/libflow_ref.so --loci 96 --seed 100 --threads 1 --profile >> $O/flow_rates.txt 2>&1
 $L oracle/_ref/libflow_ref.so --loci 96 --seed 100 --threads 16 >> $O/flow_rates.txt 2>&1
+# the CPU reference on the SAME loci as the MI355X rate rows below (16 threads: 768 loci take ~3 s): every rate row has a CPU digest beside it
+echo "== libflow_ref.so (CPU) --loci ${FLOW_RATE_LOCI:-768} --threads 16" >> $O/flow_rates.txt
+$L oracle/_ref/libflow_ref.so --loci ${FLOW_RATE_LOCI:-768} --seed 100 --threads 16 >> $O/flow_rates.txt 2>&1
 for lib in libflow_mi355x.so libflow_mi355x_batched.so; do
 for t in 1 4 16; do
   echo "== $lib --threads $t" >> $O/flow_rates.txt
