@@ -554,6 +554,8 @@ def load_hmm():
     _sig(lib.hipstr_debug_driver_allocs, C.c_int64, [])
     _sig(lib.hipstr_locus_costs, C.c_int, [_BP, _f64p])
     _sig(lib.hipstr_debug_cr_math, C.c_int, [C.c_int, _f64p, _f64p, C.c_int64])
+    _sig(lib.hipstr_debug_cache_get, C.c_void_p, [C.c_int64])
+    _sig(lib.hipstr_debug_cache_put, None, [C.c_void_p])
     _sig(lib.hipstr_debug_cache_stats, C.c_int, [C.POINTER(C.c_int64)])
     _sig(lib.hipstr_debug_allele_kinds, C.c_int, [C.c_void_p, C.POINTER(C.c_int64)])
     _sig(lib.hipstr_debug_stream_create, C.c_void_p, [])

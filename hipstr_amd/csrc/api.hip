@@ -932,12 +932,20 @@ int hipstr_debug_cr_math(int which, const double* x, double* y, int64_t n){
   double* dx = (double*)c->dev_cache.get((size_t)n*8); double* dy = (double*)c->dev_cache.get((size_t)n*8);
   int rc = 1;
   if (dx && dy && hipMemcpy(dx, x, (size_t)n*8, hipMemcpyHostToDevice) == hipSuccess){
-    hipLaunchKernelGGL(hs_cr_math_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, c->stream, which, (const double*)dx, dy, n);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int reps = getenv("HIPSTR_TIMING") ? 10 : 1;
+    for (int r = 0; r < reps; r++)
+      hipLaunchKernelGGL(hs_cr_math_kernel, dim3((unsigned)((n + 255)/256)), dim3(256), 0, c->stream, which, (const double*)dx, dy, n);
+    if (reps > 1 && hipstr::wait_stream(c->stream) == hipSuccess)
+      fprintf(stderr, "hipstr_debug_cr_math: %s of %lld arguments x %d launches: %.3f ms per launch\n", which ? "log" : "exp", (long long)n, reps,
+              1e3*std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()/reps);
     if (hipstr::wait_stream(c->stream) == hipSuccess && hipMemcpy(y, dy, (size_t)n*8, hipMemcpyDeviceToHost) == hipSuccess) rc = 0;
   }
   c->dev_cache.put(dx); c->dev_cache.put(dy);
   return rc ? fail("hipstr_debug_cr_math: device call failed") : 0;
 }
+void* hipstr_debug_cache_get(int64_t bytes){ Ctx* c = current_ctx(); if (!c || bind(c) || bytes < 0) return NULL; return c->dev_cache.get((size_t)bytes); }
+void hipstr_debug_cache_put(void* p){ Ctx* c = current_ctx(); if (c && p) c->dev_cache.put(p); }
 int hipstr_debug_cache_stats(int64_t out[12]){
   Ctx* c = current_ctx();
   if (!c) return 1;

@@ -46,6 +46,7 @@ struct hs_em_locus_t {
   int64_t post_off;        // S*A*A posteriors
   int64_t ll_off;          // R*A log_aln_probs
   int64_t prior_off;       // A*A priors
+  int64_t sa_off;          // S*A per-(sample, allele) values (gmax)
 };
 
 struct hs_em_dev_t {
@@ -70,6 +71,7 @@ struct hs_em_dev_t {
                                //   category (0 in_up, 1 in_down, 2 in_eq, 4 out_up, 5 out_down) | diffs vector (3 in, 6 out, 255 none) << 8
   double*  leff;               // same layout: ln |effective difference| (the addend of the diffs vectors), 0 where there is none
   double*  part;               // [n_loci][HS_EM_PARTS][7] partial maxima, then partial sums, of the seven M-step vectors
+  double*  gmax;               // [S*A per locus, at sa_off] largest log posterior of any diplotype of the sample that holds the allele (hs_em_gmax)
   double   log_thresh, log_half, log_1p1;
   // ---- device-resident loop (NULL / unused with the host loop): workgroup b of a per-locus kernel takes locus list[b] if b < counts[0]
   const int32_t* list;         // loci still training, ascending
@@ -95,7 +97,8 @@ __device__ __forceinline__ int em_locus(const hs_em_dev_t& d){
   return d.active[blockIdx.x] ? (int)blockIdx.x : -1;
 }
 #define HS_EM_PARTS 8          // workgroups per locus in the two big M-step reductions
-#define HS_EM_CHUNK 64          // positions of the allele-frequency scans per round of prepared exponentials (em_gt_priors)
+#define HS_EM_TILE 2048         // rows of a slice whose live rows are listed at a time (hs_em_mstep_part)
+#define HS_EM_CHUNK 32          // positions of the allele-frequency scans per round of prepared exponentials (em_gt_priors)
 #define HS_EM_MAXA_LDS 64      // alleles whose chains run side by side (lanes of the first wavefront); more alleles: several sweeps
 
 namespace {
@@ -200,13 +203,46 @@ __device__ void em_gt_priors(const hs_em_dev_t& d, const hs_em_locus_t& L, int t
   // log_sum_exp of every row (sample, allele_1) first, all rows in parallel (each row summed in allele_2 order as the reference does);
   // the streaming scans below are sequential per allele by definition
   double* row_lse = d.row_lse + L.post_off;     // S*A values in this locus' own S*A*A region: disjoint between loci whatever their A
-  for (int x = tid; x < S*A; x += 256){
-    const double* row = post + (int64_t)x*A;
-    double rm = row[0];
-    for (int j = 1; j < A; j++) rm = fmax(rm, row[j]);
-    double rs = 0.0;
-    for (int j = 0; j < A; j++) rs += cr_exp(row[j] - rm);
-    row_lse[x] = rm + cr_log(rs);
+  // The rows are fetched a tile at a time into LDS, contiguously (a thread walking its own row straight from memory touches 64 cache lines
+  // per load: the kernel was bound by exactly that), then: a thread per row takes the maximum, ALL threads form the exponentials in place,
+  // a thread per row adds them in allele order and takes the logarithm.
+  extern __shared__ double hs_em_dyn[];
+  {
+    const int Ap = A | 1;                                // odd row stride: the per-row walks of neighbouring threads fall into different banks
+    const int tile_rows = min(256, (int)((2*HS_EM_CHUNK*HS_EM_MAXA_LDS) / Ap));
+    __shared__ double s_rm[256];
+    if (tile_rows >= 1){
+      for (int x0 = 0; x0 < S*A; x0 += tile_rows){
+        const int nr = min(tile_rows, S*A - x0);
+        for (int e = tid; e < nr*A; e += 256){ const int rr = e / A, j = e - rr*A; hs_em_dyn[rr*Ap + j] = post[(int64_t)x0*A + e]; }
+        __syncthreads();
+        if (tid < nr){
+          const double* row = hs_em_dyn + tid*Ap;
+          double rm = row[0];
+          for (int j = 1; j < A; j++) rm = fmax(rm, row[j]);
+          s_rm[tid] = rm;
+        }
+        __syncthreads();
+        for (int e = tid; e < nr*A; e += 256){ const int rr = e / A, j = e - rr*A; hs_em_dyn[rr*Ap + j] = cr_exp(hs_em_dyn[rr*Ap + j] - s_rm[rr]); }
+        __syncthreads();
+        if (tid < nr){
+          const double* row = hs_em_dyn + tid*Ap;
+          double rs = 0.0;
+          for (int j = 0; j < A; j++) rs += row[j];
+          row_lse[x0 + tid] = s_rm[tid] + cr_log(rs);
+        }
+        __syncthreads();
+      }
+    } else {                                             // a row does not fit the tile (thousands of alleles): straight from memory
+      for (int x = tid; x < S*A; x += 256){
+        const double* row = post + (int64_t)x*A;
+        double rm = row[0];
+        for (int j = 1; j < A; j++) rm = fmax(rm, row[j]);
+        double rs = 0.0;
+        for (int j = 0; j < A; j++) rs += cr_exp(row[j] - rm);
+        row_lse[x] = rm + cr_log(rs);
+      }
+    }
   }
   __syncthreads();
   // The two scans of allele a are ONE dependent chain over S + S A values (update_streaming_log_sum_exp, mathops.cpp:72-80): lane a owns it.
@@ -218,7 +254,7 @@ __device__ void em_gt_priors(const hs_em_dev_t& d, const hs_em_locus_t& L, int t
   // Same values, same operations in the same order as the scalar chain.  (A > 64: alleles beyond the first wavefront's lanes loop.)
   constexpr int CH = HS_EM_CHUNK;
   __shared__ double s_m[HS_EM_MAXA_LDS];                 // running maximum per allele (the chunk's snapshot)
-  extern __shared__ double hs_em_dyn[];                  // [CH][Apad] prepared exponentials
+  // hs_em_dyn: [CH][Apad] prepared exponentials | at CH*HS_EM_MAXA_LDS: [CH][Apad] the values
   const int Apad = A;
   const int64_t n1 = S, n2 = (int64_t)S*A, ntot = n1 + n2;
   auto value_at = [&](int64_t i, int a) -> double {      // the chain of allele a: row_lse(s, a) for s < S, then post[(s, i1), a]
@@ -237,12 +273,13 @@ __device__ void em_gt_priors(const hs_em_dev_t& d, const hs_em_locus_t& L, int t
         double ex = 0.0;
         if (lv <= ms){ const double x_ = lv - ms; ex = (x_ < -37.43) ? -1.0 : cr_exp(x_); }       // -1: "below 2^-54" (see the walk)
         hs_em_dyn[i*Apad + al] = ex;
+        hs_em_dyn[CH*HS_EM_MAXA_LDS + i*Apad + al] = lv;     // the value itself: the walk is a dependent chain and must not wait for L2 at every step
       }
       __syncthreads();
       if (tid < na){
         const double ms = s_m[tid];
         for (int i = 0; i < cn; i++){
-          const double lv = value_at(c0 + i, a0 + tid);
+          const double lv = hs_em_dyn[CH*HS_EM_MAXA_LDS + i*Apad + tid];
           if (lv <= m){
             if (m == ms){
               const double ex = hs_em_dyn[i*Apad + tid];
@@ -266,6 +303,41 @@ __device__ void em_gt_priors(const hs_em_dev_t& d, const hs_em_locus_t& L, int t
     for (int a = 0; a < A; a++) t += cr_exp(gtp[a] - m);
     const double lt = m + cr_log(t);
     for (int a = 0; a < A; a++) gtp[a] -= lt;
+  }
+}
+
+// gmax[s][a] = the largest log posterior among the diplotypes (a, j) and (j, a) of sample s: the bound hs_em_mstep_part prunes by.
+// A wavefront per sample, lanes = the second allele: every row of the sample's A x A block is read once, contiguously (a thread per
+// (sample, allele) walking its row and its column touched 64 cache lines per load: 15 ms per round of 10 000 loci, now ~1).
+__global__ void __launch_bounds__(256) hs_em_gmax(const hs_em_dev_t* __restrict__ dp){
+  const hs_em_dev_t& d = *dp;
+  const int l = em_locus(d);
+  if (l < 0) return;
+  const hs_em_locus_t L = d.loci[l];
+  const int A = L.A, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const double* post = d.post + L.post_off;
+  double* g = d.gmax + L.sa_off;
+  if (A <= 64){
+    for (int s_ = w; s_ < L.S; s_ += 4){
+      const double* gp = post + (int64_t)s_*A*A;
+      double colmax = -DBL_MAX, mine = -DBL_MAX;              // lane j: max over a of gp[a][j];  lane a: max over j of gp[a][j]
+      for (int a = 0; a < A; a++){
+        const double v = (lane < A) ? gp[a*A + lane] : -DBL_MAX;
+        colmax = fmax(colmax, v);
+        double rm = v;
+        for (int o = 32; o >= 1; o >>= 1) rm = fmax(rm, __shfl_xor(rm, o));
+        if (lane == a) mine = rm;
+      }
+      if (lane < A) g[s_*A + lane] = fmax(colmax, mine);
+    }
+  } else {
+    for (int x = threadIdx.x; x < L.S*A; x += 256){
+      const int s_ = x / A, a = x - s_*A;
+      const double* gp = post + (int64_t)s_*A*A;
+      double m = gp[a*A];
+      for (int j = 0; j < A; j++) m = fmax(m, fmax(gp[a*A + j], gp[j*A + a]));
+      g[x] = m;
+    }
   }
 }
 
@@ -297,7 +369,46 @@ __global__ void __launch_bounds__(256) hs_em_mstep_part(const hs_em_dev_t* __res
   // seven-way choice is made once per (r, a) and the walk itself is branch-free.
   const int total = L.R*A;
   const int x0 = (int)((int64_t)total*k_part/HS_EM_PARTS), x1 = (int)((int64_t)total*(k_part + 1)/HS_EM_PARTS);
-  for (int x = x0 + tid; x < x1; x += 256){
+  // Round 5: most (read, source allele) rows cannot matter and are recognised without walking them.  Every term of a row is
+  //   f = log P(diplotype | sample) + log P(phase | read, diplotype)  <=  G + c,   G = gmax[sample][a] (hs_em_gmax: the sample's best diplotype
+  // that holds allele a), c = 4e-6 (the phase term is <= 0 up to the float log-sum-exp's approximation error: its bit-trick log dips to
+  // -1.65e-6 at 1.0, fastonebigheader.h:320-338), and every operation between f and its use is monotone in f.  So
+  //   PASS 0: a row whose bound cannot exceed the pseudocount entries every vector starts from (0, ln 1.1) cannot raise a maximum;
+  //   PASS 1: a row whose bound is not above max + LOG_THRESH only has terms the threshold drops (mathops.cpp:102-103)
+  // — and neither is walked.  The rows that are left (a few per cent: the alleles of a read's sample's plausible genotypes) are gathered
+  // into a list per tile of HS_EM_TILE rows, so that the walk keeps every lane busy.  Same maxima, same sums (of float terms, in double:
+  // exact in any order).
+  const double* gmax = d.gmax + L.sa_off;
+  constexpr double PH_C = 4.0e-6;
+  __shared__ int s_rows[HS_EM_TILE];
+  __shared__ int s_cnt;
+  for (int t0 = x0; t0 < x1; t0 += HS_EM_TILE){
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    const int t1 = min(x1, t0 + HS_EM_TILE);
+    for (int x = t0 + tid; x < t1; x += 256){
+      const int r = x / A, a = x - r*A;
+      const double Gb = gmax[(int64_t)d.sample_label[L.read_begin + r]*A + a] + PH_C;
+      const int c2 = catv[x];
+      const int cat = c2 & 0xff, dcat = c2 >> 8;
+      const double le = leff[x];
+      bool need;
+      if (PASS == 0){
+        need = Gb > 0.0;                                                   // (vectors 0, 1, 2, 4, 5 start from the pseudocount entry 0.0)
+        if (dcat < 7) need = need || (Gb + le > d.log_1p1);                // (the diffs vectors from ln 1.1)
+      } else {
+        double mc = 0.0, md = 0.0;
+#pragma unroll
+        for (int k = 0; k < 7; k++){ if (k == cat) mc = mx[k]; if (k == dcat) md = mx[k]; }
+        need = (Gb - mc > d.log_thresh);
+        if (dcat < 7) need = need || ((Gb + le) - md > d.log_thresh);
+      }
+      if (need) s_rows[atomicAdd(&s_cnt, 1)] = x;
+    }
+    __syncthreads();
+    const int n_live = s_cnt;
+    for (int li = tid; li < n_live; li += 256){
+      const int x = s_rows[li];
     const int r = x / A, a = x - r*A;
     const int g = L.read_begin + r;
     // recalc_log_read_phase_posteriors (:152-169); the pmf values are the E-step's log_aln_probs
@@ -347,6 +458,8 @@ __global__ void __launch_bounds__(256) hs_em_mstep_part(const hs_em_dev_t* __res
         if (k == dcat) acc[k] += sd;
       }
     }
+      }
+    __syncthreads();
   }
   double out[7];
   for (int k = 0; k < 7; k++) out[k] = (PASS == 0) ? block_max(acc[k], red) : block_sum(acc[k], red);
@@ -617,7 +730,7 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
     Q.gtp.resize(A);
     for (int a = 0; a < A; a++) Q.gtp[a] = (host_loop ? log(g[a]) : cr_log(g[a])) - lt;
   });
-  int64_t post_off = 0, ll_off = 0, prior_off = 0; int samp_off = 0;
+  int64_t post_off = 0, ll_off = 0, prior_off = 0, sa_off = 0; int samp_off = 0;
   for (int l = 0; l < nl; l++){
     const LocusPrep& Q = lp[l];
     if (Q.err) return api_fail(Q.err);
@@ -627,7 +740,7 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
     memset(&L, 0, sizeof L);
     L.A = A; L.S = S; L.R = R; L.period = eb->period[l]; L.haploid = (eb->haploid && eb->haploid[l]) ? 1 : 0;
     L.read_begin = r0; L.samp_begin = samp_off; L.bps_off = (int32_t)bps.size();
-    L.post_off = post_off; L.ll_off = ll_off; L.prior_off = prior_off;
+    L.post_off = post_off; L.ll_off = ll_off; L.prior_off = prior_off; L.sa_off = sa_off;
     gtp.insert(gtp.end(), Q.gtp.begin(), Q.gtp.end());
     bps.insert(bps.end(), Q.sizes.begin(), Q.sizes.end());
     int r = r0;
@@ -639,7 +752,7 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
       u.n_reads = r - u.read_begin;
       units.push_back(u); unit_locus.push_back(l);
     }
-    post_off += (int64_t)S*A*A; ll_off += (int64_t)R*A; prior_off += (int64_t)A*A; samp_off += S;
+    post_off += (int64_t)S*A*A; ll_off += (int64_t)R*A; prior_off += (int64_t)A*A; samp_off += S; sa_off += (int64_t)S*A;
   }
   std::vector<LocusPrep>().swap(lp);
   lap("alleles and units", NULL);
@@ -649,7 +762,7 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
   hs_em_dev_t h; memset(&h, 0, sizeof h);
   hs_post_dev_t ph; memset(&ph, 0, sizeof ph);
   hs_em_locus_t* d_loci; hs_post_unit_t* d_units; int32_t *d_active, *d_unit_active, *d_bps, *d_obs, *d_lab, *d_w, *d_mapgt;
-  double *d_logp, *d_p1, *d_p2, *d_gtp, *d_ll, *d_prior, *d_post, *d_tot, *d_newll, *d_sums, *d_rowlse, *d_leff, *d_part, *d_keep; int32_t* d_cat;
+  double *d_logp, *d_p1, *d_p2, *d_gtp, *d_ll, *d_prior, *d_post, *d_tot, *d_newll, *d_sums, *d_rowlse, *d_leff, *d_part, *d_keep, *d_gmax; int32_t* d_cat;
   std::vector<int32_t> ones(n_reads, 1);
   if (dev.put(&d_loci, loci.data(), loci.size()) || dev.put(&d_units, units.data(), units.size()) || dev.alloc(&d_active, nl) ||
       dev.alloc(&d_unit_active, units.size()) || dev.put(&d_bps, bps.data(), bps.size()) || dev.put(&d_obs, obs.data(), obs.size()) ||
@@ -657,9 +770,9 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
       dev.alloc(&d_logp, 9*(size_t)nl) || dev.put(&d_p1, eb->log_p1, n_reads) || dev.put(&d_p2, eb->log_p2, n_reads) ||
       dev.put(&d_gtp, gtp.data(), gtp.size()) || dev.alloc(&d_ll, ll_off) || dev.alloc(&d_prior, prior_off) || dev.alloc(&d_post, post_off) ||
       dev.alloc(&d_tot, samp_off) || dev.alloc(&d_newll, nl) || dev.alloc(&d_sums, 7*(size_t)nl) || dev.alloc(&d_rowlse, post_off) ||
-      dev.alloc(&d_cat, ll_off) || dev.alloc(&d_leff, ll_off) || dev.alloc(&d_part, 7*(size_t)HS_EM_PARTS*nl) || dev.alloc(&d_keep, 7*(size_t)nl)) return 1;
+      dev.alloc(&d_cat, ll_off) || dev.alloc(&d_leff, ll_off) || dev.alloc(&d_part, 7*(size_t)HS_EM_PARTS*nl) || dev.alloc(&d_keep, 7*(size_t)nl) || dev.alloc(&d_gmax, sa_off)) return 1;
   h.loci = d_loci; h.active = d_active; h.logp = d_logp; h.bps = d_bps; h.obs = d_obs; h.sample_label = d_lab; h.log_p1 = d_p1; h.log_p2 = d_p2;
-  h.gtp = d_gtp; h.ll = d_ll; h.prior = d_prior; h.post = d_post; h.sample_total = d_tot; h.int_log = T.int_log; h.new_ll = d_newll; h.sums = d_sums; h.row_lse = d_rowlse; h.cat = d_cat; h.leff = d_leff; h.part = d_part;
+  h.gtp = d_gtp; h.ll = d_ll; h.prior = d_prior; h.post = d_post; h.sample_total = d_tot; h.int_log = T.int_log; h.new_ll = d_newll; h.sums = d_sums; h.row_lse = d_rowlse; h.cat = d_cat; h.leff = d_leff; h.part = d_part; h.gmax = d_gmax;
   h.log_thresh = HT.log_thresh; h.log_half = HT.log_half; h.log_1p1 = host_loop ? log(1.1) : cr_log(1.1);
   ph.units = d_units; ph.log_aln_probs = d_ll; ph.log_p1 = d_p1; ph.log_p2 = d_p2; ph.read_weight = d_w; ph.log_prior = d_prior;
   ph.unit_active = d_unit_active; ph.log_post = d_post; ph.sample_total = d_tot; ph.map_gt = d_mapgt;
@@ -725,8 +838,9 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
         hipLaunchKernelGGL(hs_posterior_kernel, dim3(std::max(1u, bound_u)), dim3(256), 0, T.stream, PH);
         EM_HIP(hipEventRecord(side.ev_fork, T.stream));                  // posteriors are in place: the allele-frequency scans branch off
         EM_HIP(hipStreamWaitEvent(side.stream, side.ev_fork, 0));
-        hipLaunchKernelGGL(hs_em_gt_priors, dim3(bound_l), dim3(256), HS_EM_CHUNK*HS_EM_MAXA_LDS*sizeof(double), side.stream, H);
+        hipLaunchKernelGGL(hs_em_gt_priors, dim3(bound_l), dim3(256), 2*HS_EM_CHUNK*HS_EM_MAXA_LDS*sizeof(double), side.stream, H);
         EM_HIP(hipEventRecord(side.ev_join, side.stream));
+        hipLaunchKernelGGL(hs_em_gmax, dim3(bound_l), dim3(256), 0, T.stream, H);
         hipLaunchKernelGGL(hs_em_mstep_part<0>, dim3(bound_l, HS_EM_PARTS), dim3(256), 0, T.stream, H, (const double*)NULL);
         hipLaunchKernelGGL(hs_em_mstep_keepmax, dim3(bound_l), dim3(64), 0, T.stream, H, d_keep);
         hipLaunchKernelGGL(hs_em_mstep_part<1>, dim3(bound_l, HS_EM_PARTS), dim3(256), 0, T.stream, H, (const double*)d_keep);
@@ -791,8 +905,9 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
     hipLaunchKernelGGL(hs_posterior_kernel, dim3((unsigned)units.size()), dim3(256), 0, T.stream, (const hs_post_dev_t*)d_ph);
     EM_HIP(hipEventRecord(side.ev_fork, T.stream));                      // posteriors are in place: the allele-frequency scans branch off
     EM_HIP(hipStreamWaitEvent(side.stream, side.ev_fork, 0));
-    hipLaunchKernelGGL(hs_em_gt_priors, dim3(nl), dim3(256), HS_EM_CHUNK*HS_EM_MAXA_LDS*sizeof(double), side.stream, d_h);
+    hipLaunchKernelGGL(hs_em_gt_priors, dim3(nl), dim3(256), 2*HS_EM_CHUNK*HS_EM_MAXA_LDS*sizeof(double), side.stream, d_h);
     EM_HIP(hipEventRecord(side.ev_join, side.stream));
+    hipLaunchKernelGGL(hs_em_gmax, dim3(nl), dim3(256), 0, T.stream, d_h);
     hipLaunchKernelGGL(hs_em_mstep_part<0>, dim3(nl, HS_EM_PARTS), dim3(256), 0, T.stream, d_h, (const double*)NULL);
     hipLaunchKernelGGL(hs_em_mstep_keepmax, dim3(nl), dim3(64), 0, T.stream, d_h, d_keep);
     hipLaunchKernelGGL(hs_em_mstep_part<1>, dim3(nl, HS_EM_PARTS), dim3(256), 0, T.stream, d_h, (const double*)d_keep);

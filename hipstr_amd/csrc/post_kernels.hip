@@ -16,6 +16,7 @@
 #include "cr_math.h"
 
 #define HS_POST_ECHUNK 2048
+#define HS_POST_REGS 8            // diplotypes per thread a unit may have to stay in registers (256 x 8 = HS_POST_ECHUNK: its exponentials fit the LDS chunk)
 
 namespace {
 
@@ -64,6 +65,101 @@ __device__ __forceinline__ void posterior_body(const hs_post_dev_t& d){
   __shared__ int    red_i[256];
   __shared__ double ebuf[HS_POST_ECHUNK];              // a chunk of exponentials, summed in index order by thread 0
 
+  // ---- round 5: units of up to 2048 diplotypes (A <= 45: nearly all) keep their values in REGISTERS from the accumulation to the normalised
+  // posteriors — the general path below writes them, reads them back for the maximum, for the first-maximum search, for the exponentials and
+  // for the normalisation (40 KB of traffic per 1024-diplotype unit, a million units per EM round) and pays ~30 workgroup barriers in
+  // its three tree reductions; here the reductions are wavefront shuffles plus one LDS exchange.  Same operations on the same values in the
+  // same order (the sum of the exponentials is still thread 0's, in index order): bit-identical.
+  if (PHASE == 0 && nd <= 256*HS_POST_REGS && !d.raw){
+#ifdef HS_POST_TIME
+    unsigned long long tk[6]; tk[0] = __builtin_amdgcn_s_memtime();
+#define HS_PT(i) tk[i] = __builtin_amdgcn_s_memtime()
+#else
+#define HS_PT(i) do {} while (0)
+#endif
+    double v[HS_POST_REGS];
+    double lmax = -1.0e300;
+#pragma unroll
+    for (int k = 0; k < HS_POST_REGS; k++){
+      const int idx = tid + 256*k;
+      v[k] = -1.0e300;
+      if (idx < nd){
+        const int a1 = idx / A, a2 = idx - a1*A;
+        double x = d.log_prior ? d.log_prior[u.prior_off + idx] : ((a1 == a2) ? u.log_hom_prior : u.log_het_prior);
+        for (int r = 0; r < u.n_reads; r++){
+          const int g = u.read_begin + r;
+          const double* LL = LL0 + (int64_t)r*A;
+          x += (double)d.read_weight[g] * fast_lse2((d.log_half + d.log_p1[g]) + LL[a1], (d.log_half + d.log_p2[g]) + LL[a2], d.log_thresh);
+        }
+        v[k] = x;
+        lmax = fmax(lmax, x);
+      }
+    }
+    HS_PT(1);
+    const int lane = tid & 63, w = tid >> 6;
+    for (int o = 32; o >= 1; o >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, o));
+    if (lane == 0) red_v[w] = lmax;
+    __syncthreads();
+    const double mx = fmax(fmax(red_v[0], red_v[1]), fmax(red_v[2], red_v[3]));
+    int fi = 0x7fffffff;
+#pragma unroll
+    for (int k = HS_POST_REGS - 1; k >= 0; k--) if (tid + 256*k < nd && v[k] == mx) fi = tid + 256*k;
+    for (int o = 32; o >= 1; o >>= 1) fi = min(fi, __shfl_xor(fi, o));
+    if (lane == 0) red_i[w] = fi;
+    __syncthreads();
+    const int first_max = min(min(red_i[0], red_i[1]), min(red_i[2], red_i[3]));
+    HS_PT(2);
+#pragma unroll
+    for (int k = 0; k < HS_POST_REGS; k++){
+      const int idx = tid + 256*k;
+      if (idx < nd){ const double x = v[k] - mx; ebuf[idx] = (idx > first_max && x < -37.43) ? 0.0 : cr_exp(x); }
+    }
+    __syncthreads();
+    HS_PT(3);
+    if (tid == 0){
+      double lsum = 0.0;
+      int k = 0;
+      for (; k + 8 <= nd; k += 8){
+        const double e0 = ebuf[k], e1 = ebuf[k+1], e2 = ebuf[k+2], e3 = ebuf[k+3], e4 = ebuf[k+4], e5 = ebuf[k+5], e6 = ebuf[k+6], e7 = ebuf[k+7];
+        lsum += e0; lsum += e1; lsum += e2; lsum += e3; lsum += e4; lsum += e5; lsum += e6; lsum += e7;
+      }
+      for (; k < nd; k++) lsum += ebuf[k];
+      red_v[8] = mx + cr_log(lsum);
+    }
+    __syncthreads();
+    HS_PT(4);
+    const double total = red_v[8];
+    double bv = -1.7976931348623157e308; int bi = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < HS_POST_REGS; k++){
+      const int idx = tid + 256*k;
+      if (idx < nd){
+        const double x = v[k] - total;
+        post[idx] = x;
+        if (x > bv){ bv = x; bi = idx; }
+      }
+    }
+    for (int o = 32; o >= 1; o >>= 1){
+      const double ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+      if (ov > bv || (ov == bv && oi < bi)){ bv = ov; bi = oi; }
+    }
+    if (lane == 0){ red_v[16 + w] = bv; red_i[16 + w] = bi; }
+    __syncthreads();
+    if (tid == 0){
+      for (int q = 1; q < 4; q++){ const double ov = red_v[16 + q]; const int oi = red_i[16 + q]; if (ov > bv || (ov == bv && oi < bi)){ bv = ov; bi = oi; } }
+      d.sample_total[u.samp_index] = total;
+      const bool none = bi == 0x7fffffff;
+      d.map_gt[2*u.samp_index]   = none ? -1 : bi / A;
+      d.map_gt[2*u.samp_index+1] = none ? -1 : bi % A;
+    }
+#ifdef HS_POST_TIME
+    HS_PT(5);
+    if (tid == 0 && (blockIdx.x % 100000) == 777)
+      printf("post unit %d nd %d reads %d: accumulate %llu  max+first %llu  exps %llu  sum+log %llu  normalise+map %llu (x10 ns)\n", (int)blockIdx.x, nd, u.n_reads,
+             tk[1]-tk[0], tk[2]-tk[1], tk[3]-tk[2], tk[4]-tk[3], tk[5]-tk[4]);
+#endif
+    return;
+  }
   // ---- accumulate (genotyper.cpp:47-61)
   double lmax = -1.0e300;
   if (PHASE != 2){

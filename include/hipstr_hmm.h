@@ -505,6 +505,9 @@ int64_t hipstr_debug_driver_allocs(void);
  * trimming idle chunks; only then does it fail.  out[8], out[9]: driver refusals the device cache survived by the first / the second way;
  * out[10], out[11]: the pinned cache's. */
 int hipstr_debug_cache_stats(int64_t out[12]);
+/* Diagnostics (tests): one block from / back to the calling thread's device block cache — what every upload does dozens of times. */
+void* hipstr_debug_cache_get(int64_t bytes);
+void hipstr_debug_cache_put(void* block);
 /* Diagnostics (tests): the correctly rounded exp (which = 0) / log (1) of hipstr_amd/csrc/cr_math.h evaluated ON THE DEVICE, element by
  * element — the functions the posterior, genotype and EM kernels use in place of the device's own exp / log so that they reproduce
  * the host libm's bits. */

@@ -54,19 +54,27 @@ print("ok", held0, s)
 
 
 def test_driver_refusal_falls_back_to_free_blocks_then_trims():
-    """Batches that DOUBLE: a batch's blocks are all larger than the free blocks of the ones before (a request reuses a free block of at most
-    twice its size: none qualifies), so the cache carves chunk after chunk until the (simulated) driver refuses at 1500 MiB with a few
-    hundred MB in use: get() must give the idle chunks back and take what it needs (the trim-and-retry path).  Then a batch 16 times
-    SMALLER with the chunks full: its requests are served from free blocks far beyond the 2x window (the fallback path) — the round-4 cache
-    returned NULL in both situations while the free list held what was needed."""
-    out = _run({"HIPSTR_DEBUG_DRIVER_LIMIT_MIB": "1500"}, r'''
-for n in [25, 50, 100, 200, 400, 25, 400, 50]:
-    run(n, 100, check=(n <= 25))
-    s = stats()
-    assert s[0] <= 1500 << 20, s    # never more than the "driver" has
-    assert s[2] == 0, s
-s = stats()
-assert s[8] > 0 and s[9] > 0, s     # both ways of surviving a refusal were taken
-print("ok", s, hmm.hipstr_debug_driver_allocs())
+    """The two ways get() survives a driver that refuses a new chunk (simulated at 1050 MiB), block by block: a request is served from a
+    free block far beyond the 2x window; a request nothing free can hold makes the cache give its idle chunks back and take what it
+    needs.  The round-4 cache returned NULL in both situations while the free list held hundreds of MB.  Then real batches
+    of growing size under the same limit: whatever the layout, the cache never holds more than the driver has."""
+    out = _run({"HIPSTR_DEBUG_DRIVER_LIMIT_MIB": "1050"}, r'''
+MB = 1 << 20
+get = lambda n: hmm.hipstr_debug_cache_get(n); put = lambda p: hmm.hipstr_debug_cache_put(C.c_void_p(p))
+a = get(300*MB); b = get(300*MB); assert a and b, hmm.hipstr_last_error()
+put(a); put(b)                                   # two free blocks (384 MiB each with their headroom) in chunks of 384 and 512 MiB: 154 MiB left at the driver
+c = get(150*MB)                                  # 150 MB: beyond the 2x window of the free blocks, no room in a chunk, driver refuses 512 MiB ...
+assert c, hmm.hipstr_last_error()
+s = stats(); assert s[8] == 1 and s[9] == 0, s   # ... served from a 300 MB free block all the same
+d = get(600*MB)                                  # nothing free holds it; the idle 300 MB chunk goes back and the driver has room again
+assert d, hmm.hipstr_last_error()
+s = stats(); assert s[8] == 1 and s[9] == 1, s
+assert s[0] <= 1050*MB, s
+put(c); put(d)
+e = get(2000*MB)                                 # more than the driver has, whatever is given back: refused, with the driver's message
+assert not e and b"out of memory" in hmm.hipstr_last_error()
+run(25, 100, check=True)                         # and the cache serves a real batch afterwards
+s = stats(); assert s[0] <= 1050*MB and s[2] == 0, s
+print("ok", stats(), hmm.hipstr_debug_driver_allocs())
 ''')
     assert "ok" in out
