@@ -46,8 +46,8 @@ extern "C" __global__ void hs_expand_stropts_kernel(const hs_dev_t* dp);
 extern "C" __global__ void hs_expand_recs_kernel(const hs_dev_t* dp);
 extern "C" size_t hs_str_group_lds_bytes(int max_B, int nd_cap, int with_ilog);
 extern "C" size_t hs_str_group_p_lds_bytes();
-extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk);
-extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk);
+extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk, int max_cols);
+extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk, int max_cols);
 
 namespace {
 
@@ -758,7 +758,7 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
     const unsigned nact = ch.active_end - ch.active_begin;
     if (mark()) return 1;
     // leading flanks: persistent wavefronts striding over (locus side, distinct flank, 64 reads) items
-    hs_launch_lead2(nact, (unsigned)std::max(1, std::min(dev->trail_waves, ch.lead_end - ch.lead_begin)), st, dp, ch.active_begin, ch.lead_begin, ch.lead_end, 2*chunk_no);
+    hs_launch_lead2(nact, (unsigned)std::max(1, std::min(dev->trail_waves, ch.lead_end - ch.lead_begin)), st, dp, ch.active_begin, ch.lead_begin, ch.lead_end, 2*chunk_no, dev->h.band_cols);
     if (mark()) return 1;
     // tabulated alleles: reads of a locus side packed into workgroups (HIPSTR_STR_GROUP=0: one workgroup per read, for comparison)
     const bool str_group = !(getenv("HIPSTR_STR_GROUP") && atoi(getenv("HIPSTR_STR_GROUP")) == 0);
@@ -790,7 +790,7 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
     if (mark()) return 1;
     if (ch.trail_end > ch.trail_begin)     // trailing flanks: persistent wavefronts striding over (read side, allele group) items
       hs_launch_trail((unsigned)std::min(dev->trail_waves, ch.trail_end - ch.trail_begin), st, dp,
-                      dev->n_lead_items + ch.trail_begin, dev->n_lead_items + ch.trail_end, 2*chunk_no + 1);
+                      dev->n_lead_items + ch.trail_begin, dev->n_lead_items + ch.trail_end, 2*chunk_no + 1, dev->h.band_cols);
     if (mark()) return 1;
     hipLaunchKernelGGL(hs_combine_kernel, dim3(nact), dim3(64*hs_combine_waves()), 0, st, dp, ch.active_begin);
     if (mark()) return 1;

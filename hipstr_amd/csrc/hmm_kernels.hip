@@ -703,6 +703,132 @@ __global__ void __launch_bounds__(64*W, OCC) hs_lead_kernel_coop(const hs_dev_t*
   }
 }
 
+// ------------------------------------------------------------------ flank blocks, systolic form: one wavefront per alignment, rows as lanes
+// The sweeps above put reads (leading flank) or alleles (trailing flank) on the lanes and every row of a flank on ONE workgroup: a
+// column costs what 60 rows cost on one CU (~0.85 us) whatever the bands, and a one-locus call — two items, 255 idle CUs — waits
+// ~120 columns x 0.85 us for each of its two sweeps (two thirds of its 0.3 ms: profiles/r03_notes.md, r04_notes.md).  For launches of a
+// few items the matrix of every (read side[, allele]) goes to a wavefront of its own instead: lane = haplotype row, the wavefront moves
+// along the anti-diagonals (lane l works on column t - l at step t), a cell takes M and D of the row above from the lane below it with
+// one wave_shr each and keeps the diagonal from the step before.  No barrier, no ring, no sharing — 64 times the work per alignment
+// of the leading flank (it is computed per read here too, but with one row per lane) and a pipeline fill of 64 steps, which is why this
+// is the latency shape only — and n + rows steps of one short dependent chain each.  The row constants (base, transition logs) are
+// per-lane registers, the per-column operands come from an LDS copy of the read side.  Same cells, same operations per cell as
+// band_sweep: bit-identical.  Flanks of more than 64 rows run in bands of 64 rows, the boundary row kept in LDS.
+#define HS_SYS_MAXCOLS 256
+#define HS_SYS_ITEMS 96u
+template <bool LEAD>
+__global__ void __launch_bounds__(64) hs_flank_systolic(const hs_dev_t* __restrict__ dp, int item_begin){
+  const hs_dev_t& d = *dp;
+  const int lane = threadIdx.x, pair = blockIdx.y;
+  const hs_item_t* it = d.items + item_begin + blockIdx.x;
+  int side, ai, rowset;
+  const hs_tgroup_t* g = NULL; int tslot = 0, lslot = 0;
+  if (LEAD){
+    side = uni(it->side) & 1; lslot = uni(it->side) >> 1;
+    if (pair >= uni(it->slot)) return;
+    ai = uni(d.tpack[uni(it->active) + pair]); rowset = uni(it->rowset);
+  } else {
+    side = uni(it->side);
+    g = d.tgroups + uni(it->slot);
+    const int nm = uni(g->n_members), sub = pair / nm;
+    tslot = pair - sub*nm;
+    if (sub >= uni(it->rowset)) return;
+    ai = uni(d.tpack[uni(it->active) + sub]); rowset = uni(g->rowset);
+  }
+  const hs_read_t rdv = d.reads[uni(d.active[ai])];
+  const hs_locus_t* loc = d.loci + uni(rdv.locus);
+  const int nL = uni(rdv.seed), len = uni(rdv.len), n = side ? len - nL - 1 : nL;
+  if (n <= 0) return;
+  const hs_ws_t wsr = d.ws[ai];
+  const double* col = d.ws_col + uni(wsr.col) + 3*(int64_t)(side ? nL : 0);
+  const int rs_off = uni(d.rowsets[rowset].off), rs_len = uni(d.rowsets[rowset].len);
+  const hs_row_t* rows = d.rows + rs_off;
+  const int c0 = uni((int)rows[0]) & 0xff;
+  const double* mr = NULL; double* lt; double* rowp = NULL; double* side_out = NULL;
+  if (LEAD){
+    const int lead_flank = uni(loc->lead_flank[side]);
+    double* rec = d.ws_lead + uni(side ? wsr.lead[1] : wsr.lead[0]) + (int64_t)lslot*(n + lead_flank + 1);
+    rowp = rec; lt = rec + n; side_out = rec + n + lead_flank;
+  } else {
+    const int k = uni(d.tmembers[uni(g->member_off) + tslot]);
+    const hs_allele_t* al = d.alleles + uni(loc->hap_begin) + k;
+    const int ord = uni(al->re_ord);
+    mr = d.ws_mr + uni(wsr.mr) + (int64_t)ord*(len - 1) + (side ? nL : 0);
+    lt = d.ws_lt + uni(wsr.lt) + (int64_t)ord*uni(loc->lt_stride) + (side ? uni(d.rowsets[uni(al->trail_rows[0])].len) : 0);
+  }
+  __shared__ double2 s_bq[HS_SYS_MAXCOLS];               // (log P(correct), log P(error)) per read column
+  __shared__ double2 s_tb[2][HS_SYS_MAXCOLS];            // (M, D) of the row above the current band per column | the current band's last row (they swap)
+  __shared__ int s_rd[HS_SYS_MAXCOLS];
+  // ---- the read side and the block's first row (HapAligner.cpp:33-42 / :130-139): M of row 0 at every column
+  for (int j = lane; j < n; j += 64){
+    const double blc = col[3*j], blw = col[3*j + 1]; const int rdj = (int)col[3*j + 2];
+    s_bq[j] = make_double2(blc, blw); s_rd[j] = rdj;
+    const double e0 = (rdj == c0) ? blc : blw;
+    if (!LEAD) s_tb[0][j] = make_double2((j == 0) ? e0 : e0 + mr[j - 1], IMP);
+  }
+  wave_lds_sync();
+  if (LEAD){
+    if (lane == 0){                    // left_prob is a strictly sequential sum in the reference: one lane, n additions
+      double pre = 0.0;
+      for (int j = 0; j < n; j++){
+        const double2 bq = s_bq[j];
+        s_tb[0][j] = make_double2(((s_rd[j] == c0) ? bq.x : bq.y) + pre, IMP);
+        pre += bq.x;
+      }
+      *side_out = pre;
+    }
+    wave_lds_sync();
+  }
+  const int n_rows = rs_len - 1;
+  if (lane == 0) lt[0] = s_tb[0][n - 1].x;
+  if (n_rows == 0){                    // the block is its first row only
+    if (LEAD) for (int j = lane; j < n; j += 64) rowp[j] = s_tb[0][j].x;
+    return;
+  }
+  int par = 0;
+  for (int b0 = 0; b0 < n_rows; b0 += 64, par ^= 1){
+    const int nrb = min(64, n_rows - b0);
+    const bool last_band = b0 + 64 >= n_rows;
+    const int myrow = 1 + b0 + min(lane, nrb - 1);
+    const bool arow = lane < nrb, last_lane = lane == nrb - 1;
+    const int meta = (int)rows[myrow];
+    const int hc = meta & 0xff;
+    const double m2m = d.m2m[(meta >> 8) & 15], m2i = d.m2i[(meta >> 8) & 15];
+    const double2* const s_top = s_tb[par];
+    double2* const s_out = s_tb[par ^ 1];
+    double curM = 0.0, curD = 0.0, curI = 0.0, diagM = 0.0, diagD = 0.0, ltv = 0.0;
+    const int nsteps = n + nrb - 1;
+    // A lane outside its read's columns (before its first, behind its last) or beyond the band's rows computes on clamped operands and
+    // nothing of it reaches a cell that counts: column 0 takes nothing from the lane's own past, a cell's neighbours are a column
+    // behind it in the row above.  So the state is updated unconditionally — no mask, no branch — and only the results are picked:
+    // the last read column's M (ltv) and the band's last row (s_out).  The operands of step t + 1 are requested while step t is
+    // computed (a step is one short dependent chain: an LDS round trip in front of it would be most of its time).
+    int jn = -lane;                                       // the lane's column at the step being prefetched
+    auto clampj = [&](int j){ return min(max(j, 0), n - 1); };
+    double2 nx_bq = s_bq[clampj(jn)], nx_top = s_top[0]; int nx_rd = s_rd[clampj(jn)];
+    for (int t = 0; t < nsteps; t++){
+      const double2 bq = nx_bq, top = nx_top; const int rdj = nx_rd;
+      const int j = jn;
+      jn++;
+      { const int jq = clampj(jn); nx_bq = s_bq[jq]; nx_rd = s_rd[jq]; nx_top = s_top[min(t + 1, n - 1)]; }
+      const double upM = shr1(top.x, curM), upD = shr1(top.y, curD);
+      const double e = (rdj == hc) ? bq.x : bq.y;
+      // (m2d == m2i: max(a + x, b + x) == max(a, b) + x exactly, as in band_sweep); column 0: HapAligner.cpp:123-126
+      const bool first = (j == 0);
+      const double nM = first ? e : e + fmax(diagM + m2m, fmax(curI, diagD) + m2i);
+      const double nI = first ? bq.x : bq.x + fmax(diagM + T_I2M, curI + T_I2I);
+      const double nD = fmax(upM + T_D2M, upD + T_D2D);
+      curM = nM; curI = nI; curD = nD;
+      ltv = (j == n - 1) ? nM : ltv;                       // last read column
+      if (last_lane && j >= 0 && j < n) s_out[j] = make_double2(nM, nD);      // the band's last row: the next band's top, or rowP
+      diagM = upM; diagD = upD;
+    }
+    if (arow) lt[myrow] = ltv;
+    wave_lds_sync();
+    if (last_band && LEAD) for (int j = lane; j < n; j += 64) rowp[j] = s_out[j].x;
+  }
+}
+
 // ------------------------------------------------------------------ the STR block
 struct StrCtx {
   int B, p, nd;
@@ -2914,9 +3040,21 @@ static bool lat_shape(){ static const bool v = !(getenv("HIPSTR_FLANK_LATENCY_SH
 static bool flank_coop(){ static const bool v = !(getenv("HIPSTR_FLANK_COOP") && atoi(getenv("HIPSTR_FLANK_COOP")) == 0); return v; }
 extern "C" int hs_flank_waves_per_group(){ return flank_coop() ? HS_COOP_WAVES : 1; }
 extern "C" int hs_combine_waves(){ return HS_CMB_WAVES; }
-extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk){
+// HIPSTR_FLANK_SYSTOLIC: 1 (default) = launches of at most HS_LAT_ITEMS flank items whose read sides fit HS_SYS_MAXCOLS columns take the
+// systolic kernels (a wavefront per alignment); 0 = never; 2 = every launch that fits (tests: the whole suite through this form)
+static int systolic_mode(){ const char* e = getenv("HIPSTR_FLANK_SYSTOLIC"); return e ? atoi(e) : 1; }      // (read per launch: tests switch it)
+static bool use_systolic(int item_begin, int item_end, int max_cols){
+  const int m = systolic_mode();
+  // (a wavefront per alignment: up to 64 per item; beyond ~6000 of them the sweeps that share rows across lanes are faster again)
+  return m != 0 && max_cols <= HS_SYS_MAXCOLS && (m == 2 || (unsigned)(item_end - item_begin) <= HS_SYS_ITEMS);
+}
+extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk, int max_cols){
   hipLaunchKernelGGL(hs_col_kernel, dim3(n_active), dim3(64), 0, st, dp, active_begin);
   if (item_end <= item_begin) return;
+  if (use_systolic(item_begin, item_end, max_cols)){
+    hipLaunchKernelGGL((hs_flank_systolic<true>), dim3((unsigned)(item_end - item_begin), 64), dim3(64), 0, st, dp, item_begin);
+    return;
+  }
   // few items (a locus or two per call): the chip is far from full and what counts is the serial length of a sweep, so the bands are
   // half as tall and twice as many (HS_LAT_WAVES x HS_LAT_ROWS: a step is shorter, the pipeline four steps longer): -10 % per sweep
   if (flank_coop() && lat_shape() && (unsigned)(item_end - item_begin) <= HS_LAT_ITEMS)
@@ -2925,7 +3063,11 @@ extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStr
   if (flank_coop()) hipLaunchKernelGGL((hs_lead_kernel_coop<HS_COOP_ROWS, HS_COOP_WAVES, HS_COOP_OCC>), dim3(std::max(1u, std::min(n_wavefronts, 256u*HS_COOP_OCC*4/HS_COOP_WAVES))), dim3(64*HS_COOP_WAVES), 0, st, dp, item_begin, item_end, chunk);
   else hipLaunchKernelGGL((hs_lead_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end, chunk);
 }
-extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk){
+extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk, int max_cols){
+  if (item_end > item_begin && use_systolic(item_begin, item_end, max_cols)){
+    hipLaunchKernelGGL((hs_flank_systolic<false>), dim3((unsigned)(item_end - item_begin), 64), dim3(64), 0, st, dp, item_begin);
+    return;
+  }
   if (flank_coop() && lat_shape() && (unsigned)(item_end - item_begin) <= HS_LAT_ITEMS)
     hipLaunchKernelGGL((hs_trail_kernel_coop<HS_LAT_ROWS, HS_LAT_WAVES, 2>), dim3(std::max(1u, std::min(n_wavefronts, 256u))), dim3(64*HS_LAT_WAVES), 0, st, dp, item_begin, item_end, chunk);
   else

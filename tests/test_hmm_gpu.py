@@ -401,3 +401,24 @@ def test_api_profile_buckets(hmm):
     capi.run_align(hmm, "hipstr_hmm_", sb.ptr)                # switched off: nothing is added
     hmm.hipstr_debug_api_profile(-1, 32, names, secs, calls)
     assert calls[0] == 3
+
+
+def test_systolic_flank_kernels_match_the_shared_row_sweeps(hmm, oracle, monkeypatch):
+    """Round 5: launches of a few flank items (a locus or two per call) give every (read side[, allele]) matrix a wavefront of its own —
+    rows as lanes, anti-diagonal steps, wave_shr for the row above (hs_flank_systolic) — instead of the sweeps that put reads / alleles on
+    the lanes and all rows of a flank on one workgroup.  Same cells, same operations: bit-identical to the oracle and to the other form,
+    whichever is forced (HIPSTR_FLANK_SYSTOLIC = 0 never, 1 small launches, 2 every launch that fits 256 columns): flanks of 1 to 150
+    rows (one row; more than one band of 64 rows), masked reads and alleles, several flank options, interrupted repeats."""
+    cases = [dict(n_loci=2, reads_per_locus=40, n_str_alleles=32, seed=3),
+             dict(n_loci=3, reads_per_locus=25, n_str_alleles=7, n_flank_opts=2, seed=9, mask_rate=0.2),
+             dict(n_loci=2, reads_per_locus=30, n_str_alleles=5, flank_len=150, read_len=250, seed=4),
+             dict(n_loci=2, reads_per_locus=30, n_str_alleles=6, flank_len=8, seed=5),
+             dict(n_loci=40, reads_per_locus=60, n_str_alleles=16, seed=6)]
+    for kw in cases:
+        sb = capi.SynthBatch(**kw)
+        want, ws = capi.run_align(oracle, "oracle_", sb.ptr, fill=-6.5)
+        for mode in ("0", "1", "2"):
+            monkeypatch.setenv("HIPSTR_FLANK_SYSTOLIC", mode)
+            got, gs = capi.run_align(hmm, "hipstr_hmm_", sb.ptr, fill=-6.5)
+            assert np.array_equal(gs, ws) and np.array_equal(got, want), (kw, mode)
+    monkeypatch.delenv("HIPSTR_FLANK_SYSTOLIC")
