@@ -47,7 +47,7 @@ extern "C" __global__ void hs_expand_recs_kernel(const hs_dev_t* dp);
 extern "C" size_t hs_str_group_lds_bytes(int max_B, int nd_cap, int with_ilog);
 extern "C" size_t hs_str_group_p_lds_bytes();
 extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk, int max_cols);
-extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk, int max_cols);
+extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk, int max_cols, int max_rows);
 
 namespace {
 
@@ -352,6 +352,7 @@ struct hipstr_dev_batch {
   hs_dev_t* d_args = NULL;
   std::vector<void*> dev_blocks, pin_blocks;      // from the context's caches
   int grid_y = 1, max_alleles = 1, n_lead_items = 0, n_trail_items = 0, trail_waves = 1;
+  int max_rows = 0;              // longest flank rowset of the batch (rows of a flank block): picks the band shape of the trailing-flank sweep
   size_t grp_lds_bytes = 0, grp_pw_lds_bytes = 0;
   bool any_pw = false;           // some locus has alleles with piecewise simple lists (hs_str_group_kernel_pw)
   bool any_rp = false;           // ... with lists replayed in the grouped layout (hs_str_group_kernel_rp)
@@ -580,6 +581,8 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   // trailing-flank kernel: persistent wavefronts, each with two band-boundary rows of [max side columns][64 lanes][M,D]
   h.band_cols = P.max_side_len > 0 ? P.max_side_len : 1;
   dev->trail_waves = (int)std::min<size_t>(P.trail_items.size() ? P.trail_items.size() : 1, 256 * 16);
+  dev->max_rows = 0;
+  for (const hs_rowset_t& rs : P.rowsets) dev->max_rows = std::max(dev->max_rows, (int)rs.len);
   h.ws_band = (double*)dalloc(sizeof(double)*(size_t)dev->trail_waves*h.band_cols*64*2);
   h.n_active = (int32_t)P.active.size();
   // [n_active] re-do flags of hs_str_kernel | [2 x chunks] work counters of hs_lead_kernel and hs_trail_kernel
@@ -790,7 +793,7 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
     if (mark()) return 1;
     if (ch.trail_end > ch.trail_begin)     // trailing flanks: persistent wavefronts striding over (read side, allele group) items
       hs_launch_trail((unsigned)std::min(dev->trail_waves, ch.trail_end - ch.trail_begin), st, dp,
-                      dev->n_lead_items + ch.trail_begin, dev->n_lead_items + ch.trail_end, 2*chunk_no + 1, dev->h.band_cols);
+                      dev->n_lead_items + ch.trail_begin, dev->n_lead_items + ch.trail_end, 2*chunk_no + 1, dev->h.band_cols, dev->max_rows);
     if (mark()) return 1;
     hipLaunchKernelGGL(hs_combine_kernel, dim3(nact), dim3(64*hs_combine_waves()), 0, st, dp, ch.active_begin);
     if (mark()) return 1;

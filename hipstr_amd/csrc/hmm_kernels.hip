@@ -3063,13 +3063,18 @@ extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStr
   if (flank_coop()) hipLaunchKernelGGL((hs_lead_kernel_coop<HS_COOP_ROWS, HS_COOP_WAVES, HS_COOP_OCC>), dim3(std::max(1u, std::min(n_wavefronts, 256u*HS_COOP_OCC*4/HS_COOP_WAVES))), dim3(64*HS_COOP_WAVES), 0, st, dp, item_begin, item_end, chunk);
   else hipLaunchKernelGGL((hs_lead_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end, chunk);
 }
-extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk, int max_cols){
+extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk, int max_cols, int max_rows){
   if (item_end > item_begin && use_systolic(item_begin, item_end, max_cols)){
     hipLaunchKernelGGL((hs_flank_systolic<false>), dim3((unsigned)(item_end - item_begin), 64), dim3(64), 0, st, dp, item_begin);
     return;
   }
   if (flank_coop() && lat_shape() && (unsigned)(item_end - item_begin) <= HS_LAT_ITEMS)
     hipLaunchKernelGGL((hs_trail_kernel_coop<HS_LAT_ROWS, HS_LAT_WAVES, 2>), dim3(std::max(1u, std::min(n_wavefronts, 256u))), dim3(64*HS_LAT_WAVES), 0, st, dp, item_begin, item_end, chunk);
+  else
+  // short flanks (production panels: <= 35 bp): three bands of up to 12 rows fill their wavefronts better than four of 9 (p30 trailing flank
+  // 4.25 -> 4.02 ms, profiles/r05_notes.md; at 60 rows the 4 x 15 shape is the best by 25 %)
+  if (flank_coop() && max_rows - 1 <= 36 && !(getenv("HIPSTR_COOP_SHORT") && atoi(getenv("HIPSTR_COOP_SHORT")) == 0))
+    hipLaunchKernelGGL((hs_trail_kernel_coop<12, 3, 3>), dim3(std::max(1u, std::min(n_wavefronts, 256u*3*4/3))), dim3(64*3), 0, st, dp, item_begin, item_end, chunk);
   else
   if (flank_coop()) hipLaunchKernelGGL((hs_trail_kernel_coop<HS_COOP_ROWS, HS_COOP_WAVES, HS_COOP_OCC>), dim3(std::max(1u, std::min(n_wavefronts, 256u*HS_COOP_OCC*4/HS_COOP_WAVES))), dim3(64*HS_COOP_WAVES), 0, st, dp, item_begin, item_end, chunk);
   else hipLaunchKernelGGL((hs_trail_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end, chunk);
