@@ -776,7 +776,7 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
   h.log_thresh = HT.log_thresh; h.log_half = HT.log_half; h.log_1p1 = host_loop ? log(1.1) : cr_log(1.1);
   ph.units = d_units; ph.log_aln_probs = d_ll; ph.log_p1 = d_p1; ph.log_p2 = d_p2; ph.read_weight = d_w; ph.log_prior = d_prior;
   ph.unit_active = d_unit_active; ph.log_post = d_post; ph.sample_total = d_tot; ph.map_gt = d_mapgt;
-  ph.log_thresh = HT.log_thresh; ph.log_half = HT.log_half;
+  ph.log_thresh = HT.log_thresh; ph.log_half = HT.log_half; ph.sym_prior = 1;          // hs_em_fill: log f(a1) + log f(a2), or the haploid diagonal
   hs_em_dev_t* d_h; hs_post_dev_t* d_ph;
   if (dev.put(&d_h, &h, 1) || dev.put(&d_ph, &ph, 1)) return 1;
 

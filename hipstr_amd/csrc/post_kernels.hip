@@ -79,6 +79,39 @@ __device__ __forceinline__ void posterior_body(const hs_post_dev_t& d){
 #endif
     double v[HS_POST_REGS];
     double lmax = -1.0e300;
+    // Without phasing information (log_p1 == log_p2 for every read of the sample: the stutter EM, unphased samples) and with a prior
+    // that does not tell the two alleles apart, diplotypes (a1, a2) and (a2, a1) accumulate the same numbers in the same order — the
+    // float pair log-sum-exp takes the larger argument first whichever comes first (mathops.cpp:86-95), the default priors depend on
+    // a1 == a2 only — so only the pairs a1 <= a2 are computed (A (A + 1) / 2 of A^2) and mirrored through LDS: the same bits.
+    bool sym = (d.log_prior == NULL || d.sym_prior != 0) && A >= 4;
+    for (int r = 0; r < u.n_reads && sym; r++) sym = (d.log_p1[u.read_begin + r] == d.log_p2[u.read_begin + r]);
+    if (sym){
+      const int npairs = A*(A + 1)/2;
+      for (int q = tid; q < npairs; q += 256){
+        // pair q of the upper triangle, row by row: row i starts at i A - i (i - 1) / 2
+        int i = (int)(((float)(2*A + 1) - sqrtf((float)((2*A + 1)*(2*A + 1) - 8*q))) * 0.5f);
+        i = max(0, min(i, A - 1));
+        while (i > 0 && i*A - i*(i - 1)/2 > q) i--;
+        while ((i + 1)*A - (i + 1)*i/2 <= q) i++;
+        const int j = i + (q - (i*A - i*(i - 1)/2));
+        const int idx = i*A + j;
+        double x = d.log_prior ? d.log_prior[u.prior_off + idx] : ((i == j) ? u.log_hom_prior : u.log_het_prior);
+        for (int r = 0; r < u.n_reads; r++){
+          const int g = u.read_begin + r;
+          const double* LL = LL0 + (int64_t)r*A;
+          x += (double)d.read_weight[g] * fast_lse2((d.log_half + d.log_p1[g]) + LL[i], (d.log_half + d.log_p2[g]) + LL[j], d.log_thresh);
+        }
+        ebuf[idx] = x; ebuf[j*A + i] = x;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < HS_POST_REGS; k++){
+        const int idx = tid + 256*k;
+        v[k] = -1.0e300;
+        if (idx < nd){ v[k] = ebuf[idx]; lmax = fmax(lmax, v[k]); }
+      }
+      __syncthreads();                                    // (ebuf is written again below)
+    } else
 #pragma unroll
     for (int k = 0; k < HS_POST_REGS; k++){
       const int idx = tid + 256*k;

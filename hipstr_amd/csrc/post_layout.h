@@ -32,6 +32,7 @@ struct hs_post_dev_t {
   // the launch is sized by a bound the host knows, the live units by a count only the device knows.  NULL = workgroup b takes unit b.
   const int32_t* unit_list;
   const int32_t* n_list;
+  int32_t        sym_prior;      // the prior array is symmetric in the two alleles (the EM's: log f(a1) + log f(a2)): see the symmetric accumulation in post_kernels.hip
 };
 
 // One (locus, sample) pair of the genotype extraction (Genotyper::extract_genotypes_and_likelihoods, genotyper.cpp:129-251).
