@@ -46,7 +46,7 @@ extern "C" __global__ void hs_expand_stropts_kernel(const hs_dev_t* dp);
 extern "C" __global__ void hs_expand_recs_kernel(const hs_dev_t* dp);
 extern "C" size_t hs_str_group_lds_bytes(int max_B, int nd_cap, int with_ilog);
 extern "C" size_t hs_str_group_p_lds_bytes();
-extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk, int max_cols);
+extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk, int max_cols, int n_clear);
 extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk, int max_cols, int max_rows);
 
 namespace {
@@ -755,13 +755,13 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
     HS_HIP(hipEventRecord(dev->prof_pool[dev->prof_used++], st));
     return 0;
   };
-  HS_HIP(hipMemsetAsync(dev->h.redo, 0, sizeof(int32_t)*((size_t)dev->h.n_active + 2*dev->prep.chunks.size() + 2), st));
+  const int n_clear = (int)((size_t)dev->h.n_active + 2*dev->prep.chunks.size() + 2);        // re-do flags + item counters: cleared by hs_col_kernel
   int chunk_no = 0;
   for (const hipstr::Prepared::Chunk& ch : dev->prep.chunks){
     const unsigned nact = ch.active_end - ch.active_begin;
     if (mark()) return 1;
     // leading flanks: persistent wavefronts striding over (locus side, distinct flank, 64 reads) items
-    hs_launch_lead2(nact, (unsigned)std::max(1, std::min(dev->trail_waves, ch.lead_end - ch.lead_begin)), st, dp, ch.active_begin, ch.lead_begin, ch.lead_end, 2*chunk_no, dev->h.band_cols);
+    hs_launch_lead2(nact, (unsigned)std::max(1, std::min(dev->trail_waves, ch.lead_end - ch.lead_begin)), st, dp, ch.active_begin, ch.lead_begin, ch.lead_end, 2*chunk_no, dev->h.band_cols, n_clear);
     if (mark()) return 1;
     // tabulated alleles: reads of a locus side packed into workgroups (HIPSTR_STR_GROUP=0: one workgroup per read, for comparison)
     const bool str_group = !(getenv("HIPSTR_STR_GROUP") && atoi(getenv("HIPSTR_STR_GROUP")) == 0);

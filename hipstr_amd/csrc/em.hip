@@ -103,6 +103,16 @@ __device__ __forceinline__ int em_locus(const hs_em_dev_t& d){
 
 namespace {
 
+// The two float divisions of the reference's bit-trick exp2 / log (fastonebigheader.h:188-198: 27.7280233f / (4.84252568f - z), z in [0, 1];
+// :320-338: 1.72587999f / (0.3520887068f + mx), mx in [0.5, 1)) as v_rcp_f32 + one Newton step + a residual correction: six instructions
+// instead of the compiler's IEEE sequence (scale, reciprocal, three refinements, fmas, fixup: twice that), and the IEEE quotient for EVERY
+// float denominator of both ranges — tools/div_probe.hip checks all 8.4 M of them on the device.  Operands outside those ranges: never here.
+__device__ __forceinline__ float e_div_tab(float n, float d){
+  float r = __builtin_amdgcn_rcpf(d);
+  r = __fmaf_rn(__fmaf_rn(-d, r, 1.0f), r, r);
+  const float q = __fmul_rn(n, r);
+  return __fmaf_rn(__fmaf_rn(-d, q, n), r, q);
+}
 __device__ __forceinline__ float e_fasterexp(float p){           // fastonebigheader.h:206-218
   const float y = __fmul_rn(1.442695040f, p);
   const float c = (y < -126.0f) ? -126.0f : y;
@@ -118,7 +128,7 @@ __device__ __forceinline__ float e_fastpow2(float p){            // fastonebighe
   const float clipp = (p < -126.0f) ? -126.0f : p;
   const int w = (int)clipp;
   const float z = __fadd_rn(__fsub_rn(clipp, (float)w), offset);
-  const float t = __fsub_rn(__fadd_rn(__fadd_rn(clipp, 121.2740575f), __fdiv_rn(27.7280233f, __fsub_rn(4.84252568f, z))), __fmul_rn(1.49012907f, z));
+  const float t = __fsub_rn(__fadd_rn(__fadd_rn(clipp, 121.2740575f), e_div_tab(27.7280233f, __fsub_rn(4.84252568f, z))), __fmul_rn(1.49012907f, z));
   return __uint_as_float((uint32_t)__fmul_rn(8388608.0f, t));
 }
 __device__ __forceinline__ float e_fastlog(float x){             // fastonebigheader.h:320-338
@@ -127,7 +137,7 @@ __device__ __forceinline__ float e_fastlog(float x){             // fastonebighe
   float y = (float)vi;
   y = __fmul_rn(y, 1.1920928955078125e-7f);
   const float l2 = __fsub_rn(__fsub_rn(__fsub_rn(y, 124.22551499f), __fmul_rn(1.498030302f, mx)),
-                             __fdiv_rn(1.72587999f, __fadd_rn(0.3520887068f, mx)));
+                             e_div_tab(1.72587999f, __fadd_rn(0.3520887068f, mx)));
   return __fmul_rn(0.69314718f, l2);
 }
 __device__ __forceinline__ double e_fast_lse2(double a, double b, double thr){    // mathops.cpp:86-95

@@ -250,8 +250,11 @@ __global__ void __launch_bounds__(64, HS_FLANK_WAVES) hs_trail_kernel(const hs_d
 // ------------------------------------------------------------------ leading flank: reads as lanes, the same banded sweep
 // Per-column emission logs of an active read in side orientation (left side columns, then the reversed right side, HapAligner.cpp:606-609):
 // [len-1][3] doubles = log P(correct), log P(error), base.  One wavefront per read; read by hs_lead_kernel and hs_trail_kernel.
-__global__ void __launch_bounds__(64) hs_col_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
+__global__ void __launch_bounds__(64) hs_col_kernel(const hs_dev_t* __restrict__ dp, int active_begin, int n_clear){
   const hs_dev_t& d = *dp;
+  // the re-do flags and the item counters of the pass (a hipMemsetAsync before: two fill kernels and a gap in every small call).  Every chunk's
+  // launch clears all of them: the chunks run one after the other on one stream, an earlier chunk's flags and counters are used up by then
+  for (int i = blockIdx.x*64 + threadIdx.x; i < n_clear; i += gridDim.x*64) d.redo[i] = 0;
   const int ai = active_begin + blockIdx.x;
   const hs_read_t rd = d.reads[d.active[ai]];
   double* col = d.ws_col + d.ws[ai].col;
@@ -3048,8 +3051,8 @@ static bool use_systolic(int item_begin, int item_end, int max_cols){
   // (a wavefront per alignment: up to 64 per item; beyond ~6000 of them the sweeps that share rows across lanes are faster again)
   return m != 0 && max_cols <= HS_SYS_MAXCOLS && (m == 2 || (unsigned)(item_end - item_begin) <= HS_SYS_ITEMS);
 }
-extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk, int max_cols){
-  hipLaunchKernelGGL(hs_col_kernel, dim3(n_active), dim3(64), 0, st, dp, active_begin);
+extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk, int max_cols, int n_clear){
+  hipLaunchKernelGGL(hs_col_kernel, dim3(n_active), dim3(64), 0, st, dp, active_begin, n_clear);
   if (item_end <= item_begin) return;
   if (use_systolic(item_begin, item_end, max_cols)){
     hipLaunchKernelGGL((hs_flank_systolic<true>), dim3((unsigned)(item_end - item_begin), 64), dim3(64), 0, st, dp, item_begin);
