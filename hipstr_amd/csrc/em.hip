@@ -71,6 +71,7 @@ struct hs_em_dev_t {
                                //   category (0 in_up, 1 in_down, 2 in_eq, 4 out_up, 5 out_down) | diffs vector (3 in, 6 out, 255 none) << 8
   double*  leff;               // same layout: ln |effective difference| (the addend of the diffs vectors), 0 where there is none
   double*  part;               // [n_loci][HS_EM_PARTS][7] partial maxima, then partial sums, of the seven M-step vectors
+  unsigned long long* dbg;     // HIPSTR_TIMING: [0..1] rows listed / rows scanned in the maxima pass, [2..3] in the sums pass
   double*  gmax;               // [S*A per locus, at sa_off] largest log posterior of any diplotype of the sample that holds the allele (hs_em_gmax)
   double   log_thresh, log_half, log_1p1;
   // ---- device-resident loop (NULL / unused with the host loop): workgroup b of a per-locus kernel takes locus list[b] if b < counts[0]
@@ -207,6 +208,9 @@ __device__ __forceinline__ double block_sum(double v, double* red){
 // recalc_log_gt_priors (:22-57) of one locus by one workgroup: thread a owns allele a; the two scans in the reference's order.
 // Independent of the stutter reductions, so it rides in their first launch as one more slice (blockIdx.y == HS_EM_PARTS).
 __device__ void em_gt_priors(const hs_em_dev_t& d, const hs_em_locus_t& L, int tid){
+#ifdef HS_EM_TIME
+  unsigned long long tk0 = __builtin_amdgcn_s_memtime(), tk1 = 0, tk2 = 0, tkA = 0, tkB = 0;
+#endif
   const int A = L.A, S = L.S;
   const double* post = d.post + L.post_off;
   double* gtp = d.gtp + L.bps_off;
@@ -221,6 +225,7 @@ __device__ void em_gt_priors(const hs_em_dev_t& d, const hs_em_locus_t& L, int t
     const int Ap = A | 1;                                // odd row stride: the per-row walks of neighbouring threads fall into different banks
     const int tile_rows = min(256, (int)((2*HS_EM_CHUNK*HS_EM_MAXA_LDS) / Ap));
     __shared__ double s_rm[256];
+    __shared__ int s_fm[256];
     if (tile_rows >= 1){
       for (int x0 = 0; x0 < S*A; x0 += tile_rows){
         const int nr = min(tile_rows, S*A - x0);
@@ -228,18 +233,25 @@ __device__ void em_gt_priors(const hs_em_dev_t& d, const hs_em_locus_t& L, int t
         __syncthreads();
         if (tid < nr){
           const double* row = hs_em_dyn + tid*Ap;
-          double rm = row[0];
-          for (int j = 1; j < A; j++) rm = fmax(rm, row[j]);
-          s_rm[tid] = rm;
+          double rm = row[0]; int fm = 0;
+          for (int j = 1; j < A; j++) if (row[j] > rm){ rm = row[j]; fm = j; }
+          s_rm[tid] = rm; s_fm[tid] = fm;
         }
         __syncthreads();
-        for (int e = tid; e < nr*A; e += 256){ const int rr = e / A, j = e - rr*A; hs_em_dyn[rr*Ap + j] = cr_exp(hs_em_dyn[rr*Ap + j] - s_rm[rr]); }
+        // (behind the row's first maximum the running total is >= 1: a term below 2^-54 leaves it as it is and is not formed — +0.0 instead)
+        for (int e = tid; e < nr*A; e += 256){
+          const int rr = e / A, j = e - rr*A;
+          const double x_ = hs_em_dyn[rr*Ap + j] - s_rm[rr];
+          hs_em_dyn[rr*Ap + j] = (j > s_fm[rr] && x_ < -37.43) ? 0.0 : cr_exp(x_);
+        }
         __syncthreads();
         if (tid < nr){
+          __builtin_amdgcn_s_setprio(3);
           const double* row = hs_em_dyn + tid*Ap;
           double rs = 0.0;
           for (int j = 0; j < A; j++) rs += row[j];
           row_lse[x0 + tid] = s_rm[tid] + cr_log(rs);
+          __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
       }
@@ -255,6 +267,9 @@ __device__ void em_gt_priors(const hs_em_dev_t& d, const hs_em_locus_t& L, int t
     }
   }
   __syncthreads();
+#ifdef HS_EM_TIME
+  tk1 = __builtin_amdgcn_s_memtime();
+#endif
   // The two scans of allele a are ONE dependent chain over S + S A values (update_streaming_log_sum_exp, mathops.cpp:72-80): lane a owns it.
   // What is expensive in a step is the exponential, and that does not depend on the chain except through the running maximum m, which
   // changes only a handful of times: so the values are taken HS_EM_CHUNK at a time — every thread of the workgroup forms
@@ -286,26 +301,48 @@ __device__ void em_gt_priors(const hs_em_dev_t& d, const hs_em_locus_t& L, int t
         hs_em_dyn[CH*HS_EM_MAXA_LDS + i*Apad + al] = lv;     // the value itself: the walk is a dependent chain and must not wait for L2 at every step
       }
       __syncthreads();
+#ifdef HS_EM_TIME
+      const unsigned long long ta = __builtin_amdgcn_s_memtime();
+#endif
       if (tid < na){
+        __builtin_amdgcn_s_setprio(3);                   // the workgroup waits for this one wavefront's dependent chain: it goes first whenever it is ready
         const double ms = s_m[tid];
-        for (int i = 0; i < cn; i++){
-          const double lv = hs_em_dyn[CH*HS_EM_MAXA_LDS + i*Apad + tid];
-          if (lv <= m){
-            if (m == ms){
-              const double ex = hs_em_dyn[i*Apad + tid];
-              // (once a maximum is set the total is >= 1: a term below 2^-54 leaves it as it is, bit for bit; before that — t < 1 only while
-              //  m is still the initial -DBL_MAX/2, where no value is below it — it cannot occur)
-              if (ex >= 0.0) t += ex;
-            } else { const double x_ = lv - m; if (!(t >= 1.0 && x_ < -37.43)) t += cr_exp(x_); }
-          } else { t *= cr_exp(m - lv); t += 1.0; m = lv; }
+        // eight steps' operands are fetched together, ahead of the (dependent) chain: a step that waited for its own two LDS reads took ~400 cycles
+        for (int i0 = 0; i0 < cn; i0 += 8){
+          double lvv[8], exv[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++){
+            const int i = min(i0 + q, cn - 1);
+            lvv[q] = hs_em_dyn[CH*HS_EM_MAXA_LDS + i*Apad + tid]; exv[q] = hs_em_dyn[i*Apad + tid];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; q++){
+            if (i0 + q >= cn) break;
+            const double lv = lvv[q];
+            if (lv <= m){
+              if (m == ms){
+                // (once a maximum is set the total is >= 1: a term below 2^-54 leaves it as it is, bit for bit; before that — t < 1 only while
+                //  m is still the initial -DBL_MAX/2, where no value is below it — it cannot occur)
+                if (exv[q] >= 0.0) t += exv[q];
+              } else { const double x_ = lv - m; if (!(t >= 1.0 && x_ < -37.43)) t += cr_exp(x_); }
+            } else { t *= cr_exp(m - lv); t += 1.0; m = lv; }
+          }
         }
         s_m[tid] = m;
+        __builtin_amdgcn_s_setprio(0);
       }
+#ifdef HS_EM_TIME
+      tkB += __builtin_amdgcn_s_memtime() - ta;
+#endif
       __syncthreads();
     }
     if (tid < na) gtp[a0 + tid] = m + cr_log(t);
     __syncthreads();
   }
+#ifdef HS_EM_TIME
+  tk2 = __builtin_amdgcn_s_memtime();
+  if (tid == 0 && (blockIdx.x % 2000) == 7) printf("gt_priors locus %d A %d S %d: rows %llu  scans %llu (walks %llu)\n", (int)blockIdx.x, A, S, tk1 - tk0, tk2 - tk1, tkB);
+#endif
   if (tid == 0){                                          // normalise: exact log_sum_exp in allele order
     double m = gtp[0];
     for (int a = 1; a < A; a++) m = fmax(m, gtp[a]);
@@ -417,6 +454,7 @@ __global__ void __launch_bounds__(256) hs_em_mstep_part(const hs_em_dev_t* __res
     }
     __syncthreads();
     const int n_live = s_cnt;
+    if (d.dbg && tid == 0){ atomicAdd(d.dbg + 2*PASS, (unsigned long long)n_live); atomicAdd(d.dbg + 2*PASS + 1, (unsigned long long)(t1 - t0)); }
     for (int li = tid; li < n_live; li += 256){
       const int x = s_rows[li];
     const int r = x / A, a = x - r*A;
@@ -783,6 +821,9 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
       dev.alloc(&d_cat, ll_off) || dev.alloc(&d_leff, ll_off) || dev.alloc(&d_part, 7*(size_t)HS_EM_PARTS*nl) || dev.alloc(&d_keep, 7*(size_t)nl) || dev.alloc(&d_gmax, sa_off)) return 1;
   h.loci = d_loci; h.active = d_active; h.logp = d_logp; h.bps = d_bps; h.obs = d_obs; h.sample_label = d_lab; h.log_p1 = d_p1; h.log_p2 = d_p2;
   h.gtp = d_gtp; h.ll = d_ll; h.prior = d_prior; h.post = d_post; h.sample_total = d_tot; h.int_log = T.int_log; h.new_ll = d_newll; h.sums = d_sums; h.row_lse = d_rowlse; h.cat = d_cat; h.leff = d_leff; h.part = d_part; h.gmax = d_gmax;
+  unsigned long long* d_dbg = NULL;
+  if (timing){ if (dev.alloc(&d_dbg, 4)) return 1; EM_HIP(hipMemset(d_dbg, 0, 4*sizeof(unsigned long long))); }
+  h.dbg = d_dbg;
   h.log_thresh = HT.log_thresh; h.log_half = HT.log_half; h.log_1p1 = host_loop ? log(1.1) : cr_log(1.1);
   ph.units = d_units; ph.log_aln_probs = d_ll; ph.log_p1 = d_p1; ph.log_p2 = d_p2; ph.read_weight = d_w; ph.log_prior = d_prior;
   ph.unit_active = d_unit_active; ph.log_post = d_post; ph.sample_total = d_tot; ph.map_gt = d_mapgt;
@@ -841,6 +882,7 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
     hipLaunchKernelGGL(hs_em_units, dim3(nl), dim3(256), 0, T.stream, (const hs_em_dev_t*)(d_hb + 1));
     unsigned bound_l = (unsigned)nl, bound_u = (unsigned)n_units;
     int rounds = 0;
+    const bool em_serial = getenv("HIPSTR_EM_SERIAL") && atoi(getenv("HIPSTR_EM_SERIAL")) != 0;      // (experiments) the allele-frequency scans on the main stream
     for (int r = 0; r <= eb->max_iter + 1; r++){
       const hs_em_dev_t* H = d_hb + (r & 1); const hs_post_dev_t* PH = d_pb + (r & 1);
       if (bound_l > 0){
@@ -848,7 +890,7 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
         hipLaunchKernelGGL(hs_posterior_kernel, dim3(std::max(1u, bound_u)), dim3(256), 0, T.stream, PH);
         EM_HIP(hipEventRecord(side.ev_fork, T.stream));                  // posteriors are in place: the allele-frequency scans branch off
         EM_HIP(hipStreamWaitEvent(side.stream, side.ev_fork, 0));
-        hipLaunchKernelGGL(hs_em_gt_priors, dim3(bound_l), dim3(256), 2*HS_EM_CHUNK*HS_EM_MAXA_LDS*sizeof(double), side.stream, H);
+        hipLaunchKernelGGL(hs_em_gt_priors, dim3(bound_l), dim3(256), 2*HS_EM_CHUNK*HS_EM_MAXA_LDS*sizeof(double), em_serial ? T.stream : side.stream, H);
         EM_HIP(hipEventRecord(side.ev_join, side.stream));
         hipLaunchKernelGGL(hs_em_gmax, dim3(bound_l), dim3(256), 0, T.stream, H);
         hipLaunchKernelGGL(hs_em_mstep_part<0>, dim3(bound_l, HS_EM_PARTS), dim3(256), 0, T.stream, H, (const double*)NULL);
@@ -879,7 +921,11 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
     EM_HIP(hipMemcpy(final_ll, d_fll, nl*sizeof(double), hipMemcpyDeviceToHost));
     EM_HIP(hipMemcpy(stutter, d_sp, 6*(size_t)nl*sizeof(double), hipMemcpyDeviceToHost));
     for (int l = 0; l < nl; l++){ trained[l] = state[l] == 1 ? 1 : 0; n_iter[l] = niter[l]; }
-    if (timing) fprintf(stderr, "hipstr_em_train: device-resident loop, %d rounds queued: %.3f ms\n", rounds, 1e3*t_gpu);
+    if (timing){
+      unsigned long long c[4] = {0, 0, 0, 0};
+      if (d_dbg) hipMemcpy(c, d_dbg, sizeof c, hipMemcpyDeviceToHost);
+      fprintf(stderr, "hipstr_em_train: device-resident loop, %d rounds queued: %.3f ms; M-step rows walked: maxima pass %llu of %llu, sums pass %llu of %llu\n", rounds, 1e3*t_gpu, c[0], c[1], c[2], c[3]);
+    }
     return 0;
   }
   // ---- the EM loop of train() (:171-226), all loci in lock step, converged loci masked out

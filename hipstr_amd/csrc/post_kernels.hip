@@ -160,6 +160,7 @@ __device__ __forceinline__ void posterior_body(const hs_post_dev_t& d){
     __syncthreads();
     HS_PT(3);
     if (tid == 0){
+      __builtin_amdgcn_s_setprio(3);                      // 255 threads wait for this chain of additions: it goes first whenever it is ready
       double lsum = 0.0;
       int k = 0;
       for (; k + 8 <= nd; k += 8){
@@ -168,6 +169,7 @@ __device__ __forceinline__ void posterior_body(const hs_post_dev_t& d){
       }
       for (; k < nd; k++) lsum += ebuf[k];
       red_v[8] = mx + cr_log(lsum);
+      __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
     HS_PT(4);
