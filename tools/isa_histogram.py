@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Static instruction-class histogram of every kernel of hmm_kernels.hip / post_kernels.hip, from the compiler's gfx950 assembly
+"""Static instruction-class histogram of every kernel of hmm_kernels.hip / post_kernels.hip / expand_kernels.hip / em.hip, from the compiler's gfx950 assembly
 (hipcc --cuda-device-only -S with the library's flags; no GPU needed) -> profiles/<tag>_isa_histogram.json.
 
 Classes follow the measured issue costs (profiles/*_valu_microbench.json):
@@ -40,7 +40,7 @@ def classify(m):
 
 
 out = {}
-for src in ("hmm_kernels.hip", "post_kernels.hip", "expand_kernels.hip"):
+for src in ("hmm_kernels.hip", "post_kernels.hip", "expand_kernels.hip", "em.hip"):
     with tempfile.TemporaryDirectory() as t:
         asm = os.path.join(t, "k.s")
         flags = [f for f in build.HIPCC_FLAGS if f not in ("-shared", "-fPIC", "-pthread")]
