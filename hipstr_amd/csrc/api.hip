@@ -29,7 +29,7 @@
 
 extern "C" __global__ void hs_str_kernel(const hs_dev_t* dp, int active_begin, int only_long);
 extern "C" __global__ void hs_str_kernel_generic(const hs_dev_t* dp, int active_begin, int pw_grouped);
-extern "C" __global__ void hs_combine_kernel(const hs_dev_t* dp, int active_begin);
+extern "C" __global__ void hs_combine_kernel(const hs_dev_t* dp, int active_begin, int skip_fused);
 extern "C" int hs_combine_waves();
 extern "C" __global__ void hs_posterior_kernel(const hs_post_dev_t* dp);
 extern "C" __global__ void hs_posterior_accumulate_kernel(const hs_post_dev_t* dp);
@@ -47,7 +47,8 @@ extern "C" __global__ void hs_expand_recs_kernel(const hs_dev_t* dp);
 extern "C" size_t hs_str_group_lds_bytes(int max_B, int nd_cap, int with_ilog);
 extern "C" size_t hs_str_group_p_lds_bytes();
 extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk, int max_cols, int n_clear);
-extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk, int max_cols, int max_rows);
+extern "C" int hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk, int max_cols, int max_rows,
+                               int n_fused_items, int n_plain_items);
 
 namespace {
 
@@ -352,6 +353,7 @@ struct hipstr_dev_batch {
   hs_dev_t* d_args = NULL;
   std::vector<void*> dev_blocks, pin_blocks;      // from the context's caches
   int grid_y = 1, max_alleles = 1, n_lead_items = 0, n_trail_items = 0, trail_waves = 1;
+  int n_fused = 0;               // loci whose trailing flanks and compute_aln_logprob run as one item (hs_locus_t::fused)
   int max_rows = 0;              // longest flank rowset of the batch (rows of a flank block): picks the band shape of the trailing-flank sweep
   size_t grp_lds_bytes = 0, grp_pw_lds_bytes = 0;
   bool any_pw = false;           // some locus has alleles with piecewise simple lists (hs_str_group_kernel_pw)
@@ -584,6 +586,11 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   dev->max_rows = 0;
   for (const hs_rowset_t& rs : P.rowsets) dev->max_rows = std::max(dev->max_rows, (int)rs.len);
   h.ws_band = (double*)dalloc(sizeof(double)*(size_t)dev->trail_waves*h.band_cols*64*2);
+  // fused items: per workgroup of hs_trail_kernel_coop (its grids are at most 1024 workgroups) [lt_stride of the fused loci][64 lanes] last columns
+  dev->n_fused = 0; h.lts_rows = 1;
+  for (const hs_locus_t& lc : P.loci) if (lc.fused){ dev->n_fused++; h.lts_rows = std::max(h.lts_rows, lc.lt_stride); }
+  h.ws_lts = dev->n_fused ? (double*)dalloc(sizeof(double)*(size_t)std::min(dev->trail_waves, 1024)*h.lts_rows*64) : NULL;
+  if (dev->n_fused && !h.ws_lts){ hipstr_hmm_free(dev); return NULL; }
   h.n_active = (int32_t)P.active.size();
   // [n_active] re-do flags of hs_str_kernel | [2 x chunks] work counters of hs_lead_kernel and hs_trail_kernel
   h.redo = (int32_t*)dalloc(sizeof(int32_t)*((size_t)h.n_active + 2*P.chunks.size() + 2));
@@ -791,11 +798,15 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
     // alleles without a tabulated closed form (interrupted repeats, very long blocks) and whatever hs_str_kernel marked HS_REDO
     hipLaunchKernelGGL(hs_str_kernel_generic, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin, str_group ? 1 : 0);
     if (mark()) return 1;
+    int fused_done = 0;
     if (ch.trail_end > ch.trail_begin)     // trailing flanks: persistent wavefronts striding over (read side, allele group) items
-      hs_launch_trail((unsigned)std::min(dev->trail_waves, ch.trail_end - ch.trail_begin), st, dp,
-                      dev->n_lead_items + ch.trail_begin, dev->n_lead_items + ch.trail_end, 2*chunk_no + 1, dev->h.band_cols, dev->max_rows);
+      fused_done = hs_launch_trail((unsigned)std::min(dev->trail_waves, ch.trail_end - ch.trail_begin), st, dp,
+                                   dev->n_lead_items + ch.trail_begin, dev->n_lead_items + ch.trail_end, 2*chunk_no + 1, dev->h.band_cols, dev->max_rows,
+                                   ch.n_fused_items, ch.trail_end - ch.trail_begin - ch.n_fused_items);
     if (mark()) return 1;
-    hipLaunchKernelGGL(hs_combine_kernel, dim3(nact), dim3(64*hs_combine_waves()), 0, st, dp, ch.active_begin);
+    // compute_aln_logprob: fused loci got theirs inside the trailing-flank kernel; a batch of fused loci only skips the launch
+    if (!(fused_done && dev->n_fused == (int)dev->prep.loci.size()))
+      hipLaunchKernelGGL(hs_combine_kernel, dim3(nact), dim3(64*hs_combine_waves()), 0, st, dp, ch.active_begin, fused_done && dev->n_fused > 0 ? 1 : 0);
     if (mark()) return 1;
     HS_HIP(hipGetLastError());
     chunk_no++;
@@ -972,6 +983,14 @@ int hipstr_debug_allele_kinds(hipstr_dev_batch_t* dev, int64_t counts[4]){
   const hipstr::Prepared& P = dev->prep;
   for (const hs_allele_t& al : P.alleles)
     if (al.realign) for (int side = 0; side < 2; side++){ const int k = P.stropts[al.str_opt[side]].kind; if (k >= 0 && k <= 3) counts[k]++; }
+  return 0;
+}
+
+// Diagnostics (tests): out[0] = loci of the batch whose trailing flanks and compute_aln_logprob run as one item (hs_locus_t::fused; opt-in:
+// HIPSTR_TRAIL_FUSED=1), out[1] = all its loci
+int hipstr_debug_fused_loci(hipstr_dev_batch_t* dev, int64_t out[2]){
+  if (!dev || !out) return fail("null argument");
+  out[0] = dev->n_fused; out[1] = (int64_t)dev->prep.loci.size();
   return 0;
 }
 

@@ -148,7 +148,9 @@ struct hs_locus_t {
   int32_t n_pw[2];           // positions [n_tab, n_pw) of the order: alleles whose lists are simple or piecewise simple (hs_stropt_t::kind 2),
                              // hs_str_group_kernel_pw's; the rest, [n_pw, n_re), is hs_str_kernel_generic's
   int32_t period;            // the locus' STR period (the same for all of its alleles)
-  int32_t pad_;
+  int32_t fused;             // 1: the trailing flanks of both sides and compute_aln_logprob run as ONE item per (read pack, allele group)
+                             // (hs_trail_kernel_coop, side == 2; prep.cpp trail_fusable): the two sides' allele groups are the same lists,
+                             // every allele of a group has the same flank configuration; hs_combine_kernel leaves this locus' reads alone
   int32_t n_rp[2];           // positions [n_pw, n_rp) of the order: alleles with a list that has no closed form (three and more interruptions;
                              // hs_stropt_t::kind 3): hs_str_group_kernel_rp replays it inside the grouped layout; [n_rp, n_re) is hs_str_kernel_generic's
 };
@@ -223,6 +225,7 @@ struct hs_dev_t {
                                  // set = ... and is that block plus one repeat unit, periodic, with all six deletion sizes
   HS_P(double) ws_col;
   HS_P(double) ws_band;    // per persistent wavefront: 2 x [band_cols][64 lanes][2] band-boundary rows (M, D)
+  HS_P(double) ws_lts;     // per workgroup of hs_trail_fused_coop: [lts_rows][64 lanes] last columns of a fused item's two trailing flanks (scratch that stays in cache)
   HS_P(double) ws_mr;
   HS_P(double) ws_lt;
   HS_P(double) ws_lead;
@@ -242,6 +245,7 @@ struct hs_dev_t {
   int32_t            grp_nd_cap;     // hs_str_group_kernel: doubles of the read-end deletion table = max over the groups of reads x 36 period
   int32_t            lds_len;        // max read length in the batch (LDS carve of the STR kernel)
   int32_t            band_cols;      // max columns of one read side (rows of a band-boundary buffer)
+  int32_t            lts_rows;       // rows of a workgroup's ws_lts block: the batch's largest lt_stride
   int32_t            max_B;          // longest STR allele of the batch (LDS carve of the STR kernel)
   int32_t            debug_redo;     // tests (HIPSTR_DEBUG_REDO=k): hs_str_kernel leaves every k-th chunk to the re-do path
   int32_t            n_stropts, n_recs;
