@@ -326,6 +326,20 @@ hipStream_t thread_stream(Ctx* c){
   return st;
 }
 
+// A second stream per (host thread, device): the tables the device builds for itself (expand_kernels.hip) are inputs of the STR-block kernels
+// only, so on the one-shot path they are built here while the caller's stream runs the column tables and the leading flanks (20 us of a
+// 190 us one-locus call).  NULL when it cannot be made: the expansion then stays on the upload's stream.
+hipStream_t thread_aux_stream(Ctx* c){
+  thread_local std::map<Ctx*, hipStream_t> mine;
+  auto it = mine.find(c);
+  if (it != mine.end()) return it->second;
+  hipStream_t st = NULL;
+  static const bool off = getenv("HIPSTR_EXPAND_ASIDE") && atoi(getenv("HIPSTR_EXPAND_ASIDE")) == 0;
+  if (off || hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = NULL;
+  mine[c] = st;
+  return st;
+}
+
 }  // namespace
 
 // what the other translation units of the library (trace.hip, em.hip, nw.hip) need from this one: api_internal.h
@@ -361,6 +375,8 @@ struct hipstr_dev_batch {
   bool any_short = false;        // some locus has tabulated alleles hs_str_group_kernel_p does not take (period above HS_GRP_MAXP)
   size_t lds_bytes = 0;
   hipEvent_t ev0 = NULL, ev1 = NULL;
+  hipEvent_t ev_expand = NULL;            // the device-built tables are ready (recorded on the thread's aux stream; the first pass waits for it before the STR-block kernels)
+  hipStream_t aux_stream = NULL; bool expand_joined = false;
   hipEvent_t ev_h2d = NULL, ev_done = NULL, ev_d2h = NULL;     // upload finished / last pass finished / results in host_out (pipelined use)
   hipStream_t stream = NULL;                // launches, copies and waits of this batch default to it (the creating thread's stream)
   hipStream_t h2d_stream = NULL, d2h_stream = NULL;
@@ -439,6 +455,7 @@ void hipstr_hmm_free(hipstr_dev_batch_t* dev){
       hipStreamSynchronize(dev->stream);
       if (dev->h2d_stream && dev->h2d_stream != dev->stream) hipStreamSynchronize(dev->h2d_stream);
       if (dev->d2h_stream && dev->d2h_stream != dev->stream) hipStreamSynchronize(dev->d2h_stream);
+      if (dev->ev_expand) hipStreamSynchronize(dev->aux_stream);       // (a batch that was never aligned)
     }
     for (void* p : dev->dev_blocks) dev->ctx->dev_cache.put(p);
     for (void* p : dev->pin_blocks) dev->ctx->pin_cache.put(p);
@@ -446,6 +463,7 @@ void hipstr_hmm_free(hipstr_dev_batch_t* dev){
   if (dev->ctx){         // back to the context's pool (an event that is still pending is simply recorded again by its next user)
     dev->ctx->put_event(dev->ev0, true); dev->ctx->put_event(dev->ev1, true);
     dev->ctx->put_event(dev->ev_h2d, false); dev->ctx->put_event(dev->ev_done, false); dev->ctx->put_event(dev->ev_d2h, false);
+    dev->ctx->put_event(dev->ev_expand, false);
   }
   for (hipEvent_t e : dev->prof_pool) hipEventDestroy(e);
   hipstr::recycle_prepared(dev->prep);       // the tables' host storage goes to the next batch (prep.h)
@@ -652,10 +670,23 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   }
   if (up_prof){ const double n_ = hipstr::ApiTimer::now(); hipstr::api_profile_add(hipstr::PB_UP_MEMCPY, n_ - up_t); up_t = n_; }
   // what the device builds for itself (expand_kernels.hip), behind the copies on the same stream and in front of everything else
-  if (P.gen_f64 > 0) hipLaunchKernelGGL(hs_expand_stropts_kernel, dim3((unsigned)((P.stropts.size() + 3)/4)), dim3(256), 0, copy_stream, (const hs_dev_t*)dev->d_args);
-  if (!P.rec_descs.empty()) hipLaunchKernelGGL(hs_expand_recs_kernel, dim3((unsigned)((P.rec_descs.size()*HS_GRP_REC_DWORDS + 255)/256)), dim3(256), 0, copy_stream, (const hs_dev_t*)dev->d_args);
+  // One-shot path (copies and kernels on ONE stream): aside, on the thread's second stream, beside the column tables and the leading flanks
+  hipStream_t exp_stream = copy_stream;
+  if (copy_stream == compute_stream && (P.gen_f64 > 0 || !P.rec_descs.empty()) && (dev->aux_stream = thread_aux_stream(ctx)) != NULL){
+    hipEvent_t fork = ctx->get_event(false); dev->ev_expand = ctx->get_event(false);
+    if (fork && dev->ev_expand && hipEventRecord(fork, copy_stream) == hipSuccess && hipStreamWaitEvent(dev->aux_stream, fork, 0) == hipSuccess) exp_stream = dev->aux_stream;
+    else { ctx->put_event(dev->ev_expand, false); dev->ev_expand = NULL; }
+    ctx->put_event(fork, false);          // (its wait is queued: the event may be recorded again by its next user)
+  }
+  if (P.gen_f64 > 0) hipLaunchKernelGGL(hs_expand_stropts_kernel, dim3((unsigned)((P.stropts.size() + 3)/4)), dim3(256), 0, exp_stream, (const hs_dev_t*)dev->d_args);
+  if (!P.rec_descs.empty()) hipLaunchKernelGGL(hs_expand_recs_kernel, dim3((unsigned)((P.rec_descs.size()*HS_GRP_REC_DWORDS + 255)/256)), dim3(256), 0, exp_stream, (const hs_dev_t*)dev->d_args);
   HS_HIP_DEV(hipGetLastError());
-  HS_HIP_DEV(hipMemsetAsync(h.aln_probs, 0, out_bytes, copy_stream));
+  if (dev->ev_expand) HS_HIP_DEV(hipEventRecord(dev->ev_expand, dev->aux_stream));
+  // entries no kernel writes (reads or alleles that are not realigned, reads without a seed) read as 0 for whoever takes the device pointer
+  // (hipstr_hmm_dev_aln_probs); a batch where every read is active and every allele realigned — the usual one — has none: no fill launch
+  bool all_written = P.active.size() == P.reads.size();
+  for (size_t li = 0; all_written && li < P.loci.size(); li++) all_written = P.loci[li].n_re == P.loci[li].n_alleles;
+  if (!all_written) HS_HIP_DEV(hipMemsetAsync(h.aln_probs, 0, out_bytes, copy_stream));
   if (up_prof){ const double n_ = hipstr::ApiTimer::now(); hipstr::api_profile_add(hipstr::PB_UP_EXPAND, n_ - up_t); up_t = n_; }
   dev->ev0 = ctx->get_event(true); dev->ev1 = ctx->get_event(true);
   // The stream's batches take tens of milliseconds and their collectors must not burn a core waiting: hipEventSynchronize spins at 100 %
@@ -770,6 +801,7 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
     // leading flanks: persistent wavefronts striding over (locus side, distinct flank, 64 reads) items
     hs_launch_lead2(nact, (unsigned)std::max(1, std::min(dev->trail_waves, ch.lead_end - ch.lead_begin)), st, dp, ch.active_begin, ch.lead_begin, ch.lead_end, 2*chunk_no, dev->h.band_cols, n_clear);
     if (mark()) return 1;
+    if (dev->ev_expand && !dev->expand_joined){ HS_HIP(hipStreamWaitEvent(st, dev->ev_expand, 0)); dev->expand_joined = true; }
     // tabulated alleles: reads of a locus side packed into workgroups (HIPSTR_STR_GROUP=0: one workgroup per read, for comparison)
     const bool str_group = !(getenv("HIPSTR_STR_GROUP") && atoi(getenv("HIPSTR_STR_GROUP")) == 0);
     if (!str_group) hipLaunchKernelGGL(hs_str_kernel, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin, 0);
@@ -777,9 +809,23 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
       // blocks of at least six repeat units (nearly all) through the kernel with a compile-time period, the shorter ones as before
       // (HIPSTR_STR_GROUP_P=0: all of them as before, for comparison)
       static const bool group_p = !(getenv("HIPSTR_STR_GROUP_P") && atoi(getenv("HIPSTR_STR_GROUP_P")) == 0);
+      // A call of a locus or two: the interrupted alleles' kernels beside the tabulated alleles' (different alleles of the same reads: disjoint
+      // outputs; the re-do marks both may set are the same value) on the thread's second stream — 18 us of a 180 us call
+      hipStream_t st_pw = st; hipEvent_t ev_pw = NULL, ev_fork = NULL;
+      if (ch.str_end > ch.str_begin && ch.str_end - ch.str_begin <= 256 && group_p && (dev->any_pw || dev->any_rp)){
+        hipStream_t aux = thread_aux_stream(dev->ctx);
+        ev_fork = aux ? dev->ctx->get_event(false) : NULL;
+        ev_pw = ev_fork ? dev->ctx->get_event(false) : NULL;
+        if (ev_pw) st_pw = aux; else { dev->ctx->put_event(ev_fork, false); ev_fork = NULL; }
+      }
       if (ch.str_end > ch.str_begin){
         if (group_p && dev->prep.ws_nd_size > 0)       // read-end deletion sums of the tabulated alleles, every (row, column) a lane
           hipLaunchKernelGGL(hs_nd_kernel, dim3(nact, 2), dim3(256), 0, st, dp, ch.active_begin);
+        if (ev_pw){      // (back to the pool once its wait is queued: the next user records it again)
+          const bool ok = hipEventRecord(ev_fork, st) == hipSuccess && hipStreamWaitEvent(st_pw, ev_fork, 0) == hipSuccess;
+          dev->ctx->put_event(ev_fork, false);
+          if (!ok){ dev->ctx->put_event(ev_pw, false); return fail("hipEventRecord / hipStreamWaitEvent failed"); }
+        }
         if (group_p) hipLaunchKernelGGL(hs_str_group_kernel_p, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), hs_str_group_p_lds_bytes(), st, dp,
                                         dev->n_lead_items + dev->n_trail_items + ch.str_begin);
         if (!group_p || dev->any_short)      // (periods above HS_GRP_MAXP only, once hs_str_group_kernel_p is on)
@@ -787,11 +833,12 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
                              dev->n_lead_items + dev->n_trail_items + ch.str_begin, group_p ? 1 : 0);
       }
       if (dev->any_pw && ch.str_end > ch.str_begin)       // interrupted repeats: the piecewise simple lists' closed forms, grouped like the tabulated ones
-        hipLaunchKernelGGL(hs_str_group_kernel_pw, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), dev->grp_pw_lds_bytes, st, dp,
+        hipLaunchKernelGGL(hs_str_group_kernel_pw, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), dev->grp_pw_lds_bytes, st_pw, dp,
                            dev->n_lead_items + dev->n_trail_items + ch.str_begin);
       if (dev->any_rp && ch.str_end > ch.str_begin)       // three and more interruptions: lists without a closed form, replayed in the grouped layout
-        hipLaunchKernelGGL(hs_str_group_kernel_rp, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), dev->grp_pw_lds_bytes, st, dp,
+        hipLaunchKernelGGL(hs_str_group_kernel_rp, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), dev->grp_pw_lds_bytes, st_pw, dp,
                            dev->n_lead_items + dev->n_trail_items + ch.str_begin);
+      if (ev_pw){ HS_HIP(hipEventRecord(ev_pw, st_pw)); HS_HIP(hipStreamWaitEvent(st, ev_pw, 0)); dev->ctx->put_event(ev_pw, false); }
       if (ch.n_long_sides > 0)        // sides with more columns than a group holds: one workgroup per read as before
         hipLaunchKernelGGL(hs_str_kernel, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin, 1);
     }
@@ -1015,6 +1062,7 @@ int64_t hipstr_debug_fetch_table(hipstr_dev_batch_t* dev, int what, void* buf, i
   else if (what == 2){ src = dev->h.grp_recs; n = (int64_t)P.rec_descs.size()*HS_GRP_REC_DWORDS*sizeof(int32_t); }
   else { fail("unknown table"); return -1; }
   if (hipStreamSynchronize(dev->h2d_stream ? dev->h2d_stream : dev->stream) != hipSuccess){ fail("hipStreamSynchronize failed"); return -1; }
+  if (dev->ev_expand && hipStreamSynchronize(dev->aux_stream) != hipSuccess){ fail("hipStreamSynchronize failed"); return -1; }
   const int64_t m = std::min(n, cap);
   if (m > 0 && buf && hipMemcpy(buf, src, (size_t)m, hipMemcpyDeviceToHost) != hipSuccess){ fail("hipMemcpy failed"); return -1; }
   return n;
