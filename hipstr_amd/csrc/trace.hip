@@ -225,6 +225,12 @@ __device__ __forceinline__ void trace_fill_body(TraceLdsStore<C>& store, const h
   double* lastcol = d.lastcol + uni(S->lc_off);
   const bool rev = side != 0;
   const int nl = (n + C - 1) / C, lastlane = (n - 1) / C;
+#ifdef HS_TRACE_TIME        // s_memtime per stage of the first few wavefronts (experiment builds)
+  unsigned long long tt[6]; int ti = 0; tt[ti++] = __builtin_amdgcn_s_memtime();
+#define HS_TTICK() (tt[ti++] = __builtin_amdgcn_s_memtime())
+#else
+#define HS_TTICK() ((void)0)
+#endif
 
   uint8_t rd[C]; double blc[C], blw[C];
 #pragma unroll
@@ -312,6 +318,7 @@ __device__ __forceinline__ void trace_fill_body(TraceLdsStore<C>& store, const h
   if (F0 > 1) sweep(lead + 1, F0 - 1);
 #pragma unroll
   for (int kk = 0; kk < C; kk++){ const int j = lane*C + kk; if (j < n) L.prev[j] = Mrow[kk]; }
+  HS_TTICK();
 
   // ---- STR block (HapAligner.cpp:62-109)
   const hs_stropt_t so = d.stropts[uni(S->stropt)];
@@ -345,6 +352,7 @@ __device__ __forceinline__ void trace_fill_body(TraceLdsStore<C>& store, const h
     }
   }
   __syncthreads();
+  HS_TTICK();
   {
     const bool left_align = (side == 0);        // forward: left-align the artifact, reverse: right-align (HapAligner.cpp:69-71)
     int32_t* art_size = d.arts + uni(S->art_off);
@@ -381,6 +389,7 @@ __device__ __forceinline__ void trace_fill_body(TraceLdsStore<C>& store, const h
     }
   }
   __syncthreads();
+  HS_TTICK();
 
   // ---- trailing flank: "stutter block must be followed by a match" (HapAligner.cpp:122-139), then the plain recurrence
   const hs_row_t* trail = d.rows + uni(S->trail_off);
@@ -405,6 +414,11 @@ __device__ __forceinline__ void trace_fill_body(TraceLdsStore<C>& store, const h
     }
   }
   if (F2 > 1) sweep(trail + 1, F2 - 1);
+#ifdef HS_TRACE_TIME
+  HS_TTICK();
+  if (lane == 0 && blockIdx.x < 4) printf("trace fill side %d (n %d, rows %d + %d, B %d, C %d): lead %llu tables %llu STR row %llu trail %llu cycles\n", si, n, F0, F2, B, C,
+                                          tt[1]-tt[0], tt[2]-tt[1], tt[3]-tt[2], tt[4]-tt[3]);
+#endif
 }
 // sides of up to 384 columns (C <= 6): the wavefront's tables are static LDS (under the 64 KiB a kernel may declare)
 template <int C>
@@ -447,11 +461,12 @@ template <int C> int launch_fill_long(int cnt, hipStream_t ks, const hs_tdev_t* 
 
 // ------------------------------------------------------------------ seed arg-max, total likelihood and the walk
 // HapAligner::retrace (HapAligner.cpp:363-571): only the decisions; the bookkeeping is replayed on the host from `ops`.
-__device__ void trace_walk(const hs_tdev_t& d, int si, int B, int max_index){
+// dec: the side's decision bytes — the wavefront's LDS copy when the side fits HS_WALK_LDS (a walk is a chain of a few hundred dependent
+// one-byte loads: 60 ns each from LDS, ~700 ns from L2 / HBM), else the matrix in the workspace
+__device__ void trace_walk(const hs_tdev_t& d, int si, int B, int max_index, const uint8_t* dec){
   const hs_tside_t* S = d.sides + si;
   const bool rev = S->side != 0;
   const int n = S->n, F0 = S->F0, F2 = S->F2;
-  const uint8_t* dec = d.dec + S->dec_off;
   const int32_t* art_size = d.arts + S->art_off;
   const int32_t* art_pos = art_size + n;
   char* ops = d.ops + S->ops_off;
@@ -515,6 +530,7 @@ __device__ void trace_walk(const hs_tdev_t& d, int si, int B, int max_index){
   d.n_ops[si] = k;
 }
 
+#define HS_WALK_LDS 24576          // bytes of decisions per side a walk keeps in LDS (150-bp reads x 60-row flanks: 9 KB)
 __global__ void __launch_bounds__(64) hs_trace_walk(const hs_tdev_t* __restrict__ dp, int req_begin){
   const hs_tdev_t& d = *dp;
   const int lane = threadIdx.x;
@@ -560,8 +576,23 @@ __global__ void __launch_bounds__(64) hs_trace_walk(const hs_tdev_t* __restrict_
   }
   tot = wave_sum_d(tot);
   if (lane == 0){ d.ll[q] = mx + (double)f_fasterlog((float)tot); d.max_index[q] = max_index; }
-  if (lane == 0) trace_walk(d, 2*q, B, max_index);
-  else if (lane == 1) trace_walk(d, 2*q+1, B, H-1-max_index);
+  // the two sides' decision bytes into LDS, 16 bytes per lane and step (hipstr_hmm_trace aligns the matrices to 16 bytes)
+  __shared__ uint4 s_dec[2][HS_WALK_LDS/16];
+  const uint8_t* decp[2];
+#pragma unroll
+  for (int sd = 0; sd < 2; sd++){
+    const hs_tside_t* S = SL + sd;
+    const int bytes = (uni(S->F0) + 1 + uni(S->F2))*uni(S->n);
+    const uint8_t* g = d.dec + uni(S->dec_off);
+    if (bytes <= HS_WALK_LDS){
+      const uint4* g4 = (const uint4*)g;
+      for (int i = lane; i < (bytes + 15)/16; i += 64) s_dec[sd][i] = g4[i];
+      decp[sd] = (const uint8_t*)s_dec[sd];
+    } else decp[sd] = g;
+  }
+  wave_lds_sync();
+  if (lane == 0) trace_walk(d, 2*q, B, max_index, decp[0]);
+  else if (lane == 1) trace_walk(d, 2*q+1, B, H-1-max_index, decp[1]);
 }
 
 // ------------------------------------------------------------------ host side
@@ -850,7 +881,7 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
       S.trail_off = ap.trail_off[sd]; S.F2 = ap.seq[sd][2].size();
       S.stropt = ap.stropt[sd];
       S.ops_cap = S.n + S.F0 + S.F2 + (int)ap.seq[sd][1].size() + 2*HS_MAXREP*b->period[req_locus[q]] + 16;
-      need[q] += (int64_t)(S.F0 + 1 + S.F2)*S.n;
+      need[q] += ((int64_t)(S.F0 + 1 + S.F2)*S.n + 15) & ~(int64_t)15;
     }
     if (need[q] > budget) return api_fail("one traceback needs more workspace than the device offers");
   }
@@ -887,7 +918,7 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
     while (q1 < n_req && mat + need[q1] <= budget){
       for (int sd = 0; sd < 2; sd++){
         hs_tside_t& S = sides[2*q1+sd];
-        S.dec_off = mat; mat += (int64_t)(S.F0 + 1 + S.F2)*S.n;
+        S.dec_off = mat; mat += ((int64_t)(S.F0 + 1 + S.F2)*S.n + 15) & ~(int64_t)15;       // (16-byte pieces: hs_trace_walk copies a matrix to LDS in uint4s)
         S.lc_off = (int32_t)n_lc; n_lc += S.F0 + 1 + S.F2;
         S.art_off = (int32_t)n_art; n_art += 2*S.n;
         S.ops_off = (int32_t)n_ops; n_ops += S.ops_cap;

@@ -28,4 +28,15 @@ for w in p30 c2 ns; do
 done
 python tools/r05_lat.py > $O/r05_latency.txt 2>&1
 HIPSTR_FLANK_SYSTOLIC=0 python tools/r05_lat.py >> $O/r05_latency.txt 2>&1
+# the one-shot call as bench.py times it (prepared arrays, median of 200) with the host-side buckets; the second per-thread stream off for comparison
+LAT_BUCKETS=1 python tools/r05_lat2.py > $O/r05_latency_c.txt 2>&1
+HIPSTR_EXPAND_ASIDE=0 python tools/r05_lat2.py >> $O/r05_latency_c.txt 2>&1
+python tools/r05_lat2.py >> $O/r05_latency_c.txt 2>&1
+bash tools/lat_trace.sh align > $O/r05_lat_trace_align.txt 2>&1
+bash tools/lat_trace.sh trace > $O/r05_lat_trace_trace.txt 2>&1
+# trailing flanks + compute_aln_logprob as one item (opt-in) against the default
+for wl in ns p30 c5; do for f in 1 0; do
+  echo "== $wl HIPSTR_TRAIL_FUSED=$f"
+  HIPSTR_TRAIL_FUSED=$f python bench.py --workload $wl --steps 5 --no-cpu-baseline --no-pipeline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value']/1e6,2), 'M/s', d['roofline']['phase_ms'])"
+done; done > $O/r05_fused.txt 2>&1
 ls -la $O
