@@ -330,6 +330,9 @@ def main():
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     rank_cpus = None
+    # a rank's share of the node's usable CPUs, taken BEFORE the rank narrows its own mask (computed afterwards it would be the share of a
+    # share on the ranks whose pinning succeeded and the full share on one whose pinning failed: ranks disagreeing on their thread count)
+    cores_before_pin = usable_cores()
     if world > 1 and not args.host_threads and not os.environ.get("HIPSTR_BENCH_NO_PIN"):
         # one process per GPU: every rank keeps to its own slice of the node's usable CPUs — all of its threads (they inherit the mask: this
         # runs before torch, the library's pool and the stream's workers exist) — so that the ranks' host work does not migrate over each other
@@ -361,7 +364,7 @@ def main():
 
     # host threads of the library per rank: the usable cores of the node are shared by the ranks on it (each rank prepares its own batches)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    host_threads = max(1, usable_cores() // max(1, local_world))
+    host_threads = max(1, cores_before_pin // max(1, local_world))
     if world > 1:
         os.environ.setdefault("HIPSTR_HOST_THREADS", str(host_threads))
     from hipstr_amd import capi

@@ -1440,6 +1440,254 @@ __device__ __forceinline__ double pwk_eval_grp(const double* __restrict__ slots_
   return mx + (double)f_fasterlog((float)tot);
 }
 
+
+// ------------------------------------------------------------------ round 5: the two closed forms again, written for the list LOOP of str_group_body
+// (HS_EVAL_LOOP): one instance of each in the kernel instead of thirteen — the 13-list evaluation of hs_str_group_kernel_rp was 90 KB of
+// straight-line code per allele against an instruction cache of 64 KB per CU pair — and fewer vector instructions per pushed value:
+//   * the emission of (column xx - off, block base c) is one v_add: A0 = byte address of the lane's column in plane 0 of the emission
+//     table, minus a scalar 8 off - plane(c).  No clamp: the table lies 16 KB into the carve (deletion table, rowP, match_probs_ in front),
+//     a bound is at most 1024 + 36 columns, so a lane past its bound reads some double in front of its read that the level's select drops;
+//   * an absent value is NEG in its HIGH word only (one v_cndmask);
+//   * the float exponential's bits without v_cvt_u32_f32: for a term that passes the threshold y = 1.442695040f dd + 126.94269504f lies in
+//     [116.9, 126.95] ⊂ [64, 128), so 2^23 y is the integer (2^23 + mantissa) 2^6 — (bits(y) << 6) + 2^31 (mod 2^32) — exactly what
+//     fasterexp converts (fastonebigheader.h:206-218); a term under the threshold is switched off as before;
+//   * the switch acts on the 32-bit float, not on its double.
+// Same values into the same float log-sum-exp: bit-identical to pw_eval_grp / pwk_eval_grp (GPU suite + fuzzers through this path).
+typedef int hs_i2k __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) hs_i2k* hs_slot_k;
+typedef float hs_f2 __attribute__((ext_vector_type(2)));
+struct LeanAcc {
+  double tot; double mx; double log_thresh;
+  __device__ __forceinline__ static double neg_unless(bool on, double v){       // v where on, else a value near -1e300 (high word of NEG, low word of v)
+    return __hiloint2double(on ? __double2hiint(v) : (int)0xFE37E43Cu, __double2loint(v));
+  }
+  // two pushed values: a (counted wa times: 1.0 but for the plain entries) where on_a and over the threshold, b where over the threshold
+  __device__ __forceinline__ void pair(double a, bool on_a, double b, double wa, bool weighted){
+    const double dd0 = a - mx, dd1 = b - mx;
+    const bool t0 = on_a && dd0 > log_thresh, t1 = dd1 > log_thresh;
+    hs_f2 x; x.x = (float)dd0; x.y = (float)dd1;
+    const hs_f2 y = x * 1.442695040f + 126.94269504f;
+    uint32_t e0 = (__float_as_uint(y.x) << 6) + 0x80000000u, e1 = (__float_as_uint(y.y) << 6) + 0x80000000u;
+    e0 = t0 ? e0 : 0u; e1 = t1 ? e1 : 0u;
+    asm volatile("" : "+v"(e0), "+v"(e1));                      // (the selects stay on the 32-bit values)
+    if (weighted) tot += wa * (double)__uint_as_float(e0); else tot += (double)__uint_as_float(e0);
+    tot += (double)__uint_as_float(e1);
+  }
+  __device__ __forceinline__ void single(double a, bool on_a){
+    const double dd = a - mx;
+    const float y = (float)dd * 1.442695040f + 126.94269504f;
+    uint32_t e = (__float_as_uint(y) << 6) + 0x80000000u;
+    e = (on_a && dd > log_thresh) ? e : 0u;
+    asm volatile("" : "+v"(e));
+    tot += (double)__uint_as_float(e);
+  }
+  __device__ __forceinline__ void one(double b){
+    const double dd = b - mx;
+    const float y = (float)dd * 1.442695040f + 126.94269504f;
+    uint32_t e = (__float_as_uint(y) << 6) + 0x80000000u;
+    e = (dd > log_thresh) ? e : 0u;
+    asm volatile("" : "+v"(e));
+    tot += (double)__uint_as_float(e);
+  }
+};
+__device__ __forceinline__ double lds_f64(int byte_addr){ return *(const __attribute__((address_space(3))) double*)(uintptr_t)(uint32_t)byte_addr; }
+__device__ __forceinline__ int plane_of(int ch, int plane_bytes){ return ((ch >> 1) & 3) * plane_bytes; }
+
+// The level behind a break: t - e(column - m stride, base a) + e(column - m stride, base b) for m = 1..nsub, in that order
+// (StutterAlignerClass.cpp:78-82, :128-129).
+__device__ __forceinline__ double emis_chain(double t, int A0, int sa, int sb, int nsub, int stride8){
+  int ao = 0;
+  for (int m = 1; m <= nsub; m++){
+    ao += stride8;
+    const double ea = lds_f64(A0 + (sa - ao)), eb = lds_f64(A0 + (sb - ao));
+    t -= ea; t += eb;
+  }
+  return t;
+}
+
+// pw_eval_grp (one or two breaks, ten slots), lean form.  A0: see above; stride8 = 8 x stride.
+template <int XC>
+__device__ __forceinline__ double pw_eval_lean(const PwSlots& S, const double* ilog, double log_thresh, int A0, double lp0, int lim,
+                                               int nsub, int stride8, int tail){
+  auto sl = [&](int i){ hs_i2k r; r.x = S.v[2*i]; r.y = S.v[2*i + 1]; return r; };
+  const hs_i2k d0 = sl(0), d1 = sl(1), d2 = sl(2), d3 = sl(3), d4 = sl(4), d5 = sl(5), d6 = sl(6), d7 = sl(7), d8 = sl(8), d9 = sl(9);
+  const int nseg = d0.x, term_ni = d0.y;
+  const int r0 = d1.x, U0 = d1.y, r1 = d3.x, U1 = d3.y, r2 = d5.x, U2 = d5.y;
+  const int b0 = d7.x, c0 = d7.y, b1 = d8.x, c1 = d8.y, pa = d9.x, pb = d9.y;
+  const double L0 = lp0;
+  double L1, L2;
+  const bool a_b0 = b0 < lim;
+  {
+    const int sa = plane_of(c0, XC*8) - 8*b0, sb = plane_of(c0 >> 8, XC*8) - 8*b0;
+    const double t = emis_chain(L0, A0, sa, sb, nsub, stride8);
+    L1 = a_b0 ? t : L0;
+  }
+  L2 = L1;
+  bool a_b1 = false;
+  if (nseg >= 2){
+    a_b1 = b1 < lim;
+    const int sa = plane_of(c1, XC*8) - 8*b1, sb = plane_of(c1 >> 8, XC*8) - 8*b1;
+    const double t = emis_chain(L1, A0, sa, sb, nsub, stride8);
+    L2 = a_b1 ? t : L1;
+  }
+  const int np = min(max(lim - pa, 0), pb - pa);
+  int ns = term_ni;
+  if (pb > pa) ns = (lim < pb) ? max(lim, pa) : ns;
+  if (U2 > 0) ns = (r2 >= lim) ? r2 : ns;
+  if (nseg >= 2) ns = (b1 >= lim) ? b1 : ns;
+  if (U1 > 0) ns = (r1 >= lim) ? r1 : ns;
+  ns = (b0 >= lim) ? b0 : ns;
+  if (U0 > 0) ns = (r0 >= lim) ? r0 : ns;
+  constexpr double NEG = -1.0e300;
+  const double v1 = (U0 > 0) ? LeanAcc::neg_unless(r0 < lim, __hiloint2double(d2.y, d2.x) + L0) : NEG;
+  const double v3 = (U1 > 0) ? LeanAcc::neg_unless(r1 < lim, __hiloint2double(d4.y, d4.x) + L1) : NEG;
+  const double v5 = (U2 > 0) ? LeanAcc::neg_unless(r2 < lim, __hiloint2double(d6.y, d6.x) + L2) : NEG;
+  const double v7 = LeanAcc::neg_unless(ns < tail, ilog[max(tail - ns, 0)] + L2);
+  double mx = fmax(L0, L1);                                    // (a level that is not the lane's equals the one before it)
+  mx = fmax(mx, L2);
+  if (U0 > 0) mx = fmax(mx, v1);
+  if (U1 > 0) mx = fmax(mx, v3);
+  if (U2 > 0) mx = fmax(mx, v5);
+  mx = fmax(mx, v7);
+  LeanAcc acc; acc.log_thresh = log_thresh; acc.tot = 0.0; acc.mx = mx;
+  if (U0 > 0) acc.pair(L0, true, v1, 1.0, false); else acc.single(L0, true);
+  if (U1 > 0) acc.pair(L1, a_b0, v3, 1.0, false); else acc.single(L1, a_b0);
+  if (nseg >= 2){ if (U2 > 0) acc.pair(L2, a_b1, v5, 1.0, false); else acc.single(L2, a_b1); }
+  else if (U2 > 0) acc.one(v5);
+  if (pb > pa) acc.pair(L2, np > 0, v7, (double)np, true);
+  else acc.one(v7);
+  return mx + (double)f_fasterlog((float)acc.tot);
+}
+template <int XC>
+__device__ __forceinline__ double pw_eval_lean(const double* __restrict__ slots_g, const double* ilog, double log_thresh, int A0, double lp0, int lim,
+                                               int nsub, int stride8, int tail){
+  const hs_slot_k D = (hs_slot_k)(uintptr_t)slots_g;
+  PwSlots S;
+#pragma unroll
+  for (int t = 0; t < HS_PW_SLOTS; t++){ const hs_i2k q = D[t]; S.v[2*t] = q.x; S.v[2*t + 1] = q.y; }
+  return pw_eval_lean<XC>(S, ilog, log_thresh, A0, lp0, lim, nsub, stride8, tail);
+}
+
+
+#ifndef HS_LEAN_ASSUME
+#define HS_LEAN_ASSUME 1   // pwk_eval_lean is told that a K-level list has three to six breaks: the first three segments lose their scalar guards and the scheduler
+                           // moves their LDS reads ahead (two / three inherited interruptions: STR phase 117.8 -> 110.1 / 140.2 -> 131.6 ms per 400 loci)
+#endif
+#ifndef HS_LEAN_SPEC
+#define HS_LEAN_SPEC 0     // 1: one instance of pwk_eval_lean per number of breaks (3..6), picked by a scalar switch: no guard per segment at all
+#endif
+#ifndef HS_LEAN_NS
+#define HS_LEAN_NS 0       // 1: pwk_eval_lean forms the stop offset with one select per entry instead of a subtraction and a minimum (measured 3 % slower: more scalar work per segment)
+#endif
+// pwk_eval_grp (three to HS_PWK_MAX breaks, 24 slots), lean form: the list's slots are fetched together (three wide scalar loads, one
+// wait) and stay in scalar registers through both passes.
+template <int XC, int NSEG>      // NSEG > 0: the list's number of breaks, known at compile time; 0: read from the slots
+__device__ __forceinline__ double pwk_eval_lean_n(const hs_i2k (&ds)[HS_PWK_SLOTS], const double* ilog, double log_thresh, int A0, double lp0, int lim,
+                                                  int nsub, int stride8, int tail){
+  const int nseg = NSEG > 0 ? NSEG : ds[0].x, term_ni = ds[0].y, pa = ds[1].x, pb = ds[1].y;
+#if HS_LEAN_ASSUME
+  __builtin_assume(nseg >= 3 && nseg <= HS_PWK_MAX);          // (prep.cpp piecewise_k: what makes a list this shape) — the first three segments without scalar guards
+#endif
+  constexpr double NEG = -1.0e300;
+  double Lv[HS_PWK_MAX + 1];
+  Lv[0] = lp0;
+  double mx = lp0;
+#if HS_LEAN_NS
+  // The first offset of the list at or beyond the lane's bound (the replay's nistop), one select per entry: the entries are in ascending
+  // order, so "entry i is below the bound" moves the candidate to the entry behind it — a scalar known from the slots.
+  const int o_after = (pb > pa) ? pa : term_ni;
+  int nxt_run[HS_PWK_MAX + 1], nxt_brk[HS_PWK_MAX + 1], first_of[HS_PWK_MAX + 2];
+  first_of[HS_PWK_MAX + 1] = o_after;
+#pragma unroll
+  for (int s = HS_PWK_MAX; s >= 0; s--){
+    const int after_seg = (s >= nseg) ? o_after : first_of[s + 1];
+    const int bs = ds[4 + 3*s].x;                           // (slot 22 behind the last segment: unused, zero)
+    nxt_brk[s] = after_seg;
+    nxt_run[s] = (s < nseg) ? bs : after_seg;
+    first_of[s] = (ds[2 + 3*s].y > 0) ? ds[2 + 3*s].x : nxt_run[s];
+  }
+  int ns = first_of[0];
+#else
+  unsigned u = (unsigned)(term_ni - lim);                     // first offset at or beyond the bound, minus the bound (the terminal entry is one)
+#endif
+#pragma unroll
+  for (int s = 0; s <= HS_PWK_MAX; s++){
+    if (s < HS_PWK_MAX) Lv[s + 1] = Lv[s];
+    if (s <= nseg){
+      const hs_i2k run = ds[2 + 3*s];
+      if (run.y > 0){
+        const double v = __hiloint2double(ds[3 + 3*s].y, ds[3 + 3*s].x) + Lv[s];
+        const bool act = run.x < lim;
+        mx = fmax(mx, LeanAcc::neg_unless(act, v));
+#if HS_LEAN_NS
+        ns = act ? nxt_run[s] : ns;
+#else
+        u = min(u, (unsigned)(run.x - lim));
+#endif
+      }
+      if (s < HS_PWK_MAX && s < nseg){
+        const hs_i2k brk = ds[4 + 3*s];
+        const int b = brk.x;
+        const int sa = plane_of(brk.y, XC*8) - 8*b, sb = plane_of(brk.y >> 8, XC*8) - 8*b;
+        const double t = emis_chain(Lv[s], A0, sa, sb, nsub, stride8);
+        const bool act = b < lim;
+        Lv[s + 1] = act ? t : Lv[s];                             // an unreached level equals the one before it: harmless in the maximum
+        mx = fmax(mx, Lv[s + 1]);
+#if HS_LEAN_NS
+        ns = act ? nxt_brk[s] : ns;
+#else
+        u = min(u, (unsigned)(b - lim));
+#endif
+      }
+    }
+  }
+  double Llast = Lv[0];
+#pragma unroll
+  for (int s = 1; s <= HS_PWK_MAX; s++) Llast = (s <= nseg) ? Lv[s] : Llast;       // (scalar condition)
+  const int np = min(max(lim - pa, 0), pb - pa);
+#if HS_LEAN_NS
+  if (pb > pa) ns = (lim > pa) ? ((lim < pb) ? lim : term_ni) : ns;
+#else
+  if (pb > pa) u = min(u, (lim < pb) ? (unsigned)max(pa - lim, 0) : 0xffffffffu);
+  const int ns = (int)u + lim;
+#endif
+  const double v_t = LeanAcc::neg_unless(ns < tail, ilog[max(tail - ns, 0)] + Llast);
+  mx = fmax(mx, v_t);
+  LeanAcc acc; acc.log_thresh = log_thresh; acc.tot = 0.0; acc.mx = mx;
+#pragma unroll
+  for (int s = 0; s <= HS_PWK_MAX; s++){
+    if (s <= nseg){
+      const bool on = (s == 0) ? true : (ds[4 + 3*(s - 1)].x < lim);
+      const hs_i2k run = ds[2 + 3*s];
+      if (run.y > 0){
+        const double v = __hiloint2double(ds[3 + 3*s].y, ds[3 + 3*s].x) + Lv[s];
+        acc.pair(Lv[s], on, LeanAcc::neg_unless(run.x < lim, v), 1.0, false);
+      } else acc.single(Lv[s], on);
+    }
+  }
+  if (pb > pa) acc.pair(Llast, np > 0, v_t, (double)np, true);                    // equal float terms: the product is exact
+  else acc.one(v_t);
+  return mx + (double)f_fasterlog((float)acc.tot);
+}
+template <int XC>
+__device__ __forceinline__ double pwk_eval_lean(const double* __restrict__ slots_g, const double* ilog, double log_thresh, int A0, double lp0, int lim,
+                                                int nsub, int stride8, int tail){
+  const hs_slot_k D = (hs_slot_k)(uintptr_t)slots_g;
+  hs_i2k ds[HS_PWK_SLOTS];
+#pragma unroll
+  for (int t = 0; t < HS_PWK_SLOTS; t++) ds[t] = D[t];
+#if HS_LEAN_SPEC
+  switch (ds[0].x){                                             // (scalar)
+    case 3:  return pwk_eval_lean_n<XC, 3>(ds, ilog, log_thresh, A0, lp0, lim, nsub, stride8, tail);
+    case 4:  return pwk_eval_lean_n<XC, 4>(ds, ilog, log_thresh, A0, lp0, lim, nsub, stride8, tail);
+    case 5:  return pwk_eval_lean_n<XC, 5>(ds, ilog, log_thresh, A0, lp0, lim, nsub, stride8, tail);
+    default: return pwk_eval_lean_n<XC, 6>(ds, ilog, log_thresh, A0, lp0, lim, nsub, stride8, tail);
+  }
+#else
+  return pwk_eval_lean_n<XC, 0>(ds, ilog, log_thresh, A0, lp0, lim, nsub, stride8, tail);
+#endif
+}
+
 }  // namespace
 
 #ifndef HS_STR_WAVES
@@ -2005,6 +2253,16 @@ hs_str_kernel_generic(const hs_dev_t* __restrict__ dp, int active_begin, int pw_
 #else
 #define HS_TICK(k) do {} while (0)
 #endif
+#ifndef HS_EVAL_LOOP
+#define HS_EVAL_LOOP 0     // 1: hs_str_group_kernel_pw / _rp run the twelve artifact lists as a loop around one instance of each evaluator — a sixth of the code, bit-identical,
+                           // and SLOWER than the unrolled form (400 loci, STR phase: imperfect 89 -> 100 ms, two inherited interruptions 128 -> 126): profiles/r05_notes.md
+#endif
+#ifndef HS_LEAN
+#define HS_LEAN 1          // the K-level lists through pwk_eval_lean instead of pwk_eval_grp (two / three inherited interruptions: STR phase -8 % / -10 %)
+#endif
+#ifndef HS_LEAN_PW
+#define HS_LEAN_PW 1       // ... and the one- or two-break lists through pw_eval_lean on the slots fetched as before (once for the six insertion sizes): -1 %
+#endif
 #ifndef HS_GABL
 #define HS_GABL 0          // timing experiments only (results invalid): 1 no read-end sums, 2 no evaluation, 3 no table phase, 4 no barriers, 5 no chains; valid results: 6 read-end sums twice, 7 evaluation twice
 #endif
@@ -2419,6 +2677,70 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       double terms[HS_NART];
       double lp0_max = 0.0;
       const int Eb = (int)(uintptr_t)(__attribute__((address_space(3))) char*)L.E;
+      if (KIND >= 1 && HS_EVAL_LOOP){
+        // Round 5: the twelve artifact lists as a LOOP — deletion sizes p..6p, then insertion sizes p..6p — around one instance of each
+        // evaluator (see pw_eval_lean).  The thirteen terms live in registers picked by the loop counter (wave-uniform: register-indexed
+        // moves), and fast_log_sum_exp does not mind the order they are formed in.
+        const int A0 = Eb + 8*xx;
+        {
+          const int len = min(B, j + 1);
+          terms[HS_MAXREP] = (rdlane(cst, HS_MAXREP) + L.Mt[xx]) + L.rowP[xrp - len];
+        }
+        double li = 0.0;
+        int li_col = xx - nd_eq*p, li_left = j - nd_eq*p;
+#pragma nounroll
+        for (int it = 0; it < 2*HS_MAXREP; it++){
+          const bool is_ins = it >= HS_MAXREP;
+          const int q = is_ins ? it - HS_MAXREP : it;
+          const int aD = (q + 1)*p;
+          const int tix = is_ins ? HS_MAXREP + 1 + q : HS_MAXREP - 1 - q;
+          double lp0; int lim, len, kk, nsub, tailv;
+          if (!is_ins){
+            if (B - aD < 0){ terms[tix] = IMP; continue; }
+            const int cq = min(aD, n);
+            len = min(B - aD, j + 1);
+            const bool direct = (j + aD <= n - 1);
+            const int xd = xx + min(aD, n - 1 - j);
+            const double dsum = L.Mt[xd] - L.Dl[q*L.ld + xd];
+            int slq = nd_base + q; slq -= (slq >= HS_MAXREP) ? HS_MAXREP : 0;
+            const double ndv = nd[ndb + slq*sixp + min(n - 1 - j, cq - 1)];
+            lp0 = direct ? rdlane(cst, 14 + q) + dsum : ndv;
+            lim = len; kk = q; nsub = 1; tailv = B - aD;
+          } else {
+            if (q < nd_eq) li = (j >= aD - 1) ? L.Dl[q*L.ld + xx] : L.Mt[xx];
+            else {
+              for (int m = 0; m < p; m++){           // m < period <= B for a tabulated block (prep.cpp)
+                const double e = Eat(li_col, boff[B-1-m]);
+                if (li_left >= 0) li += e;
+                li_col--; li_left--;
+              }
+            }
+            len = min(B + aD, j + 1);
+            lp0 = (rdlane(cst, 13) + li) + ((len > aD) ? L.Mt[xx - min(aD, j)] : 0.0);
+            lim = min(max(0, len - aD), B);            // a lane past the group's last column repeats it: its bound is a real one
+            kk = HS_MAXREP; nsub = q + 1; tailv = B;
+          }
+          const int strd = is_ins ? p : 0;
+          const int shp = rdlane(shapes, kk);
+          double S;
+          if (shp == HS_SHAPE_PIECEWISE)                        // (the same for every lane)
+            S = pw_eval_lean<XC>(pw_desc + kk*HS_PW_SLOTS, L.ilog, d.log_thresh, A0, lp0, lim, nsub, 8*strd, tailv);
+          else if (KIND == 2 && shp == HS_SHAPE_PWK)
+            S = pwk_eval_lean<XC>(pw_desc + (HS_MAXREP + 1)*HS_PW_SLOTS + kk*HS_PWK_SLOTS, L.ilog, d.log_thresh, A0, lp0, lim, nsub, 8*strd, tailv);
+          else if (KIND == 2 && shp == -1){
+            const hs_stropt_t* so = d.stropts + rdlane(a_sopt, k);
+            const int loff = uni(kk == HS_MAXREP ? so->ins_off : so->del_off[min(kk, HS_MAXREP - 1)]);
+            const int llen = uni(kk == HS_MAXREP ? so->ins_len : so->del_len[min(kk, HS_MAXREP - 1)]);
+            S = visit_eval_grp<XC>((const hs_visit_t*)d.visits + loff, llen, L.ilog, d.log_thresh, Eb, xx, lp0, lim, tailv, nsub, strd, tailv);
+          } else {
+            const int e = rdlane(tbase, kk) + min(lim, 1) + max(lim - shp, 0);
+            const double2 ag = tab[e];
+            lp0_max = fmax(lp0_max, fabs(lp0));
+            S = (lp0 + ag.x) + ag.y;
+          }
+          terms[tix] = (rdlane(cst, tix) + S) + L.rowP[xrp - len];
+        }
+      } else {
       const int k_allele = k;                                 // (the allele's lane in the fetched batch: the lambdas below use k for the list)
       auto load_pw = [&](int k) -> PwSlots {                  // the ten descriptor slots of list k into scalar registers
           PwSlots S;
@@ -2436,12 +2758,16 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       auto tab_eval = [&](double lp0, int lim, int k, int nsub, int stride, int tail, const PwSlots* pre) -> double {
         const int shp = rdlane(shapes, k);
         if (KIND >= 1 && shp == HS_SHAPE_PIECEWISE){          // (the same for every lane)
-          if (pre) return pw_eval_grp<XC>(*pre, L.ilog, d.log_thresh, Eb, xx, lp0, lim, nsub, stride, tail);
+          if (pre) return HS_LEAN_PW ? pw_eval_lean<XC>(*pre, L.ilog, d.log_thresh, Eb + 8*xx, lp0, lim, nsub, 8*stride, tail)
+                                     : pw_eval_grp<XC>(*pre, L.ilog, d.log_thresh, Eb, xx, lp0, lim, nsub, stride, tail);
           const PwSlots S = load_pw(k);
-          return pw_eval_grp<XC>(S, L.ilog, d.log_thresh, Eb, xx, lp0, lim, nsub, stride, tail);
+          return HS_LEAN_PW ? pw_eval_lean<XC>(S, L.ilog, d.log_thresh, Eb + 8*xx, lp0, lim, nsub, 8*stride, tail)
+                            : pw_eval_grp<XC>(S, L.ilog, d.log_thresh, Eb, xx, lp0, lim, nsub, stride, tail);
         }
-        if (KIND == 2 && shp == HS_SHAPE_PWK)                 // three to six breaks: the K-level closed form (the same for every lane)
+        if (KIND == 2 && shp == HS_SHAPE_PWK){                // three to six breaks: the K-level closed form (the same for every lane)
+          if (HS_LEAN) return pwk_eval_lean<XC>(pw_desc + (HS_MAXREP + 1)*HS_PW_SLOTS + k*HS_PWK_SLOTS, L.ilog, d.log_thresh, Eb + 8*xx, lp0, lim, nsub, 8*stride, tail);
           return pwk_eval_grp<XC>(pw_desc + (HS_MAXREP + 1)*HS_PW_SLOTS + k*HS_PWK_SLOTS, L.ilog, d.log_thresh, Eb, xx, lp0, lim, nsub, stride, tail);
+        }
         if (KIND == 2 && shp == -1){                          // more: the list itself, replayed (the same for every lane)
           const hs_stropt_t* so = d.stropts + rdlane(a_sopt, k_allele);
           const int loff = uni(k == HS_MAXREP ? so->ins_off : so->del_off[min(k, HS_MAXREP - 1)]);
@@ -2459,7 +2785,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
         terms[HS_MAXREP] = (rdlane(cst, HS_MAXREP) + L.Mt[xx]) + pre;
       }
       PwSlots Sins;                                           // the insertion list serves all six sizes: its slots are fetched once
-      if (KIND >= 1) Sins = load_pw(HS_MAXREP);               // (a kind-2 option has the slots of all seven lists: "not piecewise" where the list is simple)
+      if (KIND >= 1) Sins = load_pw(HS_MAXREP);                 // (a kind-2 option has the slots of all seven lists: "not piecewise" where the list is simple)
       else { for (int t = 0; t < 2*HS_PW_SLOTS; t++) Sins.v[t] = 0; }
       auto ins_term = [&](int q, double li){
         const int D = (q+1)*p;
@@ -2509,16 +2835,19 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
           terms[HS_MAXREP - 1 - q] = (rdlane(cst, HS_MAXREP - 1 - q) + S) + pre;
         }
       }
+      }
       bool bad = !(lp0_max < tab_bmin);
       if (d.debug_redo > 0) bad |= ((ai*31 + i*7 + (j >> 6)) % d.debug_redo) == 0;       // tests: exercise the re-do path
       if (!__any(bad && actj)){
-        Lse acc;
-        for (int pass = 0; pass < 2; pass++){
-          acc.start(pass, terms[0]);
+        // fast_log_sum_exp of the 13 terms (mathops.cpp:97-106): two terms per step, the float exponential's bits as in LeanAcc
+        double mx13 = terms[0];
 #pragma unroll
-          for (int t = 0; t < HS_NART; t++) acc.push(pass, terms[t], d.log_thresh);
-        }
-        if (actj) mr_out[0] = acc.finish();
+        for (int t = 1; t < HS_NART; t++) mx13 = fmax(mx13, terms[t]);
+        LeanAcc acc; acc.log_thresh = d.log_thresh; acc.tot = 0.0; acc.mx = mx13;
+#pragma unroll
+        for (int t = 0; t + 1 < HS_NART; t += 2) acc.pair(terms[t], true, terms[t + 1], 1.0, false);
+        acc.one(terms[HS_NART - 1]);
+        if (actj) mr_out[0] = mx13 + (double)f_fasterlog((float)acc.tot);
       } else if (actj){                              // leave these columns to hs_str_kernel_generic
         mr_out[0] = HS_REDO;
         d.redo[ai] = 1;
@@ -2950,21 +3279,11 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
         // fast_log_sum_exp (mathops.cpp:97-106), branch-free.  A term that passes the threshold has 1.44 dd > -10: fasterexp's clamp at -126
         // (fastonebigheader.h:210) cannot act on it and is left out; a term that does not contributes 0.0, whatever its bits would have been
         // (two terms per float operation: packed multiplies and adds, each rounded on its own like the scalar ones)
-        typedef float hs_f2 __attribute__((ext_vector_type(2)));
-        double tot = 0.0;
+        LeanAcc acc; acc.log_thresh = d.log_thresh; acc.tot = 0.0; acc.mx = mx;
 #pragma unroll
-        for (int t = 0; t < HS_NART; t += 2){
-          const int t1 = (t + 1 < HS_NART) ? t + 1 : t;
-          const double dd0 = terms[t] - mx, dd1 = terms[t1] - mx;
-          hs_f2 x; x.x = (float)dd0; x.y = (float)dd1;
-          const hs_f2 z = (x * 1.442695040f + 126.94269504f) * 8388608.0f;
-          const float fe0 = (dd0 > d.log_thresh) ? __uint_as_float(__float2uint_rz(z.x)) : 0.0f;
-          tot += (double)fe0;
-          if (t + 1 < HS_NART){
-            const float fe1 = (dd1 > d.log_thresh) ? __uint_as_float(__float2uint_rz(z.y)) : 0.0f;
-            tot += (double)fe1;
-          }
-        }
+        for (int t = 0; t + 1 < HS_NART; t += 2) acc.pair(terms[t], true, terms[t + 1], 1.0, false);
+        acc.one(terms[HS_NART - 1]);
+        const double tot = acc.tot;
         if (actj) mr_out[0] = mx + (double)f_fasterlog((float)tot);
       } else if (actj){
         mr_out[0] = HS_REDO;
