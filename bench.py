@@ -539,15 +539,19 @@ def main():
         total_aln, total_loci = float(n_aln.value), float(loci)
 
     def profile_for(files):
-        """The newest committed profile summary collected on THIS workload (its `command` names it: bench.py --workload X, default ns; a run
-        with a HIPSTR_SYNTH_* override is nobody's profile): counters of one workload are not scaled onto another."""
+        """The newest committed profile summary collected on THIS workload (its `command` names it: bench.py --workload X, default ns) with
+        THIS run's generator overrides (tools/profile_pass.sh writes the HIPSTR_SYNTH_* settings of a pass in front of the command: the
+        interrupted-repeat modes have summaries of their own): counters of one workload are not scaled onto another."""
         import re
-        if any(k.startswith("HIPSTR_SYNTH") for k in os.environ):
-            return None, None
+        mine = sorted("%s=%s" % (k, v) for k, v in os.environ.items() if k.startswith("HIPSTR_SYNTH"))
         for f in reversed(files):
             t = json.load(open(f))
-            m = re.search(r"--workload\s+(\w+)", t.get("command", ""))
-            if (m.group(1) if m else "ns") == args.workload:
+            cmd = t.get("command", "")
+            theirs = sorted(re.findall(r"HIPSTR_SYNTH\w*=\S+", cmd))
+            if not theirs and re.search(r"_(imperfect|inherit)\d*_", os.path.basename(f)):
+                continue            # (a summary of an interrupted-repeat pass from before the overrides were recorded)
+            m = re.search(r"--workload\s+(\w+)", cmd)
+            if (m.group(1) if m else "ns") == args.workload and theirs == mine:
                 return t, f
         return None, None
 

@@ -376,7 +376,7 @@ struct hipstr_dev_batch {
   size_t lds_bytes = 0;
   hipEvent_t ev0 = NULL, ev1 = NULL;
   hipEvent_t ev_expand = NULL;            // the device-built tables are ready (recorded on the thread's aux stream; the first pass waits for it before the STR-block kernels)
-  hipStream_t aux_stream = NULL; bool expand_joined = false;
+  hipStream_t aux_stream = NULL; bool expand_joined = false; hipStream_t expand_joined_on = NULL;      // (the stream whose first pass waited for ev_expand)
   hipEvent_t ev_h2d = NULL, ev_done = NULL, ev_d2h = NULL;     // upload finished / last pass finished / results in host_out (pipelined use)
   hipStream_t stream = NULL;                // launches, copies and waits of this batch default to it (the creating thread's stream)
   hipStream_t h2d_stream = NULL, d2h_stream = NULL;
@@ -801,7 +801,8 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
     // leading flanks: persistent wavefronts striding over (locus side, distinct flank, 64 reads) items
     hs_launch_lead2(nact, (unsigned)std::max(1, std::min(dev->trail_waves, ch.lead_end - ch.lead_begin)), st, dp, ch.active_begin, ch.lead_begin, ch.lead_end, 2*chunk_no, dev->h.band_cols, n_clear);
     if (mark()) return 1;
-    if (dev->ev_expand && !dev->expand_joined){ HS_HIP(hipStreamWaitEvent(st, dev->ev_expand, 0)); dev->expand_joined = true; }
+    // (once per stream: a later pass on ANOTHER stream of the caller's is not ordered behind the first one's wait)
+    if (dev->ev_expand && (!dev->expand_joined || dev->expand_joined_on != st)){ HS_HIP(hipStreamWaitEvent(st, dev->ev_expand, 0)); dev->expand_joined = true; dev->expand_joined_on = st; }
     // tabulated alleles: reads of a locus side packed into workgroups (HIPSTR_STR_GROUP=0: one workgroup per read, for comparison)
     const bool str_group = !(getenv("HIPSTR_STR_GROUP") && atoi(getenv("HIPSTR_STR_GROUP")) == 0);
     if (!str_group) hipLaunchKernelGGL(hs_str_kernel, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin, 0);

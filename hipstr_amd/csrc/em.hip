@@ -271,68 +271,103 @@ __device__ void em_gt_priors(const hs_em_dev_t& d, const hs_em_locus_t& L, int t
   tk1 = __builtin_amdgcn_s_memtime();
 #endif
   // The two scans of allele a are ONE dependent chain over S + S A values (update_streaming_log_sum_exp, mathops.cpp:72-80): lane a owns it.
-  // What is expensive in a step is the exponential, and that does not depend on the chain except through the running maximum m, which
-  // changes only a handful of times: so the values are taken HS_EM_CHUNK at a time — every thread of the workgroup forms
-  // exp(v - m_a) for its share of the chunk's (position, allele) pairs with the maxima as they stand at the chunk's start (correctly
-  // rounded, cr_math.h; a value above its allele's maximum gets no exponential), then lane a walks its chunk: where its maximum still is
-  // what the exponentials were formed with it adds the prepared term, where a new maximum appeared it takes the step the long way.
-  // Same values, same operations in the same order as the scalar chain.  (A > 64: alleles beyond the first wavefront's lanes loop.)
+  // What is expensive in a step is the exponential — of (value - running maximum) where the value does not exceed the maximum, of
+  // (old maximum - value) where it becomes the new one — and the running maximum in front of every step is a prefix maximum of the values
+  // alone: it does not depend on the sums.  So the values are taken HS_EM_CHUNK at a time in four phases: (1) all threads put the chunk's
+  // values into LDS, (2) lane a walks its chunk once for the maximum in front of every step (a compare per step), (3) ALL threads form
+  // the step's exponential with that maximum (correctly rounded, cr_math.h; a term that cannot change a total >= 1 is marked instead),
+  // (4) lane a walks its chunk again: an addition per step, a multiplication and an addition where the maximum moves.  Same values,
+  // same operations in the same order as the scalar chain, and no exponential inside the dependent chain (until round 5 a lane whose
+  // maximum had moved inside a chunk evaluated the rest of the chunk the long way — with 33 chains side by side in one wavefront nearly
+  // every step of the walk paid for somebody's exponential: ~540 cycles per step).  (A > 64: alleles beyond the first wavefront's lanes loop.)
   constexpr int CH = HS_EM_CHUNK;
-  __shared__ double s_m[HS_EM_MAXA_LDS];                 // running maximum per allele (the chunk's snapshot)
-  // hs_em_dyn: [CH][Apad] prepared exponentials | at CH*HS_EM_MAXA_LDS: [CH][Apad] the values
-  const int Apad = A;
+  constexpr int NE = (CH*HS_EM_MAXA_LDS + 255)/256;      // a thread's share of a chunk's (position, allele) pairs
+  double* const Ebuf = hs_em_dyn;                         // [CH][na]: the maximum in front of the step, then the step's exponential
+  double* const Vbuf = hs_em_dyn + CH*HS_EM_MAXA_LDS;    // [CH][na]: the values (the walks are dependent chains and must not wait for L2 at every step)
   const int64_t n1 = S, n2 = (int64_t)S*A, ntot = n1 + n2;
-  auto value_at = [&](int64_t i, int a) -> double {      // the chain of allele a: row_lse(s, a) for s < S, then post[(s, i1), a]
-    return i < n1 ? row_lse[i*A + a] : post[(i - n1)*A + a];
-  };
   for (int a0 = 0; a0 < A; a0 += HS_EM_MAXA_LDS){
     const int na = min(HS_EM_MAXA_LDS, A - a0);
-    double m = -DBL_MAX/2, t = 0.0;                      // lane a - a0 < na of the first wavefront(s): the chain's state
-    if (tid < na) s_m[tid] = m;
-    __syncthreads();
+    double m = -DBL_MAX/2, t = 0.0;                      // lane a - a0 < na of the first wavefront: the chain's state
+    // a thread's pairs are the same in every chunk: position i (of the chunk) and allele al of pair e = tid + 256 q
+    int pi[NE], pidx[NE];
+#pragma unroll
+    for (int q = 0; q < NE; q++){ const int e = tid + 256*q; const int i = e / na; pi[q] = i; pidx[q] = i*na + (e - i*na); }
+    double nxt[NE];
+    auto fetch = [&](int64_t c0){                        // this thread's share of the chunk at c0: requested here, used after the next barrier but one
+      const int cn = (int)min((int64_t)CH, ntot - c0);
+#pragma unroll
+      for (int q = 0; q < NE; q++) if (pi[q] < cn){
+        const int64_t ci = c0 + pi[q]; const int a = a0 + (pidx[q] - pi[q]*na);
+        nxt[q] = ci < n1 ? row_lse[ci*A + a] : post[(ci - n1)*A + a];      // the chain of allele a: row_lse(s, a) for s < S, then post[(s, i1), a]
+      }
+    };
+    fetch(0);
     for (int64_t c0 = 0; c0 < ntot; c0 += CH){
       const int cn = (int)min((int64_t)CH, ntot - c0);
-      for (int e = tid; e < cn*na; e += 256){
-        const int i = e / na, al = e - i*na;
-        const double lv = value_at(c0 + i, a0 + al), ms = s_m[al];
-        double ex = 0.0;
-        if (lv <= ms){ const double x_ = lv - ms; ex = (x_ < -37.43) ? -1.0 : cr_exp(x_); }       // -1: "below 2^-54" (see the walk)
-        hs_em_dyn[i*Apad + al] = ex;
-        hs_em_dyn[CH*HS_EM_MAXA_LDS + i*Apad + al] = lv;     // the value itself: the walk is a dependent chain and must not wait for L2 at every step
-      }
+#pragma unroll
+      for (int q = 0; q < NE; q++) if (pi[q] < cn) Vbuf[pidx[q]] = nxt[q];
       __syncthreads();
 #ifdef HS_EM_TIME
       const unsigned long long ta = __builtin_amdgcn_s_memtime();
 #endif
-      if (tid < na){
-        __builtin_amdgcn_s_setprio(3);                   // the workgroup waits for this one wavefront's dependent chain: it goes first whenever it is ready
-        const double ms = s_m[tid];
+      if (tid < na){                                     // (2) the maximum in front of every step
+        __builtin_amdgcn_s_setprio(3);                   // the workgroup waits for this one wavefront's chain: it goes first whenever it is ready
+        double mr = m;
+        for (int i0 = 0; i0 < cn; i0 += 8){
+          double lvv[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) lvv[q] = Vbuf[min(i0 + q, cn - 1)*na + tid];
+#pragma unroll
+          for (int q = 0; q < 8; q++){
+            if (i0 + q >= cn) break;
+            Ebuf[(i0 + q)*na + tid] = mr;
+            mr = (lvv[q] > mr) ? lvv[q] : mr;            // (the walk below moves its maximum by the same test)
+          }
+        }
+        __builtin_amdgcn_s_setprio(0);
+      }
+#ifdef HS_EM_TIME
+      tkB += __builtin_amdgcn_s_memtime() - ta;
+#endif
+      __syncthreads();
+      if (c0 + CH < ntot) fetch(c0 + CH);                // the next chunk's values travel while this chunk's exponentials are formed
+#pragma unroll
+      for (int q = 0; q < NE; q++) if (pi[q] < cn){      // (3)
+        const double lv = Vbuf[pidx[q]], mb = Ebuf[pidx[q]];
+        double ex;
+        if (lv <= mb){ const double x_ = lv - mb; ex = (x_ < -37.43) ? -1.0 : cr_exp(x_); }       // -1: "below 2^-54" (see the walk)
+        else ex = cr_exp(mb - lv);                        // the factor of the total gathered under the old maximum
+        Ebuf[pidx[q]] = ex;
+      }
+      __syncthreads();
+#ifdef HS_EM_TIME
+      const unsigned long long tb = __builtin_amdgcn_s_memtime();
+#endif
+      if (tid < na){                                     // (4)
+        __builtin_amdgcn_s_setprio(3);
         // eight steps' operands are fetched together, ahead of the (dependent) chain: a step that waited for its own two LDS reads took ~400 cycles
         for (int i0 = 0; i0 < cn; i0 += 8){
           double lvv[8], exv[8];
 #pragma unroll
           for (int q = 0; q < 8; q++){
             const int i = min(i0 + q, cn - 1);
-            lvv[q] = hs_em_dyn[CH*HS_EM_MAXA_LDS + i*Apad + tid]; exv[q] = hs_em_dyn[i*Apad + tid];
+            lvv[q] = Vbuf[i*na + tid]; exv[q] = Ebuf[i*na + tid];
           }
 #pragma unroll
           for (int q = 0; q < 8; q++){
             if (i0 + q >= cn) break;
             const double lv = lvv[q];
             if (lv <= m){
-              if (m == ms){
-                // (once a maximum is set the total is >= 1: a term below 2^-54 leaves it as it is, bit for bit; before that — t < 1 only while
-                //  m is still the initial -DBL_MAX/2, where no value is below it — it cannot occur)
-                if (exv[q] >= 0.0) t += exv[q];
-              } else { const double x_ = lv - m; if (!(t >= 1.0 && x_ < -37.43)) t += cr_exp(x_); }
-            } else { t *= cr_exp(m - lv); t += 1.0; m = lv; }
+              // (once a maximum is set the total is >= 1: a term below 2^-54 leaves it as it is, bit for bit; before that — t < 1 only while
+              //  m is still the initial -DBL_MAX/2, where no value is below it — it cannot occur)
+              if (exv[q] >= 0.0) t += exv[q];
+            } else { t *= exv[q]; t += 1.0; m = lv; }
           }
         }
-        s_m[tid] = m;
         __builtin_amdgcn_s_setprio(0);
       }
 #ifdef HS_EM_TIME
-      tkB += __builtin_amdgcn_s_memtime() - ta;
+      tkB += __builtin_amdgcn_s_memtime() - tb;
 #endif
       __syncthreads();
     }

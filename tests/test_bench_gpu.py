@@ -35,6 +35,9 @@ def test_single_gpu_line_has_every_contract_field():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert d["end_to_end"]["alignments_per_s"] > 0 and d["valu"]["profile_matches_build"] in (True, False)
+    # the counters behind the limiter and the traffic figure are the plain north-star pass', not those of an interrupted-repeat pass
+    # (the summaries of those passes sit in the same directory and sort later by name)
+    assert "_ns_" in d["valu"]["source"] and "_ns_" in rf["traffic_source"], (d["valu"]["source"], rf["traffic_source"])
 
 
 def test_two_ranks_weak_and_strong():

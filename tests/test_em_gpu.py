@@ -65,6 +65,18 @@ def test_many_loci_increasing_allele_counts(hmm, oracle):
     _exact(got, want, oracle, kw, "48 loci, growing allele counts")
 
 
+def test_more_allele_sizes_than_a_wavefront_has_lanes(hmm, oracle):
+    """recalc_log_gt_priors (em_stutter_genotyper.cpp:22-57) on the device keeps one chain per allele size on the lanes of a wavefront, 64 at a
+    time, with the chunk's values and exponentials in LDS tiles indexed by the alleles of the sweep — loci with 70 to 130 distinct sizes
+    (highly polymorphic loci of a large cohort) take two sweeps and rows longer than a tile's usual stride; next to a small locus."""
+    kw = em_case(321, n_loci=4, samples=(130, 150), reads_per_sample=(3, 4), haploid_rate=0.0, allele_counts=[70, 4, 100, 130])
+    n_sizes = [len(set(kw["num_bps"][kw["read_off"][l]:kw["read_off"][l + 1]])) for l in range(4)]
+    assert n_sizes[0] > 64 and n_sizes[2] > 64 and n_sizes[3] > 100, n_sizes
+    got = capi.run_em(hmm, "hipstr_", **kw)
+    want = capi.run_em(oracle, "oracle_", **kw)
+    _exact(got, want, oracle, kw, "loci with more than 64 allele sizes")
+
+
 def test_loci_that_converge_at_very_different_rounds(hmm, oracle, monkeypatch):
     """The device-resident loop compacts the list of loci still training after every round and sizes its launches by a count that lags a
     round behind: loci that stop after 2 rounds next to loci that need dozens, a locus that runs out of iterations (train() == false), and

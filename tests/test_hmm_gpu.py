@@ -378,6 +378,40 @@ def test_wait_modes_of_the_one_shot_calls(mode):
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout
 
 
+def test_one_locus_calls_from_many_host_threads(hmm, oracle, monkeypatch):
+    """The unedited caller's shape (HapAligner::process_reads once per locus, README.md:167-171's N workers in ONE process): twelve host
+    threads make one-locus calls at the same time — every thread has its own pair of streams (the main chain and, since round 5, the
+    side stream of the device-built tables and the interrupted alleles' STR kernels), the block caches and the context are shared.  Loci with
+    inherited interruptions (kernel _rp on the side stream), with random ones (_pw) and plain ones, each compared with the oracle bit for bit,
+    three passes with the loci dealt differently so that a thread's streams see every kind after every other."""
+    import threading
+    loci = []
+    for inherit, imperfect, kw in [(2, "0.0", dict(reads_per_locus=40, n_str_alleles=32)), (0, "1.0", dict(reads_per_locus=50, n_str_alleles=8)),
+                                   (0, "0.05", dict(reads_per_locus=50, n_str_alleles=4)), (3, "0.3", dict(reads_per_locus=24, n_str_alleles=16, n_flank_opts=3))]:
+        monkeypatch.setenv("HIPSTR_SYNTH_INHERIT", str(inherit))
+        monkeypatch.setenv("HIPSTR_SYNTH_IMPERFECT", imperfect)
+        for k in range(6):
+            sb = capi.SynthBatch(n_loci=1, seed=900 + 10*len(loci) + k, **kw)
+            want, ws = capi.run_align(oracle, "oracle_", sb.ptr, fill=-3.25)
+            loci.append((sb, want, ws))
+    n_thr = 12
+    bad = []
+    def worker(t, rnd):
+        try:
+            for i in range(len(loci)):
+                sb, want, ws = loci[(i*(2*rnd + 1) + 5*t) % len(loci)]
+                got, gs = capi.run_align(hmm, "hipstr_hmm_", sb.ptr, fill=-3.25)
+                if not (np.array_equal(gs, ws) and np.array_equal(got, want)):
+                    bad.append((t, rnd, i))
+        except Exception as ex:      # noqa: BLE001 - reported below
+            bad.append((t, rnd, repr(ex)))
+    for rnd in range(3):
+        ths = [threading.Thread(target=worker, args=(t, rnd)) for t in range(n_thr)]
+        for th in ths: th.start()
+        for th in ths: th.join()
+    assert not bad, bad[:5]
+
+
 def test_api_profile_buckets(hmm):
     """hipstr_debug_api_profile: wall time and calls per entry point while switched on (what genotype_flow --profile prints)."""
     import ctypes as C

@@ -10,6 +10,9 @@ R=$(pwd)
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-pipeline $*"
+# the generator overrides of the caller's environment are part of what was profiled: they go in front of the recorded command (bench.py
+# does not take a summary with such an override for the plain workload's)
+SYNTH_ENV=$(env | grep '^HIPSTR_SYNTH' | sort | tr '\n' ' ')
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py $ARGS > $OUT/bench.log 2>&1
 N_ALN=$(python -c "import json;print(json.loads([l for l in open('$OUT/bench.log') if l.startswith('{')][-1])['config']['alignments_per_step_per_gpu'])")
@@ -22,6 +25,6 @@ rocprofv3 --kernel-trace --pmc $SQ2 -d $OUT/sq2 -o v -- python $R/bench.py $ARGS
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o v -- python $R/bench.py $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o v -- python $R/bench.py $ARGS > $OUT/write.log 2>&1
 db(){ find $OUT/$1 -name '*results.db' | head -1; }
-python $R/tools/sq_counters.py $(db sq1) $(db sq2) $N_ALN "bench.py $ARGS" $R/profiles > $OUT/sq_counters.json
-python $R/tools/pmc_traffic.py $(db fetch) $(db write) $N_ALN "bench.py $ARGS" > $OUT/pmc_traffic.json
+python $R/tools/sq_counters.py $(db sq1) $(db sq2) $N_ALN "${SYNTH_ENV}bench.py $ARGS" $R/profiles > $OUT/sq_counters.json
+python $R/tools/pmc_traffic.py $(db fetch) $(db write) $N_ALN "${SYNTH_ENV}bench.py $ARGS" > $OUT/pmc_traffic.json
 ls -la $OUT | head -30

@@ -16,7 +16,7 @@ HIPSTR_SYNTH_IMPERFECT=1.0 pass imperfect --loci 400
 HIPSTR_SYNTH_INHERIT=2 pass inherit2 --loci 400
 cd $R
 # the counters above are what bench.py reads back: copy them where it looks before the bench lines are taken
-for w in ns c5 p30 c4 c2; do for f in sq_counters.json pmc_traffic.json; do cp $O/r05_${w}_$f profiles/ 2>/dev/null; done; done
+for w in ns c5 p30 c4 c2 c3 imperfect inherit2; do for f in sq_counters.json pmc_traffic.json; do cp $O/r05_${w}_$f profiles/ 2>/dev/null; done; done
 python bench.py > $O/r05_bench_ns.json 2> $O/bench_ns.err
 for w in c5 p30 c4 c2; do python bench.py --workload $w --no-cpu-baseline > $O/r05_bench_$w.json 2> $O/bench_$w.err; done
 python bench.py --workload c3 --no-cpu-baseline --no-pipeline --steps 3 > $O/r05_bench_c3.json 2> $O/bench_c3.err
