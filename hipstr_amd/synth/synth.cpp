@@ -37,7 +37,7 @@ struct Rng {
   }
   double uni(){ return (next() >> 11) * (1.0/9007199254740992.0); }
   int below(int n){ return (int)(next() % (uint64_t)n); }      // n > 0
-  int range(int lo, int hi){ return lo + below(hi-lo+1); }       // inclusive
+  int range(int lo, int hi){ return hi < lo ? lo : lo + below(hi-lo+1); }       // inclusive (an empty range: lo, no draw)
   char base(){ return "ACGT"[next() & 3]; }
   char other_base(char c){ char b; do { b = base(); } while (b == c); return b; }
 };
@@ -137,7 +137,7 @@ void gen_locus(const Cfg& c, int l, Synth& out){
   for (int side = 0; side < 2; side++){
     std::string f; for (int i = 0; i < c.flank_len; i++) f += rng.base();
     fl[side].push_back(f);
-    for (int o = 1; o < c.n_flank_opts; o++){
+    for (int o = 1; o < c.n_flank_opts && c.flank_len >= 6; o++){       // (a flank of fewer than six bases has no alternatives: the edit keeps two bases from either end)
       std::string g = f;
       int pos = rng.range(2, (int)g.size()-3);
       if (o & 1) g[pos] = rng.other_base(g[pos]); else g.erase(pos, 1);
@@ -191,7 +191,7 @@ void gen_locus(const Cfg& c, int l, Synth& out){
     if (hi < lo) hi = lo;
     int s = rng.range(lo, hi);
     int indel_at = -1, indel_kind = 0;
-    if (rng.uni() < c.indel_rate){ indel_at = rng.range(3, Lr-4); indel_kind = rng.below(2) ? 1 : -1; }
+    if (rng.uni() < c.indel_rate && Lr >= 8){ indel_at = rng.range(3, Lr-4); indel_kind = rng.below(2) ? 1 : -1; }
 
     const size_t cig_first = out.cigar_op.size();
     std::string rb; rb.reserve(Lr);

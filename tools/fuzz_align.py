@@ -1,5 +1,7 @@
 """Randomised parity sweep of the forward path (GPU vs oracle) over generator shapes: read length, flank length, STR size, allele
-count, flank options, masks, share of interrupted repeats.  usage: python tools/fuzz_align.py [n_configs] [seed]"""
+count, flank options, masks, share of interrupted repeats.  usage: python tools/fuzz_align.py [n_configs] [seed] [edges]
+"edges": reads per locus and alleles per locus around the kernels' packing sizes (64 lanes, 256-lane workgroups and their multiples), very
+short reads and flanks."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,6 +19,12 @@ for c in range(n_cfg):
     kw = dict(n_loci=int(rng.integers(1, 5)), reads_per_locus=int(rng.integers(1, 40)), n_str_alleles=int(rng.integers(1, 41)), read_len=read_len,
               flank_len=int(rng.integers(8, 161)), str_bp=int(rng.integers(4, 121)), n_flank_opts=int(rng.integers(1, 4)),
               seed=int(rng.integers(1, 1 << 30)), mask_rate=float(rng.choice([0.0, 0.0, 0.3])))
+    if len(sys.argv) > 3 and sys.argv[3] == "edges":
+        kw.update(n_loci=int(rng.integers(1, 3)), reads_per_locus=int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300])) + int(rng.integers(0, 2)),
+                  n_str_alleles=int(rng.choice([1, 2, 3, 31, 32, 33, 63, 64, 65, 100, 128, 129, 160])), n_flank_opts=int(rng.choice([1, 1, 2, 3])))
+        if kw["n_str_alleles"] * kw["n_flank_opts"] ** 2 > 400: kw["n_flank_opts"] = 1
+        if kw["reads_per_locus"] * kw["n_str_alleles"] * kw["n_flank_opts"] ** 2 > 40000: kw["reads_per_locus"] = max(1, 40000 // (kw["n_str_alleles"] * kw["n_flank_opts"] ** 2))
+        if rng.random() < 0.3: kw.update(read_len=int(rng.integers(8, 40)), flank_len=int(rng.integers(2, 20)), str_bp=int(rng.integers(4, 30)))
     try:
         sb = capi.SynthBatch(**kw)
         want, ws = capi.run_align(ora, "oracle_", sb.ptr, fill=-3.25)
