@@ -621,10 +621,6 @@ def main():
         achieved = algo.value / (kernel_ms * 1e-3) / 1e9 if kernel_ms == kernel_ms else None
         traffic, traffic_src = pmc_traffic(phase_names[dom].split("<")[0], n_aln.value)
         valu = valu_block(dict(zip(phase_names, [float(x) for x in phase_ms])), n_aln.value) if n_ms > 0 else None
-        if args.workload == "c3":
-            # the counter summaries hold a kernel's counts PER LAUNCH (tools/sq_counters.py, tools/pmc_traffic.py average over dispatches) and a c3
-            # pass launches every kernel once per chunk of reads: scaled by alignments they would come out low by the number of chunks
-            traffic, traffic_src, valu = None, None, None
         out = {
             "metric": "read x allele HMM alignments/sec", "value": value, "unit": "alignments/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

@@ -782,10 +782,50 @@ void append_stropt(const std::string& blk, int period, const double* stutter, Pr
 }
 void debug_simple_table(int lim, int U0, int tail, double ent[3]){ g_bnd_scale = 1.0; simple_table_entry(lim, U0, tail, ent); }
 
+// The caller's offset tables, before anything indexes with them: the boundary takes plain pointers, so what the library can know is
+// whether the tables are consistent with EACH OTHER — counts in range, offsets non-negative and never decreasing, CIGAR runs of
+// positive length.  One pass over the tables (a few integers per read); everything behind it (check_locus, prepare_locus) may then take
+// lengths as differences of neighbouring offsets without looking again.  (tools/fuzz_malformed.py: a random corruption per case.)
+int validate_tables(const hipstr_batch_t* b, std::string& err){
+  if (b == NULL || b->n_loci < 0){ err = "null or negative-size batch"; return 1; }
+  const int nl = b->n_loci;
+  if (nl == 0) return 0;
+  if (!b->blk_start || !b->blk_end || !b->blk_nopts || !b->period || !b->stutter || !b->opt_off || !b->seq || !b->hap_off || !b->read_off ||
+      !b->base_off || !b->bases || !b->quals || !b->read_start || !b->cigar_off || !b->cigar_op || !b->cigar_len){ err = "null table in a batch with loci"; return 1; }
+  if (b->hap_off[0] < 0 || b->read_off[0] < 0 || b->opt_off[0] < 0){ err = "negative offset"; return 1; }
+  int64_t nopt = 0;
+  for (int l = 0; l < nl; l++){
+    for (int k = 0; k < 3; k++){
+      const int n = b->blk_nopts[3*l+k];
+      if (n < 1){ err = "haplotype block without options"; return 1; }
+      if (n > 1024){ err = "more than 1024 options for a haplotype block are not supported"; return 1; }
+      nopt += n;
+    }
+    if (b->read_off[l+1] < b->read_off[l]){ err = "read_off must not decrease"; return 1; }
+    if (b->hap_off[l+1] < b->hap_off[l]){ err = "hap_off must not decrease"; return 1; }
+  }
+  // (lengths no caller means: an offset far beyond its neighbour is a corrupted table, and the sequence behind it is not the caller's memory)
+  for (int64_t o = 0; o < nopt; o++){
+    if (b->opt_off[o+1] < b->opt_off[o]){ err = "opt_off must not decrease"; return 1; }
+    if (b->opt_off[o+1] - b->opt_off[o] > (1 << 16)){ err = "haplotype block option longer than 65536 bases"; return 1; }
+  }
+  const int nr = b->read_off[nl];
+  if (nr > 0 && (b->base_off[b->read_off[0]] < 0 || b->cigar_off[b->read_off[0]] < 0)){ err = "negative offset"; return 1; }
+  for (int r = b->read_off[0]; r < nr; r++){
+    if (b->base_off[r+1] < b->base_off[r]){ err = "base_off must not decrease"; return 1; }
+    if (b->base_off[r+1] - b->base_off[r] > (1 << 20)){ err = "read longer than 1 Mi bases"; return 1; }
+    if (b->cigar_off[r+1] - b->cigar_off[r] > (1 << 20)){ err = "CIGAR of more than 1 Mi runs"; return 1; }
+    if (b->cigar_off[r+1] < b->cigar_off[r]){ err = "cigar_off must not decrease"; return 1; }
+  }
+  const int nc = b->cigar_off[nr];
+  for (int c = nr > 0 ? b->cigar_off[b->read_off[0]] : 0; c < nc; c++) if (b->cigar_len[c] <= 0){ err = "CIGAR run of non-positive length"; return 1; }
+  return 0;
+}
+
 // The conditions under which prepare_batch refuses a batch, without building anything (same order, same messages): used where a
 // bad locus must be turned away before it is merged with others (hipstr_stream_submit).
 int check_batch(const hipstr_batch_t* b, std::string& err){
-  if (b == NULL || b->n_loci < 0){ err = "null or negative-size batch"; return 1; }
+  if (validate_tables(b, err)) return 1;
   int opt_cursor = 0;
   for (int l = 0; l < b->n_loci; l++)
     if (check_locus(b, l, &opt_cursor, err)) return 1;
@@ -1415,7 +1455,7 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
   auto t_lap = now();
   g_bnd_scale = getenv("HIPSTR_DEBUG_BND_SCALE") ? atof(getenv("HIPSTR_DEBUG_BND_SCALE")) : 1.0;
   g_host_tables = getenv("HIPSTR_HOST_TABLES") && atoi(getenv("HIPSTR_HOST_TABLES")) != 0;
-  if (b == NULL || b->n_loci < 0){ err = "null or negative-size batch"; return 1; }
+  if (validate_tables(b, err)) return 1;
   const int n_reads_total = b->n_loci > 0 ? b->read_off[b->n_loci] : 0;
   out.seeds.assign(n_reads_total, -1);
   out.realign_read.assign(n_reads_total, 1);

@@ -102,6 +102,9 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
 
 // Returns 0 if prepare_batch would accept the batch; otherwise its error message in err.
 int check_batch(const hipstr_batch_t* b, std::string& err);
+// The offset tables of a batch are consistent with each other (counts in range, offsets non-negative and never decreasing, CIGAR runs positive):
+// called by every entry point that takes a caller's batch, before anything indexes with the tables.
+int validate_tables(const hipstr_batch_t* b, std::string& err);
 void prep_profile_print();
 // one locus of it; the cursor into opt_off is advanced.  seeds_out (optional, indexed by the batch's read index): the seed bases the check computed anyway
 // (HIPSTR_SEED_AUTO for reads that are not realigned), so that prepare_batch does not walk the CIGARs a second time

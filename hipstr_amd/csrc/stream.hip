@@ -427,7 +427,7 @@ int64_t hipstr_stream_submit(hipstr_stream_t* s, const hipstr_batch_t* loci){
   int sub_read = 0, sub_B = 1;
   {
     std::string why;
-    if (loci->n_loci < 0){ hipstr::api_fail("null or negative-size batch"); return -1; }
+    if (hipstr::validate_tables(loci, why)){ hipstr::api_fail(why); return -1; }
     seeds.resize(loci->n_loci > 0 ? (size_t)std::max(0, loci->read_off[loci->n_loci]) : 0);
     int cursor = 0;
     for (int l = 0; l < loci->n_loci; l++){
@@ -457,6 +457,7 @@ int64_t hipstr_stream_submit(hipstr_stream_t* s, const hipstr_batch_t* loci){
 int hipstr_stream_submit_each(hipstr_stream_t* s, const hipstr_batch_t* loci, int64_t* first_ticket){
   if (!s || !loci) return hipstr::api_fail("null argument");
   CpuAdd cpu_t(s, &s->stats.cpu_submit_seconds);
+  { std::string bad; if (hipstr::validate_tables(loci, bad)) return hipstr::api_fail(bad); }
   const int n = loci->n_loci;
   const auto t_sub0 = std::chrono::steady_clock::now();
   // A locus that prepare_batch would refuse is turned away here, before it shares a batch with others.  The checks (a seed per read
@@ -546,6 +547,7 @@ int hipstr_stream_collect(hipstr_stream_t* s, int64_t n_tickets, double* aln_pro
 // processed by hipstr_hmm_process_reads, and their blocks copied back to where the caller's layout has them.
 int hipstr_hmm_process_reads_each(const hipstr_batch_t* batch, double* aln_probs, int32_t* seeds, int32_t* locus_status){
   if (!batch || !aln_probs || !seeds || !locus_status) return hipstr::api_fail("null argument");
+  { std::string bad; if (hipstr::validate_tables(batch, bad)) return hipstr::api_fail(bad); }      // (tables that contradict each other fail the call, not a locus)
   const int n = batch->n_loci;
   OwnedBatch ob;
   std::vector<int> good; std::vector<int64_t> out_off(n + 1, 0);

@@ -53,6 +53,11 @@ extern "C" {
  * RepeatBlock.h:26-43), the StutterModel parameters of the STR block
  * (stutter_model.h:31-60) and, per pooled read, the fields of `Alignment` the
  * path touches: sequence, base qualities, start and CIGAR (AlignmentData.h:28-137).
+ *
+ * Every entry point that takes a batch first checks that its tables agree with each other — counts in range, offsets non-negative
+ * and never decreasing, no option longer than 65536 bases, no read longer than 1 Mi bases, CIGAR runs of positive length — and fails
+ * the call with a message otherwise (where the reference would assert or index out of its vectors); what the pointers point AT cannot
+ * be checked: the arrays must be as long as their offset tables say.
  */
 typedef struct hipstr_batch {
   int32_t        n_loci;

@@ -24,16 +24,28 @@ def test_stutter_em_at_size_boundaries(hmm, oracle):
     assert bad == 0 and loci > 0
 
 
-def test_needleman_wunsch_and_caller_chosen_seeds_at_size_boundaries(hmm, oracle):
+def _keep_generator_settings(monkeypatch):
+    """The fuzzers set the generator's HIPSTR_SYNTH_* overrides in os.environ as they go: registered with monkeypatch first, the variables are
+    back to what they were (normally: unset) when the test ends — later tests and the processes they start see the default generator."""
+    for k in ("HIPSTR_SYNTH_IMPERFECT", "HIPSTR_SYNTH_INHERIT"):
+        was_set = k in os.environ
+        monkeypatch.setenv(k, os.environ.get(k, "0"))
+        if not was_set:
+            monkeypatch.delenv(k)
+
+
+def test_needleman_wunsch_and_caller_chosen_seeds_at_size_boundaries(hmm, oracle, monkeypatch):
     """tools/fuzz_misc.py: Needleman-Wunsch on reads of 1 ... 1536 bases against windows of 1 ... 3000 around the kernel's tile sizes; the
     forward path and the traceback with seeds anywhere in the read (HapAligner.h:83, :93: the seed base is the caller's argument)."""
     import fuzz_misc
+    _keep_generator_settings(monkeypatch)
     assert fuzz_misc.run(12, 7, hmm, oracle) == 0
 
 
-def test_heterogeneous_batches_in_one_call_and_through_the_stream(hmm, oracle):
+def test_heterogeneous_batches_in_one_call_and_through_the_stream(hmm, oracle, monkeypatch):
     """tools/fuzz_mixed.py: loci that have nothing in common (read and flank lengths, allele counts, periods, interrupted or plain repeats,
     masks) concatenated into one batch — what the host pipeline's batches look like in production (bam_processor.cpp:550-617: one region
     after the other) — in one process_reads call and one locus per submission through the stream, against the oracle."""
     import fuzz_mixed
+    _keep_generator_settings(monkeypatch)
     assert fuzz_mixed.run(6, 7, hmm, oracle, stream_every=2) == 0

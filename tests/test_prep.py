@@ -238,3 +238,15 @@ def test_locus_costs_price_interrupted_repeats_and_flanks():
     both = np.concatenate([c, ci])
     bounds = shard.split_loci(both, 2)
     assert bounds[1] > 6                                          # the cheap half holds more loci
+
+
+def test_malformed_tables_are_refused_not_crashed_on():
+    """tools/fuzz_malformed.py: a valid batch with one or two random corruptions of its tables (an offset negative / huge / decreasing, a count
+    zero / negative / huge, a CIGAR run of length 0, a character off, a period or a stutter parameter out of range) goes through the host
+    preparation in a child process — every case must come back (accepted, or refused with a message), none may end the process or hang.
+    The boundary takes plain pointers (include/hipstr_hmm.h): what it can and does check is that the tables agree with each other
+    (prep.cpp validate_tables), before anything indexes with them."""
+    import subprocess, sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_malformed.py")
+    r = subprocess.run([sys.executable, tool, "160", "5"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+    assert r.returncode == 0 and "crashes/timeouts 0" in r.stdout, r.stdout[-2000:]

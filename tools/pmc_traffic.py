@@ -9,13 +9,23 @@ import sqlite3
 import sys
 
 
+import re
+
+
+def passes_of(command):
+    m1, m2 = re.search(r"--steps\s+(\d+)", command), re.search(r"--warmup\s+(\d+)", command)
+    return max(1, (int(m1.group(1)) if m1 else 1) + (int(m2.group(1)) if m2 else 0))
+
+
 def per_kernel(db, counter):
+    """Bytes per kernel and PASS: the average over its dispatches times its dispatches per pass (a chunked pass launches a kernel per chunk)."""
     out = {}
+    passes = passes_of(sys.argv[4] if len(sys.argv) > 4 else "")
     for name, n, avg in sqlite3.connect(db).execute(
-            "select kernel_name,count(*),avg(value) from counters_collection where counter_name=? group by kernel_name", (counter,)):
+            "select kernel_name,count(distinct dispatch_id),avg(value) from counters_collection where counter_name=? group by kernel_name", (counter,)):
         if "hs_" in name:
             key = name.split("::")[-1].split("(")[0]
-            out[key] = out.get(key, 0.0) + avg * 1024.0
+            out[key] = out.get(key, 0.0) + avg * 1024.0 * n / passes
     return out
 
 

@@ -31,15 +31,26 @@ def key_of(name):
     return name.split("::")[-1].split("(")[0]
 
 
+def passes_of(command):
+    """Passes of the hot path in a profiled run: bench.py --steps S --warmup W runs S + W of them."""
+    m1, m2 = re.search(r"--steps\s+(\d+)", command), re.search(r"--warmup\s+(\d+)", command)
+    return max(1, (int(m1.group(1)) if m1 else 1) + (int(m2.group(1)) if m2 else 0))
+
+
 def collect(path):
+    """Counters and duration of every kernel PER PASS: the average over its dispatches times its dispatches per pass (a pass that takes its
+    reads in several chunks launches a kernel once per chunk: bench.py scales these figures by alignments per pass)."""
     db = sqlite3.connect(path)
+    per_pass = {}
+    for name, n in db.execute("select kernel_name, count(distinct dispatch_id) from counters_collection group by kernel_name"):
+        per_pass[name] = n / float(passes_of(cmd))
     kern = {}
     for name, counter, avg in db.execute("select kernel_name,counter_name,avg(value) from counters_collection group by kernel_name,counter_name"):
         if "hs_" in name:
-            kern.setdefault(key_of(name), {})[counter] = avg
+            kern.setdefault(key_of(name), {})[counter] = avg * per_pass[name]
     dur = {}
     for name, d in db.execute("select kernel_name, avg(duration) from (select distinct dispatch_id, kernel_name, duration from counters_collection) group by kernel_name"):
-        dur[key_of(name)] = d
+        dur[key_of(name)] = d * per_pass[name]
     return kern, dur
 
 
