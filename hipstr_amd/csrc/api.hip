@@ -439,6 +439,7 @@ void hipstr_hmm_shutdown(void){
 int hipstr_calc_seed_bases(const hipstr_batch_t* b, int32_t* seeds){
   hipstr::ApiTimer prof_t(hipstr::PB_SEED_BASES);
   if (!b || !seeds) return fail("null argument");
+  { std::string bad; if (hipstr::validate_tables(b, bad)) return fail(bad); }
   for (int l = 0; l < b->n_loci; l++)
     for (int r = b->read_off[l]; r < b->read_off[l+1]; r++){
       seeds[r] = hipstr::calc_seed_base(b, l, r);

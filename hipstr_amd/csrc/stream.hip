@@ -780,6 +780,7 @@ hipstr_multi_t* hipstr_multi_open(int32_t n_devices, const int32_t* devices, int
 
 int64_t hipstr_multi_submit(hipstr_multi_t* mm, const hipstr_batch_t* loci){
   if (!mm || !loci){ hipstr::api_fail("null argument"); return -1; }
+  { std::string bad; if (hipstr::validate_tables(loci, bad)){ hipstr::api_fail(bad); return -1; } }
   std::lock_guard<std::mutex> g(mm->m);
   int64_t work = 0; double cost = 0.0;
   for (int l = 0, opt0 = 0; l < loci->n_loci; l++){
@@ -813,6 +814,7 @@ int hipstr_multi_dealt(hipstr_multi_t* mm, double* cost_per_device, int32_t cap)
 
 int hipstr_locus_costs(const hipstr_batch_t* batch, double* costs){
   if (!batch || !costs) return hipstr::api_fail("null argument");
+  { std::string bad; if (hipstr::validate_tables(batch, bad)) return hipstr::api_fail(bad); }
   for (int l = 0, opt0 = 0; l < batch->n_loci; l++){
     int nopt = 0;
     for (int k = 0; k < 3; k++){ if (batch->blk_nopts[3*l+k] < 1) return hipstr::api_fail("haplotype block without options"); nopt += batch->blk_nopts[3*l+k]; }

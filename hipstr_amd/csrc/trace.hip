@@ -758,6 +758,7 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
   using hipstr::api_fail;
   if (!b || !o || n_req < 0 || (n_req > 0 && (!req_read || !req_allele))) return api_fail("null argument");
   if (b->n_loci < 1) return api_fail("hipstr_hmm_trace needs at least one locus");
+  { std::string bad; if (hipstr::validate_tables(b, bad)) return api_fail(bad); }
   const bool timing = getenv("HIPSTR_TRACE_TIMING") != NULL;
   auto now = [](){ return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b){ return std::chrono::duration<double, std::milli>(b - a).count(); };
