@@ -783,9 +783,13 @@ void append_stropt(const std::string& blk, int period, const double* stutter, Pr
 void debug_simple_table(int lim, int U0, int tail, double ent[3]){ g_bnd_scale = 1.0; simple_table_entry(lim, U0, tail, ent); }
 
 // The caller's offset tables, before anything indexes with them: the boundary takes plain pointers, so what the library can know is
-// whether the tables are consistent with EACH OTHER — counts in range, offsets non-negative and never decreasing, CIGAR runs of
-// positive length.  One pass over the tables (a few integers per read); everything behind it (check_locus, prepare_locus) may then take
-// lengths as differences of neighbouring offsets without looking again.  (tools/fuzz_malformed.py: a random corruption per case.)
+// whether the tables are consistent with EACH OTHER — null pointers, counts that contradict each other (a locus' haplotype count is the
+// product of its blocks' option counts), offsets that are negative or decrease, CIGAR runs of non-positive length.  One pass over the
+// tables (a few integers per read); everything behind it (check_locus, prepare_locus) may then take lengths as differences of
+// neighbouring offsets without looking again.  (tools/fuzz_malformed.py: a random corruption per case.)
+// What is NOT here: the sizes a consistent locus may have and this library does not take — more than 1024 options of a
+// block, an option of more than 65536 bases, a read of more than 1 Mi bases.  Those are check_locus' refusals, per locus: one oversized
+// locus in a shard fails alone (hipstr_hmm_process_reads_each, hipstr_stream_submit_each), not the call.
 int validate_tables(const hipstr_batch_t* b, std::string& err){
   if (b == NULL || b->n_loci < 0){ err = "null or negative-size batch"; return 1; }
   const int nl = b->n_loci;
@@ -795,30 +799,34 @@ int validate_tables(const hipstr_batch_t* b, std::string& err){
   if (b->hap_off[0] < 0 || b->read_off[0] < 0 || b->opt_off[0] < 0){ err = "negative offset"; return 1; }
   int64_t nopt = 0;
   for (int l = 0; l < nl; l++){
+    if (b->read_off[l+1] < b->read_off[l]){ err = "read_off must not decrease"; return 1; }
+    if (b->hap_off[l+1] < b->hap_off[l]){ err = "hap_off must not decrease"; return 1; }
+    // the option counts are what the walk over opt_off below trusts: they must agree with the haplotype count the caller states
+    // separately (a count no caller means contradicts it; the walk never leaves the caller's table on one corrupted integer)
+    int64_t A = 1;
     for (int k = 0; k < 3; k++){
       const int n = b->blk_nopts[3*l+k];
       if (n < 1){ err = "haplotype block without options"; return 1; }
-      if (n > 1024){ err = "more than 1024 options for a haplotype block are not supported"; return 1; }
+      A *= n;                                        // (kept below 2^32 by the test that follows: the next factor cannot wrap it)
+      if (A > ((int64_t)1 << 31)){ err = "hap_off does not match the product of block options"; return 1; }
       nopt += n;
     }
-    if (b->read_off[l+1] < b->read_off[l]){ err = "read_off must not decrease"; return 1; }
-    if (b->hap_off[l+1] < b->hap_off[l]){ err = "hap_off must not decrease"; return 1; }
+    if (A != (int64_t)b->hap_off[l+1] - b->hap_off[l]){ err = "hap_off does not match the product of block options"; return 1; }
   }
-  // (lengths no caller means: an offset far beyond its neighbour is a corrupted table, and the sequence behind it is not the caller's memory)
-  for (int64_t o = 0; o < nopt; o++){
+  for (int64_t o = 0; o < nopt; o++)
     if (b->opt_off[o+1] < b->opt_off[o]){ err = "opt_off must not decrease"; return 1; }
-    if (b->opt_off[o+1] - b->opt_off[o] > (1 << 16)){ err = "haplotype block option longer than 65536 bases"; return 1; }
-  }
   const int nr = b->read_off[nl];
   if (nr > 0 && (b->base_off[b->read_off[0]] < 0 || b->cigar_off[b->read_off[0]] < 0)){ err = "negative offset"; return 1; }
   for (int r = b->read_off[0]; r < nr; r++){
     if (b->base_off[r+1] < b->base_off[r]){ err = "base_off must not decrease"; return 1; }
-    if (b->base_off[r+1] - b->base_off[r] > (1 << 20)){ err = "read longer than 1 Mi bases"; return 1; }
-    if (b->cigar_off[r+1] - b->cigar_off[r] > (1 << 20)){ err = "CIGAR of more than 1 Mi runs"; return 1; }
     if (b->cigar_off[r+1] < b->cigar_off[r]){ err = "cigar_off must not decrease"; return 1; }
   }
-  const int nc = b->cigar_off[nr];
-  for (int c = nr > 0 ? b->cigar_off[b->read_off[0]] : 0; c < nc; c++) if (b->cigar_len[c] <= 0){ err = "CIGAR run of non-positive length"; return 1; }
+  // (a CIGAR table no caller means — more runs than bases — is an offset pointing out of the caller's memory: the walk below stays
+  // within runs that can belong to the batch's bases)
+  const int64_t nbases = nr > 0 ? (int64_t)b->base_off[nr] - b->base_off[b->read_off[0]] : 0;
+  const int c0 = nr > 0 ? b->cigar_off[b->read_off[0]] : 0, nc = nr > 0 ? b->cigar_off[nr] : 0;
+  if ((int64_t)nc - c0 > 2*nbases + 2*(int64_t)(nr - b->read_off[0])){ err = "cigar_off holds more runs than the reads have bases"; return 1; }
+  for (int c = c0; c < nc; c++) if (b->cigar_len[c] <= 0){ err = "CIGAR run of non-positive length"; return 1; }
   return 0;
 }
 
@@ -875,6 +883,7 @@ int check_locus(const hipstr_batch_t* b, int l, int* opt_cursor_io, std::string&
       for (int o = 0; o < n; o++, opt_cursor++){
         const int len = b->opt_off[opt_cursor+1] - b->opt_off[opt_cursor];
         if (len < 0){ err = "opt_off must not decrease"; return 1; }
+        if (len > (1 << 16)){ err = "haplotype block option longer than 65536 bases is not supported"; return 1; }
         if (k != 1 && len == 0){ err = "empty flank sequence"; return 1; }
         if (k == 1 && len == 0){ err = "empty STR allele is not supported"; return 1; }
         if (k == 1 && len > HS_MAX_STR_BP){ err = "STR allele longer than 2047 bp is not supported"; return 1; }
@@ -888,6 +897,8 @@ int check_locus(const hipstr_batch_t* b, int l, int* opt_cursor_io, std::string&
     for (int r = b->read_off[l]; r < b->read_off[l+1]; r++){
       if (b->realign_read && !b->realign_read[r]){ if (seeds_out) seeds_out[r] = HIPSTR_SEED_AUTO; continue; }
       const int len = b->base_off[r+1] - b->base_off[r];
+      if (len > (1 << 20)){ err = "read longer than 1 Mi bases is not supported"; return 1; }
+      if (b->cigar_off[r+1] - b->cigar_off[r] > (1 << 20)){ err = "CIGAR of more than 1 Mi runs is not supported"; return 1; }
       longest_read = std::max(longest_read, len);
       const int s = calc_seed_base(b, l, r);
       if (seeds_out) seeds_out[r] = s;
@@ -1031,12 +1042,19 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
   for (int k = 0; k < 3; k++){
     nopts[k] = b->blk_nopts[3*l+k];
     if (nopts[k] < 1){ err = "haplotype block without options"; return 1; }
+    if (nopts[k] > 1024){ err = "more than 1024 options for a haplotype block are not supported"; return 1; }      // (the sizes check_locus refuses, in its words)
     opt_first[k] = opt_cursor; opt_cursor += nopts[k];
   }
   auto O = [&](int k, int o) -> Seq { const int c = opt_first[k] + o; return Seq{ b->seq + b->opt_off[c], b->opt_off[c+1] - b->opt_off[c] }; };
   for (int k = 0; k < 3; k += 2)
-    for (int o = 0; o < nopts[k]; o++)
+    for (int o = 0; o < nopts[k]; o++){
       if (O(k, o).n == 0){ err = "empty flank sequence"; return 1; }
+      if (O(k, o).n > (1 << 16)){ err = "haplotype block option longer than 65536 bases is not supported"; return 1; }
+    }
+  for (int r = b->read_off[l]; r < b->read_off[l+1]; r++){
+    if (b->base_off[r+1] - b->base_off[r] > (1 << 20)){ err = "read longer than 1 Mi bases is not supported"; return 1; }
+    if (b->cigar_off[r+1] - b->cigar_off[r] > (1 << 20)){ err = "CIGAR of more than 1 Mi runs is not supported"; return 1; }
+  }
   size_t str_total = 0;
   for (int o = 0; o < nopts[1]; o++){
     const int n = O(1, o).n;

@@ -46,6 +46,7 @@ struct Cfg {
   int32_t n_loci, reads_per_locus, n_str_alleles, read_len, flank_len, str_bp, n_flank_opts;
   uint64_t seed;
   double sub_rate, stutter_rate, indel_rate, imperfect_rate, mask_rate;
+  int force_period; // HIPSTR_SYNTH_PERIOD=p (1..9): every locus gets period p instead of a draw from {2..6}
   int inherit;      // HIPSTR_SYNTH_INHERIT=k: the REFERENCE allele carries k (1..3) interrupted repeat units, inherited by every candidate allele
 };
 
@@ -93,6 +94,7 @@ void gen_locus(const Cfg& c, int l, Synth& out){
   static const double pw[5]   = {.35,.20,.30,.10,.05};
   double u = rng.uni(); int p = 6;
   for (int i = 0; i < 5; i++){ if (u < pw[i]){ p = periods[i]; break; } u -= pw[i]; }
+  if (c.force_period > 0) p = c.force_period;           // HIPSTR_SYNTH_PERIOD: periods the weights never draw (1, 7..9: stutter_model.h:38); the draw above still happens
   std::string motif;
   do { motif.clear(); for (int i = 0; i < p; i++) motif += rng.base(); } while (has_sub_period(motif));
   int c0 = std::max(2, (int)std::lround((double)c.str_bp / p));
@@ -248,7 +250,8 @@ void* synth_create_at(int32_t first_locus, int32_t n_loci, int32_t reads_per_loc
   c.flank_len = flank_len; c.str_bp = str_bp; c.n_flank_opts = std::max(1, n_flank_opts); c.seed = seed;
   c.sub_rate = 0.005; c.stutter_rate = 0.05; c.indel_rate = 0.01; c.imperfect_rate = 0.05; c.mask_rate = mask_rate;
   if (const char* e = getenv("HIPSTR_SYNTH_IMPERFECT")) c.imperfect_rate = atof(e);      // experiments: share of alleles with an interrupted repeat
-  c.inherit = 0;
+  c.inherit = 0; c.force_period = 0;
+  if (const char* e = getenv("HIPSTR_SYNTH_PERIOD")) c.force_period = std::max(0, std::min(9, atoi(e)));
   if (const char* e = getenv("HIPSTR_SYNTH_INHERIT")) c.inherit = std::max(0, std::min(3, atoi(e)));
   Synth* s = new Synth();
   s->opt_off.push_back(0); s->hap_off.push_back(0); s->read_off.push_back(0); s->base_off.push_back(0); s->cigar_off.push_back(0);

@@ -123,4 +123,26 @@ CASES = {
     # configs[4]-like stress, shrunk: 250 bp reads, long STR blocks, deep matrices
     "c5_stress_small": _synth(n_loci=2, reads_per_locus=6, n_str_alleles=24, read_len=250, flank_len=110, str_bp=100, seed=5),
     "short_production_like": _synth(n_loci=4, reads_per_locus=10, n_str_alleles=8, read_len=100, flank_len=35, str_bp=30, seed=3),
+    # round 6: 4 x 60 x 4 = 960 candidate haplotypes, next to MAX_TOTAL_HAPLOTYPES = 1000 (genotyper_bam_processor.h:110, enforced at
+    # seq_stutter_genotyper.cpp:610-614); fixtures by make_golden.py's "sizes" section
+    "many_haplotypes": _synth(n_loci=1, reads_per_locus=12, n_str_alleles=60, n_flank_opts=4, seed=11),
 }
+
+BIGPOST_STRIDE = 101
+
+
+def thousand_haplotype_posteriors():
+    """Posterior / genotype-call inputs with A = 1000 haplotypes (10^6 diplotypes per sample) for 3 samples, one without reads:
+    (PostBatch kwargs, n_variants, hap_to_allele).  Likelihood rows shaped like alignments: a best haplotype, neighbours a few nats
+    worse, the rest far off."""
+    rng = np.random.default_rng(20261001)
+    A, S = 1000, 3
+    lab = np.array([0] * 7 + [2] * 5, np.int32); n = lab.size
+    best = rng.integers(0, A, size=n)
+    ll = -np.abs(np.arange(A)[None, :] - best[:, None]) * rng.uniform(0.05, 0.6, size=(n, 1)) - rng.random((n, A))
+    p1 = np.where(rng.random(n) < 0.4, -rng.random(n) * 5, 0.0); p2 = np.where(p1 < 0, -rng.random(n) * 0.05, 0.0)
+    w = np.ones(n, np.int32); w[3] = 0
+    kw = dict(n_alleles=[A], n_samples=[S], read_off=[0, n], sample_label=lab, log_p1=p1, log_p2=p2, read_weight=w, log_aln_probs=ll.ravel(), haploid=[0])
+    V = 250
+    h2a = ((np.arange(A) // 2) % V).astype(np.int32)
+    return kw, [V], h2a

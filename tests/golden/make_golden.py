@@ -112,7 +112,54 @@ def pool_scatter(ref):
         print("pool_scatter", name, "reads", R, "pools", P, "mates", int(mates.sum()), "alleles", A, "untouched", int((ll == before).sum()), "of", ll.size)
 
 
-SECTIONS = {"seeded": seeded, "pool_scatter": pool_scatter}
+def sizes(ref):
+    """Round 6: the sizes the reference allows and no earlier fixture reached — a locus with 4 x 60 x 4 = 960 candidate haplotypes
+    (MAX_TOTAL_HAPLOTYPES = 1000, genotyper_bam_processor.h:110): forward log-likelihoods and tracebacks; posteriors and genotype calls
+    with 1000 haplotypes (10^6 diplotypes per sample; a strided sample of the posteriors is stored, every other output whole)."""
+    import json
+    from hipstr_amd import shard
+    from cases import CASES
+    name = "many_haplotypes"
+    b = CASES[name]()
+    probs, seeds = capi.run_align(ref, "ref_", b.ptr, fill=SENTINEL)
+    d = batch_to_dict(b)
+    d["expect_aln_probs"] = probs; d["expect_seeds"] = seeds; d["sentinel"] = np.array([SENTINEL])
+    np.savez_compressed(os.path.join(HERE, "align_%s.npz" % name), **d)
+    a = b.arrays
+    A = int(a["hap_off"][1])
+    print(name, "alignments", probs.size, "haplotypes", A, "seed -1:", int((seeds == -1).sum()))
+    rng_t = np.random.default_rng(20261001)
+    ok = [r for r in range(int(a["read_off"][1])) if seeds[r] >= 0]
+    rr, aa = [], []
+    for r in ok:
+        for k in list(rng_t.choice(A, size=5, replace=False)) + [0, A - 1]:
+            rr.append(r); aa.append(int(k))
+    exp = capi.run_trace(ref, "ref_", b.ptr, rr, aa, cap=1 << 22)
+    h2r = capi.ref_hap_aln_info(ref, b.ptr, A)
+    out = batch_to_dict(b, "L0_")
+    out["L0_req_read"] = np.array(rr, np.int32); out["L0_req_allele"] = np.array(aa, np.int32)
+    out["L0_h2r"] = np.frombuffer(b"\n".join(h2r), dtype=np.uint8).copy()
+    out["L0_expect"] = np.frombuffer(json.dumps(exp).encode(), dtype=np.uint8).copy()
+    out["n_traced"] = np.array([1])
+    np.savez_compressed(os.path.join(HERE, "trace_%s.npz" % name), **out)
+    print("trace", name, "requests", len(rr))
+    # posteriors + calls at A = 1000
+    from cases import thousand_haplotype_posteriors, BIGPOST_STRIDE
+    kw, nv, h2a = thousand_haplotype_posteriors()
+    pb = capi.PostBatch(**kw)
+    post, tot, gt, ltot = capi.run_posteriors(ref, "ref_", pb)
+    e = capi.run_gt_extract(ref, "ref_", pb, nv, h2a)
+    out = dict(expect_post_strided=post[::BIGPOST_STRIDE].copy(), expect_post_max=np.array([post.max()]), expect_total=tot, expect_gt=gt, expect_locus_total=ltot)
+    for k2 in ("best_hap", "best_gt", "log_phased_post", "log_unphased_post", "hap_log_phased_post", "hap_log_unphased_post", "gl_diff"):
+        out["expect_" + k2] = e[k2]
+    for k2 in ("gls", "pls", "phased_gls"):
+        out["expect_" + k2] = np.concatenate(e[k2]) if e[k2] else np.zeros(0)
+        out["expect_" + k2 + "_len"] = np.array([len(x) for x in e[k2]])
+    np.savez_compressed(os.path.join(HERE, "bigpost_thousand_haplotypes.npz"), **out)
+    print("bigpost: samples", tot.size, "posteriors", post.size, "stored", out["expect_post_strided"].size, "GLs", sum(len(x) for x in e["gls"]))
+
+
+SECTIONS = {"seeded": seeded, "pool_scatter": pool_scatter, "sizes": sizes}
 
 
 def main():
@@ -122,6 +169,8 @@ def main():
             SECTIONS[name](ref)
         return
     for name, make in CASES.items():
+        if name == "many_haplotypes":         # its own section ("sizes": other trace requests)
+            continue
         b = make()
         probs, seeds = capi.run_align(ref, "ref_", b.ptr, fill=SENTINEL)
         d = batch_to_dict(b)
@@ -134,6 +183,8 @@ def main():
     from hipstr_amd import shard
     rng_t = np.random.default_rng(20260929)
     for name, make in CASES.items():
+        if name == "many_haplotypes":
+            continue
         b = make()
         _, seeds = capi.run_align(ref, "ref_", b.ptr, fill=SENTINEL)
         a = b.arrays

@@ -209,3 +209,37 @@ def test_loci_that_fit_the_lds_alone_but_not_together_go_into_separate_batches(h
             st.submit(bb.ptr)
     finally:
         st.close()
+
+
+def test_oversized_middle_locus_fails_alone(hmm, oracle):
+    """a locus with 1025 options of a block (the library takes 1024) in the middle of a hipstr_hmm_process_reads_each batch
+    and of a hipstr_stream_submit_each call: that locus is refused alone with a message; process_reads_each computes the loci before AND
+    behind it, the stream keeps its contract (the loci before the refused one are in).  The table check used to fail the whole call."""
+    b = util.batch_with_an_oversized_middle_locus()
+    a = b.arrays
+    n_reads, n_out, out_off = capi.batch_dims(b.ptr)
+    probs = np.full(n_out, FILL); seeds = np.full(n_reads, -7, np.int32); status = np.full(3, -1, np.int32)
+    hmm.hipstr_hmm_process_reads_each.restype = C.c_int
+    hmm.hipstr_hmm_process_reads_each.argtypes = [capi._BP, capi._f64p, capi._i32p, capi._i32p]
+    assert hmm.hipstr_hmm_process_reads_each(b.ptr, probs.ctypes.data_as(capi._f64p), seeds.ctypes.data_as(capi._i32p), status.ctypes.data_as(capi._i32p)) == 0, hmm.hipstr_last_error()
+    assert list(status) == [0, 1, 0] and b"locus 1" in hmm.hipstr_last_error() and b"1024" in hmm.hipstr_last_error()
+    ro = a["read_off"]
+    assert np.all(probs[out_off[1]:out_off[2]] == FILL) and np.all(seeds[ro[1]:ro[2]] == -7)
+    want = {}
+    for l in (0, 2):
+        one = shard.batch_from_arrays(shard.subset_arrays(a, l, l + 1))
+        wp, ws = capi.run_align(oracle, "oracle_", one.ptr, fill=FILL)
+        assert np.array_equal(probs[out_off[l]:out_off[l + 1]], wp) and np.array_equal(seeds[ro[l]:ro[l + 1]], ws)
+        want[l] = (wp, ws)
+    with pytest.raises(RuntimeError):                          # the all-or-nothing call refuses the batch, with the locus named
+        capi.run_align(hmm, "hipstr_hmm_", b.ptr, fill=FILL)
+    st = capi.Stream(hmm)                                      # the stream's contract: stops at the refused locus, the loci before it are in
+    with pytest.raises(RuntimeError, match="1024"):
+        st.submit_each(b.ptr)
+    st.submit(shard.batch_from_arrays(shard.subset_arrays(a, 2, 3)).ptr)
+    st.flush()
+    got = [st.next(fill=FILL) for _ in range(2)]
+    assert st.next() is None
+    st.close()
+    for (t, p, s), l in zip(got, (0, 2)):
+        assert np.array_equal(p, want[l][0]) and np.array_equal(s, want[l][1])

@@ -250,3 +250,21 @@ def test_malformed_tables_are_refused_not_crashed_on():
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_malformed.py")
     r = subprocess.run([sys.executable, tool, "160", "5"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
     assert r.returncode == 0 and "crashes/timeouts 0" in r.stdout, r.stdout[-2000:]
+
+
+def test_capability_limits_are_per_locus_not_table_errors(hmm_host):
+    """validate_tables used to fail the WHOLE call for a locus with more than 1024 options of a block — a consistent table of
+    an unsupported locus.  Host entry points that only need consistent tables take such a batch now (the seeds of every locus come back),
+    hipstr_locus_costs prices it, and tables that contradict each other (hap_off against the product of the option counts) still fail
+    the call."""
+    b = util.batch_with_an_oversized_middle_locus()
+    n_reads, n_out, out_off = capi.batch_dims(b.ptr)
+    seeds = np.full(n_reads, -9, np.int32)
+    assert hmm_host.hipstr_calc_seed_bases(b.ptr, seeds.ctypes.data_as(capi._i32p)) == 0, hmm_host.hipstr_last_error()
+    assert np.all(seeds >= 0)
+    bad = capi.Batch.__new__(capi.Batch); bad.__dict__.update(b.__dict__)
+    a = dict(b.arrays); a["hap_off"] = a["hap_off"].copy(); a["hap_off"][2:] += 5
+    from hipstr_amd import shard
+    wrong = shard.batch_from_arrays(a)
+    assert hmm_host.hipstr_calc_seed_bases(wrong.ptr, seeds.ctypes.data_as(capi._i32p)) != 0
+    assert b"hap_off does not match" in hmm_host.hipstr_last_error()

@@ -354,3 +354,17 @@ def assert_arrays_exact(got, want, run_oracle_cr, what="", tol=1e-9):
     import warnings
     warnings.warn("%s: the host libm is not correctly rounded somewhere in this case (device == oracle with correctly rounded exp/log, bit for bit)" % what)
     return False
+
+
+def batch_with_an_oversized_middle_locus(n_options=1025):
+    """Three loci; the middle one has `n_options` STR options (the library takes at most 1024 per block): a CONSISTENT table of an
+    unsupported locus — check_locus' refusal, per locus, not validate_tables' (ADVICE r05)."""
+    lf = "ACGTTGCATGCATGACCTGAGTCCATGACTTGACA"; rf = "TTGACCGTAGGCTAGGCTTAACGGATCCGATTAGC"
+    b = capi.Batch()
+    strs = ["AGAT" * 6, "AGAT" * 7, "AGAT" * 5]
+    hap = lf + strs[0] + rf
+    simple_locus(lf, strs, rf, 4, [(hap[3:83], None, 3, True), (hap[0:80], None, 0, True)], batch=b)
+    many = ["AGAT" * 6] + ["AGAT" * (2 + i % 40) + "AG" * (i // 40) for i in range(n_options - 1)]
+    simple_locus(lf, many, rf, 4, [(hap[5:85], None, 5, True)], start=900, batch=b)
+    simple_locus(lf, strs[:2], rf, 4, [(hap[6:86], None, 6, True), (hap[1:81], None, 1, True), (hap[9:89], None, 9, True)], start=1300, batch=b)
+    return b.finalize()
