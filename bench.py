@@ -36,6 +36,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SEED = 20260928      # rng = mt19937(20260928 + locus); the GPU ranks and the CPU baseline take loci of this ONE seeded set
+
 WORKLOADS = {
     # name: (loci, reads/locus, STR alleles, read length, flank length, STR bp, description)
     "ns": (1000, 500, 32, 150, 60, 40, "north-star shape of BASELINE configs[1] (SURVEY §8d NS): 1000 STR loci x 500 pooled 150bp reads x 32 candidate alleles"),
@@ -62,7 +64,7 @@ def _cpu_worker(argv):
         lib, pfx = capi.load_ref(), "ref_"
     else:
         lib, pfx = capi.load_oracle(), "oracle_"
-    sb = capi.SynthBatch(n_loci=n, reads_per_locus=P, n_str_alleles=A, read_len=L, flank_len=F, str_bp=sbp, seed=977, first_locus=first)
+    sb = capi.SynthBatch(n_loci=n, reads_per_locus=P, n_str_alleles=A, read_len=L, flank_len=F, str_bp=sbp, seed=SEED, first_locus=first)
     probs = np.zeros(sb.n_out); seeds = np.zeros(sb.n_reads, np.int32)
     t0 = time.perf_counter()
     rc = getattr(lib, pfx + "process_reads")(sb.ptr, probs.ctypes.data_as(capi._f64p), seeds.ctypes.data_as(capi._i32p))
@@ -83,11 +85,30 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(capi, wl_name, budget_s=20.0):
+def device_identity(torch, local):
+    """Where this rank's GPU sits: PCI address (hipDeviceGetPCIBusId through torch's device properties), its NUMA node from sysfs, the
+    CPUs the rank may run on."""
+    out = {"cpus_allowed": sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        out["device_name"] = pr.name
+        bus = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+        out["pci_bus_id"] = bus
+        try:
+            out["numa_node"] = int(open("/sys/bus/pci/devices/%s/numa_node" % bus).read().strip())
+        except Exception:
+            out["numa_node"] = None
+    except Exception as ex:
+        out["pci_bus_id"] = None; out["error"] = repr(ex)[:120]
+    return out
+
+
+def cpu_baseline(capi, wl_name, budget_s=20.0, n_loci=0):
     """The same hot path on the host CPU, bounded sample: (i) one core, (ii) every core — N independent processes, one per core,
     each on its own contiguous loci: the reference's documented way to use a multi-core box (README.md:167-171; it is single-threaded)."""
     import subprocess
     loci, P, A, L, F, sbp, _ = WORKLOADS[wl_name]
+    loci = n_loci or loci
     kind = "reference" if capi.have_ref() else "port"
     def run_procs(n_procs, loci_each, first0):
         t0 = time.perf_counter()
@@ -96,18 +117,31 @@ def cpu_baseline(capi, wl_name, budget_s=20.0):
         outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
         wall = time.perf_counter() - t0
         return sum(o["alignments"] for o in outs), max(o["seconds"] for o in outs), wall
+    # The sample is a slice of the SAME seeded set the GPU's step runs (seed 20260928, loci [0, loci) of rank 0 — a locus depends on
+    # (seed, index) only, so these are byte for byte loci of the timed batch: SURVEY §8(d) "identical bytes go to the CPU and the GPU").
     # one core: size the sample from a single locus
-    a1, s1, _ = run_procs(1, 1, 100000)
+    a1, s1, _ = run_procs(1, 1, 0)
     per_locus = s1
-    n1 = max(1, min(16, int(budget_s * 0.5 / max(per_locus, 1e-3))))
-    a1, s1, _ = run_procs(1, n1, 100100)
+    n1 = max(1, min(16, loci, int(budget_s * 0.5 / max(per_locus, 1e-3))))
+    first1 = min(1, max(0, loci - n1))
+    a1, s1, _ = run_procs(1, n1, first1)
     cores = usable_cores()
-    each = max(1, min(16, int(budget_s * 0.6 / max(per_locus, 1e-3))))
-    aN, sN, wallN = run_procs(cores, each, 200000)
+    each = max(1, min(16, max(1, loci // cores), int(budget_s * 0.6 / max(per_locus, 1e-3))))
+    n_procs = cores
+    firstN = max(0, min(loci - n_procs * each, first1 + n1))         # behind the one-core sample where the set is large enough
+    if n_procs * each > loci:                                        # a set with fewer loci than cores (c1): the processes share them round robin
+        firstN = 0
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", wl_name, str((firstN + i * each) % max(1, loci - each + 1)), str(each)],
+                              stdout=subprocess.PIPE, universal_newlines=True) for i in range(n_procs)]
+    outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
+    wallN = time.perf_counter() - t0
+    aN, sN = sum(o["alignments"] for o in outs), max(o["seconds"] for o in outs)
     return {"value": aN / sN, "unit": "alignments/s", "cores": cores, "kind": kind,
-            "sample": "%d processes x %d loci of the same generator/shape (%d reads x %d alleles x %dbp per locus) = %d alignments; slowest process %.1f s (wall incl. start-up %.1f s); HapAligner::process_reads only"
-                      % (cores, each, P, A, L, aN, sN, wallN),
-            "single_core": {"value": a1 / s1, "cores": 1, "sample": "%d alignments, %.1f s" % (a1, s1)},
+            "sample": "%d processes x %d loci, loci [%d, %d) of the timed batch's own seeded set (seed %d; %d reads x %d alleles x %dbp per locus) = %d alignments; slowest process %.1f s (wall incl. start-up %.1f s); HapAligner::process_reads only"
+                      % (cores, each, firstN, firstN + n_procs * each, SEED, P, A, L, aN, sN, wallN),
+            "single_core": {"value": a1 / s1, "cores": 1, "sample": "loci [%d, %d) of the same set: %d alignments, %.1f s" % (first1, first1 + n1, a1, s1)},
+            "same_bytes_as_gpu_batch": True, "seed": SEED,
             "host_cores_visible": os.cpu_count(), "host_cores_usable": cores}
 
 
@@ -383,7 +417,7 @@ def main():
     else:
         first = loci * rank
     t0 = time.perf_counter()
-    sb = capi.SynthBatch(n_loci=loci, reads_per_locus=P, n_str_alleles=A, read_len=L, flank_len=F, str_bp=sbp, seed=20260928, first_locus=first)
+    sb = capi.SynthBatch(n_loci=loci, reads_per_locus=P, n_str_alleles=A, read_len=L, flank_len=F, str_bp=sbp, seed=SEED, first_locus=first)
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
     dev = hmm.hipstr_hmm_upload(sb.ptr)
@@ -510,7 +544,7 @@ def main():
     if not os.environ.get("HIPSTR_BENCH_NOCHECK"):       # kernel ablation builds (timing only, results invalid) set this
         assert np.all(np.isfinite(probs)) and np.all(probs <= 1e-10), "forward scores must be finite log-likelihoods <= 0"
 
-    per_rank = None; e2e_multi = None; rank_info = None
+    per_rank = None; e2e_multi = None; rank_info = None; cross_check = None
     if world > 1:
         dev_t = "cpu" if share else "cuda"
         # every rank's own resident rate, and the end-to-end rate (host arrays in -> results out through the stream) of all ranks at once
@@ -529,6 +563,35 @@ def main():
             ae = torch.tensor([float(n_aln.value) * e["passes"]], dtype=torch.float64, device=dev_t); dist.all_reduce(ae, op=dist.ReduceOp.SUM)
             e2e_multi = {"alignments_per_s": float(ae.item()) / float(te.item()), "seconds_max_over_ranks": float(te.item()), "passes": e["passes"],
                          "host_threads_per_rank": int(os.environ.get("HIPSTR_HOST_THREADS", host_threads))}
+        # Self-check on first contact with a multi-GPU node: every rank's device must return, for a strided sample of
+        # ITS loci, the bits rank 0's device returns for the same loci (regenerated there from (seed, index)); a mismatch ends every rank
+        # loudly instead of printing a rate.  The devices' PCI addresses and NUMA nodes go into the line: a bad affinity shows in the first record.
+        import hashlib
+        def _dig(p_, s_):
+            return hashlib.sha256(np.ascontiguousarray(p_).tobytes() + np.ascontiguousarray(s_).tobytes()).hexdigest()
+        sample = sorted(set(int(x) for x in np.linspace(0, loci - 1, num=min(4, loci)))) if loci > 0 else []
+        mine_chk = {"rank": rank, "first_locus": int(first), "sample": sample,
+                    "digests": [_dig(probs[int(sb.out_off[l]):int(sb.out_off[l + 1])], seeds[l * P:(l + 1) * P]) for l in sample]}
+        mine_chk.update(device_identity(torch, local))
+        chk = [None] * world
+        dist.all_gather_object(chk, mine_chk)
+        verdict = [None]
+        if rank == 0:
+            bad = []
+            for c in chk:
+                if c["rank"] == 0:
+                    continue
+                for l, d in zip(c["sample"], c["digests"]):
+                    one = capi.SynthBatch(n_loci=1, reads_per_locus=P, n_str_alleles=A, read_len=L, flank_len=F, str_bp=sbp, seed=SEED, first_locus=c["first_locus"] + l)
+                    p0, s0 = capi.run_align(hmm, "hipstr_hmm_", one.ptr, fill=0.0)
+                    if _dig(p0, s0) != d:
+                        bad.append("rank %d (device %s) locus %d" % (c["rank"], c.get("pci_bus_id"), c["first_locus"] + l))
+            verdict[0] = bad
+        dist.broadcast_object_list(verdict, src=0)
+        if verdict[0]:
+            raise SystemExit("bench.py: results of " + "; ".join(verdict[0]) + " differ from rank 0's device on the same loci — no rate is reported")
+        cross_check = {"loci_per_rank": len(sample), "ranks_checked_against_rank0": world - 1, "mismatches": 0,
+                       "devices": [{k: c.get(k) for k in ("rank", "pci_bus_id", "numa_node", "device_name", "cpus_allowed")} for c in chk]}
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -555,6 +618,7 @@ def main():
                 return t, f
         return None, None
 
+    pass_traffic = {}
     STR_KERNELS = ("hs_str_", "hs_nd_")          # the STR phase: read-end sums + group kernels + per-read / generic kernels
 
     def pmc_traffic(kernel_key, n_alignments):
@@ -572,6 +636,12 @@ def main():
         if not hit:
             return None, None
         per_aln = sum(2 * v["fetch_bytes_per_launch_raw"] + v["write_bytes_per_launch_raw"] for v in hit) / t["alignments_per_launch"]
+        # the whole launch set (every kernel of a pass), raw and with the guide's FETCH x 2: the figure that stands next to the
+        # algorithmic bytes of the launch set (VERDICT r05 weak 10 iii: the per-kernel figure alone mixes scopes)
+        allk = list(t["kernels"].values())
+        raw = sum(v["fetch_bytes_per_launch_raw"] + v["write_bytes_per_launch_raw"] for v in allk) / t["alignments_per_launch"]
+        cor = sum(2 * v["fetch_bytes_per_launch_raw"] + v["write_bytes_per_launch_raw"] for v in allk) / t["alignments_per_launch"]
+        pass_traffic.update(raw=raw * n_alignments, fetch_x2=cor * n_alignments, per_alignment_raw=raw, per_alignment_fetch_x2=cor)
         return per_aln * n_alignments, os.path.basename(src)
 
     def valu_block(phase_ms_now, n_alignments):
@@ -632,10 +702,25 @@ def main():
             "loci_per_sec": total_loci * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_scope": "the dominant kernel's launches of one pass (FETCH_SIZE x 2 + WRITE_SIZE)",
+                         "traffic_pass": ({"raw": pass_traffic["raw"], "fetch_x2": pass_traffic["fetch_x2"],
+                                           "over_algorithmic_raw": pass_traffic["raw"] / max(1, algo.value), "over_algorithmic_fetch_x2": pass_traffic["fetch_x2"] / max(1, algo.value),
+                                           "bytes_per_alignment_raw": pass_traffic["per_alignment_raw"], "bytes_per_alignment_fetch_x2": pass_traffic["per_alignment_fetch_x2"],
+                                           "scope": "every kernel of the launch set, scaled to this batch by alignments"} if pass_traffic else None),
                          "pass_ms": float(phase_ms.sum()) if n_ms > 0 else None,
                          "kernel": phase_names[dom], "kernel_ms": kernel_ms,
                          "phase_ms": dict(zip(phase_names, [float(x) for x in phase_ms])), "algorithmic_bytes_per_launch": algo.value,
                          "bytes_per_alignment": algo.value / max(1, n_aln.value)},
+            # the roof that binds (an FP64 max-plus recurrence — neither HBM nor MFMA): executed FP64 wave-instructions x 64
+            # lanes / the LIVE kernel time, against 256 CU x 4 SIMD x 16 lanes x 2.4 GHz (tools/valu_microbench.hip: 4 cycles per wave64 FP64 op)
+            "roofline_fp64": ({"bound": "fp64_valu_issue", "kernel": phase_names[dom],
+                               "achieved": valu["phases"][phase_names[dom]]["fp64_ops_per_s"] / 1e12 if phase_names[dom] in valu["phases"] else None,
+                               "peak": 256 * 4 * 16 * 2.4e9 / 1e12, "unit": "T FP64 op/s",
+                               "frac": valu["phases"][phase_names[dom]]["fp64_frac_of_peak"] if phase_names[dom] in valu["phases"] else None,
+                               "pass_frac": valu["pass_fp64_frac_of_peak"],
+                               "phase_frac": {ph: v["fp64_frac_of_peak"] for ph, v in valu["phases"].items()},
+                               "phase_valu_pipe_est": {ph: v["pipe_occupancy_est"] for ph, v in valu["phases"].items()},
+                               "counters": valu["source"], "profile_matches_build": valu["profile_matches_build"]} if valu else None),
             "valu": valu,
             "host": {"synth_s": t_gen, "prepare_upload_s": t_upload, "prepare_upload_first_call_s": t_upload_cold, "fetch_s": t_fetch,
                      "value_incl_prepare_pcie": total_aln / world / (t_upload + elapsed / args.steps + t_fetch) * world},
@@ -654,6 +739,7 @@ def main():
             e2e["host_threads"] = int(os.environ.get("HIPSTR_HOST_THREADS", "0")) or usable_cores()
             out["pipeline"] = pipeline_stages(capi, hmm, sb, loci, P)
         if per_rank is not None:
+            out["cross_device_check"] = cross_check
             out["per_rank_alignments_per_s"] = per_rank
             out["ranks"] = rank_info
             out["host_threads_per_rank"] = int(os.environ.get("HIPSTR_HOST_THREADS", host_threads))
@@ -661,7 +747,7 @@ def main():
             out["end_to_end"] = e2e_multi
             out["value_end_to_end"] = e2e_multi["alignments_per_s"]
         if args.gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(capi, args.workload)
+            out["cpu_baseline"] = cpu_baseline(capi, args.workload, n_loci=loci)
         if args.workload == "c4":
             # shares of the step: the stages once more, each waited for (not part of the timed region)
             torch.cuda.synchronize(); t_a = time.perf_counter()

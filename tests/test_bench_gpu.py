@@ -38,6 +38,21 @@ def test_single_gpu_line_has_every_contract_field():
     # the counters behind the limiter and the traffic figure are the plain north-star pass', not those of an interrupted-repeat pass
     # (the summaries of those passes sit in the same directory and sort later by name)
     assert "_ns_" in d["valu"]["source"] and "_ns_" in rf["traffic_source"], (d["valu"]["source"], rf["traffic_source"])
+    # round 6: the roof that binds is in the line itself, the pass' traffic next to the launch set's algorithmic bytes
+    r64 = d["roofline_fp64"]
+    assert r64["bound"] == "fp64_valu_issue" and abs(r64["frac"] - r64["achieved"] / r64["peak"]) < 1e-9 and 0 < r64["pass_frac"] < 1
+    tp = rf["traffic_pass"]
+    assert tp["fetch_x2"] >= tp["raw"] >= rf["traffic"] * 0.5 and tp["over_algorithmic_raw"] > 1
+
+
+def test_cpu_baseline_runs_loci_of_the_timed_batch():
+    """identical bytes go to the CPU and the GPU — the baseline's processes take loci [a, b) of the batch's own seeded set."""
+    d = _bench(["--steps", "1", "--warmup", "1", "--loci", "40", "--no-pipeline"])
+    cb = d["cpu_baseline"]
+    assert cb["same_bytes_as_gpu_batch"] and cb["seed"] == 20260928 and cb["value"] > 0 and cb["single_core"]["value"] > 0
+    import re
+    lo, hi = map(int, re.search(r"loci \[(\d+), (\d+)\)", cb["sample"]).groups())
+    assert 0 <= lo < hi <= 40
 
 
 def test_two_ranks_weak_and_strong():
@@ -50,6 +65,10 @@ def test_two_ranks_weak_and_strong():
     # alignments per step over all ranks: value x seconds per step
     tot = lambda d: d["value"] * d["ms_per_step"] * 1e-3
     assert abs(tot(strong) - a1) < 1e-6 * a1                  # the same 16 loci, split
+    # round 6: every rank's sample of results was compared with rank 0's device on the same loci; the devices are named
+    for d in (weak, strong):
+        cc = d["cross_device_check"]
+        assert cc["mismatches"] == 0 and cc["ranks_checked_against_rank0"] == 1 and len(cc["devices"]) == 2 and cc["devices"][1]["pci_bus_id"]
     assert tot(weak) > 1.7 * a1                               # 32 different loci
 
 
