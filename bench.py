@@ -269,6 +269,24 @@ def c3_em_inputs(sb, loci, P, S):
                 num_bps=size.ravel().astype(np.int32), log_p1=np.zeros(loci * P), log_p2=np.zeros(loci * P), haploid=np.zeros(loci, np.uint8))
 
 
+def thread_cpu_seconds():
+    """CPU seconds (user + system) of every thread of this process by thread id, with its name: /proc/self/task/<tid>/stat."""
+    out = {}
+    tck = os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                st = open("/proc/self/task/%s/stat" % tid).read()
+                name = st[st.index("(") + 1:st.rindex(")")]
+                f = st[st.rindex(")") + 2:].split()
+                out[int(tid)] = (name, (int(f[11]) + int(f[12])) / tck)
+            except Exception:
+                pass
+    except Exception:
+        pass
+    return out
+
+
 def end_to_end(capi, hmm, sb, loci, steps, device, latency=True):
     """SURVEY §8(d)'s metric taken literally — wall time from host arrays in to aln_probs/seeds out (host flatten, H2D, kernels, D2H,
     the reference's output contract) — through the streaming C-ABI, fed the way the reference's caller produces work: ONE locus per
@@ -309,11 +327,13 @@ def end_to_end(capi, hmm, sb, loci, steps, device, latency=True):
     for attempt in range(3):
         s0 = st.stats()
         a_timed0 = hmm.hipstr_debug_driver_allocs()
+        tc0 = thread_cpu_seconds()
         c0 = time.process_time()
         t0 = time.perf_counter()
         one_pass_set(steps)
         dt = time.perf_counter() - t0
         cpu_s = time.process_time() - c0              # CPU seconds of ALL threads of the process over the timed passes
+        tc1 = thread_cpu_seconds()
         s1 = st.stats()
         if hmm.hipstr_debug_driver_allocs() == a_timed0:
             break
@@ -334,6 +354,8 @@ def end_to_end(capi, hmm, sb, loci, steps, device, latency=True):
             "collector_wait_seconds": s1["wait_seconds"] - s0["wait_seconds"],
             "process_cpu_seconds": cpu_s, "process_cpu_ms_per_pass": 1e3 * cpu_s / steps, "process_cpu_us_per_locus": 1e6 * cpu_s / (steps * loci),
             "cpu_seconds_by_role": {k[4:-8]: s1[k] - s0[k] for k in ("cpu_submit_seconds", "cpu_prepare_seconds", "cpu_upload_seconds", "cpu_collect_seconds")},
+            # the threads that used the most CPU over the timed passes (10 ms clock ticks; name = the thread's comm; threads that ended meanwhile — the feeder — are missing)
+            "cpu_seconds_by_thread": sorted(([tc1[t][0], round(tc1[t][1] - tc0.get(t, (None, 0.0))[1], 3)] for t in tc1), key=lambda x: -x[1])[:8],
             "warmup_passes": warm, "timed_attempts": attempt + 1, "driver_allocs_during_timed_passes": int(hmm.hipstr_debug_driver_allocs() - a_timed0),
             "one_locus_process_reads_latency": lat,
             "path": "hipstr_stream_submit_each (1 locus per submission) -> batches of 2-8 Mi alignments (the library's choice by loci per batch and host threads) -> prepare on host threads + H2D + table expansion + kernels + D2H, 8 slots -> hipstr_stream_collect in order"}

@@ -558,7 +558,6 @@ def load_hmm():
     _sig(lib.hipstr_debug_cache_put, None, [C.c_void_p])
     _sig(lib.hipstr_debug_cache_stats, C.c_int, [C.POINTER(C.c_int64)])
     _sig(lib.hipstr_debug_allele_kinds, C.c_int, [C.c_void_p, C.POINTER(C.c_int64)])
-    _sig(lib.hipstr_debug_fused_loci, C.c_int, [C.c_void_p, C.POINTER(C.c_int64)])
     _sig(lib.hipstr_debug_stream_create, C.c_void_p, [])
     _sig(lib.hipstr_debug_stream_destroy, None, [C.c_void_p])
     _sig(lib.hipstr_debug_fetch_table, C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64])

@@ -29,7 +29,7 @@
 
 extern "C" __global__ void hs_str_kernel(const hs_dev_t* dp, int active_begin, int only_long);
 extern "C" __global__ void hs_str_kernel_generic(const hs_dev_t* dp, int active_begin, int pw_grouped);
-extern "C" __global__ void hs_combine_kernel(const hs_dev_t* dp, int active_begin, int skip_fused);
+extern "C" __global__ void hs_combine_kernel(const hs_dev_t* dp, int active_begin);
 extern "C" int hs_combine_waves();
 extern "C" __global__ void hs_posterior_kernel(const hs_post_dev_t* dp);
 extern "C" __global__ void hs_posterior_accumulate_kernel(const hs_post_dev_t* dp);
@@ -47,8 +47,7 @@ extern "C" __global__ void hs_expand_recs_kernel(const hs_dev_t* dp);
 extern "C" size_t hs_str_group_lds_bytes(int max_B, int nd_cap, int with_ilog);
 extern "C" size_t hs_str_group_p_lds_bytes();
 extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int active_begin, int item_begin, int item_end, int chunk, int max_cols, int n_clear);
-extern "C" int hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk, int max_cols, int max_rows,
-                               int n_fused_items, int n_plain_items);
+extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk, int max_cols, int max_rows);
 
 namespace {
 
@@ -162,18 +161,26 @@ struct BlockCache {
       if (in_use > 0) in_use--;
       if (Chunk* c = chunk_of(p)) if (c->live > 0) c->live--;
       over = cap && cached > cap;
+      if (over){                                   // (nothing to give back while every chunk has a block out: no second pass over the lists)
+        over = false;
+        for (const Chunk& c : chunks) if (c.live == 0){ over = true; break; }
+      }
     }
-    // more idle bytes than the cap allows (HIPSTR_DEV_CACHE_GIB / HIPSTR_PIN_CACHE_GIB): the chunks nobody uses go back to the driver
-    if (over){ g.unlock(); trim(); }
+    // more idle bytes than the cap allows (HIPSTR_DEV_CACHE_GIB / HIPSTR_PIN_CACHE_GIB): chunks nobody uses go back to the driver — down to
+    // a low-water mark of 0.8 x cap, not all of them: a stream that sits near the cap would otherwise alternate a hipFree here (it
+    // synchronises the device) with a hipMalloc at its next get(), the stall the cache exists to avoid
+    if (over){ g.unlock(); trim(cap - cap/5); }
   }
   // chunks none of whose blocks is out go back to the driver (hipstr_hmm_trim: after a stream of large batches a process may sit on tens
   // of gigabytes it no longer needs — another process on the device, a child of this one, then fails its kernel launches with "out of
   // memory"); returns the bytes released
-  size_t trim(){
+  // keep_idle: stop once the idle bytes are down to this (0: every chunk without a block out, hipstr_hmm_trim's meaning)
+  size_t trim(size_t keep_idle = 0){
     std::vector<Chunk> gone; size_t bytes = 0;
     {
       std::lock_guard<std::mutex> g(m);
       for (size_t i = 0; i < chunks.size(); ){
+        if (keep_idle && cached <= keep_idle) break;
         if (chunks[i].live != 0){ i++; continue; }
         const Chunk c = chunks[i];
         for (auto it = free_.begin(); it != free_.end(); ){
@@ -367,7 +374,6 @@ struct hipstr_dev_batch {
   hs_dev_t* d_args = NULL;
   std::vector<void*> dev_blocks, pin_blocks;      // from the context's caches
   int grid_y = 1, max_alleles = 1, n_lead_items = 0, n_trail_items = 0, trail_waves = 1;
-  int n_fused = 0;               // loci whose trailing flanks and compute_aln_logprob run as one item (hs_locus_t::fused)
   int max_rows = 0;              // longest flank rowset of the batch (rows of a flank block): picks the band shape of the trailing-flank sweep
   size_t grp_lds_bytes = 0, grp_pw_lds_bytes = 0;
   bool any_pw = false;           // some locus has alleles with piecewise simple lists (hs_str_group_kernel_pw)
@@ -376,6 +382,7 @@ struct hipstr_dev_batch {
   size_t lds_bytes = 0;
   hipEvent_t ev0 = NULL, ev1 = NULL;
   hipEvent_t ev_expand = NULL;            // the device-built tables are ready (recorded on the thread's aux stream; the first pass waits for it before the STR-block kernels)
+  hipStream_t aux_pw_stream = NULL;      // the side stream a pass launched the interrupted alleles' kernels on (joined back by an event; hipstr_hmm_free waits for it all the same)
   hipStream_t aux_stream = NULL; bool expand_joined = false; hipStream_t expand_joined_on = NULL;      // (the stream whose first pass waited for ev_expand)
   hipEvent_t ev_h2d = NULL, ev_done = NULL, ev_d2h = NULL;     // upload finished / last pass finished / results in host_out (pipelined use)
   hipStream_t stream = NULL;                // launches, copies and waits of this batch default to it (the creating thread's stream)
@@ -457,6 +464,7 @@ void hipstr_hmm_free(hipstr_dev_batch_t* dev){
       if (dev->h2d_stream && dev->h2d_stream != dev->stream) hipStreamSynchronize(dev->h2d_stream);
       if (dev->d2h_stream && dev->d2h_stream != dev->stream) hipStreamSynchronize(dev->d2h_stream);
       if (dev->ev_expand) hipStreamSynchronize(dev->aux_stream);       // (a batch that was never aligned)
+      if (dev->aux_pw_stream && hipStreamQuery(dev->aux_pw_stream) != hipSuccess) hipStreamSynchronize(dev->aux_pw_stream); // (a pass ran the interrupted alleles' kernels on the aligning thread's side stream)
     }
     for (void* p : dev->dev_blocks) dev->ctx->dev_cache.put(p);
     for (void* p : dev->pin_blocks) dev->ctx->pin_cache.put(p);
@@ -605,11 +613,7 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   dev->max_rows = 0;
   for (const hs_rowset_t& rs : P.rowsets) dev->max_rows = std::max(dev->max_rows, (int)rs.len);
   h.ws_band = (double*)dalloc(sizeof(double)*(size_t)dev->trail_waves*h.band_cols*64*2);
-  // fused items: per workgroup of hs_trail_kernel_coop (its grids are at most 1024 workgroups) [lt_stride of the fused loci][64 lanes] last columns
-  dev->n_fused = 0; h.lts_rows = 1;
-  for (const hs_locus_t& lc : P.loci) if (lc.fused){ dev->n_fused++; h.lts_rows = std::max(h.lts_rows, lc.lt_stride); }
-  h.ws_lts = dev->n_fused ? (double*)dalloc(sizeof(double)*(size_t)std::min(dev->trail_waves, 1024)*h.lts_rows*64) : NULL;
-  if (dev->n_fused && !h.ws_lts){ hipstr_hmm_free(dev); return NULL; }
+  h.lts_rows = 1; h.ws_lts = NULL;          // (fields of the removed fused trailing-flank item: the argument block keeps its layout)
   h.n_active = (int32_t)P.active.size();
   // [n_active] re-do flags of hs_str_kernel | [2 x chunks] work counters of hs_lead_kernel and hs_trail_kernel
   h.redo = (int32_t*)dalloc(sizeof(int32_t)*((size_t)h.n_active + 2*P.chunks.size() + 2));
@@ -826,7 +830,7 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
         if (ev_pw){      // (back to the pool once its wait is queued: the next user records it again)
           const bool ok = hipEventRecord(ev_fork, st) == hipSuccess && hipStreamWaitEvent(st_pw, ev_fork, 0) == hipSuccess;
           dev->ctx->put_event(ev_fork, false);
-          if (!ok){ dev->ctx->put_event(ev_pw, false); return fail("hipEventRecord / hipStreamWaitEvent failed"); }
+          if (!ok){ dev->ctx->put_event(ev_pw, false); return fail("hipEventRecord / hipStreamWaitEvent failed"); }      // (nothing launched on the side stream yet)
         }
         if (group_p) hipLaunchKernelGGL(hs_str_group_kernel_p, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), hs_str_group_p_lds_bytes(), st, dp,
                                         dev->n_lead_items + dev->n_trail_items + ch.str_begin);
@@ -840,22 +844,25 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
       if (dev->any_rp && ch.str_end > ch.str_begin)       // three and more interruptions: lists without a closed form, replayed in the grouped layout
         hipLaunchKernelGGL(hs_str_group_kernel_rp, dim3(ch.str_end - ch.str_begin, dev->grid_y), dim3(HS_GRP_COLS), dev->grp_pw_lds_bytes, st_pw, dp,
                            dev->n_lead_items + dev->n_trail_items + ch.str_begin);
-      if (ev_pw){ HS_HIP(hipEventRecord(ev_pw, st_pw)); HS_HIP(hipStreamWaitEvent(st, ev_pw, 0)); dev->ctx->put_event(ev_pw, false); }
+      if (ev_pw){
+        // the join: whatever happens the event goes back to the pool, and a join that could not be queued waits for the side stream here —
+        // its kernels read and write this batch's blocks, which the caller is about to return to the cache
+        dev->aux_pw_stream = st_pw;
+        const bool ok = hipEventRecord(ev_pw, st_pw) == hipSuccess && hipStreamWaitEvent(st, ev_pw, 0) == hipSuccess;
+        dev->ctx->put_event(ev_pw, false);
+        if (!ok){ hipStreamSynchronize(st_pw); return fail("hipEventRecord / hipStreamWaitEvent failed (side stream of the interrupted alleles' kernels)"); }
+      }
       if (ch.n_long_sides > 0)        // sides with more columns than a group holds: one workgroup per read as before
         hipLaunchKernelGGL(hs_str_kernel, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin, 1);
     }
     // alleles without a tabulated closed form (interrupted repeats, very long blocks) and whatever hs_str_kernel marked HS_REDO
     hipLaunchKernelGGL(hs_str_kernel_generic, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin, str_group ? 1 : 0);
     if (mark()) return 1;
-    int fused_done = 0;
     if (ch.trail_end > ch.trail_begin)     // trailing flanks: persistent wavefronts striding over (read side, allele group) items
-      fused_done = hs_launch_trail((unsigned)std::min(dev->trail_waves, ch.trail_end - ch.trail_begin), st, dp,
-                                   dev->n_lead_items + ch.trail_begin, dev->n_lead_items + ch.trail_end, 2*chunk_no + 1, dev->h.band_cols, dev->max_rows,
-                                   ch.n_fused_items, ch.trail_end - ch.trail_begin - ch.n_fused_items);
+      hs_launch_trail((unsigned)std::min(dev->trail_waves, ch.trail_end - ch.trail_begin), st, dp,
+                      dev->n_lead_items + ch.trail_begin, dev->n_lead_items + ch.trail_end, 2*chunk_no + 1, dev->h.band_cols, dev->max_rows);
     if (mark()) return 1;
-    // compute_aln_logprob: fused loci got theirs inside the trailing-flank kernel; a batch of fused loci only skips the launch
-    if (!(fused_done && dev->n_fused == (int)dev->prep.loci.size()))
-      hipLaunchKernelGGL(hs_combine_kernel, dim3(nact), dim3(64*hs_combine_waves()), 0, st, dp, ch.active_begin, fused_done && dev->n_fused > 0 ? 1 : 0);
+    hipLaunchKernelGGL(hs_combine_kernel, dim3(nact), dim3(64*hs_combine_waves()), 0, st, dp, ch.active_begin);       // compute_aln_logprob
     if (mark()) return 1;
     HS_HIP(hipGetLastError());
     chunk_no++;
@@ -1032,14 +1039,6 @@ int hipstr_debug_allele_kinds(hipstr_dev_batch_t* dev, int64_t counts[4]){
   const hipstr::Prepared& P = dev->prep;
   for (const hs_allele_t& al : P.alleles)
     if (al.realign) for (int side = 0; side < 2; side++){ const int k = P.stropts[al.str_opt[side]].kind; if (k >= 0 && k <= 3) counts[k]++; }
-  return 0;
-}
-
-// Diagnostics (tests): out[0] = loci of the batch whose trailing flanks and compute_aln_logprob run as one item (hs_locus_t::fused; opt-in:
-// HIPSTR_TRAIL_FUSED=1), out[1] = all its loci
-int hipstr_debug_fused_loci(hipstr_dev_batch_t* dev, int64_t out[2]){
-  if (!dev || !out) return fail("null argument");
-  out[0] = dev->n_fused; out[1] = (int64_t)dev->prep.loci.size();
   return 0;
 }
 

@@ -402,12 +402,46 @@ __device__ __forceinline__ double eload(uint32_t addr){
 }
 template <int CNT> __device__ __forceinline__ void ewait(double& e, hs_d2v& q){ asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(e), "+v"(q) : "n"(CNT)); }
 template <int CNT> __device__ __forceinline__ void ewait1(double& e){ asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(e) : "n"(CNT)); }
-template <int NR, bool FIRST, bool LAST, bool LEAD, bool EL, int LTS = 1>
+// Hand-over between the band wavefronts of a workgroup (round 6).  Until round 5 the four wavefronts met at an s_barrier after every read
+// column — 78 barriers per item, each waiting for the slowest of four wavefronts that share their SIMDs with two other workgroups: a fifth
+// of the wavefronts' cycles (SQ_WAIT_INST_ANY 0.26, VALU pipe 0.79 with 12 of 14.5 instructions per cell FP64).  Now a band publishes the
+// number of columns it has finished in an LDS word (prog[w]) after storing the column's boundary (M, D) pairs into a ring of HS_RING
+// columns, and waits only for what it needs: its upper neighbour to have finished the column it is about to start, and its lower neighbour
+// to have consumed the ring slot it is about to overwrite (HS_RING columns back).  LDS operations of a wavefront execute in order and the
+// LDS has no cache: a wavefront that sees the counter sees the boundary values stored before it.  A band runs ahead of the band below it
+// by up to HS_RING columns; nothing else synchronises inside an item.  Same cells, same operations: bit-identical.
+#ifndef HS_BAND_REM_LAST
+#define HS_BAND_REM_LAST 0
+#endif
+#ifndef HS_RING
+#define HS_RING 8        // columns of boundary values a band may be ahead of the band below it (power of two)
+#endif
+typedef __attribute__((address_space(3))) int* hs_lds_i;
+#ifdef HS_FTIME      // timing experiment: cycles a band wavefront spends waiting for its neighbours / sweeping / between items, printed by a few workgroups
+__device__ unsigned long long g_ft[1024][8][6];
+#define HS_FT_ADD(k, v) do { if (lane == 0) g_ft[blockIdx.x & 1023][w][k] += (v); } while (0)
+#define HS_FT_NOW() __builtin_amdgcn_s_memtime()
+#else
+#define HS_FT_ADD(k, v) do {} while (0)
+#define HS_FT_NOW() 0ull
+#endif
+// (the counters' addresses and values are wave-uniform: they stay in scalar registers and pass through short-lived vector registers inside
+// the statement — the sweep has none to spare: 15 rows x (M, I, D) + constants fill the 168 a wavefront may have at three per SIMD)
+__device__ __forceinline__ int prog_read(uint32_t addr_uniform){
+  int v;
+  asm volatile("v_mov_b32 %0, %1\n\tds_read_b32 %0, %0\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "s"(addr_uniform) : "memory");
+  return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ void prog_write(uint32_t addr_uniform, int v_uniform){        // (every lane stores the same word: no exec juggling)
+  int t0, t1;
+  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3\n\tds_write_b32 %0, %1" : "=&v"(t0), "=&v"(t1) : "s"(addr_uniform), "s"(v_uniform) : "memory");
+}
+template <int NR, bool FIRST, bool LAST, bool LEAD, bool EL>
 __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, bool live, int n, int nmax, const double* __restrict__ col,
                                                 const hs_row_t* __restrict__ rows, int row0, int c0, const double* __restrict__ mr,
                                                 double* __restrict__ bnd, bool topg, bool botg, hs_lds_cd2 lds_top, hs_lds_d2 lds_bot,
                                                 double* __restrict__ lt, double* __restrict__ rowp, double* __restrict__ side_out,
-                                                int skew, int nsteps, hs_lds_d2 ktab, hs_lds_d2 etab, int npad){
+                                                int w, hs_lds_i prog, int base, hs_lds_d2 ktab, hs_lds_d2 etab, int npad){
   static_assert(!EL || (HS_COOP_LDS_CONSTS != 0 && !LEAD), "the emission table rides on the constants' request pipeline");
   constexpr bool KL = HS_COOP_LDS_CONSTS != 0;
   int hc[NR]; double m2m[KL ? 1 : NR], m2i[KL ? 1 : NR];
@@ -445,15 +479,27 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
   if (EL){ e_write(0, nx_rd, nx_blc, nx_blw); wave_lds_sync(); }
   double diagM = 0, diagD = 0;
   double pre = 0.0;                              // LEAD: left_prob, a strictly sequential sum in the reference
-  for (int t = 0; t < nsteps; t++){
-    const int j = t - skew;
-    if (j >= 0 && j < nmax){
+  const uint32_t a_me = (uint32_t)uni((int)(uintptr_t)(prog + w)), a_top = (uint32_t)uni((int)(uintptr_t)(prog + (w > 0 ? w - 1 : 0))), a_bot = (uint32_t)uni((int)(uintptr_t)(prog + w + 1));
+  // base: the columns this workgroup's bands had finished before this sweep — the counters are never reset where sweeps follow each other
+  // without a barrier (hs_trail_kernel_coop); a column's number, its ring slot and the values waited for are base + j
+  int top_seen = 0, bot_seen = 0;                // columns the upper / the lower neighbour is known to have finished
+  const unsigned long long t_sweep0_ = HS_FT_NOW();
+#pragma unroll 1       // (left to itself the compiler peels and unrolls the column loop: 2000 scratch operations in a kernel that has 168 registers and needs them all)
+  for (int j = 0; j < nmax; j++){
+    {
       const double blcj = nx_blc, blwj = nx_blw; const int rdj = (int)nx_rd;
       const double cur_mr = nx_mr;
       double2 cur_b = make_double2(0.0, 0.0);
       if (!FIRST){
         if (topg) cur_b = *(const double2*)(bnd + ((size_t)j*64 + lane)*2);
-        else { const int e = 2*((j & 1)*64 + lane); cur_b = make_double2(lds_top[e], lds_top[e + 1]); }
+        else {
+          if (top_seen <= base + j){
+            const unsigned long long t0_ = HS_FT_NOW(); int spins_ = 0;
+            while ((top_seen = prog_read(a_top)) <= base + j){ __builtin_amdgcn_s_sleep(1); spins_++; }
+            HS_FT_ADD(0, HS_FT_NOW() - t0_); if (spins_) HS_FT_ADD(4, 1);
+          }
+          const int e = 2*(((base + j) & (HS_RING - 1))*64 + lane); cur_b = make_double2(lds_top[e], lds_top[e + 1]);
+        }
       }
       {
         const int jn = min(j + 1, n - 1);           // a lane past its own read end keeps re-reading its last column
@@ -537,107 +583,210 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
       }
       if (!LAST){
         if (botg) *(double2*)(bnd + ((size_t)j*64 + lane)*2) = make_double2(upM, upD);
-        else { const int e = 2*((j & 1)*64 + lane); lds_bot[e] = upM; lds_bot[e + 1] = upD; }
+        else {
+          if (base + j - bot_seen >= HS_RING){
+            const unsigned long long t0_ = HS_FT_NOW(); int spins_ = 0;
+            while (base + j - (bot_seen = prog_read(a_bot)) >= HS_RING){ __builtin_amdgcn_s_sleep(1); spins_++; }
+            HS_FT_ADD(1, HS_FT_NOW() - t0_); if (spins_) HS_FT_ADD(5, 1);
+          }
+          const int e = 2*(((base + j) & (HS_RING - 1))*64 + lane); lds_bot[e] = upM; lds_bot[e + 1] = upD;
+        }
       } else if (LEAD){ if (j < n && live) rowp[j] = upM; }
+      // this column is done: its boundary (if a band below reads it from the ring) is stored, and the ring slot the band above filled for it
+      // has been read — both in front of the counter's store, and a wavefront's LDS operations execute in order
+      if (!(FIRST && LAST)){ asm volatile("" ::: "memory"); prog_write(a_me, base + j + 1); }
       if (EL) e_write((j + 1) & 1, nx_rd, nx_blc, nx_blw);       // the next column's emissions (its values were requested at the top of this one)
       diagM = topM; diagD = topD;                // top boundary of this column = diagonal of the band's first row next column
       if (j == n-1 && live){
-        double* ltp = lt;
-        // (LTS = 64: a fused item's [row][lane] scratch.  The opaque copy keeps the row addresses out of the column loop's registers: formed here, once)
-        if (LTS != 1){ ltp += (size_t)row0*LTS; asm volatile("" : "+v"(ltp)); }
 #pragma unroll
-        for (int r = 0; r < NR; r++) ltp[LTS != 1 ? (size_t)r*LTS : (size_t)(row0 + r)] = Mp[r];           // last read column of this lane's read
+        for (int r = 0; r < NR; r++) lt[row0 + r] = Mp[r];           // last read column of this lane's read
       }
     }
-    coop_barrier(botg);
   }
+  HS_FT_ADD(2, HS_FT_NOW() - t_sweep0_); HS_FT_ADD(3, (unsigned long long)nmax);
 }
 
-template <int NR, bool LEAD, bool EL, int LTS = 1>
+template <int NR, bool LEAD, bool EL>
 __device__ __forceinline__ void band_dispatch_coop(bool first, bool last, const hs_dev_t& d, int lane, bool live, int n, int nmax, const double* col,
                                                    const hs_row_t* rows, int row0, int c0, const double* mr, double* bnd, bool topg, bool botg,
-                                                   hs_lds_cd2 lds_top, hs_lds_d2 lds_bot, double* lt, double* rowp, double* side_out, int skew, int nsteps, hs_lds_d2 ktab,
+                                                   hs_lds_cd2 lds_top, hs_lds_d2 lds_bot, double* lt, double* rowp, double* side_out, int w, hs_lds_i prog, int base, hs_lds_d2 ktab,
                                                    hs_lds_d2 etab, int npad){
-  if (first){ if (last) band_sweep_coop<NR, true, true, LEAD, EL, LTS>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps, ktab, etab, npad);
-              else      band_sweep_coop<NR, true, false, LEAD, EL, LTS>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps, ktab, etab, npad); }
-  else      { if (last) band_sweep_coop<NR, false, true, LEAD, EL, LTS>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps, ktab, etab, npad);
-              else      band_sweep_coop<NR, false, false, LEAD, EL, LTS>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, skew, nsteps, ktab, etab, npad); }
+  if (first){ if (last) band_sweep_coop<NR, true, true, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, ktab, etab, npad);
+              else      band_sweep_coop<NR, true, false, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, ktab, etab, npad); }
+  else      { if (last) band_sweep_coop<NR, false, true, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, ktab, etab, npad);
+              else      band_sweep_coop<NR, false, false, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, ktab, etab, npad); }
 }
 
-// The rounds of one item: `n_rows` haplotype rows (after the block's first row) cut into bands, HS_COOP_WAVES bands per round, one per wavefront.
-template <int R, int W, bool LEAD, bool EL = false, int LTS = 1>
+// The rounds of one item: `n_rows` haplotype rows (after the block's first row) cut into bands, W bands per round, one per wavefront.
+// prog: the bands' column counters (above).  Two regimes:
+//   * gcol == NULL (leading flanks): the counters are zero when the item starts — the caller clears them between the two barriers of its
+//     item fetch — and are cleared again between the rounds of a flank deeper than one round holds;
+//   * gcol != NULL (trailing flanks): the counters count the columns of every sweep the workgroup has run (*gcol, the same number in every
+//     wavefront); nothing is cleared, a wavefront sets its counter to the new total after every round whether it had a band or not, and
+//     consecutive items need no barrier between them.
+// Between rounds the last band hands its boundary to the next round's first band through the workgroup's HBM scratch, as before: stores
+// drained, then the barrier (every wavefront of the workgroup passes the same number of barriers per item).
+template <int R, int W, bool LEAD, bool EL = false>
 __device__ __forceinline__ void coop_rounds(const hs_dev_t& d, int w, int lane, bool live, int n, int nmax, const double* col, const hs_row_t* rows, int n_rows, int c0,
-                                            const double* mr, double* bnd, double2 (*ring)[2*64], double* lt, double* rowp, double* side_out, double2 (*ktabs)[24], double (*etabs)[128] = NULL, int npad = 64){
+                                            const double* mr, double* bnd, double2 (*ring)[HS_RING*64], int* prog_s, int* gcol, double* lt, double* rowp, double* side_out, double2 (*ktabs)[24], double (*etabs)[128] = NULL, int npad = 64){
   // as many bands as there are wavefronts whenever the rows allow it (all wavefronts busy), more rounds only for blocks deeper than one round holds
   const int rounds = (n_rows + R*W - 1) / (R*W);
   const int nbands = min(n_rows, rounds*W);
   const int nr_base = n_rows / nbands, nr_rem = n_rows - nr_base*nbands;
+  hs_lds_i prog = (hs_lds_i)prog_s;
   for (int g = 0; g < rounds; g++){
+    if (g > 0){
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the boundary the previous round's last band stored for this round's first
+      __syncthreads();
+      if (!gcol){ if (lane == 0) prog_s[w] = 0; __syncthreads(); }
+    }
+    const int base = gcol ? *gcol : 0;
     const int nb_round = min(W, nbands - g*W);
-    const int nsteps = nmax + nb_round - 1;
     const int b = g*W + w;
     if (w < nb_round){
+#if HS_BAND_REM_LAST
+      const int nr = nr_base + (b >= nbands - nr_rem ? 1 : 0);           // the bands that take a row more are the LAST ones
+      const int row0 = 1 + b*nr_base + max(0, b - (nbands - nr_rem));
+#else
       const int nr = nr_base + (b < nr_rem ? 1 : 0);
       const int row0 = 1 + b*nr_base + min(b, nr_rem);
+#endif
       const bool first = (b == 0), last = (b + 1 == nbands);
       const bool topg = (w == 0) && (g > 0), botg = (w + 1 == nb_round) && !last;
       hs_lds_cd2 lds_top = (hs_lds_cd2)ring[w > 0 ? w - 1 : 0]; hs_lds_d2 lds_bot = (hs_lds_d2)ring[w];
       hs_lds_d2 ktab = (hs_lds_d2)ktabs[w];
       hs_lds_d2 etab = EL ? (hs_lds_d2)etabs[w] : (hs_lds_d2)ktabs[w];
       switch (nr){
-#define HS_COOP_CASE(N_) case N_: if (N_ <= R) band_dispatch_coop<(N_ <= R ? N_ : 1), LEAD, EL, LTS>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, nsteps, ktab, etab, npad); break;
+#define HS_COOP_CASE(N_) case N_: if (N_ <= R) band_dispatch_coop<(N_ <= R ? N_ : 1), LEAD, EL>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, ktab, etab, npad); break;
         HS_COOP_CASE(1) HS_COOP_CASE(2) HS_COOP_CASE(3) HS_COOP_CASE(4) HS_COOP_CASE(5) HS_COOP_CASE(6) HS_COOP_CASE(7) HS_COOP_CASE(8)
         HS_COOP_CASE(9) HS_COOP_CASE(10) HS_COOP_CASE(11) HS_COOP_CASE(12) HS_COOP_CASE(13) HS_COOP_CASE(14) HS_COOP_CASE(15) HS_COOP_CASE(16)
         HS_COOP_CASE(17) HS_COOP_CASE(18) HS_COOP_CASE(19) HS_COOP_CASE(20)
 #undef HS_COOP_CASE
-        default: for (int t = 0; t < nsteps; t++) coop_barrier(false); break;
+        default: break;
       }
-    } else for (int t = 0; t < nsteps; t++) coop_barrier(false);       // a wavefront without a band in this round keeps the step count
+    }
+    if (gcol){
+      *gcol = base + nmax;
+      asm volatile("" ::: "memory");
+      prog_write((uint32_t)uni((int)(uintptr_t)(prog + w)), base + nmax);      // (also by a wavefront without a band: its neighbours' later waits count from here)
+    }
   }
 }
 
+// Trailing flanks, round 6: the workgroup STREAMS through its items.  Until round 5 an item was fetched behind a workgroup barrier, every
+// wavefront walked the item's chain of dependent loads (item -> group -> read -> locus -> workspace -> allele -> rowset: ~9 columns' worth
+// of latency per 75-column item) and the four-band pipeline filled and drained around each item (tools: HS_FTIME build, profiles/r06_notes.md:
+// 14 % of the first band's cycles outside its sweeps, 13 % of the last band's waiting for the band above).  Now
+//   * the LAST wavefront of the workgroup — the one that waits for the pipeline to fill anyway — takes the next item from the chunk's
+//     counter and walks its loads while the bands above it are already sweeping the current one; what an item's sweeps need goes into one of
+//     two LDS records (uniform words + per-lane n and the three workspace offsets), published by a counter (s_q[0]);
+//   * every wavefront reads the record of item k when it gets there, sweeps, and goes on to item k + 1 without a barrier: the bands' column
+//     counters count through the items (coop_rounds, gcol), so the first band starts the next item while the last is still three columns
+//     behind in this one — the pipeline never drains.
+// The only barriers left are those between the rounds of a flank deeper than one round (HBM hand-over), passed by every wavefront alike.
+// Same cells, same operations, same order per cell: bit-identical.
+struct TrailRec {          // what the sweeps of one item need; uniform words first
+  int item_ok;             // 0: past the last item (the stream ends)
+  int n_rows;              // rows after the block's first row (0: the single "must be followed by a match" row, HapAligner.cpp:130-139)
+  int nmax, npad, nreads, nm, el_ok, c0, rs_off, pad;
+  int n[64];
+  long long col[64], mr[64], lt[64];
+};
 template <int R, int W, int OCC>
 __global__ void __launch_bounds__(64*W, OCC) hs_trail_kernel_coop(const hs_dev_t* __restrict__ dp, int item_begin, int item_end, int chunk){
   const hs_dev_t& d = *dp;
   const int lane = threadIdx.x & 63, w = uni((int)(threadIdx.x >> 6));
-  __shared__ double2 ring[W][2*64];
+  __shared__ double2 ring[W][HS_RING*64];
+  __shared__ int s_prog[W + 1];             // columns finished per band wavefront (band_sweep_coop); [W]: never written, the last band's lower neighbour
+  __shared__ int s_q[2 + W];                // [0] records published; [2 + w] items whose record wavefront w has read
   __shared__ double2 ktabs[W][24];          // per wavefront: (m2m, m2i) of its band's rows (HS_COOP_LDS_CONSTS)
   __shared__ double etabs[W][128];          // per wavefront: emissions of the current and the next column per (read, base code)
-  __shared__ int s_item;
+  __shared__ TrailRec s_rec[2];
   double* const bnd = d.ws_band + (size_t)blockIdx.x * d.band_cols * 64 * 2;
   int32_t* const ctr = d.redo + d.n_active + chunk;
-  for (;;){
-    if (threadIdx.x == 0) s_item = atomicAdd(ctr, 1);
-    __syncthreads();
-    const int item = item_begin + uni(s_item);
-    __syncthreads();
-    if (item >= item_end) break;
-    const hs_item_t* it = d.items + item;
-    const int side = uni(it->side), nreads = uni(it->rowset);
-    if (side == 2) continue;                                  // a fused item: hs_trail_fused_coop's
-    const hs_tgroup_t* g = d.tgroups + uni(it->slot);
-    const int nm = uni(g->n_members);
-    int npad = 1; while (npad < nm) npad <<= 1;
+#ifdef HS_FTIME
+  if (lane == 0) for (int k = 0; k < 6; k++) g_ft[blockIdx.x & 1023][w][k] = 0;
+  const unsigned long long t_k0_ = HS_FT_NOW(); int n_items_ = 0;
+#endif
+  const uint32_t a_q = (uint32_t)uni((int)(uintptr_t)(__attribute__((address_space(3))) int*)&s_q[0]);
+  // The record of the k-th item of this workgroup, written by the last wavefront (all 64 lanes: lane = the sweep's lane)
+  auto prefetch = [&](int k){
+    TrailRec& rc = s_rec[k & 1];
+    int it_i = 0;
+    if (lane == 0) it_i = atomicAdd(ctr, 1);
+    const int item = item_begin + uni(it_i);
+    if (item >= item_end){ if (lane == 0) rc.item_ok = 0; }
+    else {
+      const hs_item_t* it = d.items + item;
+      const int side = uni(it->side), nreads = uni(it->rowset);
+      const hs_tgroup_t* g = d.tgroups + uni(it->slot);
+      const int nm = uni(g->n_members);
+      int npad = 1; while (npad < nm) npad <<= 1;
+      const int sub = lane / npad, slot = lane - sub*npad;
+      const int ai = d.tpack[uni(it->active) + min(sub, nreads-1)];
+      const int r = d.active[ai];
+      const hs_read_t rdv = d.reads[r];
+      const hs_locus_t* loc = d.loci + uni(rdv.locus);
+      const int nL = rdv.seed, n = side ? rdv.len - rdv.seed - 1 : rdv.seed;
+      const hs_ws_t wsr = d.ws[ai];
+      const int k_al = d.tmembers[uni(g->member_off) + min(slot, nm-1)];
+      const hs_allele_t* al = d.alleles + uni(loc->hap_begin) + k_al;
+      const int ord = al->re_ord;
+      const int rowset = uni(g->rowset);
+      const int rs_off = uni(d.rowsets[rowset].off), rs_len = uni(d.rowsets[rowset].len);
+      const hs_row_t* rows = d.rows + rs_off;
+      // emissions through the LDS table: 8 lanes per read to write a column's entries, and rows of A, C, G, T, N only
+      bool el_ok = (HS_COOP_LDS_EMIT != 0) && (npad >= 8);
+      if (el_ok){
+        bool bad = false;
+        for (int q = lane; q < rs_len; q += 64){ const int ch = (int)rows[q] & 0xff; bad |= !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == 'N'); }
+        el_ok = !__any(bad);
+      }
+      const int nmax = uni(wave_max_i(n));         // (a cross-lane maximum: every lane takes part)
+      const int c0 = uni((int)rows[0]) & 0xff;
+      rc.n[lane] = n;
+      rc.col[lane] = wsr.col + 3*(int64_t)(side ? nL : 0);
+      rc.mr[lane] = wsr.mr + (int64_t)ord*(rdv.len-1) + (side ? nL : 0);
+      rc.lt[lane] = wsr.lt + (int64_t)ord*uni(loc->lt_stride) + (side ? d.rowsets[al->trail_rows[0]].len : 0);
+      if (lane == 0){
+        rc.item_ok = 1; rc.n_rows = rs_len - 1; rc.nmax = nmax; rc.npad = npad; rc.nreads = nreads; rc.nm = nm; rc.el_ok = el_ok ? 1 : 0;
+        rc.c0 = c0; rc.rs_off = rs_off;
+      }
+    }
+    asm volatile("" ::: "memory");           // the record's stores are issued before the counter's (a wavefront's LDS operations execute in order)
+    prog_write(a_q, k + 1);
+  };
+  if (threadIdx.x < W + 1) s_prog[threadIdx.x] = 0;
+  if (threadIdx.x < 2 + W) s_q[threadIdx.x] = 0;
+  __syncthreads();
+  int gcol = 0;                              // columns this workgroup's sweeps have covered so far: the same in every wavefront
+  for (int k = 0;; k++){
+    if (w == W - 1){
+      if (k == 0) prefetch(0);
+      // item k + 1 goes into the record item k - 1 had: every wavefront must have read that one (it has, long since, unless items without sweeps let this one run ahead)
+      for (int ww = 0; ww < W - 1; ww++)
+        while (prog_read(a_q + 4u*(uint32_t)(2 + ww)) < k) __builtin_amdgcn_s_sleep(1);
+    } else {
+      while (prog_read(a_q) <= k) __builtin_amdgcn_s_sleep(1);
+    }
+    const TrailRec& rc = s_rec[k & 1];
+    if (uni(rc.item_ok) == 0) break;
+    const int n_rows = uni(rc.n_rows), nmax = uni(rc.nmax), npad = uni(rc.npad), nreads = uni(rc.nreads), nm = uni(rc.nm), c0 = uni(rc.c0);
+    const bool el_ok = uni(rc.el_ok) != 0;
+    const hs_row_t* rows = d.rows + uni(rc.rs_off);
+    const int n = rc.n[lane];
+    const double* col = d.ws_col + rc.col[lane];
+    const double* mr = d.ws_mr + rc.mr[lane];
+    double* lt = d.ws_lt + rc.lt[lane];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    prog_write(a_q + 4u*(uint32_t)(2 + w), k + 1);          // this wavefront has read the record of item k
+    if (w == W - 1) prefetch(k + 1);                            // ... and the last one walks the next item's loads while the bands above it sweep this one
+#ifdef HS_FTIME
+    n_items_++;
+#endif
     const int sub = lane / npad, slot = lane - sub*npad;
     const bool live = (sub < nreads) && (slot < nm);
-    const int ai = d.tpack[uni(it->active) + min(sub, nreads-1)];
-    const int r = d.active[ai];
-    const hs_read_t rdv = d.reads[r];
-    const hs_locus_t* loc = d.loci + uni(rdv.locus);
-    const int nL = rdv.seed, n = side ? rdv.len - rdv.seed - 1 : rdv.seed;
-    const int nmax = uni(wave_max_i(n));
-    const hs_ws_t wsr = d.ws[ai];
-    const int k = d.tmembers[uni(g->member_off) + min(slot, nm-1)];
-    const hs_allele_t* al = d.alleles + uni(loc->hap_begin) + k;
-    const int ord = al->re_ord;
-    const double* mr = d.ws_mr + wsr.mr + (int64_t)ord*(rdv.len-1) + (side ? nL : 0);
-    double* lt = d.ws_lt + wsr.lt + (int64_t)ord*uni(loc->lt_stride) + (side ? d.rowsets[al->trail_rows[0]].len : 0);
-    const double* col = d.ws_col + wsr.col + 3*(int64_t)(side ? nL : 0);
-    const int rowset = uni(g->rowset);
-    const int rs_off = uni(d.rowsets[rowset].off), rs_len = uni(d.rowsets[rowset].len);
-    const hs_row_t* rows = d.rows + rs_off;
-    const int c0 = uni((int)rows[0]) & 0xff;
-    if (rs_len - 1 == 0){     // the block is the single "must be followed by a match" row (HapAligner.cpp:130-139)
+    if (n_rows == 0){     // the block is the single "must be followed by a match" row (HapAligner.cpp:130-139)
       if (w == 0){
         const int j = n - 1;
         const double blcj = col[3*j], blwj = col[3*j+1]; const int rdj = (int)col[3*j+2];
@@ -646,217 +795,16 @@ __global__ void __launch_bounds__(64*W, OCC) hs_trail_kernel_coop(const hs_dev_t
       }
       continue;
     }
-    // emissions through the LDS table: 8 lanes per read to write a column's entries, and rows of A, C, G, T, N only
-    bool el_ok = (HS_COOP_LDS_EMIT != 0) && (npad >= 8);
-    if (el_ok){
-      bool bad = false;
-      for (int q = lane; q < rs_len; q += 64){ const int ch = (int)rows[q] & 0xff; bad |= !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == 'N'); }
-      el_ok = !__any(bad);
-    }
-    if (el_ok) coop_rounds<R, W, false, true>(d, w, lane, live, n, nmax, col, rows, rs_len - 1, c0, mr, bnd, ring, lt, NULL, NULL, ktabs, etabs, npad);
+    if (el_ok) coop_rounds<R, W, false, true>(d, w, lane, live, n, nmax, col, rows, n_rows, c0, mr, bnd, ring, s_prog, &gcol, lt, NULL, NULL, ktabs, etabs, npad);
     else
-    coop_rounds<R, W, false>(d, w, lane, live, n, nmax, col, rows, rs_len - 1, c0, mr, bnd, ring, lt, NULL, NULL, ktabs);
+    coop_rounds<R, W, false>(d, w, lane, live, n, nmax, col, rows, n_rows, c0, mr, bnd, ring, s_prog, &gcol, lt, NULL, NULL, ktabs);
   }
-}
-
-#ifndef HS_FUSE_EXP
-#define HS_FUSE_EXP 0       // timing experiments only: 1 no epilogue, 2 the epilogue's tables only (results invalid); 3 s_memtime per stage, printed by a few workgroups
-#endif
-// Fused items (side == 2, round 5; layout.h hs_locus_t::fused): the trailing flanks of BOTH sides of a pack's reads against an allele group,
-// one after the other, their last columns into this workgroup's scratch (ws_lts: [row][lane], a few KB that stay in cache; read back one row per load) instead of the LT workspace,
-// then compute_aln_logprob (HapAligner.cpp:163-231) right here: hs_combine_kernel's arithmetic — term = (X + v) + Y with exactly one addend
-// the allele's own, the maximum with -1e300, the float exponentials above LOG_THRESH summed in double, the float log — with alleles as
-// lanes and the seed positions dealt to the workgroup's wavefronts.  Items of the other kind are hs_trail_kernel_coop's (both kernels walk
-// the chunk's item list, each with its own counter).  Every stage derives its operands from the item again (opaque copies of the item
-// index): nothing but the index lives across the sweeps, whose registers are the kernel's budget.
-template <int R, int W, int OCC>
-__global__ void __launch_bounds__(64*W, OCC) hs_trail_fused_coop(const hs_dev_t* __restrict__ dp, int item_begin, int item_end, int chunk){
-  const hs_dev_t& d = *dp;
-  const int lane = threadIdx.x & 63, w = uni((int)(threadIdx.x >> 6));
-  __shared__ double2 ring[W][2*64];
-  __shared__ double2 ktabs[W][24];
-  __shared__ double etabs[W][128];
-  __shared__ double s_X[1024], s_Y[1024];   // per (read of the pack, seed position): the shared addends of a term, in the reference's order
-  __shared__ int s_src[1024];               // ... and where the allele's own addend is: bit 31 = MR column, else LT row
-  __shared__ double s_red[W][64];
-  __shared__ int s_item;
-  double* const bnd = d.ws_band + (size_t)blockIdx.x * d.band_cols * 64 * 2;
-  int32_t* const ctr = d.redo + d.n_active + chunk;
-#if HS_FUSE_EXP >= 3
-  unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime(); int n_items = 0;
-#define HS_FTICK(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[k] += now_ - tprev; tprev = now_; } while (0)
-#else
-#define HS_FTICK(k) do {} while (0)
-#endif
-  for (;;){
-    if (threadIdx.x == 0) s_item = atomicAdd(ctr, 1);
-    __syncthreads();
-    const int item0 = item_begin + uni(s_item);
-    __syncthreads();
-    if (item0 >= item_end) break;
-    if (uni(d.items[item0].side) != 2) continue;
-    HS_FTICK(0);
-#pragma unroll 1
-    for (int sd = 0; sd < 2; sd++){
-      int item = item0; asm volatile("" : "+s"(item));
-      const hs_item_t* it = d.items + item;
-      const int nreads = uni(it->rowset);
-      const hs_tgroup_t* g = d.tgroups + uni(it->slot);
-      const int nm = uni(g->n_members);
-      int npad = 1; while (npad < nm) npad <<= 1;
-      const int sub = lane / npad, slot = lane - sub*npad;
-      const bool live = (sub < nreads) && (slot < nm);
-      const int ai = d.tpack[uni(it->active) + min(sub, nreads-1)];
-      const hs_read_t rdv = d.reads[d.active[ai]];
-      const hs_locus_t* loc = d.loci + uni(rdv.locus);
-      const hs_ws_t wsr = d.ws[ai];
-      const hs_allele_t* al = d.alleles + uni(loc->hap_begin) + d.tmembers[uni(g->member_off) + min(slot, nm-1)];
-      const hs_tgroup_t* gs = sd ? d.tgroups + (uni(it->slot) - uni(loc->tg_begin[0]) + uni(loc->tg_begin[1])) : g;   // the same members, this side's rows
-      const int nL = rdv.seed, n = sd ? rdv.len - rdv.seed - 1 : rdv.seed;
-      const int nmax = uni(wave_max_i(n));
-      const double* mr = d.ws_mr + wsr.mr + (int64_t)al->re_ord*(rdv.len-1) + (sd ? nL : 0);
-      // the left side's trailing rows come first, as in an allele's row of the LT workspace
-      double* lt = d.ws_lts + ((size_t)blockIdx.x*d.lts_rows + (sd ? uni(d.rowsets[uni(al->trail_rows[0])].len) : 0))*64 + lane;
-      const double* col = d.ws_col + wsr.col + 3*(int64_t)(sd ? nL : 0);
-      const int rowset = uni(gs->rowset);
-      const int rs_off = uni(d.rowsets[rowset].off), rs_len = uni(d.rowsets[rowset].len);
-      const hs_row_t* rows = d.rows + rs_off;
-      const int c0 = uni((int)rows[0]) & 0xff;
-      if (rs_len - 1 == 0){     // the block is the single "must be followed by a match" row (HapAligner.cpp:130-139)
-        if (w == 0){
-          const int j = n - 1;
-          const double blcj = col[3*j], blwj = col[3*j+1]; const int rdj = (int)col[3*j+2];
-          const double e0 = (rdj == c0) ? blcj : blwj;
-          if (live) lt[0] = (j == 0) ? e0 : e0 + mr[max(j-1, 0)];
-        }
-      } else {
-        bool el_ok = (HS_COOP_LDS_EMIT != 0) && (npad >= 8);
-        if (el_ok){
-          bool bad = false;
-          for (int q = lane; q < rs_len; q += 64){ const int ch = (int)rows[q] & 0xff; bad |= !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == 'N'); }
-          el_ok = !__any(bad);
-        }
-        if (el_ok) coop_rounds<R, W, false, true, 64>(d, w, lane, live, n, nmax, col, rows, rs_len - 1, c0, mr, bnd, ring, lt, NULL, NULL, ktabs, etabs, npad);
-        else       coop_rounds<R, W, false, false, 64>(d, w, lane, live, n, nmax, col, rows, rs_len - 1, c0, mr, bnd, ring, lt, NULL, NULL, ktabs);
-      }
-      __syncthreads();
-      HS_FTICK(1);
-    }
-    if (HS_FUSE_EXP == 1) continue;
-    // ---- compute_aln_logprob of the pack's reads against the group's alleles.  A few hundred instructions between memory round trips,
-    // while the CU's other workgroups sweep: at equal priority the issue slots go to the older wavefronts and this stage crawls
-    __builtin_amdgcn_s_setprio(3);
-    int item = item0; asm volatile("" : "+s"(item));
-    const hs_item_t* it = d.items + item;
-    const int nreads = uni(it->rowset);
-    const hs_tgroup_t* g = d.tgroups + uni(it->slot);
-    const int nm = uni(g->n_members);
-    int npad = 1; while (npad < nm) npad <<= 1;
-    const int sub = lane / npad, slot = lane - sub*npad;
-    const bool live = (sub < nreads) && (slot < nm);
-    const int ai = d.tpack[uni(it->active) + min(sub, nreads-1)];
-    const int r = d.active[ai];
-    const hs_read_t rdv = d.reads[r];
-    const hs_locus_t* loc = d.loci + uni(rdv.locus);
-    const int k = d.tmembers[uni(g->member_off) + min(slot, nm-1)];
-    const hs_allele_t* al = d.alleles + uni(loc->hap_begin) + k;
-    // the per-(read, seed position) operands, as combine_setup makes them (every allele of the group has the same flank configuration)
-    const int N = uni(al->n_flank);
-    {
-      const int lead_rs = uni(al->lead_rows[0]), trail_rs = uni(al->trail_rows[0]);
-      const int lead_off = uni(d.rowsets[lead_rs].off), F0 = uni(d.rowsets[lead_rs].len), trail_off = uni(d.rowsets[trail_rs].off), F2 = N - F0;
-      const int slotL = uni(al->lead_slot[0]), slotR = uni(al->lead_slot[1]);
-      const int lf0 = uni(loc->lead_flank[0]), lf1 = uni(loc->lead_flank[1]);
-      const double prior = -d.int_log[N];
-      for (int e = threadIdx.x; e < nreads*N; e += 64*W){
-        const int sb = e / N, y = e - sb*N;
-        const int ais = d.tpack[uni(it->active) + sb];
-        const hs_read_t rv = d.reads[d.active[ais]];
-        const hs_ws_t ws = d.ws[ais];
-        const int nl = rv.seed, nr = rv.len - rv.seed - 1;
-        const uint8_t seed_c = (uint8_t)d.bases[rv.base_off + nl], seed_q = (uint8_t)d.quals[rv.base_off + nl];
-        const uint8_t hc = (uint8_t)((y < F0 ? d.rows[lead_off + y] : d.rows[trail_off + y - F0]) & 0xff);
-        const double pe = prior + ((seed_c == hc) ? d.qual_correct[seed_q] : d.qual_error[seed_q]);
-        const double* recL = d.ws_lead + ws.lead[0] + (int64_t)slotL*(nl + lf0 + 1);
-        const double* recR = d.ws_lead + ws.lead[1] + (int64_t)slotR*(nr + lf1 + 1);
-        const bool left_part = y < F0 && y != N-1;
-        // y == 0: the whole left side hangs off the haplotype; y == N-1: the right side does (HapAligner.cpp:182-189)
-        const double sh = (y == 0) ? recL[nl + lf0] : ((y == N-1) ? recR[nr + lf1] : (left_part ? recL[nl + y - 1] : recR[nr + (N-2-y)]));
-        const bool shared_first = left_part || y == N-1;                  // ((prior + e) + shared) + the allele's, or ((prior + e) + the allele's) + shared
-        const int u = left_part ? N-1-y : y, fl = left_part ? F2 : F0;    // the right side's compact row : the left side's; row fl is the STR block's
-        s_X[e] = shared_first ? pe + sh : pe;
-        s_Y[e] = shared_first ? -0.0 : sh;
-        s_src[e] = (u == fl) ? (int)(0x80000000u | (unsigned)(left_part ? rv.len - 2 : nl - 1)) : (left_part ? u - 1 : u - F0 - 1);
-      }
-    }
-    __syncthreads();
-    HS_FTICK(2);
-    if (HS_FUSE_EXP == 2){ __builtin_amdgcn_s_setprio(0); continue; }
-    const double* mrl = d.ws_mr + d.ws[ai].mr + (int64_t)al->re_ord*(rdv.len-1);
-    const double* lts = d.ws_lts + (size_t)blockIdx.x*d.lts_rows*64 + lane;
-    const int eb = min(sub, nreads-1)*N;
-    auto term = [&](int y) -> double {
-      const int src = s_src[eb + y];
-      const double* a = (src < 0) ? mrl + (src & 0x7fffffff) : lts + (size_t)src*64;      // (one load behind a selected address: the loads of a wavefront's terms go out together)
-#if HS_FUSE_EXP == 4
-      return (s_X[eb + y] + (double)src) + s_Y[eb + y];
-#elif HS_FUSE_EXP == 5
-      return (s_X[eb + y] + ((src < 0) ? (double)src : *a)) + s_Y[eb + y];
-#elif HS_FUSE_EXP == 6
-      return (s_X[eb + y] + ((src < 0) ? *a : (double)src)) + s_Y[eb + y];
-#endif
-      return (s_X[eb + y] + *a) + s_Y[eb + y];
-    };
-    // a wavefront's share of the positions: y = w, w + W, ...; up to 16 of them stay in registers (all their loads in flight at once:
-    // the epilogue is a latency chain with the workgroup's sweeps waiting behind it), longer flanks evaluate their terms twice
-    constexpr int TR = 16;
-    const bool in_regs = N <= TR*W;
-    double t[TR];
-    double m = -1.0e300;                                   // fast_log_sum_exp starts its maximum there (mathops.cpp:97-106)
-    if (in_regs){
-#pragma unroll
-      for (int q = 0; q < TR; q++){ const int y = w + q*W; t[q] = term(min(y, N-1)); }
-#pragma unroll
-      for (int q = 0; q < TR; q++){ t[q] = (w + q*W < N) ? t[q] : -1.0e300; m = fmax(m, t[q]); }     // (a slot past the flank: below every threshold)
-    } else
-      for (int y = w; y < N; y += W) m = fmax(m, term(y));
-    s_red[w][lane] = m;
-    __syncthreads();
-    double mx = s_red[0][lane];
-#pragma unroll
-    for (int q = 1; q < W; q++) mx = fmax(mx, s_red[q][lane]);
-    __syncthreads();
-    double sm = 0.0;
-    double thr = d.log_thresh; asm volatile("" : "+v"(thr));      // (in a vector register: re-fetched through the scalar cache per term otherwise)
-    if (in_regs){
-#pragma unroll
-      for (int q = 0; q < TR; q++){
-        const double df = t[q] - mx;
-        const double ex = (double)f_fasterexp((float)df);
-        sm += (df > thr) ? ex : 0.0;
-      }
-    } else
-      for (int y = w; y < N; y += W){
-        const double df = term(y) - mx;
-        const double ex = (double)f_fasterexp((float)df);
-        sm += (df > d.log_thresh) ? ex : 0.0;
-      }
-    s_red[w][lane] = sm;
-    __syncthreads();
-    if (w == 0 && live){
-      double tot = s_red[0][lane];
-#pragma unroll
-      for (int q = 1; q < W; q++) tot += s_red[q][lane];
-      d.aln_probs[uni(loc->out_off) + (int64_t)(r - uni(loc->read_begin))*uni(loc->n_alleles) + k] = mx + (double)f_fasterlog((float)tot);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    HS_FTICK(3);
-#if HS_FUSE_EXP >= 3
-    n_items++;
-#endif
+#ifdef HS_FTIME
+  if ((blockIdx.x % 191) == 7 && lane == 0){
+    const unsigned long long* f = g_ft[blockIdx.x & 1023][w];
+    printf("trail wg %d wave %d: kernel %llu cycles, %d items, sweeps %llu (columns %llu), wait top %llu (%llu spins>0), wait bottom %llu (%llu)\n", (int)blockIdx.x, w,
+           HS_FT_NOW() - t_k0_, n_items_, f[2], f[3], f[0], f[4], f[1], f[5]);
   }
-#if HS_FUSE_EXP >= 3
-  if (threadIdx.x == 0 && (blockIdx.x % 97) == 0) printf("fused wg %d items %d: fetch %llu sweeps %llu tables %llu terms %llu (memtime ticks)\n", (int)blockIdx.x, n_items, tacc[0], tacc[1], tacc[2], tacc[3]);
 #endif
 }
 
@@ -864,7 +812,8 @@ template <int R, int W, int OCC>
 __global__ void __launch_bounds__(64*W, OCC) hs_lead_kernel_coop(const hs_dev_t* __restrict__ dp, int item_begin, int item_end, int chunk){
   const hs_dev_t& d = *dp;
   const int lane = threadIdx.x & 63, w = uni((int)(threadIdx.x >> 6));
-  __shared__ double2 ring[W][2*64];
+  __shared__ double2 ring[W][HS_RING*64];
+  __shared__ int s_prog[W + 1];                 // columns finished per band wavefront (band_sweep_coop); [W]: never written, the last band's lower neighbour
   __shared__ double2 ktabs[W][24];          // per wavefront: (m2m, m2i) of its band's rows (HS_COOP_LDS_CONSTS)
   __shared__ int s_item;
   double* const bnd = d.ws_band + (size_t)blockIdx.x * d.band_cols * 64 * 2;
@@ -873,6 +822,7 @@ __global__ void __launch_bounds__(64*W, OCC) hs_lead_kernel_coop(const hs_dev_t*
     if (threadIdx.x == 0) s_item = atomicAdd(ctr, 1);
     __syncthreads();
     const int item = item_begin + uni(s_item);
+    if (threadIdx.x <= W) s_prog[threadIdx.x] = 0;           // every wavefront is past the previous item's sweeps (the barrier above)
     __syncthreads();
     if (item >= item_end) break;
     const hs_item_t* it = d.items + item;
@@ -907,7 +857,7 @@ __global__ void __launch_bounds__(64*W, OCC) hs_lead_kernel_coop(const hs_dev_t*
       }
       continue;
     }
-    coop_rounds<R, W, true>(d, w, lane, live, n, nmax, col, rows, rs_len - 1, c0, NULL, bnd, ring, lastcol, rec, side_out, ktabs);
+    coop_rounds<R, W, true>(d, w, lane, live, n, nmax, col, rows, rs_len - 1, c0, NULL, bnd, ring, s_prog, NULL, lastcol, rec, side_out, ktabs);
   }
 }
 
@@ -937,8 +887,6 @@ __global__ void __launch_bounds__(64) hs_flank_systolic(const hs_dev_t* __restri
     ai = uni(d.tpack[uni(it->active) + pair]); rowset = uni(it->rowset);
   } else {
     side = uni(it->side);
-    if (side == 2) side = (int)blockIdx.z | 4;            // a fused item (hs_locus_t::fused): here its two sides are two alignments, hs_combine_kernel follows
-    else if (blockIdx.z) return;
     g = d.tgroups + uni(it->slot);
     const int nm = uni(g->n_members), sub = pair / nm;
     tslot = pair - sub*nm;
@@ -947,10 +895,6 @@ __global__ void __launch_bounds__(64) hs_flank_systolic(const hs_dev_t* __restri
   }
   const hs_read_t rdv = d.reads[uni(d.active[ai])];
   const hs_locus_t* loc = d.loci + uni(rdv.locus);
-  if (!LEAD && (side & 4)){                              // the right side's group of a fused item: the same members, its own rows
-    side &= 1;
-    if (side){ g = d.tgroups + (uni(it->slot) - uni(loc->tg_begin[0]) + uni(loc->tg_begin[1])); rowset = uni(g->rowset); }
-  }
   const int nL = uni(rdv.seed), len = uni(rdv.len), n = side ? len - nL - 1 : nL;
   if (n <= 0) return;
   const hs_ws_t wsr = d.ws[ai];
@@ -3509,12 +3453,11 @@ __device__ __forceinline__ void combine_config(const hs_dev_t& d, const SideView
 
 // One workgroup (HS_CMB_WAVES wavefronts) per active read.
 extern "C" __global__ void __launch_bounds__(64*HS_CMB_WAVES)
-hs_combine_kernel(const hs_dev_t* __restrict__ dp, int active_begin, int skip_fused){
+hs_combine_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
   const hs_dev_t& d = *dp;
   const int lane = threadIdx.x & 63;
   const int ai = active_begin + blockIdx.x;
   const SideView vL = side_view(d, ai, 0);
-  if (skip_fused && uni(vL.loc->fused)) return;         // hs_trail_kernel_coop's fused items stored this read's alignment probabilities already
   const SideView vR = side_view(d, ai, 1);
   const uint8_t seed_c = (uint8_t)d.bases[vL.base_off + vL.nL];
   const uint8_t seed_q = (uint8_t)d.quals[vL.base_off + vL.nL];
@@ -3597,30 +3540,17 @@ extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStr
   if (flank_coop()) hipLaunchKernelGGL((hs_lead_kernel_coop<HS_COOP_ROWS, HS_COOP_WAVES, HS_COOP_OCC>), dim3(std::max(1u, std::min(n_wavefronts, 256u*HS_COOP_OCC*4/HS_COOP_WAVES))), dim3(64*HS_COOP_WAVES), 0, st, dp, item_begin, item_end, chunk);
   else hipLaunchKernelGGL((hs_lead_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end, chunk);
 }
-// n_fused_items / n_plain_items: how many of the chunk's items are fused ones (side == 2, hs_trail_fused_coop) and how many are not.
-// Returns 1 when the fused items were finished here (compute_aln_logprob inside the kernel): the caller then tells hs_combine_kernel
-// to skip the reads of fused loci; 0 when they were run as two plain sides (systolic form)
-extern "C" int hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk, int max_cols, int max_rows,
-                               int n_fused_items, int n_plain_items){
+extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk, int max_cols, int max_rows){
   if (item_end > item_begin && use_systolic(item_begin, item_end, max_cols)){
-    hipLaunchKernelGGL((hs_flank_systolic<false>), dim3((unsigned)(item_end - item_begin), 64, n_fused_items ? 2 : 1), dim3(64), 0, st, dp, item_begin);
-    return 0;
+    hipLaunchKernelGGL((hs_flank_systolic<false>), dim3((unsigned)(item_end - item_begin), 64), dim3(64), 0, st, dp, item_begin);
+    return;
   }
   const bool lat = flank_coop() && lat_shape() && (unsigned)(item_end - item_begin) <= HS_LAT_ITEMS;
   // short flanks (production panels: <= 35 bp): three bands of up to 12 rows fill their wavefronts better than four of 9 (p30 trailing flank
   // 4.25 -> 4.02 ms, profiles/r05_notes.md; at 60 rows the 4 x 15 shape is the best by 25 %)
   const bool shrt = flank_coop() && max_rows - 1 <= 36 && !(getenv("HIPSTR_COOP_SHORT") && atoi(getenv("HIPSTR_COOP_SHORT")) == 0);
-  if (n_fused_items > 0){             // (prep.cpp fuses nothing with HIPSTR_FLANK_COOP=0); its own item counter: chunk + 1
-    const unsigned nw = std::min(n_wavefronts, (unsigned)n_fused_items);
-    if (lat)       hipLaunchKernelGGL((hs_trail_fused_coop<HS_LAT_ROWS, HS_LAT_WAVES, 2>), dim3(std::max(1u, std::min(nw, 256u))), dim3(64*HS_LAT_WAVES), 0, st, dp, item_begin, item_end, chunk + 1);
-    else if (shrt) hipLaunchKernelGGL((hs_trail_fused_coop<12, 3, 3>), dim3(std::max(1u, std::min(nw, 256u*3*4/3))), dim3(64*3), 0, st, dp, item_begin, item_end, chunk + 1);
-    else           hipLaunchKernelGGL((hs_trail_fused_coop<HS_COOP_ROWS, HS_COOP_WAVES, HS_COOP_OCC>), dim3(std::max(1u, std::min(nw, 256u*HS_COOP_OCC*4/HS_COOP_WAVES))), dim3(64*HS_COOP_WAVES), 0, st, dp, item_begin, item_end, chunk + 1);
-    if (n_plain_items == 0) return 1;
-    n_wavefronts = std::min(n_wavefronts, (unsigned)n_plain_items);
-  }
   if (lat)       hipLaunchKernelGGL((hs_trail_kernel_coop<HS_LAT_ROWS, HS_LAT_WAVES, 2>), dim3(std::max(1u, std::min(n_wavefronts, 256u))), dim3(64*HS_LAT_WAVES), 0, st, dp, item_begin, item_end, chunk);
   else if (shrt) hipLaunchKernelGGL((hs_trail_kernel_coop<12, 3, 3>), dim3(std::max(1u, std::min(n_wavefronts, 256u*3*4/3))), dim3(64*3), 0, st, dp, item_begin, item_end, chunk);
   else if (flank_coop()) hipLaunchKernelGGL((hs_trail_kernel_coop<HS_COOP_ROWS, HS_COOP_WAVES, HS_COOP_OCC>), dim3(std::max(1u, std::min(n_wavefronts, 256u*HS_COOP_OCC*4/HS_COOP_WAVES))), dim3(64*HS_COOP_WAVES), 0, st, dp, item_begin, item_end, chunk);
   else hipLaunchKernelGGL((hs_trail_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end, chunk);
-  return 1;
 }

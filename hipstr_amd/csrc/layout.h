@@ -148,7 +148,7 @@ struct hs_locus_t {
   int32_t n_pw[2];           // positions [n_tab, n_pw) of the order: alleles whose lists are simple or piecewise simple (hs_stropt_t::kind 2),
                              // hs_str_group_kernel_pw's; the rest, [n_pw, n_re), is hs_str_kernel_generic's
   int32_t period;            // the locus' STR period (the same for all of its alleles)
-  int32_t fused;             // 1: the trailing flanks of both sides and compute_aln_logprob run as ONE item per (read pack, allele group)
+  int32_t fused;             // always 0 (round 5's fused trailing-flank item was measured slower and removed in round 6; the field keeps the record's layout)
                              // (hs_trail_kernel_coop, side == 2; prep.cpp trail_fusable): the two sides' allele groups are the same lists,
                              // every allele of a group has the same flank configuration; hs_combine_kernel leaves this locus' reads alone
   int32_t n_rp[2];           // positions [n_pw, n_rp) of the order: alleles with a list that has no closed form (three and more interruptions;
@@ -225,7 +225,7 @@ struct hs_dev_t {
                                  // set = ... and is that block plus one repeat unit, periodic, with all six deletion sizes
   HS_P(double) ws_col;
   HS_P(double) ws_band;    // per persistent wavefront: 2 x [band_cols][64 lanes][2] band-boundary rows (M, D)
-  HS_P(double) ws_lts;     // per workgroup of hs_trail_fused_coop: [lts_rows][64 lanes] last columns of a fused item's two trailing flanks (scratch that stays in cache)
+  HS_P(double) ws_lts;     // unused (NULL): scratch of the removed fused trailing-flank item; kept for the argument block's layout
   HS_P(double) ws_mr;
   HS_P(double) ws_lt;
   HS_P(double) ws_lead;

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <pthread.h>
 #include <chrono>
 #include <condition_variable>
 #include <cmath>
@@ -71,7 +72,7 @@ struct Pool {
   }
   void ensure(int n_workers){
     std::lock_guard<std::mutex> g(m);
-    while ((int)threads.size() < n_workers) threads.emplace_back([this]{ serve(); });
+    while ((int)threads.size() < n_workers) threads.emplace_back([this]{ pthread_setname_np(pthread_self(), "hipstr-pool"); serve(); });      // (named: bench.py attributes CPU time by thread)
   }
   static void run(PoolJob* j){
     for (int i = j->next.fetch_add(1); i < j->n; i = j->next.fetch_add(1)){ (*j->fn)(i); j->done.fetch_add(1, std::memory_order_release); }
@@ -1306,37 +1307,11 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
     }
     loc.tg_count[side] = out.tgroups.size() - loc.tg_begin[side];
   }
-  // Can the two sides' trailing flanks and compute_aln_logprob of this locus run as one item (hs_trail_kernel_coop, side == 2)?  The allele
-  // groups of the two sides must be the same lists in the same order (they are partitions by the side's trailing rows: the same whenever
-  // the flanks' boundary contexts do not split the alleles differently on the two sides), every allele of a group must have the same
-  // flank configuration (what hs_combine_kernel groups by), both flanks at least one base and at most 64 HS_CMB_ROUNDS bases in all, and
-  // a group at least 5 alleles (at most 8 reads per wavefront: the epilogue's per-read tables).
-  {
-    static const bool fuse_on = (getenv("HIPSTR_TRAIL_FUSED") && atoi(getenv("HIPSTR_TRAIL_FUSED")) != 0) &&       // opt-in: slower than the two kernels so far (profiles/r05_notes.md)
-                                !(getenv("HIPSTR_FLANK_COOP") && atoi(getenv("HIPSTR_FLANK_COOP")) == 0);      // (the serial sweep has no fused form)
-    bool ok = fuse_on && loc.tg_count[0] == loc.tg_count[1] && loc.tg_count[0] > 0;
-    for (int g = 0; ok && g < loc.tg_count[0]; g++){
-      const hs_tgroup_t& g0 = out.tgroups[loc.tg_begin[0] + g]; const hs_tgroup_t& g1 = out.tgroups[loc.tg_begin[1] + g];
-      ok = g0.n_members == g1.n_members && g0.n_members >= 5 &&
-           memcmp(out.tmembers.data() + g0.member_off, out.tmembers.data() + g1.member_off, sizeof(int32_t)*(size_t)g0.n_members) == 0;
-      const hs_allele_t& a0 = out.alleles[allele_base + out.tmembers[g0.member_off]];
-      const int F0 = out.rowsets[a0.lead_rows[0]].len, N = a0.n_flank;
-      int npad = 1; while (npad < g0.n_members) npad <<= 1;
-      ok = ok && F0 >= 1 && N - F0 >= 1 && N <= 256 && (64/npad)*N <= 1024;
-      for (int m = 1; ok && m < g0.n_members; m++){
-        const hs_allele_t& am = out.alleles[allele_base + out.tmembers[g0.member_off + m]];
-        ok = am.n_flank == a0.n_flank && am.lead_rows[0] == a0.lead_rows[0] && am.trail_rows[0] == a0.trail_rows[0] && am.trail_rows[1] == a0.trail_rows[1] &&
-             am.lead_slot[0] == a0.lead_slot[0] && am.lead_slot[1] == a0.lead_slot[1];
-      }
-    }
-    loc.fused = ok ? 1 : 0;
-  }
   HS_LAP(5);
   for (int side = 0; side < 2; side++){
     out.lead_off.push_back((int32_t)out.lead_ids.size());
     out.lead_ids.insert(out.lead_ids.end(), S.lead_sets[side].begin(), S.lead_sets[side].end());
   }
-  int fused_len = -1;
   for (int r = loc.read_begin; r < loc.read_begin + loc.n_reads; r++){
     hs_read_t rd;
     rd.base_off = b->base_off[r]; rd.len = b->base_off[r+1]-b->base_off[r]; rd.locus = l; rd.seed = -1;
@@ -1351,9 +1326,6 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
       sh.seeds[r] = s;
       if (s >= 0){
         if (s > HS_MAX_SIDE_FWD || rd.len-s-1 > HS_MAX_SIDE_FWD){ err = "read side longer than 1024 bases is not supported"; return 1; }
-        // fused items pack reads by their left side's length: reads of one length are then packed by their right side's too
-        // (lanes that finish together); a locus whose reads differ in length keeps the two plain items
-        if (fused_len < 0) fused_len = rd.len; else if (rd.len != fused_len) loc.fused = 0;
         out.active.push_back(r);
         out.n_alignments += n_realigned;
         out.max_read_len = std::max(out.max_read_len, rd.len);
@@ -1635,14 +1607,12 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
             R.nd_cap = std::max(R.nd_cap, it.slot*36*period);
           }
         }
-        // (a fused locus: one item per read pack and group for BOTH sides, the reads in the left side's order — side == 2)
-        if (!(loc.fused && s == 1))
         for (int g = 0; g < loc.tg_count[s]; g++){
           const int nm = out.tgroups[loc.tg_begin[s] + g].n_members;
           int npad = 1; while (npad < nm) npad <<= 1;
           const int per_wave = 64 / npad;
           for (int i = 0; i < n_run; i += per_wave){
-            hs_item_t it; it.side = loc.fused ? 2 : s; it.slot = loc.tg_begin[s] + g;
+            hs_item_t it; it.side = s; it.slot = loc.tg_begin[s] + g;
             it.active = (int32_t)R.tpack.size();
             it.rowset = (int32_t)std::min(per_wave, n_run - i);
             R.tpack.insert(R.tpack.end(), order.begin() + i, order.begin() + i + it.rowset);
@@ -1683,8 +1653,6 @@ int prepare_batch(const hipstr_batch_t* b, Prepared& out, std::string& err, int6
     }
     lap("plan:merge", t_lap);
     ch.trail_end = out.trail_items.size();
-    ch.n_fused_items = 0;
-    for (int32_t i = ch.trail_begin; i < ch.trail_end; i++) ch.n_fused_items += out.trail_items[i].side == 2;
     ch.str_end = out.str_items.size();
     ch.lead_end = out.lead_items.size();
     out.ws_mr_size = std::max(out.ws_mr_size, mr); out.ws_lt_size = std::max(out.ws_lt_size, lt); out.ws_lead_size = std::max(out.ws_lead_size, lead);

@@ -50,7 +50,6 @@ struct Prepared {
     int32_t trail_begin, trail_end;        // trail_items range
     int32_t str_begin, str_end;            // str_items range
     int32_t n_long_sides;                  // read sides with more than HS_GRP_COLS columns (hs_str_kernel takes them)
-    int32_t n_fused_items;                 // trail_items with side == 2 (both trailing flanks + compute_aln_logprob in one item: hs_trail_fused_coop)
     int64_t n_alignments;
   };
   std::vector<Chunk>      chunks;

@@ -21,6 +21,7 @@
 #include <set>
 #include <string>
 #include <thread>
+#include <pthread.h>
 #include <time.h>
 #include <vector>
 
@@ -303,6 +304,7 @@ void retire_batch(hipstr_stream* s, OwnedBatch* ob){
 }
 
 void worker_loop(hipstr_stream* s, int n_workers){
+  pthread_setname_np(pthread_self(), "hipstr-worker");
   hipstr::api_bind(s->ctx);
   // the workers prepare different batches at the same time: each takes its share of the host threads (one thread each on a two-core
   // allowance — then a batch is prepared without fragments, merges or hand-overs to pool threads)

@@ -521,9 +521,6 @@ int hipstr_debug_cr_math(int which, const double* x, double* y, int64_t n);
  * counts[2] blocks with one or two interruptions (piecewise closed form), counts[3] more interruptions (lists replayed in the grouped layout),
  * counts[0] the rest (per-read kernel). */
 int hipstr_debug_allele_kinds(hipstr_dev_batch_t* dev, int64_t counts[4]);
-/* Diagnostics (tests): out[0] = loci of a batch whose two trailing flanks and compute_aln_logprob (HapAligner.cpp:163-231) run as one work
- * item of the trailing-flank kernel (opt-in: HIPSTR_TRAIL_FUSED=1), out[1] = all loci of the batch. */
-int hipstr_debug_fused_loci(hipstr_dev_batch_t* dev, int64_t out[2]);
 /* Diagnostics (tests): a non-blocking HIP stream made by the library's own HIP runtime — what a caller passes as `hip_stream` — and its release. */
 void* hipstr_debug_stream_create(void);
 void hipstr_debug_stream_destroy(void* hip_stream);

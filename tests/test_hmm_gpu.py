@@ -456,39 +456,3 @@ def test_systolic_flank_kernels_match_the_shared_row_sweeps(hmm, oracle, monkeyp
             got, gs = capi.run_align(hmm, "hipstr_hmm_", sb.ptr, fill=-6.5)
             assert np.array_equal(gs, ws) and np.array_equal(got, want), (kw, mode)
     monkeypatch.delenv("HIPSTR_FLANK_SYSTOLIC")
-
-
-@pytest.mark.parametrize("systolic", ["0", "1", "2"])
-def test_fused_trailing_flanks_and_alignment_probability(systolic):
-    """Round 5, opt-in (HIPSTR_TRAIL_FUSED=1, read once per process: a process of its own): loci whose allele groups are the same lists on both
-    sides, with one flank configuration per group and reads of one length, run both trailing flanks of a read pack and compute_aln_logprob
-    (HapAligner.cpp:163-231) as ONE work item (hs_trail_fused_coop; the last columns stay in a per-workgroup scratch, hs_combine_kernel skips
-    those reads).  Bit-identical to the oracle: batches where (nearly) every locus is fused (no combine launch when all are), mixed batches (two flank options, masked
-    alleles, groups under five alleles: both trailing-flank kernels and the combine kernel run), flanks of 8, 35, 60 and 100 rows (the 3 x 12,
-    4 x 15 and multi-round band shapes; 150 + 150 flank bases are more than a fused item's tables hold: not fused), one-locus launches (latency shape; with HIPSTR_FLANK_SYSTOLIC=1/2 the systolic form runs a fused
-    item as two plain sides and the combine kernel takes every read).  The fused share of each batch is checked so the cases keep meaning it."""
-    import subprocess, sys
-    code = ("import sys, ctypes as C, numpy as np; sys.path.insert(0, %r); from hipstr_amd import capi\n"
-            "hmm = capi.load_hmm(); ora = capi.load_oracle(); assert hmm.hipstr_hmm_init(0) == 0\n"
-            "cases = [(dict(n_loci=40, reads_per_locus=60, n_str_alleles=16, seed=6), 'most'),\n"
-            "         (dict(n_loci=30, reads_per_locus=50, n_str_alleles=32, flank_len=35, seed=16), 'most'),\n"
-            "         (dict(n_loci=6, reads_per_locus=30, n_str_alleles=12, flank_len=150, read_len=250, seed=4), 'none'),\n"
-            "         (dict(n_loci=6, reads_per_locus=30, n_str_alleles=12, flank_len=100, read_len=250, seed=4), 'most'),\n"
-            "         (dict(n_loci=8, reads_per_locus=30, n_str_alleles=9, flank_len=8, seed=5), 'most'),\n"
-            "         (dict(n_loci=1, reads_per_locus=40, n_str_alleles=32, seed=3), 'most'),\n"
-            "         (dict(n_loci=25, reads_per_locus=25, n_str_alleles=7, n_flank_opts=2, seed=9, mask_rate=0.2), 'any'),\n"
-            "         (dict(n_loci=20, reads_per_locus=40, n_str_alleles=3, seed=11), 'none'),\n"
-            "         (dict(n_loci=60, reads_per_locus=40, n_str_alleles=16, seed=21, mask_rate=0.3), 'any')]\n"
-            "for kw, share in cases:\n"
-            "    sb = capi.SynthBatch(**kw)\n"
-            "    want, ws = capi.run_align(ora, 'oracle_', sb.ptr, fill=-3.25)\n"
-            "    got, gs = capi.run_align(hmm, 'hipstr_hmm_', sb.ptr, fill=-3.25)\n"
-            "    assert np.array_equal(gs, ws) and np.array_equal(got, want), kw\n"
-            "    dev = hmm.hipstr_hmm_upload(sb.ptr); assert dev\n"
-            "    o = (C.c_int64*2)(); assert hmm.hipstr_debug_fused_loci(dev, o) == 0; hmm.hipstr_hmm_free(dev)\n"
-            "    print(kw, list(o))\n"
-            "    assert o[1] == kw['n_loci'] and {'most': 5*o[0] >= 4*o[1], 'any': 0 <= o[0] <= o[1], 'none': o[0] == 0}[share], (kw, list(o))\n"
-            "print('ok')\n") % ROOT
-    env = dict(os.environ, HIPSTR_TRAIL_FUSED="1", HIPSTR_FLANK_SYSTOLIC=systolic)
-    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=900)
-    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout

@@ -18,19 +18,21 @@ def run_post(hmm, pb):
 def run(n_cfg, seed, hmm, ora):
     rng = np.random.default_rng(seed)
     A_EDGE = [1, 2, 3, 5, 8, 31, 32, 33, 44, 45, 46, 47, 63, 64, 65, 90, 96, 127, 128, 129, 150]
+    if os.environ.get("HIPSTR_FUZZ_BIG"):          # round 6: up to MAX_TOTAL_HAPLOTYPES = 1000 (genotyper_bam_processor.h:110): 10^6 diplotypes per sample
+        A_EDGE = [150, 191, 192, 193, 255, 256, 257, 300, 383, 384, 500, 511, 512, 513, 640, 767, 768, 900, 999, 1000]
     bad = 0; n_dip = 0
     for c in range(n_cfg):
-        nl = int(rng.integers(1, 6))
+        nl = int(rng.integers(1, 6)) if not os.environ.get("HIPSTR_FUZZ_BIG") else int(rng.integers(1, 3))
         A, S, off, lab, hap, nv, h2a = [], [], [0], [], [], [], []
         for l in range(nl):
             a = int(rng.choice(A_EDGE)) if rng.random() < 0.8 else int(rng.integers(1, 80))
-            s = int(rng.choice([1, 2, 3, 7, 40])) if a <= 65 else int(rng.choice([1, 2, 5]))
+            s = int(rng.choice([1, 2, 3, 7, 40])) if a <= 65 else (int(rng.choice([1, 2, 5])) if a <= 200 else int(rng.choice([1, 2, 3])))
             reads = []
             for smp in range(s):
                 k = int(rng.choice([0, 1, 2, 6, 9, 30], p=[.1, .15, .2, .35, .15, .05]))
                 reads += [smp] * k
             A.append(a); S.append(s); lab += reads; off.append(off[-1] + len(reads)); hap.append(int(rng.random() < 0.3))
-            v = int(rng.integers(1, min(a, 24) + 1)); nv.append(v)
+            v = int(rng.integers(1, min(a, 24 if a <= 200 else 300) + 1)); nv.append(v)
             m = rng.integers(0, v, size=a); m[:v] = rng.permutation(v); h2a += list(m)        # every variant has a haplotype
         n = off[-1]
         nll = int(np.dot(A, np.diff(off)))
