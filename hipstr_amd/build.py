@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "hipstr_amd", "csrc")
 HIP_SOURCES = ["api.hip", "hmm_kernels.hip", "expand_kernels.hip", "post_kernels.hip", "prep.cpp", "trace.hip", "em.hip", "nw.hip", "batch_io.cpp", "stream.hip", "gather.cpp"]
-HIP_HEADERS = ["exports.map", "layout.h", "post_layout.h", "prep.h", "device_common.h", "api_internal.h", os.path.join("..", "..", "include", "hipstr_hmm.h")]
+HIP_HEADERS = ["exports.map", "layout.h", "post_layout.h", "prep.h", "device_common.h", "api_internal.h", os.path.join("..", "..", "include", "hipstr_hmm.h"), os.path.join("..", "..", "include", "hipstr_hmm_debug.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans", "-mno-amdgpu-ieee", "-fPIC", "-shared", "-pthread", "-fvisibility=hidden", "-Wno-unused-result", "-Wno-unused-value"]
 
 

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/hipstr_hmm.h"
+#include "../../include/hipstr_hmm_debug.h"
 #include "layout.h"
 #include "post_layout.h"
 #include "prep.h"
@@ -993,6 +994,7 @@ void api_profile_add(int bucket, double seconds, int calls){
 double ApiTimer::now(){ return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }
 }
+#ifndef HIPSTR_NO_DEBUG_ABI      // diagnostics (include/hipstr_hmm_debug.h): tests, fuzzers, bench.py — not the drop-in ABI
 int64_t hipstr_debug_driver_allocs(void){ return g_driver_allocs.load(); }
 int hipstr_debug_cr_math(int which, const double* x, double* y, int64_t n){
   if (!x || !y || n < 0) return fail("null argument");
@@ -1155,6 +1157,7 @@ int hipstr_debug_simple_table(int bound, int U0, int tail, double entry[3]){
   hipstr::debug_simple_table(bound, U0, tail, entry);
   return 0;
 }
+#endif  // HIPSTR_NO_DEBUG_ABI
 
 // ----------------------------------------------------------------------------- posteriors
 int hipstr_post_offsets(const hipstr_post_batch_t* pb, int64_t* post_off, int64_t* samp_off){

@@ -349,11 +349,8 @@ __global__ void __launch_bounds__(64, HS_FLANK_WAVES) hs_lead_kernel(const hs_de
 #ifndef HS_COOP_ROWS
 #define HS_COOP_ROWS 15
 #endif
-#ifndef HS_COOP_VGPR_CONSTS
-#define HS_COOP_VGPR_CONSTS 0     // measured (profiles/r02_notes.md): 16 instead of 18 instructions per cell, but 2 wavefronts per SIMD instead of 3: 5 % slower
-#endif
 #ifndef HS_COOP_OCC
-#define HS_COOP_OCC (HS_COOP_VGPR_CONSTS ? 2 : 3)         // wavefronts per SIMD the register allocation aims at
+#define HS_COOP_OCC 3         // wavefronts per SIMD the register allocation aims at
 #endif
 
 // LDS operations of this wavefront are complete (and its global stores, when it hands a boundary over through memory), then the
@@ -410,9 +407,6 @@ template <int CNT> __device__ __forceinline__ void ewait1(double& e){ asm volati
 // to have consumed the ring slot it is about to overwrite (HS_RING columns back).  LDS operations of a wavefront execute in order and the
 // LDS has no cache: a wavefront that sees the counter sees the boundary values stored before it.  A band runs ahead of the band below it
 // by up to HS_RING columns; nothing else synchronises inside an item.  Same cells, same operations: bit-identical.
-#ifndef HS_BAND_REM_LAST
-#define HS_BAND_REM_LAST 0
-#endif
 #ifndef HS_RING
 #define HS_RING 8        // columns of boundary values a band may be ahead of the band below it (power of two)
 #endif
@@ -441,7 +435,7 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
                                                 const hs_row_t* __restrict__ rows, int row0, int c0, const double* __restrict__ mr,
                                                 double* __restrict__ bnd, bool topg, bool botg, hs_lds_cd2 lds_top, hs_lds_d2 lds_bot,
                                                 double* __restrict__ lt, double* __restrict__ rowp, double* __restrict__ side_out,
-                                                int w, hs_lds_i prog, int base, hs_lds_d2 ktab, hs_lds_d2 etab, int npad){
+                                                int w, hs_lds_i prog, int base, int nsteps, hs_lds_d2 ktab, hs_lds_d2 etab, int npad){
   static_assert(!EL || (HS_COOP_LDS_CONSTS != 0 && !LEAD), "the emission table rides on the constants' request pipeline");
   constexpr bool KL = HS_COOP_LDS_CONSTS != 0;
   int hc[NR]; double m2m[KL ? 1 : NR], m2i[KL ? 1 : NR];
@@ -458,13 +452,6 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
     const int meta = uni((int)rows[row0 + r]);
     hc[r] = EL ? (((meta & 0xff) >> 1) & 7) << 3 : (meta & 0xff);      // EL: byte offset of the base's entry in a read's eight-entry row
     if (!KL){ m2m[KL ? 0 : r] = uni(d.m2m[(meta >> 8) & 15]); m2i[KL ? 0 : r] = uni(d.m2i[(meta >> 8) & 15]); }
-#if HS_COOP_VGPR_CONSTS
-    // The transition logs of NR rows do not fit the SGPR file next to everything else: the compiler parks them in VGPR lanes and pays
-    // two v_readlane_b32 (4 cycles each, profiles/*_valu_microbench.json) per cell to get them back.  Held in VGPRs on purpose they
-    // cost registers (2 wavefronts per SIMD instead of 3) but no instructions — which measured slower: the serial D chain down a
-    // column (2 dependent FP64 operations per row) needs the third wavefront to hide its latency.
-    asm volatile("" : "+v"(m2m[r]), "+v"(m2i[r]));
-#endif
   }
   double Mp[NR], Dp[NR], Ip[NR];
   double nx_blc = col[0], nx_blw = col[1], nx_rd = col[2];
@@ -484,16 +471,21 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
   // without a barrier (hs_trail_kernel_coop); a column's number, its ring slot and the values waited for are base + j
   int top_seen = 0, bot_seen = 0;                // columns the upper / the lower neighbour is known to have finished
   const unsigned long long t_sweep0_ = HS_FT_NOW();
+  // BAR (the leading flanks: few items, a short chain of them per workgroup — what counts there is the latency of a hand-over, and a
+  // barrier wakes its waiters faster than a polled counter: 3.8 against 4.8 ms per NS pass): the bands meet at a barrier after every
+  // column, band w one column behind band w - 1, as until round 5; the counters are not used.
+  constexpr bool BAR = LEAD;
 #pragma unroll 1       // (left to itself the compiler peels and unrolls the column loop: 2000 scratch operations in a kernel that has 168 registers and needs them all)
-  for (int j = 0; j < nmax; j++){
-    {
+  for (int t = 0; t < (BAR ? nsteps : nmax); t++){
+    const int j = BAR ? t - w : t;
+    if (!BAR || (j >= 0 && j < nmax)){
       const double blcj = nx_blc, blwj = nx_blw; const int rdj = (int)nx_rd;
       const double cur_mr = nx_mr;
       double2 cur_b = make_double2(0.0, 0.0);
       if (!FIRST){
         if (topg) cur_b = *(const double2*)(bnd + ((size_t)j*64 + lane)*2);
         else {
-          if (top_seen <= base + j){
+          if (!BAR && top_seen <= base + j){
             const unsigned long long t0_ = HS_FT_NOW(); int spins_ = 0;
             while ((top_seen = prog_read(a_top)) <= base + j){ __builtin_amdgcn_s_sleep(1); spins_++; }
             HS_FT_ADD(0, HS_FT_NOW() - t0_); if (spins_) HS_FT_ADD(4, 1);
@@ -584,7 +576,7 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
       if (!LAST){
         if (botg) *(double2*)(bnd + ((size_t)j*64 + lane)*2) = make_double2(upM, upD);
         else {
-          if (base + j - bot_seen >= HS_RING){
+          if (!BAR && base + j - bot_seen >= HS_RING){
             const unsigned long long t0_ = HS_FT_NOW(); int spins_ = 0;
             while (base + j - (bot_seen = prog_read(a_bot)) >= HS_RING){ __builtin_amdgcn_s_sleep(1); spins_++; }
             HS_FT_ADD(1, HS_FT_NOW() - t0_); if (spins_) HS_FT_ADD(5, 1);
@@ -594,7 +586,7 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
       } else if (LEAD){ if (j < n && live) rowp[j] = upM; }
       // this column is done: its boundary (if a band below reads it from the ring) is stored, and the ring slot the band above filled for it
       // has been read — both in front of the counter's store, and a wavefront's LDS operations execute in order
-      if (!(FIRST && LAST)){ asm volatile("" ::: "memory"); prog_write(a_me, base + j + 1); }
+      if (!BAR && !(FIRST && LAST)){ asm volatile("" ::: "memory"); prog_write(a_me, base + j + 1); }
       if (EL) e_write((j + 1) & 1, nx_rd, nx_blc, nx_blw);       // the next column's emissions (its values were requested at the top of this one)
       diagM = topM; diagD = topD;                // top boundary of this column = diagonal of the band's first row next column
       if (j == n-1 && live){
@@ -602,6 +594,7 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
         for (int r = 0; r < NR; r++) lt[row0 + r] = Mp[r];           // last read column of this lane's read
       }
     }
+    if (BAR) coop_barrier(botg);
   }
   HS_FT_ADD(2, HS_FT_NOW() - t_sweep0_); HS_FT_ADD(3, (unsigned long long)nmax);
 }
@@ -609,12 +602,12 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
 template <int NR, bool LEAD, bool EL>
 __device__ __forceinline__ void band_dispatch_coop(bool first, bool last, const hs_dev_t& d, int lane, bool live, int n, int nmax, const double* col,
                                                    const hs_row_t* rows, int row0, int c0, const double* mr, double* bnd, bool topg, bool botg,
-                                                   hs_lds_cd2 lds_top, hs_lds_d2 lds_bot, double* lt, double* rowp, double* side_out, int w, hs_lds_i prog, int base, hs_lds_d2 ktab,
+                                                   hs_lds_cd2 lds_top, hs_lds_d2 lds_bot, double* lt, double* rowp, double* side_out, int w, hs_lds_i prog, int base, int nsteps, hs_lds_d2 ktab,
                                                    hs_lds_d2 etab, int npad){
-  if (first){ if (last) band_sweep_coop<NR, true, true, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, ktab, etab, npad);
-              else      band_sweep_coop<NR, true, false, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, ktab, etab, npad); }
-  else      { if (last) band_sweep_coop<NR, false, true, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, ktab, etab, npad);
-              else      band_sweep_coop<NR, false, false, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, ktab, etab, npad); }
+  if (first){ if (last) band_sweep_coop<NR, true, true, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, nsteps, ktab, etab, npad);
+              else      band_sweep_coop<NR, true, false, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, nsteps, ktab, etab, npad); }
+  else      { if (last) band_sweep_coop<NR, false, true, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, nsteps, ktab, etab, npad);
+              else      band_sweep_coop<NR, false, false, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, nsteps, ktab, etab, npad); }
 }
 
 // The rounds of one item: `n_rows` haplotype rows (after the block's first row) cut into bands, W bands per round, one per wavefront.
@@ -642,29 +635,25 @@ __device__ __forceinline__ void coop_rounds(const hs_dev_t& d, int w, int lane, 
     }
     const int base = gcol ? *gcol : 0;
     const int nb_round = min(W, nbands - g*W);
+    const int nsteps = nmax + nb_round - 1;              // (LEAD: the round's barrier steps, the same count in every wavefront)
     const int b = g*W + w;
     if (w < nb_round){
-#if HS_BAND_REM_LAST
-      const int nr = nr_base + (b >= nbands - nr_rem ? 1 : 0);           // the bands that take a row more are the LAST ones
-      const int row0 = 1 + b*nr_base + max(0, b - (nbands - nr_rem));
-#else
       const int nr = nr_base + (b < nr_rem ? 1 : 0);
       const int row0 = 1 + b*nr_base + min(b, nr_rem);
-#endif
       const bool first = (b == 0), last = (b + 1 == nbands);
       const bool topg = (w == 0) && (g > 0), botg = (w + 1 == nb_round) && !last;
       hs_lds_cd2 lds_top = (hs_lds_cd2)ring[w > 0 ? w - 1 : 0]; hs_lds_d2 lds_bot = (hs_lds_d2)ring[w];
       hs_lds_d2 ktab = (hs_lds_d2)ktabs[w];
       hs_lds_d2 etab = EL ? (hs_lds_d2)etabs[w] : (hs_lds_d2)ktabs[w];
       switch (nr){
-#define HS_COOP_CASE(N_) case N_: if (N_ <= R) band_dispatch_coop<(N_ <= R ? N_ : 1), LEAD, EL>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, ktab, etab, npad); break;
+#define HS_COOP_CASE(N_) case N_: if (N_ <= R) band_dispatch_coop<(N_ <= R ? N_ : 1), LEAD, EL>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, nsteps, ktab, etab, npad); break;
         HS_COOP_CASE(1) HS_COOP_CASE(2) HS_COOP_CASE(3) HS_COOP_CASE(4) HS_COOP_CASE(5) HS_COOP_CASE(6) HS_COOP_CASE(7) HS_COOP_CASE(8)
         HS_COOP_CASE(9) HS_COOP_CASE(10) HS_COOP_CASE(11) HS_COOP_CASE(12) HS_COOP_CASE(13) HS_COOP_CASE(14) HS_COOP_CASE(15) HS_COOP_CASE(16)
         HS_COOP_CASE(17) HS_COOP_CASE(18) HS_COOP_CASE(19) HS_COOP_CASE(20)
 #undef HS_COOP_CASE
-        default: break;
+        default: if (LEAD) for (int t = 0; t < nsteps; t++) coop_barrier(false); break;
       }
-    }
+    } else if (LEAD) for (int t = 0; t < nsteps; t++) coop_barrier(false);       // a wavefront without a band in this round keeps the step count
     if (gcol){
       *gcol = base + nmax;
       asm volatile("" ::: "memory");
@@ -1152,91 +1141,6 @@ __device__ __forceinline__ double pw_eval(const hs_dev_t& d, const StrLds& L, in
 //     an absent term adds +0.0 to the non-negative sum in pw_eval.
 // xx: the lane's column in the group's tables;  Eb: byte address (LDS) of E[0][0];  plane stride XC*8 bytes.
 struct PwSlots { int v[2*HS_PW_SLOTS]; };
-template <int XC>
-__device__ __forceinline__ double pw_eval_grp(const PwSlots& S, const double* ilog, double log_thresh, int Eb, int xx, double lp0, int lim, int nsub, int stride, int tail){
-  auto lo = [&](int sl){ return S.v[2*sl]; };
-  auto hi = [&](int sl){ return S.v[2*sl + 1]; };
-  auto dbl = [&](int sl){ return __hiloint2double(S.v[2*sl + 1], S.v[2*sl]); };
-  auto ldb = [&](int byte_addr) -> double { return *(const __attribute__((address_space(3))) double*)(uintptr_t)(uint32_t)byte_addr; };
-  const int nseg = lo(0), term_ni = hi(0);
-  const int r0 = lo(1), U0 = hi(1), r1 = lo(3), U1 = hi(3), r2 = lo(5), U2 = hi(5);
-  const int b0 = lo(7), c0 = hi(7), b1 = lo(8), c1 = hi(8);
-  const int pa = lo(9), pb = hi(9);
-  auto plane = [&](int ch){ return ((ch >> 1) & 3) * (XC*8); };
-  const double L0 = lp0;
-  double L1 = L0;
-  const bool a_b0 = b0 < lim;
-  {
-    const int pla = plane(c0), plb = plane(c0 >> 8);
-    double t = L0;
-#pragma unroll
-    for (int m = 1; m <= nsub; m++){
-      const int ca = Eb + 8*max(xx - b0 - m*stride, 0);        // a lane past its bound may point in front of its read: not used
-      const double ea = ldb(ca + pla), eb = ldb(ca + plb);
-      t -= ea; t += eb;
-    }
-    L1 = a_b0 ? t : L0;                                        // (below its bound a lane takes every step, beyond it none)
-  }
-  double L2 = L1;
-  bool a_b1 = false;
-  if (nseg >= 2){
-    a_b1 = b1 < lim;
-    const int pla = plane(c1), plb = plane(c1 >> 8);
-    double t = L1;
-#pragma unroll
-    for (int m = 1; m <= nsub; m++){
-      const int ca = Eb + 8*max(xx - b1 - m*stride, 0);
-      const double ea = ldb(ca + pla), eb = ldb(ca + plb);
-      t -= ea; t += eb;
-    }
-    L2 = a_b1 ? t : L1;
-  }
-  const double Llast = L2;                                     // nseg == 1: L2 = L1
-  const double Lfin = L2;                                      // a_b1 ? L2 : (a_b0 ? L1 : L0): the selects above already did that
-  const bool a_r0 = (U0 > 0) && (r0 < lim), a_r1 = (U1 > 0) && (r1 < lim), a_r2 = (U2 > 0) && (r2 < lim);
-  const int np = min(max(lim - pa, 0), pb - pa);
-  int ns = term_ni;
-  if (pb > pa) ns = (lim < pb) ? max(lim, pa) : ns;
-  if (U2 > 0) ns = (r2 >= lim) ? r2 : ns;
-  if (nseg >= 2) ns = (b1 >= lim) ? b1 : ns;
-  if (U1 > 0) ns = (r1 >= lim) ? r1 : ns;
-  ns = (b0 >= lim) ? b0 : ns;
-  if (U0 > 0) ns = (r0 >= lim) ? r0 : ns;
-  const bool a_t = ns < tail;
-  // The eight pushed values; one that is absent for this lane is -1e300: it loses every maximum and fails the threshold, i.e. adds the
-  // +0.0 pw_eval adds for it.  Branch-free, two float exponentials per packed operation (each half rounded on its own, like the scalar
-  // ones); a term that passes the threshold has 1.44 dd > -10, so fasterexp's clamp at -126 (fastonebigheader.h:210) cannot act on it.
-  // (a level that is not this lane's — L1 without the first break, L2 without the second, the plain entries' level with none in reach —
-  //  equals the level before it: harmless in the maximum, and its term is switched off by its own condition instead of by a select)
-  constexpr double NEG = -1.0e300;
-  const double v0 = L0, v2 = L1, v4 = L2;
-  const double v1 = a_r0 ? dbl(2) + L0 : NEG;
-  const double v3 = a_r1 ? dbl(4) + L1 : NEG;
-  const double v5 = a_r2 ? dbl(6) + L2 : NEG;
-  const double v7 = a_t ? ilog[max(tail - ns, 0)] + Lfin : NEG;
-  double mx = fmax(fmax(fmax(v0, v1), fmax(v2, v3)), fmax(fmax(v4, v5), v7));       // (the plain entries' level is L2: already in)
-  typedef float hs_f2 __attribute__((ext_vector_type(2)));
-  double tot = 0.0;
-  auto pair = [&](double a, bool on_a, double b, bool on_b, double wa){
-    const double dd0 = a - mx, dd1 = b - mx;
-    hs_f2 x; x.x = (float)dd0; x.y = (float)dd1;
-    const hs_f2 z = (x * 1.442695040f + 126.94269504f) * 8388608.0f;
-    const float fe0 = (on_a && dd0 > log_thresh) ? __uint_as_float(__float2uint_rz(z.x)) : 0.0f;
-    const float fe1 = (on_b && dd1 > log_thresh) ? __uint_as_float(__float2uint_rz(z.y)) : 0.0f;
-    tot += wa * (double)fe0;                                         // (wa = 1.0 except for the plain entries: equal float terms, the product is exact)
-    tot += (double)fe1;
-  };
-  pair(v0, true, v1, true, 1.0);
-  pair(v2, a_b0, v3, true, 1.0);
-  pair(v4, a_b1, v5, true, 1.0);
-  if (pb > pa) pair(Llast, np > 0, v7, true, (double)np);            // (the same for every lane: most lists have no plain entries)
-  else {
-    const double dd = v7 - mx;
-    const float zz = ((float)dd * 1.442695040f + 126.94269504f) * 8388608.0f;
-    tot += (double)((dd > log_thresh) ? __uint_as_float(__float2uint_rz(zz)) : 0.0f);
-  }
-  return mx + (double)f_fasterlog((float)tot);
-}
 
 // visit_eval for the grouped layout (round 4): a list that has no closed form — three and more interruptions of the repeat — replayed
 // entry by entry like visit_eval, but inside hs_str_group_kernel_pw: the entries are the same for every lane (scalar loads from the visit
@@ -1286,108 +1190,14 @@ __device__ __forceinline__ double visit_eval_grp(const hs_visit_t* __restrict__ 
   return acc.finish();
 }
 
-// The piecewise closed form with up to HS_PWK_MAX breaks (round 4; prep.cpp piecewise_k, layout.h HS_PWK_SLOTS): lists of blocks with two
-// or three interruptions — [run?] break [run?] break ... [run?] plain ... plain terminal.  The running likelihood changes only at the breaks,
-// so the pushes of visit_eval_grp are: L0 | ln U_s + L_s of segment s' run | L_{s+1} behind break s | L_nseg once per plain entry | the tail
-// term — each present only if its offset is below the lane's bound.  One pass over the segments builds the levels (kept in registers),
-// the maximum and the first offset at or beyond the bound; a second one sums the float exponentials, two per packed operation.  Same
-// values into the same float log-sum-exp as the replay (the float terms are summed in double: exact in any order).
-// The slots are the same for every lane: scalar loads through the constant address space, the loops over segments unrolled with scalar
-// guards (nseg is the list's, not the lane's).
-#ifndef HS_PWK_SKIP
-#define HS_PWK_SKIP 0         // 1: a pair of terms that is under the threshold for every lane of the wavefront skips its exponentials — measured 2.5 % SLOWER (2 / 3
-                              // inherited interruptions: STR phase 127 -> 131, 156 -> 160 ms per 400 loci): the columns of a wavefront rarely agree on which levels are dead
-#endif
-template <int XC>
-__device__ __forceinline__ double pwk_eval_grp(const double* __restrict__ slots_g, const double* ilog, double log_thresh, int Eb, int xx, double lp0, int lim,
-                                               int nsub, int stride, int tail){
-  typedef int hs_i2k __attribute__((ext_vector_type(2)));
-  typedef const __attribute__((address_space(4))) hs_i2k* hs_slot_k;
-  const hs_slot_k D = (hs_slot_k)(uintptr_t)slots_g;
-  auto ldb = [&](int byte_addr) -> double { return *(const __attribute__((address_space(3))) double*)(uintptr_t)(uint32_t)byte_addr; };
-  auto plane = [&](int ch){ return ((ch >> 1) & 3) * (XC*8); };
-  const hs_i2k h0 = D[0], h1 = D[1];
-  const int nseg = h0.x, term_ni = h0.y, pa = h1.x, pb = h1.y;
-  constexpr double NEG = -1.0e300;
-  double Lv[HS_PWK_MAX + 1];                                  // levels (the run values are formed again in the second pass: one addition each, seven registers less)
-  Lv[0] = lp0;
-  double mx = lp0;
-  unsigned u = (unsigned)(term_ni - lim);                     // first offset at or beyond the bound, minus the bound (the terminal entry is one)
-#pragma unroll
-  for (int s = 0; s <= HS_PWK_MAX; s++){
-    if (s < HS_PWK_MAX) Lv[s + 1] = Lv[s];
-    if (s <= nseg){
-      const hs_i2k run = D[2 + 3*s];
-      if (run.y > 0){
-        const hs_i2k lu = D[3 + 3*s];
-        const double v = __hiloint2double(lu.y, lu.x) + Lv[s];
-        mx = fmax(mx, (run.x < lim) ? v : NEG);
-        u = min(u, (unsigned)(run.x - lim));
-      }
-      if (s < HS_PWK_MAX && s < nseg){
-        const hs_i2k brk = D[4 + 3*s];
-        const int b = brk.x, pla = plane(brk.y), plb = plane(brk.y >> 8);
-        double t = Lv[s];
-        for (int m = 1; m <= nsub; m++){
-          const int ca = Eb + 8*max(xx - b - m*stride, 0);      // a lane past its bound may point in front of its read: not used
-          const double ea = ldb(ca + pla), eb = ldb(ca + plb);
-          t -= ea; t += eb;
-        }
-        Lv[s + 1] = (b < lim) ? t : Lv[s];                       // an unreached level equals the one before it: harmless in the maximum
-        mx = fmax(mx, Lv[s + 1]);
-        u = min(u, (unsigned)(b - lim));
-      }
-    }
-  }
-  double Llast = Lv[0];
-#pragma unroll
-  for (int s = 1; s <= HS_PWK_MAX; s++) Llast = (s <= nseg) ? Lv[s] : Llast;       // (scalar condition)
-  const int np = min(max(lim - pa, 0), pb - pa);
-  if (pb > pa) u = min(u, (lim < pb) ? (unsigned)max(pa - lim, 0) : 0xffffffffu);
-  const int ns = (int)u + lim;
-  const bool a_t = ns < tail;
-  const double v_t = a_t ? ilog[max(tail - ns, 0)] + Llast : NEG;
-  mx = fmax(mx, v_t);
-  typedef float hs_f2 __attribute__((ext_vector_type(2)));
-  double tot = 0.0;
-  auto pair = [&](double a, bool on_a, double b, double wa){       // (b is NEG where its term is absent: it fails the threshold)
-    const double dd0 = a - mx, dd1 = b - mx;
-    const bool t0 = on_a && dd0 > log_thresh, t1 = dd1 > log_thresh;
-#if HS_PWK_SKIP
-    // a level one mismatch of a good base below the maximum is under the threshold (ln 0.001): where neither term counts for any lane of the
-    // wavefront the exponentials are left out — they would add +0.0
-    if (!__any(t0 || t1)) return;
-#endif
-    hs_f2 x; x.x = (float)dd0; x.y = (float)dd1;
-    const hs_f2 z = (x * 1.442695040f + 126.94269504f) * 8388608.0f;
-    const float fe0 = t0 ? __uint_as_float(__float2uint_rz(z.x)) : 0.0f;
-    const float fe1 = t1 ? __uint_as_float(__float2uint_rz(z.y)) : 0.0f;
-    tot += wa * (double)fe0;
-    tot += (double)fe1;
-  };
-  auto run_value = [&](int s) -> double {                          // ln U_s + L_s where segment s has a run below the lane's bound, else NEG
-    const hs_i2k run = D[2 + 3*s];
-    if (run.y <= 0) return NEG;                                    // (scalar)
-    const hs_i2k lu = D[3 + 3*s];
-    const double v = __hiloint2double(lu.y, lu.x) + Lv[s];
-    return (run.x < lim) ? v : NEG;
-  };
-  pair(Lv[0], true, run_value(0), 1.0);
-#pragma unroll
-  for (int s = 1; s <= HS_PWK_MAX; s++){
-    if (s <= nseg){
-      const hs_i2k brk = D[4 + 3*(s - 1)];
-      pair(Lv[s], brk.x < lim, run_value(s), 1.0);
-    }
-  }
-  pair(Llast, np > 0, v_t, (double)np);                           // equal float terms: the product is exact
-  return mx + (double)f_fasterlog((float)tot);
-}
-
-
-// ------------------------------------------------------------------ round 5: the two closed forms again, written for the list LOOP of str_group_body
-// (HS_EVAL_LOOP): one instance of each in the kernel instead of thirteen — the 13-list evaluation of hs_str_group_kernel_rp was 90 KB of
-// straight-line code per allele against an instruction cache of 64 KB per CU pair — and fewer vector instructions per pushed value:
+// ------------------------------------------------------------------ the closed forms of the grouped kernels' interrupted lists (round 5's lean forms; the round-4
+// evaluators pw_eval_grp / pwk_eval_grp they replaced and the list LOOP they were first written for are gone: measured slower, profiles/r05_notes.md).
+// The piecewise closed form with up to HS_PWK_MAX breaks (prep.cpp piecewise_k, layout.h HS_PWK_SLOTS): lists of blocks with two or three
+// interruptions — [run?] break [run?] break ... [run?] plain ... plain terminal.  The running likelihood changes only at the breaks, so the
+// pushes of visit_eval_grp are: L0 | ln U_s + L_s of segment s' run | L_{s+1} behind break s | L_nseg once per plain entry | the tail term —
+// each present only if its offset is below the lane's bound.  One pass over the segments builds the levels (kept in registers), the maximum
+// and the first offset at or beyond the bound; a second one sums the float exponentials, two per packed operation.  Same values into the
+// same float log-sum-exp as the replay (the float terms are summed in double: exact in any order).  What keeps the instruction count down:
 //   * the emission of (column xx - off, block base c) is one v_add: A0 = byte address of the lane's column in plane 0 of the emission
 //     table, minus a scalar 8 off - plane(c).  No clamp: the table lies 16 KB into the carve (deletion table, rowP, match_probs_ in front),
 //     a bound is at most 1024 + 36 columns, so a lane past its bound reads some double in front of its read that the level's select drops;
@@ -1396,7 +1206,7 @@ __device__ __forceinline__ double pwk_eval_grp(const double* __restrict__ slots_
 //     [116.9, 126.95] ⊂ [64, 128), so 2^23 y is the integer (2^23 + mantissa) 2^6 — (bits(y) << 6) + 2^31 (mod 2^32) — exactly what
 //     fasterexp converts (fastonebigheader.h:206-218); a term under the threshold is switched off as before;
 //   * the switch acts on the 32-bit float, not on its double.
-// Same values into the same float log-sum-exp: bit-identical to pw_eval_grp / pwk_eval_grp (GPU suite + fuzzers through this path).
+// Same values into the same float log-sum-exp as the entry-by-entry replay (tests/cpp/pwk_form_test.cpp, GPU suite + fuzzers).
 typedef int hs_i2k __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) hs_i2k* hs_slot_k;
 typedef float hs_f2 __attribute__((ext_vector_type(2)));
@@ -1449,7 +1259,7 @@ __device__ __forceinline__ double emis_chain(double t, int A0, int sa, int sb, i
   return t;
 }
 
-// pw_eval_grp (one or two breaks, ten slots), lean form.  A0: see above; stride8 = 8 x stride.
+// One or two breaks, ten slots (the grouped layout's pw_eval).  A0: see above; stride8 = 8 x stride.
 template <int XC>
 __device__ __forceinline__ double pw_eval_lean(const PwSlots& S, const double* ilog, double log_thresh, int A0, double lp0, int lim,
                                                int nsub, int stride8, int tail){
@@ -1513,47 +1323,18 @@ __device__ __forceinline__ double pw_eval_lean(const double* __restrict__ slots_
 }
 
 
-#ifndef HS_LEAN_ASSUME
-#define HS_LEAN_ASSUME 1   // pwk_eval_lean is told that a K-level list has three to six breaks: the first three segments lose their scalar guards and the scheduler
-                           // moves their LDS reads ahead (two / three inherited interruptions: STR phase 117.8 -> 110.1 / 140.2 -> 131.6 ms per 400 loci)
-#endif
-#ifndef HS_LEAN_SPEC
-#define HS_LEAN_SPEC 0     // 1: one instance of pwk_eval_lean per number of breaks (3..6), picked by a scalar switch: no guard per segment at all
-#endif
-#ifndef HS_LEAN_NS
-#define HS_LEAN_NS 0       // 1: pwk_eval_lean forms the stop offset with one select per entry instead of a subtraction and a minimum (measured 3 % slower: more scalar work per segment)
-#endif
-// pwk_eval_grp (three to HS_PWK_MAX breaks, 24 slots), lean form: the list's slots are fetched together (three wide scalar loads, one
+// Three to HS_PWK_MAX breaks, 24 slots: the list's slots are fetched together (three wide scalar loads, one
 // wait) and stay in scalar registers through both passes.
 template <int XC, int NSEG>      // NSEG > 0: the list's number of breaks, known at compile time; 0: read from the slots
 __device__ __forceinline__ double pwk_eval_lean_n(const hs_i2k (&ds)[HS_PWK_SLOTS], const double* ilog, double log_thresh, int A0, double lp0, int lim,
                                                   int nsub, int stride8, int tail){
   const int nseg = NSEG > 0 ? NSEG : ds[0].x, term_ni = ds[0].y, pa = ds[1].x, pb = ds[1].y;
-#if HS_LEAN_ASSUME
   __builtin_assume(nseg >= 3 && nseg <= HS_PWK_MAX);          // (prep.cpp piecewise_k: what makes a list this shape) — the first three segments without scalar guards
-#endif
   constexpr double NEG = -1.0e300;
   double Lv[HS_PWK_MAX + 1];
   Lv[0] = lp0;
   double mx = lp0;
-#if HS_LEAN_NS
-  // The first offset of the list at or beyond the lane's bound (the replay's nistop), one select per entry: the entries are in ascending
-  // order, so "entry i is below the bound" moves the candidate to the entry behind it — a scalar known from the slots.
-  const int o_after = (pb > pa) ? pa : term_ni;
-  int nxt_run[HS_PWK_MAX + 1], nxt_brk[HS_PWK_MAX + 1], first_of[HS_PWK_MAX + 2];
-  first_of[HS_PWK_MAX + 1] = o_after;
-#pragma unroll
-  for (int s = HS_PWK_MAX; s >= 0; s--){
-    const int after_seg = (s >= nseg) ? o_after : first_of[s + 1];
-    const int bs = ds[4 + 3*s].x;                           // (slot 22 behind the last segment: unused, zero)
-    nxt_brk[s] = after_seg;
-    nxt_run[s] = (s < nseg) ? bs : after_seg;
-    first_of[s] = (ds[2 + 3*s].y > 0) ? ds[2 + 3*s].x : nxt_run[s];
-  }
-  int ns = first_of[0];
-#else
   unsigned u = (unsigned)(term_ni - lim);                     // first offset at or beyond the bound, minus the bound (the terminal entry is one)
-#endif
 #pragma unroll
   for (int s = 0; s <= HS_PWK_MAX; s++){
     if (s < HS_PWK_MAX) Lv[s + 1] = Lv[s];
@@ -1563,11 +1344,7 @@ __device__ __forceinline__ double pwk_eval_lean_n(const hs_i2k (&ds)[HS_PWK_SLOT
         const double v = __hiloint2double(ds[3 + 3*s].y, ds[3 + 3*s].x) + Lv[s];
         const bool act = run.x < lim;
         mx = fmax(mx, LeanAcc::neg_unless(act, v));
-#if HS_LEAN_NS
-        ns = act ? nxt_run[s] : ns;
-#else
         u = min(u, (unsigned)(run.x - lim));
-#endif
       }
       if (s < HS_PWK_MAX && s < nseg){
         const hs_i2k brk = ds[4 + 3*s];
@@ -1577,11 +1354,7 @@ __device__ __forceinline__ double pwk_eval_lean_n(const hs_i2k (&ds)[HS_PWK_SLOT
         const bool act = b < lim;
         Lv[s + 1] = act ? t : Lv[s];                             // an unreached level equals the one before it: harmless in the maximum
         mx = fmax(mx, Lv[s + 1]);
-#if HS_LEAN_NS
-        ns = act ? nxt_brk[s] : ns;
-#else
         u = min(u, (unsigned)(b - lim));
-#endif
       }
     }
   }
@@ -1589,12 +1362,8 @@ __device__ __forceinline__ double pwk_eval_lean_n(const hs_i2k (&ds)[HS_PWK_SLOT
 #pragma unroll
   for (int s = 1; s <= HS_PWK_MAX; s++) Llast = (s <= nseg) ? Lv[s] : Llast;       // (scalar condition)
   const int np = min(max(lim - pa, 0), pb - pa);
-#if HS_LEAN_NS
-  if (pb > pa) ns = (lim > pa) ? ((lim < pb) ? lim : term_ni) : ns;
-#else
   if (pb > pa) u = min(u, (lim < pb) ? (unsigned)max(pa - lim, 0) : 0xffffffffu);
   const int ns = (int)u + lim;
-#endif
   const double v_t = LeanAcc::neg_unless(ns < tail, ilog[max(tail - ns, 0)] + Llast);
   mx = fmax(mx, v_t);
   LeanAcc acc; acc.log_thresh = log_thresh; acc.tot = 0.0; acc.mx = mx;
@@ -1620,16 +1389,7 @@ __device__ __forceinline__ double pwk_eval_lean(const double* __restrict__ slots
   hs_i2k ds[HS_PWK_SLOTS];
 #pragma unroll
   for (int t = 0; t < HS_PWK_SLOTS; t++) ds[t] = D[t];
-#if HS_LEAN_SPEC
-  switch (ds[0].x){                                             // (scalar)
-    case 3:  return pwk_eval_lean_n<XC, 3>(ds, ilog, log_thresh, A0, lp0, lim, nsub, stride8, tail);
-    case 4:  return pwk_eval_lean_n<XC, 4>(ds, ilog, log_thresh, A0, lp0, lim, nsub, stride8, tail);
-    case 5:  return pwk_eval_lean_n<XC, 5>(ds, ilog, log_thresh, A0, lp0, lim, nsub, stride8, tail);
-    default: return pwk_eval_lean_n<XC, 6>(ds, ilog, log_thresh, A0, lp0, lim, nsub, stride8, tail);
-  }
-#else
   return pwk_eval_lean_n<XC, 0>(ds, ilog, log_thresh, A0, lp0, lim, nsub, stride8, tail);
-#endif
 }
 
 }  // namespace
@@ -1765,10 +1525,7 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin, in
 
     // --- StutterAlignerClass::load_read (StutterAlignerClass.cpp:12-53): match_probs_ and del_probs_
     // (a block that ends with the previous allele's block only appends terms to that allele's sums)
-#ifndef HS_ABLATE
-#define HS_ABLATE 0          // timing experiments only (tools/ablate_str.sh): 1 no final LSE, 2 no artifact terms, 3 no match/deletion tables, 4 no read-end deletion sums, 6 first chunk only
-#endif
-    const int t0 = (HS_ABLATE == 3) ? min(B, n) : (chained ? min(prev_B, n) : 0);
+    const int t0 = chained ? min(prev_B, n) : 0;
     prev_B = B;
     const int tmax = min(B, n);
     if (t0 < tmax)                      // a continued block that already covered the whole read side adds nothing
@@ -1866,7 +1623,6 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin, in
       // columns each size gains — and size 0 — are summed: nv p pairs instead of nv (nv + 1) p / 2 (nv = c.nd sizes fit the block).
       const int nv = c.nd;
       const bool nd_reuse = (MODE == 0) && chained && ((oe >> 29) & 1) && (n >= nv*p);
-      if (HS_ABLATE == 4){} else
       if (nd_reuse){
         auto row_off = [&](int q){ return p*((q*(q+1)) >> 1); };           // size q holds (q+1)p columns, sizes back to back
         const int ncopy = row_off(nv - 1);                                // rows 0..nv-2 -> rows 1..nv-1, read completely before the first write
@@ -1908,7 +1664,7 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin, in
     }
     wave_lds_sync();
 
-    for (int kk = 0; kk < ((HS_ABLATE == 6) ? 1 : ncyc); kk++){
+    for (int kk = 0; kk < ncyc; kk++){
       const int jraw = lane + 64*kk;
       const bool actj = jraw < n;
       const int j = min(jraw, n-1);
@@ -1917,7 +1673,6 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin, in
       // kept in a rotating register window; fast_log_sum_exp (mathops.cpp:97-106) does not depend on their order.
       double terms[HS_NART];
       auto finish_chunk = [&](){                     // fast_log_sum_exp over the 13 artifact terms (mathops.cpp:97-106)
-        if (HS_ABLATE == 1){ double sx = 0; for (int t = 0; t < HS_NART; t++) sx = fmax(sx, terms[t]); if (actj) mr_out[j] = sx; return; }
         Lse acc;
         for (int pass = 0; pass < 2; pass++){
           acc.start(pass, terms[0]);
@@ -1931,7 +1686,6 @@ __device__ __forceinline__ void str_body(const hs_dev_t& d, int active_begin, in
         // Bnd[e] sends the chunk through the long form below (rare: a float rounding boundary within reach of lp0's rounding error)
         double lp0_max = 0.0;                        // largest |lp0| of the lane's 12 evaluations, against the smallest Bnd of the table
         auto tab_eval = [&](double lp0, int lim, int k) -> double {
-          if (HS_ABLATE == 2) return lp0 + (double)lim;
           const int e = rdlane(tbase, k) + min(lim, 1) + max(lim - rdlane(shapes, k), 0);
           const double A = L.tab[e], G = L.tab[HS_TAB_CAP + e];
           lp0_max = fmax(lp0_max, fabs(lp0));
@@ -2197,19 +1951,6 @@ hs_str_kernel_generic(const hs_dev_t* __restrict__ dp, int active_begin, int pw_
 #else
 #define HS_TICK(k) do {} while (0)
 #endif
-#ifndef HS_EVAL_LOOP
-#define HS_EVAL_LOOP 0     // 1: hs_str_group_kernel_pw / _rp run the twelve artifact lists as a loop around one instance of each evaluator — a sixth of the code, bit-identical,
-                           // and SLOWER than the unrolled form (400 loci, STR phase: imperfect 89 -> 100 ms, two inherited interruptions 128 -> 126): profiles/r05_notes.md
-#endif
-#ifndef HS_LEAN
-#define HS_LEAN 1          // the K-level lists through pwk_eval_lean instead of pwk_eval_grp (two / three inherited interruptions: STR phase -8 % / -10 %)
-#endif
-#ifndef HS_LEAN_PW
-#define HS_LEAN_PW 1       // ... and the one- or two-break lists through pw_eval_lean on the slots fetched as before (once for the six insertion sizes): -1 %
-#endif
-#ifndef HS_GABL
-#define HS_GABL 0          // timing experiments only (results invalid): 1 no read-end sums, 2 no evaluation, 3 no table phase, 4 no barriers, 5 no chains; valid results: 6 read-end sums twice, 7 evaluation twice
-#endif
 struct GrpLds {
   double* rowP; double* Mt; double* Dl;
   double* E;            // [4][XC] emission log of every column against A, C, T, G (code = (char >> 1) & 3): one read instead of base + qualities + compare
@@ -2234,7 +1975,7 @@ extern "C" size_t hs_str_group_lds_bytes(int max_B, int nd_cap, int with_ilog){
 // KIND 0: tabulated alleles, positions [0, n_tab) (or [0, n_short)) of the side's order.  KIND 1 (hs_str_group_kernel_pw): the alleles with
 // piecewise simple lists, positions [n_tab, n_pw) — interrupted repeats: the same table phase and read-end sums (their blocks are
 // not periodic: nothing is inherited from allele to allele but the match / deletion tables of a block that ends with the previous one),
-// every list evaluated by the closed form its shape names (table entry or pw_eval_grp).
+// every list evaluated by the closed form its shape names (table entry or pw_eval_lean).
 template <int KIND>
 __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin, int short_only){
   constexpr int XC = HS_GRP_COLS, NT = HS_GRP_COLS;
@@ -2361,7 +2102,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     const int shapes = nx_shapes, tbase = nx_tbase;
     const double tab_bmin = uni(nx_bmin);
     if (slot != cur_slot){          // M of the row before the STR block, from the leading-flank kernel: the previous allele's readers first
-      if (HS_GABL != 4) __syncthreads();
+      __syncthreads();
       if (actj) L.rowP[xrp] = lead_base[(int64_t)slot*lead_stride];
       cur_slot = slot;
     }
@@ -2392,7 +2133,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       }
     }
     HS_TICK(0);   // phase 3 of the previous allele + setup
-    if (HS_GABL != 4) __syncthreads();                // ... and every wavefront is done with the previous allele's Mt / Dl
+    __syncthreads();                // ... and every wavefront is done with the previous allele's Mt / Dl
     HS_TICK(1);   // barrier 1 wait
     const double* cstl = L.cstl0 + par*24;
     const double2* tab = L.tab0 + par*HS_TAB_CAP;
@@ -2404,7 +2145,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     const int t0 = chained ? prev_B : 0;
     prev_B = B;
     const int tmax = min(B, jmaxw + 1);          // a step t > j is masked: no lane of this wavefront goes past its largest column
-    if (wave_act && t0 < tmax && HS_GABL != 3){
+    if (wave_act && t0 < tmax){
       double lp = (t0 > 0) ? L.Mt[xx] : 0.0;
       const int ndp = nv * p;
       int t = t0;
@@ -2463,12 +2204,12 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
     HS_TICK(2);   // phase 1
     // --- deletion start values of the columns whose segment reaches the read end (the `else` branch of StutterAlignerClass.cpp:117-120),
     // (size, column) pairs of all reads of the group spread over the workgroup's lanes; layout per read as in str_body
-    for (int rep = 0; rep < ((HS_GABL == 6) ? 2 : 1); rep++){
+    {
       asm volatile("" ::: "memory");
       auto nd_sum = [&](int q, int xcol, int jcol, bool valid, int dst){
         const int aD = (q+1)*p;
         const int len = min(B - aD, jcol + 1);
-        const int lmin = (HS_GABL == 5) ? 0 : uni(wave_min_i(len)), lmax = (HS_GABL == 5) ? 0 : uni(wave_max_i(len));
+        const int lmin = uni(wave_min_i(len)), lmax = uni(wave_max_i(len));
         double lp = cstl[14 + q];
         // step t pairs read column xcol - t with block base B-1-aD - t, four steps per group.  The chain of additions is the critical
         // path of the allele, so its operands run ahead of it: plane offsets two groups ahead, emissions one group ahead.
@@ -2520,7 +2261,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       };
       auto row_off = [&](int q){ return p*((q*(q+1)) >> 1); };
       const bool reuse_al = chained && ((oe >> 29) & 1);
-      if (reuse_al && rep == 0) nd_base = (nd_base + HS_MAXREP - 1) % HS_MAXREP;
+      if (reuse_al) nd_base = (nd_base + HS_MAXREP - 1) % HS_MAXREP;
       auto slot_of = [&](int q){ int sl = nd_base + q; sl -= (sl >= HS_MAXREP) ? HS_MAXREP : 0; return sl*sixp; };     // row of size q
       // Work of the group for this allele.  Usual case (every side of the group holds all six deletion sizes, so all reads count
       // alike): closed-form numbering, size-major so that the sums of a wavefront have (nearly) the same length.  Otherwise lane
@@ -2538,7 +2279,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
         if (reuse_al){
           const int n_sums = nv*Gp;                                // e = (q G + h) p + off
           const float rc_gp = __builtin_amdgcn_rcpf((float)Gp);
-          for (int base = 0; base < ((HS_GABL == 1) ? 0 : n_sums); base += NT){
+          for (int base = 0; base < n_sums; base += NT){
             if (base + (xw & ~63) >= n_sums) continue;             // whole wavefront past the end (wave-uniform)
             const int e = min(base + xw, n_sums - 1);
             const int q = udiv(e, Gp, rc_gp), r = e - q*Gp, hh = udiv(r, p, rc_p), off = r - hh*p;
@@ -2547,7 +2288,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
           }
         } else {
           const int n_sums = G*row_off(nv);                        // size q: G reads x (q+1)p columns, sizes back to back from G row_off(q)
-          for (int base = 0; base < ((HS_GABL == 1) ? 0 : n_sums); base += NT){
+          for (int base = 0; base < n_sums; base += NT){
             if (base + (xw & ~63) >= n_sums) continue;
             const int e = min(base + xw, n_sums - 1);
             int q = 0;
@@ -2582,7 +2323,7 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
           if (e >= ph){ hh = h + 1; loc_e = e - ph; }
         }
       };
-      for (int base = 0; base < ((HS_GABL == 1) ? 0 : n_sums); base += NT){
+      for (int base = 0; base < n_sums; base += NT){
         const int wbase = base + (xw & ~63);
         if (wbase >= n_sums) continue;                        // whole wavefront past the end (wave-uniform)
         const int e = min(base + xw, n_sums - 1);
@@ -2610,81 +2351,17 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       }
     }
     HS_TICK(3);   // nd section
-    if (HS_GABL != 4) __syncthreads();
+    __syncthreads();
 
     HS_TICK(4);   // barrier 2 wait
     if (KIND >= 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pw_touch) :: "memory");      // (long since there; the register is free again)
     // --- the 13 artifact terms of this lane's column (HapAligner.cpp:62-109) and their fast_log_sum_exp
-    for (int rep3 = 0; rep3 < ((HS_GABL == 7) ? 2 : 1); rep3++)
-    if (wave_act && HS_GABL != 2){
+    if (wave_act){
       asm volatile("" ::: "memory");
       double terms[HS_NART];
       double lp0_max = 0.0;
       const int Eb = (int)(uintptr_t)(__attribute__((address_space(3))) char*)L.E;
-      if (KIND >= 1 && HS_EVAL_LOOP){
-        // Round 5: the twelve artifact lists as a LOOP — deletion sizes p..6p, then insertion sizes p..6p — around one instance of each
-        // evaluator (see pw_eval_lean).  The thirteen terms live in registers picked by the loop counter (wave-uniform: register-indexed
-        // moves), and fast_log_sum_exp does not mind the order they are formed in.
-        const int A0 = Eb + 8*xx;
-        {
-          const int len = min(B, j + 1);
-          terms[HS_MAXREP] = (rdlane(cst, HS_MAXREP) + L.Mt[xx]) + L.rowP[xrp - len];
-        }
-        double li = 0.0;
-        int li_col = xx - nd_eq*p, li_left = j - nd_eq*p;
-#pragma nounroll
-        for (int it = 0; it < 2*HS_MAXREP; it++){
-          const bool is_ins = it >= HS_MAXREP;
-          const int q = is_ins ? it - HS_MAXREP : it;
-          const int aD = (q + 1)*p;
-          const int tix = is_ins ? HS_MAXREP + 1 + q : HS_MAXREP - 1 - q;
-          double lp0; int lim, len, kk, nsub, tailv;
-          if (!is_ins){
-            if (B - aD < 0){ terms[tix] = IMP; continue; }
-            const int cq = min(aD, n);
-            len = min(B - aD, j + 1);
-            const bool direct = (j + aD <= n - 1);
-            const int xd = xx + min(aD, n - 1 - j);
-            const double dsum = L.Mt[xd] - L.Dl[q*L.ld + xd];
-            int slq = nd_base + q; slq -= (slq >= HS_MAXREP) ? HS_MAXREP : 0;
-            const double ndv = nd[ndb + slq*sixp + min(n - 1 - j, cq - 1)];
-            lp0 = direct ? rdlane(cst, 14 + q) + dsum : ndv;
-            lim = len; kk = q; nsub = 1; tailv = B - aD;
-          } else {
-            if (q < nd_eq) li = (j >= aD - 1) ? L.Dl[q*L.ld + xx] : L.Mt[xx];
-            else {
-              for (int m = 0; m < p; m++){           // m < period <= B for a tabulated block (prep.cpp)
-                const double e = Eat(li_col, boff[B-1-m]);
-                if (li_left >= 0) li += e;
-                li_col--; li_left--;
-              }
-            }
-            len = min(B + aD, j + 1);
-            lp0 = (rdlane(cst, 13) + li) + ((len > aD) ? L.Mt[xx - min(aD, j)] : 0.0);
-            lim = min(max(0, len - aD), B);            // a lane past the group's last column repeats it: its bound is a real one
-            kk = HS_MAXREP; nsub = q + 1; tailv = B;
-          }
-          const int strd = is_ins ? p : 0;
-          const int shp = rdlane(shapes, kk);
-          double S;
-          if (shp == HS_SHAPE_PIECEWISE)                        // (the same for every lane)
-            S = pw_eval_lean<XC>(pw_desc + kk*HS_PW_SLOTS, L.ilog, d.log_thresh, A0, lp0, lim, nsub, 8*strd, tailv);
-          else if (KIND == 2 && shp == HS_SHAPE_PWK)
-            S = pwk_eval_lean<XC>(pw_desc + (HS_MAXREP + 1)*HS_PW_SLOTS + kk*HS_PWK_SLOTS, L.ilog, d.log_thresh, A0, lp0, lim, nsub, 8*strd, tailv);
-          else if (KIND == 2 && shp == -1){
-            const hs_stropt_t* so = d.stropts + rdlane(a_sopt, k);
-            const int loff = uni(kk == HS_MAXREP ? so->ins_off : so->del_off[min(kk, HS_MAXREP - 1)]);
-            const int llen = uni(kk == HS_MAXREP ? so->ins_len : so->del_len[min(kk, HS_MAXREP - 1)]);
-            S = visit_eval_grp<XC>((const hs_visit_t*)d.visits + loff, llen, L.ilog, d.log_thresh, Eb, xx, lp0, lim, tailv, nsub, strd, tailv);
-          } else {
-            const int e = rdlane(tbase, kk) + min(lim, 1) + max(lim - shp, 0);
-            const double2 ag = tab[e];
-            lp0_max = fmax(lp0_max, fabs(lp0));
-            S = (lp0 + ag.x) + ag.y;
-          }
-          terms[tix] = (rdlane(cst, tix) + S) + L.rowP[xrp - len];
-        }
-      } else {
+      {
       const int k_allele = k;                                 // (the allele's lane in the fetched batch: the lambdas below use k for the list)
       auto load_pw = [&](int k) -> PwSlots {                  // the ten descriptor slots of list k into scalar registers
           PwSlots S;
@@ -2702,15 +2379,12 @@ __device__ __forceinline__ void str_group_body(const hs_dev_t& d, int item_begin
       auto tab_eval = [&](double lp0, int lim, int k, int nsub, int stride, int tail, const PwSlots* pre) -> double {
         const int shp = rdlane(shapes, k);
         if (KIND >= 1 && shp == HS_SHAPE_PIECEWISE){          // (the same for every lane)
-          if (pre) return HS_LEAN_PW ? pw_eval_lean<XC>(*pre, L.ilog, d.log_thresh, Eb + 8*xx, lp0, lim, nsub, 8*stride, tail)
-                                     : pw_eval_grp<XC>(*pre, L.ilog, d.log_thresh, Eb, xx, lp0, lim, nsub, stride, tail);
+          if (pre) return pw_eval_lean<XC>(*pre, L.ilog, d.log_thresh, Eb + 8*xx, lp0, lim, nsub, 8*stride, tail);
           const PwSlots S = load_pw(k);
-          return HS_LEAN_PW ? pw_eval_lean<XC>(S, L.ilog, d.log_thresh, Eb + 8*xx, lp0, lim, nsub, 8*stride, tail)
-                            : pw_eval_grp<XC>(S, L.ilog, d.log_thresh, Eb, xx, lp0, lim, nsub, stride, tail);
+          return pw_eval_lean<XC>(S, L.ilog, d.log_thresh, Eb + 8*xx, lp0, lim, nsub, 8*stride, tail);
         }
         if (KIND == 2 && shp == HS_SHAPE_PWK){                // three to six breaks: the K-level closed form (the same for every lane)
-          if (HS_LEAN) return pwk_eval_lean<XC>(pw_desc + (HS_MAXREP + 1)*HS_PW_SLOTS + k*HS_PWK_SLOTS, L.ilog, d.log_thresh, Eb + 8*xx, lp0, lim, nsub, 8*stride, tail);
-          return pwk_eval_grp<XC>(pw_desc + (HS_MAXREP + 1)*HS_PW_SLOTS + k*HS_PWK_SLOTS, L.ilog, d.log_thresh, Eb, xx, lp0, lim, nsub, stride, tail);
+          return pwk_eval_lean<XC>(pw_desc + (HS_MAXREP + 1)*HS_PW_SLOTS + k*HS_PWK_SLOTS, L.ilog, d.log_thresh, Eb + 8*xx, lp0, lim, nsub, 8*stride, tail);
         }
         if (KIND == 2 && shp == -1){                          // more: the list itself, replayed (the same for every lane)
           const hs_stropt_t* so = d.stropts + rdlane(a_sopt, k_allele);
@@ -2931,9 +2605,6 @@ hs_nd_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
 #ifndef HS_GTIME_EVERY
 #define HS_GTIME_EVERY 20000
 #endif
-#ifndef HS_PEXP
-#define HS_PEXP 0        // compile-time experiments (register pressure, timing; results invalid): 1 no evaluation, 2 no read-end sums, 3 no table phase
-#endif
 template <int P>
 __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_begin){
   constexpr int XC = HS_GRP_COLS, NT = HS_GRP_COLS;
@@ -3007,15 +2678,6 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
   // this column's read-end deletion sums (hs_nd_kernel): row r of the side's block + the column's distance from the read end
   const double* const ndp = d.ws_nd + (side ? d.ws[ai].nd[1] : d.ws[ai].nd[0]) + min(rj, SIXP - 1);
   const bool nd_lane = rj < SIXP;                      // (a column farther than the largest deletion from the read end takes every start value from the tables)
-#ifndef HS_PHOIST
-#define HS_PHOIST 0        // the insertions' two allele-independent lane values per size kept in registers (12) instead of recomputed per allele (3 operations each)
-#endif
-  int aInsM[HS_MAXREP], c8[HS_MAXREP];
-#pragma unroll
-  for (int q = 0; q < HS_MAXREP; q++){
-    aInsM[q] = 8*oMt + max(aM - 8*(q+1)*P, aZ);       // match_probs_ of column j - D if the segment is longer than the insertion (StutterAlignerClass.cpp:66), else the 0.0 in front of the read
-    c8[q] = max(j8p8 - 8*(q+1)*P, 0);                 // 8 max(0, j + 1 - D)
-  }                 // + 8 SIXP slot: this column's read-end sum of the size in that slot
   // ---- what an allele needs that is the same for every lane comes from its record (layout.h HS_GRP_REC_DWORDS) by scalar loads: the header of
   // the NEXT allele while this one is evaluated (its table and block are requested one allele ahead), the constants when they are needed
   typedef int hs_i16v __attribute__((ext_vector_type(16)));
@@ -3088,7 +2750,7 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
     prev_B = B;
     const int nv = min(HS_MAXREP, B / P);                   // deletion sizes the block holds (num_deletions_, StutterAlignerClass.h:64-69)
     const int tmax = min(B, jmaxw + 1);
-    if (wave_act && (t0 == 0 || t0 < tmax) && HS_PEXP != 3){
+    if (wave_act && (t0 == 0 || t0 < tmax)){
       double lp = (t0 > 0) ? lds[oMt + xrp] : 0.0;
       int t = t0;
       if (t0 == 0){
@@ -3144,7 +2806,7 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
     HS_TICK(4);   // barrier 2 wait
 
     // --- the 13 artifact terms of this lane's column (HapAligner.cpp:62-109) and their fast_log_sum_exp
-    if (wave_act && HS_PEXP != 1){
+    if (wave_act){
       double terms[HS_NART];
       double lp0_max = 0.0;
       const int B8 = 8*B;
@@ -3190,8 +2852,8 @@ __device__ __forceinline__ void str_group_body_p(const hs_dev_t& d, int item_beg
         const int len8 = min(B8 + D8, j8p8);
         const double li = ldb(8*oDl + 8*q*XC + aCol);      // ins_probs_[q] of this column (table phase above)
         // match_probs_ of column j - D if the segment is longer than the insertion (StutterAlignerClass.cpp:66), else the 0.0 in front of the read
-        const double lp0 = (prior_ins + li) + (HS_PHOIST ? ldb(aInsM[q]) : ldb(8*oMt + max(aM - D8, aZ)));
-        const int lim8 = min(HS_PHOIST ? c8[q] : max(j8p8 - D8, 0), B8);       // min(max(0, len - D), B)
+        const double lp0 = (prior_ins + li) + ldb(8*oMt + max(aM - D8, aZ));
+        const int lim8 = min(max(j8p8 - D8, 0), B8);       // min(max(0, len - D), B)
         const double S = tab_eval(lp0, lim8, HS_MAXREP);
         terms[HS_MAXREP + 1 + q] = (pmf_hi(HS_MAXREP + 1 + q) + S) + ldb(8*oRowP + aM - len8);
         __builtin_amdgcn_sched_barrier(0);                // one term at a time: the scheduler otherwise requests every table value of the 13 terms up front, in more registers than there are
@@ -3256,16 +2918,12 @@ hs_str_group_kernel_p(const hs_dev_t* __restrict__ dp, int item_begin){
   const int oe = uni(d.str_order[uni(loc->order_off[side]) + uni(loc->n_short[side])]);
   const int p = uni(d.stropts[d.alleles[uni(loc->hap_begin) + (oe & 0x1fffffff)].str_opt[side]].period);
   switch (p){
-#ifdef HS_GRP_ONLYP       // compile-time experiments: one instantiation only
-    case HS_GRP_ONLYP: str_group_body_p<HS_GRP_ONLYP>(d, item_begin); break;
-#else
     case 1: str_group_body_p<1>(d, item_begin); break;
     case 2: str_group_body_p<2>(d, item_begin); break;
     case 3: str_group_body_p<3>(d, item_begin); break;
     case 4: str_group_body_p<4>(d, item_begin); break;
     case 5: str_group_body_p<5>(d, item_begin); break;
     case 6: str_group_body_p<6>(d, item_begin); break;
-#endif
     default: break;                                  // prep.cpp: n_short == n_tab for longer periods
   }
 }

@@ -17,10 +17,17 @@ ALIGN = sorted(glob.glob(os.path.join(GOLD, "align_*.npz")))
 
 
 def test_library_exports_every_declared_symbol(hmm_host):
-    """The C-ABI library loads and exports every function include/hipstr_hmm.h declares."""
+    """The C-ABI library loads and exports every function include/hipstr_hmm.h declares — the drop-in boundary, which has no hipstr_debug_*
+    entry any more (round 6) — and, in the default build, the diagnostics of include/hipstr_hmm_debug.h."""
     hdr = open(os.path.join(ROOT, "include", "hipstr_hmm.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     names = set(re.findall(r"\b(hipstr_[a-z0-9_]+)\s*\(", hdr))
+    assert not any(n.startswith("hipstr_debug_") for n in names)
+    dbg = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "hipstr_hmm_debug.h")).read(), flags=re.S)
+    dbg_names = set(re.findall(r"\b(hipstr_debug_[a-z0-9_]+)\s*\(", dbg))
+    assert len(dbg_names) >= 12
+    for n in sorted(dbg_names):
+        assert hasattr(hmm_host, n), "missing diagnostics export " + n
     assert {"hipstr_hmm_init", "hipstr_hmm_upload", "hipstr_hmm_align", "hipstr_hmm_fetch", "hipstr_hmm_process_reads",
             "hipstr_post_run", "hipstr_calc_seed_bases", "hipstr_last_error"} <= names
     for n in sorted(names):
