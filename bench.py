@@ -298,21 +298,20 @@ def end_to_end(capi, hmm, sb, loci, steps, device, latency=True):
     def one_pass_set(n):
         # feeder: every locus its own submission (hipstr_stream_submit_each: the per-region loop in C, as the reference's caller is C++);
         # collector: the results of a pass, in order, into one buffer (hipstr_stream_collect)
+        # (round 6: the collector used to poll — a try / except / 0.2 ms sleep loop around 256-locus collects while the feeder was behind —
+        # and that loop of the HARNESS took a third of the process' CPU under the 2-CPU pin, CPU the library's workers then did not have.
+        # Now the feeder posts a semaphore per submitted pass and the collector makes one blocking C call per pass: ctypes releases the
+        # GIL inside it, the wait sleeps inside the library.)
+        submitted = threading.Semaphore(0)
         def feed():
             for _ in range(n):
                 st.submit_each(sb.ptr)
+                submitted.release()
             st.flush()
         th = threading.Thread(target=feed); th.start()
         for _ in range(n):
-            got = 0
-            while got < loci:                      # the feeder may be behind: collect what is outstanding
-                k = min(loci - got, 256)
-                try:
-                    st.collect(k, probs, seeds); got += k
-                except RuntimeError as ex:
-                    if "fewer submissions outstanding" not in str(ex):     # a failed batch / a refused locus must end the run, not spin here
-                        raise
-                    time.sleep(0.0002)
+            submitted.acquire()
+            st.collect(loci, probs, seeds)
         th.join()
     # warm-up: kernels, and the block caches — a miss is a hipMalloc / hipHostMalloc of up to gigabytes (0.9 s seen) in the middle of the
     # stream; passes are repeated until one goes by without a new block from the driver (at most 12): the steady state of a long run

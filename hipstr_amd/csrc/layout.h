@@ -20,6 +20,7 @@
 #ifndef HS_GRP_COLS
 #define HS_GRP_COLS      256       // lanes (= read columns) of one hs_str_group_kernel workgroup; prep.cpp packs reads of a locus side up to this many columns
 #endif
+#define HS_GRP_MAX_BLOCK (4*HS_GRP_COLS)   // longest STR block hs_str_group_kernel / _pw / _rp take: a workgroup fetches an allele's block four bases per lane (hs_str_group_kernel_p never fetches it: any length); longer ones go to the per-read kernels (prep.cpp, round 6: tools/fuzz_align.py "big" found alleles of 1026+ bp mis-scored)
 #define HS_GRP_MAXP      6         // hs_str_group_kernel_p is instantiated for the periods 1..HS_GRP_MAXP
 #define HS_NART          13        // artifact sizes -6p..+6p (RepeatStutterInfo.h:10-11)
 #define HS_MAXREP        6

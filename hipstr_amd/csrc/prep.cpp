@@ -459,6 +459,7 @@ void emit_stropt(const char* blk, const int B, int period, const double pmf13[HS
     HS_SOLAP(1);
     so.tab_off = gen ? (int32_t)out.gen_f64 : (int32_t)out.f64pool.size(); so.tab_len = 0;
     bool ok = (B >= period);
+    if (period > HS_GRP_MAXP) ok &= (B <= HS_GRP_MAX_BLOCK);          // (no hs_str_group_kernel_p for this period: hs_str_group_kernel fetches the block, at most HS_GRP_MAX_BLOCK bases)
     if (!twin_periodic) for (int i = 0; i < B; i++){ const char c = blk[i]; ok &= (c == 'A' || c == 'C' || c == 'G' || c == 'T'); }      // (a twin of kind 1 has passed this)
     if (ok && gen){
       // the device writes the entries (expand_kernels.hip): here only their number and where each list's begin
@@ -697,6 +698,7 @@ void emit_stropt(const char* blk, const int B, int period, const double pmf13[HS
     bool ok = true; int total = 0;
     for (int i = 0; i < B; i++){ const char c = blk[i]; ok &= (c == 'A' || c == 'C' || c == 'G' || c == 'T'); }      // hs_str_group_kernel looks emissions up by base code
     ok &= (B >= period);                                                          // ... and lets ins_probs_ cycle through block bases only
+    ok &= (B <= HS_GRP_MAX_BLOCK);                                                // ... and fetches the block four bases per lane of its 256-lane workgroup
     for (int k = 0; k <= HS_MAXREP && ok; k++){
       const int tail = (k == HS_MAXREP) ? B : B - (k+1)*period;
       so.tab_base[k] = total;

@@ -19,6 +19,9 @@
 // The parts of SeqStutterGenotyper that need htslib (write_vcf_record, VCF input) are never called; their symbols stay unresolved
 // in both libraries (libflow_ref.so / libflow_mi355x.so, loaded with lazy binding by integration/flow_launcher.c), exactly like
 // FastaReader in oracle/_ref/libhipstr_ref.so.  TEST INFRASTRUCTURE, not product.
+#ifdef HIPSTR_MI355X_NW_PREFETCH
+#include "nw_prefetch_mi355x.h"
+#endif
 #include <algorithm>
 #include <climits>
 #include <cmath>
@@ -176,6 +179,19 @@ static int run_locus(const LocusParams& lp, FILE* f){
   // window of ALIGN_WINDOW_WIDTH = 75 bases either side, no end penalty.  (realign() itself takes a BamAlignment, whose constructor
   // needs htslib — not built here; its NeedlemanWunsch::Align call is reproduced with the arguments :15-25 derive.)
   if (lp.nw){
+#ifdef HIPSTR_MI355X_NW_PREFETCH
+    // the nw variant: what integration/left_align_reads_prepass_mi355x.inc does in front of left_align_reads' loop — every pair of the
+    // locus handed over in one call; the Align calls below (unchanged) are then served from the thread's table
+    {
+      std::vector<std::string> nw_refs, nw_reads;
+      for (size_t i = 0; i < alns.size(); i++){
+        const int32_t start = std::max(alns[i].get_start() - 75 - 1, 0), stop = std::min(alns[i].get_stop() + 75 - 1, (int32_t)(chrom.size() - 1));
+        nw_refs.push_back(chrom.substr(start, stop - start + 1)); nw_reads.push_back(alns[i].get_sequence());
+      }
+      const int n_pf = hipstr_mi355x_nw_prefetch(nw_refs, nw_reads, false);
+      fprintf(stderr, "nw_prefetch %d pairs of %zu reads in one call\n", n_pf, alns.size());
+    }
+#endif
     for (size_t i = 0; i < alns.size(); i++){
       const int32_t start = std::max(alns[i].get_start() - 75 - 1, 0), stop = std::min(alns[i].get_stop() + 75 - 1, (int32_t)(chrom.size() - 1));
       const std::string ref_seq = chrom.substr(start, stop - start + 1), read_seq = alns[i].get_sequence();
@@ -251,6 +267,7 @@ static int run_locus(const LocusParams& lp, FILE* f){
 
 #ifdef FLOW_MI355X
 #include "hipstr_hmm.h"
+#include "hipstr_hmm_debug.h"      // hipstr_debug_api_profile: what --profile prints
 #include "SeqAlignment/HapAlignerMI355X.h"
 #endif
 #include <atomic>

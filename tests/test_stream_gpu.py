@@ -339,6 +339,21 @@ def test_multi_on_every_visible_device(hmm):
         assert lib.hipstr_multi_next_size(m, C.byref(t), C.byref(no), C.byref(nr)) == 0
         probs = np.full(max(no.value, 1), FILL); seeds = np.full(max(nr.value, 1), -7, np.int32)
         assert lib.hipstr_multi_next(m, C.byref(t), probs.ctypes.data_as(capi._f64p), probs.size, seeds.ctypes.data_as(capi._i32p), seeds.size) == 0, lib.hipstr_last_error()
-        assert t.value == i and np.array_equal(probs[:no.value], wp) and np.array_equal(seeds[:nr.value], ws)
+        assert t.value == i and np.array_equal(probs[:no.value], wp) and np.array_equal(seeds[:nr.value], ws), \
+            "piece %d from the multi-device stream differs from the one-shot call on device 0" % i
+    # (round 6, first contact with a multi-GPU node) every device was dealt work, and the results above — each computed on whichever
+    # device its block went to — equal device 0's bit for bit; the devices are named so a bad placement shows in the test log
+    lib.hipstr_multi_dealt.restype = C.c_int; lib.hipstr_multi_dealt.argtypes = [C.c_void_p, capi._f64p, C.c_int32]
+    dealt = np.zeros(n_dev)
+    assert lib.hipstr_multi_dealt(m, dealt.ctypes.data_as(capi._f64p), n_dev) == n_dev and np.all(dealt > 0), dealt
+    for dv in range(n_dev):
+        pr = torch.cuda.get_device_properties(dv)
+        print("device %d: %s pci %04x:%02x:%02x dealt %.3g" % (dv, pr.name, getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0), dealt[dv]))
     lib.hipstr_multi_close(m)
+    # the one-shot call on EVERY device against device 0's results: a device that computes differently is named
+    for dv in range(1, n_dev):
+        assert lib.hipstr_hmm_init(dv) == 0, lib.hipstr_last_error()
+        for i in (0, len(pieces) // 2, len(pieces) - 1):
+            gp, gsd = capi.run_align(lib, "hipstr_hmm_", pieces[i].ptr, fill=FILL)
+            assert np.array_equal(gp, want[i][0]) and np.array_equal(gsd, want[i][1]), "device %d differs from device 0 on piece %d" % (dv, i)
     assert lib.hipstr_hmm_init(0) == 0        # back to device 0 for the tests that follow
