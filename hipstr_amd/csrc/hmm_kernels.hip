@@ -453,7 +453,7 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
     hc[r] = EL ? (((meta & 0xff) >> 1) & 7) << 3 : (meta & 0xff);      // EL: byte offset of the base's entry in a read's eight-entry row
     if (!KL){ m2m[KL ? 0 : r] = uni(d.m2m[(meta >> 8) & 15]); m2i[KL ? 0 : r] = uni(d.m2i[(meta >> 8) & 15]); }
   }
-  double Mp[NR], Dp[NR], Ip[NR];
+  double Mp[NR], Qp[NR], Ip[NR];          // per row: M[r][j], Q[r] = max(I[r][j], D[r-1][j]) and — ahead by a column — I[r][j+1]
   double nx_blc = col[0], nx_blw = col[1], nx_rd = col[2];
   double nx_mr = 0.0;
   // EL: table of two column parities x (64 / npad reads) x 8 entries; lane `slot` < 8 of a read writes the entry of base code `slot`
@@ -464,7 +464,7 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
     if (e_slot < 8) etab[par*64 + e_sub*8 + e_slot] = ((int)rdv == e_char) ? blc : blw;
   };
   if (EL){ e_write(0, nx_rd, nx_blc, nx_blw); wave_lds_sync(); }
-  double diagM = 0, diagD = 0;
+  double diagM = 0;
   double pre = 0.0;                              // LEAD: left_prob, a strictly sequential sum in the reference
   const uint32_t a_me = (uint32_t)uni((int)(uintptr_t)(prog + w)), a_top = (uint32_t)uni((int)(uintptr_t)(prog + (w > 0 ? w - 1 : 0))), a_bot = (uint32_t)uni((int)(uintptr_t)(prog + w + 1));
   // base: the columns this workgroup's bands had finished before this sweep — the counters are never reset where sweeps follow each other
@@ -509,19 +509,32 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
         upD = IMP;
         if (j == n-1 && live) lt[0] = upM;
       } else { upM = cur_b.x; upD = cur_b.y; }
-      const double topM = upM, topD = upD;
+      const double topM = upM;
+      // Round 6: 11 instead of 12 FP64 operations per cell.  I[r][j+1] = blc[j+1] + max(M[r-1][j] + T_I2M, I[r][j] + T_I2I) and
+      // D[r][j] = max(M[r-1][j] + T_D2M, D[r-1][j] + T_D2D) start from the SAME sum — T_I2M and T_D2M are one constant
+      // (AlignmentModel.h:7-10) — which the sweep used to form twice, once per column.  So the D pass of column j also forms row r's I of
+      // column j + 1 (the next column's blc is already here: it is prefetched at the top of the column) and, before I[r][j] is
+      // overwritten, Q[r] = max(I[r][j], D[r-1][j]) — what M[r][j+1] takes its second addend from.  D itself is not kept across columns any
+      // more (only Q needs it): the state stays three values per row.  Same operations on the same operands, one of them shared:
+      // bit-identical.
+      auto dstep = [&](int r, double Icur){      // row r of the top-down pass; Icur = I[r][j]; upM / upD = M / D of the row above in this column
+        const double X = upM + T_D2M;
+        const double nD = fmax(X, upD + T_D2D);
+        Qp[r] = fmax(Icur, upD);
+        Ip[r] = nx_blc + fmax(X, Icur + T_I2I);
+        upM = Mp[r]; upD = nD;
+      };
       if (j == 0){
 #pragma unroll
-        for (int r = 0; r < NR; r++){           // first read column (HapAligner.cpp:123-126)
+        for (int r = 0; r < NR; r++){           // first read column (HapAligner.cpp:123-126): M = e, I = blc, D from the row above
           double e;
           if (EL){ e = eload(e_rd + (uint32_t)hc[r]); ewait1<0>(e); }      // column 0: parity 0
           else e = (rdj == hc[r]) ? blcj : blwj;
-          const double nD = fmax(upM + T_D2M, upD + T_D2D);
-          Mp[r] = e; Ip[r] = blcj; Dp[r] = nD;
-          upM = e; upD = nD;
+          Mp[r] = e;
+          dstep(r, blcj);
         }
       } else {
-        // as in band_sweep: M and I bottom-up in place, then D top-down through the new M
+        // M bottom-up in place (row r takes M[r-1] of the previous column), then D, Q and the next column's I top-down through the new M
         if (KL){
           // rows NR-1 .. 0; the pair of row r (and, EL, its emission) is requested while row r + KD is computed
           constexpr int KD = HS_COOP_LDS_DEPTH, KM = KD + 1, PER = EL ? 2 : 1;       // PER: requests per row
@@ -551,27 +564,19 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
               default: kwait<6>(kq[r % KM]); break;
             }
             const double e = EL ? eq[EL ? r % KM : 0] : ((rdj == hc[r]) ? blcj : blwj);
-            const double dM = (r == 0) ? diagM : Mp[r > 0 ? r-1 : 0], dD = (r == 0) ? diagD : Dp[r > 0 ? r-1 : 0];
-            const double nM = e + fmax(dM + kq[r % KM].x, fmax(Ip[r], dD) + kq[r % KM].y);
-            const double nI = blcj + fmax(dM + T_I2M, Ip[r] + T_I2I);
-            Mp[r] = nM; Ip[r] = nI;
+            const double dM = (r == 0) ? diagM : Mp[r > 0 ? r-1 : 0];
+            Mp[r] = e + fmax(dM + kq[r % KM].x, Qp[r] + kq[r % KM].y);
           }
         } else {
 #pragma unroll
         for (int r = NR - 1; r >= 0; r--){
           const double e = (rdj == hc[r]) ? blcj : blwj;
-          const double dM = (r == 0) ? diagM : Mp[r > 0 ? r-1 : 0], dD = (r == 0) ? diagD : Dp[r > 0 ? r-1 : 0];
-          const double nM = e + fmax(dM + m2m[KL ? 0 : r], fmax(Ip[r], dD) + m2i[KL ? 0 : r]);
-          const double nI = blcj + fmax(dM + T_I2M, Ip[r] + T_I2I);
-          Mp[r] = nM; Ip[r] = nI;
+          const double dM = (r == 0) ? diagM : Mp[r > 0 ? r-1 : 0];
+          Mp[r] = e + fmax(dM + m2m[KL ? 0 : r], Qp[r] + m2i[KL ? 0 : r]);
         }
         }
 #pragma unroll
-        for (int r = 0; r < NR; r++){
-          const double nD = fmax(upM + T_D2M, upD + T_D2D);
-          Dp[r] = nD;
-          upM = Mp[r]; upD = nD;
-        }
+        for (int r = 0; r < NR; r++) dstep(r, Ip[r]);
       }
       if (!LAST){
         if (botg) *(double2*)(bnd + ((size_t)j*64 + lane)*2) = make_double2(upM, upD);
@@ -588,7 +593,7 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
       // has been read — both in front of the counter's store, and a wavefront's LDS operations execute in order
       if (!BAR && !(FIRST && LAST)){ asm volatile("" ::: "memory"); prog_write(a_me, base + j + 1); }
       if (EL) e_write((j + 1) & 1, nx_rd, nx_blc, nx_blw);       // the next column's emissions (its values were requested at the top of this one)
-      diagM = topM; diagD = topD;                // top boundary of this column = diagonal of the band's first row next column
+      diagM = topM;                              // top boundary of this column = diagonal of the band's first row next column
       if (j == n-1 && live){
 #pragma unroll
         for (int r = 0; r < NR; r++) lt[row0 + r] = Mp[r];           // last read column of this lane's read
@@ -943,7 +948,7 @@ __global__ void __launch_bounds__(64) hs_flank_systolic(const hs_dev_t* __restri
     const double m2m = d.m2m[(meta >> 8) & 15], m2i = d.m2i[(meta >> 8) & 15];
     const double2* const s_top = s_tb[par];
     double2* const s_out = s_tb[par ^ 1];
-    double curM = 0.0, curD = 0.0, curI = 0.0, diagM = 0.0, diagD = 0.0, ltv = 0.0;
+    double curM = 0.0, curD = 0.0, curI = 0.0, diagM = 0.0, diagD = 0.0, ltv = 0.0, xdiag = 0.0 + T_I2M;      // xdiag = diagM + T_I2M, carried from the step before
     const int nsteps = n + nrb - 1;
     // A lane outside its read's columns (before its first, behind its last) or beyond the band's rows computes on clamped operands and
     // nothing of it reaches a cell that counts: column 0 takes nothing from the lane's own past, a cell's neighbours are a column
@@ -963,8 +968,11 @@ __global__ void __launch_bounds__(64) hs_flank_systolic(const hs_dev_t* __restri
       // (m2d == m2i: max(a + x, b + x) == max(a, b) + x exactly, as in band_sweep); column 0: HapAligner.cpp:123-126
       const bool first = (j == 0);
       const double nM = first ? e : e + fmax(diagM + m2m, fmax(curI, diagD) + m2i);
-      const double nI = first ? bq.x : bq.x + fmax(diagM + T_I2M, curI + T_I2I);
-      const double nD = fmax(upM + T_D2M, upD + T_D2D);
+      // (round 6, as in band_sweep_coop: M of the row above + T_I2M of this column's I is the sum the previous step's D formed — T_I2M and T_D2M are one constant)
+      const double xup = upM + T_D2M;
+      const double nI = first ? bq.x : bq.x + fmax(xdiag, curI + T_I2I);
+      const double nD = fmax(xup, upD + T_D2D);
+      xdiag = xup;
       curM = nM; curI = nI; curD = nD;
       ltv = (j == n - 1) ? nM : ltv;                       // last read column
       if (last_lane && j >= 0 && j < n) s_out[j] = make_double2(nM, nD);      // the band's last row: the next band's top, or rowP

@@ -202,6 +202,9 @@ static int run_locus(const LocusParams& lp, FILE* f){
       for (size_t c = 0; c < cigar_list.size(); c++) fprintf(f, "%d%c", cigar_list[c].Length, cigar_list[c].Type);
       fprintf(f, " %s %s\n", ref_al.c_str(), read_al.c_str());
     }
+#ifdef HIPSTR_MI355X_NW_PREFETCH
+    fprintf(stderr, "nw_prefetch served %lld of %zu Align calls from the table\n", hipstr_mi355x_nw_hits(), alns.size());
+#endif
   }
 
   const auto t_gen0 = std::chrono::steady_clock::now();

@@ -32,11 +32,14 @@ inline std::string hipstr_mi355x_nw_key(const std::string& ref_seq, const std::s
   k += use_ref_end_penalty ? '1' : '0'; k += ref_seq; k += '\n'; k += read_seq;      // (sequences hold no newline)
   return k;
 }
+inline long long& hipstr_mi355x_nw_hits(){ static thread_local long long n = 0; return n; }      // Align calls of this thread served from the table (diagnostics)
 inline const HipstrNwPrefetched* hipstr_mi355x_nw_find(const std::string& ref_seq, const std::string& read_seq, bool use_ref_end_penalty){
   const std::unordered_map<std::string, HipstrNwPrefetched>& t = hipstr_mi355x_nw_table();
   if (t.empty()) return NULL;
   std::unordered_map<std::string, HipstrNwPrefetched>::const_iterator it = t.find(hipstr_mi355x_nw_key(ref_seq, read_seq, use_ref_end_penalty));
-  return it == t.end() ? NULL : &it->second;
+  if (it == t.end()) return NULL;
+  hipstr_mi355x_nw_hits()++;
+  return &it->second;
 }
 // All (reference window, read) pairs of a locus in one device call; returns the number of distinct pairs now in the table (0 if the call
 // failed: Align then computes pair by pair and reports the error itself).
