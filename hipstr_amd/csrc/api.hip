@@ -342,8 +342,7 @@ hipStream_t thread_aux_stream(Ctx* c){
   auto it = mine.find(c);
   if (it != mine.end()) return it->second;
   hipStream_t st = NULL;
-  static const bool off = getenv("HIPSTR_EXPAND_ASIDE") && atoi(getenv("HIPSTR_EXPAND_ASIDE")) == 0;
-  if (off || hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = NULL;
+  if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = NULL;
   mine[c] = st;
   return st;
 }
@@ -697,8 +696,8 @@ hipstr_dev_batch_t* hipstr::upload_on(Ctx* ctx, const hipstr_batch_t* batch, con
   dev->ev0 = ctx->get_event(true); dev->ev1 = ctx->get_event(true);
   // The stream's batches take tens of milliseconds and their collectors must not burn a core waiting: hipEventSynchronize spins at 100 %
   // of a CPU on this stack whatever the event's flags (tools/wait_probe.hip: 41.7 ms of thread CPU per 41.7 ms of waiting, also with
-  // hipEventBlockingSync), a query + usleep loop costs 0.6 ms (results_wait).  HIPSTR_STREAM_SPIN=1: spin all the same (comparison runs).
-  static const bool spin = getenv("HIPSTR_STREAM_SPIN") && atoi(getenv("HIPSTR_STREAM_SPIN")) != 0;
+  // hipEventBlockingSync), a query + usleep loop costs 0.6 ms (results_wait).
+  constexpr bool spin = false;
   dev->sleepy_wait = reads_pinned && !spin;
   dev->ev_h2d = ctx->get_event(false); dev->ev_done = ctx->get_event(false); dev->ev_d2h = ctx->get_event(false);
   if (!dev->ev0 || !dev->ev1 || !dev->ev_h2d || !dev->ev_done || !dev->ev_d2h){ g_err = "hipEventCreate failed"; hipstr_hmm_free(dev); return NULL; }
@@ -814,8 +813,7 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
     if (!str_group) hipLaunchKernelGGL(hs_str_kernel, dim3(nact, dev->grid_y), dim3(128), dev->lds_bytes, st, dp, ch.active_begin, 0);
     else {
       // blocks of at least six repeat units (nearly all) through the kernel with a compile-time period, the shorter ones as before
-      // (HIPSTR_STR_GROUP_P=0: all of them as before, for comparison)
-      static const bool group_p = !(getenv("HIPSTR_STR_GROUP_P") && atoi(getenv("HIPSTR_STR_GROUP_P")) == 0);
+      constexpr bool group_p = true;
       // A call of a locus or two: the interrupted alleles' kernels beside the tabulated alleles' (different alleles of the same reads: disjoint
       // outputs; the re-do marks both may set are the same value) on the thread's second stream — 18 us of a 180 us call
       hipStream_t st_pw = st; hipEvent_t ev_pw = NULL, ev_fork = NULL;
@@ -1326,7 +1324,7 @@ int hipstr_post_launch(hipstr_post_dev_t* pd, void* hip_stream){
     int max_nd = 1;
     for (const hs_post_unit_t& u : pd->R.units) max_nd = std::max(max_nd, u.n_alleles*u.n_alleles);
     const int split = (int)std::min<size_t>((size_t)(max_nd + 255)/256, n_units < 1024 ? (2048 + n_units - 1)/n_units : 1);
-    static const bool no_split = getenv("HIPSTR_POST_SPLIT") && atoi(getenv("HIPSTR_POST_SPLIT")) == 0;       // comparison runs
+    constexpr bool no_split = false;
     if (split > 1 && !no_split){
       hipLaunchKernelGGL(hs_posterior_accumulate_kernel, dim3((unsigned)n_units, (unsigned)split), dim3(256), 0, st, (const hs_post_dev_t*)pd->R.d_args);
       hipLaunchKernelGGL(hs_posterior_finish_kernel, dim3((unsigned)n_units), dim3(256), 0, st, (const hs_post_dev_t*)pd->R.d_args);

@@ -917,7 +917,7 @@ extern "C" int hipstr_em_train(const hipstr_em_batch_t* eb, uint8_t* trained, do
     hipLaunchKernelGGL(hs_em_units, dim3(nl), dim3(256), 0, T.stream, (const hs_em_dev_t*)(d_hb + 1));
     unsigned bound_l = (unsigned)nl, bound_u = (unsigned)n_units;
     int rounds = 0;
-    const bool em_serial = getenv("HIPSTR_EM_SERIAL") && atoi(getenv("HIPSTR_EM_SERIAL")) != 0;      // (experiments) the allele-frequency scans on the main stream
+    constexpr bool em_serial = false;      // (the allele-frequency scans run beside the M-step on the side stream: 0.51 against 0.57 s per 10 000 loci, profiles/r05_notes.md)
     for (int r = 0; r <= eb->max_iter + 1; r++){
       const hs_em_dev_t* H = d_hb + (r & 1); const hs_post_dev_t* PH = d_pb + (r & 1);
       if (bound_l > 0){

@@ -7,17 +7,19 @@
 // separately, handing a few hundred bytes per (read, allele, side) to the next one through HBM workspaces:
 //
 //   hs_col_kernel             per-column emission logs of every read in side orientation.
-//   hs_lead_kernel<R>         leading flank: matrix row 0 + max-plus M/I/D recurrence (HapAligner.cpp:33-42, 114-156), once
+//   hs_lead_kernel_coop       leading flank: matrix row 0 + max-plus M/I/D recurrence (HapAligner.cpp:33-42, 114-156), once
 //                             per read and distinct flank, shared by all alleles (what the reference's "reuse_alns" does one
 //                             allele at a time), with READS as lanes: the flank rows are wave-uniform, a lane carries the
-//                             M/I/D of its own read, the matrix is swept in bands of R rows held in registers.
-//                                                                                          -> rowP, last column, side_prob
-//   hs_str_group_kernel       STR block (HapAligner.cpp:62-109 + StutterAlignerClass.cpp): one lane per read column, 13
-//   hs_str_kernel_generic     artifact sizes; artifact position marginalised by a tabulated closed form (periodic blocks: the group
-//   (hs_str_kernel)           kernel, reads of a locus side packed into one workgroup's lanes), a closed form evaluated the long
-//                             way, or a replay of a host-enumerated visiting list (the generic kernel, a workgroup per read). -> MR
-//   hs_trail_kernel<R>        trailing flank: the same banded sweep with ALLELES as lanes: all alleles of a locus share the
-//                             read and (per group) the flank rows, so a lane needs no neighbour at all.   -> last column
+//                             M/I/D of its own read, the matrix is swept in bands of rows held in registers, a band per
+//                             wavefront of the workgroup.                                  -> rowP, last column, side_prob
+//   hs_nd_kernel              STR block (HapAligner.cpp:62-109 + StutterAlignerClass.cpp): one lane per read column, 13 artifact
+//   hs_str_group_kernel_p     sizes; the artifact position marginalised by a tabulated closed form (periodic blocks: _p, reads of a
+//   hs_str_group_kernel[_pw,  locus side packed into one workgroup's lanes), by the piecewise closed forms of interrupted repeats
+//    _rp], hs_str_kernel[_generic]   (_pw, _rp) or by a replay of a host-enumerated visiting list (a workgroup per read).        -> MR
+//   hs_trail_kernel_coop      trailing flank: the same banded sweep with ALLELES as lanes: all alleles of a locus share the
+//                             read and (per group) the flank rows, so a lane needs no neighbour at all; the workgroup streams
+//                             through its items without a barrier (round 6).                                  -> last column
+//   hs_flank_systolic         the flank blocks of small launches: a wavefront per alignment, rows as lanes.
 //   hs_combine_kernel         compute_aln_logprob (HapAligner.cpp:163-231): log-sum-exp over seed positions.
 //
 // Arithmetic is IEEE double add/max in exactly the reference's operation order; the reference's float
@@ -61,192 +63,15 @@ __device__ __forceinline__ double* lead_record(const hs_dev_t& d, const SideView
   return d.ws_lead + v.ws_lead + (int64_t)slot*stride;
 }
 
-#ifndef HS_FLANK_WAVES
-#define HS_FLANK_WAVES 2      // wavefronts per SIMD the flank kernels are register-allocated for (20 rows x M/I/D = 120 VGPRs of state)
-#endif
-// ------------------------------------------------------------------ trailing flank: alleles as lanes, banded sweep
-// Work item = (read side, group of <= 64 alleles sharing the trailing-flank rowset).  Lane = allele.  Every quantity
-// that depends on the read column or on the haplotype row — base, log P(correct/error), flank base, transition
-// logs, hence the emission — is wave-uniform and lives in SGPRs; a lane only carries its own M/I/D values, so the
-// recurrence (HapAligner.cpp:144-153) needs no cross-lane traffic, no emission select and no pipeline fill.
-// The matrix is swept column by column in bands of R rows whose previous-column M/I/D sit in registers; the last
-// row of a band goes to a per-wavefront scratch row (L2-resident) and comes back as the next band's top boundary.
-// Persistent wavefronts: blockIdx.x strides over the items so that the scratch is per wavefront, not per item.
-// When a group has <= 32 alleles, 64/npad reads of the same locus and side are packed into one wavefront.
-// One band of NR haplotype rows (fully unrolled, branch-free per row) swept over the read columns.
-//   FIRST: the band's top boundary is the "must be followed by a match" row, built from MR (HapAligner.cpp:130-139);
-//          otherwise it is read from `bnd`, written by the previous band (in place: column j is read before it is rewritten).
-//   LAST:  no bottom boundary is written.
-// Lanes may belong to different reads (packing): n, the column table and the workspaces are per lane; the flank rows
-// (hence bases and transition logs) are wave-uniform.
-//   LEAD:  the block is a leading flank and the lanes are READS of one locus and side (the rows are still wave-uniform): the first
-//          band's top boundary is matrix row 0 (HapAligner.cpp:33-42: emission plus the running sum of log P(correct), which also
-//          yields side_prob at the read's last column), and the last band writes M of its bottom row — rowP, what the STR block
-//          starts from — for every column.
-template <int NR, bool FIRST, bool LAST, bool LEAD = false>
-__device__ __forceinline__ void band_sweep(const hs_dev_t& d, int lane, bool live, int n, int nmax, const double* __restrict__ col,
-                                           const hs_row_t* __restrict__ rows, int row0, int c0,
-                                           const double* __restrict__ mr, double* __restrict__ bnd, double* __restrict__ lt,
-                                           double* __restrict__ rowp = NULL, double* __restrict__ side_out = NULL){
-  int hc[NR]; double m2m[NR], m2i[NR];
-#pragma unroll
-  for (int r = 0; r < NR; r++){
-    const int meta = uni((int)rows[row0 + r]);
-    hc[r] = meta & 0xff;
-    m2m[r] = uni(d.m2m[(meta >> 8) & 15]); m2i[r] = uni(d.m2i[(meta >> 8) & 15]);
-  }
-  double Mp[NR], Dp[NR], Ip[NR];
-  // software pipeline: the loads of column j+1 are issued before column j is computed
-  double nx_blc = col[0], nx_blw = col[1], nx_rd = col[2];
-  double nx_mr = 0.0; double2 nx_b = make_double2(0.0, 0.0);
-  if (!FIRST) nx_b = *(const double2*)(bnd + (size_t)lane*2);
-  double diagM = 0, diagD = 0;
-  double pre = 0.0;                              // LEAD: left_prob, a strictly sequential sum in the reference
-  // The bottom boundary of column j is stored at the top of iteration j+1, after that iteration has waited for its prefetched
-  // loads: gfx9 counts loads and stores in one counter, so a store issued right before that wait would be waited for as well
-  // (a round trip to L2 per column).  In place: position j-1 was read two iterations ago.
-  double pendM = 0.0, pendD = 0.0;
-  auto flush_pending = [&](int jp){
-    if (!LAST) *(double2*)(bnd + ((size_t)jp*64 + lane)*2) = make_double2(pendM, pendD);
-    else if (LEAD){ if (jp < n && live) rowp[jp] = pendM; }
-  };
-  for (int j = 0; j < nmax; j++){
-    const double blcj = nx_blc, blwj = nx_blw; const int rdj = (int)nx_rd;
-    const double cur_mr = nx_mr; const double2 cur_b = nx_b;
-    if (j > 0) flush_pending(j - 1);
-    {
-      const int jn = min(j + 1, n - 1);           // a lane past its own read end keeps re-reading its last column
-      nx_blc = col[3*jn]; nx_blw = col[3*jn+1]; nx_rd = col[3*jn+2];
-      if (FIRST){ if (!LEAD) nx_mr = mr[jn - 1 >= 0 ? jn - 1 : 0]; }
-      else       nx_b = *(const double2*)(bnd + ((size_t)min(j + 1, nmax - 1)*64 + lane)*2);
-    }
-    double upM, upD;
-    if (FIRST){
-      const double e0 = (rdj == c0) ? blcj : blwj;
-      if (LEAD){
-        upM = e0 + pre;
-        pre += blcj;
-        if (j == n-1 && live) *side_out = pre;                     // side_prob: the whole side hangs off the haplotype
-      } else upM = (j == 0) ? e0 : e0 + cur_mr;
-      upD = IMP;
-      if (j == n-1 && live) lt[0] = upM;
-    } else { upM = cur_b.x; upD = cur_b.y; }
-    const double topM = upM, topD = upD;
-    if (j == 0){
-#pragma unroll
-      for (int r = 0; r < NR; r++){           // first read column (HapAligner.cpp:123-126)
-        const double e = (rdj == hc[r]) ? blcj : blwj;
-        const double nD = fmax(upM + T_D2M, upD + T_D2D);
-        Mp[r] = e; Ip[r] = blcj; Dp[r] = nD;
-        upM = e; upD = nD;
-      }
-    } else {
-      // M and I of this column only read the previous column, so they are computed bottom-up and overwrite in place (row r+1, done
-      // first, was the last reader of row r's old M and D); D, which chains down the column through the new M, follows top-down.
-      // max(I+m2i, M+m2m, D+m2d) with m2d == m2i: adding the same value is monotone, so max(a+x, b+x) == max(a,b)+x exactly
-#pragma unroll
-      for (int r = NR - 1; r >= 0; r--){
-        const double e = (rdj == hc[r]) ? blcj : blwj;
-        const double dM = (r == 0) ? diagM : Mp[r > 0 ? r-1 : 0], dD = (r == 0) ? diagD : Dp[r > 0 ? r-1 : 0];
-        const double nM = e + fmax(dM + m2m[r], fmax(Ip[r], dD) + m2i[r]);
-        const double nI = blcj + fmax(dM + T_I2M, Ip[r] + T_I2I);
-        Mp[r] = nM; Ip[r] = nI;
-      }
-#pragma unroll
-      for (int r = 0; r < NR; r++){
-        const double nD = fmax(upM + T_D2M, upD + T_D2D);
-        Dp[r] = nD;
-        upM = Mp[r]; upD = nD;
-      }
-    }
-    pendM = upM; pendD = upD;
-    diagM = topM; diagD = topD;                // top boundary of this column = diagonal of the band's first row next column
-    if (j == n-1 && live){
-#pragma unroll
-      for (int r = 0; r < NR; r++) lt[row0 + r] = Mp[r];           // last read column of this lane's read
-    }
-  }
-  if (nmax > 0) flush_pending(nmax - 1);
-}
-
-template <int NR, bool LEAD = false>
-__device__ __forceinline__ void band_dispatch(bool first, bool last, const hs_dev_t& d, int lane, bool live, int n, int nmax, const double* col,
-                                              const hs_row_t* rows, int row0, int c0, const double* mr, double* bnd, double* lt,
-                                              double* rowp = NULL, double* side_out = NULL){
-  if (first){ if (last) band_sweep<NR, true, true, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt, rowp, side_out);
-              else      band_sweep<NR, true, false, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt, rowp, side_out); }
-  else      { if (last) band_sweep<NR, false, true, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt, rowp, side_out);
-              else      band_sweep<NR, false, false, LEAD>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt, rowp, side_out); }
-}
-
-template <int R>
-__global__ void __launch_bounds__(64, HS_FLANK_WAVES) hs_trail_kernel(const hs_dev_t* __restrict__ dp, int item_begin, int item_end, int chunk){
-  const hs_dev_t& d = *dp;
-  const int lane = threadIdx.x;
-  double* const bnd = d.ws_band + (size_t)blockIdx.x * d.band_cols * 64 * 2;
-  int32_t* const ctr = d.redo + d.n_active + chunk;          // items are handed out through a counter, as in hs_lead_kernel
-  for (;;){
-    int item = 0;
-    if (lane == 0) item = atomicAdd(ctr, 1);
-    item = item_begin + uni(item);
-    if (item >= item_end) break;
-    const hs_item_t* it = d.items + item;
-    const int side = uni(it->side), nreads = uni(it->rowset);
-    const hs_tgroup_t* g = d.tgroups + uni(it->slot);
-    const int nm = uni(g->n_members);
-    int npad = 1; while (npad < nm) npad <<= 1;
-    // lane -> (packed read, allele of the group)
-    const int sub = lane / npad, slot = lane - sub*npad;
-    const bool live = (sub < nreads) && (slot < nm);
-    const int ai = d.tpack[uni(it->active) + min(sub, nreads-1)];
-    const int r = d.active[ai];
-    const hs_read_t rdv = d.reads[r];
-    const hs_locus_t* loc = d.loci + uni(rdv.locus);
-    const int nL = rdv.seed, n = side ? rdv.len - rdv.seed - 1 : rdv.seed;
-    int nmax = n;
-    for (int m = 32; m >= 1; m >>= 1) nmax = max(nmax, __shfl_xor(nmax, m));
-    nmax = uni(nmax);
-    const hs_ws_t wsr = d.ws[ai];
-    const int k = d.tmembers[uni(g->member_off) + min(slot, nm-1)];
-    const hs_allele_t* al = d.alleles + uni(loc->hap_begin) + k;
-    const int ord = al->re_ord;
-    const double* mr = d.ws_mr + wsr.mr + (int64_t)ord*(rdv.len-1) + (side ? nL : 0);
-    // trailing last columns of an alignment: left side first (F2 rows), then right side (F0 rows)
-    double* lt = d.ws_lt + wsr.lt + (int64_t)ord*uni(loc->lt_stride) + (side ? d.rowsets[al->trail_rows[0]].len : 0);
-    const double* col = d.ws_col + wsr.col + 3*(int64_t)(side ? nL : 0);
-    const int rowset = uni(g->rowset);
-    const int rs_off = uni(d.rowsets[rowset].off), rs_len = uni(d.rowsets[rowset].len);
-    const hs_row_t* rows = d.rows + rs_off;
-    const int c0 = uni((int)rows[0]) & 0xff;
-    const int nbands = (rs_len - 1 + R - 1) / R;
-
-    if (nbands == 0){     // the block is the single "must be followed by a match" row (HapAligner.cpp:130-139)
-      const int j = n - 1;
-      const double blcj = col[3*j], blwj = col[3*j+1]; const int rdj = (int)col[3*j+2];
-      const double e0 = (rdj == c0) ? blcj : blwj;
-      if (live) lt[0] = (j == 0) ? e0 : e0 + mr[max(j-1, 0)];
-      continue;
-    }
-    // bands of (almost) equal height <= R
-    const int nr_base = (rs_len - 1) / nbands, nr_rem = (rs_len - 1) - nr_base*nbands;
-    int row0 = 1;
-    for (int b = 0; b < nbands; b++){
-      const int nr = nr_base + (b < nr_rem ? 1 : 0);
-      const bool first = (b == 0), last = (b + 1 == nbands);
-      if (nr == R) band_dispatch<R>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt);
-      else switch (nr){
-#define HS_BAND_CASE(N_) case N_: if (N_ < R) band_dispatch<(N_ < R ? N_ : 1)>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, lt); break;
-        HS_BAND_CASE(1) HS_BAND_CASE(2) HS_BAND_CASE(3) HS_BAND_CASE(4) HS_BAND_CASE(5) HS_BAND_CASE(6) HS_BAND_CASE(7) HS_BAND_CASE(8)
-        HS_BAND_CASE(9) HS_BAND_CASE(10) HS_BAND_CASE(11) HS_BAND_CASE(12) HS_BAND_CASE(13) HS_BAND_CASE(14) HS_BAND_CASE(15)
-        HS_BAND_CASE(16) HS_BAND_CASE(17) HS_BAND_CASE(18) HS_BAND_CASE(19) HS_BAND_CASE(20) HS_BAND_CASE(21) HS_BAND_CASE(22) HS_BAND_CASE(23)
-#undef HS_BAND_CASE
-        default: break;
-      }
-      row0 += nr;
-    }
-  }
-}
-
+// ------------------------------------------------------------------ flank blocks: what the sweeps share
+// Trailing flank: work item = (read side, group of <= 64 alleles sharing the trailing-flank rowset), lane = allele.  Every quantity that
+// depends on the read column or on the haplotype row — base, log P(correct/error), flank base, transition logs, hence the emission — is
+// wave-uniform; a lane only carries its own M / I / D values, so the recurrence (HapAligner.cpp:144-153) needs no cross-lane traffic.
+// When a group has <= 32 alleles, 64/npad reads of the same locus and side are packed into one wavefront.  Leading flank: the lanes are
+// READS of one locus and side (the rows are still wave-uniform); the first band's top boundary is matrix row 0 (HapAligner.cpp:33-42:
+// emission plus the running sum of log P(correct), which also yields side_prob at the read's last column), and the last band writes M
+// of its bottom row — rowP, what the STR block starts from — for every column.  The sweeps themselves: band_sweep_coop below (the serial
+// one-wavefront-per-item form of rounds 1-2, HIPSTR_FLANK_COOP=0, went in round 6: no test used it).
 // ------------------------------------------------------------------ leading flank: reads as lanes, the same banded sweep
 // Per-column emission logs of an active read in side orientation (left side columns, then the reversed right side, HapAligner.cpp:606-609):
 // [len-1][3] doubles = log P(correct), log P(error), base.  One wavefront per read; read by hs_lead_kernel and hs_trail_kernel.
@@ -262,75 +87,6 @@ __global__ void __launch_bounds__(64) hs_col_kernel(const hs_dev_t* __restrict__
     const int src = rd.base_off + (c < rd.seed ? c : rd.len - 1 - (c - rd.seed));
     const uint8_t q = (uint8_t)d.quals[src];
     col[3*c] = d.qual_correct[q]; col[3*c+1] = d.qual_error[q]; col[3*c+2] = (double)(uint8_t)d.bases[src];
-  }
-}
-
-// Work item = (locus, side, distinct leading flank, up to 64 reads sorted by side length).  Lane = read: the flank rows — bases and
-// transition logs — are wave-uniform, a lane carries the M/I/D of its own read, and the sweep is the trailing flank's (no shuffles, no
-// pipeline fill: the systolic sweep this replaces spent half its steps filling and draining 64 lanes for a 60-row flank).
-// This is the reference's `reuse_alns` for all alleles at once: the leading flank is computed once per read and distinct flank.
-// Writes the lead record of every read: rowP[n] | last column of the leading-flank rows | side_prob.
-//   item.active = first entry in tpack, item.side = side | slot << 1, item.rowset = rowset id, item.slot = number of reads
-template <int R>
-__global__ void __launch_bounds__(64, HS_FLANK_WAVES) hs_lead_kernel(const hs_dev_t* __restrict__ dp, int item_begin, int item_end, int chunk){
-  const hs_dev_t& d = *dp;
-  const int lane = threadIdx.x;
-  double* const bnd = d.ws_band + (size_t)blockIdx.x * d.band_cols * 64 * 2;
-  // the items differ a lot in length (side lengths are bimodal) and there are only a few per wavefront: they are handed out through a
-  // counter (cleared with the re-do flags before every pass) instead of by stride
-  int32_t* const ctr = d.redo + d.n_active + chunk;
-  for (;;){
-    int item = 0;
-    if (lane == 0) item = atomicAdd(ctr, 1);
-    item = item_begin + uni(item);
-    if (item >= item_end) break;
-    const hs_item_t* it = d.items + item;
-    const int side = uni(it->side) & 1, slot = uni(it->side) >> 1, nreads = uni(it->slot);
-    const bool live = lane < nreads;
-    const int ai = d.tpack[uni(it->active) + min(lane, nreads-1)];
-    const hs_read_t rdv = d.reads[d.active[ai]];
-    const hs_locus_t* loc = d.loci + uni(rdv.locus);
-    const int nL = rdv.seed, n = side ? rdv.len - rdv.seed - 1 : rdv.seed;
-    const int nmax = uni(wave_max_i(n));
-    const hs_ws_t wsr = d.ws[ai];
-    const int lead_flank = uni(loc->lead_flank[side]);
-    double* rec = d.ws_lead + wsr.lead[side] + (int64_t)slot*(n + lead_flank + 1);     // lead_record() of this lane's read
-    double* lastcol = rec + n;
-    double* side_out = rec + n + lead_flank;
-    const double* col = d.ws_col + wsr.col + 3*(int64_t)(side ? nL : 0);
-    const int rowset = uni(it->rowset);
-    const int rs_off = uni(d.rowsets[rowset].off), rs_len = uni(d.rowsets[rowset].len);
-    const hs_row_t* rows = d.rows + rs_off;
-    const int c0 = uni((int)rows[0]) & 0xff;
-    const int nbands = (rs_len - 1 + R - 1) / R;
-    if (nbands == 0){     // a one-base flank: matrix row 0 is all there is
-      double pre = 0.0;
-      for (int j = 0; j < nmax; j++){
-        const int jc = min(j, n - 1);
-        const double blcj = col[3*jc], blwj = col[3*jc+1]; const int rdj = (int)col[3*jc+2];
-        const double m0 = ((rdj == c0) ? blcj : blwj) + pre;
-        pre += blcj;
-        if (j < n && live) rec[j] = m0;
-        if (j == n-1 && live){ lastcol[0] = m0; *side_out = pre; }
-      }
-      continue;
-    }
-    const int nr_base = (rs_len - 1) / nbands, nr_rem = (rs_len - 1) - nr_base*nbands;
-    int row0 = 1;
-    for (int b = 0; b < nbands; b++){
-      const int nr = nr_base + (b < nr_rem ? 1 : 0);
-      const bool first = (b == 0), last = (b + 1 == nbands);
-      if (nr == R) band_dispatch<R, true>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, NULL, bnd, lastcol, rec, side_out);
-      else switch (nr){
-#define HS_BAND_CASE(N_) case N_: if (N_ < R) band_dispatch<(N_ < R ? N_ : 1), true>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, NULL, bnd, lastcol, rec, side_out); break;
-        HS_BAND_CASE(1) HS_BAND_CASE(2) HS_BAND_CASE(3) HS_BAND_CASE(4) HS_BAND_CASE(5) HS_BAND_CASE(6) HS_BAND_CASE(7) HS_BAND_CASE(8)
-        HS_BAND_CASE(9) HS_BAND_CASE(10) HS_BAND_CASE(11) HS_BAND_CASE(12) HS_BAND_CASE(13) HS_BAND_CASE(14) HS_BAND_CASE(15)
-        HS_BAND_CASE(16) HS_BAND_CASE(17) HS_BAND_CASE(18) HS_BAND_CASE(19) HS_BAND_CASE(20) HS_BAND_CASE(21) HS_BAND_CASE(22) HS_BAND_CASE(23)
-#undef HS_BAND_CASE
-        default: break;
-      }
-      row0 += nr;
-    }
   }
 }
 
@@ -3165,11 +2921,7 @@ hs_combine_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
 }
 
 // ------------------------------------------------------------------ host-side launch helpers (called from api.hip)
-#ifndef HS_TRAIL_ROWS
-#define HS_TRAIL_ROWS 20
-#endif
 // leading flanks of the reads [active_begin, active_begin + n_active) of a chunk: column tables first, then the reads-as-lanes sweep
-// HIPSTR_FLANK_COOP=0 selects the serial banded sweep (one wavefront per item, boundary rows through HBM scratch) for comparison
 #ifndef HS_LAT_WAVES
 #define HS_LAT_WAVES 8
 #endif
@@ -3179,9 +2931,7 @@ hs_combine_kernel(const hs_dev_t* __restrict__ dp, int active_begin){
 #ifndef HS_LAT_ITEMS
 #define HS_LAT_ITEMS 128u        // launches with at most this many flank items take the latency shape
 #endif
-static bool lat_shape(){ static const bool v = !(getenv("HIPSTR_FLANK_LATENCY_SHAPE") && atoi(getenv("HIPSTR_FLANK_LATENCY_SHAPE")) == 0); return v; }
-static bool flank_coop(){ static const bool v = !(getenv("HIPSTR_FLANK_COOP") && atoi(getenv("HIPSTR_FLANK_COOP")) == 0); return v; }
-extern "C" int hs_flank_waves_per_group(){ return flank_coop() ? HS_COOP_WAVES : 1; }
+extern "C" int hs_flank_waves_per_group(){ return HS_COOP_WAVES; }
 extern "C" int hs_combine_waves(){ return HS_CMB_WAVES; }
 // HIPSTR_FLANK_SYSTOLIC: 1 (default) = launches of at most HS_LAT_ITEMS flank items whose read sides fit HS_SYS_MAXCOLS columns take the
 // systolic kernels (a wavefront per alignment); 0 = never; 2 = every launch that fits (tests: the whole suite through this form)
@@ -3200,23 +2950,21 @@ extern "C" void hs_launch_lead2(unsigned n_active, unsigned n_wavefronts, hipStr
   }
   // few items (a locus or two per call): the chip is far from full and what counts is the serial length of a sweep, so the bands are
   // half as tall and twice as many (HS_LAT_WAVES x HS_LAT_ROWS: a step is shorter, the pipeline four steps longer): -10 % per sweep
-  if (flank_coop() && lat_shape() && (unsigned)(item_end - item_begin) <= HS_LAT_ITEMS)
+  if ((unsigned)(item_end - item_begin) <= HS_LAT_ITEMS)
     hipLaunchKernelGGL((hs_lead_kernel_coop<HS_LAT_ROWS, HS_LAT_WAVES, 2>), dim3(std::max(1u, std::min(n_wavefronts, 256u))), dim3(64*HS_LAT_WAVES), 0, st, dp, item_begin, item_end, chunk);
   else
-  if (flank_coop()) hipLaunchKernelGGL((hs_lead_kernel_coop<HS_COOP_ROWS, HS_COOP_WAVES, HS_COOP_OCC>), dim3(std::max(1u, std::min(n_wavefronts, 256u*HS_COOP_OCC*4/HS_COOP_WAVES))), dim3(64*HS_COOP_WAVES), 0, st, dp, item_begin, item_end, chunk);
-  else hipLaunchKernelGGL((hs_lead_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end, chunk);
+    hipLaunchKernelGGL((hs_lead_kernel_coop<HS_COOP_ROWS, HS_COOP_WAVES, HS_COOP_OCC>), dim3(std::max(1u, std::min(n_wavefronts, 256u*HS_COOP_OCC*4/HS_COOP_WAVES))), dim3(64*HS_COOP_WAVES), 0, st, dp, item_begin, item_end, chunk);
 }
 extern "C" void hs_launch_trail(unsigned n_wavefronts, hipStream_t st, const hs_dev_t* dp, int item_begin, int item_end, int chunk, int max_cols, int max_rows){
   if (item_end > item_begin && use_systolic(item_begin, item_end, max_cols)){
     hipLaunchKernelGGL((hs_flank_systolic<false>), dim3((unsigned)(item_end - item_begin), 64), dim3(64), 0, st, dp, item_begin);
     return;
   }
-  const bool lat = flank_coop() && lat_shape() && (unsigned)(item_end - item_begin) <= HS_LAT_ITEMS;
+  const bool lat = (unsigned)(item_end - item_begin) <= HS_LAT_ITEMS;
   // short flanks (production panels: <= 35 bp): three bands of up to 12 rows fill their wavefronts better than four of 9 (p30 trailing flank
   // 4.25 -> 4.02 ms, profiles/r05_notes.md; at 60 rows the 4 x 15 shape is the best by 25 %)
-  const bool shrt = flank_coop() && max_rows - 1 <= 36 && !(getenv("HIPSTR_COOP_SHORT") && atoi(getenv("HIPSTR_COOP_SHORT")) == 0);
+  const bool shrt = max_rows - 1 <= 36;
   if (lat)       hipLaunchKernelGGL((hs_trail_kernel_coop<HS_LAT_ROWS, HS_LAT_WAVES, 2>), dim3(std::max(1u, std::min(n_wavefronts, 256u))), dim3(64*HS_LAT_WAVES), 0, st, dp, item_begin, item_end, chunk);
   else if (shrt) hipLaunchKernelGGL((hs_trail_kernel_coop<12, 3, 3>), dim3(std::max(1u, std::min(n_wavefronts, 256u*3*4/3))), dim3(64*3), 0, st, dp, item_begin, item_end, chunk);
-  else if (flank_coop()) hipLaunchKernelGGL((hs_trail_kernel_coop<HS_COOP_ROWS, HS_COOP_WAVES, HS_COOP_OCC>), dim3(std::max(1u, std::min(n_wavefronts, 256u*HS_COOP_OCC*4/HS_COOP_WAVES))), dim3(64*HS_COOP_WAVES), 0, st, dp, item_begin, item_end, chunk);
-  else hipLaunchKernelGGL((hs_trail_kernel<HS_TRAIL_ROWS>), dim3(n_wavefronts), dim3(64), 0, st, dp, item_begin, item_end, chunk);
+  else hipLaunchKernelGGL((hs_trail_kernel_coop<HS_COOP_ROWS, HS_COOP_WAVES, HS_COOP_OCC>), dim3(std::max(1u, std::min(n_wavefronts, 256u*HS_COOP_OCC*4/HS_COOP_WAVES))), dim3(64*HS_COOP_WAVES), 0, st, dp, item_begin, item_end, chunk);
 }

@@ -99,7 +99,7 @@ Pool& pool(){ static Pool p; return p; }
 void parallel_for(int n, int max_threads, const std::function<void(int)>& fn){
   const int nt = std::max(1, std::min(n, max_threads));
   if (nt == 1){ for (int i = 0; i < n; i++) fn(i); return; }
-  static const bool no_pool = getenv("HIPSTR_HOST_POOL") && atoi(getenv("HIPSTR_HOST_POOL")) == 0;      // threads per call, as before (for comparison)
+  constexpr bool no_pool = false;
   if (no_pool){
     std::atomic<int> next(0);
     auto work = [&](){ for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
@@ -617,9 +617,7 @@ void emit_stropt(const char* blk, const int B, int period, const double pmf13[HS
     slot[0] = pack(k, ni_of(E[idx]));
     return true;
   };
-  // (HIPSTR_STR_PWK=0: such lists are replayed as before, for comparison runs; the form needs the grouped replay kernel)
-  static const bool group_replay = !(getenv("HIPSTR_STR_GROUP_REPLAY") && atoi(getenv("HIPSTR_STR_GROUP_REPLAY")) == 0);
-  static const bool pwk_on = group_replay && !(getenv("HIPSTR_STR_PWK") && atoi(getenv("HIPSTR_STR_PWK")) == 0);
+  constexpr bool group_replay = true, pwk_on = true;
   uint64_t pw[HS_MAXREP + 1][HS_PW_SLOTS];
   for (int k = 0; k <= HS_MAXREP; k++){ for (int i = 0; i < HS_PW_SLOTS; i++) pw[k][i] = 0; pw[k][0] = (uint64_t)(uint32_t)-1; }   // "not piecewise"
   uint64_t pwk[HS_MAXREP + 1][HS_PWK_SLOTS];
@@ -678,8 +676,8 @@ void emit_stropt(const char* blk, const int B, int period, const double pmf13[HS
     any_replay |= (tail >= 0 && (so.shape[k] == -1 || so.shape[k] == HS_SHAPE_PWK));
   }
   // (round 4: hs_str_group_kernel_pw also replays the lists that have no closed form — three and more interruptions — so an option with
-  //  such lists stays in the grouped layout (kind 2) as long as its block is made of A/C/G/T; HIPSTR_STR_GROUP_REPLAY=0: they go to
-  //  hs_str_kernel_generic as before, for comparison)
+  //  such lists stays in the grouped layout (kind 2) as long as its block is made of A/C/G/T; before round 4 they went to
+  //  hs_str_kernel_generic)
   if (any_pw || (any_replay && group_replay)){
     const size_t at = out.f64pool.size();
     out.f64pool.resize(at + (HS_MAXREP + 1)*HS_PW_SLOTS);
@@ -694,7 +692,7 @@ void emit_stropt(const char* blk, const int B, int period, const double pmf13[HS
   // tabulated closed form: only when every list the kernel can evaluate is simple and the entries fit the LDS budget
   so.tab_off = out.f64pool.size(); so.tab_len = 0;
   {
-    static const bool no_pw_group = getenv("HIPSTR_STR_GROUP_PW") && atoi(getenv("HIPSTR_STR_GROUP_PW")) == 0;     // comparison runs: piecewise lists stay with hs_str_kernel_generic
+    constexpr bool no_pw_group = false;
     bool ok = true; int total = 0;
     for (int i = 0; i < B; i++){ const char c = blk[i]; ok &= (c == 'A' || c == 'C' || c == 'G' || c == 'T'); }      // hs_str_group_kernel looks emissions up by base code
     ok &= (B >= period);                                                          // ... and lets ins_probs_ cycle through block bases only
@@ -739,8 +737,8 @@ void emit_stropt(const char* blk, const int B, int period, const double pmf13[HS
 struct StroptCached { hs_stropt_t so; std::vector<hs_visit_t> visits; std::vector<double> f64; std::vector<char> chars; };
 void emit_stropt_cached(const char* blk, int B, int period, const double* stutter, const double pmf13[HS_NART], Prepared& out, int pmf_off, int twin){
   // (off by default since round 4: building an option now costs about what a hit did — a hash of ~100 bytes and 2 KB of copies;
-  //  HIPSTR_STROPT_CACHE=1 turns it back on for comparison)
-  static const bool on = getenv("HIPSTR_STROPT_CACHE") && atoi(getenv("HIPSTR_STROPT_CACHE")) != 0;
+  //  the cache stays in the source for a caller that re-sends loci, switched off)
+  constexpr bool on = false;
   if (!on || g_bnd_scale.load() != 1.0){ emit_stropt(blk, B, period, pmf13, out, true, pmf_off, twin); return; }      // (the cache keeps host-written tables only)
   thread_local std::unordered_map<std::string, StroptCached> cache;
   thread_local std::string key;

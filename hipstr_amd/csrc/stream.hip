@@ -237,10 +237,10 @@ struct InFlight {
 struct hipstr_stream {
   hipstr::Ctx* ctx = NULL;
   hipStream_t copy_stream = NULL, d2h_stream = NULL;     // tables to the device / results back: neither waits for the other
-  // HIPSTR_STREAM_COMPUTE_STREAMS=2..4: the kernels of consecutive batches on alternating streams instead of the context's one.  Tried at the
+  // (the kernels of consecutive batches on alternating streams instead of the context's one: tried at the
   // end of round 4 against the 8 % a stream of 2 Mi batches loses to the resident rate (the tails and gaps of 60 kernels per pass instead
   // of 8): no effect, 129.5 ms per pass with 1, 2 and 3 streams — a persistent trailing-flank kernel holds every SIMD's registers until
-  // it ends.  What helped is fewer, larger batches (below).  Default 1; kept switchable for other shapes.
+  // it ends.  What helped is fewer, larger batches (below).  One stream; the arrays below are what is left of the experiment.)
   hipStream_t compute[4] = {NULL, NULL, NULL, NULL};
   int n_compute = 0;
   std::atomic<unsigned> launch_seq{0};
@@ -389,13 +389,11 @@ hipstr_stream_t* hipstr_stream_open(const hipstr_stream_opts_t* opts){
   {
     const int ht = hipstr::host_threads();
     s->big_mult = ht >= 8 ? 4 : (ht >= 4 ? 2 : 1);
-    if (const char* e = getenv("HIPSTR_STREAM_BIG_BATCH")) s->big_mult = std::max(1, atoi(e));
   }
   if (hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s->d2h_stream, hipStreamNonBlocking) != hipSuccess){
     hipstr::api_fail("hipStreamCreate failed"); delete s; return NULL; }
   {
     int nc = 1;
-    if (const char* e = getenv("HIPSTR_STREAM_COMPUTE_STREAMS")) nc = std::max(1, std::min(4, atoi(e)));
     if (nc > 1) for (int i = 0; i < nc; i++){
       if (hipStreamCreateWithFlags(&s->compute[i], hipStreamNonBlocking) != hipSuccess){
         hipstr::api_fail("hipStreamCreate failed");

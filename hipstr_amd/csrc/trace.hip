@@ -946,7 +946,7 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
     const auto c1 = now();
     // the fill kernels of the column classes: one launch per class for calls of many loci, ONE launch for the requests of a locus or two (hs_trace_fill_mixed)
     int n_cls = 0; for (int cl = 1; cl <= 6; cl++) n_cls += (cls_begin[cl] - cls_begin[cl-1]) > 0;
-    static const bool mixed_on = !(getenv("HIPSTR_TRACE_MIXED") && atoi(getenv("HIPSTR_TRACE_MIXED")) == 0);      // 0: one launch per class, as for large calls
+    constexpr bool mixed_on = true;
     const bool mixed = mixed_on && n_cls > 1 && nq <= 4096;        // small call, several classes: one launch (hs_trace_fill_mixed)
     if (mixed){
       hs_tcls_t cls;
