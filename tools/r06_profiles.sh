@@ -29,7 +29,6 @@ python tools/r05_lat.py > $O/r06_latency.txt 2>&1
 HIPSTR_FLANK_SYSTOLIC=0 python tools/r05_lat.py >> $O/r06_latency.txt 2>&1
 # the one-shot call as bench.py times it (prepared arrays, median of 200) with the host-side buckets; the second per-thread stream off for comparison
 LAT_BUCKETS=1 python tools/r05_lat2.py > $O/r06_latency_c.txt 2>&1
-HIPSTR_EXPAND_ASIDE=0 python tools/r05_lat2.py >> $O/r06_latency_c.txt 2>&1
 python tools/r05_lat2.py >> $O/r06_latency_c.txt 2>&1
 bash tools/lat_trace.sh align > $O/r06_lat_trace_align.txt 2>&1
 bash tools/lat_trace.sh trace > $O/r06_lat_trace_trace.txt 2>&1
