@@ -813,7 +813,7 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
       const int oidx = cur + oi[x];
       const std::string sq(b->seq + b->opt_off[oidx], b->opt_off[oidx+1] - b->opt_off[oidx]);
       if (sq.empty()) return api_fail(x == 1 ? "empty STR allele is not supported" : "empty flank sequence");
-      if (x == 1 && sq.size() > 1024) return api_fail("STR allele longer than 1024 bp is not supported");
+      if (x == 1 && sq.size() > HS_MAX_STR_BP) return api_fail("STR allele longer than 2047 bp is not supported");
       ap.seq[0][x] = sq;
       ap.seq[1][2-x] = std::string(sq.rbegin(), sq.rend());
     }
