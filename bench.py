@@ -287,12 +287,21 @@ def thread_cpu_seconds():
     return out
 
 
+def _name_thread(name):
+    """The calling thread's name (comm) — cpu_seconds_by_thread tells the harness' own threads from the HIP runtime's, which inherit "python"."""
+    try:
+        C.CDLL(None).prctl(15, name, 0, 0, 0)
+    except Exception:
+        pass
+
+
 def end_to_end(capi, hmm, sb, loci, steps, device, latency=True):
     """SURVEY §8(d)'s metric taken literally — wall time from host arrays in to aln_probs/seeds out (host flatten, H2D, kernels, D2H,
     the reference's output contract) — through the streaming C-ABI, fed the way the reference's caller produces work: ONE locus per
     submission (bam_processor.cpp:550-617).  `steps` passes over the batch go through one open stream back to back, a feeder
     thread submitting while this thread collects in order; reported beside `value`, never as `value` (inputs are host-resident)."""
     import threading
+    _name_thread(b"bench-collect")
     st = capi.Stream(hmm, device=device, slots=int(os.environ.get("HIPSTR_BENCH_SLOTS", "8")), batch_alignments=int(os.environ.get("HIPSTR_BENCH_BATCH", "0")))        # 0: the library's own batch size (2 Mi pairs, up to 8 Mi for batches of few heavy loci)
     probs = np.zeros(max(sb.n_out, 1)); seeds = np.zeros(max(sb.n_reads, 1), np.int32)
     def one_pass_set(n):
@@ -304,6 +313,7 @@ def end_to_end(capi, hmm, sb, loci, steps, device, latency=True):
         # GIL inside it, the wait sleeps inside the library.)
         submitted = threading.Semaphore(0)
         def feed():
+            _name_thread(b"bench-feeder")
             for _ in range(n):
                 st.submit_each(sb.ptr)
                 submitted.release()

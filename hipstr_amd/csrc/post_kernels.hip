@@ -95,24 +95,62 @@ __device__ __forceinline__ void posterior_body(const hs_post_dev_t& d){
     // a1 == a2 only — so only the pairs a1 <= a2 are computed (A (A + 1) / 2 of A^2) and mirrored through LDS: the same bits.
     bool sym = (d.log_prior == NULL || d.sym_prior != 0) && A >= 4;
     for (int r = 0; r < u.n_reads && sym; r++) sym = (d.log_p1[u.read_begin + r] == d.log_p2[u.read_begin + r]);
-    if (sym){
-      const int npairs = A*(A + 1)/2;
-      for (int q = tid; q < npairs; q += 256){
-        // pair q of the upper triangle, row by row: row i starts at i A - i (i - 1) / 2
-        int i = (int)(((float)(2*A + 1) - sqrtf((float)((2*A + 1)*(2*A + 1) - 8*q))) * 0.5f);
-        i = max(0, min(i, A - 1));
-        while (i > 0 && i*A - i*(i - 1)/2 > q) i--;
-        while ((i + 1)*A - (i + 1)*i/2 <= q) i++;
-        const int j = i + (q - (i*A - i*(i - 1)/2));
-        const int idx = i*A + j;
-        double x = d.log_prior ? d.log_prior[u.prior_off + idx] : ((i == j) ? u.log_hom_prior : u.log_het_prior);
-        for (int r = 0; r < u.n_reads; r++){
-          const int g = u.read_begin + r;
-          const double* LL = LL0 + (int64_t)r*A;
-          x += (double)d.read_weight[g] * fast_lse2((d.log_half + d.log_p1[g]) + LL[i], (d.log_half + d.log_p2[g]) + LL[j], d.log_thresh);
-        }
-        ebuf[idx] = x; ebuf[j*A + i] = x;
+    // Round 6: what a (diplotype, read) step needs — (log 1/2 + log_p1[read]) + LL[read][a1], (log 1/2 + log_p2[read]) + LL[read][a2] and the
+    // read's weight — depends on (read, allele) only, not on the diplotype, and used to be fetched and added per diplotype straight from
+    // memory: a chain of five loads per step, 13 steps per thread in the stutter EM's units — the accumulation was waiting for L2 most of
+    // its time (55 % of a unit's 55 us).  The reads are now taken a tile at a time: all threads form the two addends per (read, allele) once,
+    // side by side in LDS (the chunk buffer of the exponentials, unused until then), then every thread adds the tile's reads to its
+    // diplotypes in read order.  Same additions on the same values in the same order: bit-identical.
+    const int npairs = A*(A + 1)/2;
+    const int n_mine = sym ? npairs : nd;                 // items dealt to the threads: item q = tid + 256 k
+    int ij[HS_POST_REGS];                                 // a1 | a2 << 16 of this thread's items
+#pragma unroll
+    for (int k = 0; k < HS_POST_REGS; k++){
+      const int q = tid + 256*k;
+      int i = 0, j = 0;
+      v[k] = -1.0e300;
+      if (q < n_mine){
+        if (sym){
+          // pair q of the upper triangle, row by row: row i starts at i A - i (i - 1) / 2
+          i = (int)(((float)(2*A + 1) - sqrtf((float)((2*A + 1)*(2*A + 1) - 8*q))) * 0.5f);
+          i = max(0, min(i, A - 1));
+          while (i > 0 && i*A - i*(i - 1)/2 > q) i--;
+          while ((i + 1)*A - (i + 1)*i/2 <= q) i++;
+          j = i + (q - (i*A - i*(i - 1)/2));
+        } else { i = q / A; j = q - i*A; }
+        v[k] = d.log_prior ? d.log_prior[u.prior_off + i*A + j] : ((i == j) ? u.log_hom_prior : u.log_het_prior);
       }
+      ij[k] = i | (j << 16);
+    }
+    {
+      const int RT = max(1, min(u.n_reads, HS_POST_ECHUNK / (2*A + 1)));      // reads per tile: two addends per (read, allele) + a weight per read
+      double* const sA1 = ebuf; double* const sA2 = ebuf + RT*A; double* const sW = ebuf + 2*RT*A;
+      for (int r0 = 0; r0 < u.n_reads; r0 += RT){
+        const int nr = min(RT, u.n_reads - r0);
+        for (int e = tid; e < nr*A; e += 256){
+          const int r = e / A, g = u.read_begin + r0 + r;
+          const double ll = LL0[(int64_t)(r0 + r)*A + (e - r*A)];
+          sA1[e] = (d.log_half + d.log_p1[g]) + ll;
+          sA2[e] = (d.log_half + d.log_p2[g]) + ll;
+        }
+        if (tid < nr) sW[tid] = (double)d.read_weight[u.read_begin + r0 + tid];
+        for (int r = tid + 256; r < nr; r += 256) sW[r] = (double)d.read_weight[u.read_begin + r0 + r];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < HS_POST_REGS; k++){
+          if (tid + 256*k < n_mine){                      // (the same for every thread of a wavefront but the last item's)
+            const int i = ij[k] & 0xffff, j = ij[k] >> 16;
+            double x = v[k];
+            for (int r = 0; r < nr; r++) x += sW[r] * fast_lse2(sA1[r*A + i], sA2[r*A + j], d.log_thresh);
+            v[k] = x;
+          }
+        }
+        __syncthreads();                                  // (the tile buffer is written again: next tile, or the mirror / the exponentials below)
+      }
+    }
+    if (sym){
+#pragma unroll
+      for (int k = 0; k < HS_POST_REGS; k++) if (tid + 256*k < npairs){ const int i = ij[k] & 0xffff, j = ij[k] >> 16; ebuf[i*A + j] = v[k]; ebuf[j*A + i] = v[k]; }
       __syncthreads();
 #pragma unroll
       for (int k = 0; k < HS_POST_REGS; k++){
@@ -121,22 +159,9 @@ __device__ __forceinline__ void posterior_body(const hs_post_dev_t& d){
         if (idx < nd){ v[k] = ebuf[idx]; lmax = fmax(lmax, v[k]); }
       }
       __syncthreads();                                    // (ebuf is written again below)
-    } else
+    } else {
 #pragma unroll
-    for (int k = 0; k < HS_POST_REGS; k++){
-      const int idx = tid + 256*k;
-      v[k] = -1.0e300;
-      if (idx < nd){
-        const int a1 = idx / A, a2 = idx - a1*A;
-        double x = d.log_prior ? d.log_prior[u.prior_off + idx] : ((a1 == a2) ? u.log_hom_prior : u.log_het_prior);
-        for (int r = 0; r < u.n_reads; r++){
-          const int g = u.read_begin + r;
-          const double* LL = LL0 + (int64_t)r*A;
-          x += (double)d.read_weight[g] * fast_lse2((d.log_half + d.log_p1[g]) + LL[a1], (d.log_half + d.log_p2[g]) + LL[a2], d.log_thresh);
-        }
-        v[k] = x;
-        lmax = fmax(lmax, x);
-      }
+      for (int k = 0; k < HS_POST_REGS; k++) if (tid + 256*k < nd) lmax = fmax(lmax, v[k]);
     }
     HS_PT(1);
     const int lane = tid & 63, w = tid >> 6;
