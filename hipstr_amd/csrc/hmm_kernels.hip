@@ -191,7 +191,7 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
                                                 const hs_row_t* __restrict__ rows, int row0, int c0, const double* __restrict__ mr,
                                                 double* __restrict__ bnd, bool topg, bool botg, hs_lds_cd2 lds_top, hs_lds_d2 lds_bot,
                                                 double* __restrict__ lt, double* __restrict__ rowp, double* __restrict__ side_out,
-                                                int w, hs_lds_i prog, int base, int nsteps, hs_lds_d2 ktab, hs_lds_d2 etab, int npad){
+                                                int w, hs_lds_i prog, int base, int nsteps, int wlast, hs_lds_d2 ktab, hs_lds_d2 etab, int npad){
   static_assert(!EL || (HS_COOP_LDS_CONSTS != 0 && !LEAD), "the emission table rides on the constants' request pipeline");
   constexpr bool KL = HS_COOP_LDS_CONSTS != 0;
   int hc[NR]; double m2m[KL ? 1 : NR], m2i[KL ? 1 : NR];
@@ -239,8 +239,13 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
       const double cur_mr = nx_mr;
       double2 cur_b = make_double2(0.0, 0.0);
       if (!FIRST){
-        if (topg) cur_b = *(const double2*)(bnd + ((size_t)j*64 + lane)*2);
-        else {
+        if (topg){
+          // (streamed rounds: the previous round's last band — wavefront wlast — stored this column's boundary in the workgroup's HBM scratch and
+          //  published base - nmax + j + 1 behind it; no barrier between the rounds)
+          if (!BAR && wlast >= 0 && top_seen <= base - nmax + j)
+            while ((top_seen = prog_read((uint32_t)uni((int)(uintptr_t)(prog + wlast)))) <= base - nmax + j) __builtin_amdgcn_s_sleep(1);
+          cur_b = *(const double2*)(bnd + ((size_t)j*64 + lane)*2);
+        } else {
           if (!BAR && top_seen <= base + j){
             const unsigned long long t0_ = HS_FT_NOW(); int spins_ = 0;
             while ((top_seen = prog_read(a_top)) <= base + j){ __builtin_amdgcn_s_sleep(1); spins_++; }
@@ -347,7 +352,11 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
       } else if (LEAD){ if (j < n && live) rowp[j] = upM; }
       // this column is done: its boundary (if a band below reads it from the ring) is stored, and the ring slot the band above filled for it
       // has been read — both in front of the counter's store, and a wavefront's LDS operations execute in order
-      if (!BAR && !(FIRST && LAST)){ asm volatile("" ::: "memory"); prog_write(a_me, base + j + 1); }
+      if (!BAR && !(FIRST && LAST)){
+        if (botg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the boundary stored in HBM has arrived before the next round's first band is told
+        else asm volatile("" ::: "memory");
+        prog_write(a_me, base + j + 1);
+      }
       if (EL) e_write((j + 1) & 1, nx_rd, nx_blc, nx_blw);       // the next column's emissions (its values were requested at the top of this one)
       diagM = topM;                              // top boundary of this column = diagonal of the band's first row next column
       if (j == n-1 && live){
@@ -363,12 +372,12 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
 template <int NR, bool LEAD, bool EL>
 __device__ __forceinline__ void band_dispatch_coop(bool first, bool last, const hs_dev_t& d, int lane, bool live, int n, int nmax, const double* col,
                                                    const hs_row_t* rows, int row0, int c0, const double* mr, double* bnd, bool topg, bool botg,
-                                                   hs_lds_cd2 lds_top, hs_lds_d2 lds_bot, double* lt, double* rowp, double* side_out, int w, hs_lds_i prog, int base, int nsteps, hs_lds_d2 ktab,
+                                                   hs_lds_cd2 lds_top, hs_lds_d2 lds_bot, double* lt, double* rowp, double* side_out, int w, hs_lds_i prog, int base, int nsteps, int wlast, hs_lds_d2 ktab,
                                                    hs_lds_d2 etab, int npad){
-  if (first){ if (last) band_sweep_coop<NR, true, true, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, nsteps, ktab, etab, npad);
-              else      band_sweep_coop<NR, true, false, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, nsteps, ktab, etab, npad); }
-  else      { if (last) band_sweep_coop<NR, false, true, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, nsteps, ktab, etab, npad);
-              else      band_sweep_coop<NR, false, false, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, nsteps, ktab, etab, npad); }
+  if (first){ if (last) band_sweep_coop<NR, true, true, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, nsteps, wlast, ktab, etab, npad);
+              else      band_sweep_coop<NR, true, false, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, nsteps, wlast, ktab, etab, npad); }
+  else      { if (last) band_sweep_coop<NR, false, true, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, nsteps, wlast, ktab, etab, npad);
+              else      band_sweep_coop<NR, false, false, LEAD, EL>(d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, nsteps, wlast, ktab, etab, npad); }
 }
 
 // The rounds of one item: `n_rows` haplotype rows (after the block's first row) cut into bands, W bands per round, one per wavefront.
@@ -377,9 +386,10 @@ __device__ __forceinline__ void band_dispatch_coop(bool first, bool last, const 
 //     item fetch — and are cleared again between the rounds of a flank deeper than one round holds;
 //   * gcol != NULL (trailing flanks): the counters count the columns of every sweep the workgroup has run (*gcol, the same number in every
 //     wavefront); nothing is cleared, a wavefront sets its counter to the new total after every round whether it had a band or not, and
-//     consecutive items need no barrier between them.
-// Between rounds the last band hands its boundary to the next round's first band through the workgroup's HBM scratch, as before: stores
-// drained, then the barrier (every wavefront of the workgroup passes the same number of barriers per item).
+//     neither consecutive items nor the rounds of a deep flank have a barrier between them: the last band of a round stores its boundary in
+//     the workgroup's HBM scratch, drains the store and only then publishes the column; the next round's first band waits for that counter
+//     column by column (band_sweep_coop, topg / wlast).
+// (Leading flanks between rounds: stores drained, then the barrier, as before.)
 template <int R, int W, bool LEAD, bool EL = false>
 __device__ __forceinline__ void coop_rounds(const hs_dev_t& d, int w, int lane, bool live, int n, int nmax, const double* col, const hs_row_t* rows, int n_rows, int c0,
                                             const double* mr, double* bnd, double2 (*ring)[HS_RING*64], int* prog_s, int* gcol, double* lt, double* rowp, double* side_out, double2 (*ktabs)[24], double (*etabs)[128] = NULL, int npad = 64){
@@ -389,11 +399,14 @@ __device__ __forceinline__ void coop_rounds(const hs_dev_t& d, int w, int lane, 
   const int nr_base = n_rows / nbands, nr_rem = n_rows - nr_base*nbands;
   hs_lds_i prog = (hs_lds_i)prog_s;
   for (int g = 0; g < rounds; g++){
-    if (g > 0){
+    if (g > 0 && !gcol){
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the boundary the previous round's last band stored for this round's first
       __syncthreads();
-      if (!gcol){ if (lane == 0) prog_s[w] = 0; __syncthreads(); }
+      if (lane == 0) prog_s[w] = 0;
+      __syncthreads();
     }
+    // (streamed: no barrier between rounds either — the next round's first band waits for the previous round's last band column by column)
+    const int wlast = (gcol && g > 0) ? W - 1 : -1;
     const int base = gcol ? *gcol : 0;
     const int nb_round = min(W, nbands - g*W);
     const int nsteps = nmax + nb_round - 1;              // (LEAD: the round's barrier steps, the same count in every wavefront)
@@ -407,7 +420,7 @@ __device__ __forceinline__ void coop_rounds(const hs_dev_t& d, int w, int lane, 
       hs_lds_d2 ktab = (hs_lds_d2)ktabs[w];
       hs_lds_d2 etab = EL ? (hs_lds_d2)etabs[w] : (hs_lds_d2)ktabs[w];
       switch (nr){
-#define HS_COOP_CASE(N_) case N_: if (N_ <= R) band_dispatch_coop<(N_ <= R ? N_ : 1), LEAD, EL>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, nsteps, ktab, etab, npad); break;
+#define HS_COOP_CASE(N_) case N_: if (N_ <= R) band_dispatch_coop<(N_ <= R ? N_ : 1), LEAD, EL>(first, last, d, lane, live, n, nmax, col, rows, row0, c0, mr, bnd, topg, botg, lds_top, lds_bot, lt, rowp, side_out, w, prog, base, nsteps, wlast, ktab, etab, npad); break;
         HS_COOP_CASE(1) HS_COOP_CASE(2) HS_COOP_CASE(3) HS_COOP_CASE(4) HS_COOP_CASE(5) HS_COOP_CASE(6) HS_COOP_CASE(7) HS_COOP_CASE(8)
         HS_COOP_CASE(9) HS_COOP_CASE(10) HS_COOP_CASE(11) HS_COOP_CASE(12) HS_COOP_CASE(13) HS_COOP_CASE(14) HS_COOP_CASE(15) HS_COOP_CASE(16)
         HS_COOP_CASE(17) HS_COOP_CASE(18) HS_COOP_CASE(19) HS_COOP_CASE(20)
