@@ -174,10 +174,13 @@ def pipeline_stages(capi, hmm, sb, loci, P):
     h2r = capi.hap_aln_info(hmm, "hipstr_", sb.ptr, cap=1 << 26)
     t_info = time.perf_counter() - t0
     capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, rr[:256], aa[:256], h2r, cap=1 << 24, unpack=False)
-    t = {}
-    capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, rr, aa, h2r, cap=1 << 24, timing=t, unpack=False)
-    out["traceback"] = {"tracebacks_per_s": len(rr) / t["call_s"], "requests": len(rr), "loci": nl,
-                        "hap_aln_info_s_all_loci": t_info, "haplotypes": len(h2r)}
+    calls = []
+    for _ in range(3):                                         # (the first full-size call wakes the host pool and sizes the block caches)
+        t = {}
+        capi.run_trace(hmm, "hipstr_hmm_", sb.ptr, rr, aa, h2r, cap=1 << 24, timing=t, unpack=False)
+        calls.append(t["call_s"])
+    out["traceback"] = {"tracebacks_per_s": len(rr) / sorted(calls)[1], "tracebacks_per_s_first_call": len(rr) / calls[0], "calls": 3, "of": "median",
+                        "requests": len(rr), "loci": nl, "hap_aln_info_s_all_loci": t_info, "haplotypes": len(h2r)}
     # the whole per-locus chain of SeqStutterGenotyper::genotype + write_vcf_record on one batch of loci: forward pass -> posteriors
     # -> MAP diplotypes -> best haplotype per read (seq_stutter_genotyper.cpp:823-825) -> tracebacks -> genotype calls (GL/PL/Q)
     nc = max(1, min(loci, 64, 40000 // P))                     # (at most ~40000 tracebacks: the output pools below hold 16 Mi characters)

@@ -143,14 +143,17 @@ __device__ __forceinline__ hs_d2v kload(uint32_t addr, int off){      // off: a 
   return q;
 }
 template <int CNT> __device__ __forceinline__ void kwait(hs_d2v& q){ asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(q) : "n"(CNT)); }
-// Trailing flank, emission of a cell: (read base == haplotype base) ? log P(correct) : log P(error) is one of a handful of numbers per
-// column and read — per read five of them, for A, C, G, T, N.  With EL the lanes of a read write them to a small LDS table once per
-// column (one column ahead, from the prefetched column values) and a cell reads its own with one ds_read_b64 at
-// [the lane's read][the row's base code]: a v_add_u32 for the address instead of v_cmp + 2 v_cndmask (2 instead of 12 VALU cycles).
-// Needs >= 8 lanes per read (allele groups of 8 and more) and rows made of A, C, G, T, N; otherwise the select stays.
-__device__ __forceinline__ double eload(uint32_t addr){
+// Trailing flank, emission of a cell: (read base == haplotype base) ? log P(correct) : log P(error) is the same number in every lane of a
+// read.  With EL the lanes of a read write the band's emissions of a column — lane s of the read that of row s (and of row s + 8 where a read
+// has only 8 lanes) — to a small LDS table once per column (one column ahead, from the prefetched column values), and a cell reads its own
+// with one ds_read_b64 at [column parity][the lane's read][row]: the row is the instruction's immediate offset, so a cell costs no VALU
+// instruction at all (until round 6 the table was indexed by the row's base code: a v_add_u32 per cell and rows of A, C, G, T, N only;
+// before that v_cmp + 2 v_cndmask per cell).  Needs >= 8 lanes per read (allele groups of 8 and more); otherwise the select stays.
+#define HS_ETAB_ROWS 17          // doubles per read in the table: 16 row slots + 1 (the reads' entries of one row fall into different banks)
+#define HS_ETAB_PAR (8*HS_ETAB_ROWS)     // doubles per column parity: up to 8 reads per wavefront
+__device__ __forceinline__ double eload(uint32_t addr, int off){      // off: a constant once the row loop is unrolled
   double e;
-  asm volatile("ds_read_b64 %0, %1" : "=v"(e) : "v"(addr) : "memory");
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(e) : "v"(addr), "i"(off) : "memory");
   return e;
 }
 template <int CNT> __device__ __forceinline__ void ewait(double& e, hs_d2v& q){ asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(e), "+v"(q) : "n"(CNT)); }
@@ -206,18 +209,24 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
 #pragma unroll
   for (int r = 0; r < NR; r++){
     const int meta = uni((int)rows[row0 + r]);
-    hc[r] = EL ? (((meta & 0xff) >> 1) & 7) << 3 : (meta & 0xff);      // EL: byte offset of the base's entry in a read's eight-entry row
+    hc[r] = meta & 0xff;                                               // (EL: not used — the table's writers compare)
     if (!KL){ m2m[KL ? 0 : r] = uni(d.m2m[(meta >> 8) & 15]); m2i[KL ? 0 : r] = uni(d.m2i[(meta >> 8) & 15]); }
   }
   double Mp[NR], Qp[NR], Ip[NR];          // per row: M[r][j], Q[r] = max(I[r][j], D[r-1][j]) and — ahead by a column — I[r][j+1]
   double nx_blc = col[0], nx_blw = col[1], nx_rd = col[2];
   double nx_mr = 0.0;
-  // EL: table of two column parities x (64 / npad reads) x 8 entries; lane `slot` < 8 of a read writes the entry of base code `slot`
+  // EL: table of two column parities x (64 / npad reads) x HS_ETAB_ROWS entries; lane `slot` of a read writes the entry of row `slot`
+  // (npad == 8: and of row slot + 8), comparing the column's read base with that row's base
+  static_assert(!EL || NR <= 16, "rows of a band in the emission table");
   const int e_sub = EL ? lane / npad : 0, e_slot = EL ? lane - e_sub*npad : 0;
-  const int e_char = (e_slot == 0) ? 'A' : (e_slot == 1) ? 'C' : (e_slot == 2) ? 'T' : (e_slot == 3) ? 'G' : (e_slot == 7) ? 'N' : -1;
-  const uint32_t e_rd = EL ? (uint32_t)(uintptr_t)etab + 64u*(uint32_t)e_sub : 0;            // + parity * 512 + row's code offset
+  int e_char = 0;
+  if (EL) e_char = ((int)rows[row0 + min(e_slot, NR - 1)] & 0xff) | (((int)rows[row0 + min(e_slot + 8, NR - 1)] & 0xff) << 8);
+  const int e_wr = e_sub*HS_ETAB_ROWS + e_slot;
+  const uint32_t e_rd = EL ? (uint32_t)(uintptr_t)etab + (uint32_t)(8*HS_ETAB_ROWS)*(uint32_t)e_sub : 0;      // + parity * 8 HS_ETAB_PAR + 8 row
   auto e_write = [&](int par, double rdv, double blc, double blw){
-    if (e_slot < 8) etab[par*64 + e_sub*8 + e_slot] = ((int)rdv == e_char) ? blc : blw;
+    const int rdb = (int)rdv;
+    if (e_slot < NR) etab[par*HS_ETAB_PAR + e_wr] = (rdb == (e_char & 0xff)) ? blc : blw;
+    if (NR > 8 && npad == 8 && e_slot + 8 < NR) etab[par*HS_ETAB_PAR + e_wr + 8] = (rdb == (e_char >> 8)) ? blc : blw;
   };
   if (EL){ e_write(0, nx_rd, nx_blc, nx_blw); wave_lds_sync(); }
   double diagM = 0;
@@ -289,7 +298,7 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
 #pragma unroll
         for (int r = 0; r < NR; r++){           // first read column (HapAligner.cpp:123-126): M = e, I = blc, D from the row above
           double e;
-          if (EL){ e = eload(e_rd + (uint32_t)hc[r]); ewait1<0>(e); }      // column 0: parity 0
+          if (EL){ e = eload(e_rd, 8*r); ewait1<0>(e); }      // column 0: parity 0
           else e = (rdj == hc[r]) ? blcj : blwj;
           Mp[r] = e;
           dstep(r, blcj);
@@ -300,18 +309,18 @@ __device__ __forceinline__ void band_sweep_coop(const hs_dev_t& d, int lane, boo
           // rows NR-1 .. 0; the pair of row r (and, EL, its emission) is requested while row r + KD is computed
           constexpr int KD = HS_COOP_LDS_DEPTH, KM = KD + 1, PER = EL ? 2 : 1;       // PER: requests per row
           hs_d2v kq[KM]; double eq[EL ? KM : 1];
-          const uint32_t e_col = EL ? e_rd + 512u*(uint32_t)(j & 1) : 0;
+          const uint32_t e_col = EL ? e_rd + (uint32_t)(8*HS_ETAB_PAR)*(uint32_t)(j & 1) : 0;
 #pragma unroll
           for (int a = 0; a < KD; a++) if (NR - 1 - a >= 0){
             const int r = NR - 1 - a >= 0 ? NR - 1 - a : 0;
             kq[r % KM] = kload(kaddr, 16*r);
-            if (EL) eq[EL ? r % KM : 0] = eload(e_col + (uint32_t)hc[r]);
+            if (EL) eq[EL ? r % KM : 0] = eload(e_col, 8*r);
           }
 #pragma unroll
           for (int r = NR - 1; r >= 0; r--){
             if (r >= KD){
               kq[(r - KD) % KM] = kload(kaddr, 16*(r - KD));
-              if (EL) eq[EL ? (r - KD) % KM : 0] = eload(e_col + (uint32_t)hc[r - KD]);
+              if (EL) eq[EL ? (r - KD) % KM : 0] = eload(e_col, 8*(r - KD));
             }
             const int young = (r >= KD ? KD : r) * PER;             // requests issued after this row's
             if (EL) switch (young){
@@ -392,7 +401,7 @@ __device__ __forceinline__ void band_dispatch_coop(bool first, bool last, const 
 // (Leading flanks between rounds: stores drained, then the barrier, as before.)
 template <int R, int W, bool LEAD, bool EL = false>
 __device__ __forceinline__ void coop_rounds(const hs_dev_t& d, int w, int lane, bool live, int n, int nmax, const double* col, const hs_row_t* rows, int n_rows, int c0,
-                                            const double* mr, double* bnd, double2 (*ring)[HS_RING*64], int* prog_s, int* gcol, double* lt, double* rowp, double* side_out, double2 (*ktabs)[24], double (*etabs)[128] = NULL, int npad = 64){
+                                            const double* mr, double* bnd, double2 (*ring)[HS_RING*64], int* prog_s, int* gcol, double* lt, double* rowp, double* side_out, double2 (*ktabs)[24], double (*etabs)[2*HS_ETAB_PAR] = NULL, int npad = 64){
   // as many bands as there are wavefronts whenever the rows allow it (all wavefronts busy), more rounds only for blocks deeper than one round holds
   const int rounds = (n_rows + R*W - 1) / (R*W);
   const int nbands = min(n_rows, rounds*W);
@@ -463,7 +472,7 @@ __global__ void __launch_bounds__(64*W, OCC) hs_trail_kernel_coop(const hs_dev_t
   __shared__ int s_prog[W + 1];             // columns finished per band wavefront (band_sweep_coop); [W]: never written, the last band's lower neighbour
   __shared__ int s_q[2 + W];                // [0] records published; [2 + w] items whose record wavefront w has read
   __shared__ double2 ktabs[W][24];          // per wavefront: (m2m, m2i) of its band's rows (HS_COOP_LDS_CONSTS)
-  __shared__ double etabs[W][128];          // per wavefront: emissions of the current and the next column per (read, base code)
+  __shared__ double etabs[W][2*HS_ETAB_PAR];  // per wavefront: emissions of the current and the next column per (read, row of the band)
   __shared__ TrailRec s_rec[2];
   double* const bnd = d.ws_band + (size_t)blockIdx.x * d.band_cols * 64 * 2;
   int32_t* const ctr = d.redo + d.n_active + chunk;
@@ -498,13 +507,8 @@ __global__ void __launch_bounds__(64*W, OCC) hs_trail_kernel_coop(const hs_dev_t
       const int rowset = uni(g->rowset);
       const int rs_off = uni(d.rowsets[rowset].off), rs_len = uni(d.rowsets[rowset].len);
       const hs_row_t* rows = d.rows + rs_off;
-      // emissions through the LDS table: 8 lanes per read to write a column's entries, and rows of A, C, G, T, N only
-      bool el_ok = (HS_COOP_LDS_EMIT != 0) && (npad >= 8);
-      if (el_ok){
-        bool bad = false;
-        for (int q = lane; q < rs_len; q += 64){ const int ch = (int)rows[q] & 0xff; bad |= !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == 'N'); }
-        el_ok = !__any(bad);
-      }
+      // emissions through the LDS table: 8 lanes per read to write a column's entries (two rows each, then)
+      const bool el_ok = (HS_COOP_LDS_EMIT != 0) && (npad >= 8);
       const int nmax = uni(wave_max_i(n));         // (a cross-lane maximum: every lane takes part)
       const int c0 = uni((int)rows[0]) & 0xff;
       rc.n[lane] = n;
