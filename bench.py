@@ -754,6 +754,11 @@ def main():
                                "pass_frac": valu["pass_fp64_frac_of_peak"],
                                "phase_frac": {ph: v["fp64_frac_of_peak"] for ph, v in valu["phases"].items()},
                                "phase_valu_pipe_est": {ph: v["pipe_occupancy_est"] for ph, v in valu["phases"].items()},
+                               # what a stream of INDEPENDENT FP64 instructions reaches on this device (profiles/r02_valu_microbench.json: cycles of one
+                               # SIMD per wave64 v_add_f64 / v_max_f64, 8 register chains): 6.06 at one wavefront per SIMD, 4.94 at two, 4.47 at four —
+                               # the nominal 4 is not reached by any occupancy; the trailing-flank kernel runs three per SIMD (168 registers)
+                               "measured_issue_ceiling": {"cycles_per_fp64_inst": {"1_wave_per_simd": 6.06, "2_waves_per_simd": 4.94, "4_waves_per_simd": 4.47},
+                                                          "frac_of_nominal_at_2_to_4_waves": [4 / 4.94, 4 / 4.47], "source": "profiles/r02_valu_microbench.json"},
                                "counters": valu["source"], "profile_matches_build": valu["profile_matches_build"]} if valu else None),
             "valu": valu,
             "host": {"synth_s": t_gen, "prepare_upload_s": t_upload, "prepare_upload_first_call_s": t_upload_cold, "fetch_s": t_fetch,
