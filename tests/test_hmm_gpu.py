@@ -315,6 +315,34 @@ def test_flank_heights_around_the_band_size(hmm, oracle, lf_len, rf_len):
     assert np.array_equal(gs, ws) and np.array_equal(got, want), np.max(np.abs(got - want))
 
 
+@pytest.mark.parametrize("n_alleles", [3, 9, 20, 40])
+def test_flank_rows_of_any_character(hmm, oracle, n_alleles):
+    """A flank row is compared with a read base as a character (HapAligner.cpp:144-153): N and lower case in the flanks and N in the reads
+    take the same path as A, C, G, T (the compiled reference agrees with the oracle on these inputs).  The trailing-flank kernel writes a column's emissions to an LDS table by band row (groups of
+    8 and more alleles; the lanes of a read compare the read base with their row's base) or selects per cell (smaller groups): both here."""
+    import random
+    rnd = random.Random(77 + n_alleles)
+    def flank(n):
+        return "".join(rnd.choice("ACGT" if rnd.random() < 0.8 else "Nacgtn") for _ in range(n))
+    lf, rf = flank(37), flank(44)
+    strs = ["ACAG" * k for k in range(5, 5 + n_alleles)]
+    hap = lf + strs[0] + rf
+    reads = []
+    for s in range(0, len(hap) - 30, 2):
+        for ln in (30, 45, min(70, len(hap) - s)):
+            if s + ln <= len(hap):
+                seq = list(hap[s:s + ln].upper())
+                for k in range(len(seq)):
+                    if rnd.random() < 0.04: seq[k] = rnd.choice("ACGTN")
+                reads.append(("".join(seq), "".join(chr(33 + rnd.randint(2, 40)) for _ in seq), s, True))
+    b, A = simple_locus(lf, strs, rf, 4, reads)
+    b.finalize()
+    want, ws = capi.run_align(oracle, "oracle_", b.ptr, fill=-2.5)
+    got, gs = capi.run_align(hmm, "hipstr_hmm_", b.ptr, fill=-2.5)
+    assert (ws >= 0).sum() > 20, "too few reads of this shape have a seed: the case tests nothing"
+    assert np.array_equal(gs, ws) and np.array_equal(got, want), np.max(np.abs(got - want))
+
+
 @pytest.mark.parametrize("mask", [[0, 0, 0], [1, 0, 0], [0, 0, 1], [0, 1, 1]])
 def test_allele_masks_down_to_none(hmm, oracle, mask):
     """realign_to_haplotype masks (HapAligner.cpp:615-619) including the empty one: the kernels of every phase must cope with a locus that

@@ -133,6 +133,12 @@ def test_trace_requests_of_many_loci_in_one_call(hmm, oracle):
     order = rng.permutation(len(rr))                 # requests need not be grouped by locus
     got = capi.run_trace(hmm, "hipstr_hmm_", whole.ptr, [rr[i] for i in order], [aa[i] for i in order], h2r_all, cap=1 << 21)
     util.assert_traces_equal(got, [want[i] for i in order])
+    # a few requests of a large batch: only the requested reads' bases travel (less than half of the batch's) — the last locus' reads, one
+    # of them against two alleles
+    few = [i for i in range(len(rr)) if rr[i] >= int(a["read_off"][4])][:7]
+    few = few + few[:1]
+    got = capi.run_trace(hmm, "hipstr_hmm_", whole.ptr, [rr[i] for i in few], [aa[i] for i in few], h2r_all, cap=1 << 21)
+    util.assert_traces_equal(got, [want[i] for i in few])
 
 
 def test_trace_errors(hmm, oracle):
