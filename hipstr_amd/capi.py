@@ -268,7 +268,11 @@ def hap_aln_info(lib, prefix, bptr, cap=1 << 22):
     buf = C.create_string_buffer(cap); offs = np.zeros(n + 1, np.int64)
     rc = fn(bptr, buf, cap, offs.ctypes.data_as(C.POINTER(C.c_int64)))
     if rc != 0:
-        raise RuntimeError("%shap_aln_info failed rc=%d" % (prefix, rc))
+        why = ""
+        if prefix == "hipstr_":
+            lib.hipstr_last_error.restype = C.c_char_p
+            why = ": " + lib.hipstr_last_error().decode()
+        raise RuntimeError("%shap_aln_info failed rc=%d%s" % (prefix, rc, why))
     raw = buf.raw[:int(offs[n])]          # .raw copies the whole buffer: take it once
     return [raw[offs[k]:offs[k + 1] - 1] for k in range(n)]
 
@@ -564,6 +568,14 @@ def load_hmm():
     return lib
 
 
+def _why(lib, prefix):
+    """': <hipstr_last_error()>' for the MI355X library's entry points."""
+    if not prefix.startswith("hipstr_"):
+        return ""
+    lib.hipstr_last_error.restype = C.c_char_p
+    return ": " + lib.hipstr_last_error().decode()
+
+
 def run_align(lib, prefix, bptr, fill=np.nan, seed_in=None):
     """Call <prefix>process_reads on a batch; returns (aln_probs, seeds) numpy arrays.
     Entries the callee leaves untouched keep `fill`.  seed_in: per-read seed bases chosen by the caller
@@ -577,11 +589,11 @@ def run_align(lib, prefix, bptr, fill=np.nan, seed_in=None):
         fn.restype = C.c_int; fn.argtypes = [_BP, _i32p, _f64p, _i32p]
         rc = fn(bptr, si.ctypes.data_as(_i32p), probs.ctypes.data_as(_f64p), seeds.ctypes.data_as(_i32p))
         if rc != 0:
-            raise RuntimeError("%sprocess_reads_seeded failed rc=%d" % (prefix, rc))
+            raise RuntimeError("%sprocess_reads_seeded failed rc=%d%s" % (prefix, rc, _why(lib, prefix)))
         return probs[:n_out], seeds[:n_reads]
     rc = getattr(lib, prefix + "process_reads")(bptr, probs.ctypes.data_as(_f64p), seeds.ctypes.data_as(_i32p))
     if rc != 0:
-        raise RuntimeError("%sprocess_reads failed rc=%d" % (prefix, rc))
+        raise RuntimeError("%sprocess_reads failed rc=%d%s" % (prefix, rc, _why(lib, prefix)))
     return probs[:n_out], seeds[:n_reads]
 
 

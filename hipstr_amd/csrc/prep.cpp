@@ -1188,7 +1188,11 @@ static int prepare_locus(const hipstr_batch_t* b, int l, int opt_cursor, const P
         return e.id;
       };
       const int side_changed = cb < 0 ? -1 : (side ? 2-cb : cb);
-      if (!reuse || side_changed <= 0) lead_id[side] = cached(S.lead_tab[side], RowsKey{o_lead, es.c_first, es.run_first, 0, 0}, 0, 0);
+      // (one case looks further: a neighbour that is ONE run whose table entry equals its length lets the extension go on into the block
+      //  behind it (Haplotype.cpp:262-270: `if (rl != n) break`) — with HapBlock's carried counter that is a two-base block, 2 (n - 1) == n:
+      //  a homopolymer locus' two-copy allele.  Its leading-flank rows also depend on the far flank: part of the key.)
+      const int lead_aux = (es.run_first == S.sblk[side][o3[1]].n) ? 1 + o_trail : 0;
+      if (!reuse || side_changed <= 0) lead_id[side] = cached(S.lead_tab[side], RowsKey{o_lead, es.c_first, es.run_first, lead_aux, 0}, 0, 0);
       al.lead_rows[side]  = lead_id[side];
       {
         std::vector<int32_t>& ls = S.lead_sets[side];

@@ -417,7 +417,8 @@ int hipstr_nw_align(const hipstr_nw_batch_t* nb, hipstr_nw_out_t* out);
  * of the haplotype against the reference haplotype (all-first-options) with the end penalty, indels in the leading flank pushed
  * into the repeat (adjust_indels, Haplotype.cpp:8-56), then one of 'M','I','D' per alignment column.  The NUL-terminated string
  * of haplotype k of locus l starts at out + offs[hap_off[l] + k]; offs has hap_off[n_loci] + 1 entries.  This is the hap_to_ref
- * input of hipstr_hmm_trace. */
+ * input of hipstr_hmm_trace.  Limits: hipstr_nw_align's — a haplotype of at most 1536 bases, a reference haplotype of at most 4095 (a locus beyond
+ * them makes the call fail with that message: 1 + hipstr_last_error()). */
 int hipstr_hap_aln_info(const hipstr_batch_t* batch, char* out, int64_t out_cap, int64_t* offs);
 
 /*

@@ -81,6 +81,24 @@ def boundary_homopolymers():
     return b.finalize()
 
 
+def homopolymer_two_copy():
+    """A homopolymer locus (period 1) whose candidates include the TWO-copy allele next to flanks that continue its run: the one case in
+    which Haplotype::homopolymer_length's cross-block extension goes past its first neighbour (Haplotype.cpp:262-270 with HapBlock's carried
+    counter, HapBlock.cpp:7-30: the table entry of a one-run block is 2 (n - 1), equal to n for n = 2), so the leading-flank rows next to
+    'GG' depend on the far flank too — and alleles that start with a run of three share first base and run with it.  Interrupted and pure
+    alleles, three right and two left flank options (round 6: found by the fuzzers, tools/repro_r06_period1.py)."""
+    pre, suf = "TCAGGATCCATGCATTACGATCAG", "CTGATCGTAATGCATGGATCCTGA"
+    lfs = [pre + "ACGTTGCAGG", pre + "ACGTTGCATG"]; rfs = ["GGTACCATGC" + suf, "TGTACCATGC" + suf, "GTTACCATGC" + suf]
+    strs = ["GGGGGG", "GG", "GGGAGGGG", "GGG", "GGGGCGGGG", "GGTGG", "G" * 9]
+    hap = lfs[0] + strs[0] + rfs[0]
+    reads = [(hap[s:s + ln], None, s, True) for s in (0, 2, 5, 9, 14) for ln in (40, 55, len(hap) - s) if s + ln <= len(hap)]
+    alt = lfs[1] + strs[2] + rfs[1]
+    reads += [(alt[3:60], "".join("F:,5"[i % 4] for i in range(57)), 3, True), (alt[8:], None, 8, True)]
+    b, A = simple_locus(lfs[0], strs, rfs[0], 1, reads, lf_opts=lfs[1:], rf_opts=rfs[1:])
+    assert A == 42
+    return b.finalize()
+
+
 def masks():
     """realign_to_haplotype / realign_read masks partially false on a multi-flank locus (2 x 4 x 2 = 16 alleles)."""
     strs = ["GT" * 12, "GT" * 11, "GT" * 13, "GT" * 6 + "GA" + "GT" * 5]
@@ -114,6 +132,7 @@ CASES = {
     "edge_reads": edge_reads,
     "tiny_alleles": tiny_alleles,
     "boundary_homopolymers": boundary_homopolymers,
+    "homopolymer_two_copy": homopolymer_two_copy,
     "masks": masks,
     "empty_and_ragged": empty_and_ragged,
     # BASELINE.json configs[0]: 1 locus, 50 x 150 bp reads, 4 alleles

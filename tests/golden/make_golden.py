@@ -168,8 +168,11 @@ def main():
         for name in sys.argv[2:]:
             SECTIONS[name](ref)
         return
+    only = set(sys.argv[2:]) if len(sys.argv) > 2 and sys.argv[1] == "--cases" else None     # python make_golden.py --cases name [...]: the align_ / trace_ fixtures of these cases only
     for name, make in CASES.items():
         if name == "many_haplotypes":         # its own section ("sizes": other trace requests)
+            continue
+        if only is not None and name not in only:
             continue
         b = make()
         probs, seeds = capi.run_align(ref, "ref_", b.ptr, fill=SENTINEL)
@@ -184,6 +187,8 @@ def main():
     rng_t = np.random.default_rng(20260929)
     for name, make in CASES.items():
         if name == "many_haplotypes":
+            continue
+        if only is not None and name not in only:
             continue
         b = make()
         _, seeds = capi.run_align(ref, "ref_", b.ptr, fill=SENTINEL)
@@ -213,6 +218,8 @@ def main():
             np.savez_compressed(os.path.join(HERE, "trace_%s.npz" % name), **out)
         print("trace", name, "loci", traced, "requests", n_req)
 
+    if only is not None:
+        return
     # posteriors: SURVEY §8(c) second KAT + seeded random cases
     rng = np.random.default_rng(20260928)
     posts = {}

@@ -82,13 +82,35 @@ def _one_read_locus(d, l):
     return b, blocks, A
 
 
-@pytest.mark.parametrize("name", ["boundary_homopolymers", "synth_multiflank", "tiny_alleles", "masks"])
+@pytest.mark.parametrize("name", ["boundary_homopolymers", "homopolymer_two_copy", "synth_multiflank", "tiny_alleles", "masks"])
 def test_haplotype_rows_match_oracle(hmm_host, oracle, name):
     """Homopolymer index and base of every flank row, per allele and side — including rows inherited from an
     earlier allele by the reference's alignment reuse and its run-length-table quirk — equal what the oracle's
     literal simulation of the allele loop uses."""
     d = np.load(os.path.join(GOLD, "align_%s.npz" % name))
     b, blocks, A = _one_read_locus(d, 0)
+    _check_rows(hmm_host, oracle, b, blocks, A)
+
+
+def test_rows_next_to_a_two_copy_homopolymer_allele(hmm_host, oracle):
+    """Haplotype::homopolymer_length stops its cross-block extension after one neighbour — unless that neighbour is one run whose table entry
+    equals its length (Haplotype.cpp:262-270), which with HapBlock's carried counter (2 (n - 1) for a one-run block) is a TWO-base block: the
+    two-copy allele of a homopolymer locus.  The leading-flank rows next to it then depend on the flank behind it as well, and they must not
+    be shared with an allele that merely starts with a run of three (found by tools/r06_fuzz_fresh.sh, round 6: the rows were cached by
+    (flank option, first base, run) alone)."""
+    from util import simple_locus
+    pre, suf = "TCAGGATCCATGCATTACGATCAG", "CTGATCGTAATGCATGGATCCTGA"
+    lfs = [pre + "ACGTTGCAGG", pre + "ACGTTGCATG"]; rfs = ["GGTACCATGC" + suf, "TGTACCATGC" + suf, "GTTACCATGC" + suf]
+    strs = ["GGGGGG", "GG", "GGGAGGGG", "GGG", "GGGGCGGGG", "GGTGG", "G" * 9]
+    hap = lfs[0] + strs[0] + rfs[0]
+    b, A = simple_locus(lfs[0], strs, rfs[0], 1, [(hap[2:-2], None, 2, True)], lf_opts=lfs[1:], rf_opts=rfs[1:])
+    b.finalize()
+    blocks = [(0, 0, lfs), (0, 0, strs), (0, 0, rfs)]
+    assert A == len(lfs) * len(strs) * len(rfs)
+    _check_rows(hmm_host, oracle, b, blocks, A)
+
+
+def _check_rows(hmm_host, oracle, b, blocks, A):
     nopts = np.array([len(blk[2]) for blk in blocks], np.int32)
     for k in range(A):
         hf = np.zeros(2048, np.int32); hr = np.zeros(2048, np.int32)
