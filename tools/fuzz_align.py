@@ -1,7 +1,7 @@
 """Randomised parity sweep of the forward path (GPU vs oracle) over generator shapes: read length, flank length, STR size, allele
 count, flank options, masks, share of interrupted repeats.  usage: python tools/fuzz_align.py [n_configs] [seed] [edges]
 "edges": reads per locus and alleles per locus around the kernels' packing sizes (64 lanes, 256-lane workgroups and their multiples), very
-short reads and flanks.  "big" (round 6): 160 ... 1000 candidate haplotypes per locus, 600 ... 5000 reads per locus.  Every mode: a third of
+short reads and flanks.  "tiny" (round 6): two to a dozen copies of a period-1..3 motif.  "big" (round 6): 160 ... 1000 candidate haplotypes per locus, 600 ... 5000 reads per locus.  Every mode: a third of
 the configurations with the STR periods the generator's weights never draw (1, 7, 8, 9)."""
 import os, sys
 import numpy as np
@@ -33,6 +33,12 @@ for c in range(n_cfg):
         kw.update(n_loci=int(rng.integers(1, 3)), n_flank_opts=nf, n_str_alleles=max(2, ns), reads_per_locus=int(rng.choice([3, 8, 20, 40])))
         if rng.random() < 0.35:
             kw.update(n_flank_opts=1, n_str_alleles=int(rng.choice([8, 16, 32])), reads_per_locus=int(rng.choice([601, 1000, 1023, 1025, 2500, 5000])), n_loci=1)
+    if len(sys.argv) > 3 and sys.argv[3] == "tiny":
+        # round 6 (after the two-copy homopolymer bug): the smallest alleles the generator makes — two to a dozen copies of a period-1..3 motif,
+        # every flank option count, short and long flanks, many alleles so that the shortest ones are all there
+        os.environ["HIPSTR_SYNTH_PERIOD"] = str(int(rng.choice([1, 1, 1, 2, 2, 3])))
+        kw.update(str_bp=int(rng.integers(2, 14)), n_str_alleles=int(rng.integers(4, 30)), n_flank_opts=int(rng.choice([1, 2, 3])),
+                  flank_len=int(rng.choice([3, 8, 20, 46, 65, 120])), read_len=int(rng.integers(20, 160)), reads_per_locus=int(rng.integers(4, 70)))
     try:
         sb = capi.SynthBatch(**kw)
         want, ws = capi.run_align(ora, "oracle_", sb.ptr, fill=-3.25)

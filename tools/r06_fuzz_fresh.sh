@@ -13,6 +13,7 @@ wave(){   # label, count, command prefix (seed appended), suffix
 wave forward 12 "python tools/fuzz_align.py 60" "" 1
 wave forward_edges 8 "python tools/fuzz_align.py 25" "edges" 2
 wave forward_big 4 "python tools/fuzz_align.py 30" "big" 3
+wave forward_tiny 8 "python tools/fuzz_align.py 80" "tiny" 10
 wave trace 6 "python tools/fuzz_trace.py 30" "" 4
 wave trace_edges 4 "python tools/fuzz_trace.py 10" "edges" 5
 wave post 3 "python tools/fuzz_post.py 120" "" 6
