@@ -27,6 +27,12 @@ for c in range(n_cfg):
         if kw["n_str_alleles"] * kw["n_flank_opts"] ** 2 > 300: kw["n_flank_opts"] = 1
         if kw["read_len"] > 250: kw["reads_per_locus"] = min(kw["reads_per_locus"], 8)
         if rng.random() < 0.3: kw.update(read_len=int(rng.integers(8, 40)), flank_len=int(rng.integers(2, 20)), str_bp=int(rng.integers(4, 30)))
+    if len(sys.argv) > 3 and sys.argv[3] == "tiny":      # round 6: two to a dozen copies of a period-1..3 motif (tools/fuzz_align.py "tiny")
+        os.environ["HIPSTR_SYNTH_PERIOD"] = str(int(rng.choice([1, 1, 1, 2, 2, 3])))
+        kw.update(str_bp=int(rng.integers(2, 14)), n_str_alleles=int(rng.integers(4, 30)), n_flank_opts=int(rng.choice([1, 2, 3])),
+                  flank_len=int(rng.choice([3, 8, 20, 46, 65, 120])), read_len=int(rng.integers(20, 160)), reads_per_locus=int(rng.integers(4, 40)))
+    else:
+        os.environ["HIPSTR_SYNTH_PERIOD"] = "0"
     sb = capi.SynthBatch(**kw)
     _, seeds = capi.run_align(ora, "oracle_", sb.ptr)
     b = sb.ptr.contents
