@@ -484,7 +484,8 @@ def main():
         torch.cuda.synchronize()
         resident = 3.0 * n_aln.value / (time.perf_counter() - t_r)
         hmm.hipstr_hmm_free(dev)
-        e = end_to_end(capi, hmm, sb, loci, max(2, min(args.steps, 5), min(48, int(4e7 // max(1.0, float(n_aln.value))))), local, latency=False)
+        e2e_passes = int(os.environ.get("HIPSTR_BENCH_E2E_PASSES", "0")) or max(2, min(args.steps, 5), min(128, int(1.2e8 // max(1.0, float(n_aln.value)))))      # (the override: experiments on run length)
+        e = end_to_end(capi, hmm, sb, loci, e2e_passes, local, latency=False)
         e["alignments_per_s"] = n_aln.value * e["passes"] / e["seconds"]
         e["host_threads"] = args.host_threads or int(os.environ.get("HIPSTR_HOST_THREADS", "0")) or None
         e["cpus_allowed"] = len(os.sched_getaffinity(0))
@@ -765,9 +766,9 @@ def main():
                      "value_incl_prepare_pcie": total_aln / world / (t_upload + elapsed / args.steps + t_fetch) * world},
         }
         if args.gpus == 1 and not args.no_pipeline:
-            # passes: as many as the resident measurement, but at least ~40 M alignments' worth — a stream that sees two or three small batches
-            # measures its own fill and drain, not its rate
-            e2e = end_to_end(capi, hmm, sb, loci, max(2, min(args.steps, 5), min(48, int(4e7 // max(1.0, float(n_aln.value))))), local)
+            # passes: as many as the resident measurement, but at least ~120 M alignments' worth (about a second) — a stream that sees a few batches
+            # measures its own fill and drain, not its rate (round 6: p30 under the 2-CPU pin 0.78-0.83 of resident over 31 passes, 0.87-0.94 over 150)
+            e2e = end_to_end(capi, hmm, sb, loci, max(2, min(args.steps, 5), min(128, int(1.2e8 // max(1.0, float(n_aln.value))))), local)
             e2e["alignments_per_s"] = n_aln.value * e2e["passes"] / e2e["seconds"]
             e2e["fraction_of_resident_rate"] = e2e["alignments_per_s"] / value
             out["end_to_end"] = e2e

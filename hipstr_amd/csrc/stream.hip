@@ -338,7 +338,11 @@ void worker_loop(hipstr_stream* s, int n_workers){
         int64_t w = s->in_worker_work;
         for (const InFlight* f : s->flying) w += f->ob->work;
         const int64_t next = !s->ready.empty() ? s->ready.front()->work : (s->pending ? s->pending->work : 0);
-        return w + next <= (int64_t)s->slots * s->batch_work;
+        // (a caller's own batch size does not multiply the memory in flight: slots x 2 Mi pairs as with the default — ~40 GB of workspaces at the
+        //  north-star shape, twice that for loci of few alleles —, two batches at least.  Round 6: 8 slots x 8 Mi pairs of 8-allele loci ran the
+        //  device out of memory, tools/r06_rt_long.sh)
+        const int64_t cap = std::max((int64_t)s->slots * std::min(s->batch_work, (int64_t)2 << 20), 2 * s->batch_work);
+        return w + next <= cap;
       };
       s->cv_work.wait(g, [&]{ return s->closing || (have_work() && (room() || may_overshoot())); });
       if (s->closing) return;
