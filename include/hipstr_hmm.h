@@ -199,6 +199,8 @@ typedef struct hipstr_stream_opts {
   int32_t device;             /* ordinal; hipstr_stream_open initialises it like hipstr_hmm_init                              */
   int32_t slots;              /* batches in flight (prepared / running / waiting to be collected); 0 = 6                      */
   int64_t batch_alignments;   /* a pending batch is sent once it holds this many (read x haplotype) pairs; 0 = 2 Mi           */
+                              /* (the pairs in flight stay within slots x min(batch_alignments, 2 Mi), two batches at least:  */
+                              /*  a larger batch size does not multiply the device memory the stream holds)                   */
 } hipstr_stream_opts_t;
 typedef struct hipstr_stream_stats {
   int64_t batches, tickets, alignment_slots;  /* batches launched, tickets delivered, (read x haplotype) pairs submitted       */
