@@ -293,9 +293,17 @@ hipError_t hipstr::wait_stream(hipStream_t st){
   if (mode == 0) return hipStreamSynchronize(st);
   const auto t0 = std::chrono::steady_clock::now();
   bool slow = (mode == 2);
+  // (round 6: an event recorded behind the stream's work and hipEventQuery — a hipStreamQuery that finds the stream busy leaves work for the
+  //  HSA runtime's event thread: 0.45 s of its CPU per 3 s of polling against 0.03 with an event, tools/r06_rt_probe.py; sixteen host threads
+  //  of one-shot calls share that one thread)
+  // (the event comes from this thread's context: only when that is the device the entry point bound — the stream's)
+  Ctx* c = t_ctx;
+  { int cur = -1; if (!c || hipGetDevice(&cur) != hipSuccess || cur != c->device) c = NULL; }
+  hipEvent_t ev = c ? c->get_event(false) : NULL;
+  if (ev && hipEventRecord(ev, st) != hipSuccess){ c->put_event(ev, false); ev = NULL; }
   for (unsigned n = 0;; n++){
-    const hipError_t e = hipStreamQuery(st);
-    if (e != hipErrorNotReady) return e;
+    const hipError_t e = ev ? hipEventQuery(ev) : hipStreamQuery(st);
+    if (e != hipErrorNotReady){ if (ev) c->put_event(ev, false); return e; }
     if (slow) usleep(50);
     else {
       sched_yield();
@@ -389,6 +397,8 @@ struct hipstr_dev_batch {
   hipStream_t h2d_stream = NULL, d2h_stream = NULL;
   double* host_out = NULL;                  // pinned copy of aln_probs (fetch_begin)
   bool profiling = false, foreign_stream = false, sleepy_wait = false;
+  bool d2h_pending = false;            // fetch_begin: the copy back is queued once ev_done has fired (fetch_poll / results_wait), not behind a cross-stream wait
+  std::mutex d2h_m;
   std::vector<hipEvent_t> prof_pool;        // reusable events; every pass records 5 per chunk (phase boundaries)
   size_t prof_used = 0;
   int64_t algo_bytes = 0, dp_cells = 0;
@@ -721,13 +731,47 @@ int hipstr::fetch_begin(hipstr_dev_batch_t* dev, hipStream_t compute_stream, hip
     dev->pin_blocks.push_back(dev->host_out);
   }
   dev->d2h_stream = copy_stream;
-  HS_HIP(hipStreamWaitEvent(copy_stream, dev->ev_done, 0));
-  if (P.n_out) HS_HIP(hipMemcpyAsync(dev->host_out, dev->h.aln_probs, (size_t)P.n_out*sizeof(double), hipMemcpyDeviceToHost, copy_stream));
-  HS_HIP(hipEventRecord(dev->ev_d2h, copy_stream));
+  // Round 6: the copy back is NOT queued behind a hipStreamWaitEvent(copy_stream, ev_done).  A cross-stream wait for an event that tens of
+  // milliseconds of kernels stand in front of is resolved by the HSA runtime's event thread ON THE CPU: it spins in the KFD's wait call until
+  // the event fires (tools/r06_rt_probe.py: 2.65 s of CPU per 3 s of such waits, nothing for the same kernels without the wait) — with a
+  // stream running that was a core in use for as long as the device was busy, a third of a rank's two-CPU allowance.  The copy is queued by
+  // whoever finds ev_done fired first: a worker passing by (fetch_poll) or the collector that waits for the results (results_wait).
+  std::lock_guard<std::mutex> lg(dev->d2h_m);
+  dev->d2h_pending = true;
   return 0;
+}
+// ev_done has fired (the caller saw it): the copy back and its event, on the copy stream, with nothing to wait for
+static int fetch_issue_locked(hipstr_dev_batch_t* dev){
+  const hipstr::Prepared& P = dev->prep;
+  if (P.n_out) HS_HIP(hipMemcpyAsync(dev->host_out, dev->h.aln_probs, (size_t)P.n_out*sizeof(double), hipMemcpyDeviceToHost, dev->d2h_stream));
+  HS_HIP(hipEventRecord(dev->ev_d2h, dev->d2h_stream));
+  dev->d2h_pending = false;
+  return 0;
+}
+// a look without waiting: queues the copy back if the batch's kernels are done.  0 = nothing pending any more, 1 = still running, -1 = error
+int hipstr::fetch_poll(hipstr_dev_batch_t* dev){
+  std::unique_lock<std::mutex> lg(dev->d2h_m, std::try_to_lock);
+  if (!lg.owns_lock()) return 1;
+  if (!dev->d2h_pending) return 0;
+  if (bind(dev->ctx)) return -1;
+  const hipError_t e = hipEventQuery(dev->ev_done);
+  if (e == hipErrorNotReady) return 1;
+  if (e != hipSuccess){ g_err = std::string("hipEventQuery: ") + hipGetErrorString(e); return -1; }
+  return fetch_issue_locked(dev) == 0 ? 0 : -1;
 }
 int hipstr::results_wait(hipstr_dev_batch_t* dev){
   if (bind(dev->ctx)) return 1;
+  {
+    std::lock_guard<std::mutex> lg(dev->d2h_m);
+    if (dev->d2h_pending){
+      if (dev->sleepy_wait){
+        hipError_t e;
+        while ((e = hipEventQuery(dev->ev_done)) == hipErrorNotReady) usleep(100);
+        if (e != hipSuccess){ g_err = std::string("hipEventQuery: ") + hipGetErrorString(e); return 1; }
+      } else HS_HIP(hipEventSynchronize(dev->ev_done));
+      if (fetch_issue_locked(dev)) return 1;
+    }
+  }
   if (dev->sleepy_wait){
     hipError_t e;
     while ((e = hipEventQuery(dev->ev_d2h)) == hipErrorNotReady) usleep(100);

@@ -86,6 +86,7 @@ namespace hipstr {
 // reads_pinned: batch->bases / quals lie in pinned host memory that outlives the copy: they are sent from there, not through the staging block
 hipstr_dev_batch* upload_on(Ctx* ctx, const hipstr_batch* batch, const int32_t* seed_base, hipStream_t copy_stream, hipStream_t compute_stream, bool reads_pinned = false);
 int  fetch_begin(hipstr_dev_batch* dev, hipStream_t compute_stream, hipStream_t copy_stream);
+int  fetch_poll(hipstr_dev_batch* dev);         // queues the copy back of a batch whose kernels are done (0 queued or nothing pending, 1 still running, -1 error)
 int  results_wait(hipstr_dev_batch* dev);
 double batch_prepare_seconds(const hipstr_dev_batch* dev);      // wall time of the batch's prepare_batch
 void scatter_loci(const hipstr_dev_batch* dev, int l0, int l1, double* aln_probs, int32_t* seeds);   // outputs based at locus l0

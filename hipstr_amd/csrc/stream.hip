@@ -364,6 +364,11 @@ void worker_loop(hipstr_stream* s, int n_workers){
       fprintf(stderr, "stream: batch of %zu tickets (%lld pairs) prepared + launched %.3f .. %.3f ms after open\n", ob->tickets.size(), (long long)ob->work,
               1e3*std::chrono::duration<double>(t0 - s->t_open).count(), 1e3*std::chrono::duration<double>(std::chrono::steady_clock::now() - s->t_open).count());
     {
+      // (passing by: the copy back of earlier batches whose kernels have finished meanwhile — api.hip fetch_begin)
+      std::lock_guard<std::mutex> g(s->m);
+      for (InFlight* e : s->flying) if (e->dev && !e->failed && !e->landed) hipstr::fetch_poll(e->dev);
+    }
+    {
       std::lock_guard<std::mutex> g(s->m);
       s->flying.push_back(f); s->in_worker--; s->in_worker_work -= ob->work;
       s->stats.batches++; s->stats.host_seconds += host_s; s->stats.alignment_slots += ob->work;
