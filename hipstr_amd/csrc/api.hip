@@ -833,7 +833,21 @@ int hipstr_hmm_align(hipstr_dev_batch_t* dev, void* hip_stream){
   if (hip_stream && (hipStream_t)hip_stream != dev->stream) dev->foreign_stream = true;
   // the tables were sent on another stream.  Also with nothing to align: what follows on `st` (the copy back, the events that release the
   // batch's blocks to the cache) must come after the upload that is still writing into those blocks
-  if (dev->h2d_stream != st) HS_HIP(hipStreamWaitEvent(st, dev->ev_h2d, 0));
+  // (round 6, the stream's batches — the caller is a worker thread with a batch's time to spare: the two events a batch's kernels depend on, the
+  //  upload and the table expansion, are waited for HERE, asleep, instead of by hipStreamWaitEvent on a stream that is busy with the previous
+  //  batch: a cross-stream wait keeps the HSA runtime's event thread spinning on a CPU while it is pending, fetch_begin.  One-shot calls keep the
+  //  device-side waits: theirs are microseconds long and a host round trip would be their latency.
+  //  Measured with the two side by side, profiles/r06_host_side_dependencies.txt: the event thread's 0.65-1.04 s per second of streaming gone,
+  //  p30 under a rank's two CPUs 8.0-8.5 -> 5.5-6.3 us of CPU per locus, NS 185 -> 80.)
+  const bool host_deps = dev->sleepy_wait && !hip_stream;
+  auto host_wait = [&](hipEvent_t ev) -> int {
+    hipError_t e;
+    while ((e = hipEventQuery(ev)) == hipErrorNotReady) usleep(100);
+    if (e != hipSuccess) return fail(std::string("hipEventQuery: ") + hipGetErrorString(e));
+    return 0;
+  };
+  if (dev->h2d_stream != st){ if (host_deps){ if (host_wait(dev->ev_h2d)) return 1; } else HS_HIP(hipStreamWaitEvent(st, dev->ev_h2d, 0)); }
+  if (host_deps && dev->ev_expand && !dev->expand_joined){ if (host_wait(dev->ev_expand)) return 1; dev->expand_joined = true; dev->expand_joined_on = st; }
   if (dev->h.n_active == 0) return 0;
   const hs_dev_t* dp = dev->d_args;
   auto mark = [&]() -> int {
