@@ -42,7 +42,7 @@ for w, label in (("p30", "production-like shape (`--workload p30`: 4000 loci × 
     b = J("r06_bench_%s.json" % w); a = J("r06_e2e_%s_all.json" % w); p = J("r06_e2e_%s_pin2.json" % w)
     ea = a.get("end_to_end", a); ep = p.get("end_to_end", p)
     rows.append((label, "resident %s M/s (`r06_bench_%s.json`); end to end %s M/s = %.2f (`r06_e2e_%s_all.json`), pinned to 2 CPUs %s M/s = %.2f, %.1f µs of host CPU per locus (`r06_e2e_%s_pin2.json`)" % (
-        M(b["value"]), w, M(ea["alignments_per_s"]), ea["alignments_per_s"] / b["value"], w, M(ep["alignments_per_s"]), ep["alignments_per_s"] / b["value"], ep["process_cpu_us_per_locus"], w)))
+        M(b["value"]), w, M(ea["alignments_per_s"]), ea.get("fraction_of_resident_rate_same_process", ea["alignments_per_s"] / b["value"]), w, M(ep["alignments_per_s"]), ep.get("fraction_of_resident_rate_same_process", ep["alignments_per_s"] / b["value"]), ep["process_cpu_us_per_locus"], w)))      # (the fraction: of the same process' resident rate where the file has it)
 lat = e["one_locus_process_reads_latency"]
 rows.append(("one locus per call (`hipstr_hmm_process_reads` on prepared arrays, median of 200; `one_locus_process_reads_latency` of the NS line)",
              "50 reads × 4 alleles (configs[0]) **%.3f ms**, 40 × 32 **%.3f ms**, 500 × 32 %.3f ms (round 5: 0.142 / 0.184 / 0.406); through the python wrapper incl. the oracle-sized copies 0.20 / 0.26 / 0.52 (`r06_latency.txt`), kernel timeline `r06_lat_trace_align.txt`" % (
